@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports /root/reference/wefax.py (cwd must be the reference root because
+config.py:11 opens ``config/config.json`` relative to cwd), turns the
+reference's ``time.sleep`` calls into no-ops, runs ``Demodulator.process()`` on
+small inputs and stores, per case, the input wav and what the reference
+produced at every stage boundary of SURVEY.md section 8a:
+
+  audio (after merge/resample/notch), demodulated envelope, (low, high),
+  digitalized uint8 stream, sync peaks, phasing_signals, start_frame,
+  the final image, the websocket_stack message sequence, or the exception.
+
+Only data is written (inputs and outputs); no reference source or bytecode.
+Float stages are stored as a strided float64 subsample plus a SHA-256 of the
+full array to keep the fixtures small.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from wefax_amd import synth  # noqa: E402
+
+SUB = 5  # float stages: keep every SUB-th sample
+
+
+def _import_reference():
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    import wefax  # type: ignore
+    wefax.time.sleep = lambda s: None
+    return wefax
+
+
+def _sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+class _PeakTap:
+    """Grabs the local ``peaks`` list of wefax.py:291 when the function returns."""
+
+    def __init__(self):
+        self.peaks = None
+
+    def __call__(self, frame, event, arg):
+        if event == "return" and frame.f_code.co_name == "__find_sync_pulse":
+            pk = frame.f_locals.get("peaks")
+            if pk is not None:
+                self.peaks = list(pk)
+
+
+def run_case(wefax, name: str, wav_path: str, lpm: int) -> dict:
+    out: dict = {"name": name, "lpm": lpm}
+    d = wefax.Demodulator(wav_path, lines_per_minute=lpm, quiet=True, tcp_stream=True)
+    out["file_info"] = {k: (v if isinstance(v, str) else float(v))
+                        for k, v in d.file_info().items()}
+    tap = _PeakTap()
+    sys.setprofile(tap)
+    try:
+        d.process()
+        exc = None
+    except Exception as e:  # the reference raises ValueError when no group closes
+        exc = e
+    finally:
+        sys.setprofile(None)
+        sys.stdout = sys.__stdout__
+    out["exception"] = None if exc is None else [type(exc).__name__, str(exc)]
+    arrays = {}
+
+    def put_float(key, a):
+        a = np.asarray(a, dtype=np.float64)
+        arrays[key + "_sub"] = a[::SUB].copy()
+        out[key + "_sha256"] = _sha(a)
+        out[key + "_len"] = int(a.shape[0])
+
+    if hasattr(d, "audio_data"):
+        put_float("audio", d.audio_data)            # after merge/resample/notch
+        out["sample_rate"] = int(d.sample_rate)
+        out["length"] = float(d.length)
+    if hasattr(d, "demodulated_data"):
+        put_float("demod", d.demodulated_data)
+        lo, hi = np.percentile(d.demodulated_data, (0.5, 99.5))
+        out["low"], out["high"] = float(lo), float(hi)
+    if hasattr(d, "digitalized_data"):
+        arrays["digitalized"] = np.asarray(d.digitalized_data, dtype=np.uint8)
+    if tap.peaks is not None:
+        arrays["peaks"] = np.asarray(tap.peaks, dtype=np.int64)
+    if hasattr(d, "phasing_signals"):
+        arrays["phasing_signals"] = np.asarray(d.phasing_signals, dtype=np.int64)
+        out["start_frame"] = int(d.start_frame)
+    if hasattr(d, "output_image"):
+        img = np.asarray(d.output_image)
+        arrays["image"] = img
+        out["image_size"] = list(d.output_image.size)
+        out["image_mode"] = d.output_image.mode
+    out["websocket_stack"] = [
+        [m.get("data_type"), m.get("progress_title", m.get("message_content")),
+         None if "percentage" not in m else float(m["percentage"])]
+        for m in d.websocket_stack]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    return out
+
+
+def _stage_only(wefax, name: str, wav_path: str, lpm: int = 120) -> dict:
+    """Stage goldens for clips on which process() raises (1-second clips)."""
+    return run_case(wefax, name, wav_path, lpm)
+
+
+def main():
+    wefax = _import_reference()
+    inputs = os.path.join(HERE, "inputs")
+    os.makedirs(inputs, exist_ok=True)
+    manifest = {"reference": "wojlin/WEFAX wefax.py Demodulator.process()",
+                "versions": {}, "cases": []}
+    import scipy, PIL  # noqa: E401
+    manifest["versions"] = {"numpy": np.__version__, "scipy": scipy.__version__,
+                            "Pillow": PIL.__version__,
+                            "python": sys.version.split()[0]}
+
+    short = dict(start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0)
+
+    def emit(name, fs, data, lpm):
+        p = os.path.join(inputs, name + ".wav")
+        synth.write_wav(p, fs, data)
+        print("case", name, data.shape, flush=True)
+        c = run_case(wefax, name, p, lpm)
+        c["input"] = "inputs/" + name + ".wav"
+        manifest["cases"].append(c)
+
+    # 1. clean mono 11 025 Hz, 120 LPM (even N)
+    emit("mono_clean_120", 11025,
+         synth.synth_capture(11025.0, phasing_lines=8, image_lines=24, **short), 120)
+    # 2. noisy mono (non-empty phasing group, odd N)
+    x = synth.synth_capture(11025.0, noise=0.05, seed=1, phasing_lines=20,
+                            image_lines=30, **short)
+    emit("mono_noisy_120", 11025, x[:-1] if x.shape[0] % 2 == 0 else x, 120)
+    # 3. 240 LPM noisy
+    emit("mono_noisy_240", 11025,
+         synth.synth_capture(11025.0, noise=0.05, seed=2, lpm=240, ioc=288,
+                             phasing_lines=40, image_lines=60, **short), 240)
+    # 4. heavy noise + leading silence, prime-ish length
+    x = synth.synth_capture(11025.0, noise=0.2, seed=3, phasing_lines=20,
+                            image_lines=20, lead_silence_s=0.7, **short)
+    emit("mono_noise20_lead", 11025, x[:250007], 120)
+    # 5. 48 kHz mono (resample path)
+    emit("mono48k_noisy_120", 48000,
+         synth.synth_capture(48000.0, noise=0.05, seed=4, phasing_lines=20,
+                             image_lines=16, **short), 120)
+    # 6. 48 kHz stereo (merge + resample); short, the merge loop is slow
+    iq = synth.synth_capture(48000.0, noise=0.02, seed=5, iq=True,
+                             phasing_lines=12, image_lines=8, **short)
+    emit("stereo48k_120", 48000, iq, 120)
+    # 7. 11 025 Hz stereo that overflows int16 in the merge (wefax.py:372)
+    m = synth.synth_capture(11025.0, noise=0.05, seed=6, amplitude=0.9,
+                            phasing_lines=12, image_lines=8, **short)
+    emit("stereo_overflow_120", 11025, np.stack([m, m], axis=1), 120)
+    # 8. upsampling path: 8 kHz mono
+    emit("mono8k_noisy_120", 8000,
+         synth.synth_capture(8000.0, noise=0.05, seed=7, phasing_lines=12,
+                             image_lines=8, **short), 120)
+
+    # 9. the reference's own 1-second clips (MIT licence, LICENSE:1-3)
+    import shutil
+    for clip in ("image", "stop_tone", "start_tone", "start_tone_noisy",
+                 "start_tone_start"):
+        src = os.path.join(REF, "test_files", "parts", clip + ".wav")
+        dst = os.path.join(inputs, "ref_" + clip + ".wav")
+        shutil.copyfile(src, dst)
+        os.chmod(dst, 0o644)
+        print("clip", clip, flush=True)
+        c = _stage_only(wefax, "ref_" + clip, dst)
+        c["input"] = "inputs/ref_" + clip + ".wav"
+        manifest["cases"].append(c)
+
+    with open(os.path.join(HERE, "manifest.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1)
+    print("wrote", len(manifest["cases"]), "cases")
+
+
+if __name__ == "__main__":
+    main()

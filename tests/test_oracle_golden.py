@@ -1,0 +1,120 @@
+"""Pin the oracle (oracle/wefax_oracle.py) against the vectors the reference
+itself produced (tests/golden/make_golden.py ran /root/reference/wefax.py)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_cases
+from oracle import wefax_oracle as wo
+
+CASES = golden_cases()
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_matches_reference_every_stage(case):
+    g = np.load(os.path.join(GOLDEN, case["name"] + ".npz"))
+    r = wo.process(os.path.join(GOLDEN, case["input"]), case["lpm"])
+    assert r["sample_rate"] == case["sample_rate"]
+    assert r["length"] == case["length"]
+    # float stages: a6 notch output, a7 envelope.  Bit-exact here (same pocketfft),
+    # asserted to 1e-9 so a different numpy build does not fail the suite.
+    for key in ("audio", "demod"):
+        assert r[key].shape[0] == case[key + "_len"]
+        ref = g[key + "_sub"]
+        got = r[key][::5]
+        scale = np.max(np.abs(ref)) or 1.0
+        assert np.max(np.abs(got - ref)) <= 1e-9 * scale
+    assert r["low"] == pytest.approx(case["low"], rel=1e-12)
+    assert r["high"] == pytest.approx(case["high"], rel=1e-12)
+    # integer stages: bit-exact
+    assert np.array_equal(r["digitalized"], g["digitalized"])
+    assert np.array_equal(np.asarray(r["peaks"]), g["peaks"])
+    exc = r.get("exception")
+    got_exc = None if exc is None else [type(exc).__name__, str(exc)]
+    assert got_exc == case["exception"]
+    if exc is None:
+        assert np.array_equal(np.asarray(r["phasing_signals"], dtype=np.int64),
+                              g["phasing_signals"])
+        assert r["start_frame"] == case["start_frame"]
+        assert r["image"].shape == (case["image_size"][1], case["image_size"][0])
+        assert np.array_equal(r["image"], g["image"])
+    assert r["messages"] == [list(m) for m in case["websocket_stack"]]
+
+
+def test_oracle_float_stages_are_bit_identical_here(manifest):
+    """Informational strengthening: with the container's numpy the float stages
+    hash identically to the reference's (skipped on a different numpy)."""
+    if np.__version__ != manifest["versions"]["numpy"]:
+        pytest.skip("different numpy build")
+    c = CASES[1]
+    r = wo.process(os.path.join(GOLDEN, c["input"]), c["lpm"])
+    assert _sha(r["audio"]) == c["audio_sha256"]
+    assert _sha(r["demod"]) == c["demod_sha256"]
+
+
+def test_iirnotch_coefficients():
+    # SURVEY.md section 8 a6 [probe]: scipy.signal.iirnotch(2600, 1, 11025)
+    b, a = wo.iirnotch(2600, 1, 11025)
+    assert np.allclose(b, [0.5222765747158418, -0.09289187630508268, 0.5222765747158418],
+                       rtol=0, atol=1e-16)
+    assert np.allclose(a, [1.0, -0.09289187630508268, 0.044553149431683536],
+                       rtol=0, atol=1e-16)
+
+
+def test_restatements_against_scipy_and_pillow():
+    """Each restated third-party routine against the real one, where installed."""
+    scipy_signal = pytest.importorskip("scipy.signal")
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(4097) * 1000
+    b, a = scipy_signal.iirnotch(2600, 1, 11025)
+    assert np.array_equal(wo.filtfilt_biquad(b, a, x), scipy_signal.filtfilt(b, a, x))
+    xi = (x * 20).astype(np.int16)          # int16 odd-extension wraps inside scipy
+    assert np.array_equal(wo.filtfilt_biquad(b, a, xi), scipy_signal.filtfilt(b, a, xi))
+    assert np.array_equal(wo.hilbert_fft(x), scipy_signal.hilbert(x))
+    assert np.array_equal(wo.hilbert_fft(x[:-1]), scipy_signal.hilbert(x[:-1]))
+    assert np.array_equal(wo.medfilt5(np.abs(x)), scipy_signal.medfilt(np.abs(x), 5))
+    for num in (1000, 1001, 6000, 4097 * 2):
+        assert np.allclose(wo.resample_fft(x, num), scipy_signal.resample(x, num),
+                           rtol=0, atol=1e-9)
+    Image = pytest.importorskip("PIL.Image")
+    img = rng.integers(0, 256, size=(37, 129), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(img, "L").resize((129, 4 * 37)))
+    assert np.array_equal(wo.resize_rows_bicubic(img, 4 * 37), ref)
+    for h in (1, 2, 3):
+        img = rng.integers(0, 256, size=(h, 16), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img, "L").resize((16, 4 * h)))
+        assert np.array_equal(wo.resize_rows_bicubic(img, 4 * h), ref)
+
+
+def test_wav_reader_against_scipy(tmp_path):
+    wavfile = pytest.importorskip("scipy.io.wavfile")
+    from wefax_amd import synth
+    rng = np.random.default_rng(1)
+    for dt, ch in ((np.int16, 1), (np.int16, 2), (np.uint8, 1), (np.int32, 2),
+                   (np.float32, 1)):
+        shape = (1000,) if ch == 1 else (1000, ch)
+        if dt == np.float32:
+            d = rng.standard_normal(shape).astype(dt)
+        else:
+            info = np.iinfo(dt)
+            d = rng.integers(info.min, info.max, size=shape, dtype=dt)
+        p = str(tmp_path / f"t_{np.dtype(dt).name}_{ch}.wav")
+        synth.write_wav(p, 11025, d)
+        sr0, d0 = wavfile.read(p)
+        sr1, d1 = wo.read_wav(p)
+        assert sr0 == sr1 and d0.dtype == d1.dtype and np.array_equal(d0, d1)
+
+
+def test_merge_wraps_like_numpy_scalars():
+    d = np.array([[30000, 30000], [-30000, -30000], [1, 2], [-32768, -32768]], dtype=np.int16)
+    # SURVEY.md appendix A.2 [probe]: 30000 + 30000 -> -5536 -> -2768.0
+    assert wo.merge_channels(d).tolist() == [-2768.0, 2768.0, 1.5, 0.0]
+    with np.errstate(over="ignore"):
+        ref = [float(np.divide(np.add(r[0], r[1]), 2)) for r in d]
+    assert wo.merge_channels(d).tolist() == ref

@@ -1,0 +1,151 @@
+"""Synthetic WEFAX (HF radiofax) captures for tests and benchmarks.
+
+The reference ships no generator and its only full-length recording is a
+missing blob (/root/reference/.MISSING_LARGE_BLOBS:1), so every workload in
+BASELINE.json's ``configs`` is built here from the transmission format the
+reference documents in /root/reference/README.md:27-97 (black 1500 Hz, white
+2300 Hz, start tone 300 Hz / 675 Hz toggle, phasing lines 5 % white + 95 %
+black, stop tone 450 Hz toggle, then black).
+
+Everything is plain numpy on the host; nothing here is on the decode path.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+BLACK_HZ = 1500.0
+WHITE_HZ = 2300.0
+
+
+def wefax_frequency_track(fs: float,
+                          lpm: int = 120,
+                          ioc: int = 576,
+                          start_tone_s: float = 5.0,
+                          phasing_lines: int = 60,
+                          image_lines: int = 1200,
+                          stop_tone_s: float = 5.0,
+                          black_tail_s: float = 10.0,
+                          lead_silence_s: float = 0.0) -> np.ndarray:
+    """Instantaneous frequency (Hz) per sample of one WEFAX transmission.
+
+    Line timing sits on the exact time grid (60/lpm seconds per line, i.e.
+    5512.5 samples at 11 025 Hz / 120 LPM), so the image slants exactly the way
+    the reference's truncated ``frame_width`` makes it (wefax.py:298).
+    """
+    t_line = 60.0 / lpm
+    start_hz = 300.0 if ioc == 576 else 675.0
+    dur = (lead_silence_s + start_tone_s + (phasing_lines + image_lines) * t_line
+           + stop_tone_s + black_tail_s)
+    n = int(round(dur * fs))
+    t = np.arange(n, dtype=np.float64) / fs
+    f = np.full(n, BLACK_HZ, dtype=np.float64)
+
+    t0 = lead_silence_s
+    # start tone: square toggle white/black
+    seg = (t >= t0) & (t < t0 + start_tone_s)
+    ph = np.mod((t[seg] - t0) * start_hz, 1.0)
+    f[seg] = np.where(ph < 0.5, WHITE_HZ, BLACK_HZ)
+    t0 += start_tone_s
+
+    # phasing lines: 5 % white then 95 % black
+    t1 = t0 + phasing_lines * t_line
+    seg = (t >= t0) & (t < t1)
+    frac = np.mod((t[seg] - t0) / t_line, 1.0)
+    f[seg] = np.where(frac < 0.05, WHITE_HZ, BLACK_HZ)
+    t0 = t1
+
+    # image lines: 5 % white sync + linear black->white ramp
+    t1 = t0 + image_lines * t_line
+    seg = (t >= t0) & (t < t1)
+    frac = np.mod((t[seg] - t0) / t_line, 1.0)
+    ramp = BLACK_HZ + (WHITE_HZ - BLACK_HZ) * (frac - 0.05) / 0.95
+    f[seg] = np.where(frac < 0.05, WHITE_HZ, ramp)
+    t0 = t1
+
+    # stop tone: 450 Hz toggle
+    seg = (t >= t0) & (t < t0 + stop_tone_s)
+    ph = np.mod((t[seg] - t0) * 450.0, 1.0)
+    f[seg] = np.where(ph < 0.5, WHITE_HZ, BLACK_HZ)
+    # rest: black (already)
+    if lead_silence_s > 0:
+        f[t < lead_silence_s] = 0.0
+    return f
+
+
+def _phase(fs: float, f: np.ndarray) -> np.ndarray:
+    return 2.0 * np.pi * np.cumsum(f) / fs
+
+
+def _to_int16(x: np.ndarray) -> np.ndarray:
+    return np.clip(np.rint(x * 32767.0), -32768, 32767).astype(np.int16)
+
+
+def synth_capture(fs: float = 11025.0, noise: float = 0.0, seed: int = 0,
+                  amplitude: float = 0.5, iq: bool = False, **kw) -> np.ndarray:
+    """int16 capture: mono ``[n]``, or interleaved I/Q ``[n, 2]`` when ``iq``.
+
+    ``noise`` is the standard deviation of additive white Gaussian noise in
+    units of full scale.
+    """
+    f = wefax_frequency_track(fs, **kw)
+    phi = _phase(fs, f)
+    rng = np.random.default_rng(seed)
+    if not iq:
+        x = amplitude * np.sin(phi)
+        if kw.get("lead_silence_s", 0.0) > 0:
+            x[f == 0.0] = 0.0
+        if noise > 0:
+            x = x + noise * rng.standard_normal(x.shape[0])
+        return _to_int16(x)
+    xi = amplitude * np.cos(phi)
+    xq = amplitude * np.sin(phi)
+    if noise > 0:
+        xi = xi + noise * rng.standard_normal(xi.shape[0])
+        xq = xq + noise * rng.standard_normal(xq.shape[0])
+    return np.stack([_to_int16(xi), _to_int16(xq)], axis=1)
+
+
+# The workloads BASELINE.json names.
+def config_c2(noise: float = 0.0, seed: int = 0) -> np.ndarray:
+    """10-minute 11 025 Hz capture, 120 LPM / IOC576: N = 7 166 250 samples."""
+    return synth_capture(11025.0, noise=noise, seed=seed)
+
+
+def config_c3(noise: float = 0.0, seed: int = 0) -> np.ndarray:
+    """60-minute 48 kHz capture: N0 = 172 800 000 samples."""
+    return synth_capture(48000.0, noise=noise, seed=seed, image_lines=7110,
+                         black_tail_s=5.0)
+
+
+def config_c5_member(i: int, noise: float = 0.0) -> tuple[np.ndarray, int]:
+    """Capture ``i`` of the 64-capture batch: (samples, lines_per_minute)."""
+    lpm = 120 if i % 2 == 0 else 240
+    ioc = 576 if (i // 2) % 2 == 0 else 288
+    lines = 1200 if ioc == 576 else 600
+    if lpm == 240:
+        lines *= 2          # same duration as the 120 LPM member
+    x = synth_capture(11025.0, noise=noise, seed=i, lpm=lpm, ioc=ioc,
+                      image_lines=lines,
+                      phasing_lines=60 if lpm == 120 else 120)
+    return x, lpm
+
+
+def write_wav(path: str, fs: int, data: np.ndarray) -> None:
+    """Minimal PCM RIFF writer (int16 mono / multi-channel, uint8, int32, float32)."""
+    data = np.ascontiguousarray(data)
+    ch = 1 if data.ndim == 1 else data.shape[1]
+    if data.dtype == np.float32 or data.dtype == np.float64:
+        fmt_tag = 3
+    else:
+        fmt_tag = 1
+    bits = data.dtype.itemsize * 8
+    raw = data.astype(data.dtype.newbyteorder("<"), copy=False).tobytes()
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(raw), b"WAVE",
+                      b"fmt ", 16, fmt_tag, ch, int(fs),
+                      int(fs) * ch * bits // 8, ch * bits // 8, bits,
+                      b"data", len(raw))
+    with open(path, "wb") as fh:
+        fh.write(hdr)
+        fh.write(raw)
