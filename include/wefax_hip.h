@@ -1,0 +1,179 @@
+/*
+ * wefax_hip.h -- C ABI of libwefax_hip.so, the MI355X (gfx950) implementation of
+ * the WEFAX file-decoding hot path  wojlin/WEFAX wefax.py: Demodulator.process().
+ *
+ * The reference has no FFI (it is pure Python); each entry point below replaces
+ * the body of one reference function and cites it.  Plain C types only: no C++
+ * exceptions, no torch types.  Every function returns 0 on success or a negative
+ * wfx_status; the message is available from wfx_last_error().
+ *
+ * Ownership: the caller owns every host buffer; the library never keeps a host
+ * pointer after a call returns.  Device memory belongs to the context and is
+ * reused across calls.  A context is not thread-safe; use one per Demodulator
+ * (several contexts may run concurrently from different threads).
+ *
+ * Reference binding a maintainer would add: see INTEGRATION.md (ctypes stub).
+ */
+#ifndef WEFAX_HIP_H
+#define WEFAX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wfx_ctx wfx_ctx;
+
+typedef enum {
+    WFX_OK = 0,
+    WFX_ERR_BAD_ARG = -1,
+    WFX_ERR_HIP = -2,
+    WFX_ERR_OOM = -3,
+    WFX_ERR_STATE = -4,
+    WFX_ERR_COMM = -5
+} wfx_status;
+
+/* sample formats accepted at ingest (wefax.py:348-373) */
+typedef enum {
+    WFX_IN_I16_MONO = 0,    /* int16[n]                                         */
+    WFX_IN_I16_STEREO = 1,  /* int16[n][2] -> (int16)(L+R) wrapped, then /2      */
+    WFX_IN_F64_MONO = 2     /* float64[n] (any other wav dtype, converted on host) */
+} wfx_in_kind;
+
+/* how the analytic signal (scipy.signal.hilbert, wefax.py:174) is computed */
+typedef enum {
+    WFX_HILBERT_FFT = 0,    /* exact: N-point DFT (Bluestein over power-of-two FFTs) */
+    WFX_HILBERT_FIR = 1     /* sliding-window circular FIR with `fir_taps` taps       */
+} wfx_hilbert_mode;
+
+#define WFX_MAX_PEAKS 100   /* wefax.py:251 */
+
+/* ---- lifecycle ------------------------------------------------------- */
+int         wfx_device_count(void);
+wfx_ctx    *wfx_create(int device, int flags);          /* NULL on failure      */
+void        wfx_destroy(wfx_ctx *ctx);
+const char *wfx_last_error(wfx_ctx *ctx);               /* ctx may be NULL      */
+int         wfx_sync(wfx_ctx *ctx);                     /* wait for the stream  */
+const char *wfx_version(void);
+
+/* ---- stage entry points (host in, host out), one per reference stage --- */
+
+/* a4  wefax.py:360-373 __merge_channels: out[i] = (double)(int16)(L+R) / 2 */
+int wfx_merge_channels(wfx_ctx *ctx, const int16_t *lr, size_t n, double *out);
+
+/* a5  wefax.py:375-394 __resample -> scipy.signal.resample(x, num) (real input) */
+int wfx_resample(wfx_ctx *ctx, const double *x, size_t n0, size_t num, double *out);
+
+/* a6  wefax.py:68-72 iirnotch + filtfilt.  b/a: biquad (a[0] == 1).  For
+ *     WFX_IN_I16_MONO the 9-sample odd extension wraps in int16 as it does inside
+ *     scipy.signal.filtfilt when handed an int16 array. */
+int wfx_notch_filtfilt(wfx_ctx *ctx, const void *in, int in_kind, size_t n,
+                       const double b[3], const double a[3], double *out);
+
+/* a7  wefax.py:166-183 __demodulate: medfilt(abs(hilbert(x)), 5) */
+int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode,
+                     int fir_taps, double *env_out);
+
+/* a8  wefax.py:196 np.percentile: exact order statistics sorted(env)[rank[i]] */
+int wfx_order_stats(wfx_ctx *ctx, const double *env, size_t n,
+                    const uint64_t *ranks, int nranks, double *out);
+
+/* a8  wefax.py:198-200,216: clamp(rint(255*(env-low)/(high-low)), 0, 255);
+ *     *nan_count receives the number of NaN results (the reference raises) */
+int wfx_quantise(wfx_ctx *ctx, const double *env, size_t n, double low, double high,
+                 uint8_t *out, uint64_t *nan_count);
+
+/* a9  wefax.py:225-236: corr[i] = dot(pattern-128, d[i:i+L]-128), L = 2*n1+n0,
+ *     i in [0, n-L) */
+int wfx_sync_corr(wfx_ctx *ctx, const uint8_t *d, size_t n, int n1, int n0,
+                  int32_t *corr_out);
+
+/* a9  wefax.py:226-261 pattern_search: peak positions, the index at which each
+ *     peak was first appended (progress messages, wefax.py:245), count, and
+ *     whether the 100-peak limit was hit */
+int wfx_sync_peaks(wfx_ctx *ctx, const uint8_t *d, size_t n, int n1, int n0,
+                   int64_t mindistance, int64_t *peak_pos, int64_t *first_pos,
+                   int *npeaks, int *hit_limit);
+
+/* a10 wefax.py:296-327 __convert_to_image: rows of w samples from d[start:],
+ *     255-v, then PIL resize((w, 4h)) (vertical bicubic, 22-bit fixed point).
+ *     img must hold w*4*h bytes, h = (n-start)/w. */
+int wfx_lines_to_image(wfx_ctx *ctx, const uint8_t *d, size_t n, size_t start,
+                       int w, uint8_t *img);
+
+/* ---- fused whole path: input resident in HBM -> image resident in HBM --- */
+
+typedef struct {
+    int      in_kind;          /* wfx_in_kind                                     */
+    uint64_t n0;               /* input frames                                    */
+    uint64_t n;                /* samples at 11 025 Hz: n0, or int(11025*length)  */
+    int      resample;         /* 1 when sample_rate != 11025 (wefax.py:60)       */
+    double   notch_b[3];       /* scipy.signal.iirnotch(2600, 1, 11025)           */
+    double   notch_a[3];
+    int      hilbert_mode;     /* wfx_hilbert_mode                                */
+    int      fir_taps;         /* odd; used when hilbert_mode == WFX_HILBERT_FIR  */
+    /* np.percentile(., (0.5, 99.5)) 'linear': rank pairs and lerp weights        */
+    uint64_t rank_lo[2];
+    uint64_t rank_hi[2];
+    double   gamma_lo;
+    double   gamma_hi;
+    /* sync search constants (wefax.py:223-229,264-267), computed by the host in
+     * the same double arithmetic as the reference */
+    int      n1, n0_gap;
+    int64_t  mindistance;
+    double   frame_samples;    /* frame_len * sample_rate (float, e.g. 5512.5)    */
+    int      width;            /* int(frame_len * sample_rate)                    */
+} wfx_decode_params;
+
+typedef struct {
+    uint64_t n;
+    double   low, high;        /* the two percentiles                             */
+    uint64_t nan_count;        /* > 0: the reference raises ValueError (int(nan)) */
+    int      npeaks;
+    int      hit_limit;
+    int      no_group;         /* 1: wefax.py:294 max() of an empty list          */
+    int      n_phasing;        /* len(phasing_signals)                            */
+    int64_t  start_frame;
+    int      width, height;    /* image is width x 4*height                       */
+    int64_t  peak_pos[WFX_MAX_PEAKS + 1];
+    int64_t  first_pos[WFX_MAX_PEAKS + 1];
+    int64_t  phasing[WFX_MAX_PEAKS + 1];
+} wfx_decode_info;
+
+/* stage buffers that can be copied back after a decode */
+typedef enum {
+    WFX_BUF_AUDIO = 0,         /* double[n]  after merge/resample/notch  (a6)     */
+    WFX_BUF_ENVELOPE = 1,      /* double[n]  after medfilt               (a7)     */
+    WFX_BUF_DIGITAL = 2,       /* uint8[n]                               (a8)     */
+    WFX_BUF_IMAGE = 3          /* uint8[4*height][width]                 (a10)    */
+} wfx_buffer_id;
+
+/* copy the capture into HBM (not part of the timed region) */
+int wfx_decode_upload(wfx_ctx *ctx, const void *host_in, const wfx_decode_params *p);
+/* enqueue every kernel of the path on the context's stream (asynchronous) */
+int wfx_decode_run(wfx_ctx *ctx);
+/* wait and read back the scalars */
+int wfx_decode_result(wfx_ctx *ctx, wfx_decode_info *info);
+/* copy one stage buffer to the host (bytes must match the buffer's size) */
+int wfx_decode_fetch(wfx_ctx *ctx, int buffer_id, void *host_out, size_t bytes);
+/* device address of a stage buffer (for collectives on the final image) */
+int wfx_decode_device_ptr(wfx_ctx *ctx, int buffer_id, void **dev_ptr, size_t *bytes);
+
+/* ---- measurement ------------------------------------------------------ */
+/* HIP-event stopwatch on the context's stream */
+int wfx_timer_start(wfx_ctx *ctx);
+int wfx_timer_stop(wfx_ctx *ctx, float *ms);
+/* per-kernel HIP-event timing: enable, run, then read (count, total ms) by name;
+ * names are listed by wfx_profile_kernel_name(i), i in [0, wfx_profile_kernel_count()) */
+int         wfx_profile_enable(wfx_ctx *ctx, int on);
+int         wfx_profile_reset(wfx_ctx *ctx);
+int         wfx_profile_kernel_count(void);
+const char *wfx_profile_kernel_name(int i);
+int         wfx_profile_get(wfx_ctx *ctx, int i, uint64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEFAX_HIP_H */

@@ -1,0 +1,293 @@
+"""ctypes binding of libwefax_hip.so (include/wefax_hip.h).
+
+There is NO CPU fallback: if the library is missing or no MI355X is visible the
+calls raise.  ctypes releases the GIL for the duration of every call, so a thread
+polling ``Demodulator.websocket_stack`` keeps running (main.py:63-83 does that).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwefax_hip.so")
+
+WFX_IN_I16_MONO, WFX_IN_I16_STEREO, WFX_IN_F64_MONO = 0, 1, 2
+WFX_HILBERT_FFT, WFX_HILBERT_FIR = 0, 1
+WFX_BUF_AUDIO, WFX_BUF_ENVELOPE, WFX_BUF_DIGITAL, WFX_BUF_IMAGE = 0, 1, 2, 3
+WFX_MAX_PEAKS = 100
+
+# every symbol include/wefax_hip.h declares (tests check that all are exported)
+SYMBOLS = [
+    "wfx_device_count", "wfx_create", "wfx_destroy", "wfx_last_error", "wfx_sync",
+    "wfx_version", "wfx_merge_channels", "wfx_resample", "wfx_notch_filtfilt",
+    "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
+    "wfx_sync_peaks", "wfx_lines_to_image", "wfx_decode_upload", "wfx_decode_run",
+    "wfx_decode_result", "wfx_decode_fetch", "wfx_decode_device_ptr",
+    "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
+    "wfx_profile_kernel_count", "wfx_profile_kernel_name", "wfx_profile_get",
+]
+
+
+class DecodeParams(C.Structure):
+    _fields_ = [
+        ("in_kind", C.c_int),
+        ("n0", C.c_uint64),
+        ("n", C.c_uint64),
+        ("resample", C.c_int),
+        ("notch_b", C.c_double * 3),
+        ("notch_a", C.c_double * 3),
+        ("hilbert_mode", C.c_int),
+        ("fir_taps", C.c_int),
+        ("rank_lo", C.c_uint64 * 2),
+        ("rank_hi", C.c_uint64 * 2),
+        ("gamma_lo", C.c_double),
+        ("gamma_hi", C.c_double),
+        ("n1", C.c_int),
+        ("n0_gap", C.c_int),
+        ("mindistance", C.c_int64),
+        ("frame_samples", C.c_double),
+        ("width", C.c_int),
+    ]
+
+
+class DecodeInfo(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64),
+        ("low", C.c_double),
+        ("high", C.c_double),
+        ("nan_count", C.c_uint64),
+        ("npeaks", C.c_int),
+        ("hit_limit", C.c_int),
+        ("no_group", C.c_int),
+        ("n_phasing", C.c_int),
+        ("start_frame", C.c_int64),
+        ("width", C.c_int),
+        ("height", C.c_int),
+        ("peak_pos", C.c_int64 * (WFX_MAX_PEAKS + 1)),
+        ("first_pos", C.c_int64 * (WFX_MAX_PEAKS + 1)),
+        ("phasing", C.c_int64 * (WFX_MAX_PEAKS + 1)),
+    ]
+
+
+class NativeError(RuntimeError):
+    """A libwefax_hip.so call failed (bad argument, HIP error, out of memory)."""
+
+
+_lib = None
+
+
+def load():
+    """Load libwefax_hip.so; raises if it has not been built (python -m wefax_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} is missing: build it with `python -m wefax_amd.build` "
+            "(there is no CPU fallback for the WEFAX hot path)")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, i, dp = C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)
+    lib.wfx_device_count.restype = i
+    lib.wfx_create.argtypes = [i, i]
+    lib.wfx_create.restype = vp
+    lib.wfx_destroy.argtypes = [vp]
+    lib.wfx_destroy.restype = None
+    lib.wfx_last_error.argtypes = [vp]
+    lib.wfx_last_error.restype = C.c_char_p
+    lib.wfx_version.restype = C.c_char_p
+    lib.wfx_sync.argtypes = [vp]
+    lib.wfx_merge_channels.argtypes = [vp, vp, sz, vp]
+    lib.wfx_resample.argtypes = [vp, vp, sz, sz, vp]
+    lib.wfx_notch_filtfilt.argtypes = [vp, vp, i, sz, dp, dp, vp]
+    lib.wfx_analytic_env.argtypes = [vp, vp, sz, i, i, vp]
+    lib.wfx_order_stats.argtypes = [vp, vp, sz, vp, i, vp]
+    lib.wfx_quantise.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, C.POINTER(C.c_uint64)]
+    lib.wfx_sync_corr.argtypes = [vp, vp, sz, i, i, vp]
+    lib.wfx_sync_peaks.argtypes = [vp, vp, sz, i, i, C.c_int64, vp, vp, C.POINTER(i), C.POINTER(i)]
+    lib.wfx_lines_to_image.argtypes = [vp, vp, sz, sz, i, vp]
+    lib.wfx_decode_upload.argtypes = [vp, vp, C.POINTER(DecodeParams)]
+    lib.wfx_decode_run.argtypes = [vp]
+    lib.wfx_decode_result.argtypes = [vp, C.POINTER(DecodeInfo)]
+    lib.wfx_decode_fetch.argtypes = [vp, i, vp, sz]
+    lib.wfx_decode_device_ptr.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz)]
+    lib.wfx_timer_start.argtypes = [vp]
+    lib.wfx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.wfx_profile_enable.argtypes = [vp, i]
+    lib.wfx_profile_reset.argtypes = [vp]
+    lib.wfx_profile_kernel_count.restype = i
+    lib.wfx_profile_kernel_name.argtypes = [i]
+    lib.wfx_profile_kernel_name.restype = C.c_char_p
+    lib.wfx_profile_get.argtypes = [vp, i, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("wfx_device_count", "wfx_profile_kernel_count"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One opaque native context (device buffers + stream) per decoder."""
+
+    def __init__(self, device: int | None = None):
+        self.lib = load()
+        if device is None:
+            device = int(os.environ.get("WEFAX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self.device = device
+        self.h = self.lib.wfx_create(device, 0)
+        if not self.h:
+            msg = self.lib.wfx_last_error(None)
+            raise NativeError("wfx_create failed: " + (msg.decode() if msg else "unknown error"))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wfx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.wfx_last_error(self.h)
+            raise NativeError(f"libwefax_hip error {rc}: {msg.decode() if msg else ''}")
+
+    # ---- stage entry points -------------------------------------------------
+    def merge_channels(self, lr: np.ndarray) -> np.ndarray:
+        lr = np.ascontiguousarray(lr[:, :2], dtype=np.int16)
+        out = np.empty(lr.shape[0], dtype=np.float64)
+        self._check(self.lib.wfx_merge_channels(self.h, _ptr(lr), lr.shape[0], _ptr(out)))
+        return out
+
+    def resample(self, x: np.ndarray, num: int) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty(num, dtype=np.float64)
+        self._check(self.lib.wfx_resample(self.h, _ptr(x), x.shape[0], num, _ptr(out)))
+        return out
+
+    def notch_filtfilt(self, x: np.ndarray, b, a) -> np.ndarray:
+        if x.dtype == np.int16:
+            x = np.ascontiguousarray(x)
+            kind = WFX_IN_I16_MONO
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            kind = WFX_IN_F64_MONO
+        bb = (C.c_double * 3)(*[float(v) for v in b])
+        aa = (C.c_double * 3)(*[float(v) for v in a])
+        out = np.empty(x.shape[0], dtype=np.float64)
+        self._check(self.lib.wfx_notch_filtfilt(self.h, _ptr(x), kind, x.shape[0], bb, aa, _ptr(out)))
+        return out
+
+    def analytic_env(self, x: np.ndarray, mode: int = WFX_HILBERT_FFT, fir_taps: int = 4095) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty(x.shape[0], dtype=np.float64)
+        self._check(self.lib.wfx_analytic_env(self.h, _ptr(x), x.shape[0], mode, fir_taps, _ptr(out)))
+        return out
+
+    def order_stats(self, env: np.ndarray, ranks) -> np.ndarray:
+        env = np.ascontiguousarray(env, dtype=np.float64)
+        r = np.ascontiguousarray(ranks, dtype=np.uint64)
+        out = np.empty(r.shape[0], dtype=np.float64)
+        self._check(self.lib.wfx_order_stats(self.h, _ptr(env), env.shape[0], _ptr(r), r.shape[0], _ptr(out)))
+        return out
+
+    def quantise(self, env: np.ndarray, low: float, high: float):
+        env = np.ascontiguousarray(env, dtype=np.float64)
+        out = np.empty(env.shape[0], dtype=np.uint8)
+        nan = C.c_uint64(0)
+        self._check(self.lib.wfx_quantise(self.h, _ptr(env), env.shape[0], low, high, _ptr(out), C.byref(nan)))
+        return out, int(nan.value)
+
+    def sync_corr(self, d: np.ndarray, n1: int, n0: int) -> np.ndarray:
+        d = np.ascontiguousarray(d, dtype=np.uint8)
+        ncorr = max(0, d.shape[0] - (2 * n1 + n0))
+        out = np.empty(ncorr, dtype=np.int32)
+        self._check(self.lib.wfx_sync_corr(self.h, _ptr(d), d.shape[0], n1, n0, _ptr(out)))
+        return out
+
+    def sync_peaks(self, d: np.ndarray, n1: int, n0: int, mindistance: int):
+        d = np.ascontiguousarray(d, dtype=np.uint8)
+        pos = np.zeros(WFX_MAX_PEAKS + 1, dtype=np.int64)
+        first = np.zeros(WFX_MAX_PEAKS + 1, dtype=np.int64)
+        k, hit = C.c_int(0), C.c_int(0)
+        self._check(self.lib.wfx_sync_peaks(self.h, _ptr(d), d.shape[0], n1, n0, mindistance,
+                                            _ptr(pos), _ptr(first), C.byref(k), C.byref(hit)))
+        return pos[:k.value].tolist(), first[:k.value].tolist(), bool(hit.value)
+
+    def lines_to_image(self, d: np.ndarray, start: int, w: int) -> np.ndarray:
+        d = np.ascontiguousarray(d, dtype=np.uint8)
+        h = (d.shape[0] - start) // w
+        img = np.empty((4 * h, w), dtype=np.uint8)
+        self._check(self.lib.wfx_lines_to_image(self.h, _ptr(d), d.shape[0], start, w, _ptr(img)))
+        return img
+
+    # ---- fused decode ---------------------------------------------------------
+    def decode_upload(self, data: np.ndarray, params: DecodeParams):
+        data = np.ascontiguousarray(data)
+        self._keep = data
+        self._check(self.lib.wfx_decode_upload(self.h, _ptr(data), C.byref(params)))
+
+    def decode_run(self):
+        self._check(self.lib.wfx_decode_run(self.h))
+
+    def decode_result(self) -> DecodeInfo:
+        info = DecodeInfo()
+        self._check(self.lib.wfx_decode_result(self.h, C.byref(info)))
+        return info
+
+    def decode_fetch(self, buffer_id: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self._check(self.lib.wfx_decode_fetch(self.h, buffer_id, _ptr(out), out.nbytes))
+        return out
+
+    def decode_device_ptr(self, buffer_id: int):
+        p, nb = C.c_void_p(0), C.c_size_t(0)
+        self._check(self.lib.wfx_decode_device_ptr(self.h, buffer_id, C.byref(p), C.byref(nb)))
+        return p.value, nb.value
+
+    def sync(self):
+        self._check(self.lib.wfx_sync(self.h))
+
+    # ---- measurement ------------------------------------------------------------
+    def timer_start(self):
+        self._check(self.lib.wfx_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        self._check(self.lib.wfx_timer_stop(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def profile_enable(self, on: bool):
+        self._check(self.lib.wfx_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.wfx_profile_reset(self.h))
+
+    def profile(self) -> dict:
+        out = {}
+        for k in range(self.lib.wfx_profile_kernel_count()):
+            cnt, ms = C.c_uint64(0), C.c_double(0)
+            self._check(self.lib.wfx_profile_get(self.h, k, C.byref(cnt), C.byref(ms)))
+            if cnt.value:
+                out[self.lib.wfx_profile_kernel_name(k).decode()] = (int(cnt.value), float(ms.value))
+        return out
+
+
+def device_count() -> int:
+    return int(load().wfx_device_count())

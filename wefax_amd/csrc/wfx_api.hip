@@ -1,0 +1,360 @@
+// C ABI of libwefax_hip.so: stage entry points (host buffers in/out) and the fused
+// device-resident decode.  See include/wefax_hip.h for the contract and the
+// reference lines each entry point replaces.
+#include <cstring>
+
+#include "wfx_internal.h"
+
+#define CHECK_CTX(ctx)                                                        \
+    do {                                                                      \
+        if (!(ctx)) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null context"); \
+        (void)hipSetDevice((ctx)->device);                                        \
+    } while (0)
+
+static int h2d(wfx_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    WFX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+static int d2h_sync(wfx_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes) WFX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int ensure_scal(wfx_ctx *ctx)
+{
+    WFX_TRY(wfx_reserve(ctx, ctx->b_scal, sizeof(wfx_dev_scalars)));
+    return 0;
+}
+
+extern "C" {
+
+// ---- a4 ---------------------------------------------------------------------
+int wfx_merge_channels(wfx_ctx *ctx, const int16_t *lr, size_t n, double *out)
+{
+    CHECK_CTX(ctx);
+    if (!lr || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    ctx->ran = false;
+    if (n == 0) return 0;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_in, n * 4));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_x, n * 8));
+    WFX_TRY(h2d(ctx, ctx->b_in.p, lr, n * 4));
+    WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)ctx->b_in.p, n, (double *)ctx->b_x.p));
+    return d2h_sync(ctx, out, ctx->b_x.p, n * 8);
+}
+
+// ---- a5 ---------------------------------------------------------------------
+int wfx_resample(wfx_ctx *ctx, const double *x, size_t n0, size_t num, double *out)
+{
+    CHECK_CTX(ctx);
+    if (!x || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (n0 == 0 || num == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "resample: empty input or output");
+    ctx->ran = false;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_x, n0 * 8));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_tmp, num * 8));
+    WFX_TRY(h2d(ctx, ctx->b_x.p, x, n0 * 8));
+    WFX_TRY(wfx_dev_resample_fft(ctx, (const double *)ctx->b_x.p, n0, num, (double *)ctx->b_tmp.p));
+    return d2h_sync(ctx, out, ctx->b_tmp.p, num * 8);
+}
+
+// ---- a6 ---------------------------------------------------------------------
+int wfx_notch_filtfilt(wfx_ctx *ctx, const void *in, int in_kind, size_t n, const double b[3], const double a[3], double *out)
+{
+    CHECK_CTX(ctx);
+    if (!in || !out || !b || !a) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_F64_MONO)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "notch: input must be int16 mono or float64");
+    ctx->ran = false;
+    const size_t esz = in_kind == WFX_IN_I16_MONO ? 2 : 8;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_x, n * esz + 16));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_audio, n * 8 + 16));
+    WFX_TRY(h2d(ctx, ctx->b_x.p, in, n * esz));
+    WFX_TRY(wfx_dev_notch(ctx, ctx->b_x.p, in_kind, n, b, a, (double *)ctx->b_audio.p));
+    return d2h_sync(ctx, out, ctx->b_audio.p, n * 8);
+}
+
+// ---- a7 ---------------------------------------------------------------------
+static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode, int taps, double *env_raw, double *env)
+{
+    if (mode == WFX_HILBERT_FFT)
+        WFX_TRY(wfx_dev_hilbert_env_fft(ctx, x, n, env_raw));
+    else if (mode == WFX_HILBERT_FIR)
+        WFX_TRY(wfx_dev_hilbert_env_fir(ctx, x, n, taps, env_raw));
+    else
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown hilbert mode %d", mode);
+    return wfx_dev_median5(ctx, env_raw, n, env);
+}
+
+int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode, int fir_taps, double *env_out)
+{
+    CHECK_CTX(ctx);
+    if (!x || !env_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (n == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "N must be positive.");
+    ctx->ran = false;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_audio, n * 8));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_envraw, n * 8));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_env, n * 8 + 64));
+    WFX_TRY(h2d(ctx, ctx->b_audio.p, x, n * 8));
+    WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, hilbert_mode, fir_taps, (double *)ctx->b_envraw.p,
+                             (double *)ctx->b_env.p));
+    return d2h_sync(ctx, env_out, ctx->b_env.p, n * 8);
+}
+
+// ---- a8 ---------------------------------------------------------------------
+int wfx_order_stats(wfx_ctx *ctx, const double *env, size_t n, const uint64_t *ranks, int nranks, double *out)
+{
+    CHECK_CTX(ctx);
+    if (!env || !ranks || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (n == 0 || nranks < 1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "order_stats: empty input");
+    ctx->ran = false;
+    WFX_TRY(ensure_scal(ctx));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_env, n * 8 + 64));
+    WFX_TRY(h2d(ctx, ctx->b_env.p, env, n * 8));
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    for (int base = 0; base < nranks; base += 4) {
+        uint64_t r[4];
+        for (int q = 0; q < 4; ++q) r[q] = ranks[base + q < nranks ? base + q : nranks - 1];
+        WFX_TRY(wfx_dev_select(ctx, (const double *)ctx->b_env.p, n, r, ds));
+        WFX_TRY(d2h_sync(ctx, ctx->h_scal, ds, sizeof(wfx_dev_scalars)));
+        for (int q = 0; q < 4 && base + q < nranks; ++q) out[base + q] = ctx->h_scal->sel_value[q];
+    }
+    return 0;
+}
+
+int wfx_quantise(wfx_ctx *ctx, const double *env, size_t n, double low, double high, uint8_t *out, uint64_t *nan_count)
+{
+    CHECK_CTX(ctx);
+    if (!env || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    ctx->ran = false;
+    if (nan_count) *nan_count = 0;
+    if (n == 0) return 0;
+    WFX_TRY(ensure_scal(ctx));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_env, n * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_dig, n + 64));
+    WFX_TRY(h2d(ctx, ctx->b_env.p, env, n * 8));
+    memset(ctx->h_scal, 0, sizeof(wfx_dev_scalars));
+    ctx->h_scal->low = low;
+    ctx->h_scal->high = high;
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    WFX_TRY(h2d(ctx, ds, ctx->h_scal, sizeof(wfx_dev_scalars)));
+    WFX_TRY(wfx_dev_quantise(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, ds));
+    WFX_TRY(d2h_sync(ctx, out, ctx->b_dig.p, n));
+    WFX_TRY(d2h_sync(ctx, ctx->h_scal, ds, sizeof(wfx_dev_scalars)));
+    if (nan_count) *nan_count = ctx->h_scal->nan_count;
+    return 0;
+}
+
+// ---- a9 ---------------------------------------------------------------------
+int wfx_sync_corr(wfx_ctx *ctx, const uint8_t *d, size_t n, int n1, int n0, int32_t *corr_out)
+{
+    CHECK_CTX(ctx);
+    if (!d || !corr_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    ctx->ran = false;
+    const size_t L = (size_t)(2 * n1 + n0);
+    if (n <= L) return 0;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_dig, n + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_corr, (n - L) * 4));
+    WFX_TRY(h2d(ctx, ctx->b_dig.p, d, n));
+    WFX_TRY(wfx_dev_sync_corr(ctx, (const uint8_t *)ctx->b_dig.p, n, n1, n0, (int32_t *)ctx->b_corr.p));
+    return d2h_sync(ctx, corr_out, ctx->b_corr.p, (n - L) * 4);
+}
+
+int wfx_sync_peaks(wfx_ctx *ctx, const uint8_t *d, size_t n, int n1, int n0, int64_t mindistance, int64_t *peak_pos, int64_t *first_pos,
+                   int *npeaks, int *hit_limit)
+{
+    CHECK_CTX(ctx);
+    if (!d || !peak_pos || !first_pos || !npeaks || !hit_limit) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    ctx->ran = false;
+    WFX_TRY(ensure_scal(ctx));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_dig, n + 64));
+    WFX_TRY(h2d(ctx, ctx->b_dig.p, d, n));
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+    WFX_TRY(wfx_dev_sync_pick(ctx, (const uint8_t *)ctx->b_dig.p, n, n1, n0, mindistance, 0.0, 0, ds));
+    WFX_TRY(d2h_sync(ctx, ctx->h_scal, ds, sizeof(wfx_dev_scalars)));
+    *npeaks = ctx->h_scal->npeaks;
+    *hit_limit = ctx->h_scal->hit_limit;
+    for (int i = 0; i < ctx->h_scal->npeaks; ++i) {
+        peak_pos[i] = ctx->h_scal->peak_pos[i];
+        first_pos[i] = ctx->h_scal->first_pos[i];
+    }
+    return 0;
+}
+
+// ---- a10 --------------------------------------------------------------------
+int wfx_lines_to_image(wfx_ctx *ctx, const uint8_t *d, size_t n, size_t start, int w, uint8_t *img)
+{
+    CHECK_CTX(ctx);
+    if (!d || !img) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (w <= 0 || start > n) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "lines_to_image: bad width or start");
+    ctx->ran = false;
+    const int h = (int)((n - start) / (size_t)w);
+    if (h == 0) return 0;
+    WFX_TRY(ensure_scal(ctx));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_dig, n + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_img, (size_t)w * 4 * h));
+    WFX_TRY(h2d(ctx, ctx->b_dig.p, d, n));
+    memset(ctx->h_scal, 0, sizeof(wfx_dev_scalars));
+    ctx->h_scal->start_frame = (long long)start;
+    ctx->h_scal->height = h;
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    WFX_TRY(h2d(ctx, ds, ctx->h_scal, sizeof(wfx_dev_scalars)));
+    WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h, ds, (uint8_t *)ctx->b_img.p));
+    return d2h_sync(ctx, img, ctx->b_img.p, (size_t)w * 4 * h);
+}
+
+// ---- fused decode ---------------------------------------------------------------
+static size_t in_bytes(const wfx_decode_params *p)
+{
+    switch (p->in_kind) {
+    case WFX_IN_I16_MONO: return (size_t)p->n0 * 2;
+    case WFX_IN_I16_STEREO: return (size_t)p->n0 * 4;
+    default: return (size_t)p->n0 * 8;
+    }
+}
+
+static int check_params(wfx_ctx *ctx, const wfx_decode_params *p)
+{
+    if (p->in_kind < WFX_IN_I16_MONO || p->in_kind > WFX_IN_F64_MONO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad in_kind %d", p->in_kind);
+    if (p->n0 == 0 || p->n == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "empty capture");
+    if (!p->resample && p->n != p->n0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "n != n0 without resampling");
+    if (p->n <= 9) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "The length of the input vector x must be greater than padlen, which is 9.");
+    if (p->n > (1ull << 31)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "capture too long");
+    if (p->width <= 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad line width");
+    if (p->rank_lo[0] >= p->n || p->rank_lo[1] >= p->n || p->rank_hi[0] >= p->n || p->rank_hi[1] >= p->n)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "percentile rank out of range");
+    if (p->hilbert_mode == WFX_HILBERT_FIR && (p->fir_taps < 3 || (p->fir_taps & 1) == 0))
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fir_taps must be odd and >= 3");
+    return 0;
+}
+
+int wfx_decode_upload(wfx_ctx *ctx, const void *host_in, const wfx_decode_params *p)
+{
+    CHECK_CTX(ctx);
+    if (!host_in || !p) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    WFX_TRY(check_params(ctx, p));
+    ctx->dp = *p;
+    ctx->have_input = false;
+    ctx->ran = false;
+    const size_t nb = in_bytes(p);
+    WFX_TRY(wfx_reserve(ctx, ctx->b_in, nb + 64));
+    WFX_TRY(h2d(ctx, ctx->b_in.p, host_in, nb));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_input = true;
+    return 0;
+}
+
+int wfx_decode_run(wfx_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_input) return wfx_fail(ctx, WFX_ERR_STATE, "decode_run before decode_upload");
+    const wfx_decode_params &p = ctx->dp;
+    const uint64_t n0 = p.n0, n = p.n;
+    const int w = p.width;
+    const int h_max = (int)(n / (uint64_t)w);
+    WFX_TRY(ensure_scal(ctx));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_audio, n * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_envraw, n * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_env, n * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_dig, n + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_img, (size_t)w * 4 * (size_t)(h_max > 0 ? h_max : 1)));
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+
+    const void *cur = ctx->b_in.p;
+    int cur_kind = p.in_kind;
+    if (p.in_kind == WFX_IN_I16_STEREO) {
+        WFX_TRY(wfx_reserve(ctx, ctx->b_x, n0 * 8));
+        WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)cur, n0, (double *)ctx->b_x.p));
+        cur = ctx->b_x.p;
+        cur_kind = WFX_IN_F64_MONO;
+    }
+    if (p.resample) {
+        if (cur_kind == WFX_IN_I16_MONO) {
+            WFX_TRY(wfx_reserve(ctx, ctx->b_x, n0 * 8));
+            WFX_TRY(wfx_dev_i16_to_f64(ctx, (const int16_t *)cur, n0, (double *)ctx->b_x.p));
+            cur = ctx->b_x.p;
+            cur_kind = WFX_IN_F64_MONO;
+        }
+        WFX_TRY(wfx_reserve(ctx, ctx->b_tmp, n * 8));
+        WFX_TRY(wfx_dev_resample_fft(ctx, (const double *)cur, n0, n, (double *)ctx->b_tmp.p));
+        cur = ctx->b_tmp.p;
+    }
+    WFX_TRY(wfx_dev_notch(ctx, cur, cur_kind, n, p.notch_b, p.notch_a, (double *)ctx->b_audio.p));
+    WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, p.hilbert_mode, p.fir_taps, (double *)ctx->b_envraw.p,
+                             (double *)ctx->b_env.p));
+    const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
+    WFX_TRY(wfx_dev_select(ctx, (const double *)ctx->b_env.p, n, ranks, ds));
+    WFX_TRY(wfx_dev_percentile_lerp(ctx, p.gamma_lo, p.gamma_hi, ds));
+    WFX_TRY(wfx_dev_quantise(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, ds));
+    WFX_TRY(wfx_dev_sync_pick(ctx, (const uint8_t *)ctx->b_dig.p, n, p.n1, p.n0_gap, p.mindistance, p.frame_samples, w, ds));
+    WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h_max, ds, (uint8_t *)ctx->b_img.p));
+    WFX_HIP(ctx, hipMemcpyAsync(ctx->h_scal, ds, sizeof(wfx_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->ran = true;
+    return 0;
+}
+
+int wfx_decode_result(wfx_ctx *ctx, wfx_decode_info *info)
+{
+    CHECK_CTX(ctx);
+    if (!info) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null info");
+    if (!ctx->ran) return wfx_fail(ctx, WFX_ERR_STATE, "decode_result before decode_run");
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const wfx_dev_scalars &s = *ctx->h_scal;
+    memset(info, 0, sizeof *info);
+    info->n = ctx->dp.n;
+    info->low = s.low;
+    info->high = s.high;
+    info->nan_count = s.nan_count;
+    info->npeaks = s.npeaks;
+    info->hit_limit = s.hit_limit;
+    info->no_group = s.no_group;
+    info->n_phasing = s.n_phasing;
+    info->start_frame = s.start_frame;
+    info->width = ctx->dp.width;
+    info->height = s.height;
+    for (int i = 0; i <= WFX_MAX_PEAKS; ++i) {
+        info->peak_pos[i] = s.peak_pos[i];
+        info->first_pos[i] = s.first_pos[i];
+        info->phasing[i] = s.phasing[i];
+    }
+    return 0;
+}
+
+static int buffer_of(wfx_ctx *ctx, int id, void **p, size_t *bytes)
+{
+    if (!ctx->ran) return wfx_fail(ctx, WFX_ERR_STATE, "no decode has run on this context");
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n = ctx->dp.n;
+    switch (id) {
+    case WFX_BUF_AUDIO: *p = ctx->b_audio.p; *bytes = n * 8; return 0;
+    case WFX_BUF_ENVELOPE: *p = ctx->b_env.p; *bytes = n * 8; return 0;
+    case WFX_BUF_DIGITAL: *p = ctx->b_dig.p; *bytes = n; return 0;
+    case WFX_BUF_IMAGE: *p = ctx->b_img.p; *bytes = (size_t)ctx->dp.width * 4 * (size_t)ctx->h_scal->height; return 0;
+    default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown buffer id %d", id);
+    }
+}
+
+int wfx_decode_fetch(wfx_ctx *ctx, int buffer_id, void *host_out, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    void *p = nullptr;
+    size_t nb = 0;
+    WFX_TRY(buffer_of(ctx, buffer_id, &p, &nb));
+    if (bytes != nb) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fetch: expected %zu bytes, got %zu", nb, bytes);
+    if (nb && !host_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return d2h_sync(ctx, host_out, p, nb);
+}
+
+int wfx_decode_device_ptr(wfx_ctx *ctx, int buffer_id, void **dev_ptr, size_t *bytes)
+{
+    CHECK_CTX(ctx);
+    if (!dev_ptr || !bytes) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    return buffer_of(ctx, buffer_id, dev_ptr, bytes);
+}
+
+}  // extern "C"

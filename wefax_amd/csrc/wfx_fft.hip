@@ -1,0 +1,580 @@
+// Exact DFT engine for the two global-FFT operators of the reference:
+//   scipy.signal.hilbert  (wefax.py:174)  -> wfx_dev_hilbert_env_fft
+//   scipy.signal.resample (wefax.py:384)  -> wfx_dev_resample_fft
+//
+// Arbitrary length N is handled with Bluestein's chirp-z identity
+//   DFT_N(a)[k] = conj(w_k) * sum_n (a[n] conj(w_n)) w_{k-n},   w_n = exp(i pi n^2 / N)
+// i.e. one circular convolution of power-of-two length M >= 2N-1, computed with a
+// double-precision radix-2^r pass engine:
+//
+//   forward  = decimation in frequency, natural order in  -> digit-reversed out
+//   inverse  = decimation in time,      digit-reversed in -> natural order out
+//
+// so the convolution needs no reordering pass.  Each pass moves the whole array
+// through HBM exactly once (16 B complex loads/stores, >= 256-byte runs) and does
+// a 2^r-point sub-transform per column in registers + one LDS exchange:
+// a tile is 4096 complex values (64 KiB of LDS), 256 threads x 16 values.
+// The passes are HBM-bound (about 50 flop per 32 bytes moved), so there is no
+// MFMA formulation here -- see DESIGN.md.
+#include "wfx_internal.h"
+
+#define WFX_TILE 4096
+
+// ---------------------------------------------------------------------------
+// complex helpers (explicit FMA: the library is built with -ffp-contract=off so
+// that the parity-critical scalar code rounds like NumPy; butterflies want FMA)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b)
+{
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+// tables hold forward (e^{-i..}) values; the inverse uses the conjugate
+template <int DIR>
+__device__ __forceinline__ cplx dirw(cplx w)
+{
+    return DIR > 0 ? w : cconj(w);
+}
+// multiply by -i (forward) or +i (inverse)
+template <int DIR>
+__device__ __forceinline__ cplx mul_mi(cplx a)
+{
+    return DIR > 0 ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
+}
+
+template <int DIR>
+__device__ __forceinline__ void dft2(cplx &a, cplx &b)
+{
+    cplx t = csub(a, b);
+    a = cadd(a, b);
+    b = t;
+}
+
+template <int DIR>
+__device__ __forceinline__ void dft4(cplx &a0, cplx &a1, cplx &a2, cplx &a3)
+{
+    cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi<DIR>(csub(a1, a3));
+    a0 = cadd(t0, t2);
+    a2 = csub(t0, t2);
+    a1 = cadd(t1, t3);
+    a3 = csub(t1, t3);
+}
+
+#define WFX_C1 0.92387953251128673848   // cos(pi/8)
+#define WFX_S1 0.38268343236508978178   // sin(pi/8)
+#define WFX_C2 0.70710678118654752440   // cos(pi/4)
+
+// In-register DFTs, natural order in and out.
+template <int N, int DIR>
+struct dft_n;
+
+template <int DIR>
+struct dft_n<1, DIR> {
+    static __device__ __forceinline__ void run(cplx *) {}
+};
+template <int DIR>
+struct dft_n<2, DIR> {
+    static __device__ __forceinline__ void run(cplx *v) { dft2<DIR>(v[0], v[1]); }
+};
+template <int DIR>
+struct dft_n<4, DIR> {
+    static __device__ __forceinline__ void run(cplx *v) { dft4<DIR>(v[0], v[1], v[2], v[3]); }
+};
+template <int DIR>
+struct dft_n<8, DIR> {
+    static __device__ __forceinline__ void run(cplx *v)
+    {
+        // n = g + 2 j: DFT4 over j for g = 0, 1; twiddle W8^{q} on g = 1; DFT2 over g
+        dft4<DIR>(v[0], v[2], v[4], v[6]);
+        dft4<DIR>(v[1], v[3], v[5], v[7]);
+        const cplx w1 = dirw<DIR>(make_double2(WFX_C2, -WFX_C2));
+        const cplx w3 = dirw<DIR>(make_double2(-WFX_C2, -WFX_C2));
+        v[3] = cmul(v[3], w1);
+        v[5] = mul_mi<DIR>(v[5]);
+        v[7] = cmul(v[7], w3);
+        cplx o[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[q] = cadd(v[2 * q], v[2 * q + 1]);
+            o[q + 4] = csub(v[2 * q], v[2 * q + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = o[i];
+    }
+};
+template <int DIR>
+struct dft_n<16, DIR> {
+    static __device__ __forceinline__ void run(cplx *v)
+    {
+        // n = g + 4 j, k = q + 4 p
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dft4<DIR>(v[g], v[g + 4], v[g + 8], v[g + 12]);
+        // v[g + 4 q] = Y[g][q]; multiply by W16^{g q}
+        const cplx w1 = dirw<DIR>(make_double2(WFX_C1, -WFX_S1));
+        const cplx w2 = dirw<DIR>(make_double2(WFX_C2, -WFX_C2));
+        const cplx w3 = dirw<DIR>(make_double2(WFX_S1, -WFX_C1));
+        const cplx w6 = dirw<DIR>(make_double2(-WFX_C2, -WFX_C2));
+        const cplx w9 = dirw<DIR>(make_double2(-WFX_C1, WFX_S1));
+        v[1 + 4] = cmul(v[1 + 4], w1);   // g=1 q=1
+        v[1 + 8] = cmul(v[1 + 8], w2);   // g=1 q=2
+        v[1 + 12] = cmul(v[1 + 12], w3); // g=1 q=3
+        v[2 + 4] = cmul(v[2 + 4], w2);   // g=2 q=1
+        v[2 + 8] = mul_mi<DIR>(v[2 + 8]);// g=2 q=2 : W16^4 = -i
+        v[2 + 12] = cmul(v[2 + 12], w6); // g=2 q=3
+        v[3 + 4] = cmul(v[3 + 4], w3);   // g=3 q=1
+        v[3 + 8] = cmul(v[3 + 8], w6);   // g=3 q=2
+        v[3 + 12] = cmul(v[3 + 12], w9); // g=3 q=3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dft4<DIR>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        // v[p + 4 q] = X[q + 4 p] -> natural order
+        cplx o[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) o[q + 4 * p] = v[p + 4 * q];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = o[i];
+    }
+};
+
+// exp(-+ 2 pi i a / 2^log2mb), a already reduced modulo 2^log2mb
+template <int DIR>
+__device__ __forceinline__ cplx unit_root(uint64_t a, int log2mb)
+{
+    double s, c;
+    // 2a / Mb is exact in double (a < 2^53, Mb a power of two)
+    sincospi(ldexp((double)a, 1 - log2mb), &s, &c);
+    return DIR > 0 ? make_double2(c, -s) : make_double2(c, s);
+}
+
+// ---------------------------------------------------------------------------
+// One pass over the whole array.  R = RA * 16 points per column, T = 4096 / R
+// columns per workgroup.
+//   strided pass : column = (block of R*S, offset n2 < S), element n1 at n1*S + n2,
+//                  followed (forward) / preceded (inverse) by the twiddle
+//                  W_{R*S}^{n2 k1}
+//   CONTIG pass  : S = 1, a column is R consecutive values (always R = 256)
+// Forward: n1 = g + 16 j -> DFT_RA over j, * W_R^{g q}, LDS exchange, DFT_16 over g,
+// output k1 = q + RA p.  The inverse runs the same steps backwards, conjugated.
+// ---------------------------------------------------------------------------
+template <int RA_BITS, int DIR, bool CONTIG, bool MULB>
+__global__ void __launch_bounds__(256)
+fft_pass(cplx *__restrict__ A, int log2S, const cplx *__restrict__ w256, const cplx *__restrict__ bhat)
+{
+    constexpr int RA = 1 << RA_BITS;
+    constexpr int RB = 16;
+    constexpr int R = RA * RB;
+    constexpr int T = WFX_TILE / R;
+    constexpr int UA = 16 / RA;
+    constexpr int LDS_N = CONTIG ? T * RA * (RB + 1) : WFX_TILE;
+    __shared__ cplx lds[RA > 1 ? LDS_N : 1];
+    __shared__ cplx wt[RA > 1 ? 256 : 1];
+
+    const int t = threadIdx.x;
+    const uint64_t wg = blockIdx.x;
+    const uint64_t colg = wg * T;
+    const uint64_t n2_0 = CONTIG ? 0 : (colg & ((1ull << log2S) - 1));
+    const uint64_t base = CONTIG ? wg * (uint64_t)WFX_TILE
+                                 : (((colg >> log2S) << (log2S + RA_BITS + 4)) + n2_0);
+    auto addr = [&](int n1, int c) -> uint64_t {
+        return CONTIG ? base + (uint64_t)c * R + n1 : base + ((uint64_t)n1 << log2S) + c;
+    };
+    auto lidx = [&](int q, int g, int c) -> int {
+        return CONTIG ? c * (RA * (RB + 1)) + q * (RB + 1) + g : (q * RB + g) * T + c;
+    };
+
+    if (RA > 1) {
+        wt[t] = w256[t];
+        __syncthreads();
+    }
+
+    // stage-B coordinates of this thread
+    const int bq = CONTIG ? (t % RA) : (t / T);
+    const int bc = CONTIG ? (t / RA) : (t % T);
+    cplx v[16];
+
+    if (DIR > 0) {
+        if (RA > 1) {
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int sa = t + 256 * u;
+                const int g = CONTIG ? (sa % RB) : (sa / T);
+                const int c = CONTIG ? (sa / RB) : (sa % T);
+#pragma unroll
+                for (int j = 0; j < RA; ++j) v[j] = A[addr(g + RB * j, c)];
+                dft_n<RA, DIR>::run(v);
+#pragma unroll
+                for (int q = 1; q < RA; ++q) v[q] = cmul(v[q], wt[((g * q) << (4 - RA_BITS)) & 255]);
+#pragma unroll
+                for (int q = 0; q < RA; ++q) lds[lidx(q, g, c)] = v[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < RB; ++g) v[g] = lds[lidx(bq, g, bc)];
+        } else {
+#pragma unroll
+            for (int g = 0; g < RB; ++g) v[g] = A[addr(g, bc)];
+        }
+        dft_n<16, DIR>::run(v);
+        if (!CONTIG) {
+            const int log2mb = log2S + RA_BITS + 4;
+            const uint64_t mask = (1ull << log2mb) - 1;
+            const uint64_t n2 = n2_0 + bc;
+            cplx cur = unit_root<DIR>((n2 * (uint64_t)bq) & mask, log2mb);
+            const cplx es = unit_root<DIR>((n2 * (uint64_t)RA) & mask, log2mb);
+#pragma unroll
+            for (int p = 0; p < RB; ++p) {
+                v[p] = cmul(v[p], cur);
+                cur = cmul(cur, es);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const uint64_t a = addr(bq + RA * p, bc);
+            cplx val = v[p];
+            if (MULB) val = cmul(val, bhat[a]);
+            A[a] = val;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) v[p] = A[addr(bq + RA * p, bc)];
+        if (!CONTIG) {
+            const int log2mb = log2S + RA_BITS + 4;
+            const uint64_t mask = (1ull << log2mb) - 1;
+            const uint64_t n2 = n2_0 + bc;
+            cplx cur = unit_root<DIR>((n2 * (uint64_t)bq) & mask, log2mb);
+            const cplx es = unit_root<DIR>((n2 * (uint64_t)RA) & mask, log2mb);
+#pragma unroll
+            for (int p = 0; p < RB; ++p) {
+                v[p] = cmul(v[p], cur);
+                cur = cmul(cur, es);
+            }
+        }
+        dft_n<16, DIR>::run(v);
+        if (RA > 1) {
+#pragma unroll
+            for (int g = 0; g < RB; ++g) {
+                cplx val = v[g];
+                if (g > 0) val = cmul(val, cconj(wt[((g * bq) << (4 - RA_BITS)) & 255]));
+                lds[lidx(bq, g, bc)] = val;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int sa = t + 256 * u;
+                const int g = CONTIG ? (sa % RB) : (sa / T);
+                const int c = CONTIG ? (sa / RB) : (sa % T);
+#pragma unroll
+                for (int q = 0; q < RA; ++q) v[q] = lds[lidx(q, g, c)];
+                dft_n<RA, DIR>::run(v);
+#pragma unroll
+                for (int j = 0; j < RA; ++j) A[addr(g + RB * j, c)] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < RB; ++g) A[addr(g, bc)] = v[g];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plan: log2(M) = 8 (last, contiguous) + strided passes of 4..8 bits each
+// ---------------------------------------------------------------------------
+int wfx_dev_fft_plan_radices(int log2m, int *ra_bits, int max_passes)
+{
+    if (log2m < 12) return -1;
+    int rem = log2m - 8;
+    int k = (rem + 7) / 8;
+    if (k > max_passes) return -1;
+    int basebits = rem / k, extra = rem % k;
+    for (int i = 0; i < k; ++i) ra_bits[i] = (basebits + (i < extra ? 1 : 0)) - 4;
+    return k;
+}
+
+static int ensure_w256(wfx_ctx *ctx)
+{
+    if (ctx->w256_ready) return 0;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_w256, 256 * sizeof(cplx)));
+    cplx h[256];
+    for (int i = 0; i < 256; ++i) {
+        // exact octant symmetry is not needed; libm cos/sin are accurate to < 1 ulp
+        double ang = -2.0 * M_PI * (double)i / 256.0;
+        h[i].x = cos(ang);
+        h[i].y = sin(ang);
+    }
+    h[0] = make_double2(1.0, 0.0);
+    h[64] = make_double2(0.0, -1.0);
+    h[128] = make_double2(-1.0, 0.0);
+    h[192] = make_double2(0.0, 1.0);
+    WFX_HIP(ctx, hipMemcpyAsync(ctx->b_w256.p, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->w256_ready = true;
+    return 0;
+}
+
+template <int DIR>
+static int launch_strided(wfx_ctx *ctx, cplx *A, int log2m, int ra_bits, int log2S)
+{
+    const unsigned grid = 1u << (log2m - 12);
+    const cplx *w = (const cplx *)ctx->b_w256.p;
+    const int kid = DIR > 0 ? K_FFT_FWD : K_FFT_INV;
+    switch (ra_bits) {
+    case 0: WFX_LAUNCH(ctx, kid, (fft_pass<0, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
+    case 1: WFX_LAUNCH(ctx, kid, (fft_pass<1, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
+    case 2: WFX_LAUNCH(ctx, kid, (fft_pass<2, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
+    case 3: WFX_LAUNCH(ctx, kid, (fft_pass<3, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
+    case 4: WFX_LAUNCH(ctx, kid, (fft_pass<4, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
+    default: return wfx_fail(ctx, WFX_ERR_STATE, "bad FFT radix %d", ra_bits);
+    }
+    return 0;
+}
+
+// forward: natural -> digit-reversed; optionally multiply by bhat in the last pass
+static int fft_forward(wfx_ctx *ctx, cplx *A, int log2m, const cplx *bhat)
+{
+    WFX_TRY(ensure_w256(ctx));
+    int ra[8];
+    int k = wfx_dev_fft_plan_radices(log2m, ra, 8);
+    if (k < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unsupported FFT size 2^%d", log2m);
+    int log2S = log2m;
+    for (int i = 0; i < k; ++i) {
+        log2S -= ra[i] + 4;
+        WFX_TRY(launch_strided<1>(ctx, A, log2m, ra[i], log2S));
+    }
+    const unsigned grid = 1u << (log2m - 12);
+    const cplx *w = (const cplx *)ctx->b_w256.p;
+    if (bhat)
+        WFX_LAUNCH(ctx, K_FFT_FWD, (fft_pass<4, 1, true, true>), dim3(grid), dim3(256), A, 0, w, bhat);
+    else
+        WFX_LAUNCH(ctx, K_FFT_FWD, (fft_pass<4, 1, true, false>), dim3(grid), dim3(256), A, 0, w, bhat);
+    return 0;
+}
+
+// inverse (unnormalised): digit-reversed -> natural
+static int fft_inverse(wfx_ctx *ctx, cplx *A, int log2m)
+{
+    WFX_TRY(ensure_w256(ctx));
+    int ra[8];
+    int k = wfx_dev_fft_plan_radices(log2m, ra, 8);
+    if (k < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unsupported FFT size 2^%d", log2m);
+    const unsigned grid = 1u << (log2m - 12);
+    const cplx *w = (const cplx *)ctx->b_w256.p;
+    WFX_LAUNCH(ctx, K_FFT_INV, (fft_pass<4, -1, true, false>), dim3(grid), dim3(256), A, 0, w, (const cplx *)nullptr);
+    int log2S[8];
+    int s = log2m;
+    for (int i = 0; i < k; ++i) {
+        s -= ra[i] + 4;
+        log2S[i] = s;
+    }
+    for (int i = k - 1; i >= 0; --i) WFX_TRY(launch_strided<-1>(ctx, A, log2m, ra[i], log2S[i]));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Bluestein pointwise kernels
+// ---------------------------------------------------------------------------
+// w_n = exp(+i pi n^2 / N); n^2 is reduced modulo 2N in integers first
+__device__ __forceinline__ cplx chirp(uint64_t n, uint64_t N)
+{
+    const uint64_t r = (n * n) % (2 * N);
+    double s, c;
+    sincospi((double)r / (double)N, &s, &c);
+    return make_double2(c, s);
+}
+
+// chirp filter b[i] = w_i (i < N), w_{M-i} (i > M-N), 0 otherwise; pre-scaled by 1/M
+__global__ void __launch_bounds__(256) bs_fill_b(cplx *__restrict__ B, uint64_t N, uint64_t M, double inv_m)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < M; i += (uint64_t)gridDim.x * 256ull) {
+        cplx v = make_double2(0.0, 0.0);
+        if (i < N)
+            v = chirp(i, N);
+        else if (M - i < N)
+            v = chirp(M - i, N);
+        v.x *= inv_m;
+        v.y *= inv_m;
+        B[i] = v;
+    }
+}
+
+// U[i] = x[i] * conj(w_i) for i < N, 0 for N <= i < M
+__global__ void __launch_bounds__(256) bs_prologue_real(const double *__restrict__ x, cplx *__restrict__ U, uint64_t N, uint64_t M)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < M; i += (uint64_t)gridDim.x * 256ull) {
+        cplx v = make_double2(0.0, 0.0);
+        if (i < N) {
+            const cplx w = chirp(i, N);
+            const double xv = x[i];
+            v = make_double2(xv * w.x, -(xv * w.y));
+        }
+        U[i] = v;
+    }
+}
+
+// Between the two transforms of the analytic signal.  With X[k] = V[k] conj(w_k):
+// spectrum S = h[k] X[k] (scipy.signal.hilbert: h = 1 at DC and Nyquist, 2 on the
+// positive bins, 0 on the negative ones), and the inverse DFT of S is
+// conj(DFT(conj(S))) / N whose Bluestein input is conj(S[k]) conj(w_k) = h[k] conj(V[k])
+// (|w_k| = 1, the two chirps cancel).
+__global__ void __launch_bounds__(256) hilbert_mid(cplx *__restrict__ V, uint64_t N, uint64_t M)
+{
+    const uint64_t half = N / 2;
+    for (uint64_t k = blockIdx.x * 256ull + threadIdx.x; k < M; k += (uint64_t)gridDim.x * 256ull) {
+        cplx v = make_double2(0.0, 0.0);
+        if (k < N) {
+            double h;
+            if (k == 0)
+                h = 1.0;
+            else if ((N & 1) == 0)
+                h = k < half ? 2.0 : (k == half ? 1.0 : 0.0);
+            else
+                h = k < (N + 1) / 2 ? 2.0 : 0.0;
+            if (h != 0.0) {
+                const cplx a = V[k];
+                v = make_double2(h * a.x, -(h * a.y));
+            }
+        }
+        V[k] = v;
+    }
+}
+
+// analytic signal z[n] = conj(V[n]) w_n / N, so |z[n]| = |V[n] / N| (np.abs(hilbert), wefax.py:175)
+__global__ void __launch_bounds__(256) hilbert_abs(const cplx *__restrict__ V, uint64_t N, double inv_n, double *__restrict__ env_raw)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256ull) {
+        const cplx a = V[i];
+        env_raw[i] = hypot(a.x * inv_n, a.y * inv_n);
+    }
+}
+
+static int ceil_log2_u64(uint64_t v)
+{
+    int l = 0;
+    while ((1ull << l) < v) ++l;
+    return l;
+}
+
+static int get_plan(wfx_ctx *ctx, uint64_t n, wfx_bs_plan **out)
+{
+    auto it = ctx->plans.find(n);
+    if (it != ctx->plans.end()) {
+        *out = &it->second;
+        return 0;
+    }
+    if (n < 1 || n > (1ull << 31)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "transform length %llu out of range", (unsigned long long)n);
+    if (ctx->plans.size() >= 4) {   // keep the cache small: drop everything
+        hipStreamSynchronize(ctx->stream);
+        for (auto &kv : ctx->plans)
+            if (kv.second.bhat.p) hipFree(kv.second.bhat.p);
+        ctx->plans.clear();
+    }
+    wfx_bs_plan pl;
+    pl.n = n;
+    int l = ceil_log2_u64(2 * n - 1);
+    pl.log2m = l < 12 ? 12 : l;
+    const uint64_t M = 1ull << pl.log2m;
+    WFX_TRY(wfx_reserve(ctx, pl.bhat, M * sizeof(cplx)));
+    WFX_LAUNCH(ctx, K_BS_CHIRP, bs_fill_b, dim3(wfx_stream_grid(M, 256)), dim3(256), (cplx *)pl.bhat.p, n, M, 1.0 / (double)M);
+    int rc = fft_forward(ctx, (cplx *)pl.bhat.p, pl.log2m, nullptr);
+    if (rc != 0) {
+        hipFree(pl.bhat.p);
+        return rc;
+    }
+    auto ins = ctx->plans.emplace(n, pl);
+    *out = &ins.first->second;
+    return 0;
+}
+
+// circular convolution with the chirp filter, in place: A <- IFFT(FFT(A) .* bhat)
+static int bs_convolve(wfx_ctx *ctx, cplx *A, const wfx_bs_plan *pl)
+{
+    WFX_TRY(fft_forward(ctx, A, pl->log2m, (const cplx *)pl->bhat.p));
+    WFX_TRY(fft_inverse(ctx, A, pl->log2m));
+    return 0;
+}
+
+int wfx_dev_hilbert_env_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw)
+{
+    wfx_bs_plan *pl = nullptr;
+    WFX_TRY(get_plan(ctx, n, &pl));
+    const uint64_t M = 1ull << pl->log2m;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work, M * sizeof(cplx)));
+    cplx *W = (cplx *)ctx->b_work.p;
+    const dim3 gm(wfx_stream_grid(M, 256)), blk(256);
+    WFX_LAUNCH(ctx, K_BS_CHIRP, bs_prologue_real, gm, blk, x, W, n, M);
+    WFX_TRY(bs_convolve(ctx, W, pl));
+    WFX_LAUNCH(ctx, K_BS_CHIRP, hilbert_mid, gm, blk, W, n, M);
+    WFX_TRY(bs_convolve(ctx, W, pl));
+    WFX_LAUNCH(ctx, K_ENV_MEDIAN, hilbert_abs, dim3(wfx_stream_grid(n, 256)), blk, (const cplx *)W, n, 1.0 / (double)n, env_raw);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// scipy.signal.resample(x, num) for real x (wefax.py:384):
+//   X = rfft(x); Y[:nyq] = X[:nyq] (nyq = min(num, n0)//2 + 1), Nyquist bin doubled
+//   (down) or halved (up) when min(num, n0) is even; y = irfft(Y, num) * (num / n0)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+resample_gather(const cplx *__restrict__ V1, uint64_t n0, uint64_t num, cplx *__restrict__ U2, uint64_t M2)
+{
+    const uint64_t nmin = num < n0 ? num : n0;
+    const uint64_t nyq = nmin / 2 + 1;
+    for (uint64_t k = blockIdx.x * 256ull + threadIdx.x; k < M2; k += (uint64_t)gridDim.x * 256ull) {
+        cplx u = make_double2(0.0, 0.0);
+        if (k < num) {
+            const bool mirror = k > num / 2;
+            const uint64_t kk = mirror ? num - k : k;
+            if (kk < nyq) {
+                cplx X = cmul(V1[kk], cconj(chirp(kk, n0)));     // DFT_n0(x)[kk]
+                if ((nmin & 1) == 0 && kk == nmin / 2) {
+                    const double f = num < n0 ? 2.0 : (n0 < num ? 0.5 : 1.0);
+                    X.x *= f;
+                    X.y *= f;
+                }
+                // irfft ignores the imaginary part of the DC bin and of the Nyquist bin (num even)
+                if (kk == 0 || ((num & 1) == 0 && kk == num / 2)) X.y = 0.0;
+                const cplx Z = mirror ? cconj(X) : X;
+                u = cmul(cconj(Z), cconj(chirp(k, num)));       // Bluestein input of DFT(conj(Z))
+            }
+        }
+        U2[k] = u;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+resample_final(const cplx *__restrict__ V2, uint64_t num, double inv_num, double ratio, double *__restrict__ y)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < num; i += (uint64_t)gridDim.x * 256ull) {
+        // IDFT value = conj(V2[i] conj(w_i)) / num; its real part:
+        const cplx w = chirp(i, num);
+        const cplx a = V2[i];
+        const double re = fma(a.x, w.x, a.y * w.y);
+        y[i] = (re * inv_num) * ratio;
+    }
+}
+
+int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out)
+{
+    if (n0 < 1 || num < 1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "resample: empty input or output");
+    wfx_bs_plan *p1 = nullptr;
+    WFX_TRY(get_plan(ctx, n0, &p1));
+    const int log2m1 = p1->log2m;
+    const uint64_t M1 = 1ull << log2m1;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work, M1 * sizeof(cplx)));
+    cplx *W1 = (cplx *)ctx->b_work.p;
+    const dim3 blk(256);
+    WFX_LAUNCH(ctx, K_BS_CHIRP, bs_prologue_real, dim3(wfx_stream_grid(M1, 256)), blk, x, W1, n0, M1);
+    WFX_TRY(bs_convolve(ctx, W1, p1));
+    wfx_bs_plan *p2 = nullptr;
+    WFX_TRY(get_plan(ctx, num, &p2));       // may evict p1's filter: p1 is not used below
+    const uint64_t M2 = 1ull << p2->log2m;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, M2 * sizeof(cplx)));
+    cplx *W2 = (cplx *)ctx->b_work2.p;
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, resample_gather, dim3(wfx_stream_grid(M2, 256)), blk, (const cplx *)W1, n0, num, W2, M2);
+    WFX_TRY(bs_convolve(ctx, W2, p2));
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, resample_final, dim3(wfx_stream_grid(num, 256)), blk, (const cplx *)W2, num,
+               1.0 / (double)num, (double)num / (double)n0, out);
+    return 0;
+}

@@ -1,0 +1,168 @@
+// Internal declarations shared by the translation units of libwefax_hip.so.
+// gfx950 (MI355X) only: wave64, 160 KiB LDS per CU, no portability shims.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "wefax_hip.h"
+
+typedef double2 cplx;   // interleaved (re, im), one 16-byte vector access
+
+// ---- kernel ids for the per-kernel HIP-event profile ------------------------
+enum wfx_kernel_id {
+    K_MERGE = 0,
+    K_NOTCH,
+    K_BS_CHIRP,        // Bluestein pointwise kernels (prologue / mid / fill)
+    K_FFT_FWD,         // power-of-two FFT pass, forward (DIF)
+    K_FFT_INV,         // power-of-two FFT pass, inverse (DIT)
+    K_ENV_MEDIAN,      // Bluestein epilogue + |z| + 5-tap median
+    K_FIR_ANALYTIC,    // sliding-window FIR Hilbert + |z| (FIR mode)
+    K_MEDIAN,          // stand-alone 5-tap median (FIR mode)
+    K_SELECT_HIST,
+    K_SELECT_SCAN,
+    K_QUANTISE,
+    K_SYNC_CORR,
+    K_SYNC_PICK,
+    K_IMAGE,
+    K_RESAMPLE_PW,     // resampler pointwise kernels
+    K_COUNT
+};
+
+struct wfx_devbuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct wfx_bs_plan {          // Bluestein plan for one transform length N
+    uint64_t n = 0;
+    int log2m = 0;
+    wfx_devbuf bhat;          // FFT_M(chirp filter) / M, in the pass engine's output order
+};
+
+// scalars that live on the device between the kernels of one decode
+struct wfx_dev_scalars {
+    double low, high;
+    unsigned long long nan_count;
+    int npeaks, hit_limit, no_group, n_phasing;
+    long long start_frame;
+    int height, pad_;
+    long long peak_pos[WFX_MAX_PEAKS + 1];
+    long long first_pos[WFX_MAX_PEAKS + 1];
+    long long phasing[WFX_MAX_PEAKS + 1];
+    // radix-select state: 4 queries
+    unsigned long long sel_prefix[4];
+    unsigned long long sel_rank[4];
+    double sel_value[4];
+};
+
+struct wfx_prof_rec {
+    hipEvent_t a, b;
+    int kid;
+};
+
+struct wfx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // named device buffers (grown on demand, reused across calls)
+    wfx_devbuf b_in, b_x, b_audio, b_work, b_work2, b_envraw, b_env, b_dig, b_corr,
+        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps;
+    bool w256_ready = false;
+    std::map<uint64_t, wfx_bs_plan> plans;
+
+    // decode state
+    wfx_decode_params dp{};
+    bool have_input = false;
+    bool ran = false;
+    wfx_decode_info *h_info = nullptr;      // pinned
+    wfx_dev_scalars *h_scal = nullptr;      // pinned mirror
+
+    // measurement
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool prof = false;
+    std::vector<wfx_prof_rec> prof_recs;
+    std::vector<hipEvent_t> ev_pool;
+    uint64_t prof_count[K_COUNT] = {};
+    double prof_ms[K_COUNT] = {};
+};
+
+// ---- error helpers ----------------------------------------------------------
+int wfx_fail(wfx_ctx *ctx, int code, const char *fmt, ...);
+int wfx_fail_hip(wfx_ctx *ctx, hipError_t e, const char *what);
+void wfx_set_global_error(const char *msg);
+
+#define WFX_HIP(ctx, call)                                         \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) return wfx_fail_hip(ctx, e_, #call); \
+    } while (0)
+
+#define WFX_TRY(expr)             \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+int wfx_reserve(wfx_ctx *ctx, wfx_devbuf &b, size_t bytes);
+
+// ---- profiling-aware launch ---------------------------------------------------
+void wfx_prof_begin(wfx_ctx *ctx, int kid);
+void wfx_prof_end(wfx_ctx *ctx);
+
+#define WFX_LAUNCH(ctx, kid, kern, grid, block, ...)                               \
+    do {                                                                           \
+        wfx_prof_begin(ctx, kid);                                                  \
+        hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);      \
+        wfx_prof_end(ctx);                                                         \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) return wfx_fail_hip(ctx, e_, "launch " #kern);       \
+    } while (0)
+
+static inline unsigned wfx_blocks(uint64_t n, unsigned per_block)
+{
+    return (unsigned)((n + per_block - 1) / per_block);
+}
+
+// grid size for grid-stride streaming kernels: enough workgroups to fill 256 CUs
+static inline unsigned wfx_stream_grid(uint64_t n, unsigned per_block)
+{
+    uint64_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (unsigned)b;
+}
+
+// ---- device-level stage functions (device pointers in, device pointers out) --
+// wfx_fft.hip
+int wfx_dev_fft_plan_radices(int log2m, int *ra_bits, int max_passes);   // host only
+int wfx_dev_hilbert_env_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw);
+int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out);
+
+// wfx_stages.hip
+int wfx_dev_merge(wfx_ctx *ctx, const int16_t *lr, uint64_t n, double *out);
+int wfx_dev_i16_to_f64(wfx_ctx *ctx, const int16_t *in, uint64_t n, double *out);
+int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3],
+                  const double a[3], double *out);
+int wfx_dev_median5(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env);
+int wfx_dev_select(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4],
+                   wfx_dev_scalars *d_scal);
+int wfx_dev_percentile_lerp(wfx_ctx *ctx, double gamma_lo, double gamma_hi,
+                            wfx_dev_scalars *d_scal);
+int wfx_dev_quantise(wfx_ctx *ctx, const double *env, uint64_t n, const wfx_dev_scalars *d_scal,
+                     uint8_t *out, wfx_dev_scalars *d_scal_out);
+int wfx_dev_sync_corr(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int32_t *corr);
+int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0,
+                      int64_t mindistance, double frame_samples, int width,
+                      wfx_dev_scalars *d_scal);
+int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max,
+                  const wfx_dev_scalars *d_scal, uint8_t *img);
+
+// wfx_fir.hip
+int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps, double *env_raw);

@@ -1,0 +1,286 @@
+"""Drop-in replacement for wojlin/WEFAX ``wefax.py``: same ``Demodulator`` API
+(/root/reference/wefax.py:18-408), same progress messages, same exceptions, same
+output image layout -- the arithmetic runs in hand-written HIP kernels on an
+MI355X through the C ABI of include/wefax_hip.h.
+
+    python wefax.py <in.wav> <lines_per_minute> <out.png>        (wefax.py:411-424)
+
+What is deliberately different from the reference (none of it changes a pixel):
+  * no ``time.sleep`` calls (the reference sleeps 7 s, wefax.py:59,73,75,77,193,202);
+  * ``quiet=True`` silences this module's own prints instead of replacing
+    ``sys.stdout`` process-wide (wefax.py:48-51,92-93);
+  * ``digitalized_data`` is a numpy uint8 array, not a Python list of int;
+  * stage arrays (``audio_data`` ...) are copied from the GPU lazily on first access.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+from . import _native as nat
+from . import hostparams as hp
+
+DEFAULT_HILBERT_MODE = nat.WFX_HILBERT_FFT
+DEFAULT_FIR_TAPS = 4095
+
+
+class DecodeJob:
+    """One capture resident on the GPU: upload once, run the path any number of
+    times (bench.py times ``run()``), then read results."""
+
+    def __init__(self, ctx: nat.Context, data: np.ndarray, sample_rate: int,
+                 lines_per_minute: int = 120, notch=hp.DEFAULT_NOTCH,
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS):
+        self.ctx = ctx
+        self.frame_len = 1 / (lines_per_minute / 60)                       # wefax.py:33
+        data = np.asarray(data)
+        self.merged_on_host = False
+        if data.ndim == 2:
+            if data.dtype == np.int16:
+                kind = nat.WFX_IN_I16_STEREO
+                data = np.ascontiguousarray(data[:, :2])
+            else:   # other sample formats: numpy scalar semantics on the host (wefax.py:372)
+                with np.errstate(over="ignore"):
+                    data = np.divide(np.add(data[:, 0], data[:, 1]), 2).astype(np.float64)
+                kind = nat.WFX_IN_F64_MONO
+                self.merged_on_host = True
+        elif data.dtype == np.int16:
+            kind = nat.WFX_IN_I16_MONO
+        else:
+            data = data.astype(np.float64)
+            kind = nat.WFX_IN_F64_MONO
+        n0 = int(data.shape[0])
+        self.input_length = n0 / sample_rate                               # wefax.py:357
+        self.resampled = sample_rate != hp.TARGET_RATE                     # wefax.py:60
+        n = int(hp.TARGET_RATE * self.input_length) if self.resampled else n0   # wefax.py:384
+        self.n0, self.n = n0, n
+        self.sample_rate = hp.TARGET_RATE
+        self.length = n / hp.TARGET_RATE                                   # wefax.py:393
+        if n <= 9:
+            raise ValueError("The length of the input vector x must be greater than padlen, which is 9.")
+        b, a = hp.iirnotch(int(notch[0]), notch[1], self.sample_rate)      # wefax.py:63-70
+        p = nat.DecodeParams()
+        p.in_kind, p.n0, p.n, p.resample = kind, n0, n, int(self.resampled)
+        p.notch_b[:] = [float(v) for v in b]
+        p.notch_a[:] = [float(v) for v in a]
+        p.hilbert_mode, p.fir_taps = hilbert_mode, fir_taps
+        lo0, lo1, glo = hp.percentile_plan(n, 0.5)                         # wefax.py:194-196
+        hi0, hi1, ghi = hp.percentile_plan(n, 99.5)
+        p.rank_lo[:] = [lo0, lo1]
+        p.rank_hi[:] = [hi0, hi1]
+        p.gamma_lo, p.gamma_hi = glo, ghi
+        n1, n0g, mind = hp.sync_constants(self.sample_rate, self.frame_len)
+        p.n1, p.n0_gap, p.mindistance = n1, n0g, mind
+        p.frame_samples = self.frame_len * self.sample_rate                # wefax.py:265-266
+        p.width = int(self.frame_len * self.sample_rate)                   # wefax.py:298
+        self.params = p
+        self.width = p.width
+        ctx.decode_upload(data, p)
+        self.info = None
+
+    def run(self):
+        """Enqueue the whole path (asynchronous)."""
+        self.ctx.decode_run()
+        self.info = None
+
+    def result(self) -> nat.DecodeInfo:
+        if self.info is None:
+            self.info = self.ctx.decode_result()
+        return self.info
+
+    def fetch(self, which: str) -> np.ndarray:
+        info = self.result()
+        if which == "audio":
+            return self.ctx.decode_fetch(nat.WFX_BUF_AUDIO, (self.n,), np.float64)
+        if which == "envelope":
+            return self.ctx.decode_fetch(nat.WFX_BUF_ENVELOPE, (self.n,), np.float64)
+        if which == "digitalized":
+            return self.ctx.decode_fetch(nat.WFX_BUF_DIGITAL, (self.n,), np.uint8)
+        if which == "image":
+            return self.ctx.decode_fetch(nat.WFX_BUF_IMAGE, (4 * info.height, info.width), np.uint8)
+        raise KeyError(which)
+
+
+class Demodulator:
+    def __init__(self, filepath: str,
+                 lines_per_minute: int = 120,
+                 quiet: bool = False,
+                 tcp_stream: bool = True,
+                 device: int | None = None,
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE,
+                 fir_taps: int = DEFAULT_FIR_TAPS):
+        if not os.path.exists(filepath):                                   # wefax.py:24-25
+            raise Exception(f"INVALID FILE: file at path: {filepath} does not exist")
+        if filepath.split('.')[-1] != 'wav':                               # wefax.py:27-28
+            raise Exception("INVALID FILETYPE: only .wav files are supported at this moment")
+        self.filepath = filepath
+        self.filename = self.filepath.split('/')[-1]
+        self.lines_per_minute = lines_per_minute
+        self.time_for_one_frame = 1 / (self.lines_per_minute / 60)  # in s
+        self.quiet = quiet
+        self.stream = tcp_stream
+        self.websocket_stack = []
+        self._device = device
+        self._hilbert_mode = hilbert_mode
+        self._fir_taps = fir_taps
+        self._ctx = None
+        self._job = None
+        self._cache = {}
+        if not self.quiet:
+            print("#" * 10 + ' ' * 5 + str(self.filename).ljust(20) + ' ' * 5 + "#" * 10)
+
+    def update_lines_per_minute(self, lpm):                                # wefax.py:42-44
+        self.lines_per_minute = lpm
+        self.time_for_one_frame = 1 / (lpm / 60)  # in s
+
+    # ------------------------------------------------------------------ helpers
+    def _say(self, text):
+        if not self.quiet:
+            print(text)
+
+    def _send_websocket_packet(self, message: dict):                       # wefax.py:396-397
+        self.websocket_stack.append(message)
+
+    def _progress(self, title, percentage):
+        if self.stream:
+            self._send_websocket_packet({"data_type": "progress_bar",
+                                         "progress_title": title,
+                                         "percentage": percentage})
+
+    # ------------------------------------------------------------------ process
+    def process(self):
+        """wefax.py:46-93.  Raises what the reference raises: ValueError when no
+        phasing group closes (wefax.py:294) or when the envelope is constant
+        (int(nan), wefax.py:216)."""
+        self._cache = {}
+        sample_rate, data = hp.read_wav(self.filepath)                      # wefax.py:349
+        if data.ndim == 2:                                                  # wefax.py:351-355
+            self._say("\033[0;33mWARNING: two channels audio detected. Program will try to merge audio to one channel\033[0m")
+            self._say("MERGING AUDIO CHANNELS:")
+            parts = len(data)
+            if self.stream:
+                for p in range(0, parts, 1000):                             # wefax.py:364-370
+                    self._progress("merging channels", (p + 1) / parts * 100)
+                if (parts - 1) % 1000 != 0:
+                    self._progress("merging channels", (parts - 1 + 1) / parts * 100)
+        if sample_rate != hp.TARGET_RATE:                                   # wefax.py:376-383
+            self._say("\033[0;33mWARNING: audio sample rate is not 11025 samples per second. Program will try to resample audio\033[0m")
+            self._say(f"RESAMPLING AUDIO FROM {round(sample_rate / 1000, 2)} KhZ TO 11.025 KHZ:")
+            self._progress("resampling audio", 0)
+
+        if self._ctx is None:
+            self._ctx = nat.Context(self._device)
+        notch = hp.load_notch_settings()
+        job = DecodeJob(self._ctx, data, sample_rate, self.lines_per_minute, notch,
+                        self._hilbert_mode, self._fir_taps)
+        self._job = job
+        job.run()
+        info = job.result()
+
+        if sample_rate != hp.TARGET_RATE:
+            self._progress("resampling audio", 100)                         # wefax.py:386-390
+        self.sample_rate, self.length = job.sample_rate, job.length
+        self._say(f"{int(notch[0])} {notch[1]} {self.sample_rate}")         # wefax.py:66
+        self._say("DEMODULATING SIGNAL:")
+        self._progress("demodulating signal", 0)                            # wefax.py:169-181
+        self._progress("demodulating signal", 100)
+        self._say("DIGITALIZING SIGNAL:")
+        self._progress("digitalizing signal", 0)                            # wefax.py:188-214
+        self._progress("digitalizing signal", 99)
+        self._progress("digitalizing signal", 100)
+        if info.nan_count:
+            raise ValueError("cannot convert float NaN to integer")        # int(nan), wefax.py:216
+        self._say("FINDING SYNC PULSE:")
+        n = job.n
+        for k in range(1, info.npeaks):                                     # wefax.py:242-246
+            self._progress("finding sync pulse", (info.first_pos[k] / n) * 100)
+        if info.hit_limit:
+            self._progress("finding sync pulse", 100)                       # wefax.py:254-258
+        self._low, self._high = info.low, info.high
+        self.peaks = [int(info.peak_pos[k]) for k in range(info.npeaks)]
+        if info.no_group:
+            max([], key=len)            # raises ValueError("max() arg is an empty sequence"), wefax.py:294
+        self.phasing_signals = [int(info.phasing[k]) for k in range(info.n_phasing)]
+        self.start_frame = self.phasing_signals[-1] if self.phasing_signals else 0   # wefax.py:80
+        assert self.start_frame == info.start_frame
+
+        self._say("CONVERTING SIGNAL TO IMAGE:")
+        w, h = info.width, info.height
+        if h == 0:
+            # Image.new('L', (w, 0)).putpixel((0, 0), .) in the reference's loop (wefax.py:304)
+            raise IndexError("image index out of range")
+        if self.stream:
+            for py in range(0, h, 50):                                      # wefax.py:307-313
+                self._progress("converting signal to image", (py + 1) / h * 100)
+            self._progress("converting signal to image", 100)               # wefax.py:316-322
+        pixels = job.fetch("image")
+        self.output_array = pixels
+        try:
+            from PIL import Image
+            self.output_image = Image.fromarray(pixels, mode="L")
+        except ImportError:                                                 # Pillow optional
+            self.output_image = None
+        if self.stream:                                                     # wefax.py:87-90
+            self._send_websocket_packet({"data_type": "message",
+                                         "message_content": "convert_end"})
+
+    # stage arrays, copied back on demand -----------------------------------------
+    def _lazy(self, key):
+        if key not in self._cache:
+            if self._job is None:
+                raise AttributeError(key)
+            self._cache[key] = self._job.fetch(key)
+        return self._cache[key]
+
+    @property
+    def audio_data(self):            # after merge / resample / notch (wefax.py:72)
+        return self._lazy("audio")
+
+    @property
+    def demodulated_data(self):      # wefax.py:74
+        return self._lazy("envelope")
+
+    @property
+    def digitalized_data(self):      # wefax.py:76
+        return self._lazy("digitalized")
+
+    # ------------------------------------------------------------------ the rest
+    def file_info(self):                                                    # wefax.py:342-346
+        sample_rate, data = hp.read_wav(self.filepath)
+        channels = len(data.shape)          # the reference reports ndim, not the channel count
+        length = len(data) / sample_rate
+        return {"filename": self.filename, "channels": channels, "sample_rate": sample_rate, "length": length}
+
+    def show_output_image(self):                                            # wefax.py:403-405
+        from matplotlib import pyplot as plt
+        plt.imshow(self.output_image, cmap='gray')
+        plt.show()
+
+    def save_output_image(self, filepath: str):                             # wefax.py:407-408
+        if self.output_image is None:
+            raise RuntimeError("Pillow is not installed: cannot write " + filepath)
+        self.output_image.save(filepath)
+
+    def close(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+            self._job = None
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    filename = str(argv[1])
+    lpm = int(argv[2])
+    output = str(argv[3])
+    demodulator = Demodulator(filename, lines_per_minute=lpm, tcp_stream=False, quiet=False)
+    for key, value in demodulator.file_info().items():
+        print(key, ":", value)
+    demodulator.process()
+    demodulator.save_output_image(output)
+
+
+if __name__ == "__main__":
+    main()
