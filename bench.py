@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the WEFAX demod->pixel hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the whole path (ingest -> notch -> analytic envelope ->
+median -> percentiles -> quantise -> sync search -> lines -> 4x bicubic image) over
+one synthetic capture that is already resident in HBM.  At N = 1 the workload is
+BASELINE.json configs[1]: a synthetic 10-minute 11 025 Hz mono capture
+(7 166 250 int16 samples, 120 LPM).  At N > 1 every rank decodes its own capture of
+that shape (the path shards by capture with no data-path collective; only the
+finished images are gathered to rank 0 with one RCCL gather per step), so the
+scaling is weak.  Rank 0 prints ONE JSON line.
+
+value = input samples of all ranks / max-over-ranks wall time of the K timed steps.
+roofline = the dominant kernel's algorithmic bytes per launch / its average launch
+duration, both measured with HIP events on the library's stream in a second pass of
+K steps (the event pairs would otherwise sit inside the timed region).
+cpu_baseline = the oracle (oracle/wefax_oracle.py, a NumPy/C port of wefax.py) timed
+on this host, one process, one thread, on the same capture.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["fft", "fir"], default="fft",
+                    help="analytic-signal operator: exact DFT (default) or 4095-tap FIR")
+    ap.add_argument("--noise", type=float, default=0.05, help="AWGN sigma in full-scale units")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--short", action="store_true", help="60-line capture (debugging only)")
+    return ap.parse_args()
+
+
+def make_capture(seed: int, noise: float, short: bool):
+    from wefax_amd import synth
+    if short:
+        return synth.synth_capture(11025.0, noise=noise, seed=seed, phasing_lines=20, image_lines=40,
+                                   start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0)
+    return synth.config_c2(noise=noise, seed=seed)
+
+
+def cpu_baseline(x: np.ndarray) -> dict:
+    """Time the oracle (port of wefax.py) on this host: 1 process, 1 thread."""
+    import tempfile
+    from oracle import wefax_oracle as wo
+    from wefax_amd import synth
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "c2.wav")
+        synth.write_wav(p, 11025, x)
+        t0 = time.perf_counter()
+        r = wo.process(p, 120, want_messages=False)
+        dt = time.perf_counter() - t0
+    return {"value": round(x.shape[0] / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1,
+            "kind": "port", "host_cpus": os.cpu_count(), "seconds": round(dt, 3),
+            "sample": f"the whole capture ({x.shape[0]} samples), one run, read from a wav file",
+            "_result": r}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # plumbing only: rendezvous, barrier, the RCCL gather
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from wefax_amd import _native as nat
+    from wefax_amd.wefax import DecodeJob
+
+    x = make_capture(seed=rank, noise=args.noise, short=args.short)
+    ctx = nat.Context(local_rank)
+    mode = nat.WFX_HILBERT_FFT if args.mode == "fft" else nat.WFX_HILBERT_FIR
+    job = DecodeJob(ctx, x, 11025, 120, hilbert_mode=mode, fir_taps=4095)
+
+    img_bytes = job.width * 4 * (job.n // job.width)      # upper bound (start_frame = 0)
+    gather_buf = None
+    gather_list = None
+    if world > 1:
+        gather_buf = torch.empty(img_bytes, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            gather_list = [torch.empty(img_bytes, dtype=torch.uint8, device="cuda") for _ in range(world)]
+
+    def step():
+        job.run()
+        if world > 1:
+            job.result()                              # waits for the stream
+            ctx.decode_copy_to_device(nat.WFX_BUF_IMAGE, gather_buf.data_ptr(), img_bytes)
+            dist.gather(gather_buf, gather_list, dst=0)
+
+    def sync_all():
+        ctx.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    info = job.result()
+    # second pass: per-kernel HIP-event timing (rank 0 only)
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(args.steps):
+            job.run()
+        ctx.sync()
+        ctx.profile_enable(False)
+        prof = ctx.profile()
+        kernels = {k: {"launches_per_step": v[0] / args.steps, "avg_us": round(1e3 * v[1] / v[0], 2),
+                       "us_per_step": round(1e3 * v[1] / args.steps, 1)} for k, v in prof.items()}
+        dom = max(prof.items(), key=lambda kv: kv[1][1])
+        alg_bytes = job.n0 * 2 + 4 * job.n          # N0*B_in + 4*N
+        avg_s = dom[1][1] / dom[1][0] / 1e3
+        achieved = alg_bytes / avg_s / 1e9
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom[0], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "launches_per_step": dom[1][0] / args.steps,
+                    "whole_path_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    cpu = None
+    parity = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(x)
+        ref = cpu.pop("_result")
+        img = job.fetch("image")
+        parity = {"start_frame_equal": bool(ref.get("start_frame") == info.start_frame),
+                  "max_abs_pixel_delta": (int(np.max(np.abs(img.astype(np.int16) - ref["image"].astype(np.int16))))
+                                          if "image" in ref and img.shape == ref["image"].shape else None),
+                  "digitalized_mismatches": int(np.count_nonzero(job.fetch("digitalized") != ref["digitalized"]))}
+
+    if rank == 0:
+        total_samples = job.n0 * world * args.steps
+        out = {
+            "metric": "Msamples/s demod->pixel",
+            "value": round(total_samples / dt / 1e6, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": ("synthetic 10-min 11.025 kHz WEFAX capture (BASELINE configs[1]): "
+                                    f"{job.n0} int16 mono samples, 120 LPM, AWGN sigma {args.noise} FS"
+                                    if not args.short else "SHORT debugging capture"),
+                       "captures_per_gpu": 1, "hilbert": args.mode,
+                       "image": [info.width, 4 * info.height], "start_frame": int(info.start_frame),
+                       "parallelism": "1 capture per GPU" + (", RCCL gather of images to rank 0" if world > 1 else "")},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "parity_vs_oracle": parity,
+            "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -160,6 +160,9 @@ int wfx_decode_result(wfx_ctx *ctx, wfx_decode_info *info);
 int wfx_decode_fetch(wfx_ctx *ctx, int buffer_id, void *host_out, size_t bytes);
 /* device address of a stage buffer (for collectives on the final image) */
 int wfx_decode_device_ptr(wfx_ctx *ctx, int buffer_id, void **dev_ptr, size_t *bytes);
+/* copy a stage buffer into caller-owned DEVICE memory (e.g. the send buffer of a
+ * collective) and wait for it; at most `capacity` bytes, *copied receives the size */
+int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity, size_t *copied);
 
 /* ---- measurement ------------------------------------------------------ */
 /* HIP-event stopwatch on the context's stream */

@@ -1,0 +1,169 @@
+"""CPU-side tests: host arithmetic of the product, the C ABI surface, the drop-in
+API's argument handling.  No compute call reaches the GPU here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO, golden_cases
+from oracle import wefax_oracle as wo
+from wefax_amd import _native as nat
+from wefax_amd import hostparams as hp
+from wefax_amd import synth
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "wefax_hip.h")).read()
+    declared = set(re.findall(r"\b(wfx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(nat.SYMBOLS)
+    lib = nat.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert lib.wfx_version().startswith(b"wefax_hip")
+    assert lib.wfx_profile_kernel_count() > 10
+    assert lib.wfx_profile_kernel_name(3) == b"fft_pass_fwd"
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "wefax_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(wfx_decode_params), offsetof(wfx_decode_params, notch_b),
+         offsetof(wfx_decode_params, rank_lo), offsetof(wfx_decode_params, mindistance),
+         offsetof(wfx_decode_params, width), sizeof(wfx_decode_info), offsetof(wfx_decode_info, peak_pos));
+  return 0; }''')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    P, I = nat.DecodeParams, nat.DecodeInfo
+    assert got == [ctypes.sizeof(P), P.notch_b.offset, P.rank_lo.offset, P.mindistance.offset, P.width.offset,
+                   ctypes.sizeof(I), I.peak_pos.offset]
+
+
+def test_no_gpu_means_a_loud_failure_not_a_fallback():
+    if nat.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(nat.NativeError, match="no HIP device"):
+        nat.Context(0)
+    from wefax_amd import Demodulator
+    d = Demodulator(os.path.join(GOLDEN, "inputs", "ref_image.wav"), quiet=True)
+    with pytest.raises(nat.NativeError):
+        d.process()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "wefax_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                assert "oracle" not in text.replace("no CPU fallback", ""), os.path.join(root, f)
+    assert "oracle" not in open(os.path.join(REPO, "wefax.py")).read()
+
+
+def test_constructor_contract():
+    from wefax_amd import Demodulator
+    with pytest.raises(Exception) as e:
+        Demodulator("/nonexistent/x.wav")
+    assert str(e.value) == "INVALID FILE: file at path: /nonexistent/x.wav does not exist"   # wefax.py:25
+    with pytest.raises(Exception) as e:
+        Demodulator(os.path.join(REPO, "README.md"))
+    assert str(e.value) == "INVALID FILETYPE: only .wav files are supported at this moment"  # wefax.py:28
+    d = Demodulator(os.path.join(GOLDEN, "inputs", "stereo48k_120.wav"), lines_per_minute=120, quiet=True)
+    assert d.websocket_stack == [] and d.time_for_one_frame == 0.5
+    d.update_lines_per_minute(240)
+    assert d.lines_per_minute == 240 and d.time_for_one_frame == 0.25
+    fi = d.file_info()
+    assert fi == {"filename": "stereo48k_120.wav", "channels": 2, "sample_rate": 48000, "length": 13.0}
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=[c["name"] for c in golden_cases()])
+def test_wav_reader_matches_oracle_reader(case):
+    p = os.path.join(GOLDEN, case["input"])
+    sr0, d0 = wo.read_wav(p)
+    sr1, d1 = hp.read_wav(p)
+    assert sr0 == sr1 and d0.dtype == d1.dtype and np.array_equal(d0, d1)
+
+
+def test_iirnotch_matches_oracle():
+    for fs in (11025, 8000, 48000):
+        b0, a0 = wo.iirnotch(2600, 1, fs)
+        b1, a1 = hp.iirnotch(2600, 1, fs)
+        assert np.array_equal(b0, b1) and np.array_equal(a0, a1)
+    with pytest.raises(ValueError):
+        hp.iirnotch(6000, 1, 11025)
+    assert hp.load_notch_settings("/nonexistent.json") == (2600, 1)
+    assert hp.load_notch_settings(os.path.join(REPO, "tests", "golden", "manifest.json")) == (2600, 1)
+
+
+def test_percentile_plan_reproduces_numpy():
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 10, 199, 200, 201, 11025, 250007, 7166250):
+        v = np.sort(rng.standard_normal(min(n, 4000)))
+        for q in (0.5, 99.5, 0.0, 100.0, 50.0):
+            lo, hi, g = hp.percentile_plan(n, q)
+            assert 0 <= lo <= hi <= n - 1 and hi - lo <= 1
+            if n <= 4000:
+                a, b = v[lo], v[hi]
+                diff = b - a
+                r = a + diff * g
+                if g >= 0.5:
+                    r = b - diff * (1 - g)
+                assert r == np.percentile(v, q)
+
+
+def test_sync_constants_table():
+    # (n1, n0, mindistance, width) per lines-per-minute
+    table = {60: (55, 11, 8820, 11025), 90: (36, 7, 5880, 7350), 100: (33, 6, 5292, 6615),
+             120: (27, 5, 4410, 5512), 180: (18, 3, 2940, 3675), 240: (13, 2, 2205, 2756)}
+    for lpm, (n1, n0, mind, w) in table.items():
+        T = 1 / (lpm / 60)
+        assert hp.sync_constants(11025, T) == (n1, n0, mind) == wo.sync_constants(11025, T)
+        assert int(T * 11025) == w
+
+
+def test_synthetic_workloads_have_the_baseline_sizes():
+    f = synth.wefax_frequency_track(11025.0)
+    assert f.shape[0] == 7166250
+    assert set(np.unique(f[:55125])) == {1500.0, 2300.0}        # start tone toggles black/white
+    x = synth.synth_capture(11025.0, phasing_lines=2, image_lines=2, start_tone_s=0.1, stop_tone_s=0.1,
+                            black_tail_s=0.1)
+    assert x.dtype == np.int16 and abs(int(np.abs(x).max()) - 16384) < 3
+    iq = synth.synth_capture(48000.0, iq=True, phasing_lines=1, image_lines=1, start_tone_s=0.1,
+                             stop_tone_s=0.1, black_tail_s=0.1)
+    assert iq.ndim == 2 and iq.shape[1] == 2
+    x5, lpm = synth.config_c5_member(1, noise=0.0)      # 240 LPM, IOC576: same duration as C2
+    assert lpm == 240 and x5.shape[0] == 7166250
+    x5, lpm = synth.config_c5_member(2, noise=0.0)      # 120 LPM, IOC288: 600 image lines
+    assert lpm == 120 and x5.shape[0] == 7166250 - 600 * 5512.5
+
+
+def test_decode_job_parameter_block(monkeypatch):
+    """DecodeJob fills the ABI struct with the reference's scalar arithmetic (no GPU needed)."""
+    from wefax_amd.wefax import DecodeJob
+
+    class FakeCtx:
+        def decode_upload(self, data, p):
+            self.data, self.p = data, p
+
+    fc = FakeCtx()
+    x = np.zeros(48000 * 3 + 17, dtype=np.int16)
+    job = DecodeJob(fc, x, 48000, 240)
+    assert job.resampled and job.n == int(11025 * (x.shape[0] / 48000)) and job.width == 2756
+    p = fc.p
+    assert (p.in_kind, p.n0, p.n, p.resample) == (nat.WFX_IN_I16_MONO, x.shape[0], job.n, 1)
+    assert (p.n1, p.n0_gap, p.mindistance, p.frame_samples) == (13, 2, 2205, 2756.25)
+    b, a = wo.iirnotch(2600, 1, 11025)
+    assert list(p.notch_b) == list(b) and list(p.notch_a) == list(a)
+    st = np.zeros((1000, 2), dtype=np.int16)
+    assert DecodeJob(fc, st, 11025, 120).params.in_kind == nat.WFX_IN_I16_STEREO
+    u8 = np.full(1000, 128, dtype=np.uint8)
+    assert DecodeJob(fc, u8, 11025, 120).params.in_kind == nat.WFX_IN_F64_MONO and fc.data.dtype == np.float64
+    with pytest.raises(ValueError, match="greater than padlen"):
+        DecodeJob(fc, np.zeros(9, dtype=np.int16), 11025, 120)

@@ -26,6 +26,7 @@ SYMBOLS = [
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
     "wfx_sync_peaks", "wfx_lines_to_image", "wfx_decode_upload", "wfx_decode_run",
     "wfx_decode_result", "wfx_decode_fetch", "wfx_decode_device_ptr",
+    "wfx_decode_copy_to_device",
     "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
     "wfx_profile_kernel_count", "wfx_profile_kernel_name", "wfx_profile_get",
 ]
@@ -113,6 +114,7 @@ def load():
     lib.wfx_decode_result.argtypes = [vp, C.POINTER(DecodeInfo)]
     lib.wfx_decode_fetch.argtypes = [vp, i, vp, sz]
     lib.wfx_decode_device_ptr.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz)]
+    lib.wfx_decode_copy_to_device.argtypes = [vp, i, vp, sz, C.POINTER(sz)]
     lib.wfx_timer_start.argtypes = [vp]
     lib.wfx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.wfx_profile_enable.argtypes = [vp, i]
@@ -260,6 +262,11 @@ class Context:
         p, nb = C.c_void_p(0), C.c_size_t(0)
         self._check(self.lib.wfx_decode_device_ptr(self.h, buffer_id, C.byref(p), C.byref(nb)))
         return p.value, nb.value
+
+    def decode_copy_to_device(self, buffer_id: int, dst_dev_ptr: int, capacity: int) -> int:
+        nb = C.c_size_t(0)
+        self._check(self.lib.wfx_decode_copy_to_device(self.h, buffer_id, C.c_void_p(dst_dev_ptr), capacity, C.byref(nb)))
+        return nb.value
 
     def sync(self):
         self._check(self.lib.wfx_sync(self.h))

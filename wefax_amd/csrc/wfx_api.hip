@@ -357,4 +357,18 @@ int wfx_decode_device_ptr(wfx_ctx *ctx, int buffer_id, void **dev_ptr, size_t *b
     return buffer_of(ctx, buffer_id, dev_ptr, bytes);
 }
 
+int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity, size_t *copied)
+{
+    CHECK_CTX(ctx);
+    void *p = nullptr;
+    size_t nb = 0;
+    WFX_TRY(buffer_of(ctx, buffer_id, &p, &nb));
+    if (nb > capacity) nb = capacity;
+    if (nb && !dst_dev) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null destination");
+    if (nb) WFX_HIP(ctx, hipMemcpyAsync(dst_dev, p, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (copied) *copied = nb;
+    return 0;
+}
+
 }  // extern "C"
