@@ -44,8 +44,9 @@ typedef enum {
 
 /* how the analytic signal (scipy.signal.hilbert, wefax.py:174) is computed */
 typedef enum {
-    WFX_HILBERT_FFT = 0,    /* exact: N-point DFT (Bluestein over power-of-two FFTs) */
-    WFX_HILBERT_FIR = 1     /* sliding-window circular FIR with `fir_taps` taps       */
+    WFX_HILBERT_FFT = 0,    /* exact: circular convolution with ifft(h) by zero-padded power-of-two FFTs */
+    WFX_HILBERT_FIR = 1,    /* sliding-window circular FIR with `fir_taps` taps       */
+    WFX_HILBERT_BLUESTEIN = 2 /* exact, literal fft -> h -> ifft via two Bluestein DFTs (cross-check) */
 } wfx_hilbert_mode;
 
 #define WFX_MAX_PEAKS 100   /* wefax.py:251 */

@@ -124,6 +124,19 @@ def test_analytic_envelope_exact_mode(ctx, n):
     assert _rel(ctx.analytic_env(x), wo.demodulate(x)) <= FLOAT_TOL
 
 
+@pytest.mark.parametrize("n", [2, 3, 10, 4099, 65536, 65537, 250007, 250008])
+def test_analytic_envelope_two_exact_formulations_agree(ctx, n):
+    """Circular convolution with the closed-form kernel (default) vs the literal
+    fft -> h -> ifft through two Bluestein DFTs: independent code paths, same operator."""
+    from oracle import wefax_oracle as wo
+    from wefax_amd import _native as nat
+    x = _signal(n, 3 * n + 1)
+    a = ctx.analytic_env(x, nat.WFX_HILBERT_FFT)
+    b = ctx.analytic_env(x, nat.WFX_HILBERT_BLUESTEIN)
+    ref = wo.demodulate(x)
+    assert _rel(a, ref) <= FLOAT_TOL and _rel(b, ref) <= FLOAT_TOL and _rel(a, b) <= FLOAT_TOL
+
+
 def test_analytic_envelope_fir_mode_converges(ctx):
     """The FIR kernel approaches the exact operator as taps grow (clean narrow-band input)."""
     from oracle import wefax_oracle as wo

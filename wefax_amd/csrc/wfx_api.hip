@@ -81,9 +81,11 @@ int wfx_notch_filtfilt(wfx_ctx *ctx, const void *in, int in_kind, size_t n, cons
 static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode, int taps, double *env_raw, double *env)
 {
     if (mode == WFX_HILBERT_FFT)
-        WFX_TRY(wfx_dev_hilbert_env_fft(ctx, x, n, env_raw));
+        return wfx_dev_hilbert_envmed_fft(ctx, x, n, env);
     else if (mode == WFX_HILBERT_FIR)
         WFX_TRY(wfx_dev_hilbert_env_fir(ctx, x, n, taps, env_raw));
+    else if (mode == WFX_HILBERT_BLUESTEIN)
+        WFX_TRY(wfx_dev_hilbert_env_bluestein(ctx, x, n, env_raw));
     else
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown hilbert mode %d", mode);
     return wfx_dev_median5(ctx, env_raw, n, env);
@@ -288,8 +290,7 @@ int wfx_decode_run(wfx_ctx *ctx)
     WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, p.hilbert_mode, p.fir_taps, (double *)ctx->b_envraw.p,
                              (double *)ctx->b_env.p));
     const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
-    WFX_TRY(wfx_dev_select(ctx, (const double *)ctx->b_env.p, n, ranks, ds));
-    WFX_TRY(wfx_dev_percentile_lerp(ctx, p.gamma_lo, p.gamma_hi, ds));
+    WFX_TRY(wfx_dev_percentiles(ctx, (const double *)ctx->b_env.p, n, ranks, p.gamma_lo, p.gamma_hi, ds));
     WFX_TRY(wfx_dev_quantise(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, ds));
     WFX_TRY(wfx_dev_sync_pick(ctx, (const uint8_t *)ctx->b_dig.p, n, p.n1, p.n0_gap, p.mindistance, p.frame_samples, w, ds));
     WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h_max, ds, (uint8_t *)ctx->b_img.p));

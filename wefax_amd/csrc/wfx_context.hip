@@ -112,6 +112,7 @@ void wfx_destroy(wfx_ctx *ctx)
                           &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps};
     for (auto *b : bufs) free_buf(*b);
     for (auto &kv : ctx->plans) free_buf(kv.second.bhat);
+    for (auto &kv : ctx->hplans) free_buf(kv.second.bhat);
     for (auto &r : ctx->prof_recs) {
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);

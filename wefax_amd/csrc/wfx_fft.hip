@@ -495,7 +495,204 @@ static int bs_convolve(wfx_ctx *ctx, cplx *A, const wfx_bs_plan *pl)
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Analytic signal as ONE circular convolution (default exact mode).
+//
+// scipy.signal.hilbert is ifft(fft(x) * h): a circular convolution of x with the
+// kernel ifft(h) = delta + i*kh, whose imaginary part has a closed form,
+//   N even: kh[m] = (2/N) cot(pi m / N) for odd m, 0 for even m
+//   N odd : kh[m] = cot(pi m / 2N) / N for odd m, -tan(pi m / 2N) / N for even m != 0
+// (m reduced to (-N/2, N/2]).  The real part of the analytic signal is x itself, so
+// only H = x (*) kh is computed, by zero-padded power-of-two FFTs (no Bluestein
+// chirps, two transforms instead of four).
+//
+// N even: kh vanishes on even lags, so even outputs depend only on odd inputs and
+// vice versa.  Packing z[q] = x[2q+1] + i x[2q] (length N/2) and convolving with the
+// REAL kernel g[r] = kh[2r-1] gives Re = H[2p], Im = H[2p-1]: one complex
+// convolution of HALF the length (M >= N-1 instead of >= 2N-1).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double hilbert_tap(long long m, long long N)
+{
+    long long r = m % N;                    // kernel is N-periodic
+    if (r > N / 2) r -= N;
+    if (r < -(N / 2)) r += N;
+    double s, c;
+    if ((N & 1) == 0) {
+        if ((r & 1) == 0) return 0.0;
+        sincospi((double)r / (double)N, &s, &c);
+        return (2.0 / (double)N) * (c / s);
+    }
+    if (r == 0) return 0.0;
+    sincospi((double)r / (2.0 * (double)N), &s, &c);
+    return ((r & 1) ? (c / s) : -(s / c)) / (double)N;
+}
+
+// G[i] = g_ext[j] / M with j = i (i < L) or i - M (i > M - L); g_ext[j] = kh[2j-1] (packed) or kh[j]
+__global__ void __launch_bounds__(256) hconv_fill(cplx *__restrict__ G, long long N, int packed, long long L, long long M, double inv_m)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < M; i += (long long)gridDim.x * 256ll) {
+        double v = 0.0;
+        if (i < L || M - i < L) {
+            const long long j = i < L ? i : i - M;
+            v = hilbert_tap(packed ? 2 * j - 1 : j, N) * inv_m;
+        }
+        G[i] = make_double2(v, 0.0);
+    }
+}
+
+__global__ void __launch_bounds__(256) hconv_pack(const double *__restrict__ x, cplx *__restrict__ U, long long L, long long M, int packed)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < M; i += (long long)gridDim.x * 256ll) {
+        cplx v = make_double2(0.0, 0.0);
+        if (i < L) v = packed ? make_double2(x[2 * i + 1], x[2 * i]) : make_double2(x[i], 0.0);
+        U[i] = v;
+    }
+}
+
+// |x + i H| (np.abs(hilbert(x)), wefax.py:175)
+__global__ void __launch_bounds__(256) hconv_env(const cplx *__restrict__ V, const double *__restrict__ x, long long N, long long L, int packed,
+                                                double *__restrict__ env_raw)
+{
+    for (long long n = blockIdx.x * 256ll + threadIdx.x; n < N; n += (long long)gridDim.x * 256ll) {
+        double H;
+        if (!packed)
+            H = V[n].x;
+        else if ((n & 1) == 0)
+            H = V[n >> 1].x;
+        else {
+            const long long p = (n + 1) >> 1;
+            H = V[p == L ? 0 : p].y;
+        }
+        env_raw[n] = hypot(x[n], H);
+    }
+}
+
+static int get_hplan(wfx_ctx *ctx, uint64_t n, wfx_bs_plan **out, int *packed_out, uint64_t *L_out)
+{
+    const int packed = (n & 1) == 0 ? 1 : 0;
+    const uint64_t L = packed ? n / 2 : n;
+    *packed_out = packed;
+    *L_out = L;
+    auto it = ctx->hplans.find(n);
+    if (it != ctx->hplans.end()) {
+        *out = &it->second;
+        return 0;
+    }
+    if (n < 1 || n > (1ull << 31)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "transform length %llu out of range", (unsigned long long)n);
+    if (ctx->hplans.size() >= 2) {
+        hipStreamSynchronize(ctx->stream);
+        for (auto &kv : ctx->hplans)
+            if (kv.second.bhat.p) hipFree(kv.second.bhat.p);
+        ctx->hplans.clear();
+    }
+    wfx_bs_plan pl;
+    pl.n = n;
+    int l = ceil_log2_u64(L > 1 ? 2 * L - 1 : 1);
+    pl.log2m = l < 12 ? 12 : l;
+    const uint64_t M = 1ull << pl.log2m;
+    WFX_TRY(wfx_reserve(ctx, pl.bhat, M * sizeof(cplx)));
+    WFX_LAUNCH(ctx, K_BS_CHIRP, hconv_fill, dim3(wfx_stream_grid(M, 256)), dim3(256), (cplx *)pl.bhat.p, (long long)n, packed,
+               (long long)L, (long long)M, 1.0 / (double)M);
+    int rc = fft_forward(ctx, (cplx *)pl.bhat.p, pl.log2m, nullptr);
+    if (rc != 0) {
+        hipFree(pl.bhat.p);
+        return rc;
+    }
+    auto ins = ctx->hplans.emplace(n, pl);
+    *out = &ins.first->second;
+    return 0;
+}
+
+__device__ __forceinline__ void cswap_d(double &a, double &b)
+{
+    const double lo = fmin(a, b), hi = fmax(a, b);
+    a = lo;
+    b = hi;
+}
+
+// |x + i H| followed by the 5-tap median of wefax.py:175 (zeros beyond both ends), fused:
+// a tile of 1024 envelope values + 2 halo values per side is formed in LDS.
+__global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__ V, const double *__restrict__ x, long long N, long long L, int packed,
+                                                       double *__restrict__ env)
+{
+    __shared__ double tile[1024 + 4];
+    const int t = threadIdx.x;
+    for (long long base = (long long)blockIdx.x * 1024; base < N; base += (long long)gridDim.x * 1024) {
+        __syncthreads();
+        for (int i = t; i < 1024 + 4; i += 256) {
+            const long long n = base - 2 + i;
+            double e = 0.0;
+            if (n >= 0 && n < N) {
+                double H;
+                if (!packed)
+                    H = V[n].x;
+                else if ((n & 1) == 0)
+                    H = V[n >> 1].x;
+                else {
+                    const long long p = (n + 1) >> 1;
+                    H = V[p == L ? 0 : p].y;
+                }
+                e = hypot(x[n], H);
+            }
+            tile[i] = e;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = t + 256 * u;
+            if (base + j < N) {
+                double a = tile[j], b = tile[j + 1], c = tile[j + 2], d = tile[j + 3], e = tile[j + 4];
+                cswap_d(a, b);
+                cswap_d(d, e);
+                cswap_d(a, d);
+                cswap_d(b, e);
+                cswap_d(b, c);
+                cswap_d(c, d);
+                cswap_d(b, c);
+                env[base + j] = c;
+            }
+        }
+    }
+}
+
+static int hilbert_conv(wfx_ctx *ctx, const double *x, uint64_t n, cplx **W_out, int *packed_out, uint64_t *L_out)
+{
+    wfx_bs_plan *pl = nullptr;
+    WFX_TRY(get_hplan(ctx, n, &pl, packed_out, L_out));
+    const uint64_t M = 1ull << pl->log2m;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work, M * sizeof(cplx)));
+    cplx *W = (cplx *)ctx->b_work.p;
+    WFX_LAUNCH(ctx, K_BS_CHIRP, hconv_pack, dim3(wfx_stream_grid(M, 256)), dim3(256), x, W, (long long)*L_out, (long long)M, *packed_out);
+    WFX_TRY(bs_convolve(ctx, W, pl));
+    *W_out = W;
+    return 0;
+}
+
 int wfx_dev_hilbert_env_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw)
+{
+    cplx *W = nullptr;
+    int packed = 0;
+    uint64_t L = 0;
+    WFX_TRY(hilbert_conv(ctx, x, n, &W, &packed, &L));
+    WFX_LAUNCH(ctx, K_ENV_MEDIAN, hconv_env, dim3(wfx_stream_grid(n, 256)), dim3(256), (const cplx *)W, x, (long long)n, (long long)L, packed, env_raw);
+    return 0;
+}
+
+// envelope and median in one kernel (the decode path)
+int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env)
+{
+    cplx *W = nullptr;
+    int packed = 0;
+    uint64_t L = 0;
+    WFX_TRY(hilbert_conv(ctx, x, n, &W, &packed, &L));
+    WFX_LAUNCH(ctx, K_ENV_MEDIAN, hconv_env_median, dim3(wfx_stream_grid(n, 1024)), dim3(256), (const cplx *)W, x, (long long)n, (long long)L,
+               packed, env);
+    return 0;
+}
+
+// The same operator through two Bluestein DFTs (fft -> h -> ifft literally); kept as
+// an independent cross-check of the convolution form above (WFX_HILBERT_BLUESTEIN).
+int wfx_dev_hilbert_env_bluestein(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw)
 {
     wfx_bs_plan *pl = nullptr;
     WFX_TRY(get_plan(ctx, n, &pl));

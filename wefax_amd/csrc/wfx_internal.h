@@ -75,7 +75,8 @@ struct wfx_ctx {
     wfx_devbuf b_in, b_x, b_audio, b_work, b_work2, b_envraw, b_env, b_dig, b_corr,
         b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps;
     bool w256_ready = false;
-    std::map<uint64_t, wfx_bs_plan> plans;
+    std::map<uint64_t, wfx_bs_plan> plans;    // Bluestein chirp filters (resampler, cross-check mode)
+    std::map<uint64_t, wfx_bs_plan> hplans;   // Hilbert convolution kernels
 
     // decode state
     wfx_decode_params dp{};
@@ -143,6 +144,8 @@ static inline unsigned wfx_stream_grid(uint64_t n, unsigned per_block)
 // wfx_fft.hip
 int wfx_dev_fft_plan_radices(int log2m, int *ra_bits, int max_passes);   // host only
 int wfx_dev_hilbert_env_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw);
+int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env);
+int wfx_dev_hilbert_env_bluestein(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw);
 int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out);
 
 // wfx_stages.hip
@@ -155,6 +158,8 @@ int wfx_dev_select(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t r
                    wfx_dev_scalars *d_scal);
 int wfx_dev_percentile_lerp(wfx_ctx *ctx, double gamma_lo, double gamma_hi,
                             wfx_dev_scalars *d_scal);
+int wfx_dev_percentiles(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4],
+                        double gamma_lo, double gamma_hi, wfx_dev_scalars *d_scal);
 int wfx_dev_quantise(wfx_ctx *ctx, const double *env, uint64_t n, const wfx_dev_scalars *d_scal,
                      uint8_t *out, wfx_dev_scalars *d_scal_out);
 int wfx_dev_sync_corr(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int32_t *corr);

@@ -39,14 +39,16 @@ int wfx_dev_i16_to_f64(wfx_ctx *ctx, const int16_t *in, uint64_t n, double *out)
 //
 // Interior: forward-backward filtering with a biquad whose poles have radius
 // 0.21 equals convolution with g = autocorrelation of the impulse response; |g[k]|
-// falls below 1e-22 for |k| > 32, so a 65-tap symmetric FIR reproduces it to double
-// rounding.  The first/last NOTCH_EDGE samples depend on filtfilt's odd extension
+// falls below 1e-16 of g[0] for |k| > 24, so a 49-tap symmetric FIR reproduces it to
+// double rounding.  Each thread produces 4 consecutive outputs from a 52-sample
+// register window (13 LDS reads per output instead of 49); the LDS tile is padded by
+// one double per four so that the stride-4 accesses of a wave are conflict-free.  The first/last NOTCH_EDGE samples depend on filtfilt's odd extension
 // (9 samples) and lfilter_zi initial state, and are computed with the actual
 // recurrence by two single threads of one extra workgroup.
 // ===========================================================================
-#define NOTCH_K 32
+#define NOTCH_K 24
 #define NOTCH_EDGE 64
-#define NOTCH_SETTLE 64
+#define NOTCH_SETTLE 63
 #define NOTCH_PAD 9
 #define NOTCH_SMALL (2 * (NOTCH_EDGE + NOTCH_SETTLE))
 
@@ -92,7 +94,8 @@ __device__ __forceinline__ double biquad_step(const notch_coef &c, double xi, do
 template <typename TIN>
 __global__ void __launch_bounds__(256) notch_kernel(const TIN *__restrict__ x, uint64_t n, notch_coef c, double *__restrict__ y, unsigned interior_blocks)
 {
-    __shared__ double tile[1024 + 2 * NOTCH_K];
+    constexpr int TLEN = 1024 + 2 * NOTCH_K;
+    __shared__ double tile[TLEN + TLEN / 4 + 4];
     __shared__ double ebuf[2][NOTCH_SMALL + 2 * NOTCH_PAD + 8];
     const int t = threadIdx.x;
     if (blockIdx.x < interior_blocks) {
@@ -100,22 +103,36 @@ __global__ void __launch_bounds__(256) notch_kernel(const TIN *__restrict__ x, u
         const uint64_t lo = NOTCH_EDGE, hi = n - NOTCH_EDGE;
         for (uint64_t base = lo + (uint64_t)blockIdx.x * 1024ull; base < hi; base += (uint64_t)interior_blocks * 1024ull) {
             __syncthreads();
-            for (int i = t; i < 1024 + 2 * NOTCH_K; i += 256) {
+            for (int i = t; i < TLEN; i += 256) {
                 const uint64_t src = base - NOTCH_K + i;       // >= EDGE - K >= 0
-                tile[i] = src < n ? (double)x[src] : 0.0;
+                tile[i + (i >> 2)] = src < n ? (double)x[src] : 0.0;
             }
             __syncthreads();
+            double win[2 * NOTCH_K + 4];
+#pragma unroll
+            for (int i = 0; i < 2 * NOTCH_K + 4; ++i) win[i] = tile[(4 * t + i) + ((4 * t + i) >> 2)];
+            double acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int j = t + 256 * u;
-                const uint64_t o = base + j;
-                if (o < hi) {
-                    double acc = c.g[0] * tile[j + NOTCH_K];
+                acc[u] = c.g[0] * win[u + NOTCH_K];
 #pragma unroll
-                    for (int k = 1; k <= NOTCH_K; ++k)
-                        acc = fma(c.g[k], tile[j + NOTCH_K - k] + tile[j + NOTCH_K + k], acc);
-                    y[o] = acc;
-                }
+                for (int k = 1; k <= NOTCH_K; ++k) acc[u] = fma(c.g[k], win[u + NOTCH_K - k] + win[u + NOTCH_K + k], acc[u]);
+            }
+            // a lane's 4 outputs are contiguous: exchange through LDS so that each store
+            // instruction writes 64 x 16 contiguous bytes instead of 64 quarter lines
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tile[5 * t + u] = acc[u];
+            __syncthreads();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int j = half * 512 + 2 * t;                 // even -> same padded group of four
+                const uint64_t o = base + j;                      // base is even: 16-byte aligned
+                const double v0 = tile[j + (j >> 2)], v1 = tile[j + 1 + ((j + 1) >> 2)];
+                if (o + 1 < hi)
+                    *(double2 *)(y + o) = make_double2(v0, v1);
+                else if (o < hi)
+                    y[o] = v0;
             }
         }
         return;
@@ -138,33 +155,48 @@ __global__ void __launch_bounds__(256) notch_kernel(const TIN *__restrict__ x, u
         }
         return;
     }
-    const int L = NOTCH_EDGE + NOTCH_SETTLE;
-    if (t == 0) {
-        // left edge: exact forward pass from the true initial state, backward pass started
-        // SETTLE samples to the right with a zero state (its error decays as 0.21^k)
-        double *e = ebuf[0];
-        const int len = NOTCH_PAD + L;
-        for (int i = 0; i < NOTCH_PAD; ++i) e[i] = notch_ext_left<TIN>(x, NOTCH_PAD - i);
-        for (int i = 0; i < L; ++i) e[NOTCH_PAD + i] = (double)x[i];
-        double z0 = c.zi[0] * e[0], z1 = c.zi[1] * e[0];
-        for (int i = 0; i < len; ++i) e[i] = biquad_step(c, e[i], z0, z1);
-        z0 = 0.0;
-        z1 = 0.0;
-        for (int i = len - 1; i >= 0; --i) e[i] = biquad_step(c, e[i], z0, z1);
-        for (int i = 0; i < NOTCH_EDGE; ++i) y[i] = e[NOTCH_PAD + i];
-    } else if (t == 64) {
-        // right edge: forward pass started SETTLE samples early with a zero state, exact backward pass
-        double *e = ebuf[1];
-        const int len = L + NOTCH_PAD;
-        for (int i = 0; i < L; ++i) e[i] = (double)x[n - L + i];
-        for (int i = 0; i < NOTCH_PAD; ++i) e[L + i] = notch_ext_right<TIN>(x, n, i + 1);
-        double z0 = 0.0, z1 = 0.0;
-        for (int i = 0; i < len; ++i) e[i] = biquad_step(c, e[i], z0, z1);
-        z0 = c.zi[0] * e[len - 1];
-        z1 = c.zi[1] * e[len - 1];
-        for (int i = len - 1; i >= 0; --i) e[i] = biquad_step(c, e[i], z0, z1);
-        for (int i = 0; i < NOTCH_EDGE; ++i) y[n - NOTCH_EDGE + i] = e[L - NOTCH_EDGE + i];
+    // Both edges: the extended samples are staged in LDS by the whole workgroup, then one
+    // thread per edge runs the two recurrences eight samples at a time (loads and stores
+    // are kept off the dependent chain), then the workgroup writes the results.
+    constexpr int L = NOTCH_EDGE + NOTCH_SETTLE;        // 127
+    constexpr int LEN = NOTCH_PAD + L;                  // 136, a multiple of 8
+    static_assert(LEN % 8 == 0, "edge length must be a multiple of 8");
+    for (int i = t; i < LEN; i += 256) {
+        ebuf[0][i] = i < NOTCH_PAD ? notch_ext_left<TIN>(x, NOTCH_PAD - i) : (double)x[i - NOTCH_PAD];
+        ebuf[1][i] = i < L ? (double)x[n - L + i] : notch_ext_right<TIN>(x, n, i - L + 1);
     }
+    __syncthreads();
+    if (t == 0 || t == 64) {
+        double *e = ebuf[t == 0 ? 0 : 1];
+        // left: exact forward start, backward started SETTLE samples to the right with a zero state
+        // right: forward started SETTLE samples early with a zero state, exact backward start
+        double z0 = t == 0 ? c.zi[0] * e[0] : 0.0, z1 = t == 0 ? c.zi[1] * e[0] : 0.0;
+        for (int i0 = 0; i0 < LEN; i0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = e[i0 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = biquad_step(c, v[k], z0, z1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[i0 + k] = v[k];
+        }
+        z0 = t == 0 ? 0.0 : c.zi[0] * e[LEN - 1];
+        z1 = t == 0 ? 0.0 : c.zi[1] * e[LEN - 1];
+        for (int i0 = LEN - 8; i0 >= 0; i0 -= 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = e[i0 + k];
+#pragma unroll
+            for (int k = 7; k >= 0; --k) v[k] = biquad_step(c, v[k], z0, z1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[i0 + k] = v[k];
+        }
+    }
+    __syncthreads();
+    if (t < NOTCH_EDGE)
+        y[t] = ebuf[0][NOTCH_PAD + t];
+    else if (t < 2 * NOTCH_EDGE)
+        y[n - NOTCH_EDGE + (t - NOTCH_EDGE)] = ebuf[1][L - NOTCH_EDGE + (t - NOTCH_EDGE)];
 }
 
 int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out)
@@ -284,17 +316,8 @@ __device__ __forceinline__ double key_f64(unsigned long long k)
 __host__ __device__ static inline int sel_shift(int level) { return level < 5 ? 53 - 11 * level : 0; }
 __host__ __device__ static inline int sel_width(int level) { return level < 5 ? 11 : 9; }
 
-__global__ void __launch_bounds__(256) select_init(wfx_dev_scalars *s, uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3)
-{
-    if (threadIdx.x == 0) {
-        s->sel_prefix[0] = s->sel_prefix[1] = s->sel_prefix[2] = s->sel_prefix[3] = 0;
-        s->sel_rank[0] = r0;
-        s->sel_rank[1] = r1;
-        s->sel_rank[2] = r2;
-        s->sel_rank[3] = r3;
-    }
-}
-
+// One level: histogram of the level's digit over the elements whose higher bits equal
+// a query's prefix.  Queries that share a prefix share a histogram ("owner").
 __global__ void __launch_bounds__(256) select_hist(const double *__restrict__ v, uint64_t n, int level, const wfx_dev_scalars *__restrict__ s, unsigned *__restrict__ ghist)
 {
     __shared__ unsigned h[4][SEL_BINS];
@@ -304,10 +327,10 @@ __global__ void __launch_bounds__(256) select_hist(const double *__restrict__ v,
     for (int i = t; i < 4 * SEL_BINS; i += 256) (&h[0][0])[i] = 0;
     if (t == 0) {
         for (int q = 0; q < 4; ++q) {
-            pfx[q] = s->sel_prefix[q];
+            pfx[q] = level == 0 ? 0ull : s->sel_prefix[q];
             int o = q;
             for (int p = 0; p < q; ++p)
-                if (s->sel_prefix[p] == s->sel_prefix[q]) {
+                if (level == 0 || s->sel_prefix[p] == s->sel_prefix[q]) {
                     o = p;
                     break;
                 }
@@ -325,12 +348,7 @@ __global__ void __launch_bounds__(256) select_hist(const double *__restrict__ v,
         active[q] = owner[q] == q;
         mypfx[q] = pfx[q];
     }
-    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
-    const uint64_t nround = (n + stride - 1) / stride;
-    for (uint64_t it = 0; it < nround; ++it) {
-        const uint64_t i = it * stride + blockIdx.x * 256ull + t;
-        const bool valid = i < n;
-        const unsigned long long key = valid ? f64_key(v[i]) : 0ull;
+    auto count = [&](unsigned long long key, bool valid) {
         const unsigned digit = (unsigned)(key >> shift) & dmask;
         const unsigned long long hi = level == 0 ? 0ull : (key >> (shift + width));
 #pragma unroll
@@ -348,83 +366,35 @@ __global__ void __launch_bounds__(256) select_hist(const double *__restrict__ v,
                 atomicAdd(&h[q][digit], 1u);
             }
         }
+    };
+    // four values per thread and iteration (two 16-byte loads in flight)
+    const uint64_t quads = (n + 3) / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    const uint64_t nround = (quads + stride - 1) / stride;
+    for (uint64_t it = 0; it < nround; ++it) {
+        const uint64_t i0 = (it * stride + blockIdx.x * 256ull + t) * 4;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (i0 + 4 <= n) {
+            const double2 lo = *(const double2 *)(v + i0), hi2 = *(const double2 *)(v + i0 + 2);
+            a0 = lo.x;
+            a1 = lo.y;
+            a2 = hi2.x;
+            a3 = hi2.y;
+        } else {
+            if (i0 < n) a0 = v[i0];
+            if (i0 + 1 < n) a1 = v[i0 + 1];
+            if (i0 + 2 < n) a2 = v[i0 + 2];
+        }
+        count(f64_key(a0), i0 < n);
+        count(f64_key(a1), i0 + 1 < n);
+        count(f64_key(a2), i0 + 2 < n);
+        count(f64_key(a3), i0 + 3 < n);
     }
     __syncthreads();
     for (int i = t; i < 4 * SEL_BINS; i += 256) {
         const unsigned c = (&h[0][0])[i];
         if (c) atomicAdd(&ghist[i], c);
     }
-}
-
-__global__ void __launch_bounds__(256) select_scan(int level, wfx_dev_scalars *s, const unsigned *__restrict__ ghist)
-{
-    __shared__ unsigned long long part[256];
-    __shared__ unsigned long long newp[4], newr[4];
-    const int t = threadIdx.x;
-    const int width = sel_width(level);
-    const int bins = 1 << width;
-    for (int q = 0; q < 4; ++q) {
-        int o = q;
-        for (int p = 0; p < q; ++p)
-            if (s->sel_prefix[p] == s->sel_prefix[q]) {
-                o = p;
-                break;
-            }
-        const unsigned *hq = ghist + o * SEL_BINS;
-        const unsigned long long rank = s->sel_rank[q];
-        // each thread owns 8 consecutive bins
-        unsigned long long loc[8], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int b = t * 8 + k;
-            loc[k] = b < bins ? hq[b] : 0;
-            sum += loc[k];
-        }
-        part[t] = sum;
-        __syncthreads();
-        if (t == 0) {
-            unsigned long long run = 0;
-            for (int i = 0; i < 256; ++i) {
-                const unsigned long long v = part[i];
-                part[i] = run;
-                run += v;
-            }
-        }
-        __syncthreads();
-        unsigned long long cum = part[t];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (rank >= cum && rank < cum + loc[k]) {
-                newp[q] = (level == 0 ? 0ull : (s->sel_prefix[q] << width)) | (unsigned long long)(t * 8 + k);
-                newr[q] = rank - cum;
-            }
-            cum += loc[k];
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        for (int q = 0; q < 4; ++q) {
-            s->sel_prefix[q] = newp[q];
-            s->sel_rank[q] = newr[q];
-            if (level == SEL_LEVELS - 1) s->sel_value[q] = key_f64(newp[q]);
-        }
-    }
-}
-
-int wfx_dev_select(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], wfx_dev_scalars *d_scal)
-{
-    for (int q = 0; q < 4; ++q)
-        if (ranks[q] >= n) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "order statistic rank %llu >= n", (unsigned long long)ranks[q]);
-    WFX_TRY(wfx_reserve(ctx, ctx->b_hist, 4 * SEL_BINS * sizeof(unsigned)));
-    unsigned *gh = (unsigned *)ctx->b_hist.p;
-    WFX_LAUNCH(ctx, K_SELECT_SCAN, select_init, dim3(1), dim3(256), d_scal, ranks[0], ranks[1], ranks[2], ranks[3]);
-    for (int level = 0; level < SEL_LEVELS; ++level) {
-        WFX_HIP(ctx, hipMemsetAsync(gh, 0, 4 * SEL_BINS * sizeof(unsigned), ctx->stream));
-        WFX_LAUNCH(ctx, K_SELECT_HIST, select_hist, dim3(wfx_stream_grid(n, 2048)), dim3(256), env, n, level,
-                   (const wfx_dev_scalars *)d_scal, gh);
-        WFX_LAUNCH(ctx, K_SELECT_SCAN, select_scan, dim3(1), dim3(256), level, d_scal, (const unsigned *)gh);
-    }
-    return 0;
 }
 
 // numpy's _lerp (numpy/lib/_function_base_impl.py): a + (b-a)*t, or b - (b-a)*(1-t) when t >= 0.5
@@ -434,6 +404,109 @@ __device__ __forceinline__ double np_lerp(double a, double b, double t)
     double r = a + diff * t;
     if (t >= 0.5) r = b - diff * (1 - t);
     return r;
+}
+
+// Pick each query's digit from the level's histogram: one wave per query, 32 bins per
+// lane, shuffle scan.  Also clears the other histogram buffer for the next level and,
+// after the last level, applies the percentile interpolation.
+__global__ void __launch_bounds__(256) select_scan(int level, wfx_dev_scalars *s, const unsigned *__restrict__ ghist, unsigned *__restrict__ gnext,
+                                                  uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3, int do_lerp, double gamma_lo, double gamma_hi)
+{
+    __shared__ double vals[4];
+    const int t = threadIdx.x;
+    const int q = t >> 6, lane = t & 63;
+    const int width = sel_width(level);
+    const int bins = 1 << width;
+    int o = q;
+    for (int p = 0; p < q; ++p)
+        if (level == 0 || s->sel_prefix[p] == s->sel_prefix[q]) {
+            o = p;
+            break;
+        }
+    const unsigned long long rank = level == 0 ? (q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3) : s->sel_rank[q];
+    const unsigned long long prefix = level == 0 ? 0ull : s->sel_prefix[q];
+    const unsigned *hq = ghist + o * SEL_BINS + lane * 32;
+    unsigned loc[32];
+    unsigned sum = 0;                          // counts are < 2^32 (n <= 2^31)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint4 u = ((const uint4 *)hq)[k];
+        loc[4 * k] = u.x;
+        loc[4 * k + 1] = u.y;
+        loc[4 * k + 2] = u.z;
+        loc[4 * k + 3] = u.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if (lane * 32 + k >= bins) loc[k] = 0;
+        sum += loc[k];
+    }
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o2 = __shfl_up(incl, off);
+        if (lane >= off) incl += o2;
+    }
+    unsigned long long cum = incl - sum;      // exclusive prefix of this lane's first bin
+    __syncthreads();                           // every wave has read s->sel_* before anyone rewrites it
+    unsigned long long newp = 0, newr = 0;
+    bool mine = false;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if (!mine && rank >= cum && rank < cum + loc[k]) {
+            newp = (prefix << width) | (unsigned long long)(lane * 32 + k);
+            newr = rank - cum;
+            mine = true;
+        }
+        cum += loc[k];
+    }
+    if (mine) {
+        s->sel_prefix[q] = newp;
+        s->sel_rank[q] = newr;
+        if (level == SEL_LEVELS - 1) {
+            s->sel_value[q] = key_f64(newp);
+            vals[q] = key_f64(newp);
+        }
+    }
+    for (int i = t; i < 4 * SEL_BINS; i += 256) gnext[i] = 0;
+    if (do_lerp && level == SEL_LEVELS - 1) {
+        __syncthreads();
+        if (t == 0) {
+            s->low = np_lerp(vals[0], vals[1], gamma_lo);
+            s->high = np_lerp(vals[2], vals[3], gamma_hi);
+            s->nan_count = 0;
+        }
+    }
+}
+
+static int select_run(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], wfx_dev_scalars *d_scal, int do_lerp,
+                      double gamma_lo, double gamma_hi)
+{
+    for (int q = 0; q < 4; ++q)
+        if (ranks[q] >= n) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "order statistic rank %llu >= n", (unsigned long long)ranks[q]);
+    const size_t hbytes = 4 * SEL_BINS * sizeof(unsigned);
+    WFX_TRY(wfx_reserve(ctx, ctx->b_hist, 2 * hbytes));
+    unsigned *gh[2] = {(unsigned *)ctx->b_hist.p, (unsigned *)ctx->b_hist.p + 4 * SEL_BINS};
+    WFX_HIP(ctx, hipMemsetAsync(gh[0], 0, hbytes, ctx->stream));
+    for (int level = 0; level < SEL_LEVELS; ++level) {
+        unsigned *cur = gh[level & 1], *nxt = gh[(level + 1) & 1];
+        WFX_LAUNCH(ctx, K_SELECT_HIST, select_hist, dim3(wfx_stream_grid(n, 4096)), dim3(256), env, n, level,
+                   (const wfx_dev_scalars *)d_scal, cur);
+        WFX_LAUNCH(ctx, K_SELECT_SCAN, select_scan, dim3(1), dim3(256), level, d_scal, (const unsigned *)cur, nxt, ranks[0], ranks[1],
+                   ranks[2], ranks[3], do_lerp, gamma_lo, gamma_hi);
+    }
+    return 0;
+}
+
+int wfx_dev_select(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], wfx_dev_scalars *d_scal)
+{
+    return select_run(ctx, env, n, ranks, d_scal, 0, 0.0, 0.0);
+}
+
+int wfx_dev_percentiles(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], double gamma_lo, double gamma_hi,
+                        wfx_dev_scalars *d_scal)
+{
+    return select_run(ctx, env, n, ranks, d_scal, 1, gamma_lo, gamma_hi);
 }
 
 __global__ void percentile_lerp_kernel(wfx_dev_scalars *s, double gamma_lo, double gamma_hi)
@@ -526,7 +599,42 @@ __device__ __forceinline__ void corr_from_lds(const uint8_t *ds, int cnt, int n1
 }
 
 #define CORR_CH 4096
-__global__ void __launch_bounds__(256) sync_corr_kernel(const uint8_t *__restrict__ d, uint64_t n, int n1, int n0, int *__restrict__ corr)
+// wave64 reductions with DPP (no LDS crossbar round trips): after the four row steps every
+// lane of a 16-lane row holds the row result; row_bcast15 / row_bcast31 fold the rows
+// into lane 63.
+#define WFX_DPP(v, ctrl, rowmask) __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rowmask), 0xf, false)
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = max(v, WFX_DPP(v, 0xB1, 0xf));    // quad_perm [1,0,3,2]
+    v = max(v, WFX_DPP(v, 0x4E, 0xf));    // quad_perm [2,3,0,1]
+    v = max(v, WFX_DPP(v, 0x141, 0xf));   // row_half_mirror
+    v = max(v, WFX_DPP(v, 0x140, 0xf));   // row_mirror
+    v = max(v, WFX_DPP(v, 0x142, 0xa));   // row_bcast15 -> rows 1, 3
+    v = max(v, WFX_DPP(v, 0x143, 0xc));   // row_bcast31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = min(v, WFX_DPP(v, 0xB1, 0xf));
+    v = min(v, WFX_DPP(v, 0x4E, 0xf));
+    v = min(v, WFX_DPP(v, 0x141, 0xf));
+    v = min(v, WFX_DPP(v, 0x140, 0xf));
+    v = min(v, WFX_DPP(v, 0x142, 0xa));
+    v = min(v, WFX_DPP(v, 0x143, 0xc));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// first arg-max over the wave: (max correlation, smallest index holding it)
+__device__ __forceinline__ void wave_first_argmax(int c, int idx, int &best_c, int &best_idx)
+{
+    best_c = wave_max_i32(c);
+    best_idx = wave_min_i32(c == best_c ? idx : 0x7fffffff);
+}
+
+// corr[i] for every position, plus (optionally) per block of 64 positions the maximum
+// and the offset of its first occurrence -- what the sequential picker consumes.
+__global__ void __launch_bounds__(256) sync_corr_kernel(const uint8_t *__restrict__ d, uint64_t n, int n1, int n0, int *__restrict__ corr,
+                                                       int *__restrict__ bmax, int *__restrict__ boff)
 {
     __shared__ uint8_t ds[CORR_CH + 512];
     __shared__ int cs[CORR_CH];
@@ -541,22 +649,39 @@ __global__ void __launch_bounds__(256) sync_corr_kernel(const uint8_t *__restric
         corr_from_lds(ds, cnt, n1, n0, cs, t, 256);
         __syncthreads();
         for (int i = t; i < cnt; i += 256) corr[p0 + i] = cs[i];
+        if (bmax) {
+            const int lane = t & 63, wave = t >> 6;
+            for (int b = wave; b * 64 < cnt; b += 4) {
+                const int j = b * 64 + lane;
+                int bc, bi;
+                wave_first_argmax(j < cnt ? cs[j] : (int)0x80000000, lane, bc, bi);
+                if (lane == 0) {
+                    bmax[p0 / 64 + b] = bc;
+                    boff[p0 / 64 + b] = bi;
+                }
+            }
+        }
     }
 }
 
 int wfx_dev_sync_corr(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int32_t *corr)
 {
     if (2 * n1 + n0 > 500) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sync pattern too long");
-    WFX_LAUNCH(ctx, K_SYNC_CORR, sync_corr_kernel, dim3(wfx_stream_grid(n, CORR_CH)), dim3(256), d, n, n1, n0, (int *)corr);
+    WFX_LAUNCH(ctx, K_SYNC_CORR, sync_corr_kernel, dim3(wfx_stream_grid(n, CORR_CH)), dim3(256), d, n, n1, n0, (int *)corr, (int *)nullptr,
+               (int *)nullptr);
     return 0;
 }
 
 // Sequential peak picker (wefax.py:226-261) + grouping (wefax.py:263-294) in ONE
-// workgroup: 1024 threads stage a chunk of the byte stream and its correlation in
-// LDS, wave 0 then replays the reference's scan over the chunk with wave-wide
-// first-arg-max reductions (the scan only ever needs "first maximum of a range").
+// workgroup.  The correlation and its per-64-block first-arg-max summaries are
+// precomputed by sync_corr_kernel on the whole chip; here 1024 threads stream them
+// through LDS in chunks (the next chunk's loads stay in flight in registers across the
+// barriers, which wait for LDS only) and wave 0 replays the reference's scan: it only
+// ever needs "first maximum of a range", answered from the block summaries plus the
+// two partial blocks at the range ends, reduced across the wave with DPP.
 #define PICK_CH 16384
 #define PICK_THREADS 1024
+#define PICK_PER_THREAD (PICK_CH / PICK_THREADS)
 
 __device__ __forceinline__ bool dev_ok(double frame_samples, long long x)
 {
@@ -564,38 +689,63 @@ __device__ __forceinline__ bool dev_ok(double frame_samples, long long x)
     return (frame_samples + 500 > (double)x) && ((double)x > frame_samples - 500);
 }
 
-__global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const uint8_t *__restrict__ d, uint64_t n, int n1, int n0, long long mind,
-                                                                 double frame_samples, int width, wfx_dev_scalars *__restrict__ s)
+// workgroup barrier that orders LDS traffic only: global loads already issued (the
+// prefetch of the next chunk) stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__restrict__ corr, const int *__restrict__ bmax, const int *__restrict__ boff,
+                                                                 uint64_t n, int n1, int n0, long long mind, double frame_samples, int width,
+                                                                 wfx_dev_scalars *__restrict__ s)
 {
-    __shared__ uint8_t ds[PICK_CH + 512];
     __shared__ int cs[PICK_CH];
-    __shared__ int done_flag;
+    __shared__ int smc[PICK_CH / 64], smi[PICK_CH / 64];      // per 64-block: max correlation, first index of it
+    __shared__ long long pk_s[WFX_MAX_PEAKS + 1], first_s[WFX_MAX_PEAKS + 1];
+    __shared__ int done_flag, np_s, hit_s;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int L = 2 * n1 + n0;
     const uint64_t ncorr = n > (uint64_t)L ? n - L : 0;
+    const uint64_t nblk = (ncorr + 63) / 64;
+    const int CMIN = (int)0x80000000;
     // picker state (meaningful in wave 0, kept uniform across its lanes)
-    long long pos = 0, val = 0;
-    int np = 1, hit = 0;
+    long long pos = 0;
+    int val = 0, np = 1, hit = 0;
     if (t == 0) {
         done_flag = 0;
-        s->first_pos[0] = 0;
+        first_s[0] = 0;
     }
-    __syncthreads();
+    int pre[PICK_PER_THREAD], pre_c = CMIN, pre_o = 0;
+    auto prefetch = [&](uint64_t p0) {
+#pragma unroll
+        for (int k = 0; k < PICK_PER_THREAD; ++k) {
+            const uint64_t g = p0 + (uint64_t)k * PICK_THREADS + t;
+            pre[k] = g < ncorr ? corr[g] : 0;
+        }
+        if (t < PICK_CH / 64) {
+            const uint64_t bg = p0 / 64 + t;
+            pre_c = bg < nblk ? bmax[bg] : CMIN;
+            pre_o = bg < nblk ? boff[bg] : 0;
+        }
+    };
+    if (ncorr) prefetch(0);
     for (uint64_t p0 = 0; p0 < ncorr; p0 += PICK_CH) {
         const int cnt = (int)min((uint64_t)PICK_CH, ncorr - p0);
-        for (int i = t; i < cnt + L + 1; i += PICK_THREADS) ds[i] = (p0 + i < n) ? d[p0 + i] : 0;
-        __syncthreads();
-        corr_from_lds(ds, cnt, n1, n0, cs, t, PICK_THREADS);
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PICK_PER_THREAD; ++k) cs[k * PICK_THREADS + t] = pre[k];
+        if (t < PICK_CH / 64) {
+            smc[t] = pre_c;
+            smi[t] = t * 64 + pre_o;
+        }
+        lds_barrier();
+        if (p0 + PICK_CH < ncorr) prefetch(p0 + PICK_CH);      // in flight while this chunk is scanned
         if (t < 64) {
             long long i = (long long)p0;
             const long long ce = (long long)p0 + cnt;
             while (i < ce) {
                 if (i - pos > mind) {
                     if (lane == 0) {
-                        s->peak_pos[np - 1] = pos;
-                        s->first_pos[np] = i;
+                        pk_s[np - 1] = pos;
+                        first_s[np] = i;
                     }
                     pos = i;
                     val = cs[i - (long long)p0];
@@ -608,36 +758,63 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const uint8_t *
                 } else {
                     long long lim = pos + mind;
                     if (lim > ce - 1) lim = ce - 1;
-                    // first arg-max over [i, lim]
-                    long long best = (long long)0x8000000000000000ll;
-                    for (long long j = i + lane; j <= lim; j += 64) {
-                        const int lj = (int)(j - (long long)p0);
-                        const long long key = ((long long)cs[lj] << 32) + (long long)(0x7fffffff - lj);
-                        best = key > best ? key : best;
+                    const int li = (int)(i - (long long)p0), ll = (int)(lim - (long long)p0);
+                    const int b_lo = li >> 6, b_hi = ll >> 6;
+                    int c = CMIN, ci = 0x7fffffff;
+                    {
+                        const int j = (b_lo << 6) + lane;                   // head (or the only) block
+                        if (j >= li && j <= ll) {
+                            c = cs[j];
+                            ci = j;
+                        }
                     }
-                    for (int off = 32; off > 0; off >>= 1) {
-                        const long long o = __shfl_xor(best, off);
-                        best = o > best ? o : best;
+                    if (b_hi > b_lo) {
+                        for (int b = b_lo + 1 + lane; b < b_hi; b += 64) {  // whole blocks in between (ascending index)
+                            const int c2 = smc[b];
+                            if (c2 > c) {
+                                c = c2;
+                                ci = smi[b];
+                            }
+                        }
+                        const int j = (b_hi << 6) + lane;                   // tail block (largest indices)
+                        if (j <= ll) {
+                            const int c2 = cs[j];
+                            if (c2 > c) {
+                                c = c2;
+                                ci = j;
+                            }
+                        }
                     }
-                    const long long bc = best >> 32;            // arithmetic shift: the correlation
-                    if (bc > val) {
+                    int bc, bi;
+                    wave_first_argmax(c, ci, bc, bi);
+                    if (bc > val && bi != 0x7fffffff) {
                         val = bc;
-                        pos = (long long)p0 + (0x7fffffff - (int)(best & 0xffffffffll));
+                        pos = (long long)p0 + bi;
                     }
                     i = lim + 1;
                 }
             }
             if (hit && lane == 0) done_flag = 1;
         }
-        __syncthreads();
+        lds_barrier();
         if (done_flag) break;
     }
+    if (t == 0) {
+        pk_s[np - 1] = pos;
+        np_s = np;
+        hit_s = hit;
+    }
+    __syncthreads();
+    np = np_s;
+    for (int i = t; i < np; i += PICK_THREADS) {
+        s->peak_pos[i] = pk_s[i];
+        s->first_pos[i] = first_s[i];
+    }
     if (t != 0) return;
-    s->peak_pos[np - 1] = pos;
     s->npeaks = np;
-    s->hit_limit = hit;
+    s->hit_limit = hit_s;
+    const long long *pk = pk_s;
     // ---- grouping (wefax.py:269-294) -----------------------------------------
-    const long long *pk = s->peak_pos;
     int nclear = 0;
     for (int i = 1; i < np - 1; ++i)
         if (dev_ok(frame_samples, pk[i] - pk[i - 1])) ++nclear;
@@ -673,8 +850,13 @@ int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0
                       int width, wfx_dev_scalars *d_scal)
 {
     if (2 * n1 + n0 > 500 || n1 < 0 || n0 < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sync pattern length out of range");
-    WFX_LAUNCH(ctx, K_SYNC_PICK, sync_pick_kernel, dim3(1), dim3(PICK_THREADS), d, n, n1, n0, (long long)mindistance, frame_samples,
-               width, d_scal);
+    const size_t nblk = (size_t)n / 64 + 2;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_corr, (size_t)n * 4 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_tmp2, nblk * 8));
+    int *bmax = (int *)ctx->b_tmp2.p, *boff = bmax + nblk;
+    WFX_LAUNCH(ctx, K_SYNC_CORR, sync_corr_kernel, dim3(wfx_stream_grid(n, CORR_CH)), dim3(256), d, n, n1, n0, (int *)ctx->b_corr.p, bmax, boff);
+    WFX_LAUNCH(ctx, K_SYNC_PICK, sync_pick_kernel, dim3(1), dim3(PICK_THREADS), (const int *)ctx->b_corr.p, (const int *)bmax,
+               (const int *)boff, n, n1, n0, (long long)mindistance, frame_samples, width, d_scal);
     return 0;
 }
 
@@ -719,44 +901,83 @@ __device__ __forceinline__ void pil_row_coeffs(int yy, int h_in, int h_out, int 
     }
 }
 
+// One workgroup per SOURCE row y: it produces the four output rows 4y..4y+3, which
+// draw on source rows y-2..y+2, so every source byte is fetched once per workgroup
+// (aligned dword loads + v_alignbyte for the arbitrary byte offset start + y*w) and
+// every thread turns 8 source columns into 4 x 8 output pixels (dword stores).
+__device__ __forceinline__ void load8_any(const uint8_t *p, unsigned &lo, unsigned &hi)
+{
+    const uintptr_t a = (uintptr_t)p;
+    const unsigned *q = (const unsigned *)(a & ~(uintptr_t)3);
+    const unsigned sh = (unsigned)(a & 3);
+    const unsigned w0 = q[0], w1 = q[1], w2 = q[2];      // the stream buffer is padded by 64 bytes
+    lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+}
+
 __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ d, uint64_t n, int w, const wfx_dev_scalars *__restrict__ s,
                                                    uint8_t *__restrict__ img)
 {
     const int h = s->height;
-    const int yy = blockIdx.x;
-    if (yy >= 4 * h) return;
+    const int y = blockIdx.x;
+    if (y >= h) return;
     const uint64_t start = (uint64_t)s->start_frame;
-    int ymin, cnt, kk[5];
-    pil_row_coeffs(yy, h, 4 * h, ymin, cnt, kk);
-    const uint8_t *src = d + start + (uint64_t)ymin * w;
-    uint8_t *dst = img + (uint64_t)yy * w;
-    const bool aligned = (((uintptr_t)dst) & 3) == 0;
-    for (int x0 = threadIdx.x * 4; x0 < w; x0 += 256 * 4) {
-        int acc[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
-        const int nx = min(4, w - x0);
-        for (int y = 0; y < cnt; ++y) {
-            const uint8_t *row = src + (uint64_t)y * w + x0;
-            const int k = kk[y];
+    // coefficients of the four output rows (row-uniform, computed redundantly per thread)
+    int ymin[4], cnt[4], kk[4][5];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (e < nx) acc[e] += (255 - (int)row[e]) * k;
-        }
-        unsigned px[4];
+    for (int r = 0; r < 4; ++r) pil_row_coeffs(4 * y + r, h, 4 * h, ymin[r], cnt[r], kk[r]);
+    const int ylo = max(y - 2, 0), yhi = min(y + 2, h - 1);      // source rows any of the four can touch
+    for (int x0 = threadIdx.x * 8; x0 < w; x0 += 256 * 8) {
+        const int nx = min(8, w - x0);
+        int acc[4][8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int v = acc[e] >> 22;
-            px[e] = (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[r][e] = 1 << 21;
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+            const int sy = ylo + dy;
+            if (sy > yhi) break;
+            unsigned lo, hi;
+            load8_any(d + start + (uint64_t)sy * w + x0, lo, hi);
+            int px[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                px[e] = 255 - (int)((lo >> (8 * e)) & 0xff);
+                px[4 + e] = 255 - (int)((hi >> (8 * e)) & 0xff);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ki = sy - ymin[r];
+                if (ki >= 0 && ki < cnt[r]) {
+                    const int k = kk[r][ki];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[r][e] += px[e] * k;
+                }
+            }
         }
-        if (nx == 4 && aligned)
-            *(unsigned *)(dst + x0) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-        else
-            for (int e = 0; e < nx; ++e) dst[x0 + e] = (uint8_t)px[e];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uint8_t *dst = img + (uint64_t)(4 * y + r) * w + x0;
+            unsigned o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int v = acc[r][e] >> 22;
+                o[e] = (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+            if (nx == 8 && (((uintptr_t)dst) & 3) == 0) {
+                ((unsigned *)dst)[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+                ((unsigned *)dst)[1] = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+            } else {
+                for (int e = 0; e < nx; ++e) dst[e] = (uint8_t)o[e];
+            }
+        }
     }
 }
 
 int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max, const wfx_dev_scalars *d_scal, uint8_t *img)
 {
     if (h_max <= 0 || w <= 0) return 0;
-    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3(4u * (unsigned)h_max), dim3(256), d, n, w, d_scal, img);
+    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max), dim3(256), d, n, w, d_scal, img);
     return 0;
 }
