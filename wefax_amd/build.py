@@ -41,9 +41,10 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
+    flags = [*FLAGS, *extra_flags]
     jobs = []
     objs = []
     for s in SOURCES:
@@ -51,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
-            jobs.append([cc, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([cc, *flags, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -71,4 +72,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    stats = "--pick-stats" in sys.argv      # diagnostic build: cycle stamps in sync_pick_kernel (WFX_DEBUG=1 prints them)
+    print(build(force="--force" in sys.argv or stats, verbose=True,
+                extra_flags=("-DWFX_PICK_STATS",) if stats else ()))

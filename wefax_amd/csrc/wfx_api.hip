@@ -1,6 +1,7 @@
 // C ABI of libwefax_hip.so: stage entry points (host buffers in/out) and the fused
 // device-resident decode.  See include/wefax_hip.h for the contract and the
 // reference lines each entry point replaces.
+#include <cstdlib>
 #include <cstring>
 
 #include "wfx_internal.h"
@@ -78,17 +79,18 @@ int wfx_notch_filtfilt(wfx_ctx *ctx, const void *in, int in_kind, size_t n, cons
 }
 
 // ---- a7 ---------------------------------------------------------------------
-static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode, int taps, double *env_raw, double *env)
+static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode, int taps, double *env_raw, double *env,
+                            unsigned *l0hist = nullptr)
 {
     if (mode == WFX_HILBERT_FFT)
-        return wfx_dev_hilbert_envmed_fft(ctx, x, n, env);
+        return wfx_dev_hilbert_envmed_fft(ctx, x, n, env, l0hist);
     else if (mode == WFX_HILBERT_FIR)
         WFX_TRY(wfx_dev_hilbert_env_fir(ctx, x, n, taps, env_raw));
     else if (mode == WFX_HILBERT_BLUESTEIN)
         WFX_TRY(wfx_dev_hilbert_env_bluestein(ctx, x, n, env_raw));
     else
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown hilbert mode %d", mode);
-    return wfx_dev_median5(ctx, env_raw, n, env);
+    return wfx_dev_median5(ctx, env_raw, n, env, l0hist);
 }
 
 int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode, int fir_taps, double *env_out)
@@ -159,7 +161,7 @@ int wfx_sync_corr(wfx_ctx *ctx, const uint8_t *d, size_t n, int n1, int n0, int3
     const size_t L = (size_t)(2 * n1 + n0);
     if (n <= L) return 0;
     WFX_TRY(wfx_reserve(ctx, ctx->b_dig, n + 64));
-    WFX_TRY(wfx_reserve(ctx, ctx->b_corr, (n - L) * 4));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_corr, n * 4 + 256));
     WFX_TRY(h2d(ctx, ctx->b_dig.p, d, n));
     WFX_TRY(wfx_dev_sync_corr(ctx, (const uint8_t *)ctx->b_dig.p, n, n1, n0, (int32_t *)ctx->b_corr.p));
     return d2h_sync(ctx, corr_out, ctx->b_corr.p, (n - L) * 4);
@@ -287,10 +289,12 @@ int wfx_decode_run(wfx_ctx *ctx)
         cur = ctx->b_tmp.p;
     }
     WFX_TRY(wfx_dev_notch(ctx, cur, cur_kind, n, p.notch_b, p.notch_a, (double *)ctx->b_audio.p));
+    unsigned *sel_ws = nullptr;
+    WFX_TRY(wfx_dev_select_workspace(ctx, n, &sel_ws));           // level-0 histogram is fused into the envelope kernel
     WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, p.hilbert_mode, p.fir_taps, (double *)ctx->b_envraw.p,
-                             (double *)ctx->b_env.p));
+                             (double *)ctx->b_env.p, sel_ws));
     const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
-    WFX_TRY(wfx_dev_percentiles(ctx, (const double *)ctx->b_env.p, n, ranks, p.gamma_lo, p.gamma_hi, ds));
+    WFX_TRY(wfx_dev_percentiles_fused(ctx, (const double *)ctx->b_env.p, n, ranks, p.gamma_lo, p.gamma_hi, ds));
     WFX_TRY(wfx_dev_quantise(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, ds));
     WFX_TRY(wfx_dev_sync_pick(ctx, (const uint8_t *)ctx->b_dig.p, n, p.n1, p.n0_gap, p.mindistance, p.frame_samples, w, ds));
     WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h_max, ds, (uint8_t *)ctx->b_img.p));
@@ -318,6 +322,9 @@ int wfx_decode_result(wfx_ctx *ctx, wfx_decode_info *info)
     info->start_frame = s.start_frame;
     info->width = ctx->dp.width;
     info->height = s.height;
+    if (getenv("WFX_DEBUG"))
+        fprintf(stderr, "[wfx] sync_pick: ops %lld chunks %lld pick_cycles %lld loop_cycles %lld total_cycles %lld\n", s.dbg[0], s.dbg[1],
+                s.dbg[2], s.dbg[3], s.dbg[4]);
     for (int i = 0; i <= WFX_MAX_PEAKS; ++i) {
         info->peak_pos[i] = s.peak_pos[i];
         info->first_pos[i] = s.first_pos[i];

@@ -159,9 +159,15 @@ __device__ __forceinline__ cplx unit_root(uint64_t a, int log2mb)
 // Forward: n1 = g + 16 j -> DFT_RA over j, * W_R^{g q}, LDS exchange, DFT_16 over g,
 // output k1 = q + RA p.  The inverse runs the same steps backwards, conjugated.
 // ---------------------------------------------------------------------------
-template <int RA_BITS, int DIR, bool CONTIG, bool MULB>
+// IN_MODE (forward passes only): 0 = read the complex work array; 1 = read a REAL signal
+// packed as z[q] = x[2q+1] + i x[2q] for q < in_len, zero beyond (the Hilbert packing,
+// so no separate pack kernel and no loads of the zero padding); 2 = z[q] = x[q] + 0i.
+// Stores at or beyond out_limit are dropped (the inverse's last pass only has to produce
+// the part of the padded result that is read afterwards).
+template <int RA_BITS, int DIR, bool CONTIG, bool MULB, int IN_MODE = 0>
 __global__ void __launch_bounds__(256)
-fft_pass(cplx *__restrict__ A, int log2S, const cplx *__restrict__ w256, const cplx *__restrict__ bhat)
+fft_pass(cplx *__restrict__ A, int log2S, const cplx *__restrict__ w256, const cplx *__restrict__ bhat,
+         const double *__restrict__ xin, uint64_t in_len, uint64_t out_limit)
 {
     constexpr int RA = 1 << RA_BITS;
     constexpr int RB = 16;
@@ -184,6 +190,18 @@ fft_pass(cplx *__restrict__ A, int log2S, const cplx *__restrict__ w256, const c
     auto lidx = [&](int q, int g, int c) -> int {
         return CONTIG ? c * (RA * (RB + 1)) + q * (RB + 1) + g : (q * RB + g) * T + c;
     };
+    auto ld = [&](uint64_t a) -> cplx {
+        if (IN_MODE == 0) return A[a];
+        if (a >= in_len) return make_double2(0.0, 0.0);
+        if (IN_MODE == 1) {
+            const cplx v = ((const cplx *)xin)[a];
+            return make_double2(v.y, v.x);
+        }
+        return make_double2(xin[a], 0.0);
+    };
+    auto st = [&](uint64_t a, cplx v) {
+        if (a < out_limit) A[a] = v;
+    };
 
     if (RA > 1) {
         wt[t] = w256[t];
@@ -203,7 +221,7 @@ fft_pass(cplx *__restrict__ A, int log2S, const cplx *__restrict__ w256, const c
                 const int g = CONTIG ? (sa % RB) : (sa / T);
                 const int c = CONTIG ? (sa / RB) : (sa % T);
 #pragma unroll
-                for (int j = 0; j < RA; ++j) v[j] = A[addr(g + RB * j, c)];
+                for (int j = 0; j < RA; ++j) v[j] = ld(addr(g + RB * j, c));
                 dft_n<RA, DIR>::run(v);
 #pragma unroll
                 for (int q = 1; q < RA; ++q) v[q] = cmul(v[q], wt[((g * q) << (4 - RA_BITS)) & 255]);
@@ -215,7 +233,7 @@ fft_pass(cplx *__restrict__ A, int log2S, const cplx *__restrict__ w256, const c
             for (int g = 0; g < RB; ++g) v[g] = lds[lidx(bq, g, bc)];
         } else {
 #pragma unroll
-            for (int g = 0; g < RB; ++g) v[g] = A[addr(g, bc)];
+            for (int g = 0; g < RB; ++g) v[g] = ld(addr(g, bc));
         }
         dft_n<16, DIR>::run(v);
         if (!CONTIG) {
@@ -235,7 +253,7 @@ fft_pass(cplx *__restrict__ A, int log2S, const cplx *__restrict__ w256, const c
             const uint64_t a = addr(bq + RA * p, bc);
             cplx val = v[p];
             if (MULB) val = cmul(val, bhat[a]);
-            A[a] = val;
+            st(a, val);
         }
     } else {
 #pragma unroll
@@ -270,11 +288,11 @@ fft_pass(cplx *__restrict__ A, int log2S, const cplx *__restrict__ w256, const c
                 for (int q = 0; q < RA; ++q) v[q] = lds[lidx(q, g, c)];
                 dft_n<RA, DIR>::run(v);
 #pragma unroll
-                for (int j = 0; j < RA; ++j) A[addr(g + RB * j, c)] = v[j];
+                for (int j = 0; j < RA; ++j) st(addr(g + RB * j, c), v[j]);
             }
         } else {
 #pragma unroll
-            for (int g = 0; g < RB; ++g) A[addr(g, bc)] = v[g];
+            for (int g = 0; g < RB; ++g) st(addr(g, bc), v[g]);
         }
     }
 }
@@ -314,25 +332,39 @@ static int ensure_w256(wfx_ctx *ctx)
     return 0;
 }
 
-template <int DIR>
-static int launch_strided(wfx_ctx *ctx, cplx *A, int log2m, int ra_bits, int log2S)
+struct fft_io {
+    int in_mode = 0;              // first forward pass: 0 work array, 1 packed real, 2 plain real
+    const double *xin = nullptr;
+    uint64_t in_len = 0;
+    uint64_t out_limit = ~0ull;   // last inverse pass: drop stores at or beyond this index
+};
+
+template <int DIR, int IN_MODE>
+static int launch_strided(wfx_ctx *ctx, cplx *A, int log2m, int ra_bits, int log2S, const fft_io &io, uint64_t out_limit)
 {
     const unsigned grid = 1u << (log2m - 12);
     const cplx *w = (const cplx *)ctx->b_w256.p;
     const int kid = DIR > 0 ? K_FFT_FWD : K_FFT_INV;
+    const cplx *nb = nullptr;
+#define WFX_FFT_CASE(RAB)                                                                                                  \
+    case RAB:                                                                                                              \
+        WFX_LAUNCH(ctx, kid, (fft_pass<RAB, DIR, false, false, IN_MODE>), dim3(grid), dim3(256), A, log2S, w, nb, io.xin, \
+                   io.in_len, out_limit);                                                                                  \
+        break;
     switch (ra_bits) {
-    case 0: WFX_LAUNCH(ctx, kid, (fft_pass<0, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
-    case 1: WFX_LAUNCH(ctx, kid, (fft_pass<1, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
-    case 2: WFX_LAUNCH(ctx, kid, (fft_pass<2, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
-    case 3: WFX_LAUNCH(ctx, kid, (fft_pass<3, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
-    case 4: WFX_LAUNCH(ctx, kid, (fft_pass<4, DIR, false, false>), dim3(grid), dim3(256), A, log2S, w, (const cplx *)nullptr); break;
+        WFX_FFT_CASE(0)
+        WFX_FFT_CASE(1)
+        WFX_FFT_CASE(2)
+        WFX_FFT_CASE(3)
+        WFX_FFT_CASE(4)
     default: return wfx_fail(ctx, WFX_ERR_STATE, "bad FFT radix %d", ra_bits);
     }
+#undef WFX_FFT_CASE
     return 0;
 }
 
 // forward: natural -> digit-reversed; optionally multiply by bhat in the last pass
-static int fft_forward(wfx_ctx *ctx, cplx *A, int log2m, const cplx *bhat)
+static int fft_forward(wfx_ctx *ctx, cplx *A, int log2m, const cplx *bhat, const fft_io &io = fft_io())
 {
     WFX_TRY(ensure_w256(ctx));
     int ra[8];
@@ -341,19 +373,25 @@ static int fft_forward(wfx_ctx *ctx, cplx *A, int log2m, const cplx *bhat)
     int log2S = log2m;
     for (int i = 0; i < k; ++i) {
         log2S -= ra[i] + 4;
-        WFX_TRY(launch_strided<1>(ctx, A, log2m, ra[i], log2S));
+        if (i == 0 && io.in_mode == 1)
+            WFX_TRY((launch_strided<1, 1>(ctx, A, log2m, ra[i], log2S, io, ~0ull)));
+        else if (i == 0 && io.in_mode == 2)
+            WFX_TRY((launch_strided<1, 2>(ctx, A, log2m, ra[i], log2S, io, ~0ull)));
+        else
+            WFX_TRY((launch_strided<1, 0>(ctx, A, log2m, ra[i], log2S, io, ~0ull)));
     }
     const unsigned grid = 1u << (log2m - 12);
     const cplx *w = (const cplx *)ctx->b_w256.p;
+    const double *nx = nullptr;
     if (bhat)
-        WFX_LAUNCH(ctx, K_FFT_FWD, (fft_pass<4, 1, true, true>), dim3(grid), dim3(256), A, 0, w, bhat);
+        WFX_LAUNCH(ctx, K_FFT_FWD, (fft_pass<4, 1, true, true>), dim3(grid), dim3(256), A, 0, w, bhat, nx, (uint64_t)0, ~0ull);
     else
-        WFX_LAUNCH(ctx, K_FFT_FWD, (fft_pass<4, 1, true, false>), dim3(grid), dim3(256), A, 0, w, bhat);
+        WFX_LAUNCH(ctx, K_FFT_FWD, (fft_pass<4, 1, true, false>), dim3(grid), dim3(256), A, 0, w, bhat, nx, (uint64_t)0, ~0ull);
     return 0;
 }
 
 // inverse (unnormalised): digit-reversed -> natural
-static int fft_inverse(wfx_ctx *ctx, cplx *A, int log2m)
+static int fft_inverse(wfx_ctx *ctx, cplx *A, int log2m, const fft_io &io = fft_io())
 {
     WFX_TRY(ensure_w256(ctx));
     int ra[8];
@@ -361,14 +399,16 @@ static int fft_inverse(wfx_ctx *ctx, cplx *A, int log2m)
     if (k < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unsupported FFT size 2^%d", log2m);
     const unsigned grid = 1u << (log2m - 12);
     const cplx *w = (const cplx *)ctx->b_w256.p;
-    WFX_LAUNCH(ctx, K_FFT_INV, (fft_pass<4, -1, true, false>), dim3(grid), dim3(256), A, 0, w, (const cplx *)nullptr);
+    const double *nx = nullptr;
+    WFX_LAUNCH(ctx, K_FFT_INV, (fft_pass<4, -1, true, false>), dim3(grid), dim3(256), A, 0, w, (const cplx *)nullptr, nx, (uint64_t)0, ~0ull);
     int log2S[8];
     int s = log2m;
     for (int i = 0; i < k; ++i) {
         s -= ra[i] + 4;
         log2S[i] = s;
     }
-    for (int i = k - 1; i >= 0; --i) WFX_TRY(launch_strided<-1>(ctx, A, log2m, ra[i], log2S[i]));
+    for (int i = k - 1; i >= 0; --i)
+        WFX_TRY((launch_strided<-1, 0>(ctx, A, log2m, ra[i], log2S[i], io, i == 0 ? io.out_limit : ~0ull)));
     return 0;
 }
 
@@ -488,10 +528,10 @@ static int get_plan(wfx_ctx *ctx, uint64_t n, wfx_bs_plan **out)
 }
 
 // circular convolution with the chirp filter, in place: A <- IFFT(FFT(A) .* bhat)
-static int bs_convolve(wfx_ctx *ctx, cplx *A, const wfx_bs_plan *pl)
+static int bs_convolve(wfx_ctx *ctx, cplx *A, const wfx_bs_plan *pl, const fft_io &io = fft_io())
 {
-    WFX_TRY(fft_forward(ctx, A, pl->log2m, (const cplx *)pl->bhat.p));
-    WFX_TRY(fft_inverse(ctx, A, pl->log2m));
+    WFX_TRY(fft_forward(ctx, A, pl->log2m, (const cplx *)pl->bhat.p, io));
+    WFX_TRY(fft_inverse(ctx, A, pl->log2m, io));
     return 0;
 }
 
@@ -613,10 +653,16 @@ __device__ __forceinline__ void cswap_d(double &a, double &b)
 // |x + i H| followed by the 5-tap median of wefax.py:175 (zeros beyond both ends), fused:
 // a tile of 1024 envelope values + 2 halo values per side is formed in LDS.
 __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__ V, const double *__restrict__ x, long long N, long long L, int packed,
-                                                       double *__restrict__ env)
+                                                       double *__restrict__ env, unsigned *__restrict__ l0hist)
 {
     __shared__ double tile[1024 + 4];
+    __shared__ unsigned h0[WFX_SEL_BINS];      // level 0 of the percentile radix select (bits 63..53)
     const int t = threadIdx.x;
+    // level-0 digits (sign + 10 exponent bits) take a handful of values: each thread keeps a
+    // run (digit, count) in registers and touches the LDS histogram only when the digit changes
+    unsigned run_digit = 0, run_count = 0;
+    if (l0hist)
+        for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
     for (long long base = (long long)blockIdx.x * 1024; base < N; base += (long long)gridDim.x * 1024) {
         __syncthreads();
         for (int i = t; i < 1024 + 4; i += 256) {
@@ -640,8 +686,11 @@ __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = t + 256 * u;
-            if (base + j < N) {
-                double a = tile[j], b = tile[j + 1], c = tile[j + 2], d = tile[j + 3], e = tile[j + 4];
+            const bool valid = base + j < N;
+            double c = 0.0;
+            if (valid) {
+                double a = tile[j], b = tile[j + 1], d = tile[j + 3], e = tile[j + 4];
+                c = tile[j + 2];
                 cswap_d(a, b);
                 cswap_d(d, e);
                 cswap_d(a, d);
@@ -651,7 +700,23 @@ __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__
                 cswap_d(b, c);
                 env[base + j] = c;
             }
+            if (l0hist && valid) {
+                const unsigned dg = (unsigned)(wfx_f64_key(c) >> 53);
+                if (dg == run_digit)
+                    ++run_count;
+                else {
+                    if (run_count) atomicAdd(&h0[run_digit], run_count);
+                    run_digit = dg;
+                    run_count = 1;
+                }
+            }
         }
+    }
+    if (l0hist) {
+        if (run_count) atomicAdd(&h0[run_digit], run_count);
+        __syncthreads();
+        for (int i = t; i < WFX_SEL_BINS; i += 256)
+            if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
     }
 }
 
@@ -662,8 +727,14 @@ static int hilbert_conv(wfx_ctx *ctx, const double *x, uint64_t n, cplx **W_out,
     const uint64_t M = 1ull << pl->log2m;
     WFX_TRY(wfx_reserve(ctx, ctx->b_work, M * sizeof(cplx)));
     cplx *W = (cplx *)ctx->b_work.p;
-    WFX_LAUNCH(ctx, K_BS_CHIRP, hconv_pack, dim3(wfx_stream_grid(M, 256)), dim3(256), x, W, (long long)*L_out, (long long)M, *packed_out);
-    WFX_TRY(bs_convolve(ctx, W, pl));
+    // the first forward pass reads x directly (packed or plain) and the last inverse pass
+    // only stores the L values that are read afterwards
+    fft_io io;
+    io.in_mode = *packed_out ? 1 : 2;
+    io.xin = x;
+    io.in_len = *L_out;
+    io.out_limit = *L_out;
+    WFX_TRY(bs_convolve(ctx, W, pl, io));
     *W_out = W;
     return 0;
 }
@@ -679,14 +750,14 @@ int wfx_dev_hilbert_env_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *e
 }
 
 // envelope and median in one kernel (the decode path)
-int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env)
+int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env, unsigned *l0hist)
 {
     cplx *W = nullptr;
     int packed = 0;
     uint64_t L = 0;
     WFX_TRY(hilbert_conv(ctx, x, n, &W, &packed, &L));
     WFX_LAUNCH(ctx, K_ENV_MEDIAN, hconv_env_median, dim3(wfx_stream_grid(n, 1024)), dim3(256), (const cplx *)W, x, (long long)n, (long long)L,
-               packed, env);
+               packed, env, l0hist);
     return 0;
 }
 

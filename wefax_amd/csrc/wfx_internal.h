@@ -56,9 +56,12 @@ struct wfx_dev_scalars {
     long long first_pos[WFX_MAX_PEAKS + 1];
     long long phasing[WFX_MAX_PEAKS + 1];
     // radix-select state: 4 queries
-    unsigned long long sel_prefix[4];
+    unsigned long long sel_prefix[4];    // after level 0 (11 bits)
     unsigned long long sel_rank[4];
+    unsigned long long sel_prefix2[4];   // after level 1 (22 bits)
+    unsigned long long sel_rank2[4];
     double sel_value[4];
+    long long dbg[8];                    // diagnostic counters (tools/), not part of the ABI
 };
 
 struct wfx_prof_rec {
@@ -73,7 +76,7 @@ struct wfx_ctx {
 
     // named device buffers (grown on demand, reused across calls)
     wfx_devbuf b_in, b_x, b_audio, b_work, b_work2, b_envraw, b_env, b_dig, b_corr,
-        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps;
+        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand;
     bool w256_ready = false;
     std::map<uint64_t, wfx_bs_plan> plans;    // Bluestein chirp filters (resampler, cross-check mode)
     std::map<uint64_t, wfx_bs_plan> hplans;   // Hilbert convolution kernels
@@ -140,11 +143,39 @@ static inline unsigned wfx_stream_grid(uint64_t n, unsigned per_block)
     return (unsigned)b;
 }
 
+// ---- radix-select helpers shared by the kernels that fuse the level-0 histogram ----
+#define WFX_SEL_BINS 2048
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned long long wfx_f64_key(double v)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);     // order-preserving map to unsigned
+}
+// add one digit to an LDS histogram.  Up to three distinct digits among the wave's valid
+// lanes (smooth envelopes, coarse digits) are peeled off with one atomic each; whatever
+// is left falls back to one atomic per lane.
+__device__ __forceinline__ void wfx_sel_count(unsigned *h, unsigned digit, bool valid, int lane)
+{
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+        if (m == 0) return;
+        const int first = __ffsll((long long)m) - 1;
+        const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)digit, first);
+        const unsigned long long same = __ballot(valid && digit == d0);
+        if (lane == first) atomicAdd(&h[d0], (unsigned)__popcll(same));
+        if (digit == d0) valid = false;
+        m &= ~same;
+    }
+    if (valid) atomicAdd(&h[digit], 1u);
+}
+#endif
+
 // ---- device-level stage functions (device pointers in, device pointers out) --
 // wfx_fft.hip
 int wfx_dev_fft_plan_radices(int log2m, int *ra_bits, int max_passes);   // host only
 int wfx_dev_hilbert_env_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw);
-int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env);
+int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env, unsigned *l0hist);
 int wfx_dev_hilbert_env_bluestein(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw);
 int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out);
 
@@ -153,13 +184,16 @@ int wfx_dev_merge(wfx_ctx *ctx, const int16_t *lr, uint64_t n, double *out);
 int wfx_dev_i16_to_f64(wfx_ctx *ctx, const int16_t *in, uint64_t n, double *out);
 int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3],
                   const double a[3], double *out);
-int wfx_dev_median5(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env);
+int wfx_dev_median5(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env, unsigned *l0hist);
 int wfx_dev_select(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4],
                    wfx_dev_scalars *d_scal);
 int wfx_dev_percentile_lerp(wfx_ctx *ctx, double gamma_lo, double gamma_hi,
                             wfx_dev_scalars *d_scal);
 int wfx_dev_percentiles(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4],
                         double gamma_lo, double gamma_hi, wfx_dev_scalars *d_scal);
+int wfx_dev_select_workspace(wfx_ctx *ctx, uint64_t n, unsigned **ws);
+int wfx_dev_percentiles_fused(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4],
+                              double gamma_lo, double gamma_hi, wfx_dev_scalars *d_scal);
 int wfx_dev_quantise(wfx_ctx *ctx, const double *env, uint64_t n, const wfx_dev_scalars *d_scal,
                      uint8_t *out, wfx_dev_scalars *d_scal_out);
 int wfx_dev_sync_corr(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int32_t *corr);

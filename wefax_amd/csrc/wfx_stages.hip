@@ -5,6 +5,11 @@
 // reductions, one global atomic per workgroup.
 #include "wfx_internal.h"
 
+// workgroup barrier that orders LDS traffic only: global loads already issued (a
+// register prefetch of the next tile) stay in flight across it, which __syncthreads()
+// would drain with s_waitcnt vmcnt(0)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ===========================================================================
 // a4  stereo merge (wefax.py:360-373): np.add on np.int16 scalars wraps, /2 -> f64
 // ===========================================================================
@@ -92,38 +97,55 @@ __device__ __forceinline__ double biquad_step(const notch_coef &c, double xi, do
 }
 
 template <typename TIN>
-__global__ void __launch_bounds__(256) notch_kernel(const TIN *__restrict__ x, uint64_t n, notch_coef c, double *__restrict__ y, unsigned interior_blocks)
+__global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x, uint64_t n, notch_coef c, double *__restrict__ y, unsigned interior_blocks)
 {
     constexpr int TLEN = 1024 + 2 * NOTCH_K;
+    constexpr int NPRE = (TLEN + 255) / 256;
     __shared__ double tile[TLEN + TLEN / 4 + 4];
     __shared__ double ebuf[2][NOTCH_SMALL + 2 * NOTCH_PAD + 8];
     const int t = threadIdx.x;
     if (blockIdx.x < interior_blocks) {
-        // interior outputs [lo, hi) = [EDGE, n - EDGE)
+        // interior outputs [lo, hi) = [EDGE, n - EDGE); the next tile's samples are fetched
+        // into registers while the current tile is filtered
         const uint64_t lo = NOTCH_EDGE, hi = n - NOTCH_EDGE;
-        for (uint64_t base = lo + (uint64_t)blockIdx.x * 1024ull; base < hi; base += (uint64_t)interior_blocks * 1024ull) {
-            __syncthreads();
-            for (int i = t; i < TLEN; i += 256) {
+        const uint64_t step = (uint64_t)interior_blocks * 1024ull;
+        double pre[NPRE];
+        auto prefetch = [&](uint64_t base) {
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) {
+                const int i = t + 256 * k;
                 const uint64_t src = base - NOTCH_K + i;       // >= EDGE - K >= 0
-                tile[i + (i >> 2)] = src < n ? (double)x[src] : 0.0;
+                pre[k] = (i < TLEN && src < n) ? (double)x[src] : 0.0;
             }
-            __syncthreads();
-            double win[2 * NOTCH_K + 4];
+        };
+        uint64_t base = lo + (uint64_t)blockIdx.x * 1024ull;
+        if (base < hi) prefetch(base);
+        for (; base < hi; base += step) {
+            lds_barrier();
 #pragma unroll
-            for (int i = 0; i < 2 * NOTCH_K + 4; ++i) win[i] = tile[(4 * t + i) + ((4 * t + i) >> 2)];
-            double acc[4];
+            for (int k = 0; k < NPRE; ++k) {
+                const int i = t + 256 * k;
+                if (i < TLEN) tile[i + (i >> 2)] = pre[k];
+            }
+            lds_barrier();
+            if (base + step < hi) prefetch(base + step);
+            // window element i feeds output u with tap |i - u - K|: one LDS read, up to 4 FMAs
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[u] = c.g[0] * win[u + NOTCH_K];
+            for (int i = 0; i < 2 * NOTCH_K + 4; ++i) {
+                const double wv = tile[(4 * t + i) + ((4 * t + i) >> 2)];
 #pragma unroll
-                for (int k = 1; k <= NOTCH_K; ++k) acc[u] = fma(c.g[k], win[u + NOTCH_K - k] + win[u + NOTCH_K + k], acc[u]);
+                for (int u = 0; u < 4; ++u) {
+                    const int k = i - u - NOTCH_K;
+                    if (k >= -NOTCH_K && k <= NOTCH_K) acc[u] = fma(c.g[k < 0 ? -k : k], wv, acc[u]);
+                }
             }
             // a lane's 4 outputs are contiguous: exchange through LDS so that each store
             // instruction writes 64 x 16 contiguous bytes instead of 64 quarter lines
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int u = 0; u < 4; ++u) tile[5 * t + u] = acc[u];
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int j = half * 512 + 2 * t;                 // even -> same padded group of four
@@ -266,10 +288,13 @@ __device__ __forceinline__ double median5(double a, double b, double c, double d
     return c;
 }
 
-__global__ void __launch_bounds__(256) median5_kernel(const double *__restrict__ r, uint64_t n, double *__restrict__ out)
+__global__ void __launch_bounds__(256) median5_kernel(const double *__restrict__ r, uint64_t n, double *__restrict__ out, unsigned *__restrict__ l0hist)
 {
     __shared__ double tile[1024 + 4];
+    __shared__ unsigned h0[WFX_SEL_BINS];
     const int t = threadIdx.x;
+    if (l0hist)
+        for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
     for (uint64_t base = (uint64_t)blockIdx.x * 1024ull; base < n; base += (uint64_t)gridDim.x * 1024ull) {
         __syncthreads();
         for (int i = t; i < 1024 + 4; i += 256) {
@@ -280,121 +305,26 @@ __global__ void __launch_bounds__(256) median5_kernel(const double *__restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = t + 256 * u;
-            if (base + j < n) out[base + j] = median5(tile[j], tile[j + 1], tile[j + 2], tile[j + 3], tile[j + 4]);
-        }
-    }
-}
-
-int wfx_dev_median5(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env)
-{
-    WFX_LAUNCH(ctx, K_MEDIAN, median5_kernel, dim3(wfx_stream_grid(n, 1024)), dim3(256), env_raw, n, env);
-    return 0;
-}
-
-// ===========================================================================
-// a8  np.percentile(data, (0.5, 99.5)) (wefax.py:196): exact order statistics by
-// most-significant-digit radix select on the 64-bit keys, four ranks at once.
-// Each level reads the array once, builds one LDS histogram per distinct prefix
-// (wave-uniform digits are added with one atomic per wave), flushes it with one
-// global atomic per non-empty bin, and a single-workgroup scan picks the digit.
-// ===========================================================================
-#define SEL_BITS 11
-#define SEL_BINS (1 << SEL_BITS)
-#define SEL_LEVELS 6    // 11+11+11+11+11+9 = 64 bits
-
-__device__ __forceinline__ unsigned long long f64_key(double v)
-{
-    unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double key_f64(unsigned long long k)
-{
-    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)u);
-}
-
-__host__ __device__ static inline int sel_shift(int level) { return level < 5 ? 53 - 11 * level : 0; }
-__host__ __device__ static inline int sel_width(int level) { return level < 5 ? 11 : 9; }
-
-// One level: histogram of the level's digit over the elements whose higher bits equal
-// a query's prefix.  Queries that share a prefix share a histogram ("owner").
-__global__ void __launch_bounds__(256) select_hist(const double *__restrict__ v, uint64_t n, int level, const wfx_dev_scalars *__restrict__ s, unsigned *__restrict__ ghist)
-{
-    __shared__ unsigned h[4][SEL_BINS];
-    __shared__ unsigned long long pfx[4];
-    __shared__ int owner[4];
-    const int t = threadIdx.x;
-    for (int i = t; i < 4 * SEL_BINS; i += 256) (&h[0][0])[i] = 0;
-    if (t == 0) {
-        for (int q = 0; q < 4; ++q) {
-            pfx[q] = level == 0 ? 0ull : s->sel_prefix[q];
-            int o = q;
-            for (int p = 0; p < q; ++p)
-                if (level == 0 || s->sel_prefix[p] == s->sel_prefix[q]) {
-                    o = p;
-                    break;
-                }
-            owner[q] = o;
-        }
-    }
-    __syncthreads();
-    const int shift = sel_shift(level), width = sel_width(level);
-    const unsigned dmask = (1u << width) - 1;
-    const int lane = t & 63;
-    bool active[4];
-    unsigned long long mypfx[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        active[q] = owner[q] == q;
-        mypfx[q] = pfx[q];
-    }
-    auto count = [&](unsigned long long key, bool valid) {
-        const unsigned digit = (unsigned)(key >> shift) & dmask;
-        const unsigned long long hi = level == 0 ? 0ull : (key >> (shift + width));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (!active[q]) continue;                       // block-uniform
-            const bool match = valid && hi == mypfx[q];
-            const unsigned long long m = __ballot(match);
-            if (m == 0) continue;                           // wave-uniform
-            const int first = __ffsll((long long)m) - 1;
-            const unsigned d0 = __shfl(digit, first);
-            const bool same = !match || digit == d0;
-            if (__all(same)) {
-                if (lane == first) atomicAdd(&h[q][d0], (unsigned)__popcll(m));
-            } else if (match) {
-                atomicAdd(&h[q][digit], 1u);
+            const bool valid = base + j < n;
+            double m = 0.0;
+            if (valid) {
+                m = median5(tile[j], tile[j + 1], tile[j + 2], tile[j + 3], tile[j + 4]);
+                out[base + j] = m;
             }
+            if (l0hist) wfx_sel_count(h0, (unsigned)(wfx_f64_key(m) >> 53), valid, t & 63);
         }
-    };
-    // four values per thread and iteration (two 16-byte loads in flight)
-    const uint64_t quads = (n + 3) / 4;
-    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
-    const uint64_t nround = (quads + stride - 1) / stride;
-    for (uint64_t it = 0; it < nround; ++it) {
-        const uint64_t i0 = (it * stride + blockIdx.x * 256ull + t) * 4;
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        if (i0 + 4 <= n) {
-            const double2 lo = *(const double2 *)(v + i0), hi2 = *(const double2 *)(v + i0 + 2);
-            a0 = lo.x;
-            a1 = lo.y;
-            a2 = hi2.x;
-            a3 = hi2.y;
-        } else {
-            if (i0 < n) a0 = v[i0];
-            if (i0 + 1 < n) a1 = v[i0 + 1];
-            if (i0 + 2 < n) a2 = v[i0 + 2];
-        }
-        count(f64_key(a0), i0 < n);
-        count(f64_key(a1), i0 + 1 < n);
-        count(f64_key(a2), i0 + 2 < n);
-        count(f64_key(a3), i0 + 3 < n);
     }
-    __syncthreads();
-    for (int i = t; i < 4 * SEL_BINS; i += 256) {
-        const unsigned c = (&h[0][0])[i];
-        if (c) atomicAdd(&ghist[i], c);
+    if (l0hist) {
+        __syncthreads();
+        for (int i = t; i < WFX_SEL_BINS; i += 256)
+            if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
     }
+}
+
+int wfx_dev_median5(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env, unsigned *l0hist)
+{
+    WFX_LAUNCH(ctx, K_MEDIAN, median5_kernel, dim3(wfx_stream_grid(n, 1024)), dim3(256), env_raw, n, env, l0hist);
+    return 0;
 }
 
 // numpy's _lerp (numpy/lib/_function_base_impl.py): a + (b-a)*t, or b - (b-a)*(1-t) when t >= 0.5
@@ -406,28 +336,80 @@ __device__ __forceinline__ double np_lerp(double a, double b, double t)
     return r;
 }
 
-// Pick each query's digit from the level's histogram: one wave per query, 32 bins per
-// lane, shuffle scan.  Also clears the other histogram buffer for the next level and,
-// after the last level, applies the percentile interpolation.
-__global__ void __launch_bounds__(256) select_scan(int level, wfx_dev_scalars *s, const unsigned *__restrict__ ghist, unsigned *__restrict__ gnext,
-                                                  uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3, int do_lerp, double gamma_lo, double gamma_hi)
+// ===========================================================================
+// a8  np.percentile(data, (0.5, 99.5)) (wefax.py:196): exact order statistics by
+// most-significant-digit radix select on the 64-bit keys, four ranks at once.
+//
+//   level 0  bits 63..53   histogram fused into the kernel that writes the envelope
+//   level 1  bits 52..42   one pass over the envelope (select_l1_kernel)
+//   compact               one pass: keys whose top 22 bits match a query are appended
+//                         to that query's candidate list (select_compact_kernel)
+//   levels 2..5           one workgroup finishes on the candidate lists, applies
+//                         numpy's percentile interpolation and clears the histograms
+//
+// Every kernel re-derives the digit choices it needs from the previous level's global
+// histogram in its prologue (block 0 also records them), so there are no separate scan
+// launches.  Histograms live in LDS (wave-uniform digits cost one atomic per wave) and
+// are flushed with one global atomic per non-empty bin.
+// ===========================================================================
+#define SEL_BITS 11
+#define SEL_BINS (1 << SEL_BITS)
+#define SEL_LEVELS 6    // 11+11+11+11+11+9 = 64 bits
+
+#define f64_key wfx_f64_key
+__device__ __forceinline__ double key_f64(unsigned long long k)
 {
-    __shared__ double vals[4];
-    const int t = threadIdx.x;
-    const int q = t >> 6, lane = t & 63;
-    const int width = sel_width(level);
-    const int bins = 1 << width;
-    int o = q;
-    for (int p = 0; p < q; ++p)
-        if (level == 0 || s->sel_prefix[p] == s->sel_prefix[q]) {
-            o = p;
-            break;
-        }
-    const unsigned long long rank = level == 0 ? (q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3) : s->sel_rank[q];
-    const unsigned long long prefix = level == 0 ? 0ull : s->sel_prefix[q];
-    const unsigned *hq = ghist + o * SEL_BINS + lane * 32;
-    unsigned loc[32];
-    unsigned sum = 0;                          // counts are < 2^32 (n <= 2^31)
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+__host__ __device__ static inline int sel_shift(int level) { return level < 5 ? 53 - 11 * level : 0; }
+__host__ __device__ static inline int sel_width(int level) { return level < 5 ? 11 : 9; }
+
+// layout of the select workspace (unsigned words)
+#define SEL_H0 0                          // level-0 histogram [2048]
+#define SEL_H1 SEL_BINS                   // level-1 histograms [4][2048]
+#define SEL_CNT (5 * SEL_BINS)            // candidate counts [4]
+#define SEL_WORDS (5 * SEL_BINS + 8)
+
+#define sel_count wfx_sel_count
+
+// exclusive prefix of v over the threads of the block (NT <= 1024, multiple of 64)
+template <int NT>
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *wave_tot /* LDS [NT/64] */, unsigned *total)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const unsigned x = wave_tot[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    return base + incl - v;
+}
+
+// For the 4 (owner, rank) queries: find, in the histogram of the query's owner, the bin that
+// holds the rank.  One wave per query (blocks of >= 256 threads), 32 bins per lane, no block
+// barrier inside; results go to LDS arrays (the caller synchronises).
+__device__ __forceinline__ void sel_pick_digits(const unsigned *hist /* [4][SEL_BINS] or shared [SEL_BINS] */, bool shared_hist, int bins,
+                                                const int *owner, const unsigned long long *rank_in, unsigned *digit_out,
+                                                unsigned long long *rank_out)
+{
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (q >= 4) return;
+    const unsigned *hq = (shared_hist ? hist : hist + owner[q] * SEL_BINS) + lane * 32;
+    unsigned loc[32], sum = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint4 u = ((const uint4 *)hq)[k];
@@ -447,66 +429,355 @@ __global__ void __launch_bounds__(256) select_scan(int level, wfx_dev_scalars *s
         const unsigned o2 = __shfl_up(incl, off);
         if (lane >= off) incl += o2;
     }
-    unsigned long long cum = incl - sum;      // exclusive prefix of this lane's first bin
-    __syncthreads();                           // every wave has read s->sel_* before anyone rewrites it
-    unsigned long long newp = 0, newr = 0;
-    bool mine = false;
+    unsigned long long cum = incl - sum;
+    const unsigned long long r = rank_in[q];
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
-        if (!mine && rank >= cum && rank < cum + loc[k]) {
-            newp = (prefix << width) | (unsigned long long)(lane * 32 + k);
-            newr = rank - cum;
-            mine = true;
+        if (r >= cum && r < cum + loc[k]) {
+            digit_out[q] = (unsigned)(lane * 32 + k);
+            rank_out[q] = r - cum;
         }
         cum += loc[k];
     }
-    if (mine) {
-        s->sel_prefix[q] = newp;
-        s->sel_rank[q] = newr;
-        if (level == SEL_LEVELS - 1) {
-            s->sel_value[q] = key_f64(newp);
-            vals[q] = key_f64(newp);
-        }
-    }
-    for (int i = t; i < 4 * SEL_BINS; i += 256) gnext[i] = 0;
-    if (do_lerp && level == SEL_LEVELS - 1) {
-        __syncthreads();
-        if (t == 0) {
-            s->low = np_lerp(vals[0], vals[1], gamma_lo);
-            s->high = np_lerp(vals[2], vals[3], gamma_hi);
-            s->nan_count = 0;
-        }
+}
+
+__device__ __forceinline__ void sel_owners(const unsigned long long *pfx, int *owner)
+{
+    for (int q = 0; q < 4; ++q) {
+        int o = q;
+        for (int p = 0; p < q; ++p)
+            if (pfx[p] == pfx[q]) {
+                o = p;
+                break;
+            }
+        owner[q] = o;
     }
 }
 
-static int select_run(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], wfx_dev_scalars *d_scal, int do_lerp,
-                      double gamma_lo, double gamma_hi)
+// stand-alone level 0 (used when the envelope was not produced by a kernel that fuses it)
+__global__ void __launch_bounds__(256) select_l0_kernel(const double *__restrict__ v, uint64_t n, unsigned *__restrict__ ws)
+{
+    __shared__ unsigned h[SEL_BINS];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < SEL_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    const uint64_t nround = (n + stride - 1) / stride;
+    for (uint64_t it = 0; it < nround; ++it) {
+        const uint64_t i = it * stride + blockIdx.x * 256ull + t;
+        const bool valid = i < n;
+        const unsigned long long key = valid ? f64_key(v[i]) : 0ull;
+        sel_count(h, (unsigned)(key >> 53), valid, lane);
+    }
+    __syncthreads();
+    for (int i = t; i < SEL_BINS; i += 256)
+        if (h[i]) atomicAdd(&ws[SEL_H0 + i], h[i]);
+}
+
+// level 1: choose the level-0 digit of every query, then histogram bits 52..42 of the
+// values whose top 11 bits match
+__global__ void __launch_bounds__(256) select_l1_kernel(const double *__restrict__ v, uint64_t n, uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3,
+                                                       unsigned *__restrict__ ws, wfx_dev_scalars *__restrict__ s)
+{
+    __shared__ unsigned h[4][SEL_BINS];
+    __shared__ unsigned long long pfx[4], rnk[4], rin[4];
+    __shared__ unsigned dig[4];
+    __shared__ int owner[4];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 4 * SEL_BINS; i += 256) (&h[0][0])[i] = 0;
+    if (t == 0) {
+        rin[0] = r0;
+        rin[1] = r1;
+        rin[2] = r2;
+        rin[3] = r3;
+        owner[0] = owner[1] = owner[2] = owner[3] = 0;
+    }
+    __syncthreads();
+    sel_pick_digits(ws + SEL_H0, true, SEL_BINS, owner, rin, dig, rnk);
+    __syncthreads();
+    if (t == 0) {
+        for (int q = 0; q < 4; ++q) pfx[q] = dig[q];
+        sel_owners(pfx, owner);
+        if (blockIdx.x == 0)
+            for (int q = 0; q < 4; ++q) {
+                s->sel_prefix[q] = pfx[q];
+                s->sel_rank[q] = rnk[q];
+            }
+    }
+    __syncthreads();
+    bool active[4];
+    unsigned long long mypfx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        active[q] = owner[q] == q;
+        mypfx[q] = pfx[q];
+    }
+    auto count = [&](double x, bool valid) {
+        const unsigned long long key = f64_key(x);
+        const unsigned digit = (unsigned)(key >> 42) & (SEL_BINS - 1);
+        const unsigned long long hi = key >> 53;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (active[q] && valid && hi == mypfx[q]) atomicAdd(&h[q][digit], 1u);   // level-1 digits are diverse: no wave aggregation
+    };
+    const uint64_t quads = (n + 3) / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    const uint64_t nround = (quads + stride - 1) / stride;
+    for (uint64_t it = 0; it < nround; ++it) {
+        const uint64_t i0 = (it * stride + blockIdx.x * 256ull + t) * 4;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (i0 + 4 <= n) {
+            const double2 lo = *(const double2 *)(v + i0), hi2 = *(const double2 *)(v + i0 + 2);
+            a0 = lo.x;
+            a1 = lo.y;
+            a2 = hi2.x;
+            a3 = hi2.y;
+        } else {
+            if (i0 < n) a0 = v[i0];
+            if (i0 + 1 < n) a1 = v[i0 + 1];
+            if (i0 + 2 < n) a2 = v[i0 + 2];
+        }
+        count(a0, i0 < n);
+        count(a1, i0 + 1 < n);
+        count(a2, i0 + 2 < n);
+        count(a3, i0 + 3 < n);
+    }
+    __syncthreads();
+    for (int i = t; i < 4 * SEL_BINS; i += 256) {
+        const unsigned c = (&h[0][0])[i];
+        if (c) atomicAdd(&ws[SEL_H1 + i], c);
+    }
+}
+
+// compaction: choose the level-1 digit of every query, then append the keys whose top
+// 22 bits match to the query's candidate list (one atomic per wave and list)
+__global__ void __launch_bounds__(256) select_compact_kernel(const double *__restrict__ v, uint64_t n, unsigned *__restrict__ ws,
+                                                            wfx_dev_scalars *__restrict__ s, unsigned long long *__restrict__ cand, uint64_t cap)
+{
+    __shared__ unsigned long long pfx[4], rnk[4], rin[4];
+    __shared__ unsigned dig[4];
+    __shared__ int owner[4];
+    const int t = threadIdx.x, lane = t & 63;
+    if (t == 0) {
+        for (int q = 0; q < 4; ++q) {
+            pfx[q] = s->sel_prefix[q];
+            rin[q] = s->sel_rank[q];
+        }
+        sel_owners(pfx, owner);
+    }
+    __syncthreads();
+    sel_pick_digits(ws + SEL_H1, false, SEL_BINS, owner, rin, dig, rnk);
+    __syncthreads();
+    if (t == 0) {
+        for (int q = 0; q < 4; ++q) pfx[q] = (pfx[q] << SEL_BITS) | dig[q];
+        sel_owners(pfx, owner);
+    }
+    __syncthreads();
+    // every block has read s->sel_* above before block 0 can overwrite it?  No: other blocks may
+    // start later, so the 22-bit state goes to separate fields (sel_value is reused as scratch
+    // for the ranks until the finish kernel overwrites it with the results).
+    if (blockIdx.x == 0 && t == 0)
+        for (int q = 0; q < 4; ++q) {
+            s->sel_prefix2[q] = pfx[q];
+            s->sel_rank2[q] = rnk[q];
+        }
+    bool active[4];
+    unsigned long long mypfx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        active[q] = owner[q] == q;
+        mypfx[q] = pfx[q];
+    }
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    auto append = [&](double x, bool valid) {
+        const unsigned long long key = f64_key(x);
+        const unsigned long long hi = key >> 42;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!active[q]) continue;
+            const bool match = valid && hi == mypfx[q];
+            const unsigned long long m = __ballot(match);
+            if (m == 0) continue;
+            const int first = __ffsll((long long)m) - 1;
+            unsigned base = 0;
+            if (lane == first) base = atomicAdd(&ws[SEL_CNT + q], (unsigned)__popcll(m));
+            base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
+            if (match) {
+                const uint64_t slot = (uint64_t)base + (uint64_t)__popcll(m & lt_mask);
+                if (slot < cap) cand[(uint64_t)q * cap + slot] = key;
+            }
+        }
+    };
+    const uint64_t quads = (n + 3) / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    const uint64_t nround = (quads + stride - 1) / stride;
+    for (uint64_t it = 0; it < nround; ++it) {
+        const uint64_t i0 = (it * stride + blockIdx.x * 256ull + t) * 4;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (i0 + 4 <= n) {
+            const double2 lo = *(const double2 *)(v + i0), hi2 = *(const double2 *)(v + i0 + 2);
+            a0 = lo.x;
+            a1 = lo.y;
+            a2 = hi2.x;
+            a3 = hi2.y;
+        } else {
+            if (i0 < n) a0 = v[i0];
+            if (i0 + 1 < n) a1 = v[i0 + 1];
+            if (i0 + 2 < n) a2 = v[i0 + 2];
+        }
+        append(a0, i0 < n);
+        append(a1, i0 + 1 < n);
+        append(a2, i0 + 2 < n);
+        append(a3, i0 + 3 < n);
+    }
+}
+
+// levels 2..5 on the candidate lists, numpy's lerp, and clearing of the workspace
+__global__ void __launch_bounds__(1024) select_finish_kernel(unsigned *__restrict__ ws, wfx_dev_scalars *__restrict__ s,
+                                                            const unsigned long long *__restrict__ cand, uint64_t cap, int do_lerp, double gamma_lo,
+                                                            double gamma_hi)
+{
+    __shared__ unsigned h[SEL_BINS];
+    __shared__ unsigned wave_tot[16];
+    __shared__ unsigned long long pfx[4], rnk[4];
+    __shared__ int owner[4];
+    __shared__ unsigned long long cur_p, cur_r;
+    const int t = threadIdx.x, lane = t & 63;
+    if (t == 0) {
+        for (int q = 0; q < 4; ++q) {
+            pfx[q] = s->sel_prefix2[q];
+            rnk[q] = s->sel_rank2[q];
+        }
+        sel_owners(pfx, owner);
+    }
+    __syncthreads();
+    {
+        const int q = blockIdx.x;               // one workgroup per query
+        const int o = owner[q];
+        const uint64_t cnt = min((uint64_t)ws[SEL_CNT + o], cap);
+        const unsigned long long *list = cand + (uint64_t)o * cap;
+        if (t == 0) {
+            cur_p = pfx[q];
+            cur_r = rnk[q];
+        }
+        __syncthreads();
+        for (int level = 2; level < SEL_LEVELS; ++level) {
+            const int shift = sel_shift(level), width = sel_width(level);
+            const unsigned dmask = (1u << width) - 1;
+            const unsigned long long want = cur_p;
+            for (int i = t; i < SEL_BINS; i += 1024) h[i] = 0;
+            __syncthreads();
+            const uint64_t nround = (cnt + 1023) / 1024;
+            for (uint64_t it = 0; it < nround; ++it) {
+                const uint64_t i = it * 1024 + t;
+                const bool valid = i < cnt;
+                const unsigned long long key = valid ? list[i] : 0ull;
+                sel_count(h, (unsigned)(key >> shift) & dmask, valid && (key >> (shift + width)) == want, lane);
+            }
+            __syncthreads();
+            // thread t owns bins 2t, 2t+1
+            const unsigned c0 = h[2 * t], c1 = h[2 * t + 1];
+            unsigned long long cum = block_excl_scan<1024>(c0 + c1, wave_tot, nullptr);
+            const unsigned long long r = cur_r;
+            __syncthreads();
+            if (r >= cum && r < cum + c0) {
+                cur_p = (want << width) | (unsigned long long)(2 * t);
+                cur_r = r - cum;
+            } else if (r >= cum + c0 && r < cum + c0 + c1) {
+                cur_p = (want << width) | (unsigned long long)(2 * t + 1);
+                cur_r = r - cum - c0;
+            }
+            __syncthreads();
+        }
+        if (t == 0) s->sel_value[q] = key_f64(cur_p);
+    }
+}
+
+// numpy's interpolation between the two order statistics of each percentile, and clearing
+// of the select workspace for the next run
+__global__ void __launch_bounds__(256) select_lerp_kernel(unsigned *__restrict__ ws, wfx_dev_scalars *__restrict__ s, int do_lerp, double gamma_lo,
+                                                         double gamma_hi)
+{
+    const int t = threadIdx.x;
+    if (t == 0 && do_lerp) {
+        s->low = np_lerp(s->sel_value[0], s->sel_value[1], gamma_lo);
+        s->high = np_lerp(s->sel_value[2], s->sel_value[3], gamma_hi);
+        s->nan_count = 0;
+    }
+    for (int i = t; i < SEL_WORDS; i += 256) ws[i] = 0;
+}
+
+// workspace + candidate lists; the workspace is zeroed when it is (re)allocated and by
+// the finish kernel after every use
+static int select_prepare(wfx_ctx *ctx, uint64_t n, unsigned **ws, unsigned long long **cand)
+{
+    const bool fresh = ctx->b_hist.cap < SEL_WORDS * sizeof(unsigned) || !ctx->b_hist.p;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_hist, SEL_WORDS * sizeof(unsigned)));
+    if (fresh) WFX_HIP(ctx, hipMemsetAsync(ctx->b_hist.p, 0, SEL_WORDS * sizeof(unsigned), ctx->stream));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_cand, 4 * (size_t)n * sizeof(unsigned long long)));
+    *ws = (unsigned *)ctx->b_hist.p;
+    *cand = (unsigned long long *)ctx->b_cand.p;
+    return 0;
+}
+
+// levels 1.. given that the level-0 histogram is already in the workspace
+static int select_after_l0(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], wfx_dev_scalars *d_scal, int do_lerp,
+                           double gamma_lo, double gamma_hi)
+{
+    unsigned *ws = (unsigned *)ctx->b_hist.p;
+    unsigned long long *cand = (unsigned long long *)ctx->b_cand.p;
+    unsigned grid = wfx_stream_grid(n, 4096);
+    if (grid > 768) grid = 768;             // 3 per CU: per-workgroup prologue (digit pick) and epilogue (flush) are paid once
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l1_kernel, dim3(grid), dim3(256), env, n, ranks[0], ranks[1], ranks[2], ranks[3], ws, d_scal);
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_compact_kernel, dim3(grid), dim3(256), env, n, ws, d_scal, cand, n);
+    WFX_LAUNCH(ctx, K_SELECT_SCAN, select_finish_kernel, dim3(4), dim3(1024), ws, d_scal, (const unsigned long long *)cand, n, do_lerp, gamma_lo,
+               gamma_hi);
+    WFX_LAUNCH(ctx, K_SELECT_SCAN, select_lerp_kernel, dim3(1), dim3(256), ws, d_scal, do_lerp, gamma_lo, gamma_hi);
+    return 0;
+}
+
+static int check_ranks(wfx_ctx *ctx, uint64_t n, const uint64_t ranks[4])
 {
     for (int q = 0; q < 4; ++q)
         if (ranks[q] >= n) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "order statistic rank %llu >= n", (unsigned long long)ranks[q]);
-    const size_t hbytes = 4 * SEL_BINS * sizeof(unsigned);
-    WFX_TRY(wfx_reserve(ctx, ctx->b_hist, 2 * hbytes));
-    unsigned *gh[2] = {(unsigned *)ctx->b_hist.p, (unsigned *)ctx->b_hist.p + 4 * SEL_BINS};
-    WFX_HIP(ctx, hipMemsetAsync(gh[0], 0, hbytes, ctx->stream));
-    for (int level = 0; level < SEL_LEVELS; ++level) {
-        unsigned *cur = gh[level & 1], *nxt = gh[(level + 1) & 1];
-        WFX_LAUNCH(ctx, K_SELECT_HIST, select_hist, dim3(wfx_stream_grid(n, 4096)), dim3(256), env, n, level,
-                   (const wfx_dev_scalars *)d_scal, cur);
-        WFX_LAUNCH(ctx, K_SELECT_SCAN, select_scan, dim3(1), dim3(256), level, d_scal, (const unsigned *)cur, nxt, ranks[0], ranks[1],
-                   ranks[2], ranks[3], do_lerp, gamma_lo, gamma_hi);
-    }
     return 0;
 }
 
 int wfx_dev_select(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], wfx_dev_scalars *d_scal)
 {
-    return select_run(ctx, env, n, ranks, d_scal, 0, 0.0, 0.0);
+    WFX_TRY(check_ranks(ctx, n, ranks));
+    unsigned *ws;
+    unsigned long long *cand;
+    WFX_TRY(select_prepare(ctx, n, &ws, &cand));
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l0_kernel, dim3(wfx_stream_grid(n, 2048)), dim3(256), env, n, ws);
+    return select_after_l0(ctx, env, n, ranks, d_scal, 0, 0.0, 0.0);
 }
 
+// percentiles of an envelope whose level-0 histogram was NOT fused into its producer
 int wfx_dev_percentiles(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], double gamma_lo, double gamma_hi,
                         wfx_dev_scalars *d_scal)
 {
-    return select_run(ctx, env, n, ranks, d_scal, 1, gamma_lo, gamma_hi);
+    WFX_TRY(check_ranks(ctx, n, ranks));
+    unsigned *ws;
+    unsigned long long *cand;
+    WFX_TRY(select_prepare(ctx, n, &ws, &cand));
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l0_kernel, dim3(wfx_stream_grid(n, 2048)), dim3(256), env, n, ws);
+    return select_after_l0(ctx, env, n, ranks, d_scal, 1, gamma_lo, gamma_hi);
+}
+
+// call BEFORE the kernel that fuses the level-0 histogram: returns the workspace pointer
+int wfx_dev_select_workspace(wfx_ctx *ctx, uint64_t n, unsigned **ws)
+{
+    unsigned long long *cand;
+    return select_prepare(ctx, n, ws, &cand);
+}
+
+// percentiles when the level-0 histogram has already been accumulated into the workspace
+int wfx_dev_percentiles_fused(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], double gamma_lo, double gamma_hi,
+                              wfx_dev_scalars *d_scal)
+{
+    WFX_TRY(check_ranks(ctx, n, ranks));
+    return select_after_l0(ctx, env, n, ranks, d_scal, 1, gamma_lo, gamma_hi);
 }
 
 __global__ void percentile_lerp_kernel(wfx_dev_scalars *s, double gamma_lo, double gamma_hi)
@@ -636,19 +907,25 @@ __device__ __forceinline__ void wave_first_argmax(int c, int idx, int &best_c, i
 __global__ void __launch_bounds__(256) sync_corr_kernel(const uint8_t *__restrict__ d, uint64_t n, int n1, int n0, int *__restrict__ corr,
                                                        int *__restrict__ bmax, int *__restrict__ boff)
 {
-    __shared__ uint8_t ds[CORR_CH + 512];
-    __shared__ int cs[CORR_CH];
+    __shared__ __attribute__((aligned(16))) uint8_t ds[CORR_CH + 512 + 16];
+    __shared__ __attribute__((aligned(16))) int cs[CORR_CH];
     const int L = 2 * n1 + n0;
     const uint64_t ncorr = n > (uint64_t)L ? n - L : 0;
     const int t = threadIdx.x;
     for (uint64_t p0 = (uint64_t)blockIdx.x * CORR_CH; p0 < ncorr; p0 += (uint64_t)gridDim.x * CORR_CH) {
         const int cnt = (int)min((uint64_t)CORR_CH, ncorr - p0);
         __syncthreads();
-        for (int i = t; i < cnt + L + 1; i += 256) ds[i] = (p0 + i < n) ? d[p0 + i] : 0;
+        // the byte stream buffer is padded by 64 bytes and p0 is a multiple of 4096: 16-byte loads
+        for (int i = t * 16; i < cnt + L + 1; i += 256 * 16) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p0 + i < n + 48) v = *(const uint4 *)(d + p0 + i);
+            *(uint4 *)(ds + i) = v;
+        }
         __syncthreads();
         corr_from_lds(ds, cnt, n1, n0, cs, t, 256);
         __syncthreads();
-        for (int i = t; i < cnt; i += 256) corr[p0 + i] = cs[i];
+        // corr is padded to a multiple of 4 ints: whole int4 stores (values beyond cnt are never read)
+        for (int i = t * 4; i < cnt; i += 256 * 4) *(int4 *)(corr + p0 + i) = *(const int4 *)(cs + i);
         if (bmax) {
             const int lane = t & 63, wave = t >> 6;
             for (int b = wave; b * 64 < cnt; b += 4) {
@@ -679,7 +956,7 @@ int wfx_dev_sync_corr(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0
 // barriers, which wait for LDS only) and wave 0 replays the reference's scan: it only
 // ever needs "first maximum of a range", answered from the block summaries plus the
 // two partial blocks at the range ends, reduced across the wave with DPP.
-#define PICK_CH 16384
+#define PICK_CH 32768
 #define PICK_THREADS 1024
 #define PICK_PER_THREAD (PICK_CH / PICK_THREADS)
 
@@ -689,18 +966,15 @@ __device__ __forceinline__ bool dev_ok(double frame_samples, long long x)
     return (frame_samples + 500 > (double)x) && ((double)x > frame_samples - 500);
 }
 
-// workgroup barrier that orders LDS traffic only: global loads already issued (the
-// prefetch of the next chunk) stay in flight across it
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__restrict__ corr, const int *__restrict__ bmax, const int *__restrict__ boff,
                                                                  uint64_t n, int n1, int n0, long long mind, double frame_samples, int width,
                                                                  wfx_dev_scalars *__restrict__ s)
 {
-    __shared__ int cs[PICK_CH];
-    __shared__ int smc[PICK_CH / 64], smi[PICK_CH / 64];      // per 64-block: max correlation, first index of it
+    __shared__ __attribute__((aligned(16))) int cs[PICK_CH + 64];
+    __shared__ int2 sm2[PICK_CH / 64 + 128];                  // per 64-block: (max correlation, first index of it)
     __shared__ long long pk_s[WFX_MAX_PEAKS + 1], first_s[WFX_MAX_PEAKS + 1];
     __shared__ int done_flag, np_s, hit_s;
+    __shared__ int ok_s[WFX_MAX_PEAKS + 1];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int L = 2 * n1 + n0;
@@ -710,16 +984,25 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
     // picker state (meaningful in wave 0, kept uniform across its lanes)
     long long pos = 0;
     int val = 0, np = 1, hit = 0;
+#ifdef WFX_PICK_STATS      // diagnostic build only (python -m wefax_amd.build --pick-stats): cycle stamps per phase
+    long long n_ops = 0, n_chunks = 0, t_pick = 0, t_all = 0;
+    const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+#define PICK_STAT(x) x
+#else
+#define PICK_STAT(x)
+#endif
     if (t == 0) {
         done_flag = 0;
         first_s[0] = 0;
     }
-    int pre[PICK_PER_THREAD], pre_c = CMIN, pre_o = 0;
+    // the correlation buffer is padded to a multiple of 4 ints beyond ncorr, so whole int4s are loaded
+    int4 pre[PICK_PER_THREAD / 4];
+    int pre_c = CMIN, pre_o = 0;
     auto prefetch = [&](uint64_t p0) {
 #pragma unroll
-        for (int k = 0; k < PICK_PER_THREAD; ++k) {
-            const uint64_t g = p0 + (uint64_t)k * PICK_THREADS + t;
-            pre[k] = g < ncorr ? corr[g] : 0;
+        for (int k = 0; k < PICK_PER_THREAD / 4; ++k) {
+            const uint64_t g = p0 + ((uint64_t)k * PICK_THREADS + t) * 4;
+            pre[k] = g < ncorr ? *(const int4 *)(corr + g) : make_int4(0, 0, 0, 0);
         }
         if (t < PICK_CH / 64) {
             const uint64_t bg = p0 / 64 + t;
@@ -731,24 +1014,26 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
     for (uint64_t p0 = 0; p0 < ncorr; p0 += PICK_CH) {
         const int cnt = (int)min((uint64_t)PICK_CH, ncorr - p0);
 #pragma unroll
-        for (int k = 0; k < PICK_PER_THREAD; ++k) cs[k * PICK_THREADS + t] = pre[k];
-        if (t < PICK_CH / 64) {
-            smc[t] = pre_c;
-            smi[t] = t * 64 + pre_o;
-        }
+        for (int k = 0; k < PICK_PER_THREAD / 4; ++k) ((int4 *)cs)[k * PICK_THREADS + t] = pre[k];
+        if (t < PICK_CH / 64) sm2[t] = make_int2(pre_c, t * 64 + pre_o);
         lds_barrier();
         if (p0 + PICK_CH < ncorr) prefetch(p0 + PICK_CH);      // in flight while this chunk is scanned
         if (t < 64) {
-            long long i = (long long)p0;
-            const long long ce = (long long)p0 + cnt;
-            while (i < ce) {
-                if (i - pos > mind) {
+            PICK_STAT(const long long t0 = (long long)__builtin_amdgcn_s_memtime(); ++n_chunks;)
+            // chunk-local 32-bit coordinates; the scan state is forced into scalar registers
+            // (readfirstlane) so that the control flow of this single wave runs on the SALU
+            const int mind32 = (int)mind;
+            int rpos = __builtin_amdgcn_readfirstlane((int)(pos - (long long)p0));   // may be negative
+            int i = 0;
+            while (i < cnt) {
+                PICK_STAT(++n_ops;)
+                if (i - rpos > mind32) {
                     if (lane == 0) {
-                        pk_s[np - 1] = pos;
-                        first_s[np] = i;
+                        pk_s[np - 1] = (long long)p0 + rpos;
+                        first_s[np] = (long long)p0 + i;
                     }
-                    pos = i;
-                    val = cs[i - (long long)p0];
+                    rpos = i;
+                    val = __builtin_amdgcn_readfirstlane(cs[i]);
                     ++np;
                     ++i;
                     if (np == WFX_MAX_PEAKS) {
@@ -756,49 +1041,67 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                         break;
                     }
                 } else {
-                    long long lim = pos + mind;
-                    if (lim > ce - 1) lim = ce - 1;
-                    const int li = (int)(i - (long long)p0), ll = (int)(lim - (long long)p0);
+                    const int li = i;
+                    const int ll = min(rpos + mind32, cnt - 1);
                     const int b_lo = li >> 6, b_hi = ll >> 6;
+                    // issue every LDS read of this range first (head block, the whole blocks in
+                    // between through their summaries, tail block), then combine in index order
+                    const int jh = (b_lo << 6) + lane, jt = (b_hi << 6) + lane;
+                    const int b1 = b_lo + 1 + lane, b2 = b1 + 64;
+                    const int ch = cs[jh], ct = cs[jt];
+                    const int2 s1 = sm2[b1], s2 = sm2[b2];
                     int c = CMIN, ci = 0x7fffffff;
-                    {
-                        const int j = (b_lo << 6) + lane;                   // head (or the only) block
-                        if (j >= li && j <= ll) {
-                            c = cs[j];
-                            ci = j;
+                    if (jh >= li && jh <= ll) {
+                        c = ch;
+                        ci = jh;
+                    }
+                    if (b1 < b_hi && s1.x > c) {
+                        c = s1.x;
+                        ci = s1.y;
+                    }
+                    if (b2 < b_hi && s2.x > c) {
+                        c = s2.x;
+                        ci = s2.y;
+                    }
+                    for (int b = b2 + 64; b < b_hi; b += 64) {              // only for very long lines (60 LPM)
+                        const int2 s3 = sm2[b];
+                        if (s3.x > c) {
+                            c = s3.x;
+                            ci = s3.y;
                         }
                     }
-                    if (b_hi > b_lo) {
-                        for (int b = b_lo + 1 + lane; b < b_hi; b += 64) {  // whole blocks in between (ascending index)
-                            const int c2 = smc[b];
-                            if (c2 > c) {
-                                c = c2;
-                                ci = smi[b];
-                            }
-                        }
-                        const int j = (b_hi << 6) + lane;                   // tail block (largest indices)
-                        if (j <= ll) {
-                            const int c2 = cs[j];
-                            if (c2 > c) {
-                                c = c2;
-                                ci = j;
-                            }
-                        }
+                    if (b_hi > b_lo && jt <= ll && ct > c) {
+                        c = ct;
+                        ci = jt;
                     }
-                    int bc, bi;
-                    wave_first_argmax(c, ci, bc, bi);
-                    if (bc > val && bi != 0x7fffffff) {
+                    const int bc = wave_max_i32(c);
+                    if (bc > val) {
+                        // first occurrence: usually one lane holds the maximum; ties take the smallest index
+                        const unsigned long long tie = __ballot(c == bc);
+                        int bi;
+                        if (__popcll(tie) == 1)
+                            bi = __builtin_amdgcn_readlane(ci, __ffsll((long long)tie) - 1);
+                        else
+                            bi = wave_min_i32(c == bc ? ci : 0x7fffffff);
                         val = bc;
-                        pos = (long long)p0 + bi;
+                        rpos = bi;
                     }
-                    i = lim + 1;
+                    i = ll + 1;
                 }
             }
+            pos = (long long)p0 + rpos;
             if (hit && lane == 0) done_flag = 1;
+            PICK_STAT(t_pick += (long long)__builtin_amdgcn_s_memtime() - t0;)
         }
         lds_barrier();
         if (done_flag) break;
     }
+    PICK_STAT(t_all = (long long)__builtin_amdgcn_s_memtime() - t_begin; if (t == 0) {
+        s->dbg[0] = n_ops;
+        s->dbg[1] = n_chunks;
+        s->dbg[2] = t_pick;
+        s->dbg[3] = t_all;
+    })
     if (t == 0) {
         pk_s[np - 1] = pos;
         np_s = np;
@@ -809,18 +1112,19 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
     for (int i = t; i < np; i += PICK_THREADS) {
         s->peak_pos[i] = pk_s[i];
         s->first_pos[i] = first_s[i];
+        ok_s[i] = (i >= 1 && dev_ok(frame_samples, pk_s[i] - pk_s[i - 1])) ? 1 : 0;    // wefax.py:263-267, all gaps at once
     }
+    __syncthreads();
     if (t != 0) return;
     s->npeaks = np;
     s->hit_limit = hit_s;
     const long long *pk = pk_s;
     // ---- grouping (wefax.py:269-294) -----------------------------------------
     int nclear = 0;
-    for (int i = 1; i < np - 1; ++i)
-        if (dev_ok(frame_samples, pk[i] - pk[i - 1])) ++nclear;
+    for (int i = 1; i < np - 1; ++i) nclear += ok_s[i];
     int nclosed = 0, best_start = 0, best_len = -1, g_start = 0, g_len = 0;
     for (int i = 1; i < nclear - 1; ++i) {
-        if (dev_ok(frame_samples, pk[i] - pk[i - 1])) {
+        if (ok_s[i]) {
             if (g_len == 0) g_start = i;
             ++g_len;
         } else {
@@ -844,6 +1148,7 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
     }
     s->start_frame = start;
     s->height = (nclosed == 0 || width <= 0) ? 0 : (int)(((long long)n - start) / width);
+    PICK_STAT(s->dbg[4] = (long long)__builtin_amdgcn_s_memtime() - t_begin;)
 }
 
 int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int64_t mindistance, double frame_samples,
@@ -851,7 +1156,7 @@ int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0
 {
     if (2 * n1 + n0 > 500 || n1 < 0 || n0 < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sync pattern length out of range");
     const size_t nblk = (size_t)n / 64 + 2;
-    WFX_TRY(wfx_reserve(ctx, ctx->b_corr, (size_t)n * 4 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_corr, (size_t)n * 4 + 256));
     WFX_TRY(wfx_reserve(ctx, ctx->b_tmp2, nblk * 8));
     int *bmax = (int *)ctx->b_tmp2.p, *boff = bmax + nblk;
     WFX_LAUNCH(ctx, K_SYNC_CORR, sync_corr_kernel, dim3(wfx_stream_grid(n, CORR_CH)), dim3(256), d, n, n1, n0, (int *)ctx->b_corr.p, bmax, boff);
