@@ -74,6 +74,22 @@ def cpu_baseline(x: np.ndarray) -> dict:
             "_result": r}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner to stdout when a communicator is created; the contract
+    is ONE JSON line on stdout, so fd 1 points at stderr while the collectives warm up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,14 +97,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # WFX_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get("WFX_BENCH_FORCE_DIST") == "1"
     dist = None
     torch = None
-    if world > 1:
+    if use_dist:
         import torch  # plumbing only: rendezvous, barrier, the RCCL gather
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        with _StdoutToStderr():
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(1, dtype=torch.float64, device="cuda")
+            dist.all_reduce(warm, op=dist.ReduceOp.MAX)     # communicator creation happens here
+            dist.barrier()
+            torch.cuda.synchronize()
 
     from wefax_amd import _native as nat
     from wefax_amd.wefax import DecodeJob
@@ -99,36 +124,37 @@ def main():
     job = DecodeJob(ctx, x, 11025, 120, hilbert_mode=mode, fir_taps=4095)
 
     img_bytes = job.width * 4 * (job.n // job.width)      # upper bound (start_frame = 0)
-    gather_buf = None
-    gather_list = None
-    if world > 1:
-        gather_buf = torch.empty(img_bytes, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            gather_list = [torch.empty(img_bytes, dtype=torch.uint8, device="cuda") for _ in range(world)]
+    exchange = None
+    gathered = None
+    if use_dist:
+        from wefax_amd.multi import ImageExchange
+        exchange = ImageExchange(dist, torch, img_bytes, torch.device("cuda", local_rank))
 
     def step():
+        nonlocal gathered
         job.run()
-        if world > 1:
-            job.result()                              # waits for the stream
-            ctx.decode_copy_to_device(nat.WFX_BUF_IMAGE, gather_buf.data_ptr(), img_bytes)
-            dist.gather(gather_buf, gather_list, dst=0)
+        if use_dist:
+            info_ = job.result()                      # waits for the stream
+            nb = ctx.decode_copy_to_device(nat.WFX_BUF_IMAGE, exchange.payload_ptr, img_bytes)
+            gathered = exchange.gather(nb, info_.width)   # ONE RCCL gather per step
 
     def sync_all():
         ctx.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
+    with _StdoutToStderr():
+        for _ in range(max(args.warmup, 1 if use_dist else 0)):
+            step()
+        sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -164,6 +190,24 @@ def main():
                     "launches_per_step": dom[1][0] / args.steps,
                     "whole_path_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
 
+    # host buffers in -> host image out (PCIe both ways, upload + run + fetch); never `value`
+    pcie = None
+    if rank == 0:
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            j2 = DecodeJob(ctx, x, 11025, 120, hilbert_mode=mode, fir_taps=4095)
+            j2.run()
+            j2.fetch("image")
+        pcie = round(job.n0 * reps / (time.perf_counter() - t1) / 1e6, 1)
+        job = j2
+        info = job.result()
+    gathered_ok = None
+    if use_dist and rank == 0 and gathered is not None:
+        own = job.fetch("image")
+        gathered_ok = bool(len(gathered) == world and
+                           np.array_equal(gathered[0][0].cpu().numpy().reshape(own.shape), own))
+
     cpu = None
     parity = None
     if rank == 0 and not args.no_cpu:
@@ -195,14 +239,16 @@ def main():
                                     if not args.short else "SHORT debugging capture"),
                        "captures_per_gpu": 1, "hilbert": args.mode,
                        "image": [info.width, 4 * info.height], "start_frame": int(info.start_frame),
-                       "parallelism": "1 capture per GPU" + (", RCCL gather of images to rank 0" if world > 1 else "")},
+                       "parallelism": "1 capture per GPU" + (", RCCL gather of images to rank 0" if use_dist else "")},
             "roofline": roofline,
+            "pcie_inclusive_msamples_s": pcie,
+            "rccl_gather_checked": gathered_ok,
             "cpu_baseline": cpu,
             "parity_vs_oracle": parity,
             "kernels": kernels,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
