@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--noise", type=float, default=0.05, help="AWGN sigma in full-scale units")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--short", action="store_true", help="60-line capture (debugging only)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="captures decoded concurrently per GPU, one native context (= HIP stream) each; "
+                         "BASELINE configs[4] uses 8 per GPU with mixed 120/240 LPM, IOC576/288 members")
     return ap.parse_args()
 
 
@@ -118,10 +121,18 @@ def main():
     from wefax_amd import _native as nat
     from wefax_amd.wefax import DecodeJob
 
+    mode = nat.WFX_HILBERT_FFT if args.mode == "fft" else nat.WFX_HILBERT_FIR
     x = make_capture(seed=rank, noise=args.noise, short=args.short)
     ctx = nat.Context(local_rank)
-    mode = nat.WFX_HILBERT_FFT if args.mode == "fft" else nat.WFX_HILBERT_FIR
     job = DecodeJob(ctx, x, 11025, 120, hilbert_mode=mode, fir_taps=4095)
+    # extra members of a batch: BASELINE configs[4] recipe (mixed LPM / IOC), own context and stream each
+    extra = []
+    if args.batch > 1:
+        from wefax_amd import synth
+        for b in range(1, args.batch):
+            xb, lpm_b = synth.config_c5_member(rank * args.batch + b, noise=args.noise)
+            cb = nat.Context(local_rank)
+            extra.append((cb, DecodeJob(cb, xb, 11025, lpm_b, hilbert_mode=mode, fir_taps=4095)))
 
     img_bytes = job.width * 4 * (job.n // job.width)      # upper bound (start_frame = 0)
     exchange = None
@@ -133,6 +144,8 @@ def main():
     def step():
         nonlocal gathered
         job.run()
+        for _, jb in extra:
+            jb.run()
         if use_dist:
             info_ = job.result()                      # waits for the stream
             nb = ctx.decode_copy_to_device(nat.WFX_BUF_IMAGE, exchange.payload_ptr, img_bytes)
@@ -140,6 +153,8 @@ def main():
 
     def sync_all():
         ctx.sync()
+        for cb, _ in extra:
+            cb.sync()
         if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
@@ -220,7 +235,7 @@ def main():
                   "digitalized_mismatches": int(np.count_nonzero(job.fetch("digitalized") != ref["digitalized"]))}
 
     if rank == 0:
-        total_samples = job.n0 * world * args.steps
+        total_samples = (job.n0 + sum(jb.n0 for _, jb in extra)) * world * args.steps
         out = {
             "metric": "Msamples/s demod->pixel",
             "value": round(total_samples / dt / 1e6, 2),
@@ -237,7 +252,7 @@ def main():
             "config": {"workload": ("synthetic 10-min 11.025 kHz WEFAX capture (BASELINE configs[1]): "
                                     f"{job.n0} int16 mono samples, 120 LPM, AWGN sigma {args.noise} FS"
                                     if not args.short else "SHORT debugging capture"),
-                       "captures_per_gpu": 1, "hilbert": args.mode,
+                       "captures_per_gpu": args.batch, "hilbert": args.mode,
                        "image": [info.width, 4 * info.height], "start_frame": int(info.start_frame),
                        "parallelism": "1 capture per GPU" + (", RCCL gather of images to rank 0" if use_dist else "")},
             "roofline": roofline,

@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                                                                  wfx_dev_scalars *__restrict__ s)
 {
     __shared__ __attribute__((aligned(16))) int cs[PICK_CH + 64];
-    __shared__ int2 sm2[PICK_CH / 64 + 128];                  // per 64-block: (max correlation, first index of it)
+    __shared__ int2 sm2[PICK_CH / 64 + 192];                  // per 64-block: (max correlation, first index of it)
     __shared__ long long pk_s[WFX_MAX_PEAKS + 1], first_s[WFX_MAX_PEAKS + 1];
     __shared__ int done_flag, np_s, hit_s;
     __shared__ int ok_s[WFX_MAX_PEAKS + 1];
@@ -1046,34 +1046,25 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                     const int b_lo = li >> 6, b_hi = ll >> 6;
                     // issue every LDS read of this range first (head block, the whole blocks in
                     // between through their summaries, tail block), then combine in index order
+                    // (branch-free: this loop is a single wave's dependent instruction chain)
                     const int jh = (b_lo << 6) + lane, jt = (b_hi << 6) + lane;
-                    const int b1 = b_lo + 1 + lane, b2 = b1 + 64;
+                    const int b1 = b_lo + 1 + lane, b2 = b1 + 64, b3 = b2 + 64;   // up to 192 whole blocks: mind <= 12000
                     const int ch = cs[jh], ct = cs[jt];
-                    const int2 s1 = sm2[b1], s2 = sm2[b2];
-                    int c = CMIN, ci = 0x7fffffff;
-                    if (jh >= li && jh <= ll) {
-                        c = ch;
-                        ci = jh;
-                    }
-                    if (b1 < b_hi && s1.x > c) {
-                        c = s1.x;
-                        ci = s1.y;
-                    }
-                    if (b2 < b_hi && s2.x > c) {
-                        c = s2.x;
-                        ci = s2.y;
-                    }
-                    for (int b = b2 + 64; b < b_hi; b += 64) {              // only for very long lines (60 LPM)
-                        const int2 s3 = sm2[b];
-                        if (s3.x > c) {
-                            c = s3.x;
-                            ci = s3.y;
-                        }
-                    }
-                    if (b_hi > b_lo && jt <= ll && ct > c) {
-                        c = ct;
-                        ci = jt;
-                    }
+                    const int2 s1 = sm2[b1], s2 = sm2[b2], s3 = sm2[b3];
+                    const bool vh = (jh >= li) & (jh <= ll);
+                    int c = vh ? ch : CMIN, ci = vh ? jh : 0x7fffffff;
+                    const bool t1 = (b1 < b_hi) & (s1.x > c);
+                    c = t1 ? s1.x : c;
+                    ci = t1 ? s1.y : ci;
+                    const bool t2 = (b2 < b_hi) & (s2.x > c);
+                    c = t2 ? s2.x : c;
+                    ci = t2 ? s2.y : ci;
+                    const bool t3 = (b3 < b_hi) & (s3.x > c);
+                    c = t3 ? s3.x : c;
+                    ci = t3 ? s3.y : ci;
+                    const bool tt = (b_hi > b_lo) & (jt <= ll) & (ct > c);
+                    c = tt ? ct : c;
+                    ci = tt ? jt : ci;
                     const int bc = wave_max_i32(c);
                     if (bc > val) {
                         // first occurrence: usually one lane holds the maximum; ties take the smallest index
@@ -1155,6 +1146,7 @@ int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0
                       int width, wfx_dev_scalars *d_scal)
 {
     if (2 * n1 + n0 > 500 || n1 < 0 || n0 < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sync pattern length out of range");
+    if (mindistance < 0 || mindistance > 12000) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "peak distance %lld out of range [0, 12000]", (long long)mindistance);
     const size_t nblk = (size_t)n / 64 + 2;
     WFX_TRY(wfx_reserve(ctx, ctx->b_corr, (size_t)n * 4 + 256));
     WFX_TRY(wfx_reserve(ctx, ctx->b_tmp2, nblk * 8));
