@@ -165,6 +165,34 @@ int wfx_decode_device_ptr(wfx_ctx *ctx, int buffer_id, void **dev_ptr, size_t *b
  * collective) and wait for it; at most `capacity` bytes, *copied receives the size */
 int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity, size_t *copied);
 
+/* ---- device-resident stage calls (sample-range sharding of one capture) -------
+ * Building blocks for decoding a slice [g0, g0+n) of a long capture on one GPU with
+ * halos on both sides: every call takes DEVICE pointers obtained
+ * from wfx_dev_malloc and runs on the context's stream.  The FIR forms are the
+ * halo-local operators; results within the stated margin of the slice ends are invalid
+ * and must be covered by the caller's halo. */
+int wfx_dev_malloc(wfx_ctx *ctx, size_t bytes, void **dev_ptr);
+int wfx_dev_free(wfx_ctx *ctx, void *dev_ptr);
+int wfx_dev_upload(wfx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int wfx_dev_download(wfx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* a6 on a segment: 49-tap symmetric FIR == filtfilt away from the ends (valid for 24 <= i < n-24); with
+ * edge_flags bit 0 / bit 1 the segment starts / ends at the capture's true start / end and gets filtfilt's exact edge */
+int wfx_d_notch_fir(wfx_ctx *ctx, const int16_t *in_dev, size_t n, const double b[3], const double a[3], double *out_dev,
+                    int edge_flags);
+/* a7: |x + i H| with the `taps`-lag circular Hilbert kernel of a signal of n_global samples; valid (taps-1)/2 away from the ends */
+int wfx_d_fir_envelope(wfx_ctx *ctx, const double *x_dev, size_t n, size_t n_global, int taps, double *env_raw_dev);
+int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev);
+/* a8: one level of the radix select: hist_dev[q*2048 + digit] += count over values whose bits above the level equal prefix[q] */
+int wfx_d_select_hist(wfx_ctx *ctx, const double *env_dev, size_t n, int level, const uint64_t prefix[4], uint32_t *hist_dev);
+int wfx_d_quantise(wfx_ctx *ctx, const double *env_dev, size_t n, double low, double high, uint8_t *out_dev, uint64_t *nan_count);
+/* a9 on a device-resident stream: fills peaks, phasing, start_frame, no_group, height = (n_total - start_frame) / width */
+int wfx_d_sync_search(wfx_ctx *ctx, const uint8_t *d_dev, size_t n, size_t n_total, int n1, int n0_gap, int64_t mindistance,
+                      double frame_samples, int width, wfx_decode_info *info);
+/* a10: output rows 4*y0 .. 4*(y0+rows) of the image of a capture with h_total lines whose line 0 starts at sample
+ * `start`; d_dev[0] is global sample g0 (lines y0-2 .. y0+rows+1 must lie inside the slice) */
+int wfx_d_image_rows(wfx_ctx *ctx, const uint8_t *d_dev, size_t n, uint64_t g0, uint64_t start, int width, int h_total, int y0,
+                     int rows, uint8_t *img_dev);
+
 /* ---- measurement ------------------------------------------------------ */
 /* HIP-event stopwatch on the context's stream */
 int wfx_timer_start(wfx_ctx *ctx);

@@ -27,6 +27,9 @@ SYMBOLS = [
     "wfx_sync_peaks", "wfx_lines_to_image", "wfx_decode_upload", "wfx_decode_run",
     "wfx_decode_result", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device",
+    "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download",
+    "wfx_d_notch_fir", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
     "wfx_profile_kernel_count", "wfx_profile_kernel_name", "wfx_profile_get",
 ]
@@ -115,6 +118,17 @@ def load():
     lib.wfx_decode_fetch.argtypes = [vp, i, vp, sz]
     lib.wfx_decode_device_ptr.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz)]
     lib.wfx_decode_copy_to_device.argtypes = [vp, i, vp, sz, C.POINTER(sz)]
+    lib.wfx_dev_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.wfx_dev_free.argtypes = [vp, vp]
+    lib.wfx_dev_upload.argtypes = [vp, vp, vp, sz]
+    lib.wfx_dev_download.argtypes = [vp, vp, vp, sz]
+    lib.wfx_d_notch_fir.argtypes = [vp, vp, sz, dp, dp, vp, i]
+    lib.wfx_d_fir_envelope.argtypes = [vp, vp, sz, sz, i, vp]
+    lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
+    lib.wfx_d_select_hist.argtypes = [vp, vp, sz, i, C.POINTER(C.c_uint64), vp]
+    lib.wfx_d_quantise.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, C.POINTER(C.c_uint64)]
+    lib.wfx_d_sync_search.argtypes = [vp, vp, sz, sz, i, i, C.c_int64, C.c_double, i, C.POINTER(DecodeInfo)]
+    lib.wfx_d_image_rows.argtypes = [vp, vp, sz, C.c_uint64, C.c_uint64, i, i, i, i, vp]
     lib.wfx_timer_start.argtypes = [vp]
     lib.wfx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.wfx_profile_enable.argtypes = [vp, i]
@@ -267,6 +281,55 @@ class Context:
         nb = C.c_size_t(0)
         self._check(self.lib.wfx_decode_copy_to_device(self.h, buffer_id, C.c_void_p(dst_dev_ptr), capacity, C.byref(nb)))
         return nb.value
+
+    # ---- device-resident building blocks (wefax_amd/sharded.py) ----------------------
+    def dev_malloc(self, nbytes: int) -> int:
+        p = C.c_void_p(0)
+        self._check(self.lib.wfx_dev_malloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr: int):
+        self._check(self.lib.wfx_dev_free(self.h, C.c_void_p(ptr)))
+
+    def dev_upload(self, ptr: int, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        self._check(self.lib.wfx_dev_upload(self.h, C.c_void_p(ptr), _ptr(a), a.nbytes))
+
+    def dev_download(self, ptr: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self._check(self.lib.wfx_dev_download(self.h, _ptr(out), C.c_void_p(ptr), out.nbytes))
+        return out
+
+    def d_notch_fir(self, in_ptr: int, n: int, b, a, out_ptr: int, edge_flags: int = 0):
+        bb = (C.c_double * 3)(*[float(v) for v in b])
+        aa = (C.c_double * 3)(*[float(v) for v in a])
+        self._check(self.lib.wfx_d_notch_fir(self.h, C.c_void_p(in_ptr), n, bb, aa, C.c_void_p(out_ptr), edge_flags))
+
+    def d_fir_envelope(self, x_ptr: int, n: int, n_global: int, taps: int, out_ptr: int):
+        self._check(self.lib.wfx_d_fir_envelope(self.h, C.c_void_p(x_ptr), n, n_global, taps, C.c_void_p(out_ptr)))
+
+    def d_median5(self, in_ptr: int, n: int, out_ptr: int):
+        self._check(self.lib.wfx_d_median5(self.h, C.c_void_p(in_ptr), n, C.c_void_p(out_ptr)))
+
+    def d_select_hist(self, env_ptr: int, n: int, level: int, prefixes, hist_ptr: int):
+        pf = (C.c_uint64 * 4)(*[int(v) for v in prefixes])
+        self._check(self.lib.wfx_d_select_hist(self.h, C.c_void_p(env_ptr), n, level, pf, C.c_void_p(hist_ptr)))
+
+    def d_quantise(self, env_ptr: int, n: int, low: float, high: float, out_ptr: int) -> int:
+        nan = C.c_uint64(0)
+        self._check(self.lib.wfx_d_quantise(self.h, C.c_void_p(env_ptr), n, low, high, C.c_void_p(out_ptr), C.byref(nan)))
+        return int(nan.value)
+
+    def d_sync_search(self, d_ptr: int, n: int, n_total: int, n1: int, n0: int, mindistance: int, frame_samples: float,
+                      width: int) -> DecodeInfo:
+        info = DecodeInfo()
+        self._check(self.lib.wfx_d_sync_search(self.h, C.c_void_p(d_ptr), n, n_total, n1, n0, mindistance, frame_samples,
+                                               width, C.byref(info)))
+        return info
+
+    def d_image_rows(self, d_ptr: int, n: int, g0: int, start: int, width: int, h_total: int, y0: int, rows: int, img_ptr: int):
+        self._check(self.lib.wfx_d_image_rows(self.h, C.c_void_p(d_ptr), n, g0, start, width, h_total, y0, rows,
+                                              C.c_void_p(img_ptr)))
 
     def sync(self):
         self._check(self.lib.wfx_sync(self.h))

@@ -365,6 +365,142 @@ int wfx_decode_device_ptr(wfx_ctx *ctx, int buffer_id, void **dev_ptr, size_t *b
     return buffer_of(ctx, buffer_id, dev_ptr, bytes);
 }
 
+// ---- device-resident stage calls (sample-range sharding) ------------------------------
+int wfx_dev_malloc(wfx_ctx *ctx, size_t bytes, void **dev_ptr)
+{
+    CHECK_CTX(ctx);
+    if (!dev_ptr) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    *dev_ptr = nullptr;
+    hipError_t e = hipMalloc(dev_ptr, bytes < 256 ? 256 : bytes + 256);     // padded: kernels may read a few bytes past a byte stream
+    if (e != hipSuccess) return wfx_fail(ctx, WFX_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return 0;
+}
+
+int wfx_dev_free(wfx_ctx *ctx, void *dev_ptr)
+{
+    CHECK_CTX(ctx);
+    if (!dev_ptr) return 0;
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WFX_HIP(ctx, hipFree(dev_ptr));
+    return 0;
+}
+
+int wfx_dev_upload(wfx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    if (bytes && (!dst_dev || !src_host)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    WFX_TRY(h2d(ctx, dst_dev, src_host, bytes));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int wfx_dev_download(wfx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    if (bytes && (!dst_host || !src_dev)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return d2h_sync(ctx, dst_host, src_dev, bytes);
+}
+
+int wfx_d_notch_fir(wfx_ctx *ctx, const int16_t *in_dev, size_t n, const double b[3], const double a[3], double *out_dev, int edge_flags)
+{
+    CHECK_CTX(ctx);
+    if (!in_dev || !out_dev || !b || !a) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return wfx_dev_notch_fir_only(ctx, in_dev, n, b, a, out_dev, edge_flags);
+}
+
+int wfx_d_fir_envelope(wfx_ctx *ctx, const double *x_dev, size_t n, size_t n_global, int taps, double *env_raw_dev)
+{
+    CHECK_CTX(ctx);
+    if (!x_dev || !env_raw_dev || n == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null or empty buffer");
+    return wfx_dev_hilbert_env_fir(ctx, x_dev, n, taps, env_raw_dev, n_global);
+}
+
+int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (!in_dev || !out_dev) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return wfx_dev_median5(ctx, in_dev, n, out_dev, nullptr);
+}
+
+int wfx_d_select_hist(wfx_ctx *ctx, const double *env_dev, size_t n, int level, const uint64_t prefix[4], uint32_t *hist_dev)
+{
+    CHECK_CTX(ctx);
+    if (!env_dev || !prefix || !hist_dev) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return wfx_dev_select_level(ctx, env_dev, n, level, prefix, hist_dev);
+}
+
+int wfx_d_quantise(wfx_ctx *ctx, const double *env_dev, size_t n, double low, double high, uint8_t *out_dev, uint64_t *nan_count)
+{
+    CHECK_CTX(ctx);
+    if (!env_dev || !out_dev) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (nan_count) *nan_count = 0;
+    if (n == 0) return 0;
+    ctx->ran = false;             // the context's scalar block is reused: a previous fused decode is no longer fetchable
+    WFX_TRY(ensure_scal(ctx));
+    memset(ctx->h_scal, 0, sizeof(wfx_dev_scalars));
+    ctx->h_scal->low = low;
+    ctx->h_scal->high = high;
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    WFX_TRY(h2d(ctx, ds, ctx->h_scal, sizeof(wfx_dev_scalars)));
+    WFX_TRY(wfx_dev_quantise(ctx, env_dev, n, ds, out_dev, ds));
+    WFX_TRY(d2h_sync(ctx, ctx->h_scal, ds, sizeof(wfx_dev_scalars)));
+    if (nan_count) *nan_count = ctx->h_scal->nan_count;
+    return 0;
+}
+
+static void fill_info(wfx_decode_info *info, const wfx_dev_scalars &s, uint64_t n, int width)
+{
+    memset(info, 0, sizeof *info);
+    info->n = n;
+    info->low = s.low;
+    info->high = s.high;
+    info->nan_count = s.nan_count;
+    info->npeaks = s.npeaks;
+    info->hit_limit = s.hit_limit;
+    info->no_group = s.no_group;
+    info->n_phasing = s.n_phasing;
+    info->start_frame = s.start_frame;
+    info->width = width;
+    info->height = s.height;
+    for (int i = 0; i <= WFX_MAX_PEAKS; ++i) {
+        info->peak_pos[i] = s.peak_pos[i];
+        info->first_pos[i] = s.first_pos[i];
+        info->phasing[i] = s.phasing[i];
+    }
+}
+
+int wfx_d_sync_search(wfx_ctx *ctx, const uint8_t *d_dev, size_t n, size_t n_total, int n1, int n0_gap, int64_t mindistance, double frame_samples,
+                      int width, wfx_decode_info *info)
+{
+    CHECK_CTX(ctx);
+    if (!d_dev || !info) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    if (width <= 0 || n_total < n) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad width or total length");
+    ctx->ran = false;
+    WFX_TRY(ensure_scal(ctx));
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+    WFX_TRY(wfx_dev_sync_pick(ctx, d_dev, n, n1, n0_gap, mindistance, frame_samples, width, ds));
+    WFX_TRY(d2h_sync(ctx, ctx->h_scal, ds, sizeof(wfx_dev_scalars)));
+    fill_info(info, *ctx->h_scal, n_total, width);
+    // the picker saw only the first n samples: the line count refers to the whole capture
+    info->height = ctx->h_scal->no_group ? 0 : (int)((n_total - (uint64_t)ctx->h_scal->start_frame) / (uint64_t)width);
+    return 0;
+}
+
+int wfx_d_image_rows(wfx_ctx *ctx, const uint8_t *d_dev, size_t n, uint64_t g0, uint64_t start, int width, int h_total, int y0, int rows,
+                     uint8_t *img_dev)
+{
+    CHECK_CTX(ctx);
+    if (!d_dev || !img_dev) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (rows <= 0) return 0;
+    // the rows draw on source lines max(y0-2,0) .. min(y0+rows+1, h_total-1): they must lie inside the slice
+    const long long ylo = y0 - 2 < 0 ? 0 : y0 - 2, yhi = y0 + rows + 1 > h_total - 1 ? h_total - 1 : y0 + rows + 1;
+    const unsigned long long first = start + (unsigned long long)ylo * width, last = start + (unsigned long long)(yhi + 1) * width;
+    if (first < g0 || last > g0 + n) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "image rows need samples [%llu, %llu) outside the slice [%llu, %llu)",
+                                                     first, last, (unsigned long long)g0, (unsigned long long)(g0 + n));
+    return wfx_dev_image_rows(ctx, d_dev, g0, start, width, h_total, y0, rows, img_dev);
+}
+
 int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity, size_t *copied)
 {
     CHECK_CTX(ctx);

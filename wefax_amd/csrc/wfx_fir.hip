@@ -88,8 +88,9 @@ fir_hilbert_kernel(const double *__restrict__ xf, long long n, const float *__re
     }
 }
 
-int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps, double *env_raw)
+int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps, double *env_raw, uint64_t n_global)
 {
+    const uint64_t nk = n_global ? n_global : n;      // the kernel is that of the WHOLE signal
     if (taps < 3 || (taps & 1) == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fir_taps must be odd and >= 3");
     int half = (taps - 1) / 2;
     if ((uint64_t)half > (n - 1) / 2) half = (int)((n - 1) / 2);      // kernel cannot be longer than the signal
@@ -100,11 +101,11 @@ int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps,
     const int ntap_padded = 8 + 8 * usteps + 24;
     const int halo = ((half + 16 + 16 * 0) + 15 + 16) & ~15;   // >= half + 16, multiple of 16
     std::vector<float> h((size_t)ntap_padded, 0.f);
-    const double N = (double)n;
+    const double N = (double)nk;
     for (int i = 0; i < ntap; ++i) {
         const double m = 2.0 * i + 1.0;
         double v;
-        if ((n & 1) == 0)
+        if ((nk & 1) == 0)
             v = (2.0 / N) / tan(M_PI * m / N);
         else
             v = (1.0 / N) / tan(M_PI * m / (2.0 * N));

@@ -202,6 +202,11 @@ int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0
                       wfx_dev_scalars *d_scal);
 int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max,
                   const wfx_dev_scalars *d_scal, uint8_t *img);
+int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t start, int w, int h_total, int y0, int rows,
+                       uint8_t *img);
+int wfx_dev_notch_fir_only(wfx_ctx *ctx, const int16_t *in, uint64_t n, const double b[3], const double a[3], double *out,
+                           int edge_flags);
+int wfx_dev_select_level(wfx_ctx *ctx, const double *env, uint64_t n, int level, const uint64_t prefix[4], unsigned *hist);
 
 // wfx_fir.hip
-int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps, double *env_raw);
+int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps, double *env_raw, uint64_t n_global = 0);

@@ -97,7 +97,8 @@ __device__ __forceinline__ double biquad_step(const notch_coef &c, double xi, do
 }
 
 template <typename TIN>
-__global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x, uint64_t n, notch_coef c, double *__restrict__ y, unsigned interior_blocks)
+__global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x, uint64_t n, notch_coef c, double *__restrict__ y, unsigned interior_blocks,
+                                                       int exact_edges)
 {
     constexpr int TLEN = 1024 + 2 * NOTCH_K;
     constexpr int NPRE = (TLEN + 255) / 256;
@@ -107,14 +108,17 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
     if (blockIdx.x < interior_blocks) {
         // interior outputs [lo, hi) = [EDGE, n - EDGE); the next tile's samples are fetched
         // into registers while the current tile is filtered
-        const uint64_t lo = NOTCH_EDGE, hi = n - NOTCH_EDGE;
+        // exact_edges: bit 0 = the segment starts at the true start of the capture, bit 1 = it ends at the
+        // true end (filtfilt's odd extension + lfilter_zi there); otherwise the FIR form runs up to K
+        // samples from that end and the caller's halo covers the rest
+        const uint64_t lo = (exact_edges & 1) ? NOTCH_EDGE : NOTCH_K, hi = (exact_edges & 2) ? n - NOTCH_EDGE : n - NOTCH_K;
         const uint64_t step = (uint64_t)interior_blocks * 1024ull;
         double pre[NPRE];
         auto prefetch = [&](uint64_t base) {
 #pragma unroll
             for (int k = 0; k < NPRE; ++k) {
                 const int i = t + 256 * k;
-                const uint64_t src = base - NOTCH_K + i;       // >= EDGE - K >= 0
+                const uint64_t src = base - NOTCH_K + i;       // >= lo - K >= 0
                 pre[k] = (i < TLEN && src < n) ? (double)x[src] : 0.0;
             }
         };
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int j = half * 512 + 2 * t;                 // even -> same padded group of four
-                const uint64_t o = base + j;                      // base is even: 16-byte aligned
+                const uint64_t o = base + j;                      // base is even (64 or 24 + k*1024): 16-byte aligned
                 const double v0 = tile[j + (j >> 2)], v1 = tile[j + 1 + ((j + 1) >> 2)];
                 if (o + 1 < hi)
                     *(double2 *)(y + o) = make_double2(v0, v1);
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
         return;
     }
     // ---- edge workgroup -------------------------------------------------------
-    if (n < NOTCH_SMALL) {
+    if (n < NOTCH_SMALL) {      // (only reached through wfx_dev_notch: both ends are true edges)
         // whole signal with the exact recurrence (one thread)
         if (t == 0) {
             double *e = ebuf[0];
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
         ebuf[1][i] = i < L ? (double)x[n - L + i] : notch_ext_right<TIN>(x, n, i - L + 1);
     }
     __syncthreads();
-    if (t == 0 || t == 64) {
+    if ((t == 0 && (exact_edges & 1)) || (t == 64 && (exact_edges & 2))) {
         double *e = ebuf[t == 0 ? 0 : 1];
         // left: exact forward start, backward started SETTLE samples to the right with a zero state
         // right: forward started SETTLE samples early with a zero state, exact backward start
@@ -215,17 +219,15 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
         }
     }
     __syncthreads();
-    if (t < NOTCH_EDGE)
-        y[t] = ebuf[0][NOTCH_PAD + t];
-    else if (t < 2 * NOTCH_EDGE)
-        y[n - NOTCH_EDGE + (t - NOTCH_EDGE)] = ebuf[1][L - NOTCH_EDGE + (t - NOTCH_EDGE)];
+    if (t < NOTCH_EDGE) {
+        if (exact_edges & 1) y[t] = ebuf[0][NOTCH_PAD + t];
+    } else if (t < 2 * NOTCH_EDGE) {
+        if (exact_edges & 2) y[n - NOTCH_EDGE + (t - NOTCH_EDGE)] = ebuf[1][L - NOTCH_EDGE + (t - NOTCH_EDGE)];
+    }
 }
 
-int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out)
+static void notch_prepare(notch_coef &c, const double b[3], const double a[3])
 {
-    if (n <= NOTCH_PAD)
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "The length of the input vector x must be greater than padlen, which is 9.");
-    notch_coef c;
     for (int i = 0; i < 3; ++i) {
         c.b[i] = b[i] / a[0];
         c.a[i] = a[i] / a[0];
@@ -255,14 +257,34 @@ int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const d
             c.g[k] = s;
         }
     }
+}
+
+int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out)
+{
+    if (n <= NOTCH_PAD)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "The length of the input vector x must be greater than padlen, which is 9.");
+    notch_coef c;
+    notch_prepare(c, b, a);
     unsigned ib = 0;
     if (n >= NOTCH_SMALL) {
         ib = wfx_stream_grid(n - 2 * NOTCH_EDGE, 1024);
     }
     if (in_kind == WFX_IN_I16_MONO)
-        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + 1), dim3(256), (const short *)in, n, c, out, ib);
+        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + 1), dim3(256), (const short *)in, n, c, out, ib, 3);
     else
-        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<double>, dim3(ib + 1), dim3(256), (const double *)in, n, c, out, ib);
+        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<double>, dim3(ib + 1), dim3(256), (const double *)in, n, c, out, ib, 3);
+    return 0;
+}
+
+// segment of a longer capture: exact filtfilt edges only where the segment touches the capture's
+// true start (edge_flags bit 0) / end (bit 1); elsewhere the FIR form, valid K samples from the end
+int wfx_dev_notch_fir_only(wfx_ctx *ctx, const int16_t *in, uint64_t n, const double b[3], const double a[3], double *out, int edge_flags)
+{
+    if (n < NOTCH_SMALL) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "segment of %llu samples is too short for the notch", (unsigned long long)n);
+    notch_coef c;
+    notch_prepare(c, b, a);
+    const unsigned ib = wfx_stream_grid(n - 2 * NOTCH_K, 1024);
+    WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const short *)in, n, c, out, ib, edge_flags & 3);
     return 0;
 }
 
@@ -452,6 +474,55 @@ __device__ __forceinline__ void sel_owners(const unsigned long long *pfx, int *o
             }
         owner[q] = o;
     }
+}
+
+// one generic level with the prefixes given by the host (sharded decode: the histograms of
+// all ranks are summed between the levels, the host picks the digits)
+__global__ void __launch_bounds__(256) select_level_kernel(const double *__restrict__ v, uint64_t n, int level, unsigned long long p0, unsigned long long p1,
+                                                          unsigned long long p2, unsigned long long p3, unsigned *__restrict__ ghist)
+{
+    __shared__ unsigned h[4][SEL_BINS];
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 4 * SEL_BINS; i += 256) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const unsigned long long pfx[4] = {p0, p1, p2, p3};
+    int owner[4];
+    for (int q = 0; q < 4; ++q) {
+        owner[q] = q;
+        for (int p = 0; p < q; ++p)
+            if (level == 0 || pfx[p] == pfx[q]) {
+                owner[q] = p;
+                break;
+            }
+    }
+    const int shift = sel_shift(level), width = sel_width(level);
+    const unsigned dmask = (1u << width) - 1;
+    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    const uint64_t nround = (n + stride - 1) / stride;
+    for (uint64_t it = 0; it < nround; ++it) {
+        const uint64_t i = it * stride + blockIdx.x * 256ull + t;
+        const bool valid = i < n;
+        const unsigned long long key = valid ? f64_key(v[i]) : 0ull;
+        const unsigned digit = (unsigned)(key >> shift) & dmask;
+        const unsigned long long hi = level == 0 ? 0ull : (key >> (shift + width));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (owner[q] == q) sel_count(h[q], digit, valid && (level == 0 || hi == pfx[q]), lane);
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q)        // aliases get a copy so that the host can treat the 4 queries independently
+        for (int i = t; i < SEL_BINS; i += 256) {
+            const unsigned c = h[owner[q]][i];
+            if (c) atomicAdd(&ghist[q * SEL_BINS + i], c);
+        }
+}
+
+int wfx_dev_select_level(wfx_ctx *ctx, const double *env, uint64_t n, int level, const uint64_t prefix[4], unsigned *hist)
+{
+    if (level < 0 || level >= SEL_LEVELS) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "select level %d out of range", level);
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_level_kernel, dim3(wfx_stream_grid(n, 4096)), dim3(256), env, n, level, (unsigned long long)prefix[0],
+               (unsigned long long)prefix[1], (unsigned long long)prefix[2], (unsigned long long)prefix[3], hist);
+    return 0;
 }
 
 // stand-alone level 0 (used when the envelope was not produced by a kernel that fuses it)
@@ -1212,13 +1283,17 @@ __device__ __forceinline__ void load8_any(const uint8_t *p, unsigned &lo, unsign
     hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
 }
 
+// (h, start) come from the device scalars of a fused decode (s != nullptr) or from the arguments
+// (sharded decode: this GPU renders lines [y0, y0 + gridDim.x) of an image of h_arg lines; d points
+// at global sample 0 of the stream, possibly virtually: only the lines' own bytes are touched)
 __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ d, uint64_t n, int w, const wfx_dev_scalars *__restrict__ s,
-                                                   uint8_t *__restrict__ img)
+                                                   uint8_t *__restrict__ img_base, int h_arg, long long start_arg, int y0)
 {
-    const int h = s->height;
-    const int y = blockIdx.x;
+    const int h = s ? s->height : h_arg;
+    const int y = y0 + (int)blockIdx.x;
     if (y >= h) return;
-    const uint64_t start = (uint64_t)s->start_frame;
+    const uint64_t start = s ? (uint64_t)s->start_frame : (uint64_t)start_arg;
+    uint8_t *img = img_base - (uint64_t)4 * y0 * w;          // row 4*y0 is the first row of the local buffer
     // coefficients of the four output rows (row-uniform, computed redundantly per thread)
     int ymin[4], cnt[4], kk[4][5];
 #pragma unroll
@@ -1275,6 +1350,15 @@ __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ 
 int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max, const wfx_dev_scalars *d_scal, uint8_t *img)
 {
     if (h_max <= 0 || w <= 0) return 0;
-    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max), dim3(256), d, n, w, d_scal, img);
+    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max), dim3(256), d, n, w, d_scal, img, 0, 0ll, 0);
+    return 0;
+}
+
+int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t start, int w, int h_total, int y0, int rows, uint8_t *img)
+{
+    if (rows <= 0) return 0;
+    if (w <= 0 || y0 < 0 || y0 + rows > h_total) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "image rows out of range");
+    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)rows), dim3(256), d - g0, (uint64_t)0, w, (const wfx_dev_scalars *)nullptr, img, h_total,
+               (long long)start, y0);
     return 0;
 }
