@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--noise", type=float, default=0.05, help="AWGN sigma in full-scale units")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--short", action="store_true", help="60-line capture (debugging only)")
+    ap.add_argument("--shard", action="store_true",
+                    help="sample-range sharding of ONE capture of n_gpus x 10 minutes (halo FIR path, 6 histogram "
+                         "all-reduces + 1 image gather per step) instead of one capture per GPU")
     ap.add_argument("--batch", type=int, default=1,
                     help="captures decoded concurrently per GPU, one native context (= HIP stream) each; "
                          "BASELINE configs[4] uses 8 per GPU with mixed 120/240 LPM, IOC576/288 members")
@@ -82,15 +85,76 @@ class _StdoutToStderr:
     is ONE JSON line on stdout, so fd 1 points at stderr while the collectives warm up."""
 
     def __enter__(self):
+        import ctypes
+        self.libc = ctypes.CDLL(None)
         sys.stdout.flush()
+        self.libc.fflush(None)
         self.saved = os.dup(1)
         os.dup2(2, 1)
         return self
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        self.libc.fflush(None)          # RCCL printf()s into C stdio, which is fully buffered on a pipe
         os.dup2(self.saved, 1)
         os.close(self.saved)
+
+
+def bench_sharded(args, world, rank, local_rank, use_dist, dist, torch, nat):
+    """One capture of world x 10 minutes, sharded by sample range (wefax_amd/sharded.py)."""
+    from wefax_amd import sharded, synth
+    from wefax_amd.multi import ImageExchange
+    lines = 1300 * world - 100 if not args.short else 400 * world
+    x = synth.synth_capture(11025.0, noise=args.noise, seed=0, image_lines=lines - 60, phasing_lines=60,
+                            **(dict(start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0) if args.short else {}))
+    n = int(x.shape[0])
+    ctx = nat.Context(local_rank)
+    comm = sharded.TorchComm(dist, torch, torch.device("cuda", local_rank)) if use_dist else sharded.LocalComm()
+    dec = sharded.ShardedDecoder(sharded.HipStages(ctx), x, n, world, rank, 120, 4095)
+    p = dec.plan
+    exchange = ImageExchange(dist, torch, 4 * dec.width * ((p.o1 - p.o0) // dec.width + 4),
+                             torch.device("cuda", local_rank)) if use_dist else None
+
+    def step():
+        return dec.run(comm, exchange)
+
+    def sync_all():
+        ctx.sync()
+        if use_dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with _StdoutToStderr():
+        for _ in range(max(args.warmup, 1)):
+            res = step()
+        sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        sync = res[1]
+        print(json.dumps({
+            "metric": "Msamples/s demod->pixel", "value": round(n * args.steps / dt / 1e6, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 FIR / f64 elsewhere",
+            "data": "synthetic",
+            "config": {"workload": f"ONE synthetic 11.025 kHz capture of {n} samples ({world} x 10 min), 120 LPM, AWGN sigma "
+                                   f"{args.noise} FS, sharded by sample range",
+                       "hilbert": "fir4095", "start_frame": sync["start_frame"], "image": [dec.width, 4 * sync["height"]],
+                       "parallelism": f"sample-range sharding over {world} GPU(s): halo recompute, 6 histogram all-reduces, "
+                                      "1 broadcast, 1 RCCL image gather per step"},
+            "roofline": None, "cpu_baseline": None}))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
 
 
 def main():
@@ -120,6 +184,9 @@ def main():
 
     from wefax_amd import _native as nat
     from wefax_amd.wefax import DecodeJob
+
+    if args.shard:
+        return bench_sharded(args, world, rank, local_rank, use_dist, dist, torch, nat)
 
     mode = nat.WFX_HILBERT_FFT if args.mode == "fft" else nat.WFX_HILBERT_FIR
     x = make_capture(seed=rank, noise=args.noise, short=args.short)

@@ -175,6 +175,7 @@ int wfx_dev_malloc(wfx_ctx *ctx, size_t bytes, void **dev_ptr);
 int wfx_dev_free(wfx_ctx *ctx, void *dev_ptr);
 int wfx_dev_upload(wfx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int wfx_dev_download(wfx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int wfx_dev_copy(wfx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);     /* device to device, waits */
 /* a6 on a segment: 49-tap symmetric FIR == filtfilt away from the ends (valid for 24 <= i < n-24); with
  * edge_flags bit 0 / bit 1 the segment starts / ends at the capture's true start / end and gets filtfilt's exact edge */
 int wfx_d_notch_fir(wfx_ctx *ctx, const int16_t *in_dev, size_t n, const double b[3], const double a[3], double *out_dev,

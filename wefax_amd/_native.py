@@ -27,7 +27,7 @@ SYMBOLS = [
     "wfx_sync_peaks", "wfx_lines_to_image", "wfx_decode_upload", "wfx_decode_run",
     "wfx_decode_result", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device",
-    "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download",
+    "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
     "wfx_d_notch_fir", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
@@ -122,6 +122,7 @@ def load():
     lib.wfx_dev_free.argtypes = [vp, vp]
     lib.wfx_dev_upload.argtypes = [vp, vp, vp, sz]
     lib.wfx_dev_download.argtypes = [vp, vp, vp, sz]
+    lib.wfx_dev_copy.argtypes = [vp, vp, vp, sz]
     lib.wfx_d_notch_fir.argtypes = [vp, vp, sz, dp, dp, vp, i]
     lib.wfx_d_fir_envelope.argtypes = [vp, vp, sz, sz, i, vp]
     lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
@@ -299,6 +300,9 @@ class Context:
         out = np.empty(shape, dtype=dtype)
         self._check(self.lib.wfx_dev_download(self.h, _ptr(out), C.c_void_p(ptr), out.nbytes))
         return out
+
+    def dev_copy(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        self._check(self.lib.wfx_dev_copy(self.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes))
 
     def d_notch_fir(self, in_ptr: int, n: int, b, a, out_ptr: int, edge_flags: int = 0):
         bb = (C.c_double * 3)(*[float(v) for v in b])

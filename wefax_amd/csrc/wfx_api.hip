@@ -401,6 +401,15 @@ int wfx_dev_download(wfx_ctx *ctx, void *dst_host, const void *src_dev, size_t b
     return d2h_sync(ctx, dst_host, src_dev, bytes);
 }
 
+int wfx_dev_copy(wfx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    if (bytes && (!dst_dev || !src_dev)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (bytes) WFX_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int wfx_d_notch_fir(wfx_ctx *ctx, const int16_t *in_dev, size_t n, const double b[3], const double a[3], double *out_dev, int edge_flags)
 {
     CHECK_CTX(ctx);

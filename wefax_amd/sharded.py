@@ -175,6 +175,16 @@ class HipStages:
         self.ctx.d_image_rows(self.p_dq + lo, hi - lo, g0, start, width, h_total, y0, rows, p_img)
         return self.ctx.dev_download(p_img, (4 * rows, width), np.uint8)
 
+    def image_rows_dev(self, lo, hi, g0, start, width, h_total, y0, rows):
+        """Rows stay on the device: (device pointer, nbytes) for a collective's send buffer."""
+        if rows <= 0:
+            return 0, 0
+        need = 4 * rows * width
+        if getattr(self, "img_cap", 0) < need:
+            self.p_img, self.img_cap = self._alloc(need), need
+        self.ctx.d_image_rows(self.p_dq + lo, hi - lo, g0, start, width, h_total, y0, rows, self.p_img)
+        return self.p_img, need
+
     def fetch(self, what, lo, hi):
         if what == "env":
             return self.ctx.dev_download(self.p_em + 8 * lo, (hi - lo,), np.float64)
@@ -267,8 +277,10 @@ class ShardedDecoder:
         return y0, rows
 
     # ---- drivers --------------------------------------------------------------------
-    def run(self, comm):
-        """All ranks call this; the root gets (image, sync dict, low, high), the others None."""
+    def run(self, comm, exchange=None):
+        """All ranks call this; the root gets (image, sync dict, low, high), the others None.
+        With an ``ImageExchange`` the rows are gathered device to device (the root then gets a
+        list of (first line, uint8 device tensor) instead of one host array)."""
         self.phase_envelope()
         low, high = self.percentiles(comm.allreduce_sum)
         nan = int(comm.allreduce_sum(np.array([self.phase_quantise(low, high)], dtype=np.int64))[0])
@@ -278,6 +290,18 @@ class ShardedDecoder:
         sync = comm.bcast(sync, 0)
         if sync["no_group"]:
             max([], key=len)
+        if exchange is not None and hasattr(self.st, "image_rows_dev"):
+            # rows never leave HBM: device-to-device into the collective's send buffer, one RCCL gather
+            p = self.plan
+            y0, y1 = p.rows(sync["start_frame"], self.width, sync["height"])
+            ptr, nb = self.st.image_rows_dev(self._loc(p.c0), self._loc(p.c1), p.c0, sync["start_frame"], self.width,
+                                             sync["height"], y0, y1 - y0)
+            if nb:
+                self.st.ctx.dev_copy(exchange.payload_ptr, ptr, nb)
+            got = exchange.gather(nb, y0)            # the header's second field carries the first line
+            if comm.rank != 0:
+                return None
+            return sorted(((y, buf) for buf, y in got if buf.numel()), key=lambda t: t[0]), sync, low, high
         y0, rows = self.phase_image(sync["start_frame"], sync["height"])
         parts = comm.gather((y0, rows), 0)           # the one image collective
         if comm.rank != 0:
