@@ -295,8 +295,8 @@ int wfx_decode_run(wfx_ctx *ctx)
                              (double *)ctx->b_env.p, sel_ws));
     const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
     WFX_TRY(wfx_dev_percentiles_fused(ctx, (const double *)ctx->b_env.p, n, ranks, p.gamma_lo, p.gamma_hi, ds));
-    WFX_TRY(wfx_dev_quantise(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, ds));
-    WFX_TRY(wfx_dev_sync_pick(ctx, (const uint8_t *)ctx->b_dig.p, n, p.n1, p.n0_gap, p.mindistance, p.frame_samples, w, ds));
+    WFX_TRY(wfx_dev_quantise_corr(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, p.n1, p.n0_gap));   // a8 + correlation of a9
+    WFX_TRY(wfx_dev_sync_pick_precomputed(ctx, n, p.n1, p.n0_gap, p.mindistance, p.frame_samples, w, ds));
     WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h_max, ds, (uint8_t *)ctx->b_img.p));
     WFX_HIP(ctx, hipMemcpyAsync(ctx->h_scal, ds, sizeof(wfx_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
     ctx->ran = true;

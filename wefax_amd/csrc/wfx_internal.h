@@ -197,6 +197,9 @@ int wfx_dev_percentiles_fused(wfx_ctx *ctx, const double *env, uint64_t n, const
 int wfx_dev_quantise(wfx_ctx *ctx, const double *env, uint64_t n, const wfx_dev_scalars *d_scal,
                      uint8_t *out, wfx_dev_scalars *d_scal_out);
 int wfx_dev_sync_corr(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int32_t *corr);
+int wfx_dev_quantise_corr(wfx_ctx *ctx, const double *env, uint64_t n, wfx_dev_scalars *d_scal, uint8_t *out, int n1, int n0);
+int wfx_dev_sync_pick_precomputed(wfx_ctx *ctx, uint64_t n, int n1, int n0, int64_t mindistance, double frame_samples, int width,
+                                  wfx_dev_scalars *d_scal);
 int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0,
                       int64_t mindistance, double frame_samples, int width,
                       wfx_dev_scalars *d_scal);

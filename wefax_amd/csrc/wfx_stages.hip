@@ -1012,6 +1012,74 @@ __global__ void __launch_bounds__(256) sync_corr_kernel(const uint8_t *__restric
     }
 }
 
+// Fused a8 + a9 for the decode path: quantise one chunk of the envelope (plus the L samples of halo
+// the correlation needs) into LDS, write the chunk's bytes, correlate, write correlation + summaries.
+// Saves one launch and the re-read of the byte stream; the halo is re-quantised, not exchanged.
+__global__ void __launch_bounds__(256) quantise_corr_kernel(const double *__restrict__ env, uint64_t n, const wfx_dev_scalars *__restrict__ s,
+                                                           uint8_t *__restrict__ d, wfx_dev_scalars *__restrict__ sout, int n1, int n0,
+                                                           int *__restrict__ corr, int *__restrict__ bmax, int *__restrict__ boff)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ds[CORR_CH + 512 + 16];
+    __shared__ __attribute__((aligned(16))) int cs[CORR_CH];
+    const double low = s->low, delta = s->high - s->low;
+    const int L = 2 * n1 + n0;
+    const uint64_t ncorr = n > (uint64_t)L ? n - L : 0;
+    const int t = threadIdx.x;
+    unsigned nan = 0;
+    for (uint64_t p0 = (uint64_t)blockIdx.x * CORR_CH; p0 < n; p0 += (uint64_t)gridDim.x * CORR_CH) {
+        const int own = (int)min((uint64_t)CORR_CH, n - p0);                 // bytes this chunk owns
+        const int need = (int)min((uint64_t)(CORR_CH + L + 1), n - p0);      // bytes the correlation reads
+        __syncthreads();
+        for (int i = 2 * t; i < need; i += 512) {                            // p0 is even: 16-byte aligned pairs
+            unsigned dummy = 0;
+            if (i + 1 < need) {
+                const double2 v = *(const double2 *)(env + p0 + i);
+                ds[i] = (uint8_t)quantise_one(v.x, low, delta, i < own ? nan : dummy);
+                ds[i + 1] = (uint8_t)quantise_one(v.y, low, delta, i + 1 < own ? nan : dummy);
+            } else {
+                ds[i] = (uint8_t)quantise_one(env[p0 + i], low, delta, i < own ? nan : dummy);
+            }
+        }
+        for (int i = need + t; i < CORR_CH + L + 1; i += 256) ds[i] = 0;
+        __syncthreads();
+        for (int i = t * 16; i < own; i += 256 * 16) *(uint4 *)(d + p0 + i) = *(const uint4 *)(ds + i);   // d is padded by 64 bytes
+        if (p0 < ncorr) {
+            const int cnt = (int)min((uint64_t)CORR_CH, ncorr - p0);
+            corr_from_lds(ds, cnt, n1, n0, cs, t, 256);
+            __syncthreads();
+            for (int i = t * 4; i < cnt; i += 256 * 4) *(int4 *)(corr + p0 + i) = *(const int4 *)(cs + i);
+            const int lane = t & 63, wave = t >> 6;
+            for (int b = wave; b * 64 < cnt; b += 4) {
+                const int j = b * 64 + lane;
+                int bc, bi;
+                wave_first_argmax(j < cnt ? cs[j] : (int)0x80000000, lane, bc, bi);
+                if (lane == 0) {
+                    bmax[p0 / 64 + b] = bc;
+                    boff[p0 / 64 + b] = bi;
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(nan != 0);
+    if (m) {
+        unsigned tot = nan;
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+        if ((t & 63) == 0) atomicAdd(&sout->nan_count, (unsigned long long)tot);
+    }
+}
+
+int wfx_dev_quantise_corr(wfx_ctx *ctx, const double *env, uint64_t n, wfx_dev_scalars *d_scal, uint8_t *out, int n1, int n0)
+{
+    if (2 * n1 + n0 > 500 || n1 < 0 || n0 < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sync pattern length out of range");
+    const size_t nblk = (size_t)n / 64 + 2;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_corr, (size_t)n * 4 + 256));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_tmp2, nblk * 8));
+    int *bmax = (int *)ctx->b_tmp2.p, *boff = bmax + nblk;
+    WFX_LAUNCH(ctx, K_QUANTISE, quantise_corr_kernel, dim3(wfx_stream_grid(n, CORR_CH)), dim3(256), env, n, (const wfx_dev_scalars *)d_scal, out,
+               d_scal, n1, n0, (int *)ctx->b_corr.p, bmax, boff);
+    return 0;
+}
+
 int wfx_dev_sync_corr(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int32_t *corr)
 {
     if (2 * n1 + n0 > 500) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sync pattern too long");
@@ -1211,6 +1279,18 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
     s->start_frame = start;
     s->height = (nclosed == 0 || width <= 0) ? 0 : (int)(((long long)n - start) / width);
     PICK_STAT(s->dbg[4] = (long long)__builtin_amdgcn_s_memtime() - t_begin;)
+}
+
+// the correlation and its summaries are already in b_corr / b_tmp2 (wfx_dev_quantise_corr)
+int wfx_dev_sync_pick_precomputed(wfx_ctx *ctx, uint64_t n, int n1, int n0, int64_t mindistance, double frame_samples, int width,
+                                  wfx_dev_scalars *d_scal)
+{
+    if (mindistance < 0 || mindistance > 12000) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "peak distance %lld out of range [0, 12000]", (long long)mindistance);
+    const size_t nblk = (size_t)n / 64 + 2;
+    const int *bmax = (const int *)ctx->b_tmp2.p, *boff = bmax + nblk;
+    WFX_LAUNCH(ctx, K_SYNC_PICK, sync_pick_kernel, dim3(1), dim3(PICK_THREADS), (const int *)ctx->b_corr.p, bmax, boff, n, n1, n0,
+               (long long)mindistance, frame_samples, width, d_scal);
+    return 0;
 }
 
 int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int64_t mindistance, double frame_samples,
