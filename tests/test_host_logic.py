@@ -167,3 +167,20 @@ def test_decode_job_parameter_block(monkeypatch):
     assert DecodeJob(fc, u8, 11025, 120).params.in_kind == nat.WFX_IN_F64_MONO and fc.data.dtype == np.float64
     with pytest.raises(ValueError, match="greater than padlen"):
         DecodeJob(fc, np.zeros(9, dtype=np.int16), 11025, 120)
+
+
+def test_fast_png_writer_round_trips_through_pillow(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    from wefax_amd import pngio
+    rng = np.random.default_rng(3)
+    for shape in ((1, 1), (5, 3), (37, 5512), (440, 2756)):
+        img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        p = str(tmp_path / f"t{shape[0]}.png")
+        pngio.write_png_gray8(p, img, threads=3)
+        back = Image.open(p)
+        assert back.mode == "L" and back.size == (shape[1], shape[0])
+        assert np.array_equal(np.asarray(back), img)
+    smooth = np.repeat((np.arange(300 * 64).reshape(300, 64) // 7 % 256).astype(np.uint8), 4, axis=0)
+    assert np.array_equal(np.asarray(Image.open(__import__("io").BytesIO(pngio.encode_png_gray8(smooth, threads=1)))), smooth)
+    with pytest.raises(ValueError):
+        pngio.encode_png_gray8(np.zeros((0, 4), np.uint8))

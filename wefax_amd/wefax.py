@@ -259,6 +259,13 @@ class Demodulator:
         plt.show()
 
     def save_output_image(self, filepath: str):                             # wefax.py:407-408
+        """Same file the reference writes (8-bit gray PNG, w x 4h, identical pixels).  For .png
+        the multi-threaded encoder of wefax_amd/pngio.py is used -- PIL's single-threaded zlib
+        would otherwise dominate the whole decode; other formats go through PIL like the reference."""
+        if filepath.lower().endswith(".png") and getattr(self, "output_array", None) is not None:
+            from .pngio import write_png_gray8
+            write_png_gray8(filepath, self.output_array)
+            return
         if self.output_image is None:
             raise RuntimeError("Pillow is not installed: cannot write " + filepath)
         self.output_image.save(filepath)
