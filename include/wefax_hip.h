@@ -44,9 +44,11 @@ typedef enum {
 
 /* how the analytic signal (scipy.signal.hilbert, wefax.py:174) is computed */
 typedef enum {
-    WFX_HILBERT_FFT = 0,    /* exact: circular convolution with ifft(h) by zero-padded power-of-two FFTs */
+    WFX_HILBERT_FFT = 0,    /* exact: circular convolution with ifft(h) (mixed-radix N/2-point or zero-padded power-of-two transforms) */
     WFX_HILBERT_FIR = 1,    /* sliding-window circular FIR with `fir_taps` taps       */
-    WFX_HILBERT_BLUESTEIN = 2 /* exact, literal fft -> h -> ifft via two Bluestein DFTs (cross-check) */
+    WFX_HILBERT_BLUESTEIN = 2, /* exact, literal fft -> h -> ifft via two Bluestein DFTs (cross-check) */
+    WFX_HILBERT_FFT_POW2 = 3  /* exact, like WFX_HILBERT_FFT but always the zero-padded power-of-two form
+                                 (WFX_HILBERT_FFT picks the unpadded mixed-radix form when N/2 is 13-smooth) */
 } wfx_hilbert_mode;
 
 #define WFX_MAX_PEAKS 100   /* wefax.py:251 */

@@ -124,17 +124,31 @@ def test_analytic_envelope_exact_mode(ctx, n):
     assert _rel(ctx.analytic_env(x), wo.demodulate(x)) <= FLOAT_TOL
 
 
-@pytest.mark.parametrize("n", [2, 3, 10, 4099, 65536, 65537, 250007, 250008])
-def test_analytic_envelope_two_exact_formulations_agree(ctx, n):
-    """Circular convolution with the closed-form kernel (default) vs the literal
-    fft -> h -> ifft through two Bluestein DFTs: independent code paths, same operator."""
+@pytest.mark.parametrize("n", [2, 3, 4, 10, 26, 4099, 30030, 65536, 65537, 250007, 250008, 2 * 3583125 // 25])
+def test_analytic_envelope_three_exact_formulations_agree(ctx, n):
+    """Three independent code paths for the same operator: the unpadded mixed-radix cyclic
+    convolution with the closed-form kernel spectrum (taken by WFX_HILBERT_FFT when N/2 is
+    13-smooth), the zero-padded power-of-two convolution with the closed-form kernel taps,
+    and the literal fft -> h -> ifft through two Bluestein DFTs."""
     from oracle import wefax_oracle as wo
     from wefax_amd import _native as nat
     x = _signal(n, 3 * n + 1)
     a = ctx.analytic_env(x, nat.WFX_HILBERT_FFT)
     b = ctx.analytic_env(x, nat.WFX_HILBERT_BLUESTEIN)
+    c = ctx.analytic_env(x, nat.WFX_HILBERT_FFT_POW2)
     ref = wo.demodulate(x)
-    assert _rel(a, ref) <= FLOAT_TOL and _rel(b, ref) <= FLOAT_TOL and _rel(a, b) <= FLOAT_TOL
+    assert _rel(a, ref) <= FLOAT_TOL and _rel(b, ref) <= FLOAT_TOL and _rel(c, ref) <= FLOAT_TOL
+    assert _rel(a, b) <= FLOAT_TOL and _rel(a, c) <= FLOAT_TOL
+
+
+@pytest.mark.parametrize("n", [2 * 3 ** 7, 2 * 5 ** 6, 2 * 7 ** 5, 2 * 11 ** 4, 2 * 13 ** 4, 2 ** 14, 2 * 3 * 5 * 7 * 11 * 13 * 16,
+                               2 * 256 * 255, 2 * 257])
+def test_mixed_radix_sizes(ctx, n):
+    """Every prime radix of the mixed-radix engine, deep single-prime plans, a radix that fills
+    a group exactly, and a non-smooth length that must fall back to the padded form."""
+    from oracle import wefax_oracle as wo
+    x = _signal(n, n)
+    assert _rel(ctx.analytic_env(x), wo.demodulate(x)) <= FLOAT_TOL
 
 
 def test_analytic_envelope_fir_mode_converges(ctx):

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwefax_hip.so")
 
 WFX_IN_I16_MONO, WFX_IN_I16_STEREO, WFX_IN_F64_MONO = 0, 1, 2
-WFX_HILBERT_FFT, WFX_HILBERT_FIR, WFX_HILBERT_BLUESTEIN = 0, 1, 2
+WFX_HILBERT_FFT, WFX_HILBERT_FIR, WFX_HILBERT_BLUESTEIN, WFX_HILBERT_FFT_POW2 = 0, 1, 2, 3
 WFX_BUF_AUDIO, WFX_BUF_ENVELOPE, WFX_BUF_DIGITAL, WFX_BUF_IMAGE = 0, 1, 2, 3
 WFX_MAX_PEAKS = 100
 

@@ -82,8 +82,10 @@ int wfx_notch_filtfilt(wfx_ctx *ctx, const void *in, int in_kind, size_t n, cons
 static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode, int taps, double *env_raw, double *env,
                             unsigned *l0hist = nullptr)
 {
-    if (mode == WFX_HILBERT_FFT)
+    if (mode == WFX_HILBERT_FFT || mode == WFX_HILBERT_FFT_POW2) {
+        ctx->force_pow2 = mode == WFX_HILBERT_FFT_POW2;
         return wfx_dev_hilbert_envmed_fft(ctx, x, n, env, l0hist);
+    }
     else if (mode == WFX_HILBERT_FIR)
         WFX_TRY(wfx_dev_hilbert_env_fir(ctx, x, n, taps, env_raw));
     else if (mode == WFX_HILBERT_BLUESTEIN)

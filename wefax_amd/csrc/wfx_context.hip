@@ -113,6 +113,7 @@ void wfx_destroy(wfx_ctx *ctx)
     for (auto *b : bufs) free_buf(*b);
     for (auto &kv : ctx->plans) free_buf(kv.second.bhat);
     for (auto &kv : ctx->hplans) free_buf(kv.second.bhat);
+    wfx_mr_release(ctx);
     for (auto &r : ctx->prof_recs) {
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);

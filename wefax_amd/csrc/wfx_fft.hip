@@ -722,6 +722,12 @@ __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__
 
 static int hilbert_conv(wfx_ctx *ctx, const double *x, uint64_t n, cplx **W_out, int *packed_out, uint64_t *L_out)
 {
+    // even N with a 13-smooth N/2: unpadded mixed-radix transforms, closed-form kernel spectrum
+    if ((n & 1) == 0 && n >= 4 && !ctx->force_pow2 && wfx_mr_supported(n / 2)) {
+        *packed_out = 1;
+        *L_out = n / 2;
+        return wfx_dev_hilbert_conv_mr(ctx, x, n, W_out);
+    }
     wfx_bs_plan *pl = nullptr;
     WFX_TRY(get_hplan(ctx, n, &pl, packed_out, L_out));
     const uint64_t M = 1ull << pl->log2m;

@@ -78,6 +78,7 @@ struct wfx_ctx {
     wfx_devbuf b_in, b_x, b_audio, b_work, b_work2, b_envraw, b_env, b_dig, b_corr,
         b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand;
     bool w256_ready = false;
+    bool force_pow2 = false;     // WFX_HILBERT_FFT_POW2: always use the zero-padded power-of-two convolution
     std::map<uint64_t, wfx_bs_plan> plans;    // Bluestein chirp filters (resampler, cross-check mode)
     std::map<uint64_t, wfx_bs_plan> hplans;   // Hilbert convolution kernels
 
@@ -210,6 +211,11 @@ int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t sta
 int wfx_dev_notch_fir_only(wfx_ctx *ctx, const int16_t *in, uint64_t n, const double b[3], const double a[3], double *out,
                            int edge_flags);
 int wfx_dev_select_level(wfx_ctx *ctx, const double *env, uint64_t n, int level, const uint64_t prefix[4], unsigned *hist);
+
+// wfx_mrfft.hip
+bool wfx_mr_supported(uint64_t L);
+void wfx_mr_release(wfx_ctx *ctx);
+int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out);
 
 // wfx_fir.hip
 int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps, double *env_raw, uint64_t n_global = 0);

@@ -1,0 +1,477 @@
+// Mixed-radix cyclic transform for the analytic-signal convolution (exact mode).
+//
+// For even N the Hilbert transform is ONE cyclic convolution of the packed sequence
+// z[q] = x[2q+1] + i x[2q] (length L = N/2) with a real kernel whose L-point spectrum
+// has a closed form:
+//       G[0] = 0,   G[k] = -i * exp(-2 pi i k / N)   (0 < k < L)
+// (derivation in DESIGN.md 3.2: the N-point spectrum of the Hilbert kernel is -i*sgn,
+// and g = its odd polyphase component).  When L factors into primes <= 13 the
+// convolution is done with L-point transforms directly -- no zero padding to a power of
+// two (2.3x fewer points for the 10-minute capture), no stored kernel spectrum:
+//
+//       V = IDFT_L( G .* DFT_L(z) ),   Re V[p] = H[2p],  Im V[p] = H[2p-1]
+//
+// Engine: Stockham autosort passes, natural order in and out, out of place between two
+// buffers.  A pass with radix R (a product of small primes, <= 256) and P = product of
+// the previous radices: thread-column j in [0, L/R), k = j mod P,
+//       in_m  = x[j + m L/R] * W_{P R}^{k m},   X = DFT_R(in),   y[(j-k) R + k + q P] = X[q].
+// A workgroup owns T = 4096/R columns: loads are T-element runs, the R-point transform
+// runs in LDS as in-place decimation-in-frequency stages over the prime factors (roots
+// from a per-block LDS table, p-point butterflies in registers), the digit-reversed
+// result is read out in natural order.  Input twiddles come from a two-level table
+// (W^t = hi[t >> 11] * lo[t & 2047]).  Like the power-of-two engine the passes are
+// HBM-bound: read 16 B + write 16 B per point and pass.
+#include <algorithm>
+#include <mutex>
+#include <utility>
+
+#include "wfx_internal.h"
+
+#define MR_TILE 4096
+#define MR_MAXF 8
+#define MR_MAXPASS 4
+#define MR_LO_BITS 11
+#define MR_LO (1 << MR_LO_BITS)
+
+struct mr_pass_desc {
+    int R, nf, f[MR_MAXF];
+    long long P, ncol, L;
+    int T, log2t;
+};
+
+__device__ __forceinline__ cplx mcmul(cplx a, cplx b)
+{
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cplx mconj_if(cplx a, bool inv) { return inv ? make_double2(a.x, -a.y) : a; }
+
+// cos / sin of 2 pi i / P as compile-time constants (immediates: no registers, no LDS reads)
+template <int P>
+struct mr_roots {
+    static constexpr double c[1] = {1.0};
+    static constexpr double s[1] = {0.0};
+};
+template <> struct mr_roots<3> {
+    static constexpr double c[3] = {1.0, -0.4999999999999998, -0.5000000000000004};
+    static constexpr double s[3] = {0.0, 0.8660254037844387, -0.8660254037844384};
+};
+template <> struct mr_roots<5> {
+    static constexpr double c[5] = {1.0, 0.30901699437494745, -0.8090169943749473, -0.8090169943749476, 0.30901699437494723};
+    static constexpr double s[5] = {0.0, 0.9510565162951535, 0.5877852522924732, -0.587785252292473, -0.9510565162951536};
+};
+template <> struct mr_roots<7> {
+    static constexpr double c[7] = {1.0, 0.6234898018587336, -0.22252093395631434, -0.900968867902419, -0.9009688679024191, -0.2225209339563146, 0.6234898018587334};
+    static constexpr double s[7] = {0.0, 0.7818314824680298, 0.9749279121818236, 0.43388373911755823, -0.433883739117558, -0.9749279121818236, -0.7818314824680299};
+};
+template <> struct mr_roots<11> {
+    static constexpr double c[11] = {1.0, 0.8412535328311812, 0.41541501300188644, -0.142314838273285, -0.654860733945285, -0.9594929736144974, -0.9594929736144975, -0.6548607339452852, -0.14231483827328523, 0.41541501300188605, 0.8412535328311812};
+    static constexpr double s[11] = {0.0, 0.5406408174555976, 0.9096319953545183, 0.9898214418809328, 0.7557495743542583, 0.28173255684142967, -0.2817325568414294, -0.7557495743542582, -0.9898214418809327, -0.9096319953545186, -0.5406408174555974};
+};
+template <> struct mr_roots<13> {
+    static constexpr double c[13] = {1.0, 0.8854560256532099, 0.5680647467311559, 0.120536680255323, -0.35460488704253545, -0.7485107481711012, -0.970941817426052, -0.9709418174260521, -0.7485107481711013, -0.3546048870425359, 0.1205366802553232, 0.5680647467311548, 0.88545602565321};
+    static constexpr double s[13] = {0.0, 0.4647231720437685, 0.8229838658936564, 0.992708874098054, 0.9350162426854148, 0.6631226582407952, 0.23931566428755768, -0.23931566428755743, -0.663122658240795, -0.9350162426854147, -0.992708874098054, -0.822983865893657, -0.4647231720437684};
+};
+
+// p-point DFT of v[0..P) in registers; sg = -1 forward (W = e^{-i..}), +1 inverse.  Each output is
+// handed to `put(q, value)` as soon as it is complete (keeps the register footprint at v + a + b).
+// Odd primes use the conjugate-pair form: with a_m = v_m + v_{P-m}, b_m = v_m - v_{P-m},
+//   y[q], y[P-q] = v_0 + sum_m a_m cos(2 pi m q / P)  +-  i sg sum_m b_m sin(2 pi m q / P)
+// i.e. (P-1)^2 real FMAs instead of 4 (P-1)^2.
+template <int P, typename PUT>
+__device__ __forceinline__ void dft_small(const cplx *v, const double sg, PUT put)
+{
+    if (P == 2) {
+        put(0, make_double2(v[0].x + v[1].x, v[0].y + v[1].y));
+        put(1, make_double2(v[0].x - v[1].x, v[0].y - v[1].y));
+        return;
+    }
+    if (P == 4) {
+        const cplx t0 = make_double2(v[0].x + v[2].x, v[0].y + v[2].y), t1 = make_double2(v[0].x - v[2].x, v[0].y - v[2].y);
+        const cplx t2 = make_double2(v[1].x + v[3].x, v[1].y + v[3].y), d = make_double2(v[1].x - v[3].x, v[1].y - v[3].y);
+        const cplx t3 = make_double2(-sg * d.y, sg * d.x);     // d * (i sg)
+        put(0, make_double2(t0.x + t2.x, t0.y + t2.y));
+        put(2, make_double2(t0.x - t2.x, t0.y - t2.y));
+        put(1, make_double2(t1.x + t3.x, t1.y + t3.y));
+        put(3, make_double2(t1.x - t3.x, t1.y - t3.y));
+        return;
+    }
+    constexpr int H = (P - 1) / 2;
+    cplx a[H > 0 ? H : 1], b[H > 0 ? H : 1];
+    cplx y0 = v[0];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {
+        a[m - 1] = make_double2(v[m].x + v[P - m].x, v[m].y + v[P - m].y);
+        b[m - 1] = make_double2(v[m].x - v[P - m].x, v[m].y - v[P - m].y);
+        y0.x += a[m - 1].x;
+        y0.y += a[m - 1].y;
+    }
+    put(0, y0);
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+        double ax = v[0].x, ay = v[0].y, bx = 0.0, by = 0.0;
+#pragma unroll
+        for (int m = 1; m <= H; ++m) {
+            const double wc = mr_roots<P>::c[(m * q) % P], ws = sg * mr_roots<P>::s[(m * q) % P];
+            ax = fma(a[m - 1].x, wc, ax);
+            ay = fma(a[m - 1].y, wc, ay);
+            bx = fma(b[m - 1].x, ws, bx);
+            by = fma(b[m - 1].y, ws, by);
+        }
+        // v_m w + v_{P-m} conj(w) = a Re w + i b Im w ;  i (bx + i by) = (-by, bx)
+        put(q, make_double2(ax - by, ay + bx));
+        put(P - q, make_double2(ax + by, ay - bx));
+    }
+}
+
+// one in-place DIF stage of radix P over the LDS tile [R][T]
+template <int P>
+__device__ __forceinline__ void mr_stage(cplx *tile, const cplx *wr, int R, int log2t, int Ls, bool inv)
+{
+    const int sub = Ls / P;
+    const int nb = (R / P) << log2t;
+    const int tstep = R / Ls;
+    const int tmask = (1 << log2t) - 1;
+    const double sg = inv ? 1.0 : -1.0;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        const int c = b & tmask, bi = b >> log2t;
+        const int gi = bi / sub, j = bi - gi * sub;
+        const int row0 = gi * Ls + j;
+        cplx v[P];
+#pragma unroll
+        for (int m = 0; m < P; ++m) v[m] = tile[((row0 + m * sub) << log2t) + c];
+        const int jt = j * tstep;              // j q tstep < sub P tstep = R: no reduction needed
+        // every thread owns its P positions: they can be overwritten as the outputs complete
+        dft_small<P>(v, sg, [&](int q, cplx y) {
+            if (q > 0) y = mcmul(y, mconj_if(wr[jt * q], inv));
+            tile[((row0 + q * sub) << log2t) + c] = y;
+        });
+    }
+}
+
+// workgroup barrier that orders LDS traffic only: the register prefetch of the next tile stays
+// in flight across it (a __syncthreads() would drain it with s_waitcnt vmcnt(0))
+__device__ __forceinline__ void mr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// IN_MODE 0: complex input array; 1: packed real input z[q] = x[2q+1] + i x[2q]
+// OUT_MODE 0: plain; 1: multiply by the Hilbert spectrum G[k] / L (last forward pass)
+// Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and fetches the
+// next tile into registers while the current one is transformed, so HBM stays busy during the
+// LDS stages.
+template <int IN_MODE, int OUT_MODE>
+__global__ void __launch_bounds__(256, 2)
+mr_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
+        int inverse, int ntiles)
+{
+    constexpr int NPRE = MR_TILE / 256;
+    __shared__ cplx tile[MR_TILE];
+    __shared__ cplx wr[256];
+    __shared__ unsigned short rev[256];       // rev[q] = position of X[q] after the in-place DIF stages
+    const bool inv = inverse != 0;
+    const int R = d.R, T = d.T, log2t = d.log2t, tmask = T - 1;
+    const int nelem = R << log2t;
+    // all index arithmetic is 32-bit: L < 2^31
+    const int ncol = (int)d.ncol, P = (int)d.P;
+    if ((int)threadIdx.x < R) {
+        double s, c;
+        sincospi(2.0 * (double)threadIdx.x / (double)R, &s, &c);
+        wr[threadIdx.x] = make_double2(c, -s);                    // W_R^t (forward)
+        int u = 0, rem = (int)threadIdx.x, span = R;
+        for (int st = 0; st < d.nf; ++st) {
+            const int p = d.f[st];
+            span /= p;
+            u += (rem % p) * span;
+            rem /= p;
+        }
+        rev[threadIdx.x] = (unsigned short)u;
+    }
+    // 256 is a multiple of T: a thread keeps its column c and visits rows m0, m0 + ms, ...
+    const int c = (int)threadIdx.x & tmask;
+    const int m0 = (int)threadIdx.x >> log2t, ms = 256 >> log2t;
+    cplx pre[NPRE];
+    auto prefetch = [&](int tix) {
+        const int j = tix * T + c;
+        const bool col_ok = j < ncol;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int m = m0 + i * ms;
+            cplx v = make_double2(0.0, 0.0);
+            if (col_ok && m < R) {
+                const long long a = (long long)j + (long long)m * ncol;
+                if (IN_MODE == 1) {
+                    const cplx x2 = in[a];
+                    v = make_double2(x2.y, x2.x);
+                } else {
+                    v = in[a];
+                }
+            }
+            pre[i] = v;
+        }
+    };
+    const double inv_l = 1.0 / (double)d.L;
+    int tix = blockIdx.x;
+    if (tix < ntiles) prefetch(tix);
+    for (; tix < ntiles; tix += gridDim.x) {
+        const int j0 = tix * T;
+        const int tn = min(T, ncol - j0);                         // columns in this tile
+        mr_lds_barrier();                                         // the previous tile has been read out
+        // 1. registers -> LDS with the input twiddle W_{P R}^{k m} (recurrence along m from two table look-ups)
+        {
+            const int j = j0 + c;
+            cplx w = make_double2(1.0, 0.0), wstep = make_double2(1.0, 0.0);
+            if (P > 1 && c < tn) {
+                const int k = j % P;
+                const int t0 = k * m0, ts = k * ms;               // < P R <= L
+                w = mconj_if(mcmul(tw_hi[t0 >> MR_LO_BITS], tw_lo[t0 & (MR_LO - 1)]), inv);
+                wstep = mconj_if(mcmul(tw_hi[ts >> MR_LO_BITS], tw_lo[ts & (MR_LO - 1)]), inv);
+            }
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int e = (int)threadIdx.x + 256 * i;
+                if (e < nelem) {
+                    cplx v = pre[i];
+                    if (P > 1) {
+                        v = mcmul(v, w);
+                        w = mcmul(w, wstep);
+                    }
+                    tile[e] = v;                                  // e == m * T + c
+                }
+            }
+        }
+        mr_lds_barrier();
+        if (tix + (int)gridDim.x < ntiles) prefetch(tix + gridDim.x);      // in flight during the stages below
+        // 2. R-point transform of every column: in-place DIF stages over the factors
+        int Ls = R;
+        for (int st = 0; st < d.nf; ++st) {
+            const int p = d.f[st];
+            switch (p) {
+            case 2: mr_stage<2>(tile, wr, R, log2t, Ls, inv); break;
+            case 3: mr_stage<3>(tile, wr, R, log2t, Ls, inv); break;
+            case 4: mr_stage<4>(tile, wr, R, log2t, Ls, inv); break;
+            case 5: mr_stage<5>(tile, wr, R, log2t, Ls, inv); break;
+            case 7: mr_stage<7>(tile, wr, R, log2t, Ls, inv); break;
+            case 11: mr_stage<11>(tile, wr, R, log2t, Ls, inv); break;
+            case 13: mr_stage<13>(tile, wr, R, log2t, Ls, inv); break;
+            default: break;
+            }
+            Ls /= p;
+            mr_lds_barrier();
+        }
+        // 3. natural-order read-out: X[q] sits at position rev[q]
+        auto emit = [&](int q, int cc) {
+            cplx v = tile[((int)rev[q] << log2t) + cc];
+            const int j = j0 + cc;
+            const int k = P > 1 ? j % P : 0;
+            const long long o = (long long)(j - k) * R + k + (long long)q * P;
+            if (OUT_MODE == 1) {
+                // G[o] / L,  G[k] = -i exp(-i pi k / L) = (-sin, -cos)(pi k / L), G[0] = 0
+                double sn, cs;
+                sincospi((double)o / (double)d.L, &sn, &cs);
+                const cplx g = o == 0 ? make_double2(0.0, 0.0) : make_double2(-sn * inv_l, -cs * inv_l);
+                v = mcmul(v, g);
+            }
+            out[o] = v;
+        };
+        if (P == 1) {
+            // the tile's outputs are one contiguous run [j0 R, (j0 + tn) R): walk it in output order
+            int q = (int)threadIdx.x % R, cc = (int)threadIdx.x / R;
+            const int dq = 256 % R, dc = 256 / R;
+            for (int e = threadIdx.x; e < R * tn; e += 256) {
+                emit(q, cc);
+                q += dq;
+                cc += dc;
+                if (q >= R) {
+                    q -= R;
+                    ++cc;
+                }
+            }
+        } else if (c < tn) {
+            // for a fixed q the columns of the tile are consecutive outputs
+            for (int e = threadIdx.x; e < nelem; e += 256) emit(e >> log2t, c);
+        }
+    }
+}
+
+// two-level twiddle table for modulus `mod`: lo[i] = W^i (i < 2048), hi[i] = W^(2048 i)
+__global__ void __launch_bounds__(256) mr_fill_tables(cplx *__restrict__ lo, cplx *__restrict__ hi, long long mod, int nhi)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < MR_LO) {
+        double s, c;
+        sincospi(2.0 * (double)(i % mod) / (double)mod, &s, &c);
+        lo[i] = make_double2(c, -s);
+    }
+    if (i < nhi) {
+        const long long t = ((long long)i << MR_LO_BITS) % mod;
+        double s, c;
+        sincospi(2.0 * (double)t / (double)mod, &s, &c);
+        hi[i] = make_double2(c, -s);
+    }
+}
+
+// ---- planning (host) -----------------------------------------------------------------
+struct mr_plan_host {
+    long long L = 0;
+    int npass = 0;
+    mr_pass_desc pass[MR_MAXPASS];
+    size_t lo_off[MR_MAXPASS], hi_off[MR_MAXPASS];
+    size_t table_elems = 0;
+};
+
+// factor L into primes <= 13 and group them into radices <= 256; false when L is not smooth
+static bool mr_make_plan(long long L, mr_plan_host &pl)
+{
+    static const int primes[] = {13, 11, 7, 5, 3, 2};
+    std::vector<int> fs;
+    long long rem = L;
+    for (int p : primes)
+        while (rem % p == 0) {
+            fs.push_back(p);
+            rem /= p;
+        }
+    if (rem != 1 || L < 2) return false;
+    {   // pairs of 2s become radix-4 stages (no multiplications), listed first among the small factors
+        int twos = 0;
+        std::vector<int> other;
+        for (int p : fs) (p == 2 ? ++twos : (other.push_back(p), 0));
+        fs = other;
+        for (; twos >= 2; twos -= 2) fs.push_back(4);
+        if (twos) fs.push_back(2);
+        std::sort(fs.begin(), fs.end(), [](int x, int y) { return x > y; });
+    }
+    // greedy: largest factors first, each into the smallest group that still fits
+    std::vector<std::vector<int>> groups;
+    std::vector<int> prod;
+    for (int p : fs) {
+        int best = -1;
+        for (size_t g = 0; g < groups.size(); ++g)
+            if (prod[g] * p <= 256 && (int)groups[g].size() < MR_MAXF && (best < 0 || prod[g] < prod[best])) best = (int)g;
+        if (best < 0) {
+            groups.push_back({p});
+            prod.push_back(p);
+        } else {
+            groups[best].push_back(p);
+            prod[best] *= p;
+        }
+    }
+    if ((int)groups.size() > MR_MAXPASS) return false;
+    pl.L = L;
+    pl.npass = (int)groups.size();
+    long long P = 1;
+    size_t off = 0;
+    for (int i = 0; i < pl.npass; ++i) {
+        mr_pass_desc &d = pl.pass[i];
+        d.R = prod[i];
+        d.nf = (int)groups[i].size();
+        // merge pairs of 2s into 4s / 8s is not needed for correctness; keep the prime stages
+        for (int k = 0; k < d.nf; ++k) d.f[k] = groups[i][k];
+        for (int k = d.nf; k < MR_MAXF; ++k) d.f[k] = 1;
+        d.P = P;
+        d.L = L;
+        d.ncol = L / d.R;
+        int T = MR_TILE / d.R;
+        int t2 = 1;
+        int l2 = 0;
+        while (t2 * 2 <= T && t2 < 256) {         // power of two <= 256: cheap index arithmetic, a thread keeps its column
+            t2 *= 2;
+            ++l2;
+        }
+        d.T = t2;
+        d.log2t = l2;
+        const long long mod = P * d.R;
+        pl.lo_off[i] = off;
+        off += MR_LO;
+        pl.hi_off[i] = off;
+        off += (size_t)(mod >> MR_LO_BITS) + 2;
+        P *= d.R;
+    }
+    pl.table_elems = off;
+    return true;
+}
+
+struct mr_plan_cache {
+    mr_plan_host h;
+    wfx_devbuf tables;
+};
+static std::map<std::pair<const void *, long long>, mr_plan_cache> g_mr_plans;   // per (context, L)
+static std::mutex g_mr_mutex;
+
+bool wfx_mr_supported(uint64_t L)
+{
+    mr_plan_host pl;
+    return mr_make_plan((long long)L, pl);
+}
+
+static int mr_get_plan(wfx_ctx *ctx, long long L, mr_plan_cache **out)
+{
+    std::lock_guard<std::mutex> lock(g_mr_mutex);
+    auto key = std::make_pair((const void *)ctx, L);
+    auto it = g_mr_plans.find(key);
+    if (it != g_mr_plans.end()) {
+        *out = &it->second;
+        return 0;
+    }
+    mr_plan_cache pc;
+    if (!mr_make_plan(L, pc.h)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "length %lld is not 13-smooth", L);
+    WFX_TRY(wfx_reserve(ctx, pc.tables, pc.h.table_elems * sizeof(cplx)));
+    for (int i = 0; i < pc.h.npass; ++i) {
+        const long long mod = pc.h.pass[i].P * pc.h.pass[i].R;
+        const int nhi = (int)(mod >> MR_LO_BITS) + 2;
+        const int n = nhi > MR_LO ? nhi : MR_LO;
+        cplx *base = (cplx *)pc.tables.p;
+        WFX_LAUNCH(ctx, K_BS_CHIRP, mr_fill_tables, dim3((n + 255) / 256), dim3(256), base + pc.h.lo_off[i], base + pc.h.hi_off[i], mod, nhi);
+    }
+    auto ins = g_mr_plans.emplace(key, pc);
+    *out = &ins.first->second;
+    return 0;
+}
+
+void wfx_mr_release(wfx_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lock(g_mr_mutex);
+    for (auto it = g_mr_plans.begin(); it != g_mr_plans.end();) {
+        if (it->first.first == (const void *)ctx) {
+            if (it->second.tables.p) (void)hipFree(it->second.tables.p);
+            it = g_mr_plans.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
+// H = Hilbert transform of the even-length real signal x, packed: Re V[p] = H[2p], Im V[p] = H[2p-1 mod N].
+// Returns the device pointer holding V (L = n/2 complex values) in *V_out.
+int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out)
+{
+    const long long L = (long long)(n / 2);
+    mr_plan_cache *pc = nullptr;
+    WFX_TRY(mr_get_plan(ctx, L, &pc));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work, (size_t)L * sizeof(cplx)));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (size_t)L * sizeof(cplx)));
+    cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
+    const cplx *tb = (const cplx *)pc->tables.p;
+    const int np = pc->h.npass;
+    const cplx *src = (const cplx *)x;      // the packed real input IS x viewed as complex pairs (swapped on load)
+    cplx *dst = A;
+    for (int dir = 0; dir < 2; ++dir) {     // forward, then inverse
+        for (int i = 0; i < np; ++i) {
+            const mr_pass_desc &d = pc->h.pass[i];
+            const int ntiles = (int)((d.ncol + d.T - 1) / d.T);
+            const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);       // 2 persistent workgroups per CU
+            const cplx *lo = tb + pc->h.lo_off[i], *hi = tb + pc->h.hi_off[i];
+            const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
+            const bool first = dir == 0 && i == 0, last_fwd = dir == 0 && i == np - 1;
+            if (first && last_fwd)
+                WFX_LAUNCH(ctx, kid, (mr_pass<1, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, dir, ntiles);
+            else if (first)
+                WFX_LAUNCH(ctx, kid, (mr_pass<1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, dir, ntiles);
+            else if (last_fwd)
+                WFX_LAUNCH(ctx, kid, (mr_pass<0, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, dir, ntiles);
+            else
+                WFX_LAUNCH(ctx, kid, (mr_pass<0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, dir, ntiles);
+            src = dst;
+            dst = (dst == A) ? B : A;
+        }
+    }
+    *V_out = (cplx *)src;
+    return 0;
+}
