@@ -1,0 +1,51 @@
+#!/bin/bash
+# Collect the judged evidence set on an MI355X box (run through gpurun from the
+# repo root):   gpurun --timeout 1500 -- 'bash tools/collect_evidence.sh r01_v17'
+# Everything lands in gpurun_out/<tag>/; copy what should be judged to profiles/<tag>/.
+set -u
+TAG=${1:-evidence}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+
+python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+tail -1 "$OUT/pytest_gpu.log"
+
+# un-profiled default bench line (the contract's N=1 run)
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+cat "$OUT/bench.json"
+
+# per-kernel durations of the same command
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu > "$OUT/prof_bench.json" 2> "$OUT/prof_bench.err"
+find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
+
+# HBM traffic, one counter per pass, no trace domains besides the kernel trace
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2> "$OUT/pmc_write.err"
+python tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic.json" > "$OUT/pmc_summary.log" 2>&1
+for d in fetch write; do
+  f=$(find "$OUT/pmc_$d" -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && python - "$f" "$OUT/pmc_${d}_per_kernel.csv" <<'EOF'
+import csv, sys, collections
+acc = collections.OrderedDict()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = (r["Kernel_Name"], r["Counter_Name"])
+    a = acc.setdefault(k, [0, 0.0])
+    a[0] += 1
+    a[1] += float(r["Counter_Value"])
+with open(sys.argv[2], "w") as f:
+    f.write("kernel,counter,dispatches,mean_value\n")
+    for (k, c), (n, s) in acc.items():
+        f.write('"%s",%s,%d,%.1f\n' % (k, c, n, s / n))
+EOF
+done
+rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write"
+
+# the other modes and configurations
+python bench.py --mode fir --no-cpu > "$OUT/bench_fir.json" 2>> "$OUT/bench.err"
+for b in 2 4 8; do python bench.py --batch $b --no-cpu > "$OUT/bench_batch$b.json" 2>> "$OUT/bench.err"; done
+WFX_BENCH_FORCE_DIST=1 python bench.py --shard --no-cpu > "$OUT/bench_shard_rccl1.json" 2>> "$OUT/bench.err"
+WFX_BENCH_FORCE_DIST=1 python bench.py --no-cpu > "$OUT/bench_forced_rccl_1rank.json" 2>> "$OUT/bench.err"
+python tools/run_config.py c3 --minutes 60 --oracle > "$OUT/c3_60min.json" 2>> "$OUT/bench.err"
+python tools/e2e.py > "$OUT/e2e_c2.json" 2>> "$OUT/bench.err"
+ls -la "$OUT"

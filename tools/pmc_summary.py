@@ -19,9 +19,10 @@ from collections import defaultdict
 
 GROUPS = [
     (r"fft_pass<\d+, 1,", "fft_pass_fwd"), (r"fft_pass<\d+, -1,", "fft_pass_inv"),
+    (r"mr_pass<\d+, \d+, 0>", "fft_pass_fwd"), (r"mr_pass<\d+, \d+, 1>", "fft_pass_inv"),
     (r"notch_kernel", "notch_filtfilt"), (r"hconv_env_median|hilbert_abs|hconv_env\b", "env_median"),
     (r"select_l0|select_l1|select_compact", "select_hist"), (r"select_finish|select_lerp", "select_scan"),
-    (r"quantise_kernel", "quantise"), (r"sync_corr_kernel", "sync_corr"), (r"sync_pick_kernel", "sync_pick"),
+    (r"quantise_kernel|quantise_corr_kernel", "quantise"), (r"sync_corr_kernel", "sync_corr"), (r"sync_pick_kernel", "sync_pick"),
     (r"image_kernel", "lines_to_image"), (r"median5_kernel", "median5"), (r"fir_hilbert", "fir_analytic"),
     (r"merge_kernel|i16_to_f64", "merge_channels"), (r"bs_|hilbert_mid|hconv_fill|hconv_pack", "bluestein_pointwise"),
     (r"resample_", "resample_pointwise"),
@@ -48,6 +49,16 @@ def collect(d, counter):
                     continue
                 tot[g] += float(row["Counter_Value"])
                 cnt[g] += 1
+    for f in glob.glob(os.path.join(d, "pmc_*_per_kernel.csv")) if os.path.isdir(d) else [d]:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("counter") != counter:
+                    continue
+                g = group_of(row["kernel"])
+                if g is None:
+                    continue
+                tot[g] += float(row["mean_value"]) * int(row["dispatches"])
+                cnt[g] += int(row["dispatches"])
     return {g: (tot[g] / cnt[g], cnt[g]) for g in tot}
 
 

@@ -157,16 +157,16 @@ __device__ __forceinline__ void mr_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and fetches the
 // next tile into registers while the current one is transformed, so HBM stays busy during the
 // LDS stages.
-template <int IN_MODE, int OUT_MODE>
+template <int IN_MODE, int OUT_MODE, int INVERSE>
 __global__ void __launch_bounds__(256, 2)
 mr_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
-        int inverse, int ntiles)
+        int ntiles)
 {
     constexpr int NPRE = MR_TILE / 256;
     __shared__ cplx tile[MR_TILE];
     __shared__ cplx wr[256];
     __shared__ unsigned short rev[256];       // rev[q] = position of X[q] after the in-place DIF stages
-    const bool inv = inverse != 0;
+    constexpr bool inv = INVERSE != 0;
     const int R = d.R, T = d.T, log2t = d.log2t, tmask = T - 1;
     const int nelem = R << log2t;
     // all index arithmetic is 32-bit: L < 2^31
@@ -460,14 +460,16 @@ int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_
             const cplx *lo = tb + pc->h.lo_off[i], *hi = tb + pc->h.hi_off[i];
             const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
             const bool first = dir == 0 && i == 0, last_fwd = dir == 0 && i == np - 1;
-            if (first && last_fwd)
-                WFX_LAUNCH(ctx, kid, (mr_pass<1, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, dir, ntiles);
+            if (dir == 1)
+                WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+            else if (first && last_fwd)
+                WFX_LAUNCH(ctx, kid, (mr_pass<1, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
             else if (first)
-                WFX_LAUNCH(ctx, kid, (mr_pass<1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, dir, ntiles);
+                WFX_LAUNCH(ctx, kid, (mr_pass<1, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
             else if (last_fwd)
-                WFX_LAUNCH(ctx, kid, (mr_pass<0, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, dir, ntiles);
+                WFX_LAUNCH(ctx, kid, (mr_pass<0, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
             else
-                WFX_LAUNCH(ctx, kid, (mr_pass<0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, dir, ntiles);
+                WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
             src = dst;
             dst = (dst == A) ? B : A;
         }
