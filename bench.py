@@ -49,6 +49,11 @@ def parse():
     ap.add_argument("--shard", action="store_true",
                     help="sample-range sharding of ONE capture of n_gpus x 10 minutes (halo FIR path, 6 histogram "
                          "all-reduces + 1 image gather per step) instead of one capture per GPU")
+    ap.add_argument("--workload", choices=["c2", "iq"], default="c2",
+                    help="c2: BASELINE configs[1], the 10-minute 11 025 Hz capture (default).  iq: BASELINE configs[3], ONE "
+                         "1.536 MS/s int16 IQ stream of --iq-seconds, synthesised in HBM, time-domain front end + halo-local "
+                         "path, sharded by sample range over the ranks")
+    ap.add_argument("--iq-seconds", type=float, default=3600.0, help="length of the IQ stream (BASELINE: 60 minutes)")
     ap.add_argument("--batch", type=int, default=1,
                     help="captures decoded concurrently per GPU, one native context (= HIP stream) each; "
                          "BASELINE configs[4] uses 8 per GPU with mixed 120/240 LPM, IOC576/288 members")
@@ -157,6 +162,116 @@ def bench_sharded(args, world, rank, local_rank, use_dist, dist, torch, nat):
     ctx.close()
 
 
+def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
+    """BASELINE configs[3]: one 1.536 MS/s int16 IQ stream, sharded by sample range (strong scaling: the stream
+    is fixed, every rank owns 1/world of it plus halos)."""
+    import torch as th            # plumbing: device memory + the test-signal synthesis (wefax_amd/synth_device.py)
+    from wefax_amd import polyphase, sharded, synth_device
+    from wefax_amd.multi import ImageExchange
+    fs = 1536000
+    secs = float(args.iq_seconds)
+    kw = dict(start_tone_s=5.0, phasing_lines=60, image_lines=int((secs - 15.0) / 0.5) - 60, stop_tone_s=5.0, black_tail_s=5.0)
+    n0 = synth_device.capture_frames(float(fs), **kw)
+    fe = polyphase.FrontEnd(fs)
+    n = fe.n_out(n0)
+    dev = th.device("cuda", local_rank)
+    th.cuda.set_device(local_rank)
+    ctx = nat.Context(local_rank)
+    comm = sharded.TorchComm(dist, th, dev) if use_dist else sharded.LocalComm()
+    keep = {}
+
+    def raw_loader(lo, hi):
+        keep["raw"] = synth_device.synth_iq_slice(th, dev, lo, hi, float(fs), noise=args.noise, seed=0, **kw)
+        th.cuda.synchronize()
+        return keep["raw"].data_ptr(), hi - lo
+
+    t_syn = time.perf_counter()
+    dec = sharded.ShardedDecoder(sharded.HipStages(ctx), None, n, world, rank, 120, 4095, frontend=fe, n_in_total=n0,
+                                 in_kind=nat.WFX_IN_I16_STEREO, raw_loader=raw_loader)
+    t_syn = time.perf_counter() - t_syn
+    p = dec.plan
+    exchange = ImageExchange(dist, th, 4 * dec.width * ((p.o1 - p.o0) // dec.width + 4), dev) if use_dist else None
+
+    def step():
+        return dec.run(comm, exchange, keep_on_device=True)      # the image ends resident in HBM (one rank) / gathered by RCCL
+
+    def sync_all():
+        ctx.sync()
+        if use_dist:
+            th.cuda.synchronize()
+            dist.barrier()
+            th.cuda.synchronize()
+
+    with _StdoutToStderr():
+        for _ in range(max(args.warmup, 1)):
+            res = step()
+        sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = th.tensor([dt], dtype=th.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kernels, roofline = {}, None
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    step()
+    sync_all()
+    ctx.profile_enable(False)
+    if rank == 0:
+        prof = ctx.profile()
+        kernels = {k: {"launches_per_step": v[0], "avg_us": round(1e3 * v[1] / v[0], 2), "us_per_step": round(1e3 * v[1], 1)}
+                   for k, v in prof.items()}
+        dom = max(prof.items(), key=lambda kv: kv[1][1])
+        ia, ib = dec.chain[0][2]
+        alg_bytes = (ib - ia) * 4 + 4 * (p.o1 - p.o0)           # SURVEY.md 8(d): N0*B_in + 4*N, this rank's share
+        avg_s = dom[1][1] / dom[1][0] / 1e3
+        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(alg_bytes / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "launches_per_step": dom[1][0],
+                    "whole_path_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        import tempfile
+        from oracle import wefax_oracle as wo
+        from wefax_amd import synth
+        s_secs = 30.0
+        xs = synth.synth_capture(float(fs), noise=args.noise, seed=0, iq=True, start_tone_s=2.0, phasing_lines=20,
+                                 image_lines=int((s_secs - 14.0) / 0.5), stop_tone_s=1.0, black_tail_s=1.0)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "iq.wav")
+            synth.write_wav(path, fs, xs)
+            t1 = time.perf_counter()
+            wo.process(path, 120, want_messages=False)
+            dtc = time.perf_counter() - t1
+        cpu = {"value": round(xs.shape[0] / dtc / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+               "host_cpus": os.cpu_count(), "seconds": round(dtc, 3),
+               "sample": f"a self-contained {s_secs:.0f} s capture of the same stream format ({xs.shape[0]} IQ frames), "
+                         "reference-faithful path (stereo merge + FFT resample), one run, read from a wav file"}
+    if rank == 0:
+        sync = res[1]
+        print(json.dumps({
+            "metric": "Msamples/s demod->pixel", "value": round(n0 * args.steps / dt / 1e6, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 stencils / f64 elsewhere",
+            "data": "synthetic",
+            "config": {"workload": f"ONE synthetic 1.536 MS/s int16 IQ stream of {secs:.0f} s (BASELINE configs[3]): {n0} IQ frames "
+                                   f"-> {n} samples at 11 025 Hz, 120 LPM, AWGN sigma {args.noise} FS, synthesised in HBM",
+                       "front_end": fe.describe(), "hilbert": "fir4095", "start_frame": sync["start_frame"],
+                       "image": [dec.width, 4 * sync["height"]], "synthesis_s": round(t_syn, 2),
+                       "parallelism": f"sample-range sharding over {world} GPU(s): halo recompute, 6 histogram all-reduces, "
+                                      "1 broadcast, 1 RCCL image gather per step"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,6 +300,8 @@ def main():
     from wefax_amd import _native as nat
     from wefax_amd.wefax import DecodeJob
 
+    if args.workload == "iq":
+        return bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat)
     if args.shard:
         return bench_sharded(args, world, rank, local_rank, use_dist, dist, torch, nat)
 

@@ -39,7 +39,8 @@ typedef enum {
 typedef enum {
     WFX_IN_I16_MONO = 0,    /* int16[n]                                         */
     WFX_IN_I16_STEREO = 1,  /* int16[n][2] -> (int16)(L+R) wrapped, then /2      */
-    WFX_IN_F64_MONO = 2     /* float64[n] (any other wav dtype, converted on host) */
+    WFX_IN_F64_MONO = 2,    /* float64[n] (any other wav dtype, converted on host) */
+    WFX_IN_F32_MONO = 3     /* float32[n]: only between the stages of the time-domain front end (wfx_d_decimate_fir ...) */
 } wfx_in_kind;
 
 /* how the analytic signal (scipy.signal.hilbert, wefax.py:174) is computed */
@@ -182,6 +183,20 @@ int wfx_dev_copy(wfx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes)
  * edge_flags bit 0 / bit 1 the segment starts / ends at the capture's true start / end and gets filtfilt's exact edge */
 int wfx_d_notch_fir(wfx_ctx *ctx, const int16_t *in_dev, size_t n, const double b[3], const double a[3], double *out_dev,
                     int edge_flags);
+int wfx_d_notch_fir_f64(wfx_ctx *ctx, const double *in_dev, size_t n, const double b[3], const double a[3], double *out_dev,
+                        int edge_flags);
+/* a4 + a5 in halo-local form (oversampled captures, BASELINE configs[3]): the time-domain counterpart of
+ * wefax.py:360-394.  in_kind WFX_IN_I16_MONO, WFX_IN_I16_STEREO (= interleaved IQ; merged as (int16)(L+R)/2 while
+ * loading) or WFX_IN_F32_MONO; coefficient arrays are HOST pointers, designed by the caller
+ * (wefax_amd/polyphase.py).  fp32 accumulation in a fixed order per output sample.
+ *   decimate:  out[i] = sum_{j<ntaps} coef[j] * in[first + i*factor + j],  factor a power of two <= 64,
+ *              out float32 (out_f64 = 0) or float64 (out_f64 = 1)
+ *   rational:  out[i] = sum_{j<taps} table[(((m0+i)*p) mod q)*taps + j] * in[floor((m0+i)*p/q) - base0 + j]
+ * samples of `in` outside [0, n_in) read as zero */
+int wfx_d_decimate_fir(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const float *coef,
+                       int ntaps, void *out_dev, int out_f64, size_t n_out);
+int wfx_d_resample_rational(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t base0, int p, int q,
+                            const float *table, int taps, int64_t m0, float *out_dev, size_t n_out);
 /* a7: |x + i H| with the `taps`-lag circular Hilbert kernel of a signal of n_global samples; valid (taps-1)/2 away from the ends */
 int wfx_d_fir_envelope(wfx_ctx *ctx, const double *x_dev, size_t n, size_t n_global, int taps, double *env_raw_dev);
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev);

@@ -3,8 +3,10 @@
 
     python tools/run_config.py c3 [--minutes 60] [--oracle] [--steps 3]
 
-c2: 10-min 11 025 Hz mono; c3: N-min 48 kHz mono (resample path); prints one JSON line
-with timings, parity and the per-kernel HIP-event profile.
+c2: 10-min 11 025 Hz mono; c3: N-min 48 kHz mono (resample path); c4: --seconds S of the
+1.536 MS/s int16 IQ stream through the reference-faithful path (stereo merge with int16
+wrap, exact FFT resample); prints one JSON line with timings, parity and the per-kernel
+HIP-event profile.
 """
 import argparse
 import json
@@ -24,8 +26,9 @@ from wefax_amd.wefax import DecodeJob    # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c2", "c3"])
+    ap.add_argument("config", choices=["c2", "c3", "c4"])
     ap.add_argument("--minutes", type=float, default=None)
+    ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--oracle", action="store_true")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--noise", type=float, default=0.05)
@@ -33,6 +36,10 @@ def main():
     t0 = time.time()
     if a.config == "c2":
         fs, x = 11025, synth.config_c2(noise=a.noise, seed=0)
+    elif a.config == "c4":
+        lines = int((a.seconds - 14.0) / 0.5)
+        fs, x = 1536000, synth.synth_capture(1536000.0, noise=a.noise, seed=0, iq=True, start_tone_s=2.0, phasing_lines=20,
+                                             image_lines=lines, stop_tone_s=1.0, black_tail_s=1.0)
     else:
         minutes = a.minutes or 60.0
         lines = int((minutes * 60.0 - 15.0) / 0.5) - 60

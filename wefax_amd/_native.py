@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwefax_hip.so")
 
-WFX_IN_I16_MONO, WFX_IN_I16_STEREO, WFX_IN_F64_MONO = 0, 1, 2
+WFX_IN_I16_MONO, WFX_IN_I16_STEREO, WFX_IN_F64_MONO, WFX_IN_F32_MONO = 0, 1, 2, 3
 WFX_HILBERT_FFT, WFX_HILBERT_FIR, WFX_HILBERT_BLUESTEIN, WFX_HILBERT_FFT_POW2 = 0, 1, 2, 3
 WFX_BUF_AUDIO, WFX_BUF_ENVELOPE, WFX_BUF_DIGITAL, WFX_BUF_IMAGE = 0, 1, 2, 3
 WFX_MAX_PEAKS = 100
@@ -28,7 +28,7 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_resample_rational", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
     "wfx_profile_kernel_count", "wfx_profile_kernel_name", "wfx_profile_get",
@@ -124,6 +124,9 @@ def load():
     lib.wfx_dev_download.argtypes = [vp, vp, vp, sz]
     lib.wfx_dev_copy.argtypes = [vp, vp, vp, sz]
     lib.wfx_d_notch_fir.argtypes = [vp, vp, sz, dp, dp, vp, i]
+    lib.wfx_d_notch_fir_f64.argtypes = [vp, vp, sz, dp, dp, vp, i]
+    lib.wfx_d_decimate_fir.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, i, sz]
+    lib.wfx_d_resample_rational.argtypes = [vp, vp, i, sz, C.c_int64, i, i, vp, i, C.c_int64, vp, sz]
     lib.wfx_d_fir_envelope.argtypes = [vp, vp, sz, sz, i, vp]
     lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
     lib.wfx_d_select_hist.argtypes = [vp, vp, sz, i, C.POINTER(C.c_uint64), vp]
@@ -308,6 +311,24 @@ class Context:
         bb = (C.c_double * 3)(*[float(v) for v in b])
         aa = (C.c_double * 3)(*[float(v) for v in a])
         self._check(self.lib.wfx_d_notch_fir(self.h, C.c_void_p(in_ptr), n, bb, aa, C.c_void_p(out_ptr), edge_flags))
+
+    def d_notch_fir_f64(self, in_ptr: int, n: int, b, a, out_ptr: int, edge_flags: int = 0):
+        bb = (C.c_double * 3)(*[float(v) for v in b])
+        aa = (C.c_double * 3)(*[float(v) for v in a])
+        self._check(self.lib.wfx_d_notch_fir_f64(self.h, C.c_void_p(in_ptr), n, bb, aa, C.c_void_p(out_ptr), edge_flags))
+
+    def d_decimate_fir(self, in_ptr: int, in_kind: int, n_in: int, first: int, factor: int, coef: np.ndarray, out_ptr: int,
+                       out_f64: bool, n_out: int):
+        c = np.ascontiguousarray(coef, dtype=np.float32)
+        self._check(self.lib.wfx_d_decimate_fir(self.h, C.c_void_p(in_ptr), in_kind, n_in, first, factor, _ptr(c), c.shape[0],
+                                                C.c_void_p(out_ptr), 1 if out_f64 else 0, n_out))
+
+    def d_resample_rational(self, in_ptr: int, in_kind: int, n_in: int, base0: int, p: int, q: int, table: np.ndarray, m0: int,
+                            out_ptr: int, n_out: int):
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        assert t.ndim == 2 and t.shape[0] == q
+        self._check(self.lib.wfx_d_resample_rational(self.h, C.c_void_p(in_ptr), in_kind, n_in, base0, p, q, _ptr(t), t.shape[1], m0,
+                                                     C.c_void_p(out_ptr), n_out))
 
     def d_fir_envelope(self, x_ptr: int, n: int, n_global: int, taps: int, out_ptr: int):
         self._check(self.lib.wfx_d_fir_envelope(self.h, C.c_void_p(x_ptr), n, n_global, taps, C.c_void_p(out_ptr)))

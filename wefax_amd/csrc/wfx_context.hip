@@ -109,7 +109,7 @@ void wfx_destroy(wfx_ctx *ctx)
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     wfx_devbuf *bufs[] = {&ctx->b_in, &ctx->b_x, &ctx->b_audio, &ctx->b_work, &ctx->b_work2, &ctx->b_envraw,
                           &ctx->b_env, &ctx->b_dig, &ctx->b_corr, &ctx->b_img, &ctx->b_hist, &ctx->b_tmp,
-                          &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps, &ctx->b_cand};
+                          &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps, &ctx->b_cand, &ctx->b_pcoef};
     for (auto *b : bufs) free_buf(*b);
     for (auto &kv : ctx->plans) free_buf(kv.second.bhat);
     for (auto &kv : ctx->hplans) free_buf(kv.second.bhat);
@@ -156,7 +156,8 @@ int wfx_timer_stop(wfx_ctx *ctx, float *ms)
 static const char *k_names[K_COUNT] = {
     "merge_channels", "notch_filtfilt", "bluestein_pointwise", "fft_pass_fwd", "fft_pass_inv",
     "env_median",     "fir_analytic",   "median5",             "select_hist",  "select_scan",
-    "quantise",       "sync_corr",      "sync_pick",           "lines_to_image", "resample_pointwise"};
+    "quantise",       "sync_corr",      "sync_pick",           "lines_to_image", "resample_pointwise",
+    "polyphase_ingest", "polyphase_stages"};
 
 int wfx_profile_kernel_count(void) { return K_COUNT; }
 const char *wfx_profile_kernel_name(int i) { return (i >= 0 && i < K_COUNT) ? k_names[i] : ""; }

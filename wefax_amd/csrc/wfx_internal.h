@@ -31,6 +31,8 @@ enum wfx_kernel_id {
     K_SYNC_PICK,
     K_IMAGE,
     K_RESAMPLE_PW,     // resampler pointwise kernels
+    K_POLYPHASE_IN,    // time-domain front end, stage that reads the raw int16 capture (merge fused)
+    K_POLYPHASE,       // time-domain front end, later stages (float32 in)
     K_COUNT
 };
 
@@ -76,7 +78,7 @@ struct wfx_ctx {
 
     // named device buffers (grown on demand, reused across calls)
     wfx_devbuf b_in, b_x, b_audio, b_work, b_work2, b_envraw, b_env, b_dig, b_corr,
-        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand;
+        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand, b_pcoef;
     bool w256_ready = false;
     bool force_pow2 = false;     // WFX_HILBERT_FFT_POW2: always use the zero-padded power-of-two convolution
     std::map<uint64_t, wfx_bs_plan> plans;    // Bluestein chirp filters (resampler, cross-check mode)
@@ -208,7 +210,7 @@ int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max,
                   const wfx_dev_scalars *d_scal, uint8_t *img);
 int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t start, int w, int h_total, int y0, int rows,
                        uint8_t *img);
-int wfx_dev_notch_fir_only(wfx_ctx *ctx, const int16_t *in, uint64_t n, const double b[3], const double a[3], double *out,
+int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out,
                            int edge_flags);
 int wfx_dev_select_level(wfx_ctx *ctx, const double *env, uint64_t n, int level, const uint64_t prefix[4], unsigned *hist);
 
@@ -216,6 +218,12 @@ int wfx_dev_select_level(wfx_ctx *ctx, const double *env, uint64_t n, int level,
 bool wfx_mr_supported(uint64_t L);
 void wfx_mr_release(wfx_ctx *ctx);
 int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out);
+
+// wfx_polyphase.hip
+int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const float *coef, int ntaps,
+                         void *out, int out_f64, uint64_t n_out);
+int wfx_dev_resample_rational(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t base0, int p, int q, const float *table,
+                              int T, int64_t m0, float *out, uint64_t n_out);
 
 // wfx_fir.hip
 int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps, double *env_raw, uint64_t n_global = 0);

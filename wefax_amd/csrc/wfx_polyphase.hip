@@ -1,0 +1,467 @@
+// Halo-local sample-rate front end for oversampled captures (BASELINE configs[3]: 1.536 MS/s
+// int16 IQ; SURVEY.md section 8e "use FIR mode when sharded"): the time-domain counterpart
+// of wefax.py:375-394 (scipy FFT resample, a global operator) built from two stencils,
+//
+//   decimate_fir       y[i] = sum_j c[j] * x[first + i*M + j]            (M a power of two)
+//   resample_rational  y[i] = sum_j h[((m0+i)*p) mod q][j] * x[floor((m0+i)*p/q) - base0 + j]
+//
+// chained by the host (wefax_amd/polyphase.py designs the filters and keeps the index
+// bookkeeping): 1.536 MS/s --/32--> 48 kHz --147/160--> 44.1 kHz --/4--> 11 025 Hz.
+// Both read every input byte once (16-byte loads), keep the window in LDS and are
+// HBM-bound; fp32 accumulation in one canonical order per output sample, so the result
+// does not depend on how a capture is cut into slices.  The stereo/IQ merge of
+// wefax.py:360-373 ((int16)(L+R) wrapped, /2) is fused into the load.
+#include "wfx_internal.h"
+
+namespace {
+
+constexpr int PP_THREADS = 256;
+constexpr int PP_LDS_BYTES = 64 * 1024;
+
+// 4 consecutive LDS samples: fetched raw (so that the conversion can wait until the values are needed) ...
+__device__ __forceinline__ int2 pp_raw4(const short *p)
+{
+    const int *q = (const int *)p;                    // 4-byte aligned: rows of the int16 layout start on even indices
+    return make_int2(q[0], q[1]);
+}
+__device__ __forceinline__ float4 pp_raw4(const float *p) { return *(const float4 *)p; }
+// ... and converted to float
+__device__ __forceinline__ void pp_cvt4(const int2 &r, float *w)
+{
+    w[0] = (float)(short)r.x;
+    w[1] = (float)(r.x >> 16);
+    w[2] = (float)(short)r.y;
+    w[3] = (float)(r.y >> 16);
+}
+__device__ __forceinline__ void pp_cvt4(const float4 &r, float *w)
+{
+    w[0] = r.x;
+    w[1] = r.y;
+    w[2] = r.z;
+    w[3] = r.w;
+}
+
+// ---- element access -----------------------------------------------------------
+// IN 0: int16 mono, 1: int16 pairs merged with int16 wrap, 3: float
+template <int IN> struct pp_in;
+template <> struct pp_in<WFX_IN_I16_MONO> {
+    typedef short store_t;                    // LDS representation
+    static constexpr int PER16 = 8;           // elements per 16-byte chunk
+    static constexpr int BYTES = 2;
+    static constexpr float SCALE = 1.0f;
+    __device__ static void chunk(const uint4 &v, store_t *e)
+    {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            e[2 * k] = (short)(w[k] & 0xffffu);
+            e[2 * k + 1] = (short)(w[k] >> 16);
+        }
+    }
+    __device__ static store_t one(const void *p, long long i) { return ((const short *)p)[i]; }
+};
+template <> struct pp_in<WFX_IN_I16_STEREO> {
+    typedef short store_t;
+    static constexpr int PER16 = 4;
+    static constexpr int BYTES = 4;
+    static constexpr float SCALE = 0.5f;      // (L+R)/2: the wrapped sum is kept as int16, the /2 goes into the scale
+    __device__ static void chunk(const uint4 &v, store_t *e)
+    {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = (short)((w[k] & 0xffffu) + (w[k] >> 16));
+    }
+    __device__ static store_t one(const void *p, long long i)
+    {
+        const unsigned w = ((const unsigned *)p)[i];
+        return (short)((w & 0xffffu) + (w >> 16));
+    }
+};
+template <> struct pp_in<WFX_IN_F32_MONO> {
+    typedef float store_t;
+    static constexpr int PER16 = 4;
+    static constexpr int BYTES = 4;
+    static constexpr float SCALE = 1.0f;
+    __device__ static void chunk(const uint4 &v, store_t *e)
+    {
+        e[0] = __uint_as_float(v.x);
+        e[1] = __uint_as_float(v.y);
+        e[2] = __uint_as_float(v.z);
+        e[3] = __uint_as_float(v.w);
+    }
+    __device__ static store_t one(const void *p, long long i) { return ((const float *)p)[i]; }
+};
+
+// one 16-byte chunk starting at element e0 of the aligned view; elements outside the caller's array read as zero
+template <int IN>
+__device__ __forceinline__ uint4 pp_fetch(const void *in, const unsigned char *base, long long e0, int misalign, long long n_in)
+{
+    typedef pp_in<IN> A;
+    if (e0 >= misalign && e0 + A::PER16 <= n_in + misalign) return *(const uint4 *)(base + e0 * A::BYTES);
+    const long long ci = e0 - misalign;
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (A::BYTES == 4) {
+            w[k] = (ci + k >= 0 && ci + k < n_in) ? ((const unsigned *)in)[ci + k] : 0u;
+        } else {
+            const long long c0 = ci + 2 * k, c1 = c0 + 1;
+            const unsigned lo = (c0 >= 0 && c0 < n_in) ? ((const unsigned short *)in)[c0] : 0u;
+            const unsigned hi = (c1 >= 0 && c1 < n_in) ? ((const unsigned short *)in)[c1] : 0u;
+            w[k] = lo | (hi << 16);
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- integer decimation ---------------------------------------------------------
+// LDS holds the tile's input window in polyphase order: sample w (window-relative) sits at
+// row w % M, column w / M.  A thread owns 4 consecutive outputs and a group of rows; for one
+// row it slides a register window along the columns: one 4-column LDS read feeds 16 FMAs, and
+// the tap c[r + M*jq] is the same for every thread (scalar loads from the polyphase-ordered
+// table).  The global loads of a tile are issued in batches of PP_BATCH 16-byte chunks per
+// thread before any of them is consumed (bytes in flight, not occupancy, hide the HBM latency).
+// When a tile has fewer than 256 output quads the rows are split over `rs` thread groups whose
+// partial sums are added in group order through LDS: the order of additions per output is
+// fixed by (M, rs) alone, never by where a slice starts.
+constexpr int PP_BATCH = 8;
+constexpr bool PP_PREFETCH = false;   // keep the next tile in registers across the compute phase (costs occupancy)
+constexpr int PP_NB = 18;          // 16-byte chunks per thread and tile (decimate): 72 VGPRs of prefetch
+
+template <int IN, typename OUT, bool ALIGNED>
+__global__ void __launch_bounds__(PP_THREADS)
+decimate_kernel(const void *__restrict__ in, long long n_in, long long first, int log2m, const float *__restrict__ cp, int q4,
+                OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign)
+{
+    typedef pp_in<IN> A;
+    typedef typename A::store_t S;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    S *xs = (S *)lds_raw;
+    const int M = 1 << log2m, t = threadIdx.x, tb = 1 << log2tb;
+    const int log2q = log2tb - 2;                               // quads per tile
+    const int log2qw = log2q < 6 ? 6 : log2q;                   // a row group is made of whole waves: its index is scalar
+    int rs_log2 = 8 - log2qw;                                   // row groups: 256 threads / quads
+    if (rs_log2 > log2m) rs_log2 = log2m;
+    if (rs_log2 < 0) rs_log2 = 0;
+    const int g = t & ((1 << log2qw) - 1);
+    const int part = __builtin_amdgcn_readfirstlane(t >> 6) >> (log2qw - 6);
+    const int rows_per = M >> rs_log2;
+    float *psum = (float *)(lds_raw + (((size_t)row_stride * M * sizeof(S) + 15) & ~(size_t)15));     // [rs - 1][quads][4]
+    // the taps live in LDS as well (broadcast reads): LDS returns in order, so the software-pipelined tap loop can
+    // wait for the oldest read only -- scalar loads would force a full drain of the counter they share with LDS
+    float *cs = psum + PP_THREADS * 4;
+    for (int i = t; i < M * 4 * q4; i += PP_THREADS) cs[i] = cp[i];
+    const long long ntiles = (n_out + tb - 1) >> log2tb;
+    // 16-byte aligned view of the input: element index e of the caller's array is element e + misalign of `base`
+    const unsigned char *base = (const unsigned char *)in - (size_t)misalign * A::BYTES;
+    struct geom {
+        long long o0, src0, a0;
+        int cnt, win, nchunks, wbase;
+    };
+    auto geom_of = [&](long long tile) {
+        geom G;
+        G.o0 = tile << log2tb;
+        G.cnt = (int)((n_out - G.o0 < tb) ? (n_out - G.o0) : tb);
+        G.src0 = first + G.o0 * M;                                      // caller index of window sample 0
+        G.win = (((G.cnt + 3) & ~3) + 4 * q4) * M;                      // samples the register windows touch
+        G.a0 = (G.src0 + misalign) & ~(long long)(A::PER16 - 1);        // aligned start, in elements of `base`
+        G.nchunks = (int)((G.src0 + misalign + G.win - G.a0 + A::PER16 - 1) / A::PER16);     // <= PP_NB * 256 (host)
+        G.wbase = (int)(G.a0 - misalign - G.src0);                      // window index of chunk 0's first element (<= 0)
+        return G;
+    };
+    uint4 v[PP_NB];                                                     // one tile's input, in flight or waiting for its LDS slot
+    auto fetch = [&](const geom &G) {
+        // uniform test: the whole window lies inside the caller's array -> straight-line vector loads, all in flight at once
+        if (G.a0 >= misalign && G.a0 + (long long)G.nchunks * A::PER16 <= n_in + misalign) {
+#pragma unroll
+            for (int u = 0; u < PP_NB; ++u)
+                if (u * PP_THREADS < G.nchunks) {
+                    int c = u * PP_THREADS + t;
+                    c = c < G.nchunks ? c : G.nchunks - 1;
+                    v[u] = *(const uint4 *)(base + (G.a0 + (long long)c * A::PER16) * A::BYTES);
+                }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PP_NB; ++u) {
+                const int c = u * PP_THREADS + t;
+                if (c < G.nchunks) v[u] = pp_fetch<IN>(in, base, G.a0 + (long long)c * A::PER16, misalign, n_in);
+            }
+        }
+    };
+    auto stash = [&](const geom &G) {
+#pragma unroll
+        for (int u = 0; u < PP_NB; ++u) {
+            const int c = u * PP_THREADS + t;
+            if (c < G.nchunks) {
+                S e[A::PER16];
+                A::chunk(v[u], e);
+                const int w0 = G.wbase + c * A::PER16;
+                int r = w0 & (M - 1);
+                int addr = r * row_stride + (w0 >> log2m);
+                if (ALIGNED) {      // the host aligned the window to the 16-byte grid and M >= PER16: one column, consecutive rows
+#pragma unroll
+                    for (int k = 0; k < A::PER16; ++k) xs[addr + k * row_stride] = e[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < A::PER16; ++k) {
+                        if (w0 + k >= 0 && w0 + k < G.win) xs[addr] = e[k];
+                        ++r;
+                        addr += row_stride;
+                        if (r == M) {
+                            r = 0;
+                            addr -= M * row_stride - 1;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    long long tile = blockIdx.x;
+    geom Gn = geom_of(tile < ntiles ? tile : 0);
+    if (PP_PREFETCH && tile < ntiles) fetch(Gn);
+    for (; tile < ntiles; tile += gridDim.x) {
+        if (!PP_PREFETCH) {
+            Gn = geom_of(tile);
+            fetch(Gn);
+        }
+        __syncthreads();                       // the previous tile's compute phase is done with the LDS window
+        stash(Gn);
+        const long long o0 = Gn.o0;
+        const int cnt = Gn.cnt;
+        if (PP_PREFETCH && tile + gridDim.x < ntiles) {       // the next tile's loads fly while this one is computed
+            Gn = geom_of(tile + gridDim.x);
+            fetch(Gn);
+        }
+        __syncthreads();
+        const bool active = (4 * g < cnt) && (part < (1 << rs_log2));
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+        if (active) {
+            const int r0 = part * rows_per;
+            for (int r = r0; r < r0 + rows_per; ++r) {
+                const S *row = xs + r * row_stride + 4 * g;
+                const float *c = cs + r * 4 * q4;
+                float wa[4], wb[4];
+                pp_cvt4(pp_raw4(row), wa);
+                auto rn = pp_raw4(row + 4);
+                float4 cn = *(const float4 *)c;
+                for (int j = 0; j < q4; ++j) {
+                    const float c0 = cn.x, c1 = cn.y, c2 = cn.z, c3 = cn.w;
+                    pp_cvt4(rn, wb);
+                    if (j + 1 < q4) {                 // next taps and next columns are in flight while this group is applied
+                        cn = *(const float4 *)(c + 4 * j + 4);
+                        rn = pp_raw4(row + 4 * j + 8);
+                    }
+                    acc0 = fmaf(c0, wa[0], acc0); acc1 = fmaf(c0, wa[1], acc1); acc2 = fmaf(c0, wa[2], acc2); acc3 = fmaf(c0, wa[3], acc3);
+                    acc0 = fmaf(c1, wa[1], acc0); acc1 = fmaf(c1, wa[2], acc1); acc2 = fmaf(c1, wa[3], acc2); acc3 = fmaf(c1, wb[0], acc3);
+                    acc0 = fmaf(c2, wa[2], acc0); acc1 = fmaf(c2, wa[3], acc1); acc2 = fmaf(c2, wb[0], acc2); acc3 = fmaf(c2, wb[1], acc3);
+                    acc0 = fmaf(c3, wa[3], acc0); acc1 = fmaf(c3, wb[0], acc1); acc2 = fmaf(c3, wb[1], acc2); acc3 = fmaf(c3, wb[2], acc3);
+                    wa[0] = wb[0]; wa[1] = wb[1]; wa[2] = wb[2]; wa[3] = wb[3];
+                }
+            }
+        }
+        if (rs_log2 > 0) {
+            if (active && part > 0) *(float4 *)(psum + ((size_t)((part - 1) << log2qw) + g) * 4) = make_float4(acc0, acc1, acc2, acc3);
+            __syncthreads();
+            if (active && part == 0)
+                for (int q = 1; q < (1 << rs_log2); ++q) {
+                    const float4 o = *(const float4 *)(psum + ((size_t)((q - 1) << log2qw) + g) * 4);
+                    acc0 += o.x; acc1 += o.y; acc2 += o.z; acc3 += o.w;
+                }
+        }
+        if (active && part == 0) {
+            const float a[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * g + k < cnt) out[o0 + 4 * g + k] = (OUT)(a[k] * A::SCALE);
+        }
+    }
+}
+
+// ---- rational resampling ----------------------------------------------------------
+// A workgroup produces PP_RTILE consecutive outputs: their input span goes through LDS as
+// float (batched coalesced loads), the q x T coefficient table sits beside it with an odd row
+// stride; a thread walks its outputs (stride 256) with an incremental (position, phase).
+constexpr int PP_RTILE = 2048;
+
+template <int IN>
+__global__ void __launch_bounds__(PP_THREADS)
+rational_kernel(const void *__restrict__ in, long long n_in, long long base0, int p, int q, const float *__restrict__ table, int T,
+                long long m0, float *__restrict__ out, long long n_out, int span_cap)
+{
+    typedef pp_in<IN> A;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    float *tab = (float *)lds_raw;
+    const int ts = T | 1, t = threadIdx.x;
+    float *xs = tab + q * ts;
+    for (int i = t; i < q * T; i += PP_THREADS) tab[(i / T) * ts + (i % T)] = table[i];
+    const long long ntiles = (n_out + PP_RTILE - 1) / PP_RTILE;
+    const unsigned long long sp = (unsigned long long)PP_THREADS * (unsigned long long)p;
+    const int dpos = (int)(sp / (unsigned)q), dphase = (int)(sp % (unsigned)q);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long i0 = tile * PP_RTILE;
+        const int cnt = (int)((n_out - i0 < PP_RTILE) ? (n_out - i0) : PP_RTILE);
+        const long long posA = (long long)(((unsigned long long)(m0 + i0) * (unsigned long long)p) / (unsigned)q) - base0;
+        const long long posB = (long long)(((unsigned long long)(m0 + i0 + cnt - 1) * (unsigned long long)p) / (unsigned)q) - base0 + T;
+        const int span = (int)(posB - posA);          // <= span_cap by the host's choice of p/q
+        __syncthreads();
+        for (int sb = 0; sb < span; sb += PP_THREADS * PP_BATCH) {
+            float v[PP_BATCH];
+#pragma unroll
+            for (int u = 0; u < PP_BATCH; ++u) {
+                const int k = sb + u * PP_THREADS + t;
+                const long long s = posA + k;
+                v[u] = (k < span && s >= 0 && s < n_in) ? (float)A::one(in, s) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < PP_BATCH; ++u) {
+                const int k = sb + u * PP_THREADS + t;
+                if (k < span && k < span_cap) xs[k] = v[u];
+            }
+        }
+        __syncthreads();
+        if (t < cnt) {
+            const unsigned long long mp = (unsigned long long)(m0 + i0 + t) * (unsigned long long)p;
+            int pos = (int)((long long)(mp / (unsigned)q) - base0 - posA);
+            int phase = (int)(mp % (unsigned)q);
+            for (int i = t; i < cnt; i += PP_THREADS) {
+                const float *h = tab + phase * ts;
+                const float *x = xs + pos;
+                float acc = 0.f;
+                for (int j = 0; j < T; ++j) acc = fmaf(h[j], x[j], acc);
+                out[i0 + i] = acc * A::SCALE;
+                pos += dpos;
+                phase += dphase;
+                if (phase >= q) {
+                    phase -= q;
+                    pos += 1;
+                }
+            }
+        }
+    }
+}
+
+int ilog2_exact(int m)
+{
+    int l = 0;
+    while ((1 << l) < m) ++l;
+    return ((1 << l) == m) ? l : -1;
+}
+
+template <int IN, typename OUT>
+int launch_decimate(wfx_ctx *ctx, const void *in, long long n_in, long long first, int log2m, const float *cp, int q4, OUT *out,
+                    long long n_out, bool aligned)
+{
+    typedef pp_in<IN> A;
+    const int M = 1 << log2m;
+    const int esz = (int)sizeof(typename A::store_t);
+    const int pad = esz == 2 ? 6 : 4;                // int16 rows: stride = 2 (mod 4) spreads a chunk's rows over the banks
+    int tb = 1024;                                   // outputs per tile: 4 per thread
+    while (tb > 64 && ((size_t)(tb + 4 * q4 + pad) * M * esz > (size_t)PP_LDS_BYTES ||
+                       ((size_t)(tb + 4 * q4) * M + 2 * A::PER16) / A::PER16 > (size_t)PP_NB * PP_THREADS))
+        tb >>= 1;
+    if (((size_t)(tb + 4 * q4) * M + 2 * A::PER16) / A::PER16 > (size_t)PP_NB * PP_THREADS)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d exceed the per-tile prefetch", 4 * q4 * M, M);
+    const int row_stride = tb + 4 * q4 + pad;
+    const size_t lds_x = ((size_t)row_stride * M * esz + 15) & ~(size_t)15;
+    const size_t lds = lds_x + (size_t)PP_THREADS * 4 * sizeof(float) + (size_t)M * 4 * q4 * sizeof(float);     // + partial sums + taps
+    if (lds_x > (size_t)PP_LDS_BYTES) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
+    const int misalign = (int)(((uintptr_t)in & 15u) / A::BYTES);
+    const long long ntiles = (n_out + tb - 1) / tb;
+    const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
+    auto kern = aligned ? decimate_kernel<IN, OUT, true> : decimate_kernel<IN, OUT, false>;
+    if (lds > 48 * 1024) WFX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    wfx_prof_begin(ctx, (IN == WFX_IN_F32_MONO ? K_POLYPHASE : K_POLYPHASE_IN));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PP_THREADS), lds, ctx->stream, in, n_in, first, log2m, cp, q4, out, n_out, ilog2_exact(tb),
+                       row_stride, misalign);
+    wfx_prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch decimate_kernel");
+    return 0;
+}
+
+template <int IN>
+int launch_rational(wfx_ctx *ctx, const void *in, long long n_in, long long base0, int p, int q, const float *table, int T, long long m0,
+                    float *out, long long n_out)
+{
+    const long long span_cap = ((long long)PP_RTILE * p) / q + T + 2;
+    const size_t lds = ((size_t)q * (T | 1) + (size_t)span_cap) * sizeof(float);
+    if (lds > (size_t)PP_LDS_BYTES)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "rational: %d phases x %d taps at ratio %d/%d do not fit LDS", q, T, p, q);
+    const unsigned grid = wfx_stream_grid((uint64_t)n_out, PP_RTILE);
+    auto kern = rational_kernel<IN>;
+    if (lds > 48 * 1024) WFX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    wfx_prof_begin(ctx, (IN == WFX_IN_F32_MONO ? K_POLYPHASE : K_POLYPHASE_IN));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PP_THREADS), lds, ctx->stream, in, n_in, base0, p, q, table, T, m0, out, n_out, (int)span_cap);
+    wfx_prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch rational_kernel");
+    return 0;
+}
+
+}   // namespace
+
+// coef: ntaps taps in natural order (host memory).  They are re-ordered into M rows of 4*q4 taps
+// (row r holds c[r], c[r+M], ...; zero padded) so that a workgroup reads them with scalar loads.
+int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const float *coef, int ntaps,
+                         void *out, int out_f64, uint64_t n_out)
+{
+    const int log2m = ilog2_exact(M);
+    if (log2m < 0 || M > 64) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: factor %d is not a power of two <= 64", M);
+    if (ntaps < 1 || ntaps > 4096) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps", ntaps);
+    if (n_out == 0) return 0;
+    // Align the tile windows to the 16-byte grid of the input: move `first` down by d elements and put d zero taps in
+    // front of the filter.  Then every 16-byte chunk holds PER16 consecutive rows of ONE column (needs M >= PER16).
+    const int per16 = (in_kind == WFX_IN_I16_MONO) ? 8 : 4, ebytes = (in_kind == WFX_IN_I16_MONO) ? 2 : 4;
+    if ((uintptr_t)in % ebytes) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: misaligned input pointer");
+    const int misalign = (int)(((uintptr_t)in & 15u) / ebytes);
+    const bool aligned = M >= per16;
+    int d = 0;
+    if (aligned) {
+        d = (int)(((first + misalign) % per16 + per16) % per16);
+        first -= d;
+    }
+    const int nt = ntaps + d;
+    const int per_row = (nt + M - 1) / M;
+    const int q4 = (per_row + 3) / 4;
+    std::vector<float> cp((size_t)M * 4 * q4, 0.0f);
+    for (int j = 0; j < ntaps; ++j) cp[(size_t)((j + d) % M) * 4 * q4 + (j + d) / M] = coef[j];
+    WFX_TRY(wfx_reserve(ctx, ctx->b_pcoef, cp.size() * sizeof(float)));
+    WFX_HIP(ctx, hipMemcpyAsync(ctx->b_pcoef.p, cp.data(), cp.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));      // cp is a stack-owned staging buffer
+    const float *dcoef = (const float *)ctx->b_pcoef.p;
+    const long long ni = (long long)n_in, no = (long long)n_out;
+#define WFX_PP_CASE(KIND)                                                                                       \
+    case KIND:                                                                                                  \
+        return out_f64 ? launch_decimate<KIND, double>(ctx, in, ni, first, log2m, dcoef, q4, (double *)out, no, aligned)     \
+                       : launch_decimate<KIND, float>(ctx, in, ni, first, log2m, dcoef, q4, (float *)out, no, aligned);
+    switch (in_kind) {
+        WFX_PP_CASE(WFX_IN_I16_MONO)
+        WFX_PP_CASE(WFX_IN_I16_STEREO)
+        WFX_PP_CASE(WFX_IN_F32_MONO)
+    default:
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: input kind %d", in_kind);
+    }
+#undef WFX_PP_CASE
+}
+
+int wfx_dev_resample_rational(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t base0, int p, int q, const float *table,
+                              int T, int64_t m0, float *out, uint64_t n_out)
+{
+    if (p < 1 || q < 1 || T < 1 || T > 64 || m0 < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "rational: p %d q %d taps %d", p, q, T);
+    if (n_out == 0) return 0;
+    const size_t bytes = (size_t)q * T * sizeof(float);
+    WFX_TRY(wfx_reserve(ctx, ctx->b_pcoef, bytes));
+    WFX_HIP(ctx, hipMemcpyAsync(ctx->b_pcoef.p, table, bytes, hipMemcpyHostToDevice, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const float *d = (const float *)ctx->b_pcoef.p;
+    switch (in_kind) {
+    case WFX_IN_I16_MONO:
+        return launch_rational<WFX_IN_I16_MONO>(ctx, in, (long long)n_in, base0, p, q, d, T, m0, out, (long long)n_out);
+    case WFX_IN_I16_STEREO:
+        return launch_rational<WFX_IN_I16_STEREO>(ctx, in, (long long)n_in, base0, p, q, d, T, m0, out, (long long)n_out);
+    case WFX_IN_F32_MONO:
+        return launch_rational<WFX_IN_F32_MONO>(ctx, in, (long long)n_in, base0, p, q, d, T, m0, out, (long long)n_out);
+    default:
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "rational: input kind %d", in_kind);
+    }
+}

@@ -278,13 +278,19 @@ int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const d
 
 // segment of a longer capture: exact filtfilt edges only where the segment touches the capture's
 // true start (edge_flags bit 0) / end (bit 1); elsewhere the FIR form, valid K samples from the end
-int wfx_dev_notch_fir_only(wfx_ctx *ctx, const int16_t *in, uint64_t n, const double b[3], const double a[3], double *out, int edge_flags)
+int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out,
+                           int edge_flags)
 {
     if (n < NOTCH_SMALL) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "segment of %llu samples is too short for the notch", (unsigned long long)n);
     notch_coef c;
     notch_prepare(c, b, a);
     const unsigned ib = wfx_stream_grid(n - 2 * NOTCH_K, 1024);
-    WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const short *)in, n, c, out, ib, edge_flags & 3);
+    if (in_kind == WFX_IN_I16_MONO)
+        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const short *)in, n, c, out, ib, edge_flags & 3);
+    else if (in_kind == WFX_IN_F64_MONO)
+        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<double>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const double *)in, n, c, out, ib, edge_flags & 3);
+    else
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "notch: input kind %d", in_kind);
     return 0;
 }
 

@@ -1,0 +1,151 @@
+"""Time-domain sample-rate front end for oversampled captures (BASELINE configs[3]).
+
+The reference brings every capture to 11 025 Hz with ``scipy.signal.resample``
+(/root/reference/wefax.py:375-394): an FFT over the WHOLE capture.  That operator is global,
+so it neither shards by sample range nor fits a 60-minute 1.536 MS/s IQ stream (5.5 G pairs).
+This module is the halo-local counterpart SURVEY.md section 8e asks for: a chain of FIR stencils
+
+    [ decimate by a power of two ]*  ->  [ rational p/q to 44 100 Hz ]  ->  decimate by 4
+
+(1.536 MS/s: /32 -> 48 kHz, x147/160 -> 44.1 kHz, /4 -> 11 025 Hz; 48 kHz: the last two;
+44.1 kHz: the last one) whose kernels live in ``csrc/wfx_polyphase.hip``.  Filters are Kaiser
+windowed sincs designed here in float64 and handed to the C ABI as float32 host arrays:
+unit DC gain, linear phase centred on the output sample (zero delay), pass band flat to
+``pass_hz``, stop band from 5512.5 Hz (the brick wall of the reference) at ``att_db``.
+The stereo / IQ merge of wefax.py:360-373 is fused into the first stage's loads.
+
+It is NOT bit-compatible with the FFT resampler: it drops what the reference keeps between
+``pass_hz`` and 5512.5 Hz, its pass band ripples by 10**(-att_db/20), and it resamples by the
+nominal ratio fs_in/11025 where the reference uses n0/int(11025*n0/fs_in) (the two differ by
+up to one output sample over a whole capture whose length is not a whole number of
+1/11025-second steps).  WEFAX audio lives below 3 kHz, so decoded images agree to about one
+grey level (tests/test_polyphase.py measures it); the exact path stays the default wherever
+it fits.
+"""
+from __future__ import annotations
+
+from fractions import Fraction
+
+import numpy as np
+
+TARGET_RATE = 11025
+NYQ = TARGET_RATE / 2.0          # 5512.5 Hz: everything the reference's brick wall keeps
+
+
+def kaiser_beta(att_db: float) -> float:
+    if att_db > 50:
+        return 0.1102 * (att_db - 8.7)
+    if att_db >= 21:
+        return 0.5842 * (att_db - 21) ** 0.4 + 0.07886 * (att_db - 21)
+    return 0.0
+
+
+def kaiser_length(att_db: float, df_norm: float) -> int:
+    """Taps for a transition band of df_norm cycles/sample (Kaiser's estimate)."""
+    return int(np.ceil((att_db - 7.95) / (2.285 * 2 * np.pi * df_norm))) + 1
+
+
+def _kaiser_window(u: np.ndarray, half: float, beta: float) -> np.ndarray:
+    """Continuous Kaiser window of half-width ``half`` evaluated at offsets u."""
+    r = 1.0 - (u / half) ** 2
+    return np.where(r > 0, np.i0(beta * np.sqrt(np.maximum(r, 0.0))) / np.i0(beta), 0.0)
+
+
+class Decimate:
+    """y[k] = sum_j c[j] x[k*M - centre + j]: low-pass + keep every M-th sample."""
+    kind = "decimate"
+
+    def __init__(self, fs_in: Fraction, factor: int, pass_hz: float, stop_hz: float, att_db: float):
+        self.fs_in, self.fs_out, self.factor = fs_in, fs_in / factor, factor
+        fs = float(fs_in)
+        n = kaiser_length(att_db, (stop_hz - pass_hz) / fs) | 1           # odd: the centre tap sits on the output sample
+        self.centre = (n - 1) // 2
+        u = np.arange(n, dtype=np.float64) - self.centre
+        fc = (pass_hz + stop_hz) / 2 / fs                                   # cycles per input sample
+        h = 2 * fc * np.sinc(2 * fc * u) * _kaiser_window(u, self.centre + 1.0, kaiser_beta(att_db))
+        self.coef64 = h / h.sum()
+        self.coef = self.coef64.astype(np.float32)
+        self.ntaps = n
+
+    def in_range(self, a: int, b: int):
+        """Input index range needed for outputs [a, b)."""
+        return a * self.factor - self.centre, (b - 1) * self.factor - self.centre + self.ntaps
+
+
+class Rational:
+    """Output m sits at input position m*p/q; taps j = 0..T-1 cover floor(m*p/q) - left + j with
+    weights h(j - left - frac), frac = ((m*p) mod q)/q: one table row per phase."""
+    kind = "rational"
+
+    def __init__(self, fs_in: Fraction, fs_out: Fraction, pass_hz: float, stop_hz: float, att_db: float):
+        r = fs_in / fs_out
+        self.fs_in, self.fs_out, self.p, self.q = fs_in, fs_out, r.numerator, r.denominator
+        fs = float(fs_in)
+        t = kaiser_length(att_db, (stop_hz - pass_hz) / fs)
+        self.taps = t + (t & 1) + 2                                         # even, with a margin of one tap per side
+        self.left = self.taps // 2 - 1
+        fc = (pass_hz + stop_hz) / 2 / fs
+        frac = np.arange(self.q, dtype=np.float64)[:, None] / self.q
+        u = np.arange(self.taps, dtype=np.float64)[None, :] - self.left - frac
+        h = 2 * fc * np.sinc(2 * fc * u) * _kaiser_window(u, self.taps / 2.0, kaiser_beta(att_db))
+        self.table64 = h / h.sum(axis=1, keepdims=True)
+        self.table = self.table64.astype(np.float32)
+
+    def in_range(self, a: int, b: int):
+        return (a * self.p) // self.q - self.left, ((b - 1) * self.p) // self.q - self.left + self.taps
+
+
+class FrontEnd:
+    """Stage chain from ``fs_in`` to 11 025 Hz and the index bookkeeping around it."""
+
+    def __init__(self, fs_in: int, att_db: float = 90.0, pass_hz: float = 5300.0):
+        if int(fs_in) != fs_in or fs_in < 4 * TARGET_RATE:
+            raise ValueError(f"the time-domain front end needs an integer rate >= 44100 Hz, not {fs_in}; use the exact FFT resampler")
+        self.fs_in = int(fs_in)
+        self.stages = []
+        fs = Fraction(self.fs_in)
+        mid = Fraction(4 * TARGET_RATE)
+        while fs / mid >= 2:
+            m = 1
+            while m < 64 and fs / (2 * m) >= mid:
+                m *= 2
+            self.stages.append(Decimate(fs, m, NYQ, float(fs / m) - NYQ, att_db))
+            fs = fs / m
+        if fs != mid:
+            st = Rational(fs, mid, NYQ, float(min(fs, mid)) - NYQ, att_db)
+            if (st.q * (st.taps | 1) + 2048 * st.p // st.q + st.taps + 2) * 4 > 64 * 1024:   # table + one tile's input span
+                raise ValueError(f"{fs_in} Hz needs a {st.q}-phase table that does not fit LDS; use the exact FFT resampler")
+            self.stages.append(st)
+        self.stages.append(Decimate(mid, 4, pass_hz, NYQ, att_db))
+
+    def n_out(self, n_in: int) -> int:
+        """wefax.py:384: num = int(11025 * length), length = n / sample_rate."""
+        return int(TARGET_RATE * (n_in / self.fs_in))
+
+    def chain(self, lo: int, hi: int):
+        """Index ranges per stage for outputs [lo, hi) at 11 025 Hz: list of (stage, out range,
+        in range), first stage first; a stage's output range is the next stage's input range."""
+        out = []
+        a, b = lo, hi
+        for st in reversed(self.stages):
+            ia, ib = st.in_range(a, b)
+            out.append((st, (a, b), (ia, ib)))
+            a, b = ia, ib
+        return out[::-1]
+
+    def input_range(self, lo: int, hi: int):
+        return self.chain(lo, hi)[0][2]
+
+    def halo(self) -> int:
+        """Input samples needed beyond the nominal position of an output, per side (upper bound)."""
+        ia, ib = self.input_range(0, 1)
+        return max(-ia, ib)
+
+    def describe(self) -> str:
+        parts = []
+        for st in self.stages:
+            if st.kind == "decimate":
+                parts.append(f"/{st.factor} ({st.ntaps} taps @ {float(st.fs_in):g} Hz)")
+            else:
+                parts.append(f"x{st.q}/{st.p} ({st.q} phases x {st.taps} taps @ {float(st.fs_in):g} Hz)")
+        return " -> ".join(parts)

@@ -146,9 +146,52 @@ class HipStages:
         self.p_hist = self._alloc(4 * SEL_BINS * 4)
         self.ctx.dev_upload(self.p_x, np.ascontiguousarray(xe, dtype=np.int16))
 
+    def load_raw(self, raw, in_kind: int, nl: int):
+        """Oversampled input of the time-domain front end: ``raw`` is a host array (int16 [n] or [n, 2]) or a
+        (device pointer, frames) pair that stays owned by the caller; ``nl`` = samples of the 11 025 Hz slice."""
+        self.nl, self.in_kind = nl, in_kind
+        if isinstance(raw, tuple):
+            self.p_raw, self.n_raw = int(raw[0]), int(raw[1])
+        else:
+            raw = np.ascontiguousarray(raw, dtype=np.int16)
+            self.n_raw = int(raw.shape[0])
+            self.p_raw = self._alloc(raw.nbytes)
+            self.ctx.dev_upload(self.p_raw, raw)
+        self.p_x = self._alloc(8 * nl)                 # float64 audio at 11 025 Hz
+        self.x_f64 = True
+        self.p_af, self.p_er, self.p_em = self._alloc(8 * nl), self._alloc(8 * nl), self._alloc(8 * nl)
+        self.p_dq = self._alloc(nl + 64)
+        self.p_hist = self._alloc(4 * SEL_BINS * 4)
+        self.p_stage = {}
+
+    def front_end(self, chain):
+        """Run the stage chain of ``polyphase.FrontEnd.chain``: raw slice -> float64 audio of the slice."""
+        from . import _native as nat
+        cur, kind, n_cur = self.p_raw, self.in_kind, self.n_raw
+        for k, (st, (a, b), (ia, ib)) in enumerate(chain):
+            assert ib - ia == n_cur, (ib - ia, n_cur)
+            last = k == len(chain) - 1
+            n_out = b - a
+            if last:
+                out = self.p_x
+            else:
+                if k not in self.p_stage:
+                    self.p_stage[k] = self._alloc(4 * n_out)
+                out = self.p_stage[k]
+            if st.kind == "decimate":
+                self.ctx.d_decimate_fir(cur, kind, n_cur, 0, st.factor, st.coef, out, last, n_out)
+            else:
+                shift = max(0, -(a // st.q))              # whole phase periods: makes the first output index non-negative
+                self.ctx.d_resample_rational(cur, kind, n_cur, ia + st.left + shift * st.p, st.p, st.q, st.table,
+                                             a + shift * st.q, out, n_out)
+            cur, kind, n_cur = out, nat.WFX_IN_F32_MONO, n_out
+
     def notch_envelope(self, n_global, taps, b, a, med_lo, med_hi, segments):
         for lo, hi, flags in segments:        # pieces of the slice between the capture's true ends
-            self.ctx.d_notch_fir(self.p_x + 2 * lo, hi - lo, b, a, self.p_af + 8 * lo, flags)
+            if getattr(self, "x_f64", False):
+                self.ctx.d_notch_fir_f64(self.p_x + 8 * lo, hi - lo, b, a, self.p_af + 8 * lo, flags)
+            else:
+                self.ctx.d_notch_fir(self.p_x + 2 * lo, hi - lo, b, a, self.p_af + 8 * lo, flags)
         self.ctx.d_fir_envelope(self.p_af, self.nl, n_global, taps, self.p_er)
         self.ctx.d_median5(self.p_er + 8 * med_lo, med_hi - med_lo, self.p_em + 8 * med_lo)
 
@@ -188,6 +231,8 @@ class HipStages:
     def fetch(self, what, lo, hi):
         if what == "env":
             return self.ctx.dev_download(self.p_em + 8 * lo, (hi - lo,), np.float64)
+        if what == "audio":         # output of the front end (before the notch)
+            return self.ctx.dev_download(self.p_x + 8 * lo, (hi - lo,), np.float64)
         return self.ctx.dev_download(self.p_dq + lo, (hi - lo,), np.uint8)
 
 
@@ -196,18 +241,35 @@ class ShardedDecoder:
     ``decode_emulated`` runs every rank of a world in this process (tests, 1-GPU boxes)."""
 
     def __init__(self, stages, x: np.ndarray, n_total: int, world: int, rank: int, lines_per_minute: int = 120,
-                 taps: int = 4095, notch=hp.DEFAULT_NOTCH, slice_loader=None):
+                 taps: int = 4095, notch=hp.DEFAULT_NOTCH, slice_loader=None, frontend=None, n_in_total=None,
+                 in_kind=None, raw_loader=None):
+        """``x``: the capture at 11 025 Hz (int16), or -- with ``frontend`` (polyphase.FrontEnd) -- the oversampled
+        capture of ``n_in_total`` frames (int16 [n] / [n, 2]); ``raw_loader(lo, hi)`` then replaces indexing ``x``
+        and returns the frames [lo, hi) (indices beyond the capture wrap modulo ``n_in_total``) as a host array or
+        a (device pointer, frames) pair.  ``n_total`` is always the sample count at 11 025 Hz."""
         self.st = stages
         self.n = int(n_total)
+        self.frontend = frontend
         self.frame_len = 1 / (lines_per_minute / 60)
         self.width = int(self.frame_len * hp.TARGET_RATE)
         self.taps = taps
         self.plan = ShardPlan(self.n, world, rank, self.width, taps)
         self.b, self.a = hp.iirnotch(int(notch[0]), notch[1], hp.TARGET_RATE)
         p = self.plan
-        idx = np.arange(p.l0, p.l1) % self.n
-        xe = slice_loader(idx) if slice_loader is not None else np.asarray(x)[idx]
-        self.st.load_slice(xe)
+        if frontend is not None:
+            self.chain = frontend.chain(p.l0, p.l1)
+            ia, ib = self.chain[0][2]
+            n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
+            if ib - ia > 2 * n_in_total:
+                raise ValueError("capture too short to shard")
+            raw = raw_loader(ia, ib) if raw_loader is not None else np.asarray(x)[np.arange(ia, ib) % n_in_total]
+            if in_kind is None:
+                in_kind = 1 if (not isinstance(raw, tuple) and raw.ndim == 2) else 0
+            self.st.load_raw(raw, in_kind, p.l1 - p.l0)
+        else:
+            idx = np.arange(p.l0, p.l1) % self.n
+            xe = slice_loader(idx) if slice_loader is not None else np.asarray(x)[idx]
+            self.st.load_slice(xe)
         self.ranks4 = None
 
     def _loc(self, g):                # global sample index -> index into the loaded slice
@@ -225,6 +287,8 @@ class ShardedDecoder:
 
     def phase_envelope(self):
         p = self.plan
+        if self.frontend is not None:
+            self.st.front_end(self.chain)
         self.st.notch_envelope(self.n, self.taps, self.b, self.a, self._loc(p.m0), self._loc(p.m1), self.segments())
 
     def phase_hist(self, level, prefixes):
@@ -277,10 +341,11 @@ class ShardedDecoder:
         return y0, rows
 
     # ---- drivers --------------------------------------------------------------------
-    def run(self, comm, exchange=None):
+    def run(self, comm, exchange=None, keep_on_device=False):
         """All ranks call this; the root gets (image, sync dict, low, high), the others None.
         With an ``ImageExchange`` the rows are gathered device to device (the root then gets a
-        list of (first line, uint8 device tensor) instead of one host array)."""
+        list of (first line, uint8 device tensor) instead of one host array).  ``keep_on_device``
+        (single rank): the image stays in HBM and (device pointer, bytes) is returned in its place."""
         self.phase_envelope()
         low, high = self.percentiles(comm.allreduce_sum)
         nan = int(comm.allreduce_sum(np.array([self.phase_quantise(low, high)], dtype=np.int64))[0])
@@ -302,6 +367,11 @@ class ShardedDecoder:
             if comm.rank != 0:
                 return None
             return sorted(((y, buf) for buf, y in got if buf.numel()), key=lambda t: t[0]), sync, low, high
+        if keep_on_device and comm.world == 1 and hasattr(self.st, "image_rows_dev"):
+            p = self.plan
+            y0, y1 = p.rows(sync["start_frame"], self.width, sync["height"])
+            return self.st.image_rows_dev(self._loc(p.c0), self._loc(p.c1), p.c0, sync["start_frame"], self.width,
+                                          sync["height"], y0, y1 - y0), sync, low, high
         y0, rows = self.phase_image(sync["start_frame"], sync["height"])
         parts = comm.gather((y0, rows), 0)           # the one image collective
         if comm.rank != 0:
@@ -310,10 +380,12 @@ class ShardedDecoder:
         return img, sync, low, high
 
 
-def decode_emulated(make_stages, x: np.ndarray, world: int, lines_per_minute: int = 120, taps: int = 4095):
+def decode_emulated(make_stages, x: np.ndarray, world: int, lines_per_minute: int = 120, taps: int = 4095, frontend=None):
     """Run every rank of a ``world``-rank sharded decode in this process, phase by phase."""
     n = int(np.asarray(x).shape[0])
-    decs = [ShardedDecoder(make_stages(), x, n, world, r, lines_per_minute, taps) for r in range(world)]
+    if frontend is not None:
+        n = frontend.n_out(n)
+    decs = [ShardedDecoder(make_stages(), x, n, world, r, lines_per_minute, taps, frontend=frontend) for r in range(world)]
     for d in decs:
         d.phase_envelope()
     lo0, lo1, glo = hp.percentile_plan(n, 0.5)
@@ -332,8 +404,10 @@ def decode_emulated(make_stages, x: np.ndarray, world: int, lines_per_minute: in
     parts = [d.phase_image(sync["start_frame"], sync["height"]) for d in decs]
     img = np.concatenate([r for _, r in sorted(parts, key=lambda t: t[0])], axis=0)
     env = np.concatenate([d.st.fetch("env", d._loc(d.plan.o0), d._loc(d.plan.o1)) for d in decs])
+    aud = (np.concatenate([d.st.fetch("audio", d._loc(d.plan.o0), d._loc(d.plan.o1)) for d in decs])
+           if frontend is not None else None)
     dig = np.concatenate([d.st.fetch("dig", d._loc(d.plan.o0), d._loc(d.plan.o1)) for d in decs])
     for d in decs:
         if hasattr(d.st, "close"):
             d.st.close()
-    return {"image": img, "sync": sync, "low": low, "high": high, "envelope": env, "digitalized": dig}
+    return {"image": img, "sync": sync, "low": low, "high": high, "envelope": env, "digitalized": dig, "audio": aud}
