@@ -121,7 +121,7 @@ def bench_sharded(args, world, rank, local_rank, use_dist, dist, torch, nat):
                              torch.device("cuda", local_rank)) if use_dist else None
 
     def step():
-        return dec.run(comm, exchange)
+        return dec.run(comm, exchange, keep_on_device=True)
 
     def sync_all():
         ctx.sync()

@@ -133,6 +133,52 @@ def test_sharded_decode_with_front_end_cpu():
     assert np.sqrt(np.mean((one["audio"] - ref_audio) ** 2)) < 0.02 * np.max(np.abs(ref_audio))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _gloo_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = _capture(48000, 0.05)
+        fe = pp.FrontEnd(48000)
+        calls = []
+
+        def raw_loader(lo, hi):             # every rank asks for its own slice of the oversampled capture only
+            calls.append((lo, hi))
+            return x[np.arange(lo, hi) % x.shape[0]]
+
+        dec = sharded.ShardedDecoder(NumpyStages(), None, fe.n_out(x.shape[0]), world, rank, 240, TAPS, frontend=fe,
+                                     n_in_total=x.shape[0], in_kind=0, raw_loader=raw_loader)
+        assert len(calls) == 1 and calls[0][1] - calls[0][0] < 0.6 * x.shape[0]
+        res = dec.run(sharded.TorchComm(dist, torch, "cpu"))
+        if rank == 0:
+            img, sync, low, high = res
+            np.savez(os.path.join(out_dir, "root.npz"), image=img, start=sync["start_frame"], low=low, high=high)
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_with_front_end_equal_one_rank(tmp_path):
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    mp.spawn(_gloo_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(tmp_path, "root.npz"))
+    ref = sharded.decode_emulated(NumpyStages, _capture(48000, 0.05), 1, lines_per_minute=240, taps=TAPS, frontend=pp.FrontEnd(48000))
+    assert int(got["start"]) == ref["sync"]["start_frame"]
+    assert float(got["low"]) == ref["low"] and float(got["high"]) == ref["high"]
+    assert np.array_equal(got["image"], ref["image"])
+
+
 # ---------------------------------------------------------------------------------------
 # GPU
 # ---------------------------------------------------------------------------------------
