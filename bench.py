@@ -320,20 +320,20 @@ def main():
 
     img_bytes = job.width * 4 * (job.n // job.width)      # upper bound (start_frame = 0)
     exchange = None
-    gathered = None
+    last_slot = None
     if use_dist:
-        from wefax_amd.multi import ImageExchange
-        exchange = ImageExchange(dist, torch, img_bytes, torch.device("cuda", local_rank))
+        from wefax_amd.multi import PipelinedExchange
+        exchange = PipelinedExchange(dist, torch, img_bytes, torch.device("cuda", local_rank), ctx.stream_handle())
 
     def step():
-        nonlocal gathered
+        # nothing here waits on the host: the decode is ~20 enqueued kernels, the export a device-side header + copy,
+        # and the RCCL gather of this step's image runs on its own stream while the next decode computes
+        nonlocal last_slot
         job.run()
         for _, jb in extra:
             jb.run()
         if use_dist:
-            info_ = job.result()                      # waits for the stream
-            nb = ctx.decode_copy_to_device(nat.WFX_BUF_IMAGE, exchange.payload_ptr, img_bytes)
-            gathered = exchange.gather(nb, info_.width)   # ONE RCCL gather per step
+            last_slot = exchange.submit(ctx, nat.WFX_BUF_IMAGE)   # ONE RCCL gather per step
 
     def sync_all():
         ctx.sync()
@@ -402,6 +402,7 @@ def main():
         job = j2
         info = job.result()
     gathered_ok = None
+    gathered = exchange.result(last_slot) if (use_dist and last_slot is not None) else None
     if use_dist and rank == 0 and gathered is not None:
         own = job.fetch("image")
         gathered_ok = bool(len(gathered) == world and

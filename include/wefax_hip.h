@@ -168,6 +168,14 @@ int wfx_decode_device_ptr(wfx_ctx *ctx, int buffer_id, void **dev_ptr, size_t *b
  * collective) and wait for it; at most `capacity` bytes, *copied receives the size */
 int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity, size_t *copied);
 
+/* Asynchronous hand-over to a collective (one process per GPU, images gathered by RCCL while the next decode
+ * runs): wfx_stream_handle returns the context's hipStream_t so that the caller can order its own stream against
+ * it with events; wfx_decode_export_async enqueues on that stream, WITHOUT waiting, a 16-byte header
+ * {int64 bytes, int64 width} built on the device followed by the stage buffer of the decode in flight
+ * (at most capacity - 16 bytes) into caller-owned DEVICE memory. */
+int wfx_stream_handle(wfx_ctx *ctx, void **stream);
+int wfx_decode_export_async(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity);
+
 /* ---- device-resident stage calls (sample-range sharding of one capture) -------
  * Building blocks for decoding a slice [g0, g0+n) of a long capture on one GPU with
  * halos on both sides: every call takes DEVICE pointers obtained

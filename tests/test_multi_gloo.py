@@ -74,3 +74,21 @@ def test_image_gather_world_size_2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+@pytest.mark.gpu
+def test_pipelined_rccl_gather_single_rank(tmp_path):
+    """bench.py's N > 1 path (decode k+1 overlapped with the RCCL gather of image k, wefax_amd/multi.py:
+    PipelinedExchange) with ONE forced rank: the gathered image equals the locally fetched one."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WFX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--short"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                       # the one-JSON-line contract survives RCCL's banner
+    out = json.loads(lines[0])
+    assert out["rccl_gather_checked"] is True and out["n_gpus"] == 1

@@ -26,7 +26,7 @@ SYMBOLS = [
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
     "wfx_sync_peaks", "wfx_lines_to_image", "wfx_decode_upload", "wfx_decode_run",
     "wfx_decode_result", "wfx_decode_fetch", "wfx_decode_device_ptr",
-    "wfx_decode_copy_to_device",
+    "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
     "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_resample_rational", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
@@ -118,6 +118,8 @@ def load():
     lib.wfx_decode_fetch.argtypes = [vp, i, vp, sz]
     lib.wfx_decode_device_ptr.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz)]
     lib.wfx_decode_copy_to_device.argtypes = [vp, i, vp, sz, C.POINTER(sz)]
+    lib.wfx_stream_handle.argtypes = [vp, C.POINTER(vp)]
+    lib.wfx_decode_export_async.argtypes = [vp, i, vp, sz]
     lib.wfx_dev_malloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.wfx_dev_free.argtypes = [vp, vp]
     lib.wfx_dev_upload.argtypes = [vp, vp, vp, sz]
@@ -303,6 +305,16 @@ class Context:
         out = np.empty(shape, dtype=dtype)
         self._check(self.lib.wfx_dev_download(self.h, _ptr(out), C.c_void_p(ptr), out.nbytes))
         return out
+
+    def stream_handle(self) -> int:
+        """The context's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
+        out = C.c_void_p()
+        self._check(self.lib.wfx_stream_handle(self.h, C.byref(out)))
+        return int(out.value or 0)
+
+    def decode_export_async(self, buffer_id: int, dst_ptr: int, capacity: int):
+        """Enqueue {int64 bytes, int64 width} + the stage buffer of the decode in flight into device memory; no wait."""
+        self._check(self.lib.wfx_decode_export_async(self.h, buffer_id, C.c_void_p(dst_ptr), capacity))
 
     def dev_copy(self, dst_ptr: int, src_ptr: int, nbytes: int):
         self._check(self.lib.wfx_dev_copy(self.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes))

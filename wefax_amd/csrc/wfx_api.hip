@@ -549,4 +549,36 @@ int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t
     return 0;
 }
 
+// ---- asynchronous export for a collective ------------------------------------------------
+int wfx_stream_handle(wfx_ctx *ctx, void **stream)
+{
+    CHECK_CTX(ctx);
+    if (!stream) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    *stream = (void *)ctx->stream;
+    return 0;
+}
+
+int wfx_decode_export_async(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->ran) return wfx_fail(ctx, WFX_ERR_STATE, "no decode has been enqueued on this context");
+    if (!dst_dev || capacity < 16) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "export: destination of at least 16 bytes needed");
+    const uint64_t n = ctx->dp.n;
+    const void *src = nullptr;
+    long long fixed = -1;            // byte count known on the host, or -1: 4 * height * width with the height still on the device
+    size_t maxb = 0;
+    switch (buffer_id) {
+    case WFX_BUF_AUDIO: src = ctx->b_audio.p; fixed = (long long)(n * 8); maxb = n * 8; break;
+    case WFX_BUF_ENVELOPE: src = ctx->b_env.p; fixed = (long long)(n * 8); maxb = n * 8; break;
+    case WFX_BUF_DIGITAL: src = ctx->b_dig.p; fixed = (long long)n; maxb = n; break;
+    case WFX_BUF_IMAGE: src = ctx->b_img.p; maxb = (size_t)ctx->dp.width * 4 * (size_t)(n / (uint64_t)ctx->dp.width); break;
+    default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown buffer id %d", buffer_id);
+    }
+    const size_t room = capacity - 16;
+    const size_t nb = maxb < room ? maxb : room;
+    WFX_TRY(wfx_dev_export_header(ctx, (const wfx_dev_scalars *)ctx->b_scal.p, fixed, ctx->dp.width, (long long)room, (long long *)dst_dev));
+    if (nb) WFX_HIP(ctx, hipMemcpyAsync((char *)dst_dev + 16, src, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
 }  // extern "C"

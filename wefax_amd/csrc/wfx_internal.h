@@ -219,6 +219,8 @@ bool wfx_mr_supported(uint64_t L);
 void wfx_mr_release(wfx_ctx *ctx);
 int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out);
 
+int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long fixed, int width, long long room, long long *hdr);
+
 // wfx_polyphase.hip
 int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const float *coef, int ntaps,
                          void *out, int out_f64, uint64_t n_out);

@@ -1448,3 +1448,21 @@ int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t sta
                (long long)start, y0);
     return 0;
 }
+
+// ===========================================================================
+// header of an exported stage buffer: {bytes, width}, written on the device so that no
+// host round trip separates a decode from the collective that ships its image
+// ===========================================================================
+__global__ void export_header_kernel(const wfx_dev_scalars *__restrict__ sc, long long fixed, int width, long long room, long long *__restrict__ hdr)
+{
+    long long nb = fixed >= 0 ? fixed : 4ll * (long long)sc->height * (long long)width;
+    if (nb > room) nb = room;
+    hdr[0] = nb;
+    hdr[1] = width;
+}
+
+int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long fixed, int width, long long room, long long *hdr)
+{
+    WFX_LAUNCH(ctx, K_IMAGE, export_header_kernel, dim3(1), dim3(1), d_scal, fixed, width, room, hdr);
+    return 0;
+}

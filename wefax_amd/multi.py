@@ -64,3 +64,56 @@ class ImageExchange:
             nb, w = int(meta[0]), int(meta[1])
             out.append((buf[self.HEADER:self.HEADER + nb], w))
         return out
+
+
+class PipelinedExchange:
+    """The image gather of step k overlapped with the decode of step k + 1.
+
+    Nothing waits on the host: the decode's stream (``lib_stream``, the native context's
+    hipStream_t wrapped as a torch ExternalStream) writes {header, image} into send slot
+    k % slots with ``wfx_decode_export_async``; an event orders the collective, issued on a
+    separate communication stream, behind that copy; another event keeps the decode from
+    reusing a slot before the gather that read it has finished.  One RCCL gather per step.
+    """
+
+    HEADER = ImageExchange.HEADER
+
+    def __init__(self, dist, torch, capacity: int, device, lib_stream: int, slots: int = 2, root: int = 0):
+        self.dist, self.torch = dist, torch
+        self.world, self.rank, self.root = dist.get_world_size(), dist.get_rank(), root
+        self.capacity = int(capacity)
+        total = self.HEADER + self.capacity
+        self.send = [torch.zeros(total, dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.recv = [[torch.zeros(total, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                     if self.rank == root else None for _ in range(slots)]
+        self.lib = torch.cuda.ExternalStream(lib_stream, device=device)
+        self.comm = torch.cuda.Stream(device=device)
+        self.free = [None] * slots          # event: the gather that used the slot is complete
+        self.k = 0
+
+    def submit(self, ctx, buffer_id: int) -> int:
+        """Call right after the decode was enqueued on ``ctx``; returns the step's slot."""
+        torch = self.torch
+        s = self.k % len(self.send)
+        self.k += 1
+        if self.free[s] is not None:
+            self.lib.wait_event(self.free[s])
+        ctx.decode_export_async(buffer_id, self.send[s].data_ptr(), self.HEADER + self.capacity)
+        ready = self.lib.record_event()
+        self.comm.wait_event(ready)
+        with torch.cuda.stream(self.comm):
+            self.dist.gather(self.send[s], self.recv[s], dst=self.root)
+            self.free[s] = self.comm.record_event()
+        return s
+
+    def result(self, slot: int):
+        """Root: list of (uint8 tensor, width) per rank for the step that used ``slot`` (waits for it)."""
+        self.comm.synchronize()
+        if self.rank != self.root:
+            return None
+        out = []
+        for buf in self.recv[slot]:
+            meta = buf[:self.HEADER].cpu().view(self.torch.int64)
+            nb, w = int(meta[0]), int(meta[1])
+            out.append((buf[self.HEADER:self.HEADER + nb], w))
+        return out
