@@ -235,7 +235,7 @@ def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
                     "launches_per_step": dom[1][0],
                     "whole_path_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         import tempfile
         from oracle import wefax_oracle as wo
         from wefax_amd import synth
@@ -410,7 +410,7 @@ def main():
 
     cpu = None
     parity = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:        # the CPU leg is reported at N = 1 only
         cpu = cpu_baseline(x)
         ref = cpu.pop("_result")
         img = job.fetch("image")
