@@ -125,14 +125,14 @@ __device__ __forceinline__ uint4 pp_fetch(const void *in, const unsigned char *b
 // partial sums are added in group order through LDS: the order of additions per output is
 // fixed by (M, rs) alone, never by where a slice starts.
 constexpr int PP_BATCH = 8;
-constexpr bool PP_PREFETCH = false;   // keep the next tile in registers across the compute phase (costs occupancy)
-constexpr int PP_NB = 18;          // 16-byte chunks per thread and tile (decimate): 72 VGPRs of prefetch
+constexpr int PP_NB = 9;           // 16-byte chunks in flight per thread (decimate): 36 VGPRs
 
-template <int IN, typename OUT, bool ALIGNED>
+template <int IN, typename OUT, bool ALIGNED, int Q4T>
 __global__ void __launch_bounds__(PP_THREADS)
-decimate_kernel(const void *__restrict__ in, long long n_in, long long first, int log2m, const float *__restrict__ cp, int q4,
+decimate_kernel(const void *__restrict__ in, long long n_in, long long first, int log2m, const float *__restrict__ cp, int q4_arg,
                 OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign)
 {
+    const int q4 = Q4T ? Q4T : q4_arg;        // Q4T > 0: the tap loop has a compile-time trip count and unrolls (short filters)
     typedef pp_in<IN> A;
     typedef typename A::store_t S;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -170,28 +170,28 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
         return G;
     };
     uint4 v[PP_NB];                                                     // one tile's input, in flight or waiting for its LDS slot
-    auto fetch = [&](const geom &G) {
+    auto fetch = [&](const geom &G, int cb) {
         // uniform test: the whole window lies inside the caller's array -> straight-line vector loads, all in flight at once
         if (G.a0 >= misalign && G.a0 + (long long)G.nchunks * A::PER16 <= n_in + misalign) {
 #pragma unroll
             for (int u = 0; u < PP_NB; ++u)
-                if (u * PP_THREADS < G.nchunks) {
-                    int c = u * PP_THREADS + t;
+                if (cb + u * PP_THREADS < G.nchunks) {
+                    int c = cb + u * PP_THREADS + t;
                     c = c < G.nchunks ? c : G.nchunks - 1;
                     v[u] = *(const uint4 *)(base + (G.a0 + (long long)c * A::PER16) * A::BYTES);
                 }
         } else {
 #pragma unroll
             for (int u = 0; u < PP_NB; ++u) {
-                const int c = u * PP_THREADS + t;
+                const int c = cb + u * PP_THREADS + t;
                 if (c < G.nchunks) v[u] = pp_fetch<IN>(in, base, G.a0 + (long long)c * A::PER16, misalign, n_in);
             }
         }
     };
-    auto stash = [&](const geom &G) {
+    auto stash = [&](const geom &G, int cb) {
 #pragma unroll
         for (int u = 0; u < PP_NB; ++u) {
-            const int c = u * PP_THREADS + t;
+            const int c = cb + u * PP_THREADS + t;
             if (c < G.nchunks) {
                 S e[A::PER16];
                 A::chunk(v[u], e);
@@ -216,21 +216,14 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
             }
         }
     };
-    long long tile = blockIdx.x;
-    geom Gn = geom_of(tile < ntiles ? tile : 0);
-    if (PP_PREFETCH && tile < ntiles) fetch(Gn);
-    for (; tile < ntiles; tile += gridDim.x) {
-        if (!PP_PREFETCH) {
-            Gn = geom_of(tile);
-            fetch(Gn);
-        }
-        __syncthreads();                       // the previous tile's compute phase is done with the LDS window
-        stash(Gn);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const geom Gn = geom_of(tile);
         const long long o0 = Gn.o0;
         const int cnt = Gn.cnt;
-        if (PP_PREFETCH && tile + gridDim.x < ntiles) {       // the next tile's loads fly while this one is computed
-            Gn = geom_of(tile + gridDim.x);
-            fetch(Gn);
+        __syncthreads();                       // the previous tile's compute phase is done with the LDS window
+        for (int cb = 0; cb < Gn.nchunks; cb += PP_NB * PP_THREADS) {
+            fetch(Gn, cb);
+            stash(Gn, cb);
         }
         __syncthreads();
         const bool active = (4 * g < cnt) && (part < (1 << rs_log2));
@@ -244,7 +237,8 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                 pp_cvt4(pp_raw4(row), wa);
                 auto rn = pp_raw4(row + 4);
                 float4 cn = *(const float4 *)c;
-                for (int j = 0; j < q4; ++j) {
+#pragma unroll(Q4T ? Q4T : 1)
+                for (int j = 0; j < (Q4T ? Q4T : q4); ++j) {
                     const float c0 = cn.x, c1 = cn.y, c2 = cn.z, c3 = cn.w;
                     pp_cvt4(rn, wb);
                     if (j + 1 < q4) {                 // next taps and next columns are in flight while this group is applied
@@ -356,11 +350,7 @@ int launch_decimate(wfx_ctx *ctx, const void *in, long long n_in, long long firs
     const int esz = (int)sizeof(typename A::store_t);
     const int pad = esz == 2 ? 6 : 4;                // int16 rows: stride = 2 (mod 4) spreads a chunk's rows over the banks
     int tb = 1024;                                   // outputs per tile: 4 per thread
-    while (tb > 64 && ((size_t)(tb + 4 * q4 + pad) * M * esz > (size_t)PP_LDS_BYTES ||
-                       ((size_t)(tb + 4 * q4) * M + 2 * A::PER16) / A::PER16 > (size_t)PP_NB * PP_THREADS))
-        tb >>= 1;
-    if (((size_t)(tb + 4 * q4) * M + 2 * A::PER16) / A::PER16 > (size_t)PP_NB * PP_THREADS)
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d exceed the per-tile prefetch", 4 * q4 * M, M);
+    while (tb > 64 && (size_t)(tb + 4 * q4 + pad) * M * esz > (size_t)PP_LDS_BYTES) tb >>= 1;
     const int row_stride = tb + 4 * q4 + pad;
     const size_t lds_x = ((size_t)row_stride * M * esz + 15) & ~(size_t)15;
     const size_t lds = lds_x + (size_t)PP_THREADS * 4 * sizeof(float) + (size_t)M * 4 * q4 * sizeof(float);     // + partial sums + taps
@@ -368,7 +358,10 @@ int launch_decimate(wfx_ctx *ctx, const void *in, long long n_in, long long firs
     const int misalign = (int)(((uintptr_t)in & 15u) / A::BYTES);
     const long long ntiles = (n_out + tb - 1) / tb;
     const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
-    auto kern = aligned ? decimate_kernel<IN, OUT, true> : decimate_kernel<IN, OUT, false>;
+    auto kern = !aligned ? decimate_kernel<IN, OUT, false, 0>
+                : q4 == 2 ? decimate_kernel<IN, OUT, true, 2>
+                : q4 == 3 ? decimate_kernel<IN, OUT, true, 3>
+                          : decimate_kernel<IN, OUT, true, 0>;
     if (lds > 48 * 1024) WFX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     wfx_prof_begin(ctx, (IN == WFX_IN_F32_MONO ? K_POLYPHASE : K_POLYPHASE_IN));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PP_THREADS), lds, ctx->stream, in, n_in, first, log2m, cp, q4, out, n_out, ilog2_exact(tb),

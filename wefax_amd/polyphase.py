@@ -5,10 +5,10 @@ The reference brings every capture to 11 025 Hz with ``scipy.signal.resample``
 so it neither shards by sample range nor fits a 60-minute 1.536 MS/s IQ stream (5.5 G pairs).
 This module is the halo-local counterpart SURVEY.md section 8e asks for: a chain of FIR stencils
 
-    [ decimate by a power of two ]*  ->  [ rational p/q to 44 100 Hz ]  ->  decimate by 4
+    [ decimate by a power of two ]*  ->  [ rational p/q to 44 100 Hz ]  ->  decimate by 2  ->  decimate by 2
 
-(1.536 MS/s: /32 -> 48 kHz, x147/160 -> 44.1 kHz, /4 -> 11 025 Hz; 48 kHz: the last two;
-44.1 kHz: the last one) whose kernels live in ``csrc/wfx_polyphase.hip``.  Filters are Kaiser
+(1.536 MS/s: /32 -> 48 kHz, x147/160 -> 44.1 kHz, /2 -> 22.05 kHz, /2 -> 11 025 Hz; 48 kHz: the last three;
+44.1 kHz: the last two) whose kernels live in ``csrc/wfx_polyphase.hip``.  Filters are Kaiser
 windowed sincs designed here in float64 and handed to the C ABI as float32 host arrays:
 unit DC gain, linear phase centred on the output sample (zero delay), pass band flat to
 ``pass_hz``, stop band from 5512.5 Hz (the brick wall of the reference) at ``att_db``.
@@ -99,6 +99,9 @@ class FrontEnd:
     """Stage chain from ``fs_in`` to 11 025 Hz and the index bookkeeping around it."""
 
     def __init__(self, fs_in: int, att_db: float = 90.0, pass_hz: float = 5300.0):
+        """``pass_hz``: edge of the flat pass band of the last stage (its stop band starts at 5512.5 Hz): 5300 Hz
+        costs 595 taps at 22.05 kHz.  What lies between ``pass_hz`` and 5512.5 Hz is what the reference keeps and
+        this front end drops (tests/test_polyphase.py prints the resulting error figures)."""
         if int(fs_in) != fs_in or fs_in < 4 * TARGET_RATE:
             raise ValueError(f"the time-domain front end needs an integer rate >= 44100 Hz, not {fs_in}; use the exact FFT resampler")
         self.fs_in = int(fs_in)
@@ -116,7 +119,10 @@ class FrontEnd:
             if (st.q * (st.taps | 1) + 2048 * st.p // st.q + st.taps + 2) * 4 > 64 * 1024:   # table + one tile's input span
                 raise ValueError(f"{fs_in} Hz needs a {st.q}-phase table that does not fit LDS; use the exact FFT resampler")
             self.stages.append(st)
-        self.stages.append(Decimate(mid, 4, pass_hz, NYQ, att_db))
+        # the last /4 in two halves: a short filter brings 44.1 kHz to 22.05 kHz (its transition band may be wide: only
+        # what aliases into 0..5512.5 Hz matters), so the sharp filter runs at half the rate with half the taps
+        self.stages.append(Decimate(mid, 2, NYQ, float(mid / 2) - NYQ, att_db))
+        self.stages.append(Decimate(mid / 2, 2, pass_hz, NYQ, att_db))
 
     def n_out(self, n_in: int) -> int:
         """wefax.py:384: num = int(11025 * length), length = n / sample_rate."""
