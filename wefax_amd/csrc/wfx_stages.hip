@@ -551,6 +551,55 @@ __global__ void __launch_bounds__(256) select_l0_kernel(const double *__restrict
         if (h[i]) atomicAdd(&ws[SEL_H0 + i], h[i]);
 }
 
+// Streams v[0..n) through fn(value, valid) for a grid of 256-thread blocks, 4 values (32 bytes) per lane
+// and step.  SEL_UN steps are loaded back to back before any of them is consumed: bytes in flight,
+// not occupancy, hide the HBM latency of these one-pass kernels.
+#define SEL_UN 4
+template <typename FN>
+__device__ __forceinline__ void sel_stream(const double *__restrict__ v, uint64_t n, FN fn)
+{
+    const int t = threadIdx.x;
+    const uint64_t quads = (n + 3) / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    const uint64_t nround = (quads + stride - 1) / stride;
+    uint64_t it = 0;
+    for (; it + SEL_UN <= nround && (it + SEL_UN) * stride * 4 <= n; it += SEL_UN) {      // whole batch inside the array: no guards
+        double2 lo[SEL_UN], hi[SEL_UN];
+#pragma unroll
+        for (int u = 0; u < SEL_UN; ++u) {
+            const uint64_t i0 = ((it + u) * stride + blockIdx.x * 256ull + t) * 4;
+            lo[u] = *(const double2 *)(v + i0);
+            hi[u] = *(const double2 *)(v + i0 + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_UN; ++u) {
+            fn(lo[u].x, true);
+            fn(lo[u].y, true);
+            fn(hi[u].x, true);
+            fn(hi[u].y, true);
+        }
+    }
+    for (; it < nround; ++it) {
+        const uint64_t i0 = (it * stride + blockIdx.x * 256ull + t) * 4;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (i0 + 4 <= n) {
+            const double2 lo = *(const double2 *)(v + i0), hi2 = *(const double2 *)(v + i0 + 2);
+            a0 = lo.x;
+            a1 = lo.y;
+            a2 = hi2.x;
+            a3 = hi2.y;
+        } else {
+            if (i0 < n) a0 = v[i0];
+            if (i0 + 1 < n) a1 = v[i0 + 1];
+            if (i0 + 2 < n) a2 = v[i0 + 2];
+        }
+        fn(a0, i0 < n);
+        fn(a1, i0 + 1 < n);
+        fn(a2, i0 + 2 < n);
+        fn(a3, i0 + 3 < n);
+    }
+}
+
 // level 1: choose the level-0 digit of every query, then histogram bits 52..42 of the
 // values whose top 11 bits match
 __global__ void __launch_bounds__(256) select_l1_kernel(const double *__restrict__ v, uint64_t n, uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3,
@@ -597,28 +646,7 @@ __global__ void __launch_bounds__(256) select_l1_kernel(const double *__restrict
         for (int q = 0; q < 4; ++q)
             if (active[q] && valid && hi == mypfx[q]) atomicAdd(&h[q][digit], 1u);   // level-1 digits are diverse: no wave aggregation
     };
-    const uint64_t quads = (n + 3) / 4;
-    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
-    const uint64_t nround = (quads + stride - 1) / stride;
-    for (uint64_t it = 0; it < nround; ++it) {
-        const uint64_t i0 = (it * stride + blockIdx.x * 256ull + t) * 4;
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        if (i0 + 4 <= n) {
-            const double2 lo = *(const double2 *)(v + i0), hi2 = *(const double2 *)(v + i0 + 2);
-            a0 = lo.x;
-            a1 = lo.y;
-            a2 = hi2.x;
-            a3 = hi2.y;
-        } else {
-            if (i0 < n) a0 = v[i0];
-            if (i0 + 1 < n) a1 = v[i0 + 1];
-            if (i0 + 2 < n) a2 = v[i0 + 2];
-        }
-        count(a0, i0 < n);
-        count(a1, i0 + 1 < n);
-        count(a2, i0 + 2 < n);
-        count(a3, i0 + 3 < n);
-    }
+    sel_stream(v, n, count);
     __syncthreads();
     for (int i = t; i < 4 * SEL_BINS; i += 256) {
         const unsigned c = (&h[0][0])[i];
@@ -685,28 +713,7 @@ __global__ void __launch_bounds__(256) select_compact_kernel(const double *__res
             }
         }
     };
-    const uint64_t quads = (n + 3) / 4;
-    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
-    const uint64_t nround = (quads + stride - 1) / stride;
-    for (uint64_t it = 0; it < nround; ++it) {
-        const uint64_t i0 = (it * stride + blockIdx.x * 256ull + t) * 4;
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        if (i0 + 4 <= n) {
-            const double2 lo = *(const double2 *)(v + i0), hi2 = *(const double2 *)(v + i0 + 2);
-            a0 = lo.x;
-            a1 = lo.y;
-            a2 = hi2.x;
-            a3 = hi2.y;
-        } else {
-            if (i0 < n) a0 = v[i0];
-            if (i0 + 1 < n) a1 = v[i0 + 1];
-            if (i0 + 2 < n) a2 = v[i0 + 2];
-        }
-        append(a0, i0 < n);
-        append(a1, i0 + 1 < n);
-        append(a2, i0 + 2 < n);
-        append(a3, i0 + 3 < n);
-    }
+    sel_stream(v, n, append);
 }
 
 // levels 2..5 on the candidate lists, numpy's lerp, and clearing of the workspace
@@ -804,7 +811,7 @@ static int select_after_l0(wfx_ctx *ctx, const double *env, uint64_t n, const ui
     unsigned *ws = (unsigned *)ctx->b_hist.p;
     unsigned long long *cand = (unsigned long long *)ctx->b_cand.p;
     unsigned grid = wfx_stream_grid(n, 4096);
-    if (grid > 768) grid = 768;             // 3 per CU: per-workgroup prologue (digit pick) and epilogue (flush) are paid once
+    if (grid > 512) grid = 512;             // 2 per CU: per-workgroup prologue (digit pick) and epilogue (flush) are paid once
     WFX_LAUNCH(ctx, K_SELECT_HIST, select_l1_kernel, dim3(grid), dim3(256), env, n, ranks[0], ranks[1], ranks[2], ranks[3], ws, d_scal);
     WFX_LAUNCH(ctx, K_SELECT_HIST, select_compact_kernel, dim3(grid), dim3(256), env, n, ws, d_scal, cand, n);
     WFX_LAUNCH(ctx, K_SELECT_SCAN, select_finish_kernel, dim3(4), dim3(1024), ws, d_scal, (const unsigned long long *)cand, n, do_lerp, gamma_lo,
