@@ -45,6 +45,8 @@ def parse():
                     help="analytic-signal operator: exact DFT (default) or 4095-tap FIR")
     ap.add_argument("--noise", type=float, default=0.05, help="AWGN sigma in full-scale units")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu-loops", action="store_true",
+                    help="skip the second CPU timing that keeps the reference's per-sample Python loops (about 25 s)")
     ap.add_argument("--short", action="store_true", help="60-line capture (debugging only)")
     ap.add_argument("--shard", action="store_true",
                     help="sample-range sharding of ONE capture of n_gpus x 10 minutes (halo FIR path, 6 histogram "
@@ -68,7 +70,7 @@ def make_capture(seed: int, noise: float, short: bool):
     return synth.config_c2(noise=noise, seed=seed)
 
 
-def cpu_baseline(x: np.ndarray) -> dict:
+def cpu_baseline(x: np.ndarray, faithful: bool = False) -> dict:
     """Time the oracle (port of wefax.py) on this host: 1 process, 1 thread."""
     import tempfile
     from oracle import wefax_oracle as wo
@@ -79,10 +81,21 @@ def cpu_baseline(x: np.ndarray) -> dict:
         t0 = time.perf_counter()
         r = wo.process(p, 120, want_messages=False)
         dt = time.perf_counter() - t0
-    return {"value": round(x.shape[0] / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1,
-            "kind": "port", "host_cpus": os.cpu_count(), "seconds": round(dt, 3),
-            "sample": f"the whole capture ({x.shape[0]} samples), one run, read from a wav file",
-            "_result": r}
+        out = {"value": round(x.shape[0] / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1,
+               "kind": "port", "host_cpus": os.cpu_count(), "seconds": round(dt, 3),
+               "sample": f"the whole capture ({x.shape[0]} samples), one run, read from a wav file",
+               "_result": r}
+        if faithful:
+            # the same port with the reference's per-sample Python loops kept (list build, np.dot per offset, putpixel):
+            # what wefax.py itself costs, without and with its 7 s of time.sleep
+            t0 = time.perf_counter()
+            rf = wo.process(p, 120, want_messages=False, faithful_loops=True)
+            dtf = time.perf_counter() - t0
+            same = bool(np.array_equal(rf.get("image"), r.get("image")) and rf.get("start_frame") == r.get("start_frame"))
+            out["faithful_loops"] = {"value": round(x.shape[0] / dtf / 1e6, 4), "seconds": round(dtf, 2),
+                                     "value_with_reference_sleeps": round(x.shape[0] / (dtf + 7.0) / 1e6, 4),
+                                     "same_result_as_vectorised": same}
+    return out
 
 
 class _StdoutToStderr:
@@ -411,7 +424,7 @@ def main():
     cpu = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu:        # the CPU leg is reported at N = 1 only
-        cpu = cpu_baseline(x)
+        cpu = cpu_baseline(x, faithful=not args.no_cpu_loops)
         ref = cpu.pop("_result")
         img = job.fetch("image")
         parity = {"start_frame_equal": bool(ref.get("start_frame") == info.start_frame),

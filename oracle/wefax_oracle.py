@@ -383,8 +383,11 @@ def group_peaks(peaks, sample_rate: int, frame_len: float):
 
 def find_sync_pulse(d: np.ndarray, sample_rate: int, frame_len: float):
     n1, n0, mind = sync_constants(sample_rate, frame_len)
-    corr = sync_correlation(d, n1, n0)
-    peaks, first, hit = pick_peaks(corr, mind)
+    if faithful_loops:
+        peaks, first, hit = pick_peaks_loop(d_list, n1, n0, mind)
+    else:
+        corr = sync_correlation(d, n1, n0)
+        peaks, first, hit = pick_peaks(corr, mind)
     return peaks, first, hit, group_peaks(peaks, sample_rate, frame_len)
 
 
@@ -469,10 +472,70 @@ def lines_to_image(d: np.ndarray, frame_len: float, sample_rate: int) -> np.ndar
 # --------------------------------------------------------------------------
 # a2: the whole path  (wefax.py:46-93)
 # --------------------------------------------------------------------------
-def process(path: str, lines_per_minute: int = 120, want_messages: bool = True) -> dict:
+# ---------------------------------------------------------------------------
+# The reference's loop structure, for CPU TIMING only (BASELINE.md section 3,
+# SURVEY.md 8d "faithful_loops"): the same results as the vectorised stages
+# above, computed the way wefax.py computes them -- one Python iteration per
+# sample.  tests/test_oracle_golden.py checks that both forms agree.
+# ---------------------------------------------------------------------------
+def merge_channels_loop(data: np.ndarray) -> list:
+    """wefax.py:360-373: per frame np.add on two np.int16 scalars (wraps), then /2."""
+    out = []
+    for frame in data:
+        out.append(np.divide(np.add(frame[0], frame[1]), 2))
+    return out
+
+
+def digitalize_loop(env: np.ndarray):
+    """wefax.py:185-216: vectorised rounding, then the per-sample int() list build."""
+    d, low, high = digitalize(env)
+    return [int(p) for p in d.astype(np.float64)], low, high
+
+
+def pick_peaks_loop(d_list: list, n1: int, n0: int, mindistance: int, max_peaks: int = 100):
+    """wefax.py:222-263: np.dot of two Python lists at every offset, peak list updated in place."""
+    sync = [1 - 128] * n1 + [0 - 128] * n0 + [1 - 128] * n1
+    shifted = [x - 128 for x in d_list]
+    peaks = [(0, 0)]
+    first = [0]
+    hit = False
+    for i in range(len(d_list) - len(sync)):
+        corr = np.dot(sync, shifted[i:i + len(sync)])
+        if i - peaks[-1][0] > mindistance:
+            peaks.append((i, corr))
+            first.append(i)
+        elif corr > peaks[-1][1]:
+            peaks[-1] = (i, corr)
+        if len(peaks) == max_peaks:
+            hit = True
+            break
+    return [p[0] for p in peaks], first, hit
+
+
+def lines_to_image_loop(d_list: list, frame_len: float, sample_rate: int) -> np.ndarray:
+    """wefax.py:296-327: Image.putpixel per sample, then Pillow's own 4x vertical resize."""
+    from PIL import Image
+    w = int(frame_len * sample_rate)
+    h = len(d_list) // w
+    image = Image.new("L", (w, h))
+    px = py = 0
+    for p in range(len(d_list)):
+        image.putpixel((px, py), 255 - d_list[p])
+        px += 1
+        if px >= w:
+            px = 0
+            py += 1
+            if py >= h:
+                break
+    return np.asarray(image.resize((w, 4 * h)))
+
+
+def process(path: str, lines_per_minute: int = 120, want_messages: bool = True, faithful_loops: bool = False) -> dict:
     """Run every stage; returns a dict of stage outputs.  When the reference
     would raise (wefax.py:294) the exception is stored under 'exception' and
-    the stages computed so far are kept."""
+    the stages computed so far are kept.  ``faithful_loops`` swaps the vectorised
+    merge / list build / sync search / image construction for the reference's
+    per-sample Python loops (same results; only its running time is of interest)."""
     r: dict = {"messages": []}
     msgs = r["messages"]
 
@@ -487,7 +550,7 @@ def process(path: str, lines_per_minute: int = 120, want_messages: bool = True) 
             for p in range(parts):                      # wefax.py:364-370
                 if p % 1000 == 0 or p == parts - 1:
                     progress("merging channels", (p + 1) / parts * 100)
-        data = merge_channels(data)
+        data = np.asarray(merge_channels_loop(data), dtype=np.float64) if faithful_loops else merge_channels(data)
     length = len(data) / sr
     if sr != TARGET_RATE:                               # wefax.py:60
         progress("resampling audio", 0)
@@ -504,13 +567,20 @@ def process(path: str, lines_per_minute: int = 120, want_messages: bool = True) 
     progress("demodulating signal", 100)
     r["demod"] = env
     progress("digitalizing signal", 0)
-    d, low, high = digitalize(env)
+    if faithful_loops:
+        d_list, low, high = digitalize_loop(env)
+        d = np.asarray(d_list, dtype=np.uint8)
+    else:
+        d, low, high = digitalize(env)
     progress("digitalizing signal", 99)
     progress("digitalizing signal", 100)
     r["digitalized"], r["low"], r["high"] = d, low, high
     n1, n0, mind = sync_constants(sr, frame_len)
-    corr = sync_correlation(d, n1, n0)
-    peaks, first, hit = pick_peaks(corr, mind)
+    if faithful_loops:
+        peaks, first, hit = pick_peaks_loop(d_list, n1, n0, mind)
+    else:
+        corr = sync_correlation(d, n1, n0)
+        peaks, first, hit = pick_peaks(corr, mind)
     r["peaks"] = peaks
     for i in first[1:]:
         progress("finding sync pulse", (i / len(d)) * 100)   # wefax.py:245
@@ -534,6 +604,6 @@ def process(path: str, lines_per_minute: int = 120, want_messages: bool = True) 
             progress("converting signal to image", (py + 1) / h * 100)
     if h > 0 and len(tail) >= 1:
         progress("converting signal to image", 100)
-    r["image"] = lines_to_image(tail, frame_len, sr)
+    r["image"] = lines_to_image_loop(d_list[start:], frame_len, sr) if faithful_loops else lines_to_image(tail, frame_len, sr)
     msgs.append(["message", "convert_end", None])
     return r

@@ -118,3 +118,18 @@ def test_merge_wraps_like_numpy_scalars():
     with np.errstate(over="ignore"):
         ref = [float(np.divide(np.add(r[0], r[1]), 2)) for r in d]
     assert wo.merge_channels(d).tolist() == ref
+
+
+@pytest.mark.parametrize("name", ["mono_noisy_240", "stereo_overflow_120", "ref_image"])
+def test_faithful_loops_form_gives_the_same_results(name):
+    """oracle.process(faithful_loops=True) keeps the reference's per-sample Python loops (the CPU timing of
+    bench.py that stands for wefax.py itself): identical stream, peaks, start_frame, image or exception."""
+    case = next(c for c in golden_cases() if c["name"] == name)
+    path = os.path.join(GOLDEN, case["input"])
+    a = wo.process(path, case["lpm"], want_messages=False)
+    b = wo.process(path, case["lpm"], want_messages=False, faithful_loops=True)
+    assert np.array_equal(a["digitalized"], b["digitalized"]) and list(a["peaks"]) == list(b["peaks"])
+    assert type(a.get("exception")) is type(b.get("exception"))
+    assert a.get("start_frame") == b.get("start_frame")
+    if "image" in a:
+        assert np.array_equal(a["image"], b["image"])
