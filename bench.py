@@ -242,8 +242,15 @@ def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
         ia, ib = dec.chain[0][2]
         alg_bytes = (ib - ia) * 4 + 4 * (p.o1 - p.o0)           # N0*B_in + 4*N, this rank's share
         avg_s = dom[1][1] / dom[1][0] / 1e3
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_traffic_iq.json")      # measured on the full 3600 s stream, one rank
+        if os.path.exists(pmc) and world == 1 and secs == 3600.0:
+            try:
+                traffic = json.load(open(pmc)).get(dom[0], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(alg_bytes / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
                     "launches_per_step": dom[1][0],
                     "whole_path_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}

@@ -48,4 +48,21 @@ WFX_BENCH_FORCE_DIST=1 python bench.py --shard --no-cpu > "$OUT/bench_shard_rccl
 WFX_BENCH_FORCE_DIST=1 python bench.py --no-cpu > "$OUT/bench_forced_rccl_1rank.json" 2>> "$OUT/bench.err"
 python tools/run_config.py c3 --minutes 60 --oracle > "$OUT/c3_60min.json" 2>> "$OUT/bench.err"
 python tools/e2e.py > "$OUT/e2e_c2.json" 2>> "$OUT/bench.err"
+
+# BASELINE configs[3]: the 1.536 MS/s IQ stream.  Exact path on 30 s, halo-local path on the whole 60 minutes.
+python tools/run_config.py c4 --seconds 30 --oracle > "$OUT/c4_exact_30s.json" 2>> "$OUT/bench.err"
+python bench.py --workload iq > "$OUT/bench_iq_3600s.json" 2>> "$OUT/bench.err"
+python bench.py --workload iq --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s.json" 2>> "$OUT/bench.err"
+WFX_BENCH_FORCE_DIST=1 python bench.py --workload iq --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s_rccl1.json" 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_iq" -o run -- python3 bench.py --workload iq --steps 5 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+python tools/kstats.py "$OUT/trace_iq" "decimate|rational|fir_hilbert|select_|notch|median|image|quantise|sync" > "$OUT/kernel_stats_iq.txt"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+python tools/pmc_summary.py "$OUT/pmc_fetch_iq" "$OUT/pmc_write_iq" "$OUT/pmc_traffic_iq.json" > /dev/null 2>&1
+rm -rf "$OUT/trace_iq" "$OUT/pmc_fetch_iq" "$OUT/pmc_write_iq"
+
+# where the waves' cycles go (SQ counters, one pass)
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/sq" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+python tools/pmc_sq.py "$OUT/sq" > "$OUT/sq_counters.txt"
+rm -rf "$OUT/sq"
 ls -la "$OUT"

@@ -10,5 +10,5 @@ for f in files:
         name = r["Name"]
         if pat and not pat.search(name):
             continue
-        short = re.sub(r"\(.*", "", name).replace("void ", "").replace("(anonymous namespace)::", "")
+        short = re.sub(r"\(.*", "", name.replace("void ", "").replace("(anonymous namespace)::", ""))
         print(f"{short[:60]:60s} calls {int(r['Calls']):6d}  avg {float(r['AverageNs'])/1e3:10.1f} us  total {float(r['TotalDurationNs'])/1e6:9.2f} ms")
