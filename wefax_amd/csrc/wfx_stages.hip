@@ -1380,19 +1380,38 @@ __device__ __forceinline__ void load8_any(const uint8_t *p, unsigned &lo, unsign
 // (sharded decode: this GPU renders lines [y0, y0 + gridDim.x) of an image of h_arg lines; d points
 // at global sample 0 of the stream, possibly virtually: only the lines' own bytes are touched)
 __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ d, uint64_t n, int w, const wfx_dev_scalars *__restrict__ s,
-                                                   uint8_t *__restrict__ img_base, int h_arg, long long start_arg, int y0)
+                                                   uint8_t *__restrict__ img_base, int h_arg, long long start_arg, int y0, int xchunks)
 {
+    // blockIdx.x = source row * xchunks + chunk of 2048 columns: every thread makes one 8-column strip
     const int h = s ? s->height : h_arg;
-    const int y = y0 + (int)blockIdx.x;
+    const int y = y0 + (int)(blockIdx.x / (unsigned)xchunks);
+    const int xc = (int)(blockIdx.x % (unsigned)xchunks);
     if (y >= h) return;
     const uint64_t start = s ? (uint64_t)s->start_frame : (uint64_t)start_arg;
     uint8_t *img = img_base - (uint64_t)4 * y0 * w;          // row 4*y0 is the first row of the local buffer
-    // coefficients of the four output rows (row-uniform, computed redundantly per thread)
+    // coefficients of the four output rows: row-uniform, so four lanes evaluate Pillow's float64 filter once
+    // and hand the fixed-point taps to the workgroup through LDS
+    __shared__ int sh_ymin[4], sh_cnt[4], sh_kk[4][5];
+    if (threadIdx.x < 4) {
+        int ym, c, k5[5];
+        pil_row_coeffs(4 * y + (int)threadIdx.x, h, 4 * h, ym, c, k5);
+        sh_ymin[threadIdx.x] = ym;
+        sh_cnt[threadIdx.x] = c;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sh_kk[threadIdx.x][i] = k5[i];
+    }
+    __syncthreads();
     int ymin[4], cnt[4], kk[4][5];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pil_row_coeffs(4 * y + r, h, 4 * h, ymin[r], cnt[r], kk[r]);
+    for (int r = 0; r < 4; ++r) {
+        ymin[r] = sh_ymin[r];
+        cnt[r] = sh_cnt[r];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) kk[r][i] = sh_kk[r][i];
+    }
     const int ylo = max(y - 2, 0), yhi = min(y + 2, h - 1);      // source rows any of the four can touch
-    for (int x0 = threadIdx.x * 8; x0 < w; x0 += 256 * 8) {
+    const int x0 = xc * 2048 + (int)threadIdx.x * 8;
+    if (x0 < w) {
         const int nx = min(8, w - x0);
         int acc[4][8];
 #pragma unroll
@@ -1443,7 +1462,8 @@ __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ 
 int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max, const wfx_dev_scalars *d_scal, uint8_t *img)
 {
     if (h_max <= 0 || w <= 0) return 0;
-    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max), dim3(256), d, n, w, d_scal, img, 0, 0ll, 0);
+    const int xchunks = (w + 2047) / 2048;
+    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max * xchunks), dim3(256), d, n, w, d_scal, img, 0, 0ll, 0, xchunks);
     return 0;
 }
 
@@ -1451,8 +1471,9 @@ int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t sta
 {
     if (rows <= 0) return 0;
     if (w <= 0 || y0 < 0 || y0 + rows > h_total) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "image rows out of range");
-    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)rows), dim3(256), d - g0, (uint64_t)0, w, (const wfx_dev_scalars *)nullptr, img, h_total,
-               (long long)start, y0);
+    const int xchunks = (w + 2047) / 2048;
+    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)rows * xchunks), dim3(256), d - g0, (uint64_t)0, w, (const wfx_dev_scalars *)nullptr, img,
+               h_total, (long long)start, y0, xchunks);
     return 0;
 }
 
