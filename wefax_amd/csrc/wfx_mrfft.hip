@@ -22,6 +22,7 @@
 // (W^t = hi[t >> 11] * lo[t & 2047]).  Like the power-of-two engine the passes are
 // HBM-bound: read 16 B + write 16 B per point and pass.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 
@@ -70,6 +71,16 @@ template <> struct mr_roots<11> {
 template <> struct mr_roots<13> {
     static constexpr double c[13] = {1.0, 0.8854560256532099, 0.5680647467311559, 0.120536680255323, -0.35460488704253545, -0.7485107481711012, -0.970941817426052, -0.9709418174260521, -0.7485107481711013, -0.3546048870425359, 0.1205366802553232, 0.5680647467311548, 0.88545602565321};
     static constexpr double s[13] = {0.0, 0.4647231720437685, 0.8229838658936564, 0.992708874098054, 0.9350162426854148, 0.6631226582407952, 0.23931566428755768, -0.23931566428755743, -0.663122658240795, -0.9350162426854147, -0.992708874098054, -0.822983865893657, -0.4647231720437684};
+};
+
+// composite odd radices of the register-resident two-level passes (the conjugate-pair form holds for any odd P)
+template <> struct mr_roots<15> {
+    static constexpr double c[15] = {1.0, 0.9135454576426009, 0.6691306063588582, 0.30901699437494745, -0.10452846326765333, -0.4999999999999998, -0.8090169943749473, -0.9781476007338057, -0.9781476007338057, -0.8090169943749476, -0.5000000000000004, -0.10452846326765423, 0.30901699437494723, 0.6691306063588585, 0.913545457642601};
+    static constexpr double s[15] = {0.0, 0.40673664307580015, 0.7431448254773941, 0.9510565162951535, 0.9945218953682734, 0.8660254037844387, 0.5877852522924732, 0.20791169081775931, -0.20791169081775907, -0.587785252292473, -0.8660254037844384, -0.9945218953682733, -0.9510565162951536, -0.743144825477394, -0.40673664307580015};
+};
+template <> struct mr_roots<25> {
+    static constexpr double c[25] = {1.0, 0.9685831611286311, 0.8763066800438636, 0.7289686274214116, 0.5358267949789965, 0.30901699437494745, 0.06279051952931353, -0.1873813145857246, -0.4257792915650727, -0.6374239897486897, -0.8090169943749473, -0.9297764858882513, -0.9921147013144778, -0.9921147013144779, -0.9297764858882515, -0.8090169943749478, -0.6374239897486895, -0.42577929156507216, -0.18738131458572463, 0.06279051952931283, 0.30901699437494723, 0.5358267949789968, 0.7289686274214112, 0.8763066800438631, 0.968583161128631};
+    static constexpr double s[25] = {0.0, 0.2486898871648548, 0.4817536741017153, 0.6845471059286886, 0.8443279255020151, 0.9510565162951535, 0.9980267284282716, 0.9822872507286887, 0.9048270524660195, 0.7705132427757893, 0.5877852522924732, 0.36812455268467814, 0.12533323356430454, -0.12533323356430429, -0.3681245526846779, -0.5877852522924727, -0.7705132427757894, -0.9048270524660198, -0.9822872507286887, -0.9980267284282716, -0.9510565162951536, -0.844327925502015, -0.684547105928689, -0.4817536741017161, -0.24868988716485535};
 };
 
 // p-point DFT of v[0..P) in registers; sg = -1 forward (W = e^{-i..}), +1 inverse.  Each output is
@@ -291,6 +302,295 @@ mr_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-level register-resident pass for R = RA * RB (same index maps as mr_pass, so the two kinds
+// of pass can be mixed in one plan).  The per-prime LDS stages of mr_pass cost ~250 vector
+// instructions per point (index arithmetic, a twiddle per stage, five LDS round trips); here a
+// thread loads the RA rows {a RB + b} of its column straight from global memory into registers,
+// transforms them with compile-time indices, applies ONE twiddle W_R^{b qa}, and a second thread
+// picks the RB values {qa RB + b} up from LDS for the second transform and stores the results:
+// one LDS round trip, two barriers per tile, ~50 vector instructions per point.
+//   level A items (c, b):  T * RB, RA points each      level B items (c, qa):  T * RA, RB points each
+// The next tile's loads are issued before level B and stay in flight through it.
+// ---------------------------------------------------------------------------------------------
+// Q0..Q1: the output pairs (q, P - q) this call produces (1..H = all); EMIT0: also output 0.  Two threads can share one
+// transform by splitting the pairs (each prepares the sums and differences for itself).
+template <int P, int Q0, int Q1, bool EMIT0, typename PUT>
+__device__ __forceinline__ void dft_odd_part(cplx *v, const double sg, PUT put)
+{
+    constexpr int H = (P - 1) / 2;
+    cplx y0 = v[0];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {                 // a_m -> v[m], b_m -> v[P - m]
+        const cplx am = make_double2(v[m].x + v[P - m].x, v[m].y + v[P - m].y);
+        const cplx bm = make_double2(v[m].x - v[P - m].x, v[m].y - v[P - m].y);
+        v[m] = am;
+        v[P - m] = bm;
+        y0.x += am.x;
+        y0.y += am.y;
+    }
+    const cplx v0 = v[0];
+    if (EMIT0) put(0, y0);
+#pragma unroll
+    for (int q = Q0; q <= Q1; ++q) {
+        double ax = v0.x, ay = v0.y, bx = 0.0, by = 0.0;
+#pragma unroll
+        for (int m = 1; m <= H; ++m) {
+            const double wc = mr_roots<P>::c[(m * q) % P], ws = sg * mr_roots<P>::s[(m * q) % P];
+            ax = fma(v[m].x, wc, ax);
+            ay = fma(v[m].y, wc, ay);
+            bx = fma(v[P - m].x, ws, bx);
+            by = fma(v[P - m].y, ws, by);
+        }
+        put(q, make_double2(ax - by, ay + bx));
+        put(P - q, make_double2(ax + by, ay - bx));
+    }
+}
+
+template <int P, typename PUT>
+__device__ __forceinline__ void dft_odd_inplace(cplx *v, const double sg, PUT put)
+{
+    constexpr int H = (P - 1) / 2;
+    cplx y0 = v[0];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {                 // a_m -> v[m], b_m -> v[P - m]
+        const cplx am = make_double2(v[m].x + v[P - m].x, v[m].y + v[P - m].y);
+        const cplx bm = make_double2(v[m].x - v[P - m].x, v[m].y - v[P - m].y);
+        v[m] = am;
+        v[P - m] = bm;
+        y0.x += am.x;
+        y0.y += am.y;
+    }
+    const cplx v0 = v[0];
+    put(0, y0);
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+        double ax = v0.x, ay = v0.y, bx = 0.0, by = 0.0;
+#pragma unroll
+        for (int m = 1; m <= H; ++m) {
+            const double wc = mr_roots<P>::c[(m * q) % P], ws = sg * mr_roots<P>::s[(m * q) % P];
+            ax = fma(v[m].x, wc, ax);
+            ay = fma(v[m].y, wc, ay);
+            bx = fma(v[P - m].x, ws, bx);
+            by = fma(v[P - m].y, ws, by);
+        }
+        put(q, make_double2(ax - by, ay + bx));
+        put(P - q, make_double2(ax + by, ay - bx));
+    }
+}
+
+// 25 points as 5 x 5 (Cooley-Tukey in registers, all indices compile-time): n = 5 n1 + n0, q = qa + 5 qb
+//   A[n0][qa] = sum_n1 x[5 n1 + n0] W5^(n1 qa);   X[qa + 5 qb] = sum_n0 (A[n0][qa] W25^(n0 qa)) W5^(n0 qb)
+// 224 FMAs instead of the 576 of the direct conjugate-pair form.
+template <typename PUT>
+__device__ __forceinline__ void dft25_ct(cplx *u, const double sg, PUT put)
+{
+#pragma unroll
+    for (int n0 = 0; n0 < 5; ++n0) {
+        cplx x5[5], y5[5];
+#pragma unroll
+        for (int n1 = 0; n1 < 5; ++n1) x5[n1] = u[5 * n1 + n0];
+        dft_odd_inplace<5>(x5, sg, [&](int qa, cplx y) { y5[qa] = y; });
+#pragma unroll
+        for (int qa = 0; qa < 5; ++qa) {
+            cplx y = y5[qa];
+            if (n0 > 0 && qa > 0) y = mcmul(y, make_double2(mr_roots<25>::c[n0 * qa], sg * mr_roots<25>::s[n0 * qa]));
+            u[5 * qa + n0] = y;                   // row qa now holds A[.][qa]
+        }
+    }
+#pragma unroll
+    for (int qa = 0; qa < 5; ++qa) {
+        cplx x5[5];
+#pragma unroll
+        for (int n0 = 0; n0 < 5; ++n0) x5[n0] = u[5 * qa + n0];
+        dft_odd_inplace<5>(x5, sg, [&](int qb, cplx y) { put(qa + 5 * qb, y); });
+    }
+}
+
+template <int P, typename PUT>
+__device__ __forceinline__ void dft_any(cplx *v, const double sg, PUT put)
+{
+    if (P == 25)
+        dft25_ct(v, sg, put);
+    else
+        dft_odd_inplace<P>(v, sg, put);
+}
+
+template <int RA, int RB, int LOG2T, int PF, int IN_MODE, int OUT_MODE, int INVERSE>
+__global__ void __launch_bounds__(256, 2)
+mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
+         const cplx *__restrict__ glo, const cplx *__restrict__ ghi, int ntiles)
+{
+    constexpr int R = RA * RB, T = 1 << LOG2T;
+    constexpr int NA = (T * RB + 255) / 256, NB = (T * RA + 255) / 256;
+    constexpr bool inv = INVERSE != 0;
+    constexpr double sg = inv ? 1.0 : -1.0;
+    __shared__ cplx tile[T * R];
+    __shared__ cplx wr[R];
+    const int t = (int)threadIdx.x;
+    const int ncol = (int)d.ncol, P = (int)d.P;
+    for (int i = t; i < R; i += 256) {
+        double sn, cs;
+        sincospi(2.0 * (double)i / (double)R, &sn, &cs);
+        wr[i] = make_double2(cs, inv ? sn : -sn);                 // W_R^i in the direction of this pass
+    }
+    __shared__ cplx gpow[OUT_MODE == 1 ? RB : 1];                 // exp(-i pi qb RA P / L): the spectrum's step along qb
+    if (OUT_MODE == 1 && t < RB) {
+        double sn, cs;
+        sincospi((double)((long long)t * RA * P) / (double)d.L, &sn, &cs);
+        gpow[t] = make_double2(cs, -sn);
+    }
+    cplx pre[NA][RA];
+    auto prefetch = [&](int tix) {
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) {
+            const int item = t + 256 * ia;
+            const int c = item & (T - 1), b = item >> LOG2T;
+            const int j = tix * T + c;
+            const bool ok = item < T * RB && j < ncol;
+#pragma unroll
+            for (int a = 0; a < RA; ++a) {
+                cplx v = make_double2(0.0, 0.0);
+                if (ok) {
+                    const long long adr = (long long)j + (long long)(a * RB + b) * ncol;
+                    v = in[adr];
+                    if (IN_MODE == 1) v = make_double2(v.y, v.x);
+                }
+                pre[ia][a] = v;
+            }
+        }
+    };
+    auto lookup = [&](int e) { return mconj_if(mcmul(tw_hi[e >> MR_LO_BITS], tw_lo[e & (MR_LO - 1)]), inv); };
+    int tix = blockIdx.x;
+    if (PF && tix < ntiles) prefetch(tix);
+    for (; tix < ntiles; tix += gridDim.x) {
+        const int j0 = tix * T;
+        const int tn = min(T, ncol - j0);
+        if (!PF) prefetch(tix);                                   // register-hungry radices: no tile kept in flight across level B
+        mr_lds_barrier();                                         // the previous tile has been read out of LDS
+        // ---- level A ----
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) {
+            const int item = t + 256 * ia;
+            if (item < T * RB) {
+                const int c = item & (T - 1), b = item >> LOG2T;
+                cplx v[RA];
+#pragma unroll
+                for (int a = 0; a < RA; ++a) v[a] = pre[ia][a];
+                if (P > 1 && c < tn) {                            // input twiddle W_{P R}^{k (a RB + b)}: two look-ups, then a recurrence
+                    const int k = (j0 + c) % P;
+                    cplx w = lookup(k * b);
+                    const cplx wstep = lookup(k * RB);
+#pragma unroll
+                    for (int a = 0; a < RA; ++a) {
+                        v[a] = mcmul(v[a], w);
+                        if (a + 1 < RA) w = mcmul(w, wstep);
+                    }
+                }
+                dft_any<RA>(v, sg, [&](int qa, cplx y) {
+                    if (qa > 0 && b > 0) y = mcmul(y, wr[b * qa]);
+                    tile[((qa * RB + b) << LOG2T) + c] = y;
+                });
+            }
+        }
+        mr_lds_barrier();
+        if (PF && tix + (int)gridDim.x < ntiles) prefetch(tix + gridDim.x);       // in flight during level B
+        // ---- level B ----
+        if (P == 1) {
+            // first pass: a column's R outputs are contiguous in memory.  Results go back to LDS in output order
+            // (column-major), then the workgroup copies one contiguous run.
+            cplx res[NB][RB];
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                const int item = t + 256 * ib;
+                if (item < T * RA) {
+                    const int c = item & (T - 1), qa = item >> LOG2T;
+                    cplx u[RB];
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) u[b] = tile[((qa * RB + b) << LOG2T) + c];
+                    dft_any<RB>(u, sg, [&](int qb, cplx y) { res[ib][qb] = y; });
+                }
+            }
+            mr_lds_barrier();
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                const int item = t + 256 * ib;
+                if (item < T * RA) {
+                    const int c = item & (T - 1), qa = item >> LOG2T;
+#pragma unroll
+                    for (int qb = 0; qb < RB; ++qb) tile[c * R + qa + RA * qb] = res[ib][qb];
+                }
+            }
+            mr_lds_barrier();
+            const long long o0 = (long long)j0 * R;
+            for (int e = t; e < R * tn; e += 256) out[o0 + e] = tile[e];
+        } else {
+            // few, long transforms (T * RA <= 128 items): two threads share one, each producing half of the output pairs
+            constexpr int SPLIT = (T * RA <= 128 && RB >= 9 && RB != 25) ? 2 : 1;
+            constexpr int NBS = (T * RA * SPLIT + 255) / 256;
+            constexpr int HB = (RB - 1) / 2, HB1 = SPLIT == 2 ? (HB + 1) / 2 : HB;
+#pragma unroll
+            for (int ib = 0; ib < NBS; ++ib) {
+                const int item = t + 256 * ib;
+                const int part = SPLIT == 2 ? (item >= T * RA ? 1 : 0) : 0;
+                const int it2 = item - part * (T * RA);
+                const int c = it2 & (T - 1), qa = it2 >> LOG2T;
+                if (item < T * RA * SPLIT && c < tn) {
+                    cplx u[RB];
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) u[b] = tile[((qa * RB + b) << LOG2T) + c];
+                    const int j = j0 + c;
+                    const int k = j % P;
+                    const long long obase = (long long)(j - k) * R + k + (long long)qa * P;      // + qb * RA * P
+                    const long long ostep = (long long)RA * P;
+                    cplx g0 = make_double2(0.0, 0.0);
+                    if (OUT_MODE == 1) {
+                        const double il = 1.0 / (double)d.L;
+                        double sn, cs;
+                        sincospi((double)obase * il, &sn, &cs);
+                        g0 = make_double2(-sn * il, -cs * il);
+                    }
+                    auto emit = [&](int qb, cplx y) {
+                        const long long o = obase + (long long)qb * ostep;
+                        if (OUT_MODE == 1) {
+                            // times G[o] / L, G[o] = -i exp(-i pi o / L) (G[0] = 0) = g0 * gstep^qb: the powers of the
+                            // (kernel-uniform) step come from LDS, the start from one sincospi per thread
+                            y = o == 0 ? make_double2(0.0, 0.0) : mcmul(y, mcmul(g0, gpow[qb]));
+                        }
+                        out[o] = y;
+                    };
+                    if (SPLIT == 1) {
+                        dft_any<RB>(u, sg, emit);
+                    } else if (part == 0) {
+                        dft_odd_part<RB, 1, HB1, true>(u, sg, emit);
+                    } else {
+                        dft_odd_part<RB, HB1 + 1, HB, false>(u, sg, emit);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// two-level table of the Hilbert kernel spectrum G[o] / L = (-i / L) exp(-i pi o / L), o > 0:
+// glo[i] = (-i / L) exp(-i pi i / L) (i < 2048), ghi[i] = exp(-i pi 2048 i / L); G[o] / L = ghi[o >> 11] * glo[o & 2047]
+__global__ void __launch_bounds__(256) mr_fill_gtables(cplx *__restrict__ glo, cplx *__restrict__ ghi, long long L, int nhi)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double inv_l = 1.0 / (double)L;
+    if (i < MR_LO) {
+        double s, c;
+        sincospi((double)i / (double)L, &s, &c);
+        glo[i] = make_double2(-s * inv_l, -c * inv_l);
+    }
+    if (i < nhi) {
+        const long long t = ((long long)i << MR_LO_BITS) % (2 * L);
+        double s, c;
+        sincospi((double)t / (double)L, &s, &c);
+        ghi[i] = make_double2(c, -s);
+    }
+}
+
 // two-level twiddle table for modulus `mod`: lo[i] = W^i (i < 2048), hi[i] = W^(2048 i)
 __global__ void __launch_bounds__(256) mr_fill_tables(cplx *__restrict__ lo, cplx *__restrict__ hi, long long mod, int nhi)
 {
@@ -314,6 +614,7 @@ struct mr_plan_host {
     int npass = 0;
     mr_pass_desc pass[MR_MAXPASS];
     size_t lo_off[MR_MAXPASS], hi_off[MR_MAXPASS];
+    size_t glo_off = 0, ghi_off = 0;          // Hilbert spectrum tables (mr_fill_gtables)
     size_t table_elems = 0;
 };
 
@@ -384,6 +685,10 @@ static bool mr_make_plan(long long L, mr_plan_host &pl)
         off += (size_t)(mod >> MR_LO_BITS) + 2;
         P *= d.R;
     }
+    pl.glo_off = off;
+    off += MR_LO;
+    pl.ghi_off = off;
+    off += (size_t)(L >> MR_LO_BITS) + 2;
     pl.table_elems = off;
     return true;
 }
@@ -391,6 +696,7 @@ static bool mr_make_plan(long long L, mr_plan_host &pl)
 struct mr_plan_cache {
     mr_plan_host h;
     wfx_devbuf tables;
+    bool use_mr2 = true;        // WFX_MR2=0 in the environment forces the per-prime LDS stages (A/B comparisons)
 };
 static std::map<std::pair<const void *, long long>, mr_plan_cache> g_mr_plans;   // per (context, L)
 static std::mutex g_mr_mutex;
@@ -412,6 +718,10 @@ static int mr_get_plan(wfx_ctx *ctx, long long L, mr_plan_cache **out)
     }
     mr_plan_cache pc;
     if (!mr_make_plan(L, pc.h)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "length %lld is not 13-smooth", L);
+    {
+        const char *e = getenv("WFX_MR2");
+        pc.use_mr2 = !(e && e[0] == '0');
+    }
     WFX_TRY(wfx_reserve(ctx, pc.tables, pc.h.table_elems * sizeof(cplx)));
     for (int i = 0; i < pc.h.npass; ++i) {
         const long long mod = pc.h.pass[i].P * pc.h.pass[i].R;
@@ -419,6 +729,12 @@ static int mr_get_plan(wfx_ctx *ctx, long long L, mr_plan_cache **out)
         const int n = nhi > MR_LO ? nhi : MR_LO;
         cplx *base = (cplx *)pc.tables.p;
         WFX_LAUNCH(ctx, K_BS_CHIRP, mr_fill_tables, dim3((n + 255) / 256), dim3(256), base + pc.h.lo_off[i], base + pc.h.hi_off[i], mod, nhi);
+    }
+    {
+        const int nhi = (int)(L >> MR_LO_BITS) + 2;
+        const int n = nhi > MR_LO ? nhi : MR_LO;
+        cplx *base = (cplx *)pc.tables.p;
+        WFX_LAUNCH(ctx, K_BS_CHIRP, mr_fill_gtables, dim3((n + 255) / 256), dim3(256), base + pc.h.glo_off, base + pc.h.ghi_off, L, nhi);
     }
     auto ins = g_mr_plans.emplace(key, pc);
     *out = &ins.first->second;
@@ -455,21 +771,43 @@ int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_
     for (int dir = 0; dir < 2; ++dir) {     // forward, then inverse
         for (int i = 0; i < np; ++i) {
             const mr_pass_desc &d = pc->h.pass[i];
-            const int ntiles = (int)((d.ncol + d.T - 1) / d.T);
-            const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);       // 2 persistent workgroups per CU
             const cplx *lo = tb + pc->h.lo_off[i], *hi = tb + pc->h.hi_off[i];
             const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
             const bool first = dir == 0 && i == 0, last_fwd = dir == 0 && i == np - 1;
-            if (dir == 1)
-                WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
-            else if (first && last_fwd)
-                WFX_LAUNCH(ctx, kid, (mr_pass<1, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
-            else if (first)
-                WFX_LAUNCH(ctx, kid, (mr_pass<1, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
-            else if (last_fwd)
-                WFX_LAUNCH(ctx, kid, (mr_pass<0, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
-            else
-                WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+            const int mode = dir == 1 ? 2 : (first && last_fwd) ? 3 : first ? 1 : last_fwd ? 4 : 0;
+            // register-resident two-level passes for the radix pairs that have one (mr2_pass); per-prime LDS stages otherwise
+            const cplx *glo = tb + pc->h.glo_off, *ghi = tb + pc->h.ghi_off;
+            bool done = false;
+#define WFX_MR2_TRY(RA_, RB_, LT_, PF_)                                                                                             \
+    if (!done && pc->use_mr2 && d.R == (RA_) * (RB_) && !(first && last_fwd)) {                                                \
+        const int nt = (int)((d.ncol + (1 << (LT_)) - 1) >> (LT_));                                                            \
+        const unsigned g2 = (unsigned)(nt < 512 ? nt : 512);                                                                   \
+        switch (mode) {                                                                                                        \
+        case 2: WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, LT_, PF_, 0, 0, 1>), dim3(g2), dim3(256), src, dst, d, lo, hi, glo, ghi, nt); break; \
+        case 1: WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, LT_, PF_, 1, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, glo, ghi, nt); break; \
+        case 4: WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, LT_, 0, 0, 1, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, glo, ghi, nt); break; \
+        default: WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, LT_, PF_, 0, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, glo, ghi, nt); break; \
+        }                                                                                                                      \
+        done = true;                                                                                                           \
+    }
+            WFX_MR2_TRY(15, 15, 4, 1)
+            WFX_MR2_TRY(7, 25, 4, 0)
+            WFX_MR2_TRY(7, 13, 5, 1)
+#undef WFX_MR2_TRY
+            if (!done) {
+                const int ntiles = (int)((d.ncol + d.T - 1) / d.T);
+                const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);       // 2 persistent workgroups per CU
+                if (dir == 1)
+                    WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+                else if (first && last_fwd)
+                    WFX_LAUNCH(ctx, kid, (mr_pass<1, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+                else if (first)
+                    WFX_LAUNCH(ctx, kid, (mr_pass<1, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+                else if (last_fwd)
+                    WFX_LAUNCH(ctx, kid, (mr_pass<0, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+                else
+                    WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+            }
             src = dst;
             dst = (dst == A) ? B : A;
         }
