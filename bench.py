@@ -246,12 +246,7 @@ def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
         pmc = os.path.join(REPO, "profiles", "pmc_traffic_iq.json")      # measured on the full 3600 s stream, one rank
         if os.path.exists(pmc) and world == 1 and secs == 3600.0:
             try:
-                tj = json.load(open(pmc))
-                if dom[0] == "fft_pass":
-                    parts = [tj[k]["hbm_bytes_per_launch"] for k in ("fft_pass_fwd", "fft_pass_inv") if k in tj]
-                    traffic = int(sum(parts) / len(parts)) if parts else None
-                else:
-                    traffic = tj.get(dom[0], {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(dom[0], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(alg_bytes / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
@@ -410,7 +405,12 @@ def main():
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom[0], {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(pmc))
+                if dom[0] == "fft_pass":
+                    parts = [tj[k]["hbm_bytes_per_launch"] for k in ("fft_pass_fwd", "fft_pass_inv") if k in tj]
+                    traffic = int(sum(parts) / len(parts)) if parts else None
+                else:
+                    traffic = tj.get(dom[0], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
