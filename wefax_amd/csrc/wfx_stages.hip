@@ -979,6 +979,29 @@ __device__ __forceinline__ int wave_min_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// the same reductions over each 32-lane half of the wave (lanes 0..31 -> lo, 32..63 -> hi): five DPP steps,
+// the last one (row_bcast15 into rows 1 and 3) leaves the results in lanes 31 and 63
+__device__ __forceinline__ void half_max_i32(int v, int &lo, int &hi)
+{
+    v = max(v, WFX_DPP(v, 0xB1, 0xf));
+    v = max(v, WFX_DPP(v, 0x4E, 0xf));
+    v = max(v, WFX_DPP(v, 0x141, 0xf));
+    v = max(v, WFX_DPP(v, 0x140, 0xf));
+    v = max(v, WFX_DPP(v, 0x142, 0xa));
+    lo = __builtin_amdgcn_readlane(v, 31);
+    hi = __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ void half_min_i32(int v, int &lo, int &hi)
+{
+    v = min(v, WFX_DPP(v, 0xB1, 0xf));
+    v = min(v, WFX_DPP(v, 0x4E, 0xf));
+    v = min(v, WFX_DPP(v, 0x141, 0xf));
+    v = min(v, WFX_DPP(v, 0x140, 0xf));
+    v = min(v, WFX_DPP(v, 0x142, 0xa));
+    lo = __builtin_amdgcn_readlane(v, 31);
+    hi = __builtin_amdgcn_readlane(v, 63);
+}
+
 // first arg-max over the wave: (max correlation, smallest index holding it)
 __device__ __forceinline__ void wave_first_argmax(int c, int idx, int &best_c, int &best_idx)
 {
@@ -1177,8 +1200,101 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
             const int mind32 = (int)mind;
             int rpos = __builtin_amdgcn_readfirstlane((int)(pos - (long long)p0));   // may be negative
             int i = 0;
+            // "first maximum of [li, ll]" for the whole wave: (value, index), index = 0x7fffffff where no lane holds it.
+            // Every LDS read of the range is issued first (head block, the whole blocks in between through their
+            // summaries, tail block), then combined in index order, branch-free.
+            auto range_max = [&](int li, int ll, int &c, int &ci) {
+                const int b_lo = li >> 6, b_hi = ll >> 6;
+                const int jh = (b_lo << 6) + lane, jt = (b_hi << 6) + lane;
+                const int b1 = b_lo + 1 + lane, b2 = b1 + 64, b3 = b2 + 64;   // up to 192 whole blocks: mind <= 12000
+                const int ch = cs[jh], ct = cs[jt];
+                const int2 s1 = sm2[b1], s2 = sm2[b2], s3 = sm2[b3];
+                const bool vh = (jh >= li) & (jh <= ll);
+                c = vh ? ch : CMIN;
+                ci = vh ? jh : 0x7fffffff;
+                const bool t1 = (b1 < b_hi) & (s1.x > c);
+                c = t1 ? s1.x : c;
+                ci = t1 ? s1.y : ci;
+                const bool t2 = (b2 < b_hi) & (s2.x > c);
+                c = t2 ? s2.x : c;
+                ci = t2 ? s2.y : ci;
+                const bool t3 = (b3 < b_hi) & (s3.x > c);
+                c = t3 ? s3.x : c;
+                ci = t3 ? s3.y : ci;
+                const bool tt = (b_hi > b_lo) & (jt <= ll) & (ct > c);
+                c = tt ? ct : c;
+                ci = tt ? jt : ci;
+            };
+            // smallest index among the lanes that hold the wave maximum bc
+            auto first_of = [&](int c, int ci, int bc) {
+                const unsigned long long tie = __ballot(c == bc);
+                if (__popcll(tie) == 1) return __builtin_amdgcn_readlane(ci, __ffsll((long long)tie) - 1);
+                return wave_min_i32(c == bc ? ci : 0x7fffffff);
+            };
             while (i < cnt) {
                 PICK_STAT(++n_ops;)
+                // Steady state of the reference's scan is three dependent steps per peak: "nothing greater in the rest of
+                // this peak's window" -> "a new peak starts at rpos + mind + 1" -> "first maximum of ITS window".  The second
+                // and third do not depend on the outcome of the first, only on it being negative (which it almost always
+                // is), so all three are evaluated in one step and the speculation is dropped when the first finds something.
+                const int sp = rpos + mind32 + 1;
+                if (i <= rpos + mind32 && sp + mind32 <= cnt - 1 && np + 1 < WFX_MAX_PEAKS && mind32 <= 6000) {
+                    // lanes 0..31 search the rest of the current window, lanes 32..63 the window of the speculated peak:
+                    // 32 lanes x 3 summaries cover 96 whole blocks (mind <= 6000), head and tail blocks take two reads each
+                    const bool hiq = lane >= 32;
+                    const int hl = lane & 31;
+                    const int li = hiq ? sp + 1 : i, ll = hiq ? sp + mind32 : rpos + mind32;
+                    const int b_lo = li >> 6, b_hi = ll >> 6;
+                    const int jh0 = (b_lo << 6) + hl, jh1 = jh0 + 32, jt0 = (b_hi << 6) + hl, jt1 = jt0 + 32;
+                    const int b1 = b_lo + 1 + hl, b2 = b1 + 32, b3 = b2 + 32;
+                    const int vb = cs[sp];
+                    const int ch0 = cs[jh0], ch1 = cs[jh1], ct0 = cs[jt0], ct1 = cs[jt1];
+                    const int2 s1 = sm2[b1], s2 = sm2[b2], s3 = sm2[b3];
+                    const bool vh0 = (jh0 >= li) & (jh0 <= ll);
+                    int c = vh0 ? ch0 : CMIN, ci = vh0 ? jh0 : 0x7fffffff;
+                    const bool vh1 = (jh1 >= li) & (jh1 <= ll) & (ch1 > c);
+                    c = vh1 ? ch1 : c;
+                    ci = vh1 ? jh1 : ci;
+                    const bool t1 = (b1 < b_hi) & (s1.x > c);
+                    c = t1 ? s1.x : c;
+                    ci = t1 ? s1.y : ci;
+                    const bool t2 = (b2 < b_hi) & (s2.x > c);
+                    c = t2 ? s2.x : c;
+                    ci = t2 ? s2.y : ci;
+                    const bool t3 = (b3 < b_hi) & (s3.x > c);
+                    c = t3 ? s3.x : c;
+                    ci = t3 ? s3.y : ci;
+                    const bool tt0 = (b_hi > b_lo) & (jt0 <= ll) & (ct0 > c);
+                    c = tt0 ? ct0 : c;
+                    ci = tt0 ? jt0 : ci;
+                    const bool tt1 = (b_hi > b_lo) & (jt1 <= ll) & (ct1 > c);
+                    c = tt1 ? ct1 : c;
+                    ci = tt1 ? jt1 : ci;
+                    int bca, bcb;
+                    half_max_i32(c, bca, bcb);
+                    // smallest index among the lanes of a half that hold its maximum
+                    int fa, fb;
+                    half_min_i32(c == (hiq ? bcb : bca) ? ci : 0x7fffffff, fa, fb);
+                    if (bca > val) {                      // the window still held something greater: plain step, speculation unused
+                        rpos = fa;
+                        val = bca;
+                        i = sp;                           // == old rpos + mind + 1, the end of the range just searched + 1
+                        continue;
+                    }
+                    if (lane == 0) {
+                        pk_s[np - 1] = (long long)p0 + rpos;
+                        first_s[np] = (long long)p0 + sp;
+                    }
+                    ++np;
+                    rpos = sp;
+                    val = __builtin_amdgcn_readfirstlane(vb);
+                    if (bcb > val) {
+                        rpos = fb;
+                        val = bcb;
+                    }
+                    i = sp + mind32 + 1;
+                    continue;
+                }
                 if (i - rpos > mind32) {
                     if (lane == 0) {
                         pk_s[np - 1] = (long long)p0 + rpos;
@@ -1193,41 +1309,13 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                         break;
                     }
                 } else {
-                    const int li = i;
                     const int ll = min(rpos + mind32, cnt - 1);
-                    const int b_lo = li >> 6, b_hi = ll >> 6;
-                    // issue every LDS read of this range first (head block, the whole blocks in
-                    // between through their summaries, tail block), then combine in index order
-                    // (branch-free: this loop is a single wave's dependent instruction chain)
-                    const int jh = (b_lo << 6) + lane, jt = (b_hi << 6) + lane;
-                    const int b1 = b_lo + 1 + lane, b2 = b1 + 64, b3 = b2 + 64;   // up to 192 whole blocks: mind <= 12000
-                    const int ch = cs[jh], ct = cs[jt];
-                    const int2 s1 = sm2[b1], s2 = sm2[b2], s3 = sm2[b3];
-                    const bool vh = (jh >= li) & (jh <= ll);
-                    int c = vh ? ch : CMIN, ci = vh ? jh : 0x7fffffff;
-                    const bool t1 = (b1 < b_hi) & (s1.x > c);
-                    c = t1 ? s1.x : c;
-                    ci = t1 ? s1.y : ci;
-                    const bool t2 = (b2 < b_hi) & (s2.x > c);
-                    c = t2 ? s2.x : c;
-                    ci = t2 ? s2.y : ci;
-                    const bool t3 = (b3 < b_hi) & (s3.x > c);
-                    c = t3 ? s3.x : c;
-                    ci = t3 ? s3.y : ci;
-                    const bool tt = (b_hi > b_lo) & (jt <= ll) & (ct > c);
-                    c = tt ? ct : c;
-                    ci = tt ? jt : ci;
+                    int c, ci;
+                    range_max(i, ll, c, ci);
                     const int bc = wave_max_i32(c);
                     if (bc > val) {
-                        // first occurrence: usually one lane holds the maximum; ties take the smallest index
-                        const unsigned long long tie = __ballot(c == bc);
-                        int bi;
-                        if (__popcll(tie) == 1)
-                            bi = __builtin_amdgcn_readlane(ci, __ffsll((long long)tie) - 1);
-                        else
-                            bi = wave_min_i32(c == bc ? ci : 0x7fffffff);
+                        rpos = first_of(c, ci, bc);
                         val = bc;
-                        rpos = bi;
                     }
                     i = ll + 1;
                 }
