@@ -151,6 +151,20 @@ def test_mixed_radix_sizes(ctx, n):
     assert _rel(ctx.analytic_env(x), wo.demodulate(x)) <= FLOAT_TOL
 
 
+@pytest.mark.parametrize("n", [2 * 91 * 225, 2 * 91 * 175, 2 * 175 * 225, 2 * 91 * 175 * 225, 2 * 91, 2 * 225])
+def test_two_level_register_passes(ctx, n):
+    """Plans made of the radices that have register-resident two-level passes (mr2_pass: 91 = 7 x 13, 175 = 7 x 25,
+    225 = 15 x 15), every pair as first / middle / last pass, forward and inverse; single-pass lengths keep the
+    per-prime passes.  Checked against the oracle's FFT Hilbert and against the padded power-of-two form."""
+    from oracle import wefax_oracle as wo
+    from wefax_amd import _native as nat
+    x = _signal(n, n + 7)
+    ref = wo.demodulate(x)
+    a = ctx.analytic_env(x)
+    assert _rel(a, ref) <= FLOAT_TOL
+    assert _rel(a, ctx.analytic_env(x, nat.WFX_HILBERT_FFT_POW2)) <= FLOAT_TOL
+
+
 def test_analytic_envelope_fir_mode_converges(ctx):
     """The FIR kernel approaches the exact operator as taps grow (clean narrow-band input)."""
     from oracle import wefax_oracle as wo
