@@ -186,6 +186,16 @@ def test_resample(ctx, n0, num):
     assert _rel(ctx.resample(x, num), wo.resample_fft(x, num)) <= FLOAT_TOL
 
 
+@pytest.mark.parametrize("n0,num", [(96000, 22050), (172800, 39690), (22050, 96000), (8192, 8192), (2 * 91 * 225, 2 * 225),
+                                    (2 * 3 ** 7, 2 * 5 ** 4), (1440000, 330750)])
+def test_resample_mixed_radix_form(ctx, n0, num):
+    """Even lengths with 13-smooth halves take the packed real-FFT form on the mixed-radix passes (down- and
+    up-sampling, equal lengths, the Nyquist-bin factors of scipy.signal.resample)."""
+    from oracle import wefax_oracle as wo
+    x = _signal(n0, n0 + 3 * num)
+    assert _rel(ctx.resample(x, num), wo.resample_fft(x, num)) <= FLOAT_TOL
+
+
 @pytest.mark.parametrize("n", [1, 2, 5, 1000, 65537, 300001])
 def test_order_statistics_exact(ctx, n):
     rng = np.random.default_rng(n)

@@ -218,6 +218,8 @@ int wfx_dev_select_level(wfx_ctx *ctx, const double *env, uint64_t n, int level,
 bool wfx_mr_supported(uint64_t L);
 void wfx_mr_release(wfx_ctx *ctx);
 int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out);
+bool wfx_mr_resample_supported(uint64_t n0, uint64_t num);
+int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out);
 
 int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long fixed, int width, long long room, long long *hdr);
 

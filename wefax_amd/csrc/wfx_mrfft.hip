@@ -754,30 +754,24 @@ void wfx_mr_release(wfx_ctx *ctx)
     }
 }
 
-// H = Hilbert transform of the even-length real signal x, packed: Re V[p] = H[2p], Im V[p] = H[2p-1 mod N].
-// Returns the device pointer holding V (L = n/2 complex values) in *V_out.
-int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out)
+// One transform of the plan: `dir` 0 forward / 1 inverse, reading `src`, ping-ponging between A and B; the last pass
+// writes to `final_dst` when given.  hilbert: the packed-real load swap on the first forward pass and the multiplication
+// by the Hilbert spectrum on the last one.  Unnormalised; natural order in and out (self-sorting passes).
+static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cplx *B, int dir, bool hilbert, cplx *final_dst, cplx **result)
 {
-    const long long L = (long long)(n / 2);
-    mr_plan_cache *pc = nullptr;
-    WFX_TRY(mr_get_plan(ctx, L, &pc));
-    WFX_TRY(wfx_reserve(ctx, ctx->b_work, (size_t)L * sizeof(cplx)));
-    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (size_t)L * sizeof(cplx)));
-    cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
     const cplx *tb = (const cplx *)pc->tables.p;
     const int np = pc->h.npass;
-    const cplx *src = (const cplx *)x;      // the packed real input IS x viewed as complex pairs (swapped on load)
-    cplx *dst = A;
-    for (int dir = 0; dir < 2; ++dir) {     // forward, then inverse
-        for (int i = 0; i < np; ++i) {
-            const mr_pass_desc &d = pc->h.pass[i];
-            const cplx *lo = tb + pc->h.lo_off[i], *hi = tb + pc->h.hi_off[i];
-            const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
-            const bool first = dir == 0 && i == 0, last_fwd = dir == 0 && i == np - 1;
-            const int mode = dir == 1 ? 2 : (first && last_fwd) ? 3 : first ? 1 : last_fwd ? 4 : 0;
-            // register-resident two-level passes for the radix pairs that have one (mr2_pass); per-prime LDS stages otherwise
-            const cplx *glo = tb + pc->h.glo_off, *ghi = tb + pc->h.ghi_off;
-            bool done = false;
+    cplx *dst = (src == A) ? B : A;
+    for (int i = 0; i < np; ++i) {
+        const mr_pass_desc &d = pc->h.pass[i];
+        const cplx *lo = tb + pc->h.lo_off[i], *hi = tb + pc->h.hi_off[i];
+        const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
+        const bool first = hilbert && dir == 0 && i == 0, last_fwd = hilbert && dir == 0 && i == np - 1;
+        if (i == np - 1 && final_dst) dst = final_dst;
+        const int mode = dir == 1 ? 2 : (first && last_fwd) ? 3 : first ? 1 : last_fwd ? 4 : 0;
+        // register-resident two-level passes for the radix pairs that have one (mr2_pass); per-prime LDS stages otherwise
+        const cplx *glo = tb + pc->h.glo_off, *ghi = tb + pc->h.ghi_off;
+        bool done = false;
 #define WFX_MR2_TRY(RA_, RB_, LT_, PF_)                                                                                             \
     if (!done && pc->use_mr2 && d.R == (RA_) * (RB_) && !(first && last_fwd)) {                                                \
         const int nt = (int)((d.ncol + (1 << (LT_)) - 1) >> (LT_));                                                            \
@@ -790,28 +784,108 @@ int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_
         }                                                                                                                      \
         done = true;                                                                                                           \
     }
-            WFX_MR2_TRY(15, 15, 4, 1)
-            WFX_MR2_TRY(7, 25, 4, 0)
-            WFX_MR2_TRY(7, 13, 5, 1)
+        WFX_MR2_TRY(15, 15, 4, 1)
+        WFX_MR2_TRY(7, 25, 4, 0)
+        WFX_MR2_TRY(7, 13, 5, 1)
 #undef WFX_MR2_TRY
-            if (!done) {
-                const int ntiles = (int)((d.ncol + d.T - 1) / d.T);
-                const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);       // 2 persistent workgroups per CU
-                if (dir == 1)
-                    WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
-                else if (first && last_fwd)
-                    WFX_LAUNCH(ctx, kid, (mr_pass<1, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
-                else if (first)
-                    WFX_LAUNCH(ctx, kid, (mr_pass<1, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
-                else if (last_fwd)
-                    WFX_LAUNCH(ctx, kid, (mr_pass<0, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
-                else
-                    WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
-            }
-            src = dst;
-            dst = (dst == A) ? B : A;
+        if (!done) {
+            const int ntiles = (int)((d.ncol + d.T - 1) / d.T);
+            const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);       // 2 persistent workgroups per CU
+            if (dir == 1)
+                WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+            else if (first && last_fwd)
+                WFX_LAUNCH(ctx, kid, (mr_pass<1, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+            else if (first)
+                WFX_LAUNCH(ctx, kid, (mr_pass<1, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+            else if (last_fwd)
+                WFX_LAUNCH(ctx, kid, (mr_pass<0, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+            else
+                WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
         }
+        src = dst;
+        dst = (dst == A) ? B : A;
     }
-    *V_out = (cplx *)src;
+    *result = (cplx *)src;
     return 0;
+}
+
+// H = Hilbert transform of the even-length real signal x, packed: Re V[p] = H[2p], Im V[p] = H[2p-1 mod N].
+// Returns the device pointer holding V (L = n/2 complex values) in *V_out.
+int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out)
+{
+    const long long L = (long long)(n / 2);
+    mr_plan_cache *pc = nullptr;
+    WFX_TRY(mr_get_plan(ctx, L, &pc));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work, (size_t)L * sizeof(cplx)));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (size_t)L * sizeof(cplx)));
+    cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
+    cplx *mid = nullptr;
+    // the packed real input IS x viewed as complex pairs (swapped on load)
+    WFX_TRY(mr_run(ctx, pc, (const cplx *)x, A, B, 0, true, nullptr, &mid));
+    return mr_run(ctx, pc, mid, A, B, 1, true, nullptr, V_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// scipy.signal.resample (wefax.py:384) for even n0 and num with 13-smooth halves (every whole-second capture at
+// the usual rates): rfft and irfft as packed complex transforms of n0/2 and num/2 points on the passes above.
+//   Z = FFT_{n0/2}(x[2q] + i x[2q+1]);   X[k] = (Z[k] + conj Z[M-k])/2 - (i/2) e^{-2 pi i k/n0} (Z[k] - conj Z[M-k])
+//   Y = the kept bins of X (scipy's Nyquist-bin factors; irfft ignores Im Y[0], Im Y[K])
+//   W[k] = (Y[k] + conj Y[K-k]) + i e^{2 pi i k/num} (Y[k] - conj Y[K-k]);  out[2q] + i out[2q+1] = IFFT_K(W)[q] / n0
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) resample_mr_glue(const cplx *__restrict__ Z, long long n0, long long num, cplx *__restrict__ W)
+{
+    const long long M = n0 / 2, K = num / 2, nmin = n0 < num ? n0 : num, half = nmin / 2;
+    const double edge = (nmin % 2 == 0) ? (num < n0 ? 2.0 : (num > n0 ? 0.5 : 1.0)) : 1.0;
+    const double inv_n0 = 1.0 / (double)n0;
+    auto bin = [&](long long j) {                       // Y[j], j in [0, K]
+        if (j > half) return make_double2(0.0, 0.0);
+        const long long a = j % M, b = (M - j) % M;
+        const cplx zk = Z[a], zc = make_double2(Z[b].x, -Z[b].y);
+        double sn, cs;
+        sincospi(2.0 * (double)j / (double)n0, &sn, &cs);
+        const cplx dif = make_double2(zk.x - zc.x, zk.y - zc.y);
+        // -(i/2) (cs - i sn) dif = (-(sn dif.x) + cs dif.y, -(cs dif.x) - sn dif.y) / 2
+        cplx y = make_double2(0.5 * (zk.x + zc.x) + 0.5 * (cs * dif.y - sn * dif.x), 0.5 * (zk.y + zc.y) - 0.5 * (cs * dif.x + sn * dif.y));
+        if (j == half) {
+            y.x *= edge;
+            y.y *= edge;
+        }
+        if (j == 0 || j == K) y.y = 0.0;
+        return y;
+    };
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < K; k += (long long)gridDim.x * 256) {
+        const cplx yk = bin(k);
+        const cplx yr = bin(K - k);
+        const cplx yc = make_double2(yr.x, -yr.y);
+        const cplx sum = make_double2(yk.x + yc.x, yk.y + yc.y), dif = make_double2(yk.x - yc.x, yk.y - yc.y);
+        double sn, cs;
+        sincospi(2.0 * (double)k / (double)num, &sn, &cs);
+        // i (cs + i sn) dif = (-(sn dif.x) - cs dif.y, cs dif.x - sn dif.y)
+        W[k] = make_double2((sum.x - (sn * dif.x + cs * dif.y)) * inv_n0, (sum.y + (cs * dif.x - sn * dif.y)) * inv_n0);
+    }
+}
+
+bool wfx_mr_resample_supported(uint64_t n0, uint64_t num)
+{
+    if ((n0 & 1) || (num & 1) || n0 < 8 || num < 8 || n0 >= (1ull << 31) || num >= (1ull << 31)) return false;
+    return wfx_mr_supported(n0 / 2) && wfx_mr_supported(num / 2);
+}
+
+int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out)
+{
+    const long long M = (long long)(n0 / 2), K = (long long)(num / 2);
+    mr_plan_cache *p1 = nullptr, *p2 = nullptr;
+    WFX_TRY(mr_get_plan(ctx, M, &p1));
+    const size_t cap = (size_t)(M > K ? M : K) * sizeof(cplx);
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work, cap));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, cap));
+    cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
+    cplx *Z = nullptr;
+    WFX_TRY(mr_run(ctx, p1, (const cplx *)x, A, B, 0, false, nullptr, &Z));
+    cplx *Wb = (Z == A) ? B : A;
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, resample_mr_glue, dim3(wfx_stream_grid((uint64_t)K, 256)), dim3(256), (const cplx *)Z, (long long)n0,
+               (long long)num, Wb);
+    WFX_TRY(mr_get_plan(ctx, K, &p2));        // (std::map: p1 stays valid)
+    cplx *res = nullptr;
+    return mr_run(ctx, p2, Wb, A, B, 1, false, (cplx *)out, &res);
 }
