@@ -1346,16 +1346,22 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
         ok_s[i] = (i >= 1 && dev_ok(frame_samples, pk_s[i] - pk_s[i - 1])) ? 1 : 0;    // wefax.py:263-267, all gaps at once
     }
     __syncthreads();
+    if (t >= 64) return;
+    // ---- grouping (wefax.py:269-294): the regularity flags become a bit mask in scalar registers (two ballots),
+    // so the two sequential scans below run without a single LDS round trip
+    static_assert(WFX_MAX_PEAKS <= 127, "the flag mask holds 128 peaks");
+    const unsigned long long okm0 = __ballot(t < np && ok_s[t] != 0);
+    const unsigned long long okm1 = __ballot(64 + t < np && ok_s[64 + t] != 0);
     if (t != 0) return;
     s->npeaks = np;
     s->hit_limit = hit_s;
     const long long *pk = pk_s;
-    // ---- grouping (wefax.py:269-294) -----------------------------------------
+    auto okbit = [&](int i) { return (int)(((i < 64 ? okm0 >> i : okm1 >> (i - 64))) & 1ull); };
     int nclear = 0;
-    for (int i = 1; i < np - 1; ++i) nclear += ok_s[i];
+    for (int i = 1; i < np - 1; ++i) nclear += okbit(i);
     int nclosed = 0, best_start = 0, best_len = -1, g_start = 0, g_len = 0;
     for (int i = 1; i < nclear - 1; ++i) {
-        if (ok_s[i]) {
+        if (okbit(i)) {
             if (g_len == 0) g_start = i;
             ++g_len;
         } else {
