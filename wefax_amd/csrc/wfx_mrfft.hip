@@ -30,11 +30,12 @@
 
 #define MR_TILE 4096
 #define MR_MAXF 8
-#define MR_MAXPASS 4
+#define MR_MAXPASS 5
 #define MR_LO_BITS 11
 #define MR_LO (1 << MR_LO_BITS)
 
 struct mr_pass_desc {
+    int ra, rb;                 // R = ra * rb has a register-resident two-level pass (0, 0: per-prime LDS stages only)
     int R, nf, f[MR_MAXF];
     long long P, ncol, L;
     int T, log2t;
@@ -73,6 +74,18 @@ template <> struct mr_roots<13> {
     static constexpr double s[13] = {0.0, 0.4647231720437685, 0.8229838658936564, 0.992708874098054, 0.9350162426854148, 0.6631226582407952, 0.23931566428755768, -0.23931566428755743, -0.663122658240795, -0.9350162426854147, -0.992708874098054, -0.822983865893657, -0.4647231720437684};
 };
 
+template <> struct mr_roots<9> {
+    static constexpr double c[9] = {1.0, 0.766044443118978, 0.17364817766693041, -0.4999999999999998, -0.9396926207859083, -0.9396926207859084, -0.5000000000000004, 0.17364817766692997, 0.7660444431189778};
+    static constexpr double s[9] = {0.0, 0.6427876096865393, 0.984807753012208, 0.8660254037844387, 0.3420201433256689, -0.34202014332566866, -0.8660254037844384, -0.9848077530122081, -0.6427876096865396};
+};
+template <> struct mr_roots<8> {
+    static constexpr double c[8] = {1.0, 0.7071067811865476, 0.0, -0.7071067811865475, -1.0, -0.7071067811865477, 0.0, 0.7071067811865474};
+    static constexpr double s[8] = {0.0, 0.7071067811865475, 1.0, 0.7071067811865476, 0.0, -0.7071067811865475, -1.0, -0.7071067811865477};
+};
+template <> struct mr_roots<16> {
+    static constexpr double c[16] = {1.0, 0.9238795325112867, 0.7071067811865476, 0.38268343236508984, 0.0, -0.3826834323650897, -0.7071067811865475, -0.9238795325112867, -1.0, -0.9238795325112868, -0.7071067811865477, -0.38268343236509034, 0.0, 0.38268343236509, 0.7071067811865474, 0.9238795325112865};
+    static constexpr double s[16] = {0.0, 0.3826834323650898, 0.7071067811865475, 0.9238795325112867, 1.0, 0.9238795325112867, 0.7071067811865476, 0.3826834323650899, 0.0, -0.38268343236508967, -0.7071067811865475, -0.9238795325112865, -1.0, -0.9238795325112866, -0.7071067811865477, -0.3826834323650904};
+};
 // composite odd radices of the register-resident two-level passes (the conjugate-pair form holds for any odd P)
 template <> struct mr_roots<15> {
     static constexpr double c[15] = {1.0, 0.9135454576426009, 0.6691306063588582, 0.30901699437494745, -0.10452846326765333, -0.4999999999999998, -0.8090169943749473, -0.9781476007338057, -0.9781476007338057, -0.8090169943749476, -0.5000000000000004, -0.10452846326765423, 0.30901699437494723, 0.6691306063588585, 0.913545457642601};
@@ -407,20 +420,66 @@ __device__ __forceinline__ void dft25_ct(cplx *u, const double sg, PUT put)
     }
 }
 
+// N = 2, 4, 8, 16 points in registers: decimation in time, X = E[k] +- W_N^k O[k]; x is read with a compile-time stride
+template <int N>
+__device__ __forceinline__ void dft_pow2_rec(const cplx *x, int stride, cplx *X, const double sg)
+{
+    if constexpr (N == 1) {
+        X[0] = x[0];
+    } else if constexpr (N == 2) {
+        const cplx a = x[0], b = x[stride];
+        X[0] = make_double2(a.x + b.x, a.y + b.y);
+        X[1] = make_double2(a.x - b.x, a.y - b.y);
+    } else {
+        cplx E[N / 2], O[N / 2];
+        dft_pow2_rec<N / 2>(x, 2 * stride, E, sg);
+        dft_pow2_rec<N / 2>(x + stride, 2 * stride, O, sg);
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) {
+            cplx t;
+            if (k == 0)
+                t = O[0];
+            else if (4 * k == N)
+                t = make_double2(-sg * O[k].y, sg * O[k].x);          // times (0, sg): W = exp(sg i pi / 2)
+            else
+                t = mcmul(O[k], make_double2(mr_roots<16>::c[k * (16 / N)], sg * mr_roots<16>::s[k * (16 / N)]));
+            X[k] = make_double2(E[k].x + t.x, E[k].y + t.y);
+            X[k + N / 2] = make_double2(E[k].x - t.x, E[k].y - t.y);
+        }
+    }
+}
+
 template <int P, typename PUT>
 __device__ __forceinline__ void dft_any(cplx *v, const double sg, PUT put)
 {
-    if (P == 25)
+    if constexpr (P == 25) {
         dft25_ct(v, sg, put);
-    else
+    } else if constexpr (P == 2 || P == 4 || P == 8 || P == 16) {
+        cplx X[P];
+        dft_pow2_rec<P>(v, 1, X, sg);
+#pragma unroll
+        for (int q = 0; q < P; ++q) put(q, X[q]);
+    } else {
         dft_odd_inplace<P>(v, sg, put);
+    }
 }
 
-template <int RA, int RB, int LOG2T, int PF, int IN_MODE, int OUT_MODE, int INVERSE>
+// tile width (columns) and prefetch policy of a pair, shared by the kernel and the host
+constexpr int mr2_log2t(int r) { return r <= 16 ? 8 : r <= 32 ? 7 : r <= 64 ? 6 : r <= 128 ? 5 : 4; }
+constexpr bool mr2_prefetch(int ra, int rb)
+{
+    const int t = 1 << mr2_log2t(ra * rb);
+    const int na = (t * rb + 255) / 256;
+    return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) <= 140;      // registers: a tile in flight + a level-B transform
+}
+
+template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
 __global__ void __launch_bounds__(256, 2)
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
-         const cplx *__restrict__ glo, const cplx *__restrict__ ghi, int ntiles)
+         int ntiles)
 {
+    constexpr int LOG2T = mr2_log2t(RA * RB);
+    constexpr int PF = (mr2_prefetch(RA, RB) && OUT_MODE == 0) ? 1 : 0;
     constexpr int R = RA * RB, T = 1 << LOG2T;
     constexpr int NA = (T * RB + 255) / 256, NB = (T * RA + 255) / 256;
     constexpr bool inv = INVERSE != 0;
@@ -608,6 +667,23 @@ __global__ void __launch_bounds__(256) mr_fill_tables(cplx *__restrict__ lo, cpl
     }
 }
 
+// Radix pairs with a register-resident two-level pass (RA <= RB; both from {4,5,7,8,9,11,13,15,16,25}).
+// Every pair costs four kernels (inverse, forward, forward from packed reals, forward + Hilbert spectrum).
+#define WFX_MR2_PAIRS(X)                                                                                       \
+    X(16, 16) X(15, 16) X(15, 15) X(13, 16) X(13, 15) X(13, 13) X(11, 16) X(11, 15) X(11, 13) X(11, 11)        \
+    X(9, 25) X(9, 16) X(9, 15) X(9, 13) X(9, 11) X(9, 9) X(8, 25) X(8, 16) X(8, 15) X(8, 13) X(8, 11) X(8, 9) \
+    X(8, 8) X(7, 25) X(7, 16) X(7, 15) X(7, 13) X(7, 11) X(7, 9) X(7, 8) X(7, 7) X(5, 25) X(5, 16) X(5, 15)   \
+    X(5, 13) X(5, 11) X(5, 9) X(5, 8) X(5, 7) X(4, 25) X(4, 16) X(4, 15) X(4, 13)
+
+struct mr2_pair {
+    int ra, rb;
+};
+static const mr2_pair g_mr2_pairs[] = {
+#define X(a, b) {a, b},
+    WFX_MR2_PAIRS(X)
+#undef X
+};
+
 // ---- planning (host) -----------------------------------------------------------------
 struct mr_plan_host {
     long long L = 0;
@@ -618,7 +694,88 @@ struct mr_plan_host {
     size_t table_elems = 0;
 };
 
-// factor L into primes <= 13 and group them into radices <= 256; false when L is not smooth
+// prime-stage list of a radix for the per-prime passes (pairs of 2s as radix 4)
+static int mr_stage_factors(int R, int *f)
+{
+    static const int primes[] = {13, 11, 7, 5, 3};
+    int nf = 0, twos = 0;
+    for (int p : primes)
+        while (R % p == 0) {
+            f[nf++] = p;
+            R /= p;
+        }
+    while (R % 2 == 0) {
+        ++twos;
+        R /= 2;
+    }
+    for (; twos >= 2; twos -= 2) f[nf++] = 4;
+    if (twos) f[nf++] = 2;
+    return R == 1 ? nf : -1;
+}
+
+static void mr_fill_pass(mr_plan_host &pl, int i, int R, int ra, int rb, long long P, size_t &off)
+{
+    mr_pass_desc &d = pl.pass[i];
+    d.ra = ra;
+    d.rb = rb;
+    d.R = R;
+    d.nf = mr_stage_factors(R, d.f);
+    for (int k = d.nf; k < MR_MAXF; ++k) d.f[k] = 1;
+    d.P = P;
+    d.L = pl.L;
+    d.ncol = pl.L / R;
+    const int T = MR_TILE / R;
+    int t2 = 1, l2 = 0;
+    while (t2 * 2 <= T && t2 < 256) {         // power of two <= 256: cheap index arithmetic, a thread keeps its column
+        t2 *= 2;
+        ++l2;
+    }
+    d.T = t2;
+    d.log2t = l2;
+    const long long mod = P * R;
+    pl.lo_off[i] = off;
+    off += MR_LO;
+    pl.hi_off[i] = off;
+    off += (size_t)(mod >> MR_LO_BITS) + 2;
+}
+
+// relative cost of one pass over the data with a pair (measured: (7,13) 21.5, (15,15) 25, (7,25) 30 us per 115 MB)
+static double mr2_pair_cost(int ra, int rb)
+{
+    double c = 1.0;
+    if (rb == 25 || ra == 25) c += 0.25;
+    if (ra <= 5) c += 0.15;                    // many short level-A transforms: more twiddles per point
+    if (ra * rb < 64) c += 0.2;                // short rows: less work per byte of tile bookkeeping
+    return c;
+}
+
+// cheapest decomposition of L into pair radices (depth-first over the pair table); false if there is none
+static bool mr2_search(long long rem, int depth, double cost, std::vector<int> &cur, double &best_cost, std::vector<int> &best)
+{
+    if (rem == 1) {
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = cur;
+        }
+        return true;
+    }
+    if (depth == MR_MAXPASS || cost + 1.0 >= best_cost) return false;
+    bool any = false;
+    const int np = (int)(sizeof(g_mr2_pairs) / sizeof(g_mr2_pairs[0]));
+    const int start = cur.empty() ? 0 : cur.back();        // non-increasing table order: each multiset is visited once
+    for (int i = start; i < np; ++i) {
+        const long long r = (long long)g_mr2_pairs[i].ra * g_mr2_pairs[i].rb;
+        if (rem % r) continue;
+        cur.push_back(i);
+        any |= mr2_search(rem / r, depth + 1, cost + mr2_pair_cost(g_mr2_pairs[i].ra, g_mr2_pairs[i].rb), cur, best_cost, best);
+        cur.pop_back();
+    }
+    return any;
+}
+
+// Plan for a 13-smooth L.  First choice: every pass a radix pair with a register-resident kernel (fewest / cheapest
+// passes).  Otherwise: primes grouped greedily into radices <= 256 for the per-prime passes (a group that happens
+// to be a pair product still gets the pair kernel).  false when L is not 13-smooth.
 static bool mr_make_plan(long long L, mr_plan_host &pl)
 {
     static const int primes[] = {13, 11, 7, 5, 3, 2};
@@ -630,60 +787,59 @@ static bool mr_make_plan(long long L, mr_plan_host &pl)
             rem /= p;
         }
     if (rem != 1 || L < 2) return false;
-    {   // pairs of 2s become radix-4 stages (no multiplications), listed first among the small factors
-        int twos = 0;
-        std::vector<int> other;
-        for (int p : fs) (p == 2 ? ++twos : (other.push_back(p), 0));
-        fs = other;
-        for (; twos >= 2; twos -= 2) fs.push_back(4);
-        if (twos) fs.push_back(2);
-        std::sort(fs.begin(), fs.end(), [](int x, int y) { return x > y; });
-    }
-    // greedy: largest factors first, each into the smallest group that still fits
-    std::vector<std::vector<int>> groups;
-    std::vector<int> prod;
-    for (int p : fs) {
-        int best = -1;
-        for (size_t g = 0; g < groups.size(); ++g)
-            if (prod[g] * p <= 256 && (int)groups[g].size() < MR_MAXF && (best < 0 || prod[g] < prod[best])) best = (int)g;
-        if (best < 0) {
-            groups.push_back({p});
-            prod.push_back(p);
-        } else {
-            groups[best].push_back(p);
-            prod[best] *= p;
-        }
-    }
-    if ((int)groups.size() > MR_MAXPASS) return false;
     pl.L = L;
-    pl.npass = (int)groups.size();
-    long long P = 1;
     size_t off = 0;
-    for (int i = 0; i < pl.npass; ++i) {
-        mr_pass_desc &d = pl.pass[i];
-        d.R = prod[i];
-        d.nf = (int)groups[i].size();
-        // merge pairs of 2s into 4s / 8s is not needed for correctness; keep the prime stages
-        for (int k = 0; k < d.nf; ++k) d.f[k] = groups[i][k];
-        for (int k = d.nf; k < MR_MAXF; ++k) d.f[k] = 1;
-        d.P = P;
-        d.L = L;
-        d.ncol = L / d.R;
-        int T = MR_TILE / d.R;
-        int t2 = 1;
-        int l2 = 0;
-        while (t2 * 2 <= T && t2 < 256) {         // power of two <= 256: cheap index arithmetic, a thread keeps its column
-            t2 *= 2;
-            ++l2;
+    long long P = 1;
+    std::vector<int> cur, best;
+    double best_cost = 1e30;
+    if (mr2_search(L, 0, 0.0, cur, best_cost, best) && !best.empty()) {
+        // small radices first: the first pass pays an extra LDS transposition, the last forward pass the spectrum
+        std::sort(best.begin(), best.end(), [](int a, int b) {
+            return g_mr2_pairs[a].ra * g_mr2_pairs[a].rb < g_mr2_pairs[b].ra * g_mr2_pairs[b].rb;
+        });
+        pl.npass = (int)best.size();
+        for (int i = 0; i < pl.npass; ++i) {
+            const mr2_pair &pr = g_mr2_pairs[best[i]];
+            mr_fill_pass(pl, i, pr.ra * pr.rb, pr.ra, pr.rb, P, off);
+            P *= (long long)pr.ra * pr.rb;
         }
-        d.T = t2;
-        d.log2t = l2;
-        const long long mod = P * d.R;
-        pl.lo_off[i] = off;
-        off += MR_LO;
-        pl.hi_off[i] = off;
-        off += (size_t)(mod >> MR_LO_BITS) + 2;
-        P *= d.R;
+    } else {
+        {   // pairs of 2s become radix-4 stages (no multiplications), listed first among the small factors
+            int twos = 0;
+            std::vector<int> other;
+            for (int p : fs) (p == 2 ? ++twos : (other.push_back(p), 0));
+            fs = other;
+            for (; twos >= 2; twos -= 2) fs.push_back(4);
+            if (twos) fs.push_back(2);
+            std::sort(fs.begin(), fs.end(), [](int x, int y) { return x > y; });
+        }
+        // greedy: largest factors first, each into the smallest group that still fits
+        std::vector<int> prod, cnt;
+        for (int p : fs) {
+            int bi = -1;
+            for (size_t g = 0; g < prod.size(); ++g)
+                if (prod[g] * p <= 256 && cnt[g] < MR_MAXF && (bi < 0 || prod[g] < prod[bi])) bi = (int)g;
+            if (bi < 0) {
+                prod.push_back(p);
+                cnt.push_back(1);
+            } else {
+                prod[bi] *= p;
+                ++cnt[bi];
+            }
+        }
+        if ((int)prod.size() > MR_MAXPASS) return false;
+        pl.npass = (int)prod.size();
+        for (int i = 0; i < pl.npass; ++i) {
+            int ra = 0, rb = 0;
+            for (const mr2_pair &pr : g_mr2_pairs)
+                if (pr.ra * pr.rb == prod[i]) {
+                    ra = pr.ra;
+                    rb = pr.rb;
+                    break;
+                }
+            mr_fill_pass(pl, i, prod[i], ra, rb, P, off);
+            P *= prod[i];
+        }
     }
     pl.glo_off = off;
     off += MR_LO;
@@ -768,26 +924,27 @@ static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cpl
         const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
         const bool first = hilbert && dir == 0 && i == 0, last_fwd = hilbert && dir == 0 && i == np - 1;
         if (i == np - 1 && final_dst) dst = final_dst;
-        const int mode = dir == 1 ? 2 : (first && last_fwd) ? 3 : first ? 1 : last_fwd ? 4 : 0;
-        // register-resident two-level passes for the radix pairs that have one (mr2_pass); per-prime LDS stages otherwise
-        const cplx *glo = tb + pc->h.glo_off, *ghi = tb + pc->h.ghi_off;
+        // register-resident two-level pass when the radix is a pair (mr2_pass); per-prime LDS stages otherwise
         bool done = false;
-#define WFX_MR2_TRY(RA_, RB_, LT_, PF_)                                                                                             \
-    if (!done && pc->use_mr2 && d.R == (RA_) * (RB_) && !(first && last_fwd)) {                                                \
-        const int nt = (int)((d.ncol + (1 << (LT_)) - 1) >> (LT_));                                                            \
-        const unsigned g2 = (unsigned)(nt < 512 ? nt : 512);                                                                   \
-        switch (mode) {                                                                                                        \
-        case 2: WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, LT_, PF_, 0, 0, 1>), dim3(g2), dim3(256), src, dst, d, lo, hi, glo, ghi, nt); break; \
-        case 1: WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, LT_, PF_, 1, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, glo, ghi, nt); break; \
-        case 4: WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, LT_, 0, 0, 1, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, glo, ghi, nt); break; \
-        default: WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, LT_, PF_, 0, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, glo, ghi, nt); break; \
-        }                                                                                                                      \
-        done = true;                                                                                                           \
+        if (pc->use_mr2 && d.ra > 0 && !(first && last_fwd)) {
+            const int lt = mr2_log2t(d.R);
+            const int nt = (int)((d.ncol + (1 << lt) - 1) >> lt);
+            const unsigned g2 = (unsigned)(nt < 512 ? nt : 512);
+#define X(RA_, RB_)                                                                                                                   \
+    if (!done && d.ra == (RA_) && d.rb == (RB_)) {                                                                                    \
+        if (dir == 1)                                                                                                                 \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else if (last_fwd)                                                                                                            \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else if (first)                                                                                                               \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else                                                                                                                          \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        done = true;                                                                                                                  \
     }
-        WFX_MR2_TRY(15, 15, 4, 1)
-        WFX_MR2_TRY(7, 25, 4, 0)
-        WFX_MR2_TRY(7, 13, 5, 1)
-#undef WFX_MR2_TRY
+            WFX_MR2_PAIRS(X)
+#undef X
+        }
         if (!done) {
             const int ntiles = (int)((d.ncol + d.T - 1) / d.T);
             const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);       // 2 persistent workgroups per CU
