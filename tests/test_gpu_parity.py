@@ -165,6 +165,30 @@ def test_two_level_register_passes(ctx, n):
     assert _rel(a, ctx.analytic_env(x, nat.WFX_HILBERT_FFT_POW2)) <= FLOAT_TOL
 
 
+def _smooth_lengths(count, seed, lo, hi):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        n = 2
+        while n < lo:
+            n *= int(rng.choice([2, 2, 3, 3, 5, 5, 7, 7, 11, 13]))
+        if n <= hi and n not in out:
+            out.append(n)
+    return out
+
+
+@pytest.mark.parametrize("n", _smooth_lengths(36, 7, 20000, 3000000) + _smooth_lengths(6, 11, 1500000, 12000000))
+def test_random_smooth_lengths(ctx, n):
+    """Random 13-smooth lengths: whatever decomposition into radix pairs (or prime groups) the planner picks, the
+    analytic envelope equals the oracle's FFT form and the padded power-of-two form."""
+    from oracle import wefax_oracle as wo
+    from wefax_amd import _native as nat
+    x = _signal(n, n % 1000)
+    a = ctx.analytic_env(x)
+    assert _rel(a, wo.demodulate(x)) <= FLOAT_TOL
+    assert _rel(a, ctx.analytic_env(x, nat.WFX_HILBERT_FFT_POW2)) <= FLOAT_TOL
+
+
 def test_analytic_envelope_fir_mode_converges(ctx):
     """The FIR kernel approaches the exact operator as taps grow (clean narrow-band input)."""
     from oracle import wefax_oracle as wo
