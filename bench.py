@@ -56,6 +56,9 @@ def parse():
                          "1.536 MS/s int16 IQ stream of --iq-seconds, synthesised in HBM, time-domain front end + halo-local "
                          "path, sharded by sample range over the ranks")
     ap.add_argument("--iq-seconds", type=float, default=3600.0, help="length of the IQ stream (BASELINE: 60 minutes)")
+    ap.add_argument("--iq-rest", choices=["auto", "exact", "fir"], default="auto",
+                    help="what follows the time-domain front end: the exact fused path (one GPU only; default there) or the "
+                         "halo-local FIR-Hilbert path that shards by sample range (default for N > 1)")
     ap.add_argument("--batch", type=int, default=1,
                     help="captures decoded concurrently per GPU, one native context (= HIP stream) each; "
                          "BASELINE configs[4] uses 8 per GPU with mixed 120/240 LPM, IOC576/288 members")
@@ -198,14 +201,27 @@ def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
         th.cuda.synchronize()
         return keep["raw"].data_ptr(), hi - lo
 
+    exact_rest = (args.iq_rest == "exact") or (args.iq_rest == "auto" and world == 1 and not use_dist)
+    if exact_rest and (world > 1 or use_dist):
+        raise SystemExit("--iq-rest exact is a single-GPU form (the exact path is global per capture)")
     t_syn = time.perf_counter()
-    dec = sharded.ShardedDecoder(sharded.HipStages(ctx), None, n, world, rank, 120, 4095, frontend=fe, n_in_total=n0,
-                                 in_kind=nat.WFX_IN_I16_STEREO, raw_loader=raw_loader)
+    if exact_rest:
+        dec = sharded.FrontEndExactDecoder(ctx, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,
+                                           raw_loader=raw_loader)
+        exchange = None
+        own_out = n
+    else:
+        dec = sharded.ShardedDecoder(sharded.HipStages(ctx), None, n, world, rank, 120, 4095, frontend=fe, n_in_total=n0,
+                                     in_kind=nat.WFX_IN_I16_STEREO, raw_loader=raw_loader)
+        p = dec.plan
+        exchange = ImageExchange(dist, th, 4 * dec.width * ((p.o1 - p.o0) // dec.width + 4), dev) if use_dist else None
+        own_out = p.o1 - p.o0
     t_syn = time.perf_counter() - t_syn
-    p = dec.plan
-    exchange = ImageExchange(dist, th, 4 * dec.width * ((p.o1 - p.o0) // dec.width + 4), dev) if use_dist else None
 
     def step():
+        if exact_rest:
+            dec.run()                          # asynchronous: front end + fused exact decode, image stays in HBM
+            return None
         return dec.run(comm, exchange, keep_on_device=True)      # the image ends resident in HBM (one rank) / gathered by RCCL
 
     def sync_all():
@@ -240,7 +256,7 @@ def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
                    for k, v in prof.items()}
         dom = max(prof.items(), key=lambda kv: kv[1][1])
         ia, ib = dec.chain[0][2]
-        alg_bytes = (ib - ia) * 4 + 4 * (p.o1 - p.o0)           # N0*B_in + 4*N, this rank's share
+        alg_bytes = (ib - ia) * 4 + 4 * own_out                 # N0*B_in + 4*N, this rank's share
         avg_s = dom[1][1] / dom[1][0] / 1e3
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic_iq.json")      # measured on the full 3600 s stream, one rank
@@ -273,18 +289,24 @@ def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
                "sample": f"a self-contained {s_secs:.0f} s capture of the same stream format ({xs.shape[0]} IQ frames), "
                          "reference-faithful path (stereo merge + FFT resample), one run, read from a wav file"}
     if rank == 0:
-        sync = res[1]
+        if exact_rest:
+            info = dec.result()
+            sync = {"start_frame": int(info.start_frame), "height": int(info.height)}
+        else:
+            sync = res[1]
         print(json.dumps({
             "metric": "Msamples/s demod->pixel", "value": round(n0 * args.steps / dt / 1e6, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 stencils / f64 elsewhere",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 front end / f64 elsewhere",
             "data": "synthetic",
             "config": {"workload": f"ONE synthetic 1.536 MS/s int16 IQ stream of {secs:.0f} s (BASELINE configs[3]): {n0} IQ frames "
                                    f"-> {n} samples at 11 025 Hz, 120 LPM, AWGN sigma {args.noise} FS, synthesised in HBM",
-                       "front_end": fe.describe(), "hilbert": "fir4095", "start_frame": sync["start_frame"],
+                       "front_end": fe.describe(), "hilbert": "exact (fft)" if exact_rest else "fir4095",
+                       "start_frame": sync["start_frame"],
                        "image": [dec.width, 4 * sync["height"]], "synthesis_s": round(t_syn, 2),
-                       "parallelism": f"sample-range sharding over {world} GPU(s): halo recompute, 6 histogram all-reduces, "
-                                      "1 broadcast, 1 RCCL image gather per step"},
+                       "parallelism": ("one GPU: time-domain front end + the exact fused path on its output" if exact_rest else
+                                       f"sample-range sharding over {world} GPU(s): halo recompute, 6 histogram all-reduces, "
+                                       "1 broadcast, 1 RCCL image gather per step")},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}))
     if use_dist:
         dist.barrier()

@@ -157,6 +157,9 @@ typedef enum {
 /* copy the capture into HBM (not part of the timed region) */
 int wfx_decode_upload(wfx_ctx *ctx, const void *host_in, const wfx_decode_params *p);
 /* enqueue every kernel of the path on the context's stream (asynchronous) */
+/* like wfx_decode_upload, but the capture already lives in DEVICE memory owned by the caller (e.g. the output of the
+ * time-domain front end): nothing is copied, the pointer must stay valid while decodes run */
+int wfx_decode_attach(wfx_ctx *ctx, const void *dev_in, const wfx_decode_params *p);
 int wfx_decode_run(wfx_ctx *ctx);
 /* wait and read back the scalars */
 int wfx_decode_result(wfx_ctx *ctx, wfx_decode_info *info);

@@ -305,6 +305,26 @@ def test_sharded_decode_with_front_end_gpu(ctx, fs, iq, noise):
 
 
 @pytest.mark.gpu
+def test_front_end_plus_exact_rest_gpu(ctx):
+    """One GPU: time-domain front end + the exact rest of the path (FrontEndExactDecoder).  Only the front end's pass
+    band separates it from the reference: closer to the oracle than the halo-local (FIR Hilbert) form."""
+    fs = 1536000
+    x = _capture(fs, 0.05, seed=0, lpm=120, seconds=40.0, iq=True)
+    fe = pp.FrontEnd(fs)
+    dec = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=120)
+    dec.run()
+    info = dec.result()
+    ref = _oracle(x, fs, 120)
+    assert ref["start_frame"] == info.start_frame and dec.n == 441000
+    img = dec.fetch("image")
+    mx, w1, mean = _image_stats(img, ref["image"])
+    smx, sw1, smean = _image_stats(dec.fetch("digitalized"), ref["digitalized"])
+    print(f"front end + exact rest, 1.536 MS/s IQ 40 s: image max|d|={mx} within1={w1:.4f} mean|d|={mean:.3f}; stream mean|d|={smean:.3f}")
+    assert img.shape == ref["image"].shape and mean < 1.0 and w1 > 0.9
+    dec.close()
+
+
+@pytest.mark.gpu
 def test_iq_stream_1536k_against_oracle_gpu(ctx):
     """BASELINE configs[3] at a length the oracle finishes in seconds: 20 s of 1.536 MS/s int16 IQ through the
     time-domain front end + halo-local path on one rank, against the oracle's reference-faithful decode."""

@@ -24,7 +24,7 @@ SYMBOLS = [
     "wfx_device_count", "wfx_create", "wfx_destroy", "wfx_last_error", "wfx_sync",
     "wfx_version", "wfx_merge_channels", "wfx_resample", "wfx_notch_filtfilt",
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
-    "wfx_sync_peaks", "wfx_lines_to_image", "wfx_decode_upload", "wfx_decode_run",
+    "wfx_sync_peaks", "wfx_lines_to_image", "wfx_decode_upload", "wfx_decode_attach", "wfx_decode_run",
     "wfx_decode_result", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
@@ -118,6 +118,7 @@ def load():
     lib.wfx_decode_fetch.argtypes = [vp, i, vp, sz]
     lib.wfx_decode_device_ptr.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz)]
     lib.wfx_decode_copy_to_device.argtypes = [vp, i, vp, sz, C.POINTER(sz)]
+    lib.wfx_decode_attach.argtypes = [vp, vp, C.POINTER(DecodeParams)]
     lib.wfx_stream_handle.argtypes = [vp, C.POINTER(vp)]
     lib.wfx_decode_export_async.argtypes = [vp, i, vp, sz]
     lib.wfx_dev_malloc.argtypes = [vp, sz, C.POINTER(vp)]
@@ -305,6 +306,10 @@ class Context:
         out = np.empty(shape, dtype=dtype)
         self._check(self.lib.wfx_dev_download(self.h, _ptr(out), C.c_void_p(ptr), out.nbytes))
         return out
+
+    def decode_attach(self, dev_ptr: int, params: "DecodeParams"):
+        """Fused decode of a capture that already sits in device memory (caller-owned; nothing is copied)."""
+        self._check(self.lib.wfx_decode_attach(self.h, C.c_void_p(dev_ptr), C.byref(params)))
 
     def stream_handle(self) -> int:
         """The context's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""

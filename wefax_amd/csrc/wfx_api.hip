@@ -246,10 +246,23 @@ int wfx_decode_upload(wfx_ctx *ctx, const void *host_in, const wfx_decode_params
     ctx->dp = *p;
     ctx->have_input = false;
     ctx->ran = false;
+    ctx->ext_in = nullptr;
     const size_t nb = in_bytes(p);
     WFX_TRY(wfx_reserve(ctx, ctx->b_in, nb + 64));
     WFX_TRY(h2d(ctx, ctx->b_in.p, host_in, nb));
     WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_input = true;
+    return 0;
+}
+
+int wfx_decode_attach(wfx_ctx *ctx, const void *dev_in, const wfx_decode_params *p)
+{
+    CHECK_CTX(ctx);
+    if (!dev_in || !p) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    WFX_TRY(check_params(ctx, p));
+    ctx->dp = *p;
+    ctx->ran = false;
+    ctx->ext_in = dev_in;
     ctx->have_input = true;
     return 0;
 }
@@ -271,7 +284,7 @@ int wfx_decode_run(wfx_ctx *ctx)
     wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
     WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
 
-    const void *cur = ctx->b_in.p;
+    const void *cur = ctx->ext_in ? ctx->ext_in : ctx->b_in.p;      // caller-owned device input (wfx_decode_attach) or the uploaded copy
     int cur_kind = p.in_kind;
     if (p.in_kind == WFX_IN_I16_STEREO) {
         WFX_TRY(wfx_reserve(ctx, ctx->b_x, n0 * 8));

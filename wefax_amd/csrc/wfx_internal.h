@@ -88,6 +88,7 @@ struct wfx_ctx {
     wfx_decode_params dp{};
     bool have_input = false;
     bool ran = false;
+    const void *ext_in = nullptr;           // wfx_decode_attach: the capture lives in caller-owned device memory
     wfx_decode_info *h_info = nullptr;      // pinned
     wfx_dev_scalars *h_scal = nullptr;      // pinned mirror
 

@@ -146,9 +146,10 @@ class HipStages:
         self.p_hist = self._alloc(4 * SEL_BINS * 4)
         self.ctx.dev_upload(self.p_x, np.ascontiguousarray(xe, dtype=np.int16))
 
-    def load_raw(self, raw, in_kind: int, nl: int):
+    def load_raw(self, raw, in_kind: int, nl: int, front_end_only: bool = False):
         """Oversampled input of the time-domain front end: ``raw`` is a host array (int16 [n] or [n, 2]) or a
-        (device pointer, frames) pair that stays owned by the caller; ``nl`` = samples of the 11 025 Hz slice."""
+        (device pointer, frames) pair that stays owned by the caller; ``nl`` = samples of the 11 025 Hz slice.
+        ``front_end_only``: no buffers for the halo-local stages behind it."""
         self.nl, self.in_kind = nl, in_kind
         if isinstance(raw, tuple):
             self.p_raw, self.n_raw = int(raw[0]), int(raw[1])
@@ -159,10 +160,12 @@ class HipStages:
             self.ctx.dev_upload(self.p_raw, raw)
         self.p_x = self._alloc(8 * nl)                 # float64 audio at 11 025 Hz
         self.x_f64 = True
+        self.p_stage = {}
+        if front_end_only:
+            return
         self.p_af, self.p_er, self.p_em = self._alloc(8 * nl), self._alloc(8 * nl), self._alloc(8 * nl)
         self.p_dq = self._alloc(nl + 64)
         self.p_hist = self._alloc(4 * SEL_BINS * 4)
-        self.p_stage = {}
 
     def front_end(self, chain):
         """Run the stage chain of ``polyphase.FrontEnd.chain``: raw slice -> float64 audio of the slice."""
@@ -234,6 +237,41 @@ class HipStages:
         if what == "audio":         # output of the front end (before the notch)
             return self.ctx.dev_download(self.p_x + 8 * lo, (hi - lo,), np.float64)
         return self.ctx.dev_download(self.p_dq + lo, (hi - lo,), np.uint8)
+
+
+class FrontEndExactDecoder:
+    """ONE GPU, oversampled capture: the time-domain front end (polyphase.FrontEnd, halo-local stencils) followed by
+    the EXACT rest of the path -- notch filtfilt, FFT Hilbert, global percentiles, sync search, bicubic image: the fused
+    decode of ``wefax.DecodeJob`` attached to the front end's output in HBM.  Differs from the reference only by the
+    front end's pass band (polyphase.py); faster than the halo-local form, which is what several GPUs need."""
+
+    def __init__(self, ctx, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None):
+        from .wefax import DecodeJob
+        n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
+        self.n = frontend.n_out(n_in_total)
+        self.chain = frontend.chain(0, self.n)
+        ia, ib = self.chain[0][2]
+        raw = raw_loader(ia, ib) if raw_loader is not None else np.asarray(x)[np.arange(ia, ib) % n_in_total]
+        if in_kind is None:
+            in_kind = 1 if (not isinstance(raw, tuple) and raw.ndim == 2) else 0
+        self.st = HipStages(ctx)
+        self.st.load_raw(raw, in_kind, self.n, front_end_only=True)
+        self.job = DecodeJob.from_device(ctx, self.st.p_x, self.n, lines_per_minute)
+        self.width = self.job.width
+
+    def run(self):
+        """Enqueue front end + fused decode (asynchronous)."""
+        self.st.front_end(self.chain)
+        self.job.run()
+
+    def result(self):
+        return self.job.result()
+
+    def fetch(self, what: str):
+        return self.job.fetch(what)
+
+    def close(self):
+        self.st.close()
 
 
 class ShardedDecoder:

@@ -51,7 +51,12 @@ class DecodeJob:
         else:
             data = data.astype(np.float64)
             kind = nat.WFX_IN_F64_MONO
-        n0 = int(data.shape[0])
+        self._configure(kind, int(data.shape[0]), sample_rate, notch, hilbert_mode, fir_taps)
+        ctx.decode_upload(data, self.params)
+        self.info = None
+
+    def _configure(self, kind, n0, sample_rate, notch, hilbert_mode, fir_taps):
+        """The scalar arithmetic of the reference (lengths, notch, percentile ranks, sync constants) -> self.params."""
         self.input_length = n0 / sample_rate                               # wefax.py:357
         self.resampled = sample_rate != hp.TARGET_RATE                     # wefax.py:60
         n = int(hp.TARGET_RATE * self.input_length) if self.resampled else n0   # wefax.py:384
@@ -77,8 +82,21 @@ class DecodeJob:
         p.width = int(self.frame_len * self.sample_rate)                   # wefax.py:298
         self.params = p
         self.width = p.width
-        ctx.decode_upload(data, p)
-        self.info = None
+
+    @classmethod
+    def from_device(cls, ctx: nat.Context, dev_ptr: int, n: int, lines_per_minute: int = 120, notch=hp.DEFAULT_NOTCH,
+                    hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS):
+        """Decode ``n`` float64 samples at 11 025 Hz that already sit in device memory (e.g. the output of the
+        time-domain front end, wefax_amd/polyphase.py): the same fused path, nothing uploaded.  The memory stays owned
+        by the caller and must outlive the job."""
+        job = object.__new__(cls)
+        job.ctx = ctx
+        job.frame_len = 1 / (lines_per_minute / 60)
+        job.merged_on_host = False
+        job._configure(nat.WFX_IN_F64_MONO, int(n), hp.TARGET_RATE, notch, hilbert_mode, fir_taps)
+        ctx.decode_attach(int(dev_ptr), job.params)
+        job.info = None
+        return job
 
     def run(self):
         """Enqueue the whole path (asynchronous)."""
