@@ -188,8 +188,13 @@ def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
     secs = float(args.iq_seconds)
     kw = dict(start_tone_s=5.0, phasing_lines=60, image_lines=int((secs - 15.0) / 0.5) - 60, stop_tone_s=5.0, black_tail_s=5.0)
     n0 = synth_device.capture_frames(float(fs), **kw)
-    fe = polyphase.FrontEnd(fs)
-    n = fe.n_out(n0)
+    exact_rest = (args.iq_rest == "exact") or (args.iq_rest == "auto" and world == 1 and not use_dist)
+    if exact_rest and (world > 1 or use_dist):
+        raise SystemExit("--iq-rest exact is a single-GPU form (the exact path is global per capture)")
+    # one GPU: the stencils stop at 22 050 Hz and the exact FFT resampler takes the last factor of two (the reference's
+    # own brick wall); several GPUs: the halo-local chain down to 11 025 Hz
+    fe = polyphase.FrontEnd(fs, stop_at_2x=exact_rest)
+    n = fe.n_out(n0) // (2 if exact_rest else 1)
     dev = th.device("cuda", local_rank)
     th.cuda.set_device(local_rank)
     ctx = nat.Context(local_rank)
@@ -201,9 +206,6 @@ def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
         th.cuda.synchronize()
         return keep["raw"].data_ptr(), hi - lo
 
-    exact_rest = (args.iq_rest == "exact") or (args.iq_rest == "auto" and world == 1 and not use_dist)
-    if exact_rest and (world > 1 or use_dist):
-        raise SystemExit("--iq-rest exact is a single-GPU form (the exact path is global per capture)")
     t_syn = time.perf_counter()
     if exact_rest:
         dec = sharded.FrontEndExactDecoder(ctx, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,
@@ -301,7 +303,8 @@ def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
             "data": "synthetic",
             "config": {"workload": f"ONE synthetic 1.536 MS/s int16 IQ stream of {secs:.0f} s (BASELINE configs[3]): {n0} IQ frames "
                                    f"-> {n} samples at 11 025 Hz, 120 LPM, AWGN sigma {args.noise} FS, synthesised in HBM",
-                       "front_end": fe.describe(), "hilbert": "exact (fft)" if exact_rest else "fir4095",
+                       "front_end": fe.describe() + (" -> exact FFT resample /2" if exact_rest else ""),
+                       "hilbert": "exact (fft)" if exact_rest else "fir4095",
                        "start_frame": sync["start_frame"],
                        "image": [dec.width, 4 * sync["height"]], "synthesis_s": round(t_syn, 2),
                        "parallelism": ("one GPU: time-domain front end + the exact fused path on its output" if exact_rest else

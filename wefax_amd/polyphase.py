@@ -98,10 +98,15 @@ class Rational:
 class FrontEnd:
     """Stage chain from ``fs_in`` to 11 025 Hz and the index bookkeeping around it."""
 
-    def __init__(self, fs_in: int, att_db: float = 90.0, pass_hz: float = 5300.0):
+    def __init__(self, fs_in: int, att_db: float = 90.0, pass_hz: float = 5300.0, stop_at_2x: bool = False):
         """``pass_hz``: edge of the flat pass band of the last stage (its stop band starts at 5512.5 Hz): 5300 Hz
         costs 595 taps at 22.05 kHz.  What lies between ``pass_hz`` and 5512.5 Hz is what the reference keeps and
-        this front end drops (tests/test_polyphase.py prints the resulting error figures)."""
+        this front end drops (tests/test_polyphase.py prints the resulting error figures).
+
+        ``stop_at_2x``: leave the sharp last stage out and deliver 22 050 Hz (``n_out`` = 2 x the reference's sample
+        count): on ONE GPU the exact FFT resampler then takes the last factor of two, i.e. the reference's own brick
+        wall at 5512.5 Hz, and only the wide, flat filters of the earlier stages separate the result from it."""
+        self.stop_at_2x = bool(stop_at_2x)
         if int(fs_in) != fs_in or fs_in < 4 * TARGET_RATE:
             raise ValueError(f"the time-domain front end needs an integer rate >= 44100 Hz, not {fs_in}; use the exact FFT resampler")
         self.fs_in = int(fs_in)
@@ -122,11 +127,14 @@ class FrontEnd:
         # the last /4 in two halves: a short filter brings 44.1 kHz to 22.05 kHz (its transition band may be wide: only
         # what aliases into 0..5512.5 Hz matters), so the sharp filter runs at half the rate with half the taps
         self.stages.append(Decimate(mid, 2, NYQ, float(mid / 2) - NYQ, att_db))
-        self.stages.append(Decimate(mid / 2, 2, pass_hz, NYQ, att_db))
+        if not self.stop_at_2x:
+            self.stages.append(Decimate(mid / 2, 2, pass_hz, NYQ, att_db))
 
     def n_out(self, n_in: int) -> int:
-        """wefax.py:384: num = int(11025 * length), length = n / sample_rate."""
-        return int(TARGET_RATE * (n_in / self.fs_in))
+        """Samples this front end delivers: wefax.py:384 num = int(11025 * length), length = n / sample_rate
+        (twice that at 22 050 Hz with ``stop_at_2x``)."""
+        n = int(TARGET_RATE * (n_in / self.fs_in))
+        return 2 * n if self.stop_at_2x else n
 
     def chain(self, lo: int, hi: int):
         """Index ranges per stage for outputs [lo, hi) at 11 025 Hz: list of (stage, out range,

@@ -248,15 +248,18 @@ class FrontEndExactDecoder:
     def __init__(self, ctx, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None):
         from .wefax import DecodeJob
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
-        self.n = frontend.n_out(n_in_total)
-        self.chain = frontend.chain(0, self.n)
+        n_fe = frontend.n_out(n_in_total)                   # at 11 025 Hz, or at 22 050 Hz (FrontEnd(stop_at_2x=True))
+        rate = 2 * hp.TARGET_RATE if frontend.stop_at_2x else hp.TARGET_RATE
+        self.n = n_fe // 2 if frontend.stop_at_2x else n_fe
+        self.chain = frontend.chain(0, n_fe)
         ia, ib = self.chain[0][2]
         raw = raw_loader(ia, ib) if raw_loader is not None else np.asarray(x)[np.arange(ia, ib) % n_in_total]
         if in_kind is None:
             in_kind = 1 if (not isinstance(raw, tuple) and raw.ndim == 2) else 0
         self.st = HipStages(ctx)
-        self.st.load_raw(raw, in_kind, self.n, front_end_only=True)
-        self.job = DecodeJob.from_device(ctx, self.st.p_x, self.n, lines_per_minute)
+        self.st.load_raw(raw, in_kind, n_fe, front_end_only=True)
+        self.job = DecodeJob.from_device(ctx, self.st.p_x, n_fe, lines_per_minute, sample_rate=rate)
+        assert self.job.n == self.n
         self.width = self.job.width
 
     def run(self):

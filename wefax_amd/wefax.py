@@ -85,15 +85,15 @@ class DecodeJob:
 
     @classmethod
     def from_device(cls, ctx: nat.Context, dev_ptr: int, n: int, lines_per_minute: int = 120, notch=hp.DEFAULT_NOTCH,
-                    hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS):
-        """Decode ``n`` float64 samples at 11 025 Hz that already sit in device memory (e.g. the output of the
-        time-domain front end, wefax_amd/polyphase.py): the same fused path, nothing uploaded.  The memory stays owned
-        by the caller and must outlive the job."""
+                    hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS, sample_rate: int = hp.TARGET_RATE):
+        """Decode ``n`` float64 samples at ``sample_rate`` (11 025 Hz, or a rate the exact resampler brings there) that
+        already sit in device memory (e.g. the output of the time-domain front end, wefax_amd/polyphase.py): the same
+        fused path, nothing uploaded.  The memory stays owned by the caller and must outlive the job."""
         job = object.__new__(cls)
         job.ctx = ctx
         job.frame_len = 1 / (lines_per_minute / 60)
         job.merged_on_host = False
-        job._configure(nat.WFX_IN_F64_MONO, int(n), hp.TARGET_RATE, notch, hilbert_mode, fir_taps)
+        job._configure(nat.WFX_IN_F64_MONO, int(n), sample_rate, notch, hilbert_mode, fir_taps)
         ctx.decode_attach(int(dev_ptr), job.params)
         job.info = None
         return job
