@@ -52,7 +52,8 @@ python tools/e2e.py > "$OUT/e2e_c2.json" 2>> "$OUT/bench.err"
 # BASELINE configs[3]: the 1.536 MS/s IQ stream.  Exact path on 30 s, halo-local path on the whole 60 minutes.
 python tools/run_config.py c4 --seconds 30 --oracle > "$OUT/c4_exact_30s.json" 2>> "$OUT/bench.err"
 python bench.py --workload iq > "$OUT/bench_iq_3600s.json" 2>> "$OUT/bench.err"
-python bench.py --workload iq --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s.json" 2>> "$OUT/bench.err"
+python bench.py --workload iq --iq-rest fir --no-cpu > "$OUT/bench_iq_3600s_halo_local.json" 2>> "$OUT/bench.err"
+python bench.py --workload iq --iq-rest fir --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s.json" 2>> "$OUT/bench.err"
 WFX_BENCH_FORCE_DIST=1 python bench.py --workload iq --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s_rccl1.json" 2>> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_iq" -o run -- python3 bench.py --workload iq --steps 5 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
 python tools/kstats.py "$OUT/trace_iq" "decimate|rational|fir_hilbert|select_|notch|median|image|quantise|sync" > "$OUT/kernel_stats_iq.txt"
