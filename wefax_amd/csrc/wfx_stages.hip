@@ -981,23 +981,24 @@ __device__ __forceinline__ int wave_min_i32(int v)
 
 // the same reductions over each 32-lane half of the wave (lanes 0..31 -> lo, 32..63 -> hi): five DPP steps,
 // the last one (row_bcast15 into rows 1 and 3) leaves the results in lanes 31 and 63
+// (written as v_max/v_min with the DPP modifier on the instruction itself: the builtin form compiles to mov + mov_dpp + op)
+#define WFX_DPP_RED(OP, v)                                                                                    \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"           \
+                 "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"           \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"               \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                    \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                  \
+                 "s_nop 1"                                                                                    \
+                 : "+v"(v))
 __device__ __forceinline__ void half_max_i32(int v, int &lo, int &hi)
 {
-    v = max(v, WFX_DPP(v, 0xB1, 0xf));
-    v = max(v, WFX_DPP(v, 0x4E, 0xf));
-    v = max(v, WFX_DPP(v, 0x141, 0xf));
-    v = max(v, WFX_DPP(v, 0x140, 0xf));
-    v = max(v, WFX_DPP(v, 0x142, 0xa));
+    WFX_DPP_RED("v_max_i32_dpp", v);
     lo = __builtin_amdgcn_readlane(v, 31);
     hi = __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ void half_min_i32(int v, int &lo, int &hi)
 {
-    v = min(v, WFX_DPP(v, 0xB1, 0xf));
-    v = min(v, WFX_DPP(v, 0x4E, 0xf));
-    v = min(v, WFX_DPP(v, 0x141, 0xf));
-    v = min(v, WFX_DPP(v, 0x140, 0xf));
-    v = min(v, WFX_DPP(v, 0x142, 0xa));
+    WFX_DPP_RED("v_min_i32_dpp", v);
     lo = __builtin_amdgcn_readlane(v, 31);
     hi = __builtin_amdgcn_readlane(v, 63);
 }
@@ -1233,6 +1234,12 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
             };
             while (i < cnt) {
                 PICK_STAT(++n_ops;)
+                // the scan state is wave-uniform: pin it to scalar registers so that the branches below are s_cbranch on SCC,
+                // not exec-mask manipulation
+                i = __builtin_amdgcn_readfirstlane(i);
+                rpos = __builtin_amdgcn_readfirstlane(rpos);
+                val = __builtin_amdgcn_readfirstlane(val);
+                np = __builtin_amdgcn_readfirstlane(np);
                 // Steady state of the reference's scan is three dependent steps per peak: "nothing greater in the rest of
                 // this peak's window" -> "a new peak starts at rpos + mind + 1" -> "first maximum of ITS window".  The second
                 // and third do not depend on the outcome of the first, only on it being negative (which it almost always
@@ -1247,7 +1254,7 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                     const int b_lo = li >> 6, b_hi = ll >> 6;
                     const int jh0 = (b_lo << 6) + hl, jh1 = jh0 + 32, jt0 = (b_hi << 6) + hl, jt1 = jt0 + 32;
                     const int b1 = b_lo + 1 + hl, b2 = b1 + 32, b3 = b2 + 32;
-                    const int vb = cs[sp];
+                    const int vb_l = cs[sp];                  // (issued with the other reads, used after the reductions)
                     const int ch0 = cs[jh0], ch1 = cs[jh1], ct0 = cs[jt0], ct1 = cs[jt1];
                     const int2 s1 = sm2[b1], s2 = sm2[b2], s3 = sm2[b3];
                     const bool vh0 = (jh0 >= li) & (jh0 <= ll);
@@ -1270,6 +1277,7 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                     const bool tt1 = (b_hi > b_lo) & (jt1 <= ll) & (ct1 > c);
                     c = tt1 ? ct1 : c;
                     ci = tt1 ? jt1 : ci;
+                    const int vb = __builtin_amdgcn_readfirstlane(vb_l);
                     int bca, bcb;
                     half_max_i32(c, bca, bcb);
                     // smallest index among the lanes of a half that hold its maximum
@@ -1287,7 +1295,7 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                     }
                     ++np;
                     rpos = sp;
-                    val = __builtin_amdgcn_readfirstlane(vb);
+                    val = vb;
                     if (bcb > val) {
                         rpos = fb;
                         val = bcb;
