@@ -56,7 +56,7 @@ python bench.py --workload iq --iq-rest fir --no-cpu > "$OUT/bench_iq_3600s_halo
 python bench.py --workload iq --iq-rest fir --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s.json" 2>> "$OUT/bench.err"
 WFX_BENCH_FORCE_DIST=1 python bench.py --workload iq --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s_rccl1.json" 2>> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_iq" -o run -- python3 bench.py --workload iq --steps 5 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
-python tools/kstats.py "$OUT/trace_iq" "decimate|rational|fir_hilbert|select_|notch|median|image|quantise|sync" > "$OUT/kernel_stats_iq.txt"
+python tools/kstats.py "$OUT/trace_iq" "decimate|rational|fir_hilbert|select_|notch|median|image|quantise|sync|mr2_pass|mr_pass|resample" > "$OUT/kernel_stats_iq.txt"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
 python tools/pmc_summary.py "$OUT/pmc_fetch_iq" "$OUT/pmc_write_iq" "$OUT/pmc_traffic_iq.json" > /dev/null 2>&1
