@@ -107,6 +107,13 @@ int wfx_sync_peaks(wfx_ctx *ctx, const uint8_t *d, size_t n, int n1, int n0,
 int wfx_lines_to_image(wfx_ctx *ctx, const uint8_t *d, size_t n, size_t start,
                        int w, uint8_t *img);
 
+/* ---- live path, one audio packet: data_packet.py:408-464 DataPacket.__process_samples ----
+ * notch filtfilt with b/a designed at the packet's own sample rate (:420-434), |hilbert| + medfilt 3 (:436-448),
+ * per-packet np.percentile(., (0.5, 99.5)) (ranks / lerp weights from the host), rint(255 (x - low) / (delta + 1e-6)),
+ * clip (:450-464).  samples: WFX_IN_I16_MONO or WFX_IN_F64_MONO, host memory; out: n bytes; low / high optional. */
+int wfx_packet_process(wfx_ctx *ctx, const void *samples, int in_kind, size_t n, const double b[3], const double a[3],
+                       const uint64_t ranks[4], double gamma_lo, double gamma_hi, uint8_t *out, double *low, double *high);
+
 /* ---- fused whole path: input resident in HBM -> image resident in HBM --- */
 
 typedef struct {

@@ -473,6 +473,36 @@ def lines_to_image(d: np.ndarray, frame_len: float, sample_rate: int) -> np.ndar
 # a2: the whole path  (wefax.py:46-93)
 # --------------------------------------------------------------------------
 # ---------------------------------------------------------------------------
+# Live path, one audio packet: data_packet.py:408-464.  The same chain as the file path with
+# different constants: notch designed at the packet's own sample rate, medfilt 3, per-packet percentiles,
+# np.rint, and a 1e-6 guard on the denominator.
+# ---------------------------------------------------------------------------
+def medfilt3(x: np.ndarray) -> np.ndarray:
+    """scipy.signal.medfilt(x, 3): zero padding beyond both ends (data_packet.py:446)."""
+    x = np.asarray(x)
+    n = x.shape[0]
+    p = np.zeros(n + 2, dtype=x.dtype)
+    p[1:n + 1] = x
+    win = np.stack([p[k:k + n] for k in range(3)], axis=0)
+    win.sort(axis=0)
+    return win[1].copy()
+
+
+def process_packet(samples: np.ndarray, sample_rate: int, notch=(NOTCH_F0, NOTCH_Q)) -> dict:
+    """DataPacket.__process_samples (data_packet.py:408-418): notch filtfilt (:420-434) -> |hilbert| + medfilt 3
+    (:436-448) -> per-packet percentiles, rint with the 1e-6 guard, clip (:450-464)."""
+    b, a = iirnotch(int(notch[0]), notch[1], sample_rate)
+    notched = filtfilt_biquad(b, a, np.asarray(samples))
+    env = medfilt3(np.abs(hilbert_fft(notched)))
+    low, high = np.percentile(env, (0.5, 99.5))
+    delta = high - low
+    d = np.rint(255 * (env - low) / (delta + 0.000001))
+    d[d < 0] = 0
+    d[d > 255] = 255
+    return {"notched": notched, "envelope": env, "low": float(low), "high": float(high), "samples": d.astype(np.uint8)}
+
+
+# ---------------------------------------------------------------------------
 # The reference's loop structure, for CPU TIMING only (BASELINE.md section 3,
 # SURVEY.md 8d "faithful_loops"): the same results as the vectorised stages
 # above, computed the way wefax.py computes them -- one Python iteration per

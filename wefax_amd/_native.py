@@ -24,7 +24,7 @@ SYMBOLS = [
     "wfx_device_count", "wfx_create", "wfx_destroy", "wfx_last_error", "wfx_sync",
     "wfx_version", "wfx_merge_channels", "wfx_resample", "wfx_notch_filtfilt",
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
-    "wfx_sync_peaks", "wfx_lines_to_image", "wfx_decode_upload", "wfx_decode_attach", "wfx_decode_run",
+    "wfx_sync_peaks", "wfx_lines_to_image", "wfx_packet_process", "wfx_decode_upload", "wfx_decode_attach", "wfx_decode_run",
     "wfx_decode_result", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
@@ -118,6 +118,8 @@ def load():
     lib.wfx_decode_fetch.argtypes = [vp, i, vp, sz]
     lib.wfx_decode_device_ptr.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz)]
     lib.wfx_decode_copy_to_device.argtypes = [vp, i, vp, sz, C.POINTER(sz)]
+    lib.wfx_packet_process.argtypes = [vp, vp, i, sz, dp, dp, C.POINTER(C.c_uint64), C.c_double, C.c_double, vp,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.wfx_decode_attach.argtypes = [vp, vp, C.POINTER(DecodeParams)]
     lib.wfx_stream_handle.argtypes = [vp, C.POINTER(vp)]
     lib.wfx_decode_export_async.argtypes = [vp, i, vp, sz]
@@ -306,6 +308,23 @@ class Context:
         out = np.empty(shape, dtype=dtype)
         self._check(self.lib.wfx_dev_download(self.h, _ptr(out), C.c_void_p(ptr), out.nbytes))
         return out
+
+    def packet_process(self, samples: np.ndarray, b, a, ranks, gamma_lo: float, gamma_hi: float):
+        """One audio packet of the live path (data_packet.py:408-464): (uint8 samples, low, high)."""
+        x = np.ascontiguousarray(samples)
+        if x.dtype == np.int16:
+            kind = WFX_IN_I16_MONO
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            kind = WFX_IN_F64_MONO
+        out = np.empty(x.shape[0], dtype=np.uint8)
+        bb = (C.c_double * 3)(*[float(v) for v in b])
+        aa = (C.c_double * 3)(*[float(v) for v in a])
+        rr = (C.c_uint64 * 4)(*[int(v) for v in ranks])
+        lo, hi = C.c_double(), C.c_double()
+        self._check(self.lib.wfx_packet_process(self.h, _ptr(x), kind, x.shape[0], bb, aa, rr, gamma_lo, gamma_hi, _ptr(out),
+                                                C.byref(lo), C.byref(hi)))
+        return out, lo.value, hi.value
 
     def decode_attach(self, dev_ptr: int, params: "DecodeParams"):
         """Fused decode of a capture that already sits in device memory (caller-owned; nothing is copied)."""

@@ -562,6 +562,38 @@ int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t
     return 0;
 }
 
+// ---- live path, one audio packet (data_packet.py:408-464) ---------------------------------
+int wfx_packet_process(wfx_ctx *ctx, const void *samples, int in_kind, size_t n, const double b[3], const double a[3],
+                       const uint64_t ranks[4], double gamma_lo, double gamma_hi, uint8_t *out, double *low, double *high)
+{
+    CHECK_CTX(ctx);
+    if (!samples || !b || !a || !ranks || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_F64_MONO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "packet: int16 or float64 samples");
+    if (n == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "N must be positive.");
+    ctx->ran = false;
+    const size_t esz = in_kind == WFX_IN_I16_MONO ? 2 : 8;
+    WFX_TRY(ensure_scal(ctx));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_x, n * esz + 16));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_audio, n * 8 + 16));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_envraw, n * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_env, n * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_dig, n + 64));
+    WFX_TRY(h2d(ctx, ctx->b_x.p, samples, n * esz));
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+    WFX_TRY(wfx_dev_notch(ctx, ctx->b_x.p, in_kind, n, b, a, (double *)ctx->b_audio.p));                 // :420-434
+    ctx->force_pow2 = false;
+    WFX_TRY(wfx_dev_hilbert_env_fft(ctx, (const double *)ctx->b_audio.p, n, (double *)ctx->b_envraw.p)); // :445
+    WFX_TRY(wfx_dev_median3(ctx, (const double *)ctx->b_envraw.p, n, (double *)ctx->b_env.p));           // :446
+    WFX_TRY(wfx_dev_percentiles(ctx, (const double *)ctx->b_env.p, n, ranks, gamma_lo, gamma_hi, ds));   // :457
+    WFX_TRY(wfx_dev_quantise(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, ds, 0.000001));   // :458-463
+    WFX_TRY(d2h_sync(ctx, out, ctx->b_dig.p, n));
+    WFX_TRY(d2h_sync(ctx, ctx->h_scal, ds, sizeof(wfx_dev_scalars)));
+    if (low) *low = ctx->h_scal->low;
+    if (high) *high = ctx->h_scal->high;
+    return 0;
+}
+
 // ---- asynchronous export for a collective ------------------------------------------------
 int wfx_stream_handle(wfx_ctx *ctx, void **stream)
 {

@@ -198,8 +198,9 @@ int wfx_dev_percentiles(wfx_ctx *ctx, const double *env, uint64_t n, const uint6
 int wfx_dev_select_workspace(wfx_ctx *ctx, uint64_t n, unsigned **ws);
 int wfx_dev_percentiles_fused(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4],
                               double gamma_lo, double gamma_hi, wfx_dev_scalars *d_scal);
-int wfx_dev_quantise(wfx_ctx *ctx, const double *env, uint64_t n, const wfx_dev_scalars *d_scal,
-                     uint8_t *out, wfx_dev_scalars *d_scal_out);
+int wfx_dev_quantise(wfx_ctx *ctx, const double *env, uint64_t n, const wfx_dev_scalars *d_scal, uint8_t *out, wfx_dev_scalars *d_scal_out,
+                     double eps = 0.0);
+int wfx_dev_median3(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env);
 int wfx_dev_sync_corr(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int32_t *corr);
 int wfx_dev_quantise_corr(wfx_ctx *ctx, const double *env, uint64_t n, wfx_dev_scalars *d_scal, uint8_t *out, int n1, int n0);
 int wfx_dev_sync_pick_precomputed(wfx_ctx *ctx, uint64_t n, int n1, int n0, int64_t mindistance, double frame_samples, int width,

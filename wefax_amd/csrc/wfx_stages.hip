@@ -259,12 +259,118 @@ static void notch_prepare(notch_coef &c, const double b[3], const double a[3])
     }
 }
 
+// ---- filtfilt for any stable biquad (the live path designs the notch at the sound card's rate:
+// data_packet.py:430-432; at 48 kHz the pole radius is 0.84 and the 49-tap form above does not apply) --------
+// The recurrence forgets its state at the rate of the pole radius r: a lane that starts `warm` samples early
+// from a zero state holds, after the warm-up, the state of the sequential run to within r^warm (< 1e-20
+// relative, far below one ulp), and from there on performs the same operations on the same values.  Each lane
+// owns GEN_CHUNK outputs; the lane whose warm-up reaches the end of the extended signal starts there with
+// lfilter_zi, exactly as scipy does.  Pass 1 runs forward over the odd-extended input into `fwd`
+// (n + 2*PAD values), pass 2 backward over `fwd` into y.
+#define GEN_CHUNK 64
+template <typename TIN>
+__device__ __forceinline__ double notch_ext_at(const TIN *x, uint64_t n, int64_t i)   // i in [0, n + 2*PAD)
+{
+    if (i < NOTCH_PAD) return notch_ext_left<TIN>(x, NOTCH_PAD - (int)i);
+    if (i >= (int64_t)n + NOTCH_PAD) return notch_ext_right<TIN>(x, n, (int)(i - (int64_t)n - NOTCH_PAD) + 1);
+    return (double)x[i - NOTCH_PAD];
+}
+
+template <typename TIN>
+__global__ void __launch_bounds__(64) biquad_forward_kernel(const TIN *__restrict__ x, uint64_t n, notch_coef c, int warm, double *__restrict__ fwd)
+{
+    const int64_t len = (int64_t)n + 2 * NOTCH_PAD;
+    const int64_t first = ((int64_t)blockIdx.x * 64 + threadIdx.x) * GEN_CHUNK;
+    if (first >= len) return;
+    int64_t i = first - warm;
+    double z0 = 0.0, z1 = 0.0;
+    if (i <= 0) {
+        i = 0;
+        const double e0 = notch_ext_at<TIN>(x, n, 0);
+        z0 = c.zi[0] * e0;
+        z1 = c.zi[1] * e0;
+    }
+    const int64_t last = first + GEN_CHUNK < len ? first + GEN_CHUNK : len;
+    for (; i < last; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = i + k < last ? notch_ext_at<TIN>(x, n, i + k) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i + k < last) {
+                v[k] = biquad_step(c, v[k], z0, z1);
+                if (i + k >= first) fwd[i + k] = v[k];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) biquad_backward_kernel(const double *__restrict__ fwd, uint64_t n, notch_coef c, int warm, double *__restrict__ y)
+{
+    const int64_t len = (int64_t)n + 2 * NOTCH_PAD;
+    const int64_t first = ((int64_t)blockIdx.x * 64 + threadIdx.x) * GEN_CHUNK;     // this lane's outputs: [first, last)
+    if (first >= len) return;
+    const int64_t last = first + GEN_CHUNK < len ? first + GEN_CHUNK : len;
+    int64_t i = last - 1 + warm;
+    double z0 = 0.0, z1 = 0.0;
+    if (i >= len - 1) {
+        i = len - 1;
+        const double e0 = fwd[len - 1];
+        z0 = c.zi[0] * e0;
+        z1 = c.zi[1] * e0;
+    }
+    for (; i >= first; i -= 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = i - k >= first ? fwd[i - k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t j = i - k;
+            if (j >= first) {
+                v[k] = biquad_step(c, v[k], z0, z1);
+                if (j < last && j >= NOTCH_PAD && j < (int64_t)n + NOTCH_PAD) y[j - NOTCH_PAD] = v[k];
+            }
+        }
+    }
+}
+
+// largest pole modulus of 1 + a1 z^-1 + a2 z^-2
+static double biquad_pole_radius(const double a[3])
+{
+    const double a1 = a[1] / a[0], a2 = a[2] / a[0];
+    const double disc = a1 * a1 - 4.0 * a2;
+    if (disc < 0.0) return sqrt(a2);
+    const double s = sqrt(disc);
+    return fmax(fabs((-a1 + s) / 2.0), fabs((-a1 - s) / 2.0));
+}
+
+static int notch_general(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const notch_coef &c, double radius, double *out)
+{
+    if (!(radius < 0.9995)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "notch: pole radius %.6f is too close to the unit circle", radius);
+    int warm = radius > 0.0 ? (int)ceil(log(1e-20) / log(radius)) + 8 : 8;
+    warm = (warm + 7) & ~7;
+    const uint64_t len = n + 2 * NOTCH_PAD;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, len * sizeof(double)));
+    double *fwd = (double *)ctx->b_work2.p;
+    const unsigned lanes = (unsigned)((len + GEN_CHUNK - 1) / GEN_CHUNK), grid = (lanes + 63) / 64;
+    if (in_kind == WFX_IN_I16_MONO)
+        WFX_LAUNCH(ctx, K_NOTCH, biquad_forward_kernel<short>, dim3(grid), dim3(64), (const short *)in, n, c, warm, fwd);
+    else
+        WFX_LAUNCH(ctx, K_NOTCH, biquad_forward_kernel<double>, dim3(grid), dim3(64), (const double *)in, n, c, warm, fwd);
+    WFX_LAUNCH(ctx, K_NOTCH, biquad_backward_kernel, dim3(grid), dim3(64), (const double *)fwd, n, c, warm, out);
+    return 0;
+}
+
 int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out)
 {
     if (n <= NOTCH_PAD)
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "The length of the input vector x must be greater than padlen, which is 9.");
     notch_coef c;
     notch_prepare(c, b, a);
+    // the 49-tap form holds while the impulse response has died within NOTCH_K samples (the reference's own
+    // design at 11 025 Hz: radius 0.21); any other stable biquad takes the chunked recurrence
+    const double radius = biquad_pole_radius(a);
+    if (n >= NOTCH_SMALL && pow(radius, NOTCH_K) > 1e-16) return notch_general(ctx, in, in_kind, n, c, radius, out);
     unsigned ib = 0;
     if (n >= NOTCH_SMALL) {
         ib = wfx_stream_grid(n - 2 * NOTCH_EDGE, 1024);
@@ -896,10 +1002,10 @@ __device__ __forceinline__ unsigned quantise_one(double v, double low, double de
 }
 
 __global__ void __launch_bounds__(256) quantise_kernel(const double *__restrict__ env, uint64_t n, const wfx_dev_scalars *__restrict__ s,
-                                                      uint8_t *__restrict__ out, wfx_dev_scalars *__restrict__ sout)
+                                                      uint8_t *__restrict__ out, wfx_dev_scalars *__restrict__ sout, double eps)
 {
     const double low = s->low, high = s->high;
-    const double delta = high - low;
+    const double delta = (high - low) + eps;        // eps = 0: wefax.py:197; 1e-6: the live path's guard (data_packet.py:461)
     unsigned nan = 0;
     const uint64_t groups = (n + 7) / 8;
     for (uint64_t gi = blockIdx.x * 256ull + threadIdx.x; gi < groups; gi += (uint64_t)gridDim.x * 256ull) {
@@ -925,9 +1031,25 @@ __global__ void __launch_bounds__(256) quantise_kernel(const double *__restrict_
     }
 }
 
-int wfx_dev_quantise(wfx_ctx *ctx, const double *env, uint64_t n, const wfx_dev_scalars *d_scal, uint8_t *out, wfx_dev_scalars *d_scal_out)
+int wfx_dev_quantise(wfx_ctx *ctx, const double *env, uint64_t n, const wfx_dev_scalars *d_scal, uint8_t *out, wfx_dev_scalars *d_scal_out,
+                     double eps)
 {
-    WFX_LAUNCH(ctx, K_QUANTISE, quantise_kernel, dim3(wfx_stream_grid((n + 7) / 8, 256)), dim3(256), env, n, d_scal, out, d_scal_out);
+    WFX_LAUNCH(ctx, K_QUANTISE, quantise_kernel, dim3(wfx_stream_grid((n + 7) / 8, 256)), dim3(256), env, n, d_scal, out, d_scal_out, eps);
+    return 0;
+}
+
+// 3-tap median with zeros beyond both ends: scipy.signal.medfilt(x, 3) of the live path (data_packet.py:446)
+__global__ void __launch_bounds__(256) median3_kernel(const double *__restrict__ r, uint64_t n, double *__restrict__ out)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256ull) {
+        const double a = i > 0 ? r[i - 1] : 0.0, b = r[i], c = i + 1 < n ? r[i + 1] : 0.0;
+        out[i] = fmax(fmin(a, b), fmin(fmax(a, b), c));
+    }
+}
+
+int wfx_dev_median3(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env)
+{
+    WFX_LAUNCH(ctx, K_MEDIAN, median3_kernel, dim3(wfx_stream_grid(n, 256)), dim3(256), env_raw, n, env);
     return 0;
 }
 
