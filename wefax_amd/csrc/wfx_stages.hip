@@ -504,6 +504,7 @@ __host__ __device__ static inline int sel_width(int level) { return level < 5 ? 
 #define SEL_H0 0                          // level-0 histogram [2048]
 #define SEL_H1 SEL_BINS                   // level-1 histograms [4][2048]
 #define SEL_CNT (5 * SEL_BINS)            // candidate counts [4]
+#define SEL_TICKET (5 * SEL_BINS + 4)     // finish kernel: workgroups done
 #define SEL_WORDS (5 * SEL_BINS + 8)
 
 #define sel_count wfx_sel_count
@@ -661,19 +662,19 @@ __global__ void __launch_bounds__(256) select_l0_kernel(const double *__restrict
 // and step.  SEL_UN steps are loaded back to back before any of them is consumed: bytes in flight,
 // not occupancy, hide the HBM latency of these one-pass kernels.
 #define SEL_UN 4
-template <typename FN>
+template <int NT = 256, typename FN>
 __device__ __forceinline__ void sel_stream(const double *__restrict__ v, uint64_t n, FN fn)
 {
     const int t = threadIdx.x;
     const uint64_t quads = (n + 3) / 4;
-    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    const uint64_t stride = (uint64_t)gridDim.x * (uint64_t)NT;
     const uint64_t nround = (quads + stride - 1) / stride;
     uint64_t it = 0;
     for (; it + SEL_UN <= nround && (it + SEL_UN) * stride * 4 <= n; it += SEL_UN) {      // whole batch inside the array: no guards
         double2 lo[SEL_UN], hi[SEL_UN];
 #pragma unroll
         for (int u = 0; u < SEL_UN; ++u) {
-            const uint64_t i0 = ((it + u) * stride + blockIdx.x * 256ull + t) * 4;
+            const uint64_t i0 = ((it + u) * stride + blockIdx.x * (uint64_t)NT + t) * 4;
             lo[u] = *(const double2 *)(v + i0);
             hi[u] = *(const double2 *)(v + i0 + 2);
         }
@@ -686,7 +687,7 @@ __device__ __forceinline__ void sel_stream(const double *__restrict__ v, uint64_
         }
     }
     for (; it < nround; ++it) {
-        const uint64_t i0 = (it * stride + blockIdx.x * 256ull + t) * 4;
+        const uint64_t i0 = (it * stride + blockIdx.x * (uint64_t)NT + t) * 4;
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         if (i0 + 4 <= n) {
             const double2 lo = *(const double2 *)(v + i0), hi2 = *(const double2 *)(v + i0 + 2);
@@ -708,7 +709,8 @@ __device__ __forceinline__ void sel_stream(const double *__restrict__ v, uint64_
 
 // level 1: choose the level-0 digit of every query, then histogram bits 52..42 of the
 // values whose top 11 bits match
-__global__ void __launch_bounds__(256) select_l1_kernel(const double *__restrict__ v, uint64_t n, uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3,
+template <int NT>
+__global__ void __launch_bounds__(NT) select_l1_kernel(const double *__restrict__ v, uint64_t n, uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3,
                                                        unsigned *__restrict__ ws, wfx_dev_scalars *__restrict__ s)
 {
     __shared__ unsigned h[4][SEL_BINS];
@@ -716,7 +718,7 @@ __global__ void __launch_bounds__(256) select_l1_kernel(const double *__restrict
     __shared__ unsigned dig[4];
     __shared__ int owner[4];
     const int t = threadIdx.x, lane = t & 63;
-    for (int i = t; i < 4 * SEL_BINS; i += 256) (&h[0][0])[i] = 0;
+    for (int i = t; i < 4 * SEL_BINS; i += NT) (&h[0][0])[i] = 0;
     if (t == 0) {
         rin[0] = r0;
         rin[1] = r1;
@@ -752,9 +754,9 @@ __global__ void __launch_bounds__(256) select_l1_kernel(const double *__restrict
         for (int q = 0; q < 4; ++q)
             if (active[q] && valid && hi == mypfx[q]) atomicAdd(&h[q][digit], 1u);   // level-1 digits are diverse: no wave aggregation
     };
-    sel_stream(v, n, count);
+    sel_stream<NT>(v, n, count);
     __syncthreads();
-    for (int i = t; i < 4 * SEL_BINS; i += 256) {
+    for (int i = t; i < 4 * SEL_BINS; i += NT) {
         const unsigned c = (&h[0][0])[i];
         if (c) atomicAdd(&ws[SEL_H1 + i], c);
     }
@@ -762,7 +764,8 @@ __global__ void __launch_bounds__(256) select_l1_kernel(const double *__restrict
 
 // compaction: choose the level-1 digit of every query, then append the keys whose top
 // 22 bits match to the query's candidate list (one atomic per wave and list)
-__global__ void __launch_bounds__(256) select_compact_kernel(const double *__restrict__ v, uint64_t n, unsigned *__restrict__ ws,
+template <int NT>
+__global__ void __launch_bounds__(NT) select_compact_kernel(const double *__restrict__ v, uint64_t n, unsigned *__restrict__ ws,
                                                             wfx_dev_scalars *__restrict__ s, unsigned long long *__restrict__ cand, uint64_t cap)
 {
     __shared__ unsigned long long pfx[4], rnk[4], rin[4];
@@ -819,7 +822,7 @@ __global__ void __launch_bounds__(256) select_compact_kernel(const double *__res
             }
         }
     };
-    sel_stream(v, n, append);
+    sel_stream<NT>(v, n, append);
 }
 
 // levels 2..5 on the candidate lists, numpy's lerp, and clearing of the workspace
@@ -881,20 +884,30 @@ __global__ void __launch_bounds__(1024) select_finish_kernel(unsigned *__restric
         }
         if (t == 0) s->sel_value[q] = key_f64(cur_p);
     }
-}
-
-// numpy's interpolation between the two order statistics of each percentile, and clearing
-// of the select workspace for the next run
-__global__ void __launch_bounds__(256) select_lerp_kernel(unsigned *__restrict__ ws, wfx_dev_scalars *__restrict__ s, int do_lerp, double gamma_lo,
-                                                         double gamma_hi)
-{
-    const int t = threadIdx.x;
-    if (t == 0 && do_lerp) {
-        s->low = np_lerp(s->sel_value[0], s->sel_value[1], gamma_lo);
-        s->high = np_lerp(s->sel_value[2], s->sel_value[3], gamma_hi);
-        s->nan_count = 0;
+    // The workgroup that finishes last applies numpy's interpolation between the two order statistics of
+    // each percentile and clears the workspace for the next run (a separate 1-workgroup launch cost 4.5 us).
+    // Hand-off: result store -> release fence -> ticket; the last one: acquire fence -> sc1 loads.
+    __shared__ int is_last;
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(&ws[SEL_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = ticket == gridDim.x - 1;
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (do_lerp) {
+                double v[4];
+                for (int q = 0; q < 4; ++q) v[q] = __hip_atomic_load(&s->sel_value[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s->low = np_lerp(v[0], v[1], gamma_lo);
+                s->high = np_lerp(v[2], v[3], gamma_hi);
+                s->nan_count = 0;
+            }
+        }
     }
-    for (int i = t; i < SEL_WORDS; i += 256) ws[i] = 0;
+    __syncthreads();
+    if (is_last)
+        for (int i = t; i < SEL_WORDS; i += 1024) ws[i] = 0;
 }
 
 // workspace + candidate lists; the workspace is zeroed when it is (re)allocated and by
@@ -916,13 +929,14 @@ static int select_after_l0(wfx_ctx *ctx, const double *env, uint64_t n, const ui
 {
     unsigned *ws = (unsigned *)ctx->b_hist.p;
     unsigned long long *cand = (unsigned long long *)ctx->b_cand.p;
-    unsigned grid = wfx_stream_grid(n, 4096);
-    if (grid > 512) grid = 512;             // 2 per CU: per-workgroup prologue (digit pick) and epilogue (flush) are paid once
-    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l1_kernel, dim3(grid), dim3(256), env, n, ranks[0], ranks[1], ranks[2], ranks[3], ws, d_scal);
-    WFX_LAUNCH(ctx, K_SELECT_HIST, select_compact_kernel, dim3(grid), dim3(256), env, n, ws, d_scal, cand, n);
+    // level 1: one 1024-lane workgroup per CU -- the flush of a workgroup's 2 x 2048 live bins is 64 atomic
+    // wave-instructions that execute at the memory side (~1.3 TB/s chip-wide), so fewer, larger workgroups
+    // (18.5 us) beat 512 x 256 lanes (28 us)
+    const unsigned g1 = std::min(wfx_stream_grid(n, 16384), 256u);
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l1_kernel<1024>, dim3(g1), dim3(1024), env, n, ranks[0], ranks[1], ranks[2], ranks[3], ws, d_scal);
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_compact_kernel<1024>, dim3(g1), dim3(1024), env, n, ws, d_scal, cand, n);
     WFX_LAUNCH(ctx, K_SELECT_SCAN, select_finish_kernel, dim3(4), dim3(1024), ws, d_scal, (const unsigned long long *)cand, n, do_lerp, gamma_lo,
                gamma_hi);
-    WFX_LAUNCH(ctx, K_SELECT_SCAN, select_lerp_kernel, dim3(1), dim3(256), ws, d_scal, do_lerp, gamma_lo, gamma_hi);
     return 0;
 }
 
