@@ -113,13 +113,14 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
         // samples from that end and the caller's halo covers the rest
         const uint64_t lo = (exact_edges & 1) ? NOTCH_EDGE : NOTCH_K, hi = (exact_edges & 2) ? n - NOTCH_EDGE : n - NOTCH_K;
         const uint64_t step = (uint64_t)interior_blocks * 1024ull;
-        double pre[NPRE];
+        // raw samples, unconditional loads from a clamped index: a guarded load compiles to a branch with its
+        // own s_waitcnt, which serialises the five loads of a tile instead of leaving them in flight (36 -> 27 us)
+        TIN pre[NPRE];
         auto prefetch = [&](uint64_t base) {
 #pragma unroll
             for (int k = 0; k < NPRE; ++k) {
-                const int i = t + 256 * k;
-                const uint64_t src = base - NOTCH_K + i;       // >= lo - K >= 0
-                pre[k] = (i < TLEN && src < n) ? (double)x[src] : 0.0;
+                const uint64_t src = base - NOTCH_K + (uint64_t)(t + 256 * k);       // >= lo - K >= 0
+                pre[k] = x[src < n ? src : n - 1];
             }
         };
         uint64_t base = lo + (uint64_t)blockIdx.x * 1024ull;
@@ -129,7 +130,8 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
 #pragma unroll
             for (int k = 0; k < NPRE; ++k) {
                 const int i = t + 256 * k;
-                if (i < TLEN) tile[i + (i >> 2)] = pre[k];
+                const uint64_t src = base - NOTCH_K + (uint64_t)i;
+                if (i < TLEN) tile[i + (i >> 2)] = src < n ? (double)pre[k] : 0.0;
             }
             lds_barrier();
             if (base + step < hi) prefetch(base + step);
@@ -224,6 +226,12 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
     } else if (t < 2 * NOTCH_EDGE) {
         if (exact_edges & 2) y[n - NOTCH_EDGE + (t - NOTCH_EDGE)] = ebuf[1][L - NOTCH_EDGE + (t - NOTCH_EDGE)];
     }
+}
+
+// interior workgroups: 4 per CU, each walks its 1024-sample tiles with the next tile's loads in flight
+static unsigned notch_grid(uint64_t n_interior)
+{
+    return std::min(wfx_blocks(n_interior, 1024), 1024u);
 }
 
 static void notch_prepare(notch_coef &c, const double b[3], const double a[3])
@@ -373,7 +381,7 @@ int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const d
     if (n >= NOTCH_SMALL && pow(radius, NOTCH_K) > 1e-16) return notch_general(ctx, in, in_kind, n, c, radius, out);
     unsigned ib = 0;
     if (n >= NOTCH_SMALL) {
-        ib = wfx_stream_grid(n - 2 * NOTCH_EDGE, 1024);
+        ib = notch_grid(n - 2 * NOTCH_EDGE);
     }
     if (in_kind == WFX_IN_I16_MONO)
         WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + 1), dim3(256), (const short *)in, n, c, out, ib, 3);
@@ -390,7 +398,7 @@ int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
     if (n < NOTCH_SMALL) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "segment of %llu samples is too short for the notch", (unsigned long long)n);
     notch_coef c;
     notch_prepare(c, b, a);
-    const unsigned ib = wfx_stream_grid(n - 2 * NOTCH_K, 1024);
+    const unsigned ib = notch_grid(n - 2 * NOTCH_K);
     if (in_kind == WFX_IN_I16_MONO)
         WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const short *)in, n, c, out, ib, edge_flags & 3);
     else if (in_kind == WFX_IN_F64_MONO)
