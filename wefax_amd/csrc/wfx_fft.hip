@@ -650,12 +650,26 @@ __device__ __forceinline__ void cswap_d(double &a, double &b)
     b = hi;
 }
 
+// |x + i H| of one sample.  The device library's hypot() is an exponent-scaled sqrt(fma(x, x, H * H)); for
+// operands whose squares neither overflow nor underflow the scaling is exact, so the unscaled form gives the
+// same bits (checked on 16.7 M pairs: tools/micro/hypot_check.hip) at a third of the instructions.
+__device__ __forceinline__ double env_abs(double x, double H)
+{
+    const double ax = fabs(x), ah = fabs(H);
+    const double big = fmax(ax, ah), small = fmin(ax, ah);
+    if (big < 1e140 && (small > 1e-140 || small == 0.0)) return sqrt(__builtin_fma(x, x, H * H));
+    return hypot(x, H);
+}
+
 // |x + i H| followed by the 5-tap median of wefax.py:175 (zeros beyond both ends), fused:
 // a tile of 1024 envelope values + 2 halo values per side is formed in LDS.
+// Packed layout: V[m] = (H[2m], H[2m-1]), so one 16-byte load serves the pair of samples (2m-1, 2m); a tile
+// needs the 515 pairs m = base/2 - 1 .. base/2 + 513.  All loads of a tile are issued unguarded (clamped
+// indices) and one tile ahead: a guarded load compiles to load + s_waitcnt, one HBM round trip per iteration.
 __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__ V, const double *__restrict__ x, long long N, long long L, int packed,
                                                        double *__restrict__ env, unsigned *__restrict__ l0hist)
 {
-    __shared__ double tile[1024 + 4];
+    __shared__ double tile[1024 + 8];
     __shared__ unsigned h0[WFX_SEL_BINS];      // level 0 of the percentile radix select (bits 63..53)
     const int t = threadIdx.x;
     // level-0 digits (sign + 10 exponent bits) take a handful of values: each thread keeps a
@@ -663,51 +677,112 @@ __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__
     unsigned run_digit = 0, run_count = 0;
     if (l0hist)
         for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
-    for (long long base = (long long)blockIdx.x * 1024; base < N; base += (long long)gridDim.x * 1024) {
-        __syncthreads();
-        for (int i = t; i < 1024 + 4; i += 256) {
-            const long long n = base - 2 + i;
-            double e = 0.0;
-            if (n >= 0 && n < N) {
-                double H;
-                if (!packed)
-                    H = V[n].x;
-                else if ((n & 1) == 0)
-                    H = V[n >> 1].x;
-                else {
-                    const long long p = (n + 1) >> 1;
-                    H = V[p == L ? 0 : p].y;
-                }
-                e = hypot(x[n], H);
-            }
-            tile[i] = e;
-        }
-        __syncthreads();
+    const long long step = (long long)gridDim.x * 1024;
+    if (packed) {
+        cplx pv[3];
+        double px0[3], px1[3];
+        auto prefetch = [&](long long base) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = t + 256 * u;
-            const bool valid = base + j < N;
-            double c = 0.0;
-            if (valid) {
-                double a = tile[j], b = tile[j + 1], d = tile[j + 3], e = tile[j + 4];
-                c = tile[j + 2];
-                cswap_d(a, b);
-                cswap_d(d, e);
-                cswap_d(a, d);
-                cswap_d(b, e);
-                cswap_d(b, c);
-                cswap_d(c, d);
-                cswap_d(b, c);
-                env[base + j] = c;
+            for (int k = 0; k < 3; ++k) {
+                const long long m = base / 2 - 1 + t + 256 * k;            // pair (2m - 1, 2m)
+                const long long mc = m < 0 ? 0 : (m >= L ? 0 : m);       // H[N - 1] = V[0].y
+                const long long i1 = 2 * m, i0 = 2 * m - 1;
+                pv[k] = V[mc];
+                px0[k] = x[i0 < 0 ? 0 : (i0 >= N ? N - 1 : i0)];
+                px1[k] = x[i1 < 0 ? 0 : (i1 >= N ? N - 1 : i1)];
             }
-            if (l0hist && valid) {
-                const unsigned dg = (unsigned)(wfx_f64_key(c) >> 53);
-                if (dg == run_digit)
-                    ++run_count;
-                else {
-                    if (run_count) atomicAdd(&h0[run_digit], run_count);
-                    run_digit = dg;
-                    run_count = 1;
+        };
+        long long base = (long long)blockIdx.x * 1024;
+        if (base < N) prefetch(base);
+        for (; base < N; base += step) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int mi = t + 256 * k;                                // pair index inside the tile: 0 .. 514
+                const long long m = base / 2 - 1 + mi;
+                const long long i1 = 2 * m, i0 = 2 * m - 1;
+                // V[m].y = H[2m - 1] for m < L; at m == L the clamped load read V[0], whose .y is H[N - 1]
+                const double e0 = (i0 >= 0 && i0 < N) ? env_abs(px0[k], pv[k].y) : 0.0;
+                const double e1 = (i1 >= 0 && i1 < N) ? env_abs(px1[k], pv[k].x) : 0.0;
+                // tile[j] holds sample base - 2 + j: the pair lands at j = 2 mi - 1, 2 mi
+                if (mi < 515) {
+                    if (mi > 0) tile[2 * mi - 1] = e0;
+                    if (mi < 514) tile[2 * mi] = e1;
+                }
+            }
+            __syncthreads();
+            if (base + step < N) prefetch(base + step);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * t + 512 * u;                             // two consecutive outputs per lane
+                const double w0 = tile[j], w1 = tile[j + 1], w2 = tile[j + 2], w3 = tile[j + 3], w4 = tile[j + 4], w5 = tile[j + 5];
+                double r[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double a = h ? w1 : w0, b = h ? w2 : w1, c = h ? w3 : w2, d = h ? w4 : w3, e = h ? w5 : w4;
+                    cswap_d(a, b);
+                    cswap_d(d, e);
+                    cswap_d(a, d);
+                    cswap_d(b, e);
+                    cswap_d(b, c);
+                    cswap_d(c, d);
+                    cswap_d(b, c);
+                    r[h] = c;
+                }
+                if (base + j + 1 < N)
+                    *(double2 *)(env + base + j) = make_double2(r[0], r[1]);
+                else if (base + j < N)
+                    env[base + j] = r[0];
+                if (l0hist) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (base + j + h >= N) continue;
+                        const unsigned dg = (unsigned)(wfx_f64_key(r[h]) >> 53);
+                        if (dg == run_digit)
+                            ++run_count;
+                        else {
+                            if (run_count) atomicAdd(&h0[run_digit], run_count);
+                            run_digit = dg;
+                            run_count = 1;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        for (long long base = (long long)blockIdx.x * 1024; base < N; base += step) {
+            __syncthreads();
+            for (int i = t; i < 1024 + 4; i += 256) {
+                const long long n = base - 2 + i;
+                tile[i] = (n >= 0 && n < N) ? env_abs(x[n], V[n].x) : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = t + 256 * u;
+                const bool valid = base + j < N;
+                double c = 0.0;
+                if (valid) {
+                    double a = tile[j], b = tile[j + 1], d = tile[j + 3], e = tile[j + 4];
+                    c = tile[j + 2];
+                    cswap_d(a, b);
+                    cswap_d(d, e);
+                    cswap_d(a, d);
+                    cswap_d(b, e);
+                    cswap_d(b, c);
+                    cswap_d(c, d);
+                    cswap_d(b, c);
+                    env[base + j] = c;
+                }
+                if (l0hist && valid) {
+                    const unsigned dg = (unsigned)(wfx_f64_key(c) >> 53);
+                    if (dg == run_digit)
+                        ++run_count;
+                    else {
+                        if (run_count) atomicAdd(&h0[run_digit], run_count);
+                        run_digit = dg;
+                        run_count = 1;
+                    }
                 }
             }
         }
@@ -762,8 +837,10 @@ int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double
     int packed = 0;
     uint64_t L = 0;
     WFX_TRY(hilbert_conv(ctx, x, n, &W, &packed, &L));
-    WFX_LAUNCH(ctx, K_ENV_MEDIAN, hconv_env_median, dim3(wfx_stream_grid(n, 1024)), dim3(256), (const cplx *)W, x, (long long)n, (long long)L,
-               packed, env, l0hist);
+    // 4 workgroups per CU: every workgroup ends with one global atomic per non-empty level-0 bin, all on the same
+    // handful of addresses, and those serialise at the memory side (2048 workgroups: 47 us, 1024: 39 us)
+    const unsigned grid = std::min(wfx_stream_grid(n, 1024), 1024u);
+    WFX_LAUNCH(ctx, K_ENV_MEDIAN, hconv_env_median, dim3(grid), dim3(256), (const cplx *)W, x, (long long)n, (long long)L, packed, env, l0hist);
     return 0;
 }
 

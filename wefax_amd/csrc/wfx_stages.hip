@@ -725,7 +725,7 @@ __global__ void __launch_bounds__(NT) select_l1_kernel(const double *__restrict_
     __shared__ unsigned long long pfx[4], rnk[4], rin[4];
     __shared__ unsigned dig[4];
     __shared__ int owner[4];
-    const int t = threadIdx.x, lane = t & 63;
+    const int t = threadIdx.x;
     for (int i = t; i < 4 * SEL_BINS; i += NT) (&h[0][0])[i] = 0;
     if (t == 0) {
         rin[0] = r0;
@@ -1010,9 +1010,29 @@ int wfx_dev_percentile_lerp(wfx_ctx *ctx, double gamma_lo, double gamma_hi, wfx_
 // ===========================================================================
 // a8  quantise (wefax.py:197-200,216): np.round(255 * (data - low) / delta), clamp
 // ===========================================================================
-__device__ __forceinline__ unsigned quantise_one(double v, double low, double delta, unsigned &nan)
+// The IEEE division was ~35 of the ~70 VALU instructions a sample cost in the fused kernel.  q' = a * (1/delta)
+// is within 2 ulp of the true quotient, so rint(q') == rint(a / delta) unless q' lies within a few ulp of a
+// half-integer; only then (|frac - 0.5| < 1e-9: practically never) is the division performed.  Out-of-range
+// quotients clamp to the same end either way.  The reciprocal is used only when it is a normal finite number.
+struct quant_par {
+    double low, delta, rcp;
+    bool fast;
+};
+__device__ __forceinline__ quant_par quant_make(double low, double delta)
 {
-    double q = 255 * (v - low) / delta;     // same operation order as numpy; IEEE division
+    quant_par p;
+    p.low = low;
+    p.delta = delta;
+    p.rcp = 1.0 / delta;
+    const double ar = fabs(p.rcp);
+    p.fast = ar > 1e-290 && ar < 1e290;
+    return p;
+}
+__device__ __forceinline__ unsigned quantise_one(double v, const quant_par &p, unsigned &nan)
+{
+    const double a = 255 * (v - p.low);     // same operation order as numpy
+    double q = a * p.rcp;
+    if (!p.fast || fabs((q - floor(q)) - 0.5) < 1e-9) q = a / p.delta;      // IEEE division, as numpy
     q = rint(q);                            // round half to even == np.round
     if (q != q) {
         nan += 1;
@@ -1028,6 +1048,7 @@ __global__ void __launch_bounds__(256) quantise_kernel(const double *__restrict_
 {
     const double low = s->low, high = s->high;
     const double delta = (high - low) + eps;        // eps = 0: wefax.py:197; 1e-6: the live path's guard (data_packet.py:461)
+    const quant_par qp = quant_make(low, delta);
     unsigned nan = 0;
     const uint64_t groups = (n + 7) / 8;
     for (uint64_t gi = blockIdx.x * 256ull + threadIdx.x; gi < groups; gi += (uint64_t)gridDim.x * 256ull) {
@@ -1035,13 +1056,13 @@ __global__ void __launch_bounds__(256) quantise_kernel(const double *__restrict_
         if (i0 + 8 <= n) {
             const double2 *p = (const double2 *)(env + i0);
             const double2 a = p[0], b = p[1], c = p[2], d = p[3];
-            unsigned w0 = quantise_one(a.x, low, delta, nan) | (quantise_one(a.y, low, delta, nan) << 8) |
-                          (quantise_one(b.x, low, delta, nan) << 16) | (quantise_one(b.y, low, delta, nan) << 24);
-            unsigned w1 = quantise_one(c.x, low, delta, nan) | (quantise_one(c.y, low, delta, nan) << 8) |
-                          (quantise_one(d.x, low, delta, nan) << 16) | (quantise_one(d.y, low, delta, nan) << 24);
+            unsigned w0 = quantise_one(a.x, qp, nan) | (quantise_one(a.y, qp, nan) << 8) |
+                          (quantise_one(b.x, qp, nan) << 16) | (quantise_one(b.y, qp, nan) << 24);
+            unsigned w1 = quantise_one(c.x, qp, nan) | (quantise_one(c.y, qp, nan) << 8) |
+                          (quantise_one(d.x, qp, nan) << 16) | (quantise_one(d.y, qp, nan) << 24);
             *(uint2 *)(out + i0) = make_uint2(w0, w1);
         } else {
-            for (uint64_t i = i0; i < n; ++i) out[i] = (uint8_t)quantise_one(env[i], low, delta, nan);
+            for (uint64_t i = i0; i < n; ++i) out[i] = (uint8_t)quantise_one(env[i], qp, nan);
         }
     }
     // one atomic per wave that saw a NaN (rare path)
@@ -1079,24 +1100,6 @@ int wfx_dev_median3(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env
 // a9  sync search (wefax.py:218-294)
 // corr[i] = -127 * sum_{k<L}(d[i+k]-128) - sum_{k in middle run}(d[i+k]-128)
 // ===========================================================================
-// corr for `cnt` positions starting at global position p0; bytes d[p0 .. p0+cnt+L) are in ds
-__device__ __forceinline__ void corr_from_lds(const uint8_t *ds, int cnt, int n1, int n0, int *corr_out, int t, int nthreads)
-{
-    const int L = 2 * n1 + n0;
-    // 16 consecutive positions per thread
-    for (int j0 = t * 16; j0 < cnt; j0 += nthreads * 16) {
-        int sall = 0, smid = 0;
-        for (int k = 0; k < L; ++k) sall += ds[j0 + k];
-        for (int k = 0; k < n0; ++k) smid += ds[j0 + n1 + k];
-        const int jend = min(j0 + 16, cnt);
-        for (int j = j0; j < jend; ++j) {
-            corr_out[j] = -127 * (sall - 128 * L) - (smid - 128 * n0);
-            sall += (int)ds[j + L] - (int)ds[j];
-            smid += (int)ds[j + n1 + n0] - (int)ds[j + n1];
-        }
-    }
-}
-
 #define CORR_CH 4096
 // wave64 reductions with DPP (no LDS crossbar round trips): after the four row steps every
 // lane of a 16-lane row holds the row result; row_bcast15 / row_bcast31 fold the rows
@@ -1156,99 +1159,91 @@ __device__ __forceinline__ void wave_first_argmax(int c, int idx, int &best_c, i
 
 // corr[i] for every position, plus (optionally) per block of 64 positions the maximum
 // and the offset of its first occurrence -- what the sequential picker consumes.
+//
+// Both window sums are differences of a running byte sum P: the workgroup forms P over its chunk + halo in LDS
+// (18 consecutive bytes per lane, wave scan by DPP, one exchange across the four waves), then every lane owns
+// one position per row of 256: four conflict-free LDS reads, a coalesced 4-byte store, and per wave (= per block
+// of 64 positions) a DPP max + ballot for the summaries.  No per-lane serial loop over the pattern length: the
+// sliding-sum form (16 consecutive positions per lane, ~130 dependent LDS byte reads) took 27 us, this takes ~9.
+#define CORR_BPT 18                                   // bytes per lane: 256 * 18 = CORR_CH + 512
+__device__ __forceinline__ int wave_incl_scan_i32(int v)
+{
+    // row_shr:1,2,4,8 inside the rows of 16, then the row totals across rows
+    int x = v;
+    int y;
+    y = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); x += y;     // row_shr:1
+    y = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); x += y;     // row_shr:2
+    y = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); x += y;     // row_shr:4
+    y = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); x += y;     // row_shr:8
+    y = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); x += y;     // row_bcast15 -> rows 1, 3
+    y = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); x += y;     // row_bcast31 -> rows 2, 3
+    return x;
+}
+
 __global__ void __launch_bounds__(256) sync_corr_kernel(const uint8_t *__restrict__ d, uint64_t n, int n1, int n0, int *__restrict__ corr,
                                                        int *__restrict__ bmax, int *__restrict__ boff)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t ds[CORR_CH + 512 + 16];
-    __shared__ __attribute__((aligned(16))) int cs[CORR_CH];
+    __shared__ int P[256 * CORR_BPT + 1];
+    __shared__ int wave_tot[4];
     const int L = 2 * n1 + n0;
     const uint64_t ncorr = n > (uint64_t)L ? n - L : 0;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (uint64_t p0 = (uint64_t)blockIdx.x * CORR_CH; p0 < ncorr; p0 += (uint64_t)gridDim.x * CORR_CH) {
+        // bytes [p0 + 18 t, + 18): nine 2-byte loads (p0 is a multiple of 4096, the stream is padded by 64 bytes;
+        // anything at or beyond n counts as 0)
+        const uint64_t b0 = p0 + (uint64_t)(CORR_BPT * t);
+        unsigned short raw[CORR_BPT / 2];
+#pragma unroll
+        for (int k = 0; k < CORR_BPT / 2; ++k) {
+            const uint64_t i = b0 + 2 * k;
+            raw[k] = *(const unsigned short *)(d + (i + 1 < n + 48 ? i : 0));
+        }
+        int loc[CORR_BPT];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < CORR_BPT; ++k) {
+            const int byte = (b0 + k < n) ? (int)((raw[k >> 1] >> (8 * (k & 1))) & 0xff) : 0;
+            loc[k] = sum;
+            sum += byte;
+        }
+        const int incl = wave_incl_scan_i32(sum);
+        __syncthreads();                                   // previous chunk's rows are done with P
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int offset = incl - sum;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+            if (w < wave) offset += wave_tot[w];
+#pragma unroll
+        for (int k = 0; k < CORR_BPT; ++k) P[CORR_BPT * t + k] = offset + loc[k];
+        if (t == 255) P[256 * CORR_BPT] = offset + sum;
+        __syncthreads();
         const int cnt = (int)min((uint64_t)CORR_CH, ncorr - p0);
-        __syncthreads();
-        // the byte stream buffer is padded by 64 bytes and p0 is a multiple of 4096: 16-byte loads
-        for (int i = t * 16; i < cnt + L + 1; i += 256 * 16) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (p0 + i < n + 48) v = *(const uint4 *)(d + p0 + i);
-            *(uint4 *)(ds + i) = v;
-        }
-        __syncthreads();
-        corr_from_lds(ds, cnt, n1, n0, cs, t, 256);
-        __syncthreads();
-        // corr is padded to a multiple of 4 ints: whole int4 stores (values beyond cnt are never read)
-        for (int i = t * 4; i < cnt; i += 256 * 4) *(int4 *)(corr + p0 + i) = *(const int4 *)(cs + i);
-        if (bmax) {
-            const int lane = t & 63, wave = t >> 6;
-            for (int b = wave; b * 64 < cnt; b += 4) {
-                const int j = b * 64 + lane;
-                int bc, bi;
-                wave_first_argmax(j < cnt ? cs[j] : (int)0x80000000, lane, bc, bi);
-                if (lane == 0) {
-                    bmax[p0 / 64 + b] = bc;
-                    boff[p0 / 64 + b] = bi;
+        const int kall = 128 * L, kmid = 128 * n0;
+#pragma unroll 4
+        for (int m = 0; m < CORR_CH / 256; ++m) {
+            const int j = t + 256 * m;
+            if (256 * m >= cnt) break;
+            const int sall = P[j + L] - P[j], smid = P[j + n1 + n0] - P[j + n1];
+            const int c = -127 * (sall - kall) - (smid - kmid);
+            const bool valid = j < cnt;
+            if (valid) corr[p0 + j] = c;
+            if (bmax) {
+                const int cm = valid ? c : (int)0x80000000;
+                const int best = wave_max_i32(cm);
+                const unsigned long long hit = __ballot(cm == best);
+                if (lane == 0 && (j & ~63) < cnt) {
+                    bmax[(p0 + j) / 64] = best;
+                    boff[(p0 + j) / 64] = __ffsll((long long)hit) - 1;
                 }
             }
         }
     }
 }
 
-// Fused a8 + a9 for the decode path: quantise one chunk of the envelope (plus the L samples of halo
-// the correlation needs) into LDS, write the chunk's bytes, correlate, write correlation + summaries.
-// Saves one launch and the re-read of the byte stream; the halo is re-quantised, not exchanged.
-__global__ void __launch_bounds__(256) quantise_corr_kernel(const double *__restrict__ env, uint64_t n, const wfx_dev_scalars *__restrict__ s,
-                                                           uint8_t *__restrict__ d, wfx_dev_scalars *__restrict__ sout, int n1, int n0,
-                                                           int *__restrict__ corr, int *__restrict__ bmax, int *__restrict__ boff)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t ds[CORR_CH + 512 + 16];
-    __shared__ __attribute__((aligned(16))) int cs[CORR_CH];
-    const double low = s->low, delta = s->high - s->low;
-    const int L = 2 * n1 + n0;
-    const uint64_t ncorr = n > (uint64_t)L ? n - L : 0;
-    const int t = threadIdx.x;
-    unsigned nan = 0;
-    for (uint64_t p0 = (uint64_t)blockIdx.x * CORR_CH; p0 < n; p0 += (uint64_t)gridDim.x * CORR_CH) {
-        const int own = (int)min((uint64_t)CORR_CH, n - p0);                 // bytes this chunk owns
-        const int need = (int)min((uint64_t)(CORR_CH + L + 1), n - p0);      // bytes the correlation reads
-        __syncthreads();
-        for (int i = 2 * t; i < need; i += 512) {                            // p0 is even: 16-byte aligned pairs
-            unsigned dummy = 0;
-            if (i + 1 < need) {
-                const double2 v = *(const double2 *)(env + p0 + i);
-                ds[i] = (uint8_t)quantise_one(v.x, low, delta, i < own ? nan : dummy);
-                ds[i + 1] = (uint8_t)quantise_one(v.y, low, delta, i + 1 < own ? nan : dummy);
-            } else {
-                ds[i] = (uint8_t)quantise_one(env[p0 + i], low, delta, i < own ? nan : dummy);
-            }
-        }
-        for (int i = need + t; i < CORR_CH + L + 1; i += 256) ds[i] = 0;
-        __syncthreads();
-        for (int i = t * 16; i < own; i += 256 * 16) *(uint4 *)(d + p0 + i) = *(const uint4 *)(ds + i);   // d is padded by 64 bytes
-        if (p0 < ncorr) {
-            const int cnt = (int)min((uint64_t)CORR_CH, ncorr - p0);
-            corr_from_lds(ds, cnt, n1, n0, cs, t, 256);
-            __syncthreads();
-            for (int i = t * 4; i < cnt; i += 256 * 4) *(int4 *)(corr + p0 + i) = *(const int4 *)(cs + i);
-            const int lane = t & 63, wave = t >> 6;
-            for (int b = wave; b * 64 < cnt; b += 4) {
-                const int j = b * 64 + lane;
-                int bc, bi;
-                wave_first_argmax(j < cnt ? cs[j] : (int)0x80000000, lane, bc, bi);
-                if (lane == 0) {
-                    bmax[p0 / 64 + b] = bc;
-                    boff[p0 / 64 + b] = bi;
-                }
-            }
-        }
-    }
-    const unsigned long long m = __ballot(nan != 0);
-    if (m) {
-        unsigned tot = nan;
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-        if ((t & 63) == 0) atomicAdd(&sout->nan_count, (unsigned long long)tot);
-    }
-}
-
+// a8 + the correlation of a9 for the decode path.  (A fused kernel -- quantise a chunk and its halo into LDS,
+// correlate from there -- was measured at 34 us: every workgroup strung its loads, the quantiser and the
+// correlation into one dependent chain.  Two streaming kernels take 12 + 14 us.)
 int wfx_dev_quantise_corr(wfx_ctx *ctx, const double *env, uint64_t n, wfx_dev_scalars *d_scal, uint8_t *out, int n1, int n0)
 {
     if (2 * n1 + n0 > 500 || n1 < 0 || n0 < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sync pattern length out of range");
@@ -1256,8 +1251,10 @@ int wfx_dev_quantise_corr(wfx_ctx *ctx, const double *env, uint64_t n, wfx_dev_s
     WFX_TRY(wfx_reserve(ctx, ctx->b_corr, (size_t)n * 4 + 256));
     WFX_TRY(wfx_reserve(ctx, ctx->b_tmp2, nblk * 8));
     int *bmax = (int *)ctx->b_tmp2.p, *boff = bmax + nblk;
-    WFX_LAUNCH(ctx, K_QUANTISE, quantise_corr_kernel, dim3(wfx_stream_grid(n, CORR_CH)), dim3(256), env, n, (const wfx_dev_scalars *)d_scal, out,
-               d_scal, n1, n0, (int *)ctx->b_corr.p, bmax, boff);
+    WFX_LAUNCH(ctx, K_QUANTISE, quantise_kernel, dim3(wfx_stream_grid((n + 7) / 8, 256)), dim3(256), env, n, (const wfx_dev_scalars *)d_scal, out, d_scal,
+               0.0);
+    WFX_LAUNCH(ctx, K_SYNC_CORR, sync_corr_kernel, dim3(wfx_stream_grid(n, CORR_CH)), dim3(256), (const uint8_t *)out, n, n1, n0, (int *)ctx->b_corr.p, bmax,
+               boff);
     return 0;
 }
 
