@@ -1569,7 +1569,7 @@ int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0
 // PIL Image.resize((w, 4h)): width unchanged -> only Pillow's vertical pass
 // (ImagingResampleVertical_8bpc) with BICUBIC coefficients in 22-bit fixed point.
 // ===========================================================================
-__device__ __forceinline__ double pil_bicubic(double x)
+__host__ __device__ __forceinline__ double pil_bicubic(double x)
 {
     const double a = -0.5;
     if (x < 0.0) x = -x;
@@ -1579,7 +1579,7 @@ __device__ __forceinline__ double pil_bicubic(double x)
 }
 
 // coefficients of output row yy (precompute_coeffs + normalize_coeffs_8bpc, Resample.c)
-__device__ __forceinline__ void pil_row_coeffs(int yy, int h_in, int h_out, int &ymin, int &cnt, int kk[5])
+__host__ __device__ __forceinline__ void pil_row_coeffs(int yy, int h_in, int h_out, int &ymin, int &cnt, int kk[5])
 {
     const double scale = (double)h_in / (double)h_out;
     const double filterscale = scale < 1.0 ? 1.0 : scale;
@@ -1622,8 +1622,29 @@ __device__ __forceinline__ void load8_any(const uint8_t *p, unsigned &lo, unsign
 // (h, start) come from the device scalars of a fused decode (s != nullptr) or from the arguments
 // (sharded decode: this GPU renders lines [y0, y0 + gridDim.x) of an image of h_arg lines; d points
 // at global sample 0 of the stream, possibly virtually: only the lines' own bytes are touched)
+// K[r][dy] = fixed-point tap of source row ylo + dy in output row 4y + r (0 outside the row's window)
+struct image_taps {
+    int K[4][5];
+};
+__host__ __device__ __forceinline__ void image_row_taps(int y, int r, int h, int K5[5])
+{
+    const int ylo = y - 2 > 0 ? y - 2 : 0, yhi = y + 2 < h - 1 ? y + 2 : h - 1;
+    int ym, c, k5[5];
+    pil_row_coeffs(4 * y + r, h, 4 * h, ym, c, k5);
+    for (int dy = 0; dy < 5; ++dy) {
+        const int ki = ylo + dy - ym;
+        int k = 0;
+        for (int i = 0; i < 5; ++i) k = (ki == i && i < c && ylo + dy <= yhi) ? k5[i] : k;
+        K5[dy] = k;
+    }
+}
+
+// `interior` = the taps of any source row 2 <= y <= h - 3, evaluated on the host: for the 4x enlargement the
+// filter centre is y + (r + 0.5) / 4 exactly, so Pillow's float64 weights do not depend on y there; only the
+// four edge rows (clamped windows) evaluate the filter on the device
 __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ d, uint64_t n, int w, const wfx_dev_scalars *__restrict__ s,
-                                                   uint8_t *__restrict__ img_base, int h_arg, long long start_arg, int y0, int xchunks)
+                                                   uint8_t *__restrict__ img_base, int h_arg, long long start_arg, int y0, int xchunks,
+                                                   image_taps interior)
 {
     // blockIdx.x = source row * xchunks + chunk of 2048 columns: every thread makes one 8-column strip
     const int h = s ? s->height : h_arg;
@@ -1634,28 +1655,35 @@ __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ 
     uint8_t *img = img_base - (uint64_t)4 * y0 * w;          // row 4*y0 is the first row of the local buffer
     // coefficients of the four output rows: row-uniform, so four lanes evaluate Pillow's float64 filter once
     // and hand the fixed-point taps to the workgroup through LDS
-    __shared__ int sh_ymin[4], sh_cnt[4], sh_kk[4][5];
-    if (threadIdx.x < 4) {
-        int ym, c, k5[5];
-        pil_row_coeffs(4 * y + (int)threadIdx.x, h, 4 * h, ym, c, k5);
-        sh_ymin[threadIdx.x] = ym;
-        sh_cnt[threadIdx.x] = c;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) sh_kk[threadIdx.x][i] = k5[i];
-    }
-    __syncthreads();
-    int ymin[4], cnt[4], kk[4][5];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        ymin[r] = sh_ymin[r];
-        cnt[r] = sh_cnt[r];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) kk[r][i] = sh_kk[r][i];
-    }
+    __shared__ int sh_K[4][5];
     const int ylo = max(y - 2, 0), yhi = min(y + 2, h - 1);      // source rows any of the four can touch
+    int K[4][5];
+    if (y >= 2 && y <= h - 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) K[r][dy] = interior.K[r][dy];
+    } else {
+        if (threadIdx.x < 4) {
+            int K5[5];
+            image_row_taps(y, (int)threadIdx.x, h, K5);
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) sh_K[threadIdx.x][dy] = K5[dy];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) K[r][dy] = __builtin_amdgcn_readfirstlane(sh_K[r][dy]);
+    }
     const int x0 = xc * 2048 + (int)threadIdx.x * 8;
     if (x0 < w) {
         const int nx = min(8, w - x0);
+        // all five source rows are fetched before any is used (a row beyond yhi is clamped to yhi: it is loaded
+        // but matches no tap): with the loads inside the tap loop every row was its own memory round trip
+        unsigned lo[5], hi[5];
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) load8_any(d + start + (uint64_t)min(ylo + dy, yhi) * w + x0, lo[dy], hi[dy]);
         int acc[4][8];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -1663,24 +1691,19 @@ __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ 
             for (int e = 0; e < 8; ++e) acc[r][e] = 1 << 21;
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
-            const int sy = ylo + dy;
-            if (sy > yhi) break;
-            unsigned lo, hi;
-            load8_any(d + start + (uint64_t)sy * w + x0, lo, hi);
             int px[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                px[e] = 255 - (int)((lo >> (8 * e)) & 0xff);
-                px[4 + e] = 255 - (int)((hi >> (8 * e)) & 0xff);
+                px[e] = 255 - (int)((lo[dy] >> (8 * e)) & 0xff);
+                px[4 + e] = 255 - (int)((hi[dy] >> (8 * e)) & 0xff);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ki = sy - ymin[r];
-                if (ki >= 0 && ki < cnt[r]) {
-                    const int k = kk[r][ki];
+                const int k = K[r][dy];
+                // 8-bit pixel x 22-bit fixed-point tap (|tap| < 2^23): the 24-bit multiply-add is full rate,
+                // the 32-bit v_mul_lo_u32 quarter rate -- it made this kernel VALU-bound
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[r][e] += px[e] * k;
-                }
+                for (int e = 0; e < 8; ++e) acc[r][e] += __mul24(px[e], k);
             }
         }
 #pragma unroll
@@ -1692,9 +1715,12 @@ __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ 
                 const int v = acc[r][e] >> 22;
                 o[e] = (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v));
             }
-            if (nx == 8 && (((uintptr_t)dst) & 3) == 0) {
-                ((unsigned *)dst)[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-                ((unsigned *)dst)[1] = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+            const unsigned p0 = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24), p1 = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+            if (nx == 8 && (((uintptr_t)dst) & 7) == 0) {
+                *(uint2 *)dst = make_uint2(p0, p1);               // a wave writes 512 contiguous bytes per instruction
+            } else if (nx == 8 && (((uintptr_t)dst) & 3) == 0) {
+                ((unsigned *)dst)[0] = p0;
+                ((unsigned *)dst)[1] = p1;
             } else {
                 for (int e = 0; e < nx; ++e) dst[e] = (uint8_t)o[e];
             }
@@ -1702,11 +1728,18 @@ __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ 
     }
 }
 
+static image_taps image_interior_taps()
+{
+    image_taps T;
+    for (int r = 0; r < 4; ++r) image_row_taps(8, r, 64, T.K[r]);
+    return T;
+}
+
 int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max, const wfx_dev_scalars *d_scal, uint8_t *img)
 {
     if (h_max <= 0 || w <= 0) return 0;
     const int xchunks = (w + 2047) / 2048;
-    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max * xchunks), dim3(256), d, n, w, d_scal, img, 0, 0ll, 0, xchunks);
+    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max * xchunks), dim3(256), d, n, w, d_scal, img, 0, 0ll, 0, xchunks, image_interior_taps());
     return 0;
 }
 
@@ -1716,7 +1749,7 @@ int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t sta
     if (w <= 0 || y0 < 0 || y0 + rows > h_total) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "image rows out of range");
     const int xchunks = (w + 2047) / 2048;
     WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)rows * xchunks), dim3(256), d - g0, (uint64_t)0, w, (const wfx_dev_scalars *)nullptr, img,
-               h_total, (long long)start, y0, xchunks);
+               h_total, (long long)start, y0, xchunks, image_interior_taps());
     return 0;
 }
 
