@@ -282,7 +282,6 @@ int wfx_decode_run(wfx_ctx *ctx)
     WFX_TRY(wfx_reserve(ctx, ctx->b_dig, n + 64));
     WFX_TRY(wfx_reserve(ctx, ctx->b_img, (size_t)w * 4 * (size_t)(h_max > 0 ? h_max : 1)));
     wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
-    WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
 
     const void *cur = ctx->ext_in ? ctx->ext_in : ctx->b_in.p;      // caller-owned device input (wfx_decode_attach) or the uploaded copy
     int cur_kind = p.in_kind;
@@ -303,7 +302,10 @@ int wfx_decode_run(wfx_ctx *ctx)
         WFX_TRY(wfx_dev_resample_fft(ctx, (const double *)cur, n0, n, (double *)ctx->b_tmp.p));
         cur = ctx->b_tmp.p;
     }
-    WFX_TRY(wfx_dev_notch(ctx, cur, cur_kind, n, p.notch_b, p.notch_a, (double *)ctx->b_audio.p));
+    // the notch is the first kernel that can see the device scalars: its edge workgroup zeroes them
+    bool cleared = false;
+    WFX_TRY(wfx_dev_notch(ctx, cur, cur_kind, n, p.notch_b, p.notch_a, (double *)ctx->b_audio.p, ds, &cleared));
+    if (!cleared) WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
     unsigned *sel_ws = nullptr;
     WFX_TRY(wfx_dev_select_workspace(ctx, n, &sel_ws));           // level-0 histogram is fused into the envelope kernel
     WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, p.hilbert_mode, p.fir_taps, (double *)ctx->b_envraw.p,
@@ -312,8 +314,8 @@ int wfx_decode_run(wfx_ctx *ctx)
     WFX_TRY(wfx_dev_percentiles_fused(ctx, (const double *)ctx->b_env.p, n, ranks, p.gamma_lo, p.gamma_hi, ds));
     WFX_TRY(wfx_dev_quantise_corr(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, p.n1, p.n0_gap));   // a8 + correlation of a9
     WFX_TRY(wfx_dev_sync_pick_precomputed(ctx, n, p.n1, p.n0_gap, p.mindistance, p.frame_samples, w, ds));
-    WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h_max, ds, (uint8_t *)ctx->b_img.p));
-    WFX_HIP(ctx, hipMemcpyAsync(ctx->h_scal, ds, sizeof(wfx_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
+    // the image kernel also writes the scalars to the pinned host copy wfx_decode_result reads
+    WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h_max, ds, (uint8_t *)ctx->b_img.p, ctx->h_scal));
     ctx->ran = true;
     return 0;
 }

@@ -186,8 +186,10 @@ int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t nu
 // wfx_stages.hip
 int wfx_dev_merge(wfx_ctx *ctx, const int16_t *lr, uint64_t n, double *out);
 int wfx_dev_i16_to_f64(wfx_ctx *ctx, const int16_t *in, uint64_t n, double *out);
+// clear (optional): device scalars the kernel zeroes on its way (saves the decode's memset launch);
+// *cleared tells whether the form that ran did it
 int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3],
-                  const double a[3], double *out);
+                  const double a[3], double *out, wfx_dev_scalars *clear = nullptr, bool *cleared = nullptr);
 int wfx_dev_median5(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env, unsigned *l0hist);
 int wfx_dev_select(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4],
                    wfx_dev_scalars *d_scal);
@@ -208,8 +210,9 @@ int wfx_dev_sync_pick_precomputed(wfx_ctx *ctx, uint64_t n, int n1, int n0, int6
 int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0,
                       int64_t mindistance, double frame_samples, int width,
                       wfx_dev_scalars *d_scal);
+// mirror (optional): pinned host copy of the scalars, written by the kernel itself (saves the D2H blit launch)
 int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max,
-                  const wfx_dev_scalars *d_scal, uint8_t *img);
+                  const wfx_dev_scalars *d_scal, uint8_t *img, wfx_dev_scalars *mirror = nullptr);
 int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t start, int w, int h_total, int y0, int rows,
                        uint8_t *img);
 int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out,

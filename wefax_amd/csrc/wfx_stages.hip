@@ -98,7 +98,7 @@ __device__ __forceinline__ double biquad_step(const notch_coef &c, double xi, do
 
 template <typename TIN>
 __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x, uint64_t n, notch_coef c, double *__restrict__ y, unsigned interior_blocks,
-                                                       int exact_edges)
+                                                       int exact_edges, wfx_dev_scalars *__restrict__ clear)
 {
     constexpr int TLEN = 1024 + 2 * NOTCH_K;
     constexpr int NPRE = (TLEN + 255) / 256;
@@ -166,6 +166,8 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
         return;
     }
     // ---- edge workgroup -------------------------------------------------------
+    if (clear)       // the decode's device scalars start from zero (this is the first kernel of the path that sees them)
+        for (int i = t; i < (int)(sizeof(wfx_dev_scalars) / 8); i += 256) ((unsigned long long *)clear)[i] = 0ull;
     if (n < NOTCH_SMALL) {      // (only reached through wfx_dev_notch: both ends are true edges)
         // whole signal with the exact recurrence (one thread)
         if (t == 0) {
@@ -369,8 +371,10 @@ static int notch_general(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, 
     return 0;
 }
 
-int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out)
+int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out, wfx_dev_scalars *clear,
+                  bool *cleared)
 {
+    if (cleared) *cleared = false;
     if (n <= NOTCH_PAD)
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "The length of the input vector x must be greater than padlen, which is 9.");
     notch_coef c;
@@ -384,9 +388,10 @@ int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const d
         ib = notch_grid(n - 2 * NOTCH_EDGE);
     }
     if (in_kind == WFX_IN_I16_MONO)
-        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + 1), dim3(256), (const short *)in, n, c, out, ib, 3);
+        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + 1), dim3(256), (const short *)in, n, c, out, ib, 3, clear);
     else
-        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<double>, dim3(ib + 1), dim3(256), (const double *)in, n, c, out, ib, 3);
+        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<double>, dim3(ib + 1), dim3(256), (const double *)in, n, c, out, ib, 3, clear);
+    if (cleared) *cleared = clear != nullptr;
     return 0;
 }
 
@@ -400,9 +405,9 @@ int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
     notch_prepare(c, b, a);
     const unsigned ib = notch_grid(n - 2 * NOTCH_K);
     if (in_kind == WFX_IN_I16_MONO)
-        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const short *)in, n, c, out, ib, edge_flags & 3);
+        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const short *)in, n, c, out, ib, edge_flags & 3, (wfx_dev_scalars *)nullptr);
     else if (in_kind == WFX_IN_F64_MONO)
-        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<double>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const double *)in, n, c, out, ib, edge_flags & 3);
+        WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<double>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const double *)in, n, c, out, ib, edge_flags & 3, (wfx_dev_scalars *)nullptr);
     else
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "notch: input kind %d", in_kind);
     return 0;
@@ -1644,8 +1649,12 @@ __host__ __device__ __forceinline__ void image_row_taps(int y, int r, int h, int
 // four edge rows (clamped windows) evaluate the filter on the device
 __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ d, uint64_t n, int w, const wfx_dev_scalars *__restrict__ s,
                                                    uint8_t *__restrict__ img_base, int h_arg, long long start_arg, int y0, int xchunks,
-                                                   image_taps interior)
+                                                   image_taps interior, wfx_dev_scalars *__restrict__ mirror)
 {
+    // the scalars of the decode (peaks, start frame, height, levels) go to the caller's pinned host copy from here
+    if (mirror && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < (int)(sizeof(wfx_dev_scalars) / 8); i += 256)
+            ((unsigned long long *)mirror)[i] = ((const unsigned long long *)s)[i];
     // blockIdx.x = source row * xchunks + chunk of 2048 columns: every thread makes one 8-column strip
     const int h = s ? s->height : h_arg;
     const int y = y0 + (int)(blockIdx.x / (unsigned)xchunks);
@@ -1735,11 +1744,14 @@ static image_taps image_interior_taps()
     return T;
 }
 
-int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max, const wfx_dev_scalars *d_scal, uint8_t *img)
+int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max, const wfx_dev_scalars *d_scal, uint8_t *img, wfx_dev_scalars *mirror)
 {
-    if (h_max <= 0 || w <= 0) return 0;
+    if (h_max <= 0 || w <= 0) {
+        if (mirror) WFX_HIP(ctx, hipMemcpyAsync(mirror, d_scal, sizeof(wfx_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    }
     const int xchunks = (w + 2047) / 2048;
-    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max * xchunks), dim3(256), d, n, w, d_scal, img, 0, 0ll, 0, xchunks, image_interior_taps());
+    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max * xchunks), dim3(256), d, n, w, d_scal, img, 0, 0ll, 0, xchunks, image_interior_taps(), mirror);
     return 0;
 }
 
@@ -1749,7 +1761,7 @@ int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t sta
     if (w <= 0 || y0 < 0 || y0 + rows > h_total) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "image rows out of range");
     const int xchunks = (w + 2047) / 2048;
     WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)rows * xchunks), dim3(256), d - g0, (uint64_t)0, w, (const wfx_dev_scalars *)nullptr, img,
-               h_total, (long long)start, y0, xchunks, image_interior_taps());
+               h_total, (long long)start, y0, xchunks, image_interior_taps(), (wfx_dev_scalars *)nullptr);
     return 0;
 }
 
