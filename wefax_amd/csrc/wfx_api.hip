@@ -340,8 +340,8 @@ int wfx_decode_result(wfx_ctx *ctx, wfx_decode_info *info)
     info->width = ctx->dp.width;
     info->height = s.height;
     if (getenv("WFX_DEBUG"))
-        fprintf(stderr, "[wfx] sync_pick: ops %lld chunks %lld pick_cycles %lld loop_cycles %lld total_cycles %lld\n", s.dbg[0], s.dbg[1],
-                s.dbg[2], s.dbg[3], s.dbg[4]);
+        fprintf(stderr, "[wfx] sync_pick: ops %lld chunks %lld pick_cycles %lld loop_cycles %lld total_cycles %lld | fused steps %lld: reads %lld reduce %lld\n",
+                s.dbg[0], s.dbg[1], s.dbg[2], s.dbg[3], s.dbg[4], s.dbg[7], s.dbg[5], s.dbg[6]);
     for (int i = 0; i <= WFX_MAX_PEAKS; ++i) {
         info->peak_pos[i] = s.peak_pos[i];
         info->first_pos[i] = s.first_pos[i];

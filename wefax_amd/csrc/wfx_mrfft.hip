@@ -792,8 +792,27 @@ static bool mr_make_plan(long long L, mr_plan_host &pl)
     long long P = 1;
     std::vector<int> cur, best;
     double best_cost = 1e30;
-    if (mr2_search(L, 0, 0.0, cur, best_cost, best) && !best.empty()) {
+    bool forced = false;
+    if (const char *e = getenv("WFX_MR2_PLAN")) {       // experiments: "7x13,7x25,15x15" = the passes in this order
+        const int np = (int)(sizeof(g_mr2_pairs) / sizeof(g_mr2_pairs[0]));
+        long long prod = 1;
+        int a = 0, b = 0, used = 0;
+        while (sscanf(e, "%dx%d%n", &a, &b, &used) == 2) {
+            int idx = -1;
+            for (int i = 0; i < np; ++i)
+                if (g_mr2_pairs[i].ra == a && g_mr2_pairs[i].rb == b) idx = i;
+            if (idx < 0) break;
+            best.push_back(idx);
+            prod *= (long long)a * b;
+            e += used;
+            if (*e == ',') ++e;
+        }
+        forced = prod == L && (int)best.size() <= MR_MAXPASS;
+        if (!forced) best.clear();
+    }
+    if (forced || (mr2_search(L, 0, 0.0, cur, best_cost, best) && !best.empty())) {
         // small radices first: the first pass pays an extra LDS transposition, the last forward pass the spectrum
+        if (!forced)
         std::sort(best.begin(), best.end(), [](int a, int b) {
             return g_mr2_pairs[a].ra * g_mr2_pairs[a].rb < g_mr2_pairs[b].ra * g_mr2_pairs[b].rb;
         });

@@ -1307,7 +1307,7 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
     long long pos = 0;
     int val = 0, np = 1, hit = 0;
 #ifdef WFX_PICK_STATS      // diagnostic build only (python -m wefax_amd.build --pick-stats): cycle stamps per phase
-    long long n_ops = 0, n_chunks = 0, t_pick = 0, t_all = 0;
+    long long n_ops = 0, n_chunks = 0, t_pick = 0, t_all = 0, t_rd = 0, t_red = 0, n_spec = 0;
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
 #define PICK_STAT(x) x
 #else
@@ -1400,37 +1400,42 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                     const int b_lo = li >> 6, b_hi = ll >> 6;
                     const int jh0 = (b_lo << 6) + hl, jh1 = jh0 + 32, jt0 = (b_hi << 6) + hl, jt1 = jt0 + 32;
                     const int b1 = b_lo + 1 + hl, b2 = b1 + 32, b3 = b2 + 32;
+                    PICK_STAT(const long long ts0 = (long long)__builtin_amdgcn_s_memtime(); ++n_spec;)
                     const int vb_l = cs[sp];                  // (issued with the other reads, used after the reductions)
                     const int ch0 = cs[jh0], ch1 = cs[jh1], ct0 = cs[jt0], ct1 = cs[jt1];
                     const int2 s1 = sm2[b1], s2 = sm2[b2], s3 = sm2[b3];
-                    const bool vh0 = (jh0 >= li) & (jh0 <= ll);
-                    int c = vh0 ? ch0 : CMIN, ci = vh0 ? jh0 : 0x7fffffff;
-                    const bool vh1 = (jh1 >= li) & (jh1 <= ll) & (ch1 > c);
-                    c = vh1 ? ch1 : c;
-                    ci = vh1 ? jh1 : ci;
-                    const bool t1 = (b1 < b_hi) & (s1.x > c);
-                    c = t1 ? s1.x : c;
-                    ci = t1 ? s1.y : ci;
-                    const bool t2 = (b2 < b_hi) & (s2.x > c);
-                    c = t2 ? s2.x : c;
-                    ci = t2 ? s2.y : ci;
-                    const bool t3 = (b3 < b_hi) & (s3.x > c);
-                    c = t3 ? s3.x : c;
-                    ci = t3 ? s3.y : ci;
-                    const bool tt0 = (b_hi > b_lo) & (jt0 <= ll) & (ct0 > c);
-                    c = tt0 ? ct0 : c;
-                    ci = tt0 ? jt0 : ci;
-                    const bool tt1 = (b_hi > b_lo) & (jt1 <= ll) & (ct1 > c);
-                    c = tt1 ? ct1 : c;
-                    ci = tt1 ? jt1 : ci;
+                    // candidates stay apart by source (head block halves, three summary groups, tail block halves): the
+                    // sources follow each other in index order and inside a source lane order is index order, so the
+                    // first maximum is "first source that holds the maximum, lowest lane" -- one DPP max chain, then
+                    // ballots and scalar code instead of a second (min-index) DPP chain
+                    const int v_h0 = ((jh0 >= li) & (jh0 <= ll)) ? ch0 : CMIN;
+                    const int v_h1 = ((jh1 >= li) & (jh1 <= ll)) ? ch1 : CMIN;
+                    const int v_s1 = b1 < b_hi ? s1.x : CMIN, v_s2 = b2 < b_hi ? s2.x : CMIN, v_s3 = b3 < b_hi ? s3.x : CMIN;
+                    const int v_t0 = ((b_hi > b_lo) & (jt0 <= ll)) ? ct0 : CMIN;
+                    const int v_t1 = ((b_hi > b_lo) & (jt1 <= ll)) ? ct1 : CMIN;
+                    const int c = max(max(max(v_h0, v_h1), max(v_s1, v_s2)), max(max(v_s3, v_t0), v_t1));
                     const int vb = __builtin_amdgcn_readfirstlane(vb_l);
+                    PICK_STAT(const long long ts1 = (long long)__builtin_amdgcn_s_memtime(); t_rd += ts1 - ts0;)
                     int bca, bcb;
                     half_max_i32(c, bca, bcb);
-                    // smallest index among the lanes of a half that hold its maximum
-                    int fa, fb;
-                    half_min_i32(c == (hiq ? bcb : bca) ? ci : 0x7fffffff, fa, fb);
+                    const int M = hiq ? bcb : bca;
+                    const unsigned long long e_h0 = __ballot(v_h0 == M), e_h1 = __ballot(v_h1 == M), e_s1 = __ballot(v_s1 == M),
+                                             e_s2 = __ballot(v_s2 == M), e_s3 = __ballot(v_s3 == M), e_t0 = __ballot(v_t0 == M),
+                                             e_t1 = __ballot(v_t1 == M);
+                    // index of the first maximum of half `sh` (0: lanes 0..31, 32: lanes 32..63); blo / bhi = its range's end blocks
+                    auto first_in = [&](int sh, int blo, int bhi) {
+                        const unsigned h0 = (unsigned)(e_h0 >> sh), h1 = (unsigned)(e_h1 >> sh), q1 = (unsigned)(e_s1 >> sh), q2 = (unsigned)(e_s2 >> sh),
+                                       q3 = (unsigned)(e_s3 >> sh), t0 = (unsigned)(e_t0 >> sh), t1 = (unsigned)(e_t1 >> sh);
+                        if (h0) return (blo << 6) + __builtin_ctz(h0);
+                        if (h1) return (blo << 6) + 32 + __builtin_ctz(h1);
+                        if (q1) return __builtin_amdgcn_readlane(s1.y, sh + __builtin_ctz(q1));
+                        if (q2) return __builtin_amdgcn_readlane(s2.y, sh + __builtin_ctz(q2));
+                        if (q3) return __builtin_amdgcn_readlane(s3.y, sh + __builtin_ctz(q3));
+                        if (t0) return (bhi << 6) + __builtin_ctz(t0);
+                        return (bhi << 6) + 32 + __builtin_ctz(t1);
+                    };
                     if (bca > val) {                      // the window still held something greater: plain step, speculation unused
-                        rpos = fa;
+                        rpos = first_in(0, i >> 6, (rpos + mind32) >> 6);
                         val = bca;
                         i = sp;                           // == old rpos + mind + 1, the end of the range just searched + 1
                         continue;
@@ -1443,12 +1448,13 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                     rpos = sp;
                     val = vb;
                     if (bcb > val) {
-                        rpos = fb;
+                        rpos = first_in(32, (sp + 1) >> 6, (sp + mind32) >> 6);
                         val = bcb;
                     }
                     i = sp + mind32 + 1;
                     continue;
                 }
+                PICK_STAT(const long long tq0 = (long long)__builtin_amdgcn_s_memtime();)
                 if (i - rpos > mind32) {
                     if (lane == 0) {
                         pk_s[np - 1] = (long long)p0 + rpos;
@@ -1473,6 +1479,7 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
                     }
                     i = ll + 1;
                 }
+                PICK_STAT(t_red += (long long)__builtin_amdgcn_s_memtime() - tq0;)
             }
             pos = (long long)p0 + rpos;
             if (hit && lane == 0) done_flag = 1;
@@ -1486,6 +1493,9 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
         s->dbg[1] = n_chunks;
         s->dbg[2] = t_pick;
         s->dbg[3] = t_all;
+        s->dbg[5] = t_rd;
+        s->dbg[6] = t_red;
+        s->dbg[7] = n_spec;
     })
     if (t == 0) {
         pk_s[np - 1] = pos;
@@ -1502,17 +1512,14 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
     __syncthreads();
     if (t >= 64) return;
     // ---- grouping (wefax.py:269-294): the regularity flags become a bit mask in scalar registers (two ballots),
-    // so the two sequential scans below run without a single LDS round trip
+    // so the sequential scan below runs without a single LDS round trip; the results are stored by the whole wave
     static_assert(WFX_MAX_PEAKS <= 127, "the flag mask holds 128 peaks");
     const unsigned long long okm0 = __ballot(t < np && ok_s[t] != 0);
     const unsigned long long okm1 = __ballot(64 + t < np && ok_s[64 + t] != 0);
-    if (t != 0) return;
-    s->npeaks = np;
-    s->hit_limit = hit_s;
-    const long long *pk = pk_s;
     auto okbit = [&](int i) { return (int)(((i < 64 ? okm0 >> i : okm1 >> (i - 64))) & 1ull); };
-    int nclear = 0;
-    for (int i = 1; i < np - 1; ++i) nclear += okbit(i);
+    // nclear = number of set flags among peaks 1 .. np - 2
+    auto below = [](unsigned long long m, int k) { return k <= 0 ? 0ull : (k >= 64 ? m : (m & ((1ull << k) - 1))); };
+    const int nclear = __popcll(below(okm0, np - 1) & ~1ull) + __popcll(below(okm1, np - 1 - 64));
     int nclosed = 0, best_start = 0, best_len = -1, g_start = 0, g_len = 0;
     for (int i = 1; i < nclear - 1; ++i) {
         if (okbit(i)) {
@@ -1528,17 +1535,18 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
         }
     }
     long long start = 0;
-    if (nclosed == 0) {
-        s->no_group = 1;
-        s->n_phasing = 0;
-    } else {
-        s->no_group = 0;
-        s->n_phasing = best_len;
-        for (int k = 0; k < best_len; ++k) s->phasing[k] = pk[best_start + k];
-        if (best_len > 0) start = pk[best_start + best_len - 1];     // wefax.py:80
+    if (nclosed != 0) {
+        for (int k = t; k < best_len; k += 64) s->phasing[k] = pk_s[best_start + k];
+        if (best_len > 0) start = pk_s[best_start + best_len - 1];     // wefax.py:80
     }
-    s->start_frame = start;
-    s->height = (nclosed == 0 || width <= 0) ? 0 : (int)(((long long)n - start) / width);
+    if (t == 0) {
+        s->npeaks = np;
+        s->hit_limit = hit_s;
+        s->no_group = nclosed == 0 ? 1 : 0;
+        s->n_phasing = nclosed == 0 ? 0 : best_len;
+        s->start_frame = start;
+        s->height = (nclosed == 0 || width <= 0) ? 0 : (int)(((long long)n - start) / width);
+    }
     PICK_STAT(s->dbg[4] = (long long)__builtin_amdgcn_s_memtime() - t_begin;)
 }
 
