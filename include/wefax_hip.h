@@ -170,6 +170,11 @@ int wfx_decode_attach(wfx_ctx *ctx, const void *dev_in, const wfx_decode_params 
 int wfx_decode_run(wfx_ctx *ctx);
 /* wait and read back the scalars */
 int wfx_decode_result(wfx_ctx *ctx, wfx_decode_info *info);
+/* diagnostics of the last decode (not part of the reference's interface): out[7] = which form of the peak scan
+ * (wefax.py:226-261) produced the peaks: 1 = scans of overlapping segments joined at a common appended peak,
+ * -1 = the join failed and the sequential scan ran, 0 = sequential scan only; out[0..6]: cycle stamps of a
+ * `--pick-stats` build, else 0 */
+int wfx_debug_counters(wfx_ctx *ctx, long long out[8]);
 /* copy one stage buffer to the host (bytes must match the buffer's size) */
 int wfx_decode_fetch(wfx_ctx *ctx, int buffer_id, void *host_out, size_t bytes);
 /* device address of a stage buffer (for collectives on the final image) */

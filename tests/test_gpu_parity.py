@@ -276,6 +276,57 @@ def test_sync_correlation_and_peaks_bit_exact(ctx, lpm):
     assert ctx.sync_peaks(short, n1, n0, mind) == wo.pick_peaks(wo.sync_correlation(short, n1, n0), mind)
 
 
+def _sync_stream(kind, rng, w, n1, n0, lines):
+    n = lines * w + 321
+    L = 2 * n1 + n0
+    if kind == "noise":
+        return rng.integers(0, 256, size=n).astype(np.uint8)
+    if kind == "staircase":       # the level drops every 4000 samples (< mindistance) for 48000 samples: the correlation keeps
+        d = rng.integers(90, 256, size=n).astype(np.uint8)      # rising, the last peak creeps along and no peak is appended
+        for k in range(0, n - 300, w):                          # for three segments on end -- their scans share no appended peak
+            j = k + int(rng.integers(0, 40))
+            d[j:j + L] = rng.integers(0, 30, size=L)
+        lo = 30 * w
+        d[lo:lo + 48000] = (240 - 20 * (np.arange(48000) // 4000)).astype(np.uint8)
+        return d
+    d = rng.integers(90, 256, size=n).astype(np.uint8)
+    first = 60 * w if kind == "silence_then_pulses" else 0
+    if kind == "silence_then_pulses":
+        d[:first] = 128
+    for k in range(first, n - 300, w):
+        j = k + int(rng.integers(0, 40))
+        d[j:j + L] = rng.integers(0, 30, size=L)
+    if kind == "dropouts":        # a few lines without a pulse: the scan has to re-lock
+        for k in range(7 * w, n - 3 * w, 23 * w):
+            d[k:k + 2 * w] = rng.integers(100, 140, size=2 * w)
+    return d
+
+
+@pytest.mark.parametrize("kind,lpm,lines,want_form", [("pulses", 120, 260, 1), ("pulses", 240, 300, 1), ("pulses", 90, 200, 1),
+                                                      ("dropouts", 120, 260, 1), ("silence_then_pulses", 120, 300, None),
+                                                      ("noise", 120, 220, None), ("staircase", 120, 230, -1), ("pulses", 120, 40, 1)])
+def test_peak_scan_in_segments_equals_the_sequential_scan(ctx, monkeypatch, kind, lpm, lines, want_form):
+    """The picker scans overlapping segments on all CUs and joins them where two scans append the same peak; when a
+    join is missing it runs the sequential scan.  Either way: the sequential scan's peaks (and the oracle's)."""
+    from oracle import wefax_oracle as wo
+    rng = np.random.default_rng(lines + lpm)
+    frame_len = 1 / (lpm / 60)
+    n1, n0, mind = wo.sync_constants(11025, frame_len)
+    w = int(frame_len * 11025)
+    d = _sync_stream(kind, rng, w, n1, n0, lines)
+    got = ctx.sync_peaks(d, n1, n0, mind)
+    form = ctx.debug_counters()[7]
+    monkeypatch.setenv("WFX_PICK_SEG", "0")
+    ref = ctx.sync_peaks(d, n1, n0, mind)
+    assert ctx.debug_counters()[7] == 0
+    monkeypatch.delenv("WFX_PICK_SEG")
+    assert got == ref
+    assert got == wo.pick_peaks(wo.sync_correlation(d, n1, n0), mind)
+    assert form in (1, -1)
+    if want_form is not None:
+        assert form == want_form, (kind, form)
+
+
 def test_sync_peaks_degenerate_inputs(ctx):
     from oracle import wefax_oracle as wo
     n1, n0, mind = wo.sync_constants(11025, 0.5)

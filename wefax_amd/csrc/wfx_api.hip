@@ -340,13 +340,22 @@ int wfx_decode_result(wfx_ctx *ctx, wfx_decode_info *info)
     info->width = ctx->dp.width;
     info->height = s.height;
     if (getenv("WFX_DEBUG"))
-        fprintf(stderr, "[wfx] sync_pick: ops %lld chunks %lld pick_cycles %lld loop_cycles %lld total_cycles %lld | fused steps %lld: reads %lld reduce %lld\n",
-                s.dbg[0], s.dbg[1], s.dbg[2], s.dbg[3], s.dbg[4], s.dbg[7], s.dbg[5], s.dbg[6]);
+        fprintf(stderr, "[wfx] sync_pick: form %lld ops %lld chunks %lld pick_cycles %lld loop_cycles %lld total_cycles %lld | fused steps %lld: reads %lld\n",
+                s.dbg[7], s.dbg[0], s.dbg[1], s.dbg[2], s.dbg[3], s.dbg[4], s.dbg[6], s.dbg[5]);
     for (int i = 0; i <= WFX_MAX_PEAKS; ++i) {
         info->peak_pos[i] = s.peak_pos[i];
         info->first_pos[i] = s.first_pos[i];
         info->phasing[i] = s.phasing[i];
     }
+    return 0;
+}
+
+int wfx_debug_counters(wfx_ctx *ctx, long long out[8])
+{
+    CHECK_CTX(ctx);
+    if (!out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 8; ++i) out[i] = ctx->h_scal->dbg[i];
     return 0;
 }
 

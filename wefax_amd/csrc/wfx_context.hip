@@ -109,7 +109,7 @@ void wfx_destroy(wfx_ctx *ctx)
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     wfx_devbuf *bufs[] = {&ctx->b_in, &ctx->b_x, &ctx->b_audio, &ctx->b_work, &ctx->b_work2, &ctx->b_envraw,
                           &ctx->b_env, &ctx->b_dig, &ctx->b_corr, &ctx->b_img, &ctx->b_hist, &ctx->b_tmp,
-                          &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps, &ctx->b_cand, &ctx->b_pcoef};
+                          &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps, &ctx->b_cand, &ctx->b_pcoef, &ctx->b_seg};
     for (auto *b : bufs) free_buf(*b);
     for (auto &kv : ctx->plans) free_buf(kv.second.bhat);
     for (auto &kv : ctx->hplans) free_buf(kv.second.bhat);

@@ -78,7 +78,7 @@ struct wfx_ctx {
 
     // named device buffers (grown on demand, reused across calls)
     wfx_devbuf b_in, b_x, b_audio, b_work, b_work2, b_envraw, b_env, b_dig, b_corr,
-        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand, b_pcoef;
+        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand, b_pcoef, b_seg;
     bool w256_ready = false;
     bool force_pow2 = false;     // WFX_HILBERT_FFT_POW2: always use the zero-padded power-of-two convolution
     std::map<uint64_t, wfx_bs_plan> plans;    // Bluestein chirp filters (resampler, cross-check mode)

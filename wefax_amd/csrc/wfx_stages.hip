@@ -1288,9 +1288,30 @@ __device__ __forceinline__ bool dev_ok(double frame_samples, long long x)
     return (frame_samples + 500 > (double)x) && ((double)x > frame_samples - 500);
 }
 
+// ---- the scan in segments ------------------------------------------------------------------------------------
+// The scan is a state machine whose state right after a peak is appended at position i is (i, corr[i]) -- it has
+// forgotten everything before.  So a scan started anywhere, from the made-up state "a peak was just appended
+// here", IS the reference's scan from the first position at which both append a peak (the sync pulses pull any
+// start onto the same train within a peak or two).  MODE 1 runs one such scan per workgroup over a window of
+// PICK_CH positions starting every PICK_SEG (all CUs at once, ~7 us); the MODE 0 kernel then joins the lists:
+// segment k is cut at its last appended position that segment k + 1 also appended at, and continues there.
+// Peaks, first positions, count and the 100-peak stop are the reference's by construction; when a join is
+// missing (or the segments do not reach the 100th peak or the end of the data) the MODE 0 kernel simply runs
+// the sequential scan as before.
+#define PICK_SEG 16384
+#define PICK_SEG_MAX 128                 // segments joined by one wave, two per lane
+#define PICK_SEG_ENT 16                  // list entries per segment (a window holds 32768 / mind + 2 peaks)
+struct pick_seg {
+    int n;                               // entries: completed peaks, then (tail != 0) one appended but not completed
+    int tail, end, overflow;             // end: the window reached the end of the data (every entry is final)
+    long long first[PICK_SEG_ENT];       // position at which the peak was appended
+    long long fin[PICK_SEG_ENT];         // its final position (undefined for the tail entry)
+};
+
+template <int MODE>
 __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__restrict__ corr, const int *__restrict__ bmax, const int *__restrict__ boff,
                                                                  uint64_t n, int n1, int n0, long long mind, double frame_samples, int width,
-                                                                 wfx_dev_scalars *__restrict__ s)
+                                                                 wfx_dev_scalars *__restrict__ s, pick_seg *__restrict__ seg, int nseg)
 {
     __shared__ __attribute__((aligned(16))) int cs[PICK_CH + 64];
     __shared__ int2 sm2[PICK_CH / 64 + 192];                  // per 64-block: (max correlation, first index of it)
@@ -1317,6 +1338,106 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
         done_flag = 0;
         first_s[0] = 0;
     }
+    // ---- MODE 0: join the segment scans (see above); `joined` != 0 replaces the sequential scan below ----
+    __shared__ int join_a[PICK_SEG_MAX], join_b[PICK_SEG_MAX], join_off[PICK_SEG_MAX], join_res[PICK_SEG_MAX];
+    __shared__ int join_ok, join_u, join_np, join_hit, join_known;
+    int joined = 0;
+    if (MODE == 0 && seg != nullptr && nseg > 0 && nseg <= PICK_SEG_MAX) {
+        // the lists (272 bytes per segment) are read many times: bring them into LDS first (the chunk buffer is idle)
+        const pick_seg *gseg = seg;
+        pick_seg *lseg = (pick_seg *)cs;
+        static_assert(sizeof(pick_seg) % 8 == 0 && PICK_SEG_MAX * sizeof(pick_seg) <= sizeof(cs), "segment lists fit the chunk buffer");
+        for (int w = t; w < nseg * (int)(sizeof(pick_seg) / 8); w += PICK_THREADS) ((long long *)lseg)[w] = ((const long long *)gseg)[w];
+        __syncthreads();
+        seg = lseg;
+        if (t < 64) {
+            // phase A, a lane per pair (k, k + 1): the last position segment k appended a peak at that k + 1 also appended at
+            for (int k = lane; k < nseg; k += 64) {
+                int a = -1, b = -1;
+                if (k + 1 < nseg) {
+                    const int ek = seg[k].n + seg[k].tail, en = seg[k + 1].n + seg[k + 1].tail;
+                    for (int ia = ek - 1; ia >= 0 && a < 0; --ia) {
+                        const long long f = seg[k].first[ia];
+                        for (int ib = 0; ib < en; ++ib)
+                            if (seg[k + 1].first[ib] == f) {
+                                a = ia;
+                                b = ib;
+                                break;
+                            }
+                    }
+                }
+                join_a[k] = a;
+                join_b[k] = b;
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            // phase B, sequential over the segments (a few instructions each): where each one is entered and left
+            int res = 0, off = 0, u = 0, ok = 1;
+            for (int k = 0; k < nseg; ++k) {
+                u = k;
+                join_res[k] = res;
+                join_off[k] = off;
+                if (seg[k].overflow || res > seg[k].n + seg[k].tail) {
+                    ok = 0;
+                    break;
+                }
+                const int a = join_a[k];
+                const bool leave = k + 1 < nseg && a >= res && !seg[k].end && off + (a - res) < WFX_MAX_PEAKS;
+                if (!leave) break;                           // the list of segment k is used to its end
+                off += a - res;
+                res = join_b[k];
+            }
+            const int res_u = join_res[u], off_u = join_off[u];
+            const int known = ok ? off_u + max(seg[u].n - res_u, 0) : 0;     // peaks with a final position
+            int npj = 0, hitj = 0;
+            if (ok && res_u <= seg[u].n + seg[u].tail) {
+                if (known >= WFX_MAX_PEAKS) {
+                    npj = WFX_MAX_PEAKS;
+                    hitj = 1;
+                } else if (known == WFX_MAX_PEAKS - 1 && seg[u].tail && res_u <= seg[u].n) {
+                    npj = WFX_MAX_PEAKS;                     // the 100th peak is the one appended last: the scan stops there
+                    hitj = 1;
+                } else if (seg[u].end) {
+                    npj = known;                             // the data ended first
+                } else
+                    ok = 0;
+            } else
+                ok = 0;
+            if (npj < 1) ok = 0;
+            join_ok = ok;
+            join_u = u;
+            join_np = npj;
+            join_hit = hitj;
+            join_known = known;
+        }
+        __syncthreads();
+        joined = join_ok;
+        if (joined) {
+            if (t < 64) {
+                // phase C, a lane per segment: its stretch of the list goes to the peak arrays
+                const int u = join_u;
+                for (int k = lane; k <= u; k += 64) {
+                    const int res = join_res[k], off = join_off[k];
+                    const int stop = k < u ? join_a[k] : seg[k].n;
+                    for (int e = res; e < stop; ++e) {
+                        const int g = off + (e - res);
+                        if (g < WFX_MAX_PEAKS) {
+                            first_s[g] = seg[k].first[e];
+                            pk_s[g] = g == WFX_MAX_PEAKS - 1 ? seg[k].first[e] : seg[k].fin[e];    // the scan stops on appending the 100th
+                        }
+                    }
+                    if (k == u && seg[k].tail && join_known == WFX_MAX_PEAKS - 1 && res <= seg[k].n) {
+                        first_s[WFX_MAX_PEAKS - 1] = seg[k].first[seg[k].n];
+                        pk_s[WFX_MAX_PEAKS - 1] = seg[k].first[seg[k].n];
+                    }
+                }
+            }
+            np = join_np;
+            hit = join_hit;
+            __syncthreads();
+        }
+    }
     // the correlation buffer is padded to a multiple of 4 ints beyond ncorr, so whole int4s are loaded
     int4 pre[PICK_PER_THREAD / 4];
     int pre_c = CMIN, pre_o = 0;
@@ -1332,14 +1453,19 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
             pre_o = bg < nblk ? boff[bg] : 0;
         }
     };
-    if (ncorr) prefetch(0);
-    for (uint64_t p0 = 0; p0 < ncorr; p0 += PICK_CH) {
+    // MODE 1: exactly one window, starting at this workgroup's segment
+    const uint64_t p_begin = MODE == 1 ? (uint64_t)blockIdx.x * PICK_SEG : 0;
+    const uint64_t p_stop = joined ? 0 : (MODE == 1 ? min(ncorr, p_begin + 1) : ncorr);
+    int cnt_last = 0;
+    if (p_begin < p_stop) prefetch(p_begin);
+    for (uint64_t p0 = p_begin; p0 < p_stop; p0 += PICK_CH) {
         const int cnt = (int)min((uint64_t)PICK_CH, ncorr - p0);
+        cnt_last = cnt;
 #pragma unroll
         for (int k = 0; k < PICK_PER_THREAD / 4; ++k) ((int4 *)cs)[k * PICK_THREADS + t] = pre[k];
         if (t < PICK_CH / 64) sm2[t] = make_int2(pre_c, t * 64 + pre_o);
         lds_barrier();
-        if (p0 + PICK_CH < ncorr) prefetch(p0 + PICK_CH);      // in flight while this chunk is scanned
+        if (MODE == 0 && p0 + PICK_CH < ncorr) prefetch(p0 + PICK_CH);      // in flight while this chunk is scanned
         if (t < 64) {
             PICK_STAT(const long long t0 = (long long)__builtin_amdgcn_s_memtime(); ++n_chunks;)
             // chunk-local 32-bit coordinates; the scan state is forced into scalar registers
@@ -1347,6 +1473,12 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
             const int mind32 = (int)mind;
             int rpos = __builtin_amdgcn_readfirstlane((int)(pos - (long long)p0));   // may be negative
             int i = 0;
+            if (MODE == 1 && blockIdx.x > 0) {                 // made-up state: a peak was just appended at the segment's first position
+                rpos = 0;
+                val = __builtin_amdgcn_readfirstlane(cs[0]);
+                i = 1;
+                if (lane == 0) first_s[0] = (long long)p0;
+            }
             // "first maximum of [li, ll]" for the whole wave: (value, index), index = 0x7fffffff where no lane holds it.
             // Every LDS read of the range is issued first (head block, the whole blocks in between through their
             // summaries, tail block), then combined in index order, branch-free.
@@ -1494,13 +1626,35 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
         s->dbg[2] = t_pick;
         s->dbg[3] = t_all;
         s->dbg[5] = t_rd;
-        s->dbg[6] = t_red;
-        s->dbg[7] = n_spec;
+        s->dbg[6] = n_spec;
     })
+    if (MODE == 1) {
+        // this segment's list: every peak but the last is complete (the next one has been appended); the last one
+        // is complete only if the window ended with the data
+        __syncthreads();
+        if (t < 64) {
+            pick_seg *sg = seg + blockIdx.x;
+            const bool at_end = p_begin + (uint64_t)cnt_last == ncorr;
+            const int n_out = at_end ? np : np - 1, tail = at_end ? 0 : 1;
+            const bool over = n_out + tail > PICK_SEG_ENT || hit;
+            for (int j = lane; j < n_out + tail && j < PICK_SEG_ENT; j += 64) {
+                sg->first[j] = first_s[j];
+                sg->fin[j] = j < np - 1 ? pk_s[j] : pos;
+            }
+            if (lane == 0) {
+                sg->n = over ? 0 : n_out;
+                sg->tail = over ? 0 : tail;
+                sg->end = at_end ? 1 : 0;
+                sg->overflow = over ? 1 : 0;
+            }
+        }
+        return;
+    }
     if (t == 0) {
-        pk_s[np - 1] = pos;
+        if (!joined) pk_s[np - 1] = pos;
         np_s = np;
         hit_s = hit;
+        s->dbg[7] = joined ? 1 : (seg != nullptr ? -1 : 0);     // which form produced the peaks: joined segments / sequential after a failed join / sequential
     }
     __syncthreads();
     np = np_s;
@@ -1550,6 +1704,28 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
     PICK_STAT(s->dbg[4] = (long long)__builtin_amdgcn_s_memtime() - t_begin;)
 }
 
+// Launches the picker: the segment scans on all CUs, then the joining / sequential kernel on one.  The
+// segment form needs the window of PICK_CH positions to hold a segment plus a few peak distances of overlap.
+static int launch_pick(wfx_ctx *ctx, const int *bmax, const int *boff, uint64_t n, int n1, int n0, int64_t mindistance, double frame_samples, int width,
+                       wfx_dev_scalars *d_scal)
+{
+    const uint64_t L = (uint64_t)(2 * n1 + n0), ncorr = n > L ? n - L : 0;
+    pick_seg *seg = nullptr;
+    int nseg = 0;
+    const char *e = getenv("WFX_PICK_SEG");
+    const bool want = !(e && atoi(e) == 0);
+    if (want && ncorr >= 4ull * PICK_SEG && mindistance >= 64 && mindistance <= 6000) {
+        nseg = (int)std::min<uint64_t>((ncorr + PICK_SEG - 1) / PICK_SEG, PICK_SEG_MAX);
+        WFX_TRY(wfx_reserve(ctx, ctx->b_seg, (size_t)PICK_SEG_MAX * sizeof(pick_seg)));
+        seg = (pick_seg *)ctx->b_seg.p;
+        WFX_LAUNCH(ctx, K_SYNC_PICK, sync_pick_kernel<1>, dim3(nseg), dim3(PICK_THREADS), (const int *)ctx->b_corr.p, bmax, boff, n, n1, n0,
+                   (long long)mindistance, frame_samples, width, d_scal, seg, nseg);
+    }
+    WFX_LAUNCH(ctx, K_SYNC_PICK, sync_pick_kernel<0>, dim3(1), dim3(PICK_THREADS), (const int *)ctx->b_corr.p, bmax, boff, n, n1, n0,
+               (long long)mindistance, frame_samples, width, d_scal, seg, nseg);
+    return 0;
+}
+
 // the correlation and its summaries are already in b_corr / b_tmp2 (wfx_dev_quantise_corr)
 int wfx_dev_sync_pick_precomputed(wfx_ctx *ctx, uint64_t n, int n1, int n0, int64_t mindistance, double frame_samples, int width,
                                   wfx_dev_scalars *d_scal)
@@ -1557,9 +1733,7 @@ int wfx_dev_sync_pick_precomputed(wfx_ctx *ctx, uint64_t n, int n1, int n0, int6
     if (mindistance < 0 || mindistance > 12000) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "peak distance %lld out of range [0, 12000]", (long long)mindistance);
     const size_t nblk = (size_t)n / 64 + 2;
     const int *bmax = (const int *)ctx->b_tmp2.p, *boff = bmax + nblk;
-    WFX_LAUNCH(ctx, K_SYNC_PICK, sync_pick_kernel, dim3(1), dim3(PICK_THREADS), (const int *)ctx->b_corr.p, bmax, boff, n, n1, n0,
-               (long long)mindistance, frame_samples, width, d_scal);
-    return 0;
+    return launch_pick(ctx, bmax, boff, n, n1, n0, mindistance, frame_samples, width, d_scal);
 }
 
 int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0, int64_t mindistance, double frame_samples,
@@ -1572,9 +1746,7 @@ int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0
     WFX_TRY(wfx_reserve(ctx, ctx->b_tmp2, nblk * 8));
     int *bmax = (int *)ctx->b_tmp2.p, *boff = bmax + nblk;
     WFX_LAUNCH(ctx, K_SYNC_CORR, sync_corr_kernel, dim3(wfx_stream_grid(n, CORR_CH)), dim3(256), d, n, n1, n0, (int *)ctx->b_corr.p, bmax, boff);
-    WFX_LAUNCH(ctx, K_SYNC_PICK, sync_pick_kernel, dim3(1), dim3(PICK_THREADS), (const int *)ctx->b_corr.p, (const int *)bmax,
-               (const int *)boff, n, n1, n0, (long long)mindistance, frame_samples, width, d_scal);
-    return 0;
+    return launch_pick(ctx, bmax, boff, n, n1, n0, mindistance, frame_samples, width, d_scal);
 }
 
 // ===========================================================================
