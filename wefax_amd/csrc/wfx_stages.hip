@@ -1371,45 +1371,68 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
             }
         }
         __syncthreads();
-        if (t == 0) {
-            // phase B, sequential over the segments (a few instructions each): where each one is entered and left
-            int res = 0, off = 0, u = 0, ok = 1;
-            for (int k = 0; k < nseg; ++k) {
-                u = k;
-                join_res[k] = res;
-                join_off[k] = off;
-                if (seg[k].overflow || res > seg[k].n + seg[k].tail) {
-                    ok = 0;
-                    break;
+        if (t < 64) {
+            // phase B: where each segment's list is entered (the index its predecessor's join points at) and left (its own
+            // join), how many peaks it contributes, and the first segment whose list is used to its end (no join, end of the
+            // data, or the 100th peak inside) -- two segments per lane, one wave-wide prefix sum
+            int resv[2], cntv[2], leavev[2], badv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = lane + 64 * h;
+                resv[h] = cntv[h] = leavev[h] = badv[h] = 0;
+                if (k < nseg) {
+                    const int res = k == 0 ? 0 : join_b[k - 1], a = join_a[k];
+                    const int ent = seg[k].n + seg[k].tail;
+                    const bool bad = seg[k].overflow || res < 0 || res > ent;
+                    const bool leave = k + 1 < nseg && a >= 0 && a >= res && !seg[k].end && !bad;
+                    resv[h] = res;
+                    badv[h] = bad;
+                    leavev[h] = leave;
+                    cntv[h] = leave ? a - res : 0;
                 }
-                const int a = join_a[k];
-                const bool leave = k + 1 < nseg && a >= res && !seg[k].end && off + (a - res) < WFX_MAX_PEAKS;
-                if (!leave) break;                           // the list of segment k is used to its end
-                off += a - res;
-                res = join_b[k];
             }
-            const int res_u = join_res[u], off_u = join_off[u];
-            const int known = ok ? off_u + max(seg[u].n - res_u, 0) : 0;     // peaks with a final position
-            int npj = 0, hitj = 0;
-            if (ok && res_u <= seg[u].n + seg[u].tail) {
-                if (known >= WFX_MAX_PEAKS) {
-                    npj = WFX_MAX_PEAKS;
-                    hitj = 1;
-                } else if (known == WFX_MAX_PEAKS - 1 && seg[u].tail && res_u <= seg[u].n) {
-                    npj = WFX_MAX_PEAKS;                     // the 100th peak is the one appended last: the scan stops there
-                    hitj = 1;
-                } else if (seg[u].end) {
-                    npj = known;                             // the data ended first
-                } else
-                    ok = 0;
-            } else
-                ok = 0;
-            if (npj < 1) ok = 0;
-            join_ok = ok;
-            join_u = u;
-            join_np = npj;
-            join_hit = hitj;
-            join_known = known;
+            const int inc0 = wave_incl_scan_i32(cntv[0]);
+            const int tot0 = __builtin_amdgcn_readlane(inc0, 63);
+            const int inc1 = wave_incl_scan_i32(cntv[1]) + tot0;
+            const int exc[2] = {inc0 - cntv[0], inc1 - cntv[1]};
+            // stop at k: its list is not left, or the 100th peak falls inside its stretch
+            const unsigned long long st0 = __ballot(lane >= nseg || !leavev[0] || exc[0] + cntv[0] >= WFX_MAX_PEAKS);
+            const unsigned long long st1 = __ballot(lane + 64 >= nseg || !leavev[1] || exc[1] + cntv[1] >= WFX_MAX_PEAKS);
+            const int u = st0 ? __ffsll((long long)st0) - 1 : 64 + __ffsll((long long)st1) - 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = lane + 64 * h;
+                if (k < nseg) {
+                    join_res[k] = resv[h];
+                    join_off[k] = exc[h];
+                }
+            }
+            const int hu = u >> 6, lu = u & 63;
+            const int res_u = __builtin_amdgcn_readlane(hu ? resv[1] : resv[0], lu), off_u = __builtin_amdgcn_readlane(hu ? exc[1] : exc[0], lu);
+            const int bad_u = __builtin_amdgcn_readlane(hu ? badv[1] : badv[0], lu);
+            if (lane == 0) {
+                int ok = u < nseg && !bad_u;
+                const int known = ok ? off_u + max(seg[u].n - res_u, 0) : 0;     // peaks with a final position
+                int npj = 0, hitj = 0;
+                if (ok) {
+                    if (known >= WFX_MAX_PEAKS) {
+                        npj = WFX_MAX_PEAKS;
+                        hitj = 1;
+                    } else if (known == WFX_MAX_PEAKS - 1 && seg[u].tail && res_u <= seg[u].n) {
+                        npj = WFX_MAX_PEAKS;                     // the 100th peak is the one appended last: the scan stops there
+                        hitj = 1;
+                    } else if (seg[u].end) {
+                        npj = known;                             // the data ended first
+                    } else
+                        ok = 0;
+                }
+                if (npj < 1) ok = 0;
+                join_ok = ok;
+                join_u = u;
+                join_np = npj;
+                join_hit = hitj;
+                join_known = known;
+            }
         }
         __syncthreads();
         joined = join_ok;
@@ -1674,20 +1697,31 @@ __global__ void __launch_bounds__(PICK_THREADS) sync_pick_kernel(const int *__re
     // nclear = number of set flags among peaks 1 .. np - 2
     auto below = [](unsigned long long m, int k) { return k <= 0 ? 0ull : (k >= 64 ? m : (m & ((1ull << k) - 1))); };
     const int nclear = __popcll(below(okm0, np - 1) & ~1ull) + __popcll(below(okm1, np - 1 - 64));
-    int nclosed = 0, best_start = 0, best_len = -1, g_start = 0, g_len = 0;
-    for (int i = 1; i < nclear - 1; ++i) {
-        if (okbit(i)) {
-            if (g_len == 0) g_start = i;
-            ++g_len;
-        } else {
-            if (g_len > best_len) {
-                best_len = g_len;
-                best_start = g_start;
+    // The reference walks i = 1 .. nclear - 2: a set flag extends the current group, a clear one closes it (empty groups
+    // included) and the longest closed group wins, the first one on ties.  Per clear flag z that is "the run of set flags
+    // right below z"; every lane takes two positions z and measures its run with one 128-bit shift + count-leading-ones.
+    const int r_end = nclear - 1;                                      // positions 1 .. r_end - 1
+    const unsigned __int128 M = ((unsigned __int128)okm1 << 64) | (unsigned __int128)okm0;      // flag 0 is never set
+    int my_len = -1, my_z = 0x7fffffff;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int z = t + 64 * h;
+        if (z >= 1 && z < r_end && !okbit(z)) {
+            const unsigned __int128 inv = ~(M << (128 - z));               // bit 127 = flag z - 1, ...; zeros shifted in below
+            const unsigned long long hi = (unsigned long long)(inv >> 64), lo = (unsigned long long)inv;
+            const int len = hi ? __clzll((long long)hi) : 64 + (lo ? __clzll((long long)lo) : 64);
+            if (len > my_len) {                                            // (z grows with h: the first one wins ties)
+                my_len = len;
+                my_z = z;
             }
-            ++nclosed;
-            g_len = 0;
         }
     }
+    const int best_len = wave_max_i32(my_len);
+    const int best_z = wave_min_i32(my_len == best_len ? my_z : 0x7fffffff);
+    const int best_start = best_len > 0 ? best_z - best_len : 0;
+    const int in_range = r_end > 1 ? r_end - 1 : 0;
+    const int ones_in_range = __popcll(below(okm0, r_end) & ~1ull) + __popcll(below(okm1, r_end - 64));
+    const int nclosed = in_range - ones_in_range;
     long long start = 0;
     if (nclosed != 0) {
         for (int k = t; k < best_len; k += 64) s->phasing[k] = pk_s[best_start + k];
