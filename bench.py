@@ -374,6 +374,8 @@ def main():
         # nothing here waits on the host: the decode is ~20 enqueued kernels, the export a device-side header + copy,
         # and the RCCL gather of this step's image runs on its own stream while the next decode computes
         nonlocal last_slot
+        if use_dist:
+            exchange.prepare(ctx)                                  # this step's image goes straight into its send slot
         job.run()
         for _, jb in extra:
             jb.run()

@@ -183,6 +183,11 @@ int wfx_decode_device_ptr(wfx_ctx *ctx, int buffer_id, void **dev_ptr, size_t *b
  * collective) and wait for it; at most `capacity` bytes, *copied receives the size */
 int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity, size_t *copied);
 
+/* Let the NEXT decodes write {int64 bytes, int64 width, image} straight into caller-owned device memory (e.g. the send
+ * slot of a collective): no copy after the decode, wfx_decode_export_async of WFX_BUF_IMAGE to the same address becomes
+ * a no-op.  Used when capacity >= 16 + 4 * width * (n / width); NULL unbinds.  The pointer must stay valid while
+ * decodes run.  (No counterpart in the reference, which decodes on one host.) */
+int wfx_decode_bind_image(wfx_ctx *ctx, void *dst_dev, size_t capacity);
 /* Asynchronous hand-over to a collective (one process per GPU, images gathered by RCCL while the next decode
  * runs): wfx_stream_handle returns the context's hipStream_t so that the caller can order its own stream against
  * it with events; wfx_decode_export_async enqueues on that stream, WITHOUT waiting, a 16-byte header

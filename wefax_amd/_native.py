@@ -25,7 +25,7 @@ SYMBOLS = [
     "wfx_version", "wfx_merge_channels", "wfx_resample", "wfx_notch_filtfilt",
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
     "wfx_sync_peaks", "wfx_lines_to_image", "wfx_packet_process", "wfx_decode_upload", "wfx_decode_attach", "wfx_decode_run",
-    "wfx_decode_result", "wfx_debug_counters", "wfx_decode_fetch", "wfx_decode_device_ptr",
+    "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
     "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_resample_rational", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
@@ -116,6 +116,7 @@ def load():
     lib.wfx_decode_run.argtypes = [vp]
     lib.wfx_decode_result.argtypes = [vp, C.POINTER(DecodeInfo)]
     lib.wfx_debug_counters.argtypes = [vp, C.POINTER(C.c_longlong)]
+    lib.wfx_decode_bind_image.argtypes = [vp, vp, sz]
     lib.wfx_decode_fetch.argtypes = [vp, i, vp, sz]
     lib.wfx_decode_device_ptr.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz)]
     lib.wfx_decode_copy_to_device.argtypes = [vp, i, vp, sz, C.POINTER(sz)]
@@ -276,6 +277,10 @@ class Context:
         info = DecodeInfo()
         self._check(self.lib.wfx_decode_result(self.h, C.byref(info)))
         return info
+
+    def decode_bind_image(self, dst_ptr: int, capacity: int):
+        """The next decodes write {header, image} straight to this device address (0 unbinds)."""
+        self._check(self.lib.wfx_decode_bind_image(self.h, C.c_void_p(dst_ptr or None), capacity))
 
     def debug_counters(self):
         """Diagnostics of the last decode: [7] = form of the peak scan (1 joined segments, -1 sequential after a failed join, 0 sequential)."""

@@ -280,7 +280,10 @@ int wfx_decode_run(wfx_ctx *ctx)
     WFX_TRY(wfx_reserve(ctx, ctx->b_envraw, n * 8 + 64));
     WFX_TRY(wfx_reserve(ctx, ctx->b_env, n * 8 + 64));
     WFX_TRY(wfx_reserve(ctx, ctx->b_dig, n + 64));
-    WFX_TRY(wfx_reserve(ctx, ctx->b_img, (size_t)w * 4 * (size_t)(h_max > 0 ? h_max : 1)));
+    const size_t img_max = (size_t)w * 4 * (size_t)(h_max > 0 ? h_max : 1);
+    const bool to_ext = ctx->ext_img != nullptr && ctx->ext_img_cap >= 16 + img_max;       // straight into the caller's {header, image} slot
+    if (!to_ext) WFX_TRY(wfx_reserve(ctx, ctx->b_img, img_max));
+    ctx->img_in_ext = to_ext;
     wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
 
     const void *cur = ctx->ext_in ? ctx->ext_in : ctx->b_in.p;      // caller-owned device input (wfx_decode_attach) or the uploaded copy
@@ -315,7 +318,11 @@ int wfx_decode_run(wfx_ctx *ctx)
     WFX_TRY(wfx_dev_quantise_corr(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, p.n1, p.n0_gap));   // a8 + correlation of a9
     WFX_TRY(wfx_dev_sync_pick_precomputed(ctx, n, p.n1, p.n0_gap, p.mindistance, p.frame_samples, w, ds));
     // the image kernel also writes the scalars to the pinned host copy wfx_decode_result reads
-    WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h_max, ds, (uint8_t *)ctx->b_img.p, ctx->h_scal));
+    if (to_ext)
+        WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h_max, ds, (uint8_t *)ctx->ext_img + 16, ctx->h_scal, (long long *)ctx->ext_img,
+                              (long long)(ctx->ext_img_cap - 16)));
+    else
+        WFX_TRY(wfx_dev_image(ctx, (const uint8_t *)ctx->b_dig.p, n, w, h_max, ds, (uint8_t *)ctx->b_img.p, ctx->h_scal));
     ctx->ran = true;
     return 0;
 }
@@ -368,7 +375,10 @@ static int buffer_of(wfx_ctx *ctx, int id, void **p, size_t *bytes)
     case WFX_BUF_AUDIO: *p = ctx->b_audio.p; *bytes = n * 8; return 0;
     case WFX_BUF_ENVELOPE: *p = ctx->b_env.p; *bytes = n * 8; return 0;
     case WFX_BUF_DIGITAL: *p = ctx->b_dig.p; *bytes = n; return 0;
-    case WFX_BUF_IMAGE: *p = ctx->b_img.p; *bytes = (size_t)ctx->dp.width * 4 * (size_t)ctx->h_scal->height; return 0;
+    case WFX_BUF_IMAGE:
+        *p = ctx->img_in_ext ? (void *)((char *)ctx->ext_img + 16) : ctx->b_img.p;
+        *bytes = (size_t)ctx->dp.width * 4 * (size_t)ctx->h_scal->height;
+        return 0;
     default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown buffer id %d", id);
     }
 }
@@ -614,6 +624,15 @@ int wfx_stream_handle(wfx_ctx *ctx, void **stream)
     return 0;
 }
 
+int wfx_decode_bind_image(wfx_ctx *ctx, void *dst_dev, size_t capacity)
+{
+    CHECK_CTX(ctx);
+    if (dst_dev && capacity < 16) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bind_image: destination of at least 16 bytes needed");
+    ctx->ext_img = dst_dev;
+    ctx->ext_img_cap = dst_dev ? capacity : 0;
+    return 0;
+}
+
 int wfx_decode_export_async(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity)
 {
     CHECK_CTX(ctx);
@@ -627,7 +646,11 @@ int wfx_decode_export_async(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t c
     case WFX_BUF_AUDIO: src = ctx->b_audio.p; fixed = (long long)(n * 8); maxb = n * 8; break;
     case WFX_BUF_ENVELOPE: src = ctx->b_env.p; fixed = (long long)(n * 8); maxb = n * 8; break;
     case WFX_BUF_DIGITAL: src = ctx->b_dig.p; fixed = (long long)n; maxb = n; break;
-    case WFX_BUF_IMAGE: src = ctx->b_img.p; maxb = (size_t)ctx->dp.width * 4 * (size_t)(n / (uint64_t)ctx->dp.width); break;
+    case WFX_BUF_IMAGE:
+        if (ctx->img_in_ext && dst_dev == ctx->ext_img) return 0;       // the decode wrote header and image there itself
+        src = ctx->img_in_ext ? (const void *)((const char *)ctx->ext_img + 16) : ctx->b_img.p;
+        maxb = (size_t)ctx->dp.width * 4 * (size_t)(n / (uint64_t)ctx->dp.width);
+        break;
     default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown buffer id %d", buffer_id);
     }
     const size_t room = capacity - 16;

@@ -80,6 +80,9 @@ struct wfx_ctx {
     wfx_devbuf b_in, b_x, b_audio, b_work, b_work2, b_envraw, b_env, b_dig, b_corr,
         b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand, b_pcoef, b_seg;
     bool w256_ready = false;
+    void *ext_img = nullptr;     // wfx_decode_bind_image: {16-byte header, image} target owned by the caller (a collective's send slot)
+    size_t ext_img_cap = 0;
+    bool img_in_ext = false;     // the last decode wrote its image there
     bool force_pow2 = false;     // WFX_HILBERT_FFT_POW2: always use the zero-padded power-of-two convolution
     std::map<uint64_t, wfx_bs_plan> plans;    // Bluestein chirp filters (resampler, cross-check mode)
     std::map<uint64_t, wfx_bs_plan> hplans;   // Hilbert convolution kernels
@@ -211,8 +214,9 @@ int wfx_dev_sync_pick(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int n1, int n0
                       int64_t mindistance, double frame_samples, int width,
                       wfx_dev_scalars *d_scal);
 // mirror (optional): pinned host copy of the scalars, written by the kernel itself (saves the D2H blit launch)
+// hdr (optional): {bytes, width} header of an exported image, written by the kernel (room = bytes available behind it)
 int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max,
-                  const wfx_dev_scalars *d_scal, uint8_t *img, wfx_dev_scalars *mirror = nullptr);
+                  const wfx_dev_scalars *d_scal, uint8_t *img, wfx_dev_scalars *mirror = nullptr, long long *hdr = nullptr, long long room = 0);
 int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t start, int w, int h_total, int y0, int rows,
                        uint8_t *img);
 int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out,

@@ -1863,8 +1863,14 @@ __host__ __device__ __forceinline__ void image_row_taps(int y, int r, int h, int
 // four edge rows (clamped windows) evaluate the filter on the device
 __global__ void __launch_bounds__(256) image_kernel(const uint8_t *__restrict__ d, uint64_t n, int w, const wfx_dev_scalars *__restrict__ s,
                                                    uint8_t *__restrict__ img_base, int h_arg, long long start_arg, int y0, int xchunks,
-                                                   image_taps interior, wfx_dev_scalars *__restrict__ mirror)
+                                                   image_taps interior, wfx_dev_scalars *__restrict__ mirror, long long *__restrict__ hdr, long long room)
 {
+    // header of an image that is written straight into a collective's send slot: {bytes, width}
+    if (hdr && blockIdx.x == 0 && threadIdx.x == 0) {
+        long long nb = 4ll * (long long)(s ? s->height : h_arg) * (long long)w;
+        hdr[0] = nb > room ? room : nb;
+        hdr[1] = w;
+    }
     // the scalars of the decode (peaks, start frame, height, levels) go to the caller's pinned host copy from here
     if (mirror && blockIdx.x == 0)
         for (int i = threadIdx.x; i < (int)(sizeof(wfx_dev_scalars) / 8); i += 256)
@@ -1958,14 +1964,16 @@ static image_taps image_interior_taps()
     return T;
 }
 
-int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max, const wfx_dev_scalars *d_scal, uint8_t *img, wfx_dev_scalars *mirror)
+int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max, const wfx_dev_scalars *d_scal, uint8_t *img, wfx_dev_scalars *mirror,
+                  long long *hdr, long long room)
 {
     if (h_max <= 0 || w <= 0) {
         if (mirror) WFX_HIP(ctx, hipMemcpyAsync(mirror, d_scal, sizeof(wfx_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
+        if (hdr) WFX_TRY(wfx_dev_export_header(ctx, d_scal, 0, w, room, hdr));
         return 0;
     }
     const int xchunks = (w + 2047) / 2048;
-    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max * xchunks), dim3(256), d, n, w, d_scal, img, 0, 0ll, 0, xchunks, image_interior_taps(), mirror);
+    WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)h_max * xchunks), dim3(256), d, n, w, d_scal, img, 0, 0ll, 0, xchunks, image_interior_taps(), mirror, hdr, room);
     return 0;
 }
 
@@ -1975,7 +1983,7 @@ int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t sta
     if (w <= 0 || y0 < 0 || y0 + rows > h_total) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "image rows out of range");
     const int xchunks = (w + 2047) / 2048;
     WFX_LAUNCH(ctx, K_IMAGE, image_kernel, dim3((unsigned)rows * xchunks), dim3(256), d - g0, (uint64_t)0, w, (const wfx_dev_scalars *)nullptr, img,
-               h_total, (long long)start, y0, xchunks, image_interior_taps(), (wfx_dev_scalars *)nullptr);
+               h_total, (long long)start, y0, xchunks, image_interior_taps(), (wfx_dev_scalars *)nullptr, (long long *)nullptr, 0ll);
     return 0;
 }
 

@@ -91,6 +91,15 @@ class PipelinedExchange:
         self.free = [None] * slots          # event: the gather that used the slot is complete
         self.k = 0
 
+    def prepare(self, ctx) -> None:
+        """Call BEFORE the decode is enqueued: the decode then writes header and image straight into the step's send
+        slot (``wfx_decode_bind_image``), and ``submit`` has nothing to copy."""
+        s = self.k % len(self.send)
+        if self.free[s] is not None:
+            self.lib.wait_event(self.free[s])
+            self.free[s] = None
+        ctx.decode_bind_image(self.send[s].data_ptr(), self.HEADER + self.capacity)
+
     def submit(self, ctx, buffer_id: int) -> int:
         """Call right after the decode was enqueued on ``ctx``; returns the step's slot."""
         torch = self.torch
@@ -98,7 +107,7 @@ class PipelinedExchange:
         self.k += 1
         if self.free[s] is not None:
             self.lib.wait_event(self.free[s])
-        ctx.decode_export_async(buffer_id, self.send[s].data_ptr(), self.HEADER + self.capacity)
+        ctx.decode_export_async(buffer_id, self.send[s].data_ptr(), self.HEADER + self.capacity)   # no-op after prepare()
         ready = self.lib.record_event()
         self.comm.wait_event(ready)
         with torch.cuda.stream(self.comm):
