@@ -503,6 +503,145 @@ def process_packet(samples: np.ndarray, sample_rate: int, notch=(NOTCH_F0, NOTCH
 
 
 # ---------------------------------------------------------------------------
+# Detectors of the live path (data_packet.py:301-406): start / stop tone and sync pulse.
+# scipy.signal.find_peaks is restated for the three conditions the reference uses (height, distance,
+# prominence); pinned by tests/golden/packets.npz (answers of the reference's own DataPacket).
+# ---------------------------------------------------------------------------
+TONES = dict(start_distance=250, stop_distance=380, height=0.05, prominence=0.2, fmin=800, fmax=3200,
+             amount_min=4, amount_max=6)                     # config.json "tones_settings" (data_packet.py:25-33)
+SYNC_PULSE = dict(height=0.5, prominence=0.2, fmin=1400, fmax=1600)      # config.json "sync_pulse_settings" (:36-40)
+
+
+def packet_spectrum(raw: np.ndarray, sample_rate: int):
+    """data_packet.py:388-406 __fourier_transform: one-sided frequencies and the amplitude normalised by max + 1e-4."""
+    fft = np.fft.fft(raw)
+    n = len(fft)
+    freq = np.arange(n) / (n / sample_rate)
+    h = n // 2
+    amp = np.abs(fft[:h] / h)
+    return freq[:h], amp / (np.max(amp) + 0.0001)
+
+
+def _local_maxima(x: np.ndarray) -> np.ndarray:
+    """scipy.signal._peak_finding_utils._local_maxima_1d: strict rise, optional plateau, strict fall; plateau midpoint."""
+    out = []
+    n = len(x)
+    i, i_max = 1, n - 1
+    while i < i_max:
+        if x[i - 1] < x[i]:
+            ahead = i + 1
+            while ahead < i_max and x[ahead] == x[i]:
+                ahead += 1
+            if x[ahead] < x[i]:
+                out.append((i + ahead - 1) // 2)
+                i = ahead
+        i += 1
+    return np.asarray(out, dtype=np.int64)
+
+
+def _select_by_distance(peaks: np.ndarray, priority: np.ndarray, distance: float) -> np.ndarray:
+    """scipy _select_by_peak_distance: highest peaks first, each removes its neighbours closer than ceil(distance)."""
+    n = len(peaks)
+    d = math.ceil(distance)
+    keep = np.ones(n, dtype=bool)
+    order = np.argsort(priority)
+    for i in range(n - 1, -1, -1):
+        j = order[i]
+        if not keep[j]:
+            continue
+        k = j - 1
+        while k >= 0 and peaks[j] - peaks[k] < d:
+            keep[k] = False
+            k -= 1
+        k = j + 1
+        while k < n and peaks[k] - peaks[j] < d:
+            keep[k] = False
+            k += 1
+    return keep
+
+
+def _prominences(x: np.ndarray, peaks: np.ndarray) -> np.ndarray:
+    """scipy _peak_prominences with wlen = -1: peak height above the higher of the two lowest points reached before a
+    higher sample (or the signal's end) on either side."""
+    out = np.empty(len(peaks))
+    n = len(x)
+    for k, p in enumerate(peaks):
+        left_min = x[p]
+        i = p
+        while i >= 0 and x[i] <= x[p]:
+            left_min = min(left_min, x[i])
+            i -= 1
+        right_min = x[p]
+        i = p
+        while i < n and x[i] <= x[p]:
+            right_min = min(right_min, x[i])
+            i += 1
+        out[k] = x[p] - max(left_min, right_min)
+    return out
+
+
+def find_peaks(x: np.ndarray, height=None, distance=None, prominence=None):
+    """scipy.signal.find_peaks for the conditions the reference passes, in scipy's order: height, distance, prominence.
+    Returns (indices, peak_heights)."""
+    x = np.asarray(x, dtype=np.float64)
+    peaks = _local_maxima(x)
+    if height is not None:
+        peaks = peaks[x[peaks] >= height]
+    if distance is not None:
+        peaks = peaks[_select_by_distance(peaks, x[peaks], distance)]
+    if prominence is not None:
+        peaks = peaks[_prominences(x, peaks) >= prominence]
+    return peaks, x[peaks]
+
+
+def contain_tone(raw: np.ndarray, sample_rate: int, distance: int, cfg=TONES) -> bool:
+    """data_packet.py:366-386 __contain_tone."""
+    freq, amp = packet_spectrum(raw, sample_rate)
+    peaks, _ = find_peaks(amp, height=cfg["height"], distance=distance, prominence=cfg["prominence"])
+    in_range = all(cfg["fmin"] <= f <= cfg["fmax"] for f in freq[peaks])
+    return bool(in_range and cfg["amount_min"] <= len(peaks) <= cfg["amount_max"])
+
+
+def contain_start_tone(raw, sample_rate, cfg=TONES) -> bool:        # data_packet.py:344-353
+    return contain_tone(raw, sample_rate, cfg["start_distance"], cfg)
+
+
+def contain_stop_tone(raw, sample_rate, cfg=TONES) -> bool:         # data_packet.py:355-364
+    return contain_tone(raw, sample_rate, cfg["stop_distance"], cfg)
+
+
+def packet_pattern_search(samples: np.ndarray, sample_rate: int):
+    """data_packet.py:314-334: correlation with [255] + [0] * k + [255] (both shifted by 128), peaks at least
+    0.4 s apart; the first (dummy) entry is dropped."""
+    n = len(samples)
+    sm = lambda v: int((v / (n / sample_rate)) * n)  # noqa: E731
+    k = sm(0.025)
+    mind = sm(0.4)
+    s = np.asarray(samples, dtype=np.int64) - 128
+    ls = k + 2
+    cs = np.concatenate(([0], np.cumsum(s)))
+    peaks = [(-mind, 0)]
+    for i in range(n - ls):
+        corr = 127 * s[i] - 128 * (cs[i + k + 1] - cs[i + 1]) + 127 * s[i + k + 1]
+        if i - peaks[-1][0] > mind:
+            peaks.append((i, corr))
+        elif corr > peaks[-1][1]:
+            peaks[-1] = (i, corr)
+    return [p[0] for p in peaks][1:]
+
+
+def packet_find_sync_pulse(raw: np.ndarray, samples: np.ndarray, sample_rate: int, cfg=SYNC_PULSE) -> dict:
+    """data_packet.py:301-342 find_sync_pulse."""
+    freq, amp = packet_spectrum(raw, sample_rate)
+    peaks, heights = find_peaks(amp, height=cfg["height"], prominence=cfg["prominence"])
+    in_range = all(cfg["fmin"] <= f <= cfg["fmax"] for f in freq[peaks])
+    pulses = packet_pattern_search(samples, sample_rate)
+    freq_found = bool(in_range and len(peaks) == 1)
+    return {"frequency_peak_found": freq_found, "samples_peak_found": bool(len(pulses)),
+            "pulse_found": bool(freq_found and len(pulses)), "peaks_fft": [freq[peaks], heights], "peaks_samples": pulses}
+
+
+# ---------------------------------------------------------------------------
 # The reference's loop structure, for CPU TIMING only (BASELINE.md section 3,
 # SURVEY.md 8d "faithful_loops"): the same results as the vectorised stages
 # above, computed the way wefax.py computes them -- one Python iteration per

@@ -106,3 +106,100 @@ def test_packet_module_needs_the_library(monkeypatch):
     from wefax_amd.packet import DataPacket
     with pytest.raises(Exception):
         DataPacket(11025, np.zeros(11025, dtype=np.int16), 120, "/tmp/", 1, 0)
+
+
+# ---- detectors of the live path (data_packet.py:301-406) ---------------------------------------------
+def _det_cases():
+    z = np.load(os.path.join(GOLDEN, "packets.npz"))
+    out = []
+    for n in z["names"]:
+        n = str(n)
+        out.append((n, int(z[f"{n}__sr"]), z[f"{n}__in"], z[f"{n}__out"], z[f"{n}__amp"], bool(z[f"{n}__start_tone"]), bool(z[f"{n}__stop_tone"]),
+                    z[f"{n}__sp_flags"].tolist(), z[f"{n}__sp_fft_freq"], z[f"{n}__sp_fft_height"], z[f"{n}__sp_samples"].tolist()))
+    return out
+
+
+DET = _det_cases()
+
+
+@pytest.mark.parametrize("case", DET, ids=[c[0] for c in DET])
+def test_oracle_detectors_match_the_reference(case):
+    name, sr, raw, dig, amp, start, stop, flags, pf, ph, ps = case
+    f, a = wo.packet_spectrum(raw, sr)
+    assert np.array_equal(a, amp)                                  # same numpy calls
+    assert wo.contain_start_tone(raw, sr) == start
+    assert wo.contain_stop_tone(raw, sr) == stop
+    sp = wo.packet_find_sync_pulse(raw, dig, sr)
+    assert [sp["frequency_peak_found"], sp["samples_peak_found"], sp["pulse_found"]] == flags
+    assert np.array_equal(sp["peaks_fft"][0], pf) and np.array_equal(sp["peaks_fft"][1], ph)
+    assert sp["peaks_samples"] == ps
+
+
+@pytest.mark.parametrize("case", DET, ids=[c[0] for c in DET])
+def test_host_detector_logic_matches_the_reference(case):
+    """wefax_amd/detect.py (the product's host side) on the reference's own spectra and digitised samples."""
+    from wefax_amd import detect
+    name, sr, raw, dig, amp, start, stop, flags, pf, ph, ps = case
+    f = detect.frequencies(len(raw), sr)
+    assert detect.contain_tone(f, amp, detect.TONES["start_distance"]) == start
+    assert detect.contain_tone(f, amp, detect.TONES["stop_distance"]) == stop
+    sp = detect.find_sync_pulse(f, amp, dig, sr)
+    assert [sp["frequency_peak_found"], sp["samples_peak_found"], sp["pulse_found"]] == flags
+    assert np.array_equal(sp["peaks_fft"][0], pf) and np.array_equal(sp["peaks_fft"][1], ph)
+    assert sp["peaks_samples"] == ps
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_host_find_peaks_and_pattern_search_against_the_oracle(seed):
+    from wefax_amd import detect
+    rng = np.random.default_rng(seed)
+    x = rng.random(4000)
+    x[rng.integers(0, 4000, 300)] = 0.5                         # plateaus and ties
+    x = np.round(x, 2 if seed % 2 else 6)
+    for kw in (dict(height=0.3), dict(height=0.05, distance=25), dict(height=0.2, prominence=0.3), dict(height=0.05, distance=7.5, prominence=0.1)):
+        got, want = detect.find_peaks(x, **kw), wo.find_peaks(x, **kw)
+        if "distance" in kw and len(np.unique(x[wo._local_maxima(x)])) < len(wo._local_maxima(x)):
+            continue                                            # equal heights: scipy's own order is unspecified (argsort)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), kw
+    s = rng.integers(0, 256, size=11025 + 100 * seed).astype(np.uint8)
+    s[rng.integers(0, 9000)::2756][:3] = 255
+    assert detect.pattern_search(s, 11025) == wo.packet_pattern_search(s, 11025)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", DET, ids=[c[0] for c in DET])
+def test_hip_packet_detectors_match_the_reference(ctx, case):
+    from wefax_amd import detect
+    from wefax_amd.packet import DataPacket
+    name, sr, raw, dig, amp, start, stop, flags, pf, ph, ps = case
+    pkt = DataPacket(sr, raw, 120, "/tmp/", 1, 0, ctx=ctx)
+    f, a = pkt._spectrum()
+    assert np.abs(a - amp).max() <= 1e-12                       # amplitudes are normalised to <= 1
+    assert pkt.contain_start_tone() == start and pkt.contain_stop_tone() == stop
+    sp = pkt.find_sync_pulse()
+    assert [sp["frequency_peak_found"], sp["samples_peak_found"], sp["pulse_found"]] == flags
+    assert np.array_equal(sp["peaks_fft"][0], pf) and np.abs(sp["peaks_fft"][1] - ph).max(initial=0.0) <= 1e-12
+    assert sp["peaks_samples"] == ps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,lpm,frames", [(11025, 120, 10), (11025, 240, 10), (8000, 120, 3)])
+def test_live_strip_equals_pillow(ctx, rate, lpm, frames):
+    """wefax_live.py:124-148 rendered with Pillow exactly as the reference does (Image.new / putpixel / resize)."""
+    from PIL import Image
+    from wefax_amd.packet import frames_to_image
+    t_frame = 1 / (lpm / 60)
+    w = int(t_frame * rate)
+    rng = np.random.default_rng(rate + lpm)
+    pts = rng.integers(0, 256, size=w * frames + 777)
+    img = Image.new("L", (w, frames))
+    px = py = 0
+    for p in range(w * frames):
+        img.putpixel((px, py), 255 - int(pts[p]))
+        px += 1
+        if px >= w:
+            px = 0
+            py += 1
+    want = np.asarray(img.resize((w, 4 * frames)))
+    got = frames_to_image(ctx, pts, rate, t_frame, frames)
+    assert got.shape == want.shape and np.array_equal(got, want)

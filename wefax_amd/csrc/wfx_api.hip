@@ -615,6 +615,28 @@ int wfx_packet_process(wfx_ctx *ctx, const void *samples, int in_kind, size_t n,
     return 0;
 }
 
+// ---- live path, detectors: one-sided amplitude spectrum of a packet (data_packet.py:388-406) ----
+int wfx_packet_spectrum(wfx_ctx *ctx, const void *samples, int in_kind, size_t n, double *amp_out)
+{
+    CHECK_CTX(ctx);
+    if (!samples || !amp_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_F64_MONO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "packet: int16 or float64 samples");
+    if (n < 2) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "spectrum: at least two samples needed");
+    ctx->ran = false;
+    const size_t esz = in_kind == WFX_IN_I16_MONO ? 2 : 8;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_x, n * esz + 16));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_audio, n * 8 + 16));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_env, (n / 2) * 8 + 64));
+    WFX_TRY(h2d(ctx, ctx->b_x.p, samples, n * esz));
+    const double *x = (const double *)ctx->b_x.p;
+    if (in_kind == WFX_IN_I16_MONO) {
+        WFX_TRY(wfx_dev_i16_to_f64(ctx, (const int16_t *)ctx->b_x.p, n, (double *)ctx->b_audio.p));
+        x = (const double *)ctx->b_audio.p;
+    }
+    WFX_TRY(wfx_dev_spectrum_abs(ctx, x, n, (double *)ctx->b_env.p));
+    return d2h_sync(ctx, amp_out, ctx->b_env.p, (n / 2) * 8);
+}
+
 // ---- asynchronous export for a collective ------------------------------------------------
 int wfx_stream_handle(wfx_ctx *ctx, void **stream)
 {

@@ -906,6 +906,31 @@ resample_final(const cplx *__restrict__ V2, uint64_t num, double inv_num, double
     }
 }
 
+// amp[k] = |X[k] / h|, k < h = N / 2 (data_packet.py:388-406: abs(fft[:h] / h)); |X[k]| = |V[k]|, the chirp has modulus 1
+__global__ void __launch_bounds__(256) spectrum_abs(const cplx *__restrict__ V, uint64_t h, double *__restrict__ amp)
+{
+    const double hd = (double)h;
+    for (uint64_t k = blockIdx.x * 256ull + threadIdx.x; k < h; k += (uint64_t)gridDim.x * 256ull) {
+        const cplx a = V[k];
+        amp[k] = hypot(a.x / hd, a.y / hd);
+    }
+}
+
+// one-sided amplitude spectrum of a real sequence of any length (Bluestein DFT on the power-of-two passes)
+int wfx_dev_spectrum_abs(wfx_ctx *ctx, const double *x, uint64_t n, double *amp)
+{
+    if (n < 2) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "spectrum: at least two samples needed");
+    wfx_bs_plan *pl = nullptr;
+    WFX_TRY(get_plan(ctx, n, &pl));
+    const uint64_t M = 1ull << pl->log2m;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work, M * sizeof(cplx)));
+    cplx *W = (cplx *)ctx->b_work.p;
+    WFX_LAUNCH(ctx, K_BS_CHIRP, bs_prologue_real, dim3(wfx_stream_grid(M, 256)), dim3(256), x, W, n, M);
+    WFX_TRY(bs_convolve(ctx, W, pl));
+    WFX_LAUNCH(ctx, K_ENV_MEDIAN, spectrum_abs, dim3(wfx_stream_grid(n / 2, 256)), dim3(256), (const cplx *)W, n / 2, amp);
+    return 0;
+}
+
 int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out)
 {
     if (n0 < 1 || num < 1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "resample: empty input or output");

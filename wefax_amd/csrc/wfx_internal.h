@@ -182,6 +182,7 @@ __device__ __forceinline__ void wfx_sel_count(unsigned *h, unsigned digit, bool 
 // wfx_fft.hip
 int wfx_dev_fft_plan_radices(int log2m, int *ra_bits, int max_passes);   // host only
 int wfx_dev_hilbert_env_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw);
+int wfx_dev_spectrum_abs(wfx_ctx *ctx, const double *x, uint64_t n, double *amp);
 int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env, unsigned *l0hist);
 int wfx_dev_hilbert_env_bluestein(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw);
 int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out);

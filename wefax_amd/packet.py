@@ -4,14 +4,17 @@
 ``wefax_live.py:204-209`` builds one ``DataPacket`` per second of sound-card audio and appends its ``samples``
 (ints 0..255) to the line buffer; this class computes the same array on the GPU through the C ABI
 (``wfx_packet_process``: notch filtfilt at the packet's own rate -> |hilbert| -> medfilt 3 -> per-packet
-percentiles -> rint with the 1e-6 guard).  The matplotlib charts and the tone / sync-pulse detectors of the
-reference class (data_packet.py:67-406) are debugging and control-plane code and are not provided.
+percentiles -> rint with the 1e-6 guard), and the detectors the live decoder's state machine asks
+(``contain_start_tone``, ``contain_stop_tone``, ``find_sync_pulse``: data_packet.py:301-406) from the packet's amplitude
+spectrum (``wfx_packet_spectrum``) with the peak conditions evaluated on the host (``wefax_amd/detect.py``).  The
+matplotlib charts of the reference class (data_packet.py:67-299) are debugging code and are not provided.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from . import _native as nat
+from . import detect
 from . import hostparams as hp
 
 
@@ -26,12 +29,37 @@ class DataPacket:
         self.raw_samples = samples
         self._own_ctx = ctx is None
         self._ctx = ctx if ctx is not None else nat.Context(0)
+        self._spec = None
         try:
             out, self.low, self.high = _process(self._ctx, sample_rate, np.asarray(samples), notch)
+            if self._own_ctx:
+                self._spectrum()                          # the private context goes away below
         finally:
             if self._own_ctx:
                 self._ctx.close()
+                self._ctx = None
         self.samples = out.astype(int)                    # data_packet.py:464 digitalized.astype(int)
+
+    # ---- detectors (data_packet.py:301-406) ----
+    def _spectrum(self):
+        """(frequencies, normalised amplitude) of data_packet.py:388-406, the FFT on the GPU."""
+        if self._spec is None:
+            raw = np.asarray(self.raw_samples)
+            amp = self._ctx.packet_spectrum(raw)
+            self._spec = (detect.frequencies(raw.shape[0], self.sample_rate), detect.normalise(amp))
+        return self._spec
+
+    def contain_start_tone(self) -> bool:
+        f, a = self._spectrum()
+        return detect.contain_tone(f, a, detect.TONES["start_distance"])
+
+    def contain_stop_tone(self) -> bool:
+        f, a = self._spectrum()
+        return detect.contain_tone(f, a, detect.TONES["stop_distance"])
+
+    def find_sync_pulse(self) -> dict:
+        f, a = self._spectrum()
+        return detect.find_sync_pulse(f, a, np.asarray(self.samples), self.sample_rate)
 
     def __repr__(self):
         return (f"data packet {self.number} info: {self.number * self.duration}s-{self.number * self.duration + self.duration}s "
@@ -51,3 +79,15 @@ def _process(ctx: nat.Context, sample_rate: int, x: np.ndarray, notch=hp.DEFAULT
 def process_packets(ctx: nat.Context, sample_rate: int, packets, notch=hp.DEFAULT_NOTCH):
     """uint8 samples of every packet of an iterable / 2-D array, through one context."""
     return [_process(ctx, sample_rate, np.asarray(p), notch)[0] for p in packets]
+
+
+def frames_to_image(ctx: nat.Context, data_points, sample_rate: int, time_for_one_frame: float, frames: int) -> np.ndarray:
+    """The strip the live decoder renders every ``minimum_frames_per_update`` lines (wefax_live.py:124-148): the first
+    ``frames`` lines of ``data_points`` (digitised samples, 0..255) as pixels 255 - value, ``int(T * rate)`` per line,
+    enlarged 4x vertically by Pillow's bicubic filter -- ``wfx_lines_to_image`` with no start offset.
+    Returns the uint8 array [4 * frames, width]; ``PIL.Image.fromarray(., "L")`` is the reference's ``img``."""
+    w = int(time_for_one_frame * sample_rate)
+    pts = np.asarray(data_points)
+    if frames < 1 or pts.shape[0] < w * frames:
+        raise ValueError("not enough data points for the requested number of lines")
+    return ctx.lines_to_image(pts[:w * frames].astype(np.uint8), 0, w)
