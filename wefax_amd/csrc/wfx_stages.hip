@@ -847,7 +847,10 @@ __global__ void __launch_bounds__(1024) select_finish_kernel(unsigned *__restric
     __shared__ unsigned wave_tot[16];
     __shared__ unsigned long long pfx[4], rnk[4];
     __shared__ int owner[4];
-    __shared__ unsigned long long cur_p, cur_r;
+    __shared__ unsigned long long cur_p, cur_r, cur_full;
+    __shared__ unsigned cur_c, few_n;
+    __shared__ unsigned long long few[64];
+    bool done_direct = false;
     const int t = threadIdx.x, lane = t & 63;
     if (t == 0) {
         for (int q = 0; q < 4; ++q) {
@@ -889,13 +892,47 @@ __global__ void __launch_bounds__(1024) select_finish_kernel(unsigned *__restric
             if (r >= cum && r < cum + c0) {
                 cur_p = (want << width) | (unsigned long long)(2 * t);
                 cur_r = r - cum;
+                cur_c = c0;
             } else if (r >= cum + c0 && r < cum + c0 + c1) {
                 cur_p = (want << width) | (unsigned long long)(2 * t + 1);
                 cur_r = r - cum - c0;
+                cur_c = c1;
             }
             __syncthreads();
+            // A level leaves a handful of keys in the chosen bin (a few thousand candidates over 2048 bins): finish
+            // those directly -- gather them, rank each against the others -- instead of three more histogram levels
+            // (six workgroup barriers each).
+            if (cur_c <= 64 && level + 1 < SEL_LEVELS) {
+                const unsigned long long wantk = cur_p;
+                const int sh = shift;
+                if (t == 0) few_n = 0;
+                __syncthreads();
+                const uint64_t nround = (cnt + 1023) / 1024;
+                for (uint64_t it = 0; it < nround; ++it) {
+                    const uint64_t i = it * 1024 + t;
+                    if (i < cnt) {
+                        const unsigned long long key = list[i];
+                        if ((key >> sh) == wantk) few[atomicAdd(&few_n, 1u)] = key;
+                    }
+                }
+                __syncthreads();
+                const unsigned m = few_n;                               // == cur_c
+                if (t < (int)m) {
+                    const unsigned long long mine = few[t];
+                    unsigned below = 0, equal_before = 0;
+                    for (unsigned j = 0; j < m; ++j) {
+                        const unsigned long long o2 = few[j];
+                        below += o2 < mine;
+                        equal_before += (o2 == mine) & (j < (unsigned)t);
+                    }
+                    if (below + equal_before == (unsigned)cur_r) cur_full = mine;      // exactly one lane
+                }
+                __syncthreads();
+                done_direct = true;
+                break;
+            }
         }
-        if (t == 0) s->sel_value[q] = key_f64(cur_p);
+        if (t == 0) s->sel_value[q] = key_f64(done_direct ? cur_full : cur_p);
     }
     // The workgroup that finishes last applies numpy's interpolation between the two order statistics of
     // each percentile and clears the workspace for the next run (a separate 1-workgroup launch cost 4.5 us).
