@@ -114,6 +114,11 @@ int wfx_lines_to_image(wfx_ctx *ctx, const uint8_t *d, size_t n, size_t start,
 int wfx_packet_process(wfx_ctx *ctx, const void *samples, int in_kind, size_t n, const double b[3], const double a[3],
                        const uint64_t ranks[4], double gamma_lo, double gamma_hi, uint8_t *out, double *low, double *high);
 
+/* `count` packets of n samples each, contiguous in `samples`: the same decode per packet, enqueued back to back with one
+ * upload and one download (no host synchronisation between packets).  out: count * n bytes; low / high: count each. */
+int wfx_packets_process(wfx_ctx *ctx, const void *samples, int in_kind, size_t n, size_t count, const double b[3], const double a[3],
+                        const uint64_t ranks[4], double gamma_lo, double gamma_hi, uint8_t *out, double *low, double *high);
+
 /* ---- live path, detectors: data_packet.py:388-406 DataPacket.__fourier_transform ----
  * amp_out[k] = |FFT(samples)[k] / (n / 2)| for k < n / 2 (any n >= 2).  The caller normalises by max + 1e-4 and runs
  * the peak conditions of contain_start_tone / contain_stop_tone / find_sync_pulse (:301-386) on the n / 2 values

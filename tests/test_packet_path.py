@@ -203,3 +203,17 @@ def test_live_strip_equals_pillow(ctx, rate, lpm, frames):
     want = np.asarray(img.resize((w, 4 * frames)))
     got = frames_to_image(ctx, pts, rate, t_frame, frames)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_hip_packets_back_to_back_equal_one_by_one(ctx):
+    """wfx_packets_process: the same decode per packet, one upload / download for the whole stack."""
+    from wefax_amd import synth
+    from wefax_amd.packet import _process, process_packets
+    x = synth.config_c2(noise=0.02, seed=2)[:12 * 11025].reshape(12, 11025)
+    many = process_packets(ctx, 11025, x)
+    for p, got in zip(x, many):
+        assert np.array_equal(got, _process(ctx, 11025, p)[0])
+        assert np.array_equal(got, wo.process_packet(p, 11025)["samples"])
+    ragged = process_packets(ctx, 11025, [x[0], x[1][:9000]])            # different lengths: decoded one by one
+    assert np.array_equal(ragged[0], many[0]) and ragged[1].shape == (9000,)

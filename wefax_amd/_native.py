@@ -24,7 +24,7 @@ SYMBOLS = [
     "wfx_device_count", "wfx_create", "wfx_destroy", "wfx_last_error", "wfx_sync",
     "wfx_version", "wfx_merge_channels", "wfx_resample", "wfx_notch_filtfilt",
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
-    "wfx_sync_peaks", "wfx_lines_to_image", "wfx_packet_process", "wfx_packet_spectrum", "wfx_decode_upload", "wfx_decode_attach", "wfx_decode_run",
+    "wfx_sync_peaks", "wfx_lines_to_image", "wfx_packet_process", "wfx_packets_process", "wfx_packet_spectrum", "wfx_decode_upload", "wfx_decode_attach", "wfx_decode_run",
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
@@ -123,6 +123,7 @@ def load():
     lib.wfx_packet_process.argtypes = [vp, vp, i, sz, dp, dp, C.POINTER(C.c_uint64), C.c_double, C.c_double, vp,
                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.wfx_packet_spectrum.argtypes = [vp, vp, i, sz, vp]
+    lib.wfx_packets_process.argtypes = [vp, vp, i, sz, sz, dp, dp, C.POINTER(C.c_uint64), C.c_double, C.c_double, vp, vp, vp]
     lib.wfx_decode_attach.argtypes = [vp, vp, C.POINTER(DecodeParams)]
     lib.wfx_stream_handle.argtypes = [vp, C.POINTER(vp)]
     lib.wfx_decode_export_async.argtypes = [vp, i, vp, sz]
@@ -338,6 +339,25 @@ class Context:
         self._check(self.lib.wfx_packet_process(self.h, _ptr(x), kind, x.shape[0], bb, aa, rr, gamma_lo, gamma_hi, _ptr(out),
                                                 C.byref(lo), C.byref(hi)))
         return out, lo.value, hi.value
+
+    def packets_process(self, samples2d: np.ndarray, b, a, ranks, gamma_lo: float, gamma_hi: float):
+        """[count, n] packets decoded back to back: (uint8 [count, n], low [count], high [count])."""
+        x = np.ascontiguousarray(samples2d)
+        if x.ndim != 2:
+            raise ValueError("packets_process expects a [count, n] array")
+        if x.dtype == np.int16:
+            kind = WFX_IN_I16_MONO
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            kind = WFX_IN_F64_MONO
+        count, n = x.shape
+        out = np.empty((count, n), dtype=np.uint8)
+        lo, hi = np.empty(count), np.empty(count)
+        bb = (C.c_double * 3)(*[float(v) for v in b])
+        aa = (C.c_double * 3)(*[float(v) for v in a])
+        rr = (C.c_uint64 * 4)(*[int(v) for v in ranks])
+        self._check(self.lib.wfx_packets_process(self.h, _ptr(x), kind, n, count, bb, aa, rr, gamma_lo, gamma_hi, _ptr(out), _ptr(lo), _ptr(hi)))
+        return out, lo, hi
 
     def packet_spectrum(self, samples: np.ndarray) -> np.ndarray:
         """|FFT(samples)[:n // 2] / (n // 2)| (data_packet.py:388-406, before the normalisation)."""

@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "wfx_internal.h"
+#include <vector>
 
 #define CHECK_CTX(ctx)                                                        \
     do {                                                                      \
@@ -612,6 +613,47 @@ int wfx_packet_process(wfx_ctx *ctx, const void *samples, int in_kind, size_t n,
     WFX_TRY(d2h_sync(ctx, ctx->h_scal, ds, sizeof(wfx_dev_scalars)));
     if (low) *low = ctx->h_scal->low;
     if (high) *high = ctx->h_scal->high;
+    return 0;
+}
+
+// `count` packets of n samples each (contiguous), decoded back to back on the context's stream: one upload, no host
+// synchronisation between packets, one download (re-decoding a recorded packet stream; the live path makes one a second)
+int wfx_packets_process(wfx_ctx *ctx, const void *samples, int in_kind, size_t n, size_t count, const double b[3], const double a[3],
+                        const uint64_t ranks[4], double gamma_lo, double gamma_hi, uint8_t *out, double *low, double *high)
+{
+    CHECK_CTX(ctx);
+    if (!samples || !b || !a || !ranks || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_F64_MONO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "packet: int16 or float64 samples");
+    if (n == 0 || count == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "N must be positive.");
+    ctx->ran = false;
+    const size_t esz = in_kind == WFX_IN_I16_MONO ? 2 : 8;
+    const size_t pitch = (n + 63) / 64 * 64 + 64;                    // bytes between two packets' outputs on the device
+    WFX_TRY(wfx_reserve(ctx, ctx->b_scal, count * sizeof(wfx_dev_scalars)));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_x, count * n * esz + 16));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_audio, n * 8 + 16));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_envraw, n * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_env, n * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_dig, count * pitch));
+    WFX_TRY(h2d(ctx, ctx->b_x.p, samples, count * n * esz));
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    WFX_HIP(ctx, hipMemsetAsync(ds, 0, count * sizeof(wfx_dev_scalars), ctx->stream));
+    ctx->force_pow2 = false;
+    for (size_t p = 0; p < count; ++p) {
+        const void *xin = (const char *)ctx->b_x.p + p * n * esz;
+        uint8_t *dig = (uint8_t *)ctx->b_dig.p + p * pitch;
+        WFX_TRY(wfx_dev_notch(ctx, xin, in_kind, n, b, a, (double *)ctx->b_audio.p));
+        WFX_TRY(wfx_dev_hilbert_env_fft(ctx, (const double *)ctx->b_audio.p, n, (double *)ctx->b_envraw.p));
+        WFX_TRY(wfx_dev_median3(ctx, (const double *)ctx->b_envraw.p, n, (double *)ctx->b_env.p));
+        WFX_TRY(wfx_dev_percentiles(ctx, (const double *)ctx->b_env.p, n, ranks, gamma_lo, gamma_hi, ds + p));
+        WFX_TRY(wfx_dev_quantise(ctx, (const double *)ctx->b_env.p, n, ds + p, dig, ds + p, 0.000001));
+    }
+    WFX_HIP(ctx, hipMemcpy2DAsync(out, n, ctx->b_dig.p, pitch, n, count, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<wfx_dev_scalars> hs(count);
+    WFX_TRY(d2h_sync(ctx, hs.data(), ds, count * sizeof(wfx_dev_scalars)));
+    for (size_t p = 0; p < count; ++p) {
+        if (low) low[p] = hs[p].low;
+        if (high) high[p] = hs[p].high;
+    }
     return 0;
 }
 

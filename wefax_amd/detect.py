@@ -32,19 +32,15 @@ def local_maxima(x: np.ndarray) -> np.ndarray:
     n = x.shape[0]
     if n < 3:
         return np.empty(0, dtype=np.int64)
-    rises = np.flatnonzero(x[1:-1] > x[:-2]) + 1                  # candidates: x[i - 1] < x[i]
-    out = []
-    last = -1
-    for i in rises:
-        if i <= last:
-            continue
-        a = i + 1
-        while a < n - 1 and x[a] == x[i]:
-            a += 1
-        if x[a] < x[i]:
-            out.append((i + a - 1) // 2)
-            last = a - 1
-    return np.asarray(out, dtype=np.int64)
+    # runs of equal values: a run is a peak when the runs on both sides are lower; the first and last run never are
+    change = np.flatnonzero(x[1:] != x[:-1]) + 1
+    starts = np.concatenate(([0], change))
+    ends = np.concatenate((change - 1, [n - 1]))
+    vals = x[starts]
+    if vals.shape[0] < 3:
+        return np.empty(0, dtype=np.int64)
+    is_peak = (vals[:-2] < vals[1:-1]) & (vals[2:] < vals[1:-1])
+    return ((starts[1:-1][is_peak] + ends[1:-1][is_peak]) // 2).astype(np.int64)
 
 
 def select_by_distance(peaks: np.ndarray, priority: np.ndarray, distance: float) -> np.ndarray:
