@@ -415,3 +415,35 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(nat, "LIB_PATH", "/nonexistent/libwefax_hip.so")
     with pytest.raises(nat.NativeError, match="no CPU fallback"):
         nat.load()
+
+
+@pytest.mark.gpu
+def test_decode_into_a_bound_image_buffer(ctx):
+    """wfx_decode_bind_image: the decode writes {int64 bytes, int64 width, image} straight into caller-owned device
+    memory; the image and every scalar equal those of an unbound decode; unbinding restores the context's buffer."""
+    from wefax_amd import _native as nat, synth
+    from wefax_amd.wefax import DecodeJob
+    x = synth.synth_capture(11025.0, noise=0.05, seed=4, image_lines=90)
+    job = DecodeJob(ctx, x, 11025, 120)
+    job.run()
+    info0 = job.result()
+    img0 = ctx.decode_fetch(nat.WFX_BUF_IMAGE, (4 * info0.height, info0.width), np.uint8)
+    cap = 16 + job.width * 4 * (job.n // job.width)
+    buf = ctx.dev_malloc(cap)
+    try:
+        ctx.decode_bind_image(buf, cap)
+        job.run()
+        info1 = job.result()
+        raw = ctx.dev_download(buf, (cap,), np.uint8)
+        nb, w = np.frombuffer(raw[:16].tobytes(), dtype=np.int64)
+        assert (info1.height, info1.start_frame, info1.npeaks) == (info0.height, info0.start_frame, info0.npeaks)
+        assert w == info0.width and nb == 4 * info0.height * info0.width
+        assert np.array_equal(raw[16:16 + nb].reshape(4 * info0.height, info0.width), img0)
+        assert np.array_equal(ctx.decode_fetch(nat.WFX_BUF_IMAGE, (4 * info1.height, info1.width), np.uint8), img0)
+        ctx.decode_bind_image(0, 0)
+        job.run()
+        job.result()
+        assert np.array_equal(ctx.decode_fetch(nat.WFX_BUF_IMAGE, (4 * info0.height, info0.width), np.uint8), img0)
+    finally:
+        ctx.decode_bind_image(0, 0)
+        ctx.dev_free(buf)
