@@ -295,16 +295,19 @@ int wfx_decode_run(wfx_ctx *ctx)
         cur = ctx->b_x.p;
         cur_kind = WFX_IN_F64_MONO;
     }
+    ctx->force_pow2 = p.hilbert_mode == WFX_HILBERT_FFT_POW2;       // (also selects the padded resampler)
     if (p.resample) {
-        if (cur_kind == WFX_IN_I16_MONO) {
+        // an int16 capture whose lengths the mixed-radix resampler takes is read in place by its first pass
+        const bool in_place16 = cur_kind == WFX_IN_I16_MONO && !ctx->force_pow2 && wfx_mr_resample_supported(n0, n) && !getenv("WFX_NO_I16_RESAMPLE");
+        if (cur_kind == WFX_IN_I16_MONO && !in_place16) {
             WFX_TRY(wfx_reserve(ctx, ctx->b_x, n0 * 8));
             WFX_TRY(wfx_dev_i16_to_f64(ctx, (const int16_t *)cur, n0, (double *)ctx->b_x.p));
             cur = ctx->b_x.p;
-            cur_kind = WFX_IN_F64_MONO;
         }
         WFX_TRY(wfx_reserve(ctx, ctx->b_tmp, n * 8));
-        WFX_TRY(wfx_dev_resample_fft(ctx, (const double *)cur, n0, n, (double *)ctx->b_tmp.p));
+        WFX_TRY(wfx_dev_resample_fft(ctx, (const double *)cur, n0, n, (double *)ctx->b_tmp.p, in_place16));
         cur = ctx->b_tmp.p;
+        cur_kind = WFX_IN_F64_MONO;
     }
     // the notch is the first kernel that can see the device scalars: its edge workgroup zeroes them
     bool cleared = false;

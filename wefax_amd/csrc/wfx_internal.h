@@ -185,7 +185,8 @@ int wfx_dev_hilbert_env_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *e
 int wfx_dev_spectrum_abs(wfx_ctx *ctx, const double *x, uint64_t n, double *amp);
 int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env, unsigned *l0hist);
 int wfx_dev_hilbert_env_bluestein(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw);
-int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out);
+// x_is_i16: x points at int16 samples; valid only when wfx_mr_resample_supported(n0, num) (the mixed-radix form reads them in place)
+int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16 = false);
 
 // wfx_stages.hip
 int wfx_dev_merge(wfx_ctx *ctx, const int16_t *lr, uint64_t n, double *out);
@@ -229,7 +230,7 @@ bool wfx_mr_supported(uint64_t L);
 void wfx_mr_release(wfx_ctx *ctx);
 int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out);
 bool wfx_mr_resample_supported(uint64_t n0, uint64_t num);
-int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out);
+int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16 = false);
 
 int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long fixed, int width, long long room, long long *hdr);
 

@@ -176,7 +176,8 @@ __device__ __forceinline__ void mr_stage(cplx *tile, const cplx *wr, int R, int 
 // in flight across it (a __syncthreads() would drain it with s_waitcnt vmcnt(0))
 __device__ __forceinline__ void mr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// IN_MODE 0: complex input array; 1: packed real input z[q] = x[2q+1] + i x[2q]
+// IN_MODE 0: complex input array; 1: packed real input z[q] = x[2q+1] + i x[2q];
+// 2: int16 samples read as z[q] = x[2q] + i x[2q+1] (the resampler's first pass on an int16 capture: no f64 copy)
 // OUT_MODE 0: plain; 1: multiply by the Hilbert spectrum G[k] / L (last forward pass)
 // Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and fetches the
 // next tile into registers while the current one is transformed, so HBM stays busy during the
@@ -224,6 +225,9 @@ mr_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, con
                 if (IN_MODE == 1) {
                     const cplx x2 = in[a];
                     v = make_double2(x2.y, x2.x);
+                } else if (IN_MODE == 2) {
+                    const short2 x2 = ((const short2 *)in)[a];
+                    v = make_double2((double)x2.x, (double)x2.y);
                 } else {
                     v = in[a];
                 }
@@ -512,8 +516,13 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                 cplx v = make_double2(0.0, 0.0);
                 if (ok) {
                     const long long adr = (long long)j + (long long)(a * RB + b) * ncol;
-                    v = in[adr];
-                    if (IN_MODE == 1) v = make_double2(v.y, v.x);
+                    if (IN_MODE == 2) {
+                        const short2 x2 = ((const short2 *)in)[adr];
+                        v = make_double2((double)x2.x, (double)x2.y);
+                    } else {
+                        v = in[adr];
+                        if (IN_MODE == 1) v = make_double2(v.y, v.x);
+                    }
                 }
                 pre[ia][a] = v;
             }
@@ -932,7 +941,8 @@ void wfx_mr_release(wfx_ctx *ctx)
 // One transform of the plan: `dir` 0 forward / 1 inverse, reading `src`, ping-ponging between A and B; the last pass
 // writes to `final_dst` when given.  hilbert: the packed-real load swap on the first forward pass and the multiplication
 // by the Hilbert spectrum on the last one.  Unnormalised; natural order in and out (self-sorting passes).
-static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cplx *B, int dir, bool hilbert, cplx *final_dst, cplx **result)
+static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cplx *B, int dir, bool hilbert, cplx *final_dst, cplx **result,
+                  bool src_i16 = false)
 {
     const cplx *tb = (const cplx *)pc->tables.p;
     const int np = pc->h.npass;
@@ -942,6 +952,7 @@ static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cpl
         const cplx *lo = tb + pc->h.lo_off[i], *hi = tb + pc->h.hi_off[i];
         const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
         const bool first = hilbert && dir == 0 && i == 0, last_fwd = hilbert && dir == 0 && i == np - 1;
+        const bool first16 = src_i16 && dir == 0 && i == 0 && !hilbert;       // int16 pairs as the complex input
         if (i == np - 1 && final_dst) dst = final_dst;
         // register-resident two-level pass when the radix is a pair (mr2_pass); per-prime LDS stages otherwise
         bool done = false;
@@ -951,7 +962,9 @@ static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cpl
             const unsigned g2 = (unsigned)(nt < 512 ? nt : 512);
 #define X(RA_, RB_)                                                                                                                   \
     if (!done && d.ra == (RA_) && d.rb == (RB_)) {                                                                                    \
-        if (dir == 1)                                                                                                                 \
+        if (first16)                                                                                                                  \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 2, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 1)                                                                                                            \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
         else if (last_fwd)                                                                                                            \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
@@ -969,6 +982,8 @@ static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cpl
             const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);       // 2 persistent workgroups per CU
             if (dir == 1)
                 WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+            else if (first16)
+                WFX_LAUNCH(ctx, kid, (mr_pass<2, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
             else if (first && last_fwd)
                 WFX_LAUNCH(ctx, kid, (mr_pass<1, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
             else if (first)
@@ -1047,7 +1062,7 @@ bool wfx_mr_resample_supported(uint64_t n0, uint64_t num)
     return wfx_mr_supported(n0 / 2) && wfx_mr_supported(num / 2);
 }
 
-int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out)
+int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16)
 {
     const long long M = (long long)(n0 / 2), K = (long long)(num / 2);
     mr_plan_cache *p1 = nullptr, *p2 = nullptr;
@@ -1057,7 +1072,8 @@ int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num
     WFX_TRY(wfx_reserve(ctx, ctx->b_work2, cap));
     cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
     cplx *Z = nullptr;
-    WFX_TRY(mr_run(ctx, p1, (const cplx *)x, A, B, 0, false, nullptr, &Z));
+    // (an int16 capture is read in place by the first pass: no float64 copy of the input)
+    WFX_TRY(mr_run(ctx, p1, (const cplx *)x, A, B, 0, false, nullptr, &Z, x_is_i16));
     cplx *Wb = (Z == A) ? B : A;
     WFX_LAUNCH(ctx, K_RESAMPLE_PW, resample_mr_glue, dim3(wfx_stream_grid((uint64_t)K, 256)), dim3(256), (const cplx *)Z, (long long)n0,
                (long long)num, Wb);
