@@ -217,3 +217,15 @@ def test_hip_packets_back_to_back_equal_one_by_one(ctx):
         assert np.array_equal(got, wo.process_packet(p, 11025)["samples"])
     ragged = process_packets(ctx, 11025, [x[0], x[1][:9000]])            # different lengths: decoded one by one
     assert np.array_equal(ragged[0], many[0]) and ragged[1].shape == (9000,)
+
+
+@pytest.mark.gpu
+def test_packet_entry_points_reject_bad_input(ctx):
+    from wefax_amd import _native as nat
+    with pytest.raises(nat.NativeError):
+        ctx.packet_spectrum(np.zeros(1, dtype=np.int16))                 # fewer than two samples
+    amp = ctx.packet_spectrum(np.array([3, -3, 3, -3, 3], dtype=np.int16))      # odd length: n // 2 bins
+    f, a = wo.packet_spectrum(np.array([3, -3, 3, -3, 3], dtype=np.int16), 5)
+    assert amp.shape == (2,) and np.abs(amp / (amp.max() + 0.0001) - a).max() < 1e-12
+    with pytest.raises(ValueError):
+        ctx.packets_process(np.zeros(11025, dtype=np.int16), [1, 0, 0], [1, 0, 0], (0, 0, 1, 1), 0.0, 0.0)   # not [count, n]
