@@ -1337,7 +1337,7 @@ __device__ __forceinline__ bool dev_ok(double frame_samples, long long x)
 // the sequential scan as before.
 #define PICK_SEG 16384
 #define PICK_SEG_MAX 128                 // segments joined by one wave, two per lane
-#define PICK_SEG_ENT 16                  // list entries per segment (a window holds 32768 / mind + 2 peaks)
+#define PICK_SEG_ENT 24                  // list entries per segment (a window of 32768 holds 14 peaks at 240 LPM, 8 at 120)
 struct pick_seg {
     int n;                               // entries: completed peaks, then (tail != 0) one appended but not completed
     int tail, end, overflow;             // end: the window reached the end of the data (every entry is final)
