@@ -381,16 +381,6 @@ def group_peaks(peaks, sample_rate: int, frame_len: float):
     return max(groups, key=len)       # ValueError("max() arg is an empty sequence")
 
 
-def find_sync_pulse(d: np.ndarray, sample_rate: int, frame_len: float):
-    n1, n0, mind = sync_constants(sample_rate, frame_len)
-    if faithful_loops:
-        peaks, first, hit = pick_peaks_loop(d_list, n1, n0, mind)
-    else:
-        corr = sync_correlation(d, n1, n0)
-        peaks, first, hit = pick_peaks(corr, mind)
-    return peaks, first, hit, group_peaks(peaks, sample_rate, frame_len)
-
-
 # --------------------------------------------------------------------------
 # a10: image assembly  (wefax.py:296-327)
 # --------------------------------------------------------------------------

@@ -401,6 +401,11 @@ int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
                            int edge_flags)
 {
     if (n < NOTCH_SMALL) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "segment of %llu samples is too short for the notch", (unsigned long long)n);
+    // the 49-tap form is filtfilt only while the impulse response has died within NOTCH_K samples (wfx_dev_notch falls back to the
+    // chunked recurrence otherwise; a segment has no such fallback: its halo is sized for the 49 taps)
+    const double radius = biquad_pole_radius(a);
+    if (pow(radius, NOTCH_K) > 1e-16)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "notch: pole radius %.4f is too large for the 49-tap segment form (design at 11 025 Hz with Q <= ~1)", radius);
     notch_coef c;
     notch_prepare(c, b, a);
     const unsigned ib = notch_grid(n - 2 * NOTCH_K);

@@ -18,14 +18,15 @@ DEFAULT_NOTCH = (2600, 1)           # config/config.json:16-17
 
 def load_notch_settings(config_path: str = "config/config.json"):
     """The two constants the hot path reads from the reference's config file
-    (wefax.py:63-64; config.py:11 opens the file relative to cwd).  Defaults when
-    the file is absent."""
+    (wefax.py:63-64; config.py:11 opens the file relative to cwd).  Defaults only when
+    the file is absent; a malformed file or a missing key raises, as it does in the reference."""
     try:
-        with open(config_path) as fh:
-            s = json.load(fh)["notch_filter_settings"]
-        return int(s["notch_filter_frequency"]), s["notch_filter_quality_factor"]
-    except (OSError, KeyError, ValueError):
+        fh = open(config_path)
+    except OSError:
         return DEFAULT_NOTCH
+    with fh:
+        s = json.load(fh)["notch_filter_settings"]
+    return int(s["notch_filter_frequency"]), s["notch_filter_quality_factor"]
 
 
 def iirnotch(w0: float, q: float, fs: float):

@@ -28,7 +28,7 @@ class DataPacket:
         self.sample_rate = sample_rate
         self.raw_samples = samples
         self._own_ctx = ctx is None
-        self._ctx = ctx if ctx is not None else nat.Context(0)
+        self._ctx = ctx if ctx is not None else nat.Context(None)
         self._spec = None
         try:
             out, self.low, self.high = _process(self._ctx, sample_rate, np.asarray(samples), notch)
