@@ -250,6 +250,58 @@ int wfx_d_sync_search(wfx_ctx *ctx, const uint8_t *d_dev, size_t n, size_t n_tot
 int wfx_d_image_rows(wfx_ctx *ctx, const uint8_t *d_dev, size_t n, uint64_t g0, uint64_t start, int width, int h_total, int y0,
                      int rows, uint8_t *img_dev);
 
+/* ---- one capture over several GPUs: the exact path, sharded by sample range ---------------------------------
+ * SURVEY.md section 8b item (4) / 8e.  The reference decodes on one host; its two global operators -- scipy.signal.hilbert
+ * (wefax.py:174) and scipy.signal.resample (wefax.py:384) -- are computed here as DISTRIBUTED exact transforms (two
+ * transposes per transform over RCCL), everything else on each rank's own sample range with a halo:
+ *   rank r owns samples [own_lo, own_hi) at 11 025 Hz (and the matching input frames): [resample] -> notch filtfilt ->
+ *   Hilbert envelope + median 5 -> np.percentile by radix select (two all-reduces of histograms + one all-gather of candidate
+ *   keys) -> quantise -> ONE gather of the uint8 stream to rank 0 -> sync search + bicubic image on rank 0.
+ * The result is the single-GPU exact path's (identical uint8 stream; float stages to rounding) and bit-identical for every
+ * world size.  All collectives are enqueued on the context's stream by the library itself; the only host synchronisation
+ * of a decode is the one in wfx_shard_result.
+ *
+ * Communicator: RCCL, bound directly.  Rank 0 calls wfx_comm_unique_id and passes the 128 bytes to the other processes
+ * (wefax_amd/sharded.py: a loopback TCP socket); every rank then calls wfx_comm_create with its context.  Failures of the
+ * transport return WFX_ERR_COMM.  wfx_comm_create_local makes `world` communicators whose ranks all live in the calling
+ * process (contexts on any device): collectives complete when the last rank has posted its part -- drive the ranks phase
+ * by phase with wfx_shard_phase.  It exists to run the N-rank form on a one-GPU box (tests, emulation). */
+typedef struct wfx_comm wfx_comm;
+typedef struct wfx_shard wfx_shard;
+#define WFX_COMM_ID_BYTES 128
+int wfx_comm_unique_id(void *id_out /* WFX_COMM_ID_BYTES */);
+int wfx_comm_create(wfx_ctx *ctx, const void *id, int world, int rank, wfx_comm **out);
+int wfx_comm_create_local(int world, wfx_comm **out /* [world] */);
+int wfx_comm_info(wfx_comm *comm, int *world, int *rank, int *is_rccl);
+int wfx_comm_destroy(wfx_comm *comm);
+
+typedef struct {
+    int      world, rank;
+    int      first_radix[2];   /* radix pair of the distributed first pass                                           */
+    uint64_t in_lo, in_hi;     /* input frames [in_lo, in_hi) this rank must provide (global indices)                 */
+    uint64_t own_lo, own_hi;   /* samples at 11 025 Hz this rank owns                                                 */
+} wfx_shard_layout;
+
+/* host only (no GPU needed): how a capture described by `p` is cut for `world` ranks; WFX_ERR_BAD_ARG when it cannot be
+ * sharded (odd or non-13-smooth lengths, too short for the world size): decode it on one GPU then */
+int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_shard_layout *out);
+/* `p` describes the WHOLE capture (as for wfx_decode_upload); hilbert_mode must be WFX_HILBERT_FFT */
+int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, wfx_shard **out);
+/* this rank's input frames [in_lo, in_hi): host memory (copied) or caller-owned device memory (kept, not copied) */
+int wfx_shard_upload(wfx_shard *sh, const void *host_frames);
+int wfx_shard_attach(wfx_shard *sh, const void *dev_frames);
+/* the decode is a fixed sequence of phases, each ending in at most one collective; wfx_decode_sharded enqueues all of them
+ * (RCCL communicator, or world 1); with a local communicator call phase p for every rank before phase p + 1 for any */
+int wfx_shard_phase_count(wfx_shard *sh);
+int wfx_shard_phase(wfx_shard *sh, int phase);
+int wfx_decode_sharded(wfx_shard *sh);
+/* waits for this rank's stream.  Rank 0: the decode's scalars (as wfx_decode_result); other ranks: n, width, low, high only */
+int wfx_shard_result(wfx_shard *sh, wfx_decode_info *info);
+/* stage buffers: WFX_BUF_AUDIO / ENVELOPE / DIGITAL = this rank's own samples [own_lo, own_hi); WFX_BUF_IMAGE and the
+ * whole WFX_BUF_DIGITAL stream (bytes == n) on rank 0 only */
+int wfx_shard_fetch(wfx_shard *sh, int buffer_id, void *host_out, size_t bytes);
+int wfx_shard_destroy(wfx_shard *sh);
+
 /* ---- measurement ------------------------------------------------------ */
 /* HIP-event stopwatch on the context's stream */
 int wfx_timer_start(wfx_ctx *ctx);

@@ -30,6 +30,9 @@ SYMBOLS = [
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
     "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_resample_rational", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
+    "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_info", "wfx_comm_destroy",
+    "wfx_shard_layout_query", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
+    "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
     "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
     "wfx_profile_kernel_count", "wfx_profile_kernel_name", "wfx_profile_get",
 ]
@@ -74,6 +77,22 @@ class DecodeInfo(C.Structure):
         ("first_pos", C.c_int64 * (WFX_MAX_PEAKS + 1)),
         ("phasing", C.c_int64 * (WFX_MAX_PEAKS + 1)),
     ]
+
+
+class ShardLayout(C.Structure):
+    _fields_ = [
+        ("world", C.c_int),
+        ("rank", C.c_int),
+        ("first_radix", C.c_int * 2),
+        ("in_lo", C.c_uint64),
+        ("in_hi", C.c_uint64),
+        ("own_lo", C.c_uint64),
+        ("own_hi", C.c_uint64),
+    ]
+
+
+WFX_COMM_ID_BYTES = 128
+WFX_ERR_COMM = -5
 
 
 class NativeError(RuntimeError):
@@ -142,6 +161,21 @@ def load():
     lib.wfx_d_quantise.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, C.POINTER(C.c_uint64)]
     lib.wfx_d_sync_search.argtypes = [vp, vp, sz, sz, i, i, C.c_int64, C.c_double, i, C.POINTER(DecodeInfo)]
     lib.wfx_d_image_rows.argtypes = [vp, vp, sz, C.c_uint64, C.c_uint64, i, i, i, i, vp]
+    lib.wfx_comm_unique_id.argtypes = [vp]
+    lib.wfx_comm_create.argtypes = [vp, vp, i, i, C.POINTER(vp)]
+    lib.wfx_comm_create_local.argtypes = [i, C.POINTER(vp)]
+    lib.wfx_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    lib.wfx_comm_destroy.argtypes = [vp]
+    lib.wfx_shard_layout_query.argtypes = [C.POINTER(DecodeParams), i, i, C.POINTER(ShardLayout)]
+    lib.wfx_shard_create.argtypes = [vp, vp, C.POINTER(DecodeParams), C.POINTER(vp)]
+    lib.wfx_shard_upload.argtypes = [vp, vp]
+    lib.wfx_shard_attach.argtypes = [vp, vp]
+    lib.wfx_shard_phase_count.argtypes = [vp]
+    lib.wfx_shard_phase.argtypes = [vp, i]
+    lib.wfx_decode_sharded.argtypes = [vp]
+    lib.wfx_shard_result.argtypes = [vp, C.POINTER(DecodeInfo)]
+    lib.wfx_shard_fetch.argtypes = [vp, i, vp, sz]
+    lib.wfx_shard_destroy.argtypes = [vp]
     lib.wfx_timer_start.argtypes = [vp]
     lib.wfx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.wfx_profile_enable.argtypes = [vp, i]
@@ -463,6 +497,124 @@ class Context:
             if cnt.value:
                 out[self.lib.wfx_profile_kernel_name(k).decode()] = (int(cnt.value), float(ms.value))
         return out
+
+
+def _global_error(lib, rc: int) -> NativeError:
+    msg = lib.wfx_last_error(None)
+    return NativeError(f"libwefax_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def shard_layout(params: DecodeParams, world: int, rank: int) -> ShardLayout:
+    """Host-only: how the capture described by ``params`` is cut for ``world`` ranks (no GPU needed)."""
+    lib = load()
+    out = ShardLayout()
+    rc = lib.wfx_shard_layout_query(C.byref(params), world, rank, C.byref(out))
+    if rc != 0:
+        raise _global_error(lib, rc)
+    return out
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: the 128-byte RCCL unique id the other ranks need for ``Comm.rccl``."""
+    lib = load()
+    buf = C.create_string_buffer(WFX_COMM_ID_BYTES)
+    rc = lib.wfx_comm_unique_id(buf)
+    if rc != 0:
+        raise _global_error(lib, rc)
+    return buf.raw
+
+
+class Comm:
+    """Communicator handle of the sharded decode (include/wefax_hip.h): RCCL, or all ranks in this process."""
+
+    def __init__(self, handle: int, lib):
+        self.h, self.lib = handle, lib
+        w, r, k = C.c_int(0), C.c_int(0), C.c_int(0)
+        lib.wfx_comm_info(self.h, C.byref(w), C.byref(r), C.byref(k))
+        self.world, self.rank, self.is_rccl = w.value, r.value, bool(k.value)
+
+    @classmethod
+    def rccl(cls, ctx: "Context", unique_id: bytes, world: int, rank: int) -> "Comm":
+        if len(unique_id) != WFX_COMM_ID_BYTES:
+            raise ValueError("RCCL unique id must be 128 bytes")
+        h = C.c_void_p(0)
+        ctx._check(ctx.lib.wfx_comm_create(ctx.h, unique_id, world, rank, C.byref(h)))
+        return cls(h.value, ctx.lib)
+
+    @classmethod
+    def local(cls, world: int):
+        """``world`` communicators whose ranks all live in this process (emulation on one GPU, tests)."""
+        lib = load()
+        arr = (C.c_void_p * world)()
+        rc = lib.wfx_comm_create_local(world, arr)
+        if rc != 0:
+            raise _global_error(lib, rc)
+        return [cls(arr[r], lib) for r in range(world)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wfx_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Shard:
+    """One rank's part of a sharded exact decode (wfx_shard_*)."""
+
+    def __init__(self, ctx: "Context", comm: Comm, params: DecodeParams):
+        self.ctx, self.comm, self.params = ctx, comm, params
+        h = C.c_void_p(0)
+        ctx._check(ctx.lib.wfx_shard_create(ctx.h, comm.h, C.byref(params), C.byref(h)))
+        self.h = h.value
+        self.layout = shard_layout(params, comm.world, comm.rank)
+        self._keep = None
+
+    def upload(self, frames: np.ndarray):
+        """``frames``: this rank's input frames [layout.in_lo, layout.in_hi)."""
+        a = np.ascontiguousarray(frames)
+        if a.shape[0] != self.layout.in_hi - self.layout.in_lo:
+            raise ValueError(f"rank {self.comm.rank} needs frames [{self.layout.in_lo}, {self.layout.in_hi}), got {a.shape[0]}")
+        self.ctx._check(self.ctx.lib.wfx_shard_upload(self.h, _ptr(a)))
+
+    def attach(self, dev_ptr: int):
+        self.ctx._check(self.ctx.lib.wfx_shard_attach(self.h, C.c_void_p(dev_ptr)))
+
+    @property
+    def phases(self) -> int:
+        return int(self.ctx.lib.wfx_shard_phase_count(self.h))
+
+    def phase(self, k: int):
+        self.ctx._check(self.ctx.lib.wfx_shard_phase(self.h, k))
+
+    def run(self):
+        """Enqueue every phase (RCCL communicator or world 1); asynchronous."""
+        self.ctx._check(self.ctx.lib.wfx_decode_sharded(self.h))
+
+    def result(self) -> DecodeInfo:
+        info = DecodeInfo()
+        self.ctx._check(self.ctx.lib.wfx_shard_result(self.h, C.byref(info)))
+        return info
+
+    def fetch(self, buffer_id: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self.ctx._check(self.ctx.lib.wfx_shard_fetch(self.h, buffer_id, _ptr(out), out.nbytes))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.wfx_shard_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_count() -> int:

@@ -21,8 +21,9 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libwefax_hip.so")
-SOURCES = ["wfx_context.hip", "wfx_fft.hip", "wfx_mrfft.hip", "wfx_stages.hip", "wfx_fir.hip", "wfx_polyphase.hip", "wfx_api.hip"]
-HEADERS = [os.path.join(CSRC, "wfx_internal.h"), os.path.join(REPO, "include", "wefax_hip.h")]
+SOURCES = ["wfx_context.hip", "wfx_fft.hip", "wfx_mrfft.hip", "wfx_stages.hip", "wfx_fir.hip", "wfx_polyphase.hip", "wfx_api.hip",
+           "wfx_comm.hip", "wfx_dist.hip", "wfx_shard.hip"]
+HEADERS = [os.path.join(CSRC, "wfx_internal.h"), os.path.join(CSRC, "wfx_dist.h"), os.path.join(REPO, "include", "wefax_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(REPO, "include"), "-I", CSRC]
 
@@ -67,7 +68,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
     return LIB
 
 

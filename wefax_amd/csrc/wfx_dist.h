@@ -1,0 +1,98 @@
+// Distributed form of the two global operators of the path (wfx_dist.hip), used by the sharded decode (wfx_shard.hip).
+//
+// A transform of L = R1 * M points (R1 = first radix of the plan, a radix pair with a register-resident pass) over
+// `world` ranks.  Index n = n1 M + n2.  Three layouts of one rank's share:
+//
+//   rows     n1 in [rows[r], rows[r+1]), all n2                 -- contiguous sample ranges: what the stencil stages own
+//   columns  all n1, n2 in [cols[r], cols[r+1])                 -- [R1][w]: the first pass (R1-point transforms along n1)
+//   slab     first-pass outputs k1 in K_r (a set closed under k1 -> R1 - k1), all n2 / all k2
+//            -- [M][B] with the k1 index innermost: the remaining passes are B interleaved M-point transforms
+//
+// forward:  rows -(E1)-> columns, pass 1, -(E2)-> slab, passes 2..np            (spectrum: X[k1 + R1 k2] at [k2][kk])
+// inverse:  slab, passes np..2, -(E3)-> columns, pass 1, -(E4)-> rows (+ a halo of neighbouring points)
+//
+// Every exchange E is one personalised all-to-all (grouped send / recv on the library's stream) between a packing and an
+// unpacking copy; the passes themselves are the single-GPU kernels (mr2_pass) with a generalised twiddle index.
+#pragma once
+
+#include "wfx_internal.h"
+
+struct wfx_dist_kmap {       // k1 = kk < kc0 ? kb0 + kk : kb1 + (kk - kc0), kk in [0, B)
+    int kb0, kc0, kb1, B;
+};
+
+struct wfx_dist_geom {       // what all transforms of one sharded decode share
+    int world = 1, rank = 0;
+    int ra1 = 0, rb1 = 0, R1 = 0;
+    std::vector<int> rows;               // [world + 1]
+    std::vector<wfx_dist_kmap> km;       // [world]
+    int nrows(int r) const { return rows[r + 1] - rows[r]; }
+};
+
+// host-only: partitions for a first radix (ra1, rb1); false when the world is too large for it
+bool wfx_dist_make_geom(wfx_dist_geom &g, int world, int rank, int ra1, int rb1);
+// host-only: first radix for transforms of the given lengths (all must be multiples of it with pair-decomposable cofactors)
+bool wfx_dist_choose_r1(const long long *lengths, int nlen, int world, int *ra1, int *rb1);
+
+struct wfx_dist_piece {      // one 2-D block of a packing / unpacking copy (device descriptor)
+    unsigned long long src, dst;         // element-typed base addresses
+    int rows, cols;
+    long long src_rs, dst_rs;
+    int kb0, kc0, kb1, B;                // column map (gather / scatter by k1)
+};
+
+class wfx_dist {
+  public:
+    // buffers are owned by this object; `halo_before` / `halo_after`: points delivered around the own rows by the inverse
+    int init(wfx_ctx *ctx, const wfx_dist_geom &g, long long L, int elem_bytes_in, int halo_before, int halo_after);
+    void release();
+    // rows_in: this rank's rows of the forward input; rows_out: [halo_before + nr M + halo_after] points delivered by the
+    // inverse; inv_in: slab buffer (0 / 1) the inverse starts from.  Call once the buffers exist, before the first run.
+    int bind(const void *rows_in, cplx *rows_out, int inv_in);
+    // slab buffer index in which fwd_slab leaves the spectrum
+    int fwd_result_index() const { return (int)(d_fwd.size() & 1); }
+
+    long long L = 0, M = 0;
+    int w = 0, B = 0, nr = 0;            // this rank's columns, slab batch, rows
+    std::vector<long long> cols;         // [world + 1]
+    long long slab_points() const { return M * (long long)B; }
+
+    // ---- forward --------------------------------------------------------------------------------------------------
+    // rows_in: this rank's rows [nr][M] (elements of elem_bytes_in: 16 = cplx / pairs of doubles, 4 = int16 pairs)
+    int fwd_pack_exchange(wfx_comm *c, const void *rows_in);                       // E1
+    int fwd_pass1_exchange(wfx_comm *c, int in_mode);                              // pass 1, E2
+    int fwd_slab(int hilbert_spectrum, cplx **spectrum);                           // passes 2..np
+    // ---- inverse ---------------------------------------------------------------------------------------------------
+    // slab_in: [M][B] in one of slab_buffer(0 / 1); destroyed
+    int inv_slab_exchange(wfx_comm *c, cplx *slab_in);                             // passes np..2, E3
+    int inv_pass1_exchange(wfx_comm *c, cplx *rows_out);                           // unpack, pass 1, E4 (halo pieces land in rows_out directly)
+    int inv_unpack(cplx *rows_out);                                                // rows_out: [halo_before + nr M + halo_after]
+    cplx *slab_buffer(int i) { return (cplx *)(i ? b_a2.p : b_a.p); }
+
+  private:
+    wfx_ctx *ctx = nullptr;
+    wfx_dist_geom g;
+    int es_in = 16, hb = 0, ha = 0;
+    std::vector<std::pair<int, int>> sub;          // radix pairs of M, ascending
+    mr_pass_desc d_first{}, d_last{};
+    std::vector<mr_pass_desc> d_fwd, d_inv;
+    std::vector<size_t> tw_fwd, tw_inv;
+    size_t tw_last = 0;
+    wfx_devbuf tables, b_pack, b_recv, b_y, b_a, b_a2, b_desc;
+    cplx *inv_result = nullptr, *inv_start = nullptr;
+    // exchange lists and piece descriptors (device copies in b_desc)
+    std::vector<wfx_xfer> x1, x2, x3, x4;
+    std::vector<wfx_dist_piece> p1, p2, p3, p4;
+    size_t o1 = 0, o2 = 0, o3 = 0, o4 = 0;          // offsets of the piece arrays in b_desc
+    const void *last_rows_in = nullptr;
+    cplx *last_rows_out = nullptr;
+    void build_lists(const void *rows_in, cplx *rows_out);
+    int upload_pieces();
+};
+
+// copies driven by piece descriptors (one workgroup column per piece: grid.y)
+int wfx_dist_copy2d(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, long long max_elems, int elem_bytes);
+int wfx_dist_gather_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, long long max_elems);
+int wfx_dist_scatter_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, int max_rows);
+// scipy.signal.resample's bin copy between the forward spectrum slab (packed n0 / 2 points) and the inverse's input slab (num / 2)
+int wfx_dist_resample_glue(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Z, long long n0, long long num, cplx *W);

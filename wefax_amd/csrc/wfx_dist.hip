@@ -1,0 +1,593 @@
+// Distributed exact transforms of the sharded decode: see wfx_dist.h for the layouts.
+//
+// Why this exists: the two operators that make the reference's path global -- scipy.signal.hilbert (wefax.py:174) and
+// scipy.signal.resample (wefax.py:384) -- are DFTs over the whole capture.  Truncating them to halo-local FIRs costs
+// +-1 LSB (SURVEY.md appendix B.2, round-1 measurements), which moves sync peaks and with them the whole image.  A
+// Cooley-Tukey split L = R1 * M keeps them exact on N GPUs: the first pass is R1-point transforms along n1 (needs all n1 of a
+// column -> "columns" layout), the rest is R1 independent M-point transforms (needs all n2 of a first-pass output k1 ->
+// "slab" layout).  Two transposes per transform are the real exchange step of the path; everything else stays local.
+#include <algorithm>
+
+#include "wfx_dist.h"
+
+// ---- geometry (host) ---------------------------------------------------------------------------------------
+bool wfx_dist_make_geom(wfx_dist_geom &g, int world, int rank, int ra1, int rb1)
+{
+    if (world < 1 || rank < 0 || rank >= world || !wfx_mr_is_pair(ra1, rb1)) return false;
+    g.world = world;
+    g.rank = rank;
+    g.ra1 = ra1;
+    g.rb1 = rb1;
+    g.R1 = ra1 * rb1;
+    const int R1 = g.R1, units = R1 / 2 + 1;
+    if (units < 2 * world) return false;              // every rank needs >= 2 first-pass outputs and >= 1 row
+    g.rows.resize(world + 1);
+    for (int s = 0; s <= world; ++s) g.rows[s] = (int)((long long)s * R1 / world);
+    g.km.resize(world);
+    for (int e = 0; e < world; ++e) {
+        // units u in [a, b) stand for {u, R1 - u}: the set is closed under k1 -> -k1, so the bins k and L - k of a real
+        // signal's spectrum sit on the same rank (the resampler's untangling needs both)
+        const int a = (int)((long long)e * units / world), b = (int)((long long)(e + 1) * units / world);
+        int lo1 = R1 - b + 1, hi1 = R1 - a + 1;
+        if (a == 0) hi1 = R1;                                      // 0 is its own mirror
+        if (R1 % 2 == 0 && b - 1 == R1 / 2) lo1 = R1 / 2 + 1;      // so is R1 / 2
+        if (hi1 < lo1) hi1 = lo1;
+        g.km[e].kb0 = a;
+        g.km[e].kc0 = b - a;
+        g.km[e].kb1 = lo1;
+        g.km[e].B = (b - a) + (hi1 - lo1);
+        if (g.km[e].B < 2) return false;
+    }
+    return true;
+}
+
+bool wfx_dist_choose_r1(const long long *lengths, int nlen, int world, int *ra1, int *rb1)
+{
+    // largest first radix that divides every length, leaves pair-decomposable cofactors and gives every rank work:
+    // a large R1 balances rows / slabs over the ranks and keeps the first pass's tiles wide
+    std::vector<std::pair<int, int>> cand;
+    wfx_mr_all_pairs(cand);
+    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first * x.second > y.first * y.second; });
+    for (const auto &c : cand) {
+        const int R1 = c.first * c.second;
+        wfx_dist_geom g;
+        if (!wfx_dist_make_geom(g, world, 0, c.first, c.second)) continue;
+        bool ok = true;
+        for (int i = 0; i < nlen && ok; ++i) {
+            std::vector<std::pair<int, int>> sub;
+            ok = lengths[i] % R1 == 0 && lengths[i] / R1 >= 4ll * world && wfx_mr_pair_plan(lengths[i] / R1, sub);
+        }
+        if (ok) {
+            *ra1 = c.first;
+            *rb1 = c.second;
+            return true;
+        }
+    }
+    return false;
+}
+
+// ---- copies around an exchange --------------------------------------------------------------------------
+__device__ __forceinline__ int dist_k1(const wfx_dist_piece &p, int kk) { return kk < p.kc0 ? p.kb0 + kk : p.kb1 + (kk - p.kc0); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) dist_copy2d_kernel(const wfx_dist_piece *__restrict__ pieces)
+{
+    const wfx_dist_piece p = pieces[blockIdx.y];
+    const T *__restrict__ src = (const T *)p.src;
+    T *__restrict__ dst = (T *)p.dst;
+    const unsigned total = (unsigned)p.rows * (unsigned)p.cols, cols = (unsigned)p.cols;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const unsigned r = e / cols, c = e - r * cols;
+        dst[(long long)r * p.dst_rs + c] = src[(long long)r * p.src_rs + c];
+    }
+}
+
+// dst[j B + kk] = src[j src_rs + k1(kk)]: the columns of the first-pass output that one rank's slab takes
+__global__ void __launch_bounds__(256) dist_gather_k_kernel(const wfx_dist_piece *__restrict__ pieces)
+{
+    const wfx_dist_piece p = pieces[blockIdx.y];
+    const cplx *__restrict__ src = (const cplx *)p.src;
+    cplx *__restrict__ dst = (cplx *)p.dst;
+    const unsigned B = (unsigned)p.B, total = (unsigned)p.rows * B;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const unsigned j = e / B, kk = e - j * B;
+        dst[e] = src[(long long)j * p.src_rs + dist_k1(p, (int)kk)];
+    }
+}
+
+// dst[k1(kk) dst_rs + j] = src[j B + kk]: a slab's rows back into the [R1][w] layout of the last inverse pass
+// (a transposition: 64 x 16 tiles through LDS, 256-byte reads, 1-KB writes)
+__global__ void __launch_bounds__(256) dist_scatter_k_kernel(const wfx_dist_piece *__restrict__ pieces)
+{
+    __shared__ cplx tile[64][17];
+    const wfx_dist_piece p = pieces[blockIdx.y];
+    const cplx *__restrict__ src = (const cplx *)p.src;
+    cplx *__restrict__ dst = (cplx *)p.dst;
+    const int t = threadIdx.x, B = p.B;
+    for (int j0 = blockIdx.x * 64; j0 < p.rows; j0 += gridDim.x * 64) {
+        for (int kk0 = 0; kk0 < B; kk0 += 16) {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int k = t & 15, jj = (t >> 4) + 16 * it;
+                if (j0 + jj < p.rows && kk0 + k < B) tile[jj][k] = src[(long long)(j0 + jj) * B + kk0 + k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int jj = t & 63, k = (t >> 6) + 4 * it;
+                if (j0 + jj < p.rows && kk0 + k < B) dst[(long long)dist_k1(p, kk0 + k) * p.dst_rs + j0 + jj] = tile[jj][k];
+            }
+        }
+    }
+}
+
+static unsigned copy_grid(long long max_elems)
+{
+    long long b = (max_elems + 2047) / 2048;       // ~8 elements per thread
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (unsigned)b;
+}
+
+int wfx_dist_copy2d(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, long long max_elems, int elem_bytes)
+{
+    if (npieces <= 0 || max_elems <= 0) return 0;
+    if (elem_bytes == 16)
+        WFX_LAUNCH(ctx, K_DIST_COPY, dist_copy2d_kernel<double2>, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
+    else if (elem_bytes == 4)
+        WFX_LAUNCH(ctx, K_DIST_COPY, dist_copy2d_kernel<unsigned>, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
+    else
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "copy2d: element size %d", elem_bytes);
+    return 0;
+}
+
+int wfx_dist_gather_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, long long max_elems)
+{
+    if (npieces <= 0 || max_elems <= 0) return 0;
+    WFX_LAUNCH(ctx, K_DIST_COPY, dist_gather_k_kernel, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
+    return 0;
+}
+
+int wfx_dist_scatter_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, int max_rows)
+{
+    if (npieces <= 0 || max_rows <= 0) return 0;
+    unsigned gx = (unsigned)((max_rows + 63) / 64);
+    if (gx > 2048) gx = 2048;
+    WFX_LAUNCH(ctx, K_DIST_COPY, dist_scatter_k_kernel, dim3(gx, npieces), dim3(256), dev_pieces);
+    return 0;
+}
+
+// ---- one distributed transform length -------------------------------------------------------------------
+void wfx_dist::release()
+{
+    wfx_devbuf *bufs[] = {&tables, &b_pack, &b_recv, &b_y, &b_a, &b_a2, &b_desc};
+    for (wfx_devbuf *b : bufs) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
+}
+
+int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int elem_bytes_in, int halo_before, int halo_after)
+{
+    ctx = ctx_;
+    g = g_;
+    L = L_;
+    es_in = elem_bytes_in;
+    hb = halo_before;
+    ha = halo_after;
+    const int R1 = g.R1, W = g.world, me = g.rank;
+    if (L % R1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: %lld is not a multiple of the first radix %d", L, R1);
+    M = L / R1;
+    if (L >= (1ll << 31)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: %lld points exceed 32-bit indices", L);
+    if (!wfx_mr_pair_plan(M, sub)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: %lld has no radix-pair plan", M);
+    cols.resize(W + 1);
+    for (int d = 0; d <= W; ++d) cols[d] = d == W ? M : (long long)d * M / W / 4 * 4;
+    w = (int)(cols[me + 1] - cols[me]);
+    B = g.km[me].B;
+    nr = g.nrows(me);
+    for (int d = 0; d < W; ++d)
+        if (cols[d + 1] - cols[d] < 2 || cols[d + 1] - cols[d] < std::max(hb, ha))
+            return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: %lld points are too few for %d ranks", L, W);
+    if (nr < 1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: rank %d owns no rows", me);
+
+    // ---- pass descriptors and twiddle tables ----
+    const int ns = (int)sub.size();
+    size_t off = 0;
+    wfx_mr_pair_desc(d_first, g.ra1, g.rb1, 1, w, (long long)R1 * w);
+    d_fwd.resize(ns);
+    d_inv.resize(ns);
+    tw_fwd.resize(ns);
+    tw_inv.resize(ns);
+    {
+        long long Play = B, Ptw = R1;
+        for (int i = 0; i < ns; ++i) {              // forward: the global plan's passes 2.., twiddles by global k = k1 + R1 (.)
+            const int R = sub[i].first * sub[i].second;
+            mr_pass_desc &d = d_fwd[i];
+            wfx_mr_pair_desc(d, sub[i].first, sub[i].second, Play, (long long)B * M / R, (long long)B * M);
+            d.dist = 1;
+            d.B = B;
+            d.kb0 = g.km[me].kb0;
+            d.kc0 = g.km[me].kc0;
+            d.kb1 = g.km[me].kb1;
+            d.kscale = 1;
+            d.kstep = R1;
+            d.Ptw = Ptw;
+            d.Ltw = L;
+            tw_fwd[i] = off;
+            off += wfx_mr_table_elems(Ptw * R);
+            Play *= R;
+            Ptw *= R;
+        }
+    }
+    {
+        long long Play = B, Psub = 1;
+        for (int i = 0; i < ns; ++i) {              // inverse: M-point transforms, radices in the reverse order
+            const std::pair<int, int> pr = sub[ns - 1 - i];
+            const int R = pr.first * pr.second;
+            mr_pass_desc &d = d_inv[i];
+            wfx_mr_pair_desc(d, pr.first, pr.second, Play, (long long)B * M / R, (long long)B * M);
+            d.dist = 1;
+            d.B = B;
+            d.kb0 = d.kb1 = 0;
+            d.kc0 = B;
+            d.kscale = 0;
+            d.kstep = 1;
+            d.Ptw = Psub;
+            d.Ltw = L;
+            tw_inv[i] = off;
+            off += wfx_mr_table_elems(Psub * R);
+            Play *= R;
+            Psub *= R;
+        }
+    }
+    wfx_mr_pair_desc(d_last, g.ra1, g.rb1, w, w, (long long)R1 * w);
+    d_last.dist = 1;
+    d_last.B = 1;
+    d_last.kb0 = (int)cols[me];
+    d_last.kc0 = 1;
+    d_last.kb1 = 0;
+    d_last.kscale = 1;
+    d_last.kstep = 1;
+    d_last.Ptw = M;
+    d_last.Ltw = L;
+    tw_last = off;
+    off += wfx_mr_table_elems(L);
+    WFX_TRY(wfx_reserve(ctx, tables, off * sizeof(cplx)));
+    cplx *tb = (cplx *)tables.p;
+    {
+        long long Ptw = R1;
+        for (int i = 0; i < ns; ++i) {
+            const int R = sub[i].first * sub[i].second;
+            WFX_TRY(wfx_mr_fill_table(ctx, tb + tw_fwd[i], Ptw * R));
+            Ptw *= R;
+        }
+        long long Psub = 1;
+        for (int i = 0; i < ns; ++i) {
+            const int R = sub[ns - 1 - i].first * sub[ns - 1 - i].second;
+            WFX_TRY(wfx_mr_fill_table(ctx, tb + tw_inv[i], Psub * R));
+            Psub *= R;
+        }
+        WFX_TRY(wfx_mr_fill_table(ctx, tb + tw_last, L));
+    }
+    // ---- buffers ----
+    const size_t colsz = (size_t)R1 * w, rowsz = (size_t)nr * M, slab = (size_t)M * B;
+    WFX_TRY(wfx_reserve(ctx, b_pack, std::max(colsz, rowsz) * sizeof(cplx) + 64));
+    WFX_TRY(wfx_reserve(ctx, b_recv, std::max(colsz, rowsz) * sizeof(cplx) + 64));
+    WFX_TRY(wfx_reserve(ctx, b_y, colsz * sizeof(cplx) + 64));
+    WFX_TRY(wfx_reserve(ctx, b_a, slab * sizeof(cplx) + 64));
+    WFX_TRY(wfx_reserve(ctx, b_a2, slab * sizeof(cplx) + 64));
+    last_rows_in = nullptr;
+    last_rows_out = nullptr;
+    return 0;
+}
+
+// Exchange lists and piece descriptors.  They hold absolute addresses, so they are rebuilt when the caller's row buffers move.
+void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
+{
+    const int W = g.world, me = g.rank, R1 = g.R1;
+    const size_t ES = (size_t)es_in;
+    char *pack = (char *)b_pack.p, *recv = (char *)b_recv.p;
+    cplx *Y = (cplx *)b_y.p, *A = (cplx *)b_a.p;
+    x1.clear(); x2.clear(); x3.clear(); x4.clear();
+    p1.clear(); p2.clear(); p3.clear(); p4.clear();
+    // E1: rows -> columns
+    if (rows_in) {
+        size_t off = 0;
+        for (int d = 0; d < W; ++d) {
+            const long long wd = cols[d + 1] - cols[d];
+            char *self_dst = recv + (size_t)g.rows[me] * w * ES;
+            char *dst = d == me ? self_dst : pack + off;
+            wfx_dist_piece p{};
+            p.src = (unsigned long long)((const char *)rows_in + (size_t)cols[d] * ES);
+            p.dst = (unsigned long long)dst;
+            p.rows = nr;
+            p.cols = (int)wd;
+            p.src_rs = M;
+            p.dst_rs = wd;
+            p1.push_back(p);
+            wfx_xfer x{};
+            x.peer = d;
+            x.send = dst;
+            x.send_bytes = (size_t)nr * wd * ES;
+            x.recv = recv + (size_t)g.rows[d] * w * ES;
+            x.recv_bytes = (size_t)g.nrows(d) * w * ES;
+            x1.push_back(x);
+            if (d != me) off += (size_t)nr * wd * ES;
+        }
+    }
+    // E2: first-pass output [w][R1] -> slabs [M][B_e]
+    {
+        size_t off = 0;
+        for (int e = 0; e < W; ++e) {
+            const wfx_dist_kmap &km = g.km[e];
+            cplx *self_dst = A + (size_t)cols[me] * B;
+            cplx *dst = e == me ? self_dst : (cplx *)pack + off;
+            wfx_dist_piece p{};
+            p.src = (unsigned long long)Y;
+            p.dst = (unsigned long long)dst;
+            p.rows = w;
+            p.cols = km.B;
+            p.src_rs = R1;
+            p.dst_rs = km.B;
+            p.kb0 = km.kb0;
+            p.kc0 = km.kc0;
+            p.kb1 = km.kb1;
+            p.B = km.B;
+            p2.push_back(p);
+            wfx_xfer x{};
+            x.peer = e;
+            x.send = dst;
+            x.send_bytes = (size_t)w * km.B * sizeof(cplx);
+            x.recv = A + (size_t)cols[e] * B;
+            x.recv_bytes = (size_t)(cols[e + 1] - cols[e]) * B * sizeof(cplx);
+            x2.push_back(x);
+            if (e != me) off += (size_t)w * km.B;
+        }
+    }
+    // E3: slab rows -> [R1][w] (S = inv_result, known after init: see inv_slab_exchange)
+    {
+        cplx *S = inv_result;
+        size_t off = 0;
+        for (int e = 0; e < W; ++e) {
+            const wfx_dist_kmap &km = g.km[e];
+            cplx *src = e == me ? S + (size_t)cols[me] * B : (cplx *)recv + off;
+            wfx_dist_piece p{};
+            p.src = (unsigned long long)src;
+            p.dst = (unsigned long long)Y;
+            p.rows = w;
+            p.cols = km.B;
+            p.src_rs = km.B;
+            p.dst_rs = w;
+            p.kb0 = km.kb0;
+            p.kc0 = km.kc0;
+            p.kb1 = km.kb1;
+            p.B = km.B;
+            p3.push_back(p);
+            wfx_xfer x{};
+            x.peer = e;
+            x.send = S + (size_t)cols[e] * B;                       // to rank e: my slab's rows of its columns (contiguous)
+            x.send_bytes = (size_t)(cols[e + 1] - cols[e]) * B * sizeof(cplx);
+            x.recv = src;
+            x.recv_bytes = (size_t)w * km.B * sizeof(cplx);
+            if (e == me) x.send = x.recv;
+            x3.push_back(x);
+            if (e != me) off += (size_t)w * km.B;
+        }
+    }
+    // E4: [R1][w] rows -> own rows [nr][M] with a halo of hb points before and ha points after (circular)
+    if (rows_out) {
+        cplx *X = (cplx *)pack;                                      // output of the last inverse pass
+        size_t off = 0;
+        auto overlap = [&](int d, long long lo, long long hi, long long &a, long long &b) {
+            a = std::max(cols[d], lo);
+            b = std::min(cols[d + 1], hi);
+            return b > a;
+        };
+        for (int s = 0; s < W; ++s) {
+            const long long ws = cols[s + 1] - cols[s];
+            cplx *src = s == me ? X + (size_t)g.rows[me] * w : (cplx *)recv + off;
+            wfx_dist_piece p{};
+            p.src = (unsigned long long)src;
+            p.dst = (unsigned long long)(rows_out + hb + cols[s]);
+            p.rows = nr;
+            p.cols = (int)ws;
+            p.src_rs = ws;
+            p.dst_rs = M;
+            p4.push_back(p);
+            wfx_xfer x{};
+            x.peer = s;
+            x.send = X + (size_t)g.rows[s] * w;                      // rank s's rows of my columns (contiguous)
+            x.send_bytes = (size_t)g.nrows(s) * w * sizeof(cplx);
+            x.recv = src;
+            x.recv_bytes = (size_t)nr * ws * sizeof(cplx);
+            if (s == me) x.send = x.recv;
+            x4.push_back(x);
+            if (s != me) off += (size_t)nr * ws;
+            long long a, b;
+            // halo before: row rows[dst] - 1, columns [M - hb, M)
+            {
+                wfx_xfer h{};
+                h.peer = s;
+                if (hb > 0 && overlap(me, M - hb, M, a, b)) {        // I hold part of what rank s needs
+                    const int row = (g.rows[s] - 1 + R1) % R1;
+                    h.send = X + (size_t)row * w + (a - cols[me]);
+                    h.send_bytes = (size_t)(b - a) * sizeof(cplx);
+                }
+                if (hb > 0 && overlap(s, M - hb, M, a, b)) {         // rank s holds part of what I need
+                    h.recv = rows_out + (a - (M - hb));
+                    h.recv_bytes = (size_t)(b - a) * sizeof(cplx);
+                }
+                if (h.send_bytes || h.recv_bytes) x4.push_back(h);
+            }
+            // halo after: row rows[dst + 1], columns [0, ha)
+            {
+                wfx_xfer h{};
+                h.peer = s;
+                if (ha > 0 && overlap(me, 0, ha, a, b)) {
+                    const int row = g.rows[s + 1] % R1;
+                    h.send = X + (size_t)row * w + (a - cols[me]);
+                    h.send_bytes = (size_t)(b - a) * sizeof(cplx);
+                }
+                if (ha > 0 && overlap(s, 0, ha, a, b)) {
+                    h.recv = rows_out + hb + (size_t)nr * M + a;
+                    h.recv_bytes = (size_t)(b - a) * sizeof(cplx);
+                }
+                if (h.send_bytes || h.recv_bytes) x4.push_back(h);
+            }
+        }
+    }
+    last_rows_in = rows_in;
+    last_rows_out = rows_out;
+}
+
+int wfx_dist::upload_pieces()
+{
+    const size_t n = p1.size() + p2.size() + p3.size() + p4.size();
+    WFX_TRY(wfx_reserve(ctx, b_desc, n * sizeof(wfx_dist_piece)));
+    std::vector<wfx_dist_piece> all;
+    o1 = 0;
+    all.insert(all.end(), p1.begin(), p1.end());
+    o2 = all.size();
+    all.insert(all.end(), p2.begin(), p2.end());
+    o3 = all.size();
+    all.insert(all.end(), p3.begin(), p3.end());
+    o4 = all.size();
+    all.insert(all.end(), p4.begin(), p4.end());
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));               // kernels of an earlier run may still read the old descriptors
+    WFX_HIP(ctx, hipMemcpy(b_desc.p, all.data(), n * sizeof(wfx_dist_piece), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// rows_in: this rank's rows of the forward transform's input; rows_out: where the inverse delivers [hb + nr M + ha] points;
+// inv_in: the slab buffer (0 / 1) the inverse passes start from.  Either pointer may be null when that direction is not used.
+int wfx_dist::bind(const void *rows_in, cplx *rows_out, int inv_in)
+{
+    // the inverse slab passes ping-pong between the two slab buffers: where they end is where E3 sends from
+    const int ns = (int)d_inv.size();
+    const int end = (inv_in + ns) & 1;
+    inv_start = inv_in ? (cplx *)b_a2.p : (cplx *)b_a.p;
+    inv_result = end ? (cplx *)b_a2.p : (cplx *)b_a.p;
+    build_lists(rows_in, rows_out);
+    return upload_pieces();
+}
+
+int wfx_dist::fwd_pack_exchange(wfx_comm *c, const void *rows_in)
+{
+    if (rows_in != last_rows_in || !b_desc.p) return wfx_fail(ctx, WFX_ERR_STATE, "distributed transform: input rows not bound");
+    const wfx_dist_piece *dp = (const wfx_dist_piece *)b_desc.p;
+    long long mx = 0;
+    for (const wfx_dist_piece &p : p1) mx = std::max(mx, (long long)p.rows * p.cols);
+    WFX_TRY(wfx_dist_copy2d(ctx, dp + o1, (int)p1.size(), mx, es_in));
+    return wfx_comm_exchange(c, ctx, x1.data(), (int)x1.size());
+}
+
+int wfx_dist::fwd_pass1_exchange(wfx_comm *c, int in_mode)
+{
+    const cplx *tb = (const cplx *)tables.p;
+    WFX_TRY(wfx_mr_launch_pair(ctx, d_first, tb, in_mode, 0, 0, b_recv.p, (cplx *)b_y.p));      // P = 1: no twiddle is read
+    const wfx_dist_piece *dp = (const wfx_dist_piece *)b_desc.p;
+    long long mx = 0;
+    for (const wfx_dist_piece &p : p2) mx = std::max(mx, (long long)p.rows * p.cols);
+    WFX_TRY(wfx_dist_gather_k(ctx, dp + o2, (int)p2.size(), mx));
+    return wfx_comm_exchange(c, ctx, x2.data(), (int)x2.size());
+}
+
+int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum)
+{
+    const cplx *tb = (const cplx *)tables.p;
+    cplx *src = (cplx *)b_a.p, *dst = (cplx *)b_a2.p;
+    const int ns = (int)d_fwd.size();
+    for (int i = 0; i < ns; ++i) {
+        WFX_TRY(wfx_mr_launch_pair(ctx, d_fwd[i], tb + tw_fwd[i], 0, (hilbert_spectrum && i == ns - 1) ? 1 : 0, 0, src, dst));
+        std::swap(src, dst);
+    }
+    *spectrum = src;
+    return 0;
+}
+
+int wfx_dist::inv_slab_exchange(wfx_comm *c, cplx *slab_in)
+{
+    const cplx *tb = (const cplx *)tables.p;
+    if (slab_in != inv_start || !b_desc.p) return wfx_fail(ctx, WFX_ERR_STATE, "distributed transform: inverse input is not the bound slab buffer");
+    cplx *src = slab_in, *dst = slab_in == (cplx *)b_a.p ? (cplx *)b_a2.p : (cplx *)b_a.p;
+    const int ns = (int)d_inv.size();
+    for (int i = 0; i < ns; ++i) {
+        WFX_TRY(wfx_mr_launch_pair(ctx, d_inv[i], tb + tw_inv[i], 0, 0, 1, src, dst));
+        std::swap(src, dst);
+    }
+    return wfx_comm_exchange(c, ctx, x3.data(), (int)x3.size());
+}
+
+int wfx_dist::inv_pass1_exchange(wfx_comm *c, cplx *rows_out)
+{
+    if (rows_out != last_rows_out || !b_desc.p) return wfx_fail(ctx, WFX_ERR_STATE, "distributed transform: output rows not bound");
+    const wfx_dist_piece *dp = (const wfx_dist_piece *)b_desc.p;
+    WFX_TRY(wfx_dist_scatter_k(ctx, dp + o3, (int)p3.size(), w));
+    const cplx *tb = (const cplx *)tables.p;
+    WFX_TRY(wfx_mr_launch_pair(ctx, d_last, tb + tw_last, 0, 0, 1, b_y.p, (cplx *)b_pack.p));
+    return wfx_comm_exchange(c, ctx, x4.data(), (int)x4.size());
+}
+
+int wfx_dist::inv_unpack(cplx *rows_out)
+{
+    if (rows_out != last_rows_out) return wfx_fail(ctx, WFX_ERR_STATE, "distributed transform: output buffer changed between exchange and unpack");
+    const wfx_dist_piece *dp = (const wfx_dist_piece *)b_desc.p;
+    long long mx = 0;
+    for (const wfx_dist_piece &p : p4) mx = std::max(mx, (long long)p.rows * p.cols);
+    return wfx_dist_copy2d(ctx, dp + o4, (int)p4.size(), mx, 16);
+}
+
+// ---- scipy.signal.resample's spectral step on slabs (the single-GPU form is resample_mr_glue in wfx_mrfft.hip) -------
+// Z: forward spectrum of the packed input, slab layout [M1 / R1][B]; W: input of the inverse, slab layout [K / R1][B].
+// The k1 sets are closed under negation, so the four bins an output needs (k, M1 - k, K - k, M1 - K + k) are all local.
+__global__ void __launch_bounds__(256) dist_resample_glue_kernel(const cplx *__restrict__ Z, long long n0, long long num, int R1, wfx_dist_kmap km,
+                                                                  cplx *__restrict__ W)
+{
+    const long long M1 = n0 / 2, K = num / 2, nmin = n0 < num ? n0 : num, half = nmin / 2;
+    const double edge = (nmin % 2 == 0) ? (num < n0 ? 2.0 : (num > n0 ? 0.5 : 1.0)) : 1.0;
+    const double inv_n0 = 1.0 / (double)n0;
+    const int B = km.B;
+    auto zat = [&](long long j) {                       // Z[j], j in [0, M1)
+        const int k1 = (int)(j % R1);
+        const int kk = (k1 >= km.kb0 && k1 < km.kb0 + km.kc0) ? k1 - km.kb0 : km.kc0 + (k1 - km.kb1);
+        return Z[(j / R1) * B + kk];
+    };
+    auto bin = [&](long long j) {                       // Y[j], j in [0, K]
+        if (j > half) return make_double2(0.0, 0.0);
+        const long long a = j % M1, b = (M1 - j) % M1;
+        const cplx zk = zat(a), zb = zat(b);
+        const cplx zc = make_double2(zb.x, -zb.y);
+        double sn, cs;
+        sincospi(2.0 * (double)j / (double)n0, &sn, &cs);
+        const cplx dif = make_double2(zk.x - zc.x, zk.y - zc.y);
+        cplx y = make_double2(0.5 * (zk.x + zc.x) + 0.5 * (cs * dif.y - sn * dif.x), 0.5 * (zk.y + zc.y) - 0.5 * (cs * dif.x + sn * dif.y));
+        if (j == half) {
+            y.x *= edge;
+            y.y *= edge;
+        }
+        if (j == 0 || j == K) y.y = 0.0;
+        return y;
+    };
+    const long long total = (K / R1) * B;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long k2 = e / B;
+        const int kk = (int)(e - k2 * B);
+        const long long k = (long long)(kk < km.kc0 ? km.kb0 + kk : km.kb1 + (kk - km.kc0)) + k2 * R1;
+        const cplx yk = bin(k);
+        const cplx yr = bin(K - k);
+        const cplx yc = make_double2(yr.x, -yr.y);
+        const cplx sum = make_double2(yk.x + yc.x, yk.y + yc.y), dif = make_double2(yk.x - yc.x, yk.y - yc.y);
+        double sn, cs;
+        sincospi(2.0 * (double)k / (double)num, &sn, &cs);
+        W[e] = make_double2((sum.x - (sn * dif.x + cs * dif.y)) * inv_n0, (sum.y + (cs * dif.x - sn * dif.y)) * inv_n0);
+    }
+}
+
+int wfx_dist_resample_glue(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Z, long long n0, long long num, cplx *W)
+{
+    const long long total = (num / 2 / g.R1) * g.km[g.rank].B;
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, dist_resample_glue_kernel, dim3(wfx_stream_grid((uint64_t)total, 256)), dim3(256), Z, n0, num, g.R1, g.km[g.rank], W);
+    return 0;
+}

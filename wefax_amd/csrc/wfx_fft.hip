@@ -795,6 +795,107 @@ __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__
     }
 }
 
+// The same for one rank's block [s0, s1) of a sharded capture (s0, s1 even; packed layout only): V and x are indexed by
+// GLOBAL pair / sample index through pre-offset pointers and are valid two samples beyond the block on either side (the
+// halo the distributed inverse transform delivers); zeros beyond the capture's true ends as in the reference.
+__global__ void __launch_bounds__(256) hconv_env_median_block(const cplx *__restrict__ V, const double *__restrict__ x, long long N, long long s0, long long s1,
+                                                             double *__restrict__ env, unsigned *__restrict__ l0hist)
+{
+    __shared__ double tile[1024 + 8];
+    __shared__ unsigned h0[WFX_SEL_BINS];
+    const int t = threadIdx.x;
+    unsigned run_digit = 0, run_count = 0;
+    if (l0hist)
+        for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
+    const long long step = (long long)gridDim.x * 1024;
+    const long long mlo = s0 / 2 - 2, mhi = s1 / 2 + 1;                     // valid pair indices
+    const long long xlo = s0 - 2 < 0 ? 0 : s0 - 2, xhi = (s1 + 2 > N ? N : s1 + 2) - 1;   // valid sample indices
+    cplx pv[3];
+    double px0[3], px1[3];
+    auto prefetch = [&](long long base) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const long long m = base / 2 - 1 + t + 256 * k;                 // pair (2m - 1, 2m)
+            const long long mc = m < mlo ? mlo : (m > mhi ? mhi : m);
+            const long long i1 = 2 * m, i0 = 2 * m - 1;
+            pv[k] = V[mc];
+            px0[k] = x[i0 < xlo ? xlo : (i0 > xhi ? xhi : i0)];
+            px1[k] = x[i1 < xlo ? xlo : (i1 > xhi ? xhi : i1)];
+        }
+    };
+    long long base = s0 + (long long)blockIdx.x * 1024;
+    if (base < s1) prefetch(base);
+    for (; base < s1; base += step) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int mi = t + 256 * k;
+            const long long m = base / 2 - 1 + mi;
+            const long long i1 = 2 * m, i0 = 2 * m - 1;
+            const double e0 = (i0 >= 0 && i0 < N) ? env_abs(px0[k], pv[k].y) : 0.0;
+            const double e1 = (i1 >= 0 && i1 < N) ? env_abs(px1[k], pv[k].x) : 0.0;
+            if (mi < 515) {
+                if (mi > 0) tile[2 * mi - 1] = e0;
+                if (mi < 514) tile[2 * mi] = e1;
+            }
+        }
+        __syncthreads();
+        if (base + step < s1) prefetch(base + step);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = 2 * t + 512 * u;
+            const double w0 = tile[j], w1 = tile[j + 1], w2 = tile[j + 2], w3 = tile[j + 3], w4 = tile[j + 4], w5 = tile[j + 5];
+            double r[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double a = h ? w1 : w0, b = h ? w2 : w1, c = h ? w3 : w2, d = h ? w4 : w3, e = h ? w5 : w4;
+                cswap_d(a, b);
+                cswap_d(d, e);
+                cswap_d(a, d);
+                cswap_d(b, e);
+                cswap_d(b, c);
+                cswap_d(c, d);
+                cswap_d(b, c);
+                r[h] = c;
+            }
+            if (base + j + 1 < s1)
+                *(double2 *)(env + (base + j - s0)) = make_double2(r[0], r[1]);
+            else if (base + j < s1)
+                env[base + j - s0] = r[0];
+            if (l0hist) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (base + j + h >= s1) continue;
+                    const unsigned dg = (unsigned)(wfx_f64_key(r[h]) >> 53);
+                    if (dg == run_digit)
+                        ++run_count;
+                    else {
+                        if (run_count) atomicAdd(&h0[run_digit], run_count);
+                        run_digit = dg;
+                        run_count = 1;
+                    }
+                }
+            }
+        }
+    }
+    if (l0hist) {
+        if (run_count) atomicAdd(&h0[run_digit], run_count);
+        __syncthreads();
+        for (int i = t; i < WFX_SEL_BINS; i += 256)
+            if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
+    }
+}
+
+int wfx_dev_env_median_block(wfx_ctx *ctx, const cplx *V_global, const double *x_global, uint64_t n_total, uint64_t s0, uint64_t s1, double *env_block,
+                             unsigned *l0hist)
+{
+    if ((s0 & 1) || (s1 & 1) || s1 <= s0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "envelope block [%llu, %llu) must be even-aligned", (unsigned long long)s0, (unsigned long long)s1);
+    const unsigned grid = std::min(wfx_stream_grid(s1 - s0, 1024), 1024u);
+    WFX_LAUNCH(ctx, K_ENV_MEDIAN, hconv_env_median_block, dim3(grid), dim3(256), V_global, x_global, (long long)n_total, (long long)s0, (long long)s1, env_block,
+               l0hist);
+    return 0;
+}
+
 static int hilbert_conv(wfx_ctx *ctx, const double *x, uint64_t n, cplx **W_out, int *packed_out, uint64_t *L_out)
 {
     // even N with a 13-smooth N/2: unpadded mixed-radix transforms, closed-form kernel spectrum

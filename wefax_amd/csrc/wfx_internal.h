@@ -8,11 +8,13 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "wefax_hip.h"
 
 typedef double2 cplx;   // interleaved (re, im), one 16-byte vector access
+struct wfx_comm;
 
 // ---- kernel ids for the per-kernel HIP-event profile ------------------------
 enum wfx_kernel_id {
@@ -33,6 +35,7 @@ enum wfx_kernel_id {
     K_RESAMPLE_PW,     // resampler pointwise kernels
     K_POLYPHASE_IN,    // time-domain front end, stage that reads the raw int16 capture (merge fused)
     K_POLYPHASE,       // time-domain front end, later stages (float32 in)
+    K_DIST_COPY,       // sharded decode: pack / unpack copies around an exchange (wfx_dist.hip)
     K_COUNT
 };
 
@@ -102,6 +105,18 @@ struct wfx_ctx {
     std::vector<hipEvent_t> ev_pool;
     uint64_t prof_count[K_COUNT] = {};
     double prof_ms[K_COUNT] = {};
+};
+
+// ---- one pass of the mixed-radix transform engine (wfx_mrfft.hip) -------------------------------------------
+#define MR_MAXF 8
+struct mr_pass_desc {
+    int ra, rb;                 // R = ra * rb has a register-resident two-level pass (0, 0: per-prime LDS stages only)
+    int R, nf, f[MR_MAXF];
+    long long P, ncol, L;       // layout: columns j in [0, ncol), k = j mod P, in x[j + m ncol], out y[(j - k) R + k + q P]
+    int T, log2t;
+    // twiddle / spectrum indices when the array is one rank's part of a distributed transform (wfx_dist.hip); dist == 0: plain
+    int dist, B, kb0, kc0, kb1, kscale, kstep;
+    long long Ptw, Ltw;         // the pass's P and the length L of the GLOBAL plan (Hilbert spectrum); == P, L when plain
 };
 
 // ---- error helpers ----------------------------------------------------------
@@ -185,6 +200,10 @@ int wfx_dev_hilbert_env_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *e
 int wfx_dev_spectrum_abs(wfx_ctx *ctx, const double *x, uint64_t n, double *amp);
 int wfx_dev_hilbert_envmed_fft(wfx_ctx *ctx, const double *x, uint64_t n, double *env, unsigned *l0hist);
 int wfx_dev_hilbert_env_bluestein(wfx_ctx *ctx, const double *x, uint64_t n, double *env_raw);
+// |x + i H| + median 5 + level-0 histogram of the block [s0, s1) of a sharded capture: V_global[m] = (H[2m], H[2m-1]) and x_global[i]
+// are pointers pre-offset to GLOBAL indices, valid two samples beyond the block on either side; env_block[i - s0]
+int wfx_dev_env_median_block(wfx_ctx *ctx, const cplx *V_global, const double *x_global, uint64_t n_total, uint64_t s0, uint64_t s1, double *env_block,
+                             unsigned *l0hist);
 // x_is_i16: x points at int16 samples; valid only when wfx_mr_resample_supported(n0, num) (the mixed-radix form reads them in place)
 int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16 = false);
 
@@ -224,8 +243,32 @@ int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t sta
 int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out,
                            int edge_flags);
 int wfx_dev_select_level(wfx_ctx *ctx, const double *env, uint64_t n, int level, const uint64_t prefix[4], unsigned *hist);
+// The radix select in the steps the sharded decode separates with collectives (the histograms are summed over the ranks between them,
+// the candidate lists gathered): workspace words [0, 2048) = level-0 histogram, [2048, 5 * 2048) = level-1 histograms.
+#define WFX_SEL_H1_OFFSET 2048
+#define WFX_SEL_H1_WORDS (4 * 2048)
+int wfx_dev_select_sharded_ws(wfx_ctx *ctx, unsigned **ws);
+int wfx_dev_select_l1(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], unsigned *ws, wfx_dev_scalars *d_scal);
+// appends this rank's candidates to block[4][cap] (keys) and records the four counts behind them: block = {u64 keys[4][cap]; u32 count[4]; u32 pad[4]}
+int wfx_dev_select_compact_block(wfx_ctx *ctx, const double *env, uint64_t n, unsigned *ws, wfx_dev_scalars *d_scal, void *block, uint64_t cap);
+// all ranks' blocks (gathered) -> one candidate list per query; finishes the select; *overflow (device) += 1 when a rank's list did not fit
+int wfx_dev_select_finish_blocks(wfx_ctx *ctx, unsigned *ws, wfx_dev_scalars *d_scal, const void *blocks, int nblocks, uint64_t cap, double gamma_lo,
+                                 double gamma_hi, unsigned *overflow);
+static inline size_t wfx_select_block_bytes(uint64_t cap) { return (size_t)cap * 32 + 32; }
+int wfx_dev_add_u64(wfx_ctx *ctx, unsigned long long *dst, const unsigned long long *src, int n);
 
 // wfx_mrfft.hip
+// decomposition of a 13-smooth length into radix pairs with a register-resident pass (ascending radix); false if none
+bool wfx_mr_pair_plan(long long L, std::vector<std::pair<int, int>> &pairs);
+bool wfx_mr_is_pair(int ra, int rb);
+void wfx_mr_all_pairs(std::vector<std::pair<int, int>> &out);
+// descriptor of one pair pass with the plain index maps (dist fields cleared, Ptw = P, Ltw = L)
+void wfx_mr_pair_desc(mr_pass_desc &d, int ra, int rb, long long P, long long ncol, long long L);
+// two-level twiddle table of W_mod = exp(-2 pi i / mod): lo[2048], hi[(mod >> 11) + 2]; returns the number of cplx entries written at `base`
+size_t wfx_mr_table_elems(long long mod);
+int wfx_mr_fill_table(wfx_ctx *ctx, cplx *base, long long mod);       // lo = base, hi = base + 2048
+// launch one pair pass.  in_mode 0 complex, 1 packed reals swapped on load, 2 int16 pairs; out_mode 1: times the Hilbert spectrum; dir 1: inverse
+int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int in_mode, int out_mode, int dir, const void *src, cplx *dst);
 bool wfx_mr_supported(uint64_t L);
 void wfx_mr_release(wfx_ctx *ctx);
 int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out);
@@ -239,6 +282,21 @@ int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_i
                          void *out, int out_f64, uint64_t n_out);
 int wfx_dev_resample_rational(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t base0, int p, int q, const float *table,
                               int T, int64_t m0, float *out, uint64_t n_out);
+
+// wfx_comm.hip: the communicator behind the sharded decode (RCCL bound directly, or every rank in this process)
+struct wfx_xfer {            // one message pair of a personalised exchange; several entries per peer are matched in order
+    int peer;
+    const void *send;
+    size_t send_bytes;
+    void *recv;
+    size_t recv_bytes;
+};
+int wfx_comm_world(const wfx_comm *c);
+int wfx_comm_rank(const wfx_comm *c);
+bool wfx_comm_is_local(const wfx_comm *c);
+int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n);
+int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t count);
+int wfx_comm_allgather(wfx_comm *c, wfx_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank);
 
 // wfx_fir.hip
 int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps, double *env_raw, uint64_t n_global = 0);

@@ -29,17 +29,9 @@
 #include "wfx_internal.h"
 
 #define MR_TILE 4096
-#define MR_MAXF 8
 #define MR_MAXPASS 5
 #define MR_LO_BITS 11
 #define MR_LO (1 << MR_LO_BITS)
-
-struct mr_pass_desc {
-    int ra, rb;                 // R = ra * rb has a register-resident two-level pass (0, 0: per-prime LDS stages only)
-    int R, nf, f[MR_MAXF];
-    long long P, ncol, L;
-    int T, log2t;
-};
 
 __device__ __forceinline__ cplx mcmul(cplx a, cplx b)
 {
@@ -477,6 +469,23 @@ constexpr bool mr2_prefetch(int ra, int rb)
     return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) <= 140;      // registers: a tile in flight + a level-B transform
 }
 
+// Twiddle index of the column whose layout index is kl = j mod P.  Plain transform: kl itself.  Distributed transform
+// (wfx_dist.hip): the array is a slab [.][B] whose innermost index kk stands for the first-pass output k1 = map(kk) of the
+// global plan, or a range of columns starting at global column kb0:  k = map(kl mod B) * kscale + (kl / B) * kstep.
+__device__ __forceinline__ int mr_twiddle_k(const mr_pass_desc &d, int kl)
+{
+    if (!d.dist) return kl;
+    const int kk = kl % d.B, kq = kl / d.B;
+    return (kk < d.kc0 ? d.kb0 + kk : d.kb1 + (kk - d.kc0)) * d.kscale + kq * d.kstep;
+}
+// global frequency index of layout index o (last forward pass of a slab: the Hilbert spectrum is a function of it)
+__device__ __forceinline__ long long mr_global_index(const mr_pass_desc &d, long long o)
+{
+    if (!d.dist) return o;
+    const int kk = (int)(o % d.B);
+    return (long long)(kk < d.kc0 ? d.kb0 + kk : d.kb1 + (kk - d.kc0)) + (o / d.B) * (long long)d.kstep;
+}
+
 template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
 __global__ void __launch_bounds__(256, 2)
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
@@ -500,7 +509,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
     __shared__ cplx gpow[OUT_MODE == 1 ? RB : 1];                 // exp(-i pi qb RA P / L): the spectrum's step along qb
     if (OUT_MODE == 1 && t < RB) {
         double sn, cs;
-        sincospi((double)((long long)t * RA * P) / (double)d.L, &sn, &cs);
+        sincospi((double)((long long)t * RA * d.Ptw) / (double)d.Ltw, &sn, &cs);
         gpow[t] = make_double2(cs, -sn);
     }
     cplx pre[NA][RA];
@@ -546,7 +555,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
 #pragma unroll
                 for (int a = 0; a < RA; ++a) v[a] = pre[ia][a];
                 if (P > 1 && c < tn) {                            // input twiddle W_{P R}^{k (a RB + b)}: two look-ups, then a recurrence
-                    const int k = (j0 + c) % P;
+                    const int k = mr_twiddle_k(d, (j0 + c) % P);
                     cplx w = lookup(k * b);
                     const cplx wstep = lookup(k * RB);
 #pragma unroll
@@ -612,10 +621,12 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                     const long long obase = (long long)(j - k) * R + k + (long long)qa * P;      // + qb * RA * P
                     const long long ostep = (long long)RA * P;
                     cplx g0 = make_double2(0.0, 0.0);
+                    long long gbase = 0;                          // global frequency index of obase (== obase unless distributed)
                     if (OUT_MODE == 1) {
-                        const double il = 1.0 / (double)d.L;
+                        const double il = 1.0 / (double)d.Ltw;
+                        gbase = mr_global_index(d, obase);
                         double sn, cs;
-                        sincospi((double)obase * il, &sn, &cs);
+                        sincospi((double)gbase * il, &sn, &cs);
                         g0 = make_double2(-sn * il, -cs * il);
                     }
                     auto emit = [&](int qb, cplx y) {
@@ -623,7 +634,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                         if (OUT_MODE == 1) {
                             // times G[o] / L, G[o] = -i exp(-i pi o / L) (G[0] = 0) = g0 * gstep^qb: the powers of the
                             // (kernel-uniform) step come from LDS, the start from one sincospi per thread
-                            y = o == 0 ? make_double2(0.0, 0.0) : mcmul(y, mcmul(g0, gpow[qb]));
+                            y = (gbase == 0 && qb == 0) ? make_double2(0.0, 0.0) : mcmul(y, mcmul(g0, gpow[qb]));
                         }
                         out[o] = y;
                     };
@@ -732,6 +743,11 @@ static void mr_fill_pass(mr_plan_host &pl, int i, int R, int ra, int rb, long lo
     for (int k = d.nf; k < MR_MAXF; ++k) d.f[k] = 1;
     d.P = P;
     d.L = pl.L;
+    d.dist = 0;
+    d.B = 1;
+    d.kb0 = d.kc0 = d.kb1 = d.kscale = d.kstep = 0;
+    d.Ptw = P;
+    d.Ltw = pl.L;
     d.ncol = pl.L / R;
     const int T = MR_TILE / R;
     int t2 = 1, l2 = 0;
@@ -938,6 +954,99 @@ void wfx_mr_release(wfx_ctx *ctx)
     }
 }
 
+// hi table = lo + 2048 in every plan (mr_fill_pass lays them out that way)
+int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int in_mode, int out_mode, int dir, const void *src_v, cplx *dst)
+{
+    const cplx *src = (const cplx *)src_v;
+    const cplx *lo = tw, *hi = tw + MR_LO;
+    const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
+    const int lt = mr2_log2t(d.R);
+    const int nt = (int)((d.ncol + (1 << lt) - 1) >> lt);
+    const unsigned g2 = (unsigned)(nt < 512 ? nt : 512);
+    if (nt <= 0) return 0;
+    bool done = false;
+#define X(RA_, RB_)                                                                                                                   \
+    if (!done && d.ra == (RA_) && d.rb == (RB_)) {                                                                                    \
+        if (in_mode == 2 && dir == 0 && out_mode == 0)                                                                               \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 2, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 1 && in_mode == 0 && out_mode == 0)                                                                          \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 0 && out_mode == 1 && in_mode == 0)                                                                          \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 0 && in_mode == 1 && out_mode == 0)                                                                          \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 0 && in_mode == 0 && out_mode == 0)                                                                          \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else                                                                                                                          \
+            return wfx_fail(ctx, WFX_ERR_BAD_ARG, "no pass kernel for in_mode %d out_mode %d dir %d", in_mode, out_mode, dir);        \
+        done = true;                                                                                                                  \
+    }
+    WFX_MR2_PAIRS(X)
+#undef X
+    if (!done) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "no register-resident pass for the radix pair (%d, %d)", d.ra, d.rb);
+    return 0;
+}
+
+void wfx_mr_all_pairs(std::vector<std::pair<int, int>> &out)
+{
+    out.clear();
+    for (const mr2_pair &pr : g_mr2_pairs) out.emplace_back(pr.ra, pr.rb);
+}
+
+bool wfx_mr_is_pair(int ra, int rb)
+{
+    for (const mr2_pair &pr : g_mr2_pairs)
+        if (pr.ra == ra && pr.rb == rb) return true;
+    return false;
+}
+
+bool wfx_mr_pair_plan(long long L, std::vector<std::pair<int, int>> &pairs)
+{
+    pairs.clear();
+    if (L < 2) return false;
+    long long rem = L;
+    for (int p : {13, 11, 7, 5, 3, 2})
+        while (rem % p == 0) rem /= p;
+    if (rem != 1) return false;
+    std::vector<int> cur, best;
+    double best_cost = 1e30;
+    if (!mr2_search(L, 0, 0.0, cur, best_cost, best) || best.empty()) return false;
+    std::sort(best.begin(), best.end(), [](int a, int b) {
+        return g_mr2_pairs[a].ra * g_mr2_pairs[a].rb < g_mr2_pairs[b].ra * g_mr2_pairs[b].rb;
+    });
+    for (int i : best) pairs.emplace_back(g_mr2_pairs[i].ra, g_mr2_pairs[i].rb);
+    return true;
+}
+
+void wfx_mr_pair_desc(mr_pass_desc &d, int ra, int rb, long long P, long long ncol, long long L)
+{
+    d = mr_pass_desc();
+    d.ra = ra;
+    d.rb = rb;
+    d.R = ra * rb;
+    d.nf = mr_stage_factors(d.R, d.f);
+    for (int k = d.nf < 0 ? 0 : d.nf; k < MR_MAXF; ++k) d.f[k] = 1;
+    d.P = P;
+    d.ncol = ncol;
+    d.L = L;
+    d.T = 1 << mr2_log2t(d.R);
+    d.log2t = mr2_log2t(d.R);
+    d.dist = 0;
+    d.B = 1;
+    d.Ptw = P;
+    d.Ltw = L;
+}
+
+size_t wfx_mr_table_elems(long long mod) { return (size_t)MR_LO + (size_t)(mod >> MR_LO_BITS) + 2; }
+
+int wfx_mr_fill_table(wfx_ctx *ctx, cplx *base, long long mod)
+{
+    const int nhi = (int)(mod >> MR_LO_BITS) + 2;
+    const int n = nhi > MR_LO ? nhi : MR_LO;
+    WFX_LAUNCH(ctx, K_BS_CHIRP, mr_fill_tables, dim3((n + 255) / 256), dim3(256), base, base + MR_LO, mod, nhi);
+    return 0;
+}
+
 // One transform of the plan: `dir` 0 forward / 1 inverse, reading `src`, ping-ponging between A and B; the last pass
 // writes to `final_dst` when given.  hilbert: the packed-real load swap on the first forward pass and the multiplication
 // by the Hilbert spectrum on the last one.  Unnormalised; natural order in and out (self-sorting passes).
@@ -957,25 +1066,8 @@ static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cpl
         // register-resident two-level pass when the radix is a pair (mr2_pass); per-prime LDS stages otherwise
         bool done = false;
         if (pc->use_mr2 && d.ra > 0 && !(first && last_fwd)) {
-            const int lt = mr2_log2t(d.R);
-            const int nt = (int)((d.ncol + (1 << lt) - 1) >> lt);
-            const unsigned g2 = (unsigned)(nt < 512 ? nt : 512);
-#define X(RA_, RB_)                                                                                                                   \
-    if (!done && d.ra == (RA_) && d.rb == (RB_)) {                                                                                    \
-        if (first16)                                                                                                                  \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 2, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
-        else if (dir == 1)                                                                                                            \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
-        else if (last_fwd)                                                                                                            \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
-        else if (first)                                                                                                               \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
-        else                                                                                                                          \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
-        done = true;                                                                                                                  \
-    }
-            WFX_MR2_PAIRS(X)
-#undef X
+            WFX_TRY(wfx_mr_launch_pair(ctx, d, lo, first16 ? 2 : (first ? 1 : 0), last_fwd ? 1 : 0, dir, src, dst));
+            done = true;
         }
         if (!done) {
             const int ntiles = (int)((d.ncol + d.T - 1) / d.T);

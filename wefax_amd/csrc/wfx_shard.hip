@@ -1,0 +1,460 @@
+// One capture decoded by several GPUs: the exact path of wefax.py: Demodulator.process() sharded by sample range.
+// (include/wefax_hip.h, section "one capture over several GPUs"; the distributed transforms are in wfx_dist.hip, the
+// communicator in wfx_comm.hip.)
+//
+// Rank r owns the rows [rows[r], rows[r+1]) of the [R1][M] arrangement of the L = N/2 packed points of the Hilbert
+// transform, i.e. the samples [2 rows[r] M, 2 rows[r+1] M) at 11 025 Hz, and -- with a resampler in front -- the same rows
+// of the input's packed points.  Stages and what they exchange (all on the context's stream, no host round trip):
+//
+//   [a4 merge]  [a5 resample: distributed rfft -> bin copy -> distributed irfft, halo of 32 samples delivered with it]
+//   a6 notch on own samples + 32 (49-tap form; filtfilt's exact edges on the ranks that hold a true end)
+//   a7 distributed Hilbert convolution (4 transposes), |x + iH| + median 5 on the block (halo of 2 samples)
+//   a8 percentiles: level-0 histogram (fused) -> ALL-REDUCE -> level 1 -> ALL-REDUCE -> candidates -> ALL-GATHER -> finish
+//      (every rank ends with the same low / high on its device); quantise own block
+//   ONE GATHER of the uint8 stream (1 byte per sample) to rank 0
+//   a9 sync search + a10 bicubic image on rank 0 (17 + 60 us of work for a 60-minute capture: not worth a second exchange)
+#include <cstdlib>
+#include <cstring>
+
+#include "wfx_dist.h"
+
+#define SH_HALO 32          // samples of audio kept beyond the own range on either side (>= 24 notch taps + 2 median)
+#define SH_VHALO 2          // points of the Hilbert transform delivered beyond the own rows
+#define SH_CAND_CAP 8192    // candidate keys per query and rank that travel in the all-gather
+
+struct shard_plan {
+    int world = 1, rank = 0;
+    wfx_dist_geom g;
+    bool resample = false;
+    int in_kind = 0;
+    uint64_t n0 = 0, n = 0;
+    long long M1 = 0, K = 0, M1s = 0, Ms = 0;
+    uint64_t own_lo = 0, own_hi = 0, in_lo = 0, in_hi = 0;
+    uint64_t seg_lo = 0, seg_hi = 0;      // samples at 11 025 Hz held for the notch
+};
+
+static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int rank, shard_plan &pl)
+{
+    if (!p) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null parameters");
+    if (world < 1 || rank < 0 || rank >= world) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad rank %d for world size %d", rank, world);
+    if (p->in_kind != WFX_IN_I16_MONO && p->in_kind != WFX_IN_F64_MONO && p->in_kind != WFX_IN_I16_STEREO)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: input kind %d", p->in_kind);
+    if (p->hilbert_mode != WFX_HILBERT_FFT) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: the exact Hilbert mode only");
+    if (p->n == 0 || p->n0 == 0 || (!p->resample && p->n != p->n0)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad capture lengths");
+    if ((p->n & 1) || (p->resample && (p->n0 & 1)))
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: sample counts must be even (the transforms are packed)");
+    if (p->n >= (1ull << 31) || p->n0 >= (1ull << 32)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "capture too long");
+    if (p->width <= 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad line width");
+    pl.world = world;
+    pl.rank = rank;
+    pl.resample = p->resample != 0;
+    pl.in_kind = p->in_kind;
+    pl.n0 = p->n0;
+    pl.n = p->n;
+    pl.K = (long long)(p->n / 2);
+    pl.M1 = (long long)(p->n0 / 2);
+    long long lens[2] = {pl.K, pl.M1};
+    int ra1 = 0, rb1 = 0;
+    if (!wfx_dist_choose_r1(lens, pl.resample ? 2 : 1, world, &ra1, &rb1))
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG,
+                        "sharded decode: no distributed transform plan for %llu%s samples on %d ranks (half-lengths must be 13-smooth multiples "
+                        "of a common first radix)",
+                        (unsigned long long)p->n, pl.resample ? " (resampled)" : "", world);
+    if (!wfx_dist_make_geom(pl.g, world, rank, ra1, rb1)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: geometry");
+    const int R1 = pl.g.R1;
+    pl.Ms = pl.K / R1;
+    pl.M1s = pl.M1 / R1;
+    pl.own_lo = 2ull * (uint64_t)pl.g.rows[rank] * (uint64_t)pl.Ms;
+    pl.own_hi = 2ull * (uint64_t)pl.g.rows[rank + 1] * (uint64_t)pl.Ms;
+    pl.seg_lo = pl.own_lo >= SH_HALO ? pl.own_lo - SH_HALO : 0;
+    pl.seg_hi = pl.own_hi + SH_HALO <= pl.n ? pl.own_hi + SH_HALO : pl.n;
+    if (rank > 0 && pl.own_lo < SH_HALO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
+    if (pl.own_hi - pl.own_lo < 1024) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
+    if (pl.resample) {
+        pl.in_lo = 2ull * (uint64_t)pl.g.rows[rank] * (uint64_t)pl.M1s;
+        pl.in_hi = 2ull * (uint64_t)pl.g.rows[rank + 1] * (uint64_t)pl.M1s;
+    } else {
+        pl.in_lo = pl.seg_lo;
+        pl.in_hi = pl.seg_hi;
+    }
+    return 0;
+}
+
+struct wfx_shard {
+    wfx_ctx *ctx = nullptr;
+    wfx_comm *comm = nullptr;
+    wfx_decode_params dp{};
+    shard_plan pl;
+    wfx_dist dF, dI, dH;                  // resampler forward / inverse, Hilbert
+    wfx_devbuf b_in, b_merged, b_res, b_audio, b_v, b_env, b_dig, b_blk, b_blks, b_nan, b_flags;
+    const void *ext_in = nullptr;
+    bool have_input = false, ran = false, bound = false;
+    uint64_t cap = SH_CAND_CAP;
+    unsigned *ws = nullptr;
+};
+
+static size_t frame_bytes(int in_kind) { return in_kind == WFX_IN_I16_MONO ? 2 : (in_kind == WFX_IN_I16_STEREO ? 4 : 8); }
+
+static void free_buf(wfx_devbuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+static int shard_bind(wfx_shard *sh)
+{
+    wfx_ctx *ctx = sh->ctx;
+    shard_plan &pl = sh->pl;
+    const int me = pl.rank;
+    const long long nr = pl.g.nrows(me);
+    const uint64_t n_own = pl.own_hi - pl.own_lo, n_seg = pl.seg_hi - pl.seg_lo;
+    const void *in = sh->ext_in ? sh->ext_in : sh->b_in.p;
+    // audio segment [seg_lo, seg_hi): the notch output; the Hilbert transform's input rows start at own_lo
+    WFX_TRY(wfx_reserve(ctx, sh->b_audio, n_seg * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_v, (size_t)(2 * SH_VHALO + nr * pl.Ms) * sizeof(cplx) + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_env, n_own * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_dig, (me == 0 ? pl.n : n_own) + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_blk, wfx_select_block_bytes(sh->cap)));
+    WFX_TRY(wfx_reserve(ctx, sh->b_blks, wfx_select_block_bytes(sh->cap) * pl.world));
+    WFX_TRY(wfx_reserve(ctx, sh->b_nan, 8 * (size_t)pl.world + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_flags, 64));
+    WFX_HIP(ctx, hipMemsetAsync(sh->b_flags.p, 0, 64, ctx->stream));
+    WFX_HIP(ctx, hipMemsetAsync(sh->b_nan.p, 0, 8 * (size_t)pl.world + 64, ctx->stream));
+    const double *audio_own = (const double *)sh->b_audio.p + (pl.own_lo - pl.seg_lo);
+    if (pl.resample) {
+        const void *rows_in = in;
+        if (pl.in_kind == WFX_IN_I16_STEREO) {
+            WFX_TRY(wfx_reserve(ctx, sh->b_merged, (pl.in_hi - pl.in_lo) * 8 + 64));
+            rows_in = sh->b_merged.p;
+        }
+        // resampled audio: [own_lo - 32, own_hi + 32) circularly (16 points of halo on either side)
+        WFX_TRY(wfx_reserve(ctx, sh->b_res, (size_t)(SH_HALO + nr * pl.Ms) * sizeof(cplx) + 64));
+        WFX_TRY(sh->dF.bind(rows_in, nullptr, 0));
+        WFX_TRY(sh->dI.bind(nullptr, (cplx *)sh->b_res.p, 0));
+    } else if (pl.in_kind == WFX_IN_I16_STEREO) {
+        WFX_TRY(wfx_reserve(ctx, sh->b_merged, (pl.in_hi - pl.in_lo) * 8 + 64));
+    }
+    WFX_TRY(sh->dH.bind(audio_own, (cplx *)sh->b_v.p, sh->dH.fwd_result_index()));
+    sh->bound = true;
+    return 0;
+}
+
+// ---- the phases ------------------------------------------------------------------------------------------------
+static int phase_count(const wfx_shard *sh) { return sh->pl.resample ? 13 : 9; }
+
+static int run_phase(wfx_shard *sh, int ph)
+{
+    wfx_ctx *ctx = sh->ctx;
+    wfx_comm *c = sh->comm;
+    shard_plan &pl = sh->pl;
+    const wfx_decode_params &p = sh->dp;
+    const int me = pl.rank, W = pl.world;
+    const uint64_t n_own = pl.own_hi - pl.own_lo, n_seg = pl.seg_hi - pl.seg_lo;
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    const void *in = sh->ext_in ? sh->ext_in : sh->b_in.p;
+    double *audio = (double *)sh->b_audio.p;
+    double *env = (double *)sh->b_env.p;
+    uint8_t *dig_own = (uint8_t *)sh->b_dig.p + (me == 0 ? pl.own_lo : 0);
+    if (!pl.resample) ph += 4;              // phases 0..3 are the resampler's
+    switch (ph) {
+    case 0: {   // a4 + a5 first exchange: input rows -> columns
+        WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+        if (pl.in_kind == WFX_IN_I16_STEREO) WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, pl.in_hi - pl.in_lo, (double *)sh->b_merged.p));
+        return sh->dF.fwd_pack_exchange(c, pl.in_kind == WFX_IN_I16_STEREO ? sh->b_merged.p : in);
+    }
+    case 1: return sh->dF.fwd_pass1_exchange(c, pl.in_kind == WFX_IN_I16_MONO ? 2 : 0);
+    case 2: {   // spectrum -> scipy.signal.resample's bin copy -> inverse transform's slab passes
+        cplx *Z = nullptr;
+        WFX_TRY(sh->dF.fwd_slab(0, &Z));
+        WFX_TRY(wfx_dist_resample_glue(ctx, pl.g, Z, (long long)pl.n0, (long long)pl.n, sh->dI.slab_buffer(0)));
+        return sh->dI.inv_slab_exchange(c, sh->dI.slab_buffer(0));
+    }
+    case 3: return sh->dI.inv_pass1_exchange(c, (cplx *)sh->b_res.p);
+    case 4: {   // a6 notch on [seg_lo, seg_hi), then the Hilbert transform's first exchange
+        const void *nin = in;
+        int nkind = pl.in_kind;
+        if (pl.resample) {
+            WFX_TRY(sh->dI.inv_unpack((cplx *)sh->b_res.p));
+            // b_res holds samples [own_lo - 32, own_hi + 32) (circular); the segment starts at seg_lo
+            nin = (const double *)sh->b_res.p + (pl.seg_lo + SH_HALO - pl.own_lo);
+            nkind = WFX_IN_F64_MONO;
+        } else {
+            WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+            if (pl.in_kind == WFX_IN_I16_STEREO) {
+                WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, n_seg, (double *)sh->b_merged.p));
+                nin = sh->b_merged.p;
+                nkind = WFX_IN_F64_MONO;
+            }
+        }
+        const int flags = (pl.seg_lo == 0 ? 1 : 0) | (pl.seg_hi == pl.n ? 2 : 0);
+        WFX_TRY(wfx_dev_notch_fir_only(ctx, nin, nkind, n_seg, p.notch_b, p.notch_a, audio, flags));
+        return sh->dH.fwd_pack_exchange(c, audio + (pl.own_lo - pl.seg_lo));
+    }
+    case 5: return sh->dH.fwd_pass1_exchange(c, 1);
+    case 6: {
+        cplx *G = nullptr;
+        WFX_TRY(sh->dH.fwd_slab(1, &G));
+        return sh->dH.inv_slab_exchange(c, G);
+    }
+    case 7: return sh->dH.inv_pass1_exchange(c, (cplx *)sh->b_v.p);
+    case 8: {   // a7 envelope + median, level-0 histogram; first all-reduce
+        WFX_TRY(sh->dH.inv_unpack((cplx *)sh->b_v.p));
+        WFX_TRY(wfx_dev_select_sharded_ws(ctx, &sh->ws));
+        // pointers indexed by global pair / sample index
+        const cplx *Vg = (const cplx *)sh->b_v.p - ((long long)(pl.own_lo / 2) - SH_VHALO);
+        const double *xg = audio - (long long)pl.seg_lo;
+        WFX_TRY(wfx_dev_env_median_block(ctx, Vg, xg, pl.n, pl.own_lo, pl.own_hi, env, sh->ws));
+        return wfx_comm_allreduce_u32(c, ctx, sh->ws, WFX_SEL_BINS);
+    }
+    case 9: {
+        const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
+        WFX_TRY(wfx_dev_select_l1(ctx, env, n_own, ranks, sh->ws, ds));
+        return wfx_comm_allreduce_u32(c, ctx, sh->ws + WFX_SEL_H1_OFFSET, WFX_SEL_H1_WORDS);
+    }
+    case 10: {
+        WFX_TRY(wfx_dev_select_compact_block(ctx, env, n_own, sh->ws, ds, sh->b_blk.p, sh->cap));
+        return wfx_comm_allgather(c, ctx, sh->b_blk.p, sh->b_blks.p, wfx_select_block_bytes(sh->cap));
+    }
+    case 11: {  // a8 finish + quantise; the one gather of the stream
+        WFX_TRY(wfx_dev_select_finish_blocks(ctx, sh->ws, ds, sh->b_blks.p, W, sh->cap, p.gamma_lo, p.gamma_hi, (unsigned *)sh->b_flags.p));
+        WFX_TRY(wfx_dev_quantise(ctx, env, n_own, ds, dig_own, ds));
+        std::vector<wfx_xfer> xs;
+        if (me == 0) {
+            for (int s = 1; s < W; ++s) {
+                const uint64_t lo = 2ull * (uint64_t)pl.g.rows[s] * (uint64_t)pl.Ms, hi = 2ull * (uint64_t)pl.g.rows[s + 1] * (uint64_t)pl.Ms;
+                wfx_xfer a{};
+                a.peer = s;
+                a.recv = (uint8_t *)sh->b_dig.p + lo;
+                a.recv_bytes = hi - lo;
+                xs.push_back(a);
+                wfx_xfer b{};
+                b.peer = s;
+                b.recv = (unsigned long long *)sh->b_nan.p + s;
+                b.recv_bytes = 8;
+                xs.push_back(b);
+            }
+        } else {
+            wfx_xfer a{};
+            a.peer = 0;
+            a.send = dig_own;
+            a.send_bytes = n_own;
+            xs.push_back(a);
+            wfx_xfer b{};
+            b.peer = 0;
+            b.send = &ds->nan_count;
+            b.send_bytes = 8;
+            xs.push_back(b);
+        }
+        return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
+    }
+    case 12: {  // a9 + a10 on rank 0
+        if (me != 0) return 0;
+        if (W > 1) WFX_TRY(wfx_dev_add_u64(ctx, &ds->nan_count, (const unsigned long long *)sh->b_nan.p + 1, W - 1));
+        const int w = p.width;
+        const int h_max = (int)(pl.n / (uint64_t)w);
+        WFX_TRY(wfx_reserve(ctx, ctx->b_img, (size_t)w * 4 * (size_t)(h_max > 0 ? h_max : 1)));
+        WFX_TRY(wfx_dev_sync_pick(ctx, (const uint8_t *)sh->b_dig.p, pl.n, p.n1, p.n0_gap, p.mindistance, p.frame_samples, w, ds));
+        return wfx_dev_image(ctx, (const uint8_t *)sh->b_dig.p, pl.n, w, h_max, ds, (uint8_t *)ctx->b_img.p, ctx->h_scal);
+    }
+    default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "no such phase");
+    }
+}
+
+#define CHECK_SH(sh)                                                              \
+    do {                                                                          \
+        if (!(sh)) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null shard");       \
+        (void)hipSetDevice((sh)->ctx->device);                                    \
+    } while (0)
+
+extern "C" {
+
+int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_shard_layout *out)
+{
+    if (!out) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null argument");
+    shard_plan pl;
+    WFX_TRY(make_plan(nullptr, p, world, rank, pl));
+    memset(out, 0, sizeof *out);
+    out->world = world;
+    out->rank = rank;
+    out->first_radix[0] = pl.g.ra1;
+    out->first_radix[1] = pl.g.rb1;
+    out->in_lo = pl.in_lo;
+    out->in_hi = pl.in_hi;
+    out->own_lo = pl.own_lo;
+    out->own_hi = pl.own_hi;
+    return 0;
+}
+
+int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, wfx_shard **out)
+{
+    if (!ctx || !comm || !p || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    wfx_shard *sh = new wfx_shard();
+    sh->ctx = ctx;
+    sh->comm = comm;
+    sh->dp = *p;
+    int rc = make_plan(ctx, p, wfx_comm_world(comm), wfx_comm_rank(comm), sh->pl);
+    const shard_plan &pl = sh->pl;
+    if (rc == 0) rc = wfx_reserve(ctx, ctx->b_scal, sizeof(wfx_dev_scalars));
+    if (rc == 0 && pl.resample) {
+        rc = sh->dF.init(ctx, pl.g, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0);
+        if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, SH_HALO / 2, SH_HALO / 2);
+    }
+    if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.K, 16, SH_VHALO, SH_VHALO);
+    if (rc != 0) {
+        wfx_shard_destroy(sh);
+        return rc;
+    }
+    *out = sh;
+    return 0;
+}
+
+int wfx_shard_upload(wfx_shard *sh, const void *host_frames)
+{
+    CHECK_SH(sh);
+    wfx_ctx *ctx = sh->ctx;
+    if (!host_frames) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    const size_t nb = (size_t)(sh->pl.in_hi - sh->pl.in_lo) * frame_bytes(sh->pl.in_kind);
+    const bool moved = !sh->b_in.p || sh->b_in.cap < nb + 64 || sh->ext_in;
+    WFX_TRY(wfx_reserve(ctx, sh->b_in, nb + 64));
+    sh->ext_in = nullptr;
+    WFX_HIP(ctx, hipMemcpyAsync(sh->b_in.p, host_frames, nb, hipMemcpyHostToDevice, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sh->have_input = true;
+    sh->ran = false;
+    if (moved || !sh->bound) WFX_TRY(shard_bind(sh));
+    return 0;
+}
+
+int wfx_shard_attach(wfx_shard *sh, const void *dev_frames)
+{
+    CHECK_SH(sh);
+    if (!dev_frames) return wfx_fail(sh->ctx, WFX_ERR_BAD_ARG, "null buffer");
+    const bool moved = sh->ext_in != dev_frames;
+    sh->ext_in = dev_frames;
+    sh->have_input = true;
+    sh->ran = false;
+    if (moved || !sh->bound) WFX_TRY(shard_bind(sh));
+    return 0;
+}
+
+int wfx_shard_phase_count(wfx_shard *sh) { return sh ? phase_count(sh) : 0; }
+
+int wfx_shard_phase(wfx_shard *sh, int phase)
+{
+    CHECK_SH(sh);
+    if (!sh->have_input) return wfx_fail(sh->ctx, WFX_ERR_STATE, "sharded decode before the input was given");
+    if (phase < 0 || phase >= phase_count(sh)) return wfx_fail(sh->ctx, WFX_ERR_BAD_ARG, "phase %d out of range", phase);
+    WFX_TRY(run_phase(sh, phase));
+    if (phase == phase_count(sh) - 1) sh->ran = true;
+    return 0;
+}
+
+int wfx_decode_sharded(wfx_shard *sh)
+{
+    CHECK_SH(sh);
+    if (wfx_comm_is_local(sh->comm) && wfx_comm_world(sh->comm) > 1)
+        return wfx_fail(sh->ctx, WFX_ERR_STATE, "local communicator: drive the ranks phase by phase (wfx_shard_phase)");
+    const int np = phase_count(sh);
+    for (int ph = 0; ph < np; ++ph) WFX_TRY(wfx_shard_phase(sh, ph));
+    return 0;
+}
+
+int wfx_shard_result(wfx_shard *sh, wfx_decode_info *info)
+{
+    CHECK_SH(sh);
+    wfx_ctx *ctx = sh->ctx;
+    if (!info) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null info");
+    if (!sh->ran) return wfx_fail(ctx, WFX_ERR_STATE, "shard_result before the decode");
+    unsigned flags[4] = {0, 0, 0, 0};
+    WFX_HIP(ctx, hipMemcpyAsync(flags, sh->b_flags.p, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    if (sh->pl.rank != 0) WFX_HIP(ctx, hipMemcpyAsync(ctx->h_scal, ds, sizeof(wfx_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (flags[0]) {
+        // a rank produced more candidate keys than travel in the all-gather (long runs of equal envelope values: digital
+        // silence).  Every rank sees the same flag; the capacity is raised for the next decode of this shard.
+        WFX_HIP(ctx, hipMemsetAsync(sh->b_flags.p, 0, 64, ctx->stream));
+        sh->cap *= 16;
+        sh->bound = false;
+        sh->ran = false;
+        WFX_TRY(shard_bind(sh));
+        return wfx_fail(ctx, WFX_ERR_STATE, "percentile select: candidate lists overflowed; capacity raised to %llu keys, decode again",
+                        (unsigned long long)sh->cap);
+    }
+    const wfx_dev_scalars &s = *ctx->h_scal;
+    memset(info, 0, sizeof *info);
+    info->n = sh->pl.n;
+    info->width = sh->dp.width;
+    info->low = s.low;
+    info->high = s.high;
+    if (sh->pl.rank == 0) {
+        info->nan_count = s.nan_count;
+        info->npeaks = s.npeaks;
+        info->hit_limit = s.hit_limit;
+        info->no_group = s.no_group;
+        info->n_phasing = s.n_phasing;
+        info->start_frame = s.start_frame;
+        info->height = s.height;
+        for (int i = 0; i <= WFX_MAX_PEAKS; ++i) {
+            info->peak_pos[i] = s.peak_pos[i];
+            info->first_pos[i] = s.first_pos[i];
+            info->phasing[i] = s.phasing[i];
+        }
+    }
+    return 0;
+}
+
+int wfx_shard_fetch(wfx_shard *sh, int buffer_id, void *host_out, size_t bytes)
+{
+    CHECK_SH(sh);
+    wfx_ctx *ctx = sh->ctx;
+    if (!sh->ran) return wfx_fail(ctx, WFX_ERR_STATE, "no sharded decode has run");
+    const shard_plan &pl = sh->pl;
+    const uint64_t n_own = pl.own_hi - pl.own_lo;
+    const void *src = nullptr;
+    size_t nb = 0;
+    switch (buffer_id) {
+    case WFX_BUF_AUDIO: src = (const double *)sh->b_audio.p + (pl.own_lo - pl.seg_lo); nb = n_own * 8; break;
+    case WFX_BUF_ENVELOPE: src = sh->b_env.p; nb = n_own * 8; break;
+    case WFX_BUF_DIGITAL:
+        if (pl.rank == 0 && bytes == pl.n) {
+            src = sh->b_dig.p;
+            nb = pl.n;
+        } else {
+            src = (const uint8_t *)sh->b_dig.p + (pl.rank == 0 ? pl.own_lo : 0);
+            nb = n_own;
+        }
+        break;
+    case WFX_BUF_IMAGE:
+        if (pl.rank != 0) return wfx_fail(ctx, WFX_ERR_STATE, "the image lives on rank 0");
+        WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        src = ctx->b_img.p;
+        nb = (size_t)sh->dp.width * 4 * (size_t)ctx->h_scal->height;
+        break;
+    default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown buffer id %d", buffer_id);
+    }
+    if (bytes != nb) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fetch: expected %zu bytes, got %zu", nb, bytes);
+    if (nb && !host_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (nb) WFX_HIP(ctx, hipMemcpyAsync(host_out, src, nb, hipMemcpyDeviceToHost, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int wfx_shard_destroy(wfx_shard *sh)
+{
+    if (!sh) return 0;
+    (void)hipSetDevice(sh->ctx->device);
+    (void)hipStreamSynchronize(sh->ctx->stream);
+    sh->dF.release();
+    sh->dI.release();
+    sh->dH.release();
+    wfx_devbuf *bufs[] = {&sh->b_in, &sh->b_merged, &sh->b_res, &sh->b_audio, &sh->b_v, &sh->b_env, &sh->b_dig, &sh->b_blk, &sh->b_blks, &sh->b_nan, &sh->b_flags};
+    for (wfx_devbuf *b : bufs) free_buf(*b);
+    delete sh;
+    return 0;
+}
+
+}  // extern "C"

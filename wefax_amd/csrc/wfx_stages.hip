@@ -1039,6 +1039,92 @@ int wfx_dev_percentiles_fused(wfx_ctx *ctx, const double *env, uint64_t n, const
     return select_after_l0(ctx, env, n, ranks, d_scal, 1, gamma_lo, gamma_hi);
 }
 
+// ---- the same select in the steps a sharded decode separates with collectives (wfx_shard.hip) ----------------
+// level-0 histogram (fused into the envelope kernel) -> all-reduce -> level 1 -> all-reduce -> compaction into a fixed-size
+// block per rank -> all-gather of the blocks -> merge + finish on every rank (identical inputs, identical results).
+int wfx_dev_select_sharded_ws(wfx_ctx *ctx, unsigned **ws)
+{
+    const bool fresh = ctx->b_hist.cap < SEL_WORDS * sizeof(unsigned) || !ctx->b_hist.p;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_hist, SEL_WORDS * sizeof(unsigned)));
+    if (fresh) WFX_HIP(ctx, hipMemsetAsync(ctx->b_hist.p, 0, SEL_WORDS * sizeof(unsigned), ctx->stream));
+    *ws = (unsigned *)ctx->b_hist.p;
+    return 0;
+}
+
+int wfx_dev_select_l1(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], unsigned *ws, wfx_dev_scalars *d_scal)
+{
+    const unsigned g1 = std::min(wfx_stream_grid(n, 16384), 256u);
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l1_kernel<1024>, dim3(g1), dim3(1024), env, n, ranks[0], ranks[1], ranks[2], ranks[3], ws, d_scal);
+    return 0;
+}
+
+__global__ void select_block_counts_kernel(const unsigned *__restrict__ ws, unsigned *__restrict__ counts)
+{
+    if (threadIdx.x < 4) counts[threadIdx.x] = ws[SEL_CNT + threadIdx.x];
+}
+
+int wfx_dev_select_compact_block(wfx_ctx *ctx, const double *env, uint64_t n, unsigned *ws, wfx_dev_scalars *d_scal, void *block, uint64_t cap)
+{
+    const unsigned g1 = std::min(wfx_stream_grid(n, 16384), 256u);
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_compact_kernel<1024>, dim3(g1), dim3(1024), env, n, ws, d_scal, (unsigned long long *)block, cap);
+    WFX_LAUNCH(ctx, K_SELECT_SCAN, select_block_counts_kernel, dim3(1), dim3(64), (const unsigned *)ws, (unsigned *)((char *)block + cap * 32));
+    return 0;
+}
+
+// blocks[r] = {u64 keys[4][cap]; u32 count[4]; u32 pad[4]} -> merged[q][capm], ws[SEL_CNT + q] = total
+__global__ void __launch_bounds__(256) select_merge_blocks_kernel(const char *__restrict__ blocks, int nblocks, uint64_t cap, unsigned long long *__restrict__ merged,
+                                                                 uint64_t capm, unsigned *__restrict__ ws, unsigned *__restrict__ overflow)
+{
+    const int r = blockIdx.y, q = blockIdx.z;
+    const size_t bb = (size_t)cap * 32 + 32;
+    uint64_t off = 0, total = 0;
+    bool over = false;
+    for (int k = 0; k < nblocks; ++k) {
+        const unsigned c = ((const unsigned *)(blocks + (size_t)k * bb + cap * 32))[q];
+        const uint64_t cc = c < cap ? c : cap;
+        over = over || c > cap;
+        if (k < r) off += cc;
+        total += cc;
+    }
+    const unsigned mine = ((const unsigned *)(blocks + (size_t)r * bb + cap * 32))[q];
+    const uint64_t cnt = mine < cap ? mine : cap;
+    const unsigned long long *src = (const unsigned long long *)(blocks + (size_t)r * bb) + (size_t)q * cap;
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * 256ull) merged[(size_t)q * capm + off + i] = src[i];
+    if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        ws[SEL_CNT + q] = (unsigned)total;
+        if (over && q == 0) atomicAdd(overflow, 1u);
+        else if (over) atomicAdd(overflow, 1u);
+    }
+}
+
+int wfx_dev_select_finish_blocks(wfx_ctx *ctx, unsigned *ws, wfx_dev_scalars *d_scal, const void *blocks, int nblocks, uint64_t cap, double gamma_lo,
+                                 double gamma_hi, unsigned *overflow)
+{
+    const uint64_t capm = cap * (uint64_t)nblocks;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_cand, 4 * (size_t)capm * sizeof(unsigned long long)));
+    unsigned long long *merged = (unsigned long long *)ctx->b_cand.p;
+    unsigned gx = (unsigned)((cap + 2047) / 2048);
+    if (gx > 64) gx = 64;
+    WFX_LAUNCH(ctx, K_SELECT_SCAN, select_merge_blocks_kernel, dim3(gx, nblocks, 4), dim3(256), (const char *)blocks, nblocks, cap, merged, capm, ws, overflow);
+    WFX_LAUNCH(ctx, K_SELECT_SCAN, select_finish_kernel, dim3(4), dim3(1024), ws, d_scal, (const unsigned long long *)merged, capm, 1, gamma_lo, gamma_hi);
+    return 0;
+}
+
+__global__ void add_u64_kernel(unsigned long long *dst, const unsigned long long *src, int n)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int i = 0; i < n; ++i) s += src[i];
+        *dst += s;
+    }
+}
+
+int wfx_dev_add_u64(wfx_ctx *ctx, unsigned long long *dst, const unsigned long long *src, int n)
+{
+    WFX_LAUNCH(ctx, K_SELECT_SCAN, add_u64_kernel, dim3(1), dim3(64), dst, src, n);
+    return 0;
+}
+
 __global__ void percentile_lerp_kernel(wfx_dev_scalars *s, double gamma_lo, double gamma_hi)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {

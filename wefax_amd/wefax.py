@@ -26,6 +26,34 @@ DEFAULT_HILBERT_MODE = nat.WFX_HILBERT_FFT
 DEFAULT_FIR_TAPS = 4095
 
 
+def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEFAULT_NOTCH,
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS):
+    """The scalar arithmetic of the reference for a capture of ``n0`` frames at ``sample_rate`` (lengths, notch
+    coefficients, percentile ranks and weights, sync constants) as the C ABI's ``wfx_decode_params``, plus the derived
+    lengths.  Same expressions as wefax.py, evaluated in Python floats / NumPy scalars like there."""
+    input_length = n0 / sample_rate                                    # wefax.py:357
+    resampled = sample_rate != hp.TARGET_RATE                          # wefax.py:60
+    n = int(hp.TARGET_RATE * input_length) if resampled else n0       # wefax.py:384
+    if n <= 9:
+        raise ValueError("The length of the input vector x must be greater than padlen, which is 9.")
+    b, a = hp.iirnotch(int(notch[0]), notch[1], hp.TARGET_RATE)        # wefax.py:63-70
+    p = nat.DecodeParams()
+    p.in_kind, p.n0, p.n, p.resample = kind, n0, n, int(resampled)
+    p.notch_b[:] = [float(v) for v in b]
+    p.notch_a[:] = [float(v) for v in a]
+    p.hilbert_mode, p.fir_taps = hilbert_mode, fir_taps
+    lo0, lo1, glo = hp.percentile_plan(n, 0.5)                         # wefax.py:194-196
+    hi0, hi1, ghi = hp.percentile_plan(n, 99.5)
+    p.rank_lo[:] = [lo0, lo1]
+    p.rank_hi[:] = [hi0, hi1]
+    p.gamma_lo, p.gamma_hi = glo, ghi
+    n1, n0g, mind = hp.sync_constants(hp.TARGET_RATE, frame_len)
+    p.n1, p.n0_gap, p.mindistance = n1, n0g, mind
+    p.frame_samples = frame_len * hp.TARGET_RATE                       # wefax.py:265-266
+    p.width = int(frame_len * hp.TARGET_RATE)                          # wefax.py:298
+    return p, {"input_length": input_length, "resampled": resampled, "n": n, "length": n / hp.TARGET_RATE}   # wefax.py:393
+
+
 class DecodeJob:
     """One capture resident on the GPU: upload once, run the path any number of
     times (bench.py times ``run()``), then read results."""
@@ -57,29 +85,11 @@ class DecodeJob:
 
     def _configure(self, kind, n0, sample_rate, notch, hilbert_mode, fir_taps):
         """The scalar arithmetic of the reference (lengths, notch, percentile ranks, sync constants) -> self.params."""
-        self.input_length = n0 / sample_rate                               # wefax.py:357
-        self.resampled = sample_rate != hp.TARGET_RATE                     # wefax.py:60
-        n = int(hp.TARGET_RATE * self.input_length) if self.resampled else n0   # wefax.py:384
-        self.n0, self.n = n0, n
+        p, meta = build_params(kind, n0, sample_rate, self.frame_len, notch, hilbert_mode, fir_taps)
+        self.input_length, self.resampled = meta["input_length"], meta["resampled"]
+        self.n0, self.n = n0, meta["n"]
         self.sample_rate = hp.TARGET_RATE
-        self.length = n / hp.TARGET_RATE                                   # wefax.py:393
-        if n <= 9:
-            raise ValueError("The length of the input vector x must be greater than padlen, which is 9.")
-        b, a = hp.iirnotch(int(notch[0]), notch[1], self.sample_rate)      # wefax.py:63-70
-        p = nat.DecodeParams()
-        p.in_kind, p.n0, p.n, p.resample = kind, n0, n, int(self.resampled)
-        p.notch_b[:] = [float(v) for v in b]
-        p.notch_a[:] = [float(v) for v in a]
-        p.hilbert_mode, p.fir_taps = hilbert_mode, fir_taps
-        lo0, lo1, glo = hp.percentile_plan(n, 0.5)                         # wefax.py:194-196
-        hi0, hi1, ghi = hp.percentile_plan(n, 99.5)
-        p.rank_lo[:] = [lo0, lo1]
-        p.rank_hi[:] = [hi0, hi1]
-        p.gamma_lo, p.gamma_hi = glo, ghi
-        n1, n0g, mind = hp.sync_constants(self.sample_rate, self.frame_len)
-        p.n1, p.n0_gap, p.mindistance = n1, n0g, mind
-        p.frame_samples = self.frame_len * self.sample_rate                # wefax.py:265-266
-        p.width = int(self.frame_len * self.sample_rate)                   # wefax.py:298
+        self.length = meta["length"]
         self.params = p
         self.width = p.width
 
