@@ -285,6 +285,11 @@ typedef struct {
 /* host only (no GPU needed): how a capture described by `p` is cut for `world` ranks; WFX_ERR_BAD_ARG when it cannot be
  * sharded (odd or non-13-smooth lengths, too short for the world size): decode it on one GPU then */
 int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_shard_layout *out);
+/* host only: builds every rank's exchange lists for `world` ranks with fake buffer addresses and checks that the two ends of
+ * every message agree, that what a rank receives tiles its buffers exactly, and that every packing copy stays inside its
+ * buffers (WFX_ERR_COMM with a description otherwise).  Lets a deployment -- and the CPU test suite -- validate a plan for
+ * capture sizes and world sizes it cannot run */
+int wfx_shard_dry_run(const wfx_decode_params *p, int world);
 /* `p` describes the WHOLE capture (as for wfx_decode_upload); hilbert_mode must be WFX_HILBERT_FFT */
 int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, wfx_shard **out);
 /* this rank's input frames [in_lo, in_hi): host memory (copied) or caller-owned device memory (kept, not copied) */
@@ -303,6 +308,23 @@ int wfx_shard_fetch(wfx_shard *sh, int buffer_id, void *host_out, size_t bytes);
 int wfx_shard_destroy(wfx_shard *sh);
 
 /* ---- measurement ------------------------------------------------------ */
+/* Test-signal synthesis straight into HBM (not on the decode path; the reference ships no generator): the WEFAX transmission
+ * of wefax_amd/synth.py -- start tone, phasing lines, ramp image lines, stop tone, black tail, phase-continuous FM + white
+ * noise -> int16 mono (iq = 0) or interleaved I/Q (iq = 1) -- for frames [lo, hi) of a capture of wfx_synth_frames() frames.
+ * BASELINE configs[3] (60 minutes at 1.536 MS/s IQ, 22 GB) exists only this way. */
+typedef struct {
+    double   sample_rate;
+    int      lines_per_minute, ioc;             /* ioc 576: 300 Hz start tone, 288: 675 Hz (README.md:27-97 of the reference) */
+    double   start_tone_s;
+    int      phasing_lines, image_lines;
+    double   stop_tone_s, black_tail_s;
+    double   amplitude, noise;                  /* in units of full scale */
+    uint64_t seed;
+    int      iq;
+} wfx_synth_params;
+uint64_t wfx_synth_frames(const wfx_synth_params *p);
+int wfx_synth_capture(wfx_ctx *ctx, const wfx_synth_params *p, uint64_t lo, uint64_t hi, void *dev_out);
+
 /* HIP-event stopwatch on the context's stream */
 int wfx_timer_start(wfx_ctx *ctx);
 int wfx_timer_stop(wfx_ctx *ctx, float *ms);

@@ -1,10 +1,10 @@
 """Time-domain front end (wefax_amd/polyphase.py + csrc/wfx_polyphase.hip): the halo-local
 counterpart of the reference's FFT resampler (wefax.py:375-394) for oversampled captures.
 
-CPU: filter design, index bookkeeping and the orchestration with the NumPy stage backend,
-checked against the oracle's FFT resampler.  GPU (-m gpu): the two stencil kernels against
-their float64 models, slice invariance, and the whole sharded decode of 48 kHz and
-1.536 MS/s IQ captures against the oracle."""
+CPU: filter design and index bookkeeping, the float64 model of the chain checked against the
+oracle's FFT resampler.  GPU (-m gpu): the two stencil kernels against their float64 models,
+and whole decodes of 48 kHz / 192 kHz / 1.536 MS/s IQ captures -- front end to 22 050 Hz, then the
+exact path (one GPU fused, and sharded over emulated ranks) -- against the oracle."""
 import os
 
 import numpy as np
@@ -14,9 +14,7 @@ from conftest import GOLDEN
 from oracle import wefax_oracle as wo
 from wefax_amd import polyphase as pp
 from wefax_amd import sharded, synth
-from sharded_numpy_backend import NumpyStages, decimate_model, front_end_model, rational_model, to_real
-
-TAPS = 255
+from polyphase_models import decimate_model, front_end_model, rational_model, to_real
 
 
 def _response(st, freqs_hz):
@@ -117,68 +115,6 @@ def _capture(fs, noise, seed=1, lpm=240, seconds=61.0, iq=False):
                                start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0, iq=iq)
 
 
-def test_sharded_decode_with_front_end_cpu():
-    """Orchestration with the NumPy backend: world-size invariance and closeness to the oracle's FFT resampler."""
-    x = _capture(48000, 0.05)
-    fe = pp.FrontEnd(48000)
-    one = sharded.decode_emulated(NumpyStages, x, 1, lines_per_minute=240, taps=TAPS, frontend=fe)
-    two = sharded.decode_emulated(NumpyStages, x, 2, lines_per_minute=240, taps=TAPS, frontend=fe)
-    assert one["sync"]["start_frame"] == two["sync"]["start_frame"]
-    assert np.array_equal(one["image"], two["image"]) and np.array_equal(one["digitalized"], two["digitalized"])
-    n = fe.n_out(x.shape[0])
-    ref_audio = wo.resample_fft(x.astype(np.float64), n)
-    assert one["audio"].shape[0] == n
-    # the noise between pass_hz and 5512.5 Hz, which the reference keeps and the front end drops, is the difference
-    assert np.max(np.abs(one["audio"] - ref_audio)) < 0.08 * np.max(np.abs(ref_audio))
-    assert np.sqrt(np.mean((one["audio"] - ref_audio) ** 2)) < 0.02 * np.max(np.abs(ref_audio))
-
-
-def _free_port():
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
-
-
-def _gloo_worker(rank, world, port, out_dir):
-    import torch
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        x = _capture(48000, 0.05)
-        fe = pp.FrontEnd(48000)
-        calls = []
-
-        def raw_loader(lo, hi):             # every rank asks for its own slice of the oversampled capture only
-            calls.append((lo, hi))
-            return x[np.arange(lo, hi) % x.shape[0]]
-
-        dec = sharded.ShardedDecoder(NumpyStages(), None, fe.n_out(x.shape[0]), world, rank, 240, TAPS, frontend=fe,
-                                     n_in_total=x.shape[0], in_kind=0, raw_loader=raw_loader)
-        assert len(calls) == 1 and calls[0][1] - calls[0][0] < 0.6 * x.shape[0]
-        res = dec.run(sharded.TorchComm(dist, torch, "cpu"))
-        if rank == 0:
-            img, sync, low, high = res
-            np.savez(os.path.join(out_dir, "root.npz"), image=img, start=sync["start_frame"], low=low, high=high)
-        else:
-            assert res is None
-    finally:
-        dist.destroy_process_group()
-
-
-def test_two_gloo_ranks_with_front_end_equal_one_rank(tmp_path):
-    pytest.importorskip("torch")
-    import torch.multiprocessing as mp
-    mp.spawn(_gloo_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    got = np.load(os.path.join(tmp_path, "root.npz"))
-    ref = sharded.decode_emulated(NumpyStages, _capture(48000, 0.05), 1, lines_per_minute=240, taps=TAPS, frontend=pp.FrontEnd(48000))
-    assert int(got["start"]) == ref["sync"]["start_frame"]
-    assert float(got["low"]) == ref["low"] and float(got["high"]) == ref["high"]
-    assert np.array_equal(got["image"], ref["image"])
-
-
 # ---------------------------------------------------------------------------------------
 # GPU
 # ---------------------------------------------------------------------------------------
@@ -260,6 +196,11 @@ def test_rational_kernel_matches_model(ctx, kind, p, q, taps):
     ctx.dev_free(p_out)
 
 
+def _image_stats(img, ref):
+    d = np.abs(img.astype(np.int16) - ref.astype(np.int16))
+    return int(d.max()), int(np.count_nonzero(d > 1)), float(d.mean())
+
+
 def _oracle(x, fs, lpm):
     import tempfile
     with tempfile.TemporaryDirectory() as td:
@@ -268,77 +209,73 @@ def _oracle(x, fs, lpm):
         return wo.process(path, lpm, want_messages=False)
 
 
-def _image_stats(img, ref):
-    d = np.abs(img.astype(np.int16) - ref.astype(np.int16))
-    return int(d.max()), float(np.mean(d <= 1)), float(d.mean())
+# What separates these decodes from the reference is the front end alone (flat filters to 22 050 Hz, fp32 stencils): the
+# exact FFT resampler applies the reference's own brick wall and everything after it is the exact path.  Measured on
+# MI355X (profiles/r02): uint8 stream max |d| 1 on 0.3 % of the samples, image max |d| 2 on < 10 pixels of 1.7 M (the
+# bicubic's overshoot on neighbouring +-1), start_frame and peaks equal.  Tolerances below are those figures.
+STREAM_MAX, STREAM_NE_FRAC, IMAGE_MAX, IMAGE_GT1_FRAC = 1, 0.006, 2, 2e-5
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fs,iq,noise", [(48000, False, 0.05), (192000, True, 0.05), (192000, True, 0.02)])
-def test_sharded_decode_with_front_end_gpu(ctx, fs, iq, noise):
-    """Whole halo-local decode of an oversampled capture: bit-identical for 1 and 2 ranks; against the oracle's
-    exact path (FFT resample + FFT Hilbert) the 11 025 Hz audio agrees to what the filters' transition band
-    drops and the image to a few grey levels (measured and printed)."""
-    x = _capture(fs, noise, iq=iq)
-    fe = pp.FrontEnd(fs)
-    mk = lambda: sharded.HipStages(ctx)
-    one = sharded.decode_emulated(mk, x, 1, lines_per_minute=240, taps=4095, frontend=fe)
-    two = sharded.decode_emulated(mk, x, 2, lines_per_minute=240, taps=4095, frontend=fe)
-    assert two["sync"]["start_frame"] == one["sync"]["start_frame"]
-    assert np.array_equal(two["audio"], one["audio"])
-    assert np.array_equal(two["digitalized"], one["digitalized"])
-    assert np.array_equal(two["image"], one["image"])
-    n = fe.n_out(x.shape[0])
-    ref_audio = wo.resample_fft(to_real(x), n)
-    rel = np.max(np.abs(one["audio"] - ref_audio)) / np.max(np.abs(ref_audio))
-    ref = _oracle(x, fs, 240)
-    smx, sw1, smean = _image_stats(one["digitalized"], ref["digitalized"])
-    print(f"fs={fs} iq={iq} noise={noise}: audio rel err {rel:.2e}; uint8 stream max|d|={smx} within1={sw1:.4f} mean|d|={smean:.3f}")
-    assert rel < 0.08
-    assert smean < (2.5 if fs > 48000 else 4.5) and smx <= 40
-    if noise == 0.05:       # (which phasing group closes is a knife-edge decision on cleaner captures, SURVEY.md appendix B.4)
-        assert ref["start_frame"] == one["sync"]["start_frame"]
-    if ref.get("start_frame") == one["sync"]["start_frame"]:
-        mx, w1, mean = _image_stats(one["image"], ref["image"])
-        print(f"    image max|d|={mx} within1={w1:.4f} mean|d|={mean:.3f}")
-        assert mean < (2.5 if fs > 48000 else 4.5) and mx <= 40
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("two_x", [False, True])
-def test_front_end_plus_exact_rest_gpu(ctx, two_x):
-    """One GPU: time-domain front end + the exact rest of the path (FrontEndExactDecoder).  With the front end stopping
-    at 22 050 Hz the exact FFT resampler applies the reference's own brick wall and only wide, flat filters remain."""
-    fs = 1536000
-    x = _capture(fs, 0.05, seed=0, lpm=120, seconds=40.0, iq=True)
-    fe = pp.FrontEnd(fs, stop_at_2x=two_x)
-    dec = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=120)
+@pytest.mark.parametrize("fs,iq,lpm,seconds", [(48000, False, 240, 56.0), (192000, True, 240, 64.0), (1536000, True, 120, 40.0)])
+def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds):
+    """Front end to 22 050 Hz + the exact path: the one-GPU fused form, and the sharded form on 1, 2, 3 and 8 emulated
+    ranks (bit-identical to each other and to the fused form); against the oracle within the figures above."""
+    x = _capture(fs, 0.05, seed=0, lpm=lpm, seconds=seconds, iq=iq)
+    ref = _oracle(x, fs, lpm)
+    fe = pp.FrontEnd(fs, stop_at_2x=True)
+    dec = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=lpm)
     dec.run()
     info = dec.result()
-    ref = _oracle(x, fs, 120)
-    assert ref["start_frame"] == info.start_frame and dec.n == 441000
-    img = dec.fetch("image")
-    mx, w1, mean = _image_stats(img, ref["image"])
-    smx, sw1, smean = _image_stats(dec.fetch("digitalized"), ref["digitalized"])
-    print(f"front end (stop_at_2x={two_x}) + exact rest, 1.536 MS/s IQ 40 s: image max|d|={mx} within1={w1:.4f} mean|d|={mean:.3f}; "
-          f"stream max|d|={smx} mean|d|={smean:.3f}")
-    assert img.shape == ref["image"].shape and mean < (0.2 if two_x else 1.0) and w1 > (0.99 if two_x else 0.9)
+    img1, st1 = dec.fetch("image"), dec.fetch("digitalized")
     dec.close()
+    assert info.start_frame == ref["start_frame"]
+    for name, got, want, mx, frac in (("stream", st1, ref["digitalized"], STREAM_MAX, STREAM_NE_FRAC), ("image", img1, ref["image"], IMAGE_MAX, None)):
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        print(f"fs={fs}: {name} max|d|={d.max()} differing={np.count_nonzero(d)} of {d.size}, >1: {np.count_nonzero(d > 1)}")
+        assert got.shape == want.shape and d.max() <= mx
+        if frac is not None:
+            assert np.count_nonzero(d) <= frac * d.size
+    assert np.count_nonzero(np.abs(img1.astype(np.int16) - ref["image"].astype(np.int16)) > 1) <= max(1, IMAGE_GT1_FRAC * img1.size)
+    first = None
+    for world in (1, 2, 3, 8):
+        mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, x, lines_per_minute=lpm)      # noqa: E731
+        r = sharded.decode_emulated(x, fs, world, lpm, make_decoder=mk)
+        assert r["sync"]["start_frame"] == ref["start_frame"] and r["sync"]["peaks"] == [int(v) for v in ref["peaks"]]
+        assert np.array_equal(r["digitalized"], st1) and np.array_equal(r["image"], img1)
+        assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
+        if first is None:
+            first = r
+        else:       # the float stages too do not depend on the number of ranks
+            assert np.array_equal(r["envelope"], first["envelope"]) and np.array_equal(r["audio"], first["audio"])
+            assert r["low"] == first["low"] and r["high"] == first["high"]
 
 
 @pytest.mark.gpu
-def test_iq_stream_1536k_against_oracle_gpu(ctx):
-    """BASELINE configs[3] at a length the oracle finishes in seconds: 20 s of 1.536 MS/s int16 IQ through the
-    time-domain front end + halo-local path on one rank, against the oracle's reference-faithful decode."""
-    fs = 1536000
-    x = _capture(fs, 0.05, seed=0, lpm=120, seconds=40.0, iq=True)
-    fe = pp.FrontEnd(fs)
-    got = sharded.decode_emulated(lambda: sharded.HipStages(ctx), x, 1, lines_per_minute=120, taps=4095, frontend=fe)
-    ref = _oracle(x, fs, 120)
-    assert ref["start_frame"] == got["sync"]["start_frame"]
-    n = fe.n_out(x.shape[0])
-    rel = np.max(np.abs(got["audio"] - ref["audio_resampled"])) / np.max(np.abs(ref["audio_resampled"])) if "audio_resampled" in ref else None
-    mx, w1, mean = _image_stats(got["image"], ref["image"])
-    print(f"1.536 MS/s IQ 40 s: image {got['image'].shape} max|d|={mx} within1={w1:.4f} mean|d|={mean:.3f} audio {rel}")
-    assert got["image"].shape == ref["image"].shape and n == 441000
-    assert mean < 1.5 and w1 > 0.8 and mx <= 40
+def test_each_rank_loads_only_its_slice_of_the_raw_stream(ctx):
+    """The oversampled stream is split `world` ways and never moves: a rank asks its loader for its own frames plus the FIR
+    chain's halo (a few thousand frames), indices wrapping modulo the capture at its two ends."""
+    from wefax_amd import _native as nat
+    fs = 192000
+    x = _capture(fs, 0.05, seed=2, lpm=240, seconds=40.0, iq=True)
+    fe = pp.FrontEnd(fs, stop_at_2x=True)
+    n0 = x.shape[0]
+    comms = nat.Comm.local(4)
+    asked = []
+    decs = []
+    for r in range(4):
+        def loader(lo, hi, r=r):
+            asked.append((r, lo, hi))
+            return x[np.arange(lo, hi) % n0]
+        decs.append(sharded.FrontEndShardedDecoder(ctx, comms[r], fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=240,
+                                                   raw_loader=loader))
+    assert [a[0] for a in asked] == [0, 1, 2, 3]
+    halo = fe.halo()
+    for (r, lo, hi), d in zip(asked, decs):
+        share = (d.layout.in_hi - d.layout.in_lo) * (fs // 22050)       # the rank's rows at 22 050 Hz, in raw frames
+        assert hi - lo <= share + 2 * halo + 64 and lo < hi
+    assert asked[0][1] < 0 and asked[-1][2] > n0                         # the ends wrap (the FFT resampler behind is circular)
+    for d in decs:
+        d.close()
+    for c in comms:
+        c.close()

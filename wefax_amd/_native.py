@@ -31,8 +31,9 @@ SYMBOLS = [
     "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_resample_rational", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_info", "wfx_comm_destroy",
-    "wfx_shard_layout_query", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
+    "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
     "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
+    "wfx_synth_frames", "wfx_synth_capture",
     "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
     "wfx_profile_kernel_count", "wfx_profile_kernel_name", "wfx_profile_get",
 ]
@@ -76,6 +77,23 @@ class DecodeInfo(C.Structure):
         ("peak_pos", C.c_int64 * (WFX_MAX_PEAKS + 1)),
         ("first_pos", C.c_int64 * (WFX_MAX_PEAKS + 1)),
         ("phasing", C.c_int64 * (WFX_MAX_PEAKS + 1)),
+    ]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_double),
+        ("lines_per_minute", C.c_int),
+        ("ioc", C.c_int),
+        ("start_tone_s", C.c_double),
+        ("phasing_lines", C.c_int),
+        ("image_lines", C.c_int),
+        ("stop_tone_s", C.c_double),
+        ("black_tail_s", C.c_double),
+        ("amplitude", C.c_double),
+        ("noise", C.c_double),
+        ("seed", C.c_uint64),
+        ("iq", C.c_int),
     ]
 
 
@@ -167,6 +185,7 @@ def load():
     lib.wfx_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     lib.wfx_comm_destroy.argtypes = [vp]
     lib.wfx_shard_layout_query.argtypes = [C.POINTER(DecodeParams), i, i, C.POINTER(ShardLayout)]
+    lib.wfx_shard_dry_run.argtypes = [C.POINTER(DecodeParams), i]
     lib.wfx_shard_create.argtypes = [vp, vp, C.POINTER(DecodeParams), C.POINTER(vp)]
     lib.wfx_shard_upload.argtypes = [vp, vp]
     lib.wfx_shard_attach.argtypes = [vp, vp]
@@ -176,6 +195,9 @@ def load():
     lib.wfx_shard_result.argtypes = [vp, C.POINTER(DecodeInfo)]
     lib.wfx_shard_fetch.argtypes = [vp, i, vp, sz]
     lib.wfx_shard_destroy.argtypes = [vp]
+    lib.wfx_synth_frames.argtypes = [C.POINTER(SynthParams)]
+    lib.wfx_synth_frames.restype = C.c_uint64
+    lib.wfx_synth_capture.argtypes = [vp, C.POINTER(SynthParams), C.c_uint64, C.c_uint64, vp]
     lib.wfx_timer_start.argtypes = [vp]
     lib.wfx_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.wfx_profile_enable.argtypes = [vp, i]
@@ -186,7 +208,7 @@ def load():
     lib.wfx_profile_get.argtypes = [vp, i, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("wfx_device_count", "wfx_profile_kernel_count"):
+        if fn.restype is C.c_int and name not in ("wfx_device_count", "wfx_profile_kernel_count", "wfx_synth_frames"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -471,6 +493,10 @@ class Context:
         self._check(self.lib.wfx_d_image_rows(self.h, C.c_void_p(d_ptr), n, g0, start, width, h_total, y0, rows,
                                               C.c_void_p(img_ptr)))
 
+    def synth_capture(self, params: "SynthParams", lo: int, hi: int, out_ptr: int):
+        """Frames [lo, hi) of the synthetic transmission described by ``params`` into device memory (asynchronous)."""
+        self._check(self.lib.wfx_synth_capture(self.h, C.byref(params), lo, hi, C.c_void_p(out_ptr)))
+
     def sync(self):
         self._check(self.lib.wfx_sync(self.h))
 
@@ -512,6 +538,14 @@ def shard_layout(params: DecodeParams, world: int, rank: int) -> ShardLayout:
     if rc != 0:
         raise _global_error(lib, rc)
     return out
+
+
+def shard_dry_run(params: DecodeParams, world: int):
+    """Host-only consistency check of every rank's exchange lists for ``world`` ranks; raises NativeError with the reason."""
+    lib = load()
+    rc = lib.wfx_shard_dry_run(C.byref(params), world)
+    if rc != 0:
+        raise _global_error(lib, rc)
 
 
 def comm_unique_id() -> bytes:

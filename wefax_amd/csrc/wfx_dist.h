@@ -44,8 +44,15 @@ struct wfx_dist_piece {      // one 2-D block of a packing / unpacking copy (dev
 class wfx_dist {
   public:
     // buffers are owned by this object; `halo_before` / `halo_after`: points delivered around the own rows by the inverse
-    int init(wfx_ctx *ctx, const wfx_dist_geom &g, long long L, int elem_bytes_in, int halo_before, int halo_after);
+    // dry: plan only -- no device memory, no kernels; buffers get fake base addresses `dry_base + k * 2^36` so that exchange
+    // lists and piece descriptors can be built and checked on a machine without a GPU (wfx_shard_dry_run)
+    int init(wfx_ctx *ctx, const wfx_dist_geom &g, long long L, int elem_bytes_in, int halo_before, int halo_after, bool dry = false,
+             unsigned long long dry_base = 0);
     void release();
+    // (for the dry run) exchange e in 1..4: its messages and its copy pieces; the buffers as (base, bytes) pairs
+    const std::vector<wfx_xfer> &xfers(int e) const { return e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : x4; }
+    const std::vector<wfx_dist_piece> &pieces(int e) const { return e == 1 ? p1 : e == 2 ? p2 : e == 3 ? p3 : p4; }
+    void buffers(std::vector<std::pair<unsigned long long, unsigned long long>> &out) const;
     // rows_in: this rank's rows of the forward input; rows_out: [halo_before + nr M + halo_after] points delivered by the
     // inverse; inv_in: slab buffer (0 / 1) the inverse starts from.  Call once the buffers exist, before the first run.
     int bind(const void *rows_in, cplx *rows_out, int inv_in);
@@ -73,6 +80,7 @@ class wfx_dist {
     wfx_ctx *ctx = nullptr;
     wfx_dist_geom g;
     int es_in = 16, hb = 0, ha = 0;
+    bool dry_ = false;
     std::vector<std::pair<int, int>> sub;          // radix pairs of M, ascending
     mr_pass_desc d_first{}, d_last{};
     std::vector<mr_pass_desc> d_fwd, d_inv;

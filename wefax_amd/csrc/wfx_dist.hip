@@ -159,19 +159,27 @@ int wfx_dist_scatter_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npiec
 }
 
 // ---- one distributed transform length -------------------------------------------------------------------
+void wfx_dist::buffers(std::vector<std::pair<unsigned long long, unsigned long long>> &out) const
+{
+    const wfx_devbuf *bufs[] = {&b_pack, &b_recv, &b_y, &b_a, &b_a2};
+    for (const wfx_devbuf *b : bufs) out.emplace_back((unsigned long long)b->p, (unsigned long long)b->cap);
+}
+
 void wfx_dist::release()
 {
     wfx_devbuf *bufs[] = {&tables, &b_pack, &b_recv, &b_y, &b_a, &b_a2, &b_desc};
     for (wfx_devbuf *b : bufs) {
-        if (b->p) (void)hipFree(b->p);
+        if (b->p && !dry_) (void)hipFree(b->p);
         b->p = nullptr;
         b->cap = 0;
     }
 }
 
-int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int elem_bytes_in, int halo_before, int halo_after)
+int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int elem_bytes_in, int halo_before, int halo_after, bool dry,
+                   unsigned long long dry_base)
 {
     ctx = ctx_;
+    dry_ = dry;
     g = g_;
     L = L_;
     es_in = elem_bytes_in;
@@ -254,6 +262,19 @@ int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int ele
     d_last.Ltw = L;
     tw_last = off;
     off += wfx_mr_table_elems(L);
+    const size_t colsz = (size_t)R1 * w, rowsz = (size_t)nr * M, slab = (size_t)M * B;
+    if (dry) {
+        wfx_devbuf *bufs[] = {&b_pack, &b_recv, &b_y, &b_a, &b_a2};
+        const size_t caps[] = {std::max(colsz, rowsz) * sizeof(cplx) + 64, std::max(colsz, rowsz) * sizeof(cplx) + 64, colsz * sizeof(cplx) + 64,
+                               slab * sizeof(cplx) + 64, slab * sizeof(cplx) + 64};
+        for (int i = 0; i < 5; ++i) {
+            bufs[i]->p = (void *)(dry_base + ((unsigned long long)(i + 1) << 36));
+            bufs[i]->cap = caps[i];
+        }
+        last_rows_in = nullptr;
+        last_rows_out = nullptr;
+        return 0;
+    }
     WFX_TRY(wfx_reserve(ctx, tables, off * sizeof(cplx)));
     cplx *tb = (cplx *)tables.p;
     {
@@ -272,7 +293,6 @@ int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int ele
         WFX_TRY(wfx_mr_fill_table(ctx, tb + tw_last, L));
     }
     // ---- buffers ----
-    const size_t colsz = (size_t)R1 * w, rowsz = (size_t)nr * M, slab = (size_t)M * B;
     WFX_TRY(wfx_reserve(ctx, b_pack, std::max(colsz, rowsz) * sizeof(cplx) + 64));
     WFX_TRY(wfx_reserve(ctx, b_recv, std::max(colsz, rowsz) * sizeof(cplx) + 64));
     WFX_TRY(wfx_reserve(ctx, b_y, colsz * sizeof(cplx) + 64));
@@ -470,7 +490,7 @@ int wfx_dist::bind(const void *rows_in, cplx *rows_out, int inv_in)
     inv_start = inv_in ? (cplx *)b_a2.p : (cplx *)b_a.p;
     inv_result = end ? (cplx *)b_a2.p : (cplx *)b_a.p;
     build_lists(rows_in, rows_out);
-    return upload_pieces();
+    return dry_ ? 0 : upload_pieces();
 }
 
 int wfx_dist::fwd_pack_exchange(wfx_comm *c, const void *rows_in)

@@ -261,6 +261,126 @@ static int run_phase(wfx_shard *sh, int ph)
     }
 }
 
+// ---- plan check without a GPU -----------------------------------------------------------------------------
+// Builds every rank's exchange lists and copy descriptors of one distributed transform with fake buffer addresses and checks
+// what a real run relies on: the k-th message rank a sends to rank b has the size of the k-th message b expects from a; what a
+// rank receives lands inside its buffers, without overlaps, and adds up to the layout's size; every copy stays inside its
+// source and destination.  (The in-process communicator makes the first check at run time; this one also covers sizes no
+// test GPU holds, e.g. the 60-minute captures at 8 ranks.)
+struct dry_region {
+    unsigned long long lo, hi;
+};
+
+static bool dry_inside(const std::vector<dry_region> &regs, unsigned long long lo, unsigned long long hi)
+{
+    for (const dry_region &r : regs)
+        if (lo >= r.lo && hi <= r.hi) return true;
+    return false;
+}
+
+static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p, long long L, int es, int hb, int ha, bool fwd, bool inv, const char *name)
+{
+    const int W = pl0.world;
+    std::vector<wfx_dist> d(W);
+    std::vector<std::vector<dry_region>> regs(W);
+    std::vector<unsigned long long> rin(W), rout(W);
+    int rc = 0;
+    for (int r = 0; r < W && rc == 0; ++r) {
+        wfx_dist_geom g;
+        if (!wfx_dist_make_geom(g, W, r, pl0.g.ra1, pl0.g.rb1)) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "dry run: geometry");
+        const unsigned long long base = (unsigned long long)(r + 1) << 44;
+        rc = d[r].init(nullptr, g, L, es, hb, ha, true, base);
+        if (rc) break;
+        std::vector<std::pair<unsigned long long, unsigned long long>> b;
+        d[r].buffers(b);
+        for (auto &x : b) regs[r].push_back({x.first, x.first + x.second});
+        rin[r] = base + (6ull << 36);
+        rout[r] = base + (7ull << 36);
+        regs[r].push_back({rin[r], rin[r] + (unsigned long long)d[r].nr * d[r].M * es});
+        regs[r].push_back({rout[r], rout[r] + (unsigned long long)(hb + (long long)d[r].nr * d[r].M + ha) * 16});
+        rc = d[r].bind(fwd ? (const void *)rin[r] : nullptr, inv ? (cplx *)rout[r] : nullptr, d[r].fwd_result_index());
+    }
+    for (int e = 1; e <= 4 && rc == 0; ++e) {
+        if ((e <= 2 && !fwd) || (e >= 3 && !inv)) continue;
+        const int pes = e == 1 ? es : 16;
+        for (int src = 0; src < W && rc == 0; ++src)
+            for (int dst = 0; dst < W && rc == 0; ++dst) {
+                std::vector<size_t> snd, rcv;
+                for (const wfx_xfer &x : d[src].xfers(e))
+                    if (x.peer == dst && x.send_bytes) snd.push_back(x.send_bytes);
+                for (const wfx_xfer &x : d[dst].xfers(e))
+                    if (x.peer == src && x.recv_bytes) rcv.push_back(x.recv_bytes);
+                if (snd != rcv)
+                    rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s, exchange %d, world %d): rank %d -> rank %d message sizes do not match", name, e, W, src, dst);
+            }
+        for (int r = 0; r < W && rc == 0; ++r) {
+            std::vector<dry_region> got;
+            unsigned long long total = 0;
+            for (const wfx_xfer &x : d[r].xfers(e)) {
+                if (x.send_bytes && !dry_inside(regs[r], (unsigned long long)x.send, (unsigned long long)x.send + x.send_bytes))
+                    rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s, exchange %d): rank %d sends from outside its buffers", name, e, r);
+                if (!x.recv_bytes) continue;
+                const unsigned long long lo = (unsigned long long)x.recv, hi = lo + x.recv_bytes;
+                if (!dry_inside(regs[r], lo, hi)) rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s, exchange %d): rank %d receives outside its buffers", name, e, r);
+                for (const dry_region &o : got)
+                    if (lo < o.hi && o.lo < hi) rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s, exchange %d): rank %d receives twice into the same bytes", name, e, r);
+                got.push_back({lo, hi});
+                total += x.recv_bytes;
+            }
+            const unsigned long long R1 = pl0.g.R1;
+            const unsigned long long want = e == 1 ? R1 * d[r].w * (unsigned long long)es : e == 2 ? (unsigned long long)d[r].M * d[r].B * 16
+                                          : e == 3 ? R1 * d[r].w * 16ull : ((unsigned long long)d[r].nr * d[r].M + hb + ha) * 16ull;
+            if (rc == 0 && total != want)
+                rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s, exchange %d): rank %d receives %llu bytes, its layout holds %llu", name, e, r, total, want);
+            for (const wfx_dist_piece &q : d[r].pieces(e)) {
+                if (rc) break;
+                const bool kmap = e == 2 || e == 3;
+                // extents: copy2d rows x cols with row strides; gather / scatter by k1 touch the whole [rows][R1] / [R1][rows] array
+                unsigned long long slo = q.src, shi, dlo = q.dst, dhi;
+                if (!kmap) {
+                    shi = slo + ((unsigned long long)(q.rows - 1) * q.src_rs + q.cols) * pes;
+                    dhi = dlo + ((unsigned long long)(q.rows - 1) * q.dst_rs + q.cols) * pes;
+                } else if (e == 2) {
+                    shi = slo + (unsigned long long)q.rows * q.src_rs * 16;
+                    dhi = dlo + (unsigned long long)q.rows * q.B * 16;
+                } else {
+                    shi = slo + (unsigned long long)q.rows * q.B * 16;
+                    dhi = dlo + (unsigned long long)R1 * q.dst_rs * 16;
+                }
+                if (q.rows > 0 && q.cols > 0 && (!dry_inside(regs[r], slo, shi) || !dry_inside(regs[r], dlo, dhi)))
+                    rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s, exchange %d): a copy of rank %d leaves its buffers", name, e, r);
+            }
+        }
+    }
+    for (int r = 0; r < W; ++r) d[r].release();
+    (void)p;
+    return rc;
+}
+
+extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
+{
+    shard_plan pl;
+    WFX_TRY(make_plan(nullptr, p, world, 0, pl));
+    // every rank's own layout must tile the capture
+    uint64_t next = 0, next_in = 0;
+    for (int r = 0; r < world; ++r) {
+        shard_plan q;
+        WFX_TRY(make_plan(nullptr, p, world, r, q));
+        if (q.own_lo != next) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: rank %d starts at sample %llu, expected %llu", r, (unsigned long long)q.own_lo, (unsigned long long)next);
+        next = q.own_hi;
+        if (q.resample) {
+            if (q.in_lo != next_in) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: rank %d's input starts at frame %llu, expected %llu", r, (unsigned long long)q.in_lo, (unsigned long long)next_in);
+            next_in = q.in_hi;
+        }
+    }
+    if (next != p->n || (pl.resample && next_in != p->n0)) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: the ranks' ranges do not cover the capture");
+    if (pl.resample) {
+        WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward"));
+        WFX_TRY(dry_check_transform(pl, p, pl.K, 16, SH_HALO / 2, SH_HALO / 2, false, true, "resample inverse"));
+    }
+    return dry_check_transform(pl, p, pl.K, 16, SH_VHALO, SH_VHALO, true, true, "hilbert");
+}
+
 #define CHECK_SH(sh)                                                              \
     do {                                                                          \
         if (!(sh)) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null shard");       \

@@ -34,13 +34,14 @@ _MAGIC = b"WFXUID01"
 
 
 # ---- RCCL unique id over a loopback socket ---------------------------------------------------------------------
-def bootstrap_unique_id(rank: int, world: int, addr: str = "127.0.0.1", port: int = 29611, timeout: float = 120.0) -> bytes:
+def bootstrap_unique_id(rank: int, world: int, addr: str = "127.0.0.1", port: int = 29611, timeout: float = 120.0,
+                        make_id=nat.comm_unique_id) -> bytes:
     """Rank 0 creates the RCCL unique id and serves it to the other ``world - 1`` ranks; they fetch it.
     Plain TCP on ``addr:port`` (stdlib only); the peers retry until rank 0 listens."""
     if world == 1:
-        return nat.comm_unique_id()
+        return make_id()
     if rank == 0:
-        uid = nat.comm_unique_id()
+        uid = make_id()
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         srv.bind((addr, port))
@@ -163,7 +164,7 @@ def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute:
                     want=("image", "stream", "envelope", "audio"), make_decoder=None):
     """Every rank of a ``world``-rank sharded decode in this process, on one GPU, phase by phase (local communicator:
     a collective completes when the last rank has posted its part).  Returns the root's results plus the per-rank
-    blocks concatenated, for comparison with the single-GPU path and the oracle."""
+    blocks concatenated, for comparison with the single-GPU path (tests)."""
     data = np.asarray(data)
     comms = nat.Comm.local(world)
     ctxs = [nat.Context(device) for _ in range(world)]
@@ -174,6 +175,9 @@ def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute:
                 decs.append(make_decoder(ctxs[r], comms[r]))
             else:
                 decs.append(ShardedDecoder(ctxs[r], comms[r], data.shape[0], sample_rate, lines_per_minute, capture_kind(data), notch, data=data))
+        for d in decs:
+            if hasattr(d, "front_end"):
+                d.front_end()
         nph = decs[0].shard.phases
         for ph in range(nph):
             for d in decs:
