@@ -230,6 +230,7 @@ def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds
     img1, st1 = dec.fetch("image"), dec.fetch("digitalized")
     dec.close()
     assert info.start_frame == ref["start_frame"]
+    peaks1 = [int(info.peak_pos[k]) for k in range(info.npeaks)]
     for name, got, want, mx, frac in (("stream", st1, ref["digitalized"], STREAM_MAX, STREAM_NE_FRAC), ("image", img1, ref["image"], IMAGE_MAX, None)):
         d = np.abs(got.astype(np.int16) - want.astype(np.int16))
         print(f"fs={fs}: {name} max|d|={d.max()} differing={np.count_nonzero(d)} of {d.size}, >1: {np.count_nonzero(d > 1)}")
@@ -241,7 +242,8 @@ def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds
     for world in (1, 2, 3, 8):
         mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, x, lines_per_minute=lpm)      # noqa: E731
         r = sharded.decode_emulated(x, fs, world, lpm, make_decoder=mk)
-        assert r["sync"]["start_frame"] == ref["start_frame"] and r["sync"]["peaks"] == [int(v) for v in ref["peaks"]]
+        # (a peak of the reference may sit elsewhere where the stream differs by one grey level; the group that fixes start_frame does not)
+        assert r["sync"]["start_frame"] == ref["start_frame"] and r["sync"]["peaks"] == peaks1
         assert np.array_equal(r["digitalized"], st1) and np.array_equal(r["image"], img1)
         assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
         if first is None:
@@ -272,7 +274,7 @@ def test_each_rank_loads_only_its_slice_of_the_raw_stream(ctx):
     assert [a[0] for a in asked] == [0, 1, 2, 3]
     halo = fe.halo()
     for (r, lo, hi), d in zip(asked, decs):
-        share = (d.layout.in_hi - d.layout.in_lo) * (fs // 22050)       # the rank's rows at 22 050 Hz, in raw frames
+        share = int(np.ceil((d.layout.in_hi - d.layout.in_lo) * fs / 22050))       # the rank's rows at 22 050 Hz, in raw frames
         assert hi - lo <= share + 2 * halo + 64 and lo < hi
     assert asked[0][1] < 0 and asked[-1][2] > n0                         # the ends wrap (the FFT resampler behind is circular)
     for d in decs:

@@ -143,8 +143,8 @@ def test_sharded_exact_decode_equals_the_oracle_for_every_world_size(case):
         assert np.array_equal(r["image"], ref["image"]), f"{case} world {world}: image differs"
         assert len(set(r["lows"])) == 1 and len(set(r["highs"])) == 1
         assert abs(r["low"] - ref["low"]) <= 1e-9 * abs(ref["low"]) and abs(r["high"] - ref["high"]) <= 1e-9 * abs(ref["high"])
-        scale = np.max(np.abs(ref["envelope"]))
-        assert np.max(np.abs(r["envelope"] - ref["envelope"])) <= 1e-9 * scale
+        scale = np.max(np.abs(ref["demod"]))
+        assert np.max(np.abs(r["envelope"] - ref["demod"])) <= 1e-9 * scale
         assert np.max(np.abs(r["audio"] - ref["audio"])) <= 1e-9 * np.max(np.abs(ref["audio"]))
         if first is None:
             first = r
@@ -210,30 +210,38 @@ def test_a_bad_unique_id_is_a_comm_error_not_a_crash():
 
 @pytest.mark.gpu
 def test_candidate_overflow_of_the_percentile_select_is_reported_and_recovered():
-    """A capture with long digital silence puts more equal keys into one bin than travel in the all-gather: the decode says
-    so (on every rank alike), raises its capacity, and the next decode of the same shard is exact."""
-    x = synth.synth_capture(11025.0, noise=0.05, seed=9, **KW130).copy()
-    x[200000:500000] = 0                       # 300 000 identical envelope values (zero) -- 21 % of the capture
+    """A constant capture has ONE envelope value: every key lands in the same bin and the candidate lists of the select
+    outgrow what travels in the all-gather.  The decode says so -- on every rank alike, so no rank runs ahead --, raises the
+    capacity, and a later decode of the same shard completes: low == high, and the quantiser reports the NaNs for which the
+    reference raises ValueError (int(nan), wefax.py:216)."""
+    x = np.full(1433250, 1200, dtype=np.int16)
     ref = _oracle(x, 11025, 120)
+    assert isinstance(ref.get("exception"), ValueError)
     comms = nat.Comm.local(2)
     ctxs = [nat.Context(0) for _ in range(2)]
     decs = [sharded.ShardedDecoder(ctxs[r], comms[r], x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x) for r in range(2)]
-
-    def run_all():
+    overflows = 0
+    infos = None
+    for attempt in range(5):
         for ph in range(decs[0].shard.phases):
             for d in decs:
                 d.shard.phase(ph)
-
-    run_all()
-    for d in decs:
-        with pytest.raises(nat.NativeError) as e:
-            d.result()
-        assert "overflow" in str(e.value)
-    run_all()
-    info = decs[0].result()
-    decs[1].result()
-    assert np.array_equal(decs[0].fetch("stream"), ref["digitalized"])
-    assert info.start_frame == ref["start_frame"] and np.array_equal(decs[0].fetch("image"), ref["image"])
+        errs = []
+        got = []
+        for d in decs:
+            try:
+                got.append(d.result())
+            except nat.NativeError as e:
+                errs.append(str(e))
+        assert len(errs) in (0, 2)                       # both ranks or neither
+        if not errs:
+            infos = got
+            break
+        assert all("overflow" in e for e in errs)
+        overflows += 1
+    assert overflows >= 1 and infos is not None
+    assert infos[0].low == infos[0].high == infos[1].low == infos[1].high
+    assert infos[0].nan_count > 1000000                  # nearly every sample equals the one percentile value: 0 / 0
     for d in decs:
         d.close()
     for c in comms:

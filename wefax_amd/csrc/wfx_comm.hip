@@ -326,8 +326,10 @@ int wfx_comm_destroy(wfx_comm *comm)
 {
     if (!comm) return 0;
     if (comm->nccl) {
-        (void)hipSetDevice(comm->device);
-        if (g_rccl.CommDestroy) g_rccl.CommDestroy(comm->nccl);
+        int ndev = 0;
+        // (a communicator destroyed after the HIP runtime has shut down -- a garbage collector at interpreter exit -- is left alone)
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > comm->device && hipSetDevice(comm->device) == hipSuccess && g_rccl.CommDestroy)
+            g_rccl.CommDestroy(comm->nccl);
     }
     if (comm->group && --comm->group->refs == 0) {
         if (comm->group->scratch.p) (void)hipFree(comm->group->scratch.p);

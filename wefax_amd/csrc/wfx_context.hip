@@ -5,7 +5,19 @@
 
 #include "wfx_internal.h"
 
+#include <mutex>
+#include <set>
+
 static thread_local std::string g_err;
+
+// live contexts: objects that outlive their context (a shard destroyed late by a garbage collector) must not touch it
+static std::set<const wfx_ctx *> g_live;
+static std::mutex g_live_mutex;
+bool wfx_ctx_alive(const wfx_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    return g_live.count(ctx) != 0;
+}
 
 void wfx_set_global_error(const char *msg) { g_err = msg ? msg : ""; }
 
@@ -99,12 +111,20 @@ wfx_ctx *wfx_create(int device, int flags)
     }
     memset(ctx->h_info, 0, sizeof(wfx_decode_info));
     memset(ctx->h_scal, 0, sizeof(wfx_dev_scalars));
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live.insert(ctx);
+    }
     return ctx;
 }
 
 void wfx_destroy(wfx_ctx *ctx)
 {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live.erase(ctx);
+    }
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     wfx_devbuf *bufs[] = {&ctx->b_in, &ctx->b_x, &ctx->b_audio, &ctx->b_work, &ctx->b_work2, &ctx->b_envraw,

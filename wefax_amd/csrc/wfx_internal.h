@@ -137,6 +137,7 @@ void wfx_set_global_error(const char *msg);
     } while (0)
 
 int wfx_reserve(wfx_ctx *ctx, wfx_devbuf &b, size_t bytes);
+bool wfx_ctx_alive(const wfx_ctx *ctx);      // false once wfx_destroy has run on it
 
 // ---- profiling-aware launch ---------------------------------------------------
 void wfx_prof_begin(wfx_ctx *ctx, int kid);

@@ -381,10 +381,11 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
     return dry_check_transform(pl, p, pl.K, 16, SH_VHALO, SH_VHALO, true, true, "hilbert");
 }
 
-#define CHECK_SH(sh)                                                              \
-    do {                                                                          \
-        if (!(sh)) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null shard");       \
-        (void)hipSetDevice((sh)->ctx->device);                                    \
+#define CHECK_SH(sh)                                                                                              \
+    do {                                                                                                          \
+        if (!(sh)) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null shard");                                       \
+        if (!wfx_ctx_alive((sh)->ctx)) return wfx_fail(nullptr, WFX_ERR_STATE, "the shard's context was destroyed"); \
+        (void)hipSetDevice((sh)->ctx->device);                                                                    \
     } while (0)
 
 extern "C" {
@@ -566,6 +567,10 @@ int wfx_shard_fetch(wfx_shard *sh, int buffer_id, void *host_out, size_t bytes)
 int wfx_shard_destroy(wfx_shard *sh)
 {
     if (!sh) return 0;
+    if (!wfx_ctx_alive(sh->ctx)) {          // its context went first: the device memory went with the process's teardown or leaks
+        delete sh;
+        return 0;
+    }
     (void)hipSetDevice(sh->ctx->device);
     (void)hipStreamSynchronize(sh->ctx->stream);
     sh->dF.release();
