@@ -3,37 +3,40 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the whole path (ingest -> notch -> analytic envelope ->
-median -> percentiles -> quantise -> sync search -> lines -> 4x bicubic image) over
-one synthetic capture that is already resident in HBM.  At N = 1 the workload is
-BASELINE.json configs[1]: a synthetic 10-minute 11 025 Hz mono capture
-(7 166 250 int16 samples, 120 LPM).  At N > 1 every rank decodes its own capture of
-that shape (the path shards by capture with no data-path collective; only the
-finished images are gathered to rank 0 with one RCCL gather per step), so the
-scaling is weak.  Rank 0 prints ONE JSON line.
+A step is one pass of the whole path (ingest -> notch -> analytic envelope -> median -> percentiles -> quantise -> sync
+search -> lines -> 4x bicubic image) over one synthetic capture that is already resident in HBM.
 
-value = input samples of all ranks / max-over-ranks wall time of the K timed steps.
-roofline = the dominant kernel's algorithmic bytes per launch / its average launch
-duration, both measured with HIP events on the library's stream in a second pass of
-K steps (the event pairs would otherwise sit inside the timed region).
-cpu_baseline = the oracle (oracle/wefax_oracle.py, a NumPy/C port of wefax.py) timed
-on this host, one process, one thread, on the same capture.
+The line rank 0 prints (ONE JSON line):
+  * `value` -- BASELINE.json configs[1]: a synthetic 10-minute 11 025 Hz mono capture (7 166 250 int16 samples, 120 LPM).
+    At N > 1 every rank decodes its own capture of that shape: captures are independent objects, so this metric shards
+    with no data-path collective ("scaling": "weak").  value = samples of all ranks / max-over-ranks time of the K steps.
+  * `c4_strong` -- BASELINE.json configs[3], the curve the north star asks for: ONE 60-minute 1.536 MS/s int16 IQ stream
+    (5.53 G frames, 22 GB, synthesised in HBM) decoded by all N ranks together -- each rank runs the time-domain front end on
+    its 1/N of the stream, then the sharded exact path (distributed FFT resample + Hilbert over RCCL, csrc/wfx_dist.hip);
+    ms per decode, frames/s, RCCL ranks observed, the one-GPU time measured in the same run and the efficiency against it.
+  * `roofline` of the dominant kernel (HIP events on the library's stream, second pass of K steps) and `cpu_baseline`
+    (the oracle, a NumPy/C port of wefax.py, one thread on this host) -- both at N = 1 only for the CPU leg.
+
+With `--gpus N` and no WORLD_SIZE in the environment this process only SPAWNS the N ranks (fresh child processes, one per
+GPU; the parent never touches a GPU) and relays rank 0's line.  Under `python -m torch.distributed.run` the ranks come
+from the environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  No PyTorch is imported either way: the communicator is
+RCCL bound by libwefax_hip.so itself; the 128-byte unique id travels over a loopback TCP socket next to MASTER_PORT.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+IQ_FS = 1536000
 
 
 def parse():
@@ -41,64 +44,49 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["fft", "fir"], default="fft",
-                    help="analytic-signal operator: exact DFT (default) or 4095-tap FIR")
     ap.add_argument("--noise", type=float, default=0.05, help="AWGN sigma in full-scale units")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-cpu-loops", action="store_true",
-                    help="skip the second CPU timing that keeps the reference's per-sample Python loops (about 25 s)")
-    ap.add_argument("--short", action="store_true", help="60-line capture (debugging only)")
+                    help="skip the second CPU timing that keeps the reference's per-sample Python loops (about 7 s)")
+    ap.add_argument("--short", action="store_true", help="60-line capture and a 40-second IQ stream (debugging only)")
+    ap.add_argument("--workload", choices=["c2", "iq", "c3"], default="c2",
+                    help="c2 (default): BASELINE configs[1] as `value` plus the c4_strong object.  iq: only BASELINE configs[3], the "
+                         "IQ stream of --iq-seconds, as the line itself.  c3: BASELINE configs[2], the 60-minute 48 kHz capture "
+                         "(exact FFT resample included), one capture sharded over the ranks")
     ap.add_argument("--shard", action="store_true",
-                    help="sample-range sharding of ONE capture of n_gpus x 10 minutes (halo FIR path, 6 histogram "
-                         "all-reduces + 1 image gather per step) instead of one capture per GPU")
-    ap.add_argument("--workload", choices=["c2", "iq"], default="c2",
-                    help="c2: BASELINE configs[1], the 10-minute 11 025 Hz capture (default).  iq: BASELINE configs[3], ONE "
-                         "1.536 MS/s int16 IQ stream of --iq-seconds, synthesised in HBM, time-domain front end + halo-local "
-                         "path, sharded by sample range over the ranks")
+                    help="c2: decode ONE 10-minute capture with all ranks (sharded exact path) instead of one capture per rank")
     ap.add_argument("--iq-seconds", type=float, default=3600.0, help="length of the IQ stream (BASELINE: 60 minutes)")
-    ap.add_argument("--iq-rest", choices=["auto", "exact", "fir"], default="auto",
-                    help="what follows the time-domain front end: the exact fused path (one GPU only; default there) or the "
-                         "halo-local FIR-Hilbert path that shards by sample range (default for N > 1)")
+    ap.add_argument("--iq-form", choices=["auto", "fused", "sharded"], default="auto",
+                    help="one GPU: the fused exact decode behind the front end (auto) or the sharded form with one rank")
+    ap.add_argument("--no-c4", action="store_true", help="c2: leave the c4_strong object out (quick runs)")
     ap.add_argument("--batch", type=int, default=1,
                     help="captures decoded concurrently per GPU, one native context (= HIP stream) each; "
                          "BASELINE configs[4] uses 8 per GPU with mixed 120/240 LPM, IOC576/288 members")
     return ap.parse_args()
 
 
-def make_capture(seed: int, noise: float, short: bool):
-    from wefax_amd import synth
-    if short:
-        return synth.synth_capture(11025.0, noise=noise, seed=seed, phasing_lines=20, image_lines=40,
-                                   start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0)
-    return synth.config_c2(noise=noise, seed=seed)
-
-
-def cpu_baseline(x: np.ndarray, faithful: bool = False) -> dict:
-    """Time the oracle (port of wefax.py) on this host: 1 process, 1 thread."""
-    import tempfile
-    from oracle import wefax_oracle as wo
-    from wefax_amd import synth
-    with tempfile.TemporaryDirectory() as td:
-        p = os.path.join(td, "c2.wav")
-        synth.write_wav(p, 11025, x)
-        t0 = time.perf_counter()
-        r = wo.process(p, 120, want_messages=False)
-        dt = time.perf_counter() - t0
-        out = {"value": round(x.shape[0] / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1,
-               "kind": "port", "host_cpus": os.cpu_count(), "seconds": round(dt, 3),
-               "sample": f"the whole capture ({x.shape[0]} samples), one run, read from a wav file",
-               "_result": r}
-        if faithful:
-            # the same port with the reference's per-sample Python loops kept (list build, np.dot per offset, putpixel):
-            # what wefax.py itself costs, without and with its 7 s of time.sleep (BASELINE.md section 3)
-            t0 = time.perf_counter()
-            rf = wo.process(p, 120, want_messages=False, faithful_loops=True)
-            dtf = time.perf_counter() - t0
-            same = bool(np.array_equal(rf.get("image"), r.get("image")) and rf.get("start_frame") == r.get("start_frame"))
-            out["faithful_loops"] = {"value": round(x.shape[0] / dtf / 1e6, 4), "seconds": round(dtf, 2),
-                                     "value_with_reference_sleeps": round(x.shape[0] / (dtf + 7.0) / 1e6, 4),
-                                     "same_result_as_vectorised": same}
-    return out
+# ---- N ranks from one command ---------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    """`--gpus N` without a launcher: start N fresh processes (this script again, one rank each) BEFORE anything touches a
+    GPU, relay rank 0's stdout.  The parent imports nothing but the standard library."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
 
 
 class _StdoutToStderr:
@@ -121,394 +109,386 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
-def bench_sharded(args, world, rank, local_rank, use_dist, dist, torch, nat):
-    """One capture of world x 10 minutes, sharded by sample range (wefax_amd/sharded.py)."""
-    from wefax_amd import sharded, synth
-    from wefax_amd.multi import ImageExchange
-    lines = 1300 * world - 100 if not args.short else 400 * world
-    x = synth.synth_capture(11025.0, noise=args.noise, seed=0, image_lines=lines - 60, phasing_lines=60,
-                            **(dict(start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0) if args.short else {}))
-    n = int(x.shape[0])
-    ctx = nat.Context(local_rank)
-    comm = sharded.TorchComm(dist, torch, torch.device("cuda", local_rank)) if use_dist else sharded.LocalComm()
-    dec = sharded.ShardedDecoder(sharded.HipStages(ctx), x, n, world, rank, 120, 4095)
-    p = dec.plan
-    exchange = ImageExchange(dist, torch, 4 * dec.width * ((p.o1 - p.o0) // dec.width + 4),
-                             torch.device("cuda", local_rank)) if use_dist else None
+class Ranks:
+    """This process's place in the job: context on its GPU, RCCL communicator when there is more than one rank (or when
+    WFX_BENCH_FORCE_DIST=1 asks for the real transport with a single rank on a one-GPU box)."""
 
-    def step():
-        return dec.run(comm, exchange, keep_on_device=True)
+    def __init__(self, args):
+        from wefax_amd import _native as nat
+        from wefax_amd import sharded
+        self.nat = nat
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if args.gpus != self.world and self.world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        self.ctx = nat.Context(self.local_rank)
+        self.use_rccl = self.world > 1 or os.environ.get("WFX_BENCH_FORCE_DIST") == "1"
+        if self.use_rccl:
+            addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+            port = int(os.environ.get("MASTER_PORT", "29511")) + 1009      # next to the launcher's own rendezvous port
+            with _StdoutToStderr():
+                uid = sharded.bootstrap_unique_id(self.rank, self.world, addr=addr, port=port)
+                self.comm = nat.Comm.rccl(self.ctx, uid, self.world, self.rank)
+                self.comm.barrier(self.ctx)                                   # the communicator's first collective sets it up
+        else:
+            self.comm = nat.Comm.local(1)[0]
 
-    def sync_all():
-        ctx.sync()
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+    def barrier(self):
+        self.comm.barrier(self.ctx)
 
-    with _StdoutToStderr():
-        for _ in range(max(args.warmup, 1)):
-            res = step()
-        sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if rank == 0:
-        sync = res[1]
-        print(json.dumps({
-            "metric": "Msamples/s demod->pixel", "value": round(n * args.steps / dt / 1e6, 2), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 FIR / f64 elsewhere",
-            "data": "synthetic",
-            "config": {"workload": f"ONE synthetic 11.025 kHz capture of {n} samples ({world} x 10 min), 120 LPM, AWGN sigma "
-                                   f"{args.noise} FS, sharded by sample range",
-                       "hilbert": "fir4095", "start_frame": sync["start_frame"], "image": [dec.width, 4 * sync["height"]],
-                       "parallelism": f"sample-range sharding over {world} GPU(s): halo recompute, 6 histogram all-reduces, "
-                                      "1 broadcast, 1 RCCL image gather per step"},
-            "roofline": None, "cpu_baseline": None}))
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+    def max_over_ranks(self, seconds: float) -> float:
+        import numpy as np
+        return float(np.max(self.comm.allgather(self.ctx, np.array([seconds], dtype=np.float64))))
+
+    def timed(self, step, steps: int, warmup: int, sync=None) -> float:
+        """W untimed steps, then exactly K steps between barrier + device sync on both sides; max over ranks (seconds)."""
+        sync = sync or self.ctx.sync
+        with _StdoutToStderr():
+            for _ in range(warmup):
+                step()
+            sync()
+            self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        self.comm.close()
+        self.ctx.close()
 
 
-def bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat):
-    """BASELINE configs[3]: one 1.536 MS/s int16 IQ stream, sharded by sample range (strong scaling: the stream
-    is fixed, every rank owns 1/world of it plus halos)."""
-    import torch as th            # plumbing: device memory + the test-signal synthesis (wefax_amd/synth_device.py)
-    from wefax_amd import polyphase, sharded, synth_device
-    from wefax_amd.multi import ImageExchange
-    fs = 1536000
-    secs = float(args.iq_seconds)
-    kw = dict(start_tone_s=5.0, phasing_lines=60, image_lines=int((secs - 15.0) / 0.5) - 60, stop_tone_s=5.0, black_tail_s=5.0)
-    n0 = synth_device.capture_frames(float(fs), **kw)
-    exact_rest = (args.iq_rest == "exact") or (args.iq_rest == "auto" and world == 1 and not use_dist)
-    if exact_rest and (world > 1 or use_dist):
-        raise SystemExit("--iq-rest exact is a single-GPU form (the exact path is global per capture)")
-    # one GPU: the stencils stop at 22 050 Hz and the exact FFT resampler takes the last factor of two (the reference's
-    # own brick wall); several GPUs: the halo-local chain down to 11 025 Hz
-    fe = polyphase.FrontEnd(fs, stop_at_2x=exact_rest)
-    n = fe.n_out(n0) // (2 if exact_rest else 1)
-    dev = th.device("cuda", local_rank)
-    th.cuda.set_device(local_rank)
-    ctx = nat.Context(local_rank)
-    comm = sharded.TorchComm(dist, th, dev) if use_dist else sharded.LocalComm()
-    keep = {}
+def kernel_table(prof: dict, steps: int) -> dict:
+    return {k: {"launches_per_step": round(v[0] / steps, 2), "avg_us": round(1e3 * v[1] / v[0], 2), "us_per_step": round(1e3 * v[1] / steps, 1)}
+            for k, v in prof.items()}
 
-    def raw_loader(lo, hi):
-        keep["raw"] = synth_device.synth_iq_slice(th, dev, lo, hi, float(fs), noise=args.noise, seed=0, **kw)
-        th.cuda.synchronize()
-        return keep["raw"].data_ptr(), hi - lo
 
-    t_syn = time.perf_counter()
-    if exact_rest:
-        dec = sharded.FrontEndExactDecoder(ctx, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,
-                                           raw_loader=raw_loader)
-        exchange = None
-        own_out = n
-    else:
-        dec = sharded.ShardedDecoder(sharded.HipStages(ctx), None, n, world, rank, 120, 4095, frontend=fe, n_in_total=n0,
-                                     in_kind=nat.WFX_IN_I16_STEREO, raw_loader=raw_loader)
-        p = dec.plan
-        exchange = ImageExchange(dist, th, 4 * dec.width * ((p.o1 - p.o0) // dec.width + 4), dev) if use_dist else None
-        own_out = p.o1 - p.o0
-    t_syn = time.perf_counter() - t_syn
-
-    def step():
-        if exact_rest:
-            dec.run()                          # asynchronous: front end + fused exact decode, image stays in HBM
-            return None
-        return dec.run(comm, exchange, keep_on_device=True)      # the image ends resident in HBM (one rank) / gathered by RCCL
-
-    def sync_all():
-        ctx.sync()
-        if use_dist:
-            th.cuda.synchronize()
-            dist.barrier()
-            th.cuda.synchronize()
-
-    with _StdoutToStderr():
-        for _ in range(max(args.warmup, 1)):
-            res = step()
-        sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = th.tensor([dt], dtype=th.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    kernels, roofline = {}, None
+def profile_pass(ctx, step, steps: int, sync=None) -> dict:
+    """Second pass of `steps` steps with a HIP-event pair around every launch (the pairs would otherwise sit inside the timed region)."""
     ctx.profile_reset()
     ctx.profile_enable(True)
-    step()
-    sync_all()
+    for _ in range(steps):
+        step()
+    (sync or ctx.sync)()
     ctx.profile_enable(False)
-    if rank == 0:
-        prof = ctx.profile()
-        kernels = {k: {"launches_per_step": v[0], "avg_us": round(1e3 * v[1] / v[0], 2), "us_per_step": round(1e3 * v[1], 1)}
-                   for k, v in prof.items()}
-        dom = max(prof.items(), key=lambda kv: kv[1][1])
+    return ctx.profile()
+
+
+def roofline_of(prof: dict, steps: int, alg_bytes: int, ms_per_step: float, pmc_file: str | None, merge_fft=True) -> dict:
+    """achieved = algorithmic bytes of the step (input bytes + 4 output pixels per sample: what ONE launch of a
+    whole-capture kernel stands for) / the dominant kernel's average launch time."""
+    fam = dict(prof)
+    if merge_fft and "fft_pass_fwd" in fam and "fft_pass_inv" in fam:      # forward and inverse passes are one kernel template
+        f, i = fam.pop("fft_pass_fwd"), fam.pop("fft_pass_inv")
+        fam["fft_pass"] = (f[0] + i[0], f[1] + i[1])
+    dom = max(fam.items(), key=lambda kv: kv[1][1])
+    avg_s = dom[1][1] / dom[1][0] / 1e3
+    traffic = None
+    if pmc_file and os.path.exists(pmc_file):
+        try:
+            tj = json.load(open(pmc_file))
+            if dom[0] == "fft_pass":
+                parts = [tj[k]["hbm_bytes_per_launch"] for k in ("fft_pass_fwd", "fft_pass_inv") if k in tj]
+                traffic = int(sum(parts) / len(parts)) if parts else None
+            else:
+                traffic = tj.get(dom[0], {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    achieved = alg_bytes / avg_s / 1e9
+    return {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": round(dom[1][0] / steps, 2),
+            "whole_path_frac": round(alg_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+
+# ---- CPU leg ---------------------------------------------------------------------------------------------------
+def cpu_baseline(x, sample_rate: int, lpm: int, faithful: bool, what: str) -> dict:
+    """Time the oracle (port of wefax.py) on this host: 1 process, 1 thread."""
+    import tempfile
+    import numpy as np
+    from oracle import wefax_oracle as wo
+    from wefax_amd import synth
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "capture.wav")
+        synth.write_wav(p, sample_rate, x)
+        t0 = time.perf_counter()
+        r = wo.process(p, lpm, want_messages=False)
+        dt = time.perf_counter() - t0
+        out = {"value": round(x.shape[0] / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
+               "seconds": round(dt, 3), "sample": what, "_result": r}
+        if faithful:
+            # the same port with the reference's per-sample Python loops kept (list build, np.dot per offset, putpixel):
+            # what wefax.py itself costs, without and with its 7 s of time.sleep (BASELINE.md section 3)
+            t0 = time.perf_counter()
+            rf = wo.process(p, lpm, want_messages=False, faithful_loops=True)
+            dtf = time.perf_counter() - t0
+            same = bool(np.array_equal(rf.get("image"), r.get("image")) and rf.get("start_frame") == r.get("start_frame"))
+            out["faithful_loops"] = {"value": round(x.shape[0] / dtf / 1e6, 4), "seconds": round(dtf, 2),
+                                     "value_with_reference_sleeps": round(x.shape[0] / (dtf + 7.0) / 1e6, 4), "same_result_as_vectorised": same}
+    return out
+
+
+# ---- BASELINE configs[3]: the oversampled IQ stream, all ranks on ONE capture ---------------------------------------
+def iq_recipe(seconds: float):
+    if seconds < 30:
+        raise SystemExit("--iq-seconds must be at least 30")
+    return dict(start_tone_s=5.0, phasing_lines=60, image_lines=int((seconds - 15.0) / 0.5) - 60, stop_tone_s=5.0, black_tail_s=5.0)
+
+
+def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu: bool) -> dict:
+    """Strong scaling: the stream is fixed, every rank owns 1/world of it plus the FIR chain's halo."""
+    from wefax_amd import polyphase, sharded, synth_device
+    nat, ctx = rk.nat, rk.ctx
+    kw = iq_recipe(seconds)
+    sp = synth_device.synth_params(float(IQ_FS), noise=args.noise, seed=0, iq=True, **kw)
+    n0 = int(ctx.lib.wfx_synth_frames(sp))
+    fe = polyphase.FrontEnd(IQ_FS, stop_at_2x=True)
+    keep = []
+
+    def raw_loader(lo, hi):
+        ptr = synth_device.synth_slice(ctx, sp, lo, hi)
+        keep.append(ptr)
+        return ptr, hi - lo
+
+    t_syn = time.perf_counter()
+    fused = rk.world == 1 and (args.iq_form == "fused" or (args.iq_form == "auto" and not rk.use_rccl))
+    if fused:
+        dec = sharded.FrontEndExactDecoder(ctx, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120, raw_loader=raw_loader)
+        n = dec.n
+        own_in, own_out = n0, n
         ia, ib = dec.chain[0][2]
-        alg_bytes = (ib - ia) * 4 + 4 * own_out                 # SURVEY.md 8(d): N0*B_in + 4*N, this rank's share
-        avg_s = dom[1][1] / dom[1][0] / 1e3
-        traffic = None
-        pmc = os.path.join(REPO, "profiles", "pmc_traffic_iq.json")      # measured on the full 3600 s stream, one rank
-        if os.path.exists(pmc) and world == 1 and secs == 3600.0:
-            try:
-                traffic = json.load(open(pmc)).get(dom[0], {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(alg_bytes / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
-                    "launches_per_step": dom[1][0],
-                    "whole_path_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        import tempfile
-        from oracle import wefax_oracle as wo
+    else:
+        dec = sharded.FrontEndShardedDecoder(ctx, rk.comm, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,
+                                             raw_loader=raw_loader)
+        n = dec.n
+        ia, ib = dec.raw_range
+        own_in, own_out = ib - ia, int(dec.layout.own_hi - dec.layout.own_lo)
+    ctx.sync()
+    t_syn = time.perf_counter() - t_syn
+    dt = rk.timed(dec.run, steps, max(warmup, 1))
+    ms = 1e3 * dt / steps
+    prof = profile_pass(ctx, dec.run, 1)
+    info = dec.result()
+    alg_bytes = own_in * 4 + 4 * own_out                     # SURVEY.md 8(d): N0 * B_in + 4 N, this rank's share
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic_iq.json") if (rk.world == 1 and seconds == 3600.0) else None
+    out = {"workload": f"ONE synthetic 1.536 MS/s int16 IQ stream of {seconds:.0f} s (BASELINE configs[3]): {n0} IQ frames -> {n} samples at "
+                       f"11 025 Hz, 120 LPM, AWGN sigma {args.noise} FS, synthesised in HBM",
+           "n_gpus": rk.world, "ranks_rccl": rk.world if rk.comm.is_rccl else 0, "scaling": "strong",
+           "form": ("front end + fused exact decode on one GPU" if fused else
+                    f"front end on each rank's 1/{rk.world} of the stream + sharded exact path (distributed FFT resample and Hilbert: 8 transposes, "
+                    "2 histogram all-reduces, 1 candidate all-gather, 1 stream gather per decode)"),
+           "front_end": fe.describe() + " -> exact FFT resample /2",
+           "ms_per_step": round(ms, 4), "value": round(n0 / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "steps": steps,
+           "synthesis_s": round(t_syn, 2), "dtype": "f32 front end / f64 exact path",
+           "start_frame": int(info.start_frame) if rk.rank == 0 else None, "image": [int(info.width), 4 * int(info.height)] if rk.rank == 0 else None,
+           "roofline": roofline_of(prof, 1, alg_bytes, ms, pmc, merge_fft=True), "kernels": kernel_table(prof, 1)}
+    dec.close()
+    for p in keep:
+        ctx.dev_free(p)
+    # the one-GPU time of the same stream, measured in this run on rank 0, and the efficiency against it
+    if rk.world > 1:
+        one_ms = None
+        if rk.rank == 0:
+            keep2 = []
+
+            def loader2(lo, hi):
+                ptr = synth_device.synth_slice(ctx, sp, lo, hi)
+                keep2.append(ptr)
+                return ptr, hi - lo
+
+            one = sharded.FrontEndExactDecoder(ctx, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120, raw_loader=loader2)
+            for _ in range(2):
+                one.run()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one.run()
+            ctx.sync()
+            one_ms = 1e3 * (time.perf_counter() - t0) / steps
+            one.close()
+            for p in keep2:
+                ctx.dev_free(p)
+        rk.barrier()
+        if rk.rank == 0:
+            out["one_gpu_ms"] = round(one_ms, 4)
+            out["speedup_vs_one_gpu"] = round(one_ms / ms, 3)
+            out["efficiency_vs_one_gpu"] = round(one_ms / ms / rk.world, 4)
+    else:
+        out["one_gpu_ms"] = out["ms_per_step"]
+        out["speedup_vs_one_gpu"], out["efficiency_vs_one_gpu"] = 1.0, 1.0
+    if with_cpu and rk.rank == 0 and rk.world == 1:
         from wefax_amd import synth
         s_secs = 30.0
-        xs = synth.synth_capture(float(fs), noise=args.noise, seed=0, iq=True, start_tone_s=2.0, phasing_lines=20,
+        xs = synth.synth_capture(float(IQ_FS), noise=args.noise, seed=0, iq=True, start_tone_s=2.0, phasing_lines=20,
                                  image_lines=int((s_secs - 14.0) / 0.5), stop_tone_s=1.0, black_tail_s=1.0)
-        with tempfile.TemporaryDirectory() as td:
-            path = os.path.join(td, "iq.wav")
-            synth.write_wav(path, fs, xs)
-            t1 = time.perf_counter()
-            wo.process(path, 120, want_messages=False)
-            dtc = time.perf_counter() - t1
-        cpu = {"value": round(xs.shape[0] / dtc / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
-               "host_cpus": os.cpu_count(), "seconds": round(dtc, 3),
-               "sample": f"a self-contained {s_secs:.0f} s capture of the same stream format ({xs.shape[0]} IQ frames), "
-                         "reference-faithful path (stereo merge + FFT resample), one run, read from a wav file"}
-    if rank == 0:
-        if exact_rest:
-            info = dec.result()
-            sync = {"start_frame": int(info.start_frame), "height": int(info.height)}
-        else:
-            sync = res[1]
-        print(json.dumps({
-            "metric": "Msamples/s demod->pixel", "value": round(n0 * args.steps / dt / 1e6, 2), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 front end / f64 elsewhere",
-            "data": "synthetic",
-            "config": {"workload": f"ONE synthetic 1.536 MS/s int16 IQ stream of {secs:.0f} s (BASELINE configs[3]): {n0} IQ frames "
-                                   f"-> {n} samples at 11 025 Hz, 120 LPM, AWGN sigma {args.noise} FS, synthesised in HBM",
-                       "front_end": fe.describe() + (" -> exact FFT resample /2" if exact_rest else ""),
-                       "hilbert": "exact (fft)" if exact_rest else "fir4095",
-                       "start_frame": sync["start_frame"],
-                       "image": [dec.width, 4 * sync["height"]], "synthesis_s": round(t_syn, 2),
-                       "parallelism": ("one GPU: time-domain front end + the exact fused path on its output" if exact_rest else
-                                       f"sample-range sharding over {world} GPU(s): halo recompute, 6 histogram all-reduces, "
-                                       "1 broadcast, 1 RCCL image gather per step")},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}))
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+        cb = cpu_baseline(xs, IQ_FS, 120, False, f"a self-contained {s_secs:.0f} s capture of the same stream format ({xs.shape[0]} IQ frames), "
+                                                 "reference-faithful path (stereo merge + FFT resample), one run, read from a wav file")
+        cb.pop("_result")
+        out["cpu_baseline"] = cb
+    return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # WFX_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (1-GPU boxes)
-    use_dist = world > 1 or os.environ.get("WFX_BENCH_FORCE_DIST") == "1"
-    dist = None
-    torch = None
-    if use_dist:
-        import torch  # plumbing only: rendezvous, barrier, the RCCL gather
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        with _StdoutToStderr():
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-            warm = torch.zeros(1, dtype=torch.float64, device="cuda")
-            dist.all_reduce(warm, op=dist.ReduceOp.MAX)     # communicator creation happens here
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    from wefax_amd import _native as nat
+# ---- BASELINE configs[2]: 60 minutes at 48 kHz (exact FFT resample) ------------------------------------------------
+def bench_c3(args, rk: Ranks) -> dict:
+    import numpy as np
+    from wefax_amd import sharded, synth, synth_device
     from wefax_amd.wefax import DecodeJob
+    nat, ctx = rk.nat, rk.ctx
+    kw = dict(image_lines=7110, black_tail_s=5.0) if not args.short else dict(start_tone_s=5.0, phasing_lines=20, image_lines=20, stop_tone_s=2.0, black_tail_s=3.0)
+    sp = synth_device.synth_params(48000.0, noise=args.noise, seed=0, iq=False, **kw)
+    n0 = int(ctx.lib.wfx_synth_frames(sp))
+    if rk.world == 1 and not rk.use_rccl:
+        ptr = synth_device.synth_slice(ctx, sp, 0, n0)
+        x = ctx.dev_download(ptr, (n0,), np.int16)                  # through the host once: DecodeJob uploads its own copy
+        ctx.dev_free(ptr)
+        job = DecodeJob(ctx, x, 48000, 120)
+        run, result, n = job.run, job.result, job.n
+        own_in, own_out = n0, n
+        form = "fused exact decode on one GPU (int16 capture read in place by the resampler's first pass)"
+        closer = lambda: None                                       # noqa: E731
+    else:
+        dec = sharded.ShardedDecoder(ctx, rk.comm, n0, 48000, 120, nat.WFX_IN_I16_MONO)
+        lay = dec.layout
+        ptr = synth_device.synth_slice(ctx, sp, int(lay.in_lo), int(lay.in_hi))
+        dec.attach(ptr)
+        run, result, n = dec.run, dec.result, dec.n
+        own_in, own_out = int(lay.in_hi - lay.in_lo), int(lay.own_hi - lay.own_lo)
+        form = f"sharded exact path over {rk.world} rank(s): distributed FFT resample and Hilbert"
+        closer = lambda: (dec.close(), ctx.dev_free(ptr))          # noqa: E731
+    dt = rk.timed(run, args.steps, max(args.warmup, 1))
+    ms = 1e3 * dt / args.steps
+    prof = profile_pass(ctx, run, args.steps)
+    info = result()
+    alg = own_in * 2 + 4 * own_out
+    out = {"metric": "Msamples/s demod->pixel", "value": round(n0 / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "n_gpus": rk.world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if rk.world > 1 else "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"synthetic 60-min 48 kHz WEFAX capture (BASELINE configs[2]): {n0} int16 mono samples -> {n} at 11 025 Hz by the exact "
+                                  f"FFT resample (wefax.py:384), 120 LPM, AWGN sigma {args.noise} FS, synthesised in HBM" if not args.short else "SHORT 48 kHz capture",
+                      "form": form, "image": [int(info.width), 4 * int(info.height)] if rk.rank == 0 else None,
+                      "start_frame": int(info.start_frame) if rk.rank == 0 else None, "ranks_rccl": rk.world if rk.comm.is_rccl else 0},
+           "roofline": roofline_of(prof, args.steps, alg, ms, os.path.join(REPO, "profiles", "pmc_traffic_c3.json")),
+           "kernels": kernel_table(prof, args.steps), "cpu_baseline": None}
+    closer()
+    if rk.rank == 0 and rk.world == 1 and not args.no_cpu:
+        xs = synth.synth_capture(48000.0, noise=args.noise, seed=0, start_tone_s=5.0, phasing_lines=60, image_lines=1060, stop_tone_s=2.0, black_tail_s=3.0)
+        cb = cpu_baseline(xs, 48000, 120, False, f"a 10-minute capture of the same format ({xs.shape[0]} samples: 1/6 of the workload), one run, read from a wav file")
+        cb.pop("_result")
+        out["cpu_baseline"] = cb
+    return out
 
-    if args.workload == "iq":
-        return bench_iq(args, world, rank, local_rank, use_dist, dist, torch, nat)
-    if args.shard:
-        return bench_sharded(args, world, rank, local_rank, use_dist, dist, torch, nat)
 
-    mode = nat.WFX_HILBERT_FFT if args.mode == "fft" else nat.WFX_HILBERT_FIR
-    x = make_capture(seed=rank, noise=args.noise, short=args.short)
-    ctx = nat.Context(local_rank)
-    job = DecodeJob(ctx, x, 11025, 120, hilbert_mode=mode, fir_taps=4095)
-    # extra members of a batch: BASELINE configs[4] recipe (mixed LPM / IOC), own context and stream each
+# ---- BASELINE configs[1]: the line itself --------------------------------------------------------------------------
+def bench_c2(args, rk: Ranks) -> dict:
+    import numpy as np
+    from wefax_amd import sharded, synth
+    from wefax_amd.wefax import DecodeJob
+    nat, ctx = rk.nat, rk.ctx
+    if args.short:
+        x = synth.synth_capture(11025.0, noise=args.noise, seed=rk.rank, start_tone_s=5.0, phasing_lines=20, image_lines=220, stop_tone_s=2.0, black_tail_s=3.0)
+    else:
+        x = synth.config_c2(noise=args.noise, seed=0 if args.shard else rk.rank)
     extra = []
-    if args.batch > 1:
-        from wefax_amd import synth
-        for b in range(1, args.batch):
-            xb, lpm_b = synth.config_c5_member(rank * args.batch + b, noise=args.noise)
-            cb = nat.Context(local_rank)
-            extra.append((cb, DecodeJob(cb, xb, 11025, lpm_b, hilbert_mode=mode, fir_taps=4095)))
-
-    img_bytes = job.width * 4 * (job.n // job.width)      # upper bound (start_frame = 0)
-    exchange = None
-    last_slot = None
-    if use_dist:
-        from wefax_amd.multi import PipelinedExchange
-        exchange = PipelinedExchange(dist, torch, img_bytes, torch.device("cuda", local_rank), ctx.stream_handle())
+    if args.shard:      # ONE capture, all ranks (exercises the sharded exact path on the 10-minute size)
+        job = sharded.ShardedDecoder(ctx, rk.comm, x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x)
+        n0 = n = job.n
+        total = n0
+    else:
+        job = DecodeJob(ctx, x, 11025, 120)
+        n0, n = job.n0, job.n
+        for b in range(1, args.batch):                  # BASELINE configs[4] members: own context and stream each
+            xb, lpm_b = synth.config_c5_member(rk.rank * args.batch + b, noise=args.noise)
+            cb = nat.Context(rk.local_rank)
+            extra.append((cb, DecodeJob(cb, xb, 11025, lpm_b)))
+        total = (n0 + sum(jb.n0 for _, jb in extra)) * rk.world
 
     def step():
-        # nothing here waits on the host: the decode is ~20 enqueued kernels, the export a device-side header + copy,
-        # and the RCCL gather of this step's image runs on its own stream while the next decode computes
-        nonlocal last_slot
-        if use_dist:
-            exchange.prepare(ctx)                                  # this step's image goes straight into its send slot
         job.run()
         for _, jb in extra:
             jb.run()
-        if use_dist:
-            last_slot = exchange.submit(ctx, nat.WFX_BUF_IMAGE)   # ONE RCCL gather per step
 
     def sync_all():
         ctx.sync()
         for cb, _ in extra:
             cb.sync()
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
 
-    with _StdoutToStderr():
-        for _ in range(max(args.warmup, 1 if use_dist else 0)):
-            step()
-        sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
+    dt = rk.timed(step, args.steps, args.warmup, sync_all)
+    ms = 1e3 * dt / args.steps
     info = job.result()
-    # second pass: per-kernel HIP-event timing (rank 0 only)
-    roofline = None
-    kernels = {}
-    if rank == 0:
-        ctx.profile_reset()
-        ctx.profile_enable(True)
-        for _ in range(args.steps):
-            job.run()
-        ctx.sync()
-        ctx.profile_enable(False)
-        prof = ctx.profile()
-        kernels = {k: {"launches_per_step": v[0] / args.steps, "avg_us": round(1e3 * v[1] / v[0], 2),
-                       "us_per_step": round(1e3 * v[1] / args.steps, 1)} for k, v in prof.items()}
-        # forward and inverse transform passes are one kernel (same template, same traffic): they count together
-        fam = dict(prof)
-        if "fft_pass_fwd" in fam and "fft_pass_inv" in fam:
-            f, i = fam.pop("fft_pass_fwd"), fam.pop("fft_pass_inv")
-            fam["fft_pass"] = (f[0] + i[0], f[1] + i[1])
-        dom = max(fam.items(), key=lambda kv: kv[1][1])
-        alg_bytes = job.n0 * 2 + 4 * job.n          # SURVEY.md 8(d): N0*B_in + 4*N
-        avg_s = dom[1][1] / dom[1][0] / 1e3
-        achieved = alg_bytes / avg_s / 1e9
-        traffic = None
-        pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                tj = json.load(open(pmc))
-                if dom[0] == "fft_pass":
-                    parts = [tj[k]["hbm_bytes_per_launch"] for k in ("fft_pass_fwd", "fft_pass_inv") if k in tj]
-                    traffic = int(sum(parts) / len(parts)) if parts else None
-                else:
-                    traffic = tj.get(dom[0], {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
-                    "launches_per_step": dom[1][0] / args.steps,
-                    "whole_path_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
-
+    out = {"metric": "Msamples/s demod->pixel", "value": round(total * args.steps / dt / 1e6, 2), "unit": "Msamples/s", "n_gpus": rk.world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+           "scaling": "strong" if args.shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": ("synthetic 10-min 11.025 kHz WEFAX capture (BASELINE configs[1]): "
+                                   f"{n0} int16 mono samples, 120 LPM, AWGN sigma {args.noise} FS" if not args.short else "SHORT debugging capture"),
+                      "captures_per_gpu": args.batch, "hilbert": "fft (exact)",
+                      "image": [int(info.width), 4 * int(info.height)] if rk.rank == 0 else None,
+                      "start_frame": int(info.start_frame) if rk.rank == 0 else None,
+                      "parallelism": (f"ONE capture sharded over {rk.world} rank(s): distributed Hilbert transform, 1 stream gather" if args.shard else
+                                      "1 capture per GPU, no data-path collective"),
+                      "ranks_rccl": rk.world if rk.comm.is_rccl else 0}}
+    if rk.rank == 0:
+        prof = profile_pass(ctx, job.run, args.steps)
+        alg_bytes = (n0 * 2 + 4 * n) // (rk.world if args.shard else 1)          # SURVEY.md 8(d): N0 * B_in + 4 N (this rank's share when sharded)
+        out["roofline"] = roofline_of(prof, args.steps, alg_bytes, ms, os.path.join(REPO, "profiles", "pmc_traffic.json"))
+        out["kernels"] = kernel_table(prof, args.steps)
     # host buffers in -> host image out (PCIe both ways, upload + run + fetch); never `value`
-    pcie = None
-    if rank == 0:
+    if rk.rank == 0 and not args.shard:
         t1 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            j2 = DecodeJob(ctx, x, 11025, 120, hilbert_mode=mode, fir_taps=4095)
+            j2 = DecodeJob(ctx, x, 11025, 120)
             j2.run()
             j2.fetch("image")
-        pcie = round(job.n0 * reps / (time.perf_counter() - t1) / 1e6, 1)
+        out["pcie_inclusive_msamples_s"] = round(n0 * reps / (time.perf_counter() - t1) / 1e6, 1)
         job = j2
-        info = job.result()
-    gathered_ok = None
-    gathered = exchange.result(last_slot) if (use_dist and last_slot is not None) else None
-    if use_dist and rank == 0 and gathered is not None:
-        own = job.fetch("image")
-        gathered_ok = bool(len(gathered) == world and
-                           np.array_equal(gathered[0][0].cpu().numpy().reshape(own.shape), own))
-
-    cpu = None
-    parity = None
-    if rank == 0 and world == 1 and not args.no_cpu:        # the CPU leg is reported at N = 1 only
-        cpu = cpu_baseline(x, faithful=not args.no_cpu_loops)
+    out["cpu_baseline"] = None
+    if rk.rank == 0 and rk.world == 1 and not args.no_cpu:        # the CPU leg is reported at N = 1 only
+        cpu = cpu_baseline(x, 11025, 120, not args.no_cpu_loops, f"the whole capture ({x.shape[0]} samples), one run, read from a wav file")
         ref = cpu.pop("_result")
         img = job.fetch("image")
-        parity = {"start_frame_equal": bool(ref.get("start_frame") == info.start_frame),
-                  "max_abs_pixel_delta": (int(np.max(np.abs(img.astype(np.int16) - ref["image"].astype(np.int16))))
-                                          if "image" in ref and img.shape == ref["image"].shape else None),
-                  "digitalized_mismatches": int(np.count_nonzero(job.fetch("digitalized") != ref["digitalized"]))}
+        stream = job.fetch("stream" if args.shard else "digitalized")
+        out["cpu_baseline"] = cpu
+        out["parity_vs_oracle"] = {"start_frame_equal": bool(ref.get("start_frame") == info.start_frame),
+                                   "max_abs_pixel_delta": (int(np.max(np.abs(img.astype(np.int16) - ref["image"].astype(np.int16))))
+                                                           if "image" in ref and img.shape == ref["image"].shape else None),
+                                   "digitalized_mismatches": int(np.count_nonzero(stream != ref["digitalized"]))}
+    if args.shard:
+        job.close()
+    for cb, _ in extra:
+        cb.close()
+    return out
 
-    if rank == 0:
-        total_samples = (job.n0 + sum(jb.n0 for _, jb in extra)) * world * args.steps
-        out = {
-            "metric": "Msamples/s demod->pixel",
-            "value": round(total_samples / dt / 1e6, 2),
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": ("synthetic 10-min 11.025 kHz WEFAX capture (BASELINE configs[1]): "
-                                    f"{job.n0} int16 mono samples, 120 LPM, AWGN sigma {args.noise} FS"
-                                    if not args.short else "SHORT debugging capture"),
-                       "captures_per_gpu": args.batch, "hilbert": args.mode,
-                       "image": [info.width, 4 * info.height], "start_frame": int(info.start_frame),
-                       "parallelism": "1 capture per GPU" + (", RCCL gather of images to rank 0" if use_dist else "")},
-            "roofline": roofline,
-            "pcie_inclusive_msamples_s": pcie,
-            "rccl_gather_checked": gathered_ok,
-            "cpu_baseline": cpu,
-            "parity_vs_oracle": parity,
-            "kernels": kernels,
-        }
-        print(json.dumps(out))
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    rk = Ranks(args)
+    try:
+        if args.workload == "iq":
+            secs = 40.0 if args.short else float(args.iq_seconds)
+            c4 = bench_iq(args, rk, secs, args.steps, args.warmup, not args.no_cpu)
+            line = {"metric": "Msamples/s demod->pixel", "value": c4["value"], "unit": "Msamples/s", "n_gpus": rk.world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": c4["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                    "dtype": c4["dtype"], "data": "synthetic", "config": {k: c4[k] for k in ("workload", "form", "front_end", "ranks_rccl", "start_frame", "image")},
+                    "roofline": c4["roofline"], "cpu_baseline": c4.get("cpu_baseline"), "kernels": c4["kernels"],
+                    "one_gpu_ms": c4.get("one_gpu_ms"), "efficiency_vs_one_gpu": c4.get("efficiency_vs_one_gpu")}
+        elif args.workload == "c3":
+            line = bench_c3(args, rk)
+        else:
+            line = bench_c2(args, rk)
+            if not args.no_c4 and not args.shard and args.batch == 1:
+                rk.barrier()
+                secs = 40.0 if args.short else float(args.iq_seconds)
+                line["c4_strong"] = bench_iq(args, rk, secs, min(args.steps, 10), 2, False)
+        if rk.rank == 0:
+            print(json.dumps(line), flush=True)
+        rk.barrier()
+    finally:
+        rk.close()
 
 
 if __name__ == "__main__":

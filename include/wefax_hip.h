@@ -274,6 +274,10 @@ int wfx_comm_create(wfx_ctx *ctx, const void *id, int world, int rank, wfx_comm 
 int wfx_comm_create_local(int world, wfx_comm **out /* [world] */);
 int wfx_comm_info(wfx_comm *comm, int *world, int *rank, int *is_rccl);
 int wfx_comm_destroy(wfx_comm *comm);
+/* for drivers: wait until every rank has arrived (and this rank's stream is idle); gather `bytes` host bytes of every rank
+ * into recv_host[world * bytes] on every rank (timings, checksums).  RCCL communicators and world 1 only. */
+int wfx_comm_barrier(wfx_comm *comm, wfx_ctx *ctx);
+int wfx_comm_allgather_host(wfx_comm *comm, wfx_ctx *ctx, const void *send_host, void *recv_host, size_t bytes);
 
 typedef struct {
     int      world, rank;

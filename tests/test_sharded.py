@@ -28,7 +28,7 @@ KW30 = dict(start_tone_s=2.0, phasing_lines=20, image_lines=30, stop_tone_s=1.0,
 # CPU
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n0,sr,kind", [(1433250, 11025, 0), (7166250, 11025, 0), (1440000, 48000, 0), (1440000, 48000, 1),
-                                       (172800000, 48000, 0), (79380000, 22050, 2), (286650, 11025, 0)])
+                                       (172800000, 48000, 0), (79380000, 22050, 2), (286650, 11025, 0), (330750, 11025, 0), (9922500, 22050, 2)])
 def test_layout_tiles_the_capture_and_the_exchange_lists_are_consistent(n0, sr, kind):
     p, meta = build_params(kind, n0, sr, 0.5)
     for world in (1, 2, 3, 4, 8):
@@ -53,7 +53,7 @@ def test_captures_that_cannot_be_sharded_are_refused_with_a_reason():
     for n0, sr, world, what in [(1433251, 11025, 2, "even"),            # odd length: the transforms are packed
                                 (2 * 1000003, 11025, 2, "13-smooth"),    # a large prime factor
                                 (4000, 11025, 8, "ranks"),               # too short for the world size
-                                (661500, 22050, 2, "13-smooth")]:        # no common first radix for both transforms
+                                (749700, 22050, 2, "13-smooth")]:        # 34 s at 22 050 Hz: a factor 17 in both transforms
         p, _ = build_params(0 if sr == 11025 else 2, n0, sr, 0.5)
         with pytest.raises(nat.NativeError) as e:
             nat.shard_layout(p, world, 0)
@@ -118,6 +118,8 @@ CASES = {
     "mono_11025_130s": lambda: (synth.synth_capture(11025.0, noise=0.05, seed=3, **KW130), 11025, 120),
     "mono_11025_240lpm": lambda: (synth.synth_capture(11025.0, noise=0.05, seed=6, lpm=240, start_tone_s=5.0, phasing_lines=40, image_lines=440,
                                                       stop_tone_s=2.0, black_tail_s=3.0), 11025, 240),
+    # 30 s at 11 025 Hz: 165 375 packed points = 225 x 735, and 735 = 3 5 7^2 has no radix-pair decomposition (per-prime passes)
+    "mono_11025_30s": lambda: (synth.synth_capture(11025.0, noise=0.05, seed=12, **KW30), 11025, 120),
     "mono_48000_30s": lambda: (synth.synth_capture(48000.0, noise=0.05, seed=4, **KW30), 48000, 120),
     "stereo_48000_30s": lambda: (synth.synth_capture(48000.0, noise=0.05, seed=5, iq=True, **KW30), 48000, 120),
     "float_11025_130s": lambda: (synth.synth_capture(11025.0, noise=0.02, seed=8, **KW130).astype(np.float64) * 0.37, 11025, 120),

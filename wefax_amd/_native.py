@@ -31,6 +31,7 @@ SYMBOLS = [
     "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_resample_rational", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_info", "wfx_comm_destroy",
+    "wfx_comm_barrier", "wfx_comm_allgather_host",
     "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
     "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
     "wfx_synth_frames", "wfx_synth_capture",
@@ -184,6 +185,8 @@ def load():
     lib.wfx_comm_create_local.argtypes = [i, C.POINTER(vp)]
     lib.wfx_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     lib.wfx_comm_destroy.argtypes = [vp]
+    lib.wfx_comm_barrier.argtypes = [vp, vp]
+    lib.wfx_comm_allgather_host.argtypes = [vp, vp, vp, vp, sz]
     lib.wfx_shard_layout_query.argtypes = [C.POINTER(DecodeParams), i, i, C.POINTER(ShardLayout)]
     lib.wfx_shard_dry_run.argtypes = [C.POINTER(DecodeParams), i]
     lib.wfx_shard_create.argtypes = [vp, vp, C.POINTER(DecodeParams), C.POINTER(vp)]
@@ -584,6 +587,17 @@ class Comm:
         if rc != 0:
             raise _global_error(lib, rc)
         return [cls(arr[r], lib) for r in range(world)]
+
+    def barrier(self, ctx: "Context"):
+        """Every rank has arrived and this rank's stream is idle."""
+        ctx._check(self.lib.wfx_comm_barrier(self.h, ctx.h))
+
+    def allgather(self, ctx: "Context", values: np.ndarray) -> np.ndarray:
+        """Small host array of every rank -> [world, ...] on every rank."""
+        a = np.ascontiguousarray(values)
+        out = np.empty((self.world,) + a.shape, dtype=a.dtype)
+        ctx._check(self.lib.wfx_comm_allgather_host(self.h, ctx.h, _ptr(a), _ptr(out), a.nbytes))
+        return out
 
     def close(self):
         if getattr(self, "h", None):

@@ -322,6 +322,37 @@ int wfx_comm_info(wfx_comm *comm, int *world, int *rank, int *is_rccl)
     return 0;
 }
 
+// ---- small host-side helpers for drivers (bench.py): a barrier and an all-gather of a few host bytes ----------
+int wfx_comm_barrier(wfx_comm *comm, wfx_ctx *ctx)
+{
+    if (!comm || !ctx) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    (void)hipSetDevice(ctx->device);
+    if (comm->group && comm->world > 1) return wfx_fail(ctx, WFX_ERR_STATE, "barrier: the ranks of a local communicator run in one thread");
+    WFX_TRY(wfx_reserve(ctx, ctx->b_seg, 4096));
+    WFX_HIP(ctx, hipMemsetAsync(ctx->b_seg.p, 0, 64, ctx->stream));
+    if (!comm->group) WFX_TRY(wfx_comm_allreduce_u32(comm, ctx, (unsigned *)ctx->b_seg.p, 1));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int wfx_comm_allgather_host(wfx_comm *comm, wfx_ctx *ctx, const void *send_host, void *recv_host, size_t bytes)
+{
+    if (!comm || !ctx || !send_host || !recv_host) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    (void)hipSetDevice(ctx->device);
+    if (comm->group && comm->world > 1) return wfx_fail(ctx, WFX_ERR_STATE, "all-gather: the ranks of a local communicator run in one thread");
+    const size_t W = (size_t)comm->world;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_seg, 4096 + bytes * (W + 1)));
+    char *snd = (char *)ctx->b_seg.p + 4096, *rcv = snd + bytes;
+    WFX_HIP(ctx, hipMemcpyAsync(snd, send_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (comm->group)
+        WFX_HIP(ctx, hipMemcpyAsync(rcv, snd, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    else
+        WFX_TRY(wfx_comm_allgather(comm, ctx, snd, rcv, bytes));
+    WFX_HIP(ctx, hipMemcpyAsync(recv_host, rcv, bytes * W, hipMemcpyDeviceToHost, ctx->stream));
+    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int wfx_comm_destroy(wfx_comm *comm)
 {
     if (!comm) return 0;

@@ -51,7 +51,8 @@ class wfx_dist {
     void release();
     // (for the dry run) exchange e in 1..4: its messages and its copy pieces; the buffers as (base, bytes) pairs
     const std::vector<wfx_xfer> &xfers(int e) const { return e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : x4; }
-    const std::vector<wfx_dist_piece> &pieces(int e) const { return e == 1 ? p1 : e == 2 ? p2 : e == 3 ? p3 : p4; }
+    const std::vector<wfx_dist_piece> &pieces(int e) const { return e == 1 ? p1 : e == 2 ? p_none : e == 3 ? p3 : p4; }
+    const std::vector<mr_qmap> &first_pass_map() const { return qmap; }
     void buffers(std::vector<std::pair<unsigned long long, unsigned long long>> &out) const;
     // rows_in: this rank's rows of the forward input; rows_out: [halo_before + nr M + halo_after] points delivered by the
     // inverse; inv_in: slab buffer (0 / 1) the inverse starts from.  Call once the buffers exist, before the first run.
@@ -81,7 +82,7 @@ class wfx_dist {
     wfx_dist_geom g;
     int es_in = 16, hb = 0, ha = 0;
     bool dry_ = false;
-    std::vector<std::pair<int, int>> sub;          // radix pairs of M, ascending
+    std::vector<wfx_mr_radix> sub;                 // passes of the M-point transforms (pairs where possible)
     mr_pass_desc d_first{}, d_last{};
     std::vector<mr_pass_desc> d_fwd, d_inv;
     std::vector<size_t> tw_fwd, tw_inv;
@@ -90,8 +91,13 @@ class wfx_dist {
     cplx *inv_result = nullptr, *inv_start = nullptr;
     // exchange lists and piece descriptors (device copies in b_desc)
     std::vector<wfx_xfer> x1, x2, x3, x4;
-    std::vector<wfx_dist_piece> p1, p2, p3, p4;
-    size_t o1 = 0, o2 = 0, o3 = 0, o4 = 0;          // offsets of the piece arrays in b_desc
+    std::vector<wfx_dist_piece> p1, p3, p4;
+    std::vector<mr_qmap> qmap;                      // E2: where the first pass stores each of its R1 outputs
+    size_t oq = 0;                                  // byte offset of the qmap table in b_desc
+    const void *pass1_src = nullptr;                // rows_in itself when there is one rank, the received columns otherwise
+    cplx *pass_last_dst = nullptr;                  // likewise for the last inverse pass
+    std::vector<wfx_dist_piece> p_none;
+    size_t o1 = 0, o3 = 0, o4 = 0;                  // offsets of the piece arrays in b_desc
     const void *last_rows_in = nullptr;
     cplx *last_rows_out = nullptr;
     void build_lists(const void *rows_in, cplx *rows_out);
@@ -100,7 +106,6 @@ class wfx_dist {
 
 // copies driven by piece descriptors (one workgroup column per piece: grid.y)
 int wfx_dist_copy2d(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, long long max_elems, int elem_bytes);
-int wfx_dist_gather_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, long long max_elems);
 int wfx_dist_scatter_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, int max_rows);
 // scipy.signal.resample's bin copy between the forward spectrum slab (packed n0 / 2 points) and the inverse's input slab (num / 2)
 int wfx_dist_resample_glue(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Z, long long n0, long long num, cplx *W);

@@ -48,21 +48,25 @@ bool wfx_dist_choose_r1(const long long *lengths, int nlen, int world, int *ra1,
     std::vector<std::pair<int, int>> cand;
     wfx_mr_all_pairs(cand);
     std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first * x.second > y.first * y.second; });
-    for (const auto &c : cand) {
-        const int R1 = c.first * c.second;
-        wfx_dist_geom g;
-        if (!wfx_dist_make_geom(g, world, 0, c.first, c.second)) continue;
-        bool ok = true;
-        for (int i = 0; i < nlen && ok; ++i) {
-            std::vector<std::pair<int, int>> sub;
-            ok = lengths[i] % R1 == 0 && lengths[i] / R1 >= 4ll * world && wfx_mr_pair_plan(lengths[i] / R1, sub);
+    // first choice: every remaining pass a register-resident radix pair; otherwise any 13-smooth cofactor (per-prime passes)
+    for (int pairs_only = 1; pairs_only >= 0; --pairs_only)
+        for (const auto &c : cand) {
+            const int R1 = c.first * c.second;
+            wfx_dist_geom g;
+            if (!wfx_dist_make_geom(g, world, 0, c.first, c.second)) continue;
+            bool ok = true;
+            for (int i = 0; i < nlen && ok; ++i) {
+                std::vector<wfx_mr_radix> sub;
+                std::vector<std::pair<int, int>> prs;
+                ok = lengths[i] % R1 == 0 && lengths[i] / R1 >= 4ll * world &&
+                     (pairs_only ? wfx_mr_pair_plan(lengths[i] / R1, prs) : wfx_mr_general_plan(lengths[i] / R1, sub));
+            }
+            if (ok) {
+                *ra1 = c.first;
+                *rb1 = c.second;
+                return true;
+            }
         }
-        if (ok) {
-            *ra1 = c.first;
-            *rb1 = c.second;
-            return true;
-        }
-    }
     return false;
 }
 
@@ -79,19 +83,6 @@ __global__ void __launch_bounds__(256) dist_copy2d_kernel(const wfx_dist_piece *
     for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
         const unsigned r = e / cols, c = e - r * cols;
         dst[(long long)r * p.dst_rs + c] = src[(long long)r * p.src_rs + c];
-    }
-}
-
-// dst[j B + kk] = src[j src_rs + k1(kk)]: the columns of the first-pass output that one rank's slab takes
-__global__ void __launch_bounds__(256) dist_gather_k_kernel(const wfx_dist_piece *__restrict__ pieces)
-{
-    const wfx_dist_piece p = pieces[blockIdx.y];
-    const cplx *__restrict__ src = (const cplx *)p.src;
-    cplx *__restrict__ dst = (cplx *)p.dst;
-    const unsigned B = (unsigned)p.B, total = (unsigned)p.rows * B;
-    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
-        const unsigned j = e / B, kk = e - j * B;
-        dst[e] = src[(long long)j * p.src_rs + dist_k1(p, (int)kk)];
     }
 }
 
@@ -142,13 +133,6 @@ int wfx_dist_copy2d(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces,
     return 0;
 }
 
-int wfx_dist_gather_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, long long max_elems)
-{
-    if (npieces <= 0 || max_elems <= 0) return 0;
-    WFX_LAUNCH(ctx, K_DIST_COPY, dist_gather_k_kernel, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
-    return 0;
-}
-
 int wfx_dist_scatter_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, int max_rows)
 {
     if (npieces <= 0 || max_rows <= 0) return 0;
@@ -189,7 +173,7 @@ int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int ele
     if (L % R1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: %lld is not a multiple of the first radix %d", L, R1);
     M = L / R1;
     if (L >= (1ll << 31)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: %lld points exceed 32-bit indices", L);
-    if (!wfx_mr_pair_plan(M, sub)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: %lld has no radix-pair plan", M);
+    if (!wfx_mr_general_plan(M, sub)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: %lld is not 13-smooth", M);
     cols.resize(W + 1);
     for (int d = 0; d <= W; ++d) cols[d] = d == W ? M : (long long)d * M / W / 4 * 4;
     w = (int)(cols[me + 1] - cols[me]);
@@ -211,9 +195,9 @@ int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int ele
     {
         long long Play = B, Ptw = R1;
         for (int i = 0; i < ns; ++i) {              // forward: the global plan's passes 2.., twiddles by global k = k1 + R1 (.)
-            const int R = sub[i].first * sub[i].second;
+            const int R = sub[i].R;
             mr_pass_desc &d = d_fwd[i];
-            wfx_mr_pair_desc(d, sub[i].first, sub[i].second, Play, (long long)B * M / R, (long long)B * M);
+            wfx_mr_general_desc(d, sub[i], Play, (long long)B * M / R, (long long)B * M);
             d.dist = 1;
             d.B = B;
             d.kb0 = g.km[me].kb0;
@@ -232,10 +216,10 @@ int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int ele
     {
         long long Play = B, Psub = 1;
         for (int i = 0; i < ns; ++i) {              // inverse: M-point transforms, radices in the reverse order
-            const std::pair<int, int> pr = sub[ns - 1 - i];
-            const int R = pr.first * pr.second;
+            const wfx_mr_radix pr = sub[ns - 1 - i];
+            const int R = pr.R;
             mr_pass_desc &d = d_inv[i];
-            wfx_mr_pair_desc(d, pr.first, pr.second, Play, (long long)B * M / R, (long long)B * M);
+            wfx_mr_general_desc(d, pr, Play, (long long)B * M / R, (long long)B * M);
             d.dist = 1;
             d.B = B;
             d.kb0 = d.kb1 = 0;
@@ -280,13 +264,13 @@ int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int ele
     {
         long long Ptw = R1;
         for (int i = 0; i < ns; ++i) {
-            const int R = sub[i].first * sub[i].second;
+            const int R = sub[i].R;
             WFX_TRY(wfx_mr_fill_table(ctx, tb + tw_fwd[i], Ptw * R));
             Ptw *= R;
         }
         long long Psub = 1;
         for (int i = 0; i < ns; ++i) {
-            const int R = sub[ns - 1 - i].first * sub[ns - 1 - i].second;
+            const int R = sub[ns - 1 - i].R;
             WFX_TRY(wfx_mr_fill_table(ctx, tb + tw_inv[i], Psub * R));
             Psub *= R;
         }
@@ -311,9 +295,14 @@ void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
     char *pack = (char *)b_pack.p, *recv = (char *)b_recv.p;
     cplx *Y = (cplx *)b_y.p, *A = (cplx *)b_a.p;
     x1.clear(); x2.clear(); x3.clear(); x4.clear();
-    p1.clear(); p2.clear(); p3.clear(); p4.clear();
+    p1.clear(); p3.clear(); p4.clear();
+    qmap.assign(R1, mr_qmap{0, 0});
+    // one rank: the rows ARE the columns, so the first pass reads the caller's rows and the last inverse pass writes the caller's
+    // output directly; the exchanges E1 / E4 then carry nothing but the (self) halo copies
+    pass1_src = W == 1 ? rows_in : (const void *)recv;
+    pass_last_dst = (W == 1 && rows_out) ? rows_out + hb : (cplx *)pack;
     // E1: rows -> columns
-    if (rows_in) {
+    if (rows_in && W > 1) {
         size_t off = 0;
         for (int d = 0; d < W; ++d) {
             const long long wd = cols[d + 1] - cols[d];
@@ -337,25 +326,19 @@ void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
             if (d != me) off += (size_t)nr * wd * ES;
         }
     }
-    // E2: first-pass output [w][R1] -> slabs [M][B_e]
+    // E2: first-pass output (column j, output k1) -> slabs [M][B_e].  No packing copy: the first pass stores every output where the
+    // exchange sends it from (mr_pass_desc::qmap), the own part straight into the slab.
     {
         size_t off = 0;
         for (int e = 0; e < W; ++e) {
             const wfx_dist_kmap &km = g.km[e];
             cplx *self_dst = A + (size_t)cols[me] * B;
             cplx *dst = e == me ? self_dst : (cplx *)pack + off;
-            wfx_dist_piece p{};
-            p.src = (unsigned long long)Y;
-            p.dst = (unsigned long long)dst;
-            p.rows = w;
-            p.cols = km.B;
-            p.src_rs = R1;
-            p.dst_rs = km.B;
-            p.kb0 = km.kb0;
-            p.kc0 = km.kc0;
-            p.kb1 = km.kb1;
-            p.B = km.B;
-            p2.push_back(p);
+            for (int kk = 0; kk < km.B; ++kk) {
+                const int k1 = kk < km.kc0 ? km.kb0 + kk : km.kb1 + (kk - km.kc0);
+                qmap[k1].base = (unsigned long long)(dst + kk);
+                qmap[k1].stride = km.B;
+            }
             wfx_xfer x{};
             x.peer = e;
             x.send = dst;
@@ -398,7 +381,7 @@ void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
     }
     // E4: [R1][w] rows -> own rows [nr][M] with a halo of hb points before and ha points after (circular)
     if (rows_out) {
-        cplx *X = (cplx *)pack;                                      // output of the last inverse pass
+        cplx *X = pass_last_dst;                                     // output of the last inverse pass
         size_t off = 0;
         auto overlap = [&](int d, long long lo, long long hi, long long &a, long long &b) {
             a = std::max(cols[d], lo);
@@ -408,22 +391,24 @@ void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
         for (int s = 0; s < W; ++s) {
             const long long ws = cols[s + 1] - cols[s];
             cplx *src = s == me ? X + (size_t)g.rows[me] * w : (cplx *)recv + off;
-            wfx_dist_piece p{};
-            p.src = (unsigned long long)src;
-            p.dst = (unsigned long long)(rows_out + hb + cols[s]);
-            p.rows = nr;
-            p.cols = (int)ws;
-            p.src_rs = ws;
-            p.dst_rs = M;
-            p4.push_back(p);
-            wfx_xfer x{};
-            x.peer = s;
-            x.send = X + (size_t)g.rows[s] * w;                      // rank s's rows of my columns (contiguous)
-            x.send_bytes = (size_t)g.nrows(s) * w * sizeof(cplx);
-            x.recv = src;
-            x.recv_bytes = (size_t)nr * ws * sizeof(cplx);
-            if (s == me) x.send = x.recv;
-            x4.push_back(x);
+            if (W > 1) {
+                wfx_dist_piece p{};
+                p.src = (unsigned long long)src;
+                p.dst = (unsigned long long)(rows_out + hb + cols[s]);
+                p.rows = nr;
+                p.cols = (int)ws;
+                p.src_rs = ws;
+                p.dst_rs = M;
+                p4.push_back(p);
+                wfx_xfer x{};
+                x.peer = s;
+                x.send = X + (size_t)g.rows[s] * w;                  // rank s's rows of my columns (contiguous)
+                x.send_bytes = (size_t)g.nrows(s) * w * sizeof(cplx);
+                x.recv = src;
+                x.recv_bytes = (size_t)nr * ws * sizeof(cplx);
+                if (s == me) x.send = x.recv;
+                x4.push_back(x);
+            }
             if (s != me) off += (size_t)nr * ws;
             long long a, b;
             // halo before: row rows[dst] - 1, columns [M - hb, M)
@@ -464,19 +449,20 @@ void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
 
 int wfx_dist::upload_pieces()
 {
-    const size_t n = p1.size() + p2.size() + p3.size() + p4.size();
-    WFX_TRY(wfx_reserve(ctx, b_desc, n * sizeof(wfx_dist_piece)));
+    const size_t n = p1.size() + p3.size() + p4.size();
+    oq = (n * sizeof(wfx_dist_piece) + 255) / 256 * 256;
+    WFX_TRY(wfx_reserve(ctx, b_desc, oq + qmap.size() * sizeof(mr_qmap) + 256));
     std::vector<wfx_dist_piece> all;
     o1 = 0;
     all.insert(all.end(), p1.begin(), p1.end());
-    o2 = all.size();
-    all.insert(all.end(), p2.begin(), p2.end());
     o3 = all.size();
     all.insert(all.end(), p3.begin(), p3.end());
     o4 = all.size();
     all.insert(all.end(), p4.begin(), p4.end());
     WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));               // kernels of an earlier run may still read the old descriptors
-    WFX_HIP(ctx, hipMemcpy(b_desc.p, all.data(), n * sizeof(wfx_dist_piece), hipMemcpyHostToDevice));
+    if (n) WFX_HIP(ctx, hipMemcpy(b_desc.p, all.data(), n * sizeof(wfx_dist_piece), hipMemcpyHostToDevice));
+    WFX_HIP(ctx, hipMemcpy((char *)b_desc.p + oq, qmap.data(), qmap.size() * sizeof(mr_qmap), hipMemcpyHostToDevice));
+    d_first.qmap = (const mr_qmap *)((const char *)b_desc.p + oq);
     return 0;
 }
 
@@ -506,11 +492,8 @@ int wfx_dist::fwd_pack_exchange(wfx_comm *c, const void *rows_in)
 int wfx_dist::fwd_pass1_exchange(wfx_comm *c, int in_mode)
 {
     const cplx *tb = (const cplx *)tables.p;
-    WFX_TRY(wfx_mr_launch_pair(ctx, d_first, tb, in_mode, 0, 0, b_recv.p, (cplx *)b_y.p));      // P = 1: no twiddle is read
-    const wfx_dist_piece *dp = (const wfx_dist_piece *)b_desc.p;
-    long long mx = 0;
-    for (const wfx_dist_piece &p : p2) mx = std::max(mx, (long long)p.rows * p.cols);
-    WFX_TRY(wfx_dist_gather_k(ctx, dp + o2, (int)p2.size(), mx));
+    // P = 1: no twiddle is read; the outputs go straight to where E2 sends them from (d_first.qmap), b_y is not written
+    WFX_TRY(wfx_mr_launch_pair(ctx, d_first, tb, in_mode, 0, 0, pass1_src, (cplx *)b_y.p));
     return wfx_comm_exchange(c, ctx, x2.data(), (int)x2.size());
 }
 
@@ -520,7 +503,7 @@ int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum)
     cplx *src = (cplx *)b_a.p, *dst = (cplx *)b_a2.p;
     const int ns = (int)d_fwd.size();
     for (int i = 0; i < ns; ++i) {
-        WFX_TRY(wfx_mr_launch_pair(ctx, d_fwd[i], tb + tw_fwd[i], 0, (hilbert_spectrum && i == ns - 1) ? 1 : 0, 0, src, dst));
+        WFX_TRY(wfx_mr_launch(ctx, d_fwd[i], tb + tw_fwd[i], 0, (hilbert_spectrum && i == ns - 1) ? 1 : 0, 0, src, dst));
         std::swap(src, dst);
     }
     *spectrum = src;
@@ -534,7 +517,7 @@ int wfx_dist::inv_slab_exchange(wfx_comm *c, cplx *slab_in)
     cplx *src = slab_in, *dst = slab_in == (cplx *)b_a.p ? (cplx *)b_a2.p : (cplx *)b_a.p;
     const int ns = (int)d_inv.size();
     for (int i = 0; i < ns; ++i) {
-        WFX_TRY(wfx_mr_launch_pair(ctx, d_inv[i], tb + tw_inv[i], 0, 0, 1, src, dst));
+        WFX_TRY(wfx_mr_launch(ctx, d_inv[i], tb + tw_inv[i], 0, 0, 1, src, dst));
         std::swap(src, dst);
     }
     return wfx_comm_exchange(c, ctx, x3.data(), (int)x3.size());
@@ -546,7 +529,7 @@ int wfx_dist::inv_pass1_exchange(wfx_comm *c, cplx *rows_out)
     const wfx_dist_piece *dp = (const wfx_dist_piece *)b_desc.p;
     WFX_TRY(wfx_dist_scatter_k(ctx, dp + o3, (int)p3.size(), w));
     const cplx *tb = (const cplx *)tables.p;
-    WFX_TRY(wfx_mr_launch_pair(ctx, d_last, tb + tw_last, 0, 0, 1, b_y.p, (cplx *)b_pack.p));
+    WFX_TRY(wfx_mr_launch_pair(ctx, d_last, tb + tw_last, 0, 0, 1, b_y.p, pass_last_dst));
     return wfx_comm_exchange(c, ctx, x4.data(), (int)x4.size());
 }
 

@@ -117,6 +117,13 @@ struct mr_pass_desc {
     // twiddle / spectrum indices when the array is one rank's part of a distributed transform (wfx_dist.hip); dist == 0: plain
     int dist, B, kb0, kc0, kb1, kscale, kstep;
     long long Ptw, Ltw;         // the pass's P and the length L of the GLOBAL plan (Hilbert spectrum); == P, L when plain
+    // first pass (P == 1) of a distributed transform: output q of column j goes to ((cplx *)qmap[q].base)[j * qmap[q].stride]
+    // instead of out[j R + q] -- straight into the send buffers of the exchange that follows (no packing copy); null: off
+    const struct mr_qmap *qmap;
+};
+struct mr_qmap {
+    unsigned long long base;
+    long long stride;
 };
 
 // ---- error helpers ----------------------------------------------------------
@@ -261,6 +268,13 @@ int wfx_dev_add_u64(wfx_ctx *ctx, unsigned long long *dst, const unsigned long l
 // wfx_mrfft.hip
 // decomposition of a 13-smooth length into radix pairs with a register-resident pass (ascending radix); false if none
 bool wfx_mr_pair_plan(long long L, std::vector<std::pair<int, int>> &pairs);
+struct wfx_mr_radix {
+    int R, ra, rb;              // ra = rb = 0: no register-resident pair pass for R (per-prime LDS stages)
+};
+// passes for any 13-smooth length (pairs where possible); descriptor and launch of either kind of pass
+bool wfx_mr_general_plan(long long L, std::vector<wfx_mr_radix> &out);
+void wfx_mr_general_desc(mr_pass_desc &d, const wfx_mr_radix &r, long long P, long long ncol, long long L);
+int wfx_mr_launch(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int in_mode, int out_mode, int dir, const void *src, cplx *dst);
 bool wfx_mr_is_pair(int ra, int rb);
 void wfx_mr_all_pairs(std::vector<std::pair<int, int>> &out);
 // descriptor of one pair pass with the plain index maps (dist fields cleared, Ptw = P, Ltw = L)

@@ -168,6 +168,23 @@ __device__ __forceinline__ void mr_stage(cplx *tile, const cplx *wr, int R, int 
 // in flight across it (a __syncthreads() would drain it with s_waitcnt vmcnt(0))
 __device__ __forceinline__ void mr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Twiddle index of the column whose layout index is kl = j mod P.  Plain transform: kl itself.  Distributed transform
+// (wfx_dist.hip): the array is a slab [.][B] whose innermost index kk stands for the first-pass output k1 = map(kk) of the
+// global plan, or a range of columns starting at global column kb0:  k = map(kl mod B) * kscale + (kl / B) * kstep.
+__device__ __forceinline__ int mr_twiddle_k(const mr_pass_desc &d, int kl)
+{
+    if (!d.dist) return kl;
+    const int kk = kl % d.B, kq = kl / d.B;
+    return (kk < d.kc0 ? d.kb0 + kk : d.kb1 + (kk - d.kc0)) * d.kscale + kq * d.kstep;
+}
+// global frequency index of layout index o (last forward pass of a slab: the Hilbert spectrum is a function of it)
+__device__ __forceinline__ long long mr_global_index(const mr_pass_desc &d, long long o)
+{
+    if (!d.dist) return o;
+    const int kk = (int)(o % d.B);
+    return (long long)(kk < d.kc0 ? d.kb0 + kk : d.kb1 + (kk - d.kc0)) + (o / d.B) * (long long)d.kstep;
+}
+
 // IN_MODE 0: complex input array; 1: packed real input z[q] = x[2q+1] + i x[2q];
 // 2: int16 samples read as z[q] = x[2q] + i x[2q+1] (the resampler's first pass on an int16 capture: no f64 copy)
 // OUT_MODE 0: plain; 1: multiply by the Hilbert spectrum G[k] / L (last forward pass)
@@ -227,7 +244,7 @@ mr_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, con
             pre[i] = v;
         }
     };
-    const double inv_l = 1.0 / (double)d.L;
+    const double inv_l = 1.0 / (double)d.Ltw;
     int tix = blockIdx.x;
     if (tix < ntiles) prefetch(tix);
     for (; tix < ntiles; tix += gridDim.x) {
@@ -239,7 +256,7 @@ mr_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, con
             const int j = j0 + c;
             cplx w = make_double2(1.0, 0.0), wstep = make_double2(1.0, 0.0);
             if (P > 1 && c < tn) {
-                const int k = j % P;
+                const int k = mr_twiddle_k(d, j % P);
                 const int t0 = k * m0, ts = k * ms;               // < P R <= L
                 w = mconj_if(mcmul(tw_hi[t0 >> MR_LO_BITS], tw_lo[t0 & (MR_LO - 1)]), inv);
                 wstep = mconj_if(mcmul(tw_hi[ts >> MR_LO_BITS], tw_lo[ts & (MR_LO - 1)]), inv);
@@ -283,10 +300,11 @@ mr_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, con
             const int k = P > 1 ? j % P : 0;
             const long long o = (long long)(j - k) * R + k + (long long)q * P;
             if (OUT_MODE == 1) {
-                // G[o] / L,  G[k] = -i exp(-i pi k / L) = (-sin, -cos)(pi k / L), G[0] = 0
+                // G[o] / L,  G[k] = -i exp(-i pi k / L) = (-sin, -cos)(pi k / L), G[0] = 0  (o: the GLOBAL frequency index)
+                const long long og = mr_global_index(d, o);
                 double sn, cs;
-                sincospi((double)o / (double)d.L, &sn, &cs);
-                const cplx g = o == 0 ? make_double2(0.0, 0.0) : make_double2(-sn * inv_l, -cs * inv_l);
+                sincospi((double)og / (double)d.Ltw, &sn, &cs);
+                const cplx g = og == 0 ? make_double2(0.0, 0.0) : make_double2(-sn * inv_l, -cs * inv_l);
                 v = mcmul(v, g);
             }
             out[o] = v;
@@ -469,23 +487,6 @@ constexpr bool mr2_prefetch(int ra, int rb)
     return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) <= 140;      // registers: a tile in flight + a level-B transform
 }
 
-// Twiddle index of the column whose layout index is kl = j mod P.  Plain transform: kl itself.  Distributed transform
-// (wfx_dist.hip): the array is a slab [.][B] whose innermost index kk stands for the first-pass output k1 = map(kk) of the
-// global plan, or a range of columns starting at global column kb0:  k = map(kl mod B) * kscale + (kl / B) * kstep.
-__device__ __forceinline__ int mr_twiddle_k(const mr_pass_desc &d, int kl)
-{
-    if (!d.dist) return kl;
-    const int kk = kl % d.B, kq = kl / d.B;
-    return (kk < d.kc0 ? d.kb0 + kk : d.kb1 + (kk - d.kc0)) * d.kscale + kq * d.kstep;
-}
-// global frequency index of layout index o (last forward pass of a slab: the Hilbert spectrum is a function of it)
-__device__ __forceinline__ long long mr_global_index(const mr_pass_desc &d, long long o)
-{
-    if (!d.dist) return o;
-    const int kk = (int)(o % d.B);
-    return (long long)(kk < d.kc0 ? d.kb0 + kk : d.kb1 + (kk - d.kc0)) + (o / d.B) * (long long)d.kstep;
-}
-
 template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
 __global__ void __launch_bounds__(256, 2)
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
@@ -599,8 +600,18 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                 }
             }
             mr_lds_barrier();
-            const long long o0 = (long long)j0 * R;
-            for (int e = t; e < R * tn; e += 256) out[o0 + e] = tile[e];
+            if (d.qmap) {
+                // distributed transform: every output goes where the following exchange sends it from (wfx_dist.hip, E2):
+                // consecutive q of one destination are consecutive addresses
+                for (int e = t; e < R * tn; e += 256) {
+                    const int c = e / R, q = e - c * R;
+                    const mr_qmap m = d.qmap[q];
+                    ((cplx *)m.base)[(long long)(j0 + c) * m.stride] = tile[e];
+                }
+            } else {
+                const long long o0 = (long long)j0 * R;
+                for (int e = t; e < R * tn; e += 256) out[o0 + e] = tile[e];
+            }
         } else {
             // few, long transforms (T * RA <= 128 items): two threads share one, each producing half of the output pairs
             constexpr int SPLIT = (T * RA <= 128 && RB >= 9 && RB != 25) ? 2 : 1;
@@ -748,6 +759,7 @@ static void mr_fill_pass(mr_plan_host &pl, int i, int R, int ra, int rb, long lo
     d.kb0 = d.kc0 = d.kb1 = d.kscale = d.kstep = 0;
     d.Ptw = P;
     d.Ltw = pl.L;
+    d.qmap = nullptr;
     d.ncol = pl.L / R;
     const int T = MR_TILE / R;
     int t2 = 1, l2 = 0;
@@ -984,6 +996,69 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
     WFX_MR2_PAIRS(X)
 #undef X
     if (!done) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "no register-resident pass for the radix pair (%d, %d)", d.ra, d.rb);
+    return 0;
+}
+
+// Any 13-smooth length: the planner's passes (radix pairs where a decomposition into pairs exists, per-prime groups otherwise)
+bool wfx_mr_general_plan(long long L, std::vector<wfx_mr_radix> &out)
+{
+    out.clear();
+    mr_plan_host pl;
+    if (!mr_make_plan(L, pl)) return false;
+    for (int i = 0; i < pl.npass; ++i) out.push_back({pl.pass[i].R, pl.pass[i].ra, pl.pass[i].rb});
+    return true;
+}
+
+void wfx_mr_general_desc(mr_pass_desc &d, const wfx_mr_radix &r, long long P, long long ncol, long long L)
+{
+    if (r.ra > 0) {
+        wfx_mr_pair_desc(d, r.ra, r.rb, P, ncol, L);
+        return;
+    }
+    d = mr_pass_desc();
+    d.ra = d.rb = 0;
+    d.R = r.R;
+    d.nf = mr_stage_factors(r.R, d.f);
+    for (int k = d.nf < 0 ? 0 : d.nf; k < MR_MAXF; ++k) d.f[k] = 1;
+    d.P = P;
+    d.ncol = ncol;
+    d.L = L;
+    int t2 = 1, l2 = 0;
+    while (t2 * 2 <= MR_TILE / r.R && t2 < 256) {
+        t2 *= 2;
+        ++l2;
+    }
+    d.T = t2;
+    d.log2t = l2;
+    d.dist = 0;
+    d.B = 1;
+    d.Ptw = P;
+    d.Ltw = L;
+}
+
+int wfx_mr_launch(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int in_mode, int out_mode, int dir, const void *src_v, cplx *dst)
+{
+    if (d.ra > 0) return wfx_mr_launch_pair(ctx, d, tw, in_mode, out_mode, dir, src_v, dst);
+    const cplx *src = (const cplx *)src_v;
+    const cplx *lo = tw, *hi = tw + MR_LO;
+    const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
+    const int ntiles = (int)((d.ncol + d.T - 1) / d.T);
+    if (ntiles <= 0) return 0;
+    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
+    if (dir == 1 && in_mode == 0 && out_mode == 0)
+        WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 1>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+    else if (dir == 0 && in_mode == 2 && out_mode == 0)
+        WFX_LAUNCH(ctx, kid, (mr_pass<2, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+    else if (dir == 0 && in_mode == 1 && out_mode == 1)
+        WFX_LAUNCH(ctx, kid, (mr_pass<1, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+    else if (dir == 0 && in_mode == 1 && out_mode == 0)
+        WFX_LAUNCH(ctx, kid, (mr_pass<1, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+    else if (dir == 0 && in_mode == 0 && out_mode == 1)
+        WFX_LAUNCH(ctx, kid, (mr_pass<0, 1, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+    else if (dir == 0 && in_mode == 0 && out_mode == 0)
+        WFX_LAUNCH(ctx, kid, (mr_pass<0, 0, 0>), dim3(grid), dim3(256), src, dst, d, lo, hi, ntiles);
+    else
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "no pass kernel for in_mode %d out_mode %d dir %d", in_mode, out_mode, dir);
     return 0;
 }
 

@@ -13,6 +13,7 @@
 //      (every rank ends with the same low / high on its device); quantise own block
 //   ONE GATHER of the uint8 stream (1 byte per sample) to rank 0
 //   a9 sync search + a10 bicubic image on rank 0 (17 + 60 us of work for a 60-minute capture: not worth a second exchange)
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -20,7 +21,7 @@
 
 #define SH_HALO 32          // samples of audio kept beyond the own range on either side (>= 24 notch taps + 2 median)
 #define SH_VHALO 2          // points of the Hilbert transform delivered beyond the own rows
-#define SH_CAND_CAP 8192    // candidate keys per query and rank that travel in the all-gather
+#define SH_CAND_CAP 4096    // least number of candidate keys per query and rank that travel in the all-gather
 
 struct shard_plan {
     int world = 1, rank = 0;
@@ -328,10 +329,23 @@ static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p
                 total += x.recv_bytes;
             }
             const unsigned long long R1 = pl0.g.R1;
-            const unsigned long long want = e == 1 ? R1 * d[r].w * (unsigned long long)es : e == 2 ? (unsigned long long)d[r].M * d[r].B * 16
-                                          : e == 3 ? R1 * d[r].w * 16ull : ((unsigned long long)d[r].nr * d[r].M + hb + ha) * 16ull;
+            // (one rank: the first pass reads the rows in place and the last one writes them in place -- E1 and E4 carry the halo only)
+            const unsigned long long want = e == 1 ? (W == 1 ? 0ull : R1 * d[r].w * (unsigned long long)es) : e == 2 ? (unsigned long long)d[r].M * d[r].B * 16
+                                          : e == 3 ? R1 * d[r].w * 16ull : ((W == 1 ? 0ull : (unsigned long long)d[r].nr * d[r].M) + hb + ha) * 16ull;
             if (rc == 0 && total != want)
                 rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s, exchange %d): rank %d receives %llu bytes, its layout holds %llu", name, e, r, total, want);
+            if (e == 2 && rc == 0) {
+                // the first pass's scatter map: every output k1 has a target, each target column lies inside a buffer, no two coincide
+                std::vector<unsigned long long> bases;
+                for (const mr_qmap &m : d[r].first_pass_map()) {
+                    if (!m.base || m.stride <= 0 || !dry_inside(regs[r], m.base, m.base + ((unsigned long long)(d[r].w - 1) * m.stride + 1) * 16))
+                        rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s): rank %d's first pass stores outside its buffers", name, r);
+                    bases.push_back(m.base);
+                }
+                std::sort(bases.begin(), bases.end());
+                if (std::adjacent_find(bases.begin(), bases.end()) != bases.end() || (int)bases.size() != pl0.g.R1)
+                    rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s): rank %d's first pass stores two outputs to one place", name, r);
+            }
             for (const wfx_dist_piece &q : d[r].pieces(e)) {
                 if (rc) break;
                 const bool kmap = e == 2 || e == 3;
@@ -418,6 +432,14 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
     sh->dp = *p;
     int rc = make_plan(ctx, p, wfx_comm_world(comm), wfx_comm_rank(comm), sh->pl);
     const shard_plan &pl = sh->pl;
+    {   // The select's candidates are the keys that share 22 leading bits with a percentile: ~ n / 8192 of them per octave of
+        // envelope range in all, a world-th of that per rank; four times the even share absorbs what a picture does to the
+        // distribution.  (An overflow is detected, reported by wfx_shard_result and cured by a larger capacity.)
+        uint64_t want = p->n / (512ull * (uint64_t)(pl.world > 0 ? pl.world : 1));
+        uint64_t cap = SH_CAND_CAP;
+        while (cap < want && cap < (1ull << 20)) cap *= 2;
+        sh->cap = cap;
+    }
     if (rc == 0) rc = wfx_reserve(ctx, ctx->b_scal, sizeof(wfx_dev_scalars));
     if (rc == 0 && pl.resample) {
         rc = sh->dF.init(ctx, pl.g, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0);

@@ -34,47 +34,66 @@ _MAGIC = b"WFXUID01"
 
 
 # ---- RCCL unique id over a loopback socket ---------------------------------------------------------------------
+PORT_SPAN = 16        # rank 0 listens on the first free port of [port, port + PORT_SPAN); the others probe the range
+
+
 def bootstrap_unique_id(rank: int, world: int, addr: str = "127.0.0.1", port: int = 29611, timeout: float = 120.0,
                         make_id=nat.comm_unique_id) -> bytes:
     """Rank 0 creates the RCCL unique id and serves it to the other ``world - 1`` ranks; they fetch it.
-    Plain TCP on ``addr:port`` (stdlib only); the peers retry until rank 0 listens."""
+    Plain TCP on ``addr`` (stdlib only).  Rank 0 takes the first port of [port, port + 16) it can bind; the peers probe
+    that range until something answers with the protocol's magic, so a port that another program holds is skipped."""
     if world == 1:
         return make_id()
     if rank == 0:
         uid = make_id()
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
+        srv = None
+        for k in range(PORT_SPAN):
+            cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                cand.bind((addr, port + k))
+                srv = cand
+                break
+            except OSError:
+                cand.close()
+        if srv is None:
+            raise nat.NativeError(f"rank 0: no free port in [{port}, {port + PORT_SPAN}) on {addr}")
         srv.listen(world)
         srv.settimeout(timeout)
-        served = 0
+        served = set()
         try:
-            while served < world - 1:
+            while len(served) < world - 1:
                 conn, _ = srv.accept()
                 with conn:
-                    conn.settimeout(timeout)
-                    hello = _recv_exact(conn, len(_MAGIC) + 4)
+                    conn.settimeout(10.0)
+                    try:
+                        hello = _recv_exact(conn, len(_MAGIC) + 4)
+                    except OSError:
+                        continue
                     if hello[:len(_MAGIC)] != _MAGIC:
                         continue                      # not one of ours
                     conn.sendall(_MAGIC + uid)
-                    served += 1
+                    served.add(struct.unpack("<i", hello[len(_MAGIC):])[0])
+        except socket.timeout:
+            raise nat.NativeError(f"rank 0: only {len(served)} of {world - 1} ranks fetched the RCCL unique id within {timeout} s")
         finally:
             srv.close()
         return uid
     deadline = time.time() + timeout
     last = None
     while time.time() < deadline:
-        try:
-            with socket.create_connection((addr, port), timeout=5.0) as conn:
-                conn.settimeout(timeout)
-                conn.sendall(_MAGIC + struct.pack("<i", rank))
-                blob = _recv_exact(conn, len(_MAGIC) + nat.WFX_COMM_ID_BYTES)
-                if blob[:len(_MAGIC)] == _MAGIC:
-                    return blob[len(_MAGIC):]
-        except OSError as e:
-            last = e
+        for k in range(PORT_SPAN):
+            try:
+                with socket.create_connection((addr, port + k), timeout=2.0) as conn:
+                    conn.settimeout(10.0)
+                    conn.sendall(_MAGIC + struct.pack("<i", rank))
+                    blob = _recv_exact(conn, len(_MAGIC) + nat.WFX_COMM_ID_BYTES)
+                    if blob[:len(_MAGIC)] == _MAGIC:
+                        return blob[len(_MAGIC):]
+            except OSError as e:
+                last = e
         time.sleep(0.05)
-    raise nat.NativeError(f"rank {rank}: could not fetch the RCCL unique id from {addr}:{port} ({last})")
+    raise nat.NativeError(f"rank {rank}: could not fetch the RCCL unique id from {addr}:{port}+ ({last})")
 
 
 def _recv_exact(conn, n: int) -> bytes:
