@@ -122,7 +122,11 @@ class Ranks:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if args.gpus != self.world and self.world > 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
-        self.ctx = nat.Context(self.local_rank)
+        dev = self.local_rank
+        if os.environ.get("WFX_BENCH_OVERSUBSCRIBE") == "1":       # several ranks per GPU: only to exercise the launch path on a small box
+            dev = self.local_rank % max(1, nat.device_count())
+        self.device = dev
+        self.ctx = nat.Context(dev)
         self.use_rccl = self.world > 1 or os.environ.get("WFX_BENCH_FORCE_DIST") == "1"
         if self.use_rccl:
             addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
@@ -401,7 +405,7 @@ def bench_c2(args, rk: Ranks) -> dict:
         n0, n = job.n0, job.n
         for b in range(1, args.batch):                  # BASELINE configs[4] members: own context and stream each
             xb, lpm_b = synth.config_c5_member(rk.rank * args.batch + b, noise=args.noise)
-            cb = nat.Context(rk.local_rank)
+            cb = nat.Context(rk.device)
             extra.append((cb, DecodeJob(cb, xb, 11025, lpm_b)))
         total = (n0 + sum(jb.n0 for _, jb in extra)) * rk.world
 

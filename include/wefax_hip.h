@@ -75,6 +75,9 @@ int wfx_resample(wfx_ctx *ctx, const double *x, size_t n0, size_t num, double *o
  *     scipy.signal.filtfilt when handed an int16 array. */
 int wfx_notch_filtfilt(wfx_ctx *ctx, const void *in, int in_kind, size_t n,
                        const double b[3], const double a[3], double *out);
+/* the same with the 9 + 9 samples of the odd extension given by the caller (computed in the capture's own dtype) */
+int wfx_notch_filtfilt_ext(wfx_ctx *ctx, const void *in, int in_kind, size_t n, const double b[3], const double a[3],
+                           const double ext_left[9], const double ext_right[9], double *out);
 
 /* a7  wefax.py:166-183 __demodulate: medfilt(abs(hilbert(x)), 5) */
 int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode,
@@ -147,6 +150,13 @@ typedef struct {
     int64_t  mindistance;
     double   frame_samples;    /* frame_len * sample_rate (float, e.g. 5512.5)    */
     int      width;            /* int(frame_len * sample_rate)                    */
+    /* filtfilt's odd extension (wefax.py:72: 9 samples before the first and after the last sample) when it is NOT what
+     * 2 x[0] - x[k] gives in the arithmetic of the samples handed over: scipy evaluates it in the wav file's own dtype, so for
+     * uint8 / int32 captures it wraps and for float32 ones it is rounded to float32, while such captures reach this library
+     * converted to float64.  has_ext = 1: use ext_left[i] (extended position i - 9) and ext_right[i] (position n + i). */
+    int      has_ext;
+    double   ext_left[9];
+    double   ext_right[9];
 } wfx_decode_params;
 
 typedef struct {

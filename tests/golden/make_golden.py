@@ -175,7 +175,21 @@ def main():
          synth.synth_capture(8000.0, noise=0.05, seed=7, phasing_lines=12,
                              image_lines=8, **short), 120)
 
-    # 9. the reference's own 1-second clips (MIT licence, LICENSE:1-3)
+    # 9. resample-path captures long enough that a phasing group closes: an IMAGE downstream of scipy.signal.resample
+    #    (wefax.py:384) and of the stereo merge + resample (240 LPM keeps them short)
+    emit("mono48k_image_240", 48000,
+         synth.synth_capture(48000.0, noise=0.05, seed=22, lpm=240, phasing_lines=40, image_lines=30, **short), 240)
+    emit("stereo48k_image_240", 48000,
+         synth.synth_capture(48000.0, noise=0.05, seed=31, lpm=240, phasing_lines=40, image_lines=24, iq=True, **short), 240)
+    # 10. sample formats other than int16: scipy.io.wavfile returns uint8 / int32 / float32 arrays and filtfilt's odd extension
+    #     (wefax.py:72) is evaluated in THAT dtype (wrapping for the integers, rounded to float32 for float32)
+    base = synth.synth_capture(11025.0, noise=0.05, seed=40, lpm=240, phasing_lines=40, image_lines=40, **short)
+    emit("mono_u8_240", 11025, (base.astype(np.int32) // 256 + 128).astype(np.uint8), 240)
+    base = synth.synth_capture(11025.0, noise=0.05, seed=42, lpm=240, phasing_lines=40, image_lines=40, **short)
+    emit("mono_f32_240", 11025, base.astype(np.float32) / np.float32(32768.0), 240)
+    emit("mono_i32_240", 11025, base.astype(np.int32) * 65536, 240)
+
+    # 11. the reference's own 1-second clips (MIT licence, LICENSE:1-3)
     import shutil
     for clip in ("image", "stop_tone", "start_tone", "start_tone_noisy",
                  "start_tone_start"):

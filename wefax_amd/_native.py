@@ -22,7 +22,7 @@ WFX_MAX_PEAKS = 100
 # every symbol include/wefax_hip.h declares (tests check that all are exported)
 SYMBOLS = [
     "wfx_device_count", "wfx_create", "wfx_destroy", "wfx_last_error", "wfx_sync",
-    "wfx_version", "wfx_merge_channels", "wfx_resample", "wfx_notch_filtfilt",
+    "wfx_version", "wfx_merge_channels", "wfx_resample", "wfx_notch_filtfilt", "wfx_notch_filtfilt_ext",
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
     "wfx_sync_peaks", "wfx_lines_to_image", "wfx_packet_process", "wfx_packets_process", "wfx_packet_spectrum", "wfx_decode_upload", "wfx_decode_attach", "wfx_decode_run",
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
@@ -59,6 +59,9 @@ class DecodeParams(C.Structure):
         ("mindistance", C.c_int64),
         ("frame_samples", C.c_double),
         ("width", C.c_int),
+        ("has_ext", C.c_int),
+        ("ext_left", C.c_double * 9),
+        ("ext_right", C.c_double * 9),
     ]
 
 
@@ -144,6 +147,7 @@ def load():
     lib.wfx_merge_channels.argtypes = [vp, vp, sz, vp]
     lib.wfx_resample.argtypes = [vp, vp, sz, sz, vp]
     lib.wfx_notch_filtfilt.argtypes = [vp, vp, i, sz, dp, dp, vp]
+    lib.wfx_notch_filtfilt_ext.argtypes = [vp, vp, i, sz, dp, dp, dp, dp, vp]
     lib.wfx_analytic_env.argtypes = [vp, vp, sz, i, i, vp]
     lib.wfx_order_stats.argtypes = [vp, vp, sz, vp, i, vp]
     lib.wfx_quantise.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, C.POINTER(C.c_uint64)]
@@ -269,7 +273,8 @@ class Context:
         self._check(self.lib.wfx_resample(self.h, _ptr(x), x.shape[0], num, _ptr(out)))
         return out
 
-    def notch_filtfilt(self, x: np.ndarray, b, a) -> np.ndarray:
+    def notch_filtfilt(self, x: np.ndarray, b, a, ext=None) -> np.ndarray:
+        """``ext``: (left[9], right[9]) of filtfilt's odd extension when it was evaluated in the capture's own dtype."""
         if x.dtype == np.int16:
             x = np.ascontiguousarray(x)
             kind = WFX_IN_I16_MONO
@@ -279,7 +284,12 @@ class Context:
         bb = (C.c_double * 3)(*[float(v) for v in b])
         aa = (C.c_double * 3)(*[float(v) for v in a])
         out = np.empty(x.shape[0], dtype=np.float64)
-        self._check(self.lib.wfx_notch_filtfilt(self.h, _ptr(x), kind, x.shape[0], bb, aa, _ptr(out)))
+        if ext is not None:
+            el = (C.c_double * 9)(*[float(v) for v in ext[0]])
+            er = (C.c_double * 9)(*[float(v) for v in ext[1]])
+            self._check(self.lib.wfx_notch_filtfilt_ext(self.h, _ptr(x), kind, x.shape[0], bb, aa, el, er, _ptr(out)))
+        else:
+            self._check(self.lib.wfx_notch_filtfilt(self.h, _ptr(x), kind, x.shape[0], bb, aa, _ptr(out)))
         return out
 
     def analytic_env(self, x: np.ndarray, mode: int = WFX_HILBERT_FFT, fir_taps: int = 4095) -> np.ndarray:

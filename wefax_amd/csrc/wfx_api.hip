@@ -79,6 +79,26 @@ int wfx_notch_filtfilt(wfx_ctx *ctx, const void *in, int in_kind, size_t n, cons
     return d2h_sync(ctx, out, ctx->b_audio.p, n * 8);
 }
 
+int wfx_notch_filtfilt_ext(wfx_ctx *ctx, const void *in, int in_kind, size_t n, const double b[3], const double a[3], const double ext_left[9],
+                           const double ext_right[9], double *out)
+{
+    CHECK_CTX(ctx);
+    if (!in || !out || !b || !a || !ext_left || !ext_right) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_F64_MONO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "notch: input must be int16 mono or float64");
+    ctx->ran = false;
+    const size_t esz = in_kind == WFX_IN_I16_MONO ? 2 : 8;
+    double ext18[18];
+    for (int i = 0; i < 9; ++i) {
+        ext18[i] = ext_left[i];
+        ext18[9 + i] = ext_right[i];
+    }
+    WFX_TRY(wfx_reserve(ctx, ctx->b_x, n * esz + 16));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_audio, n * 8 + 16));
+    WFX_TRY(h2d(ctx, ctx->b_x.p, in, n * esz));
+    WFX_TRY(wfx_dev_notch(ctx, ctx->b_x.p, in_kind, n, b, a, (double *)ctx->b_audio.p, nullptr, nullptr, ext18));
+    return d2h_sync(ctx, out, ctx->b_audio.p, n * 8);
+}
+
 // ---- a7 ---------------------------------------------------------------------
 static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode, int taps, double *env_raw, double *env,
                             unsigned *l0hist = nullptr)
@@ -311,7 +331,13 @@ int wfx_decode_run(wfx_ctx *ctx)
     }
     // the notch is the first kernel that can see the device scalars: its edge workgroup zeroes them
     bool cleared = false;
-    WFX_TRY(wfx_dev_notch(ctx, cur, cur_kind, n, p.notch_b, p.notch_a, (double *)ctx->b_audio.p, ds, &cleared));
+    double ext18[18];
+    const bool use_ext = p.has_ext && !p.resample && p.in_kind != WFX_IN_I16_STEREO;       // (it describes the capture as handed over)
+    for (int i = 0; i < 9; ++i) {
+        ext18[i] = p.ext_left[i];
+        ext18[9 + i] = p.ext_right[i];
+    }
+    WFX_TRY(wfx_dev_notch(ctx, cur, cur_kind, n, p.notch_b, p.notch_a, (double *)ctx->b_audio.p, ds, &cleared, use_ext ? ext18 : nullptr));
     if (!cleared) WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
     unsigned *sel_ws = nullptr;
     WFX_TRY(wfx_dev_select_workspace(ctx, n, &sel_ws));           // level-0 histogram is fused into the envelope kernel

@@ -220,8 +220,9 @@ int wfx_dev_merge(wfx_ctx *ctx, const int16_t *lr, uint64_t n, double *out);
 int wfx_dev_i16_to_f64(wfx_ctx *ctx, const int16_t *in, uint64_t n, double *out);
 // clear (optional): device scalars the kernel zeroes on its way (saves the decode's memset launch);
 // *cleared tells whether the form that ran did it
+// ext18 (optional): the odd extension's 9 + 9 samples when the caller evaluated them (in the capture's own dtype)
 int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3],
-                  const double a[3], double *out, wfx_dev_scalars *clear = nullptr, bool *cleared = nullptr);
+                  const double a[3], double *out, wfx_dev_scalars *clear = nullptr, bool *cleared = nullptr, const double *ext18 = nullptr);
 int wfx_dev_median5(wfx_ctx *ctx, const double *env_raw, uint64_t n, double *env, unsigned *l0hist);
 int wfx_dev_select(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4],
                    wfx_dev_scalars *d_scal);
@@ -249,7 +250,7 @@ int wfx_dev_image(wfx_ctx *ctx, const uint8_t *d, uint64_t n, int w, int h_max,
 int wfx_dev_image_rows(wfx_ctx *ctx, const uint8_t *d, uint64_t g0, uint64_t start, int w, int h_total, int y0, int rows,
                        uint8_t *img);
 int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out,
-                           int edge_flags);
+                           int edge_flags, const double *ext18 = nullptr);
 int wfx_dev_select_level(wfx_ctx *ctx, const double *env, uint64_t n, int level, const uint64_t prefix[4], unsigned *hist);
 // The radix select in the steps the sharded decode separates with collectives (the histograms are summed over the ranks between them,
 // the candidate lists gathered): workspace words [0, 2048) = level-0 histogram, [2048, 5 * 2048) = level-1 histograms.

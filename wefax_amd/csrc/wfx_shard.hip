@@ -189,7 +189,13 @@ static int run_phase(wfx_shard *sh, int ph)
             }
         }
         const int flags = (pl.seg_lo == 0 ? 1 : 0) | (pl.seg_hi == pl.n ? 2 : 0);
-        WFX_TRY(wfx_dev_notch_fir_only(ctx, nin, nkind, n_seg, p.notch_b, p.notch_a, audio, flags));
+        double ext18[18];
+        const bool use_ext = p.has_ext && !pl.resample && pl.in_kind != WFX_IN_I16_STEREO;
+        for (int i = 0; i < 9; ++i) {
+            ext18[i] = p.ext_left[i];
+            ext18[9 + i] = p.ext_right[i];
+        }
+        WFX_TRY(wfx_dev_notch_fir_only(ctx, nin, nkind, n_seg, p.notch_b, p.notch_a, audio, flags, use_ext ? ext18 : nullptr));
         return sh->dH.fwd_pack_exchange(c, audio + (pl.own_lo - pl.seg_lo));
     }
     case 5: return sh->dH.fwd_pass1_exchange(c, 1);

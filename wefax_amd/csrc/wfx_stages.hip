@@ -60,6 +60,8 @@ int wfx_dev_i16_to_f64(wfx_ctx *ctx, const int16_t *in, uint64_t n, double *out)
 struct notch_coef {
     double g[NOTCH_K + 1];
     double b[3], a[3], zi[2];
+    int has_ext;                      // the odd extension is given (evaluated by the host in the capture's own dtype)
+    double extl[NOTCH_PAD], extr[NOTCH_PAD];
 };
 
 template <typename TIN>
@@ -85,6 +87,18 @@ template <>
 __device__ __forceinline__ double notch_ext_right<double>(const double *x, uint64_t n, int k)
 {
     return 2 * x[n - 1] - x[n - 1 - k];
+}
+
+// extended sample k places before x[0] / after x[n-1] (k = 1..9)
+template <typename TIN>
+__device__ __forceinline__ double notch_left(const notch_coef &c, const TIN *x, int k)
+{
+    return c.has_ext ? c.extl[NOTCH_PAD - k] : notch_ext_left<TIN>(x, k);
+}
+template <typename TIN>
+__device__ __forceinline__ double notch_right(const notch_coef &c, const TIN *x, uint64_t n, int k)
+{
+    return c.has_ext ? c.extr[k - 1] : notch_ext_right<TIN>(x, n, k);
 }
 
 // transposed direct form II step, the recurrence of scipy's lfilter
@@ -173,9 +187,9 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
         if (t == 0) {
             double *e = ebuf[0];
             const int len = (int)n + 2 * NOTCH_PAD;
-            for (int i = 0; i < NOTCH_PAD; ++i) e[i] = notch_ext_left<TIN>(x, NOTCH_PAD - i);
+            for (int i = 0; i < NOTCH_PAD; ++i) e[i] = notch_left<TIN>(c, x, NOTCH_PAD - i);
             for (int i = 0; i < (int)n; ++i) e[NOTCH_PAD + i] = (double)x[i];
-            for (int i = 0; i < NOTCH_PAD; ++i) e[NOTCH_PAD + n + i] = notch_ext_right<TIN>(x, n, i + 1);
+            for (int i = 0; i < NOTCH_PAD; ++i) e[NOTCH_PAD + n + i] = notch_right<TIN>(c, x, n, i + 1);
             double z0 = c.zi[0] * e[0], z1 = c.zi[1] * e[0];
             for (int i = 0; i < len; ++i) e[i] = biquad_step(c, e[i], z0, z1);
             z0 = c.zi[0] * e[len - 1];
@@ -192,8 +206,8 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
     constexpr int LEN = NOTCH_PAD + L;                  // 136, a multiple of 8
     static_assert(LEN % 8 == 0, "edge length must be a multiple of 8");
     for (int i = t; i < LEN; i += 256) {
-        ebuf[0][i] = i < NOTCH_PAD ? notch_ext_left<TIN>(x, NOTCH_PAD - i) : (double)x[i - NOTCH_PAD];
-        ebuf[1][i] = i < L ? (double)x[n - L + i] : notch_ext_right<TIN>(x, n, i - L + 1);
+        ebuf[0][i] = i < NOTCH_PAD ? notch_left<TIN>(c, x, NOTCH_PAD - i) : (double)x[i - NOTCH_PAD];
+        ebuf[1][i] = i < L ? (double)x[n - L + i] : notch_right<TIN>(c, x, n, i - L + 1);
     }
     __syncthreads();
     if ((t == 0 && (exact_edges & 1)) || (t == 64 && (exact_edges & 2))) {
@@ -236,8 +250,13 @@ static unsigned notch_grid(uint64_t n_interior)
     return std::min(wfx_blocks(n_interior, 1024), 1024u);
 }
 
-static void notch_prepare(notch_coef &c, const double b[3], const double a[3])
+static void notch_prepare(notch_coef &c, const double b[3], const double a[3], const double *ext18 = nullptr)
 {
+    c.has_ext = ext18 != nullptr;
+    for (int i = 0; i < NOTCH_PAD; ++i) {
+        c.extl[i] = ext18 ? ext18[i] : 0.0;
+        c.extr[i] = ext18 ? ext18[NOTCH_PAD + i] : 0.0;
+    }
     for (int i = 0; i < 3; ++i) {
         c.b[i] = b[i] / a[0];
         c.a[i] = a[i] / a[0];
@@ -279,10 +298,10 @@ static void notch_prepare(notch_coef &c, const double b[3], const double a[3])
 // (n + 2*PAD values), pass 2 backward over `fwd` into y.
 #define GEN_CHUNK 64
 template <typename TIN>
-__device__ __forceinline__ double notch_ext_at(const TIN *x, uint64_t n, int64_t i)   // i in [0, n + 2*PAD)
+__device__ __forceinline__ double notch_ext_at(const notch_coef &c, const TIN *x, uint64_t n, int64_t i)   // i in [0, n + 2*PAD)
 {
-    if (i < NOTCH_PAD) return notch_ext_left<TIN>(x, NOTCH_PAD - (int)i);
-    if (i >= (int64_t)n + NOTCH_PAD) return notch_ext_right<TIN>(x, n, (int)(i - (int64_t)n - NOTCH_PAD) + 1);
+    if (i < NOTCH_PAD) return notch_left<TIN>(c, x, NOTCH_PAD - (int)i);
+    if (i >= (int64_t)n + NOTCH_PAD) return notch_right<TIN>(c, x, n, (int)(i - (int64_t)n - NOTCH_PAD) + 1);
     return (double)x[i - NOTCH_PAD];
 }
 
@@ -296,7 +315,7 @@ __global__ void __launch_bounds__(64) biquad_forward_kernel(const TIN *__restric
     double z0 = 0.0, z1 = 0.0;
     if (i <= 0) {
         i = 0;
-        const double e0 = notch_ext_at<TIN>(x, n, 0);
+        const double e0 = notch_ext_at<TIN>(c, x, n, 0);
         z0 = c.zi[0] * e0;
         z1 = c.zi[1] * e0;
     }
@@ -304,7 +323,7 @@ __global__ void __launch_bounds__(64) biquad_forward_kernel(const TIN *__restric
     for (; i < last; i += 8) {
         double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = i + k < last ? notch_ext_at<TIN>(x, n, i + k) : 0.0;
+        for (int k = 0; k < 8; ++k) v[k] = i + k < last ? notch_ext_at<TIN>(c, x, n, i + k) : 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (i + k < last) {
@@ -372,13 +391,13 @@ static int notch_general(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, 
 }
 
 int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out, wfx_dev_scalars *clear,
-                  bool *cleared)
+                  bool *cleared, const double *ext18)
 {
     if (cleared) *cleared = false;
     if (n <= NOTCH_PAD)
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "The length of the input vector x must be greater than padlen, which is 9.");
     notch_coef c;
-    notch_prepare(c, b, a);
+    notch_prepare(c, b, a, ext18);
     // the 49-tap form holds while the impulse response has died within NOTCH_K samples (the reference's own
     // design at 11 025 Hz: radius 0.21); any other stable biquad takes the chunked recurrence
     const double radius = biquad_pole_radius(a);
@@ -398,7 +417,7 @@ int wfx_dev_notch(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const d
 // segment of a longer capture: exact filtfilt edges only where the segment touches the capture's
 // true start (edge_flags bit 0) / end (bit 1); elsewhere the FIR form, valid K samples from the end
 int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], double *out,
-                           int edge_flags)
+                           int edge_flags, const double *ext18)
 {
     if (n < NOTCH_SMALL) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "segment of %llu samples is too short for the notch", (unsigned long long)n);
     // the 49-tap form is filtfilt only while the impulse response has died within NOTCH_K samples (wfx_dev_notch falls back to the
@@ -407,7 +426,7 @@ int wfx_dev_notch_fir_only(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
     if (pow(radius, NOTCH_K) > 1e-16)
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "notch: pole radius %.4f is too large for the 49-tap segment form (design at 11 025 Hz with Q <= ~1)", radius);
     notch_coef c;
-    notch_prepare(c, b, a);
+    notch_prepare(c, b, a, ext18);
     const unsigned ib = notch_grid(n - 2 * NOTCH_K);
     if (in_kind == WFX_IN_I16_MONO)
         WFX_LAUNCH(ctx, K_NOTCH, notch_kernel<short>, dim3(ib + (edge_flags ? 1 : 0)), dim3(256), (const short *)in, n, c, out, ib, edge_flags & 3, (wfx_dev_scalars *)nullptr);

@@ -43,6 +43,18 @@ def iirnotch(w0: float, q: float, fs: float):
     return b, a
 
 
+def odd_extension(x: np.ndarray, edge: int = 9):
+    """The samples scipy.signal.filtfilt (wefax.py:72) puts before and after ``x`` (scipy.signal._arraytools.odd_ext:
+    ``2 x[0] - x[edge:0:-1]`` and ``2 x[-1] - x[-2:-(edge+2):-1]``), evaluated -- as scipy does -- in x's OWN dtype: uint8 and
+    int32 captures wrap, float32 ones round to float32.  Returned as two float64 arrays (left in time order, right in time
+    order) for the native notch, which otherwise would form the extension from the float64 copy it is handed."""
+    x = np.asarray(x)
+    with np.errstate(over="ignore"):
+        left = 2 * x[0:1] - x[edge:0:-1]
+        right = 2 * x[-1:] - x[-2:-(edge + 2):-1]
+    return left.astype(np.float64), right.astype(np.float64)
+
+
 def percentile_plan(n: int, q_percent: float):
     """np.percentile(., q) 'linear' (wefax.py:196): the two order-statistic ranks and
     the lerp weight, as numpy/lib/_function_base_impl.py::_quantile derives them."""

@@ -65,6 +65,7 @@ class DecodeJob:
         self.frame_len = 1 / (lines_per_minute / 60)                       # wefax.py:33
         data = np.asarray(data)
         self.merged_on_host = False
+        ext = None
         if data.ndim == 2:
             if data.dtype == np.int16:
                 kind = nat.WFX_IN_I16_STEREO
@@ -77,9 +78,16 @@ class DecodeJob:
         elif data.dtype == np.int16:
             kind = nat.WFX_IN_I16_MONO
         else:
+            # uint8 / int32 / float32 captures: the arithmetic runs on a float64 copy, but filtfilt's odd extension is what scipy
+            # computes in the file's own dtype (wrapping / float32 rounding): evaluated here, handed over as 9 + 9 numbers
+            ext = hp.odd_extension(data) if (data.dtype != np.float64 and data.shape[0] > 9) else None
             data = data.astype(np.float64)
             kind = nat.WFX_IN_F64_MONO
         self._configure(kind, int(data.shape[0]), sample_rate, notch, hilbert_mode, fir_taps)
+        if ext is not None and not self.resampled:
+            self.params.has_ext = 1
+            self.params.ext_left[:] = [float(v) for v in ext[0]]
+            self.params.ext_right[:] = [float(v) for v in ext[1]]
         ctx.decode_upload(data, self.params)
         self.info = None
 
