@@ -120,6 +120,9 @@ struct mr_pass_desc {
     // first pass (P == 1) of a distributed transform: output q of column j goes to ((cplx *)qmap[q].base)[j * qmap[q].stride]
     // instead of out[j R + q] -- straight into the send buffers of the exchange that follows (no packing copy); null: off
     const struct mr_qmap *qmap;
+    // outputs with skip_lo < index < skip_hi are not stored (skip_hi == 0: all are): the bins of a forward spectrum that
+    // scipy.signal.resample's down-sampling never reads (wefax.py:384 keeps the lowest num/2 + 1 bins and their mirrors)
+    long long skip_lo, skip_hi;
 };
 struct mr_qmap {
     unsigned long long base;

@@ -299,6 +299,7 @@ mr_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, con
             const int j = j0 + cc;
             const int k = P > 1 ? j % P : 0;
             const long long o = (long long)(j - k) * R + k + (long long)q * P;
+            if (d.skip_hi && o > d.skip_lo && o < d.skip_hi) return;
             if (OUT_MODE == 1) {
                 // G[o] / L,  G[k] = -i exp(-i pi k / L) = (-sin, -cos)(pi k / L), G[0] = 0  (o: the GLOBAL frequency index)
                 const long long og = mr_global_index(d, o);
@@ -487,8 +488,11 @@ constexpr bool mr2_prefetch(int ra, int rb)
     return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) <= 140;      // registers: a tile in flight + a level-B transform
 }
 
+#ifndef WFX_FUSED_LB
+#define WFX_FUSED_LB 2
+#endif
 template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, OUT_MODE == 2 ? WFX_FUSED_LB : 2)
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
          int ntiles)
 {
@@ -507,8 +511,8 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
         sincospi(2.0 * (double)i / (double)R, &sn, &cs);
         wr[i] = make_double2(cs, inv ? sn : -sn);                 // W_R^i in the direction of this pass
     }
-    __shared__ cplx gpow[OUT_MODE == 1 ? RB : 1];                 // exp(-i pi qb RA P / L): the spectrum's step along qb
-    if (OUT_MODE == 1 && t < RB) {
+    __shared__ cplx gpow[OUT_MODE >= 1 ? RB : 1];                 // exp(-i pi qb RA P / L): the spectrum's step along qb
+    if (OUT_MODE >= 1 && t < RB) {
         double sn, cs;
         sincospi((double)((long long)t * RA * d.Ptw) / (double)d.Ltw, &sn, &cs);
         gpow[t] = make_double2(cs, -sn);
@@ -612,6 +616,69 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                 const long long o0 = (long long)j0 * R;
                 for (int e = t; e < R * tn; e += 256) out[o0 + e] = tile[e];
             }
+        } else if (OUT_MODE == 2) {
+            // LAST forward pass fused with the FIRST inverse pass.  With the inverse's radices taken in the reverse order, column j
+            // of this pass produces X[j + q P], q < R -- exactly what column j of an inverse first pass of the same radix reads.
+            // The thread that finishes the forward transform for (column, qa) holds X[qa + RA qb] for all qb: it multiplies by the
+            // spectrum and runs the inverse's RB-point level on them IN REGISTERS (inverse split q = qa + RA qb, n = nb + RB na:
+            // x[n] = sum_qa W_R^(-qa nb) W_RA^(-qa na) sum_qb X[qa + RA qb] W_RB^(-qb nb)), so the spectrum never travels to
+            // memory and only one more LDS round trip than a plain first pass is needed.
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                const int item = t + 256 * ib;
+                if (item < T * RA) {
+                    const int c = item & (T - 1), qa = item >> LOG2T;
+                    cplx u[RB];
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) u[b] = tile[((qa * RB + b) << LOG2T) + c];
+                    const long long o = (long long)(j0 + c) + (long long)qa * P;         // + qb RA P
+                    const double il = 1.0 / (double)d.Ltw;
+                    double sn, cs;
+                    sincospi((double)o * il, &sn, &cs);
+                    const cplx g0 = make_double2(-sn * il, -cs * il);
+                    // the spectrum values go through the item's own LDS rows (written and read back by the same thread) instead of
+                    // a second register array: the pass already sits at the register limit of two workgroups per CU
+                    dft_any<RB>(u, sg, [&](int qb, cplx v) {
+                        tile[((qa * RB + qb) << LOG2T) + c] =
+                            (o == 0 && qb == 0) ? make_double2(0.0, 0.0) : mcmul(v, mcmul(g0, gpow[qb]));       // times G[o + qb RA P] / L
+                    });
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) u[b] = tile[((qa * RB + b) << LOG2T) + c];
+                    dft_any<RB>(u, 1.0, [&](int nb, cplx v) {
+                        if (qa > 0 && nb > 0) {
+                            const cplx w = wr[qa * nb];
+                            v = mcmul(v, make_double2(w.x, -w.y));
+                        }
+                        tile[((qa * RB + nb) << LOG2T) + c] = v;       // the rows this item read: in place
+                    });
+                }
+            }
+            mr_lds_barrier();
+            cplx xo[NA][RA];
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) {                     // inverse RA-point level over qa, for (column, nb)
+                const int item = t + 256 * ia;
+                if (item < T * RB) {
+                    const int c = item & (T - 1), nb = item >> LOG2T;
+                    cplx v[RA];
+#pragma unroll
+                    for (int a = 0; a < RA; ++a) v[a] = tile[((a * RB + nb) << LOG2T) + c];
+                    dft_any<RA>(v, 1.0, [&](int na, cplx r) { xo[ia][na] = r; });
+                }
+            }
+            mr_lds_barrier();
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) {                     // first-pass output order: a column's R values are contiguous
+                const int item = t + 256 * ia;
+                if (item < T * RB) {
+                    const int c = item & (T - 1), nb = item >> LOG2T;
+#pragma unroll
+                    for (int na = 0; na < RA; ++na) tile[c * R + nb + RB * na] = xo[ia][na];
+                }
+            }
+            mr_lds_barrier();
+            const long long o0 = (long long)j0 * R;
+            for (int e = t; e < R * tn; e += 256) out[o0 + e] = tile[e];
         } else {
             // few, long transforms (T * RA <= 128 items): two threads share one, each producing half of the output pairs
             constexpr int SPLIT = (T * RA <= 128 && RB >= 9 && RB != 25) ? 2 : 1;
@@ -642,6 +709,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                     }
                     auto emit = [&](int qb, cplx y) {
                         const long long o = obase + (long long)qb * ostep;
+                        if (OUT_MODE == 0 && d.skip_hi && o > d.skip_lo && o < d.skip_hi) return;
                         if (OUT_MODE == 1) {
                             // times G[o] / L, G[o] = -i exp(-i pi o / L) (G[0] = 0) = g0 * gstep^qb: the powers of the
                             // (kernel-uniform) step come from LDS, the start from one sincospi per thread
@@ -760,6 +828,7 @@ static void mr_fill_pass(mr_plan_host &pl, int i, int R, int ra, int rb, long lo
     d.Ptw = P;
     d.Ltw = pl.L;
     d.qmap = nullptr;
+    d.skip_lo = d.skip_hi = 0;
     d.ncol = pl.L / R;
     const int T = MR_TILE / R;
     int t2 = 1, l2 = 0;
@@ -783,6 +852,9 @@ static double mr2_pair_cost(int ra, int rb)
     if (rb == 25 || ra == 25) c += 0.25;
     if (ra <= 5) c += 0.15;                    // many short level-A transforms: more twiddles per point
     if (ra * rb < 64) c += 0.2;                // short rows: less work per byte of tile bookkeeping
+    // (measured on the 86.4 M-point transform of the 60-minute 48 kHz resampler, 2.76 GB per pass: (5,15) 409 us, (15,16) 549 us as a
+    // last pass that skips the unread bins, (8,15) 675 us, (8,16) 605 us, first passes from int16 (8,8) 676 / (5,15) 631 / (8,16) 1102 us:
+    // a penalty for radices above 128 -- 16-column tiles -- picked (5,15)(5,15)(8,15)(8,16) and lost 0.3 ms; removed again)
     return c;
 }
 
@@ -905,13 +977,50 @@ static bool mr_make_plan(long long L, mr_plan_host &pl)
     return true;
 }
 
+// the passes of `fwd` in the reverse order (tables appended behind fwd's); false when a pass has no pair kernel or there is only one
+static bool mr_make_reverse(const mr_plan_host &fwd, mr_plan_host &inv)
+{
+    inv = mr_plan_host();
+    if (fwd.npass < 2) return false;
+    for (int i = 0; i < fwd.npass; ++i)
+        if (fwd.pass[i].ra <= 0) return false;
+    inv.L = fwd.L;
+    inv.npass = fwd.npass;
+    size_t off = fwd.table_elems;
+    long long P = 1;
+    for (int i = 0; i < fwd.npass; ++i) {
+        const mr_pass_desc &r = fwd.pass[fwd.npass - 1 - i];
+        mr_fill_pass(inv, i, r.R, r.ra, r.rb, P, off);
+        P *= r.R;
+    }
+    inv.table_elems = off;
+    return true;
+}
+
 struct mr_plan_cache {
     mr_plan_host h;
+    mr_plan_host hinv;          // the same radices in the reverse order (inverse behind the fused spectral pass); npass 0: not available
     wfx_devbuf tables;
     bool use_mr2 = true;        // WFX_MR2=0 in the environment forces the per-prime LDS stages (A/B comparisons)
 };
 static std::map<std::pair<const void *, long long>, mr_plan_cache> g_mr_plans;   // per (context, L)
 static std::mutex g_mr_mutex;
+
+// "7x13,7x25,15x15" (pairs) / "98" (per-prime radix) of the plan for L; empty when L is not 13-smooth (diagnostics, tools/)
+extern "C" int wfx_debug_plan(uint64_t L, char *buf, int cap)
+{
+    mr_plan_host pl;
+    if (!buf || cap < 2) return -1;
+    buf[0] = 0;
+    if (!mr_make_plan((long long)L, pl)) return 0;
+    int n = 0;
+    for (int i = 0; i < pl.npass; ++i) {
+        const mr_pass_desc &d = pl.pass[i];
+        n += d.ra > 0 ? snprintf(buf + n, cap - n, "%s%dx%d", i ? "," : "", d.ra, d.rb) : snprintf(buf + n, cap - n, "%s%d", i ? "," : "", d.R);
+        if (n >= cap - 1) break;
+    }
+    return pl.npass;
+}
 
 bool wfx_mr_supported(uint64_t L)
 {
@@ -934,13 +1043,22 @@ static int mr_get_plan(wfx_ctx *ctx, long long L, mr_plan_cache **out)
         const char *e = getenv("WFX_MR2");
         pc.use_mr2 = !(e && e[0] == '0');
     }
-    WFX_TRY(wfx_reserve(ctx, pc.tables, pc.h.table_elems * sizeof(cplx)));
+    const bool have_inv = pc.use_mr2 && !getenv("WFX_NO_FUSED_SPECTRUM") && mr_make_reverse(pc.h, pc.hinv);
+    if (!have_inv) pc.hinv.npass = 0;
+    WFX_TRY(wfx_reserve(ctx, pc.tables, (have_inv ? pc.hinv.table_elems : pc.h.table_elems) * sizeof(cplx)));
     for (int i = 0; i < pc.h.npass; ++i) {
         const long long mod = pc.h.pass[i].P * pc.h.pass[i].R;
         const int nhi = (int)(mod >> MR_LO_BITS) + 2;
         const int n = nhi > MR_LO ? nhi : MR_LO;
         cplx *base = (cplx *)pc.tables.p;
         WFX_LAUNCH(ctx, K_BS_CHIRP, mr_fill_tables, dim3((n + 255) / 256), dim3(256), base + pc.h.lo_off[i], base + pc.h.hi_off[i], mod, nhi);
+    }
+    for (int i = 0; have_inv && i < pc.hinv.npass; ++i) {
+        const long long mod = pc.hinv.pass[i].P * pc.hinv.pass[i].R;
+        const int nhi = (int)(mod >> MR_LO_BITS) + 2;
+        const int n = nhi > MR_LO ? nhi : MR_LO;
+        cplx *base = (cplx *)pc.tables.p;
+        WFX_LAUNCH(ctx, K_BS_CHIRP, mr_fill_tables, dim3((n + 255) / 256), dim3(256), base + pc.hinv.lo_off[i], base + pc.hinv.hi_off[i], mod, nhi);
     }
     {
         const int nhi = (int)(L >> MR_LO_BITS) + 2;
@@ -985,6 +1103,8 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 1 && in_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 0 && out_mode == 2 && in_mode == 0)                                                                          \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 1 && out_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 0 && out_mode == 0)                                                                          \
@@ -1126,13 +1246,17 @@ int wfx_mr_fill_table(wfx_ctx *ctx, cplx *base, long long mod)
 // writes to `final_dst` when given.  hilbert: the packed-real load swap on the first forward pass and the multiplication
 // by the Hilbert spectrum on the last one.  Unnormalised; natural order in and out (self-sorting passes).
 static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cplx *B, int dir, bool hilbert, cplx *final_dst, cplx **result,
-                  bool src_i16 = false)
+                  bool src_i16 = false, long long skip_lo = 0, long long skip_hi = 0)
 {
     const cplx *tb = (const cplx *)pc->tables.p;
     const int np = pc->h.npass;
     cplx *dst = (src == A) ? B : A;
     for (int i = 0; i < np; ++i) {
-        const mr_pass_desc &d = pc->h.pass[i];
+        mr_pass_desc d = pc->h.pass[i];
+        if (i == np - 1 && dir == 0 && skip_hi > skip_lo + 1 && np > 1) {      // (a first pass stores whole tiles: never skipped)
+            d.skip_lo = skip_lo;
+            d.skip_hi = skip_hi;
+        }
         const cplx *lo = tb + pc->h.lo_off[i], *hi = tb + pc->h.hi_off[i];
         const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
         const bool first = hilbert && dir == 0 && i == 0, last_fwd = hilbert && dir == 0 && i == np - 1;
@@ -1177,6 +1301,27 @@ int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_
     WFX_TRY(wfx_reserve(ctx, ctx->b_work, (size_t)L * sizeof(cplx)));
     WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (size_t)L * sizeof(cplx)));
     cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
+    if (pc->hinv.npass >= 2) {
+        // forward passes 1 .. np-1, then ONE kernel for the last forward pass + spectrum + first inverse pass (the inverse takes its
+        // radices in the reverse order, so that pass works on the same columns), then the remaining inverse passes: 2 np - 1 launches
+        const cplx *tb = (const cplx *)pc->tables.p;
+        const int np = pc->h.npass;
+        const cplx *src = (const cplx *)x;
+        cplx *dst = A;
+        for (int i = 0; i < np; ++i) {
+            const bool last = i == np - 1;
+            WFX_TRY(wfx_mr_launch_pair(ctx, pc->h.pass[i], tb + pc->h.lo_off[i], i == 0 ? 1 : 0, last ? 2 : 0, 0, src, dst));
+            src = dst;
+            dst = dst == A ? B : A;
+        }
+        for (int i = 1; i < np; ++i) {
+            WFX_TRY(wfx_mr_launch_pair(ctx, pc->hinv.pass[i], tb + pc->hinv.lo_off[i], 0, 0, 1, src, dst));
+            src = dst;
+            dst = dst == A ? B : A;
+        }
+        *V_out = (cplx *)src;
+        return 0;
+    }
     cplx *mid = nullptr;
     // the packed real input IS x viewed as complex pairs (swapped on load)
     WFX_TRY(mr_run(ctx, pc, (const cplx *)x, A, B, 0, true, nullptr, &mid));
@@ -1240,7 +1385,9 @@ int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num
     cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
     cplx *Z = nullptr;
     // (an int16 capture is read in place by the first pass: no float64 copy of the input)
-    WFX_TRY(mr_run(ctx, p1, (const cplx *)x, A, B, 0, false, nullptr, &Z, x_is_i16));
+    // down-sampling reads only the bins [0, num/2] and their mirrors [M - num/2, M) of the forward spectrum: the rest is not stored
+    const long long nmin = (long long)(n0 < num ? n0 : num), half = nmin / 2;
+    WFX_TRY(mr_run(ctx, p1, (const cplx *)x, A, B, 0, false, nullptr, &Z, x_is_i16, half, M - half));
     cplx *Wb = (Z == A) ? B : A;
     WFX_LAUNCH(ctx, K_RESAMPLE_PW, resample_mr_glue, dim3(wfx_stream_grid((uint64_t)K, 256)), dim3(256), (const cplx *)Z, (long long)n0,
                (long long)num, Wb);
