@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the judged evidence set on an MI355X box (run through gpurun from the
-# repo root):   gpurun --timeout 1500 -- 'bash tools/collect_evidence.sh r01_v17'
+# repo root):   gpurun --timeout 2400 -- 'bash tools/collect_evidence.sh r02_v1'
 # Everything lands in gpurun_out/<tag>/; copy what should be judged to profiles/<tag>/.
 set -u
 TAG=${1:-evidence}
@@ -8,20 +8,20 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 
-python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
-tail -1 "$OUT/pytest_gpu.log"
+python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1
+grep -E "passed|failed" "$OUT/pytest_gpu.log" | tail -1
 
-# un-profiled default bench line (the contract's N=1 run)
+# un-profiled default bench line (the contract's N=1 run: configs[1] + the c4_strong object)
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-cat "$OUT/bench.json"
+head -c 600 "$OUT/bench.json"; echo
 
-# per-kernel durations of the same command
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu > "$OUT/prof_bench.json" 2> "$OUT/prof_bench.err"
+# per-kernel durations of the same workload (configs[1] only: --no-c4 keeps the 22 GB stream out of the trace)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-c4 > "$OUT/prof_bench.json" 2> "$OUT/prof_bench.err"
 find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 
 # HBM traffic, one counter per pass, no trace domains besides the kernel trace
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2> "$OUT/pmc_fetch.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2> "$OUT/pmc_write.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 > /dev/null 2> "$OUT/pmc_write.err"
 python tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic.json" > "$OUT/pmc_summary.log" 2>&1
 for d in fetch write; do
   f=$(find "$OUT/pmc_$d" -name '*counter_collection.csv' | head -1)
@@ -41,29 +41,35 @@ EOF
 done
 rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write"
 
-# the other modes and configurations
-python bench.py --mode fir --no-cpu > "$OUT/bench_fir.json" 2>> "$OUT/bench.err"
+# the other configurations
 for b in 2 4 8; do python bench.py --batch $b --no-cpu > "$OUT/bench_batch$b.json" 2>> "$OUT/bench.err"; done
-WFX_BENCH_FORCE_DIST=1 python bench.py --shard --no-cpu > "$OUT/bench_shard_rccl1.json" 2>> "$OUT/bench.err"
-WFX_BENCH_FORCE_DIST=1 python bench.py --no-cpu > "$OUT/bench_forced_rccl_1rank.json" 2>> "$OUT/bench.err"
-python tools/run_config.py c3 --minutes 60 --oracle > "$OUT/c3_60min.json" 2>> "$OUT/bench.err"
-python tools/e2e.py > "$OUT/e2e_c2.json" 2>> "$OUT/bench.err"
-
-# BASELINE configs[3]: the 1.536 MS/s IQ stream.  Exact path on 30 s, halo-local path on the whole 60 minutes.
-python tools/run_config.py c4 --seconds 30 --oracle > "$OUT/c4_exact_30s.json" 2>> "$OUT/bench.err"
-python bench.py --workload iq > "$OUT/bench_iq_3600s.json" 2>> "$OUT/bench.err"
-python bench.py --workload iq --iq-rest fir --no-cpu > "$OUT/bench_iq_3600s_halo_local.json" 2>> "$OUT/bench.err"
-python bench.py --workload iq --iq-rest fir --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s.json" 2>> "$OUT/bench.err"
+# the sharded exact path with the ONE rank a one-GPU box has, over the real transport (RCCL bound by the library)
+WFX_BENCH_FORCE_DIST=1 python bench.py --shard --no-c4 > "$OUT/bench_shard_rccl1.json" 2>> "$OUT/bench.err"
 WFX_BENCH_FORCE_DIST=1 python bench.py --workload iq --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s_rccl1.json" 2>> "$OUT/bench.err"
+python bench.py --workload iq --iq-seconds 450 --no-cpu > "$OUT/bench_iq_450s_fused.json" 2>> "$OUT/bench.err"
+WFX_BENCH_FORCE_DIST=1 python bench.py --workload iq --no-cpu > "$OUT/bench_iq_3600s_rccl1.json" 2>> "$OUT/bench.err"
+# BASELINE configs[2] (60 minutes at 48 kHz) and configs[3] (60 minutes at 1.536 MS/s IQ) as lines of their own, CPU leg included
+python bench.py --workload c3 > "$OUT/bench_c3.json" 2>> "$OUT/bench.err"
+WFX_BENCH_FORCE_DIST=1 python bench.py --workload c3 --no-cpu > "$OUT/bench_c3_rccl1.json" 2>> "$OUT/bench.err"
+python bench.py --workload iq > "$OUT/bench_iq_3600s.json" 2>> "$OUT/bench.err"
+python tools/e2e.py > "$OUT/e2e_c2.json" 2>> "$OUT/bench.err"
+# every rank of 1 / 2 / 3 / 8 emulated on this GPU, against the oracle
+python tools/shard_check.py --cases plain,resample,stereo,lpm240,c2 > "$OUT/shard_check.jsonl" 2>> "$OUT/bench.err"
+python tools/shard_check2.py iq > "$OUT/shard_check_iq.jsonl" 2>> "$OUT/bench.err"
+
+# BASELINE configs[3] under the profiler
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_iq" -o run -- python3 bench.py --workload iq --steps 5 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
-python tools/kstats.py "$OUT/trace_iq" "decimate|rational|fir_hilbert|select_|notch|median|image|quantise|sync|mr2_pass|mr_pass|resample" > "$OUT/kernel_stats_iq.txt"
+python tools/kstats.py "$OUT/trace_iq" "decimate|rational|select_|notch|median|image|quantise|sync|mr2_pass|mr_pass|resample|synth|dist_" > "$OUT/kernel_stats_iq.txt"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
 python tools/pmc_summary.py "$OUT/pmc_fetch_iq" "$OUT/pmc_write_iq" "$OUT/pmc_traffic_iq.json" > /dev/null 2>&1
 rm -rf "$OUT/trace_iq" "$OUT/pmc_fetch_iq" "$OUT/pmc_write_iq"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -o run -- python3 bench.py --workload c3 --steps 5 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+python tools/kstats.py "$OUT/trace_c3" "select_|notch|median|image|quantise|sync|mr2_pass|mr_pass|resample" > "$OUT/kernel_stats_c3.txt"
+rm -rf "$OUT/trace_c3"
 
 # where the waves' cycles go (SQ counters, one pass)
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/sq" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/sq" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 > /dev/null 2>> "$OUT/bench.err"
 python tools/pmc_sq.py "$OUT/sq" > "$OUT/sq_counters.txt"
 rm -rf "$OUT/sq"
 ls -la "$OUT"

@@ -69,7 +69,8 @@ class wfx_dist {
     // rows_in: this rank's rows [nr][M] (elements of elem_bytes_in: 16 = cplx / pairs of doubles, 4 = int16 pairs)
     int fwd_pack_exchange(wfx_comm *c, const void *rows_in);                       // E1
     int fwd_pass1_exchange(wfx_comm *c, int in_mode);                              // pass 1, E2
-    int fwd_slab(int hilbert_spectrum, cplx **spectrum);                           // passes 2..np
+    // passes 2..np; bins with skip_lo < k < skip_hi (global indices) are not stored by the last one (skip_hi == 0: all are)
+    int fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo = 0, long long skip_hi = 0);
     // ---- inverse ---------------------------------------------------------------------------------------------------
     // slab_in: [M][B] in one of slab_buffer(0 / 1); destroyed
     int inv_slab_exchange(wfx_comm *c, cplx *slab_in);                             // passes np..2, E3

@@ -497,13 +497,18 @@ int wfx_dist::fwd_pass1_exchange(wfx_comm *c, int in_mode)
     return wfx_comm_exchange(c, ctx, x2.data(), (int)x2.size());
 }
 
-int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum)
+int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo, long long skip_hi)
 {
     const cplx *tb = (const cplx *)tables.p;
     cplx *src = (cplx *)b_a.p, *dst = (cplx *)b_a2.p;
     const int ns = (int)d_fwd.size();
     for (int i = 0; i < ns; ++i) {
-        WFX_TRY(wfx_mr_launch(ctx, d_fwd[i], tb + tw_fwd[i], 0, (hilbert_spectrum && i == ns - 1) ? 1 : 0, 0, src, dst));
+        mr_pass_desc d = d_fwd[i];
+        if (i == ns - 1 && !hilbert_spectrum && skip_hi > skip_lo + 1) {
+            d.skip_lo = skip_lo;
+            d.skip_hi = skip_hi;
+        }
+        WFX_TRY(wfx_mr_launch(ctx, d, tb + tw_fwd[i], 0, (hilbert_spectrum && i == ns - 1) ? 1 : 0, 0, src, dst));
         std::swap(src, dst);
     }
     *spectrum = src;

@@ -299,7 +299,10 @@ mr_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, con
             const int j = j0 + cc;
             const int k = P > 1 ? j % P : 0;
             const long long o = (long long)(j - k) * R + k + (long long)q * P;
-            if (d.skip_hi && o > d.skip_lo && o < d.skip_hi) return;
+            if (d.skip_hi) {
+                const long long os = mr_global_index(d, o);
+                if (os > d.skip_lo && os < d.skip_hi) return;
+            }
             if (OUT_MODE == 1) {
                 // G[o] / L,  G[k] = -i exp(-i pi k / L) = (-sin, -cos)(pi k / L), G[0] = 0  (o: the GLOBAL frequency index)
                 const long long og = mr_global_index(d, o);
@@ -709,7 +712,10 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                     }
                     auto emit = [&](int qb, cplx y) {
                         const long long o = obase + (long long)qb * ostep;
-                        if (OUT_MODE == 0 && d.skip_hi && o > d.skip_lo && o < d.skip_hi) return;
+                        if (OUT_MODE == 0 && d.skip_hi) {          // (the range is given in GLOBAL bin indices)
+                            const long long os = mr_global_index(d, o);
+                            if (os > d.skip_lo && os < d.skip_hi) return;
+                        }
                         if (OUT_MODE == 1) {
                             // times G[o] / L, G[o] = -i exp(-i pi o / L) (G[0] = 0) = g0 * gstep^qb: the powers of the
                             // (kernel-uniform) step come from LDS, the start from one sincospi per thread

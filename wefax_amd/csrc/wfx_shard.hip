@@ -167,7 +167,9 @@ static int run_phase(wfx_shard *sh, int ph)
     case 1: return sh->dF.fwd_pass1_exchange(c, pl.in_kind == WFX_IN_I16_MONO ? 2 : 0);
     case 2: {   // spectrum -> scipy.signal.resample's bin copy -> inverse transform's slab passes
         cplx *Z = nullptr;
-        WFX_TRY(sh->dF.fwd_slab(0, &Z));
+        // down-sampling reads the bins [0, n/2] and their mirrors only: the last forward pass does not store the rest
+        const long long nmin = (long long)(pl.n0 < pl.n ? pl.n0 : pl.n), half = nmin / 2;
+        WFX_TRY(sh->dF.fwd_slab(0, &Z, half, pl.M1 - half));
         WFX_TRY(wfx_dist_resample_glue(ctx, pl.g, Z, (long long)pl.n0, (long long)pl.n, sh->dI.slab_buffer(0)));
         return sh->dI.inv_slab_exchange(c, sh->dI.slab_buffer(0));
     }
