@@ -508,7 +508,8 @@ int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo,
             d.skip_lo = skip_lo;
             d.skip_hi = skip_hi;
         }
-        WFX_TRY(wfx_mr_launch(ctx, d, tb + tw_fwd[i], 0, (hilbert_spectrum && i == ns - 1) ? 1 : 0, 0, src, dst));
+        const bool skipping = d.skip_hi != 0;
+        WFX_TRY(wfx_mr_launch(ctx, d, tb + tw_fwd[i], 0, (hilbert_spectrum && i == ns - 1) ? 1 : ((skipping && d.ra > 0) ? 3 : 0), 0, src, dst));
         std::swap(src, dst);
     }
     *spectrum = src;

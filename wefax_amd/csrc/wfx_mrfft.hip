@@ -500,7 +500,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
          int ntiles)
 {
     constexpr int LOG2T = mr2_log2t(RA * RB);
-    constexpr int PF = (mr2_prefetch(RA, RB) && OUT_MODE == 0) ? 1 : 0;
+    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3)) ? 1 : 0;
     constexpr int R = RA * RB, T = 1 << LOG2T;
     constexpr int NA = (T * RB + 255) / 256, NB = (T * RA + 255) / 256;
     constexpr bool inv = INVERSE != 0;
@@ -712,7 +712,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                     }
                     auto emit = [&](int qb, cplx y) {
                         const long long o = obase + (long long)qb * ostep;
-                        if (OUT_MODE == 0 && d.skip_hi) {          // (the range is given in GLOBAL bin indices)
+                        if (OUT_MODE == 3) {                       // plain forward pass that leaves a range of (GLOBAL) bins unstored
                             const long long os = mr_global_index(d, o);
                             if (os > d.skip_lo && os < d.skip_hi) return;
                         }
@@ -1111,6 +1111,8 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 2 && in_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 0 && out_mode == 3 && in_mode == 0)                                                                          \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 3, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 1 && out_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 0 && out_mode == 0)                                                                          \
@@ -1271,7 +1273,9 @@ static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cpl
         // register-resident two-level pass when the radix is a pair (mr2_pass); per-prime LDS stages otherwise
         bool done = false;
         if (pc->use_mr2 && d.ra > 0 && !(first && last_fwd)) {
-            WFX_TRY(wfx_mr_launch_pair(ctx, d, lo, first16 ? 2 : (first ? 1 : 0), last_fwd ? 1 : 0, dir, src, dst));
+            const bool skipping = d.skip_hi != 0 && !first16 && !first && !last_fwd;      // the pair kernels skip in a variant of their own
+            if (!skipping) d.skip_lo = d.skip_hi = 0;
+            WFX_TRY(wfx_mr_launch_pair(ctx, d, lo, first16 ? 2 : (first ? 1 : 0), last_fwd ? 1 : (skipping ? 3 : 0), dir, src, dst));
             done = true;
         }
         if (!done) {
