@@ -204,6 +204,21 @@ int wfx_decode_device_ptr(wfx_ctx *ctx, int buffer_id, void **dev_ptr, size_t *b
  * collective) and wait for it; at most `capacity` bytes, *copied receives the size */
 int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t capacity, size_t *copied);
 
+/* save_output_image (wefax.py:407-408) without the host-side encoder: the PNG file of the decode's image -- 8-bit gray, width x 4 height,
+ * no interlace, filter 0, STORED deflate blocks (valid PNG, identical pixels, not compressed) -- is assembled on the device (stream layout,
+ * Adler-32 row sums, CRC-32 segments) and finished on the host in closed form.  wfx_decode_png returns the file image in pinned
+ * memory owned by the context (valid until the next call); wfx_decode_save_png writes it to `path`. */
+int wfx_decode_png(wfx_ctx *ctx, const void **file_bytes, size_t *nbytes);
+int wfx_decode_save_png(wfx_ctx *ctx, const char *path, size_t *bytes_written);
+/* page-locked host memory: captures uploaded from it and images fetched into it cross PCIe by DMA (no staging copies) */
+void *wfx_host_alloc(size_t bytes);
+void  wfx_host_free(void *p);
+/* copy a new capture of the same description into the context (asynchronous when host_in is pinned memory) */
+int wfx_decode_reload(wfx_ctx *ctx, const void *host_in);
+/* enqueue a copy of a stage buffer to the host WITHOUT waiting (host_out should be pinned); wfx_sync / wfx_decode_result waits.
+ * For WFX_BUF_IMAGE `bytes` must be >= the largest possible image (4 * width * (n / width)); the height arrives with the result. */
+int wfx_decode_fetch_async(wfx_ctx *ctx, int buffer_id, void *host_out, size_t bytes);
+
 /* Let the NEXT decodes write {int64 bytes, int64 width, image} straight into caller-owned device memory (e.g. the send
  * slot of a collective): no copy after the decode, wfx_decode_export_async of WFX_BUF_IMAGE to the same address becomes
  * a no-op.  Used when capacity >= 16 + 4 * width * (n / width); NULL unbinds.  The pointer must stay valid while

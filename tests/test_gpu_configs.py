@@ -186,6 +186,26 @@ def test_command_line_wav_to_png(name, lpm, tmp_path):
         pass
 
 
+def test_png_assembled_on_the_device_and_the_compressed_alternative(tmp_path):
+    """save_output_image: by default the file comes from wfx_decode_save_png (stored deflate blocks, Adler-32 and CRC-32 from
+    kernels: zlib and the chunk reader below verify both); compress=6 takes the threaded zlib encoder.  Same pixels either way,
+    and a context that has moved on to another decode falls back to encoding the host copy."""
+    from wefax_amd import Demodulator
+    g = np.load(os.path.join(GOLDEN, "mono_noisy_120.npz"))
+    d = Demodulator(os.path.join(GOLDEN, "inputs", "mono_noisy_120.wav"), lines_per_minute=120, quiet=True)
+    d.process()
+    a, b, c = str(tmp_path / "a.png"), str(tmp_path / "b.png"), str(tmp_path / "c.png")
+    d.save_output_image(a)
+    d.save_output_image(b, compress=6)
+    assert os.path.getsize(a) > d.output_array.size and os.path.getsize(b) < os.path.getsize(a)
+    blob = d._ctx.decode_png()
+    assert blob == open(a, "rb").read()
+    d._ctx.notch_filtfilt(np.zeros(100), [1.0, 0.0, 0.0], [1.0, 0.0, 0.0])      # the context forgets the decode ...
+    d.save_output_image(c)                                                       # ... and the host copy is encoded instead
+    for path in (a, b, c):
+        assert np.array_equal(_read_png_gray8(path), g["image"]), path
+
+
 def test_command_line_rejects_what_the_reference_rejects(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(REPO, "wefax.py"), str(tmp_path / "missing.wav"), "120", str(tmp_path / "o.png")],
                        capture_output=True, text=True, timeout=120)

@@ -34,7 +34,8 @@ SYMBOLS = [
     "wfx_comm_barrier", "wfx_comm_allgather_host",
     "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
     "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
-    "wfx_synth_frames", "wfx_synth_capture",
+    "wfx_synth_frames", "wfx_synth_capture", "wfx_decode_png", "wfx_decode_save_png", "wfx_host_alloc", "wfx_host_free",
+    "wfx_decode_reload", "wfx_decode_fetch_async",
     "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
     "wfx_profile_kernel_count", "wfx_profile_kernel_name", "wfx_profile_get",
 ]
@@ -202,6 +203,14 @@ def load():
     lib.wfx_shard_result.argtypes = [vp, C.POINTER(DecodeInfo)]
     lib.wfx_shard_fetch.argtypes = [vp, i, vp, sz]
     lib.wfx_shard_destroy.argtypes = [vp]
+    lib.wfx_decode_png.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    lib.wfx_decode_save_png.argtypes = [vp, C.c_char_p, C.POINTER(sz)]
+    lib.wfx_host_alloc.argtypes = [sz]
+    lib.wfx_host_alloc.restype = vp
+    lib.wfx_host_free.argtypes = [vp]
+    lib.wfx_host_free.restype = None
+    lib.wfx_decode_reload.argtypes = [vp, vp]
+    lib.wfx_decode_fetch_async.argtypes = [vp, i, vp, sz]
     lib.wfx_synth_frames.argtypes = [C.POINTER(SynthParams)]
     lib.wfx_synth_frames.restype = C.c_uint64
     lib.wfx_synth_capture.argtypes = [vp, C.POINTER(SynthParams), C.c_uint64, C.c_uint64, vp]
@@ -215,7 +224,7 @@ def load():
     lib.wfx_profile_get.argtypes = [vp, i, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("wfx_device_count", "wfx_profile_kernel_count", "wfx_synth_frames"):
+        if fn.restype is C.c_int and name not in ("wfx_device_count", "wfx_profile_kernel_count", "wfx_synth_frames", "wfx_host_alloc", "wfx_host_free"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -348,6 +357,27 @@ class Context:
         info = DecodeInfo()
         self._check(self.lib.wfx_decode_result(self.h, C.byref(info)))
         return info
+
+    def decode_reload(self, data: np.ndarray):
+        """A new capture of the same description into the context (DMA when ``data`` is pinned: ``pinned_empty``)."""
+        data = np.ascontiguousarray(data)
+        self._keep = data
+        self._check(self.lib.wfx_decode_reload(self.h, _ptr(data)))
+
+    def decode_fetch_async(self, buffer_id: int, out: np.ndarray):
+        """Enqueue the copy of a stage buffer into ``out`` (pinned) without waiting; ``sync()`` / ``decode_result()`` waits."""
+        self._check(self.lib.wfx_decode_fetch_async(self.h, buffer_id, _ptr(out), out.nbytes))
+
+    def decode_png(self) -> bytes:
+        """The PNG file of the decode's image (8-bit gray, stored deflate blocks), assembled on the device."""
+        p, n = C.c_void_p(0), C.c_size_t(0)
+        self._check(self.lib.wfx_decode_png(self.h, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value)
+
+    def decode_save_png(self, path: str) -> int:
+        n = C.c_size_t(0)
+        self._check(self.lib.wfx_decode_save_png(self.h, os.fsencode(path), C.byref(n)))
+        return int(n.value)
 
     def decode_bind_image(self, dst_ptr: int, capacity: int):
         """The next decodes write {header, image} straight to this device address (0 unbinds)."""
@@ -673,6 +703,30 @@ class Shard:
             self.close()
         except Exception:
             pass
+
+
+class _Pinned:
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self.lib.wfx_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """NumPy array in page-locked host memory (wfx_host_alloc): uploads from it and fetches into it run at DMA speed."""
+    lib = load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = lib.wfx_host_alloc(max(n, 1))
+    if not ptr:
+        raise _global_error(lib, -3)
+    buf = (C.c_char * max(n, 1)).from_address(ptr)
+    buf._owner = _Pinned(lib, ptr)                 # freed when the array (and every view of it) is gone
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
 def device_count() -> int:

@@ -276,6 +276,37 @@ int wfx_decode_upload(wfx_ctx *ctx, const void *host_in, const wfx_decode_params
     return 0;
 }
 
+int wfx_decode_reload(wfx_ctx *ctx, const void *host_in)
+{
+    CHECK_CTX(ctx);
+    if (!host_in) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    if (!ctx->have_input || ctx->ext_in) return wfx_fail(ctx, WFX_ERR_STATE, "decode_reload needs a capture uploaded with wfx_decode_upload");
+    return h2d(ctx, ctx->b_in.p, host_in, in_bytes(&ctx->dp));
+}
+
+int wfx_decode_fetch_async(wfx_ctx *ctx, int buffer_id, void *host_out, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->ran) return wfx_fail(ctx, WFX_ERR_STATE, "no decode has been enqueued on this context");
+    if (!host_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    const uint64_t n = ctx->dp.n;
+    const void *src = nullptr;
+    size_t nb = 0;
+    switch (buffer_id) {
+    case WFX_BUF_AUDIO: src = ctx->b_audio.p; nb = n * 8; break;
+    case WFX_BUF_ENVELOPE: src = ctx->b_env.p; nb = n * 8; break;
+    case WFX_BUF_DIGITAL: src = ctx->b_dig.p; nb = n; break;
+    case WFX_BUF_IMAGE:
+        src = ctx->img_in_ext ? (const void *)((const char *)ctx->ext_img + 16) : ctx->b_img.p;
+        nb = (size_t)ctx->dp.width * 4 * (size_t)(n / (uint64_t)ctx->dp.width);
+        break;
+    default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown buffer id %d", buffer_id);
+    }
+    if (bytes < nb) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fetch_async: %zu bytes needed, %zu given", nb, bytes);
+    if (nb) WFX_HIP(ctx, hipMemcpyAsync(host_out, src, nb, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
 int wfx_decode_attach(wfx_ctx *ctx, const void *dev_in, const wfx_decode_params *p)
 {
     CHECK_CTX(ctx);

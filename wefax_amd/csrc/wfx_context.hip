@@ -129,7 +129,8 @@ void wfx_destroy(wfx_ctx *ctx)
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     wfx_devbuf *bufs[] = {&ctx->b_in, &ctx->b_x, &ctx->b_audio, &ctx->b_work, &ctx->b_work2, &ctx->b_envraw,
                           &ctx->b_env, &ctx->b_dig, &ctx->b_corr, &ctx->b_img, &ctx->b_hist, &ctx->b_tmp,
-                          &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps, &ctx->b_cand, &ctx->b_pcoef, &ctx->b_seg};
+                          &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps, &ctx->b_cand, &ctx->b_pcoef, &ctx->b_seg, &ctx->b_png};
+    if (ctx->h_png) hipHostFree(ctx->h_png);
     for (auto *b : bufs) free_buf(*b);
     for (auto &kv : ctx->plans) free_buf(kv.second.bhat);
     for (auto &kv : ctx->hplans) free_buf(kv.second.bhat);
@@ -154,6 +155,22 @@ int wfx_sync(wfx_ctx *ctx)
     if (!ctx) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null context");
     WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+// pinned (page-locked) host memory for captures and images that cross PCIe at DMA speed
+void *wfx_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        wfx_fail(nullptr, WFX_ERR_OOM, "pinned host allocation of %zu bytes failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void wfx_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int wfx_timer_start(wfx_ctx *ctx)

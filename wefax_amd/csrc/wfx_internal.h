@@ -81,7 +81,9 @@ struct wfx_ctx {
 
     // named device buffers (grown on demand, reused across calls)
     wfx_devbuf b_in, b_x, b_audio, b_work, b_work2, b_envraw, b_env, b_dig, b_corr,
-        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand, b_pcoef, b_seg;
+        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand, b_pcoef, b_seg, b_png;
+    void *h_png = nullptr;        // pinned host image of the last PNG file (wfx_decode_png)
+    size_t h_png_cap = 0;
     bool w256_ready = false;
     void *ext_img = nullptr;     // wfx_decode_bind_image: {16-byte header, image} target owned by the caller (a collective's send slot)
     size_t ext_img_cap = 0;

@@ -116,6 +116,17 @@ class DecodeJob:
         job.info = None
         return job
 
+    def reload(self, data: np.ndarray):
+        """Another capture of the same shape and dtype into the same job (no plan or buffer is rebuilt).  From an array in
+        pinned memory (``_native.pinned_empty``) the copy is a DMA enqueued on the stream."""
+        self.ctx.decode_reload(data)
+        self.info = None
+
+    def fetch_image_async(self, out: np.ndarray):
+        """Enqueue the copy of the image into ``out`` (uint8, at least 4 * width * (n // width) bytes, ideally pinned); the rows
+        that exist are known with ``result()``: ``out.reshape(-1)[:4 * info.height * info.width]``."""
+        self.ctx.decode_fetch_async(nat.WFX_BUF_IMAGE, out)
+
     def run(self):
         """Enqueue the whole path (asynchronous)."""
         self.ctx.decode_run()
@@ -191,6 +202,7 @@ class Demodulator:
         phasing group closes (wefax.py:294) or when the envelope is constant
         (int(nan), wefax.py:216)."""
         self._cache = {}
+        self._image_shape = None
         sample_rate, data = hp.read_wav(self.filepath)                      # wefax.py:349
         if data.ndim == 2:                                                  # wefax.py:351-355
             self._say("\033[0;33mWARNING: two channels audio detected. Program will try to merge audio to one channel\033[0m")
@@ -251,13 +263,9 @@ class Demodulator:
             for py in range(0, h, 50):                                      # wefax.py:307-313
                 self._progress("converting signal to image", (py + 1) / h * 100)
             self._progress("converting signal to image", 100)               # wefax.py:316-322
-        pixels = job.fetch("image")
-        self.output_array = pixels
-        try:
-            from PIL import Image
-            self.output_image = Image.fromarray(pixels, mode="L")
-        except ImportError:                                                 # Pillow optional
-            self.output_image = None
+        # the image stays in HBM until somebody looks at it (``output_array`` / ``output_image`` fetch it on first access;
+        # ``save_output_image`` writes the PNG straight from the device)
+        self._image_shape = (4 * h, w)
         if self.stream:                                                     # wefax.py:87-90
             self._send_websocket_packet({"data_type": "message",
                                          "message_content": "convert_end"})
@@ -269,6 +277,22 @@ class Demodulator:
                 raise AttributeError(key)
             self._cache[key] = self._job.fetch(key)
         return self._cache[key]
+
+    @property
+    def output_array(self):          # uint8 [4h, w]: the pixels of ``output_image``
+        if getattr(self, "_image_shape", None) is None:
+            raise AttributeError("output_array")
+        return self._lazy("image")
+
+    @property
+    def output_image(self):          # wefax.py:85: PIL Image, mode 'L', size (w, 4h)
+        if "pil" not in self._cache:
+            try:
+                from PIL import Image
+                self._cache["pil"] = Image.fromarray(self.output_array, mode="L")
+            except ImportError:                                             # Pillow optional
+                self._cache["pil"] = None
+        return self._cache["pil"]
 
     @property
     def audio_data(self):            # after merge / resample / notch (wefax.py:72)
@@ -294,13 +318,24 @@ class Demodulator:
         plt.imshow(self.output_image, cmap='gray')
         plt.show()
 
-    def save_output_image(self, filepath: str):                             # wefax.py:407-408
-        """Same file the reference writes (8-bit gray PNG, w x 4h, identical pixels).  For .png
-        the multi-threaded encoder of wefax_amd/pngio.py is used -- PIL's single-threaded zlib
-        would otherwise dominate the whole decode; other formats go through PIL like the reference."""
-        if filepath.lower().endswith(".png") and getattr(self, "output_array", None) is not None:
+    def save_output_image(self, filepath: str, compress: int | None = None):   # wefax.py:407-408
+        """Same picture the reference writes (8-bit gray PNG, w x 4h, identical pixels).  Encoding 27 MB on the host used to
+        dominate the whole file-to-file time (PIL: 1.6 s; threaded zlib: 55 ms; the kernels: 0.35 ms), so by default the PNG is
+        assembled ON THE DEVICE from the image still resident there (``wfx_decode_save_png``: stored deflate blocks -- valid PNG,
+        not compressed -- Adler-32 / CRC-32 computed by kernels).  ``compress`` = 1..9 (or WEFAX_PNG_COMPRESS in the environment)
+        selects the threaded zlib encoder of wefax_amd/pngio.py instead: smaller file, ~50 ms more.  Other formats go through
+        PIL like the reference."""
+        if filepath.lower().endswith(".png") and getattr(self, "_image_shape", None) is not None:
+            if compress is None and os.environ.get("WEFAX_PNG_COMPRESS"):
+                compress = int(os.environ["WEFAX_PNG_COMPRESS"])
+            if not compress and self._ctx is not None and self._job is not None:
+                try:
+                    self._ctx.decode_save_png(filepath)
+                    return
+                except nat.NativeError:
+                    pass                    # the context has moved on to another decode: encode the host copy instead
             from .pngio import write_png_gray8
-            write_png_gray8(filepath, self.output_array)
+            write_png_gray8(filepath, self.output_array, level=compress or 1)
             return
         if self.output_image is None:
             raise RuntimeError("Pillow is not installed: cannot write " + filepath)
