@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--iq-form", choices=["auto", "fused", "sharded"], default="auto",
                     help="one GPU: the fused exact decode behind the front end (auto) or the sharded form with one rank")
     ap.add_argument("--no-c4", action="store_true", help="c2: leave the c4_strong object out (quick runs)")
+    ap.add_argument("--no-pcie", action="store_true", help="c2: skip the PCIe-inclusive leg (it runs two decodes concurrently: keep it out of kernel profiles)")
     ap.add_argument("--batch", type=int, default=1,
                     help="captures decoded concurrently per GPU, one native context (= HIP stream) each; "
                          "BASELINE configs[4] uses 8 per GPU with mixed 120/240 LPM, IOC576/288 members")
@@ -440,7 +441,7 @@ def bench_c2(args, rk: Ranks) -> dict:
         out["kernels"] = kernel_table(prof, args.steps)
     # host buffers in -> host image out (PCIe both ways): the capture in pinned host memory, uploaded by DMA, decoded, the image
     # copied back into pinned memory -- every step enqueued, one wait per capture.  Never `value`.
-    if rk.rank == 0 and not args.shard:
+    if rk.rank == 0 and not args.shard and not args.no_pcie:
         xin = nat.pinned_empty(x.shape, x.dtype)
         xin[...] = x
         img_host = nat.pinned_empty((4 * (n // job.width) * job.width,), np.uint8)

@@ -488,6 +488,9 @@ constexpr bool mr2_prefetch(int ra, int rb)
 {
     const int t = 1 << mr2_log2t(ra * rb);
     const int na = (t * rb + 255) / 256;
+#ifdef WFX_EXP_R25
+    if (rb == 25 || ra == 25) return true;
+#endif
     return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) <= 140;      // registers: a tile in flight + a level-B transform
 }
 
@@ -495,7 +498,12 @@ constexpr bool mr2_prefetch(int ra, int rb)
 #define WFX_FUSED_LB 2
 #endif
 template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
-__global__ void __launch_bounds__(256, OUT_MODE == 2 ? WFX_FUSED_LB : 2)
+#ifdef WFX_EXP_R25
+#define WFX_R25_LB(RA, RB) (((RA) == 25 || (RB) == 25) ? 1 : 2)
+#else
+#define WFX_R25_LB(RA, RB) 2
+#endif
+__global__ void __launch_bounds__(256, OUT_MODE == 2 ? WFX_FUSED_LB : WFX_R25_LB(RA, RB))
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
          int ntiles)
 {
@@ -1049,7 +1057,13 @@ static int mr_get_plan(wfx_ctx *ctx, long long L, mr_plan_cache **out)
         const char *e = getenv("WFX_MR2");
         pc.use_mr2 = !(e && e[0] == '0');
     }
-    const bool have_inv = pc.use_mr2 && !getenv("WFX_NO_FUSED_SPECTRUM") && mr_make_reverse(pc.h, pc.hinv);
+    // The fused spectral pass (last forward + first inverse pass in one kernel, inverse radices reversed) saves one trip of the
+    // array through memory.  That pays where the array lives in HBM (the 60-minute captures: 317 MB per array, -30 us of 1140);
+    // on the 10-minute capture (57 MB, Infinity-Cache resident) the passes are bound by their on-chip work and the two orders
+    // measure 161 against 158 us, so the classic order stays there.  WFX_FUSED_SPECTRUM=1 / 0 forces it on / off.
+    const char *fe = getenv("WFX_FUSED_SPECTRUM");
+    const bool want_fused = fe ? fe[0] != '0' : L >= (1ll << 23);
+    const bool have_inv = pc.use_mr2 && want_fused && mr_make_reverse(pc.h, pc.hinv);
     if (!have_inv) pc.hinv.npass = 0;
     WFX_TRY(wfx_reserve(ctx, pc.tables, (have_inv ? pc.hinv.table_elems : pc.h.table_elems) * sizeof(cplx)));
     for (int i = 0; i < pc.h.npass; ++i) {
