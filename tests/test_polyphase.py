@@ -209,11 +209,11 @@ def _oracle(x, fs, lpm):
         return wo.process(path, lpm, want_messages=False)
 
 
-# What separates these decodes from the reference is the front end alone (flat filters to 22 050 Hz, fp32 stencils): the
-# exact FFT resampler applies the reference's own brick wall and everything after it is the exact path.  Measured on
-# MI355X (profiles/r02): uint8 stream max |d| 1 on 0.3 % of the samples, image max |d| 2 on < 10 pixels of 1.7 M (the
-# bicubic's overshoot on neighbouring +-1), start_frame and peaks equal.  Tolerances below are those figures.
-STREAM_MAX, STREAM_NE_FRAC, IMAGE_MAX, IMAGE_GT1_FRAC = 1, 0.006, 2, 2e-5
+# What separates these decodes from the reference is the front end alone (flat filters to 22 050 Hz with 135 dB stop bands, fp32
+# stencils): the exact FFT resampler applies the reference's own brick wall and everything after it is the exact path.
+# Measured on MI355X (tools/fe_att_sweep.py): the uint8 stream differs by 1 on 19 of 441 000 samples, the image by at most 1 --
+# the north star's bar -- with start_frame equal.  The tolerances below are that bar and ten times the measured count.
+STREAM_MAX, STREAM_NE_FRAC, IMAGE_MAX, IMAGE_GT1_FRAC = 1, 5e-4, 1, 0.0
 
 
 @pytest.mark.gpu
@@ -237,7 +237,7 @@ def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds
         assert got.shape == want.shape and d.max() <= mx
         if frac is not None:
             assert np.count_nonzero(d) <= frac * d.size
-    assert np.count_nonzero(np.abs(img1.astype(np.int16) - ref["image"].astype(np.int16)) > 1) <= max(1, IMAGE_GT1_FRAC * img1.size)
+    assert np.count_nonzero(np.abs(img1.astype(np.int16) - ref["image"].astype(np.int16)) > 1) <= IMAGE_GT1_FRAC * img1.size
     first = None
     for world in (1, 2, 3, 8):
         mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, x, lines_per_minute=lpm)      # noqa: E731

@@ -24,11 +24,17 @@ it fits.
 """
 from __future__ import annotations
 
+import os
 from fractions import Fraction
 
 import numpy as np
 
 TARGET_RATE = 11025
+# Stop-band attenuation of every stage.  What separates a decode behind this front end from the reference is what aliases into
+# 0..5512.5 Hz: measured on a 40-s noisy 1.536 MS/s IQ clip (tools/fe_att_sweep.py, fp32 kernels) -- 90 dB: 1293 of 441 000 stream
+# bytes differ by 1 and 9 pixels by 2; 105 dB: 276 / 1; 120 dB: 45 / 1; 135 dB: 19 / 0 (image max |delta| 1); 150 dB: 16 / 0, where
+# fp32 accumulation is the floor and the first stage turns compute-bound (+1.9 ms on the 60-minute stream against +0.5 ms at 135).
+DEFAULT_ATT_DB = 135.0
 NYQ = TARGET_RATE / 2.0          # 5512.5 Hz: everything the reference's brick wall keeps
 
 
@@ -98,7 +104,7 @@ class Rational:
 class FrontEnd:
     """Stage chain from ``fs_in`` to 11 025 Hz and the index bookkeeping around it."""
 
-    def __init__(self, fs_in: int, att_db: float = 90.0, pass_hz: float = 5300.0, stop_at_2x: bool = False):
+    def __init__(self, fs_in: int, att_db: float | None = None, pass_hz: float = 5300.0, stop_at_2x: bool = False):
         """``pass_hz``: edge of the flat pass band of the last stage (its stop band starts at 5512.5 Hz): 5300 Hz
         costs 595 taps at 22.05 kHz.  What lies between ``pass_hz`` and 5512.5 Hz is what the reference keeps and
         this front end drops (tests/test_polyphase.py prints the resulting error figures).
@@ -107,6 +113,9 @@ class FrontEnd:
         count): on ONE GPU the exact FFT resampler then takes the last factor of two, i.e. the reference's own brick
         wall at 5512.5 Hz, and only the wide, flat filters of the earlier stages separate the result from it."""
         self.stop_at_2x = bool(stop_at_2x)
+        if att_db is None:
+            att_db = float(os.environ.get("WFX_FE_ATT", DEFAULT_ATT_DB))
+        self.att_db = att_db
         if int(fs_in) != fs_in or fs_in < 4 * TARGET_RATE:
             raise ValueError(f"the time-domain front end needs an integer rate >= 44100 Hz, not {fs_in}; use the exact FFT resampler")
         self.fs_in = int(fs_in)
