@@ -189,3 +189,28 @@ def test_fast_png_writer_round_trips_through_pillow(tmp_path):
     assert np.array_equal(np.asarray(Image.open(__import__("io").BytesIO(pngio.encode_png_gray8(smooth, threads=1)))), smooth)
     with pytest.raises(ValueError):
         pngio.encode_png_gray8(np.zeros((0, 4), np.uint8))
+
+
+def test_detector_settings_come_from_the_config_file(tmp_path, monkeypatch):
+    """data_packet.py:21-42 reads tones_settings / sync_pulse_settings from config/config.json in the working directory; so does the
+    packet class here (shipped values when the file is absent, an error when it is malformed)."""
+    import json
+    from wefax_amd import detect
+    assert hp.load_detector_settings(str(tmp_path / "none.json")) == (None, None)
+    cfg = {"notch_filter_settings": {"notch_filter_frequency": 2500, "notch_filter_quality_factor": 2},
+           "tones_settings": {"start_tone_peaks_minimum_distance": 111, "stop_tone_peaks_minimum_distance": 222, "peaks_minimum_distance": 250,
+                              "peaks_minimum_height": 0.07, "peaks_minimum_prominence": 0.3, "peaks_minimum_frequency": 700,
+                              "peaks_maximum_frequency": 3300, "peaks_minimum_amount": 3, "peaks_maximum_amount": 7},
+           "sync_pulse_settings": {"peaks_minimum_distance": 750, "peaks_minimum_height": 0.6, "peaks_minimum_prominence": 0.25,
+                                   "peaks_minimum_frequency": 1300, "peaks_maximum_frequency": 1700}}
+    (tmp_path / "config").mkdir()
+    (tmp_path / "config" / "config.json").write_text(json.dumps(cfg))
+    monkeypatch.chdir(tmp_path)
+    tones, pulse = hp.load_detector_settings()
+    assert tones == dict(start_distance=111, stop_distance=222, height=0.07, prominence=0.3, fmin=700, fmax=3300, amount_min=3, amount_max=7)
+    assert pulse == dict(height=0.6, prominence=0.25, fmin=1300, fmax=1700)
+    assert hp.load_notch_settings() == (2500, 2)
+    assert set(tones) == set(detect.TONES) and set(pulse) == set(detect.SYNC_PULSE)
+    (tmp_path / "config" / "config.json").write_text(json.dumps({"tones_settings": {}}))
+    with pytest.raises(KeyError):
+        hp.load_detector_settings()

@@ -29,6 +29,25 @@ def load_notch_settings(config_path: str = "config/config.json"):
     return int(s["notch_filter_frequency"]), s["notch_filter_quality_factor"]
 
 
+def load_detector_settings(config_path: str = "config/config.json"):
+    """``tones_settings`` and ``sync_pulse_settings`` of the reference's config file as the live-path detectors read them
+    (data_packet.py:24-42), in the shape of ``detect.TONES`` / ``detect.SYNC_PULSE``.  (None, None) when the file is absent --
+    the caller then keeps the reference's shipped values; a malformed file or a missing key raises, as in the reference."""
+    try:
+        fh = open(config_path)
+    except OSError:
+        return None, None
+    with fh:
+        cfg = json.load(fh)
+    t, p = cfg["tones_settings"], cfg["sync_pulse_settings"]
+    tones = dict(start_distance=t["start_tone_peaks_minimum_distance"], stop_distance=t["stop_tone_peaks_minimum_distance"],
+                 height=t["peaks_minimum_height"], prominence=t["peaks_minimum_prominence"], fmin=t["peaks_minimum_frequency"],
+                 fmax=t["peaks_maximum_frequency"], amount_min=t["peaks_minimum_amount"], amount_max=t["peaks_maximum_amount"])
+    pulse = dict(height=p["peaks_minimum_height"], prominence=p["peaks_minimum_prominence"], fmin=p["peaks_minimum_frequency"],
+                 fmax=p["peaks_maximum_frequency"])
+    return tones, pulse
+
+
 def iirnotch(w0: float, q: float, fs: float):
     """scipy.signal.iirnotch (wefax.py:68): second-order notch, -3 dB bandwidth w0/Q."""
     w0 = 2 * float(w0) / fs

@@ -20,7 +20,14 @@ from . import hostparams as hp
 
 class DataPacket:
     def __init__(self, sample_rate, samples, lines_per_minute, directory, duration, number, ctx: nat.Context | None = None,
-                 notch=hp.DEFAULT_NOTCH):
+                 notch=None):
+        # the constants the reference's constructor reads from config/config.json (data_packet.py:21-42); the shipped values
+        # when there is no such file in the working directory
+        if notch is None:
+            notch = hp.load_notch_settings()
+        tones, pulse = hp.load_detector_settings()
+        self._tones = tones if tones is not None else detect.TONES
+        self._pulse = pulse if pulse is not None else detect.SYNC_PULSE
         self.lines_per_minute = lines_per_minute
         self.duration = duration
         self.number = number
@@ -51,15 +58,15 @@ class DataPacket:
 
     def contain_start_tone(self) -> bool:
         f, a = self._spectrum()
-        return detect.contain_tone(f, a, detect.TONES["start_distance"])
+        return detect.contain_tone(f, a, self._tones["start_distance"], self._tones)
 
     def contain_stop_tone(self) -> bool:
         f, a = self._spectrum()
-        return detect.contain_tone(f, a, detect.TONES["stop_distance"])
+        return detect.contain_tone(f, a, self._tones["stop_distance"], self._tones)
 
     def find_sync_pulse(self) -> dict:
         f, a = self._spectrum()
-        return detect.find_sync_pulse(f, a, np.asarray(self.samples), self.sample_rate)
+        return detect.find_sync_pulse(f, a, np.asarray(self.samples), self.sample_rate, self._pulse)
 
     def __repr__(self):
         return (f"data packet {self.number} info: {self.number * self.duration}s-{self.number * self.duration + self.duration}s "
