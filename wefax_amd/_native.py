@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwefax_hip.so")
+LIB_PATH = os.environ.get("WFX_LIB") or os.path.join(_HERE, "libwefax_hip.so")     # WFX_LIB: another build of the library (A/B runs)
 
 WFX_IN_I16_MONO, WFX_IN_I16_STEREO, WFX_IN_F64_MONO, WFX_IN_F32_MONO = 0, 1, 2, 3
 WFX_HILBERT_FFT, WFX_HILBERT_FIR, WFX_HILBERT_BLUESTEIN, WFX_HILBERT_FFT_POW2 = 0, 1, 2, 3

@@ -467,11 +467,87 @@ __device__ __forceinline__ void dft_pow2_rec(const cplx *x, int stride, cplx *X,
     }
 }
 
-template <int P, typename PUT>
+// Composite transforms "through rows": row(r) returns a pointer to the item's r-th point -- a register array (level A, all
+// indices compile-time) or the item's own LDS rows (level B: written and read back by the same thread, no barrier), where the
+// N1 x N2 intermediate then costs no registers and a pass has room for the next tile's prefetch.
+//   dft_ct_rows:  n = N2 n1 + n2, k = k1 + N1 k2, twiddles W_N^(n2 k1) between the steps (the arithmetic of dft25_ct)
+//   dft_pfa_rows: gcd(N1, N2) = 1, n = (N2 n1 + N1 n2) mod N, k = k1 mod N1 = k2 mod N2 (Good-Thomas): no twiddles at all
+#ifndef WFX_ROWS_LDS
+#define WFX_ROWS_LDS 1
+#endif
+template <int N1, int N2, typename ROW, typename PUT>
+__device__ __forceinline__ void dft_ct_rows(ROW row, const double sg, PUT put)
+{
+    constexpr int N = N1 * N2;
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+        cplx x[N1];
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) x[n1] = *row(N2 * n1 + n2);
+        dft_odd_inplace<N1>(x, sg, [&](int k1, cplx y) {
+            if (n2 > 0 && k1 > 0) y = mcmul(y, make_double2(mr_roots<N>::c[n2 * k1], sg * mr_roots<N>::s[n2 * k1]));
+            *row(N2 * k1 + n2) = y;
+        });
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < N1; ++k1) {
+        cplx x[N2];
+#pragma unroll
+        for (int n2 = 0; n2 < N2; ++n2) x[n2] = *row(N2 * k1 + n2);
+        dft_odd_inplace<N2>(x, sg, [&](int k2, cplx y) { put(k1 + N1 * k2, y); });
+    }
+}
+
+constexpr int mr_inv_mod(int a, int m)
+{
+    for (int x = 1; x < m; ++x)
+        if ((a * x) % m == 1) return x;
+    return 0;
+}
+
+template <int N1, int N2, typename ROW, typename PUT>
+__device__ __forceinline__ void dft_pfa_rows(ROW row, const double sg, PUT put)
+{
+    constexpr int N = N1 * N2;
+    constexpr int E1 = N2 * mr_inv_mod(N2 % N1, N1), E2 = N1 * mr_inv_mod(N1 % N2, N2);     // k = (E1 k1 + E2 k2) mod N
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+        cplx x[N1];
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) x[n1] = *row((N2 * n1 + N1 * n2) % N);
+        dft_odd_inplace<N1>(x, sg, [&](int k1, cplx y) { *row((N2 * k1 + N1 * n2) % N) = y; });
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < N1; ++k1) {
+        cplx x[N2];
+#pragma unroll
+        for (int n2 = 0; n2 < N2; ++n2) x[n2] = *row((N2 * k1 + N1 * n2) % N);
+        dft_odd_inplace<N2>(x, sg, [&](int k2, cplx y) { put((E1 * k1 + E2 * k2) % N, y); });
+    }
+}
+
+// radices whose level-B transform goes through the item's LDS rows
+constexpr bool mr2_rows(int rb) { return WFX_ROWS_LDS && rb == 25; }
+
+template <int P, typename ROW, typename PUT>
+__device__ __forceinline__ void dft_rows(ROW row, const double sg, PUT put)
+{
+    if constexpr (P == 25)
+        dft_ct_rows<5, 5>(row, sg, put);
+    else
+        dft_pfa_rows<3, 5>(row, sg, put);
+}
+
+#ifndef WFX_PFA15
+#define WFX_PFA15 1
+#endif
+template <int P, bool PFA = false, typename PUT>
 __device__ __forceinline__ void dft_any(cplx *v, const double sg, PUT put)
 {
     if constexpr (P == 25) {
         dft25_ct(v, sg, put);
+    } else if constexpr (P == 15 && PFA && WFX_PFA15) {
+        dft_pfa_rows<3, 5>([&](int r) { return &v[r]; }, sg, put);      // 3 x 5 without twiddles: 134 operations against 230
     } else if constexpr (P == 2 || P == 4 || P == 8 || P == 16) {
         cplx X[P];
         dft_pow2_rec<P>(v, 1, X, sg);
@@ -491,6 +567,7 @@ constexpr bool mr2_prefetch(int ra, int rb)
 #ifdef WFX_EXP_R25
     if (rb == 25 || ra == 25) return true;
 #endif
+    if (mr2_rows(rb)) return na * ra * 4 + 40 <= 140;     // level B works five points at a time (dft_rows)
     return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) <= 140;      // registers: a tile in flight + a level-B transform
 }
 
@@ -508,7 +585,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
          int ntiles)
 {
     constexpr int LOG2T = mr2_log2t(RA * RB);
-    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3)) ? 1 : 0;
+    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3 || (OUT_MODE == 1 && mr2_rows(RB)))) ? 1 : 0;
     constexpr int R = RA * RB, T = 1 << LOG2T;
     constexpr int NA = (T * RB + 255) / 256, NB = (T * RA + 255) / 256;
     constexpr bool inv = INVERSE != 0;
@@ -692,7 +769,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             for (int e = t; e < R * tn; e += 256) out[o0 + e] = tile[e];
         } else {
             // few, long transforms (T * RA <= 128 items): two threads share one, each producing half of the output pairs
-            constexpr int SPLIT = (T * RA <= 128 && RB >= 9 && RB != 25) ? 2 : 1;
+            constexpr int SPLIT = (T * RA <= 128 && RB >= 9 && RB != 25 && !mr2_rows(RB)) ? 2 : 1;
             constexpr int NBS = (T * RA * SPLIT + 255) / 256;
             constexpr int HB = (RB - 1) / 2, HB1 = SPLIT == 2 ? (HB + 1) / 2 : HB;
 #pragma unroll
@@ -702,9 +779,12 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                 const int it2 = item - part * (T * RA);
                 const int c = it2 & (T - 1), qa = it2 >> LOG2T;
                 if (item < T * RA * SPLIT && c < tn) {
-                    cplx u[RB];
+                    constexpr bool ROWS = mr2_rows(RB);
+                    cplx u[ROWS ? 1 : RB];
+                    if constexpr (!ROWS) {
 #pragma unroll
-                    for (int b = 0; b < RB; ++b) u[b] = tile[((qa * RB + b) << LOG2T) + c];
+                        for (int b = 0; b < RB; ++b) u[b] = tile[((qa * RB + b) << LOG2T) + c];
+                    }
                     const int j = j0 + c;
                     const int k = j % P;
                     const long long obase = (long long)(j - k) * R + k + (long long)qa * P;      // + qb * RA * P
@@ -731,8 +811,10 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                         }
                         out[o] = y;
                     };
-                    if (SPLIT == 1) {
-                        dft_any<RB>(u, sg, emit);
+                    if constexpr (ROWS) {
+                        dft_rows<RB>([&](int r) { return &tile[((qa * RB + r) << LOG2T) + c]; }, sg, emit);
+                    } else if (SPLIT == 1) {
+                        dft_any<RB, true>(u, sg, emit);
                     } else if (part == 0) {
                         dft_odd_part<RB, 1, HB1, true>(u, sg, emit);
                     } else {
