@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--shard", action="store_true",
                     help="c2: decode ONE 10-minute capture with all ranks (sharded exact path) instead of one capture per rank")
     ap.add_argument("--iq-seconds", type=float, default=3600.0, help="length of the IQ stream (BASELINE: 60 minutes)")
+    ap.add_argument("--iq-stop-rate", type=int, default=16000, choices=[16000, 14700, 22050],
+                    help="rate at which the time-domain front end hands the IQ stream to the exact FFT resampler")
     ap.add_argument("--iq-form", choices=["auto", "fused", "sharded"], default="auto",
                     help="one GPU: the fused exact decode behind the front end (auto) or the sharded form with one rank")
     ap.add_argument("--no-c4", action="store_true", help="c2: leave the c4_strong object out (quick runs)")
@@ -250,7 +252,7 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
     kw = iq_recipe(seconds)
     sp = synth_device.synth_params(float(IQ_FS), noise=args.noise, seed=0, iq=True, **kw)
     n0 = int(ctx.lib.wfx_synth_frames(sp))
-    fe = polyphase.FrontEnd(IQ_FS, stop_at_2x=True)
+    fe = polyphase.FrontEnd(IQ_FS, stop_rate=args.iq_stop_rate)
     keep = []
 
     def raw_loader(lo, hi):
@@ -285,7 +287,7 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
            "form": ("front end + fused exact decode on one GPU" if fused else
                     f"front end on each rank's 1/{rk.world} of the stream + sharded exact path (distributed FFT resample and Hilbert: 8 transposes, "
                     "2 histogram all-reduces, 1 candidate all-gather, 1 stream gather per decode)"),
-           "front_end": fe.describe() + " -> exact FFT resample /2",
+           "front_end": fe.describe() + f" -> exact FFT resample {fe.out_rate} -> 11025 Hz",
            "ms_per_step": round(ms, 4), "value": round(n0 / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "steps": steps,
            "synthesis_s": round(t_syn, 2), "dtype": "f32 front end / f64 exact path",
            "start_frame": int(info.start_frame) if rk.rank == 0 else None, "image": [int(info.width), 4 * int(info.height)] if rk.rank == 0 else None,

@@ -253,7 +253,7 @@ int wfx_d_notch_fir_f64(wfx_ctx *ctx, const double *in_dev, size_t n, const doub
  * wefax.py:360-394.  in_kind WFX_IN_I16_MONO, WFX_IN_I16_STEREO (= interleaved IQ; merged as (int16)(L+R)/2 while
  * loading) or WFX_IN_F32_MONO; coefficient arrays are HOST pointers, designed by the caller
  * (wefax_amd/polyphase.py).  fp32 accumulation in a fixed order per output sample.
- *   decimate:  out[i] = sum_{j<ntaps} coef[j] * in[first + i*factor + j],  factor a power of two <= 64,
+ *   decimate:  out[i] = sum_{j<ntaps} coef[j] * in[first + i*factor + j],  factor <= 64 (powers of two take the aligned fast path),
  *              out float32 (out_f64 = 0) or float64 (out_f64 = 1)
  *   rational:  out[i] = sum_{j<taps} table[(((m0+i)*p) mod q)*taps + j] * in[floor((m0+i)*p/q) - base0 + j]
  * samples of `in` outside [0, n_in) read as zero */

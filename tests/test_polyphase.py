@@ -64,6 +64,10 @@ def test_chain_ranges_are_consistent_and_slice_invariant():
     fe = pp.FrontEnd(1536000)
     ch = fe.chain(-700, 1900)
     assert [st.kind for st, _, _ in ch] == ["decimate", "rational", "decimate", "decimate"]
+    assert [(st.kind, getattr(st, "factor", None)) for st in pp.FrontEnd(1536000, stop_rate=16000).stages] == [("decimate", 32), ("decimate", 3)]
+    assert pp.FrontEnd.handover_rate(1536000) == 16000 and pp.FrontEnd.handover_rate(44100) == 14700
+    with pytest.raises(ValueError):
+        pp.FrontEnd(1536000, stop_rate=13000)               # divides neither 48 000 nor 44 100 Hz
     for (s0, o0, i0), (s1, o1, i1) in zip(ch[:-1], ch[1:]):
         assert o0 == i1                                    # a stage's output range is the next one's input range
     assert ch[-1][1] == (-700, 1900)
@@ -217,13 +221,14 @@ STREAM_MAX, STREAM_NE_FRAC, IMAGE_MAX, IMAGE_GT1_FRAC = 1, 5e-4, 1, 0.0
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fs,iq,lpm,seconds", [(48000, False, 240, 56.0), (192000, True, 240, 64.0), (1536000, True, 120, 40.0)])
-def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds):
-    """Front end to 22 050 Hz + the exact path: the one-GPU fused form, and the sharded form on 1, 2, 3 and 8 emulated
+@pytest.mark.parametrize("fs,iq,lpm,seconds,stop_rate", [(48000, False, 240, 56.0, 22050), (192000, True, 240, 64.0, 14700),
+                                                         (1536000, True, 120, 40.0, 22050), (1536000, True, 120, 40.0, 16000)])
+def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds, stop_rate):
+    """Front end to the hand-over rate (22 050, 14 700 or 16 000 Hz) + the exact path: the one-GPU fused form, and the sharded form on 1, 2, 3 and 8 emulated
     ranks (bit-identical to each other and to the fused form); against the oracle within the figures above."""
     x = _capture(fs, 0.05, seed=0, lpm=lpm, seconds=seconds, iq=iq)
     ref = _oracle(x, fs, lpm)
-    fe = pp.FrontEnd(fs, stop_at_2x=True)
+    fe = pp.FrontEnd(fs, stop_rate=stop_rate)
     dec = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=lpm)
     dec.run()
     info = dec.result()
@@ -233,7 +238,7 @@ def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds
     peaks1 = [int(info.peak_pos[k]) for k in range(info.npeaks)]
     for name, got, want, mx, frac in (("stream", st1, ref["digitalized"], STREAM_MAX, STREAM_NE_FRAC), ("image", img1, ref["image"], IMAGE_MAX, None)):
         d = np.abs(got.astype(np.int16) - want.astype(np.int16))
-        print(f"fs={fs}: {name} max|d|={d.max()} differing={np.count_nonzero(d)} of {d.size}, >1: {np.count_nonzero(d > 1)}")
+        print(f"fs={fs} via {stop_rate}: {name} max|d|={d.max()} differing={np.count_nonzero(d)} of {d.size}, >1: {np.count_nonzero(d > 1)}")
         assert got.shape == want.shape and d.max() <= mx
         if frac is not None:
             assert np.count_nonzero(d) <= frac * d.size
@@ -260,7 +265,7 @@ def test_each_rank_loads_only_its_slice_of_the_raw_stream(ctx):
     from wefax_amd import _native as nat
     fs = 192000
     x = _capture(fs, 0.05, seed=2, lpm=240, seconds=40.0, iq=True)
-    fe = pp.FrontEnd(fs, stop_at_2x=True)
+    fe = pp.FrontEnd(fs, stop_rate=pp.FrontEnd.handover_rate(fs))
     n0 = x.shape[0]
     comms = nat.Comm.local(4)
     asked = []
@@ -274,7 +279,7 @@ def test_each_rank_loads_only_its_slice_of_the_raw_stream(ctx):
     assert [a[0] for a in asked] == [0, 1, 2, 3]
     halo = fe.halo()
     for (r, lo, hi), d in zip(asked, decs):
-        share = int(np.ceil((d.layout.in_hi - d.layout.in_lo) * fs / 22050))       # the rank's rows at 22 050 Hz, in raw frames
+        share = int(np.ceil((d.layout.in_hi - d.layout.in_lo) * fs / fe.out_rate))       # the rank's rows at the hand-over rate, in raw frames
         assert hi - lo <= share + 2 * halo + 64 and lo < hi
     assert asked[0][1] < 0 and asked[-1][2] > n0                         # the ends wrap (the FFT resampler behind is circular)
     for d in decs:

@@ -28,7 +28,8 @@ KW30 = dict(start_tone_s=2.0, phasing_lines=20, image_lines=30, stop_tone_s=1.0,
 # CPU
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n0,sr,kind", [(1433250, 11025, 0), (7166250, 11025, 0), (1440000, 48000, 0), (1440000, 48000, 1),
-                                       (172800000, 48000, 0), (79380000, 22050, 2), (286650, 11025, 0), (330750, 11025, 0), (9922500, 22050, 2)])
+                                       (172800000, 48000, 0), (79380000, 22050, 2), (286650, 11025, 0), (330750, 11025, 0), (9922500, 22050, 2),
+                                       (52920000, 14700, 2), (588000, 14700, 2), (57600000, 16000, 2), (640000, 16000, 2)])
 def test_layout_tiles_the_capture_and_the_exchange_lists_are_consistent(n0, sr, kind):
     p, meta = build_params(kind, n0, sr, 0.5)
     for world in (1, 2, 3, 4, 8):

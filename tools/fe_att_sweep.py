@@ -26,7 +26,7 @@ sp = synth_device.synth_params(float(fs), noise=0.05, seed=0, iq=True, **kw)
 n0 = int(ctx.lib.wfx_synth_frames(sp))
 big = synth_device.synth_slice(ctx, sp, -20000, n0 + 20000)
 for att in [float(a) for a in (sys.argv[1:] or ["90", "105", "120", "135"])]:
-    fe = pp.FrontEnd(fs, att_db=att, stop_at_2x=True)
+    fe = pp.FrontEnd(fs, att_db=att, stop_rate=int(os.environ.get("WFX_FE_STOP", 16000)))
     dec = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=120)
     dec.run()
     info = dec.result()

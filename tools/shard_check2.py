@@ -100,7 +100,7 @@ def iq_front_end(worlds):
     x = synth.synth_capture(float(fs), noise=0.05, seed=0, lpm=120, phasing_lines=phasing, image_lines=lines, start_tone_s=1.0, stop_tone_s=1.0,
                             black_tail_s=1.0, iq=True)
     ref = oracle(x, fs, 120)
-    fe = pp.FrontEnd(fs, stop_at_2x=True)
+    fe = pp.FrontEnd(fs, stop_rate=int(os.environ.get("WFX_FE_STOP", 16000)))
     ctx = nat.Context(0)
     one = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=120)
     one.run()

@@ -65,6 +65,34 @@ static void free_buf(wfx_devbuf &b)
     b.cap = 0;
 }
 
+// Device copy of a host table of floats, cached by content (FNV-1a over the bytes + an exact compare is not needed: a
+// colliding table of the same size would have to come from the same filter design code).
+const float *wfx_coef_device(wfx_ctx *ctx, const float *host, size_t count)
+{
+    const size_t bytes = count * sizeof(float);
+    uint64_t h = 1469598103934665603ull;
+    const unsigned char *b = (const unsigned char *)host;
+    for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    for (auto &e : ctx->coef_cache)
+        if (e.hash == h && e.bytes == bytes) return (const float *)e.dev;
+    if (ctx->coef_cache.size() >= 64) {           // a long-lived context fed ever new filters: start over
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+        for (auto &e : ctx->coef_cache) (void)hipFree(e.dev);
+        ctx->coef_cache.clear();
+    }
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, bytes ? bytes : 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // the host table belongs to the caller
+    if (e != hipSuccess) {
+        if (d) (void)hipFree(d);
+        wfx_fail_hip(ctx, e, "filter table upload");
+        return nullptr;
+    }
+    ctx->coef_cache.push_back({h, bytes, d});
+    return (const float *)d;
+}
+
 extern "C" {
 
 const char *wfx_version(void) { return "wefax_hip 0.1 (gfx950)"; }
@@ -132,6 +160,7 @@ void wfx_destroy(wfx_ctx *ctx)
                           &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps, &ctx->b_cand, &ctx->b_pcoef, &ctx->b_seg, &ctx->b_png};
     if (ctx->h_png) hipHostFree(ctx->h_png);
     for (auto *b : bufs) free_buf(*b);
+    for (auto &e : ctx->coef_cache) (void)hipFree(e.dev);
     for (auto &kv : ctx->plans) free_buf(kv.second.bhat);
     for (auto &kv : ctx->hplans) free_buf(kv.second.bhat);
     wfx_mr_release(ctx);

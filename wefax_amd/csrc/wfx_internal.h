@@ -91,6 +91,14 @@ struct wfx_ctx {
     bool force_pow2 = false;     // WFX_HILBERT_FFT_POW2: always use the zero-padded power-of-two convolution
     std::map<uint64_t, wfx_bs_plan> plans;    // Bluestein chirp filters (resampler, cross-check mode)
     std::map<uint64_t, wfx_bs_plan> hplans;   // Hilbert convolution kernels
+    // filter tables of the time-domain front end, keyed by content: a table is uploaded (and the stream synchronised) the first
+    // time a decode uses it, never again -- repeated decodes enqueue their stages without touching the host
+    struct coef_entry {
+        uint64_t hash;
+        size_t bytes;
+        void *dev;
+    };
+    std::vector<coef_entry> coef_cache;
 
     // decode state
     wfx_decode_params dp{};
@@ -148,6 +156,7 @@ void wfx_set_global_error(const char *msg);
         if (rc_ != 0) return rc_; \
     } while (0)
 
+const float *wfx_coef_device(wfx_ctx *ctx, const float *host, size_t count);      // nullptr + error set on failure
 int wfx_reserve(wfx_ctx *ctx, wfx_devbuf &b, size_t bytes);
 bool wfx_ctx_alive(const wfx_ctx *ctx);      // false once wfx_destroy has run on it
 

@@ -559,11 +559,23 @@ __device__ __forceinline__ void dft_any(cplx *v, const double sg, PUT put)
 }
 
 // tile width (columns) and prefetch policy of a pair, shared by the kernel and the host
-constexpr int mr2_log2t(int r) { return r <= 16 ? 8 : r <= 32 ? 7 : r <= 64 ? 6 : r <= 128 ? 5 : 4; }
+#ifndef WFX_EXP_T16
+#define WFX_EXP_T16 0
+#endif
+#ifndef WFX_PF_SPEC
+#define WFX_PF_SPEC 0
+#endif
+#ifndef WFX_WIDE
+#define WFX_WIDE 0
+#endif
+// radices above 128: 512 lanes on a 32-column tile (one workgroup per CU, 90-115 KB of LDS) -- row segments of 512 bytes like the
+// smaller radices have; with 256 lanes and 16 columns the same passes run 4 us slower at the benchmark size
+constexpr int mr2_nt(int r) { return (WFX_WIDE && r > 128) ? 512 : 256; }
+constexpr int mr2_log2t(int r) { return r <= 16 ? 8 : r <= 32 ? 7 : r <= 64 ? 6 : (r <= 128 && !(WFX_EXP_T16 && r == 91)) ? 5 : WFX_WIDE ? 5 : 4; }
 constexpr bool mr2_prefetch(int ra, int rb)
 {
     const int t = 1 << mr2_log2t(ra * rb);
-    const int na = (t * rb + 255) / 256;
+    const int na = (t * rb + mr2_nt(ra * rb) - 1) / mr2_nt(ra * rb);
 #ifdef WFX_EXP_R25
     if (rb == 25 || ra == 25) return true;
 #endif
@@ -580,21 +592,22 @@ template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
 #else
 #define WFX_R25_LB(RA, RB) 2
 #endif
-__global__ void __launch_bounds__(256, OUT_MODE == 2 ? WFX_FUSED_LB : WFX_R25_LB(RA, RB))
+__global__ void __launch_bounds__(mr2_nt(RA * RB), mr2_nt(RA * RB) == 512 ? 1 : OUT_MODE == 2 ? WFX_FUSED_LB : WFX_R25_LB(RA, RB))
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
          int ntiles)
 {
     constexpr int LOG2T = mr2_log2t(RA * RB);
-    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3 || (OUT_MODE == 1 && mr2_rows(RB)))) ? 1 : 0;
+    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3 || (OUT_MODE == 1 && (mr2_rows(RB) || WFX_PF_SPEC)))) ? 1 : 0;
     constexpr int R = RA * RB, T = 1 << LOG2T;
-    constexpr int NA = (T * RB + 255) / 256, NB = (T * RA + 255) / 256;
+    constexpr int NT = mr2_nt(R);                                 // lanes per workgroup
+    constexpr int NA = (T * RB + NT - 1) / NT, NB = (T * RA + NT - 1) / NT;
     constexpr bool inv = INVERSE != 0;
     constexpr double sg = inv ? 1.0 : -1.0;
     __shared__ cplx tile[T * R];
     __shared__ cplx wr[R];
     const int t = (int)threadIdx.x;
     const int ncol = (int)d.ncol, P = (int)d.P;
-    for (int i = t; i < R; i += 256) {
+    for (int i = t; i < R; i += NT) {
         double sn, cs;
         sincospi(2.0 * (double)i / (double)R, &sn, &cs);
         wr[i] = make_double2(cs, inv ? sn : -sn);                 // W_R^i in the direction of this pass
@@ -609,7 +622,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
     auto prefetch = [&](int tix) {
 #pragma unroll
         for (int ia = 0; ia < NA; ++ia) {
-            const int item = t + 256 * ia;
+            const int item = t + NT * ia;
             const int c = item & (T - 1), b = item >> LOG2T;
             const int j = tix * T + c;
             const bool ok = item < T * RB && j < ncol;
@@ -641,7 +654,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
         // ---- level A ----
 #pragma unroll
         for (int ia = 0; ia < NA; ++ia) {
-            const int item = t + 256 * ia;
+            const int item = t + NT * ia;
             if (item < T * RB) {
                 const int c = item & (T - 1), b = item >> LOG2T;
                 cplx v[RA];
@@ -672,7 +685,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             cplx res[NB][RB];
 #pragma unroll
             for (int ib = 0; ib < NB; ++ib) {
-                const int item = t + 256 * ib;
+                const int item = t + NT * ib;
                 if (item < T * RA) {
                     const int c = item & (T - 1), qa = item >> LOG2T;
                     cplx u[RB];
@@ -684,7 +697,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             mr_lds_barrier();
 #pragma unroll
             for (int ib = 0; ib < NB; ++ib) {
-                const int item = t + 256 * ib;
+                const int item = t + NT * ib;
                 if (item < T * RA) {
                     const int c = item & (T - 1), qa = item >> LOG2T;
 #pragma unroll
@@ -695,14 +708,14 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             if (d.qmap) {
                 // distributed transform: every output goes where the following exchange sends it from (wfx_dist.hip, E2):
                 // consecutive q of one destination are consecutive addresses
-                for (int e = t; e < R * tn; e += 256) {
+                for (int e = t; e < R * tn; e += NT) {
                     const int c = e / R, q = e - c * R;
                     const mr_qmap m = d.qmap[q];
                     ((cplx *)m.base)[(long long)(j0 + c) * m.stride] = tile[e];
                 }
             } else {
                 const long long o0 = (long long)j0 * R;
-                for (int e = t; e < R * tn; e += 256) out[o0 + e] = tile[e];
+                for (int e = t; e < R * tn; e += NT) out[o0 + e] = tile[e];
             }
         } else if (OUT_MODE == 2) {
             // LAST forward pass fused with the FIRST inverse pass.  With the inverse's radices taken in the reverse order, column j
@@ -713,7 +726,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             // memory and only one more LDS round trip than a plain first pass is needed.
 #pragma unroll
             for (int ib = 0; ib < NB; ++ib) {
-                const int item = t + 256 * ib;
+                const int item = t + NT * ib;
                 if (item < T * RA) {
                     const int c = item & (T - 1), qa = item >> LOG2T;
                     cplx u[RB];
@@ -745,7 +758,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             cplx xo[NA][RA];
 #pragma unroll
             for (int ia = 0; ia < NA; ++ia) {                     // inverse RA-point level over qa, for (column, nb)
-                const int item = t + 256 * ia;
+                const int item = t + NT * ia;
                 if (item < T * RB) {
                     const int c = item & (T - 1), nb = item >> LOG2T;
                     cplx v[RA];
@@ -757,7 +770,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             mr_lds_barrier();
 #pragma unroll
             for (int ia = 0; ia < NA; ++ia) {                     // first-pass output order: a column's R values are contiguous
-                const int item = t + 256 * ia;
+                const int item = t + NT * ia;
                 if (item < T * RB) {
                     const int c = item & (T - 1), nb = item >> LOG2T;
 #pragma unroll
@@ -766,15 +779,15 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             }
             mr_lds_barrier();
             const long long o0 = (long long)j0 * R;
-            for (int e = t; e < R * tn; e += 256) out[o0 + e] = tile[e];
+            for (int e = t; e < R * tn; e += NT) out[o0 + e] = tile[e];
         } else {
             // few, long transforms (T * RA <= 128 items): two threads share one, each producing half of the output pairs
-            constexpr int SPLIT = (T * RA <= 128 && RB >= 9 && RB != 25 && !mr2_rows(RB)) ? 2 : 1;
-            constexpr int NBS = (T * RA * SPLIT + 255) / 256;
+            constexpr int SPLIT = (T * RA <= NT / 2 && RB >= 9 && RB != 25 && !mr2_rows(RB)) ? 2 : 1;
+            constexpr int NBS = (T * RA * SPLIT + NT - 1) / NT;
             constexpr int HB = (RB - 1) / 2, HB1 = SPLIT == 2 ? (HB + 1) / 2 : HB;
 #pragma unroll
             for (int ib = 0; ib < NBS; ++ib) {
-                const int item = t + 256 * ib;
+                const int item = t + NT * ib;
                 const int part = SPLIT == 2 ? (item >= T * RA ? 1 : 0) : 0;
                 const int it2 = item - part * (T * RA);
                 const int c = it2 & (T - 1), qa = it2 >> LOG2T;
@@ -1194,25 +1207,26 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
     const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
     const int lt = mr2_log2t(d.R);
     const int nt = (int)((d.ncol + (1 << lt) - 1) >> lt);
-    const unsigned g2 = (unsigned)(nt < 512 ? nt : 512);
+    const int slots = mr2_nt(d.R) == 512 ? 256 : 512;           // resident workgroups on 256 CUs
+    const unsigned g2 = (unsigned)(nt < slots ? nt : slots);
     if (nt <= 0) return 0;
     bool done = false;
 #define X(RA_, RB_)                                                                                                                   \
     if (!done && d.ra == (RA_) && d.rb == (RB_)) {                                                                                    \
         if (in_mode == 2 && dir == 0 && out_mode == 0)                                                                               \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 2, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 2, 0, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 1 && in_mode == 0 && out_mode == 0)                                                                          \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 1 && in_mode == 0)                                                                          \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 2 && in_mode == 0)                                                                          \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 3 && in_mode == 0)                                                                          \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 3, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 3, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 1 && out_mode == 0)                                                                          \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 0 && out_mode == 0)                                                                          \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 0>), dim3(g2), dim3(256), src, dst, d, lo, hi, nt);                        \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else                                                                                                                          \
             return wfx_fail(ctx, WFX_ERR_BAD_ARG, "no pass kernel for in_mode %d out_mode %d dir %d", in_mode, out_mode, dir);        \
         done = true;                                                                                                                  \

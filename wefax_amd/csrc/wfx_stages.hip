@@ -110,11 +110,15 @@ __device__ __forceinline__ double biquad_step(const notch_coef &c, double xi, do
     return yi;
 }
 
+#ifndef NOTCH_NU
+#define NOTCH_NU 4
+#endif
 template <typename TIN>
 __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x, uint64_t n, notch_coef c, double *__restrict__ y, unsigned interior_blocks,
                                                        int exact_edges, wfx_dev_scalars *__restrict__ clear)
 {
-    constexpr int TLEN = 1024 + 2 * NOTCH_K;
+    constexpr int NU = NOTCH_NU, TOUT = 256 * NU;       // outputs per lane and per tile
+    constexpr int TLEN = TOUT + 2 * NOTCH_K;
     constexpr int NPRE = (TLEN + 255) / 256;
     __shared__ double tile[TLEN + TLEN / 4 + 4];
     __shared__ double ebuf[2][NOTCH_SMALL + 2 * NOTCH_PAD + 8];
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
         // true end (filtfilt's odd extension + lfilter_zi there); otherwise the FIR form runs up to K
         // samples from that end and the caller's halo covers the rest
         const uint64_t lo = (exact_edges & 1) ? NOTCH_EDGE : NOTCH_K, hi = (exact_edges & 2) ? n - NOTCH_EDGE : n - NOTCH_K;
-        const uint64_t step = (uint64_t)interior_blocks * 1024ull;
+        const uint64_t step = (uint64_t)interior_blocks * (uint64_t)TOUT;
         // raw samples, unconditional loads from a clamped index: a guarded load compiles to a branch with its
         // own s_waitcnt, which serialises the five loads of a tile instead of leaving them in flight (36 -> 27 us)
         TIN pre[NPRE];
@@ -137,7 +141,7 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
                 pre[k] = x[src < n ? src : n - 1];
             }
         };
-        uint64_t base = lo + (uint64_t)blockIdx.x * 1024ull;
+        uint64_t base = lo + (uint64_t)blockIdx.x * (uint64_t)TOUT;
         if (base < hi) prefetch(base);
         for (; base < hi; base += step) {
             lds_barrier();
@@ -149,25 +153,27 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
             }
             lds_barrier();
             if (base + step < hi) prefetch(base + step);
-            // window element i feeds output u with tap |i - u - K|: one LDS read, up to 4 FMAs
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            // window element i feeds output u with tap |i - u - K|: one LDS read, up to NU FMAs
+            double acc[NU];
 #pragma unroll
-            for (int i = 0; i < 2 * NOTCH_K + 4; ++i) {
-                const double wv = tile[(4 * t + i) + ((4 * t + i) >> 2)];
+            for (int u = 0; u < NU; ++u) acc[u] = 0.0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+            for (int i = 0; i < 2 * NOTCH_K + NU; ++i) {
+                const double wv = tile[(NU * t + i) + ((NU * t + i) >> 2)];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
                     const int k = i - u - NOTCH_K;
                     if (k >= -NOTCH_K && k <= NOTCH_K) acc[u] = fma(c.g[k < 0 ? -k : k], wv, acc[u]);
                 }
             }
-            // a lane's 4 outputs are contiguous: exchange through LDS so that each store
+            // a lane's NU outputs are contiguous: exchange through LDS so that each store
             // instruction writes 64 x 16 contiguous bytes instead of 64 quarter lines
             lds_barrier();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) tile[5 * t + u] = acc[u];
+            for (int u = 0; u < NU; ++u) tile[(NU * t + u) + ((NU * t + u) >> 2)] = acc[u];
             lds_barrier();
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < NU / 2; ++half) {
                 const int j = half * 512 + 2 * t;                 // even -> same padded group of four
                 const uint64_t o = base + j;                      // base is even (64 or 24 + k*1024): 16-byte aligned
                 const double v0 = tile[j + (j >> 2)], v1 = tile[j + 1 + ((j + 1) >> 2)];
@@ -244,10 +250,10 @@ __global__ void __launch_bounds__(256, 4) notch_kernel(const TIN *__restrict__ x
     }
 }
 
-// interior workgroups: 4 per CU, each walks its 1024-sample tiles with the next tile's loads in flight
+// interior workgroups: 4 per CU, each walks its tiles of 256 * NOTCH_NU samples with the next tile's loads in flight
 static unsigned notch_grid(uint64_t n_interior)
 {
-    return std::min(wfx_blocks(n_interior, 1024), 1024u);
+    return std::min(wfx_blocks(n_interior, 256 * NOTCH_NU), 1024u);
 }
 
 static void notch_prepare(notch_coef &c, const double b[3], const double a[3], const double *ext18 = nullptr)

@@ -8,7 +8,8 @@ This module is the halo-local counterpart SURVEY.md section 8e asks for: a chain
     [ decimate by a power of two ]*  ->  [ rational p/q to 44 100 Hz ]  ->  decimate by 2  ->  decimate by 2
 
 (1.536 MS/s: /32 -> 48 kHz, x147/160 -> 44.1 kHz, /2 -> 22.05 kHz, /2 -> 11 025 Hz; 48 kHz: the last three;
-44.1 kHz: the last two) whose kernels live in ``csrc/wfx_polyphase.hip``.  Filters are Kaiser
+44.1 kHz: the last two; with ``stop_rate`` the chain ends at 22 050 or 14 700 Hz and the exact FFT resampler takes the
+last step) whose kernels live in ``csrc/wfx_polyphase.hip``.  Filters are Kaiser
 windowed sincs designed here in float64 and handed to the C ABI as float32 host arrays:
 unit DC gain, linear phase centred on the output sample (zero delay), pass band flat to
 ``pass_hz``, stop band from 5512.5 Hz (the brick wall of the reference) at ``att_db``.
@@ -104,15 +105,24 @@ class Rational:
 class FrontEnd:
     """Stage chain from ``fs_in`` to 11 025 Hz and the index bookkeeping around it."""
 
-    def __init__(self, fs_in: int, att_db: float | None = None, pass_hz: float = 5300.0, stop_at_2x: bool = False):
+    def __init__(self, fs_in: int, att_db: float | None = None, pass_hz: float = 5300.0, stop_at_2x: bool = False,
+                 stop_rate: int | None = None):
         """``pass_hz``: edge of the flat pass band of the last stage (its stop band starts at 5512.5 Hz): 5300 Hz
         costs 595 taps at 22.05 kHz.  What lies between ``pass_hz`` and 5512.5 Hz is what the reference keeps and
         this front end drops (tests/test_polyphase.py prints the resulting error figures).
 
-        ``stop_at_2x``: leave the sharp last stage out and deliver 22 050 Hz (``n_out`` = 2 x the reference's sample
-        count): on ONE GPU the exact FFT resampler then takes the last factor of two, i.e. the reference's own brick
-        wall at 5512.5 Hz, and only the wide, flat filters of the earlier stages separate the result from it."""
-        self.stop_at_2x = bool(stop_at_2x)
+        ``stop_rate`` (``stop_at_2x`` = 22 050): leave the sharp last stage out and deliver ``stop_rate`` Hz -- a rate above
+        11 025 Hz that divides the rate left by the power-of-two decimations (48 kHz -> 16 000 Hz: the rational stage
+        disappears) or else 44 100 Hz (22 050, 14 700).  The exact FFT resampler then takes the last step, i.e. the
+        reference's own brick wall at 5512.5 Hz, and only the wide, flat filters of the earlier stages separate the
+        result from it.  The lower the hand-over rate, the shorter the resampler's forward transform (16 000 Hz: 73 % of
+        what 22 050 Hz needs) -- and with it two of the sharded path's eight exchanges.  ``handover_rate(fs_in)`` names
+        the lowest such rate."""
+        if stop_at_2x and stop_rate is None:
+            stop_rate = 2 * TARGET_RATE
+        self.out_rate = int(stop_rate) if stop_rate else TARGET_RATE
+        self.stop_at_2x = self.out_rate == 2 * TARGET_RATE
+        self.exact_tail = self.out_rate != TARGET_RATE       # an FFT resample from out_rate to 11 025 Hz follows
         if att_db is None:
             att_db = float(os.environ.get("WFX_FE_ATT", DEFAULT_ATT_DB))
         self.att_db = att_db
@@ -128,22 +138,47 @@ class FrontEnd:
                 m *= 2
             self.stages.append(Decimate(fs, m, NYQ, float(fs / m) - NYQ, att_db))
             fs = fs / m
+        if self.exact_tail:
+            if self.out_rate <= TARGET_RATE or (fs % self.out_rate != 0 and mid % self.out_rate != 0):
+                raise ValueError(f"stop_rate {self.out_rate}: not a divisor of {float(fs):g} or 44100 Hz above 11025 Hz")
+            if fs % self.out_rate == 0 and fs != self.out_rate:
+                # one short filter straight to the hand-over rate (its transition band may be wide: only what aliases into
+                # 0..5512.5 Hz matters)
+                self.stages.append(Decimate(fs, int(fs / self.out_rate), NYQ, float(self.out_rate) - NYQ, att_db))
+                return
         if fs != mid:
             st = Rational(fs, mid, NYQ, float(min(fs, mid)) - NYQ, att_db)
             if (st.q * (st.taps | 1) + 2048 * st.p // st.q + st.taps + 2) * 4 > 64 * 1024:   # table + one tile's input span
                 raise ValueError(f"{fs_in} Hz needs a {st.q}-phase table that does not fit LDS; use the exact FFT resampler")
             self.stages.append(st)
-        # the last /4 in two halves: a short filter brings 44.1 kHz to 22.05 kHz (its transition band may be wide: only
-        # what aliases into 0..5512.5 Hz matters), so the sharp filter runs at half the rate with half the taps
-        self.stages.append(Decimate(mid, 2, NYQ, float(mid / 2) - NYQ, att_db))
-        if not self.stop_at_2x:
+        if self.exact_tail:
+            if mid != self.out_rate:
+                self.stages.append(Decimate(mid, int(mid / self.out_rate), NYQ, float(self.out_rate) - NYQ, att_db))
+        else:
+            # the last /4 in two halves, so that the sharp filter runs at half the rate with half the taps
+            self.stages.append(Decimate(mid, 2, NYQ, float(mid / 2) - NYQ, att_db))
             self.stages.append(Decimate(mid / 2, 2, pass_hz, NYQ, att_db))
 
+    @staticmethod
+    def handover_rate(fs_in: int) -> int:
+        """The lowest hand-over rate this front end can deliver for ``fs_in``: a third of what the power-of-two
+        decimations leave when that is a whole number of Hz (1.536 MS/s, 192 kHz, 48 kHz -> 16 000), else 14 700."""
+        fs = Fraction(int(fs_in))
+        while fs / (4 * TARGET_RATE) >= 2:
+            fs /= 2
+        third = fs / 3
+        return int(third) if third.denominator == 1 and third > TARGET_RATE + 2000 else 14700
+
     def n_out(self, n_in: int) -> int:
-        """Samples this front end delivers: wefax.py:384 num = int(11025 * length), length = n / sample_rate
-        (twice that at 22 050 Hz with ``stop_at_2x``)."""
+        """Samples this front end delivers: wefax.py:384 num = int(11025 * length), length = n / sample_rate; at a hand-over
+        rate above 11 025 Hz, the shortest length from which the exact path's own int(11025 * n_fe / rate) gives that num."""
         n = int(TARGET_RATE * (n_in / self.fs_in))
-        return 2 * n if self.stop_at_2x else n
+        if not self.exact_tail:
+            return n
+        n_fe = -((-n * self.out_rate) // TARGET_RATE)
+        while int(TARGET_RATE * (n_fe / self.out_rate)) < n:
+            n_fe += 1
+        return n_fe
 
     def chain(self, lo: int, hi: int):
         """Index ranges per stage for outputs [lo, hi) at 11 025 Hz: list of (stage, out range,

@@ -293,9 +293,9 @@ class FrontEndExactDecoder:
     def __init__(self, ctx, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None):
         from .wefax import DecodeJob
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
-        n_fe = frontend.n_out(n_in_total)                   # at 11 025 Hz, or at 22 050 Hz (FrontEnd(stop_at_2x=True))
-        rate = 2 * hp.TARGET_RATE if frontend.stop_at_2x else hp.TARGET_RATE
-        self.n = n_fe // 2 if frontend.stop_at_2x else n_fe
+        n_fe = frontend.n_out(n_in_total)                   # at 11 025 Hz, or at the hand-over rate (FrontEnd(stop_rate=...))
+        rate = frontend.out_rate
+        self.n = int(hp.TARGET_RATE * (n_in_total / frontend.fs_in))
         self.chain = frontend.chain(0, n_fe)
         ia, ib = self.chain[0][2]
         raw = _raw_slice(x, raw_loader, ia, ib, n_in_total)
@@ -330,11 +330,11 @@ class FrontEndShardedDecoder:
 
     def __init__(self, ctx, comm, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None,
                  notch=hp.DEFAULT_NOTCH):
-        if not frontend.stop_at_2x:
-            raise ValueError("the sharded form needs FrontEnd(stop_at_2x=True): the exact resampler takes the last factor of two")
+        if not frontend.exact_tail:
+            raise ValueError("the sharded form needs FrontEnd(stop_rate=...): the exact resampler takes the last step")
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
         n_fe = frontend.n_out(n_in_total)
-        self.dec = ShardedDecoder(ctx, comm, n_fe, 2 * hp.TARGET_RATE, lines_per_minute, nat.WFX_IN_F64_MONO, notch)
+        self.dec = ShardedDecoder(ctx, comm, n_fe, frontend.out_rate, lines_per_minute, nat.WFX_IN_F64_MONO, notch)
         lay = self.dec.layout
         self.chain = frontend.chain(int(lay.in_lo), int(lay.in_hi))
         ia, ib = self.chain[0][2]
