@@ -128,6 +128,22 @@ constexpr int PP_BATCH = 8;
 #ifndef PP_ACC64
 #define PP_ACC64 0
 #endif
+#ifndef PP_PAIRS
+#define PP_PAIRS 1
+#endif
+#ifndef PP_PREFETCH
+#define PP_PREFETCH 1
+#endif
+#ifndef PP_TAPS_SMEM
+#define PP_TAPS_SMEM 1
+#endif
+#ifndef PP_TB_MAX
+#define PP_TB_MAX 1024
+#endif
+#ifndef PP_MINB
+#define PP_MINB 1
+#endif
+typedef float pp_f2 __attribute__((ext_vector_type(2)));
 #if PP_ACC64
 typedef double pp_acc_t;
 #else
@@ -136,7 +152,7 @@ typedef float pp_acc_t;
 constexpr int PP_NB = 9;           // 16-byte chunks in flight per thread (decimate): 36 VGPRs
 
 template <int IN, typename OUT, bool ALIGNED, int Q4T>
-__global__ void __launch_bounds__(PP_THREADS)
+__global__ void __launch_bounds__(PP_THREADS, PP_MINB)
 decimate_kernel(const void *__restrict__ in, long long n_in, long long first, int M, int log2m, const float *__restrict__ cp, int q4_arg,
                 OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign)
 {
@@ -157,10 +173,15 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
     const int part = __builtin_amdgcn_readfirstlane(t >> 6) >> (log2qw - 6);
     const int rows_per = M >> rs_log2;
     float *psum = (float *)(lds_raw + (((size_t)row_stride * M * sizeof(S) + 15) & ~(size_t)15));     // [rs - 1][quads][4]
-    // the taps live in LDS as well (broadcast reads): LDS returns in order, so the software-pipelined tap loop can
-    // wait for the oldest read only -- scalar loads would force a full drain of the counter they share with LDS
-    float *cs = psum + PP_THREADS * 4 * (sizeof(pp_acc_t) / sizeof(float));
-    for (int i = t; i < M * 4 * q4; i += PP_THREADS) cs[i] = cp[i];
+    // Aligned form (the ingest of an oversampled capture): the taps are read from the table in memory with scalar loads (the
+    // row index is uniform) -- as LDS broadcast reads, 16 bytes per lane, they cost the LDS pipe as much as the window reads
+    // and the tap loop was LDS-bound -- and the next tile's first chunks are requested before the tap loop.  The short
+    // stages behind it measure faster with the taps in LDS and without the prefetch.
+    constexpr bool SMEM = PP_PAIRS && PP_TAPS_SMEM && ALIGNED, PF = PP_PREFETCH && ALIGNED;
+    float *cl = psum + PP_THREADS * 4 * (sizeof(pp_acc_t) / sizeof(float));
+    if (!SMEM)
+        for (int i = t; i < M * (PP_PAIRS ? 8 * q4 + 4 : 4 * q4); i += PP_THREADS) cl[i] = cp[i];
+    const float *cs = SMEM ? cp : cl;
     const long long ntiles = (n_out + tb - 1) >> log2tb;
     // 16-byte aligned view of the input: element index e of the caller's array is element e + misalign of `base`
     const unsigned char *base = (const unsigned char *)in - (size_t)misalign * A::BYTES;
@@ -233,16 +254,21 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
             }
         }
     };
+    if (PF && (long long)blockIdx.x < ntiles) fetch(geom_of(blockIdx.x), 0);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const geom Gn = geom_of(tile);
         const long long o0 = Gn.o0;
         const int cnt = Gn.cnt;
         __syncthreads();                       // the previous tile's compute phase is done with the LDS window
-        for (int cb = 0; cb < Gn.nchunks; cb += PP_NB * PP_THREADS) {
+        // (PF: the tile's first batch of chunks was requested before the previous tile's compute phase)
+        if (!PF) fetch(Gn, 0);
+        stash(Gn, 0);
+        for (int cb = PP_NB * PP_THREADS; cb < Gn.nchunks; cb += PP_NB * PP_THREADS) {
             fetch(Gn, cb);
             stash(Gn, cb);
         }
         __syncthreads();
+        if (PF && tile + gridDim.x < ntiles) fetch(geom_of(tile + gridDim.x), 0);      // in flight during the compute phase
         const bool active = (4 * g < cnt) && (part < (1 << rs_log2));
         // a row's 4 * q4 taps are summed in fp32 (packed FMAs) and the row sums are added up: two short chains instead of one
         // of 4 * q4 * M terms keep the rounding of the sum near that of the fp32 sample the stage stores (measured against a
@@ -250,6 +276,46 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
         pp_acc_t tot0 = 0, tot1 = 0, tot2 = 0, tot3 = 0;
         if (active) {
             const int r0 = part * rows_per;
+#if PP_PAIRS
+            // Packed FMAs over TAP pairs: output k keeps two partial sums (even / odd window positions), so that every product
+            // pairs an even-aligned window pair (w[2p], w[2p+1]) with a coefficient pair -- (c[t], c[t+1]) for the even outputs,
+            // the table shifted by one tap, (c[t-1], c[t]), for the odd ones.  No register shuffling between the FMAs (packing
+            // over OUTPUT pairs needs every window pair at both alignments: one v_mov per sample and row).
+            pp_f2 ta0 = {0.f, 0.f}, ta1 = {0.f, 0.f}, ta2 = {0.f, 0.f}, ta3 = {0.f, 0.f};
+            for (int r = r0; r < r0 + rows_per; ++r) {
+                const S *row = xs + r * row_stride + 4 * g;
+                const float *c = cs + r * (8 * q4 + 4);           // [4 q4] taps, then [4 q4 + 4] the same taps one place later
+                const float *dsh = c + 4 * q4;
+                float wa[4], wb[4];
+                pp_cvt4(pp_raw4(row), wa);
+                auto rn = pp_raw4(row + 4);
+                float4 cn = *(const float4 *)c, dn = *(const float4 *)dsh;
+                pp_f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+#pragma unroll(Q4T ? Q4T : 1)
+                for (int j = 0; j < (Q4T ? Q4T : q4); ++j) {
+                    const pp_f2 e0 = {cn.x, cn.y}, e1 = {cn.z, cn.w}, d0 = {dn.x, dn.y}, d1 = {dn.z, dn.w};
+                    pp_cvt4(rn, wb);
+                    dn = *(const float4 *)(dsh + 4 * j + 4);      // (the last one feeds the tail below)
+                    if (j + 1 < q4) {
+                        cn = *(const float4 *)(c + 4 * j + 4);
+                        rn = pp_raw4(row + 4 * j + 8);
+                    }
+                    const pp_f2 p0 = {wa[0], wa[1]}, p1 = {wa[2], wa[3]}, p2 = {wb[0], wb[1]};
+                    a0 = __builtin_elementwise_fma(e0, p0, a0); a2 = __builtin_elementwise_fma(e0, p1, a2);
+                    a1 = __builtin_elementwise_fma(d0, p0, a1); a3 = __builtin_elementwise_fma(d0, p1, a3);
+                    a0 = __builtin_elementwise_fma(e1, p1, a0); a2 = __builtin_elementwise_fma(e1, p2, a2);
+                    a1 = __builtin_elementwise_fma(d1, p1, a1); a3 = __builtin_elementwise_fma(d1, p2, a3);
+                    wa[0] = wb[0]; wa[1] = wb[1]; wa[2] = wb[2]; wa[3] = wb[3];
+                }
+                {       // the odd outputs' last tap, c[4 q4 - 1], sits alone in the shifted table's last pair
+                    const pp_f2 dq = {dn.x, dn.y}, p0 = {wa[0], wa[1]}, p1 = {wa[2], wa[3]};
+                    a1 = __builtin_elementwise_fma(dq, p0, a1);
+                    a3 = __builtin_elementwise_fma(dq, p1, a3);
+                }
+                ta0 += a0; ta1 += a1; ta2 += a2; ta3 += a3;
+            }
+            tot0 = ta0.x + ta0.y; tot1 = ta1.x + ta1.y; tot2 = ta2.x + ta2.y; tot3 = ta3.x + ta3.y;
+#else
             for (int r = r0; r < r0 + rows_per; ++r) {
                 const S *row = xs + r * row_stride + 4 * g;
                 const float *c = cs + r * 4 * q4;
@@ -274,6 +340,7 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                 }
                 tot0 += (pp_acc_t)acc0; tot1 += (pp_acc_t)acc1; tot2 += (pp_acc_t)acc2; tot3 += (pp_acc_t)acc3;
             }
+#endif
         }
         if (rs_log2 > 0) {
             pp_acc_t *ps = (pp_acc_t *)psum;
@@ -375,12 +442,13 @@ int launch_decimate(wfx_ctx *ctx, const void *in, long long n_in, long long firs
     const int log2m = ilog2_exact(M);
     const int esz = (int)sizeof(typename A::store_t);
     const int pad = esz == 2 ? 6 : 4;                // int16 rows: stride = 2 (mod 4) spreads a chunk's rows over the banks
-    int tb = 1024;                                   // outputs per tile: 4 per thread
+    int tb = log2m < 0 ? 1024 : PP_TB_MAX;           // outputs per tile: 4 per thread (rows of a non-power-of-two factor are never split)
     while (tb > 64 && (size_t)(tb + 4 * q4 + pad) * M * esz > (size_t)PP_LDS_BYTES) tb >>= 1;
     if (log2m < 0 && tb < 1024) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
     const int row_stride = tb + 4 * q4 + pad;
     const size_t lds_x = ((size_t)row_stride * M * esz + 15) & ~(size_t)15;
-    const size_t lds = lds_x + (size_t)PP_THREADS * 4 * sizeof(pp_acc_t) + (size_t)M * 4 * q4 * sizeof(float);     // + partial sums + taps
+    const size_t lds = lds_x + (size_t)PP_THREADS * 4 * sizeof(pp_acc_t) +                                      // + partial sums
+                       ((aligned && PP_PAIRS && PP_TAPS_SMEM) ? 0 : (size_t)M * (8 * q4 + 4) * sizeof(float));     // + taps (twice)
     if (lds_x > (size_t)PP_LDS_BYTES) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
     const int misalign = (int)(((uintptr_t)in & 15u) / A::BYTES);
     const long long ntiles = (n_out + tb - 1) / tb;
@@ -442,8 +510,19 @@ int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_i
     const int nt = ntaps + d;
     const int per_row = (nt + M - 1) / M;
     const int q4 = (per_row + 3) / 4;
+#if PP_PAIRS
+    // row r: its 4 q4 taps, then the same taps one place later (d[k] = c[k - 1], 4 q4 + 4 entries): the pairs the odd outputs use
+    const size_t rowlen = (size_t)8 * q4 + 4;
+    std::vector<float> cp((size_t)M * rowlen, 0.0f);
+    for (int j = 0; j < ntaps; ++j) {
+        const size_t r = (size_t)((j + d) % M), k = (size_t)((j + d) / M);
+        cp[r * rowlen + k] = coef[j];
+        cp[r * rowlen + 4 * q4 + k + 1] = coef[j];
+    }
+#else
     std::vector<float> cp((size_t)M * 4 * q4, 0.0f);
     for (int j = 0; j < ntaps; ++j) cp[(size_t)((j + d) % M) * 4 * q4 + (j + d) / M] = coef[j];
+#endif
     const float *dcoef = wfx_coef_device(ctx, cp.data(), cp.size());     // uploaded once per distinct table
     if (!dcoef) return WFX_ERR_HIP;
     const long long ni = (long long)n_in, no = (long long)n_out;
