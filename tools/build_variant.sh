@@ -9,5 +9,5 @@ mkdir -p wefax_amd/variants wefax_amd/csrc/build/variants
 O=wefax_amd/csrc/build/variants/$SRC.$NAME.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I include -I wefax_amd/csrc "$@" -c wefax_amd/csrc/$SRC.hip -o $O
 OBJS=$(ls wefax_amd/csrc/build/*.o | grep -v "/$SRC.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o wefax_amd/variants/libwefax_hip.$NAME.so $OBJS $O -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o wefax_amd/variants/libwefax_hip.$NAME.so $OBJS $O -ldl -lpthread
 ls -la wefax_amd/variants/libwefax_hip.$NAME.so

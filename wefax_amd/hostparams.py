@@ -100,12 +100,12 @@ def read_wav(path: str):
     dtypes scipy.io.wavfile.read (wefax.py:349) returns: uint8, int16, int32
     (24-bit left-justified), float32, float64; [n] or [n, channels]."""
     with open(path, "rb") as fh:
-        blob = fh.read()
+        blob = memoryview(fh.read())           # slices below are views: the samples are copied once, by the upload
     if len(blob) < 12 or blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
         raise ValueError("File format not understood. Only 'RIFF' and 'WAVE' supported.")
     pos, fmt, payload = 12, None, None
     while pos + 8 <= len(blob):
-        cid, size = blob[pos:pos + 4], struct.unpack_from("<I", blob, pos + 4)[0]
+        cid, size = bytes(blob[pos:pos + 4]), struct.unpack_from("<I", blob, pos + 4)[0]
         body = pos + 8
         if cid == b"fmt ":
             tag, ch, rate, _bps, _align, bits = struct.unpack_from("<HHIIHH", blob, body)

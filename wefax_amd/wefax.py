@@ -15,6 +15,7 @@ What is deliberately different from the reference (none of it changes a pixel):
 from __future__ import annotations
 
 import os
+import threading
 import sys
 
 import numpy as np
@@ -52,6 +53,46 @@ def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEF
     p.frame_samples = frame_len * hp.TARGET_RATE                       # wefax.py:265-266
     p.width = int(frame_len * hp.TARGET_RATE)                          # wefax.py:298
     return p, {"input_length": input_length, "resampled": resampled, "n": n, "length": n / hp.TARGET_RATE}   # wefax.py:393
+
+
+# Idle contexts, per device.  Creating a context (stream, pinned mirrors, first allocations: 2-8 ms) and destroying one (10 ms of
+# hipFree) cost more than decoding a ten-minute capture (0.34 ms), and a service makes one Demodulator per file: a Demodulator
+# takes an idle context when it starts processing and hands it back when it is closed or collected.  Buffers, transform plans and
+# filter tables stay with the context.  WFX_CTX_POOL=<n> idle contexts are kept per device (default 2, 0 = none).
+_POOL_LOCK = threading.Lock()
+_POOL: dict = {}
+
+
+def _device_index(device) -> int:
+    """None = the process's default device, as nat.Context resolves it."""
+    return int(os.environ.get("WEFAX_DEVICE", os.environ.get("LOCAL_RANK", "0"))) if device is None else int(device)
+
+
+def _acquire_context(device: int):
+    with _POOL_LOCK:
+        idle = _POOL.get(device)
+        if idle:
+            return idle.pop()
+    return nat.Context(device)
+
+
+def _release_context(ctx, device: int):
+    keep = int(os.environ.get("WFX_CTX_POOL", "2"))
+    with _POOL_LOCK:
+        idle = _POOL.setdefault(device, [])
+        if len(idle) < keep:
+            idle.append(ctx)
+            return
+    ctx.close()
+
+
+def release_contexts():
+    """Destroy the idle contexts (and with them the device memory they hold)."""
+    with _POOL_LOCK:
+        idle = [c for lst in _POOL.values() for c in lst]
+        _POOL.clear()
+    for c in idle:
+        c.close()
 
 
 class DecodeJob:
@@ -169,7 +210,7 @@ class Demodulator:
         self.quiet = quiet
         self.stream = tcp_stream
         self.websocket_stack = []
-        self._device = device
+        self._device = _device_index(device)
         self._hilbert_mode = hilbert_mode
         self._fir_taps = fir_taps
         self._ctx = None
@@ -219,7 +260,7 @@ class Demodulator:
             self._progress("resampling audio", 0)
 
         if self._ctx is None:
-            self._ctx = nat.Context(self._device)
+            self._ctx = _acquire_context(self._device)
         notch = hp.load_notch_settings()
         job = DecodeJob(self._ctx, data, sample_rate, self.lines_per_minute, notch,
                         self._hilbert_mode, self._fir_taps)
@@ -342,10 +383,16 @@ class Demodulator:
         self.output_image.save(filepath)
 
     def close(self):
-        if self._ctx is not None:
-            self._ctx.close()
-            self._ctx = None
-            self._job = None
+        """Hand the context back (the image, if nobody has looked at it yet, goes with it)."""
+        ctx, self._ctx, self._job = self._ctx, None, None
+        if ctx is not None:
+            _release_context(ctx, self._device)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
 
 
 def main(argv=None):
