@@ -206,6 +206,32 @@ def test_png_assembled_on_the_device_and_the_compressed_alternative(tmp_path):
         assert np.array_equal(_read_png_gray8(path), g["image"]), path
 
 
+def test_demodulators_share_idle_contexts():
+    """One Demodulator per file like the reference, but the context (stream, buffers, plans) outlives it: a closed or collected
+    Demodulator hands it to the idle pool and the next one takes it from there; two that are alive at once get two contexts;
+    a Demodulator keeps its image until it is closed."""
+    from wefax_amd import Demodulator, wefax as wx
+    g = np.load(os.path.join(GOLDEN, "mono_noisy_120.npz"))
+    wav = os.path.join(GOLDEN, "inputs", "mono_noisy_120.wav")
+    wx.release_contexts()
+    d1 = Demodulator(wav, lines_per_minute=120, quiet=True)
+    d1.process()
+    h1 = d1._ctx.h
+    d2 = Demodulator(wav, lines_per_minute=120, quiet=True)
+    d2.process()
+    assert d2._ctx.h != h1                                      # both alive: separate contexts
+    assert np.array_equal(d1.output_array, g["image"]) and np.array_equal(d2.output_array, g["image"])
+    d1.close()
+    d3 = Demodulator(wav, lines_per_minute=120, quiet=True)
+    d3.process()
+    assert d3._ctx.h == h1                                      # taken from the pool
+    assert np.array_equal(d3.output_array, g["image"])
+    del d2, d3
+    assert sum(len(v) for v in wx._POOL.values()) == 2
+    wx.release_contexts()
+    assert not wx._POOL
+
+
 def test_command_line_rejects_what_the_reference_rejects(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(REPO, "wefax.py"), str(tmp_path / "missing.wav"), "120", str(tmp_path / "o.png")],
                        capture_output=True, text=True, timeout=120)
