@@ -68,6 +68,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -o run -
 python tools/kstats.py "$OUT/trace_c3" "select_|notch|median|image|quantise|sync|mr2_pass|mr_pass|resample" > "$OUT/kernel_stats_c3.txt"
 rm -rf "$OUT/trace_c3"
 
+# the read-streaming ceiling of this box and the ingest stage against it
+if [ -x tools/micro/build/stream_big ]; then timeout 120 tools/micro/build/stream_big > "$OUT/stream_ceiling.txt" 2>&1; fi
+timeout 600 python tools/ingest_probe.py > "$OUT/ingest_probe.txt" 2>> "$OUT/bench.err"
+
 # where the waves' cycles go (SQ counters, one pass)
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/sq" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie > /dev/null 2>> "$OUT/bench.err"
 python tools/pmc_sq.py "$OUT/sq" > "$OUT/sq_counters.txt"
