@@ -122,9 +122,11 @@ class ShardedDecoder:
     Ranks other than 0 get ``None`` images; scalars (low, high) are available everywhere."""
 
     def __init__(self, ctx: nat.Context, comm: nat.Comm, n0: int, sample_rate, lines_per_minute: int = 120, kind: int = nat.WFX_IN_I16_MONO,
-                 notch=hp.DEFAULT_NOTCH, data: np.ndarray | None = None, loader=None):
+                 notch=None, data: np.ndarray | None = None, loader=None):
         self.ctx, self.comm = ctx, comm
         self.frame_len = 1 / (lines_per_minute / 60)
+        if notch is None:                       # config/config.json like Demodulator (wefax.py:63-66), defaults when there is no file
+            notch = hp.load_notch_settings()
         self.params, self.meta = build_params(kind, int(n0), sample_rate, self.frame_len, notch)
         self.n = self.meta["n"]
         self.width = self.params.width
@@ -179,7 +181,7 @@ def _info_dict(info: nat.DecodeInfo) -> dict:
             "phasing": [int(info.phasing[k]) for k in range(info.n_phasing)]}
 
 
-def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute: int = 120, device: int = 0, notch=hp.DEFAULT_NOTCH,
+def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute: int = 120, device: int = 0, notch=None,
                     want=("image", "stream", "envelope", "audio"), make_decoder=None):
     """Every rank of a ``world``-rank sharded decode in this process, on one GPU, phase by phase (local communicator:
     a collective completes when the last rank has posted its part).  Returns the root's results plus the per-rank
@@ -286,7 +288,7 @@ def _raw_slice(x, raw_loader, ia: int, ib: int, n_in_total: int):
 
 class FrontEndExactDecoder:
     """ONE GPU, oversampled capture: the time-domain front end (polyphase.FrontEnd(stop_at_2x=True), halo-local stencils)
-    down to 22 050 Hz, then the fused exact decode of ``wefax.DecodeJob`` attached to its output in HBM -- notch
+    down to the hand-over rate, then the fused exact decode of ``wefax.DecodeJob`` attached to its output in HBM -- notch
     filtfilt, FFT resample by 2, FFT Hilbert, global percentiles, sync search, bicubic image.  Differs from the reference
     only by the front end's pass band (polyphase.py)."""
 
@@ -302,7 +304,7 @@ class FrontEndExactDecoder:
         if in_kind is None:
             in_kind = 1 if (not isinstance(raw, tuple) and raw.ndim == 2) else 0
         self.fe = FrontEndDevice(ctx, self.chain, raw, in_kind)
-        self.job = DecodeJob.from_device(ctx, self.fe.p_out, n_fe, lines_per_minute, sample_rate=rate)
+        self.job = DecodeJob.from_device(ctx, self.fe.p_out, n_fe, lines_per_minute, notch=hp.load_notch_settings(), sample_rate=rate)
         assert self.job.n == self.n
         self.width = self.job.width
 
@@ -329,7 +331,7 @@ class FrontEndShardedDecoder:
     between GPUs; what is exchanged is the transposes of the transforms at 22 050 / 11 025 Hz."""
 
     def __init__(self, ctx, comm, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None,
-                 notch=hp.DEFAULT_NOTCH):
+                 notch=None):
         if not frontend.exact_tail:
             raise ValueError("the sharded form needs FrontEnd(stop_rate=...): the exact resampler takes the last step")
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
