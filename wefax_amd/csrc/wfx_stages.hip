@@ -750,6 +750,63 @@ __device__ __forceinline__ void sel_stream(const double *__restrict__ v, uint64_
     }
 }
 
+// the same walk in two phases per batch: every value of the batch goes through `first`, then `between` runs once, then every
+// value goes through `second` (the compaction counts a lane's matches, reserves list space for the whole wave with ONE atomic,
+// then writes -- an atomic per element slot and wave made the pass latency-bound on captures whose bins are full)
+template <int NT, typename F1, typename FB, typename F2>
+__device__ __forceinline__ void sel_stream2(const double *__restrict__ v, uint64_t n, F1 first, FB between, F2 second)
+{
+    const int t = threadIdx.x;
+    const uint64_t quads = (n + 3) / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * (uint64_t)NT;
+    const uint64_t nround = (quads + stride - 1) / stride;
+    uint64_t it = 0;
+    for (; it + SEL_UN <= nround && (it + SEL_UN) * stride * 4 <= n; it += SEL_UN) {
+        double2 lo[SEL_UN], hi[SEL_UN];
+#pragma unroll
+        for (int u = 0; u < SEL_UN; ++u) {
+            const uint64_t i0 = ((it + u) * stride + blockIdx.x * (uint64_t)NT + t) * 4;
+            lo[u] = *(const double2 *)(v + i0);
+            hi[u] = *(const double2 *)(v + i0 + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_UN; ++u) {
+            first(lo[u].x, true);
+            first(lo[u].y, true);
+            first(hi[u].x, true);
+            first(hi[u].y, true);
+        }
+        between();
+#pragma unroll
+        for (int u = 0; u < SEL_UN; ++u) {
+            second(lo[u].x, true);
+            second(lo[u].y, true);
+            second(hi[u].x, true);
+            second(hi[u].y, true);
+        }
+    }
+    for (; it < nround; ++it) {
+        const uint64_t i0 = (it * stride + blockIdx.x * (uint64_t)NT + t) * 4;
+        double a[4] = {0, 0, 0, 0};
+        if (i0 + 4 <= n) {
+            const double2 lo = *(const double2 *)(v + i0), hi2 = *(const double2 *)(v + i0 + 2);
+            a[0] = lo.x;
+            a[1] = lo.y;
+            a[2] = hi2.x;
+            a[3] = hi2.y;
+        } else {
+            if (i0 < n) a[0] = v[i0];
+            if (i0 + 1 < n) a[1] = v[i0 + 1];
+            if (i0 + 2 < n) a[2] = v[i0 + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) first(a[k], i0 + k < n);
+        between();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) second(a[k], i0 + k < n);
+    }
+}
+
 // level 1: choose the level-0 digit of every query, then histogram bits 52..42 of the
 // values whose top 11 bits match
 template <int NT>
@@ -845,27 +902,42 @@ __global__ void __launch_bounds__(NT) select_compact_kernel(const double *__rest
         active[q] = owner[q] == q;
         mypfx[q] = pfx[q];
     }
-    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    unsigned cnt[4] = {0, 0, 0, 0}, off[4] = {0, 0, 0, 0};
+    auto count = [&](double x, bool valid) {
+        const unsigned long long hi = f64_key(x) >> 42;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (active[q] && valid && hi == mypfx[q]) ++cnt[q];
+    };
+    auto reserve = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!active[q]) continue;
+            if (__ballot(cnt[q] != 0) == 0) continue;                  // nothing in this wave (the common case on noisy captures)
+            unsigned incl = cnt[q];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            unsigned base = 0;
+            if (lane == 63) base = atomicAdd(&ws[SEL_CNT + q], incl);   // one atomic per wave, list and batch
+            base = (unsigned)__builtin_amdgcn_readlane((int)base, 63);
+            off[q] = base + incl - cnt[q];
+            cnt[q] = 0;
+        }
+    };
     auto append = [&](double x, bool valid) {
         const unsigned long long key = f64_key(x);
         const unsigned long long hi = key >> 42;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (!active[q]) continue;
-            const bool match = valid && hi == mypfx[q];
-            const unsigned long long m = __ballot(match);
-            if (m == 0) continue;
-            const int first = __ffsll((long long)m) - 1;
-            unsigned base = 0;
-            if (lane == first) base = atomicAdd(&ws[SEL_CNT + q], (unsigned)__popcll(m));
-            base = (unsigned)__builtin_amdgcn_readlane((int)base, first);
-            if (match) {
-                const uint64_t slot = (uint64_t)base + (uint64_t)__popcll(m & lt_mask);
+        for (int q = 0; q < 4; ++q)
+            if (active[q] && valid && hi == mypfx[q]) {
+                const uint64_t slot = off[q]++;
                 if (slot < cap) cand[(uint64_t)q * cap + slot] = key;
             }
-        }
     };
-    sel_stream<NT>(v, n, append);
+    sel_stream2<NT>(v, n, count, reserve, append);
 }
 
 // levels 2..5 on the candidate lists, numpy's lerp, and clearing of the workspace
