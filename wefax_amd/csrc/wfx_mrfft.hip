@@ -1462,7 +1462,7 @@ __global__ void __launch_bounds__(256) resample_mr_glue(const cplx *__restrict__
     const double inv_n0 = 1.0 / (double)n0;
     auto bin = [&](long long j) {                       // Y[j], j in [0, K]
         if (j > half) return make_double2(0.0, 0.0);
-        const long long a = j % M, b = (M - j) % M;
+        const long long a = j >= M ? j - M : j, b = (j == 0 || j >= M) ? 0 : M - j;       // j % M, (M - j) % M for j <= M
         const cplx zk = Z[a], zc = make_double2(Z[b].x, -Z[b].y);
         double sn, cs;
         sincospi(2.0 * (double)j / (double)n0, &sn, &cs);
@@ -1476,15 +1476,20 @@ __global__ void __launch_bounds__(256) resample_mr_glue(const cplx *__restrict__
         if (j == 0 || j == K) y.y = 0.0;
         return y;
     };
-    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < K; k += (long long)gridDim.x * 256) {
-        const cplx yk = bin(k);
-        const cplx yr = bin(K - k);
+    // W[k] and W[K - k] are made of the same two bins: one lane does both (each spectrum value is read once)
+    auto emit = [&](long long k, const cplx &yk, const cplx &yr) {
         const cplx yc = make_double2(yr.x, -yr.y);
         const cplx sum = make_double2(yk.x + yc.x, yk.y + yc.y), dif = make_double2(yk.x - yc.x, yk.y - yc.y);
         double sn, cs;
         sincospi(2.0 * (double)k / (double)num, &sn, &cs);
         // i (cs + i sn) dif = (-(sn dif.x) - cs dif.y, cs dif.x - sn dif.y)
         W[k] = make_double2((sum.x - (sn * dif.x + cs * dif.y)) * inv_n0, (sum.y + (cs * dif.x - sn * dif.y)) * inv_n0);
+    };
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; 2 * k <= K; k += (long long)gridDim.x * 256) {
+        const cplx yk = bin(k);
+        const cplx yr = bin(K - k);
+        emit(k, yk, yr);
+        if (k != 0 && K - k != k) emit(K - k, yr, yk);
     }
 }
 
@@ -1509,7 +1514,7 @@ int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num
     const long long nmin = (long long)(n0 < num ? n0 : num), half = nmin / 2;
     WFX_TRY(mr_run(ctx, p1, (const cplx *)x, A, B, 0, false, nullptr, &Z, x_is_i16, half, M - half));
     cplx *Wb = (Z == A) ? B : A;
-    WFX_LAUNCH(ctx, K_RESAMPLE_PW, resample_mr_glue, dim3(wfx_stream_grid((uint64_t)K, 256)), dim3(256), (const cplx *)Z, (long long)n0,
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, resample_mr_glue, dim3(wfx_stream_grid((uint64_t)K / 2 + 1, 256)), dim3(256), (const cplx *)Z, (long long)n0,
                (long long)num, Wb);
     WFX_TRY(mr_get_plan(ctx, K, &p2));        // (std::map: p1 stays valid)
     cplx *res = nullptr;
