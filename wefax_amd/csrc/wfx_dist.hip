@@ -558,14 +558,15 @@ __global__ void __launch_bounds__(256) dist_resample_glue_kernel(const cplx *__r
     const double edge = (nmin % 2 == 0) ? (num < n0 ? 2.0 : (num > n0 ? 0.5 : 1.0)) : 1.0;
     const double inv_n0 = 1.0 / (double)n0;
     const int B = km.B;
-    auto zat = [&](long long j) {                       // Z[j], j in [0, M1)
-        const int k1 = (int)(j % R1);
+    auto zat = [&](long long j) {                       // Z[j], j in [0, M1): all indices fit 32 bits (n0 < 2^31)
+        const unsigned q = (unsigned)j / (unsigned)R1;
+        const int k1 = (int)((unsigned)j - q * (unsigned)R1);
         const int kk = (k1 >= km.kb0 && k1 < km.kb0 + km.kc0) ? k1 - km.kb0 : km.kc0 + (k1 - km.kb1);
-        return Z[(j / R1) * B + kk];
+        return Z[(long long)q * B + kk];
     };
     auto bin = [&](long long j) {                       // Y[j], j in [0, K]
         if (j > half) return make_double2(0.0, 0.0);
-        const long long a = j % M1, b = (M1 - j) % M1;
+        const long long a = j >= M1 ? j - M1 : j, b = (j == 0 || j >= M1) ? 0 : M1 - j;      // j % M1, (M1 - j) % M1 for j <= M1
         const cplx zk = zat(a), zb = zat(b);
         const cplx zc = make_double2(zb.x, -zb.y);
         double sn, cs;
@@ -581,7 +582,7 @@ __global__ void __launch_bounds__(256) dist_resample_glue_kernel(const cplx *__r
     };
     const long long total = (K / R1) * B;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long k2 = e / B;
+        const long long k2 = (long long)((unsigned)e / (unsigned)B);              // (total < 2^31)
         const int kk = (int)(e - k2 * B);
         const long long k = (long long)(kk < km.kc0 ? km.kb0 + kk : km.kb1 + (kk - km.kc0)) + k2 * R1;
         const cplx yk = bin(k);
