@@ -453,7 +453,8 @@ int launch_decimate(wfx_ctx *ctx, const void *in, long long n_in, long long firs
     const int misalign = (int)(((uintptr_t)in & 15u) / A::BYTES);
     const long long ntiles = (n_out + tb - 1) / tb;
     const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
-    auto kern = !aligned ? decimate_kernel<IN, OUT, false, 0>
+    auto kern = (!aligned && q4 == 8) ? decimate_kernel<IN, OUT, false, 8>      // (/3 with 87 taps behind the ingest: unrolled)
+                : !aligned ? decimate_kernel<IN, OUT, false, 0>
                 : q4 == 2 ? decimate_kernel<IN, OUT, true, 2>
                 : q4 == 3 ? decimate_kernel<IN, OUT, true, 3>
                           : decimate_kernel<IN, OUT, true, 0>;
