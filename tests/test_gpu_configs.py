@@ -7,6 +7,7 @@
   * the CLI `python wefax.py in.wav LPM out.png` (/root/reference/wefax.py:411-424): the PNG on disk decodes to the golden image.
   * filtfilt's odd extension in the capture's own dtype (wefax.py:72) as a stage call.
 """
+import json
 import os
 import subprocess
 import sys
@@ -204,6 +205,16 @@ def test_png_assembled_on_the_device_and_the_compressed_alternative(tmp_path):
     d.save_output_image(c)                                                       # ... and the host copy is encoded instead
     for path in (a, b, c):
         assert np.array_equal(_read_png_gray8(path), g["image"]), path
+
+
+def test_random_captures_against_the_oracle():
+    """tools/random_parity.py: random rate / length / LPM / noise / sample format / channel count, the drop-in Demodulator
+    against the oracle -- same exception type or same start_frame, identical uint8 stream, progress messages and image
+    (profiles/r02_v3/random_parity_summary.json holds a 400-case run)."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "random_parity.py"), "--cases", "16", "--seed", "3"], capture_output=True, text=True,
+                       timeout=600)
+    last = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and last == {"cases": 16, "failed": 0}, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_demodulators_share_idle_contexts():
