@@ -562,6 +562,9 @@ __device__ __forceinline__ void dft_any(cplx *v, const double sg, PUT put)
 #ifndef WFX_EXP_T16
 #define WFX_EXP_T16 0
 #endif
+#ifndef WFX_PF_BUDGET
+#define WFX_PF_BUDGET 140
+#endif
 #ifndef WFX_PF_SPEC
 #define WFX_PF_SPEC 0
 #endif
@@ -580,7 +583,9 @@ constexpr bool mr2_prefetch(int ra, int rb)
     if (rb == 25 || ra == 25) return true;
 #endif
     if (mr2_rows(rb)) return na * ra * 4 + 40 <= 140;     // level B works five points at a time (dft_rows)
-    return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) <= 140;      // registers: a tile in flight + a level-B transform
+    // registers: a tile in flight + a level-B transform (the 16-point level keeps two half-size scratch arrays: with the tile in
+    // flight the (15,16) pass spilled 87 registers and took 580 us on the 86.4 M-point transform, 433 without)
+    return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) + (rb == 16 ? 24 : 0) <= WFX_PF_BUDGET;
 }
 
 #ifndef WFX_FUSED_LB
