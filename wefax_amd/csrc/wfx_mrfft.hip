@@ -574,7 +574,10 @@ __device__ __forceinline__ void dft_any(cplx *v, const double sg, PUT put)
 // radices above 128: 512 lanes on a 32-column tile (one workgroup per CU, 90-115 KB of LDS) -- row segments of 512 bytes like the
 // smaller radices have; with 256 lanes and 16 columns the same passes run 4 us slower at the benchmark size
 constexpr int mr2_nt(int r) { return (WFX_WIDE && r > 128) ? 512 : 256; }
-constexpr int mr2_log2t(int r) { return r <= 16 ? 8 : r <= 32 ? 7 : r <= 64 ? 6 : (r <= 128 && !(WFX_EXP_T16 && r == 91)) ? 5 : WFX_WIDE ? 5 : 4; }
+#ifndef WFX_T64
+#define WFX_T64 5
+#endif
+constexpr int mr2_log2t(int r) { return r <= 16 ? 8 : r <= 32 ? 7 : r <= 63 ? 6 : r == 64 ? WFX_T64 : (r <= 128 && !(WFX_EXP_T16 && r == 91)) ? 5 : WFX_WIDE ? 5 : 4; }
 constexpr bool mr2_prefetch(int ra, int rb)
 {
     const int t = 1 << mr2_log2t(ra * rb);
