@@ -6,10 +6,11 @@ so it neither shards by sample range nor fits a 60-minute 1.536 MS/s IQ stream (
 This module is the halo-local counterpart SURVEY.md section 8e asks for: a chain of FIR stencils
 
     [ decimate by a power of two ]*  ->  [ rational p/q to 44 100 Hz ]  ->  decimate by 2  ->  decimate by 2
+    [ decimate by a power of two ]*  ->  decimate by 3  ->  (exact FFT resampler)          with ``stop_rate``
 
 (1.536 MS/s: /32 -> 48 kHz, x147/160 -> 44.1 kHz, /2 -> 22.05 kHz, /2 -> 11 025 Hz; 48 kHz: the last three;
-44.1 kHz: the last two; with ``stop_rate`` the chain ends at 22 050 or 14 700 Hz and the exact FFT resampler takes the
-last step) whose kernels live in ``csrc/wfx_polyphase.hip``.  Filters are Kaiser
+44.1 kHz: the last two; with ``stop_rate`` the chain ends at 16 000, 14 700 or 22 050 Hz and the exact FFT resampler
+takes the last step: 1.536 MS/s: /32 -> 48 kHz, /3 -> 16 kHz) whose kernels live in ``csrc/wfx_polyphase.hip``.  Filters are Kaiser
 windowed sincs designed here in float64 and handed to the C ABI as float32 host arrays:
 unit DC gain, linear phase centred on the output sample (zero delay), pass band flat to
 ``pass_hz``, stop band from 5512.5 Hz (the brick wall of the reference) at ``att_db``.

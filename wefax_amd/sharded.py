@@ -15,7 +15,7 @@ frames, and drives the phases.  No PyTorch anywhere: the communicator is RCCL bo
     * ``decode_emulated``     every rank of a world in THIS process on one GPU (tests, one-GPU boxes)
     * ``FrontEndDevice`` / ``FrontEndExactDecoder`` / ``FrontEndShardedDecoder``
                               oversampled captures (BASELINE configs[3]): the time-domain front end of
-                              ``polyphase.py`` down to 22 050 Hz on each rank's slice, then the exact (sharded) path
+                              ``polyphase.py`` down to the hand-over rate (16 000 Hz) on each rank's slice, then the exact (sharded) path
                               whose FFT resampler takes the last factor of two -- the reference's own brick wall
 """
 from __future__ import annotations
@@ -287,7 +287,7 @@ def _raw_slice(x, raw_loader, ia: int, ib: int, n_in_total: int):
 
 
 class FrontEndExactDecoder:
-    """ONE GPU, oversampled capture: the time-domain front end (polyphase.FrontEnd(stop_at_2x=True), halo-local stencils)
+    """ONE GPU, oversampled capture: the time-domain front end (polyphase.FrontEnd(stop_rate=...), halo-local stencils)
     down to the hand-over rate, then the fused exact decode of ``wefax.DecodeJob`` attached to its output in HBM -- notch
     filtfilt, FFT resample by 2, FFT Hilbert, global percentiles, sync search, bicubic image.  Differs from the reference
     only by the front end's pass band (polyphase.py)."""
@@ -325,10 +325,10 @@ class FrontEndExactDecoder:
 
 class FrontEndShardedDecoder:
     """One rank of the sharded decode of an oversampled capture (BASELINE configs[3]): the rank runs the front end over the raw
-    frames its rows of the 22 050 Hz signal need (halo of the FIR chain included: ``raw_loader(lo, hi)`` with indices
+    frames its rows of the hand-over-rate signal need (halo of the FIR chain included: ``raw_loader(lo, hi)`` with indices
     wrapping modulo the capture), then the sharded exact path takes over -- its distributed FFT resampler brings the
-    22 050 Hz signal to 11 025 Hz exactly as the one-GPU form does.  The raw stream is split ``world`` ways and never moves
-    between GPUs; what is exchanged is the transposes of the transforms at 22 050 / 11 025 Hz."""
+    hand-over-rate signal to 11 025 Hz exactly as the one-GPU form does.  The raw stream is split ``world`` ways and never moves
+    between GPUs; what is exchanged is the transposes of the transforms at the hand-over rate and at 11 025 Hz."""
 
     def __init__(self, ctx, comm, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None,
                  notch=None):
