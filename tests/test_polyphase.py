@@ -66,6 +66,11 @@ def test_chain_ranges_are_consistent_and_slice_invariant():
     assert [st.kind for st, _, _ in ch] == ["decimate", "rational", "decimate", "decimate"]
     assert [(st.kind, getattr(st, "factor", None)) for st in pp.FrontEnd(1536000, stop_rate=16000).stages] == [("decimate", 32), ("decimate", 3)]
     assert pp.FrontEnd.handover_rate(1536000) == 16000 and pp.FrontEnd.handover_rate(44100) == 14700
+    fe16 = pp.FrontEnd(1536000, stop_rate=16000)
+    # the ingest pair is the least-squares multiband design: 8 taps per polyphase row, stop bands and pair flatness as asked for
+    assert fe16.stages[0].ntaps == 8 * 32 - 3 and fe16.design is not None
+    assert fe16.design["stage1_stop_db"] < -129 and fe16.design["stage2_stop_db"] < -135 and fe16.design["pair_flatness"] < 1.8e-7
+    assert pp.FrontEnd(192000, stop_rate=16000).design is None          # small factors keep the Kaiser designs
     with pytest.raises(ValueError):
         pp.FrontEnd(1536000, stop_rate=13000)               # divides neither 48 000 nor 44 100 Hz
     for (s0, o0, i0), (s1, o1, i1) in zip(ch[:-1], ch[1:]):
