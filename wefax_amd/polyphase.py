@@ -228,7 +228,7 @@ class FrontEnd:
         h1 = ls_fir(n1, fs1, [(0.0, NYQ)] + stops, [1.0] + [0.0] * len(stops), [1.0] + [30.0] * len(stops))
         h1 /= h1.sum()
         fs2, fo2 = float(s2.fs_in), float(s2.fs_out)
-        n2 = s2.ntaps + 8 - (s2.ntaps + 8) % 2 + 1 if (s2.ntaps + 8) % 2 == 0 else s2.ntaps + 8
+        n2 = (s2.ntaps + 8) | 1                      # a few more taps than the plain low-pass: the pass band now has a shape to follow
         h2 = ls_fir(n2, fs2, [(0.0, NYQ), (fo2 - NYQ, fs2 / 2)], [lambda f: 1.0 / _response(h1, fs1, f), 0.0], [1.0, 1.0], grid=1200, iters=14)
         # verify before adopting
         fp = np.linspace(0.0, NYQ, 3000)
