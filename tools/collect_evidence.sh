@@ -71,6 +71,7 @@ rm -rf "$OUT/trace_c3"
 # randomised whole-path parity sweep against the oracle
 timeout 1200 python tools/random_parity.py --cases 200 --seed 11 > "$OUT/random_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_parity.jsonl"
 
+timeout 1200 python tools/random_fe_parity.py --cases 12 --seed 8 > "$OUT/random_fe_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_fe_parity.jsonl"
 timeout 1200 python tools/random_shard_parity.py --cases 24 --seed 5 > "$OUT/random_shard_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_shard_parity.jsonl"
 
 # the read-streaming ceiling of this box and the ingest stage against it

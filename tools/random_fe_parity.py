@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the oversampled-capture path (time-domain front end to the hand-over rate + exact path) against the
+oracle: rate, length, LPM, noise and seed at random; prints per case how many uint8 stream bytes differ (by how much) and the
+largest pixel difference -- the front end is fp32 and band-limited by filters, so this path is within +-1, not bit-identical.
+
+    python tools/random_fe_parity.py [--cases 12] [--seed 0]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from wefax_amd import _native as nat, polyphase as pp, sharded, synth      # noqa: E402
+from oracle import wefax_oracle as wo                                       # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    ctx = nat.Context(0)
+    worst = {"stream_max": 0, "image_max": 0, "image_gt1": 0, "start_ne": 0}
+    with tempfile.TemporaryDirectory() as td:
+        for k in range(a.cases):
+            fs = int(rng.choice([1536000, 1536000, 192000, 48000]))
+            iq = fs != 48000
+            lpm = int(rng.choice([120, 240]))
+            seconds = int(rng.integers(24, 41))                       # whole seconds: the nominal and the reference's rate ratio agree
+            t_line = 60.0 / lpm
+            phasing = 40 if lpm == 240 else 20
+            lines = int(round((seconds - 3.0) / t_line)) - phasing
+            x = synth.synth_capture(float(fs), noise=float(rng.choice([0.01, 0.05, 0.1])), seed=int(rng.integers(1 << 30)), lpm=lpm, phasing_lines=phasing,
+                                    image_lines=lines, start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0, iq=iq)
+            path = os.path.join(td, "c.wav")
+            synth.write_wav(path, fs, x)
+            ref = wo.process(path, lpm, want_messages=False)
+            fe = pp.FrontEnd(fs, stop_rate=pp.FrontEnd.handover_rate(fs))
+            dec = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=lpm)
+            dec.run()
+            info = dec.result()
+            rec = dict(fs=fs, lpm=lpm, seconds=seconds, frames=int(x.shape[0]))
+            if ref.get("exception") is not None or info.no_group:
+                rec["no_group"] = [ref.get("exception") is not None, bool(info.no_group)]
+                rec["ok"] = rec["no_group"][0] == rec["no_group"][1]
+            else:
+                st, img = dec.fetch("digitalized"), dec.fetch("image")
+                d = np.abs(st.astype(np.int16) - ref["digitalized"].astype(np.int16))
+                di = np.abs(img.astype(np.int16) - ref["image"].astype(np.int16)) if img.shape == ref["image"].shape else np.array([255])
+                rec.update(start_eq=bool(info.start_frame == ref["start_frame"]), stream_ne=int(np.count_nonzero(d)), stream_max=int(d.max()),
+                           image_ne=int(np.count_nonzero(di)), image_gt1=int(np.count_nonzero(di > 1)), image_max=int(di.max()))
+                rec["ok"] = rec["start_eq"] and rec["stream_max"] <= 1 and rec["image_max"] <= 1
+                worst["stream_max"] = max(worst["stream_max"], rec["stream_max"])
+                worst["image_max"] = max(worst["image_max"], rec["image_max"])
+                worst["image_gt1"] += rec["image_gt1"]
+                worst["start_ne"] += 0 if rec["start_eq"] else 1
+            dec.close()
+            print(json.dumps(rec), flush=True)
+    print(json.dumps({"cases": a.cases, **worst}))
+
+
+if __name__ == "__main__":
+    main()
