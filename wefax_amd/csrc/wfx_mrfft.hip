@@ -181,8 +181,9 @@ __device__ __forceinline__ int mr_twiddle_k(const mr_pass_desc &d, int kl)
 __device__ __forceinline__ long long mr_global_index(const mr_pass_desc &d, long long o)
 {
     if (!d.dist) return o;
-    const int kk = (int)(o % d.B);
-    return (long long)(kk < d.kc0 ? d.kb0 + kk : d.kb1 + (kk - d.kc0)) + (o / d.B) * (long long)d.kstep;
+    const unsigned q = (unsigned)o / (unsigned)d.B;                    // (a rank's part of a transform has fewer than 2^31 points)
+    const int kk = (int)((unsigned)o - q * (unsigned)d.B);
+    return (long long)(kk < d.kc0 ? d.kb0 + kk : d.kb1 + (kk - d.kc0)) + (long long)q * (long long)d.kstep;
 }
 
 // IN_MODE 0: complex input array; 1: packed real input z[q] = x[2q+1] + i x[2q];
