@@ -209,7 +209,7 @@ class FrontEnd:
         per polyphase row: a third less work in the kernel's tap loop than the Kaiser design's 12) at the price of a pass band that
         ripples by 1e-5; the SECOND filter is designed against the inverse of that response, so that the pair is flat to better
         than the Kaiser chain was (measured 9e-8 for 1.536 MS/s, against 1.8e-7).  Kept only if the achieved figures meet att_db."""
-        if len(self.stages) != 2 or self.stages[0].kind != "decimate" or self.stages[0].factor < 16:
+        if len(self.stages) != 2 or self.stages[0].kind != "decimate" or self.stages[0].factor < 8:
             return
         s1, s2 = self.stages
         n1 = 8 * s1.factor - 3
