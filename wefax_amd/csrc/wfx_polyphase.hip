@@ -125,6 +125,10 @@ __device__ __forceinline__ uint4 pp_fetch(const void *in, const unsigned char *b
 // partial sums are added in group order through LDS: the order of additions per output is
 // fixed by (M, rs) alone, never by where a slice starts.
 constexpr int PP_BATCH = 8;
+// Build-time switches for A/B runs (tools/build_variant.sh); the defaults are what measured fastest on MI355X:
+//   PP_PAIRS 1      packed FMAs over tap pairs (0: over output pairs)      PP_TAPS_SMEM 1  aligned form: taps by scalar loads (0: LDS)
+//   PP_PREFETCH 1   aligned form: next tile's first chunks in flight       PP_ACC64 0      row sums added in fp64 (+9 % time)
+//   PP_TB_MAX 1024  largest tile (outputs)                                 PP_MINB 1       __launch_bounds__ minimum workgroups per CU
 #ifndef PP_ACC64
 #define PP_ACC64 0
 #endif
