@@ -559,15 +559,12 @@ __device__ __forceinline__ void dft_any(cplx *v, const double sg, PUT put)
     }
 }
 
-// tile width (columns) and prefetch policy of a pair, shared by the kernel and the host
-#ifndef WFX_EXP_T16
-#define WFX_EXP_T16 0
-#endif
+// tile width (columns) and prefetch policy of a pair, shared by the kernel and the host.  Build-time switches for A/B runs
+// (tools/build_variant.sh; DESIGN.md 3.2 has what each measured): WFX_ROWS_LDS, WFX_PFA15 (composite levels), WFX_PF_BUDGET (registers
+// a pass may spend on the tile in flight), WFX_T64 (log2 columns of a radix-64 tile), WFX_WIDE (512-lane workgroups for radices
+// above 128), WFX_FUSED_LB (workgroups per CU of the fused spectral pass), WFX_FUSED_SPECTRUM is a run-time switch.
 #ifndef WFX_PF_BUDGET
 #define WFX_PF_BUDGET 140
-#endif
-#ifndef WFX_PF_SPEC
-#define WFX_PF_SPEC 0
 #endif
 #ifndef WFX_WIDE
 #define WFX_WIDE 0
@@ -578,14 +575,11 @@ constexpr int mr2_nt(int r) { return (WFX_WIDE && r > 128) ? 512 : 256; }
 #ifndef WFX_T64
 #define WFX_T64 5
 #endif
-constexpr int mr2_log2t(int r) { return r <= 16 ? 8 : r <= 32 ? 7 : r <= 63 ? 6 : r == 64 ? WFX_T64 : (r <= 128 && !(WFX_EXP_T16 && r == 91)) ? 5 : WFX_WIDE ? 5 : 4; }
+constexpr int mr2_log2t(int r) { return r <= 16 ? 8 : r <= 32 ? 7 : r <= 63 ? 6 : r == 64 ? WFX_T64 : r <= 128 ? 5 : WFX_WIDE ? 5 : 4; }
 constexpr bool mr2_prefetch(int ra, int rb)
 {
     const int t = 1 << mr2_log2t(ra * rb);
     const int na = (t * rb + mr2_nt(ra * rb) - 1) / mr2_nt(ra * rb);
-#ifdef WFX_EXP_R25
-    if (rb == 25 || ra == 25) return true;
-#endif
     if (mr2_rows(rb)) return na * ra * 4 + 40 <= 140;     // level B works five points at a time (dft_rows)
     // registers: a tile in flight + a level-B transform (the 16-point level keeps two half-size scratch arrays: with the tile in
     // flight the (15,16) pass spilled 87 registers and took 580 us on the 86.4 M-point transform, 433 without)
@@ -596,17 +590,12 @@ constexpr bool mr2_prefetch(int ra, int rb)
 #define WFX_FUSED_LB 2
 #endif
 template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
-#ifdef WFX_EXP_R25
-#define WFX_R25_LB(RA, RB) (((RA) == 25 || (RB) == 25) ? 1 : 2)
-#else
-#define WFX_R25_LB(RA, RB) 2
-#endif
-__global__ void __launch_bounds__(mr2_nt(RA * RB), mr2_nt(RA * RB) == 512 ? 1 : OUT_MODE == 2 ? WFX_FUSED_LB : WFX_R25_LB(RA, RB))
+__global__ void __launch_bounds__(mr2_nt(RA * RB), mr2_nt(RA * RB) == 512 ? 1 : OUT_MODE == 2 ? WFX_FUSED_LB : 2)
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
          int ntiles)
 {
     constexpr int LOG2T = mr2_log2t(RA * RB);
-    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3 || (OUT_MODE == 1 && (mr2_rows(RB) || WFX_PF_SPEC)))) ? 1 : 0;
+    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3 || (OUT_MODE == 1 && mr2_rows(RB)))) ? 1 : 0;
     constexpr int R = RA * RB, T = 1 << LOG2T;
     constexpr int NT = mr2_nt(R);                                 // lanes per workgroup
     constexpr int NA = (T * RB + NT - 1) / NT, NB = (T * RA + NT - 1) / NT;
