@@ -296,6 +296,17 @@ void wfx_prof_begin(wfx_ctx *ctx, int kid)
     ctx->prof_recs.push_back(r);
 }
 
+void wfx_prof_events(wfx_ctx *ctx, int kid, hipEvent_t *a, hipEvent_t *b)
+{
+    wfx_prof_rec r;
+    r.a = take_event(ctx);
+    r.b = take_event(ctx);
+    r.kid = kid;
+    ctx->prof_recs.push_back(r);
+    *a = r.a;
+    *b = r.b;
+}
+
 void wfx_prof_end(wfx_ctx *ctx)
 {
     if (!ctx->prof) return;

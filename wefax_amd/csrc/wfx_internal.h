@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -162,15 +163,21 @@ bool wfx_ctx_alive(const wfx_ctx *ctx);      // false once wfx_destroy has run o
 
 // ---- profiling-aware launch ---------------------------------------------------
 void wfx_prof_begin(wfx_ctx *ctx, int kid);
+void wfx_prof_events(wfx_ctx *ctx, int kid, hipEvent_t *a, hipEvent_t *b);      // a record whose events the launch itself fills
 void wfx_prof_end(wfx_ctx *ctx);
 
-#define WFX_LAUNCH(ctx, kid, kern, grid, block, ...)                               \
-    do {                                                                           \
-        wfx_prof_begin(ctx, kid);                                                  \
-        hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);      \
-        wfx_prof_end(ctx);                                                         \
-        hipError_t e_ = hipGetLastError();                                         \
-        if (e_ != hipSuccess) return wfx_fail_hip(ctx, e_, "launch " #kern);       \
+// While the per-kernel profile is on, a launch carries its own start / stop events (hipExtLaunchKernelGGL: the time stamps of the
+// dispatch itself, what rocprofv3's kernel trace reports); event records queued around a launch read ~2 us long on a 25 us kernel.
+#define WFX_LAUNCH(ctx, kid, kern, grid, block, ...)                                                            \
+    do {                                                                                                        \
+        hipEvent_t ea_ = nullptr, eb_ = nullptr;                                                                \
+        if ((ctx)->prof) wfx_prof_events(ctx, kid, &ea_, &eb_);                                                 \
+        if (ea_)                                                                                                \
+            hipExtLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, ea_, eb_, 0, __VA_ARGS__);               \
+        else                                                                                                    \
+            hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);                               \
+        hipError_t e_ = hipGetLastError();                                                                      \
+        if (e_ != hipSuccess) return wfx_fail_hip(ctx, e_, "launch " #kern);                                    \
     } while (0)
 
 static inline unsigned wfx_blocks(uint64_t n, unsigned per_block)
