@@ -99,6 +99,48 @@ def test_unique_id_bootstrap_between_processes(tmp_path):
     assert own[0][0] == 0 and own[2][1] == 1433250 and own[0][1] == own[1][0] and own[1][1] == own[2][0]
 
 
+def _gloo_worker(rank, world, port, uid_port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # what a rank of the sharded decode derives on its own: its slice of the capture, of the 60-minute 48 kHz configuration
+        p, meta = build_params(0, 172800000, 48000, 0.5)
+        lay = nat.shard_layout(p, world, rank)
+        mine = dict(rank=rank, own=(int(lay.own_lo), int(lay.own_hi)), inp=(int(lay.in_lo), int(lay.in_hi)), radix=tuple(lay.first_radix))
+        uid = sharded.bootstrap_unique_id(rank, world, port=uid_port, timeout=30.0, make_id=lambda: bytes(range(128)))
+        mine["uid_ok"] = uid == bytes(range(128))
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        dist.barrier()
+        if rank == 0:
+            import json
+            with open(os.path.join(out_dir, "gathered.json"), "w") as fh:
+                json.dump({"n": meta["n"], "ranks": everyone}, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_processes_agree_on_the_partition(tmp_path):
+    """world_size 2 over gloo on the CPU (torch only here, in the test): each process derives its own rows from the capture's
+    parameters alone, fetches the communicator id over the product's TCP bootstrap, and the gathered pieces tile the capture."""
+    pytest.importorskip("torch")
+    import json
+    ctx = mp.get_context("spawn")
+    port, uid_port = _free_port(), _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, uid_port, str(tmp_path))) for r in (1, 0)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    g = json.load(open(os.path.join(tmp_path, "gathered.json")))
+    r0, r1 = sorted(g["ranks"], key=lambda r: r["rank"])
+    assert r0["uid_ok"] and r1["uid_ok"] and r0["radix"] == r1["radix"]
+    assert r0["own"][0] == 0 and r0["own"][1] == r1["own"][0] and r1["own"][1] == g["n"]
+    assert r0["inp"][0] == 0 and r0["inp"][1] == r1["inp"][0] and r1["inp"][1] == 172800000
+
+
 def test_bootstrap_times_out_loudly_without_rank_zero():
     with pytest.raises(nat.NativeError):
         sharded.bootstrap_unique_id(1, 2, port=_free_port(), timeout=0.5)
