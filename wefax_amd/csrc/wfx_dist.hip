@@ -580,18 +580,31 @@ __global__ void __launch_bounds__(256) dist_resample_glue_kernel(const cplx *__r
         if (j == 0 || j == K) y.y = 0.0;
         return y;
     };
-    const long long total = (K / R1) * B;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long k2 = (long long)((unsigned)e / (unsigned)B);              // (total < 2^31)
-        const int kk = (int)(e - k2 * B);
-        const long long k = (long long)(kk < km.kc0 ? km.kb0 + kk : km.kb1 + (kk - km.kc0)) + k2 * R1;
-        const cplx yk = bin(k);
-        const cplx yr = bin(K - k);
+    // W[k] and W[K - k] are made of the same two bins and both live on this rank (the k1 sets are closed under negation): the lane
+    // whose k is the smaller of the pair makes both, the other one has nothing to do
+    auto slot = [&](long long k) {                      // position of output k in this rank's slab [K / R1][B]
+        const unsigned q = (unsigned)k / (unsigned)R1;
+        const int k1 = (int)((unsigned)k - q * (unsigned)R1);
+        const int kk = (k1 >= km.kb0 && k1 < km.kb0 + km.kc0) ? k1 - km.kb0 : km.kc0 + (k1 - km.kb1);
+        return (long long)q * B + kk;
+    };
+    auto emit = [&](long long e, long long k, const cplx &yk, const cplx &yr) {
         const cplx yc = make_double2(yr.x, -yr.y);
         const cplx sum = make_double2(yk.x + yc.x, yk.y + yc.y), dif = make_double2(yk.x - yc.x, yk.y - yc.y);
         double sn, cs;
         sincospi(2.0 * (double)k / (double)num, &sn, &cs);
         W[e] = make_double2((sum.x - (sn * dif.x + cs * dif.y)) * inv_n0, (sum.y + (cs * dif.x - sn * dif.y)) * inv_n0);
+    };
+    const long long total = (K / R1) * B;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long k2 = (long long)((unsigned)e / (unsigned)B);              // (total < 2^31)
+        const int kk = (int)(e - k2 * B);
+        const long long k = (long long)(kk < km.kc0 ? km.kb0 + kk : km.kb1 + (kk - km.kc0)) + k2 * R1;
+        if (k != 0 && 2 * k > K) continue;               // the partner K - k < k makes this one
+        const cplx yk = bin(k);
+        const cplx yr = bin(K - k);
+        emit(e, k, yk, yr);
+        if (k != 0 && K - k != k) emit(slot(K - k), K - k, yr, yk);
     }
 }
 
