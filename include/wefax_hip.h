@@ -213,8 +213,12 @@ int wfx_decode_save_png(wfx_ctx *ctx, const char *path, size_t *bytes_written);
 /* page-locked host memory: captures uploaded from it and images fetched into it cross PCIe by DMA (no staging copies) */
 void *wfx_host_alloc(size_t bytes);
 void  wfx_host_free(void *p);
-/* copy a new capture of the same description into the context (asynchronous when host_in is pinned memory) */
-int wfx_decode_reload(wfx_ctx *ctx, const void *host_in);
+/* copy a new capture of the same description into the context (asynchronous when host_in is pinned memory).  `bytes` must equal
+ * the size of the capture described to wfx_decode_upload (n0 frames of in_kind) -- WFX_ERR_BAD_ARG otherwise, nothing is read.
+ * ext_left / ext_right (9 values each, or both NULL): filtfilt's odd extension of THIS capture for float64 hand-overs of
+ * uint8 / int32 / float32 files (wfx_decode_params.ext_left/right); NULL clears has_ext.  Results of the previous capture stop
+ * being fetchable (WFX_ERR_STATE until the next wfx_decode_run). */
+int wfx_decode_reload(wfx_ctx *ctx, const void *host_in, size_t bytes, const double *ext_left, const double *ext_right);
 /* enqueue a copy of a stage buffer to the host WITHOUT waiting (host_out should be pinned); wfx_sync / wfx_decode_result waits.
  * For WFX_BUF_IMAGE `bytes` must be >= the largest possible image (4 * width * (n / width)); the height arrives with the result. */
 int wfx_decode_fetch_async(wfx_ctx *ctx, int buffer_id, void *host_out, size_t bytes);

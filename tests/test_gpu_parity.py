@@ -380,7 +380,9 @@ def test_full_size_capture_properties(c2_job):
     base = 255 - dig[info.start_frame:info.start_frame + h * w].reshape(h, w).astype(np.int16)
     # bicubic 4x is an interpolation: each output row stays within the overshoot bound of its neighbours
     up = img[2::4].astype(np.int16)          # rows whose centre is nearest the source row centre
-    assert np.max(np.abs(up - base)) <= 255   # sanity: shapes line up
+    # Pillow's bicubic weights at phase 2 of 4 are (-0.0068, 0.0908, 0.9639, -0.0479) on rows y-2..y+1: the output cannot leave the
+    # source pixel by more than (0.0068 + 0.0908 + 0.0479) * 255 + rounding
+    assert np.max(np.abs(up[2:-2] - base[2:-2])) <= 38
     assert np.mean(np.abs(up - base)) < 12.0
     assert info.npeaks == 100 and info.hit_limit == 1 and not info.no_group
 

@@ -113,6 +113,47 @@ def test_front_end_model_tracks_the_fft_resampler(fs, stereo):
     assert np.max(np.abs(out)) < 8000 * 10 ** (-80 / 20)
 
 
+def test_hand_over_length_keeps_the_reference_grid_for_captures_that_are_not_whole_seconds():
+    """wefax.py:384: num = int(11025 * n0 / fs) and scipy's resample puts output j at input position j * n0 / num.  The chain
+    to the hand-over rate tiles the capture's period exactly (n0 * out_rate / fs_in samples) or refuses the length."""
+    fe = pp.FrontEnd(1536000, stop_rate=16000)
+    assert fe.granule() == 96 and pp.FrontEnd(48000, stop_rate=16000).granule() == 3 and pp.FrontEnd(192000, stop_rate=14700).granule() == 640
+    n0 = 1536000 * 7 + 96 * 1234 + 96                      # 7.0772 s
+    assert fe.n_out(n0) == n0 // 96
+    assert fe.n_target(n0) == int(11025 * (n0 / 1536000)) == 78025
+    for bad in (n0 + 1, n0 + 95, n0 - 31):
+        with pytest.raises(ValueError, match="granule 96"):
+            fe.n_out(bad)
+    # the all-time-domain chain to 11 025 Hz has a fixed ratio: only lengths the reference maps to exactly that many samples
+    fe0 = pp.FrontEnd(48000)
+    assert fe0.n_out(48000 * 3 + 640) == 11025 * 3 + 147
+    with pytest.raises(ValueError):
+        fe0.n_out(48000 * 3 + 641)
+
+
+def test_front_end_model_then_fft_resample_tracks_the_reference_off_whole_seconds():
+    """A capture of 2.26 s at 48 kHz (a multiple of 3 frames, not of 640): chain to 16 kHz, then the oracle's FFT resampler to
+    int(11025 * n0 / fs) samples -- against the oracle's FFT resampler on the raw capture.  The nominal-ratio form (round 2) is off
+    by up to one output sample at the end; this one is not."""
+    fs = 48000
+    n0 = 108480 + 3 * 7                                    # 108501 = 3 * 36167; 11025 * n0 / fs = 24921.32...
+    t = np.arange(n0) / fs
+    sig = 6000 * np.sin(2 * np.pi * 1500 * t) + 5000 * np.sin(2 * np.pi * 2300 * t + 1) + 3000 * np.sin(2 * np.pi * 3900 * t + 2)
+    sig *= np.hanning(n0)
+    x = np.rint(sig).astype(np.int16)
+    fe = pp.FrontEnd(fs, stop_rate=16000)
+    n_fe, n = fe.n_out(n0), fe.n_target(n0)
+    assert n_fe == 36167 and n == 24921 and (11025 * n0) % fs != 0
+    ia, ib = fe.input_range(0, n_fe)
+    mid = front_end_model(x[np.arange(ia, ib) % n0], fe.chain(0, n_fe))
+    got = wo.resample_fft(mid, n)
+    ref = wo.resample_fft(x.astype(np.float64), n)
+    assert np.max(np.abs(got - ref)) < 3e-4 * np.max(np.abs(ref))
+    # what the nominal ratio would have given: the same samples on a grid stretched by n0 / (n * fs / 11025)
+    stretched = wo.resample_fft(x.astype(np.float64), n + 1)[:n]
+    assert np.max(np.abs(stretched - ref)) > 100 * np.max(np.abs(got - ref))
+
+
 def _capture(fs, noise, seed=1, lpm=240, seconds=61.0, iq=False):
     """Short capture that still holds 100 sync peaks in its first half (240 LPM: a line is 0.25 s).  Whole
     seconds: 11025 * length is then an integer and the reference's n0/num equals the nominal rate ratio (for
@@ -226,12 +267,18 @@ STREAM_MAX, STREAM_NE_FRAC, IMAGE_MAX, IMAGE_GT1_FRAC = 1, 5e-4, 1, 0.0
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fs,iq,lpm,seconds,stop_rate", [(48000, False, 240, 56.0, 22050), (192000, True, 240, 64.0, 14700),
-                                                         (1536000, True, 120, 40.0, 22050), (1536000, True, 120, 40.0, 16000)])
-def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds, stop_rate):
+@pytest.mark.parametrize("fs,iq,lpm,seconds,stop_rate,drop", [(48000, False, 240, 56.0, 22050, 0), (192000, True, 240, 64.0, 14700, 0),
+                                                              (1536000, True, 120, 40.0, 22050, 0), (1536000, True, 120, 40.0, 16000, 0),
+                                                              (48000, False, 240, 56.0, 16000, 3 * 4567), (1536000, True, 120, 40.0, 16000, 96 * 4321)])
+def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds, stop_rate, drop):
     """Front end to the hand-over rate (22 050, 14 700 or 16 000 Hz) + the exact path: the one-GPU fused form, and the sharded form on 1, 2, 3 and 8 emulated
-    ranks (bit-identical to each other and to the fused form); against the oracle within the figures above."""
+    ranks (bit-identical to each other and to the fused form); against the oracle within the figures above.  ``drop`` frames less
+    than whole seconds: int(11025 * n0 / fs) is then not n0 * 11025 / fs and the reference's resampling grid (wefax.py:384) is
+    stretched by up to one sample over the capture -- the hand-over keeps it (polyphase.FrontEnd.n_out)."""
     x = _capture(fs, 0.05, seed=0, lpm=lpm, seconds=seconds, iq=iq)
+    if drop:
+        x = np.ascontiguousarray(x[:x.shape[0] - drop])
+        assert (11025 * x.shape[0]) % fs != 0
     ref = _oracle(x, fs, lpm)
     fe = pp.FrontEnd(fs, stop_rate=stop_rate)
     dec = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=lpm)

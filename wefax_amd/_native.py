@@ -209,7 +209,7 @@ def load():
     lib.wfx_host_alloc.restype = vp
     lib.wfx_host_free.argtypes = [vp]
     lib.wfx_host_free.restype = None
-    lib.wfx_decode_reload.argtypes = [vp, vp]
+    lib.wfx_decode_reload.argtypes = [vp, vp, sz, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.wfx_decode_fetch_async.argtypes = [vp, i, vp, sz]
     lib.wfx_synth_frames.argtypes = [C.POINTER(SynthParams)]
     lib.wfx_synth_frames.restype = C.c_uint64
@@ -358,11 +358,18 @@ class Context:
         self._check(self.lib.wfx_decode_result(self.h, C.byref(info)))
         return info
 
-    def decode_reload(self, data: np.ndarray):
-        """A new capture of the same description into the context (DMA when ``data`` is pinned: ``pinned_empty``)."""
+    def decode_reload(self, data: np.ndarray, ext=None):
+        """A new capture of the same description into the context (DMA when ``data`` is pinned: ``pinned_empty``).  The library
+        checks the byte count against the uploaded capture's; ``ext`` = (left, right) odd-extension values for float64
+        hand-overs of uint8 / int32 / float32 files, None when the capture has none."""
         data = np.ascontiguousarray(data)
         self._keep = data
-        self._check(self.lib.wfx_decode_reload(self.h, _ptr(data)))
+        if ext is None:
+            self._check(self.lib.wfx_decode_reload(self.h, _ptr(data), data.nbytes, None, None))
+        else:
+            left = (C.c_double * 9)(*[float(v) for v in ext[0]])
+            right = (C.c_double * 9)(*[float(v) for v in ext[1]])
+            self._check(self.lib.wfx_decode_reload(self.h, _ptr(data), data.nbytes, left, right))
 
     def decode_fetch_async(self, buffer_id: int, out: np.ndarray):
         """Enqueue the copy of a stage buffer into ``out`` (pinned) without waiting; ``sync()`` / ``decode_result()`` waits."""

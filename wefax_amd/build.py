@@ -42,7 +42,11 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LAST_BUILD = {"compiled": 0, "up_to_date": 0, "linked": False}
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    """Compile what is stale (everything with ``force``) and link.  LAST_BUILD says what this call did."""
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     flags = [*FLAGS, *extra_flags]
@@ -67,8 +71,10 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
+    link = bool(force or jobs or _stale(LIB, objs))
+    if link:
         run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"])
+    LAST_BUILD.update(compiled=len(jobs), up_to_date=len(SOURCES) - len(jobs), linked=link)
     return LIB
 
 

@@ -276,12 +276,28 @@ int wfx_decode_upload(wfx_ctx *ctx, const void *host_in, const wfx_decode_params
     return 0;
 }
 
-int wfx_decode_reload(wfx_ctx *ctx, const void *host_in)
+int wfx_decode_reload(wfx_ctx *ctx, const void *host_in, size_t bytes, const double *ext_left, const double *ext_right)
 {
     CHECK_CTX(ctx);
     if (!host_in) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
     if (!ctx->have_input || ctx->ext_in) return wfx_fail(ctx, WFX_ERR_STATE, "decode_reload needs a capture uploaded with wfx_decode_upload");
-    return h2d(ctx, ctx->b_in.p, host_in, in_bytes(&ctx->dp));
+    const size_t nb = in_bytes(&ctx->dp);
+    if (bytes != nb)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decode_reload: the uploaded capture has %zu bytes (%llu frames of kind %d), %zu given", nb,
+                        (unsigned long long)ctx->dp.n0, ctx->dp.in_kind, bytes);
+    // results of the previous capture are no longer fetchable, and filtfilt's odd extension (evaluated by the host in the
+    // file's own dtype for float64 hand-overs) belongs to the capture: the new one brings its own or has none
+    ctx->ran = false;
+    if (ext_left && ext_right) {
+        ctx->dp.has_ext = 1;
+        for (int i = 0; i < 9; ++i) {
+            ctx->dp.ext_left[i] = ext_left[i];
+            ctx->dp.ext_right[i] = ext_right[i];
+        }
+    } else {
+        ctx->dp.has_ext = 0;
+    }
+    return h2d(ctx, ctx->b_in.p, host_in, nb);
 }
 
 int wfx_decode_fetch_async(wfx_ctx *ctx, int buffer_id, void *host_out, size_t bytes)

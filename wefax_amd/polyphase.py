@@ -17,12 +17,13 @@ unit DC gain, linear phase centred on the output sample (zero delay), pass band 
 The stereo / IQ merge of wefax.py:360-373 is fused into the first stage's loads.
 
 It is NOT bit-compatible with the FFT resampler: it drops what the reference keeps between
-``pass_hz`` and 5512.5 Hz, its pass band ripples by 10**(-att_db/20), and it resamples by the
-nominal ratio fs_in/11025 where the reference uses n0/int(11025*n0/fs_in) (the two differ by
-up to one output sample over a whole capture whose length is not a whole number of
-1/11025-second steps).  WEFAX audio lives below 3 kHz, so decoded images agree to about one
-grey level (tests/test_polyphase.py measures it); the exact path stays the default wherever
-it fits.
+``pass_hz`` and 5512.5 Hz and its pass band ripples by 10**(-att_db/20).  The reference's sampling
+grid -- output j at input position j * n0 / int(11025 * n0 / fs_in), one period = the whole capture --
+is kept exactly: the chain hands over n0 * out_rate / fs_in samples (lengths for which that is not
+a whole number are refused, ``FrontEnd.n_out``) and the exact FFT resampler behind it delivers
+int(11025 * n0 / fs_in) samples like wefax.py:384, whole seconds or not.  WEFAX audio lives below
+3 kHz, so decoded images agree to one grey level (tests/test_polyphase.py measures it); the exact
+path stays the default wherever it fits.
 """
 from __future__ import annotations
 
@@ -252,15 +253,33 @@ class FrontEnd:
         third = fs / 3
         return int(third) if third.denominator == 1 and third > TARGET_RATE + 2000 else 14700
 
+    def n_target(self, n_in: int) -> int:
+        """wefax.py:384 ``num = int(11025 * length)`` with ``length = n / sample_rate`` (wefax.py:357), in the reference's own
+        float arithmetic: the number of 11 025 Hz samples the decode of an ``n_in``-frame capture must have."""
+        return int(TARGET_RATE * (n_in / self.fs_in))
+
+    def granule(self) -> int:
+        """Capture lengths this front end reproduces the reference's sampling grid for: whole multiples of this many frames."""
+        return Fraction(self.out_rate, self.fs_in).denominator
+
     def n_out(self, n_in: int) -> int:
-        """Samples this front end delivers: wefax.py:384 num = int(11025 * length), length = n / sample_rate; at a hand-over
-        rate above 11 025 Hz, the shortest length from which the exact path's own int(11025 * n_fe / rate) gives that num."""
-        n = int(TARGET_RATE * (n_in / self.fs_in))
-        if not self.exact_tail:
-            return n
-        n_fe = -((-n * self.out_rate) // TARGET_RATE)
-        while int(TARGET_RATE * (n_fe / self.out_rate)) < n:
-            n_fe += 1
+        """Samples this front end delivers for an ``n_in``-frame capture: ``n_in * out_rate / fs_in``, which must be a whole
+        number.  The reference's FFT resampler treats the capture as ONE period of ``n_in`` frames and puts output j at input
+        position ``j * n_in / num`` (wefax.py:384, scipy.signal.resample).  A chain of fixed-ratio stencils keeps that period
+        only when its outputs tile it exactly; the exact FFT resampler behind the hand-over then goes from ``n_out`` samples
+        to ``n_target(n_in)`` whatever their ratio -- the reference's grid, also for captures that are not whole seconds.
+        Any other length is refused (drop ``n_in % granule()`` trailing frames -- less than one hand-over sample -- or use
+        the exact path, which takes every length that fits)."""
+        prod = Fraction(n_in) * Fraction(self.out_rate, self.fs_in)
+        if prod.denominator != 1:
+            g = self.granule()
+            raise ValueError(f"time-domain front end {self.fs_in} -> {self.out_rate} Hz: a capture of {n_in} frames is not a whole number of "
+                             f"hand-over samples (granule {g} frames, {n_in % g} too many): the reference's resampling grid "
+                             "(wefax.py:384) cannot be kept; drop the surplus frames or use the exact path")
+        n_fe = int(prod)
+        if not self.exact_tail and n_fe != self.n_target(n_in):
+            raise ValueError(f"time-domain front end to 11 025 Hz: the reference resamples {n_in} frames to {self.n_target(n_in)} samples "
+                             f"(wefax.py:384), the fixed-ratio chain gives {n_fe}; use FrontEnd(stop_rate=...) or the exact path")
         return n_fe
 
     def chain(self, lo: int, hi: int):

@@ -122,12 +122,12 @@ class ShardedDecoder:
     Ranks other than 0 get ``None`` images; scalars (low, high) are available everywhere."""
 
     def __init__(self, ctx: nat.Context, comm: nat.Comm, n0: int, sample_rate, lines_per_minute: int = 120, kind: int = nat.WFX_IN_I16_MONO,
-                 notch=None, data: np.ndarray | None = None, loader=None):
+                 notch=None, data: np.ndarray | None = None, loader=None, n_out: int | None = None):
         self.ctx, self.comm = ctx, comm
         self.frame_len = 1 / (lines_per_minute / 60)
         if notch is None:                       # config/config.json like Demodulator (wefax.py:63-66), defaults when there is no file
             notch = hp.load_notch_settings()
-        self.params, self.meta = build_params(kind, int(n0), sample_rate, self.frame_len, notch)
+        self.params, self.meta = build_params(kind, int(n0), sample_rate, self.frame_len, notch, n_out=n_out)
         self.n = self.meta["n"]
         self.width = self.params.width
         self.shard = nat.Shard(ctx, comm, self.params)
@@ -297,14 +297,15 @@ class FrontEndExactDecoder:
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
         n_fe = frontend.n_out(n_in_total)                   # at 11 025 Hz, or at the hand-over rate (FrontEnd(stop_rate=...))
         rate = frontend.out_rate
-        self.n = int(hp.TARGET_RATE * (n_in_total / frontend.fs_in))
+        self.n = frontend.n_target(n_in_total)              # wefax.py:384 on the ORIGINAL capture
         self.chain = frontend.chain(0, n_fe)
         ia, ib = self.chain[0][2]
         raw = _raw_slice(x, raw_loader, ia, ib, n_in_total)
         if in_kind is None:
             in_kind = 1 if (not isinstance(raw, tuple) and raw.ndim == 2) else 0
         self.fe = FrontEndDevice(ctx, self.chain, raw, in_kind)
-        self.job = DecodeJob.from_device(ctx, self.fe.p_out, n_fe, lines_per_minute, notch=hp.load_notch_settings(), sample_rate=rate)
+        self.job = DecodeJob.from_device(ctx, self.fe.p_out, n_fe, lines_per_minute, notch=hp.load_notch_settings(), sample_rate=rate,
+                                         n_out=self.n if frontend.exact_tail else None)
         assert self.job.n == self.n
         self.width = self.job.width
 
@@ -336,7 +337,8 @@ class FrontEndShardedDecoder:
             raise ValueError("the sharded form needs FrontEnd(stop_rate=...): the exact resampler takes the last step")
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
         n_fe = frontend.n_out(n_in_total)
-        self.dec = ShardedDecoder(ctx, comm, n_fe, frontend.out_rate, lines_per_minute, nat.WFX_IN_F64_MONO, notch)
+        self.dec = ShardedDecoder(ctx, comm, n_fe, frontend.out_rate, lines_per_minute, nat.WFX_IN_F64_MONO, notch,
+                                  n_out=frontend.n_target(n_in_total))
         lay = self.dec.layout
         self.chain = frontend.chain(int(lay.in_lo), int(lay.in_hi))
         ia, ib = self.chain[0][2]

@@ -28,13 +28,20 @@ DEFAULT_FIR_TAPS = 4095
 
 
 def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEFAULT_NOTCH,
-                 hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS):
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS, n_out: int | None = None):
     """The scalar arithmetic of the reference for a capture of ``n0`` frames at ``sample_rate`` (lengths, notch
     coefficients, percentile ranks and weights, sync constants) as the C ABI's ``wfx_decode_params``, plus the derived
-    lengths.  Same expressions as wefax.py, evaluated in Python floats / NumPy scalars like there."""
+    lengths.  Same expressions as wefax.py, evaluated in Python floats / NumPy scalars like there.
+
+    ``n_out``: the number of 11 025 Hz samples, when the ``n0`` samples are an intermediate of a longer chain (the time-domain
+    front end's hand-over: the reference's ``int(11025 * length)`` refers to the ORIGINAL capture, polyphase.FrontEnd.n_target)."""
     input_length = n0 / sample_rate                                    # wefax.py:357
     resampled = sample_rate != hp.TARGET_RATE                          # wefax.py:60
     n = int(hp.TARGET_RATE * input_length) if resampled else n0       # wefax.py:384
+    if n_out is not None:
+        if not resampled and n_out != n0:
+            raise ValueError("n_out given for a capture that is not resampled")
+        n = int(n_out)
     if n <= 9:
         raise ValueError("The length of the input vector x must be greater than padlen, which is 9.")
     b, a = hp.iirnotch(int(notch[0]), notch[1], hp.TARGET_RATE)        # wefax.py:63-70
@@ -106,6 +113,18 @@ class DecodeJob:
         self.frame_len = 1 / (lines_per_minute / 60)                       # wefax.py:33
         data = np.asarray(data)
         self.merged_on_host = False
+        self._in_shape, self._in_dtype = tuple(data.shape), data.dtype
+        data, kind, ext = self._host_form(data)
+        self._configure(kind, int(data.shape[0]), sample_rate, notch, hilbert_mode, fir_taps)
+        if ext is not None and not self.resampled:
+            self.params.has_ext = 1
+            self.params.ext_left[:] = [float(v) for v in ext[0]]
+            self.params.ext_right[:] = [float(v) for v in ext[1]]
+        ctx.decode_upload(data, self.params)
+        self.info = None
+
+    def _host_form(self, data: np.ndarray):
+        """What reaches the device for a capture as read from the wav: (array, in_kind, odd extension or None)."""
         ext = None
         if data.ndim == 2:
             if data.dtype == np.int16:
@@ -124,17 +143,11 @@ class DecodeJob:
             ext = hp.odd_extension(data) if (data.dtype != np.float64 and data.shape[0] > 9) else None
             data = data.astype(np.float64)
             kind = nat.WFX_IN_F64_MONO
-        self._configure(kind, int(data.shape[0]), sample_rate, notch, hilbert_mode, fir_taps)
-        if ext is not None and not self.resampled:
-            self.params.has_ext = 1
-            self.params.ext_left[:] = [float(v) for v in ext[0]]
-            self.params.ext_right[:] = [float(v) for v in ext[1]]
-        ctx.decode_upload(data, self.params)
-        self.info = None
+        return data, kind, ext
 
-    def _configure(self, kind, n0, sample_rate, notch, hilbert_mode, fir_taps):
+    def _configure(self, kind, n0, sample_rate, notch, hilbert_mode, fir_taps, n_out=None):
         """The scalar arithmetic of the reference (lengths, notch, percentile ranks, sync constants) -> self.params."""
-        p, meta = build_params(kind, n0, sample_rate, self.frame_len, notch, hilbert_mode, fir_taps)
+        p, meta = build_params(kind, n0, sample_rate, self.frame_len, notch, hilbert_mode, fir_taps, n_out)
         self.input_length, self.resampled = meta["input_length"], meta["resampled"]
         self.n0, self.n = n0, meta["n"]
         self.sample_rate = hp.TARGET_RATE
@@ -144,7 +157,8 @@ class DecodeJob:
 
     @classmethod
     def from_device(cls, ctx: nat.Context, dev_ptr: int, n: int, lines_per_minute: int = 120, notch=hp.DEFAULT_NOTCH,
-                    hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS, sample_rate: int = hp.TARGET_RATE):
+                    hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS, sample_rate: int = hp.TARGET_RATE,
+                    n_out: int | None = None):
         """Decode ``n`` float64 samples at ``sample_rate`` (11 025 Hz, or a rate the exact resampler brings there) that
         already sit in device memory (e.g. the output of the time-domain front end, wefax_amd/polyphase.py): the same
         fused path, nothing uploaded.  The memory stays owned by the caller and must outlive the job."""
@@ -152,7 +166,8 @@ class DecodeJob:
         job.ctx = ctx
         job.frame_len = 1 / (lines_per_minute / 60)
         job.merged_on_host = False
-        job._configure(nat.WFX_IN_F64_MONO, int(n), sample_rate, notch, hilbert_mode, fir_taps)
+        job._in_shape = job._in_dtype = None
+        job._configure(nat.WFX_IN_F64_MONO, int(n), sample_rate, notch, hilbert_mode, fir_taps, n_out)
         ctx.decode_attach(int(dev_ptr), job.params)
         job.info = None
         return job
@@ -160,7 +175,14 @@ class DecodeJob:
     def reload(self, data: np.ndarray):
         """Another capture of the same shape and dtype into the same job (no plan or buffer is rebuilt).  From an array in
         pinned memory (``_native.pinned_empty``) the copy is a DMA enqueued on the stream."""
-        self.ctx.decode_reload(data)
+        data = np.asarray(data)
+        if getattr(self, "_in_shape", None) is None:
+            raise ValueError("reload: this job decodes caller-owned device memory (from_device)")
+        if tuple(data.shape) != self._in_shape or data.dtype != self._in_dtype:
+            raise ValueError(f"reload: the job was built for a {self._in_dtype} capture of shape {self._in_shape}, "
+                             f"got {data.dtype} {tuple(data.shape)}")
+        data, _, ext = self._host_form(data)
+        self.ctx.decode_reload(data, ext if (ext is not None and not self.resampled) else None)
         self.info = None
 
     def fetch_image_async(self, out: np.ndarray):
