@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--iq-form", choices=["auto", "fused", "sharded"], default="auto",
                     help="one GPU: the fused exact decode behind the front end (auto) or the sharded form with one rank")
     ap.add_argument("--no-c4", action="store_true", help="c2: leave the c4_strong object out (quick runs)")
+    ap.add_argument("--no-extras", action="store_true", help="c2: leave the general_length and c3 objects out (kernel profiles of the headline alone)")
     ap.add_argument("--no-pcie", action="store_true", help="c2: skip the PCIe-inclusive leg (it runs two decodes concurrently: keep it out of kernel profiles)")
     ap.add_argument("--batch", type=int, default=1,
                     help="captures decoded concurrently per GPU, one native context (= HIP stream) each; "
@@ -71,23 +72,58 @@ def parse():
 # ---- N ranks from one command ---------------------------------------------------------------------------------
 def spawn_ranks(args) -> int:
     """`--gpus N` without a launcher: start N fresh processes (this script again, one rank each) BEFORE anything touches a
-    GPU, relay rank 0's stdout.  The parent imports nothing but the standard library."""
+    GPU, relay rank 0's stdout.  The parent imports nothing but the standard library.  Each child sees ONE device
+    (HIP_VISIBLE_DEVICES = its local rank, LOCAL_RANK 0 inside) unless WFX_BENCH_OVERSUBSCRIBE=1 puts several ranks on the
+    devices there are.  A child that dies takes its siblings with it: the parent polls all of them, terminates the rest on
+    the first non-zero exit (a rank inside a collective would otherwise wait for ever) and gives up after WFX_BENCH_TIMEOUT s."""
+    import secrets
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    with socket.socket() as sk:                       # the unique-id bootstrap gets a port of its own, reserved here
+        sk.bind(("127.0.0.1", 0))
+        boot = sk.getsockname()[1]
+    nonce = secrets.token_hex(8)
+    over = os.environ.get("WFX_BENCH_OVERSUBSCRIBE") == "1"
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   WFX_BOOT_PORT=str(boot), WFX_JOB_NONCE=nonce,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if not over:
+            vis = os.environ.get("HIP_VISIBLE_DEVICES")
+            devs = vis.split(",") if vis else [str(k) for k in range(args.gpus)]
+            if r < len(devs):
+                env.update(HIP_VISIBLE_DEVICES=devs[r], LOCAL_RANK="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, p.wait())
-    sys.stdout.write(out.decode())
+    import threading
+    out_box = []
+    reader = threading.Thread(target=lambda: out_box.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("WFX_BENCH_TIMEOUT", "1800"))
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = bad[0] if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write((out_box[0] if out_box else b"").decode())
     sys.stdout.flush()
     return rc
 
@@ -133,9 +169,12 @@ class Ranks:
         self.use_rccl = self.world > 1 or os.environ.get("WFX_BENCH_FORCE_DIST") == "1"
         if self.use_rccl:
             addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-            port = int(os.environ.get("MASTER_PORT", "29511")) + 1009      # next to the launcher's own rendezvous port
+            mport = int(os.environ.get("MASTER_PORT", "29511"))
+            # spawn_ranks reserves a port of its own; under a launcher: next to its rendezvous port, kept inside the valid range
+            port = int(os.environ.get("WFX_BOOT_PORT", str(mport + 1009 if mport + 1009 + 16 < 65536 else mport - 1009)))
+            nonce = os.environ.get("WFX_JOB_NONCE", f"{addr}:{mport}")        # peers of another job on this host are turned away
             with _StdoutToStderr():
-                uid = sharded.bootstrap_unique_id(self.rank, self.world, addr=addr, port=port)
+                uid = sharded.bootstrap_unique_id(self.rank, self.world, addr=addr, port=port, nonce=nonce)
                 self.comm = nat.Comm.rccl(self.ctx, uid, self.world, self.rank)
                 self.comm.barrier(self.ctx)                                   # the communicator's first collective sets it up
         else:
@@ -194,9 +233,12 @@ def roofline_of(prof: dict, steps: int, alg_bytes: int, ms_per_step: float, pmc_
     dom = max(fam.items(), key=lambda kv: kv[1][1])
     avg_s = dom[1][1] / dom[1][0] / 1e3
     traffic = None
+    traffic_source = None
     if pmc_file and os.path.exists(pmc_file):
         try:
             tj = json.load(open(pmc_file))
+            traffic_source = (os.path.relpath(pmc_file, REPO) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; collected at "
+                              + str(tj.get("_collected_at", "an earlier tree")) + ", not in this run)")
             if dom[0] == "fft_pass":
                 parts = [tj[k]["hbm_bytes_per_launch"] for k in ("fft_pass_fwd", "fft_pass_inv") if k in tj]
                 traffic = int(sum(parts) / len(parts)) if parts else None
@@ -206,7 +248,8 @@ def roofline_of(prof: dict, steps: int, alg_bytes: int, ms_per_step: float, pmc_
             traffic = None
     achieved = alg_bytes / avg_s / 1e9
     return {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+            "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": round(dom[1][0] / steps, 2),
             "whole_path_frac": round(alg_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 5)}
 
@@ -498,6 +541,44 @@ def bench_c2(args, rk: Ranks) -> dict:
     return out
 
 
+def bench_general_lengths(args, rk: Ranks, x) -> dict:
+    """The reference decodes whatever length the wav has (wefax.py:174 calls scipy on it).  The headline length has a 13-smooth
+    half (every BASELINE size does) and takes the unpadded transforms; one sample more makes it odd (unpacked convolution,
+    padded to a power of two >= 2N - 1), two samples more even with a half that has a large prime factor (packed convolution
+    zero-padded to the cheapest 13-smooth M >= N - 1).  Same capture plus 1 / 2 trailing samples, same kernels otherwise."""
+    import numpy as np
+    from wefax_amd.wefax import DecodeJob
+    nat, ctx = rk.nat, rk.ctx
+    out = {}
+    for extra in (1, 2):
+        xe = np.concatenate([x, x[-extra:]])
+        job = DecodeJob(ctx, xe, 11025, 120)
+        for _ in range(2):
+            job.run()
+        ctx.sync()
+        steps = max(3, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.run()
+        ctx.sync()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        info = job.result()
+        n = int(xe.shape[0])
+        rec = {"n": n, "ms_per_step": round(ms, 4), "msamples_s": round(n / ms / 1e3, 1), "start_frame": int(info.start_frame)}
+        if extra == 2:
+            m = nat.padded_length(n - 1)
+            rec["form"] = (f"packed convolution of n/2 = {n // 2} points zero-padded to the 13-smooth M = {m} ({nat.plan_describe(m)})" if m else
+                           "packed convolution padded to a power of two")
+        else:
+            rec["form"] = f"odd length: unpacked convolution padded to 2^{int(np.ceil(np.log2(2 * n - 1)))}"
+        if not args.no_cpu:
+            ref = cpu_baseline(xe, 11025, 120, False, "")["_result"]
+            rec["digitalized_mismatches"] = int(np.count_nonzero(job.fetch("digitalized") != ref["digitalized"]))
+            rec["start_frame_equal"] = bool(ref.get("start_frame") == info.start_frame)
+        out[f"n_plus_{extra}"] = rec
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -516,6 +597,14 @@ def main():
             line = bench_c3(args, rk)
         else:
             line = bench_c2(args, rk)
+            if rk.world == 1 and not args.shard and args.batch == 1 and not args.short and not args.no_extras:
+                # driver-timed companions of the headline: other capture lengths, and BASELINE configs[2] with its own roofline / CPU leg
+                from wefax_amd import synth
+                line["general_length"] = bench_general_lengths(args, rk, synth.config_c2(noise=args.noise, seed=rk.rank))
+                a3 = argparse.Namespace(**vars(args))
+                a3.steps, a3.warmup = max(3, min(args.steps, 10)), 2
+                c3 = bench_c3(a3, rk)
+                line["c3"] = {k: c3[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "kernels")}
             if not args.no_c4 and not args.shard and args.batch == 1:
                 rk.barrier()
                 secs = 40.0 if args.short else float(args.iq_seconds)

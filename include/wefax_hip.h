@@ -213,6 +213,12 @@ int wfx_decode_save_png(wfx_ctx *ctx, const char *path, size_t *bytes_written);
 /* page-locked host memory: captures uploaded from it and images fetched into it cross PCIe by DMA (no staging copies) */
 void *wfx_host_alloc(size_t bytes);
 void  wfx_host_free(void *p);
+/* Planning queries (host only, no GPU needed).  wfx_plan_padded_length: the transform length the analytic-signal convolution of
+ * a capture takes when N/2 is not 13-smooth -- the cheapest 13-smooth M >= min_len (= N - 1) with a radix-pair plan, at most
+ * 8 % above it; 0 when min_len is below 4096 (such captures pad to a power of two).  wfx_plan_describe: the passes of the
+ * transform of length L as text ("7x13,7x25,15x15"; "" when L is not 13-smooth), returns the number of passes. */
+uint64_t wfx_plan_padded_length(uint64_t min_len);
+int wfx_plan_describe(uint64_t L, char *buf, int cap);
 /* copy a new capture of the same description into the context (asynchronous when host_in is pinned memory).  `bytes` must equal
  * the size of the capture described to wfx_decode_upload (n0 frames of in_kind) -- WFX_ERR_BAD_ARG otherwise, nothing is read.
  * ext_left / ext_right (9 values each, or both NULL): filtfilt's odd extension of THIS capture for float64 hand-overs of
@@ -265,6 +271,18 @@ int wfx_d_decimate_fir(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_i
                        int ntaps, void *out_dev, int out_f64, size_t n_out);
 int wfx_d_resample_rational(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t base0, int p, int q,
                             const float *table, int taps, int64_t m0, float *out_dev, size_t n_out);
+/* decimate with float64 taps and a float64 result (the default chain of the front end: what reaches the exact path carries the
+ * filters' design error only, wefax.py:384 sees the same numbers whatever the tiling).  in_kind WFX_IN_I16_MONO / WFX_IN_I16_STEREO
+ * / WFX_IN_F64_MONO.  With fix_shift = s > 0, int16 input and a power-of-two factor >= the samples per 16 bytes (8 mono, 4 IQ)
+ * the stencil is computed EXACTLY: the taps are rounded to multiples of 2^-s and the products summed as integers
+ * (v_dot2_i32_i16) --
+ *   out[i] = sum_j round(coef[j] * 2^s) * in[first + i*factor + j] / 2^s  (IQ: of the wrapped int16 sum, / 2)
+ * with no rounding of the sum; *exact (may be NULL) is set to 1.  s must keep every tap below 2^23 steps and the sum of
+ * |tap >> 12| below 2^16 (wefax_amd/polyphase.fix_shift_for picks it; 27-28 for the ingest filters).  Everything else
+ * (fix_shift 0, other inputs / factors, a shift the taps do not fit) runs float64 FMAs in one fixed order per output
+ * (*exact = 0): |error| <= ntaps * 2^-53 * sum |coef * in|. */
+int wfx_d_decimate_fir64(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const double *coef,
+                         int ntaps, double *out_dev, size_t n_out, int fix_shift, int *exact);
 /* a7: |x + i H| with the `taps`-lag circular Hilbert kernel of a signal of n_global samples; valid (taps-1)/2 away from the ends */
 int wfx_d_fir_envelope(wfx_ctx *ctx, const double *x_dev, size_t n, size_t n_global, int taps, double *env_raw_dev);
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev);

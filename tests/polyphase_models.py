@@ -55,7 +55,8 @@ def front_end_model(raw, chain):
     for st, (a, b), (ia, ib) in chain:
         assert cur.shape[0] == ib - ia
         if st.kind == "decimate":
-            cur = decimate_model(cur, 0, st.factor, st.coef, b - a)
+            # (a float64 chain -- decimations only -- applies its float64 taps; the fp32 chains the float32 ones)
+            cur = decimate_model(cur, 0, st.factor, st.coef64 if getattr(st, "f64_chain", False) else st.coef, b - a)
         else:
             shift = max(0, -(a // st.q))
             cur = rational_model(cur, ia + st.left + shift * st.p, st.p, st.q, st.table, a + shift * st.q, b - a)

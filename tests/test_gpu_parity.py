@@ -189,6 +189,26 @@ def test_random_smooth_lengths(ctx, n):
     assert _rel(a, ctx.analytic_env(x, nat.WFX_HILBERT_FFT_POW2)) <= FLOAT_TOL
 
 
+def _any_even_lengths(count, seed, lo, hi):
+    rng = np.random.default_rng(seed)
+    return [int(2 * rng.integers(lo // 2, hi // 2)) for _ in range(count)]
+
+
+@pytest.mark.parametrize("n", _any_even_lengths(20, 3, 9000, 2500000) + [2 * 3583126, 2 * 1048583, 8192 + 2, 2 * 4099])
+def test_any_even_length_takes_the_smooth_padded_form(ctx, n):
+    """wefax.py:174 takes whatever length the wav has.  An even N whose half has a prime factor above 13 is convolved with zero
+    padding to the cheapest 13-smooth M >= N - 1 on the mixed-radix passes (no power of two in sight: M is 0-3 % above N - 1);
+    same operator as the oracle's FFT Hilbert and as the padded power-of-two form."""
+    from oracle import wefax_oracle as wo
+    from wefax_amd import _native as nat
+    x = _signal(n, n % 977)
+    a = ctx.analytic_env(x)
+    assert _rel(a, wo.demodulate(x)) <= FLOAT_TOL
+    assert _rel(a, ctx.analytic_env(x, nat.WFX_HILBERT_FFT_POW2)) <= FLOAT_TOL
+    m = nat.padded_length(n - 1)
+    assert m == 0 or n - 1 <= m <= (n - 1) * 1.09
+
+
 def test_analytic_envelope_fir_mode_converges(ctx):
     """The FIR kernel approaches the exact operator as taps grow (clean narrow-band input)."""
     from oracle import wefax_oracle as wo

@@ -216,6 +216,69 @@ def test_decimate_kernel_matches_model(ctx, kind, factor, ntaps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["i16", "iq", "f64"])
+@pytest.mark.parametrize("factor,ntaps,worst", [(32, 253, False), (32, 253, True), (4, 47, False), (8, 61, False), (3, 95, False), (2, 17, False),
+                                                (64, 301, False), (16, 125, True)])
+def test_decimate_fir64_is_exact_where_it_says_so(ctx, kind, factor, ntaps, worst):
+    """wfx_d_decimate_fir64: int16 input with an aligned power-of-two factor is an integer dot product -- EQUAL to the integer
+    model for every input, also the worst case for the accumulators (all samples -32768 / +32767 with the signs of the taps);
+    anything else is float64 arithmetic in a fixed order."""
+    from wefax_amd import _native as nat
+    rng = np.random.default_rng(factor * 1000 + ntaps)
+    n_out = 5000 + factor
+    first = 37
+    n_in = first + (n_out - 1) * factor + ntaps + 11
+    h = np.sinc((np.arange(ntaps) - (ntaps - 1) / 2) / factor / 1.3) * np.hanning(ntaps + 2)[1:-1]
+    sh = pp.fix_shift_for(h / h.sum())
+    assert 20 <= sh <= 30
+    coef = pp.quantize_taps(h / h.sum(), sh)
+    fix = np.rint(coef * 2.0 ** sh).astype(np.int64)
+    assert np.array_equal(fix / 2.0 ** sh, coef) and coef.sum() == 1.0
+    if kind == "f64":
+        raw = rng.standard_normal(n_in) * 1000
+        real, k, esz = raw, nat.WFX_IN_F64_MONO, 8
+    elif kind == "iq":
+        raw = rng.integers(-32768, 32767, size=(n_in, 2)).astype(np.int16)
+        if worst:
+            raw[:, 1] = 0
+            raw[:, 0] = np.where(rng.integers(0, 2, n_in) > 0, 32767, -32768)
+        real, k, esz = to_real(raw), nat.WFX_IN_I16_STEREO, 4
+    else:
+        raw = rng.integers(-32768, 32767, size=n_in).astype(np.int16)
+        if worst:       # every product of output 0's window has the same sign
+            raw[:] = -32768
+            idx = first + np.arange(ntaps)
+            raw[idx] = np.where(fix >= 0, 32767, -32768).astype(np.int16)
+        real, k, esz = raw.astype(np.float64), nat.WFX_IN_I16_MONO, 2
+    p_in = _dev(ctx, raw)
+    per16 = 16 // esz
+    expect_exact = kind != "f64" and factor >= per16 and factor & (factor - 1) == 0
+    for off in (0, 1, 3):
+        p_out = ctx.dev_malloc(n_out * 8)
+        ex = ctx.d_decimate_fir64(p_in + off * esz, k, n_in - off - 5, first - off, factor, coef, p_out, n_out, sh)
+        got = ctx.dev_download(p_out, (n_out,), np.float64)
+        ctx.dev_free(p_out)
+        assert ex == expect_exact
+        x = real[off:n_in - 5]
+        if ex:
+            # integer model: sum_j fix[j] * (2 * sample) / 2**28, all in int64 (IQ halves are k/2: doubled they are integers)
+            xi = np.rint(2 * x).astype(np.int64)
+            lo, hi = first - off, first - off + (n_out - 1) * factor + ntaps
+            xp = np.zeros(hi - lo, dtype=np.int64)
+            a, b = max(lo, 0), min(hi, xi.shape[0])
+            xp[a - lo:b - lo] = xi[a:b]
+            acc = np.zeros(n_out, dtype=np.int64)
+            for j in range(ntaps):
+                acc += fix[j] * xp[j:j + (n_out - 1) * factor + 1:factor]
+            want = acc.astype(np.float64) / 2.0 ** (sh + 1)
+            assert np.array_equal(got, want)
+        else:
+            want = decimate_model(x, first - off, factor, coef, n_out)
+            assert np.max(np.abs(got - want)) <= 1e-13 * np.sum(np.abs(coef)) * np.max(np.abs(real))
+    ctx.dev_free(p_in)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["i16", "iq", "f32"])
 @pytest.mark.parametrize("p,q,taps", [(160, 147, 12), (250, 147, 16), (500, 441, 12), (147, 160, 8)])
 def test_rational_kernel_matches_model(ctx, kind, p, q, taps):

@@ -141,6 +141,29 @@ def test_two_gloo_processes_agree_on_the_partition(tmp_path):
     assert r0["inp"][0] == 0 and r0["inp"][1] == r1["inp"][0] and r1["inp"][1] == 172800000
 
 
+def _nonce_worker(rank, world, port, nonce, uid_byte, out_dir):
+    uid = sharded.bootstrap_unique_id(rank, world, port=port, timeout=30.0, make_id=lambda: bytes([uid_byte]) * 128, nonce=nonce)
+    with open(os.path.join(out_dir, f"{nonce}_{rank}"), "wb") as fh:
+        fh.write(uid)
+
+
+def test_two_jobs_on_one_port_range_do_not_serve_each_others_ranks(tmp_path):
+    """Two decodes on one host probing the SAME port range: each rank 0 answers only peers that present its job's nonce, so the
+    ranks of job A never end up with job B's communicator id (they skip to the next port of the range)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_nonce_worker, args=(r, 2, port, nonce, b, str(tmp_path)))
+             for nonce, b in (("jobA", 0xA1), ("jobB", 0xB2)) for r in (1, 0)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(90)
+        assert pr.exitcode == 0
+    for nonce, b in (("jobA", 0xA1), ("jobB", 0xB2)):
+        for r in range(2):
+            assert open(os.path.join(tmp_path, f"{nonce}_{r}"), "rb").read() == bytes([b]) * 128
+
+
 def test_bootstrap_times_out_loudly_without_rank_zero():
     with pytest.raises(nat.NativeError):
         sharded.bootstrap_unique_id(1, 2, port=_free_port(), timeout=0.5)

@@ -16,12 +16,12 @@ python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 head -c 600 "$OUT/bench.json"; echo
 
 # per-kernel durations of the same workload (configs[1] only: --no-c4 keeps the 22 GB stream out of the trace)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-c4 --no-pcie > "$OUT/prof_bench.json" 2> "$OUT/prof_bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-c4 --no-pcie --no-extras > "$OUT/prof_bench.json" 2> "$OUT/prof_bench.err"
 find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 
 # HBM traffic, one counter per pass, no trace domains besides the kernel trace
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie > /dev/null 2> "$OUT/pmc_fetch.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie > /dev/null 2> "$OUT/pmc_write.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie --no-extras > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie --no-extras > /dev/null 2> "$OUT/pmc_write.err"
 python tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic.json" > "$OUT/pmc_summary.log" 2>&1
 for d in fetch write; do
   f=$(find "$OUT/pmc_$d" -name '*counter_collection.csv' | head -1)
@@ -79,7 +79,7 @@ if [ -x tools/micro/build/stream_big ]; then timeout 120 tools/micro/build/strea
 timeout 600 python tools/ingest_probe.py > "$OUT/ingest_probe.txt" 2>> "$OUT/bench.err"
 
 # where the waves' cycles go (SQ counters, one pass)
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/sq" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/sq" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie --no-extras > /dev/null 2>> "$OUT/bench.err"
 python tools/pmc_sq.py "$OUT/sq" > "$OUT/sq_counters.txt"
 rm -rf "$OUT/sq"
 ls -la "$OUT"

@@ -11,7 +11,7 @@ for setting in "$@"; do
     rm -rf "$OUT"; mkdir -p "$OUT"
     (
         for kv in $setting; do export "$kv"; done
-        rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-c4 --no-pcie $EXP_ARGS > "$OUT/bench.json" 2> "$OUT/err.txt"
+        rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o run -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-c4 --no-pcie --no-extras $EXP_ARGS > "$OUT/bench.json" 2> "$OUT/err.txt"
     )
     echo "== [$setting]  $(python3 -c "import json,sys; d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'])" 2>/dev/null)"
     python3 tools/kstats.py "$OUT" "$FILTER"

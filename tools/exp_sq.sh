@@ -3,9 +3,9 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/exp_sq; rm -rf "$OUT"; mkdir -p "$OUT"
 for kv in $2; do export "$kv"; done
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d "$OUT/a" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie $EXP_ARGS > /dev/null 2> "$OUT/err.txt"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d "$OUT/a" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie --no-extras $EXP_ARGS > /dev/null 2> "$OUT/err.txt"
 python3 tools/pmc_sq.py "$OUT/a" "$1"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/b" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie $EXP_ARGS > /dev/null 2>> "$OUT/err.txt"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/b" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie --no-extras $EXP_ARGS > /dev/null 2>> "$OUT/err.txt"
 python3 - "$OUT/b" "$1" <<'PY'
 import csv, glob, os, re, sys
 from collections import defaultdict

@@ -23,29 +23,42 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=12)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default=None, help="also append the per-case records and the summary to this file (JSON lines)")
     a = ap.parse_args()
+    sink = open(a.out, "a") if a.out else None
+
+    def emit(rec):
+        line = json.dumps(rec)
+        print(line, flush=True)
+        if sink:
+            sink.write(line + "\n")
+            sink.flush()
     rng = np.random.default_rng(a.seed)
     ctx = nat.Context(0)
-    worst = {"stream_max": 0, "image_max": 0, "image_gt1": 0, "start_ne": 0}
+    worst = {"stream_max": 0, "image_max": 0, "image_gt1": 0, "start_ne": 0, "not_ok": 0, "stream_bytes": 0, "stream_ne": 0, "image_bytes": 0, "image_ne": 0}
+    hist_stream, hist_image = {}, {}                                   # differing bytes per clip -> clips
     with tempfile.TemporaryDirectory() as td:
         for k in range(a.cases):
             fs = int(rng.choice([1536000, 1536000, 192000, 48000]))
             iq = fs != 48000
             lpm = int(rng.choice([120, 240]))
-            seconds = int(rng.integers(24, 41))                       # whole seconds: the nominal and the reference's rate ratio agree
+            seconds = int(rng.integers(24, 41))
             t_line = 60.0 / lpm
             phasing = 40 if lpm == 240 else 20
             lines = int(round((seconds - 3.0) / t_line)) - phasing
             x = synth.synth_capture(float(fs), noise=float(rng.choice([0.01, 0.05, 0.1])), seed=int(rng.integers(1 << 30)), lpm=lpm, phasing_lines=phasing,
                                     image_lines=lines, start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0, iq=iq)
+            fe = pp.FrontEnd(fs, stop_rate=pp.FrontEnd.handover_rate(fs))
+            if rng.integers(0, 2):       # not a whole number of seconds (still whole hand-over samples): int(11025 * n0 / fs) != n0 * 11025 / fs
+                x = np.ascontiguousarray(x[:x.shape[0] - fe.granule() * int(rng.integers(1, 5000))])
             path = os.path.join(td, "c.wav")
             synth.write_wav(path, fs, x)
             ref = wo.process(path, lpm, want_messages=False)
-            fe = pp.FrontEnd(fs, stop_rate=pp.FrontEnd.handover_rate(fs))
             dec = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=lpm)
             dec.run()
             info = dec.result()
-            rec = dict(fs=fs, lpm=lpm, seconds=seconds, frames=int(x.shape[0]))
+            rec = dict(fs=fs, lpm=lpm, seconds=seconds, frames=int(x.shape[0]), whole_seconds=bool(x.shape[0] % fs == 0), f64_chain=bool(fe.f64),
+                       exact_ingest=dec.fe.exact_ingest)
             if ref.get("exception") is not None or info.no_group:
                 rec["no_group"] = [ref.get("exception") is not None, bool(info.no_group)]
                 rec["ok"] = rec["no_group"][0] == rec["no_group"][1]
@@ -60,9 +73,20 @@ def main():
                 worst["image_max"] = max(worst["image_max"], rec["image_max"])
                 worst["image_gt1"] += rec["image_gt1"]
                 worst["start_ne"] += 0 if rec["start_eq"] else 1
+                worst["stream_bytes"] += int(d.size)
+                worst["stream_ne"] += rec["stream_ne"]
+                worst["image_bytes"] += int(di.size)
+                worst["image_ne"] += rec["image_ne"]
+                hist_stream[rec["stream_ne"]] = hist_stream.get(rec["stream_ne"], 0) + 1
+                hist_image[rec["image_ne"]] = hist_image.get(rec["image_ne"], 0) + 1
+            worst["not_ok"] += 0 if rec["ok"] else 1
             dec.close()
-            print(json.dumps(rec), flush=True)
-    print(json.dumps({"cases": a.cases, **worst}))
+            emit(rec)
+    emit({"summary": True, "cases": a.cases, "seed": a.seed, **worst,
+          "clips_by_differing_stream_bytes": {str(k): v for k, v in sorted(hist_stream.items())},
+          "clips_by_differing_image_bytes": {str(k): v for k, v in sorted(hist_image.items())}})
+    if worst["not_ok"]:
+        raise SystemExit(f"{worst['not_ok']} case(s) outside the bar (start_frame equal, stream and image within 1)")
 
 
 if __name__ == "__main__":

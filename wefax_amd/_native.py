@@ -28,14 +28,14 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_resample_rational", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_decimate_fir64", "wfx_d_resample_rational", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
     "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
     "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
     "wfx_synth_frames", "wfx_synth_capture", "wfx_decode_png", "wfx_decode_save_png", "wfx_host_alloc", "wfx_host_free",
-    "wfx_decode_reload", "wfx_decode_fetch_async",
+    "wfx_decode_reload", "wfx_decode_fetch_async", "wfx_plan_padded_length", "wfx_plan_describe",
     "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
     "wfx_profile_kernel_count", "wfx_profile_kernel_name", "wfx_profile_get",
 ]
@@ -178,6 +178,7 @@ def load():
     lib.wfx_d_notch_fir.argtypes = [vp, vp, sz, dp, dp, vp, i]
     lib.wfx_d_notch_fir_f64.argtypes = [vp, vp, sz, dp, dp, vp, i]
     lib.wfx_d_decimate_fir.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, i, sz]
+    lib.wfx_d_decimate_fir64.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int)]
     lib.wfx_d_resample_rational.argtypes = [vp, vp, i, sz, C.c_int64, i, i, vp, i, C.c_int64, vp, sz]
     lib.wfx_d_fir_envelope.argtypes = [vp, vp, sz, sz, i, vp]
     lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
@@ -211,6 +212,9 @@ def load():
     lib.wfx_host_free.restype = None
     lib.wfx_decode_reload.argtypes = [vp, vp, sz, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.wfx_decode_fetch_async.argtypes = [vp, i, vp, sz]
+    lib.wfx_plan_padded_length.argtypes = [C.c_uint64]
+    lib.wfx_plan_padded_length.restype = C.c_uint64
+    lib.wfx_plan_describe.argtypes = [C.c_uint64, C.c_char_p, i]
     lib.wfx_synth_frames.argtypes = [C.POINTER(SynthParams)]
     lib.wfx_synth_frames.restype = C.c_uint64
     lib.wfx_synth_capture.argtypes = [vp, C.POINTER(SynthParams), C.c_uint64, C.c_uint64, vp]
@@ -224,10 +228,21 @@ def load():
     lib.wfx_profile_get.argtypes = [vp, i, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("wfx_device_count", "wfx_profile_kernel_count", "wfx_synth_frames", "wfx_host_alloc", "wfx_host_free"):
+        if fn.restype is C.c_int and name not in ("wfx_device_count", "wfx_profile_kernel_count", "wfx_synth_frames", "wfx_host_alloc", "wfx_host_free", "wfx_plan_padded_length"):
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def padded_length(min_len: int) -> int:
+    """13-smooth transform length for an any-length analytic-signal convolution (include/wefax_hip.h wfx_plan_padded_length)."""
+    return int(load().wfx_plan_padded_length(int(min_len)))
+
+
+def plan_describe(length: int) -> str:
+    buf = C.create_string_buffer(256)
+    load().wfx_plan_describe(int(length), buf, 256)
+    return buf.value.decode()
 
 
 def _ptr(a: np.ndarray):
@@ -509,6 +524,15 @@ class Context:
         c = np.ascontiguousarray(coef, dtype=np.float32)
         self._check(self.lib.wfx_d_decimate_fir(self.h, C.c_void_p(in_ptr), in_kind, n_in, first, factor, _ptr(c), c.shape[0],
                                                 C.c_void_p(out_ptr), 1 if out_f64 else 0, n_out))
+
+    def d_decimate_fir64(self, in_ptr: int, in_kind: int, n_in: int, first: int, factor: int, coef: np.ndarray, out_ptr: int, n_out: int,
+                         fix_shift: int = 0) -> bool:
+        """float64 taps, float64 result; True when the integer-exact form ran (taps on the grid 2**-fix_shift; include/wefax_hip.h)."""
+        c = np.ascontiguousarray(coef, dtype=np.float64)
+        ex = C.c_int(0)
+        self._check(self.lib.wfx_d_decimate_fir64(self.h, C.c_void_p(in_ptr), in_kind, n_in, first, factor, _ptr(c), c.shape[0],
+                                                  C.c_void_p(out_ptr), n_out, int(fix_shift), C.byref(ex)))
+        return bool(ex.value)
 
     def d_resample_rational(self, in_ptr: int, in_kind: int, n_in: int, base0: int, p: int, q: int, table: np.ndarray, m0: int,
                             out_ptr: int, n_out: int):

@@ -904,6 +904,16 @@ static int hilbert_conv(wfx_ctx *ctx, const double *x, uint64_t n, cplx **W_out,
         *L_out = n / 2;
         return wfx_dev_hilbert_conv_mr(ctx, x, n, W_out);
     }
+    // any other even N: the same packed convolution zero-padded to a 13-smooth M >= N - 1 on the mixed-radix passes
+    if ((n & 1) == 0 && n >= 8192 && !ctx->force_pow2 && !getenv("WFX_NO_SMOOTH_PAD")) {
+        int handled = 0;
+        WFX_TRY(wfx_dev_hilbert_conv_mr_padded(ctx, x, n, W_out, &handled));
+        if (handled) {
+            *packed_out = 1;
+            *L_out = n / 2;
+            return 0;
+        }
+    }
     wfx_bs_plan *pl = nullptr;
     WFX_TRY(get_hplan(ctx, n, &pl, packed_out, L_out));
     const uint64_t M = 1ull << pl->log2m;

@@ -134,6 +134,11 @@ struct mr_pass_desc {
     // outputs with skip_lo < index < skip_hi are not stored (skip_hi == 0: all are): the bins of a forward spectrum that
     // scipy.signal.resample's down-sampling never reads (wefax.py:384 keeps the lowest num/2 + 1 bins and their mirrors)
     long long skip_lo, skip_hi;
+    // zero-padded convolution on these passes (any even capture length, wfx_dev_hilbert_conv_mr_padded): a first pass from packed
+    // reals reads only the first in_len points, the rest of the array counts as zero (0: no limit); a last forward pass of
+    // OUT_MODE 4 multiplies output o by gtab[o] (the transformed kernel)
+    long long in_len;
+    const double2 *gtab;
 };
 struct mr_qmap {
     unsigned long long base;
@@ -309,6 +314,10 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
 bool wfx_mr_supported(uint64_t L);
 void wfx_mr_release(wfx_ctx *ctx);
 int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out);
+// even n whose half is NOT 13-smooth: the same packed convolution zero-padded to the cheapest 13-smooth M >= n - 1 with a
+// radix-pair plan (at most a few per cent above n - 1); *handled = 0 when no such M exists (tiny n): the caller pads to 2^k
+int wfx_dev_hilbert_conv_mr_padded(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out, int *handled);
+long long wfx_mr_padded_length(long long min_len);
 bool wfx_mr_resample_supported(uint64_t n0, uint64_t num);
 int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16 = false);
 
@@ -317,6 +326,8 @@ int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long
 // wfx_polyphase.hip
 int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const float *coef, int ntaps,
                          void *out, int out_f64, uint64_t n_out);
+int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const double *coef, int ntaps,
+                           double *out, uint64_t n_out, int fix_shift, int *exact_out);
 int wfx_dev_resample_rational(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t base0, int p, int q, const float *table,
                               int T, int64_t m0, float *out, uint64_t n_out);
 

@@ -595,7 +595,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
          int ntiles)
 {
     constexpr int LOG2T = mr2_log2t(RA * RB);
-    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3 || (OUT_MODE == 1 && mr2_rows(RB)))) ? 1 : 0;
+    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3 || ((OUT_MODE == 1 || OUT_MODE == 4) && mr2_rows(RB)))) ? 1 : 0;
     constexpr int R = RA * RB, T = 1 << LOG2T;
     constexpr int NT = mr2_nt(R);                                 // lanes per workgroup
     constexpr int NA = (T * RB + NT - 1) / NT, NB = (T * RA + NT - 1) / NT;
@@ -610,13 +610,14 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
         sincospi(2.0 * (double)i / (double)R, &sn, &cs);
         wr[i] = make_double2(cs, inv ? sn : -sn);                 // W_R^i in the direction of this pass
     }
-    __shared__ cplx gpow[OUT_MODE >= 1 ? RB : 1];                 // exp(-i pi qb RA P / L): the spectrum's step along qb
-    if (OUT_MODE >= 1 && t < RB) {
+    __shared__ cplx gpow[(OUT_MODE == 1 || OUT_MODE == 2) ? RB : 1];   // exp(-i pi qb RA P / L): the spectrum's step along qb
+    if ((OUT_MODE == 1 || OUT_MODE == 2) && t < RB) {
         double sn, cs;
         sincospi((double)((long long)t * RA * d.Ptw) / (double)d.Ltw, &sn, &cs);
         gpow[t] = make_double2(cs, -sn);
     }
     cplx pre[NA][RA];
+    const long long in_lim = (IN_MODE == 1 && d.in_len > 0) ? d.in_len : 0x7fffffffffffffffll;     // zero padding behind the packed reals
     auto prefetch = [&](int tix) {
 #pragma unroll
         for (int ia = 0; ia < NA; ++ia) {
@@ -627,8 +628,8 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
 #pragma unroll
             for (int a = 0; a < RA; ++a) {
                 cplx v = make_double2(0.0, 0.0);
-                if (ok) {
-                    const long long adr = (long long)j + (long long)(a * RB + b) * ncol;
+                const long long adr = (long long)j + (long long)(a * RB + b) * ncol;
+                if (ok && (IN_MODE != 1 || adr < in_lim)) {
                     if (IN_MODE == 2) {
                         const short2 x2 = ((const short2 *)in)[adr];
                         v = make_double2((double)x2.x, (double)x2.y);
@@ -820,6 +821,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                             // (kernel-uniform) step come from LDS, the start from one sincospi per thread
                             y = (gbase == 0 && qb == 0) ? make_double2(0.0, 0.0) : mcmul(y, mcmul(g0, gpow[qb]));
                         }
+                        if (OUT_MODE == 4) y = mcmul(y, d.gtab[o]);        // zero-padded convolution: the transformed kernel, from memory
                         out[o] = y;
                     };
                     if constexpr (ROWS) {
@@ -936,6 +938,8 @@ static void mr_fill_pass(mr_plan_host &pl, int i, int R, int ra, int rb, long lo
     d.Ltw = pl.L;
     d.qmap = nullptr;
     d.skip_lo = d.skip_hi = 0;
+    d.in_len = 0;
+    d.gtab = nullptr;
     d.ncol = pl.L / R;
     const int T = MR_TILE / R;
     int t2 = 1, l2 = 0;
@@ -1114,7 +1118,9 @@ static std::map<std::pair<const void *, long long>, mr_plan_cache> g_mr_plans;  
 static std::mutex g_mr_mutex;
 
 // "7x13,7x25,15x15" (pairs) / "98" (per-prime radix) of the plan for L; empty when L is not 13-smooth (diagnostics, tools/)
-extern "C" int wfx_debug_plan(uint64_t L, char *buf, int cap)
+extern "C" uint64_t wfx_plan_padded_length(uint64_t min_len) { return (uint64_t)wfx_mr_padded_length((long long)min_len); }
+
+extern "C" int wfx_plan_describe(uint64_t L, char *buf, int cap)
 {
     mr_plan_host pl;
     if (!buf || cap < 2) return -1;
@@ -1184,8 +1190,11 @@ static int mr_get_plan(wfx_ctx *ctx, long long L, mr_plan_cache **out)
     return 0;
 }
 
+static void mr_padded_release(wfx_ctx *ctx);
+
 void wfx_mr_release(wfx_ctx *ctx)
 {
+    mr_padded_release(ctx);
     std::lock_guard<std::mutex> lock(g_mr_mutex);
     for (auto it = g_mr_plans.begin(); it != g_mr_plans.end();) {
         if (it->first.first == (const void *)ctx) {
@@ -1221,6 +1230,8 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 3 && in_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 3, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 0 && out_mode == 4 && in_mode == 0)                                                                          \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 4, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 1 && out_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 0 && out_mode == 0)                                                                          \
@@ -1444,6 +1455,147 @@ int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_
     // the packed real input IS x viewed as complex pairs (swapped on load)
     WFX_TRY(mr_run(ctx, pc, (const cplx *)x, A, B, 0, true, nullptr, &mid));
     return mr_run(ctx, pc, mid, A, B, 1, true, nullptr, V_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Any even capture length (wefax.py:174 takes whatever the wav holds).  When L = N/2 has a prime factor above 13 the cyclic
+// convolution of length L is embedded in one of length M >= 2L - 1: z zero-padded, the kernel laid out on both sides of
+// index 0 (g_ext[j] = kh[2j - 1], |j| < L), the first L outputs are the cyclic result.  M is the cheapest 13-smooth length
+// with a radix-pair plan in [2L - 1, 1.08 (2L - 1)] (a power of two can be 2x above 2L - 1; these are 0-2 % above), the
+// kernel's M-point transform is computed once per N on the same passes and multiplied in by the last forward pass.
+// ---------------------------------------------------------------------------------------------
+static void smooth_candidates(long long lo, long long hi, long long cur, int pi, std::vector<long long> &out)
+{
+    static const int primes[] = {2, 3, 5, 7, 11, 13};
+    if (cur >= lo) out.push_back(cur);
+    for (int i = pi; i < 6; ++i) {
+        if (cur > hi / primes[i]) break;
+        smooth_candidates(lo, hi, cur * primes[i], i, out);
+    }
+}
+
+long long wfx_mr_padded_length(long long min_len)
+{
+    if (min_len >= (1ll << 31)) return 0;
+    if (min_len < 4096) return 0;
+    const long long hi = min_len + min_len / 12;
+    std::vector<long long> cand;
+    smooth_candidates(min_len, hi, 1, 0, cand);
+    long long best = 0;
+    double best_cost = 1e300;
+    for (long long m : cand) {
+        std::vector<int> cur, plan;
+        double c = 1e30;
+        if (!mr2_search(m, 0, 0.0, cur, c, plan) || plan.size() < 2) continue;
+        const double total = c * (double)m;
+        if (total < best_cost) {
+            best_cost = total;
+            best = m;
+        }
+    }
+    return best;
+}
+
+__device__ __forceinline__ double mr_hilbert_tap_even(long long r, long long N)      // kh[r], N even: (2/N) cot(pi r / N) on odd lags
+{
+    r %= N;
+    if (r < 0) r += N;
+    if ((r & 1) == 0) return 0.0;
+    double s, c;
+    sincospi((double)r / (double)N, &s, &c);
+    return (2.0 / (double)N) * (c / s);
+}
+
+__global__ void __launch_bounds__(256) mr_padded_fill(cplx *__restrict__ G, long long N, long long L, long long M, double inv_m)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < M; i += (long long)gridDim.x * 256ll) {
+        double v = 0.0;
+        if (i < L || M - i < L) {
+            const long long j = i < L ? i : i - M;
+            v = mr_hilbert_tap_even(2 * j - 1, N) * inv_m;
+        }
+        G[i] = make_double2(v, 0.0);
+    }
+}
+
+struct mr_padded_cache {
+    long long M = 0;
+    wfx_devbuf ghat;
+};
+static std::map<std::pair<const void *, long long>, mr_padded_cache> g_mr_padded;      // per (context, N)
+
+int wfx_dev_hilbert_conv_mr_padded(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out, int *handled)
+{
+    *handled = 0;
+    const long long L = (long long)(n / 2);
+    mr_padded_cache *pd = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mr_mutex);
+        auto key = std::make_pair((const void *)ctx, (long long)n);
+        auto it = g_mr_padded.find(key);
+        if (it == g_mr_padded.end()) {
+            mr_padded_cache c;
+            c.M = wfx_mr_padded_length(2 * L - 1);
+            // (one kernel spectrum per context is kept: a context decodes captures of one length over and over)
+            for (auto jt = g_mr_padded.begin(); jt != g_mr_padded.end();) {
+                if (jt->first.first == (const void *)ctx) {
+                    (void)hipStreamSynchronize(ctx->stream);
+                    if (jt->second.ghat.p) (void)hipFree(jt->second.ghat.p);
+                    jt = g_mr_padded.erase(jt);
+                } else {
+                    ++jt;
+                }
+            }
+            it = g_mr_padded.emplace(key, c).first;
+        }
+        pd = &it->second;
+    }
+    if (pd->M == 0) return 0;
+    const long long M = pd->M;
+    mr_plan_cache *pc = nullptr;
+    WFX_TRY(mr_get_plan(ctx, M, &pc));
+    const int np = pc->h.npass;
+    for (int i = 0; i < np; ++i)
+        if (pc->h.pass[i].ra <= 0) return 0;                       // (the search only returns pair plans; WFX_MR2_PLAN may force others)
+    if (np < 2 || !pc->use_mr2) return 0;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work, (size_t)M * sizeof(cplx)));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (size_t)M * sizeof(cplx)));
+    cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
+    const cplx *tb = (const cplx *)pc->tables.p;
+    if (!pd->ghat.p) {
+        WFX_TRY(wfx_reserve(ctx, pd->ghat, (size_t)M * sizeof(cplx)));
+        cplx *G = (cplx *)pd->ghat.p;
+        WFX_LAUNCH(ctx, K_BS_CHIRP, mr_padded_fill, dim3(wfx_stream_grid((uint64_t)M, 256)), dim3(256), G, (long long)n, L, M, 1.0 / (double)M);
+        cplx *res = nullptr;
+        WFX_TRY(mr_run(ctx, pc, G, A, B, 0, false, G, &res));      // (np >= 2: G is read by the first pass only)
+    }
+    // forward: first pass from the packed reals (the first L points; zeros behind them), last pass times the kernel's transform
+    const cplx *src = (const cplx *)x;
+    cplx *dst = A;
+    for (int i = 0; i < np; ++i) {
+        mr_pass_desc d = pc->h.pass[i];
+        if (i == 0) d.in_len = L;
+        if (i == np - 1) d.gtab = (const double2 *)pd->ghat.p;
+        WFX_TRY(wfx_mr_launch_pair(ctx, d, tb + pc->h.lo_off[i], i == 0 ? 1 : 0, i == np - 1 ? 4 : 0, 0, src, dst));
+        src = dst;
+        dst = dst == A ? B : A;
+    }
+    WFX_TRY(mr_run(ctx, pc, src, A, B, 1, false, nullptr, V_out));
+    *handled = 1;
+    return 0;
+}
+
+static void mr_padded_release(wfx_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lock(g_mr_mutex);
+    for (auto it = g_mr_padded.begin(); it != g_mr_padded.end();) {
+        if (it->first.first == (const void *)ctx) {
+            if (it->second.ghat.p) (void)hipFree(it->second.ghat.p);
+            it = g_mr_padded.erase(it);
+        } else {
+            ++it;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -41,6 +41,31 @@ __device__ __forceinline__ void pp_cvt4(const float4 &r, float *w)
     w[3] = r.w;
 }
 
+// the same 4 samples as float64 (MODE 2)
+__device__ __forceinline__ void pp_load4d(const short *p, double *w)
+{
+    const int *q = (const int *)p;
+    const int a = q[0], b = q[1];
+    w[0] = (double)(short)a;
+    w[1] = (double)(a >> 16);
+    w[2] = (double)(short)b;
+    w[3] = (double)(b >> 16);
+}
+__device__ __forceinline__ void pp_load4d(const float *p, double *w)
+{
+    const float4 v = *(const float4 *)p;
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+__device__ __forceinline__ void pp_load4d(const double *p, double *w)
+{
+    w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3];
+}
+typedef short pp_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pp_dot2(int w, int c, int acc)      // acc + w.lo * c.lo + w.hi * c.hi, int16 x int16 -> int32, exact
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(pp_s2, w), __builtin_bit_cast(pp_s2, c), acc, false);
+}
+
 // ---- element access -----------------------------------------------------------
 // IN 0: int16 mono, 1: int16 pairs merged with int16 wrap, 3: float
 template <int IN> struct pp_in;
@@ -92,6 +117,19 @@ template <> struct pp_in<WFX_IN_F32_MONO> {
     __device__ static store_t one(const void *p, long long i) { return ((const float *)p)[i]; }
 };
 
+template <> struct pp_in<WFX_IN_F64_MONO> {          // float64 between the stages of the exact chain (MODE 2 only)
+    typedef double store_t;
+    static constexpr int PER16 = 2;
+    static constexpr int BYTES = 8;
+    static constexpr float SCALE = 1.0f;
+    __device__ static void chunk(const uint4 &v, store_t *e)
+    {
+        e[0] = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+        e[1] = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
+    }
+    __device__ static store_t one(const void *p, long long i) { return ((const double *)p)[i]; }
+};
+
 // one 16-byte chunk starting at element e0 of the aligned view; elements outside the caller's array read as zero
 template <int IN>
 __device__ __forceinline__ uint4 pp_fetch(const void *in, const unsigned char *base, long long e0, int misalign, long long n_in)
@@ -100,6 +138,15 @@ __device__ __forceinline__ uint4 pp_fetch(const void *in, const unsigned char *b
     if (e0 >= misalign && e0 + A::PER16 <= n_in + misalign) return *(const uint4 *)(base + e0 * A::BYTES);
     const long long ci = e0 - misalign;
     unsigned w[4];
+    if (A::BYTES == 8) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool ok = ci + k >= 0 && ci + k < n_in;
+            w[2 * k] = ok ? ((const unsigned *)in)[2 * (ci + k)] : 0u;
+            w[2 * k + 1] = ok ? ((const unsigned *)in)[2 * (ci + k) + 1] : 0u;
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (A::BYTES == 4) {
@@ -155,10 +202,16 @@ typedef float pp_acc_t;
 #endif
 constexpr int PP_NB = 9;           // 16-byte chunks in flight per thread (decimate): 36 VGPRs
 
-template <int IN, typename OUT, bool ALIGNED, int Q4T>
+// MODE 0: fp32 taps and sums (the round-1/2 form).  MODE 1: EXACT -- int16 samples times taps on a fixed-point grid
+// 2^-shift, split into a high and a low int16 part, summed with v_dot2_i32_i16 (two multiply-adds per instruction, the
+// window pairs straight from LDS, no conversions; the shift travels in bits 8.. of `flush_rows`); the sum of a tile's products is an integer that fits 64 bits, so the
+// float64 output is THE value of the FIR with those taps: no rounding anywhere, nothing depends on the tiling.  MODE 2:
+// float64 taps and sums in one canonical order (the stages behind the ingest: a few per cent of the samples).
+constexpr int PP_FIX_LB = 12;
+template <int IN, typename OUT, bool ALIGNED, int Q4T, int MODE = 0>
 __global__ void __launch_bounds__(PP_THREADS, PP_MINB)
 decimate_kernel(const void *__restrict__ in, long long n_in, long long first, int M, int log2m, const float *__restrict__ cp, int q4_arg,
-                OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign)
+                OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign, int flush_rows = 0)
 {
     // log2m < 0: M is not a power of two (/3 at the end of a chain) -- rows are never split over thread groups then and the
     // window position of a chunk is found by a division
@@ -181,9 +234,13 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
     // row index is uniform) -- as LDS broadcast reads, 16 bytes per lane, they cost the LDS pipe as much as the window reads
     // and the tap loop was LDS-bound -- and the next tile's first chunks are requested before the tap loop.  The short
     // stages behind it measure faster with the taps in LDS and without the prefetch.
-    constexpr bool SMEM = PP_PAIRS && PP_TAPS_SMEM && ALIGNED, PF = PP_PREFETCH && ALIGNED;
-    float *cl = psum + PP_THREADS * 4 * (sizeof(pp_acc_t) / sizeof(float));
-    if (!SMEM)
+    constexpr bool SMEM = MODE == 1 || (MODE == 0 && PP_PAIRS && PP_TAPS_SMEM && ALIGNED), PF = PP_PREFETCH && ALIGNED;
+    constexpr int ACCW = MODE ? 2 : (int)(sizeof(pp_acc_t) / sizeof(float));         // floats per partial sum
+    // (MODE 1 / 2 reserve exactly the partial sums the row groups exchange: the ingest then fits four workgroups per CU)
+    float *cl = psum + (MODE ? ((((1 << rs_log2) - 1) << log2qw) * 4) : PP_THREADS * 4) * ACCW;
+    if (MODE == 2) {
+        for (int i = t; i < M * 4 * q4; i += PP_THREADS) ((double *)cl)[i] = ((const double *)cp)[i];
+    } else if (!SMEM)
         for (int i = t; i < M * (PP_PAIRS ? 8 * q4 + 4 : 4 * q4); i += PP_THREADS) cl[i] = cp[i];
     const float *cs = SMEM ? cp : cl;
     const long long ntiles = (n_out + tb - 1) >> log2tb;
@@ -277,6 +334,115 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
         // a row's 4 * q4 taps are summed in fp32 (packed FMAs) and the row sums are added up: two short chains instead of one
         // of 4 * q4 * M terms keep the rounding of the sum near that of the fp32 sample the stage stores (measured against a
         // float64 model: rms 6e-8 of the signal).  PP_ACC64 1 adds the rows in fp64 instead: rms 4.4e-8, ingest + 9 %.
+        if constexpr (MODE == 1) {
+            // exact: hi parts in one int32 per output over the whole tile, lo parts flushed into an int64 every flush_rows rows
+            // (the host checked both bounds against the worst-case sample, |s| = 32768)
+            long long tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0;
+            if (active) {
+                const int r0 = part * rows_per;
+                int ah0 = 0, ah1 = 0, ah2 = 0, ah3 = 0, al0 = 0, al1 = 0, al2 = 0, al3 = 0;
+                const int *ci = (const int *)cp;
+                constexpr int NP = 2 * (Q4T ? Q4T : 1);
+                for (int r = r0; r < r0 + rows_per; ++r) {
+                    const int *row = (const int *)(xs + r * row_stride + 4 * g);      // dword p = samples (w[2p], w[2p+1])
+                    const int *c = ci + r * (8 * q4 + 4);     // E_hi[2 q4], E_lo[2 q4], D_hi[2 q4 + 2], D_lo[2 q4 + 2]
+                    const int np = Q4T ? NP : 2 * q4;
+                    const int *ehi = c, *elo = c + np, *dhi = c + 2 * np, *dlo = c + 3 * np + 2;
+                    int w0 = row[0];
+#pragma unroll(Q4T ? NP : 1)
+                    for (int p = 0; p < np; ++p) {
+                        const int w1 = row[p + 1];
+                        const int eh = ehi[p], el = elo[p], dh = dhi[p], dl = dlo[p];
+                        ah0 = pp_dot2(w0, eh, ah0); al0 = pp_dot2(w0, el, al0);      // output 0: sum_p W[p] . (c[2p], c[2p+1])
+                        ah2 = pp_dot2(w1, eh, ah2); al2 = pp_dot2(w1, el, al2);      // output 2: the window one pair later
+                        ah1 = pp_dot2(w0, dh, ah1); al1 = pp_dot2(w0, dl, al1);      // output 1: sum_p W[p] . (c[2p-1], c[2p])
+                        ah3 = pp_dot2(w1, dh, ah3); al3 = pp_dot2(w1, dl, al3);
+                        w0 = w1;
+                    }
+                    {       // the odd outputs' last pair (c[4 q4 - 1], 0)
+                        const int w1 = row[np + 1];
+                        const int dh = dhi[np], dl = dlo[np];
+                        ah1 = pp_dot2(w0, dh, ah1); al1 = pp_dot2(w0, dl, al1);
+                        ah3 = pp_dot2(w1, dh, ah3); al3 = pp_dot2(w1, dl, al3);
+                    }
+                    if (((r + 1) & ((flush_rows & 255) - 1)) == 0) {
+                        tl0 += al0; tl1 += al1; tl2 += al2; tl3 += al3;
+                        al0 = al1 = al2 = al3 = 0;
+                    }
+                }
+                tl0 += al0 + ((long long)ah0 << PP_FIX_LB); tl1 += al1 + ((long long)ah1 << PP_FIX_LB);
+                tl2 += al2 + ((long long)ah2 << PP_FIX_LB); tl3 += al3 + ((long long)ah3 << PP_FIX_LB);
+            }
+            if (rs_log2 > 0) {
+                long long *ps = (long long *)psum;
+                if (active && part > 0) {
+                    long long *q = ps + ((size_t)((part - 1) << log2qw) + g) * 4;
+                    q[0] = tl0; q[1] = tl1; q[2] = tl2; q[3] = tl3;
+                }
+                __syncthreads();
+                if (active && part == 0)
+                    for (int q = 1; q < (1 << rs_log2); ++q) {
+                        const long long *o = ps + ((size_t)((q - 1) << log2qw) + g) * 4;
+                        tl0 += o[0]; tl1 += o[1]; tl2 += o[2]; tl3 += o[3];
+                    }
+            }
+            if (active && part == 0) {
+                const long long a[4] = {tl0, tl1, tl2, tl3};
+                const double sc = (double)A::SCALE / (double)(1ll << (flush_rows >> 8));   // a power of two: exact
+                if (4 * g + 3 < cnt && ((o0 + 4 * g) & 1) == 0 && sizeof(OUT) == 8) {
+                    double2 *o2 = (double2 *)(out + o0 + 4 * g);
+                    o2[0] = make_double2((double)a[0] * sc, (double)a[1] * sc);
+                    o2[1] = make_double2((double)a[2] * sc, (double)a[3] * sc);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * g + k < cnt) out[o0 + 4 * g + k] = (OUT)((double)a[k] * sc);
+                }
+            }
+        } else if constexpr (MODE == 2) {
+            double tot0 = 0, tot1 = 0, tot2 = 0, tot3 = 0;
+            if (active) {
+                const int r0 = part * rows_per;
+                const double *cd = (const double *)cl;
+                for (int r = r0; r < r0 + rows_per; ++r) {
+                    const S *row = xs + r * row_stride + 4 * g;
+                    const double *c = cd + r * 4 * q4;
+                    double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+                    double wa[4], wb[4];
+                    pp_load4d(row, wa);
+#pragma unroll(Q4T ? Q4T : 1)
+                    for (int j = 0; j < (Q4T ? Q4T : q4); ++j) {
+                        const double c0 = c[4 * j], c1 = c[4 * j + 1], c2 = c[4 * j + 2], c3 = c[4 * j + 3];
+                        pp_load4d(row + 4 * j + 4, wb);
+                        acc0 = fma(c0, wa[0], acc0); acc1 = fma(c0, wa[1], acc1); acc2 = fma(c0, wa[2], acc2); acc3 = fma(c0, wa[3], acc3);
+                        acc0 = fma(c1, wa[1], acc0); acc1 = fma(c1, wa[2], acc1); acc2 = fma(c1, wa[3], acc2); acc3 = fma(c1, wb[0], acc3);
+                        acc0 = fma(c2, wa[2], acc0); acc1 = fma(c2, wa[3], acc1); acc2 = fma(c2, wb[0], acc2); acc3 = fma(c2, wb[1], acc3);
+                        acc0 = fma(c3, wa[3], acc0); acc1 = fma(c3, wb[0], acc1); acc2 = fma(c3, wb[1], acc2); acc3 = fma(c3, wb[2], acc3);
+                        wa[0] = wb[0]; wa[1] = wb[1]; wa[2] = wb[2]; wa[3] = wb[3];
+                    }
+                    tot0 += acc0; tot1 += acc1; tot2 += acc2; tot3 += acc3;
+                }
+            }
+            if (rs_log2 > 0) {
+                double *ps = (double *)psum;
+                if (active && part > 0) {
+                    double *q = ps + ((size_t)((part - 1) << log2qw) + g) * 4;
+                    q[0] = tot0; q[1] = tot1; q[2] = tot2; q[3] = tot3;
+                }
+                __syncthreads();
+                if (active && part == 0)
+                    for (int q = 1; q < (1 << rs_log2); ++q) {
+                        const double *o = ps + ((size_t)((q - 1) << log2qw) + g) * 4;
+                        tot0 += o[0]; tot1 += o[1]; tot2 += o[2]; tot3 += o[3];
+                    }
+            }
+            if (active && part == 0) {
+                const double a[4] = {tot0, tot1, tot2, tot3};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * g + k < cnt) out[o0 + 4 * g + k] = (OUT)(a[k] * (double)A::SCALE);
+            }
+        } else {
         pp_acc_t tot0 = 0, tot1 = 0, tot2 = 0, tot3 = 0;
         if (active) {
             const int r0 = part * rows_per;
@@ -364,6 +530,7 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (4 * g + k < cnt) out[o0 + 4 * g + k] = (OUT)(a[k] * (pp_acc_t)A::SCALE);
+        }
         }
     }
 }
@@ -465,10 +632,49 @@ int launch_decimate(wfx_ctx *ctx, const void *in, long long n_in, long long firs
     if (lds > 48 * 1024) WFX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     wfx_prof_begin(ctx, (IN == WFX_IN_F32_MONO ? K_POLYPHASE : K_POLYPHASE_IN));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PP_THREADS), lds, ctx->stream, in, n_in, first, M, log2m, cp, q4, out, n_out, ilog2_exact(tb),
-                       row_stride, misalign);
+                       row_stride, misalign, 0);
     wfx_prof_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch decimate_kernel");
+    return 0;
+}
+
+// MODE 1 (exact, int16 in, aligned) and MODE 2 (float64 arithmetic, any input kind): float64 out
+template <int IN, int MODE>
+int launch_decimate64(wfx_ctx *ctx, const void *in, long long n_in, long long first, int M, const void *cp, int q4, double *out, long long n_out,
+                      bool aligned, int flush_rows)
+{
+    typedef pp_in<IN> A;
+    const int log2m = ilog2_exact(M);
+    const int esz = (int)sizeof(typename A::store_t);
+    const int pad = esz == 2 ? 6 : 4;
+    int tb = log2m < 0 ? 1024 : PP_TB_MAX;
+    while (tb > 64 && (size_t)(tb + 4 * q4 + pad) * M * esz > (size_t)PP_LDS_BYTES) tb >>= 1;
+    if (log2m < 0 && tb < 1024) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
+    const int row_stride = tb + 4 * q4 + pad;
+    const size_t lds_x = ((size_t)row_stride * M * esz + 15) & ~(size_t)15;
+    // partial sums of the row groups, laid out as the kernel does: rs - 1 groups of (quads rounded up to whole waves) x 4
+    const int log2tb = ilog2_exact(tb), log2q = log2tb - 2, log2qw = log2q < 6 ? 6 : log2q;
+    int rs_log2 = 8 - log2qw;
+    if (rs_log2 > log2m) rs_log2 = log2m;
+    if (rs_log2 < 0) rs_log2 = 0;
+    const size_t lds = lds_x + (size_t)((((1 << rs_log2) - 1) << log2qw) * 4) * 8 + (MODE == 2 ? (size_t)M * 4 * q4 * sizeof(double) : 0);
+    if (lds_x > (size_t)PP_LDS_BYTES || lds > 150 * 1024) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
+    const int misalign = (int)(((uintptr_t)in & 15u) / A::BYTES);
+    const long long ntiles = (n_out + tb - 1) / tb;
+    const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
+    void (*kern)(const void *, long long, long long, int, int, const float *, int, double *, long long, int, int, int, int);
+    if (MODE == 1)
+        kern = q4 == 2 ? decimate_kernel<IN, double, true, 2, MODE> : q4 == 3 ? decimate_kernel<IN, double, true, 3, MODE> : decimate_kernel<IN, double, true, 0, MODE>;
+    else
+        kern = aligned ? decimate_kernel<IN, double, true, 0, MODE> : decimate_kernel<IN, double, false, 0, MODE>;
+    if (lds > 48 * 1024) WFX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    wfx_prof_begin(ctx, (IN == WFX_IN_F64_MONO ? K_POLYPHASE : K_POLYPHASE_IN));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PP_THREADS), lds, ctx->stream, in, n_in, first, M, log2m, (const float *)cp, q4, out, n_out,
+                       ilog2_exact(tb), row_stride, misalign, flush_rows);
+    wfx_prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch decimate_kernel (float64 out)");
     return 0;
 }
 
@@ -543,6 +749,105 @@ int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_i
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: input kind %d", in_kind);
     }
 #undef WFX_PP_CASE
+}
+
+// The same stencil with float64 taps and a float64 result that carries NO rounding of the sum where that is possible:
+//   int16 input (mono / IQ) and a power-of-two factor >= the samples per 16 bytes (the ingest of an oversampled capture):
+//     taps rounded to the grid 2^-fix_shift, split hi * 2^12 + lo, integer dot products (MODE 1).  The output IS
+//     sum_j round(c[j] 2^shift) x[..] / 2^shift -- it depends on neither tiling nor slicing; *exact_out = 1.
+//   anything else (float64 between stages, other factors): float64 FMAs in one canonical order per output (MODE 2).
+// fix_shift 0, or taps the exact form cannot take at that shift (a tap >= 2^23 grid steps, sums that could overflow 32 bits
+// for the worst-case input): MODE 2.
+int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const double *coef, int ntaps,
+                           double *out, uint64_t n_out, int fix_shift, int *exact_out)
+{
+    if (exact_out) *exact_out = 0;
+    if (M < 1 || M > 64) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: factor %d is not in 1..64", M);
+    if (ntaps < 1 || ntaps > 4096) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps", ntaps);
+    if (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_I16_STEREO && in_kind != WFX_IN_F64_MONO)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate (float64): input kind %d", in_kind);
+    if (n_out == 0) return 0;
+    const int per16 = in_kind == WFX_IN_I16_MONO ? 8 : (in_kind == WFX_IN_I16_STEREO ? 4 : 2);
+    const int ebytes = in_kind == WFX_IN_I16_MONO ? 2 : (in_kind == WFX_IN_I16_STEREO ? 4 : 8);
+    if ((uintptr_t)in % ebytes) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: misaligned input pointer");
+    const int misalign = (int)(((uintptr_t)in & 15u) / ebytes);
+    const bool aligned = M >= per16 && ilog2_exact(M) >= 0;
+    int d = 0;
+    if (aligned) {
+        d = (int)(((first + misalign) % per16 + per16) % per16);
+        first -= d;
+    }
+    const int nt = ntaps + d;
+    const int per_row = (nt + M - 1) / M;
+    const int q4 = (per_row + 3) / 4;
+    const long long ni = (long long)n_in, no = (long long)n_out;
+    if (aligned && in_kind != WFX_IN_F64_MONO && fix_shift >= 8 && fix_shift <= 40 && !getenv("WFX_FE_NO_EXACT")) {
+        // fixed-point taps; row r: E_hi[2 q4] E_lo[2 q4] D_hi[2 q4 + 2] D_lo[2 q4 + 2] as int16 pairs (E[p] = (c[2p], c[2p+1]) of the
+        // row's taps c[k] = coef[r + M k - d], D[p] = (c[2p-1], c[2p]))
+        const size_t rowlen = (size_t)8 * q4 + 4;
+        std::vector<int32_t> fix((size_t)M * 4 * q4, 0);
+        bool ok = true;
+        for (int j = 0; j < ntaps && ok; ++j) {
+            const double v = nearbyint(ldexp(coef[j], fix_shift));
+            if (!(fabs(v) < (double)(1 << 23))) ok = false;
+            else fix[(size_t)((j + d) % M) * 4 * q4 + (size_t)((j + d) / M)] = (int32_t)v;
+        }
+        // worst-case |sample| = 32768: the hi parts of ALL taps go into one int32 per output, the lo parts of flush_rows rows
+        const int half = 1 << (PP_FIX_LB - 1);
+        auto hi_of = [&](int32_t v) { return (v + half) >> PP_FIX_LB; };
+        auto lo_of = [&](int32_t v) { return v - (hi_of(v) << PP_FIX_LB); };
+        long long sum_hi = 0;
+        for (int32_t v : fix) sum_hi += llabs((long long)hi_of(v));
+        if (sum_hi * 32768 >= (1ll << 31)) ok = false;
+        int flush_rows = 0;
+        if (ok) {
+            // rows are split over thread groups only in powers of two: a flush interval that divides every group's row count
+            for (int fr = M; fr >= 1 && !flush_rows; fr >>= 1) {
+                bool fits = true;
+                for (int r0 = 0; r0 < M && fits; r0 += fr) {
+                    long long sl = 0;
+                    for (int r = r0; r < r0 + fr; ++r)
+                        for (int k = 0; k < 4 * q4; ++k) sl += llabs((long long)lo_of(fix[(size_t)r * 4 * q4 + k]));
+                    if (sl * 32768 >= (1ll << 31)) fits = false;
+                }
+                if (fits) flush_rows = fr;
+            }
+            if (!flush_rows) ok = false;
+        }
+        if (ok) {
+            std::vector<int32_t> tab((size_t)M * rowlen, 0);
+            auto pack = [](int a, int b) { return (int32_t)(((uint32_t)(uint16_t)(int16_t)a) | ((uint32_t)(uint16_t)(int16_t)b << 16)); };
+            for (int r = 0; r < M; ++r) {
+                const int32_t *c = &fix[(size_t)r * 4 * q4];
+                int32_t *row = &tab[(size_t)r * rowlen];
+                const int np = 2 * q4;
+                for (int p = 0; p < np; ++p) {
+                    row[p] = pack(hi_of(c[2 * p]), hi_of(c[2 * p + 1]));
+                    row[np + p] = pack(lo_of(c[2 * p]), lo_of(c[2 * p + 1]));
+                }
+                for (int p = 0; p <= np; ++p) {
+                    const int32_t a = p > 0 ? c[2 * p - 1] : 0, b = p < np ? c[2 * p] : 0;
+                    row[2 * np + p] = pack(hi_of(a), hi_of(b));
+                    row[3 * np + 2 + p] = pack(lo_of(a), lo_of(b));
+                }
+            }
+            const float *dtab = wfx_coef_device(ctx, (const float *)tab.data(), tab.size());
+            if (!dtab) return WFX_ERR_HIP;
+            if (exact_out) *exact_out = 1;
+            const int fr = flush_rows | (fix_shift << 8);
+            return in_kind == WFX_IN_I16_MONO ? launch_decimate64<WFX_IN_I16_MONO, 1>(ctx, in, ni, first, M, dtab, q4, out, no, true, fr)
+                                              : launch_decimate64<WFX_IN_I16_STEREO, 1>(ctx, in, ni, first, M, dtab, q4, out, no, true, fr);
+        }
+    }
+    std::vector<double> cp((size_t)M * 4 * q4, 0.0);
+    for (int j = 0; j < ntaps; ++j) cp[(size_t)((j + d) % M) * 4 * q4 + (size_t)((j + d) / M)] = coef[j];
+    const float *dcoef = wfx_coef_device(ctx, (const float *)cp.data(), cp.size() * 2);
+    if (!dcoef) return WFX_ERR_HIP;
+    switch (in_kind) {
+    case WFX_IN_I16_MONO: return launch_decimate64<WFX_IN_I16_MONO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0);
+    case WFX_IN_I16_STEREO: return launch_decimate64<WFX_IN_I16_STEREO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0);
+    default: return launch_decimate64<WFX_IN_F64_MONO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0);
+    }
 }
 
 int wfx_dev_resample_rational(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t base0, int p, int q, const float *table,

@@ -38,6 +38,7 @@ TARGET_RATE = 11025
 # bytes differ by 1 and 9 pixels by 2; 105 dB: 276 / 1; 120 dB: 45 / 1; 135 dB: 19 / 0 (image max |delta| 1); 150 dB: 16 / 0, where
 # fp32 accumulation is the floor and the first stage turns compute-bound (+1.9 ms on the 60-minute stream against +0.5 ms at 135).
 DEFAULT_ATT_DB = 135.0
+LOW_RATE_ATT_DB = 160.0      # Kaiser stages at <= 192 kHz of the float64 chains (FrontEnd._finish)
 NYQ = TARGET_RATE / 2.0          # 5512.5 Hz: everything the reference's brick wall keeps
 
 
@@ -92,6 +93,38 @@ def ls_fir(n: int, fs: float, bands, desired, weights, grid: int = 400, iters: i
     return np.concatenate([x[:0:-1], x])
 
 
+FIX_LB = 12             # csrc/wfx_polyphase.hip PP_FIX_LB: a fixed-point tap is hi * 2**12 + lo, two int16 halves
+
+
+def fix_shift_for(h: np.ndarray) -> int:
+    """The finest grid 2**-s the integer-exact stencil (csrc/wfx_polyphase.hip MODE 1) takes these taps on: every tap below 2**23
+    steps, and the high halves of all taps together below 2**16 -- times the largest int16 sample that still fits the kernel's
+    one int32 accumulator per output.  0: none (the float64 form runs instead)."""
+    h = np.asarray(h, dtype=np.float64)
+    for s in range(30, 15, -1):
+        v = np.rint(np.ldexp(h, s))
+        hi = np.floor((v + (1 << (FIX_LB - 1))) / (1 << FIX_LB))
+        if np.max(np.abs(v)) < (1 << 23) - 2 and np.sum(np.abs(hi)) + h.shape[0] < 0.98 * (1 << 16):
+            return s
+    return 0
+
+
+def quantize_taps(h: np.ndarray, shift: int) -> np.ndarray:
+    """Taps rounded to multiples of 2**-shift with first-order error feedback: the rounding error of one tap is carried into
+    the next, so the error sequence is a first difference and its spectrum vanishes at DC -- across 0..5512.5 Hz of a 1.536 MS/s
+    filter the response moves by 2e-10 instead of the 2e-8 plain rounding costs (the stop bands lose 1 dB at -132).  The sum of
+    the taps is kept exactly."""
+    out = np.empty(h.shape[0], dtype=np.float64)
+    e = 0.0
+    sc = float(1 << shift)
+    for k, v in enumerate(np.asarray(h, dtype=np.float64)):
+        t = v * sc + e
+        r = np.rint(t)
+        e = t - r
+        out[k] = r / sc
+    return out
+
+
 class Decimate:
     """y[k] = sum_j c[j] x[k*M - centre + j]: low-pass + keep every M-th sample."""
     kind = "decimate"
@@ -108,9 +141,12 @@ class Decimate:
         self.coef = self.coef64.astype(np.float32)
         self.ntaps = n
 
-    def set_taps(self, h: np.ndarray):
+    fix_shift = 0            # > 0: coef64 lies on the grid 2**-fix_shift (integer-exact ingest)
+
+    def set_taps(self, h: np.ndarray, fix_shift: int = 0):
         """Replace the Kaiser design by another odd-length symmetric one (same stage geometry otherwise)."""
         assert h.shape[0] % 2 == 1
+        self.fix_shift = fix_shift
         self.ntaps = int(h.shape[0])
         self.centre = (self.ntaps - 1) // 2
         self.coef64 = np.asarray(h, dtype=np.float64)
@@ -189,6 +225,7 @@ class FrontEnd:
                 # 0..5512.5 Hz matters)
                 self.stages.append(Decimate(fs, int(fs / self.out_rate), NYQ, float(self.out_rate) - NYQ, att_db))
                 self._multiband_pair()
+                self._finish()
                 return
         if fs != mid:
             st = Rational(fs, mid, NYQ, float(min(fs, mid)) - NYQ, att_db)
@@ -198,10 +235,37 @@ class FrontEnd:
         if self.exact_tail:
             if mid != self.out_rate:
                 self.stages.append(Decimate(mid, int(mid / self.out_rate), NYQ, float(self.out_rate) - NYQ, att_db))
+            self._finish()
         else:
             # the last /4 in two halves, so that the sharp filter runs at half the rate with half the taps
             self.stages.append(Decimate(mid, 2, NYQ, float(mid / 2) - NYQ, att_db))
             self.stages.append(Decimate(mid / 2, 2, pass_hz, NYQ, att_db))
+
+    f64 = False
+
+    def _finish(self):
+        """A chain of decimations only (every hand-over at 16 000 Hz) runs in float64 end to end: the first stage -- int16 samples, a
+        power-of-two factor -- as an integer-exact dot product with taps on the grid 2**-27 (``quantize_taps``; csrc/wfx_polyphase.hip
+        MODE 1), the stages behind it with float64 taps and sums.  What reaches the exact path then differs from an ideal filter
+        by the designs' own error alone -- no fp32 rounding of samples or sums, which is what flipped 5-30 stream bytes per clip in
+        round 2 (a float64 model of the same chain flips none).  ``f64`` tells FrontEndDevice which entry points to use."""
+        if os.environ.get("WFX_FE_FP32") == "1" or any(st.kind != "decimate" for st in self.stages):
+            return
+        self.f64 = True
+        if self.design is None:
+            # Kaiser designs at the low rates (48 kHz: /3; 192 kHz: /4, /3): their pass-band ripple 10**(-att/20) = 1.8e-7 is now the
+            # largest error left (4-9 flipped stream bytes per 48 kHz clip in float64 arithmetic); 160 dB costs a fifth more taps
+            # where taps are cheap
+            for k, st in enumerate(self.stages):
+                if float(st.fs_in) <= 200e3 and self.att_db < LOW_RATE_ATT_DB:
+                    self.stages[k] = Decimate(st.fs_in, st.factor, NYQ, float(st.fs_out) - NYQ, LOW_RATE_ATT_DB)
+        for st in self.stages:
+            st.f64_chain = True
+        s0 = self.stages[0]
+        if s0.factor & (s0.factor - 1) == 0 and s0.factor >= 4 and not s0.fix_shift:
+            sh = fix_shift_for(s0.coef64)            # (the least-squares pair quantised its first filter before designing the second)
+            if sh:
+                s0.set_taps(quantize_taps(s0.coef64, sh), sh)
 
     def _multiband_pair(self):
         """[ /M, /k ] with a large M (the ingest of an oversampled stream): the first filter only has to reject what folds into
@@ -218,18 +282,22 @@ class FrontEnd:
             return
         key = (self.fs_in, s1.factor, s2.factor, self.att_db)
         if key in _PAIR_CACHE:                       # (two least-squares solves: 2 s)
-            h1, h2, self.design = _PAIR_CACHE[key]
+            h1, h2, self.design, sh1 = _PAIR_CACHE[key]
             if h1 is not None:
-                s1.set_taps(h1)
+                s1.set_taps(h1, sh1)
                 s2.set_taps(h2)
             return
-        _PAIR_CACHE[key] = (None, None, None)
+        _PAIR_CACHE[key] = (None, None, None, 0)
         fs1, fo1 = float(s1.fs_in), float(s1.fs_out)
         stops = [(k * fo1 - NYQ, min(k * fo1 + NYQ, fs1 / 2)) for k in range(1, int(fs1 / 2 // fo1) + 1) if k * fo1 - NYQ < fs1 / 2]
         h1 = ls_fir(n1, fs1, [(0.0, NYQ)] + stops, [1.0] + [0.0] * len(stops), [1.0] + [30.0] * len(stops))
         h1 /= h1.sum()
+        sh1 = fix_shift_for(h1)
+        if sh1:
+            h1 = quantize_taps(h1, sh1)              # what the integer-exact kernel applies; the second filter is designed against THIS response
         fs2, fo2 = float(s2.fs_in), float(s2.fs_out)
-        n2 = (s2.ntaps + 8) | 1                      # a few more taps than the plain low-pass: the pass band now has a shape to follow
+        n2 = (s2.ntaps + 32) | 1                     # more taps than the plain low-pass: the pass band has a shape to follow, and at 119
+        #                                              taps the PAIR is flat to 3e-10 (95 taps: 2e-8, which still flipped 0-3 stream bytes per clip)
         h2 = ls_fir(n2, fs2, [(0.0, NYQ), (fo2 - NYQ, fs2 / 2)], [lambda f: 1.0 / _response(h1, fs1, f), 0.0], [1.0, 1.0], grid=1200, iters=14)
         # verify before adopting
         fp = np.linspace(0.0, NYQ, 3000)
@@ -238,10 +306,10 @@ class FrontEnd:
         stop2 = np.abs(_response(h2, fs2, np.linspace(fo2 - NYQ, fs2 / 2, 4000))).max()
         flat = np.max(np.abs(_response(h1, fs1, fp) * _response(h2, fs2, fp) - 1.0))
         if stop1 <= 2.0 * tol and stop2 <= tol and flat <= tol:
-            s1.set_taps(h1)
+            s1.set_taps(h1, sh1)
             s2.set_taps(h2)
             self.design = {"stage1_stop_db": float(20 * np.log10(stop1)), "stage2_stop_db": float(20 * np.log10(stop2)), "pair_flatness": float(flat)}
-            _PAIR_CACHE[key] = (h1, h2, self.design)
+            _PAIR_CACHE[key] = (h1, h2, self.design, sh1)
 
     @staticmethod
     def handover_rate(fs_in: int) -> int:

@@ -37,11 +37,19 @@ _MAGIC = b"WFXUID01"
 PORT_SPAN = 16        # rank 0 listens on the first free port of [port, port + PORT_SPAN); the others probe the range
 
 
+def _nonce16(nonce) -> bytes:
+    import hashlib
+    return hashlib.sha256(str(nonce).encode()).digest()[:16]
+
+
 def bootstrap_unique_id(rank: int, world: int, addr: str = "127.0.0.1", port: int = 29611, timeout: float = 120.0,
-                        make_id=nat.comm_unique_id) -> bytes:
+                        make_id=nat.comm_unique_id, nonce="") -> bytes:
     """Rank 0 creates the RCCL unique id and serves it to the other ``world - 1`` ranks; they fetch it.
     Plain TCP on ``addr`` (stdlib only).  Rank 0 takes the first port of [port, port + 16) it can bind; the peers probe
-    that range until something answers with the protocol's magic, so a port that another program holds is skipped."""
+    that range until something answers with the protocol's magic AND the job's ``nonce`` (any string the ranks of one job
+    share: two decodes on one host do not serve each other's peers), so a port that another program -- or another job --
+    holds is skipped.  A rank is counted once, whatever it claims to be."""
+    tag = _nonce16(nonce)
     if world == 1:
         return make_id()
     if rank == 0:
@@ -67,13 +75,14 @@ def bootstrap_unique_id(rank: int, world: int, addr: str = "127.0.0.1", port: in
                 with conn:
                     conn.settimeout(10.0)
                     try:
-                        hello = _recv_exact(conn, len(_MAGIC) + 4)
+                        hello = _recv_exact(conn, len(_MAGIC) + 4 + 16)
                     except OSError:
                         continue
-                    if hello[:len(_MAGIC)] != _MAGIC:
+                    peer = struct.unpack("<i", hello[len(_MAGIC):len(_MAGIC) + 4])[0]
+                    if hello[:len(_MAGIC)] != _MAGIC or hello[len(_MAGIC) + 4:] != tag or not 0 < peer < world:
                         continue                      # not one of ours
-                    conn.sendall(_MAGIC + uid)
-                    served.add(struct.unpack("<i", hello[len(_MAGIC):])[0])
+                    conn.sendall(_MAGIC + tag + uid)
+                    served.add(peer)
         except socket.timeout:
             raise nat.NativeError(f"rank 0: only {len(served)} of {world - 1} ranks fetched the RCCL unique id within {timeout} s")
         finally:
@@ -86,10 +95,10 @@ def bootstrap_unique_id(rank: int, world: int, addr: str = "127.0.0.1", port: in
             try:
                 with socket.create_connection((addr, port + k), timeout=2.0) as conn:
                     conn.settimeout(10.0)
-                    conn.sendall(_MAGIC + struct.pack("<i", rank))
-                    blob = _recv_exact(conn, len(_MAGIC) + nat.WFX_COMM_ID_BYTES)
-                    if blob[:len(_MAGIC)] == _MAGIC:
-                        return blob[len(_MAGIC):]
+                    conn.sendall(_MAGIC + struct.pack("<i", rank) + tag)
+                    blob = _recv_exact(conn, len(_MAGIC) + 16 + nat.WFX_COMM_ID_BYTES)
+                    if blob[:len(_MAGIC)] == _MAGIC and blob[len(_MAGIC):len(_MAGIC) + 16] == tag:
+                        return blob[len(_MAGIC) + 16:]
             except OSError as e:
                 last = e
         time.sleep(0.05)
@@ -247,8 +256,11 @@ class FrontEndDevice:
         self.n_out = b - a
         self.p_out = self._alloc(8 * self.n_out)
         self.p_stage = {}
+        # a chain of decimations runs in float64 throughout (integer-exact ingest, polyphase.FrontEnd._finish)
+        self.f64 = all(st.kind == "decimate" for st, _, _ in chain) and bool(getattr(chain[0][0], "f64_chain", False))
         for k, (st, (a, b), _) in enumerate(chain[:-1]):
-            self.p_stage[k] = self._alloc(4 * (b - a))
+            self.p_stage[k] = self._alloc((8 if self.f64 else 4) * (b - a))
+        self.exact_ingest = None
 
     def _alloc(self, nbytes):
         p = self.ctx.dev_malloc(nbytes)
@@ -263,6 +275,12 @@ class FrontEndDevice:
             last = k == len(self.chain) - 1
             n_out = b - a
             out = self.p_out if last else self.p_stage[k]
+            if st.kind == "decimate" and self.f64:
+                ex = self.ctx.d_decimate_fir64(cur, kind, n_cur, 0, st.factor, st.coef64, out, n_out, st.fix_shift if k == 0 else 0)
+                if k == 0:
+                    self.exact_ingest = ex
+                cur, kind, n_cur = out, nat.WFX_IN_F64_MONO, n_out
+                continue
             if st.kind == "decimate":
                 self.ctx.d_decimate_fir(cur, kind, n_cur, 0, st.factor, st.coef, out, last, n_out)
             else:
