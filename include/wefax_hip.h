@@ -46,7 +46,8 @@ typedef enum {
 /* how the analytic signal (scipy.signal.hilbert, wefax.py:174) is computed */
 typedef enum {
     WFX_HILBERT_FFT = 0,    /* exact: circular convolution with ifft(h) (mixed-radix N/2-point or zero-padded power-of-two transforms) */
-    WFX_HILBERT_FIR = 1,    /* sliding-window circular FIR with `fir_taps` taps       */
+    /* 1 was WFX_HILBERT_FIR (rounds 1-2): a truncated sliding-window FIR.  It cannot stay within one grey level of the
+     * reference's global FFT on noisy captures and no product path used it: removed in round 3. */
     WFX_HILBERT_BLUESTEIN = 2, /* exact, literal fft -> h -> ifft via two Bluestein DFTs (cross-check) */
     WFX_HILBERT_FFT_POW2 = 3  /* exact, like WFX_HILBERT_FFT but always the zero-padded power-of-two form
                                  (WFX_HILBERT_FFT picks the unpadded mixed-radix form when N/2 is 13-smooth) */
@@ -80,8 +81,7 @@ int wfx_notch_filtfilt_ext(wfx_ctx *ctx, const void *in, int in_kind, size_t n, 
                            const double ext_left[9], const double ext_right[9], double *out);
 
 /* a7  wefax.py:166-183 __demodulate: medfilt(abs(hilbert(x)), 5) */
-int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode,
-                     int fir_taps, double *env_out);
+int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode, double *env_out);
 
 /* a8  wefax.py:196 np.percentile: exact order statistics sorted(env)[rank[i]] */
 int wfx_order_stats(wfx_ctx *ctx, const double *env, size_t n,
@@ -138,7 +138,7 @@ typedef struct {
     double   notch_b[3];       /* scipy.signal.iirnotch(2600, 1, 11025)           */
     double   notch_a[3];
     int      hilbert_mode;     /* wfx_hilbert_mode                                */
-    int      fir_taps;         /* odd; used when hilbert_mode == WFX_HILBERT_FIR  */
+    int      reserved0;        /* (was fir_taps)                                  */
     /* np.percentile(., (0.5, 99.5)) 'linear': rank pairs and lerp weights        */
     uint64_t rank_lo[2];
     uint64_t rank_hi[2];
@@ -283,8 +283,6 @@ int wfx_d_resample_rational(wfx_ctx *ctx, const void *in_dev, int in_kind, size_
  * (*exact = 0): |error| <= ntaps * 2^-53 * sum |coef * in|. */
 int wfx_d_decimate_fir64(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const double *coef,
                          int ntaps, double *out_dev, size_t n_out, int fix_shift, int *exact);
-/* a7: |x + i H| with the `taps`-lag circular Hilbert kernel of a signal of n_global samples; valid (taps-1)/2 away from the ends */
-int wfx_d_fir_envelope(wfx_ctx *ctx, const double *x_dev, size_t n, size_t n_global, int taps, double *env_raw_dev);
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev);
 /* a8: one level of the radix select: hist_dev[q*2048 + digit] += count over values whose bits above the level equal prefix[q] */
 int wfx_d_select_hist(wfx_ctx *ctx, const double *env_dev, size_t n, int level, const uint64_t prefix[4], uint32_t *hist_dev);

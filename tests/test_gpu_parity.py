@@ -209,19 +209,6 @@ def test_any_even_length_takes_the_smooth_padded_form(ctx, n):
     assert m == 0 or n - 1 <= m <= (n - 1) * 1.09
 
 
-def test_analytic_envelope_fir_mode_converges(ctx):
-    """The FIR kernel approaches the exact operator as taps grow (clean narrow-band input)."""
-    from oracle import wefax_oracle as wo
-    from wefax_amd import _native as nat
-    n = 220500
-    t = np.arange(n)
-    x = 8000 * np.sin(2 * np.pi * 1900 / 11025 * t + 3 * np.sin(2 * np.pi * t / 700.0))
-    ref = wo.demodulate(x)
-    errs = [_rel(ctx.analytic_env(x, nat.WFX_HILBERT_FIR, taps), ref) for taps in (255, 1023, 4095)]
-    assert errs[0] > errs[1] > errs[2]
-    assert errs[2] < 2e-3
-
-
 @pytest.mark.parametrize("n0,num", [(48000, 11025), (8000, 11025), (1000, 999), (999, 1000),
                                     (44100, 11025), (12345, 2836), (100, 137), (4097, 8194)])
 def test_resample(ctx, n0, num):

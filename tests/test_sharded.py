@@ -62,9 +62,9 @@ def test_captures_that_cannot_be_sharded_are_refused_with_a_reason():
     p, _ = build_params(0, 1433250, 11025, 0.5)
     with pytest.raises(nat.NativeError):
         nat.shard_layout(p, 2, 2)                                       # rank out of range
-    p.hilbert_mode = nat.WFX_HILBERT_FIR
+    p.hilbert_mode = nat.WFX_HILBERT_BLUESTEIN
     with pytest.raises(nat.NativeError):
-        nat.shard_layout(p, 2, 0)                                       # the exact mode only
+        nat.shard_layout(p, 2, 0)                                       # the convolution form only
 
 
 def _free_port():

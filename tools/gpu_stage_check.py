@@ -53,9 +53,6 @@ def main():
             print(f" notch rel err {rel(au, ref['audio']):.3e}  edges {rel(au[:80], ref['audio'][:80]):.3e} {rel(au[-80:], ref['audio'][-80:]):.3e}")
             env = ctx.analytic_env(ref["audio"])
             print(f" env(fft) rel err {rel(env, ref['demod']):.3e}")
-            for taps in (1023, 4095):
-                envf = ctx.analytic_env(ref["audio"], nat.WFX_HILBERT_FIR, taps)
-                print(f" env(fir {taps}) rel err {rel(envf, ref['demod']):.3e}")
             n = len(ref["demod"])
             ranks = [hp.percentile_plan(n, 0.5)[0], hp.percentile_plan(n, 0.5)[1],
                      hp.percentile_plan(n, 99.5)[0], hp.percentile_plan(n, 99.5)[1], 0, n - 1]

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WFX_LIB") or os.path.join(_HERE, "libwefax_hip.so")     # WFX_LIB: another build of the library (A/B runs)
 
 WFX_IN_I16_MONO, WFX_IN_I16_STEREO, WFX_IN_F64_MONO, WFX_IN_F32_MONO = 0, 1, 2, 3
-WFX_HILBERT_FFT, WFX_HILBERT_FIR, WFX_HILBERT_BLUESTEIN, WFX_HILBERT_FFT_POW2 = 0, 1, 2, 3
+WFX_HILBERT_FFT, WFX_HILBERT_BLUESTEIN, WFX_HILBERT_FFT_POW2 = 0, 2, 3      # (1 was the truncated FIR mode of rounds 1-2: removed)
 WFX_BUF_AUDIO, WFX_BUF_ENVELOPE, WFX_BUF_DIGITAL, WFX_BUF_IMAGE = 0, 1, 2, 3
 WFX_MAX_PEAKS = 100
 
@@ -28,7 +28,7 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_decimate_fir64", "wfx_d_resample_rational", "wfx_d_fir_envelope", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_decimate_fir64", "wfx_d_resample_rational", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
@@ -50,7 +50,7 @@ class DecodeParams(C.Structure):
         ("notch_b", C.c_double * 3),
         ("notch_a", C.c_double * 3),
         ("hilbert_mode", C.c_int),
-        ("fir_taps", C.c_int),
+        ("reserved0", C.c_int),
         ("rank_lo", C.c_uint64 * 2),
         ("rank_hi", C.c_uint64 * 2),
         ("gamma_lo", C.c_double),
@@ -149,7 +149,7 @@ def load():
     lib.wfx_resample.argtypes = [vp, vp, sz, sz, vp]
     lib.wfx_notch_filtfilt.argtypes = [vp, vp, i, sz, dp, dp, vp]
     lib.wfx_notch_filtfilt_ext.argtypes = [vp, vp, i, sz, dp, dp, dp, dp, vp]
-    lib.wfx_analytic_env.argtypes = [vp, vp, sz, i, i, vp]
+    lib.wfx_analytic_env.argtypes = [vp, vp, sz, i, vp]
     lib.wfx_order_stats.argtypes = [vp, vp, sz, vp, i, vp]
     lib.wfx_quantise.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, C.POINTER(C.c_uint64)]
     lib.wfx_sync_corr.argtypes = [vp, vp, sz, i, i, vp]
@@ -180,7 +180,6 @@ def load():
     lib.wfx_d_decimate_fir.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, i, sz]
     lib.wfx_d_decimate_fir64.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int)]
     lib.wfx_d_resample_rational.argtypes = [vp, vp, i, sz, C.c_int64, i, i, vp, i, C.c_int64, vp, sz]
-    lib.wfx_d_fir_envelope.argtypes = [vp, vp, sz, sz, i, vp]
     lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
     lib.wfx_d_select_hist.argtypes = [vp, vp, sz, i, C.POINTER(C.c_uint64), vp]
     lib.wfx_d_quantise.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, C.POINTER(C.c_uint64)]
@@ -316,10 +315,10 @@ class Context:
             self._check(self.lib.wfx_notch_filtfilt(self.h, _ptr(x), kind, x.shape[0], bb, aa, _ptr(out)))
         return out
 
-    def analytic_env(self, x: np.ndarray, mode: int = WFX_HILBERT_FFT, fir_taps: int = 4095) -> np.ndarray:
+    def analytic_env(self, x: np.ndarray, mode: int = WFX_HILBERT_FFT) -> np.ndarray:
         x = np.ascontiguousarray(x, dtype=np.float64)
         out = np.empty(x.shape[0], dtype=np.float64)
-        self._check(self.lib.wfx_analytic_env(self.h, _ptr(x), x.shape[0], mode, fir_taps, _ptr(out)))
+        self._check(self.lib.wfx_analytic_env(self.h, _ptr(x), x.shape[0], mode, _ptr(out)))
         return out
 
     def order_stats(self, env: np.ndarray, ranks) -> np.ndarray:
@@ -541,8 +540,6 @@ class Context:
         self._check(self.lib.wfx_d_resample_rational(self.h, C.c_void_p(in_ptr), in_kind, n_in, base0, p, q, _ptr(t), t.shape[1], m0,
                                                      C.c_void_p(out_ptr), n_out))
 
-    def d_fir_envelope(self, x_ptr: int, n: int, n_global: int, taps: int, out_ptr: int):
-        self._check(self.lib.wfx_d_fir_envelope(self.h, C.c_void_p(x_ptr), n, n_global, taps, C.c_void_p(out_ptr)))
 
     def d_median5(self, in_ptr: int, n: int, out_ptr: int):
         self._check(self.lib.wfx_d_median5(self.h, C.c_void_p(in_ptr), n, C.c_void_p(out_ptr)))

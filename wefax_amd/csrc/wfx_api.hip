@@ -100,15 +100,12 @@ int wfx_notch_filtfilt_ext(wfx_ctx *ctx, const void *in, int in_kind, size_t n, 
 }
 
 // ---- a7 ---------------------------------------------------------------------
-static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode, int taps, double *env_raw, double *env,
-                            unsigned *l0hist = nullptr)
+static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode, double *env_raw, double *env, unsigned *l0hist = nullptr)
 {
     if (mode == WFX_HILBERT_FFT || mode == WFX_HILBERT_FFT_POW2) {
         ctx->force_pow2 = mode == WFX_HILBERT_FFT_POW2;
         return wfx_dev_hilbert_envmed_fft(ctx, x, n, env, l0hist);
     }
-    else if (mode == WFX_HILBERT_FIR)
-        WFX_TRY(wfx_dev_hilbert_env_fir(ctx, x, n, taps, env_raw));
     else if (mode == WFX_HILBERT_BLUESTEIN)
         WFX_TRY(wfx_dev_hilbert_env_bluestein(ctx, x, n, env_raw));
     else
@@ -116,7 +113,7 @@ static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode,
     return wfx_dev_median5(ctx, env_raw, n, env, l0hist);
 }
 
-int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode, int fir_taps, double *env_out)
+int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode, double *env_out)
 {
     CHECK_CTX(ctx);
     if (!x || !env_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
@@ -126,8 +123,7 @@ int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode, 
     WFX_TRY(wfx_reserve(ctx, ctx->b_envraw, n * 8));
     WFX_TRY(wfx_reserve(ctx, ctx->b_env, n * 8 + 64));
     WFX_TRY(h2d(ctx, ctx->b_audio.p, x, n * 8));
-    WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, hilbert_mode, fir_taps, (double *)ctx->b_envraw.p,
-                             (double *)ctx->b_env.p));
+    WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, hilbert_mode, (double *)ctx->b_envraw.p, (double *)ctx->b_env.p));
     return d2h_sync(ctx, env_out, ctx->b_env.p, n * 8);
 }
 
@@ -254,8 +250,8 @@ static int check_params(wfx_ctx *ctx, const wfx_decode_params *p)
     if (p->width <= 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad line width");
     if (p->rank_lo[0] >= p->n || p->rank_lo[1] >= p->n || p->rank_hi[0] >= p->n || p->rank_hi[1] >= p->n)
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "percentile rank out of range");
-    if (p->hilbert_mode == WFX_HILBERT_FIR && (p->fir_taps < 3 || (p->fir_taps & 1) == 0))
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fir_taps must be odd and >= 3");
+    if (p->hilbert_mode != WFX_HILBERT_FFT && p->hilbert_mode != WFX_HILBERT_BLUESTEIN && p->hilbert_mode != WFX_HILBERT_FFT_POW2)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown hilbert mode %d", p->hilbert_mode);
     return 0;
 }
 
@@ -388,8 +384,7 @@ int wfx_decode_run(wfx_ctx *ctx)
     if (!cleared) WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
     unsigned *sel_ws = nullptr;
     WFX_TRY(wfx_dev_select_workspace(ctx, n, &sel_ws));           // level-0 histogram is fused into the envelope kernel
-    WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, p.hilbert_mode, p.fir_taps, (double *)ctx->b_envraw.p,
-                             (double *)ctx->b_env.p, sel_ws));
+    WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, p.hilbert_mode, (double *)ctx->b_envraw.p, (double *)ctx->b_env.p, sel_ws));
     const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
     WFX_TRY(wfx_dev_percentiles_fused(ctx, (const double *)ctx->b_env.p, n, ranks, p.gamma_lo, p.gamma_hi, ds));
     WFX_TRY(wfx_dev_quantise_corr(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, p.n1, p.n0_gap));   // a8 + correlation of a9
@@ -559,13 +554,6 @@ int wfx_d_resample_rational(wfx_ctx *ctx, const void *in_dev, int in_kind, size_
     CHECK_CTX(ctx);
     if (!in_dev || !out_dev || !table) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
     return wfx_dev_resample_rational(ctx, in_dev, in_kind, n_in, base0, p, q, table, taps, m0, out_dev, n_out);
-}
-
-int wfx_d_fir_envelope(wfx_ctx *ctx, const double *x_dev, size_t n, size_t n_global, int taps, double *env_raw_dev)
-{
-    CHECK_CTX(ctx);
-    if (!x_dev || !env_raw_dev || n == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null or empty buffer");
-    return wfx_dev_hilbert_env_fir(ctx, x_dev, n, taps, env_raw_dev, n_global);
 }
 
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev)

@@ -346,5 +346,3 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n);
 int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t count);
 int wfx_comm_allgather(wfx_comm *c, wfx_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank);
 
-// wfx_fir.hip
-int wfx_dev_hilbert_env_fir(wfx_ctx *ctx, const double *x, uint64_t n, int taps, double *env_raw, uint64_t n_global = 0);

@@ -234,13 +234,11 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
     // row index is uniform) -- as LDS broadcast reads, 16 bytes per lane, they cost the LDS pipe as much as the window reads
     // and the tap loop was LDS-bound -- and the next tile's first chunks are requested before the tap loop.  The short
     // stages behind it measure faster with the taps in LDS and without the prefetch.
-    constexpr bool SMEM = MODE == 1 || (MODE == 0 && PP_PAIRS && PP_TAPS_SMEM && ALIGNED), PF = PP_PREFETCH && ALIGNED;
+    constexpr bool SMEM = MODE == 1 || (MODE == 0 && PP_PAIRS && PP_TAPS_SMEM && ALIGNED), PF = PP_PREFETCH && (ALIGNED || MODE == 2);
     constexpr int ACCW = MODE ? 2 : (int)(sizeof(pp_acc_t) / sizeof(float));         // floats per partial sum
     // (MODE 1 / 2 reserve exactly the partial sums the row groups exchange: the ingest then fits four workgroups per CU)
     float *cl = psum + (MODE ? ((((1 << rs_log2) - 1) << log2qw) * 4) : PP_THREADS * 4) * ACCW;
-    if (MODE == 2) {
-        for (int i = t; i < M * 4 * q4; i += PP_THREADS) ((double *)cl)[i] = ((const double *)cp)[i];
-    } else if (!SMEM)
+    if (MODE == 0 && !SMEM)
         for (int i = t; i < M * (PP_PAIRS ? 8 * q4 + 4 : 4 * q4); i += PP_THREADS) cl[i] = cp[i];
     const float *cs = SMEM ? cp : cl;
     const long long ntiles = (n_out + tb - 1) >> log2tb;
@@ -403,22 +401,28 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
             double tot0 = 0, tot1 = 0, tot2 = 0, tot3 = 0;
             if (active) {
                 const int r0 = part * rows_per;
-                const double *cd = (const double *)cl;
+                const double *cd = (const double *)cp;            // taps by scalar loads from the table in memory (the row index is uniform)
                 for (int r = r0; r < r0 + rows_per; ++r) {
                     const S *row = xs + r * row_stride + 4 * g;
                     const double *c = cd + r * 4 * q4;
                     double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-                    double wa[4], wb[4];
+                    double wa[4], wb[4], wn[4];
                     pp_load4d(row, wa);
-#pragma unroll(Q4T ? Q4T : 1)
-                    for (int j = 0; j < (Q4T ? Q4T : q4); ++j) {
-                        const double c0 = c[4 * j], c1 = c[4 * j + 1], c2 = c[4 * j + 2], c3 = c[4 * j + 3];
-                        pp_load4d(row + 4 * j + 4, wb);
-                        acc0 = fma(c0, wa[0], acc0); acc1 = fma(c0, wa[1], acc1); acc2 = fma(c0, wa[2], acc2); acc3 = fma(c0, wa[3], acc3);
-                        acc0 = fma(c1, wa[1], acc0); acc1 = fma(c1, wa[2], acc1); acc2 = fma(c1, wa[3], acc2); acc3 = fma(c1, wb[0], acc3);
-                        acc0 = fma(c2, wa[2], acc0); acc1 = fma(c2, wa[3], acc1); acc2 = fma(c2, wb[0], acc2); acc3 = fma(c2, wb[1], acc3);
-                        acc0 = fma(c3, wa[3], acc0); acc1 = fma(c3, wb[0], acc1); acc2 = fma(c3, wb[1], acc2); acc3 = fma(c3, wb[2], acc3);
+                    pp_load4d(row + 4, wb);
+                    double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+                    for (int j = 0; j < q4; ++j) {
+                        // the window columns and taps of the NEXT group are requested before this group's 16 FMAs
+                        const double u0 = c0, u1 = c1, u2 = c2, u3 = c3;
+                        if (j + 1 < q4) {
+                            pp_load4d(row + 4 * j + 8, wn);
+                            c0 = c[4 * j + 4]; c1 = c[4 * j + 5]; c2 = c[4 * j + 6]; c3 = c[4 * j + 7];
+                        }
+                        acc0 = fma(u0, wa[0], acc0); acc1 = fma(u0, wa[1], acc1); acc2 = fma(u0, wa[2], acc2); acc3 = fma(u0, wa[3], acc3);
+                        acc0 = fma(u1, wa[1], acc0); acc1 = fma(u1, wa[2], acc1); acc2 = fma(u1, wa[3], acc2); acc3 = fma(u1, wb[0], acc3);
+                        acc0 = fma(u2, wa[2], acc0); acc1 = fma(u2, wa[3], acc1); acc2 = fma(u2, wb[0], acc2); acc3 = fma(u2, wb[1], acc3);
+                        acc0 = fma(u3, wa[3], acc0); acc1 = fma(u3, wb[0], acc1); acc2 = fma(u3, wb[1], acc2); acc3 = fma(u3, wb[2], acc3);
                         wa[0] = wb[0]; wa[1] = wb[1]; wa[2] = wb[2]; wa[3] = wb[3];
+                        wb[0] = wn[0]; wb[1] = wn[1]; wb[2] = wn[2]; wb[3] = wn[3];
                     }
                     tot0 += acc0; tot1 += acc1; tot2 += acc2; tot3 += acc3;
                 }
@@ -658,7 +662,7 @@ int launch_decimate64(wfx_ctx *ctx, const void *in, long long n_in, long long fi
     int rs_log2 = 8 - log2qw;
     if (rs_log2 > log2m) rs_log2 = log2m;
     if (rs_log2 < 0) rs_log2 = 0;
-    const size_t lds = lds_x + (size_t)((((1 << rs_log2) - 1) << log2qw) * 4) * 8 + (MODE == 2 ? (size_t)M * 4 * q4 * sizeof(double) : 0);
+    const size_t lds = lds_x + (size_t)((((1 << rs_log2) - 1) << log2qw) * 4) * 8;
     if (lds_x > (size_t)PP_LDS_BYTES || lds > 150 * 1024) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
     const int misalign = (int)(((uintptr_t)in & 15u) / A::BYTES);
     const long long ntiles = (n_out + tb - 1) / tb;

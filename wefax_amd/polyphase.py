@@ -38,7 +38,7 @@ TARGET_RATE = 11025
 # bytes differ by 1 and 9 pixels by 2; 105 dB: 276 / 1; 120 dB: 45 / 1; 135 dB: 19 / 0 (image max |delta| 1); 150 dB: 16 / 0, where
 # fp32 accumulation is the floor and the first stage turns compute-bound (+1.9 ms on the 60-minute stream against +0.5 ms at 135).
 DEFAULT_ATT_DB = 135.0
-LOW_RATE_ATT_DB = 160.0      # Kaiser stages at <= 192 kHz of the float64 chains (FrontEnd._finish)
+LOW_RATE_ATT_DB = 200.0      # Kaiser stages at <= 192 kHz of the float64 chains (FrontEnd._finish)
 NYQ = TARGET_RATE / 2.0          # 5512.5 Hz: everything the reference's brick wall keeps
 
 
@@ -93,6 +93,7 @@ def ls_fir(n: int, fs: float, bands, desired, weights, grid: int = 400, iters: i
     return np.concatenate([x[:0:-1], x])
 
 
+MIN_FIX_SHIFT = 26      # coarser grids than 2**-26 are not worth it: the float64 form runs instead
 FIX_LB = 12             # csrc/wfx_polyphase.hip PP_FIX_LB: a fixed-point tap is hi * 2**12 + lo, two int16 halves
 
 
@@ -254,8 +255,8 @@ class FrontEnd:
         self.f64 = True
         if self.design is None:
             # Kaiser designs at the low rates (48 kHz: /3; 192 kHz: /4, /3): their pass-band ripple 10**(-att/20) = 1.8e-7 is now the
-            # largest error left (4-9 flipped stream bytes per 48 kHz clip in float64 arithmetic); 160 dB costs a fifth more taps
-            # where taps are cheap
+            # largest error left (4-9 flipped stream bytes per 48 kHz clip in float64 arithmetic at 135 dB, 1-3 at 160 dB);
+            # 200 dB costs half as many taps again where taps are cheap
             for k, st in enumerate(self.stages):
                 if float(st.fs_in) <= 200e3 and self.att_db < LOW_RATE_ATT_DB:
                     self.stages[k] = Decimate(st.fs_in, st.factor, NYQ, float(st.fs_out) - NYQ, LOW_RATE_ATT_DB)
@@ -264,7 +265,9 @@ class FrontEnd:
         s0 = self.stages[0]
         if s0.factor & (s0.factor - 1) == 0 and s0.factor >= 4 and not s0.fix_shift:
             sh = fix_shift_for(s0.coef64)            # (the least-squares pair quantised its first filter before designing the second)
-            if sh:
+            # a filter with large taps (small factors: /4 at 192 kHz) only gets a coarse grid, and nothing behind it compensates:
+            # measured 11-12 flipped stream bytes per 192 kHz clip at 2**-24 -- such stages run in float64 instead (cheap there)
+            if sh >= MIN_FIX_SHIFT:
                 s0.set_taps(quantize_taps(s0.coef64, sh), sh)
 
     def _multiband_pair(self):
@@ -293,6 +296,8 @@ class FrontEnd:
         h1 = ls_fir(n1, fs1, [(0.0, NYQ)] + stops, [1.0] + [0.0] * len(stops), [1.0] + [30.0] * len(stops))
         h1 /= h1.sum()
         sh1 = fix_shift_for(h1)
+        if sh1 < MIN_FIX_SHIFT:
+            sh1 = 0
         if sh1:
             h1 = quantize_taps(h1, sh1)              # what the integer-exact kernel applies; the second filter is designed against THIS response
         fs2, fo2 = float(s2.fs_in), float(s2.fs_out)

@@ -182,6 +182,17 @@ class ShardedDecoder:
         self.shard.close()
 
 
+def layout_supported(n0: int, sample_rate, world: int, lines_per_minute: int = 120, kind: int = nat.WFX_IN_F64_MONO, n_out: int | None = None) -> bool:
+    """Whether the sharded exact path takes a capture of this description over ``world`` ranks (``wfx_shard_layout_query``
+    answers without a GPU)."""
+    p, _ = build_params(kind, int(n0), sample_rate, 1 / (lines_per_minute / 60), hp.DEFAULT_NOTCH, n_out=n_out)
+    try:
+        nat.shard_layout(p, world, 0)
+        return True
+    except nat.NativeError:
+        return False
+
+
 def _info_dict(info: nat.DecodeInfo) -> dict:
     return {"start_frame": int(info.start_frame), "height": int(info.height), "no_group": int(info.no_group),
             "npeaks": int(info.npeaks), "hit_limit": int(info.hit_limit), "nan_count": int(info.nan_count),
@@ -191,7 +202,7 @@ def _info_dict(info: nat.DecodeInfo) -> dict:
 
 
 def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute: int = 120, device: int = 0, notch=None,
-                    want=("image", "stream", "envelope", "audio"), make_decoder=None):
+                    want=("image", "stream", "envelope", "audio"), make_decoder=None, free_after=None):
     """Every rank of a ``world``-rank sharded decode in this process, on one GPU, phase by phase (local communicator:
     a collective completes when the last rank has posted its part).  Returns the root's results plus the per-rank
     blocks concatenated, for comparison with the single-GPU path (tests)."""
@@ -230,6 +241,8 @@ def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute:
     finally:
         for d in decs:
             d.close()
+        for c, ptr in (free_after or []):          # device memory the decoders' loaders allocated on the ranks' contexts
+            c.dev_free(ptr)
         for c in comms:
             c.close()
         for c in ctxs:

@@ -24,11 +24,10 @@ from . import _native as nat
 from . import hostparams as hp
 
 DEFAULT_HILBERT_MODE = nat.WFX_HILBERT_FFT
-DEFAULT_FIR_TAPS = 4095
 
 
 def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEFAULT_NOTCH,
-                 hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS, n_out: int | None = None):
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE, n_out: int | None = None):
     """The scalar arithmetic of the reference for a capture of ``n0`` frames at ``sample_rate`` (lengths, notch
     coefficients, percentile ranks and weights, sync constants) as the C ABI's ``wfx_decode_params``, plus the derived
     lengths.  Same expressions as wefax.py, evaluated in Python floats / NumPy scalars like there.
@@ -49,7 +48,7 @@ def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEF
     p.in_kind, p.n0, p.n, p.resample = kind, n0, n, int(resampled)
     p.notch_b[:] = [float(v) for v in b]
     p.notch_a[:] = [float(v) for v in a]
-    p.hilbert_mode, p.fir_taps = hilbert_mode, fir_taps
+    p.hilbert_mode = hilbert_mode
     lo0, lo1, glo = hp.percentile_plan(n, 0.5)                         # wefax.py:194-196
     hi0, hi1, ghi = hp.percentile_plan(n, 99.5)
     p.rank_lo[:] = [lo0, lo1]
@@ -108,14 +107,14 @@ class DecodeJob:
 
     def __init__(self, ctx: nat.Context, data: np.ndarray, sample_rate: int,
                  lines_per_minute: int = 120, notch=hp.DEFAULT_NOTCH,
-                 hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS):
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE):
         self.ctx = ctx
         self.frame_len = 1 / (lines_per_minute / 60)                       # wefax.py:33
         data = np.asarray(data)
         self.merged_on_host = False
         self._in_shape, self._in_dtype = tuple(data.shape), data.dtype
         data, kind, ext = self._host_form(data)
-        self._configure(kind, int(data.shape[0]), sample_rate, notch, hilbert_mode, fir_taps)
+        self._configure(kind, int(data.shape[0]), sample_rate, notch, hilbert_mode)
         if ext is not None and not self.resampled:
             self.params.has_ext = 1
             self.params.ext_left[:] = [float(v) for v in ext[0]]
@@ -145,9 +144,9 @@ class DecodeJob:
             kind = nat.WFX_IN_F64_MONO
         return data, kind, ext
 
-    def _configure(self, kind, n0, sample_rate, notch, hilbert_mode, fir_taps, n_out=None):
+    def _configure(self, kind, n0, sample_rate, notch, hilbert_mode, n_out=None):
         """The scalar arithmetic of the reference (lengths, notch, percentile ranks, sync constants) -> self.params."""
-        p, meta = build_params(kind, n0, sample_rate, self.frame_len, notch, hilbert_mode, fir_taps, n_out)
+        p, meta = build_params(kind, n0, sample_rate, self.frame_len, notch, hilbert_mode, n_out)
         self.input_length, self.resampled = meta["input_length"], meta["resampled"]
         self.n0, self.n = n0, meta["n"]
         self.sample_rate = hp.TARGET_RATE
@@ -157,7 +156,7 @@ class DecodeJob:
 
     @classmethod
     def from_device(cls, ctx: nat.Context, dev_ptr: int, n: int, lines_per_minute: int = 120, notch=hp.DEFAULT_NOTCH,
-                    hilbert_mode: int = DEFAULT_HILBERT_MODE, fir_taps: int = DEFAULT_FIR_TAPS, sample_rate: int = hp.TARGET_RATE,
+                    hilbert_mode: int = DEFAULT_HILBERT_MODE, sample_rate: int = hp.TARGET_RATE,
                     n_out: int | None = None):
         """Decode ``n`` float64 samples at ``sample_rate`` (11 025 Hz, or a rate the exact resampler brings there) that
         already sit in device memory (e.g. the output of the time-domain front end, wefax_amd/polyphase.py): the same
@@ -167,7 +166,7 @@ class DecodeJob:
         job.frame_len = 1 / (lines_per_minute / 60)
         job.merged_on_host = False
         job._in_shape = job._in_dtype = None
-        job._configure(nat.WFX_IN_F64_MONO, int(n), sample_rate, notch, hilbert_mode, fir_taps, n_out)
+        job._configure(nat.WFX_IN_F64_MONO, int(n), sample_rate, notch, hilbert_mode, n_out)
         ctx.decode_attach(int(dev_ptr), job.params)
         job.info = None
         return job
@@ -219,8 +218,7 @@ class Demodulator:
                  quiet: bool = False,
                  tcp_stream: bool = True,
                  device: int | None = None,
-                 hilbert_mode: int = DEFAULT_HILBERT_MODE,
-                 fir_taps: int = DEFAULT_FIR_TAPS):
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE):
         if not os.path.exists(filepath):                                   # wefax.py:24-25
             raise Exception(f"INVALID FILE: file at path: {filepath} does not exist")
         if filepath.split('.')[-1] != 'wav':                               # wefax.py:27-28
@@ -234,7 +232,6 @@ class Demodulator:
         self.websocket_stack = []
         self._device = _device_index(device)
         self._hilbert_mode = hilbert_mode
-        self._fir_taps = fir_taps
         self._ctx = None
         self._job = None
         self._cache = {}
@@ -285,7 +282,7 @@ class Demodulator:
             self._ctx = _acquire_context(self._device)
         notch = hp.load_notch_settings()
         job = DecodeJob(self._ctx, data, sample_rate, self.lines_per_minute, notch,
-                        self._hilbert_mode, self._fir_taps)
+                        self._hilbert_mode)
         self._job = job
         job.run()
         info = job.result()
