@@ -317,6 +317,16 @@ typedef struct wfx_shard wfx_shard;
 int wfx_comm_unique_id(void *id_out /* WFX_COMM_ID_BYTES */);
 int wfx_comm_create(wfx_ctx *ctx, const void *id, int world, int rank, wfx_comm **out);
 int wfx_comm_create_local(int world, wfx_comm **out /* [world] */);
+/* Third transport: one PROCESS per rank on one host, messages staged through POSIX shared memory (/dev/shm/wfx_<job>_*), two
+ * barriers per collective.  For boxes where RCCL cannot run the job (several ranks on ONE GPU) and for tests: real processes,
+ * contexts and streams, ranks out of step with each other.  `job`: a name the ranks of one job share (letters, digits, '-',
+ * '.'); rank 0 creates the control block, the others wait for it up to timeout_s.  ctx may be NULL: the collectives then move
+ * HOST memory (protocol tests on a machine without a GPU).  A peer that dies, or disagrees about a message, is WFX_ERR_COMM
+ * on every rank within timeout_s. */
+int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, double timeout_s, wfx_comm **out);
+/* `rounds` rounds of randomised exchanges / all-reduces / all-gathers with known answers and random pauses (every rank derives
+ * the same plan from `seed`); RCCL or shm communicators; device buffers, or host buffers when ctx is NULL (shm only) */
+int wfx_comm_selftest(wfx_comm *comm, wfx_ctx *ctx, int rounds, uint64_t seed);
 int wfx_comm_info(wfx_comm *comm, int *world, int *rank, int *is_rccl);
 int wfx_comm_destroy(wfx_comm *comm);
 /* for drivers: wait until every rank has arrived (and this rank's stream is idle); gather `bytes` host bytes of every rank

@@ -1,0 +1,202 @@
+"""The shared-memory communicator (include/wefax_hip.h wfx_comm_create_shm): one PROCESS per rank, messages staged through
+/dev/shm.  CPU tests drive the protocol with host buffers (no GPU: ctx = NULL); GPU tests run the same collectives on device
+buffers and the whole sharded decode with several real processes on ONE GPU -- separate address spaces, contexts and streams,
+ranks that reach a phase at different times: what the in-process emulation (lock-step by construction) cannot show."""
+import multiprocessing as mp
+import os
+import secrets
+import time
+
+import numpy as np
+import pytest
+
+from wefax_amd import _native as nat
+
+
+def _job():
+    return "t" + secrets.token_hex(6)
+
+
+def _selftest_worker(job, world, rank, rounds, seed, q, device):
+    try:
+        ctx = nat.Context(device) if device is not None else None
+        comm = nat.Comm.shm(ctx, job, world, rank, timeout=60.0)
+        comm.selftest(ctx, rounds, seed)
+        comm.barrier(ctx)
+        comm.close()
+        if ctx is not None:
+            ctx.close()
+        q.put((rank, "ok"))
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}"))
+
+
+def _run(world, target, args_of, timeout=120):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=args_of(r) + (q,)) for r in range(world)]
+    # the ranks start out of order and apart in time
+    for r in reversed(range(world)):
+        procs[r].start()
+        time.sleep(0.05)
+    out = {}
+    for _ in range(world):
+        r, msg = q.get(timeout=timeout)
+        out[r] = msg
+    for p in procs:
+        p.join(30)
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_randomised_collectives_between_processes_host_memory(world):
+    job = _job()
+    out = _run(world, _selftest_worker_q, lambda r: (job, world, r, 12, 1234 + world, None))
+    assert out == {r: "ok" for r in range(world)}
+    assert not [f for f in os.listdir("/dev/shm") if job in f]              # the ranks cleaned up after themselves
+
+
+def _selftest_worker_q(job, world, rank, rounds, seed, device, q):
+    _selftest_worker(job, world, rank, rounds, seed, q, device)
+
+
+def _dying_worker(job, world, rank, q):
+    try:
+        comm = nat.Comm.shm(None, job, world, rank, timeout=3.0)
+        if rank == 1:
+            os._exit(17)                                                     # dies after the rendezvous, before the first collective
+        comm.selftest(None, 4, 7)
+        q.put((rank, "ok"))
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}"))
+
+
+def test_a_rank_that_dies_is_an_error_on_the_others_not_a_hang():
+    job = _job()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dying_worker, args=(job, 3, r, q)) for r in range(3)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs:
+        p.join(30)
+    assert time.time() - t0 < 40
+    assert set(got) == {0, 2} and all("NativeError" in m and ("timed out" in m or "peer" in m) for m in got.values()), got
+    for f in os.listdir("/dev/shm"):
+        if job in f:
+            os.unlink(os.path.join("/dev/shm", f))
+
+
+def _disagree_worker(job, rank, q):
+    """Rank 0 runs the selftest with one seed, rank 1 with another: their exchange plans differ."""
+    try:
+        comm = nat.Comm.shm(None, job, 2, rank, timeout=5.0)
+        comm.selftest(None, 3, 100 + rank)
+        q.put((rank, "ok"))
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}"))
+
+
+def test_ranks_that_disagree_about_a_message_fail_loudly():
+    job = _job()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_disagree_worker, args=(job, r, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs:
+        p.join(30)
+    assert all("NativeError" in m for m in got.values()), got
+    assert any("bytes" in m or "messages" in m or "wrong" in m or "expected" in m for m in got.values()), got
+    for f in os.listdir("/dev/shm"):
+        if job in f:
+            os.unlink(os.path.join("/dev/shm", f))
+
+
+def test_bad_arguments():
+    with pytest.raises(nat.NativeError, match="job name"):
+        nat.Comm.shm(None, "no/slash", 1, 0)
+    with pytest.raises(nat.NativeError, match="bad rank"):
+        nat.Comm.shm(None, _job(), 2, 2)
+    with pytest.raises(nat.NativeError, match="never created"):
+        nat.Comm.shm(None, _job(), 2, 1, timeout=0.3)
+    c = nat.Comm.shm(None, _job(), 1, 0)
+    c.selftest(None, 3, 5)
+    assert (c.world, c.rank, c.is_rccl) == (1, 0, False)
+    c.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU: several processes on one device
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_randomised_collectives_between_processes_device_memory(world):
+    job = _job()
+    out = _run(world, _selftest_worker_q, lambda r: (job, world, r, 8, 99 + world, 0), timeout=300)
+    assert out == {r: "ok" for r in range(world)}
+
+
+def _decode_worker(job, world, rank, seed, rate, lpm, out_dir, q):
+    """One rank of a sharded decode in its own process: own context, own slice of the capture, the shm transport."""
+    try:
+        from wefax_amd import sharded, synth
+        x = _capture(rate, seed, lpm)
+        ctx = nat.Context(0)
+        comm = nat.Comm.shm(ctx, job, world, rank, timeout=120.0)
+        time.sleep(0.02 * ((rank * 7) % 5))                                 # the ranks drift apart
+        dec = sharded.ShardedDecoder(ctx, comm, x.shape[0], rate, lpm, sharded.capture_kind(x), data=x)
+        for rep in range(3):                                                 # buffers are reused decode after decode
+            dec.run()
+            if rank % 2 == rep % 2:
+                time.sleep(0.01)
+        info = dec.result()
+        np.save(os.path.join(out_dir, f"env{rank}.npy"), dec.fetch("envelope"))
+        if rank == 0:
+            np.save(os.path.join(out_dir, "stream.npy"), dec.fetch("stream"))
+            np.save(os.path.join(out_dir, "image.npy"), dec.fetch("image"))
+            np.save(os.path.join(out_dir, "sync.npy"), np.array([info.start_frame, info.height, info.npeaks]))
+        comm.barrier(ctx)
+        dec.close()
+        comm.close()
+        ctx.close()
+        q.put((rank, "ok"))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+
+
+def _capture(rate, seed, lpm):
+    from wefax_amd import synth
+    n_lines = {120: 70, 240: 148}[lpm]             # whole seconds: lengths with 13-smooth halves (what the distributed transforms take)
+    x = synth.synth_capture(float(rate), noise=0.05, seed=seed, lpm=lpm, start_tone_s=1.0, phasing_lines=40 if lpm == 240 else 20,
+                            image_lines=n_lines, stop_tone_s=1.0, black_tail_s=1.0)
+    return x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,rate,lpm", [(2, 11025, 240), (3, 48000, 240), (4, 11025, 120), (8, 48000, 120)])
+def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, world, rate, lpm):
+    """ShardedDecoder over the shm transport, `world` processes on one GPU, three decodes back to back with the ranks drifting
+    apart: uint8 stream, image, start_frame and the float64 envelope blocks equal the fused one-GPU decode / the in-process
+    emulation bit for bit."""
+    from wefax_amd import sharded
+    from wefax_amd.wefax import DecodeJob
+    x = _capture(rate, 5, lpm)
+    assert sharded.layout_supported(x.shape[0], rate, world, lpm, sharded.capture_kind(x))
+    job = _job()
+    out = _run(world, _decode_worker, lambda r: (job, world, r, 5, rate, lpm, str(tmp_path)), timeout=600)
+    assert out == {r: "ok" for r in range(world)}, out
+    ctx = nat.Context(0)
+    ref = DecodeJob(ctx, x, rate, lpm)
+    ref.run()
+    info = ref.result()
+    assert np.array_equal(np.load(tmp_path / "stream.npy"), ref.fetch("digitalized"))
+    assert np.array_equal(np.load(tmp_path / "image.npy"), ref.fetch("image"))
+    assert list(np.load(tmp_path / "sync.npy")) == [info.start_frame, info.height, info.npeaks]
+    emu = sharded.decode_emulated(x, rate, world, lpm, want=("envelope",))
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"env{r}.npy") for r in range(world)]), emu["envelope"])
+    ctx.close()

@@ -338,6 +338,7 @@ def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds
     ranks (bit-identical to each other and to the fused form); against the oracle within the figures above.  ``drop`` frames less
     than whole seconds: int(11025 * n0 / fs) is then not n0 * 11025 / fs and the reference's resampling grid (wefax.py:384) is
     stretched by up to one sample over the capture -- the hand-over keeps it (polyphase.FrontEnd.n_out)."""
+    from wefax_amd import _native as nat
     x = _capture(fs, 0.05, seed=0, lpm=lpm, seconds=seconds, iq=iq)
     if drop:
         x = np.ascontiguousarray(x[:x.shape[0] - drop])

@@ -30,7 +30,7 @@ SYMBOLS = [
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
     "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_decimate_fir64", "wfx_d_resample_rational", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
-    "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_info", "wfx_comm_destroy",
+    "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
     "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
     "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
@@ -188,6 +188,8 @@ def load():
     lib.wfx_comm_unique_id.argtypes = [vp]
     lib.wfx_comm_create.argtypes = [vp, vp, i, i, C.POINTER(vp)]
     lib.wfx_comm_create_local.argtypes = [i, C.POINTER(vp)]
+    lib.wfx_comm_create_shm.argtypes = [vp, C.c_char_p, i, i, C.c_double, C.POINTER(vp)]
+    lib.wfx_comm_selftest.argtypes = [vp, vp, i, C.c_uint64]
     lib.wfx_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     lib.wfx_comm_destroy.argtypes = [vp]
     lib.wfx_comm_barrier.argtypes = [vp, vp]
@@ -637,6 +639,7 @@ class Comm:
         w, r, k = C.c_int(0), C.c_int(0), C.c_int(0)
         lib.wfx_comm_info(self.h, C.byref(w), C.byref(r), C.byref(k))
         self.world, self.rank, self.is_rccl = w.value, r.value, bool(k.value)
+        self.is_shm = False
 
     @classmethod
     def rccl(cls, ctx: "Context", unique_id: bytes, world: int, rank: int) -> "Comm":
@@ -656,8 +659,36 @@ class Comm:
             raise _global_error(lib, rc)
         return [cls(arr[r], lib) for r in range(world)]
 
+    @classmethod
+    def shm(cls, ctx: "Context | None", job: str, world: int, rank: int, timeout: float = 120.0) -> "Comm":
+        """One process per rank on this host, messages staged through shared memory (any number of ranks per GPU).  ``ctx`` None:
+        the collectives move host memory (``selftest`` on a machine without a GPU)."""
+        lib = ctx.lib if ctx is not None else load()
+        h = C.c_void_p(0)
+        rc = lib.wfx_comm_create_shm(ctx.h if ctx is not None else None, job.encode(), world, rank, float(timeout), C.byref(h))
+        if rc != 0:
+            if ctx is not None:
+                ctx._check(rc)
+            raise _global_error(lib, rc)
+        c = cls(h.value, lib)
+        c.is_shm = True
+        return c
+
+    def selftest(self, ctx: "Context | None", rounds: int = 8, seed: int = 1):
+        """Randomised collectives with known answers (wfx_comm_selftest)."""
+        rc = self.lib.wfx_comm_selftest(self.h, ctx.h if ctx is not None else None, int(rounds), int(seed))
+        if rc != 0:
+            if ctx is not None:
+                ctx._check(rc)
+            raise _global_error(self.lib, rc)
+
     def barrier(self, ctx: "Context"):
         """Every rank has arrived and this rank's stream is idle."""
+        if ctx is None:
+            rc = self.lib.wfx_comm_barrier(self.h, None)
+            if rc != 0:
+                raise _global_error(self.lib, rc)
+            return
         ctx._check(self.lib.wfx_comm_barrier(self.h, ctx.h))
 
     def allgather(self, ctx: "Context", values: np.ndarray) -> np.ndarray:

@@ -9,10 +9,26 @@
 //     the decode -- every index of every exchange -- runs on a one-GPU box and in the driver's `-m gpu` test suite; a byte
 //     count that does not match between the two ends of a transfer is an error there, not a hang.
 //
+//   * shm backend: one PROCESS per rank on one host, any number of them per GPU; messages are staged through POSIX shared
+//     memory (sender: device -> its outbox file, receiver: outbox -> device) between two barriers on a shared counter.
+//     Slow (PCIe both ways) and blocking on the host, but everything the RCCL path has is real here: separate address
+//     spaces, contexts and streams, ranks that reach a phase at different times, buffers reused by the next phase while a
+//     peer is still a phase behind.  It is how `bench.py --gpus 2/4/8` runs end to end on a one-GPU box (RCCL refuses two
+//     ranks on one device) and what the multi-process tests drive; a peer that dies or disagrees about a message surfaces as
+//     WFX_ERR_COMM on every rank within the timeout -- never a hang.
+//
 // Only three collectives are needed (wfx_shard.hip): a personalised exchange (grouped send / recv: the transposes of the
 // distributed transforms and the final gather), a sum all-reduce of uint32 histograms, and an all-gather of equal blocks.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
+#include <atomic>
+#include <cstdarg>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -95,12 +111,334 @@ struct wfx_comm_group {
     int device = 0;
 };
 
+// ---- shm backend -------------------------------------------------------------------------------------------
+struct shm_ctl {                        // /dev/shm/wfx_<job>_ctl, created by rank 0
+    std::atomic<uint32_t> magic;        // set last
+    uint32_t world;
+    std::atomic<uint32_t> arrived, generation, failed, attached;
+    std::atomic<uint64_t> box_bytes[64];    // size of each rank's outbox file
+};
+struct shm_msg {
+    int32_t peer;
+    uint32_t pad;
+    uint64_t bytes, offset;
+};
+struct shm_box_hdr {
+    uint64_t seq;
+    uint32_t kind, nmsg;
+    uint64_t count;
+};
+constexpr uint32_t SHM_MAGIC = 0x57465843u;
+constexpr size_t SHM_ALIGN = 256;
+
+struct wfx_shm {
+    std::string job;
+    int world = 1, rank = 0;
+    double timeout = 120.0;
+    shm_ctl *ctl = nullptr;
+    int fd[64];
+    void *map[64];
+    size_t mapped[64];
+    uint64_t seq = 0;
+    bool host_mode = false;             // buffers are host memory (no context: the protocol tests on a machine without a GPU)
+    wfx_shm()
+    {
+        for (int i = 0; i < 64; ++i) {
+            fd[i] = -1;
+            map[i] = nullptr;
+            mapped[i] = 0;
+        }
+    }
+};
+
 struct wfx_comm {
     int world = 1, rank = 0;
     ncclComm_t nccl = nullptr;          // RCCL backend
     wfx_comm_group *group = nullptr;    // local backend
+    wfx_shm *shm = nullptr;             // shm backend
     int device = 0;
 };
+
+static double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static std::string shm_name(const std::string &job, const char *what, int r = -1)
+{
+    std::string n = "/wfx_" + job + "_" + what;
+    if (r >= 0) n += std::to_string(r);
+    return n;
+}
+
+static int shm_fail(wfx_shm *s, wfx_ctx *ctx, const char *fmt, ...)
+{
+    if (s && s->ctl) s->ctl->failed.store(1, std::memory_order_release);
+    char buf[400];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator, rank %d: %s", s ? s->rank : -1, buf);
+}
+
+// every rank has arrived (central counter, generation flips when the last one does); a failed peer or the timeout ends the wait
+static int shm_barrier(wfx_shm *s, wfx_ctx *ctx)
+{
+    shm_ctl *c = s->ctl;
+    if (c->failed.load(std::memory_order_acquire)) return shm_fail(s, ctx, "a peer reported a failure");
+    const uint32_t gen = c->generation.load(std::memory_order_acquire);
+    if (c->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)s->world) {
+        c->arrived.store(0, std::memory_order_relaxed);
+        c->generation.fetch_add(1, std::memory_order_acq_rel);
+        return 0;
+    }
+    const double t0 = now_s();
+    unsigned spins = 0;
+    while (c->generation.load(std::memory_order_acquire) == gen) {
+        if (c->failed.load(std::memory_order_acquire)) return shm_fail(s, ctx, "a peer reported a failure");
+        if (++spins > 2000) {
+            usleep(50);
+            if (now_s() - t0 > s->timeout) return shm_fail(s, ctx, "barrier timed out after %lld s (a peer died or never arrived)", (long long)s->timeout);
+        } else {
+            sched_yield();
+        }
+    }
+    return 0;
+}
+
+static int shm_map(wfx_shm *s, wfx_ctx *ctx, int r, size_t need)
+{
+    if (s->mapped[r] >= need) return 0;
+    if (s->map[r]) munmap(s->map[r], s->mapped[r]);
+    s->map[r] = nullptr;
+    s->mapped[r] = 0;
+    if (s->fd[r] < 0) {
+        s->fd[r] = shm_open(shm_name(s->job, "box", r).c_str(), O_RDWR, 0600);
+        if (s->fd[r] < 0) return shm_fail(s, ctx, "cannot open the outbox of rank %d", r);
+    }
+    void *m = mmap(nullptr, need, PROT_READ | PROT_WRITE, MAP_SHARED, s->fd[r], 0);
+    if (m == MAP_FAILED) return shm_fail(s, ctx, "mmap of %lld bytes of rank %d's outbox failed", (long long)need, r);
+    s->map[r] = m;
+    s->mapped[r] = need;
+    return 0;
+}
+
+// own outbox with room for `need` bytes (grown geometrically; the new size is published before the next barrier)
+static int shm_own_box(wfx_shm *s, wfx_ctx *ctx, size_t need, char **base)
+{
+    const int r = s->rank;
+    size_t have = (size_t)s->ctl->box_bytes[r].load(std::memory_order_acquire);
+    if (need > have) {
+        size_t cap = have ? have : (1u << 20);
+        while (cap < need) cap *= 2;
+        if (ftruncate(s->fd[r], (off_t)cap) != 0) return shm_fail(s, ctx, "cannot grow the outbox to %lld bytes (is /dev/shm full?)", (long long)cap);
+        s->ctl->box_bytes[r].store(cap, std::memory_order_release);
+        have = cap;
+    }
+    WFX_TRY(shm_map(s, ctx, r, have));
+    *base = (char *)s->map[r];
+    return 0;
+}
+
+static int shm_peer_box(wfx_shm *s, wfx_ctx *ctx, int p, const char **base, size_t *size)
+{
+    const size_t have = (size_t)s->ctl->box_bytes[p].load(std::memory_order_acquire);
+    if (have < sizeof(shm_box_hdr)) return shm_fail(s, ctx, "rank %d has no outbox", p);
+    WFX_TRY(shm_map(s, ctx, p, have));
+    *base = (const char *)s->map[p];
+    *size = have;
+    return 0;
+}
+
+static int shm_copy(wfx_shm *s, wfx_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    if (bytes == 0) return 0;
+    if (s->host_mode) {
+        memmove(dst, src, bytes);
+        return 0;
+    }
+    WFX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+    return 0;
+}
+
+static int shm_sync(wfx_shm *s, wfx_ctx *ctx)
+{
+    if (s->host_mode) return 0;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        s->ctl->failed.store(1, std::memory_order_release);
+        return wfx_fail_hip(ctx, e, "hipStreamSynchronize (shm communicator)");
+    }
+    return 0;
+}
+
+static int shm_exchange(wfx_shm *s, wfx_ctx *ctx, const wfx_xfer *list, int n)
+{
+    const uint64_t seq = ++s->seq;
+    WFX_TRY(shm_sync(s, ctx));                           // what the messages are made of has been computed
+    // outbox: header, one descriptor per outgoing message (list order), the payloads
+    int nmsg = 0;
+    size_t payload = 0;
+    for (int i = 0; i < n; ++i)
+        if (list[i].peer != s->rank && list[i].send_bytes) {
+            ++nmsg;
+            payload += (list[i].send_bytes + SHM_ALIGN - 1) / SHM_ALIGN * SHM_ALIGN;
+        }
+    const size_t head = (sizeof(shm_box_hdr) + (size_t)nmsg * sizeof(shm_msg) + SHM_ALIGN - 1) / SHM_ALIGN * SHM_ALIGN;
+    char *box = nullptr;
+    WFX_TRY(shm_own_box(s, ctx, head + payload, &box));
+    shm_box_hdr *h = (shm_box_hdr *)box;
+    shm_msg *m = (shm_msg *)(box + sizeof(shm_box_hdr));
+    size_t off = head;
+    int k = 0;
+    for (int i = 0; i < n; ++i)
+        if (list[i].peer != s->rank && list[i].send_bytes) {
+            m[k].peer = list[i].peer;
+            m[k].pad = 0;
+            m[k].bytes = list[i].send_bytes;
+            m[k].offset = off;
+            WFX_TRY(shm_copy(s, ctx, box + off, list[i].send, list[i].send_bytes, hipMemcpyDeviceToHost));
+            off += (list[i].send_bytes + SHM_ALIGN - 1) / SHM_ALIGN * SHM_ALIGN;
+            ++k;
+        }
+    h->seq = seq;
+    h->kind = 1;
+    h->nmsg = (uint32_t)nmsg;
+    h->count = 0;
+    WFX_TRY(shm_sync(s, ctx));
+    WFX_TRY(shm_barrier(s, ctx));                        // every outbox of this collective is complete
+    // a rank's message to itself is a copy (normally the packer has already written it in place)
+    for (int i = 0; i < n; ++i)
+        if (list[i].peer == s->rank && list[i].send_bytes) {
+            if (list[i].send_bytes != list[i].recv_bytes) return shm_fail(s, ctx, "self message of %lld bytes into %lld", (long long)list[i].send_bytes, (long long)list[i].recv_bytes);
+            if (list[i].send != list[i].recv) WFX_TRY(shm_copy(s, ctx, list[i].recv, list[i].send, list[i].send_bytes, hipMemcpyDeviceToDevice));
+        }
+    // the k-th receive posted for peer p takes the k-th message p addressed to this rank
+    std::vector<int> taken((size_t)s->world, 0);
+    for (int i = 0; i < n; ++i) {
+        const int p = list[i].peer;
+        if (p == s->rank || !list[i].recv_bytes) continue;
+        const char *pb = nullptr;
+        size_t psz = 0;
+        WFX_TRY(shm_peer_box(s, ctx, p, &pb, &psz));
+        const shm_box_hdr *ph = (const shm_box_hdr *)pb;
+        if (ph->seq != seq || ph->kind != 1)
+            return shm_fail(s, ctx, "rank %d is at collective %lld, this rank at exchange %lld: the ranks disagree about the sequence of collectives", p,
+                            (long long)ph->seq, (long long)seq);
+        const shm_msg *pm = (const shm_msg *)(pb + sizeof(shm_box_hdr));
+        int want = taken[(size_t)p]++, found = -1;
+        for (uint32_t q = 0; q < ph->nmsg; ++q)
+            if (pm[q].peer == s->rank && want-- == 0) {
+                found = (int)q;
+                break;
+            }
+        if (found < 0) return shm_fail(s, ctx, "rank %d sent fewer messages to this rank than it expects (receive %d)", p, i);
+        if (pm[found].bytes != list[i].recv_bytes)
+            return shm_fail(s, ctx, "a message from rank %d has %lld bytes, the receiver expects %lld", p, (long long)pm[found].bytes, (long long)list[i].recv_bytes);
+        if (pm[found].offset + pm[found].bytes > psz) return shm_fail(s, ctx, "rank %d's outbox is shorter than its descriptors say", p);
+        WFX_TRY(shm_copy(s, ctx, list[i].recv, pb + pm[found].offset, pm[found].bytes, hipMemcpyHostToDevice));
+    }
+    // and nothing is left over: every message addressed to this rank was expected
+    for (int p = 0; p < s->world; ++p) {
+        if (p == s->rank) continue;
+        const char *pb = nullptr;
+        size_t psz = 0;
+        WFX_TRY(shm_peer_box(s, ctx, p, &pb, &psz));
+        const shm_box_hdr *ph = (const shm_box_hdr *)pb;
+        if (ph->seq != seq || ph->kind != 1)
+            return shm_fail(s, ctx, "rank %d is at collective %lld, this rank at exchange %lld", p, (long long)ph->seq, (long long)seq);
+        const shm_msg *pm = (const shm_msg *)(pb + sizeof(shm_box_hdr));
+        int sent = 0;
+        for (uint32_t q = 0; q < ph->nmsg; ++q) sent += pm[q].peer == s->rank;
+        if (sent != taken[(size_t)p]) return shm_fail(s, ctx, "rank %d sent %d messages to this rank, which expected %d", p, sent, taken[(size_t)p]);
+    }
+    WFX_TRY(shm_sync(s, ctx));
+    return shm_barrier(s, ctx);                          // outboxes may be overwritten
+}
+
+static int shm_allreduce_u32(wfx_shm *s, wfx_ctx *ctx, unsigned *buf, size_t count)
+{
+    const uint64_t seq = ++s->seq;
+    WFX_TRY(shm_sync(s, ctx));
+    const size_t head = (sizeof(shm_box_hdr) + SHM_ALIGN - 1) / SHM_ALIGN * SHM_ALIGN;
+    char *box = nullptr;
+    WFX_TRY(shm_own_box(s, ctx, head + count * 4, &box));
+    WFX_TRY(shm_copy(s, ctx, box + head, buf, count * 4, hipMemcpyDeviceToHost));
+    shm_box_hdr *h = (shm_box_hdr *)box;
+    h->seq = seq;
+    h->kind = 2;
+    h->nmsg = 0;
+    h->count = count;
+    WFX_TRY(shm_sync(s, ctx));
+    WFX_TRY(shm_barrier(s, ctx));
+    std::vector<unsigned> acc(count, 0u);
+    for (int p = 0; p < s->world; ++p) {                 // rank order: the same sum on every rank
+        const char *pb = nullptr;
+        size_t psz = 0;
+        WFX_TRY(shm_peer_box(s, ctx, p, &pb, &psz));
+        const shm_box_hdr *ph = (const shm_box_hdr *)pb;
+        if (ph->seq != seq || ph->kind != 2 || ph->count != count)
+            return shm_fail(s, ctx, "all-reduce: rank %d is at collective %lld (kind %u), this rank at %lld", p, (long long)ph->seq, ph->kind, (long long)seq);
+        const unsigned *v = (const unsigned *)(pb + head);
+        for (size_t i = 0; i < count; ++i) acc[i] += v[i];
+    }
+    WFX_TRY(shm_copy(s, ctx, buf, acc.data(), count * 4, hipMemcpyHostToDevice));
+    WFX_TRY(shm_sync(s, ctx));                           // (acc lives on this stack frame)
+    return shm_barrier(s, ctx);
+}
+
+static int shm_allgather(wfx_shm *s, wfx_ctx *ctx, const void *send, void *recv, size_t bytes, bool host_ptrs)
+{
+    const uint64_t seq = ++s->seq;
+    WFX_TRY(shm_sync(s, ctx));
+    const size_t head = (sizeof(shm_box_hdr) + SHM_ALIGN - 1) / SHM_ALIGN * SHM_ALIGN;
+    char *box = nullptr;
+    WFX_TRY(shm_own_box(s, ctx, head + bytes, &box));
+    if (host_ptrs)
+        memcpy(box + head, send, bytes);
+    else
+        WFX_TRY(shm_copy(s, ctx, box + head, send, bytes, hipMemcpyDeviceToHost));
+    shm_box_hdr *h = (shm_box_hdr *)box;
+    h->seq = seq;
+    h->kind = 3;
+    h->nmsg = 0;
+    h->count = bytes;
+    WFX_TRY(shm_sync(s, ctx));
+    WFX_TRY(shm_barrier(s, ctx));
+    for (int p = 0; p < s->world; ++p) {
+        const char *pb = nullptr;
+        size_t psz = 0;
+        WFX_TRY(shm_peer_box(s, ctx, p, &pb, &psz));
+        const shm_box_hdr *ph = (const shm_box_hdr *)pb;
+        if (ph->seq != seq || ph->kind != 3 || ph->count != bytes)
+            return shm_fail(s, ctx, "all-gather: rank %d is at collective %lld (kind %u), this rank at %lld", p, (long long)ph->seq, ph->kind, (long long)seq);
+        if (host_ptrs)
+            memcpy((char *)recv + (size_t)p * bytes, pb + head, bytes);
+        else
+            WFX_TRY(shm_copy(s, ctx, (char *)recv + (size_t)p * bytes, pb + head, bytes, hipMemcpyHostToDevice));
+    }
+    WFX_TRY(shm_sync(s, ctx));
+    return shm_barrier(s, ctx);
+}
+
+static void shm_close(wfx_shm *s)
+{
+    if (!s) return;
+    for (int r = 0; r < 64; ++r) {
+        if (s->map[r]) munmap(s->map[r], s->mapped[r]);
+        if (s->fd[r] >= 0) close(s->fd[r]);
+    }
+    shm_unlink(shm_name(s->job, "box", s->rank).c_str());
+    if (s->ctl) {
+        // the last rank to leave removes the control block
+        if (s->ctl->attached.fetch_sub(1, std::memory_order_acq_rel) == 1) shm_unlink(shm_name(s->job, "ctl").c_str());
+        munmap(s->ctl, sizeof(shm_ctl));
+    }
+    delete s;
+}
 
 __global__ void __launch_bounds__(256) comm_add_u32(unsigned *__restrict__ acc, const unsigned *__restrict__ x, size_t n)
 {
@@ -192,7 +530,12 @@ static int local_post(wfx_comm *c, wfx_ctx *ctx, local_op &&op)
         bool all = true;
         for (int r = 0; r < g->world; ++r) all = all && !g->pending[r].empty();
         if (!all) return 0;
-        WFX_TRY(local_execute(g, ctx));
+        const int rc = local_execute(g, ctx);
+        if (rc != 0) {                                   // the failed collective does not stay queued: the group remains usable
+            for (int r = 0; r < g->world; ++r)
+                if (!g->pending[r].empty()) g->pending[r].pop_front();
+            return rc;
+        }
     }
 }
 
@@ -212,6 +555,7 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
         op.list.assign(list, list + n);
         return local_post(c, ctx, std::move(op));
     }
+    if (c->shm) return shm_exchange(c->shm, ctx, list, n);
     bool any_remote = false;
     for (int i = 0; i < n; ++i) any_remote = any_remote || list[i].peer != c->rank;
     // a rank's message to itself is a copy on the stream (normally the packer has already written it in place)
@@ -223,12 +567,15 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
         }
     if (!any_remote) return 0;
     WFX_NCCL(ctx, g_rccl.GroupStart());
-    for (int i = 0; i < n; ++i) {
+    ncclResult_t bad = ncclSuccess;
+    for (int i = 0; i < n && bad == ncclSuccess; ++i) {
         if (list[i].peer == c->rank) continue;
-        if (list[i].send_bytes) WFX_NCCL(ctx, g_rccl.Send(list[i].send, list[i].send_bytes, ncclUint8, list[i].peer, c->nccl, ctx->stream));
-        if (list[i].recv_bytes) WFX_NCCL(ctx, g_rccl.Recv(list[i].recv, list[i].recv_bytes, ncclUint8, list[i].peer, c->nccl, ctx->stream));
+        if (list[i].send_bytes) bad = g_rccl.Send(list[i].send, list[i].send_bytes, ncclUint8, list[i].peer, c->nccl, ctx->stream);
+        if (bad == ncclSuccess && list[i].recv_bytes) bad = g_rccl.Recv(list[i].recv, list[i].recv_bytes, ncclUint8, list[i].peer, c->nccl, ctx->stream);
     }
-    WFX_NCCL(ctx, g_rccl.GroupEnd());
+    const ncclResult_t end = g_rccl.GroupEnd();          // the group is closed on the error path too: the communicator stays usable
+    if (bad != ncclSuccess) return fail_nccl(ctx, bad, "ncclSend / ncclRecv of an exchange");
+    if (end != ncclSuccess) return fail_nccl(ctx, end, "ncclGroupEnd");
     return 0;
 }
 
@@ -242,6 +589,7 @@ int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t coun
         op.count = count;
         return local_post(c, ctx, std::move(op));
     }
+    if (c->shm) return shm_allreduce_u32(c->shm, ctx, buf, count);
     WFX_NCCL(ctx, g_rccl.AllReduce(buf, buf, count, ncclUint32, ncclSum, c->nccl, ctx->stream));
     return 0;
 }
@@ -257,6 +605,7 @@ int wfx_comm_allgather(wfx_comm *c, wfx_ctx *ctx, const void *send, void *recv, 
         op.count = bytes_per_rank;
         return local_post(c, ctx, std::move(op));
     }
+    if (c->shm) return shm_allgather(c->shm, ctx, send, recv, bytes_per_rank, false);
     WFX_NCCL(ctx, g_rccl.AllGather(send, recv, bytes_per_rank, ncclUint8, c->nccl, ctx->stream));
     return 0;
 }
@@ -313,6 +662,229 @@ int wfx_comm_create_local(int world, wfx_comm **out)
     return 0;
 }
 
+int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, double timeout_s, wfx_comm **out)
+{
+    if (!job || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad rank %d for world size %d (shm: at most 64)", rank, world);
+    for (const char *q = job; *q; ++q)
+        if (!((*q >= '0' && *q <= '9') || (*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || *q == '-' || *q == '.'))
+            return wfx_fail(ctx, WFX_ERR_BAD_ARG, "shm job name: letters, digits, '-' and '.' only");
+    if (strlen(job) < 1 || strlen(job) > 100) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "shm job name: 1..100 characters");
+    wfx_shm *s = new wfx_shm();
+    s->job = job;
+    s->world = world;
+    s->rank = rank;
+    s->timeout = timeout_s > 0 ? timeout_s : 120.0;
+    s->host_mode = ctx == nullptr;
+    const std::string cn = shm_name(s->job, "ctl");
+    int cfd = -1;
+    const double t0 = now_s();
+    if (rank == 0) {
+        shm_unlink(cn.c_str());                          // a leftover of a crashed job of the same name
+        cfd = shm_open(cn.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (cfd < 0 || ftruncate(cfd, (off_t)sizeof(shm_ctl)) != 0) {
+            if (cfd >= 0) close(cfd);
+            delete s;
+            return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator: cannot create %s", cn.c_str());
+        }
+    } else {
+        while ((cfd = shm_open(cn.c_str(), O_RDWR, 0600)) < 0) {
+            if (now_s() - t0 > s->timeout) {
+                delete s;
+                return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator, rank %d: rank 0 never created %s", rank, cn.c_str());
+            }
+            usleep(2000);
+        }
+        struct stat st;
+        while (fstat(cfd, &st) == 0 && (size_t)st.st_size < sizeof(shm_ctl)) {
+            if (now_s() - t0 > s->timeout) break;
+            usleep(1000);
+        }
+    }
+    void *m = mmap(nullptr, sizeof(shm_ctl), PROT_READ | PROT_WRITE, MAP_SHARED, cfd, 0);
+    close(cfd);
+    if (m == MAP_FAILED) {
+        delete s;
+        return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator: cannot map %s", cn.c_str());
+    }
+    s->ctl = (shm_ctl *)m;
+    if (rank == 0) {
+        s->ctl->world = (uint32_t)world;
+        s->ctl->arrived.store(0);
+        s->ctl->generation.store(0);
+        s->ctl->failed.store(0);
+        s->ctl->attached.store(0);
+        for (int r = 0; r < 64; ++r) s->ctl->box_bytes[r].store(0);
+        s->ctl->magic.store(SHM_MAGIC, std::memory_order_release);
+    } else {
+        while (s->ctl->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+            if (now_s() - t0 > s->timeout) {
+                munmap(m, sizeof(shm_ctl));
+                s->ctl = nullptr;
+                delete s;
+                return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator, rank %d: the control block was never initialised", rank);
+            }
+            usleep(1000);
+        }
+        if ((int)s->ctl->world != world) {
+            const unsigned theirs = s->ctl->world;
+            munmap(m, sizeof(shm_ctl));
+            s->ctl = nullptr;
+            delete s;
+            return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator: job %s has world size %u, this rank was told %d", job, theirs, world);
+        }
+    }
+    s->ctl->attached.fetch_add(1, std::memory_order_acq_rel);
+    const std::string bn = shm_name(s->job, "box", rank);
+    shm_unlink(bn.c_str());
+    s->fd[rank] = shm_open(bn.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (s->fd[rank] < 0) {
+        const int rc = shm_fail(s, ctx, "cannot create the outbox %s", bn.c_str());
+        shm_close(s);
+        return rc;
+    }
+    wfx_comm *c = new wfx_comm();
+    c->world = world;
+    c->rank = rank;
+    c->shm = s;
+    c->device = ctx ? ctx->device : 0;
+    char *box = nullptr;
+    int rc = shm_own_box(s, ctx, 1u << 20, &box);        // outboxes exist before anyone looks for them
+    if (rc == 0) rc = shm_barrier(s, ctx);
+    if (rc != 0) {
+        shm_close(s);
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+// A randomised sequence of collectives with known answers (every rank derives the same plan from `seed`): exchanges with 0-2
+// messages of up to 1 MB per ordered pair of ranks, all-reduces, all-gathers, with a random pause before each so that the
+// ranks arrive out of step.  Device buffers when ctx is given, host buffers when it is NULL (shm communicators only).
+static uint64_t st_mix(uint64_t x)
+{
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+int wfx_comm_selftest(wfx_comm *comm, wfx_ctx *ctx, int rounds, uint64_t seed)
+{
+    if (!comm) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null communicator");
+    if (comm->group) return wfx_fail(ctx, WFX_ERR_STATE, "selftest: the ranks of a local communicator run in one thread");
+    if (!ctx && !comm->shm) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "selftest without a context needs a shm communicator");
+    if (ctx) (void)hipSetDevice(ctx->device);
+    const int W = comm->world, me = comm->rank;
+    auto dalloc = [&](size_t bytes) -> void * {
+        void *p = nullptr;
+        if (!ctx) return malloc(bytes ? bytes : 8);
+        return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? p : nullptr;
+    };
+    auto dfree = [&](void *p) {
+        if (!ctx) free(p);
+        else (void)hipFree(p);
+    };
+    auto put = [&](void *dst, const void *src, size_t bytes) {      // host -> buffer
+        if (!ctx) memcpy(dst, src, bytes);
+        else (void)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    auto get = [&](void *dst, const void *src, size_t bytes) {      // buffer -> host
+        if (!ctx) memcpy(dst, src, bytes);
+        else (void)hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    };
+    for (int round = 0; round < rounds; ++round) {
+        usleep((useconds_t)(st_mix(seed ^ (uint64_t)(round * 64 + me)) % 3000));
+        // ---- exchange ----
+        struct msg {
+            int src, dst;
+            size_t bytes;
+            uint64_t key;
+        };
+        std::vector<msg> plan;
+        for (int a = 0; a < W; ++a)
+            for (int b = 0; b < W; ++b) {
+                const uint64_t h = st_mix(seed * 1315423911ull + (uint64_t)round * 4099 + (uint64_t)a * 67 + (uint64_t)b);
+                const int cnt = (int)(h % 3);
+                for (int k = 0; k < cnt; ++k) {
+                    const uint64_t hk = st_mix(h + (uint64_t)k);
+                    plan.push_back({a, b, (size_t)(8 + 8 * (hk % ((round % 4 == 3) ? 131072 : 2048))), hk});
+                }
+            }
+        std::vector<wfx_xfer> list;
+        std::vector<void *> sbuf, rbuf;
+        std::vector<const msg *> rmsg;
+        for (const msg &m : plan) {
+            if (m.src == me) {
+                std::vector<uint64_t> host(m.bytes / 8);
+                for (size_t i = 0; i < host.size(); ++i) host[i] = st_mix(m.key + i);
+                void *d = dalloc(m.bytes);
+                if (!d) return wfx_fail(ctx, WFX_ERR_OOM, "selftest: allocation failed");
+                put(d, host.data(), m.bytes);
+                sbuf.push_back(d);
+                if (m.dst != me) list.push_back({m.dst, d, m.bytes, nullptr, 0});
+            }
+            if (m.dst == me) {
+                void *d = dalloc(m.bytes);
+                if (!d) return wfx_fail(ctx, WFX_ERR_OOM, "selftest: allocation failed");
+                rbuf.push_back(d);
+                rmsg.push_back(&m);
+                if (m.src != me) list.push_back({m.src, nullptr, 0, d, m.bytes});
+                else list.push_back({me, sbuf.back(), m.bytes, d, m.bytes});      // (the send entry of a self message was skipped above)
+            }
+        }
+        WFX_TRY(wfx_comm_exchange(comm, ctx, list.data(), (int)list.size()));
+        if (ctx) WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t q = 0; q < rbuf.size(); ++q) {
+            std::vector<uint64_t> host(rmsg[q]->bytes / 8);
+            get(host.data(), rbuf[q], rmsg[q]->bytes);
+            for (size_t i = 0; i < host.size(); ++i)
+                if (host[i] != st_mix(rmsg[q]->key + i))
+                    return wfx_fail(ctx, WFX_ERR_COMM, "selftest round %d: word %zu of a %zu-byte message from rank %d arrived wrong on rank %d", round, i,
+                                    rmsg[q]->bytes, rmsg[q]->src, me);
+        }
+        for (void *p : sbuf) dfree(p);
+        for (void *p : rbuf) dfree(p);
+        // ---- all-reduce ----
+        usleep((useconds_t)(st_mix(seed ^ (uint64_t)(round * 64 + me) ^ 0x55) % 2000));
+        const size_t nw = 257 + (size_t)(st_mix(seed + (uint64_t)round) % 4000);
+        std::vector<unsigned> hv(nw), want(nw, 0u);
+        for (int r = 0; r < W; ++r)
+            for (size_t i = 0; i < nw; ++i) {
+                const unsigned v = (unsigned)(st_mix(seed + (uint64_t)round * 131 + (uint64_t)r * 7919 + i) % 100000);
+                if (r == me) hv[i] = v;
+                want[i] += v;
+            }
+        void *ar = dalloc(nw * 4);
+        put(ar, hv.data(), nw * 4);
+        WFX_TRY(wfx_comm_allreduce_u32(comm, ctx, (unsigned *)ar, nw));
+        if (ctx) WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        get(hv.data(), ar, nw * 4);
+        dfree(ar);
+        for (size_t i = 0; i < nw; ++i)
+            if (hv[i] != want[i]) return wfx_fail(ctx, WFX_ERR_COMM, "selftest round %d: all-reduce word %zu is %u, expected %u", round, i, hv[i], want[i]);
+        // ---- all-gather ----
+        const size_t gb = 64 + 8 * (size_t)(st_mix(seed + 17 * (uint64_t)round) % 2000);
+        std::vector<uint64_t> gs(gb / 8), gr(gb / 8 * (size_t)W);
+        for (size_t i = 0; i < gs.size(); ++i) gs[i] = st_mix(seed + (uint64_t)round * 977 + (uint64_t)me * 31 + i);
+        void *ds = dalloc(gb), *dr = dalloc(gb * (size_t)W);
+        put(ds, gs.data(), gb);
+        WFX_TRY(wfx_comm_allgather(comm, ctx, ds, dr, gb));
+        if (ctx) WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        get(gr.data(), dr, gb * (size_t)W);
+        dfree(ds);
+        dfree(dr);
+        for (int r = 0; r < W; ++r)
+            for (size_t i = 0; i < gs.size(); ++i)
+                if (gr[(size_t)r * gs.size() + i] != st_mix(seed + (uint64_t)round * 977 + (uint64_t)r * 31 + i))
+                    return wfx_fail(ctx, WFX_ERR_COMM, "selftest round %d: all-gather block of rank %d arrived wrong on rank %d", round, r, me);
+    }
+    return 0;
+}
+
 int wfx_comm_info(wfx_comm *comm, int *world, int *rank, int *is_rccl)
 {
     if (!comm) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null communicator");
@@ -325,9 +897,13 @@ int wfx_comm_info(wfx_comm *comm, int *world, int *rank, int *is_rccl)
 // ---- small host-side helpers for drivers (bench.py): a barrier and an all-gather of a few host bytes ----------
 int wfx_comm_barrier(wfx_comm *comm, wfx_ctx *ctx)
 {
-    if (!comm || !ctx) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
-    (void)hipSetDevice(ctx->device);
+    if (!comm || (!ctx && !(comm->shm && comm->shm->host_mode))) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    if (ctx) (void)hipSetDevice(ctx->device);
     if (comm->group && comm->world > 1) return wfx_fail(ctx, WFX_ERR_STATE, "barrier: the ranks of a local communicator run in one thread");
+    if (comm->shm) {
+        WFX_TRY(shm_sync(comm->shm, ctx));
+        return shm_barrier(comm->shm, ctx);
+    }
     WFX_TRY(wfx_reserve(ctx, ctx->b_seg, 4096));
     WFX_HIP(ctx, hipMemsetAsync(ctx->b_seg.p, 0, 64, ctx->stream));
     if (!comm->group) WFX_TRY(wfx_comm_allreduce_u32(comm, ctx, (unsigned *)ctx->b_seg.p, 1));
@@ -337,9 +913,10 @@ int wfx_comm_barrier(wfx_comm *comm, wfx_ctx *ctx)
 
 int wfx_comm_allgather_host(wfx_comm *comm, wfx_ctx *ctx, const void *send_host, void *recv_host, size_t bytes)
 {
-    if (!comm || !ctx || !send_host || !recv_host) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
-    (void)hipSetDevice(ctx->device);
+    if (!comm || (!ctx && !(comm->shm && comm->shm->host_mode)) || !send_host || !recv_host) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
+    if (ctx) (void)hipSetDevice(ctx->device);
     if (comm->group && comm->world > 1) return wfx_fail(ctx, WFX_ERR_STATE, "all-gather: the ranks of a local communicator run in one thread");
+    if (comm->shm) return shm_allgather(comm->shm, ctx, send_host, recv_host, bytes, true);
     const size_t W = (size_t)comm->world;
     WFX_TRY(wfx_reserve(ctx, ctx->b_seg, 4096 + bytes * (W + 1)));
     char *snd = (char *)ctx->b_seg.p + 4096, *rcv = snd + bytes;
@@ -362,6 +939,7 @@ int wfx_comm_destroy(wfx_comm *comm)
         if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > comm->device && hipSetDevice(comm->device) == hipSuccess && g_rccl.CommDestroy)
             g_rccl.CommDestroy(comm->nccl);
     }
+    if (comm->shm) shm_close(comm->shm);
     if (comm->group && --comm->group->refs == 0) {
         if (comm->group->scratch.p) (void)hipFree(comm->group->scratch.p);
         delete comm->group;

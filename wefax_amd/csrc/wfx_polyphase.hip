@@ -194,6 +194,12 @@ constexpr int PP_BATCH = 8;
 #ifndef PP_MINB
 #define PP_MINB 1
 #endif
+#ifndef PP_EXACT_PIPE
+#define PP_EXACT_PIPE 1      // integer-exact ingest: next row's window and taps in flight during this row's dot products
+#endif
+#ifndef PP_EXACT_WAVES
+#define PP_EXACT_WAVES 4     // ... compiled for this many waves per SIMD (128 VGPRs at 4)
+#endif
 typedef float pp_f2 __attribute__((ext_vector_type(2)));
 #if PP_ACC64
 typedef double pp_acc_t;
@@ -209,7 +215,7 @@ constexpr int PP_NB = 9;           // 16-byte chunks in flight per thread (decim
 // float64 taps and sums in one canonical order (the stages behind the ingest: a few per cent of the samples).
 constexpr int PP_FIX_LB = 12;
 template <int IN, typename OUT, bool ALIGNED, int Q4T, int MODE = 0>
-__global__ void __launch_bounds__(PP_THREADS, PP_MINB)
+__global__ void __launch_bounds__(PP_THREADS, MODE == 1 ? PP_EXACT_WAVES : PP_MINB)
 decimate_kernel(const void *__restrict__ in, long long n_in, long long first, int M, int log2m, const float *__restrict__ cp, int q4_arg,
                 OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign, int flush_rows = 0)
 {
@@ -341,6 +347,50 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                 int ah0 = 0, ah1 = 0, ah2 = 0, ah3 = 0, al0 = 0, al1 = 0, al2 = 0, al3 = 0;
                 const int *ci = (const int *)cp;
                 constexpr int NP = 2 * (Q4T ? Q4T : 1);
+                if constexpr (Q4T > 0 && PP_EXACT_PIPE) {
+                    // compile-time tap count: the NEXT row's window pairs (LDS) and taps (scalar loads) are requested before this
+                    // row's 16 q4 + 4 dot products -- one row's load latency no longer sits in front of every row's arithmetic
+                    constexpr int NW = NP + 2, NC = 4 * NP + 4;
+                    int w[NW], wn[NW], c[NC], cn[NC];
+                    {
+                        const int *row = (const int *)(xs + r0 * row_stride + 4 * g);
+                        const int *ct = ci + r0 * NC;
+#pragma unroll
+                        for (int p = 0; p < NW; ++p) w[p] = row[p];
+#pragma unroll
+                        for (int p = 0; p < NC; ++p) c[p] = ct[p];
+                    }
+                    for (int r = r0; r < r0 + rows_per; ++r) {
+                        const int rn = r + 1 < r0 + rows_per ? r + 1 : r;                  // (the last row fetches itself again: no branch)
+                        const int *rowx = (const int *)(xs + rn * row_stride + 4 * g);
+                        const int *ctx_ = ci + rn * NC;
+#pragma unroll
+                        for (int p = 0; p < NW; ++p) wn[p] = rowx[p];
+#pragma unroll
+                        for (int p = 0; p < NC; ++p) cn[p] = ctx_[p];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const int eh = c[p], el = c[NP + p], dh = c[2 * NP + p], dl = c[3 * NP + 2 + p];
+                            ah0 = pp_dot2(w[p], eh, ah0); al0 = pp_dot2(w[p], el, al0);
+                            ah2 = pp_dot2(w[p + 1], eh, ah2); al2 = pp_dot2(w[p + 1], el, al2);
+                            ah1 = pp_dot2(w[p], dh, ah1); al1 = pp_dot2(w[p], dl, al1);
+                            ah3 = pp_dot2(w[p + 1], dh, ah3); al3 = pp_dot2(w[p + 1], dl, al3);
+                        }
+                        {
+                            const int dh = c[3 * NP], dl = c[4 * NP + 2];
+                            ah1 = pp_dot2(w[NP], dh, ah1); al1 = pp_dot2(w[NP], dl, al1);
+                            ah3 = pp_dot2(w[NP + 1], dh, ah3); al3 = pp_dot2(w[NP + 1], dl, al3);
+                        }
+                        if (((r + 1) & ((flush_rows & 255) - 1)) == 0) {
+                            tl0 += al0; tl1 += al1; tl2 += al2; tl3 += al3;
+                            al0 = al1 = al2 = al3 = 0;
+                        }
+#pragma unroll
+                        for (int p = 0; p < NW; ++p) w[p] = wn[p];
+#pragma unroll
+                        for (int p = 0; p < NC; ++p) c[p] = cn[p];
+                    }
+                } else
                 for (int r = r0; r < r0 + rows_per; ++r) {
                     const int *row = (const int *)(xs + r * row_stride + 4 * g);      // dword p = samples (w[2p], w[2p+1])
                     const int *c = ci + r * (8 * q4 + 4);     // E_hi[2 q4], E_lo[2 q4], D_hi[2 q4 + 2], D_lo[2 q4 + 2]
