@@ -167,7 +167,16 @@ class Ranks:
         self.device = dev
         self.ctx = nat.Context(dev)
         self.use_rccl = self.world > 1 or os.environ.get("WFX_BENCH_FORCE_DIST") == "1"
-        if self.use_rccl:
+        # transport: RCCL (one rank per GPU), or the library's shared-memory communicator -- real processes, host-staged messages --
+        # where RCCL cannot run the job: several ranks on ONE GPU (WFX_BENCH_OVERSUBSCRIBE=1 on a box with fewer devices than ranks).
+        # WFX_BENCH_COMM=rccl|shm forces one.
+        over = os.environ.get("WFX_BENCH_OVERSUBSCRIBE") == "1"
+        self.transport = os.environ.get("WFX_BENCH_COMM") or ("shm" if over and self.world > max(1, nat.device_count()) else "rccl")
+        if self.use_rccl and self.transport == "shm":
+            job = os.environ.get("WFX_JOB_NONCE") or ("p" + os.environ.get("MASTER_PORT", "29511"))
+            self.comm = nat.Comm.shm(self.ctx, job, self.world, self.rank, timeout=float(os.environ.get("WFX_BENCH_TIMEOUT", "600")))
+            self.comm.barrier(self.ctx)
+        elif self.use_rccl:
             addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
             mport = int(os.environ.get("MASTER_PORT", "29511"))
             # spawn_ranks reserves a port of its own; under a launcher: next to its rendezvous port, kept inside the valid range
@@ -182,6 +191,13 @@ class Ranks:
 
     def barrier(self):
         self.comm.barrier(self.ctx)
+
+    def transport_name(self) -> str:
+        if self.comm.is_rccl:
+            return "RCCL"
+        if getattr(self.comm, "is_shm", False):
+            return "shared memory (host-staged, one process per rank; NOT a performance figure: PCIe both ways)"
+        return "none (one rank)"
 
     def max_over_ranks(self, seconds: float) -> float:
         import numpy as np
@@ -326,7 +342,7 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
     pmc = os.path.join(REPO, "profiles", "pmc_traffic_iq.json") if (rk.world == 1 and seconds == 3600.0) else None
     out = {"workload": f"ONE synthetic 1.536 MS/s int16 IQ stream of {seconds:.0f} s (BASELINE configs[3]): {n0} IQ frames -> {n} samples at "
                        f"11 025 Hz, 120 LPM, AWGN sigma {args.noise} FS, synthesised in HBM",
-           "n_gpus": rk.world, "ranks_rccl": rk.world if rk.comm.is_rccl else 0, "scaling": "strong",
+           "n_gpus": rk.world, "ranks_rccl": rk.world if rk.comm.is_rccl else 0, "transport": rk.transport_name(), "scaling": "strong",
            "form": ("front end + fused exact decode on one GPU" if fused else
                     f"front end on each rank's 1/{rk.world} of the stream + sharded exact path (distributed FFT resample and Hilbert: 8 transposes, "
                     "2 histogram all-reduces, 1 candidate all-gather, 1 stream gather per decode)"),
@@ -478,9 +494,9 @@ def bench_c2(args, rk: Ranks) -> dict:
                       "start_frame": int(info.start_frame) if rk.rank == 0 else None,
                       "parallelism": (f"ONE capture sharded over {rk.world} rank(s): distributed Hilbert transform, 1 stream gather" if args.shard else
                                       "1 capture per GPU, no data-path collective"),
-                      "ranks_rccl": rk.world if rk.comm.is_rccl else 0}}
+                      "ranks_rccl": rk.world if rk.comm.is_rccl else 0, "transport": rk.transport_name()}}
+    prof = profile_pass(ctx, job.run, args.steps) if (args.shard or rk.rank == 0) else None      # (a sharded decode is a collective: every rank takes part)
     if rk.rank == 0:
-        prof = profile_pass(ctx, job.run, args.steps)
         alg_bytes = (n0 * 2 + 4 * n) // (rk.world if args.shard else 1)          # N0 * B_in + 4 N (this rank's share when sharded)
         out["roofline"] = roofline_of(prof, args.steps, alg_bytes, ms, os.path.join(REPO, "profiles", "pmc_traffic.json"))
         out["kernels"] = kernel_table(prof, args.steps)
@@ -524,12 +540,13 @@ def bench_c2(args, rk: Ranks) -> dict:
                                  "how": "capture in pinned host memory -> DMA upload -> decode -> DMA of the image into pinned host memory, per capture"}
         ctx2.close()
     out["cpu_baseline"] = None
-    if rk.rank == 0 and rk.world == 1 and not args.no_cpu:        # the CPU leg is reported at N = 1 only
-        cpu = cpu_baseline(x, 11025, 120, not args.no_cpu_loops, f"the whole capture ({x.shape[0]} samples), one run, read from a wav file")
+    if rk.rank == 0 and (rk.world == 1 or args.shard) and not args.no_cpu:        # the CPU leg is reported at N = 1 only; a sharded decode is still CHECKED against it
+        cpu = cpu_baseline(x, 11025, 120, (not args.no_cpu_loops) and rk.world == 1, f"the whole capture ({x.shape[0]} samples), one run, read from a wav file")
         ref = cpu.pop("_result")
         img = job.fetch("image")
         stream = job.fetch("stream" if args.shard else "digitalized")
-        out["cpu_baseline"] = cpu
+        if rk.world == 1:
+            out["cpu_baseline"] = cpu
         out["parity_vs_oracle"] = {"start_frame_equal": bool(ref.get("start_frame") == info.start_frame),
                                    "max_abs_pixel_delta": (int(np.max(np.abs(img.astype(np.int16) - ref["image"].astype(np.int16))))
                                                            if "image" in ref and img.shape == ref["image"].shape else None),
