@@ -200,3 +200,33 @@ def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, wo
     emu = sharded.decode_emulated(x, rate, world, lpm, want=("envelope",))
     assert np.array_equal(np.concatenate([np.load(tmp_path / f"env{r}.npy") for r in range(world)]), emu["envelope"])
     ctx.close()
+
+
+def _silence_worker(job, rank, q):
+    """A constant capture overflows the select's candidate lists: the library repeats the decode by itself on every rank."""
+    try:
+        from wefax_amd import sharded
+        x = np.full(1433250, 1200, dtype=np.int16)
+        ctx = nat.Context(0)
+        comm = nat.Comm.shm(ctx, job, 2, rank, timeout=120.0)
+        dec = sharded.ShardedDecoder(ctx, comm, x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x)
+        dec.run()
+        info = dec.result()
+        ok = info.low == info.high and (rank != 0 or info.nan_count > 1000000)
+        dec.run()                       # and the shard stays usable at the larger capacity
+        info2 = dec.result()
+        ok = ok and info2.low == info.low
+        comm.barrier(ctx)
+        dec.close()
+        comm.close()
+        ctx.close()
+        q.put((rank, "ok" if ok else f"unexpected result {info.low} {info.high} {info.nan_count}"))
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}"))
+
+
+@pytest.mark.gpu
+def test_candidate_overflow_is_repeated_inside_the_library_on_real_ranks():
+    job = _job()
+    out = _run(2, _silence_worker, lambda r: (job, r), timeout=300)
+    assert out == {0: "ok", 1: "ok"}, out

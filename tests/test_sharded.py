@@ -189,6 +189,11 @@ CASES = {
     "mono_48000_30s": lambda: (synth.synth_capture(48000.0, noise=0.05, seed=4, **KW30), 48000, 120),
     "stereo_48000_30s": lambda: (synth.synth_capture(48000.0, noise=0.05, seed=5, iq=True, **KW30), 48000, 120),
     "float_11025_130s": lambda: (synth.synth_capture(11025.0, noise=0.02, seed=8, **KW130).astype(np.float64) * 0.37, 11025, 120),
+    # sample formats whose filtfilt odd extension scipy evaluates in the file's own dtype: uint8 wraps (the capture starts and ends
+    # near the top of the range), int32 wraps, float32 rounds -- the sharded path takes the 9 + 9 numbers from the host like DecodeJob
+    "uint8_11025_130s": lambda: (np.clip(synth.synth_capture(11025.0, noise=0.05, seed=9, **KW130).astype(np.int32) // 160 + 150, 0, 255).astype(np.uint8), 11025, 120),
+    "int32_11025_130s": lambda: (synth.synth_capture(11025.0, noise=0.05, seed=10, **KW130).astype(np.int32) * 98000, 11025, 120),
+    "float32_11025_130s": lambda: ((synth.synth_capture(11025.0, noise=0.05, seed=11, **KW130).astype(np.float64) / 32768.0 * 1.0000001).astype(np.float32), 11025, 120),
 }
 
 

@@ -519,21 +519,28 @@ int wfx_shard_result(wfx_shard *sh, wfx_decode_info *info)
     wfx_ctx *ctx = sh->ctx;
     if (!info) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null info");
     if (!sh->ran) return wfx_fail(ctx, WFX_ERR_STATE, "shard_result before the decode");
-    unsigned flags[4] = {0, 0, 0, 0};
-    WFX_HIP(ctx, hipMemcpyAsync(flags, sh->b_flags.p, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
     wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
-    if (sh->pl.rank != 0) WFX_HIP(ctx, hipMemcpyAsync(ctx->h_scal, ds, sizeof(wfx_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
-    WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (flags[0]) {
-        // a rank produced more candidate keys than travel in the all-gather (long runs of equal envelope values: digital
-        // silence).  Every rank sees the same flag; the capacity is raised for the next decode of this shard.
+    for (int attempt = 0;; ++attempt) {
+        unsigned flags[4] = {0, 0, 0, 0};
+        WFX_HIP(ctx, hipMemcpyAsync(flags, sh->b_flags.p, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+        if (sh->pl.rank != 0) WFX_HIP(ctx, hipMemcpyAsync(ctx->h_scal, ds, sizeof(wfx_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
+        WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!flags[0]) break;
+        // A rank produced more candidate keys than travel in the all-gather (long runs of equal envelope values: digital silence,
+        // a clipped carrier).  The flag comes out of the merged blocks, which are identical on every rank: every rank takes this
+        // branch in the same decode.  The capacity grows 16x and the capture is decoded again -- here, when this process can run
+        // the phases by itself (RCCL / shared-memory transport, or one rank); the ranks of an in-process world are driven phase by
+        // phase by their caller, who gets the same message on every rank and repeats the decode (sharded.decode_emulated does).
         WFX_HIP(ctx, hipMemsetAsync(sh->b_flags.p, 0, 64, ctx->stream));
         sh->cap *= 16;
         sh->bound = false;
         sh->ran = false;
         WFX_TRY(shard_bind(sh));
-        return wfx_fail(ctx, WFX_ERR_STATE, "percentile select: candidate lists overflowed; capacity raised to %llu keys, decode again",
-                        (unsigned long long)sh->cap);
+        const bool self_driven = !(wfx_comm_is_local(sh->comm) && wfx_comm_world(sh->comm) > 1);
+        if (!self_driven || attempt >= 6 || sh->cap > (1ull << 34))
+            return wfx_fail(ctx, WFX_ERR_STATE, "percentile select: candidate lists overflowed; capacity raised to %llu keys, decode again",
+                            (unsigned long long)sh->cap);
+        WFX_TRY(wfx_decode_sharded(sh));
     }
     const wfx_dev_scalars &s = *ctx->h_scal;
     memset(info, 0, sizeof *info);

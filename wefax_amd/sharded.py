@@ -137,6 +137,23 @@ class ShardedDecoder:
         if notch is None:                       # config/config.json like Demodulator (wefax.py:63-66), defaults when there is no file
             notch = hp.load_notch_settings()
         self.params, self.meta = build_params(kind, int(n0), sample_rate, self.frame_len, notch, n_out=n_out)
+        # uint8 / int32 / float32 captures reach the device as float64, but filtfilt's odd extension (wefax.py:72) is what scipy
+        # evaluates in the file's OWN dtype (wraps / float32 rounding): 9 + 9 numbers from the capture's two ends, as DecodeJob
+        # hands them over (the ranks holding a true end use them; wfx_shard.hip phase 4)
+        if kind == nat.WFX_IN_F64_MONO and not self.meta["resampled"] and int(n0) > 9:
+            head = tail = None
+            if data is not None and np.asarray(data).dtype not in (np.float64, np.int16):
+                head, tail = np.asarray(data)[:10], np.asarray(data)[-10:]
+            elif data is None and loader is not None:
+                h0 = np.asarray(loader(0, 10))
+                if h0.dtype not in (np.float64, np.int16):
+                    head, tail = h0, np.asarray(loader(int(n0) - 10, int(n0)))
+            if head is not None:
+                left, _ = hp.odd_extension(head)
+                _, right = hp.odd_extension(tail)
+                self.params.has_ext = 1
+                self.params.ext_left[:] = [float(v) for v in left]
+                self.params.ext_right[:] = [float(v) for v in right]
         self.n = self.meta["n"]
         self.width = self.params.width
         self.shard = nat.Shard(ctx, comm, self.params)
@@ -219,11 +236,24 @@ def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute:
         for d in decs:
             if hasattr(d, "front_end"):
                 d.front_end()
-        nph = decs[0].shard.phases
-        for ph in range(nph):
-            for d in decs:
-                d.shard.phase(ph)
-        infos = [d.result() for d in decs]
+        for attempt in range(8):
+            nph = decs[0].shard.phases
+            for ph in range(nph):
+                for d in decs:
+                    d.shard.phase(ph)
+            try:
+                infos = [d.result() for d in decs]
+                break
+            except nat.NativeError as e:
+                # the percentile select's candidate lists overflowed (every rank reports it alike and has raised its capacity):
+                # the ranks of an in-process world are driven from here, so the repeat is ours
+                if "overflow" not in str(e) or attempt == 7:
+                    raise
+                for d in decs[1:]:
+                    try:
+                        d.result()
+                    except nat.NativeError:
+                        pass
         out = {"sync": _info_dict(infos[0]), "low": infos[0].low, "high": infos[0].high,
                "lows": [i.low for i in infos], "highs": [i.high for i in infos], "n": decs[0].n, "width": decs[0].width,
                "layouts": [(int(d.layout.own_lo), int(d.layout.own_hi), int(d.layout.in_lo), int(d.layout.in_hi)) for d in decs],
