@@ -197,6 +197,15 @@ constexpr int PP_BATCH = 8;
 #ifndef PP_EXACT_PIPE
 #define PP_EXACT_PIPE 1      // integer-exact ingest: next row's window and taps in flight during this row's dot products
 #endif
+#ifndef PP_F64_WAVES
+#define PP_F64_WAVES 1       // float64 stages: waves per SIMD the kernel is compiled for
+#endif
+#ifndef PP_F64_PF
+#define PP_F64_PF 1          // float64 stages: next tile's chunks in flight during the tap loop
+#endif
+#ifndef PP_F64_UNROLL
+#define PP_F64_UNROLL 1      // float64 stages: tap groups per loop trip
+#endif
 #ifndef PP_EXACT_WAVES
 #define PP_EXACT_WAVES 4     // ... compiled for this many waves per SIMD (128 VGPRs at 4)
 #endif
@@ -214,8 +223,15 @@ constexpr int PP_NB = 9;           // 16-byte chunks in flight per thread (decim
 // float64 output is THE value of the FIR with those taps: no rounding anywhere, nothing depends on the tiling.  MODE 2:
 // float64 taps and sums in one canonical order (the stages behind the ingest: a few per cent of the samples).
 constexpr int PP_FIX_LB = 12;
+// float64 rows in LDS: a lane reads 4 consecutive doubles at a stride of 4 doubles (32 bytes), i.e. every other 16-byte granule
+// of a 256-byte bank row -- lanes i and i + 8 would meet in the same banks (8-way conflicts on every window read: the /3 stage
+// behind the ingest ran LDS-bound at 1.05 ms for 57.6 M outputs).  Two doubles of padding after every 32 shift alternate
+// 256-byte rows by one granule: 16 consecutive lanes then cover all 16 granules of a bank row (4-way for 64 lanes = 1 KB
+// through a 256-byte port: the least there is).
+template <typename S> __device__ __forceinline__ int pp_swz(int col) { return sizeof(S) == 8 ? col + 2 * (col >> 5) : col; }
+static int pp_swz_stride(int cols, int esz) { return esz == 8 ? cols + 2 * (cols / 32 + 1) : cols; }
 template <int IN, typename OUT, bool ALIGNED, int Q4T, int MODE = 0>
-__global__ void __launch_bounds__(PP_THREADS, MODE == 1 ? PP_EXACT_WAVES : PP_MINB)
+__global__ void __launch_bounds__(PP_THREADS, MODE == 1 ? PP_EXACT_WAVES : MODE == 2 ? PP_F64_WAVES : PP_MINB)
 decimate_kernel(const void *__restrict__ in, long long n_in, long long first, int M, int log2m, const float *__restrict__ cp, int q4_arg,
                 OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign, int flush_rows = 0)
 {
@@ -240,7 +256,7 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
     // row index is uniform) -- as LDS broadcast reads, 16 bytes per lane, they cost the LDS pipe as much as the window reads
     // and the tap loop was LDS-bound -- and the next tile's first chunks are requested before the tap loop.  The short
     // stages behind it measure faster with the taps in LDS and without the prefetch.
-    constexpr bool SMEM = MODE == 1 || (MODE == 0 && PP_PAIRS && PP_TAPS_SMEM && ALIGNED), PF = PP_PREFETCH && (ALIGNED || MODE == 2);
+    constexpr bool SMEM = MODE == 1 || (MODE == 0 && PP_PAIRS && PP_TAPS_SMEM && ALIGNED), PF = PP_PREFETCH && (ALIGNED || (MODE == 2 && PP_F64_PF));
     constexpr int ACCW = MODE ? 2 : (int)(sizeof(pp_acc_t) / sizeof(float));         // floats per partial sum
     // (MODE 1 / 2 reserve exactly the partial sums the row groups exchange: the ingest then fits four workgroups per CU)
     float *cl = psum + (MODE ? ((((1 << rs_log2) - 1) << log2qw) * 4) : PP_THREADS * 4) * ACCW;
@@ -300,19 +316,18 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                     col = (w0 >= 0 ? w0 : w0 - (M - 1)) / M;
                     r = w0 - col * M;
                 }
-                int addr = r * row_stride + col;
                 if (ALIGNED) {      // the host aligned the window to the 16-byte grid and M >= PER16: one column, consecutive rows
+                    const int addr = r * row_stride + pp_swz<S>(col);
 #pragma unroll
                     for (int k = 0; k < A::PER16; ++k) xs[addr + k * row_stride] = e[k];
                 } else {
 #pragma unroll
                     for (int k = 0; k < A::PER16; ++k) {
-                        if (w0 + k >= 0 && w0 + k < G.win) xs[addr] = e[k];
+                        if (w0 + k >= 0 && w0 + k < G.win) xs[r * row_stride + pp_swz<S>(col)] = e[k];
                         ++r;
-                        addr += row_stride;
                         if (r == M) {
                             r = 0;
-                            addr -= M * row_stride - 1;
+                            ++col;
                         }
                     }
                 }
@@ -453,18 +468,19 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                 const int r0 = part * rows_per;
                 const double *cd = (const double *)cp;            // taps by scalar loads from the table in memory (the row index is uniform)
                 for (int r = r0; r < r0 + rows_per; ++r) {
-                    const S *row = xs + r * row_stride + 4 * g;
+                    const S *rowb = xs + r * row_stride;
                     const double *c = cd + r * 4 * q4;
                     double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
                     double wa[4], wb[4], wn[4];
-                    pp_load4d(row, wa);
-                    pp_load4d(row + 4, wb);
+                    pp_load4d(rowb + pp_swz<S>(4 * g), wa);
+                    pp_load4d(rowb + pp_swz<S>(4 * g + 4), wb);
                     double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+#pragma unroll PP_F64_UNROLL
                     for (int j = 0; j < q4; ++j) {
                         // the window columns and taps of the NEXT group are requested before this group's 16 FMAs
                         const double u0 = c0, u1 = c1, u2 = c2, u3 = c3;
                         if (j + 1 < q4) {
-                            pp_load4d(row + 4 * j + 8, wn);
+                            pp_load4d(rowb + pp_swz<S>(4 * g + 4 * j + 8), wn);
                             c0 = c[4 * j + 4]; c1 = c[4 * j + 5]; c2 = c[4 * j + 6]; c3 = c[4 * j + 7];
                         }
                         acc0 = fma(u0, wa[0], acc0); acc1 = fma(u0, wa[1], acc1); acc2 = fma(u0, wa[2], acc2); acc3 = fma(u0, wa[3], acc3);
@@ -703,9 +719,9 @@ int launch_decimate64(wfx_ctx *ctx, const void *in, long long n_in, long long fi
     const int esz = (int)sizeof(typename A::store_t);
     const int pad = esz == 2 ? 6 : 4;
     int tb = log2m < 0 ? 1024 : PP_TB_MAX;
-    while (tb > 64 && (size_t)(tb + 4 * q4 + pad) * M * esz > (size_t)PP_LDS_BYTES) tb >>= 1;
+    while (tb > 64 && (size_t)pp_swz_stride(tb + 4 * q4 + pad, esz) * M * esz > (size_t)PP_LDS_BYTES) tb >>= 1;
     if (log2m < 0 && tb < 1024) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
-    const int row_stride = tb + 4 * q4 + pad;
+    const int row_stride = pp_swz_stride(tb + 4 * q4 + pad, esz);
     const size_t lds_x = ((size_t)row_stride * M * esz + 15) & ~(size_t)15;
     // partial sums of the row groups, laid out as the kernel does: rs - 1 groups of (quads rounded up to whole waves) x 4
     const int log2tb = ilog2_exact(tb), log2q = log2tb - 2, log2qw = log2q < 6 ? 6 : log2q;
