@@ -342,6 +342,9 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
         __syncthreads();                       // the previous tile's compute phase is done with the LDS window
         // (PF: the tile's first batch of chunks was requested before the previous tile's compute phase)
         if (!PF) fetch(Gn, 0);
+#ifdef PP_F64_NOSTASH
+        if (MODE != 2 || n_out < 0)
+#endif
         stash(Gn, 0);
         for (int cb = PP_NB * PP_THREADS; cb < Gn.nchunks; cb += PP_NB * PP_THREADS) {
             fetch(Gn, cb);
@@ -464,7 +467,11 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
             }
         } else if constexpr (MODE == 2) {
             double tot0 = 0, tot1 = 0, tot2 = 0, tot3 = 0;
+#ifdef PP_F64_NOCOMPUTE
+            if (active && n_out < 0) {
+#else
             if (active) {
+#endif
                 const int r0 = part * rows_per;
                 const double *cd = (const double *)cp;            // taps by scalar loads from the table in memory (the row index is uniform)
                 for (int r = r0; r < r0 + rows_per; ++r) {
@@ -475,21 +482,28 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                     pp_load4d(rowb + pp_swz<S>(4 * g), wa);
                     pp_load4d(rowb + pp_swz<S>(4 * g + 4), wb);
                     double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-#pragma unroll PP_F64_UNROLL
-                    for (int j = 0; j < q4; ++j) {
-                        // the window columns and taps of the NEXT group are requested before this group's 16 FMAs
+                    // one group of 4 taps on the window (A = columns 0..3, B = 4..7); the columns and taps of the NEXT group are
+                    // requested first.  The three window arrays rotate by NAME over three consecutive groups (no register moves:
+                    // eight v_mov_b64 per group cost as much as half its FMAs).
+                    auto group = [&](const double (&A)[4], const double (&B)[4], double (&N)[4], int j) {
                         const double u0 = c0, u1 = c1, u2 = c2, u3 = c3;
                         if (j + 1 < q4) {
-                            pp_load4d(rowb + pp_swz<S>(4 * g + 4 * j + 8), wn);
+                            pp_load4d(rowb + pp_swz<S>(4 * g + 4 * j + 8), N);
                             c0 = c[4 * j + 4]; c1 = c[4 * j + 5]; c2 = c[4 * j + 6]; c3 = c[4 * j + 7];
                         }
-                        acc0 = fma(u0, wa[0], acc0); acc1 = fma(u0, wa[1], acc1); acc2 = fma(u0, wa[2], acc2); acc3 = fma(u0, wa[3], acc3);
-                        acc0 = fma(u1, wa[1], acc0); acc1 = fma(u1, wa[2], acc1); acc2 = fma(u1, wa[3], acc2); acc3 = fma(u1, wb[0], acc3);
-                        acc0 = fma(u2, wa[2], acc0); acc1 = fma(u2, wa[3], acc1); acc2 = fma(u2, wb[0], acc2); acc3 = fma(u2, wb[1], acc3);
-                        acc0 = fma(u3, wa[3], acc0); acc1 = fma(u3, wb[0], acc1); acc2 = fma(u3, wb[1], acc2); acc3 = fma(u3, wb[2], acc3);
-                        wa[0] = wb[0]; wa[1] = wb[1]; wa[2] = wb[2]; wa[3] = wb[3];
-                        wb[0] = wn[0]; wb[1] = wn[1]; wb[2] = wn[2]; wb[3] = wn[3];
+                        acc0 = fma(u0, A[0], acc0); acc1 = fma(u0, A[1], acc1); acc2 = fma(u0, A[2], acc2); acc3 = fma(u0, A[3], acc3);
+                        acc0 = fma(u1, A[1], acc0); acc1 = fma(u1, A[2], acc1); acc2 = fma(u1, A[3], acc2); acc3 = fma(u1, B[0], acc3);
+                        acc0 = fma(u2, A[2], acc0); acc1 = fma(u2, A[3], acc1); acc2 = fma(u2, B[0], acc2); acc3 = fma(u2, B[1], acc3);
+                        acc0 = fma(u3, A[3], acc0); acc1 = fma(u3, B[0], acc1); acc2 = fma(u3, B[1], acc2); acc3 = fma(u3, B[2], acc3);
+                    };
+                    int j = 0;
+                    for (; j + 3 <= q4; j += 3) {
+                        group(wa, wb, wn, j);
+                        group(wb, wn, wa, j + 1);
+                        group(wn, wa, wb, j + 2);
                     }
+                    if (q4 - j >= 1) group(wa, wb, wn, j);
+                    if (q4 - j >= 2) group(wb, wn, wa, j + 1);
                     tot0 += acc0; tot1 += acc1; tot2 += acc2; tot3 += acc3;
                 }
             }

@@ -293,7 +293,9 @@ class FrontEnd:
         _PAIR_CACHE[key] = (None, None, None, 0)
         fs1, fo1 = float(s1.fs_in), float(s1.fs_out)
         stops = [(k * fo1 - NYQ, min(k * fo1 + NYQ, fs1 / 2)) for k in range(1, int(fs1 / 2 // fo1) + 1) if k * fo1 - NYQ < fs1 / 2]
-        h1 = ls_fir(n1, fs1, [(0.0, NYQ)] + stops, [1.0] + [0.0] * len(stops), [1.0] + [30.0] * len(stops))
+        # (stop bands weighted 3000 : 1 -- the pass band may ripple by 1e-4, the second filter follows it anyway: -149 dB instead of
+        # -133 dB before the taps are put on their grid, -138 dB after)
+        h1 = ls_fir(n1, fs1, [(0.0, NYQ)] + stops, [1.0] + [0.0] * len(stops), [1.0] + [3000.0] * len(stops))
         h1 /= h1.sum()
         sh1 = fix_shift_for(h1)
         if sh1 < MIN_FIX_SHIFT:
@@ -301,8 +303,10 @@ class FrontEnd:
         if sh1:
             h1 = quantize_taps(h1, sh1)              # what the integer-exact kernel applies; the second filter is designed against THIS response
         fs2, fo2 = float(s2.fs_in), float(s2.fs_out)
-        n2 = (s2.ntaps + 32) | 1                     # more taps than the plain low-pass: the pass band has a shape to follow, and at 119
-        #                                              taps the PAIR is flat to 3e-10 (95 taps: 2e-8, which still flipped 0-3 stream bytes per clip)
+        # a few more taps than the plain low-pass: the pass band now has a shape to follow.  95 taps make the PAIR flat to 2e-8;
+        # 119 taps reach 3e-10 but measured no fewer flipped stream bytes (0-5 per 1.536 MS/s clip either way: what is left is
+        # the first filter's -132 dB stop band folding out-of-band noise into the band) for a quarter more work in this stage
+        n2 = (s2.ntaps + int(os.environ.get("WFX_FE_N2_EXTRA", "8"))) | 1
         h2 = ls_fir(n2, fs2, [(0.0, NYQ), (fo2 - NYQ, fs2 / 2)], [lambda f: 1.0 / _response(h1, fs1, f), 0.0], [1.0, 1.0], grid=1200, iters=14)
         # verify before adopting
         fp = np.linspace(0.0, NYQ, 3000)
