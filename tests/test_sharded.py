@@ -50,11 +50,29 @@ def test_layout_tiles_the_capture_and_the_exchange_lists_are_consistent(n0, sr, 
         nat.shard_dry_run(p, world)          # raises if two ends of a message disagree, a receive leaves its buffer, ...
 
 
+@pytest.mark.parametrize("n0", [2 * 1000003, 1433252, 7166252, 2 * 3583126 + 2, 9000 * 2 + 2, 39690002, 2 * 104729, 600000 + 2 * 7919])
+def test_any_even_length_at_the_native_rate_gets_a_padded_plan(n0):
+    """An 11 025 Hz capture whose half-length has a prime factor above 13 (i.e. almost every real recording) is sharded too: the
+    Hilbert convolution is embedded in a 13-smooth transform of Kp >= n - 1 points whose rows are dealt to the ranks; a rank owns
+    the samples of its rows that lie inside the capture (the ranks whose rows are all padding own none and still take part in
+    every exchange).  The layouts tile the capture and every rank's exchange lists agree (host-only dry run)."""
+    p, meta = build_params(0, n0, 11025, 0.5)
+    for world in (1, 2, 3, 8):
+        if n0 < 40000 and world == 8:
+            continue
+        lays = [nat.shard_layout(p, world, r) for r in range(world)]
+        assert lays[0].own_lo == 0 and lays[-1].own_hi == n0
+        assert all(lays[i].own_hi == lays[i + 1].own_lo for i in range(world - 1))
+        sizes = [lay.own_hi - lay.own_lo for lay in lays]
+        assert all(sz == 0 or sz >= 4096 for sz in sizes) and sizes[0] > 0
+        assert all(lay.in_lo == max(0, lay.own_lo - 32) and lay.in_hi == min(n0, lay.own_hi + 32) for lay in lays if lay.own_hi > lay.own_lo)
+        nat.shard_dry_run(p, world)
+
+
 def test_captures_that_cannot_be_sharded_are_refused_with_a_reason():
     for n0, sr, world, what in [(1433251, 11025, 2, "even"),            # odd length: the transforms are packed
-                                (2 * 1000003, 11025, 2, "13-smooth"),    # a large prime factor
-                                (4000, 11025, 8, "ranks"),               # too short for the world size
-                                (749700, 22050, 2, "13-smooth")]:        # 34 s at 22 050 Hz: a factor 17 in both transforms
+                                (4000, 11025, 8, "short"),               # too short for the world size
+                                (749700, 22050, 2, "13-smooth")]:        # 34 s at 22 050 Hz: a factor 17 in both transforms (resampled: no padded form yet)
         p, _ = build_params(0 if sr == 11025 else 2, n0, sr, 0.5)
         with pytest.raises(nat.NativeError) as e:
             nat.shard_layout(p, world, 0)
@@ -279,6 +297,41 @@ def test_a_bad_unique_id_is_a_comm_error_not_a_crash():
         nat.Comm.rccl(ctx, bytes(128), 1, 3)         # rank outside the world
     assert "rank" in str(e.value)
     ctx.close()
+
+
+def _arbitrary_even_lengths(count, seed, lo, hi):
+    rng = np.random.default_rng(seed)
+    return [int(2 * rng.integers(lo // 2, hi // 2)) for _ in range(count)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", _arbitrary_even_lengths(6, 21, 300000, 900000) + [2 * 200003, 1433252])
+def test_sharded_decode_of_any_even_length_equals_the_oracle(n):
+    """Arbitrary even lengths at 11 025 Hz (random, a prime times two, the 130-s capture plus two samples) through the padded
+    distributed convolution, worlds 1 / 2 / 3 / 8: stream, peaks, start_frame, image equal to the oracle's; the float stages do
+    not depend on the world size; decoding twice (the second decode skips the kernel's transform) gives the same again."""
+    lines = max(20, int(n / 5512.5) - 40)
+    x = synth.synth_capture(11025.0, noise=0.05, seed=n % 1000, start_tone_s=2.0, phasing_lines=20, image_lines=lines, stop_tone_s=1.0, black_tail_s=1.0)
+    x = np.concatenate([x, x[:max(0, n - x.shape[0])]])[:n]
+    assert x.shape[0] == n
+    ref = _oracle(x, 11025, 120)
+    first = None
+    for world in (1, 2, 3, 8):
+        r = sharded.decode_emulated(x, 11025, world, 120, repeat=2)
+        assert np.array_equal(r["digitalized"], ref["digitalized"]), f"world {world}: uint8 stream differs"
+        assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
+        if ref.get("exception") is None:
+            assert r["sync"]["start_frame"] == ref["start_frame"] and r["sync"]["peaks"] == [int(v) for v in ref["peaks"]]
+            assert np.array_equal(r["image"], ref["image"])
+        else:
+            assert r["sync"]["no_group"]
+        assert len(set(r["lows"])) == 1 and len(set(r["highs"])) == 1
+        scale = np.max(np.abs(ref["demod"]))
+        assert np.max(np.abs(r["envelope"] - ref["demod"])) <= 1e-9 * scale
+        if first is None:
+            first = r
+        else:
+            assert np.array_equal(r["envelope"], first["envelope"]) and r["low"] == first["low"] and r["high"] == first["high"]
 
 
 @pytest.mark.gpu

@@ -7,6 +7,7 @@ TAG=${1:-evidence}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export WFX_EVIDENCE_TAG="profiles/$TAG ($(python -c "import hashlib,glob;h=hashlib.sha1();[h.update(open(f,'rb').read()) for f in sorted(glob.glob('wefax_amd/csrc/*.h*'))];print('csrc sha1 '+h.hexdigest()[:12])"))"
 
 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1
 grep -E "passed|failed" "$OUT/pytest_gpu.log" | tail -1
@@ -67,11 +68,22 @@ rm -rf "$OUT/trace_iq" "$OUT/pmc_fetch_iq" "$OUT/pmc_write_iq"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -o run -- python3 bench.py --workload c3 --steps 5 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
 python tools/kstats.py "$OUT/trace_c3" "select_|notch|median|image|quantise|sync|mr2_pass|mr_pass|resample" > "$OUT/kernel_stats_c3.txt"
 rm -rf "$OUT/trace_c3"
+# BASELINE configs[2] asks for "rocprof HBM GB/s": FETCH_SIZE / WRITE_SIZE per kernel, separate passes
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c3" -o run -- python3 bench.py --workload c3 --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c3" -o run -- python3 bench.py --workload c3 --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+python tools/pmc_summary.py "$OUT/pmc_fetch_c3" "$OUT/pmc_write_c3" "$OUT/pmc_traffic_c3.json" > /dev/null 2>&1
+rm -rf "$OUT/pmc_fetch_c3" "$OUT/pmc_write_c3"
+
+# N real processes on this ONE GPU (shared-memory transport): spawn -> rendezvous -> every phase -> gather, checked against the oracle
+for g in 2 4 8; do
+  WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus $g --shard --steps 3 --warmup 1 --no-c4 --no-cpu-loops > "$OUT/bench_shard_shm$g.json" 2>> "$OUT/bench.err"
+done
+WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 --no-pcie --no-cpu > "$OUT/bench_c4_shm8.json" 2>> "$OUT/bench.err"
 
 # randomised whole-path parity sweep against the oracle
 timeout 1200 python tools/random_parity.py --cases 200 --seed 11 > "$OUT/random_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_parity.jsonl"
 
-timeout 1200 python tools/random_fe_parity.py --cases 12 --seed 8 > "$OUT/random_fe_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_fe_parity.jsonl"
+timeout 2400 python tools/random_fe_parity.py --cases 200 --seed 8 > "$OUT/random_fe_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_fe_parity.jsonl" | cut -c1-400
 timeout 1200 python tools/random_shard_parity.py --cases 24 --seed 5 > "$OUT/random_shard_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_shard_parity.jsonl"
 
 # the read-streaming ceiling of this box and the ingest stage against it

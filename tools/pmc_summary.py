@@ -27,7 +27,8 @@ GROUPS = [
     (r"image_kernel", "lines_to_image"), (r"median5_kernel", "median5"), (r"fir_hilbert", "fir_analytic"),
     (r"merge_kernel|i16_to_f64", "merge_channels"), (r"bs_|hilbert_mid|hconv_fill|hconv_pack", "bluestein_pointwise"),
     (r"resample_", "resample_pointwise"),
-    (r"decimate_kernel<[01],", "polyphase_ingest"), (r"decimate_kernel<3,|rational_kernel", "polyphase_stages"),
+    (r"decimate_kernel<[01],", "polyphase_ingest"), (r"decimate_kernel<[23],|rational_kernel", "polyphase_stages"),
+    (r"mr_padded_fill", "bluestein_pointwise"),
     (r"select_level_kernel", "select_hist"), (r"quantise_kernel", "quantise"),
 ]
 
@@ -80,6 +81,9 @@ def main():
             "hbm_bytes_per_launch": int(round((2.0 * f_kib + w_kib) * 1024)),
             "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as is",
         }
+    # where and when these counters were taken: bench.py quotes it next to `roofline.traffic` (the line itself does not run rocprofv3)
+    res["_collected_at"] = os.environ.get("WFX_EVIDENCE_TAG", "unknown tree") + ", per-launch means over " + ", ".join(
+        f"{g}: {v['launches_seen'][0]}" for g, v in list(res.items())[:3]) + " ... launches"
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))

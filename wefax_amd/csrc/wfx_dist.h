@@ -32,7 +32,7 @@ struct wfx_dist_geom {       // what all transforms of one sharded decode share
 // host-only: partitions for a first radix (ra1, rb1); false when the world is too large for it
 bool wfx_dist_make_geom(wfx_dist_geom &g, int world, int rank, int ra1, int rb1);
 // host-only: first radix for transforms of the given lengths (all must be multiples of it with pair-decomposable cofactors)
-bool wfx_dist_choose_r1(const long long *lengths, int nlen, int world, int *ra1, int *rb1);
+bool wfx_dist_choose_r1(const long long *lengths, int nlen, int world, int *ra1, int *rb1, bool pairs_required = false);
 
 struct wfx_dist_piece {      // one 2-D block of a packing / unpacking copy (device descriptor)
     unsigned long long src, dst;         // element-typed base addresses
@@ -70,7 +70,9 @@ class wfx_dist {
     int fwd_pack_exchange(wfx_comm *c, const void *rows_in);                       // E1
     int fwd_pass1_exchange(wfx_comm *c, int in_mode);                              // pass 1, E2
     // passes 2..np; bins with skip_lo < k < skip_hi (global indices) are not stored by the last one (skip_hi == 0: all are)
-    int fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo = 0, long long skip_hi = 0);
+    // gtab: the last pass multiplies output o (slab layout) by gtab[o] -- a zero-padded convolution's transformed kernel,
+    // computed by these very passes (any-length sharded Hilbert transform); needs radix-pair passes
+    int fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo = 0, long long skip_hi = 0, const cplx *gtab = nullptr);
     // ---- inverse ---------------------------------------------------------------------------------------------------
     // slab_in: [M][B] in one of slab_buffer(0 / 1); destroyed
     int inv_slab_exchange(wfx_comm *c, cplx *slab_in);                             // passes np..2, E3

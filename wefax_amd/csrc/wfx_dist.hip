@@ -41,7 +41,7 @@ bool wfx_dist_make_geom(wfx_dist_geom &g, int world, int rank, int ra1, int rb1)
     return true;
 }
 
-bool wfx_dist_choose_r1(const long long *lengths, int nlen, int world, int *ra1, int *rb1)
+bool wfx_dist_choose_r1(const long long *lengths, int nlen, int world, int *ra1, int *rb1, bool pairs_required)
 {
     // largest first radix that divides every length, leaves pair-decomposable cofactors and gives every rank work:
     // a large R1 balances rows / slabs over the ranks and keeps the first pass's tiles wide
@@ -49,7 +49,7 @@ bool wfx_dist_choose_r1(const long long *lengths, int nlen, int world, int *ra1,
     wfx_mr_all_pairs(cand);
     std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first * x.second > y.first * y.second; });
     // first choice: every remaining pass a register-resident radix pair; otherwise any 13-smooth cofactor (per-prime passes)
-    for (int pairs_only = 1; pairs_only >= 0; --pairs_only)
+    for (int pairs_only = 1; pairs_only >= (pairs_required ? 1 : 0); --pairs_only)
         for (const auto &c : cand) {
             const int R1 = c.first * c.second;
             wfx_dist_geom g;
@@ -497,7 +497,7 @@ int wfx_dist::fwd_pass1_exchange(wfx_comm *c, int in_mode)
     return wfx_comm_exchange(c, ctx, x2.data(), (int)x2.size());
 }
 
-int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo, long long skip_hi)
+int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo, long long skip_hi, const cplx *gtab)
 {
     const cplx *tb = (const cplx *)tables.p;
     cplx *src = (cplx *)b_a.p, *dst = (cplx *)b_a2.p;
@@ -509,7 +509,13 @@ int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo,
             d.skip_hi = skip_hi;
         }
         const bool skipping = d.skip_hi != 0;
-        WFX_TRY(wfx_mr_launch(ctx, d, tb + tw_fwd[i], 0, (hilbert_spectrum && i == ns - 1) ? 1 : ((skipping && d.ra > 0) ? 3 : 0), 0, src, dst));
+        int out_mode = (hilbert_spectrum && i == ns - 1) ? 1 : ((skipping && d.ra > 0) ? 3 : 0);
+        if (gtab && i == ns - 1) {
+            if (d.ra <= 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed padded convolution needs radix-pair passes");
+            d.gtab = (const double2 *)gtab;
+            out_mode = 4;
+        }
+        WFX_TRY(wfx_mr_launch(ctx, d, tb + tw_fwd[i], 0, out_mode, 0, src, dst));
         std::swap(src, dst);
     }
     *spectrum = src;

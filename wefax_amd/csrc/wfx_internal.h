@@ -318,6 +318,8 @@ int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_
 // radix-pair plan (at most a few per cent above n - 1); *handled = 0 when no such M exists (tiny n): the caller pads to 2^k
 int wfx_dev_hilbert_conv_mr_padded(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out, int *handled);
 long long wfx_mr_padded_length(long long min_len);
+void wfx_mr_smooth_numbers(long long lo, long long hi, std::vector<long long> &out);       // ascending 13-smooth numbers in [lo, hi]
+int wfx_dev_hilbert_kernel_rows(wfx_ctx *ctx, cplx *dst, long long p0, long long count, long long N, long long M);
 bool wfx_mr_resample_supported(uint64_t n0, uint64_t num);
 int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16 = false);
 

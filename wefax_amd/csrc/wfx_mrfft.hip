@@ -1474,6 +1474,13 @@ static void smooth_candidates(long long lo, long long hi, long long cur, int pi,
     }
 }
 
+void wfx_mr_smooth_numbers(long long lo, long long hi, std::vector<long long> &out)
+{
+    out.clear();
+    smooth_candidates(lo, hi, 1, 0, out);
+    std::sort(out.begin(), out.end());
+}
+
 long long wfx_mr_padded_length(long long min_len)
 {
     if (min_len >= (1ll << 31)) return 0;
@@ -1516,6 +1523,27 @@ __global__ void __launch_bounds__(256) mr_padded_fill(cplx *__restrict__ G, long
         }
         G[i] = make_double2(v, 0.0);
     }
+}
+
+// rows of the same padded kernel for a distributed transform: points [p0, p0 + count) of g_ext / M (wfx_shard.hip)
+__global__ void __launch_bounds__(256) mr_padded_fill_range(cplx *__restrict__ G, long long p0, long long count, long long N, long long L, long long M, double inv_m)
+{
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < count; e += (long long)gridDim.x * 256ll) {
+        const long long i = p0 + e;
+        double v = 0.0;
+        if (i < L || M - i < L) {
+            const long long j = i < L ? i : i - M;
+            v = mr_hilbert_tap_even(2 * j - 1, N) * inv_m;
+        }
+        G[e] = make_double2(v, 0.0);
+    }
+}
+
+int wfx_dev_hilbert_kernel_rows(wfx_ctx *ctx, cplx *dst, long long p0, long long count, long long N, long long M)
+{
+    if (count <= 0) return 0;
+    WFX_LAUNCH(ctx, K_BS_CHIRP, mr_padded_fill_range, dim3(wfx_stream_grid((uint64_t)count, 256)), dim3(256), dst, p0, count, N, N / 2, M, 1.0 / (double)M);
+    return 0;
 }
 
 struct mr_padded_cache {

@@ -30,6 +30,13 @@ struct shard_plan {
     int in_kind = 0;
     uint64_t n0 = 0, n = 0;
     long long M1 = 0, K = 0, M1s = 0, Ms = 0;
+    // any even length (round 3): when K = n / 2 has no distributed plan the Hilbert convolution is embedded in a transform of
+    // Kp >= 2K - 1 points (13-smooth, radix pairs only); the rows of THAT arrangement are dealt to the ranks, so a rank owns the
+    // samples of its rows that lie inside the capture -- the ranks whose rows are all padding own none (they still take part in
+    // every transform and collective)
+    bool padded = false;
+    long long Kp = 0;
+    int wrap_rank = 0;                    // the rank holding the capture's last pair: it needs V[0] from rank 0 as "V[K]"
     uint64_t own_lo = 0, own_hi = 0, in_lo = 0, in_hi = 0;
     uint64_t seg_lo = 0, seg_hi = 0;      // samples at 11 025 Hz held for the notch
 };
@@ -56,21 +63,57 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     pl.M1 = (long long)(p->n0 / 2);
     long long lens[2] = {pl.K, pl.M1};
     int ra1 = 0, rb1 = 0;
-    if (!wfx_dist_choose_r1(lens, pl.resample ? 2 : 1, world, &ra1, &rb1))
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG,
-                        "sharded decode: no distributed transform plan for %llu%s samples on %d ranks (half-lengths must be 13-smooth multiples "
-                        "of a common first radix)",
-                        (unsigned long long)p->n, pl.resample ? " (resampled)" : "", world);
+    pl.Kp = pl.K;
+    if (!wfx_dist_choose_r1(lens, pl.resample ? 2 : 1, world, &ra1, &rb1)) {
+        // no plan for the capture's own half-length: pad the Hilbert convolution (a capture that is resampled on the way would
+        // need the same for its two other transforms, whose lengths are the reference's to choose: not built)
+        bool found = false;
+        if (!pl.resample && pl.K >= 4096) {
+            std::vector<long long> cand;
+            wfx_mr_smooth_numbers(2 * pl.K - 1, (2 * pl.K - 1) + (2 * pl.K - 1) / 8, cand);
+            for (long long m : cand) {
+                if (m >= (1ll << 31)) break;
+                if (!wfx_dist_choose_r1(&m, 1, world, &ra1, &rb1, true)) continue;
+                // the rank whose rows straddle the capture's end must own a workable number of samples (or none)
+                const int r1 = ra1 * rb1;
+                const long long ms = m / r1;
+                bool fine = true;
+                for (int r = 0; r < world && fine; ++r) {
+                    const long long a = (long long)r * r1 / world * ms, b = (long long)(r + 1) * r1 / world * ms;
+                    const long long own = (b < pl.K ? b : pl.K) - (a < pl.K ? a : pl.K);
+                    if (own > 0 && own < 2048) fine = false;
+                }
+                if (!fine) continue;
+                pl.Kp = m;
+                pl.padded = found = true;
+                break;
+            }
+        }
+        if (!found)
+            return wfx_fail(ctx, WFX_ERR_BAD_ARG,
+                            "sharded decode: no distributed transform plan for %llu%s samples on %d ranks (%s)",
+                            (unsigned long long)p->n, pl.resample ? " (resampled)" : "", world,
+                            pl.resample ? "a resampled capture's half-lengths must be 13-smooth multiples of a common first radix"
+                                        : "the capture is too short for a padded plan");
+    }
     if (!wfx_dist_make_geom(pl.g, world, rank, ra1, rb1)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: geometry");
     const int R1 = pl.g.R1;
-    pl.Ms = pl.K / R1;
+    pl.Ms = pl.Kp / R1;
     pl.M1s = pl.M1 / R1;
-    pl.own_lo = 2ull * (uint64_t)pl.g.rows[rank] * (uint64_t)pl.Ms;
-    pl.own_hi = 2ull * (uint64_t)pl.g.rows[rank + 1] * (uint64_t)pl.Ms;
+    auto clipK = [&](long long pts) { return (uint64_t)(pts < pl.K ? pts : pl.K); };
+    pl.own_lo = 2ull * clipK((long long)pl.g.rows[rank] * pl.Ms);
+    pl.own_hi = 2ull * clipK((long long)pl.g.rows[rank + 1] * pl.Ms);
+    pl.wrap_rank = 0;
+    for (int r = 0; r < world; ++r)
+        if ((long long)pl.g.rows[r] * pl.Ms < pl.K) pl.wrap_rank = r;           // the last rank that owns samples
     pl.seg_lo = pl.own_lo >= SH_HALO ? pl.own_lo - SH_HALO : 0;
     pl.seg_hi = pl.own_hi + SH_HALO <= pl.n ? pl.own_hi + SH_HALO : pl.n;
-    if (rank > 0 && pl.own_lo < SH_HALO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
-    if (pl.own_hi - pl.own_lo < 1024) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
+    if (pl.own_hi == pl.own_lo) pl.seg_lo = pl.seg_hi = pl.own_lo;                // a rank of padding rows: nothing to filter
+    if (rank > 0 && pl.own_hi > pl.own_lo && pl.own_lo < SH_HALO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
+    if (pl.own_hi - pl.own_lo < 1024 && !(pl.padded && rank > 0))
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
+    if (pl.padded && pl.own_hi > pl.own_lo && pl.own_hi - pl.own_lo < 64)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
     if (pl.resample) {
         pl.in_lo = 2ull * (uint64_t)pl.g.rows[rank] * (uint64_t)pl.M1s;
         pl.in_hi = 2ull * (uint64_t)pl.g.rows[rank + 1] * (uint64_t)pl.M1s;
@@ -88,6 +131,8 @@ struct wfx_shard {
     shard_plan pl;
     wfx_dist dF, dI, dH;                  // resampler forward / inverse, Hilbert
     wfx_devbuf b_in, b_merged, b_res, b_audio, b_v, b_env, b_dig, b_blk, b_blks, b_nan, b_flags;
+    wfx_devbuf b_grow, b_ghat;            // padded form: this rank's rows of the kernel g_ext / Kp, and its slab of the kernel's transform
+    bool ghat_ready = false;              // computed by three extra phases in front of the first decode
     const void *ext_in = nullptr;
     bool have_input = false, ran = false, bound = false;
     uint64_t cap = SH_CAND_CAP;
@@ -112,8 +157,17 @@ static int shard_bind(wfx_shard *sh)
     const uint64_t n_own = pl.own_hi - pl.own_lo, n_seg = pl.seg_hi - pl.seg_lo;
     const void *in = sh->ext_in ? sh->ext_in : sh->b_in.p;
     // audio segment [seg_lo, seg_hi): the notch output; the Hilbert transform's input rows start at own_lo
-    WFX_TRY(wfx_reserve(ctx, sh->b_audio, n_seg * 8 + 64));
+    // (padded form: the Hilbert transform reads all nr Ms points of the rank's rows starting at its first own sample; what lies
+    // beyond the capture is the zero padding -- the notch never writes there, one memset at binding time is enough)
+    const size_t audio_bytes = pl.padded ? std::max((size_t)n_seg, (size_t)(pl.own_lo - pl.seg_lo) + 2 * (size_t)nr * (size_t)pl.Ms) * 8 + 64 : n_seg * 8 + 64;
+    const bool audio_moved = !sh->b_audio.p || sh->b_audio.cap < audio_bytes;
+    WFX_TRY(wfx_reserve(ctx, sh->b_audio, audio_bytes));
+    if (pl.padded && (audio_moved || !sh->bound)) WFX_HIP(ctx, hipMemsetAsync(sh->b_audio.p, 0, audio_bytes, ctx->stream));
     WFX_TRY(wfx_reserve(ctx, sh->b_v, (size_t)(2 * SH_VHALO + nr * pl.Ms) * sizeof(cplx) + 64));
+    if (pl.padded) {
+        WFX_TRY(wfx_reserve(ctx, sh->b_grow, (size_t)nr * pl.Ms * sizeof(cplx) + 64));
+        WFX_TRY(wfx_reserve(ctx, sh->b_ghat, (size_t)sh->dH.slab_points() * sizeof(cplx) + 64));
+    }
     WFX_TRY(wfx_reserve(ctx, sh->b_env, n_own * 8 + 64));
     WFX_TRY(wfx_reserve(ctx, sh->b_dig, (me == 0 ? pl.n : n_own) + 64));
     WFX_TRY(wfx_reserve(ctx, sh->b_blk, wfx_select_block_bytes(sh->cap)));
@@ -136,13 +190,15 @@ static int shard_bind(wfx_shard *sh)
     } else if (pl.in_kind == WFX_IN_I16_STEREO) {
         WFX_TRY(wfx_reserve(ctx, sh->b_merged, (pl.in_hi - pl.in_lo) * 8 + 64));
     }
-    WFX_TRY(sh->dH.bind(audio_own, (cplx *)sh->b_v.p, sh->dH.fwd_result_index()));
+    // (until the kernel's transform exists the Hilbert transform's forward half is bound to the kernel's rows: see run_phase)
+    WFX_TRY(sh->dH.bind((pl.padded && !sh->ghat_ready) ? (const void *)sh->b_grow.p : (const void *)audio_own, (cplx *)sh->b_v.p, sh->dH.fwd_result_index()));
     sh->bound = true;
     return 0;
 }
 
 // ---- the phases ------------------------------------------------------------------------------------------------
-static int phase_count(const wfx_shard *sh) { return sh->pl.resample ? 13 : 9; }
+// padded form: + 1 phase (the wrap of V, see phase 8) and, in front of the first decode, + 3 (the kernel's transform)
+static int phase_count(const wfx_shard *sh) { return sh->pl.resample ? 13 : (sh->pl.padded ? (sh->ghat_ready ? 10 : 13) : 9); }
 
 static int run_phase(wfx_shard *sh, int ph)
 {
@@ -157,7 +213,44 @@ static int run_phase(wfx_shard *sh, int ph)
     double *audio = (double *)sh->b_audio.p;
     double *env = (double *)sh->b_env.p;
     uint8_t *dig_own = (uint8_t *)sh->b_dig.p + (me == 0 ? pl.own_lo : 0);
+    if (pl.padded && !sh->ghat_ready) {
+        // ---- the padded convolution's kernel, transformed once per shard: rows -> E1 -> pass 1 -> E2 -> slab passes ----
+        if (ph == 0) {
+            WFX_TRY(wfx_dev_hilbert_kernel_rows(ctx, (cplx *)sh->b_grow.p, (long long)pl.g.rows[me] * pl.Ms, (long long)pl.g.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
+            return sh->dH.fwd_pack_exchange(c, sh->b_grow.p);
+        }
+        if (ph == 1) return sh->dH.fwd_pass1_exchange(c, 0);
+        if (ph == 2) {
+            cplx *G = nullptr;
+            WFX_TRY(sh->dH.fwd_slab(0, &G));
+            WFX_HIP(ctx, hipMemcpyAsync(sh->b_ghat.p, G, (size_t)sh->dH.slab_points() * sizeof(cplx), hipMemcpyDeviceToDevice, ctx->stream));
+            // from here on the forward half reads the audio rows (re-binding rebuilds the E1 lists: a host synchronisation, once)
+            return sh->dH.bind(audio + (pl.own_lo - pl.seg_lo), (cplx *)sh->b_v.p, sh->dH.fwd_result_index());
+        }
+        ph -= 3;
+    }
     if (!pl.resample) ph += 4;              // phases 0..3 are the resampler's
+    if (pl.padded && ph >= 8) {             // one phase more than the unpadded form: 8 = unpack + wrap, 9.. = the old 8..
+        if (ph == 8) {
+            // the cyclic result's V[K] is V[0] (H[N - 1] sits in its .y): it lives on rank 0, the rank that holds the capture's
+            // last pair needs it where its rows continue into the padding (the padded convolution left garbage there)
+            WFX_TRY(sh->dH.inv_unpack((cplx *)sh->b_v.p));
+            cplx *vown = (cplx *)sh->b_v.p + SH_VHALO;
+            wfx_xfer x{};
+            x.peer = me == 0 ? pl.wrap_rank : 0;
+            if (me == 0) {
+                x.send = vown;
+                x.send_bytes = sizeof(cplx);
+            }
+            if (me == pl.wrap_rank) {
+                x.recv = vown + (pl.K - (long long)pl.g.rows[me] * pl.Ms);
+                x.recv_bytes = sizeof(cplx);
+            }
+            if (me == 0 && pl.wrap_rank == 0) x.peer = 0;
+            return (x.send_bytes || x.recv_bytes) ? wfx_comm_exchange(c, ctx, &x, 1) : wfx_comm_exchange(c, ctx, &x, 0);
+        }
+        ph -= 1;
+    }
     switch (ph) {
     case 0: {   // a4 + a5 first exchange: input rows -> columns
         WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
@@ -184,7 +277,7 @@ static int run_phase(wfx_shard *sh, int ph)
             nkind = WFX_IN_F64_MONO;
         } else {
             WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
-            if (pl.in_kind == WFX_IN_I16_STEREO) {
+            if (pl.in_kind == WFX_IN_I16_STEREO && n_seg) {
                 WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, n_seg, (double *)sh->b_merged.p));
                 nin = sh->b_merged.p;
                 nkind = WFX_IN_F64_MONO;
@@ -197,23 +290,26 @@ static int run_phase(wfx_shard *sh, int ph)
             ext18[i] = p.ext_left[i];
             ext18[9 + i] = p.ext_right[i];
         }
-        WFX_TRY(wfx_dev_notch_fir_only(ctx, nin, nkind, n_seg, p.notch_b, p.notch_a, audio, flags, use_ext ? ext18 : nullptr));
+        if (n_seg) WFX_TRY(wfx_dev_notch_fir_only(ctx, nin, nkind, n_seg, p.notch_b, p.notch_a, audio, flags, use_ext ? ext18 : nullptr));
         return sh->dH.fwd_pack_exchange(c, audio + (pl.own_lo - pl.seg_lo));
     }
     case 5: return sh->dH.fwd_pass1_exchange(c, 1);
     case 6: {
         cplx *G = nullptr;
-        WFX_TRY(sh->dH.fwd_slab(1, &G));
+        if (pl.padded)
+            WFX_TRY(sh->dH.fwd_slab(0, &G, 0, 0, (const cplx *)sh->b_ghat.p));
+        else
+            WFX_TRY(sh->dH.fwd_slab(1, &G));
         return sh->dH.inv_slab_exchange(c, G);
     }
     case 7: return sh->dH.inv_pass1_exchange(c, (cplx *)sh->b_v.p);
     case 8: {   // a7 envelope + median, level-0 histogram; first all-reduce
-        WFX_TRY(sh->dH.inv_unpack((cplx *)sh->b_v.p));
+        if (!pl.padded) WFX_TRY(sh->dH.inv_unpack((cplx *)sh->b_v.p));         // (padded: done with the wrap, one phase earlier)
         WFX_TRY(wfx_dev_select_sharded_ws(ctx, &sh->ws));
-        // pointers indexed by global pair / sample index
+        // pointers indexed by global pair / sample index (the rank's rows start at pair rows[me] Ms = own_lo / 2 when it owns samples)
         const cplx *Vg = (const cplx *)sh->b_v.p - ((long long)(pl.own_lo / 2) - SH_VHALO);
         const double *xg = audio - (long long)pl.seg_lo;
-        WFX_TRY(wfx_dev_env_median_block(ctx, Vg, xg, pl.n, pl.own_lo, pl.own_hi, env, sh->ws));
+        if (n_own) WFX_TRY(wfx_dev_env_median_block(ctx, Vg, xg, pl.n, pl.own_lo, pl.own_hi, env, sh->ws));
         return wfx_comm_allreduce_u32(c, ctx, sh->ws, WFX_SEL_BINS);
     }
     case 9: {
@@ -227,16 +323,18 @@ static int run_phase(wfx_shard *sh, int ph)
     }
     case 11: {  // a8 finish + quantise; the one gather of the stream
         WFX_TRY(wfx_dev_select_finish_blocks(ctx, sh->ws, ds, sh->b_blks.p, W, sh->cap, p.gamma_lo, p.gamma_hi, (unsigned *)sh->b_flags.p));
-        WFX_TRY(wfx_dev_quantise(ctx, env, n_own, ds, dig_own, ds));
+        if (n_own) WFX_TRY(wfx_dev_quantise(ctx, env, n_own, ds, dig_own, ds));
         std::vector<wfx_xfer> xs;
         if (me == 0) {
             for (int s = 1; s < W; ++s) {
-                const uint64_t lo = 2ull * (uint64_t)pl.g.rows[s] * (uint64_t)pl.Ms, hi = 2ull * (uint64_t)pl.g.rows[s + 1] * (uint64_t)pl.Ms;
+                uint64_t lo = 2ull * (uint64_t)pl.g.rows[s] * (uint64_t)pl.Ms, hi = 2ull * (uint64_t)pl.g.rows[s + 1] * (uint64_t)pl.Ms;
+                lo = lo < pl.n ? lo : pl.n;                      // (padded form: rows beyond the capture hold no samples)
+                hi = hi < pl.n ? hi : pl.n;
                 wfx_xfer a{};
                 a.peer = s;
                 a.recv = (uint8_t *)sh->b_dig.p + lo;
                 a.recv_bytes = hi - lo;
-                xs.push_back(a);
+                if (a.recv_bytes) xs.push_back(a);
                 wfx_xfer b{};
                 b.peer = s;
                 b.recv = (unsigned long long *)sh->b_nan.p + s;
@@ -248,7 +346,7 @@ static int run_phase(wfx_shard *sh, int ph)
             a.peer = 0;
             a.send = dig_own;
             a.send_bytes = n_own;
-            xs.push_back(a);
+            if (n_own) xs.push_back(a);
             wfx_xfer b{};
             b.peer = 0;
             b.send = &ds->nan_count;
@@ -400,7 +498,7 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
         WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward"));
         WFX_TRY(dry_check_transform(pl, p, pl.K, 16, SH_HALO / 2, SH_HALO / 2, false, true, "resample inverse"));
     }
-    return dry_check_transform(pl, p, pl.K, 16, SH_VHALO, SH_VHALO, true, true, "hilbert");
+    return dry_check_transform(pl, p, pl.Kp, 16, SH_VHALO, SH_VHALO, true, true, pl.padded ? "hilbert (padded)" : "hilbert");
 }
 
 #define CHECK_SH(sh)                                                                                              \
@@ -453,7 +551,7 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
         rc = sh->dF.init(ctx, pl.g, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0);
         if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, SH_HALO / 2, SH_HALO / 2);
     }
-    if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.K, 16, SH_VHALO, SH_VHALO);
+    if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.Kp, 16, SH_VHALO, SH_VHALO);
     if (rc != 0) {
         wfx_shard_destroy(sh);
         return rc;
@@ -466,12 +564,12 @@ int wfx_shard_upload(wfx_shard *sh, const void *host_frames)
 {
     CHECK_SH(sh);
     wfx_ctx *ctx = sh->ctx;
-    if (!host_frames) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
     const size_t nb = (size_t)(sh->pl.in_hi - sh->pl.in_lo) * frame_bytes(sh->pl.in_kind);
+    if (!host_frames && nb) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
     const bool moved = !sh->b_in.p || sh->b_in.cap < nb + 64 || sh->ext_in;
     WFX_TRY(wfx_reserve(ctx, sh->b_in, nb + 64));
     sh->ext_in = nullptr;
-    WFX_HIP(ctx, hipMemcpyAsync(sh->b_in.p, host_frames, nb, hipMemcpyHostToDevice, ctx->stream));
+    if (nb) WFX_HIP(ctx, hipMemcpyAsync(sh->b_in.p, host_frames, nb, hipMemcpyHostToDevice, ctx->stream));
     WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     sh->have_input = true;
     sh->ran = false;
@@ -497,9 +595,13 @@ int wfx_shard_phase(wfx_shard *sh, int phase)
 {
     CHECK_SH(sh);
     if (!sh->have_input) return wfx_fail(sh->ctx, WFX_ERR_STATE, "sharded decode before the input was given");
-    if (phase < 0 || phase >= phase_count(sh)) return wfx_fail(sh->ctx, WFX_ERR_BAD_ARG, "phase %d out of range", phase);
+    const int np = phase_count(sh);
+    if (phase < 0 || phase >= np) return wfx_fail(sh->ctx, WFX_ERR_BAD_ARG, "phase %d out of range", phase);
     WFX_TRY(run_phase(sh, phase));
-    if (phase == phase_count(sh) - 1) sh->ran = true;
+    if (phase == np - 1) {
+        sh->ran = true;
+        if (sh->pl.padded) sh->ghat_ready = true;        // (the next decode has three phases fewer)
+    }
     return 0;
 }
 
@@ -613,7 +715,8 @@ int wfx_shard_destroy(wfx_shard *sh)
     sh->dF.release();
     sh->dI.release();
     sh->dH.release();
-    wfx_devbuf *bufs[] = {&sh->b_in, &sh->b_merged, &sh->b_res, &sh->b_audio, &sh->b_v, &sh->b_env, &sh->b_dig, &sh->b_blk, &sh->b_blks, &sh->b_nan, &sh->b_flags};
+    wfx_devbuf *bufs[] = {&sh->b_in, &sh->b_merged, &sh->b_res, &sh->b_audio, &sh->b_v, &sh->b_env, &sh->b_dig, &sh->b_blk, &sh->b_blks, &sh->b_nan, &sh->b_flags,
+                          &sh->b_grow, &sh->b_ghat};
     for (wfx_devbuf *b : bufs) free_buf(*b);
     delete sh;
     return 0;

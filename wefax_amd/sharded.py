@@ -219,7 +219,7 @@ def _info_dict(info: nat.DecodeInfo) -> dict:
 
 
 def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute: int = 120, device: int = 0, notch=None,
-                    want=("image", "stream", "envelope", "audio"), make_decoder=None, free_after=None):
+                    want=("image", "stream", "envelope", "audio"), make_decoder=None, free_after=None, repeat: int = 1):
     """Every rank of a ``world``-rank sharded decode in this process, on one GPU, phase by phase (local communicator:
     a collective completes when the last rank has posted its part).  Returns the root's results plus the per-rank
     blocks concatenated, for comparison with the single-GPU path (tests)."""
@@ -236,6 +236,12 @@ def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute:
         for d in decs:
             if hasattr(d, "front_end"):
                 d.front_end()
+        for rep in range(max(1, repeat) - 1):       # earlier decodes of the same shards (buffers and plans are reused by the last one)
+            for ph in range(decs[0].shard.phases):
+                for d in decs:
+                    d.shard.phase(ph)
+            for d in decs:
+                d.result()
         for attempt in range(8):
             nph = decs[0].shard.phases
             for ph in range(nph):
