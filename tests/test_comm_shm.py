@@ -140,11 +140,11 @@ def test_randomised_collectives_between_processes_device_memory(world):
     assert out == {r: "ok" for r in range(world)}
 
 
-def _decode_worker(job, world, rank, seed, rate, lpm, out_dir, q):
+def _decode_worker(job, world, rank, seed, rate, lpm, out_dir, q, trim=0):
     """One rank of a sharded decode in its own process: own context, own slice of the capture, the shm transport."""
     try:
         from wefax_amd import sharded, synth
-        x = _capture(rate, seed, lpm)
+        x = _capture(rate, seed, lpm, trim)
         ctx = nat.Context(0)
         comm = nat.Comm.shm(ctx, job, world, rank, timeout=120.0)
         time.sleep(0.02 * ((rank * 7) % 5))                                 # the ranks drift apart
@@ -169,26 +169,36 @@ def _decode_worker(job, world, rank, seed, rate, lpm, out_dir, q):
         q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
 
 
-def _capture(rate, seed, lpm):
+def _capture(rate, seed, lpm, trim=0):
     from wefax_amd import synth
     n_lines = {120: 70, 240: 148}[lpm]             # whole seconds: lengths with 13-smooth halves (what the distributed transforms take)
     x = synth.synth_capture(float(rate), noise=0.05, seed=seed, lpm=lpm, start_tone_s=1.0, phasing_lines=40 if lpm == 240 else 20,
                             image_lines=n_lines, stop_tone_s=1.0, black_tail_s=1.0)
-    return x
+    return np.ascontiguousarray(x[:x.shape[0] - trim]) if trim else x
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,rate,lpm", [(2, 11025, 240), (3, 48000, 240), (4, 11025, 120), (8, 48000, 120)])
-def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, world, rate, lpm):
+@pytest.mark.parametrize("world,rate,lpm,trim", [(2, 11025, 240, 0), (3, 48000, 240, 0), (4, 11025, 120, 0), (8, 48000, 120, 0),
+                                                 (3, 11025, 120, 4478), (8, 11025, 240, 1234)])
+def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, world, rate, lpm, trim):
     """ShardedDecoder over the shm transport, `world` processes on one GPU, three decodes back to back with the ranks drifting
     apart: uint8 stream, image, start_frame and the float64 envelope blocks equal the fused one-GPU decode / the in-process
-    emulation bit for bit."""
+    emulation bit for bit.  ``trim``: an arbitrary even length (half-length not 13-smooth): the padded distributed convolution,
+    whose first decode carries three extra phases and whose ranks may own no samples at all."""
     from wefax_amd import sharded
     from wefax_amd.wefax import DecodeJob
-    x = _capture(rate, 5, lpm)
+    x = _capture(rate, 5, lpm, trim)
     assert sharded.layout_supported(x.shape[0], rate, world, lpm, sharded.capture_kind(x))
     job = _job()
-    out = _run(world, _decode_worker, lambda r: (job, world, r, 5, rate, lpm, str(tmp_path)), timeout=600)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_decode_worker, args=(job, world, r, 5, rate, lpm, str(tmp_path), q, trim)) for r in range(world)]
+    for r in reversed(range(world)):
+        procs[r].start()
+        time.sleep(0.05)
+    out = dict(q.get(timeout=600) for _ in range(world))
+    for p_ in procs:
+        p_.join(30)
     assert out == {r: "ok" for r in range(world)}, out
     ctx = nat.Context(0)
     ref = DecodeJob(ctx, x, rate, lpm)
@@ -199,6 +209,11 @@ def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, wo
     assert list(np.load(tmp_path / "sync.npy")) == [info.start_frame, info.height, info.npeaks]
     emu = sharded.decode_emulated(x, rate, world, lpm, want=("envelope",))
     assert np.array_equal(np.concatenate([np.load(tmp_path / f"env{r}.npy") for r in range(world)]), emu["envelope"])
+    if trim:
+        from wefax_amd.wefax import build_params
+        p, _ = build_params(0, x.shape[0], rate, 1 / (lpm / 60))
+        sizes = [nat.shard_layout(p, world, r).own_hi - nat.shard_layout(p, world, r).own_lo for r in range(world)]
+        assert sizes[0] > 0 and (world < 3 or sizes[-1] == 0)                 # the last ranks' rows are padding
     ctx.close()
 
 
