@@ -40,7 +40,13 @@ typedef enum {
     WFX_IN_I16_MONO = 0,    /* int16[n]                                         */
     WFX_IN_I16_STEREO = 1,  /* int16[n][2] -> (int16)(L+R) wrapped, then /2      */
     WFX_IN_F64_MONO = 2,    /* float64[n] (any other wav dtype, converted on host) */
-    WFX_IN_F32_MONO = 3     /* float32[n]: only between the stages of the time-domain front end (wfx_d_decimate_fir ...) */
+    WFX_IN_F32_MONO = 3,    /* float32[n]: only between the stages of the time-domain front end (wfx_d_decimate_fir ...) */
+    /* two-channel wavs in the other sample formats scipy.io.wavfile returns: wefax.py:372 adds the two numpy scalars IN THE FILE'S
+     * dtype -- uint8 wraps modulo 2^8, int32 modulo 2^32, float32 rounds to float32 -- then divides by 2 (fused decode and
+     * wfx_merge_channels_any only; the merged samples continue as float64) */
+    WFX_IN_U8_STEREO = 4,   /* uint8[n][2]   */
+    WFX_IN_I32_STEREO = 5,  /* int32[n][2]   */
+    WFX_IN_F32_STEREO = 6   /* float32[n][2] */
 } wfx_in_kind;
 
 /* how the analytic signal (scipy.signal.hilbert, wefax.py:174) is computed */
@@ -67,6 +73,8 @@ const char *wfx_version(void);
 
 /* a4  wefax.py:360-373 __merge_channels: out[i] = (double)(int16)(L+R) / 2 */
 int wfx_merge_channels(wfx_ctx *ctx, const int16_t *lr, size_t n, double *out);
+/* the same for any two-channel kind (WFX_IN_I16_STEREO, WFX_IN_U8_STEREO, WFX_IN_I32_STEREO, WFX_IN_F32_STEREO) */
+int wfx_merge_channels_any(wfx_ctx *ctx, const void *lr, int in_kind, size_t n, double *out);
 
 /* a5  wefax.py:375-394 __resample -> scipy.signal.resample(x, num) (real input) */
 int wfx_resample(wfx_ctx *ctx, const double *x, size_t n0, size_t num, double *out);

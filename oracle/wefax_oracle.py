@@ -150,11 +150,16 @@ def read_wav(path: str):
 # --------------------------------------------------------------------------
 def merge_channels(data: np.ndarray) -> np.ndarray:
     """np.divide(np.add(L, R), 2) on numpy scalars: the add happens in the
-    sample dtype (int16 wraps modulo 2**16), the divide gives float64."""
+    sample dtype (int16 / uint8 / int32 wrap), the divide gives float64 for the
+    integer formats -- and float32 for a float32 wav, so the list the reference
+    hands to filtfilt (wefax.py:72) becomes a float32 array there and the odd
+    extension at its two ends is evaluated in float32 (pinned by the golden
+    stereo_f32_240: the first audio sample differs by 1.7e-10 otherwise)."""
     l, r = data[:, 0], data[:, 1]
     with np.errstate(over="ignore"):
         s = np.add(l, r)            # stays in the input dtype -> wraps
-    return np.divide(s, 2).astype(np.float64)
+    out = np.divide(s, 2)
+    return out if out.dtype == np.float32 else out.astype(np.float64)
 
 
 # --------------------------------------------------------------------------
@@ -709,7 +714,7 @@ def process(path: str, lines_per_minute: int = 120, want_messages: bool = True, 
             for p in range(parts):                      # wefax.py:364-370
                 if p % 1000 == 0 or p == parts - 1:
                     progress("merging channels", (p + 1) / parts * 100)
-        data = np.asarray(merge_channels_loop(data), dtype=np.float64) if faithful_loops else merge_channels(data)
+        data = np.asarray(merge_channels_loop(data)) if faithful_loops else merge_channels(data)     # (a list of numpy scalars: float64, or float32 for a float32 wav)
     length = len(data) / sr
     if sr != TARGET_RATE:                               # wefax.py:60
         progress("resampling audio", 0)

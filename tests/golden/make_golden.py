@@ -3,7 +3,7 @@
 
 Run in the build container only (the reference does not exist on the GPU box):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [--only case1,case2]      (--only: add / refresh these cases, keep the rest of the manifest)
 
 It imports /root/reference/wefax.py (cwd must be the reference root because
 config.py:11 opens ``config/config.json`` relative to cwd), turns the
@@ -123,11 +123,17 @@ def _stage_only(wefax, name: str, wav_path: str, lpm: int = 120) -> dict:
 
 
 def main():
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     wefax = _import_reference()
     inputs = os.path.join(HERE, "inputs")
     os.makedirs(inputs, exist_ok=True)
     manifest = {"reference": "wojlin/WEFAX wefax.py Demodulator.process()",
                 "versions": {}, "cases": []}
+    old_cases = []
+    if only is not None:
+        old_cases = [c for c in json.load(open(os.path.join(HERE, "manifest.json")))["cases"] if c["name"] not in only]
     import scipy, PIL  # noqa: E401
     manifest["versions"] = {"numpy": np.__version__, "scipy": scipy.__version__,
                             "Pillow": PIL.__version__,
@@ -136,6 +142,8 @@ def main():
     short = dict(start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0)
 
     def emit(name, fs, data, lpm):
+        if only is not None and name not in only:
+            return
         p = os.path.join(inputs, name + ".wav")
         synth.write_wav(p, fs, data)
         print("case", name, data.shape, flush=True)
@@ -189,10 +197,20 @@ def main():
     emit("mono_f32_240", 11025, base.astype(np.float32) / np.float32(32768.0), 240)
     emit("mono_i32_240", 11025, base.astype(np.int32) * 65536, 240)
 
+    # 10b. the same sample formats in STEREO: the merge loop (wefax.py:360-373) adds two numpy scalars of the file's dtype -- uint8
+    #      wraps modulo 256, int32 modulo 2**32, float32 stays float32 (and so does the list filtfilt later extends at its ends)
+    base = synth.synth_capture(11025.0, noise=0.05, seed=43, lpm=240, phasing_lines=40, image_lines=40, **short)
+    u8 = (base.astype(np.int32) // 300 + 170).astype(np.uint8)                 # 61 .. 279 -> sums of the two channels wrap
+    emit("stereo_u8_240", 11025, np.stack([u8, (u8.astype(np.int32) * 3 // 4).astype(np.uint8)], axis=1), 240)
+    i32 = base.astype(np.int32) * 50000                                         # up to 1.6e9 per channel: sums wrap
+    emit("stereo_i32_240", 11025, np.stack([i32, i32 // 2 + 7], axis=1), 240)
+    f32 = base.astype(np.float32) / np.float32(32768.0)
+    emit("stereo_f32_240", 11025, np.stack([f32, f32 * np.float32(0.3333333)], axis=1), 240)
+
     # 11. the reference's own 1-second clips (MIT licence, LICENSE:1-3)
     import shutil
-    for clip in ("image", "stop_tone", "start_tone", "start_tone_noisy",
-                 "start_tone_start"):
+    for clip in (() if only is not None else ("image", "stop_tone", "start_tone", "start_tone_noisy",
+                 "start_tone_start")):
         src = os.path.join(REF, "test_files", "parts", clip + ".wav")
         dst = os.path.join(inputs, "ref_" + clip + ".wav")
         shutil.copyfile(src, dst)
@@ -202,6 +220,8 @@ def main():
         c["input"] = "inputs/ref_" + clip + ".wav"
         manifest["cases"].append(c)
 
+    if only is not None:
+        manifest["cases"] = old_cases + manifest["cases"]
     with open(os.path.join(HERE, "manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1)
     print("wrote", len(manifest["cases"]), "cases")

@@ -95,6 +95,16 @@ def test_merge_channels_bit_exact(ctx):
         assert np.array_equal(ctx.merge_channels(lr), wo.merge_channels(lr))
     edge = np.array([[32767, 32767], [-32768, -32768], [32767, -32768], [30000, 30000]], dtype=np.int16)
     assert np.array_equal(ctx.merge_channels(edge), wo.merge_channels(edge))
+    # the other sample formats scipy.io.wavfile hands over: the add wraps in uint8 / int32, float32 stays float32 (wefax.py:372)
+    for n in (1, 9, 4099):
+        u8 = rng.integers(0, 256, size=(n, 2), dtype=np.uint8)
+        i32 = rng.integers(-2 ** 31, 2 ** 31, size=(n, 2), dtype=np.int64).astype(np.int32)
+        f32 = (rng.standard_normal((n, 2)) * 10.0 ** rng.integers(-30, 30, size=(n, 2))).astype(np.float32)
+        for arr in (u8, i32, f32):
+            got = ctx.merge_channels(arr)
+            want = np.asarray(wo.merge_channels_loop(arr), dtype=np.float64)        # the reference's own per-frame scalar arithmetic
+            assert np.array_equal(got, want), arr.dtype
+            assert np.array_equal(got, wo.merge_channels(arr).astype(np.float64))
 
 
 @pytest.mark.parametrize("n", SIZES)

@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WFX_LIB") or os.path.join(_HERE, "libwefax_hip.so")     # WFX_LIB: another build of the library (A/B runs)
 
 WFX_IN_I16_MONO, WFX_IN_I16_STEREO, WFX_IN_F64_MONO, WFX_IN_F32_MONO = 0, 1, 2, 3
+WFX_IN_U8_STEREO, WFX_IN_I32_STEREO, WFX_IN_F32_STEREO = 4, 5, 6
+STEREO_KIND_OF = {np.dtype(np.int16): 1, np.dtype(np.uint8): 4, np.dtype(np.int32): 5, np.dtype(np.float32): 6}
 WFX_HILBERT_FFT, WFX_HILBERT_BLUESTEIN, WFX_HILBERT_FFT_POW2 = 0, 2, 3      # (1 was the truncated FIR mode of rounds 1-2: removed)
 WFX_BUF_AUDIO, WFX_BUF_ENVELOPE, WFX_BUF_DIGITAL, WFX_BUF_IMAGE = 0, 1, 2, 3
 WFX_MAX_PEAKS = 100
@@ -22,7 +24,7 @@ WFX_MAX_PEAKS = 100
 # every symbol include/wefax_hip.h declares (tests check that all are exported)
 SYMBOLS = [
     "wfx_device_count", "wfx_create", "wfx_destroy", "wfx_last_error", "wfx_sync",
-    "wfx_version", "wfx_merge_channels", "wfx_resample", "wfx_notch_filtfilt", "wfx_notch_filtfilt_ext",
+    "wfx_version", "wfx_merge_channels", "wfx_merge_channels_any", "wfx_resample", "wfx_notch_filtfilt", "wfx_notch_filtfilt_ext",
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
     "wfx_sync_peaks", "wfx_lines_to_image", "wfx_packet_process", "wfx_packets_process", "wfx_packet_spectrum", "wfx_decode_upload", "wfx_decode_attach", "wfx_decode_run",
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
@@ -146,6 +148,7 @@ def load():
     lib.wfx_version.restype = C.c_char_p
     lib.wfx_sync.argtypes = [vp]
     lib.wfx_merge_channels.argtypes = [vp, vp, sz, vp]
+    lib.wfx_merge_channels_any.argtypes = [vp, vp, i, sz, vp]
     lib.wfx_resample.argtypes = [vp, vp, sz, sz, vp]
     lib.wfx_notch_filtfilt.argtypes = [vp, vp, i, sz, dp, dp, vp]
     lib.wfx_notch_filtfilt_ext.argtypes = [vp, vp, i, sz, dp, dp, dp, dp, vp]
@@ -287,9 +290,16 @@ class Context:
 
     # ---- stage entry points -------------------------------------------------
     def merge_channels(self, lr: np.ndarray) -> np.ndarray:
-        lr = np.ascontiguousarray(lr[:, :2], dtype=np.int16)
+        """wefax.py:360-373 on the first two channels, in the file's own sample format (int16 / uint8 / int32 / float32)."""
+        lr = np.asarray(lr)
+        if lr.dtype not in STEREO_KIND_OF:
+            lr = lr.astype(np.int16)
+        lr = np.ascontiguousarray(lr[:, :2])
         out = np.empty(lr.shape[0], dtype=np.float64)
-        self._check(self.lib.wfx_merge_channels(self.h, _ptr(lr), lr.shape[0], _ptr(out)))
+        if lr.dtype == np.int16:
+            self._check(self.lib.wfx_merge_channels(self.h, _ptr(lr), lr.shape[0], _ptr(out)))
+        else:
+            self._check(self.lib.wfx_merge_channels_any(self.h, _ptr(lr), STEREO_KIND_OF[lr.dtype], lr.shape[0], _ptr(out)))
         return out
 
     def resample(self, x: np.ndarray, num: int) -> np.ndarray:

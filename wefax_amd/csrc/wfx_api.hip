@@ -49,6 +49,21 @@ int wfx_merge_channels(wfx_ctx *ctx, const int16_t *lr, size_t n, double *out)
     return d2h_sync(ctx, out, ctx->b_x.p, n * 8);
 }
 
+int wfx_merge_channels_any(wfx_ctx *ctx, const void *lr, int in_kind, size_t n, double *out)
+{
+    CHECK_CTX(ctx);
+    if (!lr || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    if (!wfx_kind_is_stereo(in_kind)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "merge: input kind %d has one channel", in_kind);
+    ctx->ran = false;
+    if (n == 0) return 0;
+    const size_t fb = wfx_kind_frame_bytes(in_kind);
+    WFX_TRY(wfx_reserve(ctx, ctx->b_in, n * fb));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_x, n * 8));
+    WFX_TRY(h2d(ctx, ctx->b_in.p, lr, n * fb));
+    WFX_TRY(wfx_dev_merge_any(ctx, ctx->b_in.p, in_kind, n, (double *)ctx->b_x.p));
+    return d2h_sync(ctx, out, ctx->b_x.p, n * 8);
+}
+
 // ---- a5 ---------------------------------------------------------------------
 int wfx_resample(wfx_ctx *ctx, const double *x, size_t n0, size_t num, double *out)
 {
@@ -233,16 +248,13 @@ int wfx_lines_to_image(wfx_ctx *ctx, const uint8_t *d, size_t n, size_t start, i
 // ---- fused decode ---------------------------------------------------------------
 static size_t in_bytes(const wfx_decode_params *p)
 {
-    switch (p->in_kind) {
-    case WFX_IN_I16_MONO: return (size_t)p->n0 * 2;
-    case WFX_IN_I16_STEREO: return (size_t)p->n0 * 4;
-    default: return (size_t)p->n0 * 8;
-    }
+    return (size_t)p->n0 * wfx_kind_frame_bytes(p->in_kind);
 }
 
 static int check_params(wfx_ctx *ctx, const wfx_decode_params *p)
 {
-    if (p->in_kind < WFX_IN_I16_MONO || p->in_kind > WFX_IN_F64_MONO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad in_kind %d", p->in_kind);
+    if (p->in_kind < WFX_IN_I16_MONO || p->in_kind > WFX_IN_F32_STEREO || p->in_kind == WFX_IN_F32_MONO)
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad in_kind %d", p->in_kind);
     if (p->n0 == 0 || p->n == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "empty capture");
     if (!p->resample && p->n != p->n0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "n != n0 without resampling");
     if (p->n <= 9) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "The length of the input vector x must be greater than padlen, which is 9.");
@@ -352,9 +364,9 @@ int wfx_decode_run(wfx_ctx *ctx)
 
     const void *cur = ctx->ext_in ? ctx->ext_in : ctx->b_in.p;      // caller-owned device input (wfx_decode_attach) or the uploaded copy
     int cur_kind = p.in_kind;
-    if (p.in_kind == WFX_IN_I16_STEREO) {
+    if (wfx_kind_is_stereo(p.in_kind)) {
         WFX_TRY(wfx_reserve(ctx, ctx->b_x, n0 * 8));
-        WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)cur, n0, (double *)ctx->b_x.p));
+        WFX_TRY(wfx_dev_merge_any(ctx, cur, p.in_kind, n0, (double *)ctx->b_x.p));
         cur = ctx->b_x.p;
         cur_kind = WFX_IN_F64_MONO;
     }

@@ -243,6 +243,16 @@ int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t nu
 
 // wfx_stages.hip
 int wfx_dev_merge(wfx_ctx *ctx, const int16_t *lr, uint64_t n, double *out);
+int wfx_dev_merge_any(wfx_ctx *ctx, const void *lr, int in_kind, uint64_t n, double *out);
+inline bool wfx_kind_is_stereo(int k) { return k == WFX_IN_I16_STEREO || k == WFX_IN_U8_STEREO || k == WFX_IN_I32_STEREO || k == WFX_IN_F32_STEREO; }
+inline size_t wfx_kind_frame_bytes(int k)
+{
+    switch (k) {
+    case WFX_IN_I16_MONO: case WFX_IN_U8_STEREO: return 2;
+    case WFX_IN_I16_STEREO: case WFX_IN_F32_MONO: return 4;
+    default: return 8;       // float64 mono, int32 / float32 stereo
+    }
+}
 int wfx_dev_i16_to_f64(wfx_ctx *ctx, const int16_t *in, uint64_t n, double *out);
 // clear (optional): device scalars the kernel zeroes on its way (saves the decode's memset launch);
 // *cleared tells whether the form that ran did it

@@ -28,6 +28,38 @@ int wfx_dev_merge(wfx_ctx *ctx, const int16_t *lr, uint64_t n, double *out)
     return 0;
 }
 
+// the other sample formats of a two-channel wav (numpy scalar semantics of wefax.py:372): the add in the file's dtype, then / 2
+template <int KIND>
+__global__ void __launch_bounds__(256) merge_any_kernel(const void *__restrict__ lr, uint64_t n, double *__restrict__ out)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256ull) {
+        double v;
+        if (KIND == WFX_IN_U8_STEREO) {
+            const uchar2 p = ((const uchar2 *)lr)[i];
+            v = (double)(unsigned char)((unsigned)p.x + (unsigned)p.y) / 2.0;          // wraps modulo 2^8
+        } else if (KIND == WFX_IN_I32_STEREO) {
+            const int2 p = ((const int2 *)lr)[i];
+            v = (double)(int)((unsigned)p.x + (unsigned)p.y) / 2.0;                    // wraps modulo 2^32
+        } else {
+            const float2 p = ((const float2 *)lr)[i];
+            v = (double)(__fadd_rn(p.x, p.y) / 2.0f);                                   // float32 sum, float32 quotient
+        }
+        out[i] = v;
+    }
+}
+
+int wfx_dev_merge_any(wfx_ctx *ctx, const void *lr, int in_kind, uint64_t n, double *out)
+{
+    const dim3 g(wfx_stream_grid(n, 256)), b(256);
+    switch (in_kind) {
+    case WFX_IN_I16_STEREO: return wfx_dev_merge(ctx, (const int16_t *)lr, n, out);
+    case WFX_IN_U8_STEREO: WFX_LAUNCH(ctx, K_MERGE, merge_any_kernel<WFX_IN_U8_STEREO>, g, b, lr, n, out); return 0;
+    case WFX_IN_I32_STEREO: WFX_LAUNCH(ctx, K_MERGE, merge_any_kernel<WFX_IN_I32_STEREO>, g, b, lr, n, out); return 0;
+    case WFX_IN_F32_STEREO: WFX_LAUNCH(ctx, K_MERGE, merge_any_kernel<WFX_IN_F32_STEREO>, g, b, lr, n, out); return 0;
+    default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "merge: input kind %d has one channel", in_kind);
+    }
+}
+
 __global__ void __launch_bounds__(256) i16_to_f64_kernel(const short *__restrict__ in, uint64_t n, double *__restrict__ out)
 {
     for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256ull) out[i] = (double)in[i];

@@ -129,7 +129,19 @@ class DecodeJob:
             if data.dtype == np.int16:
                 kind = nat.WFX_IN_I16_STEREO
                 data = np.ascontiguousarray(data[:, :2])
-            else:   # other sample formats: numpy scalar semantics on the host (wefax.py:372)
+            elif data.dtype in nat.STEREO_KIND_OF:
+                # uint8 / int32 / float32 wavs: merged ON THE DEVICE with numpy's scalar semantics of wefax.py:372 (the add wraps
+                # in the file's dtype; float32 stays float32).  A float32 wav's merged list is float32 when filtfilt extends it
+                # at its two ends (wefax.py:72): those 9 + 9 numbers are formed here from the first / last ten frames, in float32
+                # (golden stereo_f32_240: the first audio sample is off by 1.7e-10 otherwise)
+                kind = nat.STEREO_KIND_OF[data.dtype]
+                data = np.ascontiguousarray(data[:, :2])
+                if data.dtype == np.float32 and data.shape[0] > 9:
+                    with np.errstate(over="ignore"):
+                        head = np.divide(np.add(data[:10, 0], data[:10, 1]), 2)
+                        tail = np.divide(np.add(data[-10:, 0], data[-10:, 1]), 2)
+                    ext = (hp.odd_extension(head)[0], hp.odd_extension(tail)[1])
+            else:   # anything else scipy might hand over (float64 stereo): numpy on the host
                 with np.errstate(over="ignore"):
                     data = np.divide(np.add(data[:, 0], data[:, 1]), 2).astype(np.float64)
                 kind = nat.WFX_IN_F64_MONO
