@@ -71,23 +71,29 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         if (!pl.resample && pl.K >= 4096) {
             std::vector<long long> cand;
             wfx_mr_smooth_numbers(2 * pl.K - 1, (2 * pl.K - 1) + (2 * pl.K - 1) / 8, cand);
-            for (long long m : cand) {
-                if (m >= (1ll << 31)) break;
-                if (!wfx_dist_choose_r1(&m, 1, world, &ra1, &rb1, true)) continue;
-                // the rank whose rows straddle the capture's end must own a workable number of samples (or none)
-                const int r1 = ra1 * rb1;
-                const long long ms = m / r1;
-                bool fine = true;
-                for (int r = 0; r < world && fine; ++r) {
-                    const long long a = (long long)r * r1 / world * ms, b = (long long)(r + 1) * r1 / world * ms;
-                    const long long own = (b < pl.K ? b : pl.K) - (a < pl.K ? a : pl.K);
-                    if (own > 0 && own < 2048) fine = false;
+            // The padded length and its first radix are chosen the same way for every world size up to 8 (the plan of the largest:
+            // what works for 8 ranks works for fewer), so that the float stages do not depend on the number of ranks here either;
+            // the rank whose rows straddle the capture's end must be left with a workable number of samples (or none) -- first
+            // for every world size up to 8, and only if no candidate manages that, for this one alone.
+            const int wref = world > 8 ? world : 8;
+            for (int strict = 1; strict >= 0 && !found; --strict)
+                for (long long m : cand) {
+                    if (m >= (1ll << 31)) break;
+                    if (!wfx_dist_choose_r1(&m, 1, wref, &ra1, &rb1, true)) continue;
+                    const int r1 = ra1 * rb1;
+                    const long long ms = m / r1;
+                    bool fine = true;
+                    for (int w = strict ? 1 : world; w <= (strict ? wref : world) && fine; ++w)
+                        for (int r = 0; r < w && fine; ++r) {
+                            const long long a = (long long)r * r1 / w * ms, b = (long long)(r + 1) * r1 / w * ms;
+                            const long long own = (b < pl.K ? b : pl.K) - (a < pl.K ? a : pl.K);
+                            if (own > 0 && own < 2048) fine = false;
+                        }
+                    if (!fine) continue;
+                    pl.Kp = m;
+                    pl.padded = found = true;
+                    break;
                 }
-                if (!fine) continue;
-                pl.Kp = m;
-                pl.padded = found = true;
-                break;
-            }
         }
         if (!found)
             return wfx_fail(ctx, WFX_ERR_BAD_ARG,
