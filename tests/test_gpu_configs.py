@@ -71,6 +71,59 @@ def test_batch_of_mixed_captures_on_concurrent_contexts():
         c.close()
 
 
+def test_all_64_members_of_the_batch_eight_contexts_at_a_time():
+    """BASELINE configs[4] in full: 64 captures (mixed 120 / 240 LPM, IOC576 / 288, seeds 0..63) decoded 8 at a time on 8 contexts
+    that are REUSED round after round (what one GPU of the 8-GPU configuration does: 8 captures per GPU stream set; captures are
+    independent objects, nothing is exchanged).  A context keeps its plans and buffers while captures of different lengths and
+    line rates pass through it; every sixth member is checked against the oracle in full, every member decodes without error,
+    and a member decoded again on another context gives the same bytes."""
+    from wefax_amd import _native as nat
+    from wefax_amd import synth
+    from wefax_amd.wefax import DecodeJob
+    ctxs = [nat.Context(0) for _ in range(8)]
+    digests = {}
+    for rnd in range(8):
+        members = [synth.config_c5_member(8 * rnd + k, noise=0.05) for k in range(8)]
+        jobs = [DecodeJob(ctxs[(k + rnd) % 8], x, 11025, lpm) for k, (x, lpm) in enumerate(members)]      # contexts see other shapes each round
+        errors = []
+
+        def work(j):
+            try:
+                j.run()
+                j.result()
+            except Exception as e:           # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for k, (job, (x, lpm)) in enumerate(zip(jobs, members)):
+            i = 8 * rnd + k
+            info = job.result()
+            stream = job.fetch("digitalized")
+            digests[i] = (int(info.start_frame), int(info.height), int(stream.astype(np.uint64).sum()), int(stream[::997].astype(np.uint64).sum()))
+            assert info.width == (5512 if lpm == 120 else 2756) and info.n == x.shape[0]
+            if i % 6 == 0:
+                ref = _oracle(x, 11025, lpm)
+                assert info.start_frame == ref["start_frame"], f"member {i}"
+                assert np.array_equal(stream, ref["digitalized"]), f"member {i}: uint8 stream"
+                assert np.array_equal(job.fetch("image"), ref["image"]), f"member {i}: image"
+    # a few members again, on other contexts, after everything else has been through them
+    for i in (3, 29, 62):
+        x, lpm = synth.config_c5_member(i, noise=0.05)
+        job = DecodeJob(ctxs[(i * 5) % 8], x, 11025, lpm)
+        job.run()
+        info = job.result()
+        stream = job.fetch("digitalized")
+        assert digests[i] == (int(info.start_frame), int(info.height), int(stream.astype(np.uint64).sum()), int(stream[::997].astype(np.uint64).sum()))
+    assert len(digests) == 64
+    for c in ctxs:
+        c.close()
+
+
 def test_int16_capture_is_resampled_in_place_thirty_seconds():
     """n0 = 1 440 000 int16 samples at 48 kHz: even, 13-smooth halves -> the mixed-radix resampler whose first pass reads the
     int16 pairs directly (no float64 copy of the capture).  Against the oracle: identical stream / peaks / image; and the
