@@ -589,13 +589,28 @@ constexpr bool mr2_prefetch(int ra, int rb)
 #ifndef WFX_FUSED_LB
 #define WFX_FUSED_LB 2
 #endif
+// int16 first pass (IN_MODE 2): a tile's row segments are only T * 4 bytes (128 for radix 64).  The workgroup stages the rows of
+// SUP consecutive tiles in LDS as int16 pairs -- 256..512-byte segments, the next block's loads in flight in registers across the
+// SUP tiles of this one -- and the tiles read their points from there.  WFX_I16_STAGE=0: every tile reads its own segments.
+#ifndef WFX_I16_STAGE
+#define WFX_I16_STAGE 1
+#endif
+constexpr int mr2_i16_sup(int r)
+{
+    if (!WFX_I16_STAGE || mr2_nt(r) != 256) return 1;
+    const int t = 1 << mr2_log2t(r);
+    for (int sw = 128; sw > t; sw >>= 1)                          // staged columns; two workgroups per CU must still fit (80 KB each)
+        if (t * r * 16 + r * sw * 4 + r * 16 + 2048 <= 80 * 1024) return sw / t;
+    return 1;
+}
 template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
 __global__ void __launch_bounds__(mr2_nt(RA * RB), mr2_nt(RA * RB) == 512 ? 1 : OUT_MODE == 2 ? WFX_FUSED_LB : 2)
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
          int ntiles)
 {
     constexpr int LOG2T = mr2_log2t(RA * RB);
-    constexpr int PF = (mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3 || ((OUT_MODE == 1 || OUT_MODE == 4) && mr2_rows(RB)))) ? 1 : 0;
+    constexpr int SUP = IN_MODE == 2 ? mr2_i16_sup(RA * RB) : 1;  // tiles per staged block of int16 rows
+    constexpr int PF = (SUP == 1 && mr2_prefetch(RA, RB) && (OUT_MODE == 0 || OUT_MODE == 3 || ((OUT_MODE == 1 || OUT_MODE == 4) && mr2_rows(RB)))) ? 1 : 0;
     constexpr int R = RA * RB, T = 1 << LOG2T;
     constexpr int NT = mr2_nt(R);                                 // lanes per workgroup
     constexpr int NA = (T * RB + NT - 1) / NT, NB = (T * RA + NT - 1) / NT;
@@ -618,6 +633,20 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
     }
     cplx pre[NA][RA];
     const long long in_lim = (IN_MODE == 1 && d.in_len > 0) ? d.in_len : 0x7fffffffffffffffll;     // zero padding behind the packed reals
+    constexpr int SW = SUP * T, NSL = SUP > 1 ? (R * SW + NT - 1) / NT : 1;
+    __shared__ short2 stage[SUP > 1 ? R * SW : 1];
+    short2 sreg[NSL];
+    auto stage_fetch = [&](int st) {                              // rows of block st -> registers (row r, staged column c: item r SW + c)
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int item = t + NT * i;
+            const int c = item & (SW - 1), r = item / SW;
+            const long long j = (long long)st * SW + c;
+            short2 v = make_short2(0, 0);
+            if (r < R && j < ncol) v = ((const short2 *)in)[j + (long long)r * ncol];
+            sreg[i] = v;
+        }
+    };
     auto prefetch = [&](int tix) {
 #pragma unroll
         for (int ia = 0; ia < NA; ++ia) {
@@ -631,7 +660,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                 const long long adr = (long long)j + (long long)(a * RB + b) * ncol;
                 if (ok && (IN_MODE != 1 || adr < in_lim)) {
                     if (IN_MODE == 2) {
-                        const short2 x2 = ((const short2 *)in)[adr];
+                        const short2 x2 = SUP > 1 ? stage[(a * RB + b) * SW + (tix & (SUP - 1)) * T + c] : ((const short2 *)in)[adr];
                         v = make_double2((double)x2.x, (double)x2.y);
                     } else {
                         v = in[adr];
@@ -643,9 +672,20 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
         }
     };
     auto lookup = [&](int e) { return mconj_if(mcmul(tw_hi[e >> MR_LO_BITS], tw_lo[e & (MR_LO - 1)]), inv); };
-    int tix = blockIdx.x;
+    int tix = blockIdx.x * SUP;
     if (PF && tix < ntiles) prefetch(tix);
-    for (; tix < ntiles; tix += gridDim.x) {
+    if (SUP > 1 && tix < ntiles) stage_fetch(blockIdx.x);
+    // a workgroup takes blocks of SUP consecutive tiles, gridDim.x blocks apart (SUP == 1: every gridDim.x-th tile)
+    for (; tix < ntiles; tix = ((tix + 1) & (SUP - 1)) ? tix + 1 : tix + 1 + ((int)gridDim.x - 1) * SUP) {
+        if (SUP > 1 && (tix & (SUP - 1)) == 0) {
+            mr_lds_barrier();                                     // the previous block's tiles have read the stage
+#pragma unroll
+            for (int i = 0; i < NSL; ++i)
+                if (t + NT * i < R * SW) stage[t + NT * i] = sreg[i];
+            mr_lds_barrier();
+            const int st = tix / SUP + (int)gridDim.x;
+            if (st * SUP < ntiles) stage_fetch(st);               // in flight across this block's tiles
+        }
         const int j0 = tix * T;
         const int tn = min(T, ncol - j0);
         if (!PF) prefetch(tix);                                   // register-hungry radices: no tile kept in flight across level B
@@ -1215,7 +1255,9 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
     const int lt = mr2_log2t(d.R);
     const int nt = (int)((d.ncol + (1 << lt) - 1) >> lt);
     const int slots = mr2_nt(d.R) == 512 ? 256 : 512;           // resident workgroups on 256 CUs
-    const unsigned g2 = (unsigned)(nt < slots ? nt : slots);
+    const int sup = in_mode == 2 ? mr2_i16_sup(d.R) : 1;         // the int16 pass hands out blocks of `sup` tiles
+    const int nblk = (nt + sup - 1) / sup;
+    const unsigned g2 = (unsigned)(nblk < slots ? nblk : slots);
     if (nt <= 0) return 0;
     bool done = false;
 #define X(RA_, RB_)                                                                                                                   \
