@@ -50,12 +50,14 @@ def test_layout_tiles_the_capture_and_the_exchange_lists_are_consistent(n0, sr, 
         nat.shard_dry_run(p, world)          # raises if two ends of a message disagree, a receive leaves its buffer, ...
 
 
-@pytest.mark.parametrize("n0", [2 * 1000003, 1433252, 7166252, 2 * 3583126 + 2, 9000 * 2 + 2, 39690002, 2 * 104729, 600000 + 2 * 7919])
-def test_any_even_length_at_the_native_rate_gets_a_padded_plan(n0):
+@pytest.mark.parametrize("n0", [2 * 1000003, 1433252, 7166252, 2 * 3583126 + 2, 9000 * 2 + 2, 39690002, 2 * 104729, 600000 + 2 * 7919,
+                                1433251, 7166251, 1000003, 39690001, 20001])
+def test_any_length_at_the_native_rate_gets_a_padded_plan(n0):
     """An 11 025 Hz capture whose half-length has a prime factor above 13 (i.e. almost every real recording) is sharded too: the
     Hilbert convolution is embedded in a 13-smooth transform of Kp >= n - 1 points whose rows are dealt to the ranks; a rank owns
     the samples of its rows that lie inside the capture (the ranks whose rows are all padding own none and still take part in
-    every exchange).  The layouts tile the capture and every rank's exchange lists agree (host-only dry run)."""
+    every exchange).  The layouts tile the capture and every rank's exchange lists agree (host-only dry run).
+    ODD lengths (nothing to pack: scipy's kernel has taps on every lag) take the same form with one point per sample, Kp >= 2n - 1."""
     p, meta = build_params(0, n0, 11025, 0.5)
     for world in (1, 2, 3, 8):
         if n0 < 40000 and world == 8:
@@ -70,7 +72,7 @@ def test_any_even_length_at_the_native_rate_gets_a_padded_plan(n0):
 
 
 def test_captures_that_cannot_be_sharded_are_refused_with_a_reason():
-    for n0, sr, world, what in [(1433251, 11025, 2, "even"),            # odd length: the transforms are packed
+    for n0, sr, world, what in [(1440001, 48000, 2, "even"),            # odd length, resampled: its transforms are packed
                                 (4000, 11025, 8, "short"),               # too short for the world size
                                 (749700, 22050, 2, "13-smooth")]:        # 34 s at 22 050 Hz: a factor 17 in both transforms (resampled: no padded form yet)
         p, _ = build_params(0 if sr == 11025 else 2, n0, sr, 0.5)
@@ -304,12 +306,17 @@ def _arbitrary_even_lengths(count, seed, lo, hi):
     return [int(2 * rng.integers(lo // 2, hi // 2)) for _ in range(count)]
 
 
+def _arbitrary_odd_lengths(count, seed, lo, hi):
+    return [n + 1 for n in _arbitrary_even_lengths(count, seed, lo, hi)]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", _arbitrary_even_lengths(6, 21, 300000, 900000) + [2 * 200003, 1433252])
-def test_sharded_decode_of_any_even_length_equals_the_oracle(n):
-    """Arbitrary even lengths at 11 025 Hz (random, a prime times two, the 130-s capture plus two samples) through the padded
-    distributed convolution, worlds 1 / 2 / 3 / 8: stream, peaks, start_frame, image equal to the oracle's; the float stages do
-    not depend on the world size; decoding twice (the second decode skips the kernel's transform) gives the same again."""
+@pytest.mark.parametrize("n", _arbitrary_even_lengths(6, 21, 300000, 900000) + [2 * 200003, 1433252] + _arbitrary_odd_lengths(4, 22, 300000, 900000) + [400009, 1433251])
+def test_sharded_decode_of_any_length_equals_the_oracle(n):
+    """Arbitrary lengths at 11 025 Hz (random even and odd ones, a prime and a prime times two, the 130-s capture plus one and two
+    samples) through the padded distributed convolution, worlds 1 / 2 / 3 / 8: stream, peaks, start_frame, image equal to the
+    oracle's; the float stages do not depend on the world size; decoding twice (the second decode skips the kernel's transform)
+    gives the same again."""
     lines = max(20, int(n / 5512.5) - 40)
     x = synth.synth_capture(11025.0, noise=0.05, seed=n % 1000, start_tone_s=2.0, phasing_lines=20, image_lines=lines, stop_tone_s=1.0, black_tail_s=1.0)
     x = np.concatenate([x, x[:max(0, n - x.shape[0])]])[:n]

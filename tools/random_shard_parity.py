@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised sweep of the sharded exact decode (every rank emulated on one GPU) against the oracle: at 11 025 Hz ANY even
-length (two thirds of those cases: arbitrary, the rest 13-smooth), smooth lengths at the rates with the distributed resampler, LPM, noise, mono / stereo, world sizes 2..8.  A capture the library refuses
+"""Randomised sweep of the sharded exact decode (every rank emulated on one GPU) against the oracle: at 11 025 Hz ANY
+length (two thirds of those cases: arbitrary, even or odd; the rest 13-smooth), smooth lengths at the rates with the distributed resampler, LPM, noise, mono / stereo, world sizes 2..8.  A capture the library refuses
 to shard must be refused on every rank alike, with a reason; everything else must give the oracle's uint8 stream, start_frame
 and image, identically for every world size.
 
@@ -43,8 +43,8 @@ def main():
             lpm = int(rng.choice([120, 240]))
             ratio = fs // 11025
             n_out = smooth_length(rng, 150000, 420000)
-            if fs == 11025 and rng.integers(0, 3) > 0:              # the native rate takes ANY even length (padded distributed convolution)
-                n_out = int(2 * rng.integers(75000, 210000))
+            if fs == 11025 and rng.integers(0, 3) > 0:              # the native rate takes ANY length (padded distributed convolution)
+                n_out = int(rng.integers(150000, 420000))
             n0 = n_out * ratio                                      # whole ratio: int(11025 * n0 / fs) == n_out
             kw = dict(lpm=lpm, start_tone_s=0.5, phasing_lines=int(rng.integers(20, 44)), image_lines=400, stop_tone_s=0.5, black_tail_s=0.5)
             x = synth.synth_capture(float(fs), noise=float(rng.choice([0.0, 0.02, 0.05])), seed=int(rng.integers(1 << 30)), **kw)

@@ -126,6 +126,8 @@ int wfx_dist_copy2d(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces,
     if (npieces <= 0 || max_elems <= 0) return 0;
     if (elem_bytes == 16)
         WFX_LAUNCH(ctx, K_DIST_COPY, dist_copy2d_kernel<double2>, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
+    else if (elem_bytes == 8)
+        WFX_LAUNCH(ctx, K_DIST_COPY, dist_copy2d_kernel<double>, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
     else if (elem_bytes == 4)
         WFX_LAUNCH(ctx, K_DIST_COPY, dist_copy2d_kernel<unsigned>, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
     else

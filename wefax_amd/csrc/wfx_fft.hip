@@ -896,6 +896,68 @@ int wfx_dev_env_median_block(wfx_ctx *ctx, const cplx *V_global, const double *x
     return 0;
 }
 
+// One rank's block [s0, s1) of a sharded capture of ODD length: one point per sample, V[n].x = H[n].  V and x are indexed by
+// global sample index and valid two samples beyond the block on either side; zeros beyond the capture's true ends.
+__global__ void __launch_bounds__(256) hconv_env_median_block_plain(const cplx *__restrict__ V, const double *__restrict__ x, long long N, long long s0,
+                                                                   long long s1, double *__restrict__ env, unsigned *__restrict__ l0hist)
+{
+    __shared__ double tile[1024 + 8];
+    __shared__ unsigned h0[WFX_SEL_BINS];
+    const int t = threadIdx.x;
+    unsigned run_digit = 0, run_count = 0;
+    if (l0hist)
+        for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
+    const long long step = (long long)gridDim.x * 1024;
+    for (long long base = s0 + (long long)blockIdx.x * 1024; base < s1; base += step) {
+        __syncthreads();
+        for (int i = t; i < 1024 + 4; i += 256) {
+            const long long n = base - 2 + i;
+            tile[i] = (n >= 0 && n < N && n >= s0 - 2 && n < s1 + 2) ? env_abs(x[n], V[n].x) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = t + 256 * u;
+            if (base + j >= s1) continue;
+            double a = tile[j], b = tile[j + 1], c = tile[j + 2], d = tile[j + 3], e = tile[j + 4];
+            cswap_d(a, b);
+            cswap_d(d, e);
+            cswap_d(a, d);
+            cswap_d(b, e);
+            cswap_d(b, c);
+            cswap_d(c, d);
+            cswap_d(b, c);
+            env[base + j - s0] = c;
+            if (l0hist) {
+                const unsigned dg = (unsigned)(wfx_f64_key(c) >> 53);
+                if (dg == run_digit)
+                    ++run_count;
+                else {
+                    if (run_count) atomicAdd(&h0[run_digit], run_count);
+                    run_digit = dg;
+                    run_count = 1;
+                }
+            }
+        }
+    }
+    if (l0hist) {
+        if (run_count) atomicAdd(&h0[run_digit], run_count);
+        __syncthreads();
+        for (int i = t; i < WFX_SEL_BINS; i += 256)
+            if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
+    }
+}
+
+int wfx_dev_env_median_block_plain(wfx_ctx *ctx, const cplx *V_global, const double *x_global, uint64_t n_total, uint64_t s0, uint64_t s1, double *env_block,
+                                   unsigned *l0hist)
+{
+    if (s1 <= s0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "empty envelope block");
+    const unsigned grid = std::min(wfx_stream_grid(s1 - s0, 1024), 1024u);
+    WFX_LAUNCH(ctx, K_ENV_MEDIAN, hconv_env_median_block_plain, dim3(grid), dim3(256), V_global, x_global, (long long)n_total, (long long)s0, (long long)s1,
+               env_block, l0hist);
+    return 0;
+}
+
 static int hilbert_conv(wfx_ctx *ctx, const double *x, uint64_t n, cplx **W_out, int *packed_out, uint64_t *L_out)
 {
     // even N with a 13-smooth N/2: unpadded mixed-radix transforms, closed-form kernel spectrum

@@ -35,6 +35,10 @@ struct shard_plan {
     // samples of its rows that lie inside the capture -- the ranks whose rows are all padding own none (they still take part in
     // every transform and collective)
     bool padded = false;
+    // odd lengths (no resampling): nothing to pack -- one point per sample (K = n), real rows (mr2_pass IN_MODE 3), a real kernel,
+    // always the padded form (Kp >= 2n - 1: twice the points and four times the exchanged bytes of an even capture of that length)
+    bool plain = false;
+    int spp = 2;                          // samples per point
     long long Kp = 0;
     int wrap_rank = 0;                    // the rank holding the capture's last pair: it needs V[0] from rank 0 as "V[K]"
     uint64_t own_lo = 0, own_hi = 0, in_lo = 0, in_hi = 0;
@@ -49,8 +53,8 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: input kind %d", p->in_kind);
     if (p->hilbert_mode != WFX_HILBERT_FFT) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: the exact Hilbert mode only");
     if (p->n == 0 || p->n0 == 0 || (!p->resample && p->n != p->n0)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad capture lengths");
-    if ((p->n & 1) || (p->resample && (p->n0 & 1)))
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: sample counts must be even (the transforms are packed)");
+    if (p->resample && ((p->n & 1) || (p->n0 & 1)))
+        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: a resampled capture's sample counts must be even (its transforms are packed)");
     if (p->n >= (1ull << 31) || p->n0 >= (1ull << 32)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "capture too long");
     if (p->width <= 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad line width");
     pl.world = world;
@@ -59,12 +63,14 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     pl.in_kind = p->in_kind;
     pl.n0 = p->n0;
     pl.n = p->n;
-    pl.K = (long long)(p->n / 2);
+    pl.plain = (p->n & 1) != 0;
+    pl.spp = pl.plain ? 1 : 2;
+    pl.K = pl.plain ? (long long)p->n : (long long)(p->n / 2);
     pl.M1 = (long long)(p->n0 / 2);
     long long lens[2] = {pl.K, pl.M1};
     int ra1 = 0, rb1 = 0;
     pl.Kp = pl.K;
-    if (!wfx_dist_choose_r1(lens, pl.resample ? 2 : 1, world, &ra1, &rb1)) {
+    if (pl.plain || !wfx_dist_choose_r1(lens, pl.resample ? 2 : 1, world, &ra1, &rb1)) {
         // no plan for the capture's own half-length: pad the Hilbert convolution (a capture that is resampled on the way would
         // need the same for its two other transforms, whose lengths are the reference's to choose: not built)
         bool found = false;
@@ -107,8 +113,8 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     pl.Ms = pl.Kp / R1;
     pl.M1s = pl.M1 / R1;
     auto clipK = [&](long long pts) { return (uint64_t)(pts < pl.K ? pts : pl.K); };
-    pl.own_lo = 2ull * clipK((long long)pl.g.rows[rank] * pl.Ms);
-    pl.own_hi = 2ull * clipK((long long)pl.g.rows[rank + 1] * pl.Ms);
+    pl.own_lo = (uint64_t)pl.spp * clipK((long long)pl.g.rows[rank] * pl.Ms);
+    pl.own_hi = (uint64_t)pl.spp * clipK((long long)pl.g.rows[rank + 1] * pl.Ms);
     pl.wrap_rank = 0;
     for (int r = 0; r < world; ++r)
         if ((long long)pl.g.rows[r] * pl.Ms < pl.K) pl.wrap_rank = r;           // the last rank that owns samples
@@ -165,7 +171,7 @@ static int shard_bind(wfx_shard *sh)
     // audio segment [seg_lo, seg_hi): the notch output; the Hilbert transform's input rows start at own_lo
     // (padded form: the Hilbert transform reads all nr Ms points of the rank's rows starting at its first own sample; what lies
     // beyond the capture is the zero padding -- the notch never writes there, one memset at binding time is enough)
-    const size_t audio_bytes = pl.padded ? std::max((size_t)n_seg, (size_t)(pl.own_lo - pl.seg_lo) + 2 * (size_t)nr * (size_t)pl.Ms) * 8 + 64 : n_seg * 8 + 64;
+    const size_t audio_bytes = pl.padded ? std::max((size_t)n_seg, (size_t)(pl.own_lo - pl.seg_lo) + (size_t)pl.spp * (size_t)nr * (size_t)pl.Ms) * 8 + 64 : n_seg * 8 + 64;
     const bool audio_moved = !sh->b_audio.p || sh->b_audio.cap < audio_bytes;
     WFX_TRY(wfx_reserve(ctx, sh->b_audio, audio_bytes));
     if (pl.padded && (audio_moved || !sh->bound)) WFX_HIP(ctx, hipMemsetAsync(sh->b_audio.p, 0, audio_bytes, ctx->stream));
@@ -222,10 +228,13 @@ static int run_phase(wfx_shard *sh, int ph)
     if (pl.padded && !sh->ghat_ready) {
         // ---- the padded convolution's kernel, transformed once per shard: rows -> E1 -> pass 1 -> E2 -> slab passes ----
         if (ph == 0) {
-            WFX_TRY(wfx_dev_hilbert_kernel_rows(ctx, (cplx *)sh->b_grow.p, (long long)pl.g.rows[me] * pl.Ms, (long long)pl.g.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
+            if (pl.plain)
+                WFX_TRY(wfx_dev_hilbert_kernel_rows_plain(ctx, (double *)sh->b_grow.p, (long long)pl.g.rows[me] * pl.Ms, (long long)pl.g.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
+            else
+                WFX_TRY(wfx_dev_hilbert_kernel_rows(ctx, (cplx *)sh->b_grow.p, (long long)pl.g.rows[me] * pl.Ms, (long long)pl.g.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
             return sh->dH.fwd_pack_exchange(c, sh->b_grow.p);
         }
-        if (ph == 1) return sh->dH.fwd_pass1_exchange(c, 0);
+        if (ph == 1) return sh->dH.fwd_pass1_exchange(c, pl.plain ? 3 : 0);
         if (ph == 2) {
             cplx *G = nullptr;
             WFX_TRY(sh->dH.fwd_slab(0, &G));
@@ -243,6 +252,7 @@ static int run_phase(wfx_shard *sh, int ph)
             WFX_TRY(sh->dH.inv_unpack((cplx *)sh->b_v.p));
             cplx *vown = (cplx *)sh->b_v.p + SH_VHALO;
             wfx_xfer x{};
+            if (pl.plain) return wfx_comm_exchange(c, ctx, &x, 0);         // (one point per sample: H[n] = V[n].x, nothing wraps)
             x.peer = me == 0 ? pl.wrap_rank : 0;
             if (me == 0) {
                 x.send = vown;
@@ -299,7 +309,7 @@ static int run_phase(wfx_shard *sh, int ph)
         if (n_seg) WFX_TRY(wfx_dev_notch_fir_only(ctx, nin, nkind, n_seg, p.notch_b, p.notch_a, audio, flags, use_ext ? ext18 : nullptr));
         return sh->dH.fwd_pack_exchange(c, audio + (pl.own_lo - pl.seg_lo));
     }
-    case 5: return sh->dH.fwd_pass1_exchange(c, 1);
+    case 5: return sh->dH.fwd_pass1_exchange(c, pl.plain ? 3 : 1);
     case 6: {
         cplx *G = nullptr;
         if (pl.padded)
@@ -313,9 +323,10 @@ static int run_phase(wfx_shard *sh, int ph)
         if (!pl.padded) WFX_TRY(sh->dH.inv_unpack((cplx *)sh->b_v.p));         // (padded: done with the wrap, one phase earlier)
         WFX_TRY(wfx_dev_select_sharded_ws(ctx, &sh->ws));
         // pointers indexed by global pair / sample index (the rank's rows start at pair rows[me] Ms = own_lo / 2 when it owns samples)
-        const cplx *Vg = (const cplx *)sh->b_v.p - ((long long)(pl.own_lo / 2) - SH_VHALO);
+        const cplx *Vg = (const cplx *)sh->b_v.p - ((long long)(pl.own_lo / pl.spp) - SH_VHALO);
         const double *xg = audio - (long long)pl.seg_lo;
-        if (n_own) WFX_TRY(wfx_dev_env_median_block(ctx, Vg, xg, pl.n, pl.own_lo, pl.own_hi, env, sh->ws));
+        if (n_own && pl.plain) WFX_TRY(wfx_dev_env_median_block_plain(ctx, Vg, xg, pl.n, pl.own_lo, pl.own_hi, env, sh->ws));
+        if (n_own && !pl.plain) WFX_TRY(wfx_dev_env_median_block(ctx, Vg, xg, pl.n, pl.own_lo, pl.own_hi, env, sh->ws));
         return wfx_comm_allreduce_u32(c, ctx, sh->ws, WFX_SEL_BINS);
     }
     case 9: {
@@ -333,7 +344,7 @@ static int run_phase(wfx_shard *sh, int ph)
         std::vector<wfx_xfer> xs;
         if (me == 0) {
             for (int s = 1; s < W; ++s) {
-                uint64_t lo = 2ull * (uint64_t)pl.g.rows[s] * (uint64_t)pl.Ms, hi = 2ull * (uint64_t)pl.g.rows[s + 1] * (uint64_t)pl.Ms;
+                uint64_t lo = (uint64_t)pl.spp * (uint64_t)pl.g.rows[s] * (uint64_t)pl.Ms, hi = (uint64_t)pl.spp * (uint64_t)pl.g.rows[s + 1] * (uint64_t)pl.Ms;
                 lo = lo < pl.n ? lo : pl.n;                      // (padded form: rows beyond the capture hold no samples)
                 hi = hi < pl.n ? hi : pl.n;
                 wfx_xfer a{};
@@ -504,7 +515,7 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
         WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward"));
         WFX_TRY(dry_check_transform(pl, p, pl.K, 16, SH_HALO / 2, SH_HALO / 2, false, true, "resample inverse"));
     }
-    return dry_check_transform(pl, p, pl.Kp, 16, SH_VHALO, SH_VHALO, true, true, pl.padded ? "hilbert (padded)" : "hilbert");
+    return dry_check_transform(pl, p, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO, true, true, pl.plain ? "hilbert (odd length)" : (pl.padded ? "hilbert (padded)" : "hilbert"));
 }
 
 #define CHECK_SH(sh)                                                                                              \
@@ -557,7 +568,7 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
         rc = sh->dF.init(ctx, pl.g, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0);
         if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, SH_HALO / 2, SH_HALO / 2);
     }
-    if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.Kp, 16, SH_VHALO, SH_VHALO);
+    if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO);
     if (rc != 0) {
         wfx_shard_destroy(sh);
         return rc;
