@@ -350,7 +350,8 @@ typedef struct {
 } wfx_shard_layout;
 
 /* host only (no GPU needed): how a capture described by `p` is cut for `world` ranks; WFX_ERR_BAD_ARG when it cannot be
- * sharded (odd or non-13-smooth lengths, too short for the world size): decode it on one GPU then */
+ * sharded (a resampled capture of odd or non-13-smooth half-lengths; too short for the world size): decode it on one GPU then.
+ * Captures at 11 025 Hz shard at ANY length (odd ones with one point per sample: own_lo / own_hi need not be even then) */
 int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_shard_layout *out);
 /* host only: builds every rank's exchange lists for `world` ranks with fake buffer addresses and checks that the two ends of
  * every message agree, that what a rank receives tiles its buffers exactly, and that every packing copy stays inside its
