@@ -218,6 +218,12 @@ int wfx_decode_copy_to_device(wfx_ctx *ctx, int buffer_id, void *dst_dev, size_t
  * memory owned by the context (valid until the next call); wfx_decode_save_png writes it to `path`. */
 int wfx_decode_png(wfx_ctx *ctx, const void **file_bytes, size_t *nbytes);
 int wfx_decode_save_png(wfx_ctx *ctx, const char *path, size_t *bytes_written);
+/* the same with deflate != 0: the COMPRESSED file, also encoded on the device -- rows "Up"-filtered, chunks of whole rows as
+ * dynamic-Huffman deflate blocks (literals + distance-1 runs, one code per image built from the token histogram, chunks joined by
+ * empty stored blocks), i.e. what PIL's zlib stream is for the reference (wefax.py:408: identical pixels, a file of the same order
+ * of size).  deflate == 0: the stored form above */
+int wfx_decode_png_ex(wfx_ctx *ctx, int deflate, const void **file_bytes, size_t *nbytes);
+int wfx_decode_save_png_ex(wfx_ctx *ctx, const char *path, int deflate, size_t *bytes_written);
 /* page-locked host memory: captures uploaded from it and images fetched into it cross PCIe by DMA (no staging copies) */
 void *wfx_host_alloc(size_t bytes);
 void  wfx_host_free(void *p);

@@ -307,24 +307,69 @@ def test_command_line_wav_to_png(name, lpm, tmp_path):
         pass
 
 
-def test_png_assembled_on_the_device_and_the_compressed_alternative(tmp_path):
-    """save_output_image: by default the file comes from wfx_decode_save_png (stored deflate blocks, Adler-32 and CRC-32 from
-    kernels: zlib and the chunk reader below verify both); compress=6 takes the threaded zlib encoder.  Same pixels either way,
-    and a context that has moved on to another decode falls back to encoding the host copy."""
+def test_png_assembled_on_the_device_and_the_compressed_alternative(tmp_path, monkeypatch):
+    """save_output_image: by default the file comes from wfx_decode_save_png_ex (device deflate; WEFAX_PNG_STORED=1: stored deflate
+    blocks; Adler-32 and CRC-32 from kernels either way: zlib and the chunk reader below verify both); compress=6 takes the threaded
+    zlib encoder on the host.  Same pixels every way, and a context that has moved on to another decode falls back to encoding the
+    host copy."""
     from wefax_amd import Demodulator
     g = np.load(os.path.join(GOLDEN, "mono_noisy_120.npz"))
     d = Demodulator(os.path.join(GOLDEN, "inputs", "mono_noisy_120.wav"), lines_per_minute=120, quiet=True)
     d.process()
-    a, b, c = str(tmp_path / "a.png"), str(tmp_path / "b.png"), str(tmp_path / "c.png")
+    a, b, c, e = str(tmp_path / "a.png"), str(tmp_path / "b.png"), str(tmp_path / "c.png"), str(tmp_path / "e.png")
+    monkeypatch.setenv("WEFAX_PNG_STORED", "1")
     d.save_output_image(a)
+    monkeypatch.delenv("WEFAX_PNG_STORED")
+    d.save_output_image(e)
     d.save_output_image(b, compress=6)
     assert os.path.getsize(a) > d.output_array.size and os.path.getsize(b) < os.path.getsize(a)
+    assert os.path.getsize(e) < 0.75 * os.path.getsize(a) and os.path.getsize(e) < 1.1 * os.path.getsize(b)
+    assert np.array_equal(_read_png_gray8(e), g["image"])
+    assert d._ctx.decode_png(deflate=True) == open(e, "rb").read()
     blob = d._ctx.decode_png()
     assert blob == open(a, "rb").read()
     d._ctx.notch_filtfilt(np.zeros(100), [1.0, 0.0, 0.0], [1.0, 0.0, 0.0])      # the context forgets the decode ...
     d.save_output_image(c)                                                       # ... and the host copy is encoded instead
     for path in (a, b, c):
         assert np.array_equal(_read_png_gray8(path), g["image"]), path
+
+
+@pytest.mark.parametrize("name,lpm", [("mono_clean_120", 120), ("mono_noisy_240", 240), ("mono48k_image_240", 240), ("synthetic", 100)])
+def test_device_deflate_png(name, lpm, tmp_path):
+    """wfx_decode_png_ex(deflate = 1): the compressed PNG encoded by kernels (Up filter, dynamic-Huffman blocks with distance-1
+    runs, one code per image, chunks joined by empty stored blocks) inflates -- with zlib, which checks the Adler-32, through a
+    reader that checks the CRC-32s, and with Pillow -- to the decoder's image; the same bytes every time; far smaller than the
+    stored form on a clean picture, within 15 % of zlib level 6 (which also has LZ77 matches) on the same filtered bytes otherwise.
+    LPM 100 gives a width that is not a multiple of four (the byte-wise loader)."""
+    from wefax_amd import Demodulator, synth
+    if name == "synthetic":
+        wav = str(tmp_path / "s.wav")
+        synth.write_wav(wav, 11025, synth.synth_capture(11025.0, noise=0.02, seed=5, lpm=lpm, image_lines=90, phasing_lines=20))
+    else:
+        wav = os.path.join(GOLDEN, "inputs", name + ".wav")
+    d = Demodulator(wav, lines_per_minute=lpm, quiet=True)
+    d.process()
+    img = d.output_array
+    if name != "synthetic":
+        assert np.array_equal(img, np.load(os.path.join(GOLDEN, name + ".npz"))["image"])
+    blob, stored = d._ctx.decode_png(deflate=True), d._ctx.decode_png()
+    assert blob == d._ctx.decode_png(deflate=True)
+    out = str(tmp_path / "d.png")
+    open(out, "wb").write(blob)
+    assert np.array_equal(_read_png_gray8(out), img)
+    raw = np.empty((img.shape[0], img.shape[1] + 1), np.uint8)
+    raw[:, 0] = 2
+    raw[0, 1:] = img[0]
+    np.subtract(img[1:], img[:-1], out=raw[1:, 1:])
+    z6 = len(zlib.compress(raw.tobytes(), 6))
+    assert len(blob) < (0.2 if name == "mono_clean_120" else 0.8) * len(stored)
+    assert len(blob) < (1.6 if name == "mono_clean_120" else 1.15) * z6
+    try:
+        from PIL import Image
+        assert np.array_equal(np.asarray(Image.open(out)), img)
+    except ImportError:
+        pass
+    d.close()
 
 
 def test_random_captures_against_the_oracle():

@@ -36,7 +36,7 @@ SYMBOLS = [
     "wfx_comm_barrier", "wfx_comm_allgather_host",
     "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
     "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
-    "wfx_synth_frames", "wfx_synth_capture", "wfx_decode_png", "wfx_decode_save_png", "wfx_host_alloc", "wfx_host_free",
+    "wfx_synth_frames", "wfx_synth_capture", "wfx_decode_png", "wfx_decode_save_png", "wfx_decode_png_ex", "wfx_decode_save_png_ex", "wfx_host_alloc", "wfx_host_free",
     "wfx_decode_reload", "wfx_decode_fetch_async", "wfx_plan_padded_length", "wfx_plan_describe",
     "wfx_timer_start", "wfx_timer_stop", "wfx_profile_enable", "wfx_profile_reset",
     "wfx_profile_kernel_count", "wfx_profile_kernel_name", "wfx_profile_get",
@@ -210,6 +210,8 @@ def load():
     lib.wfx_shard_destroy.argtypes = [vp]
     lib.wfx_decode_png.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     lib.wfx_decode_save_png.argtypes = [vp, C.c_char_p, C.POINTER(sz)]
+    lib.wfx_decode_png_ex.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz)]
+    lib.wfx_decode_save_png_ex.argtypes = [vp, C.c_char_p, i, C.POINTER(sz)]
     lib.wfx_host_alloc.argtypes = [sz]
     lib.wfx_host_alloc.restype = vp
     lib.wfx_host_free.argtypes = [vp]
@@ -401,15 +403,16 @@ class Context:
         """Enqueue the copy of a stage buffer into ``out`` (pinned) without waiting; ``sync()`` / ``decode_result()`` waits."""
         self._check(self.lib.wfx_decode_fetch_async(self.h, buffer_id, _ptr(out), out.nbytes))
 
-    def decode_png(self) -> bytes:
-        """The PNG file of the decode's image (8-bit gray, stored deflate blocks), assembled on the device."""
+    def decode_png(self, deflate: bool = False) -> bytes:
+        """The PNG file of the decode's image (8-bit gray), assembled on the device: stored deflate blocks, or with ``deflate`` the
+        compressed form (Up filter + dynamic-Huffman blocks encoded by kernels)."""
         p, n = C.c_void_p(0), C.c_size_t(0)
-        self._check(self.lib.wfx_decode_png(self.h, C.byref(p), C.byref(n)))
+        self._check(self.lib.wfx_decode_png_ex(self.h, 1 if deflate else 0, C.byref(p), C.byref(n)))
         return C.string_at(p.value, n.value)
 
-    def decode_save_png(self, path: str) -> int:
+    def decode_save_png(self, path: str, deflate: bool = False) -> int:
         n = C.c_size_t(0)
-        self._check(self.lib.wfx_decode_save_png(self.h, os.fsencode(path), C.byref(n)))
+        self._check(self.lib.wfx_decode_save_png_ex(self.h, os.fsencode(path), 1 if deflate else 0, C.byref(n)))
         return int(n.value)
 
     def decode_bind_image(self, dst_ptr: int, capacity: int):

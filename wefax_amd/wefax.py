@@ -393,16 +393,17 @@ class Demodulator:
     def save_output_image(self, filepath: str, compress: int | None = None):   # wefax.py:407-408
         """Same picture the reference writes (8-bit gray PNG, w x 4h, identical pixels).  Encoding 27 MB on the host used to
         dominate the whole file-to-file time (PIL: 1.6 s; threaded zlib: 55 ms; the kernels: 0.35 ms), so by default the PNG is
-        assembled ON THE DEVICE from the image still resident there (``wfx_decode_save_png``: stored deflate blocks -- valid PNG,
-        not compressed -- Adler-32 / CRC-32 computed by kernels).  ``compress`` = 1..9 (or WEFAX_PNG_COMPRESS in the environment)
-        selects the threaded zlib encoder of wefax_amd/pngio.py instead: smaller file, ~50 ms more.  Other formats go through
-        PIL like the reference."""
+        encoded ON THE DEVICE from the image still resident there (``wfx_decode_save_png_ex``: rows Up-filtered, dynamic-Huffman
+        deflate blocks with distance-1 runs, Adler-32 / CRC-32 -- all by kernels; a file within a few percent of zlib level 6's on
+        noisy pictures, 5 ms for the 10-minute capture).  WEFAX_PNG_STORED=1 in the environment selects stored (uncompressed)
+        deflate blocks instead; ``compress`` = 1..9 (or WEFAX_PNG_COMPRESS) the threaded zlib encoder of wefax_amd/pngio.py on the
+        host, ~50 ms.  Other formats go through PIL like the reference."""
         if filepath.lower().endswith(".png") and getattr(self, "_image_shape", None) is not None:
             if compress is None and os.environ.get("WEFAX_PNG_COMPRESS"):
                 compress = int(os.environ["WEFAX_PNG_COMPRESS"])
             if not compress and self._ctx is not None and self._job is not None:
                 try:
-                    self._ctx.decode_save_png(filepath)
+                    self._ctx.decode_save_png(filepath, deflate=os.environ.get("WEFAX_PNG_STORED") != "1")
                     return
                 except nat.NativeError:
                     pass                    # the context has moved on to another decode: encode the host copy instead
