@@ -94,6 +94,50 @@ def test_wav_reader_matches_oracle_reader(case):
     assert sr0 == sr1 and d0.dtype == d1.dtype and np.array_equal(d0, d1)
 
 
+def test_wav_reader_threads_allocator_and_truncated_files(tmp_path):
+    """Files beyond one read slice are copied out of the page cache by several threads, into memory the caller provides when it
+    gives an allocator (the decoder: its context's page-locked staging buffer); chunks in front of `data` are skipped; a data
+    chunk whose header promises more than the file holds yields the whole frames that are there (scipy: the same, with a
+    warning); 24-bit PCM is widened as scipy does."""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(4)
+    x = rng.integers(-32768, 32767, size=(1_400_001, 2), dtype=np.int16)            # 5.6 MB: three slices
+    p = str(tmp_path / "big.wav")
+    wavfile.write(p, 48000, x)
+    blob = open(p, "rb").read()
+    q = str(tmp_path / "list.wav")
+    pos = blob.index(b"data")
+    with open(q, "wb") as fh:                                                        # a LIST chunk of odd size (padded) before the samples
+        extra = b"LIST" + (5).to_bytes(4, "little") + b"abcde\0"
+        body = blob[12:pos] + extra + blob[pos:]
+        fh.write(b"RIFF" + (4 + len(body)).to_bytes(4, "little") + b"WAVE" + body)
+    asked = []
+
+    def alloc(nbytes):
+        asked.append(nbytes)
+        return np.zeros(nbytes + 100, np.uint8)
+
+    for path in (p, q):
+        sr, d = hp.read_wav(path, alloc=alloc)
+        assert sr == 48000 and d.dtype == np.int16 and d.shape == x.shape and np.array_equal(d, x)
+        assert d.flags.writeable
+    assert asked == [x.nbytes, x.nbytes]
+    t = str(tmp_path / "cut.wav")
+    open(t, "wb").write(blob[:len(blob) - 4 * 1000 - 3])                             # 1000 frames and 3 bytes short
+    sr, d = hp.read_wav(t)
+    assert d.shape == (x.shape[0] - 1001, 2) and np.array_equal(d, x[:-1001])
+    y = rng.integers(-2**23, 2**23 - 1, size=50_000, dtype=np.int32)
+    raw = np.ascontiguousarray((y.astype("<i4").view(np.uint8).reshape(-1, 4))[:, :3]).tobytes()
+    hdr = b"fmt " + (16).to_bytes(4, "little") + (1).to_bytes(2, "little") + (1).to_bytes(2, "little") + (11025).to_bytes(4, "little") + \
+        (33075).to_bytes(4, "little") + (3).to_bytes(2, "little") + (24).to_bytes(2, "little")
+    body = hdr + b"data" + len(raw).to_bytes(4, "little") + raw
+    u = str(tmp_path / "p24.wav")
+    open(u, "wb").write(b"RIFF" + (4 + len(body)).to_bytes(4, "little") + b"WAVE" + body)
+    sr, d = hp.read_wav(u)
+    sr0, d0 = wavfile.read(u)
+    assert sr == sr0 == 11025 and d.dtype == d0.dtype and np.array_equal(d, d0)
+
+
 def test_iirnotch_matches_oracle():
     for fs in (11025, 8000, 48000):
         b0, a0 = wo.iirnotch(2600, 1, fs)

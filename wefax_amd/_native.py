@@ -272,6 +272,8 @@ class Context:
         if getattr(self, "h", None):
             self.lib.wfx_destroy(self.h)
             self.h = None
+        self._staging = None
+        self._keep = None
 
     def __del__(self):
         try:
@@ -373,6 +375,16 @@ class Context:
         return img
 
     # ---- fused decode ---------------------------------------------------------
+    def staging(self, nbytes: int) -> np.ndarray:
+        """This context's page-locked staging buffer (uint8, at least ``nbytes``; grown when needed, freed with the context):
+        where ``hostparams.read_wav`` puts a file's samples so that the upload is a DMA.  Its contents are valid until the next
+        call."""
+        buf = getattr(self, "_staging", None)
+        if buf is None or buf.nbytes < nbytes:
+            self._staging = None
+            buf = self._staging = pinned_empty((max(int(nbytes) * 5 // 4, 1 << 20),), np.uint8)
+        return buf
+
     def decode_upload(self, data: np.ndarray, params: DecodeParams):
         data = np.ascontiguousarray(data)
         self._keep = data

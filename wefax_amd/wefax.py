@@ -275,7 +275,11 @@ class Demodulator:
         (int(nan), wefax.py:216)."""
         self._cache = {}
         self._image_shape = None
-        sample_rate, data = hp.read_wav(self.filepath)                      # wefax.py:349
+        if self._ctx is None:
+            self._ctx = _acquire_context(self._device)
+        # the samples go from the page cache into the context's page-locked staging buffer (a few threads) and from there to the
+        # device by DMA; `data` is a view of that buffer, used before process() returns
+        sample_rate, data = hp.read_wav(self.filepath, alloc=self._ctx.staging)    # wefax.py:349
         if data.ndim == 2:                                                  # wefax.py:351-355
             self._say("\033[0;33mWARNING: two channels audio detected. Program will try to merge audio to one channel\033[0m")
             self._say("MERGING AUDIO CHANNELS:")
@@ -290,8 +294,6 @@ class Demodulator:
             self._say(f"RESAMPLING AUDIO FROM {round(sample_rate / 1000, 2)} KhZ TO 11.025 KHZ:")
             self._progress("resampling audio", 0)
 
-        if self._ctx is None:
-            self._ctx = _acquire_context(self._device)
         notch = hp.load_notch_settings()
         job = DecodeJob(self._ctx, data, sample_rate, self.lines_per_minute, notch,
                         self._hilbert_mode)
