@@ -763,7 +763,7 @@ int wfx_decode_save_png_ex(wfx_ctx *ctx, const char *path, int deflate, size_t *
     // writer), so the file is written in slices by a few threads
     const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "cannot open %s for writing", path);
-    const size_t slice = (size_t)4 << 20;
+    static const size_t slice = getenv("WFX_PNG_SLICE_KB") ? (size_t)atol(getenv("WFX_PNG_SLICE_KB")) << 10 : (size_t)4 << 20;
     unsigned nthr = std::thread::hardware_concurrency();
     nthr = nthr < 1 ? 1 : nthr > 8 ? 8 : nthr;
     const size_t nslices = (n + slice - 1) / slice;
