@@ -179,12 +179,13 @@ def _capture(rate, seed, lpm, trim=0):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,rate,lpm,trim", [(2, 11025, 240, 0), (3, 48000, 240, 0), (4, 11025, 120, 0), (8, 48000, 120, 0),
-                                                 (3, 11025, 120, 4478), (8, 11025, 240, 1234)])
+                                                 (3, 11025, 120, 4478), (8, 11025, 240, 1234), (4, 11025, 120, 3333), (8, 11025, 240, 777)])
 def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, world, rate, lpm, trim):
     """ShardedDecoder over the shm transport, `world` processes on one GPU, three decodes back to back with the ranks drifting
     apart: uint8 stream, image, start_frame and the float64 envelope blocks equal the fused one-GPU decode / the in-process
     emulation bit for bit.  ``trim``: an arbitrary even length (half-length not 13-smooth): the padded distributed convolution,
-    whose first decode carries three extra phases and whose ranks may own no samples at all."""
+    whose first decode carries three extra phases and whose ranks may own no samples at all; an odd trim gives an ODD length (one
+    point per sample, real rows)."""
     from wefax_amd import sharded
     from wefax_amd.wefax import DecodeJob
     x = _capture(rate, 5, lpm, trim)

@@ -54,6 +54,9 @@ python bench.py --workload c3 > "$OUT/bench_c3.json" 2>> "$OUT/bench.err"
 WFX_BENCH_FORCE_DIST=1 python bench.py --workload c3 --no-cpu > "$OUT/bench_c3_rccl1.json" 2>> "$OUT/bench.err"
 python bench.py --workload iq > "$OUT/bench_iq_3600s.json" 2>> "$OUT/bench.err"
 python tools/e2e.py > "$OUT/e2e_c2.json" 2>> "$OUT/bench.err"
+python tools/e2e_breakdown.py > "$OUT/e2e_breakdown.txt" 2>> "$OUT/bench.err"
+# the PNG encoded on the device (deflate) against zlib: decodes to the image, sizes, times
+python tools/png_deflate_check.py --full > "$OUT/png_deflate.jsonl" 2>> "$OUT/bench.err"
 # every rank of 1 / 2 / 3 / 8 emulated on this GPU, against the oracle
 python tools/shard_check.py --cases plain,resample,stereo,lpm240,c2 > "$OUT/shard_check.jsonl" 2>> "$OUT/bench.err"
 python tools/shard_check2.py iq > "$OUT/shard_check_iq.jsonl" 2>> "$OUT/bench.err"
@@ -84,7 +87,7 @@ WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --steps 3 --warmu
 timeout 1200 python tools/random_parity.py --cases 200 --seed 11 > "$OUT/random_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_parity.jsonl"
 
 timeout 2400 python tools/random_fe_parity.py --cases 200 --seed 8 > "$OUT/random_fe_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_fe_parity.jsonl" | cut -c1-400
-timeout 1200 python tools/random_shard_parity.py --cases 24 --seed 5 > "$OUT/random_shard_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_shard_parity.jsonl"
+timeout 1200 python tools/random_shard_parity.py --cases 60 --seed 5 > "$OUT/random_shard_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_shard_parity.jsonl"
 
 # the read-streaming ceiling of this box and the ingest stage against it
 if [ -x tools/micro/build/stream_big ]; then timeout 120 tools/micro/build/stream_big > "$OUT/stream_ceiling.txt" 2>&1; fi
