@@ -125,6 +125,47 @@ def _read_into(fd: int, dest: np.ndarray, offset: int):
     list(_READ_POOL.map(part, starts))
 
 
+def _wav_header(fh):
+    """(format tag, channels, rate, bits, offset of the samples, their byte count) of an open RIFF/WAVE file."""
+    head = fh.read(12)
+    if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+        raise ValueError("File format not understood. Only 'RIFF' and 'WAVE' supported.")
+    file_size = os.fstat(fh.fileno()).st_size
+    pos, fmt, payload = 12, None, None
+    while pos + 8 <= file_size:
+        fh.seek(pos)
+        hdr = fh.read(8)
+        if len(hdr) < 8:
+            break
+        cid, size = hdr[:4], struct.unpack("<I", hdr[4:])[0]
+        body = pos + 8
+        if cid == b"fmt ":
+            blob = fh.read(min(size, 64))
+            tag, ch, rate, _bps, _align, bits = struct.unpack_from("<HHIIHH", blob, 0)
+            if tag == 0xFFFE and size >= 40:
+                tag = struct.unpack_from("<H", blob, 24)[0]
+            fmt = (tag, ch, rate, bits)
+        elif cid == b"data":
+            payload = (body, max(0, min(size, file_size - body)))
+            break
+        pos = body + size + (size & 1)
+    if fmt is None or payload is None:
+        raise ValueError("Incomplete wav file: missing fmt or data chunk")
+    return (*fmt[:2], fmt[2], fmt[3], *payload)
+
+
+_WAV_ITEM = {(1, 8): 1, (1, 16): 2, (1, 24): 3, (1, 32): 4, (3, 32): 4, (3, 64): 8}
+
+
+def wav_info(path: str):
+    """(sample_rate, frames, channels) from the headers alone -- what file_info (wefax.py:342-346) reports, without the samples."""
+    with open(path, "rb") as fh:
+        tag, ch, rate, bits, _body, nbytes = _wav_header(fh)
+    if (tag, bits) not in _WAV_ITEM:
+        raise ValueError(f"Unsupported wav format tag {tag:#x} with {bits} bits")
+    return int(rate), (nbytes // (_WAV_ITEM[(tag, bits)] * ch) if ch else 0), int(ch)
+
+
 def read_wav(path: str, alloc=None):
     """(sample_rate, ndarray) from a RIFF/WAVE file, PCM or IEEE float, in the
     dtypes scipy.io.wavfile.read (wefax.py:349) returns: uint8, int16, int32
@@ -134,32 +175,7 @@ def read_wav(path: str, alloc=None):
     (bytes -> uint8 array of at least that size) lets the caller provide the memory: the decoder passes its context's page-locked
     staging buffer, from which the upload is a DMA (the array is then only valid until that context reads its next file)."""
     with open(path, "rb") as fh:
-        head = fh.read(12)
-        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
-            raise ValueError("File format not understood. Only 'RIFF' and 'WAVE' supported.")
-        file_size = os.fstat(fh.fileno()).st_size
-        pos, fmt, payload = 12, None, None
-        while pos + 8 <= file_size:
-            fh.seek(pos)
-            hdr = fh.read(8)
-            if len(hdr) < 8:
-                break
-            cid, size = hdr[:4], struct.unpack("<I", hdr[4:])[0]
-            body = pos + 8
-            if cid == b"fmt ":
-                blob = fh.read(min(size, 64))
-                tag, ch, rate, _bps, _align, bits = struct.unpack_from("<HHIIHH", blob, 0)
-                if tag == 0xFFFE and size >= 40:
-                    tag = struct.unpack_from("<H", blob, 24)[0]
-                fmt = (tag, ch, rate, bits)
-            elif cid == b"data":
-                payload = (body, max(0, min(size, file_size - body)))
-                break
-            pos = body + size + (size & 1)
-        if fmt is None or payload is None:
-            raise ValueError("Incomplete wav file: missing fmt or data chunk")
-        tag, ch, rate, bits = fmt
-        body, nbytes = payload
+        tag, ch, rate, bits, body, nbytes = _wav_header(fh)
         if tag == 1 and bits == 24:
             raw = np.empty(nbytes // 3 * 3, dtype=np.uint8)
             _read_into(fh.fileno(), raw, body)

@@ -382,9 +382,9 @@ class Demodulator:
 
     # ------------------------------------------------------------------ the rest
     def file_info(self):                                                    # wefax.py:342-346
-        sample_rate, data = hp.read_wav(self.filepath)
-        channels = len(data.shape)          # the reference reports ndim, not the channel count
-        length = len(data) / sample_rate
+        sample_rate, frames, ch = hp.wav_info(self.filepath)               # (the reference reads the samples for this)
+        channels = 2 if ch > 1 else 1       # the reference reports ndim, not the channel count
+        length = frames / sample_rate
         return {"filename": self.filename, "channels": channels, "sample_rate": sample_rate, "length": length}
 
     def show_output_image(self):                                            # wefax.py:403-405
