@@ -355,9 +355,12 @@ typedef struct {
     uint64_t own_lo, own_hi;   /* samples at 11 025 Hz this rank owns                                                 */
 } wfx_shard_layout;
 
-/* host only (no GPU needed): how a capture described by `p` is cut for `world` ranks; WFX_ERR_BAD_ARG when it cannot be
- * sharded (a resampled capture of odd or non-13-smooth half-lengths; too short for the world size): decode it on one GPU then.
- * Captures at 11 025 Hz shard at ANY length (odd ones with one point per sample: own_lo / own_hi need not be even then) */
+/* host only (no GPU needed): how a capture described by `p` is cut for `world` ranks.  Captures at 11 025 Hz shard at ANY
+ * length (odd ones with one point per sample: own_lo / own_hi need not be even then; some ranks may own nothing).  A capture
+ * with no distributed form -- resampled with odd or non-13-smooth half-lengths, or too short for the world size -- gets the
+ * SINGLE plan: first_radix = {0, 0}, rank 0 owns (and must provide) the whole capture and decodes it alone with the fused
+ * one-GPU path, the other ranks provide nothing and receive the scalars; the calls below behave the same either way.
+ * WFX_ERR_BAD_ARG only for parameters no path accepts */
 int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_shard_layout *out);
 /* host only: builds every rank's exchange lists for `world` ranks with fake buffer addresses and checks that the two ends of
  * every message agree, that what a rank receives tiles its buffers exactly, and that every packing copy stays inside its

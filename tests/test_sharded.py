@@ -71,14 +71,22 @@ def test_any_length_at_the_native_rate_gets_a_padded_plan(n0):
         nat.shard_dry_run(p, world)
 
 
-def test_captures_that_cannot_be_sharded_are_refused_with_a_reason():
-    for n0, sr, world, what in [(1440001, 48000, 2, "even"),            # odd length, resampled: its transforms are packed
-                                (4000, 11025, 8, "short"),               # too short for the world size
-                                (749700, 22050, 2, "13-smooth")]:        # 34 s at 22 050 Hz: a factor 17 in both transforms (resampled: no padded form yet)
-        p, _ = build_params(0 if sr == 11025 else 2, n0, sr, 0.5)
-        with pytest.raises(nat.NativeError) as e:
-            nat.shard_layout(p, world, 0)
-        assert what in str(e.value), str(e.value)
+def test_captures_without_a_distributed_form_get_the_single_plan():
+    """A resampled capture whose half-lengths are odd or not 13-smooth (its inverse transform's length is the reference's to
+    choose), or a capture too short for the world size, is not refused: rank 0 owns it whole and decodes it alone (first_radix
+    (0, 0)), the other ranks own nothing.  Every rank reaches the same verdict from the description alone."""
+    for n0, sr, world in [(1440001, 48000, 2),             # odd length, resampled: its transforms are packed
+                          (4000, 11025, 8),                 # too short for the world size
+                          (749700, 22050, 2),               # 34 s at 22 050 Hz: a factor 17 in both transforms
+                          (1440002, 48000, 3), (792000, 44100, 8)]:      # (int(11025 * (792000 / 44100)) = 197999: odd)
+        p, meta = build_params(0 if sr == 11025 else 2, n0, sr, 0.5)
+        lays = [nat.shard_layout(p, world, r) for r in range(world)]
+        assert all(tuple(lay.first_radix) == (0, 0) for lay in lays)
+        assert (lays[0].own_lo, lays[0].own_hi, lays[0].in_lo, lays[0].in_hi) == (0, meta["n"], 0, n0)
+        assert all(lay.own_lo == lay.own_hi == meta["n"] and lay.in_lo == lay.in_hi == n0 for lay in lays[1:])
+        nat.shard_dry_run(p, world)
+        assert sharded.layout_supported(n0, sr, world, kind=0 if sr == 11025 else 2) and not sharded.layout_distributed(n0, sr, world, kind=0 if sr == 11025 else 2)
+    assert sharded.layout_distributed(1433250, 11025, 8, kind=0)
     p, _ = build_params(0, 1433250, 11025, 0.5)
     with pytest.raises(nat.NativeError):
         nat.shard_layout(p, 2, 2)                                       # rank out of range
@@ -339,6 +347,31 @@ def test_sharded_decode_of_any_length_equals_the_oracle(n):
             first = r
         else:
             assert np.array_equal(r["envelope"], first["envelope"]) and r["low"] == first["low"] and r["high"] == first["high"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs,n0,stereo", [(48000, 1440001, False), (48000, 1200002 + 2 * 7919, True), (22050, 749700, False), (44100, 792000, False),
+                                          (11025, 30000, False)])
+def test_captures_on_the_single_plan_decode_like_the_one_gpu_path(fs, n0, stereo):
+    """Resampled captures of arbitrary length (odd; a prime factor above 13; a reference length int(11025 n0 / fs) that comes out
+    odd) and a capture too short for eight ranks: the sharded interface takes them -- rank 0 decodes alone, the others receive
+    the scalars -- and the result is the oracle's for every world size."""
+    lines = max(12, int(n0 / fs * 2) - 30)
+    x = synth.synth_capture(float(fs), noise=0.03, seed=n0 % 997, start_tone_s=1.0, phasing_lines=20, image_lines=lines, stop_tone_s=0.5, black_tail_s=0.5)
+    x = np.concatenate([x, x[:max(0, n0 - x.shape[0])]])[:n0]
+    data = np.stack([x, (x // 3).astype(np.int16)], axis=1) if stereo else x
+    ref = _oracle(data, fs, 120)
+    for world in (1, 2, 3, 8):
+        assert not sharded.layout_distributed(n0, fs, world, kind=sharded.capture_kind(data)) or fs == 11025 and world < 8
+        r = sharded.decode_emulated(data, fs, world, 120, repeat=2)
+        assert np.array_equal(r["digitalized"], ref["digitalized"]), f"world {world}: uint8 stream differs"
+        assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
+        if ref.get("exception") is None:
+            assert r["sync"]["start_frame"] == ref["start_frame"] and r["sync"]["peaks"] == [int(v) for v in ref["peaks"]]
+            assert np.array_equal(r["image"], ref["image"])
+        else:
+            assert r["sync"]["no_group"]
+        assert len(set(r["lows"])) == 1 and len(set(r["highs"])) == 1           # the scalars reached every rank
 
 
 @pytest.mark.gpu

@@ -46,6 +46,9 @@ def main():
             if fs == 11025 and rng.integers(0, 3) > 0:              # the native rate takes ANY length (padded distributed convolution)
                 n_out = int(rng.integers(150000, 420000))
             n0 = n_out * ratio                                      # whole ratio: int(11025 * n0 / fs) == n_out
+            if fs != 11025 and rng.integers(0, 3) == 0:             # resampled captures of ARBITRARY length: no distributed form -> the single plan
+                n0 = int(rng.integers(150000, 420000)) * ratio + int(rng.integers(0, ratio))
+                n_out = int(11025 * (n0 / fs))
             kw = dict(lpm=lpm, start_tone_s=0.5, phasing_lines=int(rng.integers(20, 44)), image_lines=400, stop_tone_s=0.5, black_tail_s=0.5)
             x = synth.synth_capture(float(fs), noise=float(rng.choice([0.0, 0.02, 0.05])), seed=int(rng.integers(1 << 30)), **kw)
             if x.shape[0] < n0:
@@ -64,6 +67,7 @@ def main():
                     r = sharded.decode_emulated(data, fs, w, lpm, want=("image", "stream"))
                 except nat.NativeError as e:
                     rec[f"world{w}"] = "refused: " + str(e)[-90:]
+                    ok = False                                      # nothing valid is refused any more (single plan)
                     continue
                 res = dict(stream_ne=int(np.count_nonzero(r["digitalized"] != ref["digitalized"])), blocks_eq=bool(np.array_equal(r["digitalized"], r["digitalized_blocks"])))
                 if ref.get("exception") is not None:

@@ -39,6 +39,14 @@ struct shard_plan {
     // always the padded form (Kp >= 2n - 1: twice the points and four times the exchanged bytes of an even capture of that length)
     bool plain = false;
     int spp = 2;                          // samples per point
+    // No distributed form (a RESAMPLED capture whose half-lengths are odd or not 13-smooth multiples of a common first radix --
+    // its inverse transform's length is the reference's int(11025 n0 / fs), not ours to choose -- or a capture too short for
+    // the world size): rank 0 owns the whole capture and decodes it alone with the fused one-GPU path, the other ranks own
+    // nothing and only receive the scalars.  Not a stopgap: the distributed form of such a capture would be two Bluestein
+    // convolutions (2.5-3x the points of the packed transforms, 8 more exchanges), and the cost model of DESIGN 6.6 puts that
+    // behind one GPU at every world size up to 8.
+    bool single = false;
+    char single_reason[160] = {0};
     long long Kp = 0;
     int wrap_rank = 0;                    // the rank holding the capture's last pair: it needs V[0] from rank 0 as "V[K]"
     uint64_t own_lo = 0, own_hi = 0, in_lo = 0, in_hi = 0;
@@ -53,9 +61,7 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: input kind %d", p->in_kind);
     if (p->hilbert_mode != WFX_HILBERT_FFT) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: the exact Hilbert mode only");
     if (p->n == 0 || p->n0 == 0 || (!p->resample && p->n != p->n0)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad capture lengths");
-    if (p->resample && ((p->n & 1) || (p->n0 & 1)))
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: a resampled capture's sample counts must be even (its transforms are packed)");
-    if (p->n >= (1ull << 31) || p->n0 >= (1ull << 32)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "capture too long");
+    if (p->n > (1ull << 31) || p->n0 >= (1ull << 32)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "capture too long");
     if (p->width <= 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad line width");
     pl.world = world;
     pl.rank = rank;
@@ -63,6 +69,23 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     pl.in_kind = p->in_kind;
     pl.n0 = p->n0;
     pl.n = p->n;
+    auto single = [&](const char *why) {
+        pl.single = true;
+        pl.padded = pl.plain = false;
+        snprintf(pl.single_reason, sizeof pl.single_reason, "%s", why);
+        pl.g = wfx_dist_geom();
+        pl.g.world = world;
+        pl.g.rank = rank;
+        pl.own_lo = rank == 0 ? 0 : pl.n;
+        pl.own_hi = pl.n;
+        pl.in_lo = rank == 0 ? 0 : pl.n0;
+        pl.in_hi = pl.n0;
+        pl.seg_lo = pl.own_lo;
+        pl.seg_hi = pl.own_hi;
+        return 0;
+    };
+    if (p->n >= (1ull << 31)) return single("2^31 samples: beyond the distributed transforms' 32-bit indices");
+    if (p->resample && ((p->n & 1) || (p->n0 & 1))) return single("a resampled capture with an odd sample count (its transforms are packed)");
     pl.plain = (p->n & 1) != 0;
     pl.spp = pl.plain ? 1 : 2;
     pl.K = pl.plain ? (long long)p->n : (long long)(p->n / 2);
@@ -102,13 +125,10 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
                 }
         }
         if (!found)
-            return wfx_fail(ctx, WFX_ERR_BAD_ARG,
-                            "sharded decode: no distributed transform plan for %llu%s samples on %d ranks (%s)",
-                            (unsigned long long)p->n, pl.resample ? " (resampled)" : "", world,
-                            pl.resample ? "a resampled capture's half-lengths must be 13-smooth multiples of a common first radix"
-                                        : "the capture is too short for a padded plan");
+            return single(pl.resample ? "a resampled capture whose half-lengths are not 13-smooth multiples of a common first radix"
+                                      : "too short for a padded plan");
     }
-    if (!wfx_dist_make_geom(pl.g, world, rank, ra1, rb1)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: geometry");
+    if (!wfx_dist_make_geom(pl.g, world, rank, ra1, rb1)) return single("no geometry for this world size");
     const int R1 = pl.g.R1;
     pl.Ms = pl.Kp / R1;
     pl.M1s = pl.M1 / R1;
@@ -121,11 +141,24 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     pl.seg_lo = pl.own_lo >= SH_HALO ? pl.own_lo - SH_HALO : 0;
     pl.seg_hi = pl.own_hi + SH_HALO <= pl.n ? pl.own_hi + SH_HALO : pl.n;
     if (pl.own_hi == pl.own_lo) pl.seg_lo = pl.seg_hi = pl.own_lo;                // a rank of padding rows: nothing to filter
-    if (rank > 0 && pl.own_hi > pl.own_lo && pl.own_lo < SH_HALO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
-    if (pl.own_hi - pl.own_lo < 1024 && !(pl.padded && rank > 0))
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
-    if (pl.padded && pl.own_hi > pl.own_lo && pl.own_hi - pl.own_lo < 64)
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode: capture too short for %d ranks", world);
+    // (the same verdict on every rank: the tests run over all of them)
+    {
+        // what wfx_dist::init asks of a transform of L points: every rank a row, and columns enough for the halo it delivers
+        auto dist_ok = [&](long long L, int halo) {
+            const long long M = L / R1;
+            for (int d = 0; d < world; ++d) {
+                const long long c0 = (long long)d * M / world / 4 * 4, c1 = d + 1 == world ? M : (long long)(d + 1) * M / world / 4 * 4;
+                if (c1 - c0 < 2 || c1 - c0 < halo || pl.g.nrows(d) < 1) return false;
+            }
+            return true;
+        };
+        if (!dist_ok(pl.Kp, SH_VHALO) || (pl.resample && (!dist_ok(pl.M1, 0) || !dist_ok(pl.K, SH_HALO / 2)))) return single("too short for this world size");
+    }
+    for (int r = 0; r < world; ++r) {
+        const uint64_t lo = (uint64_t)pl.spp * clipK((long long)pl.g.rows[r] * pl.Ms), hi = (uint64_t)pl.spp * clipK((long long)pl.g.rows[r + 1] * pl.Ms);
+        if ((r > 0 && hi > lo && lo < SH_HALO) || (hi - lo < 1024 && !(pl.padded && r > 0)) || (pl.padded && hi > lo && hi - lo < 64))
+            return single("too short for this world size");
+    }
     if (pl.resample) {
         pl.in_lo = 2ull * (uint64_t)pl.g.rows[rank] * (uint64_t)pl.M1s;
         pl.in_hi = 2ull * (uint64_t)pl.g.rows[rank + 1] * (uint64_t)pl.M1s;
@@ -164,6 +197,10 @@ static int shard_bind(wfx_shard *sh)
 {
     wfx_ctx *ctx = sh->ctx;
     shard_plan &pl = sh->pl;
+    if (pl.single) {                      // rank 0 decodes alone (the fused path owns its buffers)
+        sh->bound = true;
+        return 0;
+    }
     const int me = pl.rank;
     const long long nr = pl.g.nrows(me);
     const uint64_t n_own = pl.own_hi - pl.own_lo, n_seg = pl.seg_hi - pl.seg_lo;
@@ -210,7 +247,7 @@ static int shard_bind(wfx_shard *sh)
 
 // ---- the phases ------------------------------------------------------------------------------------------------
 // padded form: + 1 phase (the wrap of V, see phase 8) and, in front of the first decode, + 3 (the kernel's transform)
-static int phase_count(const wfx_shard *sh) { return sh->pl.resample ? 13 : (sh->pl.padded ? (sh->ghat_ready ? 10 : 13) : 9); }
+static int phase_count(const wfx_shard *sh) { return sh->pl.single ? 1 : sh->pl.resample ? 13 : (sh->pl.padded ? (sh->ghat_ready ? 10 : 13) : 9); }
 
 static int run_phase(wfx_shard *sh, int ph)
 {
@@ -222,6 +259,30 @@ static int run_phase(wfx_shard *sh, int ph)
     const uint64_t n_own = pl.own_hi - pl.own_lo, n_seg = pl.seg_hi - pl.seg_lo;
     wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
     const void *in = sh->ext_in ? sh->ext_in : sh->b_in.p;
+    if (pl.single) {
+        // rank 0: the fused one-GPU decode of the whole capture on this context; then the scalars (levels, peaks, start frame) to
+        // every rank, so that wfx_shard_result answers everywhere as it does after a distributed decode
+        if (me == 0) {
+            WFX_TRY(wfx_decode_attach(ctx, in, &sh->dp));
+            WFX_TRY(wfx_decode_run(ctx));
+            ds = (wfx_dev_scalars *)ctx->b_scal.p;
+        }
+        std::vector<wfx_xfer> xs;
+        for (int r = 1; r < W; ++r) {
+            wfx_xfer x{};
+            x.peer = me == 0 ? r : 0;
+            if (me == 0) {
+                x.send = ds;
+                x.send_bytes = sizeof(wfx_dev_scalars);
+                xs.push_back(x);
+            } else if (r == me) {
+                x.recv = ds;
+                x.recv_bytes = sizeof(wfx_dev_scalars);
+                xs.push_back(x);
+            }
+        }
+        return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
+    }
     double *audio = (double *)sh->b_audio.p;
     double *env = (double *)sh->b_env.p;
     uint8_t *dig_own = (uint8_t *)sh->b_dig.p + (me == 0 ? pl.own_lo : 0);
@@ -511,6 +572,7 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
         }
     }
     if (next != p->n || (pl.resample && next_in != p->n0)) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: the ranks' ranges do not cover the capture");
+    if (pl.single) return 0;              // rank 0 alone: one message of scalars per peer, nothing to cross-check
     if (pl.resample) {
         WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward"));
         WFX_TRY(dry_check_transform(pl, p, pl.K, 16, SH_HALO / 2, SH_HALO / 2, false, true, "resample inverse"));
@@ -564,6 +626,16 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
         sh->cap = cap;
     }
     if (rc == 0) rc = wfx_reserve(ctx, ctx->b_scal, sizeof(wfx_dev_scalars));
+    if (rc == 0 && pl.single) {
+        rc = wfx_reserve(ctx, sh->b_flags, 64);
+        if (rc == 0 && hipMemsetAsync(sh->b_flags.p, 0, 64, ctx->stream) != hipSuccess) rc = wfx_fail(ctx, WFX_ERR_HIP, "memset");
+        if (rc != 0) {
+            wfx_shard_destroy(sh);
+            return rc;
+        }
+        *out = sh;
+        return 0;
+    }
     if (rc == 0 && pl.resample) {
         rc = sh->dF.init(ctx, pl.g, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0);
         if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, SH_HALO / 2, SH_HALO / 2);
@@ -638,6 +710,7 @@ int wfx_shard_result(wfx_shard *sh, wfx_decode_info *info)
     wfx_ctx *ctx = sh->ctx;
     if (!info) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null info");
     if (!sh->ran) return wfx_fail(ctx, WFX_ERR_STATE, "shard_result before the decode");
+    if (sh->pl.single && sh->pl.rank == 0) return wfx_decode_result(ctx, info);
     wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
     for (int attempt = 0;; ++attempt) {
         unsigned flags[4] = {0, 0, 0, 0};
@@ -691,6 +764,12 @@ int wfx_shard_fetch(wfx_shard *sh, int buffer_id, void *host_out, size_t bytes)
     if (!sh->ran) return wfx_fail(ctx, WFX_ERR_STATE, "no sharded decode has run");
     const shard_plan &pl = sh->pl;
     const uint64_t n_own = pl.own_hi - pl.own_lo;
+    if (pl.single) {
+        if (pl.rank == 0) return wfx_decode_fetch(ctx, buffer_id, host_out, bytes);
+        if (buffer_id == WFX_BUF_IMAGE) return wfx_fail(ctx, WFX_ERR_STATE, "the image lives on rank 0");
+        if (bytes != 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fetch: expected 0 bytes, got %zu (rank 0 owns the whole capture)", bytes);
+        return 0;
+    }
     const void *src = nullptr;
     size_t nb = 0;
     switch (buffer_id) {

@@ -200,14 +200,21 @@ class ShardedDecoder:
 
 
 def layout_supported(n0: int, sample_rate, world: int, lines_per_minute: int = 120, kind: int = nat.WFX_IN_F64_MONO, n_out: int | None = None) -> bool:
-    """Whether the sharded exact path takes a capture of this description over ``world`` ranks (``wfx_shard_layout_query``
-    answers without a GPU)."""
+    """Whether the sharded path takes a capture of this description over ``world`` ranks (``wfx_shard_layout_query`` answers
+    without a GPU).  Since round 3 that is every valid capture: one with no distributed form gets the single plan."""
     p, _ = build_params(kind, int(n0), sample_rate, 1 / (lines_per_minute / 60), hp.DEFAULT_NOTCH, n_out=n_out)
     try:
         nat.shard_layout(p, world, 0)
         return True
     except nat.NativeError:
         return False
+
+
+def layout_distributed(n0: int, sample_rate, world: int, lines_per_minute: int = 120, kind: int = nat.WFX_IN_F64_MONO, n_out: int | None = None) -> bool:
+    """Whether the capture's transforms are distributed over the ranks (False: the single plan -- rank 0 decodes it alone)."""
+    p, _ = build_params(kind, int(n0), sample_rate, 1 / (lines_per_minute / 60), hp.DEFAULT_NOTCH, n_out=n_out)
+    lay = nat.shard_layout(p, world, 0)
+    return not (lay.first_radix[0] == 0 and lay.first_radix[1] == 0)
 
 
 def _info_dict(info: nat.DecodeInfo) -> dict:
@@ -407,6 +414,14 @@ class FrontEndShardedDecoder:
         self.dec = ShardedDecoder(ctx, comm, n_fe, frontend.out_rate, lines_per_minute, nat.WFX_IN_F64_MONO, notch,
                                   n_out=frontend.n_target(n_in_total))
         lay = self.dec.layout
+        self.shard, self.layout, self.n, self.width = self.dec.shard, lay, self.dec.n, self.dec.width
+        if lay.in_hi == lay.in_lo:
+            # a rank that owns nothing (the SINGLE plan of a capture with no distributed form: rank 0 decodes alone) has no front
+            # end to run; it takes part in the phases with a placeholder input
+            self.chain, self.fe, self.raw_range = [], None, (0, 0)
+            self._none = ctx.dev_malloc(64)
+            self.dec.attach(self._none)
+            return
         self.chain = frontend.chain(int(lay.in_lo), int(lay.in_hi))
         ia, ib = self.chain[0][2]
         raw = _raw_slice(x, raw_loader, ia, ib, n_in_total)
@@ -414,15 +429,15 @@ class FrontEndShardedDecoder:
             in_kind = 1 if (not isinstance(raw, tuple) and raw.ndim == 2) else 0
         self.fe = FrontEndDevice(ctx, self.chain, raw, in_kind)
         self.dec.attach(self.fe.p_out)
-        self.shard, self.layout, self.n, self.width = self.dec.shard, lay, self.dec.n, self.dec.width
         self.raw_range = (ia, ib)
 
     def run(self):
-        self.fe.run()
+        self.front_end()
         self.dec.run()
 
     def front_end(self):
-        self.fe.run()
+        if self.fe is not None:
+            self.fe.run()
 
     def result(self):
         return self.dec.result()
@@ -432,4 +447,8 @@ class FrontEndShardedDecoder:
 
     def close(self):
         self.dec.close()
-        self.fe.close()
+        if self.fe is not None:
+            self.fe.close()
+        elif getattr(self, "_none", None):
+            self.dec.ctx.dev_free(self._none)
+            self._none = None
