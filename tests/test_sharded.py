@@ -351,7 +351,7 @@ def test_sharded_decode_of_any_length_equals_the_oracle(n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fs,n0,stereo", [(48000, 1440001, False), (48000, 1200002 + 2 * 7919, True), (22050, 749700, False), (44100, 792000, False),
-                                          (11025, 30000, False)])
+                                          (11025, 6000, False)])
 def test_captures_on_the_single_plan_decode_like_the_one_gpu_path(fs, n0, stereo):
     """Resampled captures of arbitrary length (odd; a prime factor above 13; a reference length int(11025 n0 / fs) that comes out
     odd) and a capture too short for eight ranks: the sharded interface takes them -- rank 0 decodes alone, the others receive
