@@ -184,8 +184,8 @@ def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, wo
     """ShardedDecoder over the shm transport, `world` processes on one GPU, three decodes back to back with the ranks drifting
     apart: uint8 stream, image, start_frame and the float64 envelope blocks equal the fused one-GPU decode / the in-process
     emulation bit for bit.  ``trim``: an arbitrary even length (half-length not 13-smooth): the padded distributed convolution,
-    whose first decode carries three extra phases and whose ranks may own no samples at all; an odd trim gives an ODD length (one
-    point per sample, real rows)."""
+    whose first decode carries three extra phases (on a transform object of their own: the kernel has taps in the padding rows
+    too, the capture does not); an odd trim gives an ODD length (one point per sample, real rows)."""
     from wefax_amd import sharded
     from wefax_amd.wefax import DecodeJob
     x = _capture(rate, 5, lpm, trim)
@@ -214,7 +214,7 @@ def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, wo
         from wefax_amd.wefax import build_params
         p, _ = build_params(0, x.shape[0], rate, 1 / (lpm / 60))
         sizes = [nat.shard_layout(p, world, r).own_hi - nat.shard_layout(p, world, r).own_lo for r in range(world)]
-        assert sizes[0] > 0 and (world < 3 or sizes[-1] == 0)                 # the last ranks' rows are padding
+        assert min(sizes) > 0 and max(sizes) - min(sizes) <= x.shape[0] // 16   # only the rows that hold samples are dealt: equal shares
     ctx.close()
 
 

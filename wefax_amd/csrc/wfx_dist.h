@@ -24,13 +24,17 @@ struct wfx_dist_kmap {       // k1 = kk < kc0 ? kb0 + kk : kb1 + (kk - kc0), kk 
 struct wfx_dist_geom {       // what all transforms of one sharded decode share
     int world = 1, rank = 0;
     int ra1 = 0, rb1 = 0, R1 = 0;
-    std::vector<int> rows;               // [world + 1]
+    // rows dealt to the ranks: all R1 of them, or -- a zero-padded convolution's INPUT and OUTPUT -- only the first rows_used: the
+    // rows behind them are zero padding going in (nobody sends them: the receiver clears its copy) and garbage coming out (nobody
+    // wants them), so E1 and E4 carry rows_used / R1 of their bytes and every rank owns an equal share of the real samples
+    int rows_used = 0;
+    std::vector<int> rows;               // [world + 1], rows[world] = rows_used
     std::vector<wfx_dist_kmap> km;       // [world]
     int nrows(int r) const { return rows[r + 1] - rows[r]; }
 };
 
 // host-only: partitions for a first radix (ra1, rb1); false when the world is too large for it
-bool wfx_dist_make_geom(wfx_dist_geom &g, int world, int rank, int ra1, int rb1);
+bool wfx_dist_make_geom(wfx_dist_geom &g, int world, int rank, int ra1, int rb1, int rows_used = 0);
 // host-only: first radix for transforms of the given lengths (all must be multiples of it with pair-decomposable cofactors)
 bool wfx_dist_choose_r1(const long long *lengths, int nlen, int world, int *ra1, int *rb1, bool pairs_required = false);
 

@@ -11,7 +11,7 @@
 #include "wfx_dist.h"
 
 // ---- geometry (host) ---------------------------------------------------------------------------------------
-bool wfx_dist_make_geom(wfx_dist_geom &g, int world, int rank, int ra1, int rb1)
+bool wfx_dist_make_geom(wfx_dist_geom &g, int world, int rank, int ra1, int rb1, int rows_used)
 {
     if (world < 1 || rank < 0 || rank >= world || !wfx_mr_is_pair(ra1, rb1)) return false;
     g.world = world;
@@ -21,8 +21,10 @@ bool wfx_dist_make_geom(wfx_dist_geom &g, int world, int rank, int ra1, int rb1)
     g.R1 = ra1 * rb1;
     const int R1 = g.R1, units = R1 / 2 + 1;
     if (units < 2 * world) return false;              // every rank needs >= 2 first-pass outputs and >= 1 row
+    g.rows_used = (rows_used > 0 && rows_used < R1) ? rows_used : R1;
+    if (g.rows_used < world) return false;
     g.rows.resize(world + 1);
-    for (int s = 0; s <= world; ++s) g.rows[s] = (int)((long long)s * R1 / world);
+    for (int s = 0; s <= world; ++s) g.rows[s] = (int)((long long)s * g.rows_used / world);
     g.km.resize(world);
     for (int e = 0; e < world; ++e) {
         // units u in [a, b) stand for {u, R1 - u}: the set is closed under k1 -> -k1, so the bins k and L - k of a real
@@ -488,6 +490,9 @@ int wfx_dist::fwd_pack_exchange(wfx_comm *c, const void *rows_in)
     long long mx = 0;
     for (const wfx_dist_piece &p : p1) mx = std::max(mx, (long long)p.rows * p.cols);
     WFX_TRY(wfx_dist_copy2d(ctx, dp + o1, (int)p1.size(), mx, es_in));
+    // rows nobody owns are zero padding: the first pass reads them from the receive buffer, which other exchanges have used since
+    if (g.world > 1 && g.rows_used < g.R1)
+        WFX_HIP(ctx, hipMemsetAsync((char *)b_recv.p + (size_t)g.rows_used * w * es_in, 0, (size_t)(g.R1 - g.rows_used) * w * es_in, ctx->stream));
     return wfx_comm_exchange(c, ctx, x1.data(), (int)x1.size());
 }
 

@@ -26,6 +26,11 @@
 struct shard_plan {
     int world = 1, rank = 0;
     wfx_dist_geom g;
+    // padded forms over more than one rank: `g` deals only the rows that hold samples (wfx_dist_geom::rows_used) -- every rank owns an
+    // equal share of the capture, E1 / E4 carry half the bytes; the kernel's own transform (first decode) has taps in ALL rows and
+    // runs on `gk`, the full-rows geometry, through a transform object of its own that is released afterwards
+    wfx_dist_geom gk;
+    bool split_kernel = false;
     bool resample = false;
     int in_kind = 0;
     uint64_t n0 = 0, n = 0;
@@ -111,13 +116,17 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
                     if (!wfx_dist_choose_r1(&m, 1, wref, &ra1, &rb1, true)) continue;
                     const int r1 = ra1 * rb1;
                     const long long ms = m / r1;
+                    const long long rv = (pl.K + ms - 1) / ms;                    // rows that hold samples
                     bool fine = true;
-                    for (int w = strict ? 1 : world; w <= (strict ? wref : world) && fine; ++w)
+                    for (int w = strict ? 1 : world; w <= (strict ? wref : world) && fine; ++w) {
+                        if (w > 1 && rv < w) fine = false;
                         for (int r = 0; r < w && fine; ++r) {
-                            const long long a = (long long)r * r1 / w * ms, b = (long long)(r + 1) * r1 / w * ms;
+                            const long long dealt = w > 1 ? rv : r1;                 // (one rank keeps all rows: its first pass reads them in place)
+                            const long long a = (long long)r * dealt / w * ms, b = (long long)(r + 1) * dealt / w * ms;
                             const long long own = (b < pl.K ? b : pl.K) - (a < pl.K ? a : pl.K);
-                            if (own > 0 && own < 2048) fine = false;
+                            if (own < 2048) fine = false;
                         }
+                    }
                     if (!fine) continue;
                     pl.Kp = m;
                     pl.padded = found = true;
@@ -128,7 +137,13 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
             return single(pl.resample ? "a resampled capture whose half-lengths are not 13-smooth multiples of a common first radix"
                                       : "too short for a padded plan");
     }
-    if (!wfx_dist_make_geom(pl.g, world, rank, ra1, rb1)) return single("no geometry for this world size");
+    {
+        const long long ms = pl.Kp / (ra1 * rb1);
+        const int rv = (int)((pl.K + ms - 1) / ms);
+        pl.split_kernel = pl.padded && world > 1 && rv < ra1 * rb1;
+        if (!wfx_dist_make_geom(pl.g, world, rank, ra1, rb1, pl.split_kernel ? rv : 0)) return single("no geometry for this world size");
+        if (pl.split_kernel && !wfx_dist_make_geom(pl.gk, world, rank, ra1, rb1)) return single("no geometry for this world size");
+    }
     const int R1 = pl.g.R1;
     pl.Ms = pl.Kp / R1;
     pl.M1s = pl.M1 / R1;
@@ -175,6 +190,7 @@ struct wfx_shard {
     wfx_decode_params dp{};
     shard_plan pl;
     wfx_dist dF, dI, dH;                  // resampler forward / inverse, Hilbert
+    wfx_dist dHk;                         // padded form over several ranks: the kernel's transform (full rows), first decode only
     wfx_devbuf b_in, b_merged, b_res, b_audio, b_v, b_env, b_dig, b_blk, b_blks, b_nan, b_flags;
     wfx_devbuf b_grow, b_ghat;            // padded form: this rank's rows of the kernel g_ext / Kp, and its slab of the kernel's transform
     bool ghat_ready = false;              // computed by three extra phases in front of the first decode
@@ -214,7 +230,7 @@ static int shard_bind(wfx_shard *sh)
     if (pl.padded && (audio_moved || !sh->bound)) WFX_HIP(ctx, hipMemsetAsync(sh->b_audio.p, 0, audio_bytes, ctx->stream));
     WFX_TRY(wfx_reserve(ctx, sh->b_v, (size_t)(2 * SH_VHALO + nr * pl.Ms) * sizeof(cplx) + 64));
     if (pl.padded) {
-        WFX_TRY(wfx_reserve(ctx, sh->b_grow, (size_t)nr * pl.Ms * sizeof(cplx) + 64));
+        if (!sh->ghat_ready) WFX_TRY(wfx_reserve(ctx, sh->b_grow, (size_t)(pl.split_kernel ? pl.gk.nrows(me) : nr) * pl.Ms * sizeof(cplx) + 64));
         WFX_TRY(wfx_reserve(ctx, sh->b_ghat, (size_t)sh->dH.slab_points() * sizeof(cplx) + 64));
     }
     WFX_TRY(wfx_reserve(ctx, sh->b_env, n_own * 8 + 64));
@@ -239,8 +255,11 @@ static int shard_bind(wfx_shard *sh)
     } else if (pl.in_kind == WFX_IN_I16_STEREO) {
         WFX_TRY(wfx_reserve(ctx, sh->b_merged, (pl.in_hi - pl.in_lo) * 8 + 64));
     }
-    // (until the kernel's transform exists the Hilbert transform's forward half is bound to the kernel's rows: see run_phase)
-    WFX_TRY(sh->dH.bind((pl.padded && !sh->ghat_ready) ? (const void *)sh->b_grow.p : (const void *)audio_own, (cplx *)sh->b_v.p, sh->dH.fwd_result_index()));
+    // (until the kernel's transform exists the Hilbert transform's forward half is bound to the kernel's rows: see run_phase;
+    // with the rows split, the kernel has a transform object of its own)
+    if (pl.split_kernel && !sh->ghat_ready) WFX_TRY(sh->dHk.bind(sh->b_grow.p, nullptr, 0));
+    WFX_TRY(sh->dH.bind((pl.padded && !pl.split_kernel && !sh->ghat_ready) ? (const void *)sh->b_grow.p : (const void *)audio_own, (cplx *)sh->b_v.p,
+                        sh->dH.fwd_result_index()));
     sh->bound = true;
     return 0;
 }
@@ -288,18 +307,26 @@ static int run_phase(wfx_shard *sh, int ph)
     uint8_t *dig_own = (uint8_t *)sh->b_dig.p + (me == 0 ? pl.own_lo : 0);
     if (pl.padded && !sh->ghat_ready) {
         // ---- the padded convolution's kernel, transformed once per shard: rows -> E1 -> pass 1 -> E2 -> slab passes ----
+        wfx_dist &dk = pl.split_kernel ? sh->dHk : sh->dH;
+        const wfx_dist_geom &gk = pl.split_kernel ? pl.gk : pl.g;
         if (ph == 0) {
             if (pl.plain)
-                WFX_TRY(wfx_dev_hilbert_kernel_rows_plain(ctx, (double *)sh->b_grow.p, (long long)pl.g.rows[me] * pl.Ms, (long long)pl.g.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
+                WFX_TRY(wfx_dev_hilbert_kernel_rows_plain(ctx, (double *)sh->b_grow.p, (long long)gk.rows[me] * pl.Ms, (long long)gk.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
             else
-                WFX_TRY(wfx_dev_hilbert_kernel_rows(ctx, (cplx *)sh->b_grow.p, (long long)pl.g.rows[me] * pl.Ms, (long long)pl.g.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
-            return sh->dH.fwd_pack_exchange(c, sh->b_grow.p);
+                WFX_TRY(wfx_dev_hilbert_kernel_rows(ctx, (cplx *)sh->b_grow.p, (long long)gk.rows[me] * pl.Ms, (long long)gk.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
+            return dk.fwd_pack_exchange(c, sh->b_grow.p);
         }
-        if (ph == 1) return sh->dH.fwd_pass1_exchange(c, pl.plain ? 3 : 0);
+        if (ph == 1) return dk.fwd_pass1_exchange(c, pl.plain ? 3 : 0);
         if (ph == 2) {
             cplx *G = nullptr;
-            WFX_TRY(sh->dH.fwd_slab(0, &G));
+            WFX_TRY(dk.fwd_slab(0, &G));
             WFX_HIP(ctx, hipMemcpyAsync(sh->b_ghat.p, G, (size_t)sh->dH.slab_points() * sizeof(cplx), hipMemcpyDeviceToDevice, ctx->stream));
+            if (pl.split_kernel) {       // the kernel's transform object and its rows have done their work
+                WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                sh->dHk.release();
+                free_buf(sh->b_grow);
+                return 0;
+            }
             // from here on the forward half reads the audio rows (re-binding rebuilds the E1 lists: a host synchronisation, once)
             return sh->dH.bind(audio + (pl.own_lo - pl.seg_lo), (cplx *)sh->b_v.p, sh->dH.fwd_result_index());
         }
@@ -463,7 +490,8 @@ static bool dry_inside(const std::vector<dry_region> &regs, unsigned long long l
     return false;
 }
 
-static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p, long long L, int es, int hb, int ha, bool fwd, bool inv, const char *name)
+static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p, long long L, int es, int hb, int ha, bool fwd, bool inv, const char *name,
+                               int rows_used = 0)
 {
     const int W = pl0.world;
     std::vector<wfx_dist> d(W);
@@ -472,7 +500,7 @@ static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p
     int rc = 0;
     for (int r = 0; r < W && rc == 0; ++r) {
         wfx_dist_geom g;
-        if (!wfx_dist_make_geom(g, W, r, pl0.g.ra1, pl0.g.rb1)) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "dry run: geometry");
+        if (!wfx_dist_make_geom(g, W, r, pl0.g.ra1, pl0.g.rb1, rows_used)) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "dry run: geometry");
         const unsigned long long base = (unsigned long long)(r + 1) << 44;
         rc = d[r].init(nullptr, g, L, es, hb, ha, true, base);
         if (rc) break;
@@ -512,9 +540,9 @@ static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p
                 got.push_back({lo, hi});
                 total += x.recv_bytes;
             }
-            const unsigned long long R1 = pl0.g.R1;
+            const unsigned long long R1 = pl0.g.R1, Rd = (rows_used > 0 && rows_used < pl0.g.R1) ? (unsigned long long)rows_used : R1;     // rows that travel in E1
             // (one rank: the first pass reads the rows in place and the last one writes them in place -- E1 and E4 carry the halo only)
-            const unsigned long long want = e == 1 ? (W == 1 ? 0ull : R1 * d[r].w * (unsigned long long)es) : e == 2 ? (unsigned long long)d[r].M * d[r].B * 16
+            const unsigned long long want = e == 1 ? (W == 1 ? 0ull : Rd * d[r].w * (unsigned long long)es) : e == 2 ? (unsigned long long)d[r].M * d[r].B * 16
                                           : e == 3 ? R1 * d[r].w * 16ull : ((W == 1 ? 0ull : (unsigned long long)d[r].nr * d[r].M) + hb + ha) * 16ull;
             if (rc == 0 && total != want)
                 rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s, exchange %d): rank %d receives %llu bytes, its layout holds %llu", name, e, r, total, want);
@@ -577,7 +605,9 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
         WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward"));
         WFX_TRY(dry_check_transform(pl, p, pl.K, 16, SH_HALO / 2, SH_HALO / 2, false, true, "resample inverse"));
     }
-    return dry_check_transform(pl, p, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO, true, true, pl.plain ? "hilbert (odd length)" : (pl.padded ? "hilbert (padded)" : "hilbert"));
+    if (pl.split_kernel) WFX_TRY(dry_check_transform(pl, p, pl.Kp, pl.plain ? 8 : 16, 0, 0, true, false, "hilbert kernel (all rows)"));
+    return dry_check_transform(pl, p, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO, true, true, pl.plain ? "hilbert (odd length)" : (pl.padded ? "hilbert (padded)" : "hilbert"),
+                               pl.g.rows_used);
 }
 
 #define CHECK_SH(sh)                                                                                              \
@@ -641,6 +671,7 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
         if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, SH_HALO / 2, SH_HALO / 2);
     }
     if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO);
+    if (rc == 0 && pl.split_kernel) rc = sh->dHk.init(ctx, pl.gk, pl.Kp, pl.plain ? 8 : 16, 0, 0);
     if (rc != 0) {
         wfx_shard_destroy(sh);
         return rc;
@@ -811,6 +842,7 @@ int wfx_shard_destroy(wfx_shard *sh)
     sh->dF.release();
     sh->dI.release();
     sh->dH.release();
+    sh->dHk.release();
     wfx_devbuf *bufs[] = {&sh->b_in, &sh->b_merged, &sh->b_res, &sh->b_audio, &sh->b_v, &sh->b_env, &sh->b_dig, &sh->b_blk, &sh->b_blks, &sh->b_nan, &sh->b_flags,
                           &sh->b_grow, &sh->b_ghat};
     for (wfx_devbuf *b : bufs) free_buf(*b);
