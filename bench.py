@@ -60,6 +60,7 @@ def parse():
                     help="rate at which the time-domain front end hands the IQ stream to the exact FFT resampler")
     ap.add_argument("--iq-form", choices=["auto", "fused", "sharded"], default="auto",
                     help="one GPU: the fused exact decode behind the front end (auto) or the sharded form with one rank")
+    ap.add_argument("--trim", type=int, default=0, help="c2: drop this many samples from the end of the capture (--trim 2 with --shard: the padded distributed convolution; odd: one point per sample)")
     ap.add_argument("--no-c4", action="store_true", help="c2: leave the c4_strong object out (quick runs)")
     ap.add_argument("--no-extras", action="store_true", help="c2: leave the general_length and c3 objects out (kernel profiles of the headline alone)")
     ap.add_argument("--no-pcie", action="store_true", help="c2: skip the PCIe-inclusive leg (it runs two decodes concurrently: keep it out of kernel profiles)")
@@ -457,6 +458,8 @@ def bench_c2(args, rk: Ranks) -> dict:
         x = synth.synth_capture(11025.0, noise=args.noise, seed=rk.rank, start_tone_s=5.0, phasing_lines=20, image_lines=220, stop_tone_s=2.0, black_tail_s=3.0)
     else:
         x = synth.config_c2(noise=args.noise, seed=0 if args.shard else rk.rank)
+    if args.trim:
+        x = np.ascontiguousarray(x[:x.shape[0] - args.trim])
     extra = []
     if args.shard:      # ONE capture, all ranks (exercises the sharded exact path on the 10-minute size)
         job = sharded.ShardedDecoder(ctx, rk.comm, x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x)
