@@ -36,9 +36,9 @@ struct shard_plan {
     uint64_t n0 = 0, n = 0;
     long long M1 = 0, K = 0, M1s = 0, Ms = 0;
     // any even length (round 3): when K = n / 2 has no distributed plan the Hilbert convolution is embedded in a transform of
-    // Kp >= 2K - 1 points (13-smooth, radix pairs only); the rows of THAT arrangement are dealt to the ranks, so a rank owns the
-    // samples of its rows that lie inside the capture -- the ranks whose rows are all padding own none (they still take part in
-    // every transform and collective)
+    // Kp >= 2K - 1 points (13-smooth, radix pairs only); the rows of THAT arrangement that hold samples are dealt to the ranks in
+    // equal shares (`g.rows_used`; with WFX_SHARD_ALL_ROWS, or one rank, all rows are: the ranks whose rows are all padding then own
+    // nothing and still take part in every transform and collective)
     bool padded = false;
     // odd lengths (no resampling): nothing to pack -- one point per sample (K = n), real rows (mr2_pass IN_MODE 3), a real kernel,
     // always the padded form (Kp >= 2n - 1: twice the points and four times the exchanged bytes of an even capture of that length)
