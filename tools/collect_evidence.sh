@@ -82,6 +82,15 @@ for g in 2 4 8; do
   WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus $g --shard --steps 3 --warmup 1 --no-c4 --no-cpu-loops > "$OUT/bench_shard_shm$g.json" 2>> "$OUT/bench.err"
 done
 WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 --no-pcie --no-cpu > "$OUT/bench_c4_shm8.json" 2>> "$OUT/bench.err"
+# the driver's own launch for N > 1 (torch.distributed.run: ranks from the environment), here with the ranks sharing the one GPU
+for g in 2 4; do
+  WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $g --master-addr 127.0.0.1 --master-port 2955$g bench.py --gpus $g --steps 5 --warmup 2 > "$OUT/bench_torchrun_shm$g.json" 2>> "$OUT/bench.err"
+done
+# a padded sharded decode (the 10-minute capture less two samples): only the sample-bearing rows dealt vs all rows
+for g in 4 8; do
+  WFX_BENCH_OVERSUBSCRIBE=1 timeout 600 python bench.py --gpus $g --shard --trim 2 --steps 5 --warmup 2 --no-c4 --no-cpu --no-extras --no-pcie > "$OUT/bench_shard_trim2_shm${g}_all0.json" 2>> "$OUT/bench.err"
+  WFX_SHARD_ALL_ROWS=1 WFX_BENCH_OVERSUBSCRIBE=1 timeout 600 python bench.py --gpus $g --shard --trim 2 --steps 5 --warmup 2 --no-c4 --no-cpu --no-extras --no-pcie > "$OUT/bench_shard_trim2_shm${g}_all1.json" 2>> "$OUT/bench.err"
+done
 
 # randomised whole-path parity sweep against the oracle
 timeout 1200 python tools/random_parity.py --cases 200 --seed 11 > "$OUT/random_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_parity.jsonl"
