@@ -94,6 +94,19 @@ def test_wav_reader_matches_oracle_reader(case):
     assert sr0 == sr1 and d0.dtype == d1.dtype and np.array_equal(d0, d1)
 
 
+@pytest.mark.parametrize("case", golden_cases(), ids=[c["name"] for c in golden_cases()])
+def test_file_info_from_the_headers_equals_the_references(case):
+    """file_info (wefax.py:342-346) is answered from the wav's headers alone; the manifest holds what the reference printed."""
+    from wefax_amd import Demodulator
+    d = Demodulator(os.path.join(GOLDEN, case["input"]), lines_per_minute=case.get("lpm", 120), quiet=True)
+    fi, ref = d.file_info(), case["file_info"]
+    assert fi["filename"] == ref["filename"] and fi["channels"] == ref["channels"] and fi["sample_rate"] == ref["sample_rate"]
+    assert fi["length"] == ref["length"]
+    sr, frames, ch = hp.wav_info(os.path.join(GOLDEN, case["input"]))
+    sr1, data = hp.read_wav(os.path.join(GOLDEN, case["input"]))
+    assert (sr, frames, ch) == (sr1, data.shape[0], 1 if data.ndim == 1 else data.shape[1])
+
+
 def test_wav_reader_threads_allocator_and_truncated_files(tmp_path):
     """Files beyond one read slice are copied out of the page cache by several threads, into memory the caller provides when it
     gives an allocator (the decoder: its context's page-locked staging buffer); chunks in front of `data` are skipped; a data
