@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=12)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--fs", type=int, default=0, help="every clip at this rate (default: 1.536 MS/s, 192 kHz and 48 kHz mixed)")
     ap.add_argument("--out", default=None, help="also append the per-case records and the summary to this file (JSON lines)")
     a = ap.parse_args()
     sink = open(a.out, "a") if a.out else None
@@ -40,6 +41,8 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         for k in range(a.cases):
             fs = int(rng.choice([1536000, 1536000, 192000, 48000]))
+            if a.fs:
+                fs = a.fs
             iq = fs != 48000
             lpm = int(rng.choice([120, 240]))
             seconds = int(rng.integers(24, 41))

@@ -399,9 +399,11 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                             ah1 = pp_dot2(w[NP], dh, ah1); al1 = pp_dot2(w[NP], dl, al1);
                             ah3 = pp_dot2(w[NP + 1], dh, ah3); al3 = pp_dot2(w[NP + 1], dl, al3);
                         }
-                        if (((r + 1) & ((flush_rows & 255) - 1)) == 0) {
-                            tl0 += al0; tl1 += al1; tl2 += al2; tl3 += al3;
+                        if (((r + 1) & ((flush_rows & 255) - 1)) == 0) {          // both halves leave their int32 here (taps on grids up to 2^-30)
+                            tl0 += al0 + ((long long)ah0 << PP_FIX_LB); tl1 += al1 + ((long long)ah1 << PP_FIX_LB);
+                            tl2 += al2 + ((long long)ah2 << PP_FIX_LB); tl3 += al3 + ((long long)ah3 << PP_FIX_LB);
                             al0 = al1 = al2 = al3 = 0;
+                            ah0 = ah1 = ah2 = ah3 = 0;
                         }
 #pragma unroll
                         for (int p = 0; p < NW; ++p) w[p] = wn[p];
@@ -432,8 +434,10 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                         ah3 = pp_dot2(w1, dh, ah3); al3 = pp_dot2(w1, dl, al3);
                     }
                     if (((r + 1) & ((flush_rows & 255) - 1)) == 0) {
-                        tl0 += al0; tl1 += al1; tl2 += al2; tl3 += al3;
+                        tl0 += al0 + ((long long)ah0 << PP_FIX_LB); tl1 += al1 + ((long long)ah1 << PP_FIX_LB);
+                        tl2 += al2 + ((long long)ah2 << PP_FIX_LB); tl3 += al3 + ((long long)ah3 << PP_FIX_LB);
                         al0 = al1 = al2 = al3 = 0;
+                        ah0 = ah1 = ah2 = ah3 = 0;
                     }
                 }
                 tl0 += al0 + ((long long)ah0 << PP_FIX_LB); tl1 += al1 + ((long long)ah1 << PP_FIX_LB);
@@ -873,26 +877,26 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
         bool ok = true;
         for (int j = 0; j < ntaps && ok; ++j) {
             const double v = nearbyint(ldexp(coef[j], fix_shift));
-            if (!(fabs(v) < (double)(1 << 23))) ok = false;
+            if (!(fabs(v) < (double)((1 << 27) - (1 << PP_FIX_LB)))) ok = false;        // (the high half is an int16)
             else fix[(size_t)((j + d) % M) * 4 * q4 + (size_t)((j + d) / M)] = (int32_t)v;
         }
-        // worst-case |sample| = 32768: the hi parts of ALL taps go into one int32 per output, the lo parts of flush_rows rows
+        // worst-case |sample| = 32768: the hi parts and the lo parts of flush_rows rows each go into one int32 per output
         const int half = 1 << (PP_FIX_LB - 1);
         auto hi_of = [&](int32_t v) { return (v + half) >> PP_FIX_LB; };
         auto lo_of = [&](int32_t v) { return v - (hi_of(v) << PP_FIX_LB); };
-        long long sum_hi = 0;
-        for (int32_t v : fix) sum_hi += llabs((long long)hi_of(v));
-        if (sum_hi * 32768 >= (1ll << 31)) ok = false;
         int flush_rows = 0;
         if (ok) {
             // rows are split over thread groups only in powers of two: a flush interval that divides every group's row count
             for (int fr = M; fr >= 1 && !flush_rows; fr >>= 1) {
                 bool fits = true;
                 for (int r0 = 0; r0 < M && fits; r0 += fr) {
-                    long long sl = 0;
+                    long long sl = 0, sh = 0;
                     for (int r = r0; r < r0 + fr; ++r)
-                        for (int k = 0; k < 4 * q4; ++k) sl += llabs((long long)lo_of(fix[(size_t)r * 4 * q4 + k]));
-                    if (sl * 32768 >= (1ll << 31)) fits = false;
+                        for (int k = 0; k < 4 * q4; ++k) {
+                            sl += llabs((long long)lo_of(fix[(size_t)r * 4 * q4 + k]));
+                            sh += llabs((long long)hi_of(fix[(size_t)r * 4 * q4 + k]));
+                        }
+                    if (sl * 32768 >= (1ll << 31) || sh * 32768 >= (1ll << 31)) fits = false;
                 }
                 if (fits) flush_rows = fr;
             }

@@ -97,15 +97,42 @@ MIN_FIX_SHIFT = 26      # coarser grids than 2**-26 are not worth it: the float6
 FIX_LB = 12             # csrc/wfx_polyphase.hip PP_FIX_LB: a fixed-point tap is hi * 2**12 + lo, two int16 halves
 
 
-def fix_shift_for(h: np.ndarray) -> int:
-    """The finest grid 2**-s the integer-exact stencil (csrc/wfx_polyphase.hip MODE 1) takes these taps on: every tap below 2**23
-    steps, and the high halves of all taps together below 2**16 -- times the largest int16 sample that still fits the kernel's
-    one int32 accumulator per output.  0: none (the float64 form runs instead)."""
+def fix_shift_for(h: np.ndarray, factor: int | None = None) -> int:
+    """The finest grid 2**-s (s <= 30) the integer-exact stencil (csrc/wfx_polyphase.hip MODE 1) takes these taps on: the high half
+    of every tap an int16, and -- the kernel moves both halves' int32 sums into an int64 every `flush` polyphase rows -- the high
+    halves (and the low halves) of the taps of SOME power-of-two number of rows together below 2**16: times the largest int16
+    sample that still fits one int32.  The rows a tap lands in depend on where a slice starts (the kernel aligns windows to 16
+    bytes: up to 7 samples of shift), so every shift is tried.  Without ``factor``: all taps in one window (the round-3 first
+    form of the kernel; grids to 2**-27).  0: none (the float64 form runs instead)."""
     h = np.asarray(h, dtype=np.float64)
+    lim = 0.98 * (1 << 16)
     for s in range(30, 15, -1):
         v = np.rint(np.ldexp(h, s))
         hi = np.floor((v + (1 << (FIX_LB - 1))) / (1 << FIX_LB))
-        if np.max(np.abs(v)) < (1 << 23) - 2 and np.sum(np.abs(hi)) + h.shape[0] < 0.98 * (1 << 16):
+        lo = v - hi * (1 << FIX_LB)
+        if np.max(np.abs(v)) >= (1 << 27) - (1 << FIX_LB) - 2:
+            continue
+        if factor is None:
+            if np.max(np.abs(v)) < (1 << 23) - 2 and np.sum(np.abs(hi)) + h.shape[0] < lim:
+                return s
+            continue
+        M = int(factor)
+        ok_all = True
+        for d in range(8):
+            rows_hi, rows_lo = np.zeros(M), np.zeros(M)
+            idx = (np.arange(h.shape[0]) + d) % M
+            np.add.at(rows_hi, idx, np.abs(hi))
+            np.add.at(rows_lo, idx, np.abs(lo))
+            per_row = -(-(h.shape[0] + d) // M)
+            fits = False
+            fr = M
+            while fr >= 1 and not fits:
+                wh = rows_hi.reshape(-1, fr).sum(axis=1).max() + fr * per_row
+                wl = rows_lo.reshape(-1, fr).sum(axis=1).max() + fr * per_row
+                fits = wh < lim and wl < lim
+                fr //= 2
+            ok_all &= fits
+        if ok_all:
             return s
     return 0
 
@@ -246,7 +273,7 @@ class FrontEnd:
 
     def _finish(self):
         """A chain of decimations only (every hand-over at 16 000 Hz) runs in float64 end to end: the first stage -- int16 samples, a
-        power-of-two factor -- as an integer-exact dot product with taps on the grid 2**-27 (``quantize_taps``; csrc/wfx_polyphase.hip
+        power-of-two factor -- as an integer-exact dot product with taps on the grid 2**-30 (``quantize_taps``; csrc/wfx_polyphase.hip
         MODE 1), the stages behind it with float64 taps and sums.  What reaches the exact path then differs from an ideal filter
         by the designs' own error alone -- no fp32 rounding of samples or sums, which is what flipped 5-30 stream bytes per clip in
         round 2 (a float64 model of the same chain flips none).  ``f64`` tells FrontEndDevice which entry points to use."""
@@ -263,8 +290,8 @@ class FrontEnd:
         for st in self.stages:
             st.f64_chain = True
         s0 = self.stages[0]
-        if s0.factor & (s0.factor - 1) == 0 and s0.factor >= 4 and not s0.fix_shift:
-            sh = fix_shift_for(s0.coef64)            # (the least-squares pair quantised its first filter before designing the second)
+        if s0.factor & (s0.factor - 1) == 0 and s0.factor >= 8 and not s0.fix_shift:
+            sh = fix_shift_for(s0.coef64, s0.factor)            # (the least-squares pair quantised its first filter before designing the second)
             # a filter with large taps (small factors: /4 at 192 kHz) only gets a coarse grid, and nothing behind it compensates:
             # measured 11-12 flipped stream bytes per 192 kHz clip at 2**-24 -- such stages run in float64 instead (cheap there)
             if sh >= MIN_FIX_SHIFT:
@@ -294,19 +321,21 @@ class FrontEnd:
         fs1, fo1 = float(s1.fs_in), float(s1.fs_out)
         stops = [(k * fo1 - NYQ, min(k * fo1 + NYQ, fs1 / 2)) for k in range(1, int(fs1 / 2 // fo1) + 1) if k * fo1 - NYQ < fs1 / 2]
         # (stop bands weighted 3000 : 1 -- the pass band may ripple by 1e-4, the second filter follows it anyway: -149 dB instead of
-        # -133 dB before the taps are put on their grid, -138 dB after)
+        # -133 dB before the taps are put on their grid; after: -138 dB on the 2**-27 grid of the kernel's first form, -149 dB on
+        # 2**-30 now that it flushes the high halves of its sums too)
         h1 = ls_fir(n1, fs1, [(0.0, NYQ)] + stops, [1.0] + [0.0] * len(stops), [1.0] + [3000.0] * len(stops))
         h1 /= h1.sum()
-        sh1 = fix_shift_for(h1)
+        sh1 = fix_shift_for(h1, s1.factor)
         if sh1 < MIN_FIX_SHIFT:
             sh1 = 0
         if sh1:
             h1 = quantize_taps(h1, sh1)              # what the integer-exact kernel applies; the second filter is designed against THIS response
         fs2, fo2 = float(s2.fs_in), float(s2.fs_out)
-        # a few more taps than the plain low-pass: the pass band now has a shape to follow.  95 taps make the PAIR flat to 2e-8;
-        # 119 taps reach 3e-10 but measured no fewer flipped stream bytes (0-5 per 1.536 MS/s clip either way: what is left is
-        # the first filter's -132 dB stop band folding out-of-band noise into the band) for a quarter more work in this stage
-        n2 = (s2.ntaps + int(os.environ.get("WFX_FE_N2_EXTRA", "8"))) | 1
+        # more taps than the plain low-pass: the pass band now has a shape to follow.  95 taps (WFX_FE_N2_EXTRA=8) make the PAIR flat
+        # to 2e-8, 119 taps to 3e-10.  While the first filter sat on the 2**-27 grid (-138 dB of stop band) the longer filter bought
+        # nothing; on the 2**-30 grid (-149 dB, the design's own depth) it does -- 80 random 1.536 MS/s clips: 55 -> 62 of 65
+        # decodable ones with the identical uint8 stream, 17 -> 5 differing bytes of 22.5 M -- for +1.3 % on the whole decode
+        n2 = (s2.ntaps + int(os.environ.get("WFX_FE_N2_EXTRA", "32"))) | 1
         h2 = ls_fir(n2, fs2, [(0.0, NYQ), (fo2 - NYQ, fs2 / 2)], [lambda f: 1.0 / _response(h1, fs1, f), 0.0], [1.0, 1.0], grid=1200, iters=14)
         # verify before adopting
         fp = np.linspace(0.0, NYQ, 3000)
