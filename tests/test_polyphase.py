@@ -217,9 +217,10 @@ def test_decimate_kernel_matches_model(ctx, kind, factor, ntaps):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["i16", "iq", "f64"])
-@pytest.mark.parametrize("factor,ntaps,worst", [(32, 253, False), (32, 253, True), (4, 47, False), (8, 61, False), (3, 95, False), (2, 17, False),
-                                                (64, 301, False), (16, 125, True)])
-def test_decimate_fir64_is_exact_where_it_says_so(ctx, kind, factor, ntaps, worst):
+@pytest.mark.parametrize("factor,ntaps,worst,legacy", [(32, 253, False, False), (32, 253, True, False), (32, 253, True, True), (4, 47, False, False),
+                                                       (8, 61, False, False), (8, 61, True, False), (3, 95, False, False), (2, 17, False, False),
+                                                       (64, 301, False, False), (64, 301, True, False), (16, 125, True, False), (16, 125, True, True)])
+def test_decimate_fir64_is_exact_where_it_says_so(ctx, kind, factor, ntaps, worst, legacy):
     """wfx_d_decimate_fir64: int16 input with an aligned power-of-two factor is an integer dot product -- EQUAL to the integer
     model for every input, also the worst case for the accumulators (all samples -32768 / +32767 with the signs of the taps);
     anything else is float64 arithmetic in a fixed order."""
@@ -229,8 +230,12 @@ def test_decimate_fir64_is_exact_where_it_says_so(ctx, kind, factor, ntaps, wors
     first = 37
     n_in = first + (n_out - 1) * factor + ntaps + 11
     h = np.sinc((np.arange(ntaps) - (ntaps - 1) / 2) / factor / 1.3) * np.hanning(ntaps + 2)[1:-1]
-    sh = pp.fix_shift_for(h / h.sum())
-    assert 20 <= sh <= 30
+    # grid: the finest one the kernel takes for this factor (both halves of the sums flushed every few rows: up to 2**-30; the
+    # worst-case inputs below then fill the int32 sums of a flush window to within 2 % of their range), or -- `legacy` -- the one
+    # that keeps the high halves of all taps in one int32
+    pow2 = factor & (factor - 1) == 0
+    sh = pp.fix_shift_for(h / h.sum()) if legacy or not pow2 else pp.fix_shift_for(h / h.sum(), factor)
+    assert 20 <= sh <= 30 and (legacy or not pow2 or sh >= pp.fix_shift_for(h / h.sum()))
     coef = pp.quantize_taps(h / h.sum(), sh)
     fix = np.rint(coef * 2.0 ** sh).astype(np.int64)
     assert np.array_equal(fix / 2.0 ** sh, coef) and coef.sum() == 1.0
