@@ -327,11 +327,12 @@ def _oracle(x, fs, lpm):
         return wo.process(path, lpm, want_messages=False)
 
 
-# What separates these decodes from the reference is the front end alone (flat filters to 22 050 Hz with 135 dB stop bands, fp32
-# stencils): the exact FFT resampler applies the reference's own brick wall and everything after it is the exact path.
-# Measured on MI355X (tools/fe_att_sweep.py): the uint8 stream differs by 1 on 19 of 441 000 samples, the image by at most 1 --
-# the north star's bar -- with start_frame equal.  The tolerances below are that bar and ten times the measured count.
-STREAM_MAX, STREAM_NE_FRAC, IMAGE_MAX, IMAGE_GT1_FRAC = 1, 5e-4, 1, 0.0
+# What separates these decodes from the reference is the front end alone: the exact FFT resampler applies the reference's own
+# brick wall and everything after it is the exact path.  Round 3 (integer-exact ingest on the 2**-30 grid, float64 behind it):
+# 179 of 182 random clips give the identical uint8 stream, the rest differ by 1 on at most 3 of ~440 000 samples, the image by at
+# most 1 -- the north star's bar -- with start_frame equal (profiles/r03_v4/random_fe_parity.jsonl).  The tolerances below are that
+# bar and several times the measured count (round 2, fp32 stencils: 19 of 441 000 samples, tolerance 5e-4).
+STREAM_MAX, STREAM_NE_FRAC, IMAGE_MAX, IMAGE_GT1_FRAC = 1, 5e-5, 1, 0.0
 
 
 @pytest.mark.gpu
@@ -357,7 +358,10 @@ def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds
     dec.close()
     assert info.start_frame == ref["start_frame"]
     peaks1 = [int(info.peak_pos[k]) for k in range(info.npeaks)]
-    for name, got, want, mx, frac in (("stream", st1, ref["digitalized"], STREAM_MAX, STREAM_NE_FRAC), ("image", img1, ref["image"], IMAGE_MAX, None)):
+    # (the 16 000 Hz hand-over is the default chain: decimations only, integer-exact ingest + float64; the 22 050 / 14 700 Hz
+    # hand-overs end in the fp32 rational stage of round 2 and keep its tolerance)
+    ne_frac = STREAM_NE_FRAC if fe.f64 else 5e-4
+    for name, got, want, mx, frac in (("stream", st1, ref["digitalized"], STREAM_MAX, ne_frac), ("image", img1, ref["image"], IMAGE_MAX, None)):
         d = np.abs(got.astype(np.int16) - want.astype(np.int16))
         print(f"fs={fs} via {stop_rate}: {name} max|d|={d.max()} differing={np.count_nonzero(d)} of {d.size}, >1: {np.count_nonzero(d > 1)}")
         assert got.shape == want.shape and d.max() <= mx
