@@ -73,9 +73,9 @@ def parse():
 # ---- N ranks from one command ---------------------------------------------------------------------------------
 def spawn_ranks(args) -> int:
     """`--gpus N` without a launcher: start N fresh processes (this script again, one rank each) BEFORE anything touches a
-    GPU, relay rank 0's stdout.  The parent imports nothing but the standard library.  Each child sees ONE device
-    (HIP_VISIBLE_DEVICES = its local rank, LOCAL_RANK 0 inside) unless WFX_BENCH_OVERSUBSCRIBE=1 puts several ranks on the
-    devices there are.  A child that dies takes its siblings with it: the parent polls all of them, terminates the rest on
+    GPU, relay rank 0's stdout.  The parent imports nothing but the standard library.  Each child sees every device and
+    takes the one its LOCAL_RANK names (RCCL needs its peers' devices visible for P2P / IPC); WFX_BENCH_OVERSUBSCRIBE=1 puts
+    several ranks on the devices there are.  A child that dies takes its siblings with it: the parent polls all of them, terminates the rest on
     the first non-zero exit (a rank inside a collective would otherwise wait for ever) and gives up after WFX_BENCH_TIMEOUT s."""
     import secrets
     import socket
@@ -93,7 +93,10 @@ def spawn_ranks(args) -> int:
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    WFX_BOOT_PORT=str(boot), WFX_JOB_NONCE=nonce,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        if not over:
+        # Every rank keeps ALL devices visible and picks its own by LOCAL_RANK: RCCL's intra-node path opens IPC handles on its
+        # peers' devices and checks peer access, which a rank that sees only its own GPU cannot do (it would fall back to host
+        # staging or fail).  WFX_BENCH_ISOLATE=1 restores one visible device per rank (HIP_VISIBLE_DEVICES), for experiments.
+        if not over and os.environ.get("WFX_BENCH_ISOLATE") == "1":
             vis = os.environ.get("HIP_VISIBLE_DEVICES")
             devs = vis.split(",") if vis else [str(k) for k in range(args.gpus)]
             if r < len(devs):
@@ -174,7 +177,17 @@ class Ranks:
         over = os.environ.get("WFX_BENCH_OVERSUBSCRIBE") == "1"
         self.transport = os.environ.get("WFX_BENCH_COMM") or ("shm" if over and self.world > max(1, nat.device_count()) else "rccl")
         if self.use_rccl and self.transport == "shm":
-            job = os.environ.get("WFX_JOB_NONCE") or ("p" + os.environ.get("MASTER_PORT", "29511"))
+            job = os.environ.get("WFX_JOB_NONCE")
+            if not job:
+                # under a launcher there is no nonce from spawn_ranks: rank 0 draws one per LAUNCH and hands it out over the
+                # bootstrap socket (a job name reused across launches would let a rank attach to the control block a crashed
+                # earlier run left in /dev/shm)
+                addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+                mport = int(os.environ.get("MASTER_PORT", "29511"))
+                port = int(os.environ.get("WFX_BOOT_PORT", str(mport + 1009 if mport + 1009 + 16 < 65536 else mport - 1009)))
+                blob = sharded.bootstrap_unique_id(self.rank, self.world, addr=addr, port=port, nonce=f"{addr}:{mport}",
+                                                   make_id=lambda: os.urandom(nat.WFX_COMM_ID_BYTES))
+                job = "p" + str(mport) + "-" + bytes(blob[:8]).hex()
             self.comm = nat.Comm.shm(self.ctx, job, self.world, self.rank, timeout=float(os.environ.get("WFX_BENCH_TIMEOUT", "600")))
             self.comm.barrier(self.ctx)
         elif self.use_rccl:

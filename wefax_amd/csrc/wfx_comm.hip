@@ -20,6 +20,7 @@
 // Only three collectives are needed (wfx_shard.hip): a personalised exchange (grouped send / recv: the transposes of the
 // distributed transforms and the final gather), a sum all-reduce of uint32 histograms, and an all-gather of equal blocks.
 #include <dlfcn.h>
+#include <errno.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -235,6 +236,16 @@ static int shm_own_box(wfx_shm *s, wfx_ctx *ctx, size_t need, char **base)
         size_t cap = have ? have : (1u << 20);
         while (cap < need) cap *= 2;
         if (ftruncate(s->fd[r], (off_t)cap) != 0) return shm_fail(s, ctx, "cannot grow the outbox to %lld bytes (is /dev/shm full?)", (long long)cap);
+        // tmpfs reserves nothing at ftruncate: without the pages a later copy into the mapping dies with SIGBUS (a container's
+        // default /dev/shm is 64 MB) and the peers only notice at the barrier's timeout.  Reserve them now; failure is an error
+        // on every rank (shm_fail sets the job's failure flag).
+        int fe;
+        while ((fe = posix_fallocate(s->fd[r], 0, (off_t)cap)) == EINTR) {}
+        if (fe != 0) {
+            (void)!ftruncate(s->fd[r], (off_t)have);
+            return shm_fail(s, ctx, "cannot reserve %lld bytes of shared memory for the outbox (%s): /dev/shm is too small for this exchange", (long long)cap,
+                            strerror(fe));
+        }
         s->ctl->box_bytes[r].store(cap, std::memory_order_release);
         have = cap;
     }
@@ -681,33 +692,79 @@ int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, doub
     int cfd = -1;
     const double t0 = now_s();
     if (rank == 0) {
-        shm_unlink(cn.c_str());                          // a leftover of a crashed job of the same name
+        // a leftover of a crashed job of the same name: a peer of THIS launch may already have opened it -- take its magic away
+        // and mark it failed before unlinking, so that such a peer finds out (it re-opens: see below) instead of sitting on a
+        // dead control block; stale outboxes of that job go too
+        {
+            const int ofd = shm_open(cn.c_str(), O_RDWR, 0600);
+            if (ofd >= 0) {
+                struct stat st;
+                if (fstat(ofd, &st) == 0 && (size_t)st.st_size >= sizeof(shm_ctl)) {
+                    void *om = mmap(nullptr, sizeof(shm_ctl), PROT_READ | PROT_WRITE, MAP_SHARED, ofd, 0);
+                    if (om != MAP_FAILED) {
+                        ((shm_ctl *)om)->magic.store(0, std::memory_order_release);
+                        ((shm_ctl *)om)->failed.store(1, std::memory_order_release);
+                        munmap(om, sizeof(shm_ctl));
+                    }
+                }
+                close(ofd);
+            }
+            shm_unlink(cn.c_str());
+            for (int r = 0; r < 64; ++r) shm_unlink(shm_name(s->job, "box", r).c_str());
+        }
         cfd = shm_open(cn.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (cfd < 0 || ftruncate(cfd, (off_t)sizeof(shm_ctl)) != 0) {
             if (cfd >= 0) close(cfd);
             delete s;
             return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator: cannot create %s", cn.c_str());
         }
-    } else {
-        while ((cfd = shm_open(cn.c_str(), O_RDWR, 0600)) < 0) {
-            if (now_s() - t0 > s->timeout) {
-                delete s;
-                return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator, rank %d: rank 0 never created %s", rank, cn.c_str());
+    }
+    void *m = MAP_FAILED;
+    for (;;) {
+        if (rank != 0) {
+            while ((cfd = shm_open(cn.c_str(), O_RDWR, 0600)) < 0) {
+                if (now_s() - t0 > s->timeout) {
+                    delete s;
+                    return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator, rank %d: rank 0 never created %s", rank, cn.c_str());
+                }
+                usleep(2000);
             }
-            usleep(2000);
+            struct stat st;
+            while (fstat(cfd, &st) == 0 && (size_t)st.st_size < sizeof(shm_ctl)) {
+                if (now_s() - t0 > s->timeout) break;
+                usleep(1000);
+            }
         }
-        struct stat st;
-        while (fstat(cfd, &st) == 0 && (size_t)st.st_size < sizeof(shm_ctl)) {
-            if (now_s() - t0 > s->timeout) break;
-            usleep(1000);
+        m = mmap(nullptr, sizeof(shm_ctl), PROT_READ | PROT_WRITE, MAP_SHARED, cfd, 0);
+        if (m == MAP_FAILED) {
+            close(cfd);
+            delete s;
+            return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator: cannot map %s", cn.c_str());
         }
+        if (rank == 0) break;
+        // wait for rank 0's magic -- on a block that is still linked under the job's name: one that was unlinked meanwhile is the
+        // leftover of an earlier job which rank 0 has just replaced (it took the magic away first), so open the name again
+        bool stale = false, ready = false;
+        while (!ready && !stale) {
+            struct stat st;
+            if (fstat(cfd, &st) != 0 || st.st_nlink == 0) stale = true;
+            else if (((shm_ctl *)m)->magic.load(std::memory_order_acquire) == SHM_MAGIC) {
+                ready = fstat(cfd, &st) == 0 && st.st_nlink > 0 && ((shm_ctl *)m)->magic.load(std::memory_order_acquire) == SHM_MAGIC;
+                stale = !ready;
+            } else if (now_s() - t0 > s->timeout) {
+                munmap(m, sizeof(shm_ctl));
+                close(cfd);
+                delete s;
+                return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator, rank %d: the control block was never initialised", rank);
+            } else
+                usleep(1000);
+        }
+        if (ready) break;
+        munmap(m, sizeof(shm_ctl));
+        close(cfd);
+        usleep(2000);
     }
-    void *m = mmap(nullptr, sizeof(shm_ctl), PROT_READ | PROT_WRITE, MAP_SHARED, cfd, 0);
     close(cfd);
-    if (m == MAP_FAILED) {
-        delete s;
-        return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator: cannot map %s", cn.c_str());
-    }
     s->ctl = (shm_ctl *)m;
     if (rank == 0) {
         s->ctl->world = (uint32_t)world;
@@ -718,15 +775,6 @@ int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, doub
         for (int r = 0; r < 64; ++r) s->ctl->box_bytes[r].store(0);
         s->ctl->magic.store(SHM_MAGIC, std::memory_order_release);
     } else {
-        while (s->ctl->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
-            if (now_s() - t0 > s->timeout) {
-                munmap(m, sizeof(shm_ctl));
-                s->ctl = nullptr;
-                delete s;
-                return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator, rank %d: the control block was never initialised", rank);
-            }
-            usleep(1000);
-        }
         if ((int)s->ctl->world != world) {
             const unsigned theirs = s->ctl->world;
             munmap(m, sizeof(shm_ctl));

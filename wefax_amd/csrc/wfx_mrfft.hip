@@ -473,9 +473,6 @@ __device__ __forceinline__ void dft_pow2_rec(const cplx *x, int stride, cplx *X,
 // N1 x N2 intermediate then costs no registers and a pass has room for the next tile's prefetch.
 //   dft_ct_rows:  n = N2 n1 + n2, k = k1 + N1 k2, twiddles W_N^(n2 k1) between the steps (the arithmetic of dft25_ct)
 //   dft_pfa_rows: gcd(N1, N2) = 1, n = (N2 n1 + N1 n2) mod N, k = k1 mod N1 = k2 mod N2 (Good-Thomas): no twiddles at all
-#ifndef WFX_ROWS_LDS
-#define WFX_ROWS_LDS 1
-#endif
 template <int N1, int N2, typename ROW, typename PUT>
 __device__ __forceinline__ void dft_ct_rows(ROW row, const double sg, PUT put)
 {
@@ -528,7 +525,7 @@ __device__ __forceinline__ void dft_pfa_rows(ROW row, const double sg, PUT put)
 }
 
 // radices whose level-B transform goes through the item's LDS rows
-constexpr bool mr2_rows(int rb) { return WFX_ROWS_LDS && rb == 25; }
+constexpr bool mr2_rows(int rb) { return rb == 25; }
 
 template <int P, typename ROW, typename PUT>
 __device__ __forceinline__ void dft_rows(ROW row, const double sg, PUT put)
@@ -539,15 +536,12 @@ __device__ __forceinline__ void dft_rows(ROW row, const double sg, PUT put)
         dft_pfa_rows<3, 5>(row, sg, put);
 }
 
-#ifndef WFX_PFA15
-#define WFX_PFA15 1
-#endif
 template <int P, bool PFA = false, typename PUT>
 __device__ __forceinline__ void dft_any(cplx *v, const double sg, PUT put)
 {
     if constexpr (P == 25) {
         dft25_ct(v, sg, put);
-    } else if constexpr (P == 15 && PFA && WFX_PFA15) {
+    } else if constexpr (P == 15 && PFA) {
         dft_pfa_rows<3, 5>([&](int r) { return &v[r]; }, sg, put);      // 3 x 5 without twiddles: 134 operations against 230
     } else if constexpr (P == 2 || P == 4 || P == 8 || P == 16) {
         cplx X[P];
@@ -559,23 +553,13 @@ __device__ __forceinline__ void dft_any(cplx *v, const double sg, PUT put)
     }
 }
 
-// tile width (columns) and prefetch policy of a pair, shared by the kernel and the host.  Build-time switches for A/B runs
-// (tools/build_variant.sh; DESIGN.md 3.2 has what each measured): WFX_ROWS_LDS, WFX_PFA15 (composite levels), WFX_PF_BUDGET (registers
-// a pass may spend on the tile in flight), WFX_T64 (log2 columns of a radix-64 tile), WFX_WIDE (512-lane workgroups for radices
-// above 128), WFX_FUSED_LB (workgroups per CU of the fused spectral pass), WFX_FUSED_SPECTRUM is a run-time switch.
-#ifndef WFX_PF_BUDGET
-#define WFX_PF_BUDGET 140
-#endif
-#ifndef WFX_WIDE
-#define WFX_WIDE 0
-#endif
-// radices above 128: 512 lanes on a 32-column tile (one workgroup per CU, 90-115 KB of LDS) -- row segments of 512 bytes like the
-// smaller radices have; with 256 lanes and 16 columns the same passes run 4 us slower at the benchmark size
-constexpr int mr2_nt(int r) { return (WFX_WIDE && r > 128) ? 512 : 256; }
-#ifndef WFX_T64
-#define WFX_T64 5
-#endif
-constexpr int mr2_log2t(int r) { return r <= 16 ? 8 : r <= 32 ? 7 : r <= 63 ? 6 : r == 64 ? WFX_T64 : r <= 128 ? 5 : WFX_WIDE ? 5 : 4; }
+// tile width (columns) and prefetch policy of a pair, shared by the kernel and the host.  (The build-time A/B switches of rounds
+// 2-3 -- 25-point level through LDS rows, Good-Thomas 15-point level, 512-lane workgroups for radices above 128, 64-column
+// radix-64 tiles, int16 staging -- are settled: DESIGN.md 3.2 has what each measured; the winners are what is written here.)
+constexpr int MR2_PF_BUDGET = 140;       // registers a pass may spend on the tile in flight
+constexpr int MR2_FUSED_LB = 2;          // workgroups per CU of the fused spectral pass
+constexpr int mr2_nt(int) { return 256; }       // lanes per workgroup (512 lanes on 32-column tiles for radices above 128 lost to barriers)
+constexpr int mr2_log2t(int r) { return r <= 16 ? 8 : r <= 32 ? 7 : r <= 63 ? 6 : r <= 128 ? 5 : 4; }
 constexpr bool mr2_prefetch(int ra, int rb)
 {
     const int t = 1 << mr2_log2t(ra * rb);
@@ -583,28 +567,21 @@ constexpr bool mr2_prefetch(int ra, int rb)
     if (mr2_rows(rb)) return na * ra * 4 + 40 <= 140;     // level B works five points at a time (dft_rows)
     // registers: a tile in flight + a level-B transform (the 16-point level keeps two half-size scratch arrays: with the tile in
     // flight the (15,16) pass spilled 87 registers and took 580 us on the 86.4 M-point transform, 433 without)
-    return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) + (rb == 16 ? 24 : 0) <= WFX_PF_BUDGET;
+    return na * ra * 4 + rb * 4 + (rb == 25 || ra == 25 ? 40 : 0) + (rb == 16 ? 24 : 0) <= MR2_PF_BUDGET;
 }
 
-#ifndef WFX_FUSED_LB
-#define WFX_FUSED_LB 2
-#endif
 // int16 first pass (IN_MODE 2): a tile's row segments are only T * 4 bytes (128 for radix 64).  The workgroup stages the rows of
 // SUP consecutive tiles in LDS as int16 pairs -- 256..512-byte segments, the next block's loads in flight in registers across the
-// SUP tiles of this one -- and the tiles read their points from there.  WFX_I16_STAGE=0: every tile reads its own segments.
-#ifndef WFX_I16_STAGE
-#define WFX_I16_STAGE 1
-#endif
+// SUP tiles of this one -- and the tiles read their points from there.
 constexpr int mr2_i16_sup(int r)
 {
-    if (!WFX_I16_STAGE || mr2_nt(r) != 256) return 1;
     const int t = 1 << mr2_log2t(r);
     for (int sw = 128; sw > t; sw >>= 1)                          // staged columns; two workgroups per CU must still fit (80 KB each)
         if (t * r * 16 + r * sw * 4 + r * 16 + 2048 <= 80 * 1024) return sw / t;
     return 1;
 }
 template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
-__global__ void __launch_bounds__(mr2_nt(RA * RB), mr2_nt(RA * RB) == 512 ? 1 : OUT_MODE == 2 ? WFX_FUSED_LB : 2)
+__global__ void __launch_bounds__(mr2_nt(RA * RB), mr2_nt(RA * RB) == 512 ? 1 : OUT_MODE == 2 ? MR2_FUSED_LB : 2)
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
          int ntiles)
 {
@@ -1625,6 +1602,7 @@ int wfx_dev_hilbert_kernel_rows(wfx_ctx *ctx, cplx *dst, long long p0, long long
 struct mr_padded_cache {
     long long M = 0;
     wfx_devbuf ghat;
+    bool ready = false;          // the kernel's transform has been enqueued in full (a failed launch in between leaves it false)
 };
 static std::map<std::pair<const void *, long long>, mr_padded_cache> g_mr_padded;      // per (context, N)
 
@@ -1666,12 +1644,13 @@ int wfx_dev_hilbert_conv_mr_padded(wfx_ctx *ctx, const double *x, uint64_t n, cp
     WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (size_t)M * sizeof(cplx)));
     cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
     const cplx *tb = (const cplx *)pc->tables.p;
-    if (!pd->ghat.p) {
+    if (!pd->ready) {
         WFX_TRY(wfx_reserve(ctx, pd->ghat, (size_t)M * sizeof(cplx)));
         cplx *G = (cplx *)pd->ghat.p;
         WFX_LAUNCH(ctx, K_BS_CHIRP, mr_padded_fill, dim3(wfx_stream_grid((uint64_t)M, 256)), dim3(256), G, (long long)n, L, M, 1.0 / (double)M);
         cplx *res = nullptr;
         WFX_TRY(mr_run(ctx, pc, G, A, B, 0, false, G, &res));      // (np >= 2: G is read by the first pass only)
+        pd->ready = true;        // only now: a decode that failed above rebuilds the spectrum instead of multiplying by a partial one
     }
     // forward: first pass from the packed reals (the first L points; zeros behind them), last pass times the kernel's transform
     const cplx *src = (const cplx *)x;

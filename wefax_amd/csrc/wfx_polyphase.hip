@@ -342,9 +342,6 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
         __syncthreads();                       // the previous tile's compute phase is done with the LDS window
         // (PF: the tile's first batch of chunks was requested before the previous tile's compute phase)
         if (!PF) fetch(Gn, 0);
-#ifdef PP_F64_NOSTASH
-        if (MODE != 2 || n_out < 0)
-#endif
         stash(Gn, 0);
         for (int cb = PP_NB * PP_THREADS; cb < Gn.nchunks; cb += PP_NB * PP_THREADS) {
             fetch(Gn, cb);
@@ -471,11 +468,7 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
             }
         } else if constexpr (MODE == 2) {
             double tot0 = 0, tot1 = 0, tot2 = 0, tot3 = 0;
-#ifdef PP_F64_NOCOMPUTE
-            if (active && n_out < 0) {
-#else
             if (active) {
-#endif
                 const int r0 = part * rows_per;
                 const double *cd = (const double *)cp;            // taps by scalar loads from the table in memory (the row index is uniform)
                 for (int r = r0; r < r0 + rows_per; ++r) {

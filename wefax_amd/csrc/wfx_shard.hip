@@ -194,11 +194,24 @@ struct wfx_shard {
     wfx_devbuf b_in, b_merged, b_res, b_audio, b_v, b_env, b_dig, b_blk, b_blks, b_nan, b_flags;
     wfx_devbuf b_grow, b_ghat;            // padded form: this rank's rows of the kernel g_ext / Kp, and its slab of the kernel's transform
     bool ghat_ready = false;              // computed by three extra phases in front of the first decode
+    // those three phases have run but the decode they belonged to has not finished (ghat_ready selects the phase numbering, so it
+    // cannot flip in the middle of one): promoted to ghat_ready when the next decode starts -- a decode that aborts in a later
+    // phase and is retried starts from the audio phases, with the forward half already re-bound to the audio rows
+    bool ghat_pending = false;
+    bool in_decode = false;
     const void *ext_in = nullptr;
     bool have_input = false, ran = false, bound = false;
     uint64_t cap = SH_CAND_CAP;
     unsigned *ws = nullptr;
 };
+
+static void settle_kernel(wfx_shard *sh)
+{
+    if (sh->ghat_pending && !sh->in_decode) {
+        sh->ghat_ready = true;
+        sh->ghat_pending = false;
+    }
+}
 
 static size_t frame_bytes(int in_kind) { return in_kind == WFX_IN_I16_MONO ? 2 : (in_kind == WFX_IN_I16_STEREO ? 4 : 8); }
 
@@ -213,6 +226,7 @@ static int shard_bind(wfx_shard *sh)
 {
     wfx_ctx *ctx = sh->ctx;
     shard_plan &pl = sh->pl;
+    settle_kernel(sh);
     if (pl.single) {                      // rank 0 decodes alone (the fused path owns its buffers)
         sh->bound = true;
         return 0;
@@ -321,14 +335,19 @@ static int run_phase(wfx_shard *sh, int ph)
             cplx *G = nullptr;
             WFX_TRY(dk.fwd_slab(0, &G));
             WFX_HIP(ctx, hipMemcpyAsync(sh->b_ghat.p, G, (size_t)sh->dH.slab_points() * sizeof(cplx), hipMemcpyDeviceToDevice, ctx->stream));
+            // the kernel's transform exists from here on: a decode that aborts in a later phase and is retried must NOT re-run
+            // these three phases (the forward half is re-bound to the audio rows below)
             if (pl.split_kernel) {       // the kernel's transform object and its rows have done their work
                 WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 sh->dHk.release();
                 free_buf(sh->b_grow);
+                sh->ghat_pending = true;
                 return 0;
             }
             // from here on the forward half reads the audio rows (re-binding rebuilds the E1 lists: a host synchronisation, once)
-            return sh->dH.bind(audio + (pl.own_lo - pl.seg_lo), (cplx *)sh->b_v.p, sh->dH.fwd_result_index());
+            WFX_TRY(sh->dH.bind(audio + (pl.own_lo - pl.seg_lo), (cplx *)sh->b_v.p, sh->dH.fwd_result_index()));
+            sh->ghat_pending = true;
+            return 0;
         }
         ph -= 3;
     }
@@ -709,18 +728,36 @@ int wfx_shard_attach(wfx_shard *sh, const void *dev_frames)
     return 0;
 }
 
-int wfx_shard_phase_count(wfx_shard *sh) { return sh ? phase_count(sh) : 0; }
+int wfx_shard_phase_count(wfx_shard *sh)
+{
+    if (!sh) return 0;
+    settle_kernel(sh);
+    return phase_count(sh);
+}
 
 int wfx_shard_phase(wfx_shard *sh, int phase)
 {
     CHECK_SH(sh);
     if (!sh->have_input) return wfx_fail(sh->ctx, WFX_ERR_STATE, "sharded decode before the input was given");
+    if (phase == 0) {                                    // a new decode (whatever became of the previous one)
+        sh->in_decode = false;
+        settle_kernel(sh);
+    }
     const int np = phase_count(sh);
     if (phase < 0 || phase >= np) return wfx_fail(sh->ctx, WFX_ERR_BAD_ARG, "phase %d out of range", phase);
-    WFX_TRY(run_phase(sh, phase));
+    sh->in_decode = true;
+    const int rc = run_phase(sh, phase);
+    if (rc != 0) {
+        sh->in_decode = false;
+        return rc;
+    }
     if (phase == np - 1) {
+        sh->in_decode = false;
         sh->ran = true;
-        if (sh->pl.padded) sh->ghat_ready = true;        // (the next decode has three phases fewer)
+        if (sh->pl.padded) {                             // (the next decode has three phases fewer)
+            sh->ghat_ready = true;
+            sh->ghat_pending = false;
+        }
     }
     return 0;
 }
@@ -730,7 +767,7 @@ int wfx_decode_sharded(wfx_shard *sh)
     CHECK_SH(sh);
     if (wfx_comm_is_local(sh->comm) && wfx_comm_world(sh->comm) > 1)
         return wfx_fail(sh->ctx, WFX_ERR_STATE, "local communicator: drive the ranks phase by phase (wfx_shard_phase)");
-    const int np = phase_count(sh);
+    const int np = wfx_shard_phase_count(sh);
     for (int ph = 0; ph < np; ++ph) WFX_TRY(wfx_shard_phase(sh, ph));
     return 0;
 }
