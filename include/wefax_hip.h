@@ -146,7 +146,11 @@ typedef struct {
     double   notch_b[3];       /* scipy.signal.iirnotch(2600, 1, 11025)           */
     double   notch_a[3];
     int      hilbert_mode;     /* wfx_hilbert_mode                                */
-    int      reserved0;        /* (was fir_taps)                                  */
+    /* sharded decode only (ignored by the one-GPU calls): which plan wfx_shard_* takes.  0 = the library's cost model decides
+     * (distributed transforms, or -- where their exchanges would take longer than one GPU needs for the whole capture -- the
+     * single plan: rank 0 alone); 1 = distributed whenever a distributed form exists; 2 = single.  Bit 4 (value 16) set:
+     * the ROWS layout of rounds 2-3 instead of the columns layout (A/B runs and the any-length padded forms, which still use it) */
+    int      shard_plan;
     /* np.percentile(., (0.5, 99.5)) 'linear': rank pairs and lerp weights        */
     uint64_t rank_lo[2];
     uint64_t rank_hi[2];
@@ -353,6 +357,20 @@ typedef struct {
     int      first_radix[2];   /* radix pair of the distributed first pass                                           */
     uint64_t in_lo, in_hi;     /* input frames [in_lo, in_hi) this rank must provide (global indices)                 */
     uint64_t own_lo, own_hi;   /* samples at 11 025 Hz this rank owns                                                 */
+    /* Round 4, the COLUMNS layout (nseg > 1): a rank owns nseg equally long, equally spaced SEGMENTS instead of one range --
+     * segment s = samples [own_lo + s * own_seg_stride, + own_seg_len) at 11 025 Hz (own_hi = the end of the last one), and
+     * provides the input frames [in_lo + s * in_seg_stride - in_halo, in_lo + s * in_seg_stride + in_seg_len + in_halo) of
+     * every segment, back to back: nseg * (in_seg_len + 2 in_halo) frames (frames outside the capture: anything).  The stage
+     * buffers wfx_shard_fetch returns are the segments back to back.  nseg == 1: one range, as in_lo / in_hi / own_lo /
+     * own_hi say (rows layout, single plan, one rank). */
+    int      nseg, in_halo;
+    uint64_t in_seg_len, in_seg_stride, own_seg_len, own_seg_stride;
+    int      plan;             /* 0 single (rank 0 alone), 1 rows layout, 2 columns layout                              */
+    int      plan_forced;      /* 1: wfx_decode_params.shard_plan asked for it; 0: the cost model chose                   */
+    /* the cost model's figures for this capture and world size, seconds (0 when no distributed form exists) */
+    double   model_single_s, model_dist_compute_s, model_dist_wire_s;
+    uint64_t model_wire_bytes; /* bytes all ranks put on the wire per decode in the distributed form                     */
+    char     plan_reason[160];
 } wfx_shard_layout;
 
 /* host only (no GPU needed): how a capture described by `p` is cut for `world` ranks.  Captures at 11 025 Hz shard at ANY
@@ -367,6 +385,20 @@ int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_
  * buffers (WFX_ERR_COMM with a description otherwise).  Lets a deployment -- and the CPU test suite -- validate a plan for
  * capture sizes and world sizes it cannot run */
 int wfx_shard_dry_run(const wfx_decode_params *p, int world);
+/* host only: what the plan puts on the wire.  One entry per collective of a decode, in order: name (<= 23 characters), the
+ * bytes all ranks together send to OTHER ranks, the most any one rank sends, and the most that crosses one directed link
+ * (rank a -> rank b).  Returns the number of collectives (entries beyond `cap` are not written), negative on error. */
+typedef struct {
+    char     name[24];
+    uint64_t total_bytes, max_rank_bytes, max_link_bytes;
+} wfx_wire_entry;
+int wfx_shard_wire_plan(const wfx_decode_params *p, int world, wfx_wire_entry *out, int cap);
+/* what this rank's communicator has moved since the last reset: one entry per collective in call order (ring buffer of the
+ * last 256), total_bytes = bytes THIS rank sent to other ranks, max_rank_bytes = bytes it received from them, max_link_bytes =
+ * the largest message; transport-independent (RCCL, shm and local communicators count alike).  Returns the number of
+ * collectives since the reset. */
+int wfx_comm_wire_reset(wfx_comm *comm);
+int wfx_comm_wire_stats(wfx_comm *comm, wfx_wire_entry *out, int cap);
 /* `p` describes the WHOLE capture (as for wfx_decode_upload); hilbert_mode must be WFX_HILBERT_FFT */
 int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, wfx_shard **out);
 /* this rank's input frames [in_lo, in_hi): host memory (copied) or caller-owned device memory (kept, not copied) */

@@ -148,7 +148,7 @@ def _decode_worker(job, world, rank, seed, rate, lpm, out_dir, q, trim=0):
         ctx = nat.Context(0)
         comm = nat.Comm.shm(ctx, job, world, rank, timeout=120.0)
         time.sleep(0.02 * ((rank * 7) % 5))                                 # the ranks drift apart
-        dec = sharded.ShardedDecoder(ctx, comm, x.shape[0], rate, lpm, sharded.capture_kind(x), data=x)
+        dec = sharded.ShardedDecoder(ctx, comm, x.shape[0], rate, lpm, sharded.capture_kind(x), data=x, plan="dist")
         for rep in range(3):                                                 # buffers are reused decode after decode
             dec.run()
             if rank % 2 == rep % 2:
@@ -209,10 +209,12 @@ def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, wo
     assert np.array_equal(np.load(tmp_path / "image.npy"), ref.fetch("image"))
     assert list(np.load(tmp_path / "sync.npy")) == [info.start_frame, info.height, info.npeaks]
     emu = sharded.decode_emulated(x, rate, world, lpm, want=("envelope",))
-    assert np.array_equal(np.concatenate([np.load(tmp_path / f"env{r}.npy") for r in range(world)]), emu["envelope"])
+    from wefax_amd.wefax import build_params
+    p, _ = build_params(sharded.capture_kind(x), x.shape[0], rate, 1 / (lpm / 60), shard_plan=sharded.plan_code("dist"))
+    lays = [nat.shard_layout(p, world, r) for r in range(world)]
+    assert np.array_equal(sharded.assemble(lays, [np.load(tmp_path / f"env{r}.npy") for r in range(world)], emu["n"]), emu["envelope"])
+    assert lays[0].plan == (1 if trim else 2)               # whole seconds: the columns layout; arbitrary lengths: the padded rows form
     if trim:
-        from wefax_amd.wefax import build_params
-        p, _ = build_params(0, x.shape[0], rate, 1 / (lpm / 60))
         sizes = [nat.shard_layout(p, world, r).own_hi - nat.shard_layout(p, world, r).own_lo for r in range(world)]
         assert min(sizes) > 0 and max(sizes) - min(sizes) <= x.shape[0] // 16   # only the rows that hold samples are dealt: equal shares
     ctx.close()
@@ -225,7 +227,7 @@ def _silence_worker(job, rank, q):
         x = np.full(1433250, 1200, dtype=np.int16)
         ctx = nat.Context(0)
         comm = nat.Comm.shm(ctx, job, 2, rank, timeout=120.0)
-        dec = sharded.ShardedDecoder(ctx, comm, x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x)
+        dec = sharded.ShardedDecoder(ctx, comm, x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x, plan="dist")
         dec.run()
         info = dec.result()
         ok = info.low == info.high and (rank != 0 or info.nan_count > 1000000)

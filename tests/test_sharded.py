@@ -27,27 +27,116 @@ KW30 = dict(start_tone_s=2.0, phasing_lines=20, image_lines=30, stop_tone_s=1.0,
 # ---------------------------------------------------------------------------------------------------------------
 # CPU
 # ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("plan", ["dist", "rows"])
 @pytest.mark.parametrize("n0,sr,kind", [(1433250, 11025, 0), (7166250, 11025, 0), (1440000, 48000, 0), (1440000, 48000, 1),
                                        (172800000, 48000, 0), (79380000, 22050, 2), (286650, 11025, 0), (330750, 11025, 0), (9922500, 22050, 2),
                                        (52920000, 14700, 2), (588000, 14700, 2), (57600000, 16000, 2), (640000, 16000, 2)])
-def test_layout_tiles_the_capture_and_the_exchange_lists_are_consistent(n0, sr, kind):
-    p, meta = build_params(kind, n0, sr, 0.5)
+def test_layout_tiles_the_capture_and_the_exchange_lists_are_consistent(n0, sr, kind, plan):
+    """Both layouts of the distributed form ("dist": the columns layout of round 4 wherever it applies; "rows": rounds 2-3)."""
+    p, meta = build_params(kind, n0, sr, 0.5, shard_plan=sharded.plan_code(plan))
+    n = meta["n"]
     for world in (1, 2, 3, 4, 8):
         lays = [nat.shard_layout(p, world, r) for r in range(world)]
-        assert lays[0].own_lo == 0 and lays[-1].own_hi == meta["n"]
-        assert all(lays[i].own_hi == lays[i + 1].own_lo for i in range(world - 1))
-        assert all(lay.own_lo % 2 == 0 and lay.own_hi % 2 == 0 for lay in lays)             # packed pairs stay together
-        sizes = [lay.own_hi - lay.own_lo for lay in lays]
         r1 = lays[0].first_radix[0] * lays[0].first_radix[1]
-        assert max(sizes) - min(sizes) <= meta["n"] // r1                                     # balanced to one row of the first radix
-        if meta["resampled"]:
-            assert lays[0].in_lo == 0 and lays[-1].in_hi == n0
-            assert all(lays[i].in_hi == lays[i + 1].in_lo for i in range(world - 1))
-            # the input rows are the same share of the capture as the output rows
-            assert all(abs((lay.in_hi - lay.in_lo) / n0 - (lay.own_hi - lay.own_lo) / meta["n"]) < 1e-12 for lay in lays)
-        else:   # the notch needs 24 + 2 samples beyond the own range: the slice carries 32, clipped at the capture's ends
-            assert all(lay.in_lo == max(0, lay.own_lo - 32) and lay.in_hi == min(n0, lay.own_hi + 32) for lay in lays)
+        assert r1 > 0 and all(lay.plan_forced == 1 for lay in lays)
+        assert sum(lay.own_samples for lay in lays) == n
+        if lays[0].plan == 2 and world > 1:
+            # COLUMNS layout: every rank holds the same columns of each of the r1 rows -- r1 segments, one row apart
+            assert plan == "dist" and all(lay.plan == 2 and lay.nseg == r1 for lay in lays)
+            stride = lays[0].own_seg_stride
+            assert r1 * stride == n and all(lay.own_seg_stride == stride for lay in lays)
+            assert lays[0].own_lo == 0 and lays[-1].own_lo + lays[-1].own_seg_len == stride                 # the segments of the ranks tile a row
+            assert all(lays[i].own_lo + lays[i].own_seg_len == lays[i + 1].own_lo for i in range(world - 1))
+            assert all(lay.own_lo % 8 == 0 and lay.own_seg_len % 2 == 0 and lay.own_seg_len >= 256 for lay in lays)
+            lens = [lay.own_seg_len for lay in lays]
+            assert max(lens) - min(lens) <= 16                                                               # balanced to a few columns
+            assert all(lay.own_hi == lay.own_lo + (r1 - 1) * stride + lay.own_seg_len for lay in lays)
+            if meta["resampled"]:   # input: the rank's columns of the input's own arrangement, no halo (the resampler is global)
+                istr = lays[0].in_seg_stride
+                assert r1 * istr == n0 and all(lay.in_halo == 0 and lay.in_seg_stride == istr for lay in lays)
+                assert lays[0].in_lo == 0 and lays[-1].in_lo + lays[-1].in_seg_len == istr
+                assert all(lays[i].in_lo + lays[i].in_seg_len == lays[i + 1].in_lo for i in range(world - 1))
+            else:                   # the notch needs 24 + 2 samples beyond every segment: 32 are handed over
+                assert all(lay.in_halo == 32 and lay.in_lo == lay.own_lo and lay.in_seg_len == lay.own_seg_len and lay.in_seg_stride == stride for lay in lays)
+            assert all(lay.in_frames == r1 * (lay.in_seg_len + 2 * lay.in_halo) for lay in lays)
+            if n <= 2000000:        # (the index arrays of the small cases: every sample owned exactly once)
+                owned = np.concatenate([lay.own_index() for lay in lays])
+                assert owned.shape[0] == n and np.array_equal(np.sort(owned), np.arange(n))
+        else:
+            assert all(lay.nseg == 1 for lay in lays) and (world == 1 or all(lay.plan == 1 for lay in lays))
+            assert lays[0].own_lo == 0 and lays[-1].own_hi == n
+            assert all(lays[i].own_hi == lays[i + 1].own_lo for i in range(world - 1))
+            assert all(lay.own_lo % 2 == 0 and lay.own_hi % 2 == 0 for lay in lays)             # packed pairs stay together
+            sizes = [lay.own_hi - lay.own_lo for lay in lays]
+            assert max(sizes) - min(sizes) <= n // r1                                             # balanced to one row of the first radix
+            if meta["resampled"]:
+                assert lays[0].in_lo == 0 and lays[-1].in_hi == n0
+                assert all(lays[i].in_hi == lays[i + 1].in_lo for i in range(world - 1))
+                # the input rows are the same share of the capture as the output rows
+                assert all(abs((lay.in_hi - lay.in_lo) / n0 - (lay.own_hi - lay.own_lo) / n) < 1e-12 for lay in lays)
+            else:   # the notch needs 24 + 2 samples beyond the own range: the slice carries 32, clipped at the capture's ends
+                assert all(lay.in_lo == max(0, lay.own_lo - 32) and lay.in_hi == min(n0, lay.own_hi + 32) for lay in lays)
         nat.shard_dry_run(p, world)          # raises if two ends of a message disagree, a receive leaves its buffer, ...
+
+
+def _wire_total(p, world, only=None):
+    return sum(e["bytes"] for e in nat.shard_wire_plan(p, world) if only is None or only(e["name"]))
+
+
+def test_columns_layout_halves_the_bytes_on_the_wire():
+    """BASELINE configs[3] behind the front end (57.6 M samples at 16 kHz -> 39.69 M at 11 025 Hz) on 8 ranks: the rows layout of
+    rounds 2-3 moves eight array transposes (2 x 461 + 6 x 317.5 MB, 7/8 of each over the links), the columns layout four
+    (461 + 3 x 317.5 MB) plus two halo exchanges of a few hundred KB -- asserted from the plan's own exchange lists (no GPU)."""
+    n0, n = 57600000, 39690000
+    rows, _ = build_params(2, n0, 16000, 0.5, n_out=n, shard_plan=sharded.plan_code("rows"))
+    cols, _ = build_params(2, n0, 16000, 0.5, n_out=n, shard_plan=sharded.plan_code("dist"))
+    a_f, a_h = 16 * (n0 // 2), 16 * (n // 2)                     # bytes of the resampler's forward array and of the 11 025 Hz arrays
+    for world in (2, 4, 8):
+        wr, wc = nat.shard_wire_plan(rows, world), nat.shard_wire_plan(cols, world)
+        names_c = [e["name"] for e in wc]
+        assert names_c == ["resample fwd E2", "resample inv E3", "resample inv halo", "hilbert E2", "hilbert E3", "hilbert halo",
+                           "select level 0", "select level 1", "select candidates", "stream gather"]
+        assert [e["name"] for e in wr][:8] == ["resample fwd E1", "resample fwd E2", "resample inv E3", "resample inv E4", "hilbert E1", "hilbert E2",
+                                               "hilbert E3", "hilbert E4"]
+        tr = _wire_total(rows, world, lambda nm: " E" in nm)
+        tc = _wire_total(cols, world, lambda nm: " E" in nm)
+        share = (world - 1) / world
+        assert abs(tr - share * (2 * a_f + 6 * a_h)) <= 0.002 * tr          # (column ranges are multiples of four: not exactly 1 / world)
+        assert abs(tc - share * (a_f + 3 * a_h)) <= 0.002 * tc
+        halo = _wire_total(cols, world, lambda nm: nm.endswith("halo"))
+        assert halo <= world * 225 * (16 + 16 + 2 + 2) * 16
+        total_r, total_c = _wire_total(rows, world), _wire_total(cols, world)
+        assert total_c <= 0.52 * total_r
+        by = {e["name"]: e for e in wc}
+        # a transpose puts array / world^2 on every directed link
+        assert abs(by["hilbert E2"]["max_link_bytes"] - a_h / world ** 2) <= 0.10 * a_h / world ** 2        # (the k1 sets differ by a unit or two)
+    assert _wire_total(cols, 8) <= 1.31e9 and _wire_total(rows, 8) >= 2.5e9
+
+
+def test_the_cost_model_declines_a_distributed_plan_that_would_lose(monkeypatch):
+    """shard_plan 0 (the default): with 50 GB/s links two ranks would spend longer exchanging configs[3]'s arrays than one GPU
+    needs for the whole decode -- the single plan is taken and says why; eight ranks get the distributed (columns) plan; links
+    that are fast enough flip the choice; the caller can force either."""
+    n0, n = 57600000, 39690000
+    monkeypatch.delenv("WFX_LINK_GBS", raising=False)
+    p, _ = build_params(2, n0, 16000, 0.5, n_out=n)
+    lay2, lay8 = nat.shard_layout(p, 2, 0), nat.shard_layout(p, 8, 0)
+    assert lay2.plan == 0 and lay2.plan_forced == 0 and lay2.plan_reason.decode().startswith("cost model")
+    assert lay2.model_dist_compute_s + lay2.model_dist_wire_s > lay2.model_single_s > 0
+    assert (lay2.own_lo, lay2.own_hi) == (0, n) and nat.shard_layout(p, 2, 1).own_samples == 0
+    assert lay8.plan == 2 and lay8.model_dist_compute_s + lay8.model_dist_wire_s < lay8.model_single_s
+    assert 1.2e9 < lay8.model_wire_bytes < 1.35e9
+    monkeypatch.setenv("WFX_LINK_GBS", "400")
+    assert nat.shard_layout(p, 2, 0).plan == 2
+    monkeypatch.delenv("WFX_LINK_GBS")
+    forced, _ = build_params(2, n0, 16000, 0.5, n_out=n, shard_plan=sharded.plan_code("dist"))
+    assert nat.shard_layout(forced, 2, 0).plan == 2 and nat.shard_layout(forced, 2, 0).plan_forced == 1
+    single, _ = build_params(2, n0, 16000, 0.5, n_out=n, shard_plan=sharded.plan_code("single"))
+    assert nat.shard_layout(single, 8, 0).plan == 0 and nat.shard_layout(single, 8, 3).own_samples == 0
+    nat.shard_dry_run(single, 8)
+    # the 10-minute capture of configs[1]: 0.33 ms on one GPU -- only eight ranks' exchanges are short enough
+    c2, _ = build_params(0, 7166250, 11025, 0.5)
+    assert [nat.shard_layout(c2, w, 0).plan for w in (2, 4, 8)] == [0, 0, 2]
 
 
 @pytest.mark.parametrize("n0", [2 * 1000003, 1433252, 7166252, 2 * 3583126 + 2, 9000 * 2 + 2, 39690002, 2 * 104729, 600000 + 2 * 7919,
@@ -58,7 +147,7 @@ def test_any_length_at_the_native_rate_gets_a_padded_plan(n0):
     the samples of its rows that lie inside the capture (the ranks whose rows are all padding own none and still take part in
     every exchange).  The layouts tile the capture and every rank's exchange lists agree (host-only dry run).
     ODD lengths (nothing to pack: scipy's kernel has taps on every lag) take the same form with one point per sample, Kp >= 2n - 1."""
-    p, meta = build_params(0, n0, 11025, 0.5)
+    p, meta = build_params(0, n0, 11025, 0.5, shard_plan=sharded.plan_code("dist"))
     for world in (1, 2, 3, 8):
         if n0 < 40000 and world == 8:
             continue
@@ -79,9 +168,9 @@ def test_captures_without_a_distributed_form_get_the_single_plan():
                           (4000, 11025, 8),                 # too short for the world size
                           (749700, 22050, 2),               # 34 s at 22 050 Hz: a factor 17 in both transforms
                           (1440002, 48000, 3), (792000, 44100, 8)]:      # (int(11025 * (792000 / 44100)) = 197999: odd)
-        p, meta = build_params(0 if sr == 11025 else 2, n0, sr, 0.5)
+        p, meta = build_params(0 if sr == 11025 else 2, n0, sr, 0.5, shard_plan=sharded.plan_code("dist"))
         lays = [nat.shard_layout(p, world, r) for r in range(world)]
-        assert all(tuple(lay.first_radix) == (0, 0) for lay in lays)
+        assert all(tuple(lay.first_radix) == (0, 0) and lay.plan == 0 for lay in lays)
         assert (lays[0].own_lo, lays[0].own_hi, lays[0].in_lo, lays[0].in_hi) == (0, meta["n"], 0, n0)
         assert all(lay.own_lo == lay.own_hi == meta["n"] and lay.in_lo == lay.in_hi == n0 for lay in lays[1:])
         nat.shard_dry_run(p, world)
@@ -104,7 +193,7 @@ def _free_port():
 def _bootstrap_worker(rank, world, port, out_dir):
     uid = sharded.bootstrap_unique_id(rank, world, port=port, timeout=30.0, make_id=lambda: bytes(range(128)))
     # every rank also derives its own slice from the layout alone: nothing else is shared between the processes
-    p, _ = build_params(0, 1433250, 11025, 0.5)
+    p, _ = build_params(0, 1433250, 11025, 0.5, shard_plan=sharded.plan_code("rows"))
     lay = nat.shard_layout(p, world, rank)
     with open(os.path.join(out_dir, f"r{rank}"), "wb") as fh:
         fh.write(uid + int(lay.own_lo).to_bytes(8, "little") + int(lay.own_hi).to_bytes(8, "little"))
@@ -133,9 +222,11 @@ def _gloo_worker(rank, world, port, uid_port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # what a rank of the sharded decode derives on its own: its slice of the capture, of the 60-minute 48 kHz configuration
-        p, meta = build_params(0, 172800000, 48000, 0.5)
+        p, meta = build_params(0, 172800000, 48000, 0.5, shard_plan=sharded.plan_code("dist"))
         lay = nat.shard_layout(p, world, rank)
-        mine = dict(rank=rank, own=(int(lay.own_lo), int(lay.own_hi)), inp=(int(lay.in_lo), int(lay.in_hi)), radix=tuple(lay.first_radix))
+        # columns layout: the rank's columns of every row -- (first sample of its first segment, segment length, segments, stride)
+        mine = dict(rank=rank, own=(int(lay.own_lo), int(lay.own_lo + lay.own_seg_len)), inp=(int(lay.in_lo), int(lay.in_lo + lay.in_seg_len)),
+                    radix=tuple(lay.first_radix), nseg=int(lay.nseg), stride=(int(lay.own_seg_stride), int(lay.in_seg_stride)), plan=int(lay.plan))
         uid = sharded.bootstrap_unique_id(rank, world, port=uid_port, timeout=30.0, make_id=lambda: bytes(range(128)))
         mine["uid_ok"] = uid == bytes(range(128))
         everyone = [None] * world
@@ -165,8 +256,11 @@ def test_two_gloo_processes_agree_on_the_partition(tmp_path):
     g = json.load(open(os.path.join(tmp_path, "gathered.json")))
     r0, r1 = sorted(g["ranks"], key=lambda r: r["rank"])
     assert r0["uid_ok"] and r1["uid_ok"] and r0["radix"] == r1["radix"]
-    assert r0["own"][0] == 0 and r0["own"][1] == r1["own"][0] and r1["own"][1] == g["n"]
-    assert r0["inp"][0] == 0 and r0["inp"][1] == r1["inp"][0] and r1["inp"][1] == 172800000
+    # the two ranks' segments tile a row of the 11 025 Hz arrangement, and of the input's, and the rows tile the capture
+    nseg = r0["nseg"]
+    assert r0["plan"] == r1["plan"] == 2 and nseg == r1["nseg"] == r0["radix"][0] * r0["radix"][1] and r0["stride"] == r1["stride"]
+    assert r0["own"][0] == 0 and r0["own"][1] == r1["own"][0] and r1["own"][1] == r0["stride"][0] and nseg * r0["stride"][0] == g["n"]
+    assert r0["inp"][0] == 0 and r0["inp"][1] == r1["inp"][0] and r1["inp"][1] == r0["stride"][1] and nseg * r0["stride"][1] == 172800000
 
 
 def _nonce_worker(rank, world, port, nonce, uid_byte, out_dir):
@@ -226,17 +320,22 @@ CASES = {
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["dist", "rows"])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_sharded_exact_decode_equals_the_oracle_for_every_world_size(case):
+def test_sharded_exact_decode_equals_the_oracle_for_every_world_size(case, layout):
     """max |delta pixel| 0 and equal start_frame / peaks against the oracle, for 1, 2, 3 and 8 ranks; every float stage
-    bit-identical across world sizes; every rank ends with the same percentiles on its device."""
+    bit-identical across world sizes; every rank ends with the same percentiles on its device.  Both layouts of the stencil
+    stages: "dist" = the columns layout (round 4: no rows <-> columns transposes), "rows" = rounds 2-3."""
     x, sr, lpm = CASES[case]()
     if x.dtype == np.float64:
         import scipy.io.wavfile  # noqa: F401  (float wav: the oracle reads it like scipy does)
     ref = _oracle(x, sr, lpm)
     first = None
     for world in (1, 2, 3, 8):
-        r = sharded.decode_emulated(x, sr, world, lpm)
+        r = sharded.decode_emulated(x, sr, world, lpm, plan=layout)
+        assert r["plan"] == (2 if layout == "dist" else 1)
+        names = [e["name"] for e in r["wire"][0]]
+        assert ("hilbert E1" in names) == (layout == "rows") and ("hilbert halo" in names) == (layout == "dist")
         assert np.array_equal(r["digitalized"], ref["digitalized"]), f"{case} world {world}: uint8 stream differs"
         assert np.array_equal(r["digitalized"], r["digitalized_blocks"])          # the gathered stream is the ranks' blocks
         assert r["sync"]["start_frame"] == ref["start_frame"] and r["sync"]["peaks"] == [int(v) for v in ref["peaks"]]
@@ -253,6 +352,25 @@ def test_sharded_exact_decode_equals_the_oracle_for_every_world_size(case):
             for k in ("envelope", "audio", "digitalized", "image"):
                 assert np.array_equal(r[k], first[k]), f"{case}: {k} depends on the world size ({world})"
             assert r["low"] == first["low"] and r["high"] == first["high"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,layout", [("mono_11025_130s", "dist"), ("stereo_48000_30s", "dist"), ("mono_48000_30s", "rows")])
+def test_bytes_counted_by_the_communicator_equal_the_plan(case, layout):
+    """What every rank's communicator counted during a decode (wfx_comm_wire_stats: per collective, bytes to other ranks) adds up
+    to what the host-only wire plan says for that capture and world size -- the figures bench.py prints are the plan's."""
+    x, sr, lpm = CASES[case]()
+    p, _ = build_params(sharded.capture_kind(x), x.shape[0], sr, 1 / (lpm / 60), shard_plan=sharded.plan_code(layout))
+    for world in (2, 3, 8):
+        r = sharded.decode_emulated(x, sr, world, lpm, plan=layout, want=("stream",))
+        plan = nat.shard_wire_plan(p, world)
+        seen = {}
+        for rank_stats in r["wire"]:
+            for e in rank_stats:
+                seen[e["name"]] = seen.get(e["name"], 0) + e["sent"]
+        for e in plan:
+            assert seen.get(e["name"]) == e["bytes"], (world, e, seen.get(e["name"]))
+        assert len(r["wire"][0]) == len(plan)
 
 
 @pytest.mark.gpu
@@ -385,7 +503,7 @@ def test_candidate_overflow_of_the_percentile_select_is_reported_and_recovered()
     assert isinstance(ref.get("exception"), ValueError)
     comms = nat.Comm.local(2)
     ctxs = [nat.Context(0) for _ in range(2)]
-    decs = [sharded.ShardedDecoder(ctxs[r], comms[r], x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x) for r in range(2)]
+    decs = [sharded.ShardedDecoder(ctxs[r], comms[r], x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x, plan="dist") for r in range(2)]
     overflows = 0
     infos = None
     for attempt in range(5):
@@ -421,7 +539,7 @@ def test_driving_a_local_world_out_of_step_is_an_error():
     x = synth.synth_capture(11025.0, noise=0.05, seed=3, **KW130)
     comms = nat.Comm.local(2)
     ctxs = [nat.Context(0) for _ in range(2)]
-    decs = [sharded.ShardedDecoder(ctxs[r], comms[r], x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x) for r in range(2)]
+    decs = [sharded.ShardedDecoder(ctxs[r], comms[r], x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x, plan="dist") for r in range(2)]
     with pytest.raises(nat.NativeError):
         decs[0].run()                          # all phases of one rank while the other has not started: refused, not a hang
     with pytest.raises(nat.NativeError):

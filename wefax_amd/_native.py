@@ -34,7 +34,7 @@ SYMBOLS = [
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
-    "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
+    "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_wire_plan", "wfx_comm_wire_reset", "wfx_comm_wire_stats", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
     "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
     "wfx_synth_frames", "wfx_synth_capture", "wfx_decode_png", "wfx_decode_save_png", "wfx_decode_png_ex", "wfx_decode_save_png_ex", "wfx_host_alloc", "wfx_host_free",
     "wfx_decode_reload", "wfx_decode_fetch_async", "wfx_plan_padded_length", "wfx_plan_describe",
@@ -52,7 +52,7 @@ class DecodeParams(C.Structure):
         ("notch_b", C.c_double * 3),
         ("notch_a", C.c_double * 3),
         ("hilbert_mode", C.c_int),
-        ("reserved0", C.c_int),
+        ("shard_plan", C.c_int),
         ("rank_lo", C.c_uint64 * 2),
         ("rank_hi", C.c_uint64 * 2),
         ("gamma_lo", C.c_double),
@@ -113,7 +113,48 @@ class ShardLayout(C.Structure):
         ("in_hi", C.c_uint64),
         ("own_lo", C.c_uint64),
         ("own_hi", C.c_uint64),
+        ("nseg", C.c_int),
+        ("in_halo", C.c_int),
+        ("in_seg_len", C.c_uint64),
+        ("in_seg_stride", C.c_uint64),
+        ("own_seg_len", C.c_uint64),
+        ("own_seg_stride", C.c_uint64),
+        ("plan", C.c_int),
+        ("plan_forced", C.c_int),
+        ("model_single_s", C.c_double),
+        ("model_dist_compute_s", C.c_double),
+        ("model_dist_wire_s", C.c_double),
+        ("model_wire_bytes", C.c_uint64),
+        ("plan_reason", C.c_char * 160),
     ]
+
+    @property
+    def in_frames(self) -> int:
+        """Frames the rank hands over (segments with their halos, back to back)."""
+        return int(self.nseg) * (int(self.in_seg_len) + 2 * int(self.in_halo)) if self.nseg > 1 else int(self.in_hi - self.in_lo)
+
+    @property
+    def own_samples(self) -> int:
+        return int(self.nseg) * int(self.own_seg_len) if self.nseg > 1 else int(self.own_hi - self.own_lo)
+
+    def own_index(self) -> "np.ndarray":
+        """Global sample indices of the rank's own samples, in the order of its stage buffers."""
+        if self.nseg <= 1:
+            return np.arange(int(self.own_lo), int(self.own_hi), dtype=np.int64)
+        s = np.arange(int(self.nseg), dtype=np.int64)[:, None] * int(self.own_seg_stride)
+        return (int(self.own_lo) + s + np.arange(int(self.own_seg_len), dtype=np.int64)[None, :]).reshape(-1)
+
+    def in_index(self) -> "np.ndarray":
+        """Global frame indices of the frames the rank hands over (may lie outside the capture: provide anything there)."""
+        if self.nseg <= 1:
+            return np.arange(int(self.in_lo), int(self.in_hi), dtype=np.int64)
+        h = int(self.in_halo)
+        s = np.arange(int(self.nseg), dtype=np.int64)[:, None] * int(self.in_seg_stride)
+        return (int(self.in_lo) - h + s + np.arange(int(self.in_seg_len) + 2 * h, dtype=np.int64)[None, :]).reshape(-1)
+
+
+class WireEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 24), ("total_bytes", C.c_uint64), ("max_rank_bytes", C.c_uint64), ("max_link_bytes", C.c_uint64)]
 
 
 WFX_COMM_ID_BYTES = 128
@@ -199,6 +240,9 @@ def load():
     lib.wfx_comm_allgather_host.argtypes = [vp, vp, vp, vp, sz]
     lib.wfx_shard_layout_query.argtypes = [C.POINTER(DecodeParams), i, i, C.POINTER(ShardLayout)]
     lib.wfx_shard_dry_run.argtypes = [C.POINTER(DecodeParams), i]
+    lib.wfx_shard_wire_plan.argtypes = [C.POINTER(DecodeParams), i, C.POINTER(WireEntry), i]
+    lib.wfx_comm_wire_reset.argtypes = [vp]
+    lib.wfx_comm_wire_stats.argtypes = [vp, C.POINTER(WireEntry), i]
     lib.wfx_shard_create.argtypes = [vp, vp, C.POINTER(DecodeParams), C.POINTER(vp)]
     lib.wfx_shard_upload.argtypes = [vp, vp]
     lib.wfx_shard_attach.argtypes = [vp, vp]
@@ -638,6 +682,22 @@ def shard_layout(params: DecodeParams, world: int, rank: int) -> ShardLayout:
     return out
 
 
+def _wire_list(arr, n) -> list:
+    return [{"name": arr[k].name.decode(), "bytes": int(arr[k].total_bytes), "max_rank_bytes": int(arr[k].max_rank_bytes),
+             "max_link_bytes": int(arr[k].max_link_bytes)} for k in range(n)]
+
+
+def shard_wire_plan(params: DecodeParams, world: int) -> list:
+    """Host-only: the collectives of one sharded decode in order, with the bytes they put on the wire (all ranks together, the
+    busiest rank, the busiest directed link)."""
+    lib = load()
+    arr = (WireEntry * 64)()
+    n = lib.wfx_shard_wire_plan(C.byref(params), world, arr, 64)
+    if n < 0:
+        raise _global_error(lib, n)
+    return _wire_list(arr, min(n, 64))
+
+
 def shard_dry_run(params: DecodeParams, world: int):
     """Host-only consistency check of every rank's exchange lists for ``world`` ranks; raises NativeError with the reason."""
     lib = load()
@@ -665,6 +725,18 @@ class Comm:
         lib.wfx_comm_info(self.h, C.byref(w), C.byref(r), C.byref(k))
         self.world, self.rank, self.is_rccl = w.value, r.value, bool(k.value)
         self.is_shm = False
+
+    def wire_reset(self):
+        self.lib.wfx_comm_wire_reset(self.h)
+
+    def wire_stats(self) -> list:
+        """This rank's collectives since the last reset: name, bytes sent to / received from other ranks, largest message."""
+        arr = (WireEntry * 256)()
+        n = self.lib.wfx_comm_wire_stats(self.h, arr, 256)
+        out = _wire_list(arr, max(0, min(n, 256)))
+        for e in out:
+            e["sent"], e["received"], e["largest_message"] = e.pop("bytes"), e.pop("max_rank_bytes"), e.pop("max_link_bytes")
+        return out
 
     @classmethod
     def rccl(cls, ctx: "Context", unique_id: bytes, world: int, rank: int) -> "Comm":
@@ -749,8 +821,8 @@ class Shard:
     def upload(self, frames: np.ndarray):
         """``frames``: this rank's input frames [layout.in_lo, layout.in_hi)."""
         a = np.ascontiguousarray(frames)
-        if a.shape[0] != self.layout.in_hi - self.layout.in_lo:
-            raise ValueError(f"rank {self.comm.rank} needs frames [{self.layout.in_lo}, {self.layout.in_hi}), got {a.shape[0]}")
+        if a.shape[0] != self.layout.in_frames:
+            raise ValueError(f"rank {self.comm.rank} needs {self.layout.in_frames} frames ({self.layout.nseg} segment(s) from frame {self.layout.in_lo}), got {a.shape[0]}")
         self.ctx._check(self.ctx.lib.wfx_shard_upload(self.h, _ptr(a)))
 
     def attach(self, dev_ptr: int):

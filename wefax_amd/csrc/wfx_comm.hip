@@ -158,7 +158,31 @@ struct wfx_comm {
     wfx_comm_group *group = nullptr;    // local backend
     wfx_shm *shm = nullptr;             // shm backend
     int device = 0;
+    // what this rank has put on the wire since the last reset, one record per collective (counted where the collective is
+    // posted, so every transport reports the same figures)
+    std::vector<wfx_wire_entry> wire;
+    unsigned long long wire_count = 0;
+    char label[24] = {0};
 };
+
+void wfx_comm_label(wfx_comm *c, const char *name)
+{
+    if (c) snprintf(c->label, sizeof c->label, "%s", name ? name : "");
+}
+
+static void wire_record(wfx_comm *c, const char *fallback, unsigned long long sent, unsigned long long received, unsigned long long largest)
+{
+    wfx_wire_entry e;
+    memset(&e, 0, sizeof e);
+    snprintf(e.name, sizeof e.name, "%s", c->label[0] ? c->label : fallback);
+    e.total_bytes = sent;
+    e.max_rank_bytes = received;
+    e.max_link_bytes = largest;
+    if (c->wire.size() < 256) c->wire.push_back(e);
+    else c->wire[(size_t)(c->wire_count % 256)] = e;
+    ++c->wire_count;
+    c->label[0] = 0;
+}
 
 static double now_s()
 {
@@ -560,6 +584,16 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
     if (!c) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null communicator");
     for (int i = 0; i < n; ++i)
         if (list[i].peer < 0 || list[i].peer >= c->world) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "exchange: peer %d out of range", list[i].peer);
+    {
+        unsigned long long sent = 0, got = 0, big = 0;
+        for (int i = 0; i < n; ++i)
+            if (list[i].peer != c->rank) {
+                sent += list[i].send_bytes;
+                got += list[i].recv_bytes;
+                if (list[i].send_bytes > big) big = list[i].send_bytes;
+            }
+        wire_record(c, "exchange", sent, got, big);
+    }
     if (c->group) {
         local_op op;
         op.kind = 1;
@@ -593,6 +627,9 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
 int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t count)
 {
     if (!c) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null communicator");
+    // (a ring all-reduce moves 2 (W - 1) / W of the buffer out of and into every rank)
+    wire_record(c, "all-reduce", 2ull * (unsigned long long)(c->world - 1) * count * 4 / (unsigned long long)c->world,
+                2ull * (unsigned long long)(c->world - 1) * count * 4 / (unsigned long long)c->world, count * 4 / (unsigned long long)c->world);
     if (c->group) {
         local_op op;
         op.kind = 2;
@@ -608,6 +645,7 @@ int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t coun
 int wfx_comm_allgather(wfx_comm *c, wfx_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank)
 {
     if (!c) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null communicator");
+    wire_record(c, "all-gather", (unsigned long long)(c->world - 1) * bytes_per_rank, (unsigned long long)(c->world - 1) * bytes_per_rank, bytes_per_rank);
     if (c->group) {
         local_op op;
         op.kind = 3;
@@ -931,6 +969,22 @@ int wfx_comm_selftest(wfx_comm *comm, wfx_ctx *ctx, int rounds, uint64_t seed)
                     return wfx_fail(ctx, WFX_ERR_COMM, "selftest round %d: all-gather block of rank %d arrived wrong on rank %d", round, r, me);
     }
     return 0;
+}
+
+int wfx_comm_wire_reset(wfx_comm *comm)
+{
+    if (!comm) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null communicator");
+    comm->wire.clear();
+    comm->wire_count = 0;
+    return 0;
+}
+
+int wfx_comm_wire_stats(wfx_comm *comm, wfx_wire_entry *out, int cap)
+{
+    if (!comm) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null communicator");
+    const int n = (int)comm->wire.size();
+    for (int i = 0; i < n && i < cap && out; ++i) out[i] = comm->wire[(size_t)i];
+    return (int)(comm->wire_count < 0x7fffffffull ? comm->wire_count : 0x7fffffffull);
 }
 
 int wfx_comm_info(wfx_comm *comm, int *world, int *rank, int *is_rccl)

@@ -53,14 +53,26 @@ class wfx_dist {
     int init(wfx_ctx *ctx, const wfx_dist_geom &g, long long L, int elem_bytes_in, int halo_before, int halo_after, bool dry = false,
              unsigned long long dry_base = 0);
     void release();
+    void set_tag(const char *t) { snprintf(tag_, sizeof tag_, "%s", t); }        // names this transform's exchanges in the wire statistics
+    const char *tag() const { return tag_; }
     // (for the dry run) exchange e in 1..4: its messages and its copy pieces; the buffers as (base, bytes) pairs
-    const std::vector<wfx_xfer> &xfers(int e) const { return e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : x4; }
-    const std::vector<wfx_dist_piece> &pieces(int e) const { return e == 1 ? p1 : e == 2 ? p_none : e == 3 ? p3 : p4; }
+    const std::vector<wfx_xfer> &xfers(int e) const { return e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : e == 4 ? x4 : xh; }
+    const std::vector<wfx_dist_piece> &pieces(int e) const { return e == 1 ? p1 : e == 2 ? p_none : e == 3 ? p3 : e == 4 ? p4 : ph; }
     const std::vector<mr_qmap> &first_pass_map() const { return qmap; }
     void buffers(std::vector<std::pair<unsigned long long, unsigned long long>> &out) const;
     // rows_in: this rank's rows of the forward input; rows_out: [halo_before + nr M + halo_after] points delivered by the
     // inverse; inv_in: slab buffer (0 / 1) the inverse starts from.  Call once the buffers exist, before the first run.
     int bind(const void *rows_in, cplx *rows_out, int inv_in);
+    // COLUMNS mode (round 4): the stages around the transform live in the columns layout too, so E1 and E4 do not exist.
+    //   cols_in : this rank's w columns of every row n1, rows `in_rs` elements (of elem_bytes_in) apart: the first pass reads them
+    //             in place
+    //   cols_out: rows of [halo_before | w own points | halo_after], `out_rs` points apart: the last inverse pass writes the own
+    //             points of row n1 at cols_out + n1 out_rs + halo_before, inv_pass1_halo_exchange then fetches the halos from the
+    //             neighbouring ranks' columns -- the points before (n1, cols[r]) are the last columns of row n1 on rank r - 1, or,
+    //             on rank 0, of row n1 - 1 on the last rank (circular: both transforms are cyclic); likewise behind
+    // Either pointer may be null when that direction is not used.
+    int bind_cols(const void *cols_in, long long in_rs, cplx *cols_out, long long out_rs, int inv_in);
+    bool cols_mode() const { return cols_; }
     // slab buffer index in which fwd_slab leaves the spectrum
     int fwd_result_index() const { return (int)(d_fwd.size() & 1); }
 
@@ -82,6 +94,10 @@ class wfx_dist {
     int inv_slab_exchange(wfx_comm *c, cplx *slab_in);                             // passes np..2, E3
     int inv_pass1_exchange(wfx_comm *c, cplx *rows_out);                           // unpack, pass 1, E4 (halo pieces land in rows_out directly)
     int inv_unpack(cplx *rows_out);                                                // rows_out: [halo_before + nr M + halo_after]
+    int inv_pass1_halo_exchange(wfx_comm *c);                                      // columns mode: unpack E3, pass 1, the halo exchange
+    int inv_halo_unpack();                                                         // columns mode: received halo columns into their rows
+    // bytes this rank sends to OTHER ranks in exchange e (1..4; 5 = the halo exchange of the columns mode): the wire model's input
+    unsigned long long wire_bytes(int e) const;
     cplx *slab_buffer(int i) { return (cplx *)(i ? b_a2.p : b_a.p); }
 
   private:
@@ -94,7 +110,16 @@ class wfx_dist {
     std::vector<mr_pass_desc> d_fwd, d_inv;
     std::vector<size_t> tw_fwd, tw_inv;
     size_t tw_last = 0;
-    wfx_devbuf tables, b_pack, b_recv, b_y, b_a, b_a2, b_desc;
+    wfx_devbuf tables, b_pack, b_recv, b_y, b_a, b_a2, b_desc, b_halo;
+    char tag_[16] = "transform";
+    void label(wfx_comm *c, const char *e) const;
+    bool cols_ = false;
+    long long in_rs_ = 0, out_rs_ = 0;
+    std::vector<wfx_xfer> xh;                       // columns mode: the halo exchange
+    std::vector<wfx_dist_piece> ph;                 // its packing pieces [0, nph_pack) and unpacking pieces behind them
+    int nph_pack = 0;
+    size_t oh = 0;
+    cplx *cols_out_ = nullptr;
     cplx *inv_result = nullptr, *inv_start = nullptr;
     // exchange lists and piece descriptors (device copies in b_desc)
     std::vector<wfx_xfer> x1, x2, x3, x4;

@@ -132,6 +132,8 @@ int wfx_dist_copy2d(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces,
         WFX_LAUNCH(ctx, K_DIST_COPY, dist_copy2d_kernel<double>, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
     else if (elem_bytes == 4)
         WFX_LAUNCH(ctx, K_DIST_COPY, dist_copy2d_kernel<unsigned>, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
+    else if (elem_bytes == 2)
+        WFX_LAUNCH(ctx, K_DIST_COPY, dist_copy2d_kernel<unsigned short>, dim3(copy_grid(max_elems), npieces), dim3(256), dev_pieces);
     else
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "copy2d: element size %d", elem_bytes);
     return 0;
@@ -149,13 +151,21 @@ int wfx_dist_scatter_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npiec
 // ---- one distributed transform length -------------------------------------------------------------------
 void wfx_dist::buffers(std::vector<std::pair<unsigned long long, unsigned long long>> &out) const
 {
-    const wfx_devbuf *bufs[] = {&b_pack, &b_recv, &b_y, &b_a, &b_a2};
-    for (const wfx_devbuf *b : bufs) out.emplace_back((unsigned long long)b->p, (unsigned long long)b->cap);
+    const wfx_devbuf *bufs[] = {&b_pack, &b_recv, &b_y, &b_a, &b_a2, &b_halo};
+    for (const wfx_devbuf *b : bufs)
+        if (b->p) out.emplace_back((unsigned long long)b->p, (unsigned long long)b->cap);
+}
+
+void wfx_dist::label(wfx_comm *c, const char *e) const
+{
+    char b[24];
+    snprintf(b, sizeof b, "%.15s %s", tag_, e);
+    wfx_comm_label(c, b);
 }
 
 void wfx_dist::release()
 {
-    wfx_devbuf *bufs[] = {&tables, &b_pack, &b_recv, &b_y, &b_a, &b_a2, &b_desc};
+    wfx_devbuf *bufs[] = {&tables, &b_pack, &b_recv, &b_y, &b_a, &b_a2, &b_desc, &b_halo};
     for (wfx_devbuf *b : bufs) {
         if (b->p && !dry_) (void)hipFree(b->p);
         b->p = nullptr;
@@ -251,7 +261,10 @@ int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int ele
     tw_last = off;
     off += wfx_mr_table_elems(L);
     const size_t colsz = (size_t)R1 * w, rowsz = (size_t)nr * M, slab = (size_t)M * B;
+    const size_t halosz = (size_t)R1 * (size_t)(hb + ha) * 2 * sizeof(cplx) + 64;      // columns mode: halo columns out and in
     if (dry) {
+        b_halo.p = (void *)(dry_base + (8ull << 36));
+        b_halo.cap = halosz;
         wfx_devbuf *bufs[] = {&b_pack, &b_recv, &b_y, &b_a, &b_a2};
         const size_t caps[] = {std::max(colsz, rowsz) * sizeof(cplx) + 64, std::max(colsz, rowsz) * sizeof(cplx) + 64, colsz * sizeof(cplx) + 64,
                                slab * sizeof(cplx) + 64, slab * sizeof(cplx) + 64};
@@ -286,6 +299,7 @@ int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int ele
     WFX_TRY(wfx_reserve(ctx, b_y, colsz * sizeof(cplx) + 64));
     WFX_TRY(wfx_reserve(ctx, b_a, slab * sizeof(cplx) + 64));
     WFX_TRY(wfx_reserve(ctx, b_a2, slab * sizeof(cplx) + 64));
+    WFX_TRY(wfx_reserve(ctx, b_halo, halosz));
     last_rows_in = nullptr;
     last_rows_out = nullptr;
     return 0;
@@ -298,15 +312,16 @@ void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
     const size_t ES = (size_t)es_in;
     char *pack = (char *)b_pack.p, *recv = (char *)b_recv.p;
     cplx *Y = (cplx *)b_y.p, *A = (cplx *)b_a.p;
-    x1.clear(); x2.clear(); x3.clear(); x4.clear();
-    p1.clear(); p3.clear(); p4.clear();
+    x1.clear(); x2.clear(); x3.clear(); x4.clear(); xh.clear();
+    p1.clear(); p3.clear(); p4.clear(); ph.clear();
+    nph_pack = 0;
     qmap.assign(R1, mr_qmap{0, 0});
     // one rank: the rows ARE the columns, so the first pass reads the caller's rows and the last inverse pass writes the caller's
     // output directly; the exchanges E1 / E4 then carry nothing but the (self) halo copies
-    pass1_src = W == 1 ? rows_in : (const void *)recv;
-    pass_last_dst = (W == 1 && rows_out) ? rows_out + hb : (cplx *)pack;
+    pass1_src = (W == 1 || cols_) ? rows_in : (const void *)recv;
+    pass_last_dst = ((W == 1 || cols_) && rows_out) ? rows_out + hb : (cplx *)pack;
     // E1: rows -> columns
-    if (rows_in && W > 1) {
+    if (rows_in && W > 1 && !cols_) {
         size_t off = 0;
         for (int d = 0; d < W; ++d) {
             const long long wd = cols[d + 1] - cols[d];
@@ -383,8 +398,58 @@ void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
             if (e != me) off += (size_t)w * km.B;
         }
     }
+    // columns mode: no E4 -- the rows stay where the last pass wrote them (rows_out + q out_rs + hb) and only the halo columns
+    // travel: my last hb own columns of every row to the rank on my right (its "before" halo), my first ha own columns to the
+    // rank on my left (its "after" halo); across the wrap (last rank -> rank 0 and back) the rows shift by one, circularly
+    if (rows_out && cols_ && (hb > 0 || ha > 0)) {
+        cplx *X = rows_out;                                           // row q at X + q out_rs: [hb | w | ha]
+        cplx *H = (cplx *)b_halo.p;
+        cplx *sendR = H, *sendL = H + (size_t)R1 * hb, *recvL = H + (size_t)R1 * (hb + ha), *recvR = recvL + (size_t)R1 * hb;
+        const int right = (me + 1) % W, left = (me + W - 1) % W;
+        auto piece = [&](const cplx *src, cplx *dst, int rows, int cols_n, long long src_rs, long long dst_rs) {
+            wfx_dist_piece p{};
+            p.src = (unsigned long long)src;
+            p.dst = (unsigned long long)dst;
+            p.rows = rows;
+            p.cols = cols_n;
+            p.src_rs = src_rs;
+            p.dst_rs = dst_rs;
+            if (rows > 0 && cols_n > 0) ph.push_back(p);
+        };
+        if (hb > 0) {                                                 // sendR[q] = my row q (the last rank: row q - 1, circularly)
+            const cplx *src = X + hb + (w - hb);
+            if (me == W - 1) {
+                piece(src, sendR + hb, R1 - 1, hb, out_rs_, hb);
+                piece(src + (size_t)(R1 - 1) * out_rs_, sendR, 1, hb, out_rs_, hb);
+            } else
+                piece(src, sendR, R1, hb, out_rs_, hb);
+        }
+        if (ha > 0) {                                                 // sendL[q] = my row q (rank 0: row q + 1, circularly)
+            const cplx *src = X + hb;
+            if (me == 0) {
+                piece(src + out_rs_, sendL, R1 - 1, ha, out_rs_, ha);
+                piece(src, sendL + (size_t)(R1 - 1) * ha, 1, ha, out_rs_, ha);
+            } else
+                piece(src, sendL, R1, ha, out_rs_, ha);
+        }
+        nph_pack = (int)ph.size();
+        if (hb > 0) piece(recvL, X, R1, hb, hb, out_rs_);
+        if (ha > 0) piece(recvR, X + hb + w, R1, ha, ha, out_rs_);
+        const size_t nbR = (size_t)R1 * hb * sizeof(cplx), nbL = (size_t)R1 * ha * sizeof(cplx);
+        if (W == 1) {                                                 // (a rank's message to itself: send and receive in one entry)
+            if (nbR) xh.push_back(wfx_xfer{me, sendR, nbR, recvL, nbR});
+            if (nbL) xh.push_back(wfx_xfer{me, sendL, nbL, recvR, nbL});
+        } else {
+            // send-only and receive-only entries: the k-th send to a peer meets the k-th receive posted for it, and with two ranks
+            // both neighbours are the same peer -- "to the right" goes first on every rank, so "from the left" is received first
+            if (nbR) xh.push_back(wfx_xfer{right, sendR, nbR, nullptr, 0});
+            if (nbL) xh.push_back(wfx_xfer{left, sendL, nbL, nullptr, 0});
+            if (nbR) xh.push_back(wfx_xfer{left, nullptr, 0, recvL, nbR});
+            if (nbL) xh.push_back(wfx_xfer{right, nullptr, 0, recvR, nbL});
+        }
+    }
     // E4: [R1][w] rows -> own rows [nr][M] with a halo of hb points before and ha points after (circular)
-    if (rows_out) {
+    if (rows_out && !cols_) {
         cplx *X = pass_last_dst;                                     // output of the last inverse pass
         size_t off = 0;
         auto overlap = [&](int d, long long lo, long long hi, long long &a, long long &b) {
@@ -453,7 +518,7 @@ void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
 
 int wfx_dist::upload_pieces()
 {
-    const size_t n = p1.size() + p3.size() + p4.size();
+    const size_t n = p1.size() + p3.size() + p4.size() + ph.size();
     oq = (n * sizeof(wfx_dist_piece) + 255) / 256 * 256;
     WFX_TRY(wfx_reserve(ctx, b_desc, oq + qmap.size() * sizeof(mr_qmap) + 256));
     std::vector<wfx_dist_piece> all;
@@ -463,6 +528,8 @@ int wfx_dist::upload_pieces()
     all.insert(all.end(), p3.begin(), p3.end());
     o4 = all.size();
     all.insert(all.end(), p4.begin(), p4.end());
+    oh = all.size();
+    all.insert(all.end(), ph.begin(), ph.end());
     WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));               // kernels of an earlier run may still read the old descriptors
     if (n) WFX_HIP(ctx, hipMemcpy(b_desc.p, all.data(), n * sizeof(wfx_dist_piece), hipMemcpyHostToDevice));
     WFX_HIP(ctx, hipMemcpy((char *)b_desc.p + oq, qmap.data(), qmap.size() * sizeof(mr_qmap), hipMemcpyHostToDevice));
@@ -472,6 +539,19 @@ int wfx_dist::upload_pieces()
 
 // rows_in: this rank's rows of the forward transform's input; rows_out: where the inverse delivers [hb + nr M + ha] points;
 // inv_in: the slab buffer (0 / 1) the inverse passes start from.  Either pointer may be null when that direction is not used.
+int wfx_dist::bind_cols(const void *cols_in, long long in_rs, cplx *cols_out, long long out_rs, int inv_in)
+{
+    if (cols_out && out_rs < (long long)hb + w + ha) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: output rows of %lld points do not hold %d + %d + %d", out_rs, hb, w, ha);
+    if (cols_in && in_rs < w) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: input rows of %lld elements do not hold %d columns", in_rs, w);
+    cols_ = true;
+    in_rs_ = in_rs;
+    out_rs_ = out_rs;
+    cols_out_ = cols_out;
+    d_first.in_rs = cols_in ? in_rs : 0;
+    d_last.out_rs = cols_out ? out_rs : 0;
+    return bind(cols_in, cols_out, inv_in);
+}
+
 int wfx_dist::bind(const void *rows_in, cplx *rows_out, int inv_in)
 {
     // the inverse slab passes ping-pong between the two slab buffers: where they end is where E3 sends from
@@ -493,6 +573,7 @@ int wfx_dist::fwd_pack_exchange(wfx_comm *c, const void *rows_in)
     // rows nobody owns are zero padding: the first pass reads them from the receive buffer, which other exchanges have used since
     if (g.world > 1 && g.rows_used < g.R1)
         WFX_HIP(ctx, hipMemsetAsync((char *)b_recv.p + (size_t)g.rows_used * w * es_in, 0, (size_t)(g.R1 - g.rows_used) * w * es_in, ctx->stream));
+    label(c, "E1");
     return wfx_comm_exchange(c, ctx, x1.data(), (int)x1.size());
 }
 
@@ -501,6 +582,7 @@ int wfx_dist::fwd_pass1_exchange(wfx_comm *c, int in_mode)
     const cplx *tb = (const cplx *)tables.p;
     // P = 1: no twiddle is read; the outputs go straight to where E2 sends them from (d_first.qmap), b_y is not written
     WFX_TRY(wfx_mr_launch_pair(ctx, d_first, tb, in_mode, 0, 0, pass1_src, (cplx *)b_y.p));
+    label(c, "E2");
     return wfx_comm_exchange(c, ctx, x2.data(), (int)x2.size());
 }
 
@@ -539,6 +621,7 @@ int wfx_dist::inv_slab_exchange(wfx_comm *c, cplx *slab_in)
         WFX_TRY(wfx_mr_launch(ctx, d_inv[i], tb + tw_inv[i], 0, 0, 1, src, dst));
         std::swap(src, dst);
     }
+    label(c, "E3");
     return wfx_comm_exchange(c, ctx, x3.data(), (int)x3.size());
 }
 
@@ -549,7 +632,39 @@ int wfx_dist::inv_pass1_exchange(wfx_comm *c, cplx *rows_out)
     WFX_TRY(wfx_dist_scatter_k(ctx, dp + o3, (int)p3.size(), w));
     const cplx *tb = (const cplx *)tables.p;
     WFX_TRY(wfx_mr_launch_pair(ctx, d_last, tb + tw_last, 0, 0, 1, b_y.p, pass_last_dst));
+    label(c, "E4");
     return wfx_comm_exchange(c, ctx, x4.data(), (int)x4.size());
+}
+
+int wfx_dist::inv_pass1_halo_exchange(wfx_comm *c)
+{
+    if (!cols_ || !cols_out_ || cols_out_ != last_rows_out || !b_desc.p) return wfx_fail(ctx, WFX_ERR_STATE, "distributed transform: output columns not bound");
+    const wfx_dist_piece *dp = (const wfx_dist_piece *)b_desc.p;
+    WFX_TRY(wfx_dist_scatter_k(ctx, dp + o3, (int)p3.size(), w));
+    const cplx *tb = (const cplx *)tables.p;
+    WFX_TRY(wfx_mr_launch_pair(ctx, d_last, tb + tw_last, 0, 0, 1, b_y.p, pass_last_dst));
+    long long mx = 0;
+    for (int i = 0; i < nph_pack; ++i) mx = std::max(mx, (long long)ph[i].rows * ph[i].cols);
+    WFX_TRY(wfx_dist_copy2d(ctx, dp + oh, nph_pack, mx, 16));
+    label(c, "halo");
+    return wfx_comm_exchange(c, ctx, xh.data(), (int)xh.size());
+}
+
+int wfx_dist::inv_halo_unpack()
+{
+    if (!cols_ || !b_desc.p) return wfx_fail(ctx, WFX_ERR_STATE, "distributed transform: output columns not bound");
+    const wfx_dist_piece *dp = (const wfx_dist_piece *)b_desc.p;
+    long long mx = 0;
+    for (size_t i = nph_pack; i < ph.size(); ++i) mx = std::max(mx, (long long)ph[i].rows * ph[i].cols);
+    return wfx_dist_copy2d(ctx, dp + oh + nph_pack, (int)ph.size() - nph_pack, mx, 16);
+}
+
+unsigned long long wfx_dist::wire_bytes(int e) const
+{
+    unsigned long long t = 0;
+    for (const wfx_xfer &x : xfers(e))
+        if (x.peer != g.rank) t += x.send_bytes;
+    return t;
 }
 
 int wfx_dist::inv_unpack(cplx *rows_out)

@@ -896,6 +896,117 @@ int wfx_dev_env_median_block(wfx_ctx *ctx, const cplx *V_global, const double *x
     return 0;
 }
 
+// The same for one rank's COLUMNS of a sharded capture (round 4): nseg segments of seg_len samples (even), segment s holding the
+// global samples [g0 + s g_stride, + seg_len).  V rows (pairs; row s at V + s v_rs, the segment's first pair at index 0, valid
+// from -1 to seg_len / 2 + 1) and x rows (samples; row s at x + s x_rs, valid from -2 to seg_len + 1) carry the halos the
+// neighbouring ranks' columns delivered; zeros beyond the capture's true ends as in the reference.  env: dense [nseg][seg_len].
+__global__ void __launch_bounds__(256) hconv_env_median_segs(const cplx *__restrict__ V, long long v_rs, const double *__restrict__ x, long long x_rs, int nseg,
+                                                            int seg_len, long long g0, long long g_stride, long long N, double *__restrict__ env,
+                                                            unsigned *__restrict__ l0hist)
+{
+    __shared__ double tile[1024 + 8];
+    __shared__ unsigned h0[WFX_SEL_BINS];
+    const int t = threadIdx.x;
+    unsigned run_digit = 0, run_count = 0;
+    if (l0hist)
+        for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
+    const int tps = (seg_len + 1023) >> 10;                                  // tiles per segment
+    const long long ntiles = (long long)nseg * tps;
+    const int mhi = seg_len / 2 + 1, xhi = seg_len + 1;                      // last valid pair / sample index of a row
+    cplx pv[3];
+    double px0[3], px1[3];
+    auto prefetch = [&](long long tix) {
+        const int s = (int)(tix / tps), base = (int)(tix - (long long)s * tps) << 10;
+        const cplx *Vs = V + (long long)s * v_rs;
+        const double *xs = x + (long long)s * x_rs;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int m = base / 2 - 1 + t + 256 * k;                       // pair (2m - 1, 2m), local
+            const int mc = m > mhi ? mhi : m;                               // (m >= -1 always)
+            const int i1 = 2 * m, i0 = 2 * m - 1;
+            pv[k] = Vs[mc];
+            px0[k] = xs[i0 < -2 ? -2 : (i0 > xhi ? xhi : i0)];
+            px1[k] = xs[i1 > xhi ? xhi : i1];
+        }
+    };
+    long long tix = blockIdx.x;
+    if (tix < ntiles) prefetch(tix);
+    for (; tix < ntiles; tix += gridDim.x) {
+        const int s = (int)(tix / tps), base = (int)(tix - (long long)s * tps) << 10;
+        const long long gseg = g0 + (long long)s * g_stride;                // global index of the segment's sample 0
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int mi = t + 256 * k;
+            const int m = base / 2 - 1 + mi;
+            const int i1 = 2 * m, i0 = 2 * m - 1;
+            const long long q0 = gseg + i0, q1 = gseg + i1;
+            const double e0 = (q0 >= 0 && q0 < N && i0 <= xhi) ? env_abs(px0[k], pv[k].y) : 0.0;
+            const double e1 = (q1 >= 0 && q1 < N && i1 <= xhi) ? env_abs(px1[k], pv[k].x) : 0.0;
+            if (mi < 515) {
+                if (mi > 0) tile[2 * mi - 1] = e0;
+                if (mi < 514) tile[2 * mi] = e1;
+            }
+        }
+        __syncthreads();
+        if (tix + gridDim.x < ntiles) prefetch(tix + gridDim.x);
+        double *eo = env + (long long)s * seg_len;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = 2 * t + 512 * u;
+            const double w0 = tile[j], w1 = tile[j + 1], w2 = tile[j + 2], w3 = tile[j + 3], w4 = tile[j + 4], w5 = tile[j + 5];
+            double r[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double a = h ? w1 : w0, b = h ? w2 : w1, c = h ? w3 : w2, d = h ? w4 : w3, e = h ? w5 : w4;
+                cswap_d(a, b);
+                cswap_d(d, e);
+                cswap_d(a, d);
+                cswap_d(b, e);
+                cswap_d(b, c);
+                cswap_d(c, d);
+                cswap_d(b, c);
+                r[h] = c;
+            }
+            if (base + j + 1 < seg_len)
+                *(double2 *)(eo + base + j) = make_double2(r[0], r[1]);      // (seg_len and base + j are even: 16-byte aligned)
+            else if (base + j < seg_len)
+                eo[base + j] = r[0];
+            if (l0hist) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (base + j + h >= seg_len) continue;
+                    const unsigned dg = (unsigned)(wfx_f64_key(r[h]) >> 53);
+                    if (dg == run_digit)
+                        ++run_count;
+                    else {
+                        if (run_count) atomicAdd(&h0[run_digit], run_count);
+                        run_digit = dg;
+                        run_count = 1;
+                    }
+                }
+            }
+        }
+    }
+    if (l0hist) {
+        if (run_count) atomicAdd(&h0[run_digit], run_count);
+        __syncthreads();
+        for (int i = t; i < WFX_SEL_BINS; i += 256)
+            if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
+    }
+}
+
+int wfx_dev_env_median_segs(wfx_ctx *ctx, const cplx *V_rows, long long v_rs, const double *x_rows, long long x_rs, int nseg, int seg_len, long long g0,
+                            long long g_stride, uint64_t n_total, double *env, unsigned *l0hist)
+{
+    if (nseg < 1 || seg_len < 2 || (seg_len & 1)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "envelope segments of %d samples", seg_len);
+    const long long ntiles = (long long)nseg * ((seg_len + 1023) >> 10);
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, 1024);
+    WFX_LAUNCH(ctx, K_ENV_MEDIAN, hconv_env_median_segs, dim3(grid), dim3(256), V_rows, v_rs, x_rows, x_rs, nseg, seg_len, g0, g_stride, (long long)n_total, env,
+               l0hist);
+    return 0;
+}
+
 // One rank's block [s0, s1) of a sharded capture of ODD length: one point per sample, V[n].x = H[n].  V and x are indexed by
 // global sample index and valid two samples beyond the block on either side; zeros beyond the capture's true ends.
 __global__ void __launch_bounds__(256) hconv_env_median_block_plain(const cplx *__restrict__ V, const double *__restrict__ x, long long N, long long s0,

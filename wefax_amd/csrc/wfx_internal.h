@@ -139,6 +139,10 @@ struct mr_pass_desc {
     // OUT_MODE 4 multiplies output o by gtab[o] (the transformed kernel)
     long long in_len;
     const double2 *gtab;
+    // pair passes of a distributed transform whose neighbours live in the columns layout (wfx_dist.hip, round 4): the first pass
+    // reads row m of its input at in + m * in_rs (elements) instead of m * ncol, the last inverse pass (P == ncol) writes output
+    // row q at out + q * out_rs -- rows that carry a halo between them.  0: the dense strides
+    long long in_rs, out_rs;
 };
 struct mr_qmap {
     unsigned long long base;
@@ -240,6 +244,9 @@ int wfx_dev_env_median_block_plain(wfx_ctx *ctx, const cplx *V_global, const dou
                                    unsigned *l0hist);                // odd captures: V[n].x = H[n]
 int wfx_dev_env_median_block(wfx_ctx *ctx, const cplx *V_global, const double *x_global, uint64_t n_total, uint64_t s0, uint64_t s1, double *env_block,
                              unsigned *l0hist);
+// one rank's COLUMNS: nseg segments of seg_len samples; V_rows / x_rows point at the first OWN pair / sample of row 0 (halos on both sides)
+int wfx_dev_env_median_segs(wfx_ctx *ctx, const cplx *V_rows, long long v_rs, const double *x_rows, long long x_rs, int nseg, int seg_len, long long g0,
+                            long long g_stride, uint64_t n_total, double *env, unsigned *l0hist);
 // x_is_i16: x points at int16 samples; valid only when wfx_mr_resample_supported(n0, num) (the mixed-radix form reads them in place)
 int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16 = false);
 
@@ -357,6 +364,7 @@ struct wfx_xfer {            // one message pair of a personalised exchange; sev
 int wfx_comm_world(const wfx_comm *c);
 int wfx_comm_rank(const wfx_comm *c);
 bool wfx_comm_is_local(const wfx_comm *c);
+void wfx_comm_label(wfx_comm *c, const char *name);      // names the next collective in the wire statistics (wfx_comm_wire_stats)
 int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n);
 int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t count);
 int wfx_comm_allgather(wfx_comm *c, wfx_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank);

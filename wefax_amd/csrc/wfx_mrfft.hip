@@ -597,6 +597,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
     __shared__ cplx wr[R];
     const int t = (int)threadIdx.x;
     const int ncol = (int)d.ncol, P = (int)d.P;
+    const long long in_rs = d.in_rs ? d.in_rs : (long long)ncol;  // distance between the rows of a column's R inputs
     for (int i = t; i < R; i += NT) {
         double sn, cs;
         sincospi(2.0 * (double)i / (double)R, &sn, &cs);
@@ -620,7 +621,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             const int c = item & (SW - 1), r = item / SW;
             const long long j = (long long)st * SW + c;
             short2 v = make_short2(0, 0);
-            if (r < R && j < ncol) v = ((const short2 *)in)[j + (long long)r * ncol];
+            if (r < R && j < ncol) v = ((const short2 *)in)[j + (long long)r * in_rs];
             sreg[i] = v;
         }
     };
@@ -634,7 +635,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
 #pragma unroll
             for (int a = 0; a < RA; ++a) {
                 cplx v = make_double2(0.0, 0.0);
-                const long long adr = (long long)j + (long long)(a * RB + b) * ncol;
+                const long long adr = (long long)j + (long long)(a * RB + b) * in_rs;
                 if (ok && (IN_MODE != 1 || adr < in_lim)) {
                     if (IN_MODE == 2) {
                         const short2 x2 = SUP > 1 ? stage[(a * RB + b) * SW + (tix & (SUP - 1)) * T + c] : ((const short2 *)in)[adr];
@@ -818,8 +819,11 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                     }
                     const int j = j0 + c;
                     const int k = j % P;
-                    const long long obase = (long long)(j - k) * R + k + (long long)qa * P;      // + qb * RA * P
-                    const long long ostep = (long long)RA * P;
+                    // (out_rs: the last inverse pass of a distributed transform, P == ncol -- output row q of column j goes to
+                    // j + q out_rs, rows with a halo between them)
+                    const long long orow = d.out_rs ? d.out_rs : (long long)P;
+                    const long long obase = (long long)(j - k) * R + k + (long long)qa * orow;   // + qb * RA * P
+                    const long long ostep = (long long)RA * orow;
                     cplx g0 = make_double2(0.0, 0.0);
                     long long gbase = 0;                          // global frequency index of obase (== obase unless distributed)
                     if (OUT_MODE == 1) {
@@ -959,6 +963,7 @@ static void mr_fill_pass(mr_plan_host &pl, int i, int R, int ra, int rb, long lo
     d.skip_lo = d.skip_hi = 0;
     d.in_len = 0;
     d.gtab = nullptr;
+    d.in_rs = d.out_rs = 0;
     d.ncol = pl.L / R;
     const int T = MR_TILE / R;
     int t2 = 1, l2 = 0;

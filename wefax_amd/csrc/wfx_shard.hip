@@ -19,6 +19,16 @@
 
 #include "wfx_dist.h"
 
+//
+// Round 4, the COLUMNS layout (shard_plan::cols): the stencil stages run where the transforms' first / last passes
+// leave their data -- rank r holds, of every row n1 of the [R1][M] arrangement, the columns [cols[r], cols[r+1]): R1 segments of
+// samples, each with a halo from the neighbouring ranks' columns (24 + 2 samples of audio for the notch, 2 points of the Hilbert
+// transform for the median) -- so the rows <-> columns transposes E1 and E4 of every transform disappear: 4 array transposes per
+// decode instead of 8 (2 instead of 4 without a resampler), plus two halo exchanges of a few KB.
+//   [a4 merge] [a5: first pass on the caller's columns, E2, slab passes, bin copy, slab passes, E3, last pass, HALO exchange]
+//   a6 notch on the R1 segments (one launch over the rows laid end to end; true edges on rank 0's first / the last rank's last)
+//   a7 first pass in place, E2, slab passes x spectrum, E3, last pass, HALO exchange, |x + iH| + median 5 per segment
+//   a8 as before; the gather delivers every rank's segments to rank 0, which puts them in order (one 2-D copy) -- a9, a10
 #define SH_HALO 32          // samples of audio kept beyond the own range on either side (>= 24 notch taps + 2 median)
 #define SH_VHALO 2          // points of the Hilbert transform delivered beyond the own rows
 #define SH_CAND_CAP 4096    // least number of candidate keys per query and rank that travel in the all-gather
@@ -56,7 +66,54 @@ struct shard_plan {
     int wrap_rank = 0;                    // the rank holding the capture's last pair: it needs V[0] from rank 0 as "V[K]"
     uint64_t own_lo = 0, own_hi = 0, in_lo = 0, in_hi = 0;
     uint64_t seg_lo = 0, seg_hi = 0;      // samples at 11 025 Hz held for the notch
+    // columns layout (round 4): this rank's columns of the K-point arrangement (Hilbert transform, resampler inverse) and of the
+    // M1-point one (resampler forward); hs = samples of halo on either side of a segment of audio (0 with one rank: the rows are
+    // dense and the neighbours in memory ARE the halo)
+    bool cols = false;
+    long long cH0 = 0, wH = 0, cF0 = 0, wF = 0;
+    int hs = 0;
+    long long xrs = 0;                    // samples between the starts of two rows of audio: 2 wH + 2 hs
+    // the cost model's verdict
+    int forced = 0;
+    double model_single = 0, model_comp = 0, model_wire = 0;
+    unsigned long long model_bytes = 0;
 };
+
+// ---- cost model of a sharded decode on one node -------------------------------------------------------------
+// One GPU (measured, MI355X): the exact path takes ~46 ps per 11 025 Hz sample while its arrays fit the 256 MiB Infinity Cache
+// (configs[1]: 0.33 ms), ~70 ps beyond (configs[2] / [3]), plus ~8.7 ps per input frame when a resampler runs in front.
+// N ranks: that work / N, one copy of the rank's share per surviving packing step, and the exchanges: in a transpose over N ranks
+// a rank sends array / N^2 to each peer, every peer over its own xGMI link, so an exchange takes (array / N^2) / B_link + latency.
+// B_link defaults to 50 GB/s (what grouped send / recv reaches of a link's 153 GB/s peak); WFX_LINK_GBS overrides it.
+static double link_gbs()
+{
+    const char *e = getenv("WFX_LINK_GBS");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 50.0;
+}
+
+static void plan_cost(shard_plan &pl, bool cols)
+{
+    const int W = pl.world;
+    const double n = (double)pl.n, n0 = (double)pl.n0;
+    const double per = n * 16.0 <= 256e6 ? 46e-12 : 70e-12;
+    pl.model_single = 20e-6 + per * n + (pl.resample ? 8.7e-12 * n0 : 0.0);
+    const double K16 = 16.0 * (double)pl.Kp, M16 = 16.0 * (double)pl.M1;
+    const double in_es = pl.in_kind == WFX_IN_I16_MONO ? 4.0 : 16.0;
+    // array transposes: rows layout E1..E4 per transform, columns layout E2 / E3 only
+    double arrays = cols ? 2.0 * K16 : 4.0 * K16;
+    int nex = cols ? 2 : 4, ncopy = cols ? 1 : 3;
+    if (pl.resample) {
+        arrays += cols ? (M16 + K16) : (M16 * (in_es / 16.0) + M16 + 2.0 * K16);
+        nex += cols ? 2 : 4;
+        ncopy += cols ? 1 : 3;
+    }
+    const double lat = 20e-6, bl = link_gbs() * 1e9;
+    const double small = (cols ? (pl.resample ? 2 : 1) : 0) + 3;          // halo exchanges, two all-reduces, one all-gather
+    pl.model_wire = W > 1 ? arrays / ((double)W * W) / bl + (nex + small) * lat + (n / W) / bl + lat : 0.0;
+    pl.model_comp = pl.model_single / W + ncopy * (32.0 * (double)pl.Kp / W) / 4e12 + (W > 1 ? 80e-6 : 0.0);      // + rank 0's tail: sync search, image
+    pl.model_bytes = W > 1 ? (unsigned long long)(arrays * (W - 1) / W + n * (W - 1) / W) : 0ull;
+}
 
 static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int rank, shard_plan &pl)
 {
@@ -89,6 +146,10 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         pl.seg_hi = pl.own_hi;
         return 0;
     };
+    const int want = p->shard_plan & 15;               // 0 auto, 1 distributed, 2 single
+    const bool want_rows = (p->shard_plan & 16) != 0 || getenv("WFX_SHARD_ROWS") != nullptr;
+    pl.forced = want != 0;
+    if (want == 2) return single("asked for by the caller (wfx_decode_params.shard_plan)");
     if (p->n >= (1ull << 31)) return single("2^31 samples: beyond the distributed transforms' 32-bit indices");
     if (p->resample && ((p->n & 1) || (p->n0 & 1))) return single("a resampled capture with an odd sample count (its transforms are packed)");
     pl.plain = (p->n & 1) != 0;
@@ -181,6 +242,50 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         pl.in_lo = pl.seg_lo;
         pl.in_hi = pl.seg_hi;
     }
+    // ---- columns layout: unpadded even captures (every BASELINE size); the any-length padded forms keep the rows layout ----
+    auto colrange = [&](long long M, int r, long long &c0, long long &w) {
+        c0 = (long long)r * M / world / 4 * 4;
+        const long long c1 = r + 1 == world ? M : (long long)(r + 1) * M / world / 4 * 4;
+        w = c1 - c0;
+    };
+    bool cols_ok = !want_rows && !pl.padded && !pl.plain;
+    for (int r = 0; r < world && cols_ok; ++r) {
+        long long c0, w;
+        colrange(pl.Ms, r, c0, w);
+        if (w < 128) cols_ok = false;                                          // a segment must hold the notch's edge block and its halo
+        if (pl.resample) {
+            colrange(pl.M1s, r, c0, w);
+            if (w < 4) cols_ok = false;
+        }
+    }
+    if (cols_ok) {
+        pl.cols = true;
+        colrange(pl.Ms, rank, pl.cH0, pl.wH);
+        if (pl.resample) colrange(pl.M1s, rank, pl.cF0, pl.wF);
+        pl.hs = world > 1 ? SH_HALO : 0;
+        pl.xrs = 2 * pl.wH + 2 * pl.hs;
+        pl.own_lo = 2ull * (uint64_t)pl.cH0;
+        pl.own_hi = 2ull * (uint64_t)((long long)(R1 - 1) * pl.Ms + pl.cH0 + pl.wH);
+        pl.in_lo = pl.resample ? 2ull * (uint64_t)pl.cF0 : pl.own_lo;
+        pl.in_hi = pl.resample ? 2ull * (uint64_t)((long long)(R1 - 1) * pl.M1s + pl.cF0 + pl.wF) : pl.own_hi;
+        pl.seg_lo = pl.own_lo;
+        pl.seg_hi = pl.own_hi;
+    }
+    // ---- the cost model's choice (unless the caller forced one) ----
+    plan_cost(pl, pl.cols);
+    if (want == 0 && world > 1 && pl.model_comp + pl.model_wire >= 0.97 * pl.model_single) {
+        const double ms1 = 1e3 * pl.model_single, msc = 1e3 * pl.model_comp, msw = 1e3 * pl.model_wire;
+        const unsigned long long mb = pl.model_bytes;
+        char why[160];
+        snprintf(why, sizeof why, "cost model: %d ranks %.2f ms of work + %.2f ms on the wire (%.0f GB/s links) >= one GPU's %.2f ms", world, msc, msw,
+                 link_gbs(), ms1);
+        single(why);
+        pl.model_single = 1e-3 * ms1;
+        pl.model_comp = 1e-3 * msc;
+        pl.model_wire = 1e-3 * msw;
+        pl.model_bytes = mb;
+        pl.cols = false;
+    }
     return 0;
 }
 
@@ -192,6 +297,9 @@ struct wfx_shard {
     wfx_dist dF, dI, dH;                  // resampler forward / inverse, Hilbert
     wfx_dist dHk;                         // padded form over several ranks: the kernel's transform (full rows), first decode only
     wfx_devbuf b_in, b_merged, b_res, b_audio, b_v, b_env, b_dig, b_blk, b_blks, b_nan, b_flags;
+    wfx_devbuf b_gath, b_pieces;          // columns layout, rank 0: the ranks' segments as gathered, and the 2-D copies that put them in order
+    int n_pieces = 0;
+    long long piece_max = 0;
     wfx_devbuf b_grow, b_ghat;            // padded form: this rank's rows of the kernel g_ext / Kp, and its slab of the kernel's transform
     bool ghat_ready = false;              // computed by three extra phases in front of the first decode
     // those three phases have run but the decode they belonged to has not finished (ghat_ready selects the phase numbering, so it
@@ -222,6 +330,79 @@ static void free_buf(wfx_devbuf &b)
     b.cap = 0;
 }
 
+// ---- columns layout: buffers and bindings --------------------------------------------------------------------------------
+// Audio (and, with a resampler, its input b_res) is R1 rows of xrs = 2 wH + 2 hs samples laid end to end, SH_HALO samples of
+// slack in front and behind (the envelope kernel's clamped loads reach two samples beyond a row); the own samples of row q
+// start at pad + q xrs + hs.  V: R1 rows of 2 + wH + 2 points.
+#define SH_PAD SH_HALO
+static uint64_t cols_own(const shard_plan &pl) { return (uint64_t)pl.g.R1 * 2ull * (uint64_t)pl.wH; }
+static uint64_t cols_in_frames(const shard_plan &pl)
+{
+    return pl.resample ? (uint64_t)pl.g.R1 * 2ull * (uint64_t)pl.wF : (uint64_t)pl.g.R1 * (uint64_t)pl.xrs;
+}
+
+static int shard_bind_cols(wfx_shard *sh)
+{
+    wfx_ctx *ctx = sh->ctx;
+    shard_plan &pl = sh->pl;
+    const int me = pl.rank, W = pl.world, R1 = pl.g.R1;
+    const uint64_t n_own = cols_own(pl), flat = (uint64_t)R1 * (uint64_t)pl.xrs;
+    const void *in = sh->ext_in ? sh->ext_in : sh->b_in.p;
+    WFX_TRY(wfx_reserve(ctx, sh->b_audio, (flat + 2 * SH_PAD) * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_v, (size_t)R1 * (size_t)(pl.wH + 2 * SH_VHALO) * sizeof(cplx) + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_env, n_own * 8 + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_dig, (me == 0 ? pl.n : n_own) + 64));
+    if (me == 0 && W > 1) WFX_TRY(wfx_reserve(ctx, sh->b_gath, pl.n + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_blk, wfx_select_block_bytes(sh->cap)));
+    WFX_TRY(wfx_reserve(ctx, sh->b_blks, wfx_select_block_bytes(sh->cap) * W));
+    WFX_TRY(wfx_reserve(ctx, sh->b_nan, 8 * (size_t)W + 64));
+    WFX_TRY(wfx_reserve(ctx, sh->b_flags, 64));
+    WFX_HIP(ctx, hipMemsetAsync(sh->b_flags.p, 0, 64, ctx->stream));
+    WFX_HIP(ctx, hipMemsetAsync(sh->b_nan.p, 0, 8 * (size_t)W + 64, ctx->stream));
+    if (!sh->bound) WFX_HIP(ctx, hipMemsetAsync(sh->b_audio.p, 0, (flat + 2 * SH_PAD) * 8 + 64, ctx->stream));
+    double *audio_row0 = (double *)sh->b_audio.p + SH_PAD + pl.hs;          // first own sample of row 0
+    if (pl.resample) {
+        const void *cols_in = in;
+        if (pl.in_kind == WFX_IN_I16_STEREO) {
+            WFX_TRY(wfx_reserve(ctx, sh->b_merged, cols_in_frames(pl) * 8 + 64));
+            cols_in = sh->b_merged.p;
+        }
+        WFX_TRY(wfx_reserve(ctx, sh->b_res, (flat + 2 * SH_PAD) * 8 + 64));
+        if (!sh->bound) WFX_HIP(ctx, hipMemsetAsync(sh->b_res.p, 0, (flat + 2 * SH_PAD) * 8 + 64, ctx->stream));
+        WFX_TRY(sh->dF.bind_cols(cols_in, pl.wF, nullptr, 0, 0));
+        WFX_TRY(sh->dI.bind_cols(nullptr, 0, (cplx *)((double *)sh->b_res.p + SH_PAD), pl.xrs / 2, 0));
+    } else if (pl.in_kind == WFX_IN_I16_STEREO) {
+        WFX_TRY(wfx_reserve(ctx, sh->b_merged, flat * 8 + 64));
+    }
+    WFX_TRY(sh->dH.bind_cols(audio_row0, pl.xrs / 2, (cplx *)sh->b_v.p, pl.wH + 2 * SH_VHALO, sh->dH.fwd_result_index()));
+    // rank 0: the gathered segments of every rank -> the stream in order (2-byte elements: every offset is even)
+    sh->n_pieces = 0;
+    if (me == 0 && W > 1) {
+        std::vector<wfx_dist_piece> ps;
+        unsigned long long off = 0;
+        sh->piece_max = 0;
+        for (int r = 0; r < W; ++r) {
+            const long long c0 = (long long)r * pl.Ms / W / 4 * 4, c1 = r + 1 == W ? pl.Ms : (long long)(r + 1) * pl.Ms / W / 4 * 4;
+            wfx_dist_piece q{};
+            q.src = (unsigned long long)((uint8_t *)sh->b_gath.p + off);
+            q.dst = (unsigned long long)((uint8_t *)sh->b_dig.p + 2 * c0);
+            q.rows = R1;
+            q.cols = (int)(c1 - c0);                // 2-byte elements: one per packed point
+            q.src_rs = c1 - c0;
+            q.dst_rs = pl.Ms;
+            ps.push_back(q);
+            sh->piece_max = std::max(sh->piece_max, (long long)q.rows * q.cols);
+            off += (unsigned long long)R1 * 2ull * (unsigned long long)(c1 - c0);
+        }
+        WFX_TRY(wfx_reserve(ctx, sh->b_pieces, ps.size() * sizeof(wfx_dist_piece) + 64));
+        WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        WFX_HIP(ctx, hipMemcpy(sh->b_pieces.p, ps.data(), ps.size() * sizeof(wfx_dist_piece), hipMemcpyHostToDevice));
+        sh->n_pieces = (int)ps.size();
+    }
+    sh->bound = true;
+    return 0;
+}
+
 static int shard_bind(wfx_shard *sh)
 {
     wfx_ctx *ctx = sh->ctx;
@@ -231,6 +412,7 @@ static int shard_bind(wfx_shard *sh)
         sh->bound = true;
         return 0;
     }
+    if (pl.cols) return shard_bind_cols(sh);
     const int me = pl.rank;
     const long long nr = pl.g.nrows(me);
     const uint64_t n_own = pl.own_hi - pl.own_lo, n_seg = pl.seg_hi - pl.seg_lo;
@@ -280,7 +462,131 @@ static int shard_bind(wfx_shard *sh)
 
 // ---- the phases ------------------------------------------------------------------------------------------------
 // padded form: + 1 phase (the wrap of V, see phase 8) and, in front of the first decode, + 3 (the kernel's transform)
-static int phase_count(const wfx_shard *sh) { return sh->pl.single ? 1 : sh->pl.resample ? 13 : (sh->pl.padded ? (sh->ghat_ready ? 10 : 13) : 9); }
+static int phase_count(const wfx_shard *sh)
+{
+    if (sh->pl.single) return 1;
+    if (sh->pl.cols) return sh->pl.resample ? 11 : 8;
+    return sh->pl.resample ? 13 : (sh->pl.padded ? (sh->ghat_ready ? 10 : 13) : 9);
+}
+
+// ---- the phases of the columns layout -------------------------------------------------------------------------------
+static int run_phase_cols(wfx_shard *sh, int ph)
+{
+    wfx_ctx *ctx = sh->ctx;
+    wfx_comm *c = sh->comm;
+    shard_plan &pl = sh->pl;
+    const wfx_decode_params &p = sh->dp;
+    const int me = pl.rank, W = pl.world, R1 = pl.g.R1;
+    const uint64_t n_own = cols_own(pl), flat = (uint64_t)R1 * (uint64_t)pl.xrs;
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    const void *in = sh->ext_in ? sh->ext_in : sh->b_in.p;
+    double *audio = (double *)sh->b_audio.p + SH_PAD;                       // row 0, halo included
+    double *env = (double *)sh->b_env.p;
+    uint8_t *dig_own = (me == 0 && W > 1) ? (uint8_t *)sh->b_gath.p : (uint8_t *)sh->b_dig.p;
+    if (!pl.resample) ph += 3;                                              // phases 0..2 are the resampler's
+    switch (ph) {
+    case 0: {   // a4 + a5: first pass on the caller's columns, E2
+        WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+        if (pl.in_kind == WFX_IN_I16_STEREO) WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, cols_in_frames(pl), (double *)sh->b_merged.p));
+        return sh->dF.fwd_pass1_exchange(c, pl.in_kind == WFX_IN_I16_MONO ? 2 : 0);
+    }
+    case 1: {   // spectrum -> scipy.signal.resample's bin copy -> the inverse's slab passes, E3
+        cplx *Z = nullptr;
+        const long long nmin = (long long)(pl.n0 < pl.n ? pl.n0 : pl.n), half = nmin / 2;
+        WFX_TRY(sh->dF.fwd_slab(0, &Z, half, pl.M1 - half));
+        WFX_TRY(wfx_dist_resample_glue(ctx, pl.g, Z, (long long)pl.n0, (long long)pl.n, sh->dI.slab_buffer(0)));
+        return sh->dI.inv_slab_exchange(c, sh->dI.slab_buffer(0));
+    }
+    case 2: return sh->dI.inv_pass1_halo_exchange(c);                       // the resampled audio, in columns; its halo columns
+    case 3: {   // a6 notch over the rows laid end to end, then the Hilbert transform's first pass (in place) and E2
+        const void *nin = in;
+        int nkind = pl.in_kind;
+        if (pl.resample) {
+            WFX_TRY(sh->dI.inv_halo_unpack());
+            nin = (const double *)sh->b_res.p + SH_PAD;
+            nkind = WFX_IN_F64_MONO;
+        } else {
+            WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+            if (pl.in_kind == WFX_IN_I16_STEREO) {
+                WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, flat, (double *)sh->b_merged.p));
+                nin = sh->b_merged.p;
+                nkind = WFX_IN_F64_MONO;
+            }
+        }
+        // rank 0's first row starts at the capture's true start, the last rank's last row ends at its true end: filtfilt's exact
+        // edges there; everywhere else the 49-tap form, whose outputs within 24 samples of a row's end are never read
+        const uint64_t lo = me == 0 ? (uint64_t)pl.hs : 0, hi = flat - (me == W - 1 ? (uint64_t)pl.hs : 0);
+        const int flags = (me == 0 ? 1 : 0) | (me == W - 1 ? 2 : 0);
+        double ext18[18];
+        const bool use_ext = p.has_ext && !pl.resample && pl.in_kind != WFX_IN_I16_STEREO;
+        for (int i = 0; i < 9; ++i) {
+            ext18[i] = p.ext_left[i];
+            ext18[9 + i] = p.ext_right[i];
+        }
+        const void *nin_lo = nkind == WFX_IN_I16_MONO ? (const void *)((const int16_t *)nin + lo) : (const void *)((const double *)nin + lo);
+        WFX_TRY(wfx_dev_notch_fir_only(ctx, nin_lo, nkind, hi - lo, p.notch_b, p.notch_a, audio + lo, flags, use_ext ? ext18 : nullptr));
+        return sh->dH.fwd_pass1_exchange(c, 1);
+    }
+    case 4: {
+        cplx *G = nullptr;
+        WFX_TRY(sh->dH.fwd_slab(1, &G));
+        return sh->dH.inv_slab_exchange(c, G);
+    }
+    case 5: return sh->dH.inv_pass1_halo_exchange(c);
+    case 6: {   // a7 envelope + median per segment, level-0 histogram; first all-reduce
+        WFX_TRY(sh->dH.inv_halo_unpack());
+        WFX_TRY(wfx_dev_select_sharded_ws(ctx, &sh->ws));
+        WFX_TRY(wfx_dev_env_median_segs(ctx, (const cplx *)sh->b_v.p + SH_VHALO, pl.wH + 2 * SH_VHALO, audio + pl.hs, pl.xrs, R1, (int)(2 * pl.wH),
+                                        2 * pl.cH0, 2 * pl.Ms, pl.n, env, sh->ws));
+        wfx_comm_label(c, "select level 0");
+        return wfx_comm_allreduce_u32(c, ctx, sh->ws, WFX_SEL_BINS);
+    }
+    case 7: {
+        const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
+        WFX_TRY(wfx_dev_select_l1(ctx, env, n_own, ranks, sh->ws, ds));
+        wfx_comm_label(c, "select level 1");
+        return wfx_comm_allreduce_u32(c, ctx, sh->ws + WFX_SEL_H1_OFFSET, WFX_SEL_H1_WORDS);
+    }
+    case 8: {
+        WFX_TRY(wfx_dev_select_compact_block(ctx, env, n_own, sh->ws, ds, sh->b_blk.p, sh->cap));
+        wfx_comm_label(c, "select candidates");
+        return wfx_comm_allgather(c, ctx, sh->b_blk.p, sh->b_blks.p, wfx_select_block_bytes(sh->cap));
+    }
+    case 9: {   // a8 finish + quantise; the one gather of the stream (every rank's segments, back to back)
+        WFX_TRY(wfx_dev_select_finish_blocks(ctx, sh->ws, ds, sh->b_blks.p, W, sh->cap, p.gamma_lo, p.gamma_hi, (unsigned *)sh->b_flags.p));
+        WFX_TRY(wfx_dev_quantise(ctx, env, n_own, ds, dig_own, ds));
+        std::vector<wfx_xfer> xs;
+        if (me == 0) {
+            uint64_t off = n_own;
+            for (int s = 1; s < W; ++s) {
+                const long long c0 = (long long)s * pl.Ms / W / 4 * 4, c1 = s + 1 == W ? pl.Ms : (long long)(s + 1) * pl.Ms / W / 4 * 4;
+                const uint64_t nb = (uint64_t)R1 * 2ull * (uint64_t)(c1 - c0);
+                xs.push_back(wfx_xfer{s, nullptr, 0, (uint8_t *)sh->b_gath.p + off, (size_t)nb});
+                xs.push_back(wfx_xfer{s, nullptr, 0, (unsigned long long *)sh->b_nan.p + s, 8});
+                off += nb;
+            }
+        } else {
+            xs.push_back(wfx_xfer{0, dig_own, (size_t)n_own, nullptr, 0});
+            xs.push_back(wfx_xfer{0, &ds->nan_count, 8, nullptr, 0});
+        }
+        wfx_comm_label(c, "stream gather");
+        return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
+    }
+    case 10: {  // rank 0: the segments in order, then a9 + a10
+        if (me != 0) return 0;
+        if (W > 1) {
+            WFX_TRY(wfx_dist_copy2d(ctx, (const wfx_dist_piece *)sh->b_pieces.p, sh->n_pieces, sh->piece_max, 2));
+            WFX_TRY(wfx_dev_add_u64(ctx, &ds->nan_count, (const unsigned long long *)sh->b_nan.p + 1, W - 1));
+        }
+        const int w = p.width;
+        const int h_max = (int)(pl.n / (uint64_t)w);
+        WFX_TRY(wfx_reserve(ctx, ctx->b_img, (size_t)w * 4 * (size_t)(h_max > 0 ? h_max : 1)));
+        WFX_TRY(wfx_dev_sync_pick(ctx, (const uint8_t *)sh->b_dig.p, pl.n, p.n1, p.n0_gap, p.mindistance, p.frame_samples, w, ds));
+        return wfx_dev_image(ctx, (const uint8_t *)sh->b_dig.p, pl.n, w, h_max, ds, (uint8_t *)ctx->b_img.p, ctx->h_scal);
+    }
+    default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "no such phase");
+    }
+}
 
 static int run_phase(wfx_shard *sh, int ph)
 {
@@ -316,6 +622,7 @@ static int run_phase(wfx_shard *sh, int ph)
         }
         return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
     }
+    if (pl.cols) return run_phase_cols(sh, ph);
     double *audio = (double *)sh->b_audio.p;
     double *env = (double *)sh->b_env.p;
     uint8_t *dig_own = (uint8_t *)sh->b_dig.p + (me == 0 ? pl.own_lo : 0);
@@ -434,15 +741,18 @@ static int run_phase(wfx_shard *sh, int ph)
         const double *xg = audio - (long long)pl.seg_lo;
         if (n_own && pl.plain) WFX_TRY(wfx_dev_env_median_block_plain(ctx, Vg, xg, pl.n, pl.own_lo, pl.own_hi, env, sh->ws));
         if (n_own && !pl.plain) WFX_TRY(wfx_dev_env_median_block(ctx, Vg, xg, pl.n, pl.own_lo, pl.own_hi, env, sh->ws));
+        wfx_comm_label(c, "select level 0");
         return wfx_comm_allreduce_u32(c, ctx, sh->ws, WFX_SEL_BINS);
     }
     case 9: {
         const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
         WFX_TRY(wfx_dev_select_l1(ctx, env, n_own, ranks, sh->ws, ds));
+        wfx_comm_label(c, "select level 1");
         return wfx_comm_allreduce_u32(c, ctx, sh->ws + WFX_SEL_H1_OFFSET, WFX_SEL_H1_WORDS);
     }
     case 10: {
         WFX_TRY(wfx_dev_select_compact_block(ctx, env, n_own, sh->ws, ds, sh->b_blk.p, sh->cap));
+        wfx_comm_label(c, "select candidates");
         return wfx_comm_allgather(c, ctx, sh->b_blk.p, sh->b_blks.p, wfx_select_block_bytes(sh->cap));
     }
     case 11: {  // a8 finish + quantise; the one gather of the stream
@@ -477,6 +787,7 @@ static int run_phase(wfx_shard *sh, int ph)
             b.send_bytes = 8;
             xs.push_back(b);
         }
+        wfx_comm_label(c, "stream gather");
         return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
     }
     case 12: {  // a9 + a10 on rank 0
@@ -509,13 +820,14 @@ static bool dry_inside(const std::vector<dry_region> &regs, unsigned long long l
     return false;
 }
 
-static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p, long long L, int es, int hb, int ha, bool fwd, bool inv, const char *name,
-                               int rows_used = 0)
+// every rank's transform object of one distributed transform, planned with fake addresses (no device memory)
+static int dry_build(const shard_plan &pl0, long long L, int es, int hb, int ha, bool fwd, bool inv, bool cols, int rows_used, std::vector<wfx_dist> &d,
+                     std::vector<std::vector<dry_region>> &regs)
 {
     const int W = pl0.world;
-    std::vector<wfx_dist> d(W);
-    std::vector<std::vector<dry_region>> regs(W);
-    std::vector<unsigned long long> rin(W), rout(W);
+    d.clear();
+    d.resize(W);
+    regs.assign(W, {});
     int rc = 0;
     for (int r = 0; r < W && rc == 0; ++r) {
         wfx_dist_geom g;
@@ -526,14 +838,31 @@ static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p
         std::vector<std::pair<unsigned long long, unsigned long long>> b;
         d[r].buffers(b);
         for (auto &x : b) regs[r].push_back({x.first, x.first + x.second});
-        rin[r] = base + (6ull << 36);
-        rout[r] = base + (7ull << 36);
-        regs[r].push_back({rin[r], rin[r] + (unsigned long long)d[r].nr * d[r].M * es});
-        regs[r].push_back({rout[r], rout[r] + (unsigned long long)(hb + (long long)d[r].nr * d[r].M + ha) * 16});
-        rc = d[r].bind(fwd ? (const void *)rin[r] : nullptr, inv ? (cplx *)rout[r] : nullptr, d[r].fwd_result_index());
+        const unsigned long long rin = base + (6ull << 36), rout = base + (7ull << 36);
+        if (cols) {
+            const long long in_rs = d[r].w + 8, out_rs = (long long)hb + d[r].w + ha + 2;      // (any strides that hold a row)
+            regs[r].push_back({rin, rin + (unsigned long long)pl0.g.R1 * in_rs * es});
+            regs[r].push_back({rout, rout + (unsigned long long)pl0.g.R1 * out_rs * 16});
+            rc = d[r].bind_cols(fwd ? (const void *)rin : nullptr, in_rs, inv ? (cplx *)rout : nullptr, out_rs, d[r].fwd_result_index());
+        } else {
+            regs[r].push_back({rin, rin + (unsigned long long)d[r].nr * d[r].M * es});
+            regs[r].push_back({rout, rout + (unsigned long long)(hb + (long long)d[r].nr * d[r].M + ha) * 16});
+            rc = d[r].bind(fwd ? (const void *)rin : nullptr, inv ? (cplx *)rout : nullptr, d[r].fwd_result_index());
+        }
     }
-    for (int e = 1; e <= 4 && rc == 0; ++e) {
+    return rc;
+}
+
+static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p, long long L, int es, int hb, int ha, bool fwd, bool inv, const char *name,
+                               int rows_used = 0, bool cols = false)
+{
+    const int W = pl0.world;
+    std::vector<wfx_dist> d;
+    std::vector<std::vector<dry_region>> regs;
+    int rc = dry_build(pl0, L, es, hb, ha, fwd, inv, cols, rows_used, d, regs);
+    for (int e = 1; e <= 5 && rc == 0; ++e) {
         if ((e <= 2 && !fwd) || (e >= 3 && !inv)) continue;
+        if (cols ? (e == 1 || e == 4) : e == 5) continue;         // columns layout: no E1 / E4, a halo exchange (5) instead
         const int pes = e == 1 ? es : 16;
         for (int src = 0; src < W && rc == 0; ++src)
             for (int dst = 0; dst < W && rc == 0; ++dst) {
@@ -562,7 +891,8 @@ static int dry_check_transform(const shard_plan &pl0, const wfx_decode_params *p
             const unsigned long long R1 = pl0.g.R1, Rd = (rows_used > 0 && rows_used < pl0.g.R1) ? (unsigned long long)rows_used : R1;     // rows that travel in E1
             // (one rank: the first pass reads the rows in place and the last one writes them in place -- E1 and E4 carry the halo only)
             const unsigned long long want = e == 1 ? (W == 1 ? 0ull : Rd * d[r].w * (unsigned long long)es) : e == 2 ? (unsigned long long)d[r].M * d[r].B * 16
-                                          : e == 3 ? R1 * d[r].w * 16ull : ((W == 1 ? 0ull : (unsigned long long)d[r].nr * d[r].M) + hb + ha) * 16ull;
+                                          : e == 3 ? R1 * d[r].w * 16ull : e == 5 ? R1 * (unsigned long long)(hb + ha) * 16ull
+                                          : ((W == 1 ? 0ull : (unsigned long long)d[r].nr * d[r].M) + hb + ha) * 16ull;
             if (rc == 0 && total != want)
                 rc = wfx_fail(nullptr, WFX_ERR_COMM, "dry run (%s, exchange %d): rank %d receives %llu bytes, its layout holds %llu", name, e, r, total, want);
             if (e == 2 && rc == 0) {
@@ -611,6 +941,16 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
     for (int r = 0; r < world; ++r) {
         shard_plan q;
         WFX_TRY(make_plan(nullptr, p, world, r, q));
+        if (q.cols) {
+            // columns layout: the ranks' column ranges tile [0, Ms) (and [0, M1s)); a rank's samples are those columns of every row
+            if (2ull * (uint64_t)q.cH0 != next) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: rank %d's columns start at sample %llu of a row, expected %llu", r, 2ull * (unsigned long long)q.cH0, (unsigned long long)next);
+            next = 2ull * (uint64_t)(q.cH0 + q.wH);
+            if (q.resample) {
+                if (2ull * (uint64_t)q.cF0 != next_in) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: rank %d's input columns do not follow rank %d's", r, r - 1);
+                next_in = 2ull * (uint64_t)(q.cF0 + q.wF);
+            }
+            continue;
+        }
         if (q.own_lo != next) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: rank %d starts at sample %llu, expected %llu", r, (unsigned long long)q.own_lo, (unsigned long long)next);
         next = q.own_hi;
         if (q.resample) {
@@ -618,8 +958,19 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
             next_in = q.in_hi;
         }
     }
-    if (next != p->n || (pl.resample && next_in != p->n0)) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: the ranks' ranges do not cover the capture");
+    if (pl.cols) {
+        if (next != 2ull * (uint64_t)pl.Ms || (pl.resample && next_in != 2ull * (uint64_t)pl.M1s) || (uint64_t)pl.g.R1 * 2ull * (uint64_t)pl.Ms != p->n)
+            return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: the ranks' columns do not cover the rows");
+    } else if (next != p->n || (pl.resample && next_in != p->n0))
+        return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: the ranks' ranges do not cover the capture");
     if (pl.single) return 0;              // rank 0 alone: one message of scalars per peer, nothing to cross-check
+    if (pl.cols) {
+        if (pl.resample) {
+            WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward (columns)", 0, true));
+            WFX_TRY(dry_check_transform(pl, p, pl.K, 16, pl.hs / 2, pl.hs / 2, false, true, "resample inverse (columns)", 0, true));
+        }
+        return dry_check_transform(pl, p, pl.K, 16, SH_VHALO, SH_VHALO, true, true, "hilbert (columns)", 0, true);
+    }
     if (pl.resample) {
         WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward"));
         WFX_TRY(dry_check_transform(pl, p, pl.K, 16, SH_HALO / 2, SH_HALO / 2, false, true, "resample inverse"));
@@ -627,6 +978,85 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
     if (pl.split_kernel) WFX_TRY(dry_check_transform(pl, p, pl.Kp, pl.plain ? 8 : 16, 0, 0, true, false, "hilbert kernel (all rows)"));
     return dry_check_transform(pl, p, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO, true, true, pl.plain ? "hilbert (odd length)" : (pl.padded ? "hilbert (padded)" : "hilbert"),
                                pl.g.rows_used);
+}
+
+// ---- what the plan puts on the wire (host only) -----------------------------------------------------------------
+extern "C" int wfx_shard_wire_plan(const wfx_decode_params *p, int world, wfx_wire_entry *out, int cap)
+{
+    shard_plan pl;
+    WFX_TRY(make_plan(nullptr, p, world, 0, pl));
+    const int W = world;
+    int n = 0;
+    auto put = [&](const char *name, unsigned long long total, unsigned long long max_rank, unsigned long long max_link) {
+        if (out && n < cap) {
+            memset(&out[n], 0, sizeof out[n]);
+            snprintf(out[n].name, sizeof out[n].name, "%s", name);
+            out[n].total_bytes = total;
+            out[n].max_rank_bytes = max_rank;
+            out[n].max_link_bytes = max_link;
+        }
+        ++n;
+    };
+    if (pl.single) {
+        put("scalars", (unsigned long long)(W - 1) * sizeof(wfx_dev_scalars), (unsigned long long)(W - 1) * sizeof(wfx_dev_scalars), sizeof(wfx_dev_scalars));
+        return n;
+    }
+    // one transform's exchanges, from every rank's (dry) exchange lists
+    auto transform = [&](const char *tag, long long L, int es, int hb, int ha, bool fwd, bool inv, int rows_used) -> int {
+        std::vector<wfx_dist> d;
+        std::vector<std::vector<dry_region>> regs;
+        WFX_TRY(dry_build(pl, L, es, hb, ha, fwd, inv, pl.cols, rows_used, d, regs));
+        for (int e = 1; e <= 5; ++e) {
+            if ((e <= 2 && !fwd) || (e >= 3 && !inv)) continue;
+            if (pl.cols ? (e == 1 || e == 4) : e == 5) continue;
+            // (order within a transform: E1, E2, E3, E4 | E2, E3, halo)
+            unsigned long long total = 0, mr = 0, ml = 0;
+            for (int r = 0; r < W; ++r) {
+                std::vector<unsigned long long> link((size_t)W, 0ull);
+                unsigned long long mine = 0;
+                for (const wfx_xfer &x : d[r].xfers(e))
+                    if (x.peer != r) {
+                        mine += x.send_bytes;
+                        link[(size_t)x.peer] += x.send_bytes;
+                    }
+                total += mine;
+                mr = std::max(mr, mine);
+                for (unsigned long long v : link) ml = std::max(ml, v);
+            }
+            char name[24];
+            snprintf(name, sizeof name, "%.15s %s", tag, e == 5 ? "halo" : (e == 1 ? "E1" : e == 2 ? "E2" : e == 3 ? "E3" : "E4"));
+            put(name, total, mr, ml);
+        }
+        for (int r = 0; r < W; ++r) d[r].release();
+        return 0;
+    };
+    if (pl.resample) {
+        WFX_TRY(transform("resample fwd", pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, 0));
+        const int h = pl.cols ? pl.hs / 2 : SH_HALO / 2;
+        WFX_TRY(transform("resample inv", pl.K, 16, h, h, false, true, 0));
+    }
+    WFX_TRY(transform("hilbert", pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO, true, true, pl.g.rows_used));
+    const unsigned long long ar0 = 2ull * (W - 1) * WFX_SEL_BINS * 4 / W, ar1 = 2ull * (W - 1) * WFX_SEL_H1_WORDS * 4 / W;
+    put("select level 0", ar0 * W, ar0, WFX_SEL_BINS * 4ull / W);
+    put("select level 1", ar1 * W, ar1, WFX_SEL_H1_WORDS * 4ull / W);
+    {
+        uint64_t want = p->n / (512ull * (uint64_t)W), capk = SH_CAND_CAP;
+        while (capk < want && capk < (1ull << 20)) capk *= 2;
+        const unsigned long long blk = wfx_select_block_bytes(capk);
+        put("select candidates", (unsigned long long)W * (W - 1) * blk, (unsigned long long)(W - 1) * blk, blk);
+    }
+    {
+        unsigned long long total = 0, big = 0;
+        for (int r = 1; r < W; ++r) {
+            shard_plan q;
+            WFX_TRY(make_plan(nullptr, p, world, r, q));
+            const unsigned long long nb = (q.cols ? cols_own(q) : q.own_hi - q.own_lo) + 8;
+            total += nb;
+            big = std::max(big, nb);
+        }
+        put("stream gather", total, big, big);
+    }
+    return n;
 }
 
 #define CHECK_SH(sh)                                                                                              \
@@ -652,6 +1082,22 @@ int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_
     out->in_hi = pl.in_hi;
     out->own_lo = pl.own_lo;
     out->own_hi = pl.own_hi;
+    out->nseg = 1;
+    out->plan = pl.single ? 0 : (pl.cols ? 2 : 1);
+    out->plan_forced = pl.forced;
+    out->model_single_s = pl.model_single;
+    out->model_dist_compute_s = pl.model_comp;
+    out->model_dist_wire_s = pl.model_wire;
+    out->model_wire_bytes = pl.model_bytes;
+    snprintf(out->plan_reason, sizeof out->plan_reason, "%s", pl.single ? pl.single_reason : (pl.cols ? "columns layout" : (pl.padded ? "rows layout (padded form)" : "rows layout")));
+    if (pl.cols && world > 1) {
+        out->nseg = pl.g.R1;
+        out->own_seg_len = 2ull * (uint64_t)pl.wH;
+        out->own_seg_stride = 2ull * (uint64_t)pl.Ms;
+        out->in_halo = pl.resample ? 0 : pl.hs;
+        out->in_seg_len = pl.resample ? 2ull * (uint64_t)pl.wF : 2ull * (uint64_t)pl.wH;
+        out->in_seg_stride = pl.resample ? 2ull * (uint64_t)pl.M1s : 2ull * (uint64_t)pl.Ms;
+    }
     return 0;
 }
 
@@ -685,9 +1131,13 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
         *out = sh;
         return 0;
     }
+    sh->dF.set_tag("resample fwd");
+    sh->dI.set_tag("resample inv");
+    sh->dH.set_tag("hilbert");
+    sh->dHk.set_tag("hilbert kernel");
     if (rc == 0 && pl.resample) {
         rc = sh->dF.init(ctx, pl.g, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0);
-        if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, SH_HALO / 2, SH_HALO / 2);
+        if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, pl.cols ? pl.hs / 2 : SH_HALO / 2, pl.cols ? pl.hs / 2 : SH_HALO / 2);
     }
     if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO);
     if (rc == 0 && pl.split_kernel) rc = sh->dHk.init(ctx, pl.gk, pl.Kp, pl.plain ? 8 : 16, 0, 0);
@@ -703,7 +1153,7 @@ int wfx_shard_upload(wfx_shard *sh, const void *host_frames)
 {
     CHECK_SH(sh);
     wfx_ctx *ctx = sh->ctx;
-    const size_t nb = (size_t)(sh->pl.in_hi - sh->pl.in_lo) * frame_bytes(sh->pl.in_kind);
+    const size_t nb = (size_t)(sh->pl.cols ? cols_in_frames(sh->pl) : sh->pl.in_hi - sh->pl.in_lo) * frame_bytes(sh->pl.in_kind);
     if (!host_frames && nb) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
     const bool moved = !sh->b_in.p || sh->b_in.cap < nb + 64 || sh->ext_in;
     WFX_TRY(wfx_reserve(ctx, sh->b_in, nb + 64));
@@ -838,6 +1288,42 @@ int wfx_shard_fetch(wfx_shard *sh, int buffer_id, void *host_out, size_t bytes)
         if (bytes != 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fetch: expected 0 bytes, got %zu (rank 0 owns the whole capture)", bytes);
         return 0;
     }
+    if (pl.cols) {
+        const uint64_t nc = cols_own(pl);
+        const void *src = nullptr;
+        size_t nb = 0;
+        switch (buffer_id) {
+        case WFX_BUF_AUDIO:       // the own samples of the R1 rows, back to back
+            if (bytes != nc * 8) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fetch: expected %zu bytes, got %zu", (size_t)nc * 8, bytes);
+            if (!host_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+            WFX_HIP(ctx, hipMemcpy2DAsync(host_out, (size_t)pl.wH * 16, (const double *)sh->b_audio.p + SH_PAD + pl.hs, (size_t)pl.xrs * 8, (size_t)pl.wH * 16,
+                                          (size_t)pl.g.R1, hipMemcpyDeviceToHost, ctx->stream));
+            WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return 0;
+        case WFX_BUF_ENVELOPE: src = sh->b_env.p; nb = nc * 8; break;
+        case WFX_BUF_DIGITAL:
+            if (pl.rank == 0 && bytes == pl.n && (pl.world > 1 || nc != pl.n)) {
+                src = sh->b_dig.p;
+                nb = pl.n;
+            } else {
+                src = (pl.rank == 0 && pl.world > 1) ? sh->b_gath.p : sh->b_dig.p;
+                nb = nc;
+            }
+            break;
+        case WFX_BUF_IMAGE:
+            if (pl.rank != 0) return wfx_fail(ctx, WFX_ERR_STATE, "the image lives on rank 0");
+            WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            src = ctx->b_img.p;
+            nb = (size_t)sh->dp.width * 4 * (size_t)ctx->h_scal->height;
+            break;
+        default: return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown buffer id %d", buffer_id);
+        }
+        if (bytes != nb) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fetch: expected %zu bytes, got %zu", nb, bytes);
+        if (nb && !host_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+        if (nb) WFX_HIP(ctx, hipMemcpyAsync(host_out, src, nb, hipMemcpyDeviceToHost, ctx->stream));
+        WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
     const void *src = nullptr;
     size_t nb = 0;
     switch (buffer_id) {
@@ -881,7 +1367,7 @@ int wfx_shard_destroy(wfx_shard *sh)
     sh->dH.release();
     sh->dHk.release();
     wfx_devbuf *bufs[] = {&sh->b_in, &sh->b_merged, &sh->b_res, &sh->b_audio, &sh->b_v, &sh->b_env, &sh->b_dig, &sh->b_blk, &sh->b_blks, &sh->b_nan, &sh->b_flags,
-                          &sh->b_grow, &sh->b_ghat};
+                          &sh->b_grow, &sh->b_ghat, &sh->b_gath, &sh->b_pieces};
     for (wfx_devbuf *b : bufs) free_buf(*b);
     delete sh;
     return 0;

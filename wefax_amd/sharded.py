@@ -131,12 +131,12 @@ class ShardedDecoder:
     Ranks other than 0 get ``None`` images; scalars (low, high) are available everywhere."""
 
     def __init__(self, ctx: nat.Context, comm: nat.Comm, n0: int, sample_rate, lines_per_minute: int = 120, kind: int = nat.WFX_IN_I16_MONO,
-                 notch=None, data: np.ndarray | None = None, loader=None, n_out: int | None = None):
+                 notch=None, data: np.ndarray | None = None, loader=None, n_out: int | None = None, plan="auto"):
         self.ctx, self.comm = ctx, comm
         self.frame_len = 1 / (lines_per_minute / 60)
         if notch is None:                       # config/config.json like Demodulator (wefax.py:63-66), defaults when there is no file
             notch = hp.load_notch_settings()
-        self.params, self.meta = build_params(kind, int(n0), sample_rate, self.frame_len, notch, n_out=n_out)
+        self.params, self.meta = build_params(kind, int(n0), sample_rate, self.frame_len, notch, n_out=n_out, shard_plan=plan_code(plan))
         # uint8 / int32 / float32 captures reach the device as float64, but filtfilt's odd extension (wefax.py:72) is what scipy
         # evaluates in the file's OWN dtype (wraps / float32 rounding): 9 + 9 numbers from the capture's two ends, as DecodeJob
         # hands them over (the ranks holding a true end use them; wfx_shard.hip phase 4)
@@ -160,9 +160,9 @@ class ShardedDecoder:
         lay = self.shard.layout
         self.layout = lay
         if data is not None:
-            frames = np.asarray(data)[lay.in_lo:lay.in_hi]
+            frames = gather_frames(lay, np.asarray(data))
         elif loader is not None:
-            frames = loader(int(lay.in_lo), int(lay.in_hi))
+            frames = gather_frames(lay, None, loader, int(n0))
         else:
             frames = None
         if frames is not None:
@@ -181,7 +181,7 @@ class ShardedDecoder:
 
     def fetch(self, which: str) -> np.ndarray:
         lay = self.layout
-        own = int(lay.own_hi - lay.own_lo)
+        own = lay.own_samples
         if which == "audio":
             return self.shard.fetch(nat.WFX_BUF_AUDIO, (own,), np.float64)
         if which == "envelope":
@@ -199,6 +199,45 @@ class ShardedDecoder:
         self.shard.close()
 
 
+PLAN_CODES = {"auto": 0, "dist": 1, "single": 2, "rows": 17, "auto-rows": 16}
+
+
+def plan_code(plan) -> int:
+    """``wfx_decode_params.shard_plan``: "auto" (the library's cost model picks distributed or single), "dist" (distributed
+    whenever a distributed form exists), "single" (rank 0 alone), "rows" (distributed in the rows layout of rounds 2-3: A/B runs),
+    "auto-rows"; or the integer itself."""
+    return int(PLAN_CODES[plan]) if isinstance(plan, str) else int(plan)
+
+
+def gather_frames(lay, data=None, loader=None, n0: int | None = None) -> np.ndarray:
+    """The frames a rank hands over for its layout: one range (rows layout, single plan, one rank), or -- columns layout --
+    ``nseg`` segments with ``in_halo`` frames on either side, back to back; frames outside the capture are zeros."""
+    if lay.nseg <= 1:
+        lo, hi = int(lay.in_lo), int(lay.in_hi)
+        return np.asarray(data)[lo:hi] if data is not None else loader(lo, hi)
+    h, ln, st, lo = int(lay.in_halo), int(lay.in_seg_len), int(lay.in_seg_stride), int(lay.in_lo)
+    n0 = int(data.shape[0] if data is not None else n0)
+    parts = []
+    for sgm in range(int(lay.nseg)):
+        a, b = lo + sgm * st - h, lo + sgm * st + ln + h
+        ca, cb = max(a, 0), min(b, n0)
+        part = np.asarray(data[ca:cb] if data is not None else loader(ca, cb))
+        if ca > a or cb < b:
+            pad = [(ca - a, b - cb)] + [(0, 0)] * (part.ndim - 1)
+            part = np.pad(part, pad)
+        parts.append(part)
+    return np.concatenate(parts)
+
+
+def assemble(layouts, blocks, n: int, dtype=None) -> np.ndarray:
+    """Per-rank stage buffers (``ShardedDecoder.fetch``) -> the whole capture's array in sample order."""
+    out = np.zeros(int(n), dtype=dtype if dtype is not None else np.asarray(blocks[0]).dtype)
+    for lay, blk in zip(layouts, blocks):
+        if lay.own_samples:
+            out[lay.own_index()] = blk
+    return out
+
+
 def layout_supported(n0: int, sample_rate, world: int, lines_per_minute: int = 120, kind: int = nat.WFX_IN_F64_MONO, n_out: int | None = None) -> bool:
     """Whether the sharded path takes a capture of this description over ``world`` ranks (``wfx_shard_layout_query`` answers
     without a GPU).  Since round 3 that is every valid capture: one with no distributed form gets the single plan."""
@@ -212,7 +251,7 @@ def layout_supported(n0: int, sample_rate, world: int, lines_per_minute: int = 1
 
 def layout_distributed(n0: int, sample_rate, world: int, lines_per_minute: int = 120, kind: int = nat.WFX_IN_F64_MONO, n_out: int | None = None) -> bool:
     """Whether the capture's transforms are distributed over the ranks (False: the single plan -- rank 0 decodes it alone)."""
-    p, _ = build_params(kind, int(n0), sample_rate, 1 / (lines_per_minute / 60), hp.DEFAULT_NOTCH, n_out=n_out)
+    p, _ = build_params(kind, int(n0), sample_rate, 1 / (lines_per_minute / 60), hp.DEFAULT_NOTCH, n_out=n_out, shard_plan=plan_code("dist"))
     lay = nat.shard_layout(p, world, 0)
     return not (lay.first_radix[0] == 0 and lay.first_radix[1] == 0)
 
@@ -226,10 +265,11 @@ def _info_dict(info: nat.DecodeInfo) -> dict:
 
 
 def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute: int = 120, device: int = 0, notch=None,
-                    want=("image", "stream", "envelope", "audio"), make_decoder=None, free_after=None, repeat: int = 1):
+                    want=("image", "stream", "envelope", "audio"), make_decoder=None, free_after=None, repeat: int = 1, plan="dist"):
     """Every rank of a ``world``-rank sharded decode in this process, on one GPU, phase by phase (local communicator:
     a collective completes when the last rank has posted its part).  Returns the root's results plus the per-rank
-    blocks concatenated, for comparison with the single-GPU path (tests)."""
+    blocks put in sample order, for comparison with the single-GPU path (tests).  ``plan``: "dist" by default -- the emulation
+    exists to exercise the distributed form at every world size, whatever the cost model would pick on real links."""
     data = np.asarray(data)
     comms = nat.Comm.local(world)
     ctxs = [nat.Context(device) for _ in range(world)]
@@ -239,7 +279,7 @@ def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute:
             if make_decoder is not None:
                 decs.append(make_decoder(ctxs[r], comms[r]))
             else:
-                decs.append(ShardedDecoder(ctxs[r], comms[r], data.shape[0], sample_rate, lines_per_minute, capture_kind(data), notch, data=data))
+                decs.append(ShardedDecoder(ctxs[r], comms[r], data.shape[0], sample_rate, lines_per_minute, capture_kind(data), notch, data=data, plan=plan))
         for d in decs:
             if hasattr(d, "front_end"):
                 d.front_end()
@@ -270,14 +310,16 @@ def decode_emulated(data: np.ndarray, sample_rate, world: int, lines_per_minute:
         out = {"sync": _info_dict(infos[0]), "low": infos[0].low, "high": infos[0].high,
                "lows": [i.low for i in infos], "highs": [i.high for i in infos], "n": decs[0].n, "width": decs[0].width,
                "layouts": [(int(d.layout.own_lo), int(d.layout.own_hi), int(d.layout.in_lo), int(d.layout.in_hi)) for d in decs],
-               "first_radix": tuple(decs[0].layout.first_radix)}
+               "own": [d.layout.own_samples for d in decs], "plan": int(decs[0].layout.plan),
+               "first_radix": tuple(decs[0].layout.first_radix), "wire": [c.wire_stats() for c in comms]}
+        lays = [d.layout for d in decs]
         if "stream" in want:
             out["digitalized"] = decs[0].fetch("stream")
-            out["digitalized_blocks"] = np.concatenate([d.fetch("digitalized") for d in decs])
+            out["digitalized_blocks"] = assemble(lays, [d.fetch("digitalized") for d in decs], decs[0].n, np.uint8)
         if "envelope" in want:
-            out["envelope"] = np.concatenate([d.fetch("envelope") for d in decs])
+            out["envelope"] = assemble(lays, [d.fetch("envelope") for d in decs], decs[0].n, np.float64)
         if "audio" in want:
-            out["audio"] = np.concatenate([d.fetch("audio") for d in decs])
+            out["audio"] = assemble(lays, [d.fetch("audio") for d in decs], decs[0].n, np.float64)
         if "image" in want and not infos[0].no_group and not infos[0].nan_count and infos[0].height > 0:
             out["image"] = decs[0].fetch("image")
         return out
@@ -406,13 +448,13 @@ class FrontEndShardedDecoder:
     between GPUs; what is exchanged is the transposes of the transforms at the hand-over rate and at 11 025 Hz."""
 
     def __init__(self, ctx, comm, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None,
-                 notch=None):
+                 notch=None, plan="rows"):
         if not frontend.exact_tail:
             raise ValueError("the sharded form needs FrontEnd(stop_rate=...): the exact resampler takes the last step")
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
         n_fe = frontend.n_out(n_in_total)
         self.dec = ShardedDecoder(ctx, comm, n_fe, frontend.out_rate, lines_per_minute, nat.WFX_IN_F64_MONO, notch,
-                                  n_out=frontend.n_target(n_in_total))
+                                  n_out=frontend.n_target(n_in_total), plan=plan)
         lay = self.dec.layout
         self.shard, self.layout, self.n, self.width = self.dec.shard, lay, self.dec.n, self.dec.width
         if lay.in_hi == lay.in_lo:

@@ -27,7 +27,7 @@ DEFAULT_HILBERT_MODE = nat.WFX_HILBERT_FFT
 
 
 def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEFAULT_NOTCH,
-                 hilbert_mode: int = DEFAULT_HILBERT_MODE, n_out: int | None = None):
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE, n_out: int | None = None, shard_plan: int = 0):
     """The scalar arithmetic of the reference for a capture of ``n0`` frames at ``sample_rate`` (lengths, notch
     coefficients, percentile ranks and weights, sync constants) as the C ABI's ``wfx_decode_params``, plus the derived
     lengths.  Same expressions as wefax.py, evaluated in Python floats / NumPy scalars like there.
@@ -49,6 +49,7 @@ def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEF
     p.notch_b[:] = [float(v) for v in b]
     p.notch_a[:] = [float(v) for v in a]
     p.hilbert_mode = hilbert_mode
+    p.shard_plan = int(shard_plan)       # sharded decodes only: 0 cost model, 1 distributed, 2 single; + 16 rows layout (include/wefax_hip.h)
     lo0, lo1, glo = hp.percentile_plan(n, 0.5)                         # wefax.py:194-196
     hi0, hi1, ghi = hp.percentile_plan(n, 99.5)
     p.rank_lo[:] = [lo0, lo1]
