@@ -60,6 +60,9 @@ def parse():
                     help="rate at which the time-domain front end hands the IQ stream to the exact FFT resampler")
     ap.add_argument("--iq-form", choices=["auto", "fused", "sharded"], default="auto",
                     help="one GPU: the fused exact decode behind the front end (auto) or the sharded form with one rank")
+    ap.add_argument("--plan", choices=["auto", "dist", "single", "rows", "auto-rows"], default="auto",
+                    help="sharded decodes: auto = the library's cost model picks the distributed form or rank 0 alone (DESIGN 6.6); dist / single "
+                         "force one; rows = distributed in the rows layout of rounds 2-3 (8 array transposes instead of 4: A/B runs)")
     ap.add_argument("--trim", type=int, default=0, help="c2: drop this many samples from the end of the capture (--trim 2 with --shard: the padded distributed convolution; odd: one point per sample)")
     ap.add_argument("--no-c4", action="store_true", help="c2: leave the c4_strong object out (quick runs)")
     ap.add_argument("--no-extras", action="store_true", help="c2: leave the general_length and c3 objects out (kernel profiles of the headline alone)")
@@ -318,6 +321,25 @@ def iq_recipe(seconds: float):
     return dict(start_tone_s=5.0, phasing_lines=60, image_lines=int((seconds - 15.0) / 0.5) - 60, stop_tone_s=5.0, black_tail_s=5.0)
 
 
+def wire_object(rk: Ranks, params, layout, run, sync) -> dict:
+    """What one sharded decode puts on the wire: the plan's collectives with their bytes (host-only: every rank's exchange lists),
+    what THIS rank's communicator counted during one decode (transport-independent), and the cost model's figures behind the
+    choice of plan."""
+    nat = rk.nat
+    plan = nat.shard_wire_plan(params, rk.world)
+    rk.comm.wire_reset()
+    run()
+    sync()
+    mine = rk.comm.wire_stats()
+    return {"layout": {0: "single (rank 0 alone)", 1: "rows", 2: "columns"}[int(layout.plan)], "chosen_by": "caller" if layout.plan_forced else "cost model",
+            "reason": layout.plan_reason.decode(), "total_bytes": sum(e["bytes"] for e in plan),
+            "array_transposes": sum(1 for e in plan if " E" in e["name"]),
+            "per_collective": plan, "this_rank_sent": sum(e["sent"] for e in mine), "this_rank": mine,
+            "model": {"link_GBs": float(os.environ.get("WFX_LINK_GBS", "50")), "one_gpu_ms": round(1e3 * layout.model_single_s, 3),
+                      "dist_compute_ms": round(1e3 * layout.model_dist_compute_s, 3), "dist_wire_ms": round(1e3 * layout.model_dist_wire_s, 3),
+                      "wire_bytes": int(layout.model_wire_bytes)}}
+
+
 def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu: bool) -> dict:
     """Strong scaling: the stream is fixed, every rank owns 1/world of it plus the FIR chain's halo."""
     from wefax_amd import polyphase, sharded, synth_device
@@ -326,13 +348,7 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
     sp = synth_device.synth_params(float(IQ_FS), noise=args.noise, seed=0, iq=True, **kw)
     n0 = int(ctx.lib.wfx_synth_frames(sp))
     fe = polyphase.FrontEnd(IQ_FS, stop_rate=args.iq_stop_rate)
-    keep = []
-
-    def raw_loader(lo, hi):
-        ptr = synth_device.synth_slice(ctx, sp, lo, hi)
-        keep.append(ptr)
-        return ptr, hi - lo
-
+    raw_loader = synth_device.SliceLoader(ctx, sp)
     t_syn = time.perf_counter()
     fused = rk.world == 1 and (args.iq_form == "fused" or (args.iq_form == "auto" and not rk.use_rccl))
     if fused:
@@ -342,10 +358,9 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
         ia, ib = dec.chain[0][2]
     else:
         dec = sharded.FrontEndShardedDecoder(ctx, rk.comm, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,
-                                             raw_loader=raw_loader)
+                                             raw_loader=raw_loader, plan=args.plan)
         n = dec.n
-        ia, ib = dec.raw_range
-        own_in, own_out = ib - ia, int(dec.layout.own_hi - dec.layout.own_lo)
+        own_in, own_out = dec.raw_frames, dec.layout.own_samples
     ctx.sync()
     t_syn = time.perf_counter() - t_syn
     dt = rk.timed(dec.run, steps, max(warmup, 1))
@@ -358,27 +373,24 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
                        f"11 025 Hz, 120 LPM, AWGN sigma {args.noise} FS, synthesised in HBM",
            "n_gpus": rk.world, "ranks_rccl": rk.world if rk.comm.is_rccl else 0, "transport": rk.transport_name(), "scaling": "strong",
            "form": ("front end + fused exact decode on one GPU" if fused else
-                    f"front end on each rank's 1/{rk.world} of the stream + sharded exact path (distributed FFT resample and Hilbert: 8 transposes, "
-                    "2 histogram all-reduces, 1 candidate all-gather, 1 stream gather per decode)"),
+                    ("rank 0 alone behind the sharded interface (the cost model declined the distributed plan)" if dec.layout.plan == 0 else
+                     f"front end on each rank's 1/{rk.world} of the stream + sharded exact path (distributed FFT resample and Hilbert, "
+                     f"{'columns layout: 4' if dec.layout.plan == 2 else 'rows layout: 8'} array transposes, 2 histogram all-reduces, 1 candidate all-gather, "
+                     "1 stream gather per decode)")),
            "front_end": fe.describe() + f" -> exact FFT resample {fe.out_rate} -> 11025 Hz",
            "ms_per_step": round(ms, 4), "value": round(n0 / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "steps": steps,
-           "synthesis_s": round(t_syn, 2), "dtype": "f32 front end / f64 exact path",
+           "synthesis_s": round(t_syn, 2), "dtype": "i16 integer-exact ingest / f64 everywhere behind it" if fe.f64 else "f32 front end / f64 exact path",
            "start_frame": int(info.start_frame) if rk.rank == 0 else None, "image": [int(info.width), 4 * int(info.height)] if rk.rank == 0 else None,
            "roofline": roofline_of(prof, 1, alg_bytes, ms, pmc, merge_fft=True), "kernels": kernel_table(prof, 1)}
+    if not fused:
+        out["wire"] = wire_object(rk, dec.dec.params, dec.layout, dec.run, ctx.sync)
     dec.close()
-    for p in keep:
-        ctx.dev_free(p)
+    raw_loader.close()
     # the one-GPU time of the same stream, measured in this run on rank 0, and the efficiency against it
     if rk.world > 1:
         one_ms = None
         if rk.rank == 0:
-            keep2 = []
-
-            def loader2(lo, hi):
-                ptr = synth_device.synth_slice(ctx, sp, lo, hi)
-                keep2.append(ptr)
-                return ptr, hi - lo
-
+            loader2 = synth_device.SliceLoader(ctx, sp)
             one = sharded.FrontEndExactDecoder(ctx, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120, raw_loader=loader2)
             for _ in range(2):
                 one.run()
@@ -389,8 +401,7 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
             ctx.sync()
             one_ms = 1e3 * (time.perf_counter() - t0) / steps
             one.close()
-            for p in keep2:
-                ctx.dev_free(p)
+            loader2.close()
         rk.barrier()
         if rk.rank == 0:
             out["one_gpu_ms"] = round(one_ms, 4)
@@ -430,13 +441,20 @@ def bench_c3(args, rk: Ranks) -> dict:
         form = "fused exact decode on one GPU (int16 capture read in place by the resampler's first pass)"
         closer = lambda: None                                       # noqa: E731
     else:
-        dec = sharded.ShardedDecoder(ctx, rk.comm, n0, 48000, 120, nat.WFX_IN_I16_MONO)
+        dec = sharded.ShardedDecoder(ctx, rk.comm, n0, 48000, 120, nat.WFX_IN_I16_MONO, plan=args.plan)
         lay = dec.layout
-        ptr = synth_device.synth_slice(ctx, sp, int(lay.in_lo), int(lay.in_hi))
+        if lay.nseg > 1:        # columns layout: the rank's columns of every row, segment by segment into one buffer
+            ptr = ctx.dev_malloc(max(2, lay.in_frames * 2))
+            for sgm in range(int(lay.nseg)):
+                a = int(lay.in_lo) + sgm * int(lay.in_seg_stride)
+                synth_device.synth_into(ctx, sp, ptr + sgm * int(lay.in_seg_len) * 2, a, a + int(lay.in_seg_len))
+        else:
+            ptr = synth_device.synth_slice(ctx, sp, int(lay.in_lo), int(lay.in_hi)) if lay.in_hi > lay.in_lo else ctx.dev_malloc(64)
         dec.attach(ptr)
         run, result, n = dec.run, dec.result, dec.n
-        own_in, own_out = int(lay.in_hi - lay.in_lo), int(lay.own_hi - lay.own_lo)
-        form = f"sharded exact path over {rk.world} rank(s): distributed FFT resample and Hilbert"
+        own_in, own_out = lay.in_frames, lay.own_samples
+        form = (f"sharded exact path over {rk.world} rank(s): distributed FFT resample and Hilbert, "
+                f"{ {0: 'single plan (rank 0 alone)', 1: 'rows layout', 2: 'columns layout'}[int(lay.plan)] }")
         closer = lambda: (dec.close(), ctx.dev_free(ptr))          # noqa: E731
     dt = rk.timed(run, args.steps, max(args.warmup, 1))
     ms = 1e3 * dt / args.steps
@@ -452,6 +470,8 @@ def bench_c3(args, rk: Ranks) -> dict:
                       "start_frame": int(info.start_frame) if rk.rank == 0 else None, "ranks_rccl": rk.world if rk.comm.is_rccl else 0},
            "roofline": roofline_of(prof, args.steps, alg, ms, os.path.join(REPO, "profiles", "pmc_traffic_c3.json")),
            "kernels": kernel_table(prof, args.steps), "cpu_baseline": None}
+    if not (rk.world == 1 and not rk.use_rccl):
+        out["wire"] = wire_object(rk, dec.params, dec.layout, run, ctx.sync)
     closer()
     if rk.rank == 0 and rk.world == 1 and not args.no_cpu:
         xs = synth.synth_capture(48000.0, noise=args.noise, seed=0, start_tone_s=5.0, phasing_lines=60, image_lines=1060, stop_tone_s=2.0, black_tail_s=3.0)
@@ -475,7 +495,7 @@ def bench_c2(args, rk: Ranks) -> dict:
         x = np.ascontiguousarray(x[:x.shape[0] - args.trim])
     extra = []
     if args.shard:      # ONE capture, all ranks (exercises the sharded exact path on the 10-minute size)
-        job = sharded.ShardedDecoder(ctx, rk.comm, x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x)
+        job = sharded.ShardedDecoder(ctx, rk.comm, x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x, plan=args.plan)
         n0 = n = job.n
         total = n0
     else:
@@ -512,6 +532,8 @@ def bench_c2(args, rk: Ranks) -> dict:
                                       "1 capture per GPU, no data-path collective"),
                       "ranks_rccl": rk.world if rk.comm.is_rccl else 0, "transport": rk.transport_name()}}
     prof = profile_pass(ctx, job.run, args.steps) if (args.shard or rk.rank == 0) else None      # (a sharded decode is a collective: every rank takes part)
+    if args.shard:
+        out["wire"] = wire_object(rk, job.params, job.layout, job.run, ctx.sync)
     if rk.rank == 0:
         alg_bytes = (n0 * 2 + 4 * n) // (rk.world if args.shard else 1)          # N0 * B_in + 4 N (this rank's share when sharded)
         out["roofline"] = roofline_of(prof, args.steps, alg_bytes, ms, os.path.join(REPO, "profiles", "pmc_traffic.json"))
@@ -625,7 +647,8 @@ def main():
                     "warmup": args.warmup, "ms_per_step": c4["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                     "dtype": c4["dtype"], "data": "synthetic", "config": {k: c4[k] for k in ("workload", "form", "front_end", "ranks_rccl", "start_frame", "image")},
                     "roofline": c4["roofline"], "cpu_baseline": c4.get("cpu_baseline"), "kernels": c4["kernels"],
-                    "one_gpu_ms": c4.get("one_gpu_ms"), "efficiency_vs_one_gpu": c4.get("efficiency_vs_one_gpu")}
+                    "one_gpu_ms": c4.get("one_gpu_ms"), "speedup_vs_one_gpu": c4.get("speedup_vs_one_gpu"),
+                    "efficiency_vs_one_gpu": c4.get("efficiency_vs_one_gpu"), "transport": c4.get("transport"), "wire": c4.get("wire")}
         elif args.workload == "c3":
             line = bench_c3(args, rk)
         else:
@@ -641,7 +664,8 @@ def main():
             if not args.no_c4 and not args.shard and args.batch == 1:
                 rk.barrier()
                 secs = 40.0 if args.short else float(args.iq_seconds)
-                line["c4_strong"] = bench_iq(args, rk, secs, min(args.steps, 10), 2, False)
+                # (with its own CPU leg at N = 1: the oracle's reference-faithful path on a 30-s clip of the same stream format, ~15 s)
+                line["c4_strong"] = bench_iq(args, rk, secs, min(args.steps, 10), 2, not args.no_cpu)
         if rk.rank == 0:
             print(json.dumps(line), flush=True)
         rk.barrier()

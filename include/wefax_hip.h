@@ -301,6 +301,10 @@ int wfx_d_resample_rational(wfx_ctx *ctx, const void *in_dev, int in_kind, size_
  * (*exact = 0): |error| <= ntaps * 2^-53 * sum |coef * in|. */
 int wfx_d_decimate_fir64(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const double *coef,
                          int ntaps, double *out_dev, size_t n_out, int fix_shift, int *exact);
+/* `nbatch` equally shaped jobs in ONE launch (the segments a rank owns in the columns layout of the sharded decode): member b
+ * reads in_dev + b * in_stride frames (b * in_stride * frame bytes must be a multiple of 16) and writes out_dev + b * out_stride */
+int wfx_d_decimate_fir64_batch(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const double *coef,
+                               int ntaps, double *out_dev, size_t n_out, int fix_shift, int *exact, int nbatch, size_t in_stride, size_t out_stride);
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev);
 /* a8: one level of the radix select: hist_dev[q*2048 + digit] += count over values whose bits above the level equal prefix[q] */
 int wfx_d_select_hist(wfx_ctx *ctx, const double *env_dev, size_t n, int level, const uint64_t prefix[4], uint32_t *hist_dev);

@@ -232,16 +232,19 @@ def test_sixty_minute_iq_stream_full_size_properties():
     keep = []
     fe = pp.FrontEnd(fs, stop_rate=16000)
     mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,   # noqa: E731
-                                                     raw_loader=loader_on(c, keep))
+                                                     raw_loader=synth_device.SliceLoader(c, sp), plan="dist")
     try:
         r = sharded.decode_emulated(np.zeros(1, dtype=np.int16), fs, 8, 120, want=("image", "stream"), make_decoder=mk, free_after=keep)
     finally:
         pass
+    assert r["plan"] == 2                                                             # the columns layout: 4 array transposes, not 8
     assert r["sync"]["start_frame"] == s16 and r["sync"]["peaks"] == pk16
     assert np.array_equal(r["digitalized"], st16) and np.array_equal(r["digitalized_blocks"], st16)
     assert np.array_equal(r["image"], img16)
-    own = [b - a for a, b, _, _ in r["layouts"]]
-    assert sum(own) == 39690000 and max(own) - min(own) <= 39690000 // 200           # even shares up to one of the 225 rows
+    own = r["own"]
+    assert sum(own) == 39690000 and max(own) - min(own) <= 39690000 // 200           # even shares up to a few columns of every row
+    sent = sum(e["sent"] for rank_stats in r["wire"] for e in rank_stats)
+    assert 1.2e9 < sent < 1.32e9                                                      # (rows layout: 2.54 GB)
     ctx.close()
 
 

@@ -370,7 +370,7 @@ def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds
     assert np.count_nonzero(np.abs(img1.astype(np.int16) - ref["image"].astype(np.int16)) > 1) <= IMAGE_GT1_FRAC * img1.size
     first = None
     for world in (1, 2, 3, 8):
-        mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, x, lines_per_minute=lpm)      # noqa: E731
+        mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, x, lines_per_minute=lpm, plan="dist")      # noqa: E731
         # (a trimmed clip's hand-over length has no distributed plan -- the distributed transforms take 13-smooth halves only,
         # DESIGN.md 6 -- so it gets the single plan: rank 0 runs the front end over the whole stream and decodes alone; same result)
         assert sharded.layout_supported(fe.n_out(x.shape[0]), fe.out_rate, world, n_out=fe.n_target(x.shape[0]))
@@ -387,9 +387,11 @@ def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds
 
 
 @pytest.mark.gpu
-def test_each_rank_loads_only_its_slice_of_the_raw_stream(ctx):
+@pytest.mark.parametrize("layout", ["dist", "rows"])
+def test_each_rank_loads_only_its_slice_of_the_raw_stream(ctx, layout):
     """The oversampled stream is split `world` ways and never moves: a rank asks its loader for its own frames plus the FIR
-    chain's halo (a few thousand frames), indices wrapping modulo the capture at its two ends."""
+    chain's halo (a few thousand frames), indices wrapping modulo the capture at its two ends -- one range in the rows layout,
+    one range per segment (225 of them) in the columns layout, whose halos add ~0.3 % per segment at the 60-minute size."""
     from wefax_amd import _native as nat
     fs = 192000
     x = _capture(fs, 0.05, seed=2, lpm=240, seconds=40.0, iq=True)
@@ -403,13 +405,24 @@ def test_each_rank_loads_only_its_slice_of_the_raw_stream(ctx):
             asked.append((r, lo, hi))
             return x[np.arange(lo, hi) % n0]
         decs.append(sharded.FrontEndShardedDecoder(ctx, comms[r], fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=240,
-                                                   raw_loader=loader))
-    assert [a[0] for a in asked] == [0, 1, 2, 3]
+                                                   raw_loader=loader, plan=layout))
     halo = fe.halo()
-    for (r, lo, hi), d in zip(asked, decs):
-        share = int(np.ceil((d.layout.in_hi - d.layout.in_lo) * fs / fe.out_rate))       # the rank's rows at the hand-over rate, in raw frames
-        assert hi - lo <= share + 2 * halo + 64 and lo < hi
-    assert asked[0][1] < 0 and asked[-1][2] > n0                         # the ends wrap (the FFT resampler behind is circular)
+    if layout == "rows":
+        assert [a[0] for a in asked] == [0, 1, 2, 3]
+        for (r, lo, hi), d in zip(asked, decs):
+            share = int(np.ceil((d.layout.in_hi - d.layout.in_lo) * fs / fe.out_rate))       # the rank's rows at the hand-over rate, in raw frames
+            assert hi - lo <= share + 2 * halo + 64 and lo < hi
+        assert asked[0][1] < 0 and asked[-1][2] > n0                         # the ends wrap (the FFT resampler behind is circular)
+    else:
+        nseg = decs[0].layout.nseg
+        assert nseg > 1 and all(d.layout.plan == 2 for d in decs) and len(asked) == 4 * nseg
+        for r, d in enumerate(decs):
+            mine = [(lo, hi) for rr, lo, hi in asked if rr == r]
+            share = int(d.layout.in_seg_len) * fs // fe.out_rate                              # a segment at the hand-over rate, in raw frames
+            assert all(hi - lo <= share + 2 * halo + 64 and lo < hi for lo, hi in mine)
+            assert all(b[0] - a[0] == int(d.layout.in_seg_stride) * fs // fe.out_rate for a, b in zip(mine, mine[1:]))   # equally spaced
+            assert sum(hi - lo for lo, hi in mine) == d.raw_frames
+        assert min(lo for _, lo, _ in asked) < 0 and max(hi for _, _, hi in asked) > n0
     for d in decs:
         d.close()
     for c in comms:

@@ -112,7 +112,7 @@ def iq_front_end(worlds):
     ctx.close()
     first = None
     for w in worlds:
-        mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, x, lines_per_minute=120)      # noqa: E731
+        mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, x, lines_per_minute=120, plan="dist")      # noqa: E731
         try:
             r = sharded.decode_emulated(x, fs, w, 120, make_decoder=mk)
         except Exception as e:

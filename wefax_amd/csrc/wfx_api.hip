@@ -560,6 +560,14 @@ int wfx_d_decimate_fir64(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n
     return wfx_dev_decimate_fir64(ctx, in_dev, in_kind, n_in, first, factor, coef, ntaps, out_dev, n_out, fix_shift, exact);
 }
 
+int wfx_d_decimate_fir64_batch(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const double *coef,
+                               int ntaps, double *out_dev, size_t n_out, int fix_shift, int *exact, int nbatch, size_t in_stride, size_t out_stride)
+{
+    CHECK_CTX(ctx);
+    if (!in_dev || !out_dev || !coef) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return wfx_dev_decimate_fir64(ctx, in_dev, in_kind, n_in, first, factor, coef, ntaps, out_dev, n_out, fix_shift, exact, nbatch, in_stride, out_stride);
+}
+
 int wfx_d_resample_rational(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t base0, int p, int q, const float *table,
                             int taps, int64_t m0, float *out_dev, size_t n_out)
 {

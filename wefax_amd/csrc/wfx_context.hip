@@ -157,7 +157,7 @@ void wfx_destroy(wfx_ctx *ctx)
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     wfx_devbuf *bufs[] = {&ctx->b_in, &ctx->b_x, &ctx->b_audio, &ctx->b_work, &ctx->b_work2, &ctx->b_envraw,
                           &ctx->b_env, &ctx->b_dig, &ctx->b_corr, &ctx->b_img, &ctx->b_hist, &ctx->b_tmp,
-                          &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps, &ctx->b_cand, &ctx->b_pcoef, &ctx->b_seg, &ctx->b_png};
+                          &ctx->b_tmp2, &ctx->b_w256, &ctx->b_scal, &ctx->b_taps, &ctx->b_cand, &ctx->b_pcoef, &ctx->b_seg, &ctx->b_png, &ctx->b_synth};
     if (ctx->h_png) hipHostFree(ctx->h_png);
     for (auto *b : bufs) free_buf(*b);
     for (auto &e : ctx->coef_cache) (void)hipFree(e.dev);

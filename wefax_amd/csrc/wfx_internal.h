@@ -82,7 +82,8 @@ struct wfx_ctx {
 
     // named device buffers (grown on demand, reused across calls)
     wfx_devbuf b_in, b_x, b_audio, b_work, b_work2, b_envraw, b_env, b_dig, b_corr,
-        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand, b_pcoef, b_seg, b_png;
+        b_img, b_hist, b_tmp, b_tmp2, b_w256, b_scal, b_taps, b_cand, b_pcoef, b_seg, b_png, b_synth;
+    unsigned long long synth_key = 0;       // recipe whose chunk phases b_synth holds (wfx_synth_capture)
     void *h_png = nullptr;        // pinned host image of the last PNG file (wfx_decode_png)
     size_t h_png_cap = 0;
     bool w256_ready = false;
@@ -348,8 +349,10 @@ int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long
 // wfx_polyphase.hip
 int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const float *coef, int ntaps,
                          void *out, int out_f64, uint64_t n_out);
+// nbatch > 1: that many equally shaped jobs in one launch -- member b reads in + b * in_stride frames (a multiple of 16 bytes) and
+// writes out + b * out_stride
 int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const double *coef, int ntaps,
-                           double *out, uint64_t n_out, int fix_shift, int *exact_out);
+                           double *out, uint64_t n_out, int fix_shift, int *exact_out, int nbatch = 1, uint64_t in_stride = 0, uint64_t out_stride = 0);
 int wfx_dev_resample_rational(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t base0, int p, int q, const float *table,
                               int T, int64_t m0, float *out, uint64_t n_out);
 

@@ -11,6 +11,8 @@
 // HBM-bound; fp32 accumulation in one canonical order per output sample, so the result
 // does not depend on how a capture is cut into slices.  The stereo/IQ merge of
 // wefax.py:360-373 ((int16)(L+R) wrapped, /2) is fused into the load.
+#include <algorithm>
+
 #include "wfx_internal.h"
 
 namespace {
@@ -233,8 +235,12 @@ static int pp_swz_stride(int cols, int esz) { return esz == 8 ? cols + 2 * (cols
 template <int IN, typename OUT, bool ALIGNED, int Q4T, int MODE = 0>
 __global__ void __launch_bounds__(PP_THREADS, MODE == 1 ? PP_EXACT_WAVES : MODE == 2 ? PP_F64_WAVES : PP_MINB)
 decimate_kernel(const void *__restrict__ in, long long n_in, long long first, int M, int log2m, const float *__restrict__ cp, int q4_arg,
-                OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign, int flush_rows = 0)
+                OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign, int flush_rows, long long in_bs, long long out_bs)
 {
+    // blockIdx.y: member of a batch of equally shaped jobs (the segments of a rank's columns layout, wfx_shard.hip): its input
+    // starts in_bs BYTES (a multiple of 16: the same alignment for every member), its output out_bs elements further on
+    in = (const unsigned char *)in + (size_t)blockIdx.y * (size_t)in_bs;
+    out += (size_t)blockIdx.y * (size_t)out_bs;
     // log2m < 0: M is not a power of two (/3 at the end of a chain) -- rows are never split over thread groups then and the
     // window position of a chunk is found by a division
     const int q4 = Q4T ? Q4T : q4_arg;        // Q4T > 0: the tap loop has a compile-time trip count and unrolls (short filters)
@@ -713,7 +719,7 @@ int launch_decimate(wfx_ctx *ctx, const void *in, long long n_in, long long firs
     if (lds > 48 * 1024) WFX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     wfx_prof_begin(ctx, (IN == WFX_IN_F32_MONO ? K_POLYPHASE : K_POLYPHASE_IN));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PP_THREADS), lds, ctx->stream, in, n_in, first, M, log2m, cp, q4, out, n_out, ilog2_exact(tb),
-                       row_stride, misalign, 0);
+                       row_stride, misalign, 0, 0ll, 0ll);
     wfx_prof_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch decimate_kernel");
@@ -723,7 +729,7 @@ int launch_decimate(wfx_ctx *ctx, const void *in, long long n_in, long long firs
 // MODE 1 (exact, int16 in, aligned) and MODE 2 (float64 arithmetic, any input kind): float64 out
 template <int IN, int MODE>
 int launch_decimate64(wfx_ctx *ctx, const void *in, long long n_in, long long first, int M, const void *cp, int q4, double *out, long long n_out,
-                      bool aligned, int flush_rows)
+                      bool aligned, int flush_rows, int nbatch = 1, long long in_bs = 0, long long out_bs = 0)
 {
     typedef pp_in<IN> A;
     const int log2m = ilog2_exact(M);
@@ -743,16 +749,17 @@ int launch_decimate64(wfx_ctx *ctx, const void *in, long long n_in, long long fi
     if (lds_x > (size_t)PP_LDS_BYTES || lds > 150 * 1024) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
     const int misalign = (int)(((uintptr_t)in & 15u) / A::BYTES);
     const long long ntiles = (n_out + tb - 1) / tb;
-    const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
-    void (*kern)(const void *, long long, long long, int, int, const float *, int, double *, long long, int, int, int, int);
+    unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
+    if (nbatch > 1 && (long long)grid * nbatch > 8192) grid = (unsigned)std::max<long long>(1, 8192 / nbatch);      // (tiles are walked grid-stride)
+    void (*kern)(const void *, long long, long long, int, int, const float *, int, double *, long long, int, int, int, int, long long, long long);
     if (MODE == 1)
         kern = q4 == 2 ? decimate_kernel<IN, double, true, 2, MODE> : q4 == 3 ? decimate_kernel<IN, double, true, 3, MODE> : decimate_kernel<IN, double, true, 0, MODE>;
     else
         kern = aligned ? decimate_kernel<IN, double, true, 0, MODE> : decimate_kernel<IN, double, false, 0, MODE>;
     if (lds > 48 * 1024) WFX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     wfx_prof_begin(ctx, (IN == WFX_IN_F64_MONO ? K_POLYPHASE : K_POLYPHASE_IN));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PP_THREADS), lds, ctx->stream, in, n_in, first, M, log2m, (const float *)cp, q4, out, n_out,
-                       ilog2_exact(tb), row_stride, misalign, flush_rows);
+    hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(PP_THREADS), lds, ctx->stream, in, n_in, first, M, log2m, (const float *)cp, q4, out, n_out,
+                       ilog2_exact(tb), row_stride, misalign, flush_rows, in_bs, out_bs);
     wfx_prof_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch decimate_kernel (float64 out)");
@@ -840,9 +847,10 @@ int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_i
 // fix_shift 0, or taps the exact form cannot take at that shift (a tap >= 2^23 grid steps, sums that could overflow 32 bits
 // for the worst-case input): MODE 2.
 int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const double *coef, int ntaps,
-                           double *out, uint64_t n_out, int fix_shift, int *exact_out)
+                           double *out, uint64_t n_out, int fix_shift, int *exact_out, int nbatch, uint64_t in_stride, uint64_t out_stride)
 {
     if (exact_out) *exact_out = 0;
+    if (nbatch < 1 || nbatch > 65535) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: batch of %d", nbatch);
     if (M < 1 || M > 64) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: factor %d is not in 1..64", M);
     if (ntaps < 1 || ntaps > 4096) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps", ntaps);
     if (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_I16_STEREO && in_kind != WFX_IN_F64_MONO)
@@ -852,6 +860,8 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
     const int ebytes = in_kind == WFX_IN_I16_MONO ? 2 : (in_kind == WFX_IN_I16_STEREO ? 4 : 8);
     if ((uintptr_t)in % ebytes) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: misaligned input pointer");
     const int misalign = (int)(((uintptr_t)in & 15u) / ebytes);
+    const long long in_bs = nbatch > 1 ? (long long)in_stride * ebytes : 0, out_bs = nbatch > 1 ? (long long)out_stride : 0;
+    if (in_bs % 16) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: the members of a batch must start a multiple of 16 bytes apart (%lld)", in_bs);
     const bool aligned = M >= per16 && ilog2_exact(M) >= 0;
     int d = 0;
     if (aligned) {
@@ -916,8 +926,8 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
             if (!dtab) return WFX_ERR_HIP;
             if (exact_out) *exact_out = 1;
             const int fr = flush_rows | (fix_shift << 8);
-            return in_kind == WFX_IN_I16_MONO ? launch_decimate64<WFX_IN_I16_MONO, 1>(ctx, in, ni, first, M, dtab, q4, out, no, true, fr)
-                                              : launch_decimate64<WFX_IN_I16_STEREO, 1>(ctx, in, ni, first, M, dtab, q4, out, no, true, fr);
+            return in_kind == WFX_IN_I16_MONO ? launch_decimate64<WFX_IN_I16_MONO, 1>(ctx, in, ni, first, M, dtab, q4, out, no, true, fr, nbatch, in_bs, out_bs)
+                                              : launch_decimate64<WFX_IN_I16_STEREO, 1>(ctx, in, ni, first, M, dtab, q4, out, no, true, fr, nbatch, in_bs, out_bs);
         }
     }
     std::vector<double> cp((size_t)M * 4 * q4, 0.0);
@@ -925,9 +935,9 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
     const float *dcoef = wfx_coef_device(ctx, (const float *)cp.data(), cp.size() * 2);
     if (!dcoef) return WFX_ERR_HIP;
     switch (in_kind) {
-    case WFX_IN_I16_MONO: return launch_decimate64<WFX_IN_I16_MONO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0);
-    case WFX_IN_I16_STEREO: return launch_decimate64<WFX_IN_I16_STEREO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0);
-    default: return launch_decimate64<WFX_IN_F64_MONO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0);
+    case WFX_IN_I16_MONO: return launch_decimate64<WFX_IN_I16_MONO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0, nbatch, in_bs, out_bs);
+    case WFX_IN_I16_STEREO: return launch_decimate64<WFX_IN_I16_STEREO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0, nbatch, in_bs, out_bs);
+    default: return launch_decimate64<WFX_IN_F64_MONO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0, nbatch, in_bs, out_bs);
     }
 }
 

@@ -164,11 +164,20 @@ int wfx_synth_capture(wfx_ctx *ctx, const wfx_synth_params *p, uint64_t lo, uint
     if (n_total == 0 || lo >= hi || hi > n_total) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "synth: frames [%llu, %llu) outside the capture of %llu", (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)n_total);
     synth_track k;
     make_track(*p, k);
-    const int c0 = (int)(lo / SY_CHUNK), c1 = (int)((hi + SY_CHUNK - 1) / SY_CHUNK);       // chunks of the range; sums are needed for [0, c1)
-    WFX_TRY(wfx_reserve(ctx, ctx->b_tmp2, (size_t)c1 * 2 * sizeof(double) + 64));
-    double *sums = (double *)ctx->b_tmp2.p, *offs = sums + c1;
-    WFX_LAUNCH(ctx, K_MERGE, synth_chunk_sums, dim3(c1), dim3(256), k, (long long)n_total, c1, sums);
-    WFX_LAUNCH(ctx, K_MERGE, synth_scan_chunks, dim3(1), dim3(64), (const double *)sums, c1, k.fs, offs);
+    const int c0 = (int)(lo / SY_CHUNK), c1 = (int)((hi + SY_CHUNK - 1) / SY_CHUNK);       // chunks of the range
+    // the phase at the start of every chunk of the capture: computed once per recipe and kept with the context (a rank of the
+    // columns layout asks for 225 slices of one capture; the serial scan over 84 000 chunks of the 60-minute stream takes ~10 ms)
+    const int call = (int)((n_total + SY_CHUNK - 1) / SY_CHUNK);
+    unsigned long long key = 1469598103934665603ull;
+    for (size_t i = 0; i < sizeof(wfx_synth_params); ++i) key = (key ^ ((const unsigned char *)p)[i]) * 1099511628211ull;
+    if (!ctx->b_synth.p || ctx->synth_key != key) {
+        WFX_TRY(wfx_reserve(ctx, ctx->b_synth, (size_t)call * 2 * sizeof(double) + 64));
+        double *sums_all = (double *)ctx->b_synth.p + call;
+        WFX_LAUNCH(ctx, K_MERGE, synth_chunk_sums, dim3(call), dim3(256), k, (long long)n_total, call, sums_all);
+        WFX_LAUNCH(ctx, K_MERGE, synth_scan_chunks, dim3(1), dim3(64), (const double *)sums_all, call, k.fs, (double *)ctx->b_synth.p);
+        ctx->synth_key = key;
+    }
+    const double *offs = (const double *)ctx->b_synth.p;
     WFX_LAUNCH(ctx, K_MERGE, synth_emit, dim3(c1 - c0), dim3(256), k, (long long)lo, (long long)hi, c0, (const double *)offs, p->amplitude, p->noise,
                (unsigned long long)p->seed, p->iq, (short *)dev_out);
     return 0;

@@ -23,6 +23,7 @@ from __future__ import annotations
 import socket
 import struct
 import time
+from fractions import Fraction
 
 import numpy as np
 
@@ -340,8 +341,12 @@ class FrontEndDevice:
 
     ``raw``: host array (int16 [n] or [n, 2]) or a (device pointer, frames) pair that stays owned by the caller."""
 
-    def __init__(self, ctx: nat.Context, chain, raw, in_kind: int):
+    def __init__(self, ctx: nat.Context, chain, raw, in_kind: int, nbatch: int = 1, raw_stride: int = 0):
+        """``nbatch`` > 1 (the segments a rank owns in the columns layout of the sharded decode): ``raw`` holds that many equally
+        long slices, ``raw_stride`` frames apart (a multiple of 16 bytes); every stage runs them in ONE launch and the result is
+        ``nbatch`` rows of ``n_out`` samples back to back.  Float64 chains only."""
         self.ctx, self.chain, self.in_kind = ctx, chain, in_kind
+        self.nbatch = int(nbatch)
         self.ptrs = []
         if isinstance(raw, tuple):
             self.p_raw, self.n_raw = int(raw[0]), int(raw[1])
@@ -350,14 +355,20 @@ class FrontEndDevice:
             self.n_raw = int(raw.shape[0])
             self.p_raw = self._alloc(raw.nbytes)
             ctx.dev_upload(self.p_raw, raw)
+        self.raw_stride = int(raw_stride) if self.nbatch > 1 else 0
         a, b = chain[-1][1]
         self.n_out = b - a
-        self.p_out = self._alloc(8 * self.n_out)
+        self.p_out = self._alloc(8 * self.n_out * self.nbatch)
         self.p_stage = {}
         # a chain of decimations runs in float64 throughout (integer-exact ingest, polyphase.FrontEnd._finish)
         self.f64 = all(st.kind == "decimate" for st, _, _ in chain) and bool(getattr(chain[0][0], "f64_chain", False))
+        if self.nbatch > 1 and not self.f64:
+            raise ValueError("batched front end: float64 chains of decimations only")
+        self.stage_stride = {}
         for k, (st, (a, b), _) in enumerate(chain[:-1]):
-            self.p_stage[k] = self._alloc((8 if self.f64 else 4) * (b - a))
+            stride = (b - a) + ((b - a) & 1)                    # members of a batch start a multiple of 16 bytes apart
+            self.stage_stride[k] = stride
+            self.p_stage[k] = self._alloc((8 if self.f64 else 4) * stride * self.nbatch)
         self.exact_ingest = None
 
     def _alloc(self, nbytes):
@@ -374,7 +385,9 @@ class FrontEndDevice:
             n_out = b - a
             out = self.p_out if last else self.p_stage[k]
             if st.kind == "decimate" and self.f64:
-                ex = self.ctx.d_decimate_fir64(cur, kind, n_cur, 0, st.factor, st.coef64, out, n_out, st.fix_shift if k == 0 else 0)
+                in_stride = self.raw_stride if k == 0 else self.stage_stride[k - 1]
+                ex = self.ctx.d_decimate_fir64(cur, kind, n_cur, 0, st.factor, st.coef64, out, n_out, st.fix_shift if k == 0 else 0,
+                                               nbatch=self.nbatch, in_stride=in_stride, out_stride=n_out if last else self.stage_stride[k])
                 if k == 0:
                     self.exact_ingest = ex
                 cur, kind, n_cur = out, nat.WFX_IN_F64_MONO, n_out
@@ -388,7 +401,7 @@ class FrontEndDevice:
             cur, kind, n_cur = out, nat.WFX_IN_F32_MONO, n_out
 
     def fetch(self) -> np.ndarray:
-        return self.ctx.dev_download(self.p_out, (self.n_out,), np.float64)
+        return self.ctx.dev_download(self.p_out, (self.n_out * self.nbatch,), np.float64)
 
     def close(self):
         for p in self.ptrs:
@@ -448,11 +461,13 @@ class FrontEndShardedDecoder:
     between GPUs; what is exchanged is the transposes of the transforms at the hand-over rate and at 11 025 Hz."""
 
     def __init__(self, ctx, comm, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None,
-                 notch=None, plan="rows"):
+                 notch=None, plan="auto"):
         if not frontend.exact_tail:
             raise ValueError("the sharded form needs FrontEnd(stop_rate=...): the exact resampler takes the last step")
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
         n_fe = frontend.n_out(n_in_total)
+        if not getattr(frontend, "f64", False):            # (chains with a rational stage: one contiguous range per rank)
+            plan = plan_code(plan) | 16
         self.dec = ShardedDecoder(ctx, comm, n_fe, frontend.out_rate, lines_per_minute, nat.WFX_IN_F64_MONO, notch,
                                   n_out=frontend.n_target(n_in_total), plan=plan)
         lay = self.dec.layout
@@ -460,9 +475,46 @@ class FrontEndShardedDecoder:
         if lay.in_hi == lay.in_lo:
             # a rank that owns nothing (the SINGLE plan of a capture with no distributed form: rank 0 decodes alone) has no front
             # end to run; it takes part in the phases with a placeholder input
-            self.chain, self.fe, self.raw_range = [], None, (0, 0)
+            self.chain, self.fe, self.raw_range, self.raw_frames = [], None, (0, 0), 0
             self._none = ctx.dev_malloc(64)
             self.dec.attach(self._none)
+            return
+        if lay.nseg > 1:
+            # COLUMNS layout: the rank owns nseg equally long, equally spaced segments of the hand-over-rate signal -- the front end
+            # runs over the raw frames of every one of them (its own halo around each: a few thousand frames, 0.3 % of a segment
+            # of the 60-minute stream) in one batched launch per stage and delivers the rows the resampler's first pass reads
+            assert lay.in_halo == 0
+            ratio = Fraction(frontend.fs_in, frontend.out_rate)
+            assert ratio.denominator == 1, "a chain of decimations only"
+            self.chain = frontend.chain(int(lay.in_lo), int(lay.in_lo + lay.in_seg_len))
+            ia, ib = self.chain[0][2]
+            seg_raw = int(lay.in_seg_stride) * int(ratio)                       # raw frames between the starts of two segments
+            if in_kind is None:
+                in_kind = 1 if (x is not None and np.asarray(x).ndim == 2) else 0
+            fb = 4 if in_kind == nat.WFX_IN_I16_STEREO else 2
+            per16 = 16 // fb
+            rstride = -(-(ib - ia) // per16) * per16
+            nseg = int(lay.nseg)
+            p_raw = ctx.dev_malloc(nseg * rstride * fb + 64)
+            self._raw_ptr = p_raw
+            if raw_loader is not None and hasattr(raw_loader, "into"):
+                for sgm in range(nseg):                                         # (a loader that writes where it is told: no copy)
+                    raw_loader.into(p_raw + sgm * rstride * fb, ia + sgm * seg_raw, ib + sgm * seg_raw)
+            elif raw_loader is not None:
+                for sgm in range(nseg):
+                    got = raw_loader(ia + sgm * seg_raw, ib + sgm * seg_raw)
+                    if isinstance(got, tuple):
+                        ctx.dev_copy(p_raw + sgm * rstride * fb, int(got[0]), (ib - ia) * fb)
+                    else:
+                        ctx.dev_upload(p_raw + sgm * rstride * fb, np.ascontiguousarray(got, dtype=np.int16))
+            else:
+                xa = np.asarray(x)
+                idx = (ia + np.arange(nseg, dtype=np.int64)[:, None] * seg_raw + np.arange(rstride, dtype=np.int64)[None, :]) % n_in_total
+                ctx.dev_upload(p_raw, np.ascontiguousarray(xa[idx.reshape(-1)], dtype=np.int16))
+            self.fe = FrontEndDevice(ctx, self.chain, (p_raw, ib - ia), in_kind, nbatch=nseg, raw_stride=rstride)
+            self.dec.attach(self.fe.p_out)
+            self.raw_range = (ia, ia + (nseg - 1) * seg_raw + (ib - ia))
+            self.raw_frames = nseg * (ib - ia)
             return
         self.chain = frontend.chain(int(lay.in_lo), int(lay.in_hi))
         ia, ib = self.chain[0][2]
@@ -472,6 +524,7 @@ class FrontEndShardedDecoder:
         self.fe = FrontEndDevice(ctx, self.chain, raw, in_kind)
         self.dec.attach(self.fe.p_out)
         self.raw_range = (ia, ib)
+        self.raw_frames = ib - ia
 
     def run(self):
         self.front_end()
@@ -489,6 +542,9 @@ class FrontEndShardedDecoder:
 
     def close(self):
         self.dec.close()
+        if getattr(self, "_raw_ptr", None):
+            self.dec.ctx.dev_free(self._raw_ptr)
+            self._raw_ptr = None
         if self.fe is not None:
             self.fe.close()
         elif getattr(self, "_none", None):

@@ -30,16 +30,46 @@ def capture_frames(fs: float, lpm: int = 120, start_tone_s: float = 5.0, phasing
     return int(round(dur * fs))
 
 
-def synth_slice(ctx: nat.Context, params: nat.SynthParams, lo: int, hi: int) -> int:
-    """Device pointer (owned by the caller: ``ctx.dev_free``) to frames lo..hi-1 of the capture, global indices wrapping
-    modulo its length.  int16 [hi - lo] or, with ``params.iq``, interleaved [hi - lo, 2]."""
+def synth_into(ctx: nat.Context, params: nat.SynthParams, ptr: int, lo: int, hi: int):
+    """Frames lo..hi-1 of the capture (global indices wrapping modulo its length) into device memory at ``ptr``."""
     n0 = int(ctx.lib.wfx_synth_frames(params))
     fb = 4 if params.iq else 2
-    ptr = ctx.dev_malloc((hi - lo) * fb)
     g = lo
     while g < hi:
         s = g % n0
         c = min(hi - g, n0 - s)
         ctx.synth_capture(params, s, s + c, ptr + (g - lo) * fb)
         g += c
+
+
+def synth_slice(ctx: nat.Context, params: nat.SynthParams, lo: int, hi: int) -> int:
+    """Device pointer (owned by the caller: ``ctx.dev_free``) to frames lo..hi-1 of the capture, global indices wrapping
+    modulo its length.  int16 [hi - lo] or, with ``params.iq``, interleaved [hi - lo, 2]."""
+    fb = 4 if params.iq else 2
+    ptr = ctx.dev_malloc((hi - lo) * fb)
+    synth_into(ctx, params, ptr, lo, hi)
     return ptr
+
+
+class SliceLoader:
+    """``raw_loader`` for the front-end decoders of ``sharded.py``: slices of a synthesised capture, each in device memory of
+    its own (``loader(lo, hi)``; freed by ``close``) or written where the decoder wants them (``loader.into(ptr, lo, hi)``: the
+    segments of the columns layout go straight into the decoder's batch buffer)."""
+
+    def __init__(self, ctx: nat.Context, params: nat.SynthParams):
+        self.ctx, self.params, self.keep, self.calls = ctx, params, [], []
+
+    def __call__(self, lo: int, hi: int):
+        ptr = synth_slice(self.ctx, self.params, lo, hi)
+        self.keep.append(ptr)
+        self.calls.append((lo, hi))
+        return ptr, hi - lo
+
+    def into(self, ptr: int, lo: int, hi: int):
+        synth_into(self.ctx, self.params, ptr, lo, hi)
+        self.calls.append((lo, hi))
+
+    def close(self):
+        for p in self.keep:
+            self.ctx.dev_free(p)
+        self.keep = []
