@@ -598,8 +598,8 @@ def bench_c2(args, rk: Ranks) -> dict:
 
 def bench_general_lengths(args, rk: Ranks, x) -> dict:
     """The reference decodes whatever length the wav has (wefax.py:174 calls scipy on it).  The headline length has a 13-smooth
-    half (every BASELINE size does) and takes the unpadded transforms; one sample more makes it odd (unpacked convolution,
-    padded to a power of two >= 2N - 1), two samples more even with a half that has a large prime factor (packed convolution
+    half (every BASELINE size does) and takes the unpadded transforms; one sample more makes it odd (real samples against scipy's real
+    kernel: two packed transforms of M/2 >= N points and a glue pass, round 4), two samples more even with a half that has a large prime factor (packed convolution
     zero-padded to the cheapest 13-smooth M >= N - 1).  Same capture plus 1 / 2 trailing samples, same kernels otherwise."""
     import numpy as np
     from wefax_amd.wefax import DecodeJob
@@ -625,7 +625,10 @@ def bench_general_lengths(args, rk: Ranks, x) -> dict:
             rec["form"] = (f"packed convolution of n/2 = {n // 2} points zero-padded to the 13-smooth M = {m} ({nat.plan_describe(m)})" if m else
                            "packed convolution padded to a power of two")
         else:
-            rec["form"] = f"odd length: unpacked convolution padded to 2^{int(np.ceil(np.log2(2 * n - 1)))}"
+            mh = nat.padded_length(n)
+            rec["form"] = (f"odd length: real samples x real kernel as two PACKED transforms of M/2 = {mh} points ({nat.plan_describe(mh)}) + one glue pass" if mh
+                           else f"odd length: unpacked convolution padded to 2^{int(np.ceil(np.log2(2 * n - 1)))}")
+        rec["kernels"] = kernel_table(profile_pass(ctx, job.run, steps), steps)
         if not args.no_cpu:
             ref = cpu_baseline(xe, 11025, 120, False, "")["_result"]
             rec["digitalized_mismatches"] = int(np.count_nonzero(job.fetch("digitalized") != ref["digitalized"]))

@@ -1,10 +1,14 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04a
 O=gpurun_out/r04a
-timeout 1500 python -m pytest tests/test_polyphase.py tests/test_gpu_configs.py -m gpu -q -x > $O/pytest_fe.log 2>&1
-tail -5 $O/pytest_fe.log
-WFX_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload iq --no-cpu --steps 5 > $O/bench_iq_rccl1_cols.json 2> $O/err1.log; head -c 700 $O/bench_iq_rccl1_cols.json; echo
-WFX_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload iq --no-cpu --steps 5 --plan rows > $O/bench_iq_rccl1_rows.json 2>> $O/err1.log; head -c 300 $O/bench_iq_rccl1_rows.json; echo
-WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --workload iq --steps 3 --warmup 1 --no-cpu --plan dist > $O/bench_iq_shm8_cols.json 2>> $O/err1.log; head -c 400 $O/bench_iq_shm8_cols.json; echo
-WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --workload iq --steps 3 --warmup 1 --no-cpu --plan rows > $O/bench_iq_shm8_rows.json 2>> $O/err1.log; head -c 400 $O/bench_iq_shm8_rows.json; echo
-tail -5 $O/err1.log
+timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_all.log 2>&1
+tail -5 $O/pytest_all.log
+timeout 600 python bench.py --no-c4 --no-cpu --no-pcie > $O/bench_odd2.json 2> $O/err2.log
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r04a/bench_odd2.json").read().strip().splitlines()[-1])
+print(d["ms_per_step"])
+for k in ("n_plus_1","n_plus_2"):
+    g=d["general_length"][k]
+    print(k, g["ms_per_step"], g["form"][:80])
+PY

@@ -134,7 +134,7 @@ int wfx_analytic_env(wfx_ctx *ctx, const double *x, size_t n, int hilbert_mode, 
     if (!x || !env_out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
     if (n == 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "N must be positive.");
     ctx->ran = false;
-    WFX_TRY(wfx_reserve(ctx, ctx->b_audio, n * 8));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_audio, n * 8 + 16));
     WFX_TRY(wfx_reserve(ctx, ctx->b_envraw, n * 8));
     WFX_TRY(wfx_reserve(ctx, ctx->b_env, n * 8 + 64));
     WFX_TRY(h2d(ctx, ctx->b_audio.p, x, n * 8));

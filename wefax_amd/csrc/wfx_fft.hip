@@ -595,7 +595,9 @@ __global__ void __launch_bounds__(256) hconv_env(const cplx *__restrict__ V, con
 {
     for (long long n = blockIdx.x * 256ll + threadIdx.x; n < N; n += (long long)gridDim.x * 256ll) {
         double H;
-        if (!packed)
+        if (packed == 2)
+            H = ((const double *)V)[n];
+        else if (!packed)
             H = V[n].x;
         else if ((n & 1) == 0)
             H = V[n >> 1].x;
@@ -678,7 +680,10 @@ __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__
     if (l0hist)
         for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
     const long long step = (long long)gridDim.x * 1024;
-    if (packed) {
+    if (packed == 1 || packed == 2) {
+        // packed == 2: H is a flat array of doubles (odd lengths on the packed real transforms): the same tile structure, the pair's
+        // two values of H by two 8-byte loads instead of one 16-byte one
+        const double *Hf = (const double *)V;
         cplx pv[3];
         double px0[3], px1[3];
         auto prefetch = [&](long long base) {
@@ -687,9 +692,13 @@ __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__
                 const long long m = base / 2 - 1 + t + 256 * k;            // pair (2m - 1, 2m)
                 const long long mc = m < 0 ? 0 : (m >= L ? 0 : m);       // H[N - 1] = V[0].y
                 const long long i1 = 2 * m, i0 = 2 * m - 1;
-                pv[k] = V[mc];
-                px0[k] = x[i0 < 0 ? 0 : (i0 >= N ? N - 1 : i0)];
-                px1[k] = x[i1 < 0 ? 0 : (i1 >= N ? N - 1 : i1)];
+                const long long c0 = i0 < 0 ? 0 : (i0 >= N ? N - 1 : i0), c1 = i1 < 0 ? 0 : (i1 >= N ? N - 1 : i1);
+                if (packed == 2)
+                    pv[k] = make_double2(Hf[c1], Hf[c0]);
+                else
+                    pv[k] = V[mc];
+                px0[k] = x[c0];
+                px1[k] = x[c1];
             }
         };
         long long base = (long long)blockIdx.x * 1024;
@@ -754,7 +763,8 @@ __global__ void __launch_bounds__(256) hconv_env_median(const cplx *__restrict__
             __syncthreads();
             for (int i = t; i < 1024 + 4; i += 256) {
                 const long long n = base - 2 + i;
-                tile[i] = (n >= 0 && n < N) ? env_abs(x[n], V[n].x) : 0.0;
+                // (packed == 2: H as a flat array of doubles -- odd lengths on the packed real transforms; 0: one point per sample)
+                tile[i] = (n >= 0 && n < N) ? env_abs(x[n], packed == 2 ? ((const double *)V)[n] : V[n].x) : 0.0;
             }
             __syncthreads();
 #pragma unroll
@@ -1084,6 +1094,19 @@ static int hilbert_conv(wfx_ctx *ctx, const double *x, uint64_t n, cplx **W_out,
         if (handled) {
             *packed_out = 1;
             *L_out = n / 2;
+            return 0;
+        }
+    }
+    // odd N: samples and kernel are real -- two packed transforms of M/2 >= N points and a glue pass (wfx_mrfft.hip, round 4);
+    // the result is H as a flat array of doubles (*packed_out = 2).  x[n] (the odd sample's partner in the last pair) must be zero:
+    // every caller hands over a context buffer with slack behind the n samples
+    if ((n & 1) == 1 && n >= 8192 && !ctx->force_pow2 && !getenv("WFX_NO_REAL_ODD")) {
+        WFX_HIP(ctx, hipMemsetAsync((void *)(x + n), 0, sizeof(double), ctx->stream));
+        int handled = 0;
+        WFX_TRY(wfx_dev_hilbert_conv_mr_real(ctx, x, n, W_out, &handled));
+        if (handled) {
+            *packed_out = 2;
+            *L_out = n;
             return 0;
         }
     }

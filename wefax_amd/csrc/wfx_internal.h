@@ -337,6 +337,9 @@ int wfx_dev_hilbert_conv_mr(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_
 // even n whose half is NOT 13-smooth: the same packed convolution zero-padded to the cheapest 13-smooth M >= n - 1 with a
 // radix-pair plan (at most a few per cent above n - 1); *handled = 0 when no such M exists (tiny n): the caller pads to 2^k
 int wfx_dev_hilbert_conv_mr_padded(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out, int *handled);
+// odd n: the real sequence against scipy's real kernel as two PACKED transforms of M/2 >= n points (13-smooth) and one glue pass;
+// H[i] = ((double *)*V_out)[i].  x[n] must be readable and ZERO (the last packed pair).  *handled = 0 when n is too small
+int wfx_dev_hilbert_conv_mr_real(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out, int *handled);
 long long wfx_mr_padded_length(long long min_len);
 void wfx_mr_smooth_numbers(long long lo, long long hi, std::vector<long long> &out);       // ascending 13-smooth numbers in [lo, hi]
 int wfx_dev_hilbert_kernel_rows(wfx_ctx *ctx, cplx *dst, long long p0, long long count, long long N, long long M);

@@ -1673,8 +1673,160 @@ int wfx_dev_hilbert_conv_mr_padded(wfx_ctx *ctx, const double *x, uint64_t n, cp
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ODD capture lengths (round 4): scipy's kernel for odd N has taps on every lag, so nothing packs the way even lengths do -- but
+// samples and kernel are REAL, and a real linear convolution embedded in a cyclic one of M >= 2N points (M even) is two packed
+// transforms of M/2 points with one glue pass between them (the resampler's form, resample_mr_glue):
+//   z'[q] = x[2q+1] + i x[2q] (the passes' packed-real load; zeros behind the capture), Z' = FFT_{M/2}(z')
+//   Z[k] = i conj Z'[M/2 - k] is the transform of x[2q] + i x[2q+1];  X[k] = (Z[k] + conj Z[M/2-k]) / 2 - (i/2) e^{-2 pi i k/M} (Z[k] - conj Z[M/2-k])
+//   Y[k] = X[k] * i c[k]   (the kernel g_ext is real and ODD in the lag: its transform is purely imaginary; c[k] / M from a table
+//                           made once per N by these very passes)
+//   W[k] = (Y[k] + conj Y[M/2-k]) + i e^{2 pi i k/M} (Y[k] - conj Y[M/2-k]);  IFFT_{M/2}(W)[q] = H[2q] + i H[2q+1]
+// Half the points of the complex-transform-of-a-real-sequence form rounds 1-3 used for odd N (2^24 points for the 10-minute
+// capture plus one sample: 2.24x the headline), at the price of the glue pass: one read and one write of the M/2-point array.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mr_real_kernel_fill(cplx *__restrict__ G, long long N, long long Mh, double inv_m)
+{
+    const long long M = 2 * Mh;
+    for (long long q = blockIdx.x * 256ll + threadIdx.x; q < Mh; q += (long long)gridDim.x * 256ll) {
+        double v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long i = 2 * q + h;
+            v[h] = (i < N || M - i < N) ? mr_hilbert_tap_odd(i < N ? i : i - M, N) * inv_m : 0.0;
+        }
+        G[q] = make_double2(v[0], v[1]);
+    }
+}
+
+// c[k] = Im G[k], k = 0 .. M/2, from the packed transform Zg of (g[2q], g[2q+1])
+__global__ void __launch_bounds__(256) mr_real_kernel_untangle(const cplx *__restrict__ Zg, long long Mh, double *__restrict__ c)
+{
+    for (long long k = blockIdx.x * 256ll + threadIdx.x; k <= Mh; k += (long long)gridDim.x * 256ll) {
+        const cplx zk = Zg[k == Mh ? 0 : k], zr = Zg[k == 0 || k == Mh ? 0 : Mh - k];
+        const cplx zc = make_double2(zr.x, -zr.y);
+        double sn, cs;
+        sincospi((double)k / (double)Mh, &sn, &cs);                      // e^{-2 pi i k / M} = cs - i sn
+        const cplx dif = make_double2(zk.x - zc.x, zk.y - zc.y);
+        // -(i/2) (cs - i sn) dif: imaginary part -(cs dif.x + sn dif.y) / 2
+        c[k] = 0.5 * (zk.y + zc.y) - 0.5 * (cs * dif.x + sn * dif.y);
+    }
+}
+
+__global__ void __launch_bounds__(256) mr_real_conv_glue(cplx *__restrict__ Z, long long Mh, const double *__restrict__ c)
+{
+    for (long long k = blockIdx.x * 256ll + threadIdx.x; 2 * k <= Mh; k += (long long)gridDim.x * 256ll) {
+        if (k == 0) {                                                    // Y[0] = Y[M/2] = 0: the kernel sums to zero both ways
+            Z[0] = make_double2(0.0, 0.0);
+            continue;
+        }
+        const long long r = Mh - k;
+        const cplx a = Z[k], b = Z[r];                                   // Z'[k], Z'[M/2 - k]
+        const cplx zk = make_double2(b.y, b.x), zm = make_double2(a.y, a.x);      // Z[k] = i conj Z'[r], Z[r] = i conj Z'[k]
+        double sn, cs;
+        sincospi((double)k / (double)Mh, &sn, &cs);                      // theta_k = 2 pi k / M; theta_r = pi - theta_k
+        // X[k] and X[r] from the pair (zk, conj zm)
+        const cplx zmc = make_double2(zm.x, -zm.y), zkc = make_double2(zk.x, -zk.y);
+        const cplx dk = make_double2(zk.x - zmc.x, zk.y - zmc.y), dr = make_double2(zm.x - zkc.x, zm.y - zkc.y);
+        // -(i/2) e^{-i t} d = ((-sn d.x + cs d.y) / 2 ... ) with e^{-i t} = cs - i sn:  -(i/2)(cs - i sn)(d.x + i d.y) = ( cs d.y - sn d.x,  -(cs d.x + sn d.y) ) / 2
+        const cplx xk = make_double2(0.5 * (zk.x + zmc.x) + 0.5 * (cs * dk.y - sn * dk.x), 0.5 * (zk.y + zmc.y) - 0.5 * (cs * dk.x + sn * dk.y));
+        // for r: e^{-i (pi - t)} = -cs - i sn
+        const cplx xr = make_double2(0.5 * (zm.x + zkc.x) + 0.5 * (-cs * dr.y - sn * dr.x), 0.5 * (zm.y + zkc.y) - 0.5 * (-cs * dr.x + sn * dr.y));
+        // Y = X * i c
+        const double ck = c[k], cr = c[r];
+        const cplx yk = make_double2(-xk.y * ck, xk.x * ck), yr = make_double2(-xr.y * cr, xr.x * cr);
+        // W[k] = (Y[k] + conj Y[r]) + i e^{i t} (Y[k] - conj Y[r]);  i (cs + i sn)(d.x + i d.y) = ( -(sn d.x + cs d.y), cs d.x - sn d.y )
+        const cplx yrc = make_double2(yr.x, -yr.y), ykc = make_double2(yk.x, -yk.y);
+        const cplx sk = make_double2(yk.x + yrc.x, yk.y + yrc.y), ek = make_double2(yk.x - yrc.x, yk.y - yrc.y);
+        const cplx sr = make_double2(yr.x + ykc.x, yr.y + ykc.y), er = make_double2(yr.x - ykc.x, yr.y - ykc.y);
+        Z[k] = make_double2(sk.x - (sn * ek.x + cs * ek.y), sk.y + (cs * ek.x - sn * ek.y));
+        // for r: e^{i (pi - t)} = -cs + i sn:  i (-cs + i sn)(d.x + i d.y) = ( -(sn d.x - cs d.y), -(cs d.x + sn d.y) )
+        if (r != k) Z[r] = make_double2(sr.x - (sn * er.x - cs * er.y), sr.y - (cs * er.x + sn * er.y));
+    }
+}
+
+struct mr_real_cache {
+    long long Mh = 0;
+    wfx_devbuf ctab;
+    bool ready = false;
+};
+static std::map<std::pair<const void *, long long>, mr_real_cache> g_mr_real;          // per (context, N)
+
+// H as a flat array of doubles: H[n] = ((double *)*V_out)[n], n < N
+int wfx_dev_hilbert_conv_mr_real(wfx_ctx *ctx, const double *x, uint64_t n, cplx **V_out, int *handled)
+{
+    *handled = 0;
+    mr_real_cache *pd = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mr_mutex);
+        auto key = std::make_pair((const void *)ctx, (long long)n);
+        auto it = g_mr_real.find(key);
+        if (it == g_mr_real.end()) {
+            mr_real_cache c;
+            c.Mh = wfx_mr_padded_length((long long)n);                     // 13-smooth, radix pairs, at most a few per cent above n
+            for (auto jt = g_mr_real.begin(); jt != g_mr_real.end();) {    // (one table per context)
+                if (jt->first.first == (const void *)ctx) {
+                    (void)hipStreamSynchronize(ctx->stream);
+                    if (jt->second.ctab.p) (void)hipFree(jt->second.ctab.p);
+                    jt = g_mr_real.erase(jt);
+                } else {
+                    ++jt;
+                }
+            }
+            it = g_mr_real.emplace(key, c).first;
+        }
+        pd = &it->second;
+    }
+    if (pd->Mh == 0) return 0;
+    const long long Mh = pd->Mh;
+    mr_plan_cache *pc = nullptr;
+    WFX_TRY(mr_get_plan(ctx, Mh, &pc));
+    const int np = pc->h.npass;
+    for (int i = 0; i < np; ++i)
+        if (pc->h.pass[i].ra <= 0) return 0;
+    if (np < 2 || !pc->use_mr2) return 0;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work, (size_t)Mh * sizeof(cplx)));
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (size_t)Mh * sizeof(cplx)));
+    cplx *A = (cplx *)ctx->b_work.p, *B = (cplx *)ctx->b_work2.p;
+    const cplx *tb = (const cplx *)pc->tables.p;
+    if (!pd->ready) {
+        WFX_TRY(wfx_reserve(ctx, pd->ctab, (size_t)(Mh + 1) * sizeof(double) + 64));
+        WFX_LAUNCH(ctx, K_BS_CHIRP, mr_real_kernel_fill, dim3(wfx_stream_grid((uint64_t)Mh, 256)), dim3(256), A, (long long)n, Mh, 0.5 / (double)Mh);
+        cplx *res = nullptr;
+        WFX_TRY(mr_run(ctx, pc, A, A, B, 0, false, nullptr, &res));
+        WFX_LAUNCH(ctx, K_BS_CHIRP, mr_real_kernel_untangle, dim3(wfx_stream_grid((uint64_t)Mh + 1, 256)), dim3(256), (const cplx *)res, Mh, (double *)pd->ctab.p);
+        pd->ready = true;
+    }
+    // forward: the first pass packs the reals (points behind (n + 1) / 2 count as zero; the caller keeps x[n] = 0)
+    const cplx *src = (const cplx *)x;
+    cplx *dst = A;
+    for (int i = 0; i < np; ++i) {
+        mr_pass_desc d = pc->h.pass[i];
+        if (i == 0) d.in_len = (long long)((n + 1) / 2);
+        WFX_TRY(wfx_mr_launch_pair(ctx, d, tb + pc->h.lo_off[i], i == 0 ? 1 : 0, 0, 0, src, dst));
+        src = dst;
+        dst = dst == A ? B : A;
+    }
+    cplx *Zs = (cplx *)src;
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, mr_real_conv_glue, dim3(wfx_stream_grid((uint64_t)Mh / 2 + 1, 256)), dim3(256), Zs, Mh, (const double *)pd->ctab.p);
+    WFX_TRY(mr_run(ctx, pc, Zs, A, B, 1, false, nullptr, V_out));
+    *handled = 1;
+    return 0;
+}
+
 static void mr_padded_release(wfx_ctx *ctx)
 {
+    {
+        std::lock_guard<std::mutex> lock(g_mr_mutex);
+        for (auto it = g_mr_real.begin(); it != g_mr_real.end();) {
+            if (it->first.first == (const void *)ctx) {
+                if (it->second.ctab.p) (void)hipFree(it->second.ctab.p);
+                it = g_mr_real.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
     std::lock_guard<std::mutex> lock(g_mr_mutex);
     for (auto it = g_mr_padded.begin(); it != g_mr_padded.end();) {
         if (it->first.first == (const void *)ctx) {
