@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--shard", action="store_true",
                     help="c2: decode ONE 10-minute capture with all ranks (sharded exact path) instead of one capture per rank")
     ap.add_argument("--iq-seconds", type=float, default=3600.0, help="length of the IQ stream (BASELINE: 60 minutes)")
-    ap.add_argument("--iq-stop-rate", type=int, default=16000, choices=[16000, 14700, 22050],
+    ap.add_argument("--iq-stop-rate", type=int, default=16000, choices=[16000, 24000, 48000],
                     help="rate at which the time-domain front end hands the IQ stream to the exact FFT resampler")
     ap.add_argument("--iq-form", choices=["auto", "fused", "sharded"], default="auto",
                     help="one GPU: the fused exact decode behind the front end (auto) or the sharded form with one rank")
@@ -379,7 +379,7 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
                      "1 stream gather per decode)")),
            "front_end": fe.describe() + f" -> exact FFT resample {fe.out_rate} -> 11025 Hz",
            "ms_per_step": round(ms, 4), "value": round(n0 / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "steps": steps,
-           "synthesis_s": round(t_syn, 2), "dtype": "i16 integer-exact ingest / f64 everywhere behind it" if fe.f64 else "f32 front end / f64 exact path",
+           "synthesis_s": round(t_syn, 2), "dtype": "i16 integer-exact ingest / f64 everywhere behind it",
            "start_frame": int(info.start_frame) if rk.rank == 0 else None, "image": [int(info.width), 4 * int(info.height)] if rk.rank == 0 else None,
            "roofline": roofline_of(prof, 1, alg_bytes, ms, pmc, merge_fft=True), "kernels": kernel_table(prof, 1)}
     if not fused:

@@ -277,28 +277,19 @@ int wfx_d_notch_fir(wfx_ctx *ctx, const int16_t *in_dev, size_t n, const double 
                     int edge_flags);
 int wfx_d_notch_fir_f64(wfx_ctx *ctx, const double *in_dev, size_t n, const double b[3], const double a[3], double *out_dev,
                         int edge_flags);
-/* a4 + a5 in halo-local form (oversampled captures, BASELINE configs[3]): the time-domain counterpart of
- * wefax.py:360-394.  in_kind WFX_IN_I16_MONO, WFX_IN_I16_STEREO (= interleaved IQ; merged as (int16)(L+R)/2 while
- * loading) or WFX_IN_F32_MONO; coefficient arrays are HOST pointers, designed by the caller
- * (wefax_amd/polyphase.py).  fp32 accumulation in a fixed order per output sample.
- *   decimate:  out[i] = sum_{j<ntaps} coef[j] * in[first + i*factor + j],  factor <= 64 (powers of two take the aligned fast path),
- *              out float32 (out_f64 = 0) or float64 (out_f64 = 1)
- *   rational:  out[i] = sum_{j<taps} table[(((m0+i)*p) mod q)*taps + j] * in[floor((m0+i)*p/q) - base0 + j]
- * samples of `in` outside [0, n_in) read as zero */
-int wfx_d_decimate_fir(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const float *coef,
-                       int ntaps, void *out_dev, int out_f64, size_t n_out);
-int wfx_d_resample_rational(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t base0, int p, int q,
-                            const float *table, int taps, int64_t m0, float *out_dev, size_t n_out);
-/* decimate with float64 taps and a float64 result (the default chain of the front end: what reaches the exact path carries the
- * filters' design error only, wefax.py:384 sees the same numbers whatever the tiling).  in_kind WFX_IN_I16_MONO / WFX_IN_I16_STEREO
- * / WFX_IN_F64_MONO.  With fix_shift = s > 0, int16 input and a power-of-two factor >= the samples per 16 bytes (8 mono, 4 IQ)
- * the stencil is computed EXACTLY: the taps are rounded to multiples of 2^-s and the products summed as integers
- * (v_dot2_i32_i16) --
+/* a4 + a5 in halo-local form (oversampled captures, BASELINE configs[3]): the time-domain counterpart of wefax.py:360-394 down to
+ * a hand-over rate above 11 025 Hz (the exact FFT resampler of the decode path takes the last step).  One stencil,
+ *   out[i] = sum_{j<ntaps} coef[j] * in[first + i*factor + j],  factor <= 64, samples of `in` outside [0, n_in) read as zero,
+ * with float64 taps and a float64 result.  in_kind WFX_IN_I16_MONO, WFX_IN_I16_STEREO (= interleaved IQ; merged as (int16)(L+R)/2
+ * while loading) or WFX_IN_F64_MONO; coef is a HOST pointer, designed by the caller (wefax_amd/polyphase.py).  With fix_shift =
+ * s > 0, int16 input and a power-of-two factor >= the samples per 16 bytes (8 mono, 4 IQ) the stencil is computed EXACTLY: the
+ * taps are rounded to multiples of 2^-s and the products summed as integers (v_dot2_i32_i16) --
  *   out[i] = sum_j round(coef[j] * 2^s) * in[first + i*factor + j] / 2^s  (IQ: of the wrapped int16 sum, / 2)
- * with no rounding of the sum; *exact (may be NULL) is set to 1.  s must keep every tap below 2^23 steps and the sum of
- * |tap >> 12| below 2^16 (wefax_amd/polyphase.fix_shift_for picks it; 27-28 for the ingest filters).  Everything else
- * (fix_shift 0, other inputs / factors, a shift the taps do not fit) runs float64 FMAs in one fixed order per output
- * (*exact = 0): |error| <= ntaps * 2^-53 * sum |coef * in|. */
+ * with no rounding of the sum; *exact (may be NULL) is set to 1.  s must keep every tap below 2^27 steps and the sums of a
+ * flush window inside 32 bits for the worst-case input (wefax_amd/polyphase.fix_shift_for picks it; 30 for the ingest filters).
+ * Everything else (fix_shift 0, other inputs / factors, a shift the taps do not fit) runs float64 FMAs in one fixed order per
+ * output (*exact = 0): |error| <= ntaps * 2^-53 * sum |coef * in|.  (The fp32 forms of rounds 1-2, wfx_d_decimate_fir and
+ * wfx_d_resample_rational, were removed in round 4.) */
 int wfx_d_decimate_fir64(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const double *coef,
                          int ntaps, double *out_dev, size_t n_out, int fix_shift, int *exact);
 /* `nbatch` equally shaped jobs in ONE launch (the segments a rank owns in the columns layout of the sharded decode): member b

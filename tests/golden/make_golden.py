@@ -34,8 +34,10 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 
 from wefax_amd import synth  # noqa: E402
+sys.path.insert(0, HERE)
+import recipes  # noqa: E402
 
-SUB = 5  # float stages: keep every SUB-th sample
+SUB = 25  # float stages: keep every SUB-th sample (the SHA-256 of the whole array is in the manifest)
 
 
 def _import_reference():
@@ -88,6 +90,7 @@ def run_case(wefax, name: str, wav_path: str, lpm: int) -> dict:
         arrays[key + "_sub"] = a[::SUB].copy()
         out[key + "_sha256"] = _sha(a)
         out[key + "_len"] = int(a.shape[0])
+        out["float_stride"] = SUB
 
     if hasattr(d, "audio_data"):
         put_float("audio", d.audio_data)            # after merge/resample/notch
@@ -141,7 +144,7 @@ def main():
 
     short = dict(start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0)
 
-    def emit(name, fs, data, lpm):
+    def emit(name, fs, data, lpm, recipe=None):
         if only is not None and name not in only:
             return
         p = os.path.join(inputs, name + ".wav")
@@ -149,6 +152,9 @@ def main():
         print("case", name, data.shape, flush=True)
         c = run_case(wefax, name, p, lpm)
         c["input"] = "inputs/" + name + ".wav"
+        if recipe:      # too large to keep: regenerated from tests/golden/recipes.py wherever it is missing (.gitignore lists the file)
+            c["recipe"] = recipe
+            c["input_sha256"] = recipes.file_sha256(p)
         manifest["cases"].append(c)
 
     # 1. clean mono 11 025 Hz, 120 LPM (even N)
@@ -206,6 +212,14 @@ def main():
     emit("stereo_i32_240", 11025, np.stack([i32, i32 // 2 + 7], axis=1), 240)
     f32 = base.astype(np.float32) / np.float32(32768.0)
     emit("stereo_f32_240", 11025, np.stack([f32, f32 * np.float32(0.3333333)], axis=1), 240)
+
+    # 10c. BASELINE configs[3]'s own format through the REFERENCE: a two-channel int16 stream at 1.536 MS/s (merge of wefax.py:360-373,
+    #      FFT resample by 147 / 20480 of wefax.py:384) and a 192 kHz stereo capture.  Inputs come from tests/golden/recipes.py and
+    #      are not stored (12 MB / 4.6 MB); a clip this short closes no phasing group: the ValueError of wefax.py:294 is the golden
+    for rname in ("iq1536k_2s_240", "stereo192k_6s_240"):
+        if only is None or rname in only:
+            fs_r, data_r, lpm_r = recipes.RECIPES[rname]()
+            emit(rname, fs_r, data_r, lpm_r, recipe=rname)
 
     # 11. the reference's own 1-second clips (MIT licence, LICENSE:1-3)
     import shutil

@@ -1,4 +1,4 @@
-"""Float64 NumPy models of the time-domain front end's two stencil kernels (csrc/wfx_polyphase.hip): what
+"""Float64 NumPy models of the time-domain front end's stencil kernel (csrc/wfx_polyphase.hip): what
 the GPU tests compare the kernels with, and what the CPU tests run the filter design through."""
 import numpy as np
 
@@ -34,30 +34,10 @@ def decimate_model(x, first, factor, coef, n_out):
     return y
 
 
-def rational_model(x, base0, p, q, table, m0, n_out):
-    """float64 model of wfx_d_resample_rational."""
-    x = np.asarray(x, dtype=np.float64)
-    t = np.asarray(table, dtype=np.float64)
-    m = m0 + np.arange(n_out, dtype=np.int64)
-    pos = (m * p) // q - base0
-    ph = (m * p) % q
-    y = np.zeros(n_out)
-    for j in range(t.shape[1]):
-        s = pos + j
-        ok = (s >= 0) & (s < x.shape[0])
-        y += t[ph, j] * np.where(ok, x[np.clip(s, 0, x.shape[0] - 1)], 0.0)
-    return y
-
-
 def front_end_model(raw, chain):
-    """The stage chain of polyphase.FrontEnd.chain on a raw slice, in float64."""
+    """The stage chain of polyphase.FrontEnd.chain on a raw slice, in float64 (decimations with their float64 taps)."""
     cur = to_real(raw)
     for st, (a, b), (ia, ib) in chain:
-        assert cur.shape[0] == ib - ia
-        if st.kind == "decimate":
-            # (a float64 chain -- decimations only -- applies its float64 taps; the fp32 chains the float32 ones)
-            cur = decimate_model(cur, 0, st.factor, st.coef64 if getattr(st, "f64_chain", False) else st.coef, b - a)
-        else:
-            shift = max(0, -(a // st.q))
-            cur = rational_model(cur, ia + st.left + shift * st.p, st.p, st.q, st.table, a + shift * st.q, b - a)
+        assert cur.shape[0] == ib - ia and st.kind == "decimate"
+        cur = decimate_model(cur, 0, st.factor, st.coef64, b - a)
     return cur

@@ -181,9 +181,10 @@ def test_sixty_minute_48k_capture_full_size():
 def test_sixty_minute_iq_stream_full_size_properties():
     """BASELINE configs[3] at FULL size: one 60-minute 1.536 MS/s int16 IQ stream, 5 529 600 000 frames = 22 GB synthesised in
     HBM.  Neither the reference (wefax.py:360-373 merges per sample in Python) nor the oracle can process it, so the checks are
-    properties: (1) two different front ends -- hand-over at 16 000 Hz (integer-exact ingest + float64 /3) and at 22 050 Hz
-    (fp32 /32, x147/160, /2) -- in front of the same exact path give the same start_frame, the same picture size and pictures
-    that agree within one grey level on every one of 158 M pixels; (2) the sharded form on 8 emulated ranks, each synthesising
+    properties: (1) two different float64 front ends -- hand-over at 16 000 Hz (integer-exact /32 on the least-squares pair + float64 /3)
+    and at 48 000 Hz (one integer-exact Kaiser /32 and nothing else: the exact FFT resampler then works on 172.8 M samples, the
+    size of configs[2]) -- in front of the same exact path give the same start_frame, the same picture size and pictures that
+    agree within one grey level on every one of 158 M pixels; (2) the sharded form on 8 emulated ranks, each synthesising
     only its own 1/8 of the stream, reproduces the one-GPU decode bit for bit (uint8 stream and image)."""
     from wefax_amd import _native as nat
     from wefax_amd import polyphase as pp
@@ -203,7 +204,7 @@ def test_sixty_minute_iq_stream_full_size_properties():
         return load
 
     results = {}
-    for rate in (16000, 22050):
+    for rate in (16000, 48000):
         keep = []
         fe = pp.FrontEnd(fs, stop_rate=rate)
         dec = sharded.FrontEndExactDecoder(ctx, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,
@@ -213,18 +214,17 @@ def test_sixty_minute_iq_stream_full_size_properties():
         info = dec.result()
         results[rate] = (int(info.start_frame), int(info.height), int(info.width), dec.fetch("digitalized"), dec.fetch("image"),
                          [int(info.peak_pos[k]) for k in range(info.npeaks)])
-        if rate == 16000:
-            assert dec.fe.exact_ingest is True
+        assert dec.fe.exact_ingest is True
         dec.close()
         for c, p in keep:
             c.dev_free(p)
     s16, h16, w16, st16, img16, pk16 = results[16000]
-    s22, h22, w22, st22, img22, _ = results[22050]
+    s22, h22, w22, st22, img22, _ = results[48000]
     assert (w16, h16) == (5512, (39690000 - s16) // 5512) and img16.shape == (4 * h16, w16)
     assert s16 == s22 and (h16, w16) == (h22, w22)
     d = np.abs(img16.astype(np.int16) - img22.astype(np.int16))
     ds = np.abs(st16.astype(np.int16) - st22.astype(np.int16))
-    print(f"16 kHz vs 22.05 kHz hand-over, full size: stream differs on {np.count_nonzero(ds)} of {ds.size} (max {ds.max()}), "
+    print(f"16 kHz vs 48 kHz hand-over, full size: stream differs on {np.count_nonzero(ds)} of {ds.size} (max {ds.max()}), "
           f"image on {np.count_nonzero(d)} of {d.size} (max {d.max()}, > 1: {np.count_nonzero(d > 1)})")
     assert ds.max() <= 1 and d.max() <= 1
     del d, ds, st22, img22

@@ -30,7 +30,7 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_resample_rational", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
@@ -221,10 +221,8 @@ def load():
     lib.wfx_dev_copy.argtypes = [vp, vp, vp, sz]
     lib.wfx_d_notch_fir.argtypes = [vp, vp, sz, dp, dp, vp, i]
     lib.wfx_d_notch_fir_f64.argtypes = [vp, vp, sz, dp, dp, vp, i]
-    lib.wfx_d_decimate_fir.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, i, sz]
     lib.wfx_d_decimate_fir64.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int)]
     lib.wfx_d_decimate_fir64_batch.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int), i, sz, sz]
-    lib.wfx_d_resample_rational.argtypes = [vp, vp, i, sz, C.c_int64, i, i, vp, i, C.c_int64, vp, sz]
     lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
     lib.wfx_d_select_hist.argtypes = [vp, vp, sz, i, C.POINTER(C.c_uint64), vp]
     lib.wfx_d_quantise.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, C.POINTER(C.c_uint64)]
@@ -590,12 +588,6 @@ class Context:
         aa = (C.c_double * 3)(*[float(v) for v in a])
         self._check(self.lib.wfx_d_notch_fir_f64(self.h, C.c_void_p(in_ptr), n, bb, aa, C.c_void_p(out_ptr), edge_flags))
 
-    def d_decimate_fir(self, in_ptr: int, in_kind: int, n_in: int, first: int, factor: int, coef: np.ndarray, out_ptr: int,
-                       out_f64: bool, n_out: int):
-        c = np.ascontiguousarray(coef, dtype=np.float32)
-        self._check(self.lib.wfx_d_decimate_fir(self.h, C.c_void_p(in_ptr), in_kind, n_in, first, factor, _ptr(c), c.shape[0],
-                                                C.c_void_p(out_ptr), 1 if out_f64 else 0, n_out))
-
     def d_decimate_fir64(self, in_ptr: int, in_kind: int, n_in: int, first: int, factor: int, coef: np.ndarray, out_ptr: int, n_out: int,
                          fix_shift: int = 0, nbatch: int = 1, in_stride: int = 0, out_stride: int = 0) -> bool:
         """float64 taps, float64 result; True when the integer-exact form ran (taps on the grid 2**-fix_shift; include/wefax_hip.h).
@@ -609,14 +601,6 @@ class Context:
             self._check(self.lib.wfx_d_decimate_fir64(self.h, C.c_void_p(in_ptr), in_kind, n_in, first, factor, _ptr(c), c.shape[0],
                                                       C.c_void_p(out_ptr), n_out, int(fix_shift), C.byref(ex)))
         return bool(ex.value)
-
-    def d_resample_rational(self, in_ptr: int, in_kind: int, n_in: int, base0: int, p: int, q: int, table: np.ndarray, m0: int,
-                            out_ptr: int, n_out: int):
-        t = np.ascontiguousarray(table, dtype=np.float32)
-        assert t.ndim == 2 and t.shape[0] == q
-        self._check(self.lib.wfx_d_resample_rational(self.h, C.c_void_p(in_ptr), in_kind, n_in, base0, p, q, _ptr(t), t.shape[1], m0,
-                                                     C.c_void_p(out_ptr), n_out))
-
 
     def d_median5(self, in_ptr: int, n: int, out_ptr: int):
         self._check(self.lib.wfx_d_median5(self.h, C.c_void_p(in_ptr), n, C.c_void_p(out_ptr)))

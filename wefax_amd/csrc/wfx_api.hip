@@ -544,14 +544,6 @@ int wfx_d_notch_fir_f64(wfx_ctx *ctx, const double *in_dev, size_t n, const doub
     return wfx_dev_notch_fir_only(ctx, in_dev, WFX_IN_F64_MONO, n, b, a, out_dev, edge_flags);
 }
 
-int wfx_d_decimate_fir(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const float *coef,
-                       int ntaps, void *out_dev, int out_f64, size_t n_out)
-{
-    CHECK_CTX(ctx);
-    if (!in_dev || !out_dev || !coef) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
-    return wfx_dev_decimate_fir(ctx, in_dev, in_kind, n_in, first, factor, coef, ntaps, out_dev, out_f64, n_out);
-}
-
 int wfx_d_decimate_fir64(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const double *coef,
                          int ntaps, double *out_dev, size_t n_out, int fix_shift, int *exact)
 {
@@ -566,14 +558,6 @@ int wfx_d_decimate_fir64_batch(wfx_ctx *ctx, const void *in_dev, int in_kind, si
     CHECK_CTX(ctx);
     if (!in_dev || !out_dev || !coef) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
     return wfx_dev_decimate_fir64(ctx, in_dev, in_kind, n_in, first, factor, coef, ntaps, out_dev, n_out, fix_shift, exact, nbatch, in_stride, out_stride);
-}
-
-int wfx_d_resample_rational(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t base0, int p, int q, const float *table,
-                            int taps, int64_t m0, float *out_dev, size_t n_out)
-{
-    CHECK_CTX(ctx);
-    if (!in_dev || !out_dev || !table) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
-    return wfx_dev_resample_rational(ctx, in_dev, in_kind, n_in, base0, p, q, table, taps, m0, out_dev, n_out);
 }
 
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev)

@@ -35,7 +35,7 @@ enum wfx_kernel_id {
     K_IMAGE,
     K_RESAMPLE_PW,     // resampler pointwise kernels
     K_POLYPHASE_IN,    // time-domain front end, stage that reads the raw int16 capture (merge fused)
-    K_POLYPHASE,       // time-domain front end, later stages (float32 in)
+    K_POLYPHASE,       // time-domain front end, later stages (float64 in)
     K_DIST_COPY,       // sharded decode: pack / unpack copies around an exchange (wfx_dist.hip)
     K_COUNT
 };
@@ -350,14 +350,10 @@ int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num
 int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long fixed, int width, long long room, long long *hdr);
 
 // wfx_polyphase.hip
-int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const float *coef, int ntaps,
-                         void *out, int out_f64, uint64_t n_out);
 // nbatch > 1: that many equally shaped jobs in one launch -- member b reads in + b * in_stride frames (a multiple of 16 bytes) and
 // writes out + b * out_stride
 int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const double *coef, int ntaps,
                            double *out, uint64_t n_out, int fix_shift, int *exact_out, int nbatch = 1, uint64_t in_stride = 0, uint64_t out_stride = 0);
-int wfx_dev_resample_rational(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t base0, int p, int q, const float *table,
-                              int T, int64_t m0, float *out, uint64_t n_out);
 
 // wfx_comm.hip: the communicator behind the sharded decode (RCCL bound directly, or every rank in this process)
 struct wfx_xfer {            // one message pair of a personalised exchange; several entries per peer are matched in order

@@ -1,16 +1,16 @@
-// Halo-local sample-rate front end for oversampled captures (BASELINE configs[3]: 1.536 MS/s
-// int16 IQ; SURVEY.md section 8e "use FIR mode when sharded"): the time-domain counterpart
-// of wefax.py:375-394 (scipy FFT resample, a global operator) built from two stencils,
+// Halo-local sample-rate front end for oversampled captures (BASELINE configs[3]: 1.536 MS/s int16 IQ):
+// the time-domain counterpart of wefax.py:375-394 (scipy FFT resample, a global operator) down to a hand-over rate above
+// 11 025 Hz, built from ONE stencil,
 //
-//   decimate_fir       y[i] = sum_j c[j] * x[first + i*M + j]            (M a power of two)
-//   resample_rational  y[i] = sum_j h[((m0+i)*p) mod q][j] * x[floor((m0+i)*p/q) - base0 + j]
+//   decimate_fir64     y[i] = sum_j c[j] * x[first + i*M + j]
 //
-// chained by the host (wefax_amd/polyphase.py designs the filters and keeps the index
-// bookkeeping): 1.536 MS/s --/32--> 48 kHz --147/160--> 44.1 kHz --/4--> 11 025 Hz.
-// Both read every input byte once (16-byte loads), keep the window in LDS and are
-// HBM-bound; fp32 accumulation in one canonical order per output sample, so the result
-// does not depend on how a capture is cut into slices.  The stereo/IQ merge of
-// wefax.py:360-373 ((int16)(L+R) wrapped, /2) is fused into the load.
+// chained by the host (wefax_amd/polyphase.py designs the filters and keeps the index bookkeeping: 1.536 MS/s --/32--> 48 kHz
+// --/3--> 16 kHz; the exact FFT resampler of the decode path takes the last step).  It reads every input byte once (16-byte
+// loads), keeps the window in LDS and is HBM-bound.  Two arithmetic forms, neither with a rounding error of its own where that is
+// possible: int16 input and a power-of-two factor -- the ingest -- as an INTEGER dot product with taps on a 2^-30 grid (MODE 1);
+// everything else float64 taps and sums in one canonical order per output (MODE 2).  The result never depends on how a capture
+// is cut into slices.  The stereo / IQ merge of wefax.py:360-373 ((int16)(L+R) wrapped, /2) is fused into the load.  (The fp32
+// forms of rounds 1-2 -- MODE 0, the rational x147/160 stage -- were removed in round 4.)
 #include <algorithm>
 
 #include "wfx_internal.h"
@@ -19,29 +19,6 @@ namespace {
 
 constexpr int PP_THREADS = 256;
 constexpr int PP_LDS_BYTES = 64 * 1024;
-
-// 4 consecutive LDS samples: fetched raw (so that the conversion can wait until the values are needed) ...
-__device__ __forceinline__ int2 pp_raw4(const short *p)
-{
-    const int *q = (const int *)p;                    // 4-byte aligned: rows of the int16 layout start on even indices
-    return make_int2(q[0], q[1]);
-}
-__device__ __forceinline__ float4 pp_raw4(const float *p) { return *(const float4 *)p; }
-// ... and converted to float
-__device__ __forceinline__ void pp_cvt4(const int2 &r, float *w)
-{
-    w[0] = (float)(short)r.x;
-    w[1] = (float)(r.x >> 16);
-    w[2] = (float)(short)r.y;
-    w[3] = (float)(r.y >> 16);
-}
-__device__ __forceinline__ void pp_cvt4(const float4 &r, float *w)
-{
-    w[0] = r.x;
-    w[1] = r.y;
-    w[2] = r.z;
-    w[3] = r.w;
-}
 
 // the same 4 samples as float64 (MODE 2)
 __device__ __forceinline__ void pp_load4d(const short *p, double *w)
@@ -52,11 +29,6 @@ __device__ __forceinline__ void pp_load4d(const short *p, double *w)
     w[1] = (double)(a >> 16);
     w[2] = (double)(short)b;
     w[3] = (double)(b >> 16);
-}
-__device__ __forceinline__ void pp_load4d(const float *p, double *w)
-{
-    const float4 v = *(const float4 *)p;
-    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
 __device__ __forceinline__ void pp_load4d(const double *p, double *w)
 {
@@ -69,7 +41,7 @@ __device__ __forceinline__ int pp_dot2(int w, int c, int acc)      // acc + w.lo
 }
 
 // ---- element access -----------------------------------------------------------
-// IN 0: int16 mono, 1: int16 pairs merged with int16 wrap, 3: float
+// IN 0: int16 mono, 1: int16 pairs merged with int16 wrap, 2: float64 (between the stages)
 template <int IN> struct pp_in;
 template <> struct pp_in<WFX_IN_I16_MONO> {
     typedef short store_t;                    // LDS representation
@@ -104,21 +76,6 @@ template <> struct pp_in<WFX_IN_I16_STEREO> {
         return (short)((w & 0xffffu) + (w >> 16));
     }
 };
-template <> struct pp_in<WFX_IN_F32_MONO> {
-    typedef float store_t;
-    static constexpr int PER16 = 4;
-    static constexpr int BYTES = 4;
-    static constexpr float SCALE = 1.0f;
-    __device__ static void chunk(const uint4 &v, store_t *e)
-    {
-        e[0] = __uint_as_float(v.x);
-        e[1] = __uint_as_float(v.y);
-        e[2] = __uint_as_float(v.z);
-        e[3] = __uint_as_float(v.w);
-    }
-    __device__ static store_t one(const void *p, long long i) { return ((const float *)p)[i]; }
-};
-
 template <> struct pp_in<WFX_IN_F64_MONO> {          // float64 between the stages of the exact chain (MODE 2 only)
     typedef double store_t;
     static constexpr int PER16 = 2;
@@ -173,53 +130,13 @@ __device__ __forceinline__ uint4 pp_fetch(const void *in, const unsigned char *b
 // When a tile has fewer than 256 output quads the rows are split over `rs` thread groups whose
 // partial sums are added in group order through LDS: the order of additions per output is
 // fixed by (M, rs) alone, never by where a slice starts.
-constexpr int PP_BATCH = 8;
-// Build-time switches for A/B runs (tools/build_variant.sh); the defaults are what measured fastest on MI355X:
-//   PP_PAIRS 1      packed FMAs over tap pairs (0: over output pairs)      PP_TAPS_SMEM 1  aligned form: taps by scalar loads (0: LDS)
-//   PP_PREFETCH 1   aligned form: next tile's first chunks in flight       PP_ACC64 0      row sums added in fp64 (+9 % time)
-//   PP_TB_MAX 1024  largest tile (outputs)                                 PP_MINB 1       __launch_bounds__ minimum workgroups per CU
-#ifndef PP_ACC64
-#define PP_ACC64 0
-#endif
-#ifndef PP_PAIRS
-#define PP_PAIRS 1
-#endif
-#ifndef PP_PREFETCH
-#define PP_PREFETCH 1
-#endif
-#ifndef PP_TAPS_SMEM
-#define PP_TAPS_SMEM 1
-#endif
-#ifndef PP_TB_MAX
-#define PP_TB_MAX 1024
-#endif
-#ifndef PP_MINB
-#define PP_MINB 1
-#endif
-#ifndef PP_EXACT_PIPE
-#define PP_EXACT_PIPE 1      // integer-exact ingest: next row's window and taps in flight during this row's dot products
-#endif
-#ifndef PP_F64_WAVES
-#define PP_F64_WAVES 1       // float64 stages: waves per SIMD the kernel is compiled for
-#endif
-#ifndef PP_F64_PF
-#define PP_F64_PF 1          // float64 stages: next tile's chunks in flight during the tap loop
-#endif
-#ifndef PP_F64_UNROLL
-#define PP_F64_UNROLL 1      // float64 stages: tap groups per loop trip
-#endif
-#ifndef PP_EXACT_WAVES
-#define PP_EXACT_WAVES 4     // ... compiled for this many waves per SIMD (128 VGPRs at 4)
-#endif
-typedef float pp_f2 __attribute__((ext_vector_type(2)));
-#if PP_ACC64
-typedef double pp_acc_t;
-#else
-typedef float pp_acc_t;
-#endif
+// (The build-time A/B switches of rounds 1-3 are settled -- DESIGN.md 3.6 has what each measured; these are the winners.)
+constexpr int PP_TB_MAX = 1024;        // largest tile (outputs)
+constexpr int PP_EXACT_WAVES = 4;      // integer-exact ingest: compiled for this many waves per SIMD (128 VGPRs)
+constexpr int PP_F64_WAVES = 1;        // float64 stages: waves per SIMD the kernel is compiled for
 constexpr int PP_NB = 9;           // 16-byte chunks in flight per thread (decimate): 36 VGPRs
 
-// MODE 0: fp32 taps and sums (the round-1/2 form).  MODE 1: EXACT -- int16 samples times taps on a fixed-point grid
+// MODE 1: EXACT -- int16 samples times taps on a fixed-point grid
 // 2^-shift, split into a high and a low int16 part, summed with v_dot2_i32_i16 (two multiply-adds per instruction, the
 // window pairs straight from LDS, no conversions; the shift travels in bits 8.. of `flush_rows`); the sum of a tile's products is an integer that fits 64 bits, so the
 // float64 output is THE value of the FIR with those taps: no rounding anywhere, nothing depends on the tiling.  MODE 2:
@@ -232,8 +149,8 @@ constexpr int PP_FIX_LB = 12;
 // through a 256-byte port: the least there is).
 template <typename S> __device__ __forceinline__ int pp_swz(int col) { return sizeof(S) == 8 ? col + 2 * (col >> 5) : col; }
 static int pp_swz_stride(int cols, int esz) { return esz == 8 ? cols + 2 * (cols / 32 + 1) : cols; }
-template <int IN, typename OUT, bool ALIGNED, int Q4T, int MODE = 0>
-__global__ void __launch_bounds__(PP_THREADS, MODE == 1 ? PP_EXACT_WAVES : MODE == 2 ? PP_F64_WAVES : PP_MINB)
+template <int IN, typename OUT, bool ALIGNED, int Q4T, int MODE>
+__global__ void __launch_bounds__(PP_THREADS, MODE == 1 ? PP_EXACT_WAVES : PP_F64_WAVES)
 decimate_kernel(const void *__restrict__ in, long long n_in, long long first, int M, int log2m, const float *__restrict__ cp, int q4_arg,
                 OUT *__restrict__ out, long long n_out, int log2tb, int row_stride, int misalign, int flush_rows, long long in_bs, long long out_bs)
 {
@@ -258,17 +175,9 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
     const int part = __builtin_amdgcn_readfirstlane(t >> 6) >> (log2qw - 6);
     const int rows_per = M >> rs_log2;
     float *psum = (float *)(lds_raw + (((size_t)row_stride * M * sizeof(S) + 15) & ~(size_t)15));     // [rs - 1][quads][4]
-    // Aligned form (the ingest of an oversampled capture): the taps are read from the table in memory with scalar loads (the
-    // row index is uniform) -- as LDS broadcast reads, 16 bytes per lane, they cost the LDS pipe as much as the window reads
-    // and the tap loop was LDS-bound -- and the next tile's first chunks are requested before the tap loop.  The short
-    // stages behind it measure faster with the taps in LDS and without the prefetch.
-    constexpr bool SMEM = MODE == 1 || (MODE == 0 && PP_PAIRS && PP_TAPS_SMEM && ALIGNED), PF = PP_PREFETCH && (ALIGNED || (MODE == 2 && PP_F64_PF));
-    constexpr int ACCW = MODE ? 2 : (int)(sizeof(pp_acc_t) / sizeof(float));         // floats per partial sum
-    // (MODE 1 / 2 reserve exactly the partial sums the row groups exchange: the ingest then fits four workgroups per CU)
-    float *cl = psum + (MODE ? ((((1 << rs_log2) - 1) << log2qw) * 4) : PP_THREADS * 4) * ACCW;
-    if (MODE == 0 && !SMEM)
-        for (int i = t; i < M * (PP_PAIRS ? 8 * q4 + 4 : 4 * q4); i += PP_THREADS) cl[i] = cp[i];
-    const float *cs = SMEM ? cp : cl;
+    // the taps are read from the table in memory with scalar loads (the row index is uniform) -- as LDS broadcast reads, 16 bytes per
+    // lane, they cost the LDS pipe as much as the window reads -- and the next tile's first chunks are requested before the tap loop
+    constexpr bool PF = true;
     const long long ntiles = (n_out + tb - 1) >> log2tb;
     // 16-byte aligned view of the input: element index e of the caller's array is element e + misalign of `base`
     const unsigned char *base = (const unsigned char *)in - (size_t)misalign * A::BYTES;
@@ -356,9 +265,6 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
         __syncthreads();
         if (PF && tile + gridDim.x < ntiles) fetch(geom_of(tile + gridDim.x), 0);      // in flight during the compute phase
         const bool active = (4 * g < cnt) && (part < (1 << rs_log2));
-        // a row's 4 * q4 taps are summed in fp32 (packed FMAs) and the row sums are added up: two short chains instead of one
-        // of 4 * q4 * M terms keep the rounding of the sum near that of the fp32 sample the stage stores (measured against a
-        // float64 model: rms 6e-8 of the signal).  PP_ACC64 1 adds the rows in fp64 instead: rms 4.4e-8, ingest + 9 %.
         if constexpr (MODE == 1) {
             // exact: hi parts in one int32 per output over the whole tile, lo parts flushed into an int64 every flush_rows rows
             // (the host checked both bounds against the worst-case sample, |s| = 32768)
@@ -368,7 +274,7 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                 int ah0 = 0, ah1 = 0, ah2 = 0, ah3 = 0, al0 = 0, al1 = 0, al2 = 0, al3 = 0;
                 const int *ci = (const int *)cp;
                 constexpr int NP = 2 * (Q4T ? Q4T : 1);
-                if constexpr (Q4T > 0 && PP_EXACT_PIPE) {
+                if constexpr (Q4T > 0) {
                     // compile-time tap count: the NEXT row's window pairs (LDS) and taps (scalar loads) are requested before this
                     // row's 16 q4 + 4 dot products -- one row's load latency no longer sits in front of every row's arithmetic
                     constexpr int NW = NP + 2, NC = 4 * NP + 4;
@@ -529,158 +435,6 @@ decimate_kernel(const void *__restrict__ in, long long n_in, long long first, in
                 for (int k = 0; k < 4; ++k)
                     if (4 * g + k < cnt) out[o0 + 4 * g + k] = (OUT)(a[k] * (double)A::SCALE);
             }
-        } else {
-        pp_acc_t tot0 = 0, tot1 = 0, tot2 = 0, tot3 = 0;
-        if (active) {
-            const int r0 = part * rows_per;
-#if PP_PAIRS
-            // Packed FMAs over TAP pairs: output k keeps two partial sums (even / odd window positions), so that every product
-            // pairs an even-aligned window pair (w[2p], w[2p+1]) with a coefficient pair -- (c[t], c[t+1]) for the even outputs,
-            // the table shifted by one tap, (c[t-1], c[t]), for the odd ones.  No register shuffling between the FMAs (packing
-            // over OUTPUT pairs needs every window pair at both alignments: one v_mov per sample and row).
-            pp_f2 ta0 = {0.f, 0.f}, ta1 = {0.f, 0.f}, ta2 = {0.f, 0.f}, ta3 = {0.f, 0.f};
-            for (int r = r0; r < r0 + rows_per; ++r) {
-                const S *row = xs + r * row_stride + 4 * g;
-                const float *c = cs + r * (8 * q4 + 4);           // [4 q4] taps, then [4 q4 + 4] the same taps one place later
-                const float *dsh = c + 4 * q4;
-                float wa[4], wb[4];
-                pp_cvt4(pp_raw4(row), wa);
-                auto rn = pp_raw4(row + 4);
-                float4 cn = *(const float4 *)c, dn = *(const float4 *)dsh;
-                pp_f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
-#pragma unroll(Q4T ? Q4T : 1)
-                for (int j = 0; j < (Q4T ? Q4T : q4); ++j) {
-                    const pp_f2 e0 = {cn.x, cn.y}, e1 = {cn.z, cn.w}, d0 = {dn.x, dn.y}, d1 = {dn.z, dn.w};
-                    pp_cvt4(rn, wb);
-                    dn = *(const float4 *)(dsh + 4 * j + 4);      // (the last one feeds the tail below)
-                    if (j + 1 < q4) {
-                        cn = *(const float4 *)(c + 4 * j + 4);
-                        rn = pp_raw4(row + 4 * j + 8);
-                    }
-                    const pp_f2 p0 = {wa[0], wa[1]}, p1 = {wa[2], wa[3]}, p2 = {wb[0], wb[1]};
-                    a0 = __builtin_elementwise_fma(e0, p0, a0); a2 = __builtin_elementwise_fma(e0, p1, a2);
-                    a1 = __builtin_elementwise_fma(d0, p0, a1); a3 = __builtin_elementwise_fma(d0, p1, a3);
-                    a0 = __builtin_elementwise_fma(e1, p1, a0); a2 = __builtin_elementwise_fma(e1, p2, a2);
-                    a1 = __builtin_elementwise_fma(d1, p1, a1); a3 = __builtin_elementwise_fma(d1, p2, a3);
-                    wa[0] = wb[0]; wa[1] = wb[1]; wa[2] = wb[2]; wa[3] = wb[3];
-                }
-                {       // the odd outputs' last tap, c[4 q4 - 1], sits alone in the shifted table's last pair
-                    const pp_f2 dq = {dn.x, dn.y}, p0 = {wa[0], wa[1]}, p1 = {wa[2], wa[3]};
-                    a1 = __builtin_elementwise_fma(dq, p0, a1);
-                    a3 = __builtin_elementwise_fma(dq, p1, a3);
-                }
-                ta0 += a0; ta1 += a1; ta2 += a2; ta3 += a3;
-            }
-            tot0 = ta0.x + ta0.y; tot1 = ta1.x + ta1.y; tot2 = ta2.x + ta2.y; tot3 = ta3.x + ta3.y;
-#else
-            for (int r = r0; r < r0 + rows_per; ++r) {
-                const S *row = xs + r * row_stride + 4 * g;
-                const float *c = cs + r * 4 * q4;
-                float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-                float wa[4], wb[4];
-                pp_cvt4(pp_raw4(row), wa);
-                auto rn = pp_raw4(row + 4);
-                float4 cn = *(const float4 *)c;
-#pragma unroll(Q4T ? Q4T : 1)
-                for (int j = 0; j < (Q4T ? Q4T : q4); ++j) {
-                    const float c0 = cn.x, c1 = cn.y, c2 = cn.z, c3 = cn.w;
-                    pp_cvt4(rn, wb);
-                    if (j + 1 < q4) {                 // next taps and next columns are in flight while this group is applied
-                        cn = *(const float4 *)(c + 4 * j + 4);
-                        rn = pp_raw4(row + 4 * j + 8);
-                    }
-                    acc0 = fmaf(c0, wa[0], acc0); acc1 = fmaf(c0, wa[1], acc1); acc2 = fmaf(c0, wa[2], acc2); acc3 = fmaf(c0, wa[3], acc3);
-                    acc0 = fmaf(c1, wa[1], acc0); acc1 = fmaf(c1, wa[2], acc1); acc2 = fmaf(c1, wa[3], acc2); acc3 = fmaf(c1, wb[0], acc3);
-                    acc0 = fmaf(c2, wa[2], acc0); acc1 = fmaf(c2, wa[3], acc1); acc2 = fmaf(c2, wb[0], acc2); acc3 = fmaf(c2, wb[1], acc3);
-                    acc0 = fmaf(c3, wa[3], acc0); acc1 = fmaf(c3, wb[0], acc1); acc2 = fmaf(c3, wb[1], acc2); acc3 = fmaf(c3, wb[2], acc3);
-                    wa[0] = wb[0]; wa[1] = wb[1]; wa[2] = wb[2]; wa[3] = wb[3];
-                }
-                tot0 += (pp_acc_t)acc0; tot1 += (pp_acc_t)acc1; tot2 += (pp_acc_t)acc2; tot3 += (pp_acc_t)acc3;
-            }
-#endif
-        }
-        if (rs_log2 > 0) {
-            pp_acc_t *ps = (pp_acc_t *)psum;
-            if (active && part > 0) {
-                pp_acc_t *q = ps + ((size_t)((part - 1) << log2qw) + g) * 4;
-                q[0] = tot0; q[1] = tot1; q[2] = tot2; q[3] = tot3;
-            }
-            __syncthreads();
-            if (active && part == 0)
-                for (int q = 1; q < (1 << rs_log2); ++q) {
-                    const pp_acc_t *o = ps + ((size_t)((q - 1) << log2qw) + g) * 4;
-                    tot0 += o[0]; tot1 += o[1]; tot2 += o[2]; tot3 += o[3];
-                }
-        }
-        if (active && part == 0) {
-            const pp_acc_t a[4] = {tot0, tot1, tot2, tot3};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (4 * g + k < cnt) out[o0 + 4 * g + k] = (OUT)(a[k] * (pp_acc_t)A::SCALE);
-        }
-        }
-    }
-}
-
-// ---- rational resampling ----------------------------------------------------------
-// A workgroup produces PP_RTILE consecutive outputs: their input span goes through LDS as
-// float (batched coalesced loads), the q x T coefficient table sits beside it with an odd row
-// stride; a thread walks its outputs (stride 256) with an incremental (position, phase).
-constexpr int PP_RTILE = 2048;
-
-template <int IN>
-__global__ void __launch_bounds__(PP_THREADS)
-rational_kernel(const void *__restrict__ in, long long n_in, long long base0, int p, int q, const float *__restrict__ table, int T,
-                long long m0, float *__restrict__ out, long long n_out, int span_cap)
-{
-    typedef pp_in<IN> A;
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    float *tab = (float *)lds_raw;
-    const int ts = T | 1, t = threadIdx.x;
-    float *xs = tab + q * ts;
-    for (int i = t; i < q * T; i += PP_THREADS) tab[(i / T) * ts + (i % T)] = table[i];
-    const long long ntiles = (n_out + PP_RTILE - 1) / PP_RTILE;
-    const unsigned long long sp = (unsigned long long)PP_THREADS * (unsigned long long)p;
-    const int dpos = (int)(sp / (unsigned)q), dphase = (int)(sp % (unsigned)q);
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long i0 = tile * PP_RTILE;
-        const int cnt = (int)((n_out - i0 < PP_RTILE) ? (n_out - i0) : PP_RTILE);
-        const long long posA = (long long)(((unsigned long long)(m0 + i0) * (unsigned long long)p) / (unsigned)q) - base0;
-        const long long posB = (long long)(((unsigned long long)(m0 + i0 + cnt - 1) * (unsigned long long)p) / (unsigned)q) - base0 + T;
-        const int span = (int)(posB - posA);          // <= span_cap by the host's choice of p/q
-        __syncthreads();
-        for (int sb = 0; sb < span; sb += PP_THREADS * PP_BATCH) {
-            float v[PP_BATCH];
-#pragma unroll
-            for (int u = 0; u < PP_BATCH; ++u) {
-                const int k = sb + u * PP_THREADS + t;
-                const long long s = posA + k;
-                v[u] = (k < span && s >= 0 && s < n_in) ? (float)A::one(in, s) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < PP_BATCH; ++u) {
-                const int k = sb + u * PP_THREADS + t;
-                if (k < span && k < span_cap) xs[k] = v[u];
-            }
-        }
-        __syncthreads();
-        if (t < cnt) {
-            const unsigned long long mp = (unsigned long long)(m0 + i0 + t) * (unsigned long long)p;
-            int pos = (int)((long long)(mp / (unsigned)q) - base0 - posA);
-            int phase = (int)(mp % (unsigned)q);
-            for (int i = t; i < cnt; i += PP_THREADS) {
-                const float *h = tab + phase * ts;
-                const float *x = xs + pos;
-                float acc = 0.f;
-                for (int j = 0; j < T; ++j) acc = fmaf(h[j], x[j], acc);
-                out[i0 + i] = acc * A::SCALE;
-                pos += dpos;
-                phase += dphase;
-                if (phase >= q) {
-                    phase -= q;
-                    pos += 1;
-                }
-            }
         }
     }
 }
@@ -690,40 +444,6 @@ int ilog2_exact(int m)
     int l = 0;
     while ((1 << l) < m) ++l;
     return ((1 << l) == m) ? l : -1;
-}
-
-template <int IN, typename OUT>
-int launch_decimate(wfx_ctx *ctx, const void *in, long long n_in, long long first, int M, const float *cp, int q4, OUT *out,
-                    long long n_out, bool aligned)
-{
-    typedef pp_in<IN> A;
-    const int log2m = ilog2_exact(M);
-    const int esz = (int)sizeof(typename A::store_t);
-    const int pad = esz == 2 ? 6 : 4;                // int16 rows: stride = 2 (mod 4) spreads a chunk's rows over the banks
-    int tb = log2m < 0 ? 1024 : PP_TB_MAX;           // outputs per tile: 4 per thread (rows of a non-power-of-two factor are never split)
-    while (tb > 64 && (size_t)(tb + 4 * q4 + pad) * M * esz > (size_t)PP_LDS_BYTES) tb >>= 1;
-    if (log2m < 0 && tb < 1024) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
-    const int row_stride = tb + 4 * q4 + pad;
-    const size_t lds_x = ((size_t)row_stride * M * esz + 15) & ~(size_t)15;
-    const size_t lds = lds_x + (size_t)PP_THREADS * 4 * sizeof(pp_acc_t) +                                      // + partial sums
-                       ((aligned && PP_PAIRS && PP_TAPS_SMEM) ? 0 : (size_t)M * (8 * q4 + 4) * sizeof(float));     // + taps (twice)
-    if (lds_x > (size_t)PP_LDS_BYTES) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps x factor %d do not fit the LDS window", 4 * q4 * M, M);
-    const int misalign = (int)(((uintptr_t)in & 15u) / A::BYTES);
-    const long long ntiles = (n_out + tb - 1) / tb;
-    const unsigned grid = (unsigned)(ntiles < 4096 ? ntiles : 4096);
-    auto kern = (!aligned && q4 == 8) ? decimate_kernel<IN, OUT, false, 8>      // (/3 with 87 taps behind the ingest: unrolled)
-                : !aligned ? decimate_kernel<IN, OUT, false, 0>
-                : q4 == 2 ? decimate_kernel<IN, OUT, true, 2>
-                : q4 == 3 ? decimate_kernel<IN, OUT, true, 3>
-                          : decimate_kernel<IN, OUT, true, 0>;
-    if (lds > 48 * 1024) WFX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    wfx_prof_begin(ctx, (IN == WFX_IN_F32_MONO ? K_POLYPHASE : K_POLYPHASE_IN));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PP_THREADS), lds, ctx->stream, in, n_in, first, M, log2m, cp, q4, out, n_out, ilog2_exact(tb),
-                       row_stride, misalign, 0, 0ll, 0ll);
-    wfx_prof_end(ctx);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch decimate_kernel");
-    return 0;
 }
 
 // MODE 1 (exact, int16 in, aligned) and MODE 2 (float64 arithmetic, any input kind): float64 out
@@ -766,78 +486,7 @@ int launch_decimate64(wfx_ctx *ctx, const void *in, long long n_in, long long fi
     return 0;
 }
 
-template <int IN>
-int launch_rational(wfx_ctx *ctx, const void *in, long long n_in, long long base0, int p, int q, const float *table, int T, long long m0,
-                    float *out, long long n_out)
-{
-    const long long span_cap = ((long long)PP_RTILE * p) / q + T + 2;
-    const size_t lds = ((size_t)q * (T | 1) + (size_t)span_cap) * sizeof(float);
-    if (lds > (size_t)PP_LDS_BYTES)
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "rational: %d phases x %d taps at ratio %d/%d do not fit LDS", q, T, p, q);
-    const unsigned grid = wfx_stream_grid((uint64_t)n_out, PP_RTILE);
-    auto kern = rational_kernel<IN>;
-    if (lds > 48 * 1024) WFX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    wfx_prof_begin(ctx, (IN == WFX_IN_F32_MONO ? K_POLYPHASE : K_POLYPHASE_IN));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PP_THREADS), lds, ctx->stream, in, n_in, base0, p, q, table, T, m0, out, n_out, (int)span_cap);
-    wfx_prof_end(ctx);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch rational_kernel");
-    return 0;
-}
-
 }   // namespace
-
-// coef: ntaps taps in natural order (host memory).  They are re-ordered into M rows of 4*q4 taps
-// (row r holds c[r], c[r+M], ...; zero padded) so that a workgroup reads them with scalar loads.
-int wfx_dev_decimate_fir(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const float *coef, int ntaps,
-                         void *out, int out_f64, uint64_t n_out)
-{
-    if (M < 1 || M > 64) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: factor %d is not in 1..64", M);
-    if (ntaps < 1 || ntaps > 4096) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: %d taps", ntaps);
-    if (n_out == 0) return 0;
-    // Align the tile windows to the 16-byte grid of the input: move `first` down by d elements and put d zero taps in
-    // front of the filter.  Then every 16-byte chunk holds PER16 consecutive rows of ONE column (needs M >= PER16).
-    const int per16 = (in_kind == WFX_IN_I16_MONO) ? 8 : 4, ebytes = (in_kind == WFX_IN_I16_MONO) ? 2 : 4;
-    if ((uintptr_t)in % ebytes) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: misaligned input pointer");
-    const int misalign = (int)(((uintptr_t)in & 15u) / ebytes);
-    const bool aligned = M >= per16 && ilog2_exact(M) >= 0;
-    int d = 0;
-    if (aligned) {
-        d = (int)(((first + misalign) % per16 + per16) % per16);
-        first -= d;
-    }
-    const int nt = ntaps + d;
-    const int per_row = (nt + M - 1) / M;
-    const int q4 = (per_row + 3) / 4;
-#if PP_PAIRS
-    // row r: its 4 q4 taps, then the same taps one place later (d[k] = c[k - 1], 4 q4 + 4 entries): the pairs the odd outputs use
-    const size_t rowlen = (size_t)8 * q4 + 4;
-    std::vector<float> cp((size_t)M * rowlen, 0.0f);
-    for (int j = 0; j < ntaps; ++j) {
-        const size_t r = (size_t)((j + d) % M), k = (size_t)((j + d) / M);
-        cp[r * rowlen + k] = coef[j];
-        cp[r * rowlen + 4 * q4 + k + 1] = coef[j];
-    }
-#else
-    std::vector<float> cp((size_t)M * 4 * q4, 0.0f);
-    for (int j = 0; j < ntaps; ++j) cp[(size_t)((j + d) % M) * 4 * q4 + (j + d) / M] = coef[j];
-#endif
-    const float *dcoef = wfx_coef_device(ctx, cp.data(), cp.size());     // uploaded once per distinct table
-    if (!dcoef) return WFX_ERR_HIP;
-    const long long ni = (long long)n_in, no = (long long)n_out;
-#define WFX_PP_CASE(KIND)                                                                                       \
-    case KIND:                                                                                                  \
-        return out_f64 ? launch_decimate<KIND, double>(ctx, in, ni, first, M, dcoef, q4, (double *)out, no, aligned)     \
-                       : launch_decimate<KIND, float>(ctx, in, ni, first, M, dcoef, q4, (float *)out, no, aligned);
-    switch (in_kind) {
-        WFX_PP_CASE(WFX_IN_I16_MONO)
-        WFX_PP_CASE(WFX_IN_I16_STEREO)
-        WFX_PP_CASE(WFX_IN_F32_MONO)
-    default:
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: input kind %d", in_kind);
-    }
-#undef WFX_PP_CASE
-}
 
 // The same stencil with float64 taps and a float64 result that carries NO rounding of the sum where that is possible:
 //   int16 input (mono / IQ) and a power-of-two factor >= the samples per 16 bytes (the ingest of an oversampled capture):
@@ -938,24 +587,5 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
     case WFX_IN_I16_MONO: return launch_decimate64<WFX_IN_I16_MONO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0, nbatch, in_bs, out_bs);
     case WFX_IN_I16_STEREO: return launch_decimate64<WFX_IN_I16_STEREO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0, nbatch, in_bs, out_bs);
     default: return launch_decimate64<WFX_IN_F64_MONO, 2>(ctx, in, ni, first, M, dcoef, q4, out, no, aligned, 0, nbatch, in_bs, out_bs);
-    }
-}
-
-int wfx_dev_resample_rational(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t base0, int p, int q, const float *table,
-                              int T, int64_t m0, float *out, uint64_t n_out)
-{
-    if (p < 1 || q < 1 || T < 1 || T > 1024 || m0 < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "rational: p %d q %d taps %d", p, q, T);
-    if (n_out == 0) return 0;
-    const float *d = wfx_coef_device(ctx, table, (size_t)q * T);
-    if (!d) return WFX_ERR_HIP;
-    switch (in_kind) {
-    case WFX_IN_I16_MONO:
-        return launch_rational<WFX_IN_I16_MONO>(ctx, in, (long long)n_in, base0, p, q, d, T, m0, out, (long long)n_out);
-    case WFX_IN_I16_STEREO:
-        return launch_rational<WFX_IN_I16_STEREO>(ctx, in, (long long)n_in, base0, p, q, d, T, m0, out, (long long)n_out);
-    case WFX_IN_F32_MONO:
-        return launch_rational<WFX_IN_F32_MONO>(ctx, in, (long long)n_in, base0, p, q, d, T, m0, out, (long long)n_out);
-    default:
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "rational: input kind %d", in_kind);
     }
 }

@@ -3,27 +3,24 @@
 The reference brings every capture to 11 025 Hz with ``scipy.signal.resample``
 (/root/reference/wefax.py:375-394): an FFT over the WHOLE capture.  That operator is global,
 so it neither shards by sample range nor fits a 60-minute 1.536 MS/s IQ stream (5.5 G pairs).
-This module is the halo-local counterpart SURVEY.md section 8e asks for: a chain of FIR stencils
+This module is the halo-local counterpart SURVEY.md section 8e asks for: a chain of FIR DECIMATORS
 
-    [ decimate by a power of two ]*  ->  [ rational p/q to 44 100 Hz ]  ->  decimate by 2  ->  decimate by 2
-    [ decimate by a power of two ]*  ->  decimate by 3  ->  (exact FFT resampler)          with ``stop_rate``
+    [ decimate by a power of two <= 64 ]*  ->  [ decimate by 2, 3, 5 or 6 ]  ->  hand-over rate  ->  (exact FFT resampler)
 
-(1.536 MS/s: /32 -> 48 kHz, x147/160 -> 44.1 kHz, /2 -> 22.05 kHz, /2 -> 11 025 Hz; 48 kHz: the last three;
-44.1 kHz: the last two; with ``stop_rate`` the chain ends at 16 000, 14 700 or 22 050 Hz and the exact FFT resampler
-takes the last step: 1.536 MS/s: /32 -> 48 kHz, /3 -> 16 kHz) whose kernels live in ``csrc/wfx_polyphase.hip``.  Filters are Kaiser
-windowed sincs designed here in float64 and handed to the C ABI as float32 host arrays:
-unit DC gain, linear phase centred on the output sample (zero delay), pass band flat to
-``pass_hz``, stop band from 5512.5 Hz (the brick wall of the reference) at ``att_db``.
-The stereo / IQ merge of wefax.py:360-373 is fused into the first stage's loads.
+down to a hand-over rate that divides the capture's rate and lies above 11 025 Hz (1.536 MS/s: /32 -> 48 kHz, /3 -> 16 kHz;
+192 kHz: /4, /3; 48 kHz: /3; 44.1 kHz: /3 -> 14 700 Hz), where the exact FFT resampler of the decode path takes the last step --
+the reference's own brick wall at 5512.5 Hz.  The kernels live in ``csrc/wfx_polyphase.hip`` and carry NO rounding error of
+their own where that is possible: the ingest of an int16 capture is an integer dot product on a 2**-30 tap grid, everything
+behind it float64 (round 3).  The fp32 chains of rounds 1-2 (a rational x147/160 stage, hand-overs at 22 050 / 14 700 Hz from
+48 kHz, an all-time-domain chain to 11 025 Hz) are gone since round 4: arithmetic narrower than the reference's has no place
+next to an exact path.  Filters: linear phase centred on the output sample (zero delay), unit DC gain, pass band to
+5512.5 Hz, stop bands wherever something would alias into 0..5512.5 Hz at the stage's output rate.  The stereo / IQ merge of
+wefax.py:360-373 is fused into the first stage's loads.
 
-It is NOT bit-compatible with the FFT resampler: it drops what the reference keeps between
-``pass_hz`` and 5512.5 Hz and its pass band ripples by 10**(-att_db/20).  The reference's sampling
-grid -- output j at input position j * n0 / int(11025 * n0 / fs_in), one period = the whole capture --
-is kept exactly: the chain hands over n0 * out_rate / fs_in samples (lengths for which that is not
-a whole number are refused, ``FrontEnd.n_out``) and the exact FFT resampler behind it delivers
-int(11025 * n0 / fs_in) samples like wefax.py:384, whole seconds or not.  WEFAX audio lives below
-3 kHz, so decoded images agree to one grey level (tests/test_polyphase.py measures it); the exact
-path stays the default wherever it fits.
+The reference's sampling grid -- output j at input position j * n0 / int(11025 * n0 / fs_in), one period = the whole
+capture -- is kept exactly: the chain hands over n0 * out_rate / fs_in samples (lengths for which that is not a whole number
+are refused, ``FrontEnd.n_out``) and the exact FFT resampler behind it delivers int(11025 * n0 / fs_in) samples like
+wefax.py:384, whole seconds or not.
 """
 from __future__ import annotations
 
@@ -166,7 +163,6 @@ class Decimate:
         fc = (pass_hz + stop_hz) / 2 / fs                                   # cycles per input sample
         h = 2 * fc * np.sinc(2 * fc * u) * _kaiser_window(u, self.centre + 1.0, kaiser_beta(att_db))
         self.coef64 = h / h.sum()
-        self.coef = self.coef64.astype(np.float32)
         self.ntaps = n
 
     fix_shift = 0            # > 0: coef64 lies on the grid 2**-fix_shift (integer-exact ingest)
@@ -178,111 +174,69 @@ class Decimate:
         self.ntaps = int(h.shape[0])
         self.centre = (self.ntaps - 1) // 2
         self.coef64 = np.asarray(h, dtype=np.float64)
-        self.coef = self.coef64.astype(np.float32)
 
     def in_range(self, a: int, b: int):
         """Input index range needed for outputs [a, b)."""
         return a * self.factor - self.centre, (b - 1) * self.factor - self.centre + self.ntaps
 
 
-class Rational:
-    """Output m sits at input position m*p/q; taps j = 0..T-1 cover floor(m*p/q) - left + j with
-    weights h(j - left - frac), frac = ((m*p) mod q)/q: one table row per phase."""
-    kind = "rational"
+LAST_FACTORS = (1, 2, 3, 5, 6)     # what may be left for the last stage once the powers of two are taken out
+MIN_HANDOVER = 14000               # Hz: the last filter's transition band (5512.5 .. rate - 5512.5) stays wide
 
-    def __init__(self, fs_in: Fraction, fs_out: Fraction, pass_hz: float, stop_hz: float, att_db: float):
-        r = fs_in / fs_out
-        self.fs_in, self.fs_out, self.p, self.q = fs_in, fs_out, r.numerator, r.denominator
-        fs = float(fs_in)
-        t = kaiser_length(att_db, (stop_hz - pass_hz) / fs)
-        self.taps = t + (t & 1) + 2                                         # even, with a margin of one tap per side
-        self.left = self.taps // 2 - 1
-        fc = (pass_hz + stop_hz) / 2 / fs
-        frac = np.arange(self.q, dtype=np.float64)[:, None] / self.q
-        u = np.arange(self.taps, dtype=np.float64)[None, :] - self.left - frac
-        h = 2 * fc * np.sinc(2 * fc * u) * _kaiser_window(u, self.taps / 2.0, kaiser_beta(att_db))
-        self.table64 = h / h.sum(axis=1, keepdims=True)
-        self.table = self.table64.astype(np.float32)
 
-    def in_range(self, a: int, b: int):
-        return (a * self.p) // self.q - self.left, ((b - 1) * self.p) // self.q - self.left + self.taps
+def stage_factors(ratio: int):
+    """``ratio`` = fs_in / hand-over rate as a list of stage factors: powers of two (<= 64 each) first, then whatever is left
+    (2, 3, 5 or 6); None when the ratio has no such form."""
+    out, rem = [], int(ratio)
+    while rem > 6 and rem % 2 == 0:
+        f = 2
+        while f < 64 and rem % (2 * f) == 0:
+            f *= 2
+        out.append(f)
+        rem //= f
+    if rem not in LAST_FACTORS:
+        return None
+    if rem > 1:
+        out.append(rem)
+    return out or None
 
 
 class FrontEnd:
-    """Stage chain from ``fs_in`` to 11 025 Hz and the index bookkeeping around it."""
+    """Stage chain from ``fs_in`` to the hand-over rate and the index bookkeeping around it."""
 
-    def __init__(self, fs_in: int, att_db: float | None = None, pass_hz: float = 5300.0, stop_at_2x: bool = False,
-                 stop_rate: int | None = None):
-        """``pass_hz``: edge of the flat pass band of the last stage (its stop band starts at 5512.5 Hz): 5300 Hz
-        costs 595 taps at 22.05 kHz.  What lies between ``pass_hz`` and 5512.5 Hz is what the reference keeps and
-        this front end drops (tests/test_polyphase.py prints the resulting error figures).
-
-        ``stop_rate`` (``stop_at_2x`` = 22 050): leave the sharp last stage out and deliver ``stop_rate`` Hz -- a rate above
-        11 025 Hz that divides the rate left by the power-of-two decimations (48 kHz -> 16 000 Hz: the rational stage
-        disappears) or else 44 100 Hz (22 050, 14 700).  The exact FFT resampler then takes the last step, i.e. the
-        reference's own brick wall at 5512.5 Hz, and only the wide, flat filters of the earlier stages separate the
-        result from it.  The lower the hand-over rate, the shorter the resampler's forward transform (16 000 Hz: 73 % of
-        what 22 050 Hz needs) -- and with it two of the sharded path's eight exchanges.  ``handover_rate(fs_in)`` names
-        the lowest such rate."""
-        if stop_at_2x and stop_rate is None:
-            stop_rate = 2 * TARGET_RATE
-        self.out_rate = int(stop_rate) if stop_rate else TARGET_RATE
-        self.stop_at_2x = self.out_rate == 2 * TARGET_RATE
-        self.exact_tail = self.out_rate != TARGET_RATE       # an FFT resample from out_rate to 11 025 Hz follows
+    def __init__(self, fs_in: int, att_db: float | None = None, stop_rate: int | None = None):
+        """``stop_rate``: the hand-over rate -- a divisor of ``fs_in`` above 11 025 Hz whose ratio ``stage_factors`` can split
+        (``handover_rate(fs_in)``, the lowest one, by default).  The exact FFT resampler takes the last step from there, i.e. the
+        reference's own brick wall at 5512.5 Hz, and only the wide, flat filters of these stages separate the result from it.
+        The lower the hand-over rate, the shorter the resampler's forward transform."""
         if att_db is None:
             att_db = float(os.environ.get("WFX_FE_ATT", DEFAULT_ATT_DB))
         self.att_db = att_db
-        if int(fs_in) != fs_in or fs_in < 4 * TARGET_RATE:
-            raise ValueError(f"the time-domain front end needs an integer rate >= 44100 Hz, not {fs_in}; use the exact FFT resampler")
+        if int(fs_in) != fs_in or fs_in < 2 * MIN_HANDOVER:
+            raise ValueError(f"the time-domain front end needs an integer rate >= {2 * MIN_HANDOVER} Hz, not {fs_in}; use the exact FFT resampler")
         self.fs_in = int(fs_in)
+        self.out_rate = int(stop_rate) if stop_rate else self.handover_rate(self.fs_in)
+        if self.out_rate <= TARGET_RATE + 1000 or self.fs_in % self.out_rate or stage_factors(self.fs_in // self.out_rate) is None:
+            raise ValueError(f"stop_rate {self.out_rate}: not a rate above 11025 Hz that {self.fs_in} Hz reaches by decimations "
+                             "(powers of two, then 2, 3, 5 or 6)")
+        self.exact_tail = True               # an FFT resample from out_rate to 11 025 Hz follows (kept for callers of rounds 2-3)
+        self.f64 = True                      # the chain runs integer-exact + float64 (FrontEndDevice)
         self.stages = []
-        self.design = None               # figures of the least-squares pair, when it replaced the Kaiser designs
+        self.design = None                   # figures of the least-squares pair, when it replaced the Kaiser designs
         fs = Fraction(self.fs_in)
-        mid = Fraction(4 * TARGET_RATE)
-        while fs / mid >= 2:
-            m = 1
-            while m < 64 and fs / (2 * m) >= mid:
-                m *= 2
-            self.stages.append(Decimate(fs, m, NYQ, float(fs / m) - NYQ, att_db))
-            fs = fs / m
-        if self.exact_tail:
-            if self.out_rate <= TARGET_RATE or (fs % self.out_rate != 0 and mid % self.out_rate != 0):
-                raise ValueError(f"stop_rate {self.out_rate}: not a divisor of {float(fs):g} or 44100 Hz above 11025 Hz")
-            if fs % self.out_rate == 0 and fs != self.out_rate:
-                # one short filter straight to the hand-over rate (its transition band may be wide: only what aliases into
-                # 0..5512.5 Hz matters)
-                self.stages.append(Decimate(fs, int(fs / self.out_rate), NYQ, float(self.out_rate) - NYQ, att_db))
-                self._multiband_pair()
-                self._finish()
-                return
-        if fs != mid:
-            st = Rational(fs, mid, NYQ, float(min(fs, mid)) - NYQ, att_db)
-            if (st.q * (st.taps | 1) + 2048 * st.p // st.q + st.taps + 2) * 4 > 64 * 1024:   # table + one tile's input span
-                raise ValueError(f"{fs_in} Hz needs a {st.q}-phase table that does not fit LDS; use the exact FFT resampler")
-            self.stages.append(st)
-        if self.exact_tail:
-            if mid != self.out_rate:
-                self.stages.append(Decimate(mid, int(mid / self.out_rate), NYQ, float(self.out_rate) - NYQ, att_db))
-            self._finish()
-        else:
-            # the last /4 in two halves, so that the sharp filter runs at half the rate with half the taps
-            self.stages.append(Decimate(mid, 2, NYQ, float(mid / 2) - NYQ, att_db))
-            self.stages.append(Decimate(mid / 2, 2, pass_hz, NYQ, att_db))
-
-    f64 = False
+        for f in stage_factors(self.fs_in // self.out_rate):
+            self.stages.append(Decimate(fs, f, NYQ, float(fs / f) - NYQ, att_db))
+            fs = fs / f
+        self._multiband_pair()
+        self._finish()
 
     def _finish(self):
-        """A chain of decimations only (every hand-over at 16 000 Hz) runs in float64 end to end: the first stage -- int16 samples, a
-        power-of-two factor -- as an integer-exact dot product with taps on the grid 2**-30 (``quantize_taps``; csrc/wfx_polyphase.hip
-        MODE 1), the stages behind it with float64 taps and sums.  What reaches the exact path then differs from an ideal filter
-        by the designs' own error alone -- no fp32 rounding of samples or sums, which is what flipped 5-30 stream bytes per clip in
-        round 2 (a float64 model of the same chain flips none).  ``f64`` tells FrontEndDevice which entry points to use."""
-        if os.environ.get("WFX_FE_FP32") == "1" or any(st.kind != "decimate" for st in self.stages):
-            return
-        self.f64 = True
+        """The first stage -- int16 samples, a power-of-two factor >= 8 -- runs as an integer-exact dot product with taps on the grid
+        2**-30 (``quantize_taps``; csrc/wfx_polyphase.hip MODE 1), the stages behind it with float64 taps and sums.  What reaches
+        the exact path then differs from an ideal filter by the designs' own error alone."""
         if self.design is None:
-            # Kaiser designs at the low rates (48 kHz: /3; 192 kHz: /4, /3): their pass-band ripple 10**(-att/20) = 1.8e-7 is now the
-            # largest error left (4-9 flipped stream bytes per 48 kHz clip in float64 arithmetic at 135 dB, 1-3 at 160 dB);
+            # Kaiser designs at the low rates (48 kHz: /3; 192 kHz: /4, /3): their pass-band ripple 10**(-att/20) = 1.8e-7 would be the
+            # largest error left (4-9 flipped stream bytes per 48 kHz clip at 135 dB, 1-3 at 160 dB, none at 200 dB);
             # 200 dB costs half as many taps again where taps are cheap
             for k, st in enumerate(self.stages):
                 if float(st.fs_in) <= 200e3 and self.att_db < LOW_RATE_ATT_DB:
@@ -351,13 +305,13 @@ class FrontEnd:
 
     @staticmethod
     def handover_rate(fs_in: int) -> int:
-        """The lowest hand-over rate this front end can deliver for ``fs_in``: a third of what the power-of-two
-        decimations leave when that is a whole number of Hz (1.536 MS/s, 192 kHz, 48 kHz -> 16 000), else 14 700."""
-        fs = Fraction(int(fs_in))
-        while fs / (4 * TARGET_RATE) >= 2:
-            fs /= 2
-        third = fs / 3
-        return int(third) if third.denominator == 1 and third > TARGET_RATE + 2000 else 14700
+        """The lowest hand-over rate this front end can deliver for ``fs_in``: at least 14 000 Hz, reached by powers of two and a
+        last factor of 2, 3, 5 or 6 (1.536 MS/s, 192 kHz, 48 kHz -> 16 000; 44.1 kHz -> 14 700; 96 kHz -> 16 000)."""
+        fs_in = int(fs_in)
+        for ratio in range(fs_in // MIN_HANDOVER, 0, -1):
+            if fs_in % ratio == 0 and stage_factors(ratio) is not None:
+                return fs_in // ratio
+        raise ValueError(f"no hand-over rate for {fs_in} Hz")
 
     def n_target(self, n_in: int) -> int:
         """wefax.py:384 ``num = int(11025 * length)`` with ``length = n / sample_rate`` (wefax.py:357), in the reference's own
@@ -382,14 +336,10 @@ class FrontEnd:
             raise ValueError(f"time-domain front end {self.fs_in} -> {self.out_rate} Hz: a capture of {n_in} frames is not a whole number of "
                              f"hand-over samples (granule {g} frames, {n_in % g} too many): the reference's resampling grid "
                              "(wefax.py:384) cannot be kept; drop the surplus frames or use the exact path")
-        n_fe = int(prod)
-        if not self.exact_tail and n_fe != self.n_target(n_in):
-            raise ValueError(f"time-domain front end to 11 025 Hz: the reference resamples {n_in} frames to {self.n_target(n_in)} samples "
-                             f"(wefax.py:384), the fixed-ratio chain gives {n_fe}; use FrontEnd(stop_rate=...) or the exact path")
-        return n_fe
+        return int(prod)
 
     def chain(self, lo: int, hi: int):
-        """Index ranges per stage for outputs [lo, hi) at 11 025 Hz: list of (stage, out range,
+        """Index ranges per stage for outputs [lo, hi) at the hand-over rate: list of (stage, out range,
         in range), first stage first; a stage's output range is the next stage's input range."""
         out = []
         a, b = lo, hi
@@ -410,8 +360,5 @@ class FrontEnd:
     def describe(self) -> str:
         parts = []
         for st in self.stages:
-            if st.kind == "decimate":
-                parts.append(f"/{st.factor} ({st.ntaps} taps @ {float(st.fs_in):g} Hz)")
-            else:
-                parts.append(f"x{st.q}/{st.p} ({st.q} phases x {st.taps} taps @ {float(st.fs_in):g} Hz)")
+            parts.append(f"/{st.factor} ({st.ntaps} taps @ {float(st.fs_in):g} Hz{', integer-exact on the 2^-%d grid' % st.fix_shift if st.fix_shift else ', float64'})")
         return " -> ".join(parts)

@@ -360,15 +360,15 @@ class FrontEndDevice:
         self.n_out = b - a
         self.p_out = self._alloc(8 * self.n_out * self.nbatch)
         self.p_stage = {}
-        # a chain of decimations runs in float64 throughout (integer-exact ingest, polyphase.FrontEnd._finish)
-        self.f64 = all(st.kind == "decimate" for st, _, _ in chain) and bool(getattr(chain[0][0], "f64_chain", False))
-        if self.nbatch > 1 and not self.f64:
-            raise ValueError("batched front end: float64 chains of decimations only")
+        # a chain of decimations: integer-exact ingest where the first stage qualifies, float64 behind it (polyphase.FrontEnd._finish)
+        self.f64 = True
+        if any(st.kind != "decimate" for st, _, _ in chain):
+            raise ValueError("front end: chains of decimations only (the fp32 rational stage was removed in round 4)")
         self.stage_stride = {}
         for k, (st, (a, b), _) in enumerate(chain[:-1]):
             stride = (b - a) + ((b - a) & 1)                    # members of a batch start a multiple of 16 bytes apart
             self.stage_stride[k] = stride
-            self.p_stage[k] = self._alloc((8 if self.f64 else 4) * stride * self.nbatch)
+            self.p_stage[k] = self._alloc(8 * stride * self.nbatch)
         self.exact_ingest = None
 
     def _alloc(self, nbytes):
@@ -384,21 +384,12 @@ class FrontEndDevice:
             last = k == len(self.chain) - 1
             n_out = b - a
             out = self.p_out if last else self.p_stage[k]
-            if st.kind == "decimate" and self.f64:
-                in_stride = self.raw_stride if k == 0 else self.stage_stride[k - 1]
-                ex = self.ctx.d_decimate_fir64(cur, kind, n_cur, 0, st.factor, st.coef64, out, n_out, st.fix_shift if k == 0 else 0,
-                                               nbatch=self.nbatch, in_stride=in_stride, out_stride=n_out if last else self.stage_stride[k])
-                if k == 0:
-                    self.exact_ingest = ex
-                cur, kind, n_cur = out, nat.WFX_IN_F64_MONO, n_out
-                continue
-            if st.kind == "decimate":
-                self.ctx.d_decimate_fir(cur, kind, n_cur, 0, st.factor, st.coef, out, last, n_out)
-            else:
-                shift = max(0, -(a // st.q))              # whole phase periods: makes the first output index non-negative
-                self.ctx.d_resample_rational(cur, kind, n_cur, ia + st.left + shift * st.p, st.p, st.q, st.table,
-                                             a + shift * st.q, out, n_out)
-            cur, kind, n_cur = out, nat.WFX_IN_F32_MONO, n_out
+            in_stride = self.raw_stride if k == 0 else self.stage_stride[k - 1]
+            ex = self.ctx.d_decimate_fir64(cur, kind, n_cur, 0, st.factor, st.coef64, out, n_out, st.fix_shift if k == 0 else 0,
+                                           nbatch=self.nbatch, in_stride=in_stride, out_stride=n_out if last else self.stage_stride[k])
+            if k == 0:
+                self.exact_ingest = ex
+            cur, kind, n_cur = out, nat.WFX_IN_F64_MONO, n_out
 
     def fetch(self) -> np.ndarray:
         return self.ctx.dev_download(self.p_out, (self.n_out * self.nbatch,), np.float64)
@@ -462,12 +453,8 @@ class FrontEndShardedDecoder:
 
     def __init__(self, ctx, comm, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None,
                  notch=None, plan="auto"):
-        if not frontend.exact_tail:
-            raise ValueError("the sharded form needs FrontEnd(stop_rate=...): the exact resampler takes the last step")
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
         n_fe = frontend.n_out(n_in_total)
-        if not getattr(frontend, "f64", False):            # (chains with a rational stage: one contiguous range per rank)
-            plan = plan_code(plan) | 16
         self.dec = ShardedDecoder(ctx, comm, n_fe, frontend.out_rate, lines_per_minute, nat.WFX_IN_F64_MONO, notch,
                                   n_out=frontend.n_target(n_in_total), plan=plan)
         lay = self.dec.layout
