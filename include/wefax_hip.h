@@ -392,6 +392,9 @@ int wfx_shard_wire_plan(const wfx_decode_params *p, int world, wfx_wire_entry *o
  * last 256), total_bytes = bytes THIS rank sent to other ranks, max_rank_bytes = bytes it received from them, max_link_bytes =
  * the largest message; transport-independent (RCCL, shm and local communicators count alike).  Returns the number of
  * collectives since the reset. */
+/* exchanges this communicator has run on its own stream so far (RCCL: the k1 subsets' E2 / E3, overlapping the slab passes of other
+ * subsets; 0 on the transports that complete an exchange before returning) */
+uint64_t wfx_comm_async_exchanges(wfx_comm *comm);
 int wfx_comm_wire_reset(wfx_comm *comm);
 int wfx_comm_wire_stats(wfx_comm *comm, wfx_wire_entry *out, int cap);
 /* `p` describes the WHOLE capture (as for wfx_decode_upload); hilbert_mode must be WFX_HILBERT_FFT */

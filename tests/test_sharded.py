@@ -94,8 +94,12 @@ def test_columns_layout_halves_the_bytes_on_the_wire():
     for world in (2, 4, 8):
         wr, wc = nat.shard_wire_plan(rows, world), nat.shard_wire_plan(cols, world)
         names_c = [e["name"] for e in wc]
-        assert names_c == ["resample fwd E2", "resample inv E3", "resample inv halo", "hilbert E2", "hilbert E3", "hilbert halo",
-                           "select level 0", "select level 1", "select candidates", "stream gather"]
+        # (every transpose travels in 4 k1 subsets, each a collective of its own: the exchange of one overlaps the passes of another)
+        nsub = names_c.count("hilbert E2")
+        assert nsub == 4
+        dedup = [n for i, n in enumerate(names_c) if i == 0 or names_c[i - 1] != n]
+        assert dedup == ["resample fwd E2", "resample inv E3", "resample inv halo", "hilbert E2", "hilbert E3", "hilbert halo",
+                         "select level 0", "select level 1", "select candidates", "stream gather"]
         assert [e["name"] for e in wr][:8] == ["resample fwd E1", "resample fwd E2", "resample inv E3", "resample inv E4", "hilbert E1", "hilbert E2",
                                                "hilbert E3", "hilbert E4"]
         tr = _wire_total(rows, world, lambda nm: " E" in nm)
@@ -107,9 +111,9 @@ def test_columns_layout_halves_the_bytes_on_the_wire():
         assert halo <= world * 225 * (16 + 16 + 2 + 2) * 16
         total_r, total_c = _wire_total(rows, world), _wire_total(cols, world)
         assert total_c <= 0.52 * total_r
-        by = {e["name"]: e for e in wc}
-        # a transpose puts array / world^2 on every directed link
-        assert abs(by["hilbert E2"]["max_link_bytes"] - a_h / world ** 2) <= 0.10 * a_h / world ** 2        # (the k1 sets differ by a unit or two)
+        # a transpose puts array / world^2 on every directed link, a quarter of it per subset
+        link = sum(e["max_link_bytes"] for e in wc if e["name"] == "hilbert E2")
+        assert abs(link - a_h / world ** 2) <= 0.2 * a_h / world ** 2         # (the maxima of four subsets, whose k1 sets differ by a unit or two)
     assert _wire_total(cols, 8) <= 1.31e9 and _wire_total(rows, 8) >= 2.5e9
 
 
@@ -368,9 +372,11 @@ def test_bytes_counted_by_the_communicator_equal_the_plan(case, layout):
         for rank_stats in r["wire"]:
             for e in rank_stats:
                 seen[e["name"]] = seen.get(e["name"], 0) + e["sent"]
-        for e in plan:
-            assert seen.get(e["name"]) == e["bytes"], (world, e, seen.get(e["name"]))
-        assert len(r["wire"][0]) == len(plan)
+        want = {}
+        for e in plan:                                    # (a transpose appears once per k1 subset)
+            want[e["name"]] = want.get(e["name"], 0) + e["bytes"]
+        assert seen == want, (world, seen, want)
+        assert [e["name"] for e in r["wire"][0]] == [e["name"] for e in plan]      # the same collectives in the same order
 
 
 @pytest.mark.gpu
@@ -411,6 +417,40 @@ def test_rccl_communicator_with_one_rank():
     info = dec.result()
     assert np.array_equal(dec.fetch("image"), img) and np.array_equal(dec.fetch("stream"), stream)
     assert info.start_frame == job.result().start_frame
+    dec.close()
+    comm.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,stereo", [(11025, False), (48000, True)])
+def test_exchanges_of_k1_subsets_on_the_communicators_own_stream(monkeypatch, rate, stereo):
+    """RCCL with the one rank a one-GPU box has, the k1 set cut into 4 subsets: every E2 / E3 goes to the communicator's stream
+    (an event on the context's stream gates it, an event per slot releases the slab passes that consume it), the passes of one
+    subset are enqueued while the exchange of the next is in flight -- and the decode is the fused one's, decode after decode.
+    WFX_COMM_ASYNC=0 runs the same exchanges in stream order: same result."""
+    from wefax_amd.wefax import DecodeJob
+    kw = dict(KW30) if rate != 11025 else dict(KW130)
+    x = synth.synth_capture(float(rate), noise=0.05, seed=5, iq=stereo, **kw)
+    ctx = nat.Context(0)
+    job = DecodeJob(ctx, x, rate, 120)
+    job.run()
+    img, stream, start = job.fetch("image"), job.fetch("digitalized"), job.result().start_frame
+    monkeypatch.setenv("WFX_SHARD_CHUNKS", "4")
+    uid = sharded.bootstrap_unique_id(0, 1)
+    comm = nat.Comm.rccl(ctx, uid, 1, 0)
+    dec = sharded.ShardedDecoder(ctx, comm, x.shape[0], rate, 120, sharded.capture_kind(x), data=x, plan="dist")
+    pairs = 2 if rate != 11025 else 1                   # distributed transform pairs per decode: resampler + Hilbert, or Hilbert alone
+    assert dec.shard.phases == (4 * 4 + 7 if rate != 11025 else 2 * 4 + 6)
+    for rep in range(3):
+        dec.run()
+    info = dec.result()
+    assert comm.async_exchanges == 3 * pairs * 2 * 4    # E2 and E3 of 4 subsets per pair and decode
+    assert np.array_equal(dec.fetch("image"), img) and np.array_equal(dec.fetch("stream"), stream) and info.start_frame == start
+    before = comm.async_exchanges
+    monkeypatch.setenv("WFX_COMM_ASYNC", "0")
+    dec.run()
+    assert comm.async_exchanges == before and np.array_equal(dec.fetch("stream"), stream)
     dec.close()
     comm.close()
     ctx.close()

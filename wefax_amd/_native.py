@@ -34,7 +34,7 @@ SYMBOLS = [
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
-    "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_wire_plan", "wfx_comm_wire_reset", "wfx_comm_wire_stats", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
+    "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_wire_plan", "wfx_comm_wire_reset", "wfx_comm_wire_stats", "wfx_comm_async_exchanges", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
     "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
     "wfx_synth_frames", "wfx_synth_capture", "wfx_decode_png", "wfx_decode_save_png", "wfx_decode_png_ex", "wfx_decode_save_png_ex", "wfx_host_alloc", "wfx_host_free",
     "wfx_decode_reload", "wfx_decode_fetch_async", "wfx_plan_padded_length", "wfx_plan_describe",
@@ -241,6 +241,8 @@ def load():
     lib.wfx_shard_dry_run.argtypes = [C.POINTER(DecodeParams), i]
     lib.wfx_shard_wire_plan.argtypes = [C.POINTER(DecodeParams), i, C.POINTER(WireEntry), i]
     lib.wfx_comm_wire_reset.argtypes = [vp]
+    lib.wfx_comm_async_exchanges.argtypes = [vp]
+    lib.wfx_comm_async_exchanges.restype = C.c_uint64
     lib.wfx_comm_wire_stats.argtypes = [vp, C.POINTER(WireEntry), i]
     lib.wfx_shard_create.argtypes = [vp, vp, C.POINTER(DecodeParams), C.POINTER(vp)]
     lib.wfx_shard_upload.argtypes = [vp, vp]
@@ -718,6 +720,11 @@ class Comm:
 
     def wire_reset(self):
         self.lib.wfx_comm_wire_reset(self.h)
+
+    @property
+    def async_exchanges(self) -> int:
+        """Exchanges run on the communicator's own stream so far (RCCL only: overlapping the caller's kernels)."""
+        return int(self.lib.wfx_comm_async_exchanges(self.h))
 
     def wire_stats(self) -> list:
         """This rank's collectives since the last reset: name, bytes sent to / received from other ranks, largest message."""

@@ -163,6 +163,13 @@ struct wfx_comm {
     std::vector<wfx_wire_entry> wire;
     unsigned long long wire_count = 0;
     char label[24] = {0};
+    // RCCL backend: exchanges that may overlap compute go to a stream of the communicator's own (wfx_comm_exchange_async): an
+    // event recorded on the context's stream gates them, an event per slot marks their completion (wfx_comm_wait)
+    hipStream_t xstream = nullptr;
+    hipEvent_t ready = nullptr;
+    std::vector<hipEvent_t> done;
+    std::vector<char> pending;
+    unsigned long long async_count = 0;
 };
 
 void wfx_comm_label(wfx_comm *c, const char *name)
@@ -624,6 +631,75 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
     return 0;
 }
 
+// An exchange that need not finish before the caller enqueues more work on its stream: RCCL communicators run it on their own
+// stream, after everything the context's stream holds so far; wfx_comm_wait(slot) makes the context's stream wait for it.  The other
+// transports (in-process, shared memory) complete it before returning, as wfx_comm_exchange does -- same results, no overlap.
+// WFX_COMM_ASYNC=0 keeps RCCL exchanges in stream order too (A/B runs).
+int wfx_comm_exchange_async(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n, int slot)
+{
+    if (!c) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null communicator");
+    const char *env = getenv("WFX_COMM_ASYNC");
+    const bool off = env && atoi(env) == 0;
+    if (!c->nccl || off || slot < 0 || slot >= 64) return wfx_comm_exchange(c, ctx, list, n);
+    for (int i = 0; i < n; ++i)
+        if (list[i].peer < 0 || list[i].peer >= c->world) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "exchange: peer %d out of range", list[i].peer);
+    if (!c->xstream) {
+        WFX_HIP(ctx, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+        WFX_HIP(ctx, hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+        c->done.assign(64, nullptr);
+        c->pending.assign(64, 0);
+        for (int k = 0; k < 64; ++k) WFX_HIP(ctx, hipEventCreateWithFlags(&c->done[(size_t)k], hipEventDisableTiming));
+    }
+    {
+        unsigned long long sent = 0, got = 0, big = 0;
+        for (int i = 0; i < n; ++i)
+            if (list[i].peer != c->rank) {
+                sent += list[i].send_bytes;
+                got += list[i].recv_bytes;
+                if (list[i].send_bytes > big) big = list[i].send_bytes;
+            }
+        wire_record(c, "exchange", sent, got, big);
+    }
+    WFX_HIP(ctx, hipEventRecord(c->ready, ctx->stream));
+    WFX_HIP(ctx, hipStreamWaitEvent(c->xstream, c->ready, 0));
+    bool any_remote = false;
+    for (int i = 0; i < n; ++i) {
+        any_remote = any_remote || list[i].peer != c->rank;
+        if (list[i].peer == c->rank && list[i].send_bytes) {
+            if (list[i].send_bytes != list[i].recv_bytes) return wfx_fail(ctx, WFX_ERR_COMM, "exchange: self message of %zu bytes into %zu", list[i].send_bytes, list[i].recv_bytes);
+            if (list[i].send != list[i].recv)
+                WFX_HIP(ctx, hipMemcpyAsync(list[i].recv, list[i].send, list[i].send_bytes, hipMemcpyDeviceToDevice, c->xstream));
+        }
+    }
+    if (any_remote) {
+        WFX_NCCL(ctx, g_rccl.GroupStart());
+        ncclResult_t bad = ncclSuccess;
+        for (int i = 0; i < n && bad == ncclSuccess; ++i) {
+            if (list[i].peer == c->rank) continue;
+            if (list[i].send_bytes) bad = g_rccl.Send(list[i].send, list[i].send_bytes, ncclUint8, list[i].peer, c->nccl, c->xstream);
+            if (bad == ncclSuccess && list[i].recv_bytes) bad = g_rccl.Recv(list[i].recv, list[i].recv_bytes, ncclUint8, list[i].peer, c->nccl, c->xstream);
+        }
+        const ncclResult_t end = g_rccl.GroupEnd();
+        if (bad != ncclSuccess) return fail_nccl(ctx, bad, "ncclSend / ncclRecv of an exchange");
+        if (end != ncclSuccess) return fail_nccl(ctx, end, "ncclGroupEnd");
+    }
+    WFX_HIP(ctx, hipEventRecord(c->done[(size_t)slot], c->xstream));
+    c->pending[(size_t)slot] = 1;
+    ++c->async_count;
+    return 0;
+}
+
+// the context's stream waits for the exchange recorded under `slot` (no-op when it ran in stream order or has been waited for)
+int wfx_comm_wait(wfx_comm *c, wfx_ctx *ctx, int slot)
+{
+    if (!c || slot < 0 || slot >= (int)c->pending.size() || !c->pending[(size_t)slot]) return 0;
+    WFX_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->done[(size_t)slot], 0));
+    c->pending[(size_t)slot] = 0;
+    return 0;
+}
+
+unsigned long long wfx_comm_async_count(const wfx_comm *c) { return c ? c->async_count : 0; }
+
 int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t count)
 {
     if (!c) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null communicator");
@@ -971,6 +1047,8 @@ int wfx_comm_selftest(wfx_comm *comm, wfx_ctx *ctx, int rounds, uint64_t seed)
     return 0;
 }
 
+uint64_t wfx_comm_async_exchanges(wfx_comm *comm) { return comm ? comm->async_count : 0; }
+
 int wfx_comm_wire_reset(wfx_comm *comm)
 {
     if (!comm) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null communicator");
@@ -1035,6 +1113,16 @@ int wfx_comm_allgather_host(wfx_comm *comm, wfx_ctx *ctx, const void *send_host,
 int wfx_comm_destroy(wfx_comm *comm)
 {
     if (!comm) return 0;
+    if (comm->xstream) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > comm->device && hipSetDevice(comm->device) == hipSuccess) {
+            (void)hipStreamSynchronize(comm->xstream);
+            for (hipEvent_t e : comm->done)
+                if (e) (void)hipEventDestroy(e);
+            if (comm->ready) (void)hipEventDestroy(comm->ready);
+            (void)hipStreamDestroy(comm->xstream);
+        }
+    }
     if (comm->nccl) {
         int ndev = 0;
         // (a communicator destroyed after the HIP runtime has shut down -- a garbage collector at interpreter exit -- is left alone)

@@ -50,13 +50,19 @@ class wfx_dist {
     // buffers are owned by this object; `halo_before` / `halo_after`: points delivered around the own rows by the inverse
     // dry: plan only -- no device memory, no kernels; buffers get fake base addresses `dry_base + k * 2^36` so that exchange
     // lists and piece descriptors can be built and checked on a machine without a GPU (wfx_shard_dry_run)
+    // nchunk > 1 (columns mode): the rank's first-pass outputs k1 are cut into that many subsets -- each closed under k1 -> R1 - k1
+    // like the rank's whole set, i.e. the k1 sets of a geometry with world * nchunk ranks -- and E2, the slab passes and E3 run
+    // subset by subset, so that the exchange of one subset (on the communicator's own stream) overlaps the passes of another
     int init(wfx_ctx *ctx, const wfx_dist_geom &g, long long L, int elem_bytes_in, int halo_before, int halo_after, bool dry = false,
-             unsigned long long dry_base = 0);
+             unsigned long long dry_base = 0, int nchunk = 1);
+    int chunks() const { return C; }
     void release();
     void set_tag(const char *t) { snprintf(tag_, sizeof tag_, "%s", t); }        // names this transform's exchanges in the wire statistics
     const char *tag() const { return tag_; }
     // (for the dry run) exchange e in 1..4: its messages and its copy pieces; the buffers as (base, bytes) pairs
-    const std::vector<wfx_xfer> &xfers(int e) const { return e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : e == 4 ? x4 : xh; }
+    const std::vector<wfx_xfer> &xfers(int e) const { return e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : e == 4 ? x4 : xh; }      // (E2 / E3: all subsets, in order)
+    const std::vector<wfx_xfer> &xfers_chunk(int e, int c) const { return e == 2 ? x2c[c] : x3c[c]; }
+    const wfx_dist_kmap &chunk_kmap(int c) const { return kmc[c]; }
     const std::vector<wfx_dist_piece> &pieces(int e) const { return e == 1 ? p1 : e == 2 ? p_none : e == 3 ? p3 : e == 4 ? p4 : ph; }
     const std::vector<mr_qmap> &first_pass_map() const { return qmap; }
     void buffers(std::vector<std::pair<unsigned long long, unsigned long long>> &out) const;
@@ -74,12 +80,20 @@ class wfx_dist {
     int bind_cols(const void *cols_in, long long in_rs, cplx *cols_out, long long out_rs, int inv_in);
     bool cols_mode() const { return cols_; }
     // slab buffer index in which fwd_slab leaves the spectrum
-    int fwd_result_index() const { return (int)(d_fwd.size() & 1); }
+    int fwd_result_index() const { return d_fwd.empty() ? 0 : (int)(d_fwd[0].size() & 1); }
 
     long long L = 0, M = 0;
     int w = 0, B = 0, nr = 0;            // this rank's columns, slab batch, rows
     std::vector<long long> cols;         // [world + 1]
     long long slab_points() const { return M * (long long)B; }
+    // ---- subset by subset (nchunk >= 1; `slot`: which of the communicator's completion events the exchange records) -------
+    int fwd_pass1(int in_mode);                                                    // pass 1: every subset's E2 messages are ready
+    int e2_exchange(wfx_comm *c, int chunk, int slot);                             // E2 of one subset (asynchronous where the transport can)
+    int fwd_slab_chunk(int chunk, int hilbert_spectrum, cplx **spectrum, long long skip_lo = 0, long long skip_hi = 0);
+    int inv_slab_chunk(int chunk, cplx *slab_in);                                  // passes np..2 of one subset
+    int e3_exchange(wfx_comm *c, int chunk, int slot);
+    cplx *slab_chunk(int i, int chunk) { return slab_buffer(i) + soff[chunk]; }
+    int fwd_result_index_chunk() const { return fwd_result_index(); }
 
     // ---- forward --------------------------------------------------------------------------------------------------
     // rows_in: this rank's rows [nr][M] (elements of elem_bytes_in: 16 = cplx / pairs of doubles, 4 = int16 pairs)
@@ -107,7 +121,12 @@ class wfx_dist {
     bool dry_ = false;
     std::vector<wfx_mr_radix> sub;                 // passes of the M-point transforms (pairs where possible)
     mr_pass_desc d_first{}, d_last{};
-    std::vector<mr_pass_desc> d_fwd, d_inv;
+    std::vector<std::vector<mr_pass_desc>> d_fwd, d_inv;     // [subset][pass]
+    int C = 1;                                     // subsets of this rank's k1 set
+    std::vector<wfx_dist_kmap> kmc;                // [C] this rank's subsets; kmv: every rank's, [world * C]
+    std::vector<wfx_dist_kmap> kmv;
+    std::vector<long long> soff;                   // [C + 1] offsets of the subsets' slabs (points) in the slab buffers
+    std::vector<std::vector<wfx_xfer>> x2c, x3c;   // [C]
     std::vector<size_t> tw_fwd, tw_inv;
     size_t tw_last = 0;
     wfx_devbuf tables, b_pack, b_recv, b_y, b_a, b_a2, b_desc, b_halo;
@@ -141,3 +160,5 @@ int wfx_dist_copy2d(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces,
 int wfx_dist_scatter_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npieces, int max_rows);
 // scipy.signal.resample's bin copy between the forward spectrum slab (packed n0 / 2 points) and the inverse's input slab (num / 2)
 int wfx_dist_resample_glue(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Z, long long n0, long long num, cplx *W);
+// the same for one k1 subset of a rank (its own slab [.][km.B] in, its own slab out)
+int wfx_dist_resample_glue_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, const cplx *Z, long long n0, long long num, cplx *W);

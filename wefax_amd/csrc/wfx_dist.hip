@@ -174,7 +174,7 @@ void wfx_dist::release()
 }
 
 int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int elem_bytes_in, int halo_before, int halo_after, bool dry,
-                   unsigned long long dry_base)
+                   unsigned long long dry_base, int nchunk)
 {
     ctx = ctx_;
     dry_ = dry;
@@ -198,52 +198,78 @@ int wfx_dist::init(wfx_ctx *ctx_, const wfx_dist_geom &g_, long long L_, int ele
             return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: %lld points are too few for %d ranks", L, W);
     if (nr < 1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: rank %d owns no rows", me);
 
+    // ---- subsets of the k1 set: the k1 sets of a geometry with W * C ranks (rank r's subsets are the virtual ranks r C .. r C + C - 1:
+    // the unit ranges nest, so together they are exactly rank r's own set) ----
+    C = nchunk < 1 ? 1 : nchunk;
+    wfx_dist_geom gv;
+    while (C > 1 && !wfx_dist_make_geom(gv, W * C, me * C, g.ra1, g.rb1)) --C;
+    kmv.clear();
+    if (C > 1) {
+        kmv = gv.km;
+        int tot = 0;
+        for (int c = 0; c < C; ++c) tot += kmv[(size_t)me * C + c].B;
+        if (tot != B || kmv[(size_t)me * C].kb0 != g.km[me].kb0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed transform: the k1 subsets do not tile the rank's set");
+    } else
+        kmv = g.km;
+    kmc.assign(kmv.begin() + (size_t)me * C, kmv.begin() + (size_t)me * C + C);
+    soff.assign(C + 1, 0);
+    for (int c = 0; c < C; ++c) soff[c + 1] = soff[c] + M * (long long)kmc[c].B;
     // ---- pass descriptors and twiddle tables ----
     const int ns = (int)sub.size();
     size_t off = 0;
     wfx_mr_pair_desc(d_first, g.ra1, g.rb1, 1, w, (long long)R1 * w);
-    d_fwd.resize(ns);
-    d_inv.resize(ns);
+    d_fwd.assign(C, std::vector<mr_pass_desc>(ns));
+    d_inv.assign(C, std::vector<mr_pass_desc>(ns));
     tw_fwd.resize(ns);
     tw_inv.resize(ns);
     {
-        long long Play = B, Ptw = R1;
+        long long Ptw = R1;
         for (int i = 0; i < ns; ++i) {              // forward: the global plan's passes 2.., twiddles by global k = k1 + R1 (.)
+            tw_fwd[i] = off;
+            off += wfx_mr_table_elems(Ptw * sub[i].R);
+            Ptw *= sub[i].R;
+        }
+        long long Psub = 1;
+        for (int i = 0; i < ns; ++i) {              // inverse: M-point transforms, radices in the reverse order
+            tw_inv[i] = off;
+            off += wfx_mr_table_elems(Psub * sub[ns - 1 - i].R);
+            Psub *= sub[ns - 1 - i].R;
+        }
+    }
+    for (int c = 0; c < C; ++c) {
+        const int Bc = kmc[c].B;
+        long long Play = Bc, Ptw = R1;
+        for (int i = 0; i < ns; ++i) {
             const int R = sub[i].R;
-            mr_pass_desc &d = d_fwd[i];
-            wfx_mr_general_desc(d, sub[i], Play, (long long)B * M / R, (long long)B * M);
+            mr_pass_desc &d = d_fwd[c][i];
+            wfx_mr_general_desc(d, sub[i], Play, (long long)Bc * M / R, (long long)Bc * M);
             d.dist = 1;
-            d.B = B;
-            d.kb0 = g.km[me].kb0;
-            d.kc0 = g.km[me].kc0;
-            d.kb1 = g.km[me].kb1;
+            d.B = Bc;
+            d.kb0 = kmc[c].kb0;
+            d.kc0 = kmc[c].kc0;
+            d.kb1 = kmc[c].kb1;
             d.kscale = 1;
             d.kstep = R1;
             d.Ptw = Ptw;
             d.Ltw = L;
-            tw_fwd[i] = off;
-            off += wfx_mr_table_elems(Ptw * R);
             Play *= R;
             Ptw *= R;
         }
-    }
-    {
-        long long Play = B, Psub = 1;
-        for (int i = 0; i < ns; ++i) {              // inverse: M-point transforms, radices in the reverse order
+        Play = Bc;
+        long long Psub = 1;
+        for (int i = 0; i < ns; ++i) {
             const wfx_mr_radix pr = sub[ns - 1 - i];
             const int R = pr.R;
-            mr_pass_desc &d = d_inv[i];
-            wfx_mr_general_desc(d, pr, Play, (long long)B * M / R, (long long)B * M);
+            mr_pass_desc &d = d_inv[c][i];
+            wfx_mr_general_desc(d, pr, Play, (long long)Bc * M / R, (long long)Bc * M);
             d.dist = 1;
-            d.B = B;
+            d.B = Bc;
             d.kb0 = d.kb1 = 0;
-            d.kc0 = B;
+            d.kc0 = Bc;
             d.kscale = 0;
             d.kstep = 1;
             d.Ptw = Psub;
             d.Ltw = L;
-            tw_inv[i] = off;
-            off += wfx_mr_table_elems(Psub * R);
             Play *= R;
             Psub *= R;
         }
@@ -345,58 +371,67 @@ void wfx_dist::build_lists(const void *rows_in, cplx *rows_out)
             if (d != me) off += (size_t)nr * wd * ES;
         }
     }
-    // E2: first-pass output (column j, output k1) -> slabs [M][B_e].  No packing copy: the first pass stores every output where the
-    // exchange sends it from (mr_pass_desc::qmap), the own part straight into the slab.
+    // E2: first-pass output (column j, output k1) -> slabs [M][B_(e,c)], one per rank e and subset c.  No packing copy: the first
+    // pass stores every output where the exchange sends it from (mr_pass_desc::qmap), the own part straight into the slab.
+    x2c.assign(C, {});
+    x3c.assign(C, {});
     {
         size_t off = 0;
-        for (int e = 0; e < W; ++e) {
-            const wfx_dist_kmap &km = g.km[e];
-            cplx *self_dst = A + (size_t)cols[me] * B;
-            cplx *dst = e == me ? self_dst : (cplx *)pack + off;
-            for (int kk = 0; kk < km.B; ++kk) {
-                const int k1 = kk < km.kc0 ? km.kb0 + kk : km.kb1 + (kk - km.kc0);
-                qmap[k1].base = (unsigned long long)(dst + kk);
-                qmap[k1].stride = km.B;
+        for (int c = 0; c < C; ++c)
+            for (int e = 0; e < W; ++e) {
+                const wfx_dist_kmap &km = kmv[(size_t)e * C + c];
+                const int Bme = kmc[c].B;
+                cplx *self_dst = A + soff[c] + (size_t)cols[me] * Bme;
+                cplx *dst = e == me ? self_dst : (cplx *)pack + off;
+                for (int kk = 0; kk < km.B; ++kk) {
+                    const int k1 = kk < km.kc0 ? km.kb0 + kk : km.kb1 + (kk - km.kc0);
+                    qmap[k1].base = (unsigned long long)(dst + kk);
+                    qmap[k1].stride = km.B;
+                }
+                wfx_xfer x{};
+                x.peer = e;
+                x.send = dst;
+                x.send_bytes = (size_t)w * km.B * sizeof(cplx);
+                x.recv = A + soff[c] + (size_t)cols[e] * Bme;
+                x.recv_bytes = (size_t)(cols[e + 1] - cols[e]) * Bme * sizeof(cplx);
+                x2c[c].push_back(x);
+                x2.push_back(x);
+                if (e != me) off += (size_t)w * km.B;
             }
-            wfx_xfer x{};
-            x.peer = e;
-            x.send = dst;
-            x.send_bytes = (size_t)w * km.B * sizeof(cplx);
-            x.recv = A + (size_t)cols[e] * B;
-            x.recv_bytes = (size_t)(cols[e + 1] - cols[e]) * B * sizeof(cplx);
-            x2.push_back(x);
-            if (e != me) off += (size_t)w * km.B;
-        }
     }
     // E3: slab rows -> [R1][w] (S = inv_result, known after init: see inv_slab_exchange)
     {
         cplx *S = inv_result;
         size_t off = 0;
-        for (int e = 0; e < W; ++e) {
-            const wfx_dist_kmap &km = g.km[e];
-            cplx *src = e == me ? S + (size_t)cols[me] * B : (cplx *)recv + off;
-            wfx_dist_piece p{};
-            p.src = (unsigned long long)src;
-            p.dst = (unsigned long long)Y;
-            p.rows = w;
-            p.cols = km.B;
-            p.src_rs = km.B;
-            p.dst_rs = w;
-            p.kb0 = km.kb0;
-            p.kc0 = km.kc0;
-            p.kb1 = km.kb1;
-            p.B = km.B;
-            p3.push_back(p);
-            wfx_xfer x{};
-            x.peer = e;
-            x.send = S + (size_t)cols[e] * B;                       // to rank e: my slab's rows of its columns (contiguous)
-            x.send_bytes = (size_t)(cols[e + 1] - cols[e]) * B * sizeof(cplx);
-            x.recv = src;
-            x.recv_bytes = (size_t)w * km.B * sizeof(cplx);
-            if (e == me) x.send = x.recv;
-            x3.push_back(x);
-            if (e != me) off += (size_t)w * km.B;
-        }
+        for (int c = 0; c < C; ++c)
+            for (int e = 0; e < W; ++e) {
+                const wfx_dist_kmap &km = kmv[(size_t)e * C + c];
+                const int Bme = kmc[c].B;
+                cplx *Sc = S + soff[c];
+                cplx *src = e == me ? Sc + (size_t)cols[me] * Bme : (cplx *)recv + off;
+                wfx_dist_piece p{};
+                p.src = (unsigned long long)src;
+                p.dst = (unsigned long long)Y;
+                p.rows = w;
+                p.cols = km.B;
+                p.src_rs = km.B;
+                p.dst_rs = w;
+                p.kb0 = km.kb0;
+                p.kc0 = km.kc0;
+                p.kb1 = km.kb1;
+                p.B = km.B;
+                p3.push_back(p);
+                wfx_xfer x{};
+                x.peer = e;
+                x.send = Sc + (size_t)cols[e] * Bme;                    // to rank e: this subset's slab rows of its columns (contiguous)
+                x.send_bytes = (size_t)(cols[e + 1] - cols[e]) * Bme * sizeof(cplx);
+                x.recv = src;
+                x.recv_bytes = (size_t)w * km.B * sizeof(cplx);
+                if (e == me) x.send = x.recv;
+                x3c[c].push_back(x);
+                x3.push_back(x);
+                if (e != me) off += (size_t)w * km.B;
+            }
     }
     // columns mode: no E4 -- the rows stay where the last pass wrote them (rows_out + q out_rs + hb) and only the halo columns
     // travel: my last hb own columns of every row to the rank on my right (its "before" halo), my first ha own columns to the
@@ -555,7 +590,7 @@ int wfx_dist::bind_cols(const void *cols_in, long long in_rs, cplx *cols_out, lo
 int wfx_dist::bind(const void *rows_in, cplx *rows_out, int inv_in)
 {
     // the inverse slab passes ping-pong between the two slab buffers: where they end is where E3 sends from
-    const int ns = (int)d_inv.size();
+    const int ns = d_inv.empty() ? 0 : (int)d_inv[0].size();
     const int end = (inv_in + ns) & 1;
     inv_start = inv_in ? (cplx *)b_a2.p : (cplx *)b_a.p;
     inv_result = end ? (cplx *)b_a2.p : (cplx *)b_a.p;
@@ -577,22 +612,67 @@ int wfx_dist::fwd_pack_exchange(wfx_comm *c, const void *rows_in)
     return wfx_comm_exchange(c, ctx, x1.data(), (int)x1.size());
 }
 
-int wfx_dist::fwd_pass1_exchange(wfx_comm *c, int in_mode)
+int wfx_dist::fwd_pass1(int in_mode)
 {
     const cplx *tb = (const cplx *)tables.p;
     // P = 1: no twiddle is read; the outputs go straight to where E2 sends them from (d_first.qmap), b_y is not written
-    WFX_TRY(wfx_mr_launch_pair(ctx, d_first, tb, in_mode, 0, 0, pass1_src, (cplx *)b_y.p));
+    return wfx_mr_launch_pair(ctx, d_first, tb, in_mode, 0, 0, pass1_src, (cplx *)b_y.p);
+}
+
+int wfx_dist::e2_exchange(wfx_comm *c, int chunk, int slot)
+{
     label(c, "E2");
-    return wfx_comm_exchange(c, ctx, x2.data(), (int)x2.size());
+    return wfx_comm_exchange_async(c, ctx, x2c[chunk].data(), (int)x2c[chunk].size(), slot);
+}
+
+int wfx_dist::fwd_pass1_exchange(wfx_comm *c, int in_mode)
+{
+    WFX_TRY(fwd_pass1(in_mode));
+    for (int k = 0; k < C; ++k) {
+        label(c, "E2");
+        WFX_TRY(wfx_comm_exchange(c, ctx, x2c[k].data(), (int)x2c[k].size()));
+    }
+    return 0;
+}
+
+int wfx_dist::fwd_slab_chunk(int chunk, int hilbert_spectrum, cplx **spectrum, long long skip_lo, long long skip_hi)
+{
+    const cplx *tb = (const cplx *)tables.p;
+    cplx *src = (cplx *)b_a.p + soff[chunk], *dst = (cplx *)b_a2.p + soff[chunk];
+    const int ns = (int)d_fwd[chunk].size();
+    for (int i = 0; i < ns; ++i) {
+        mr_pass_desc d = d_fwd[chunk][i];
+        if (i == ns - 1 && !hilbert_spectrum && skip_hi > skip_lo + 1) {
+            d.skip_lo = skip_lo;
+            d.skip_hi = skip_hi;
+        }
+        const bool skipping = d.skip_hi != 0;
+        const int out_mode = (hilbert_spectrum && i == ns - 1) ? 1 : ((skipping && d.ra > 0) ? 3 : 0);
+        WFX_TRY(wfx_mr_launch(ctx, d, tb + tw_fwd[i], 0, out_mode, 0, src, dst));
+        std::swap(src, dst);
+    }
+    *spectrum = src;
+    return 0;
 }
 
 int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo, long long skip_hi, const cplx *gtab)
 {
+    if (C > 1) {
+        if (gtab) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed padded convolution: one k1 subset only");
+        cplx *first = nullptr;
+        for (int k = 0; k < C; ++k) {
+            cplx *sp = nullptr;
+            WFX_TRY(fwd_slab_chunk(k, hilbert_spectrum, &sp, skip_lo, skip_hi));
+            if (k == 0) first = sp;
+        }
+        *spectrum = first;                 // (the subsets' results lie behind one another, as the slab buffer's layout has them)
+        return 0;
+    }
     const cplx *tb = (const cplx *)tables.p;
     cplx *src = (cplx *)b_a.p, *dst = (cplx *)b_a2.p;
-    const int ns = (int)d_fwd.size();
+    const int ns = (int)d_fwd[0].size();
     for (int i = 0; i < ns; ++i) {
-        mr_pass_desc d = d_fwd[i];
+        mr_pass_desc d = d_fwd[0][i];
         if (i == ns - 1 && !hilbert_spectrum && skip_hi > skip_lo + 1) {
             d.skip_lo = skip_lo;
             d.skip_hi = skip_hi;
@@ -611,18 +691,35 @@ int wfx_dist::fwd_slab(int hilbert_spectrum, cplx **spectrum, long long skip_lo,
     return 0;
 }
 
-int wfx_dist::inv_slab_exchange(wfx_comm *c, cplx *slab_in)
+int wfx_dist::inv_slab_chunk(int chunk, cplx *slab_in)
 {
     const cplx *tb = (const cplx *)tables.p;
-    if (slab_in != inv_start || !b_desc.p) return wfx_fail(ctx, WFX_ERR_STATE, "distributed transform: inverse input is not the bound slab buffer");
-    cplx *src = slab_in, *dst = slab_in == (cplx *)b_a.p ? (cplx *)b_a2.p : (cplx *)b_a.p;
-    const int ns = (int)d_inv.size();
+    if (slab_in != inv_start + soff[chunk] || !b_desc.p) return wfx_fail(ctx, WFX_ERR_STATE, "distributed transform: inverse input is not the bound slab buffer");
+    cplx *other = (inv_start == (cplx *)b_a.p ? (cplx *)b_a2.p : (cplx *)b_a.p) + soff[chunk];
+    cplx *src = slab_in, *dst = other;
+    const int ns = (int)d_inv[chunk].size();
     for (int i = 0; i < ns; ++i) {
-        WFX_TRY(wfx_mr_launch(ctx, d_inv[i], tb + tw_inv[i], 0, 0, 1, src, dst));
+        WFX_TRY(wfx_mr_launch(ctx, d_inv[chunk][i], tb + tw_inv[i], 0, 0, 1, src, dst));
         std::swap(src, dst);
     }
+    return 0;
+}
+
+int wfx_dist::e3_exchange(wfx_comm *c, int chunk, int slot)
+{
     label(c, "E3");
-    return wfx_comm_exchange(c, ctx, x3.data(), (int)x3.size());
+    return wfx_comm_exchange_async(c, ctx, x3c[chunk].data(), (int)x3c[chunk].size(), slot);
+}
+
+int wfx_dist::inv_slab_exchange(wfx_comm *c, cplx *slab_in)
+{
+    if (slab_in != inv_start || !b_desc.p) return wfx_fail(ctx, WFX_ERR_STATE, "distributed transform: inverse input is not the bound slab buffer");
+    for (int k = 0; k < C; ++k) {
+        WFX_TRY(inv_slab_chunk(k, slab_in + soff[k]));
+        label(c, "E3");
+        WFX_TRY(wfx_comm_exchange(c, ctx, x3c[k].data(), (int)x3c[k].size()));
+    }
+    return 0;
 }
 
 int wfx_dist::inv_pass1_exchange(wfx_comm *c, cplx *rows_out)
@@ -736,9 +833,14 @@ __global__ void __launch_bounds__(256) dist_resample_glue_kernel(const cplx *__r
     }
 }
 
+int wfx_dist_resample_glue_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, const cplx *Z, long long n0, long long num, cplx *W)
+{
+    const long long total = (num / 2 / R1) * km.B;
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, dist_resample_glue_kernel, dim3(wfx_stream_grid((uint64_t)total, 256)), dim3(256), Z, n0, num, R1, km, W);
+    return 0;
+}
+
 int wfx_dist_resample_glue(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Z, long long n0, long long num, cplx *W)
 {
-    const long long total = (num / 2 / g.R1) * g.km[g.rank].B;
-    WFX_LAUNCH(ctx, K_RESAMPLE_PW, dist_resample_glue_kernel, dim3(wfx_stream_grid((uint64_t)total, 256)), dim3(256), Z, n0, num, g.R1, g.km[g.rank], W);
-    return 0;
+    return wfx_dist_resample_glue_km(ctx, g.R1, g.km[g.rank], Z, n0, num, W);
 }

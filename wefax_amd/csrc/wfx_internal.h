@@ -368,6 +368,11 @@ int wfx_comm_rank(const wfx_comm *c);
 bool wfx_comm_is_local(const wfx_comm *c);
 void wfx_comm_label(wfx_comm *c, const char *name);      // names the next collective in the wire statistics (wfx_comm_wire_stats)
 int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n);
+// an exchange that may overlap the caller's next kernels (RCCL: on the communicator's own stream; others: completed on return);
+// wfx_comm_wait orders the context's stream behind it.  slot in [0, 64)
+int wfx_comm_exchange_async(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n, int slot);
+int wfx_comm_wait(wfx_comm *c, wfx_ctx *ctx, int slot);
+unsigned long long wfx_comm_async_count(const wfx_comm *c);
 int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t count);
 int wfx_comm_allgather(wfx_comm *c, wfx_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank);
 

@@ -73,6 +73,10 @@ struct shard_plan {
     long long cH0 = 0, wH = 0, cF0 = 0, wF = 0;
     int hs = 0;
     long long xrs = 0;                    // samples between the starts of two rows of audio: 2 wH + 2 hs
+    // k1 subsets per rank: E2, the slab passes and E3 of every distributed transform run subset by subset, the exchange of one (on
+    // the communicator's own stream) overlapping the passes of another.  4 where the first radix has enough outputs for
+    // world * 4 subsets, 1 with one rank; WFX_SHARD_CHUNKS overrides (every rank must see the same value)
+    int nchunk = 1;
     // the cost model's verdict
     int forced = 0;
     double model_single = 0, model_comp = 0, model_wire = 0;
@@ -264,6 +268,15 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         if (pl.resample) colrange(pl.M1s, rank, pl.cF0, pl.wF);
         pl.hs = world > 1 ? SH_HALO : 0;
         pl.xrs = 2 * pl.wH + 2 * pl.hs;
+        {
+            const char *e = getenv("WFX_SHARD_CHUNKS");
+            int want_c = e ? atoi(e) : (world > 1 ? 4 : 1);
+            if (want_c < 1) want_c = 1;
+            if (want_c > 8) want_c = 8;
+            wfx_dist_geom gv;
+            while (want_c > 1 && !wfx_dist_make_geom(gv, world * want_c, 0, pl.g.ra1, pl.g.rb1)) --want_c;
+            pl.nchunk = want_c;
+        }
         pl.own_lo = 2ull * (uint64_t)pl.cH0;
         pl.own_hi = 2ull * (uint64_t)((long long)(R1 - 1) * pl.Ms + pl.cH0 + pl.wH);
         pl.in_lo = pl.resample ? 2ull * (uint64_t)pl.cF0 : pl.own_lo;
@@ -465,7 +478,7 @@ static int shard_bind(wfx_shard *sh)
 static int phase_count(const wfx_shard *sh)
 {
     if (sh->pl.single) return 1;
-    if (sh->pl.cols) return sh->pl.resample ? 11 : 8;
+    if (sh->pl.cols) return sh->pl.resample ? 4 * sh->pl.nchunk + 7 : 2 * sh->pl.nchunk + 6;
     return sh->pl.resample ? 13 : (sh->pl.padded ? (sh->ghat_ready ? 10 : 13) : 9);
 }
 
@@ -483,56 +496,83 @@ static int run_phase_cols(wfx_shard *sh, int ph)
     double *audio = (double *)sh->b_audio.p + SH_PAD;                       // row 0, halo included
     double *env = (double *)sh->b_env.p;
     uint8_t *dig_own = (me == 0 && W > 1) ? (uint8_t *)sh->b_gath.p : (uint8_t *)sh->b_dig.p;
-    if (!pl.resample) ph += 3;                                              // phases 0..2 are the resampler's
-    switch (ph) {
-    case 0: {   // a4 + a5: first pass on the caller's columns, E2
-        WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
-        if (pl.in_kind == WFX_IN_I16_STEREO) WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, cols_in_frames(pl), (double *)sh->b_merged.p));
-        return sh->dF.fwd_pass1_exchange(c, pl.in_kind == WFX_IN_I16_MONO ? 2 : 0);
-    }
-    case 1: {   // spectrum -> scipy.signal.resample's bin copy -> the inverse's slab passes, E3
-        cplx *Z = nullptr;
-        const long long nmin = (long long)(pl.n0 < pl.n ? pl.n0 : pl.n), half = nmin / 2;
-        WFX_TRY(sh->dF.fwd_slab(0, &Z, half, pl.M1 - half));
-        WFX_TRY(wfx_dist_resample_glue(ctx, pl.g, Z, (long long)pl.n0, (long long)pl.n, sh->dI.slab_buffer(0)));
-        return sh->dI.inv_slab_exchange(c, sh->dI.slab_buffer(0));
-    }
-    case 2: return sh->dI.inv_pass1_halo_exchange(c);                       // the resampled audio, in columns; its halo columns
-    case 3: {   // a6 notch over the rows laid end to end, then the Hilbert transform's first pass (in place) and E2
-        const void *nin = in;
-        int nkind = pl.in_kind;
-        if (pl.resample) {
-            WFX_TRY(sh->dI.inv_halo_unpack());
-            nin = (const double *)sh->b_res.p + SH_PAD;
-            nkind = WFX_IN_F64_MONO;
-        } else {
+    // Phases.  C = k1 subsets per rank.  A distributed transform pair takes 2 C + 1 phases:
+    //   [0]            first pass on the columns, E2 of subset 0          (exchanges are asynchronous on RCCL: slot s)
+    //   [1 .. C-1]     E2 of subset c
+    //   [C + c]        wait E2(c); slab passes of subset c (forward, spectral step, inverse); E3 of subset c
+    //   [2 C]          wait every E3; last pass; halo exchange
+    // the resampler's pair first (when there is one), then the Hilbert transform's, then the five phases of the tail.
+    const int C = pl.nchunk, TP = 2 * C + 1;
+    if (!pl.resample) ph += TP;
+    if (ph < TP) {
+        // ---- a4 + a5: distributed rfft -> scipy.signal.resample's bin copy -> distributed irfft, in columns ----
+        if (ph == 0) {
             WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
-            if (pl.in_kind == WFX_IN_I16_STEREO) {
-                WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, flat, (double *)sh->b_merged.p));
-                nin = sh->b_merged.p;
+            if (pl.in_kind == WFX_IN_I16_STEREO) WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, cols_in_frames(pl), (double *)sh->b_merged.p));
+            WFX_TRY(sh->dF.fwd_pass1(pl.in_kind == WFX_IN_I16_MONO ? 2 : 0));
+            return sh->dF.e2_exchange(c, 0, 0);
+        }
+        if (ph < C) return sh->dF.e2_exchange(c, ph, ph);
+        if (ph < 2 * C) {
+            const int k = ph - C;
+            WFX_TRY(wfx_comm_wait(c, ctx, k));
+            cplx *Z = nullptr;
+            // down-sampling reads the bins [0, n/2] and their mirrors only: the last forward pass does not store the rest
+            const long long nmin = (long long)(pl.n0 < pl.n ? pl.n0 : pl.n), half = nmin / 2;
+            WFX_TRY(sh->dF.fwd_slab_chunk(k, 0, &Z, half, pl.M1 - half));
+            WFX_TRY(wfx_dist_resample_glue_km(ctx, pl.g.R1, sh->dF.chunk_kmap(k), Z, (long long)pl.n0, (long long)pl.n, sh->dI.slab_chunk(0, k)));
+            WFX_TRY(sh->dI.inv_slab_chunk(k, sh->dI.slab_chunk(0, k)));
+            return sh->dI.e3_exchange(c, k, C + k);
+        }
+        for (int k = 0; k < C; ++k) WFX_TRY(wfx_comm_wait(c, ctx, C + k));
+        return sh->dI.inv_pass1_halo_exchange(c);                       // the resampled audio, in columns; its halo columns
+    }
+    ph -= TP;
+    if (ph < TP) {
+        if (ph == 0) {   // a6 notch over the rows laid end to end, then the Hilbert transform's first pass (in place) and E2
+            const void *nin = in;
+            int nkind = pl.in_kind;
+            if (pl.resample) {
+                WFX_TRY(sh->dI.inv_halo_unpack());
+                nin = (const double *)sh->b_res.p + SH_PAD;
                 nkind = WFX_IN_F64_MONO;
+            } else {
+                WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+                if (pl.in_kind == WFX_IN_I16_STEREO) {
+                    WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, flat, (double *)sh->b_merged.p));
+                    nin = sh->b_merged.p;
+                    nkind = WFX_IN_F64_MONO;
+                }
             }
+            // rank 0's first row starts at the capture's true start, the last rank's last row ends at its true end: filtfilt's exact
+            // edges there; everywhere else the 49-tap form, whose outputs within 24 samples of a row's end are never read
+            const uint64_t lo = me == 0 ? (uint64_t)pl.hs : 0, hi = flat - (me == W - 1 ? (uint64_t)pl.hs : 0);
+            const int flags = (me == 0 ? 1 : 0) | (me == W - 1 ? 2 : 0);
+            double ext18[18];
+            const bool use_ext = p.has_ext && !pl.resample && pl.in_kind != WFX_IN_I16_STEREO;
+            for (int i = 0; i < 9; ++i) {
+                ext18[i] = p.ext_left[i];
+                ext18[9 + i] = p.ext_right[i];
+            }
+            const void *nin_lo = nkind == WFX_IN_I16_MONO ? (const void *)((const int16_t *)nin + lo) : (const void *)((const double *)nin + lo);
+            WFX_TRY(wfx_dev_notch_fir_only(ctx, nin_lo, nkind, hi - lo, p.notch_b, p.notch_a, audio + lo, flags, use_ext ? ext18 : nullptr));
+            WFX_TRY(sh->dH.fwd_pass1(1));
+            return sh->dH.e2_exchange(c, 0, 2 * C);
         }
-        // rank 0's first row starts at the capture's true start, the last rank's last row ends at its true end: filtfilt's exact
-        // edges there; everywhere else the 49-tap form, whose outputs within 24 samples of a row's end are never read
-        const uint64_t lo = me == 0 ? (uint64_t)pl.hs : 0, hi = flat - (me == W - 1 ? (uint64_t)pl.hs : 0);
-        const int flags = (me == 0 ? 1 : 0) | (me == W - 1 ? 2 : 0);
-        double ext18[18];
-        const bool use_ext = p.has_ext && !pl.resample && pl.in_kind != WFX_IN_I16_STEREO;
-        for (int i = 0; i < 9; ++i) {
-            ext18[i] = p.ext_left[i];
-            ext18[9 + i] = p.ext_right[i];
+        if (ph < C) return sh->dH.e2_exchange(c, ph, 2 * C + ph);
+        if (ph < 2 * C) {
+            const int k = ph - C;
+            WFX_TRY(wfx_comm_wait(c, ctx, 2 * C + k));
+            cplx *G = nullptr;
+            WFX_TRY(sh->dH.fwd_slab_chunk(k, 1, &G));
+            WFX_TRY(sh->dH.inv_slab_chunk(k, G));
+            return sh->dH.e3_exchange(c, k, 3 * C + k);
         }
-        const void *nin_lo = nkind == WFX_IN_I16_MONO ? (const void *)((const int16_t *)nin + lo) : (const void *)((const double *)nin + lo);
-        WFX_TRY(wfx_dev_notch_fir_only(ctx, nin_lo, nkind, hi - lo, p.notch_b, p.notch_a, audio + lo, flags, use_ext ? ext18 : nullptr));
-        return sh->dH.fwd_pass1_exchange(c, 1);
+        for (int k = 0; k < C; ++k) WFX_TRY(wfx_comm_wait(c, ctx, 3 * C + k));
+        return sh->dH.inv_pass1_halo_exchange(c);
     }
-    case 4: {
-        cplx *G = nullptr;
-        WFX_TRY(sh->dH.fwd_slab(1, &G));
-        return sh->dH.inv_slab_exchange(c, G);
-    }
-    case 5: return sh->dH.inv_pass1_halo_exchange(c);
+    ph = ph - TP + 6;
+    switch (ph) {
     case 6: {   // a7 envelope + median per segment, level-0 histogram; first all-reduce
         WFX_TRY(sh->dH.inv_halo_unpack());
         WFX_TRY(wfx_dev_select_sharded_ws(ctx, &sh->ws));
@@ -833,7 +873,7 @@ static int dry_build(const shard_plan &pl0, long long L, int es, int hb, int ha,
         wfx_dist_geom g;
         if (!wfx_dist_make_geom(g, W, r, pl0.g.ra1, pl0.g.rb1, rows_used)) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "dry run: geometry");
         const unsigned long long base = (unsigned long long)(r + 1) << 44;
-        rc = d[r].init(nullptr, g, L, es, hb, ha, true, base);
+        rc = d[r].init(nullptr, g, L, es, hb, ha, true, base, cols ? pl0.nchunk : 1);
         if (rc) break;
         std::vector<std::pair<unsigned long long, unsigned long long>> b;
         d[r].buffers(b);
@@ -1009,23 +1049,26 @@ extern "C" int wfx_shard_wire_plan(const wfx_decode_params *p, int world, wfx_wi
         for (int e = 1; e <= 5; ++e) {
             if ((e <= 2 && !fwd) || (e >= 3 && !inv)) continue;
             if (pl.cols ? (e == 1 || e == 4) : e == 5) continue;
-            // (order within a transform: E1, E2, E3, E4 | E2, E3, halo)
-            unsigned long long total = 0, mr = 0, ml = 0;
-            for (int r = 0; r < W; ++r) {
-                std::vector<unsigned long long> link((size_t)W, 0ull);
-                unsigned long long mine = 0;
-                for (const wfx_xfer &x : d[r].xfers(e))
-                    if (x.peer != r) {
-                        mine += x.send_bytes;
-                        link[(size_t)x.peer] += x.send_bytes;
-                    }
-                total += mine;
-                mr = std::max(mr, mine);
-                for (unsigned long long v : link) ml = std::max(ml, v);
+            // (order within a transform: E1, E2, E3, E4 | E2 and E3 of every k1 subset, halo)
+            const int nsub = (e == 2 || e == 3) ? d[0].chunks() : 1;
+            for (int c = 0; c < nsub; ++c) {
+                unsigned long long total = 0, mr = 0, ml = 0;
+                for (int r = 0; r < W; ++r) {
+                    std::vector<unsigned long long> link((size_t)W, 0ull);
+                    unsigned long long mine = 0;
+                    for (const wfx_xfer &x : ((e == 2 || e == 3) ? d[r].xfers_chunk(e, c) : d[r].xfers(e)))
+                        if (x.peer != r) {
+                            mine += x.send_bytes;
+                            link[(size_t)x.peer] += x.send_bytes;
+                        }
+                    total += mine;
+                    mr = std::max(mr, mine);
+                    for (unsigned long long v : link) ml = std::max(ml, v);
+                }
+                char name[24];
+                snprintf(name, sizeof name, "%.15s %s", tag, e == 5 ? "halo" : (e == 1 ? "E1" : e == 2 ? "E2" : e == 3 ? "E3" : "E4"));
+                put(name, total, mr, ml);
             }
-            char name[24];
-            snprintf(name, sizeof name, "%.15s %s", tag, e == 5 ? "halo" : (e == 1 ? "E1" : e == 2 ? "E2" : e == 3 ? "E3" : "E4"));
-            put(name, total, mr, ml);
         }
         for (int r = 0; r < W; ++r) d[r].release();
         return 0;
@@ -1136,10 +1179,11 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
     sh->dH.set_tag("hilbert");
     sh->dHk.set_tag("hilbert kernel");
     if (rc == 0 && pl.resample) {
-        rc = sh->dF.init(ctx, pl.g, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0);
-        if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, pl.cols ? pl.hs / 2 : SH_HALO / 2, pl.cols ? pl.hs / 2 : SH_HALO / 2);
+        const int nc = pl.cols ? pl.nchunk : 1;
+        rc = sh->dF.init(ctx, pl.g, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, false, 0, nc);
+        if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, pl.cols ? pl.hs / 2 : SH_HALO / 2, pl.cols ? pl.hs / 2 : SH_HALO / 2, false, 0, nc);
     }
-    if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO);
+    if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO, false, 0, pl.cols ? pl.nchunk : 1);
     if (rc == 0 && pl.split_kernel) rc = sh->dHk.init(ctx, pl.gk, pl.Kp, pl.plain ? 8 : 16, 0, 0);
     if (rc != 0) {
         wfx_shard_destroy(sh);
