@@ -78,25 +78,33 @@ python tools/pmc_summary.py "$OUT/pmc_fetch_c3" "$OUT/pmc_write_c3" "$OUT/pmc_tr
 rm -rf "$OUT/pmc_fetch_c3" "$OUT/pmc_write_c3"
 
 # N real processes on this ONE GPU (shared-memory transport): spawn -> rendezvous -> every phase -> gather, checked against the oracle
+# (--plan dist: the cost model would decline the distributed plan at 2 and 4 ranks, and this is about running it)
 for g in 2 4 8; do
-  WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus $g --shard --steps 3 --warmup 1 --no-c4 --no-cpu-loops > "$OUT/bench_shard_shm$g.json" 2>> "$OUT/bench.err"
+  WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus $g --shard --plan dist --steps 3 --warmup 1 --no-c4 --no-cpu-loops > "$OUT/bench_shard_shm$g.json" 2>> "$OUT/bench.err"
 done
-WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 --no-pcie --no-cpu > "$OUT/bench_c4_shm8.json" 2>> "$OUT/bench.err"
+# BASELINE configs[3] on 8 processes: the columns layout (4 array transposes, in k1 subsets) and the rows layout of rounds 2-3 (8): the
+# `wire` object has every collective's bytes; the host-staged transport's time follows them
+WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --workload iq --plan dist --steps 3 --warmup 1 --no-cpu > "$OUT/bench_c4_shm8.json" 2>> "$OUT/bench.err"
+WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --workload iq --plan rows --steps 3 --warmup 1 --no-cpu > "$OUT/bench_c4_shm8_rows.json" 2>> "$OUT/bench.err"
+# the default line at 2 ranks: the cost model takes the single plan for c4_strong (rank 0 alone) instead of a distributed one that loses
+WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --no-pcie --no-cpu > "$OUT/bench_default_shm2.json" 2>> "$OUT/bench.err"
 # the driver's own launch for N > 1 (torch.distributed.run: ranks from the environment), here with the ranks sharing the one GPU
 for g in 2 4; do
   WFX_BENCH_OVERSUBSCRIBE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $g --master-addr 127.0.0.1 --master-port 2955$g bench.py --gpus $g --steps 5 --warmup 2 > "$OUT/bench_torchrun_shm$g.json" 2>> "$OUT/bench.err"
 done
 # a padded sharded decode (the 10-minute capture less two samples): only the sample-bearing rows dealt vs all rows
-for g in 4 8; do
-  WFX_BENCH_OVERSUBSCRIBE=1 timeout 600 python bench.py --gpus $g --shard --trim 2 --steps 5 --warmup 2 --no-c4 --no-cpu --no-extras --no-pcie > "$OUT/bench_shard_trim2_shm${g}_all0.json" 2>> "$OUT/bench.err"
-  WFX_SHARD_ALL_ROWS=1 WFX_BENCH_OVERSUBSCRIBE=1 timeout 600 python bench.py --gpus $g --shard --trim 2 --steps 5 --warmup 2 --no-c4 --no-cpu --no-extras --no-pcie > "$OUT/bench_shard_trim2_shm${g}_all1.json" 2>> "$OUT/bench.err"
+for g in 8; do
+  WFX_BENCH_OVERSUBSCRIBE=1 timeout 600 python bench.py --gpus $g --shard --plan dist --trim 2 --steps 5 --warmup 2 --no-c4 --no-cpu --no-extras --no-pcie > "$OUT/bench_shard_trim2_shm${g}.json" 2>> "$OUT/bench.err"
 done
+# the real transport with the one rank there is, exchanges in 4 k1 subsets on the communicator's own stream / in stream order
+WFX_SHARD_CHUNKS=4 WFX_BENCH_FORCE_DIST=1 python bench.py --workload iq --no-cpu > "$OUT/bench_iq_rccl1_chunks4.json" 2>> "$OUT/bench.err"
+WFX_SHARD_CHUNKS=4 WFX_COMM_ASYNC=0 WFX_BENCH_FORCE_DIST=1 python bench.py --workload iq --no-cpu > "$OUT/bench_iq_rccl1_chunks4_inorder.json" 2>> "$OUT/bench.err"
 
 # randomised whole-path parity sweep against the oracle
-timeout 1200 python tools/random_parity.py --cases 200 --seed 11 > "$OUT/random_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_parity.jsonl"
+timeout 1200 python tools/random_parity.py --cases 200 --seed 14 > "$OUT/random_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_parity.jsonl"
 
-timeout 2400 python tools/random_fe_parity.py --cases 200 --seed 8 > "$OUT/random_fe_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_fe_parity.jsonl" | cut -c1-400
-timeout 1200 python tools/random_shard_parity.py --cases 60 --seed 5 > "$OUT/random_shard_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_shard_parity.jsonl"
+timeout 2400 python tools/random_fe_parity.py --cases 120 --seed 9 > "$OUT/random_fe_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_fe_parity.jsonl" | cut -c1-400
+timeout 1200 python tools/random_shard_parity.py --cases 80 --seed 6 > "$OUT/random_shard_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_shard_parity.jsonl"
 
 # the read-streaming ceiling of this box and the ingest stage against it
 if [ -x tools/micro/build/stream_big ]; then timeout 120 tools/micro/build/stream_big > "$OUT/stream_ceiling.txt" 2>&1; fi

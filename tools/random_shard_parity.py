@@ -69,7 +69,8 @@ def main():
                     rec[f"world{w}"] = "refused: " + str(e)[-90:]
                     ok = False                                      # nothing valid is refused any more (single plan)
                     continue
-                res = dict(stream_ne=int(np.count_nonzero(r["digitalized"] != ref["digitalized"])), blocks_eq=bool(np.array_equal(r["digitalized"], r["digitalized_blocks"])))
+                res = dict(plan={0: "single", 1: "rows", 2: "columns"}[int(r["plan"])], stream_ne=int(np.count_nonzero(r["digitalized"] != ref["digitalized"])),
+                           blocks_eq=bool(np.array_equal(r["digitalized"], r["digitalized_blocks"])))
                 if ref.get("exception") is not None:
                     res["no_group"] = bool(r["sync"]["no_group"])
                     ok &= res["no_group"]

@@ -114,7 +114,11 @@ static void plan_cost(shard_plan &pl, bool cols)
     }
     const double lat = 20e-6, bl = link_gbs() * 1e9;
     const double small = (cols ? (pl.resample ? 2 : 1) : 0) + 3;          // halo exchanges, two all-reduces, one all-gather
-    pl.model_wire = W > 1 ? arrays / ((double)W * W) / bl + (nex + small) * lat + (n / W) / bl + lat : 0.0;
+    // columns layout: every transpose travels as C k1 subsets on the communicator's own stream while the slab passes of the subsets
+    // already there run (about 45 % of a rank's transform work sits in slab passes): (C - 1) / C of the shorter of the two is hidden
+    const double t_arrays = W > 1 ? arrays / ((double)W * W) / bl : 0.0;
+    const double hidden = (cols && pl.nchunk > 1) ? (double)(pl.nchunk - 1) / pl.nchunk * std::min(0.45 * pl.model_single / W, t_arrays) : 0.0;
+    pl.model_wire = W > 1 ? t_arrays - hidden + (nex + small) * lat + (n / W) / bl + lat : 0.0;
     pl.model_comp = pl.model_single / W + ncopy * (32.0 * (double)pl.Kp / W) / 4e12 + (W > 1 ? 80e-6 : 0.0);      // + rank 0's tail: sync search, image
     pl.model_bytes = W > 1 ? (unsigned long long)(arrays * (W - 1) / W + n * (W - 1) / W) : 0ull;
 }
