@@ -213,6 +213,15 @@ def main():
     f32 = base.astype(np.float32) / np.float32(32768.0)
     emit("stereo_f32_240", 11025, np.stack([f32, f32 * np.float32(0.3333333)], axis=1), 240)
 
+    # 10b'. a float32 wav that is RESAMPLED: scipy.signal.resample keeps single precision for float32 input (complex64 transforms,
+    #       float32 result, and filtfilt then extends THAT array) -- the oracle and the device compute in float64, which is more
+    #       accurate and therefore not identical: the case is marked inexact, the tests assert the documented delta (<= 1 grey level
+    #       on <= 0.1 % of the stream) instead of equality
+    if only is None or "mono48k_f32_240" in only:
+        b48 = synth.synth_capture(48000.0, noise=0.05, seed=44, lpm=240, phasing_lines=40, image_lines=30, **short)
+        emit("mono48k_f32_240", 48000, b48.astype(np.float32) / np.float32(32768.0), 240)
+        manifest["cases"][-1]["oracle_exact"] = False
+
     # 10c. BASELINE configs[3]'s own format through the REFERENCE: a two-channel int16 stream at 1.536 MS/s (merge of wefax.py:360-373,
     #      FFT resample by 147 / 20480 of wefax.py:384) and a 192 kHz stereo capture.  Inputs come from tests/golden/recipes.py and
     #      are not stored (12 MB / 4.6 MB); a clip this short closes no phasing group: the ValueError of wefax.py:294 is the golden
