@@ -218,8 +218,8 @@ def main():
     #       accurate and therefore not identical: the case is marked inexact, the tests assert the documented delta (<= 1 grey level
     #       on <= 0.1 % of the stream) instead of equality
     if only is None or "mono48k_f32_240" in only:
-        b48 = synth.synth_capture(48000.0, noise=0.05, seed=44, lpm=240, phasing_lines=40, image_lines=30, **short)
-        emit("mono48k_f32_240", 48000, b48.astype(np.float32) / np.float32(32768.0), 240)
+        fs_r, data_r, lpm_r = recipes.RECIPES["mono48k_f32_240"]()
+        emit("mono48k_f32_240", fs_r, data_r, lpm_r, recipe="mono48k_f32_240")
         manifest["cases"][-1]["oracle_exact"] = False
 
     # 10c. BASELINE configs[3]'s own format through the REFERENCE: a two-channel int16 stream at 1.536 MS/s (merge of wefax.py:360-373,

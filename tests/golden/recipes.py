@@ -28,7 +28,15 @@ def _stereo192k_6s_240():
                                        stop_tone_s=0.25, black_tail_s=0.25), 240
 
 
-RECIPES = {"iq1536k_2s_240": _iq1536k_2s_240, "stereo192k_6s_240": _stereo192k_6s_240}
+def _mono48k_f32_240():
+    from wefax_amd import synth
+    # a float32 wav that needs resampling (3.9 MB): the one place where the reference's arithmetic is single precision
+    b48 = synth.synth_capture(48000.0, noise=0.05, seed=44, lpm=240, phasing_lines=40, image_lines=30, start_tone_s=1.0, stop_tone_s=1.0,
+                              black_tail_s=1.0)
+    return 48000, b48.astype(np.float32) / np.float32(32768.0), 240
+
+
+RECIPES = {"iq1536k_2s_240": _iq1536k_2s_240, "stereo192k_6s_240": _stereo192k_6s_240, "mono48k_f32_240": _mono48k_f32_240}
 
 
 def file_sha256(path: str) -> str:
