@@ -644,11 +644,24 @@ int wfx_comm_exchange_async(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int
     for (int i = 0; i < n; ++i)
         if (list[i].peer < 0 || list[i].peer >= c->world) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "exchange: peer %d out of range", list[i].peer);
     if (!c->xstream) {
-        WFX_HIP(ctx, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
-        WFX_HIP(ctx, hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
-        c->done.assign(64, nullptr);
+        // all or nothing: a communicator whose stream exists has every event it will be asked for
+        hipStream_t xs = nullptr;
+        hipEvent_t ready = nullptr;
+        std::vector<hipEvent_t> done(64, nullptr);
+        hipError_t e = hipStreamCreateWithFlags(&xs, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+        for (int k = 0; k < 64 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&done[(size_t)k], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (hipEvent_t ev : done)
+                if (ev) (void)hipEventDestroy(ev);
+            if (ready) (void)hipEventDestroy(ready);
+            if (xs) (void)hipStreamDestroy(xs);
+            return wfx_fail(ctx, WFX_ERR_HIP, "exchange stream / events: %s", hipGetErrorString(e));
+        }
+        c->xstream = xs;
+        c->ready = ready;
+        c->done = std::move(done);
         c->pending.assign(64, 0);
-        for (int k = 0; k < 64; ++k) WFX_HIP(ctx, hipEventCreateWithFlags(&c->done[(size_t)k], hipEventDisableTiming));
     }
     {
         unsigned long long sent = 0, got = 0, big = 0;
