@@ -761,7 +761,11 @@ def main():
         if guard is None or guard.claim():
             if rk.rank == 0:
                 print(json.dumps(line), flush=True)
-        rk.barrier()
+        try:
+            rk.barrier()
+        except Exception:      # noqa: BLE001 -- a peer that failed inside the sharded part has left; the line is out
+            if guard is None:
+                raise
     finally:
         if guard is not None:
             guard.printed_exit_only()

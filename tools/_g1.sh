@@ -1,14 +1,16 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r04a
-O=gpurun_out/r04a
-timeout 2400 python -m pytest tests/test_sharded.py -m gpu -q -x -k "own_stream or rccl" > $O/pytest_async.log 2>&1
-grep -v "^  File \"/usr" $O/pytest_async.log | tail -25
-WFX_SHARD_CHUNKS=4 WFX_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload iq --no-cpu --steps 5 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('iq rccl1 chunks4', d['ms_per_step'], d['config']['start_frame'])"
-WFX_SHARD_CHUNKS=4 WFX_COMM_ASYNC=0 WFX_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload iq --no-cpu --steps 5 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('iq rccl1 chunks4 sync', d['ms_per_step'], d['config']['start_frame'])"
-WFX_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload iq --no-cpu --steps 5 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('iq rccl1 chunks1', d['ms_per_step'], d['config']['start_frame'])"
+#!/bin/bash
+set -u
+OUT=$PWD/gpurun_out/pred3
+mkdir -p "$OUT"
+timeout 900 python -m pytest tests/test_pred_select.py -q > "$OUT/pytest_pred.log" 2>&1; tail -3 "$OUT/pytest_pred.log"
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+WFX_PRED_MIN_N=1 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tr_c3_1" -o run -- python3 bench.py --workload c3 --steps 3 --warmup 1 --no-cpu > /dev/null 2> "$OUT/err_tr.txt"
+python tools/kseq.py "$OUT/tr_c3_1" > "$OUT/kseq_c3_pred1.txt" 2>&1; rm -rf "$OUT/tr_c3_1"
+grep -E 'pred_|select_|env_median|quantise|sum of' "$OUT/kseq_c3_pred1.txt"
+for rep in 1 2 3; do for m in 0 1; do
+  WFX_PRED_MIN_N=$m python bench.py --workload c3 --no-cpu --steps 20 --warmup 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c3 pred$m', d['ms_per_step'])"
+done; done
+for rep in 1 2; do for m in 0 1; do
+  WFX_PRED_MIN_N=$m python bench.py --workload iq --no-cpu --steps 10 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('iq pred$m', d['ms_per_step'])"
+  WFX_PRED_MIN_N=$m python bench.py --no-cpu --no-c4 --no-pcie --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2 pred$m', d['ms_per_step'])"
+done; done
