@@ -749,7 +749,7 @@ def main():
                 # At N > 1 this is the one part of the line that runs data-path collectives: a rank that fails inside it leaves
                 # its peers waiting in an exchange.  The headline above is already measured -- it must not be lost to that -- so a
                 # guard prints the line with an `error` in place of the object when no result arrives in time, and ends the rank.
-                guard = _LineGuard(line, rk, float(os.environ.get("WFX_BENCH_C4_TIMEOUT", "420"))) if rk.world > 1 else None
+                guard = _LineGuard(line, rk, float(os.environ.get("WFX_BENCH_C4_TIMEOUT", "240"))) if rk.world > 1 else None
                 try:
                     if os.environ.get("WFX_BENCH_TEST_FAIL_RANK") == str(rk.rank):      # exercises the guard (tools/, tests)
                         raise RuntimeError("injected failure on this rank")

@@ -271,3 +271,32 @@ def test_detector_settings_come_from_the_config_file(tmp_path, monkeypatch):
     (tmp_path / "config" / "config.json").write_text(json.dumps({"tones_settings": {}}))
     with pytest.raises(KeyError):
         hp.load_detector_settings()
+
+
+def test_bench_guard_prints_the_headline_when_the_sharded_part_hangs(tmp_path):
+    """bench.py at N > 1: the headline is measured before the one part of the line that runs data-path collectives; if that part
+    does not come back (a peer died, a collective hangs) rank 0 prints the line it has with the reason in `c4_strong` and every rank
+    leaves.  No GPU: the guard alone, around a sleep."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import sys, time, types\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        "import bench\n"
+        "rk = types.SimpleNamespace(rank=int(sys.argv[1]), world=2)\n"
+        "line = {'metric': 'm', 'value': 1.5}\n"
+        "g = bench._LineGuard(line, rk, 0.3)\n"
+        "time.sleep(30)\n")
+    for rank, want_rc in ((0, 0), (1, 3)):
+        r = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == want_rc, r.stderr
+        if rank == 0:
+            out = json.loads(r.stdout.strip().splitlines()[-1])
+            assert out["value"] == 1.5 and "no result" in out["c4_strong"]["error"]
+        else:
+            assert r.stdout.strip() == ""
+    # the part came back in time: the main thread claims the line, a late timer prints nothing
+    code2 = code.replace("time.sleep(30)", "assert g.claim(); print('LINE'); g.printed_exit_only(); time.sleep(0.6)")
+    r = subprocess.run([sys.executable, "-c", code2, "0"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "LINE", (r.stdout, r.stderr)
