@@ -9,6 +9,11 @@ if REPO not in sys.path:
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# The sharded decode cuts every transpose into k1 subsets; left alone, its cost model picks their number per capture and world
+# size -- one for the short captures of this suite.  The suite runs with FOUR unless a test says otherwise, so that every sharded
+# parity test goes through the subset machinery (tests of the model's own choice remove the variable).
+os.environ.setdefault("WFX_SHARD_CHUNKS", "4")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

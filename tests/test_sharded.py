@@ -117,12 +117,37 @@ def test_columns_layout_halves_the_bytes_on_the_wire():
     assert _wire_total(cols, 8) <= 1.31e9 and _wire_total(rows, 8) >= 2.5e9
 
 
+def test_the_number_of_k1_subsets_follows_the_cost_model(monkeypatch):
+    """Without WFX_SHARD_CHUNKS the plan takes the subset count its model prices cheapest among 1 .. 4: more subsets hide more of the
+    slab passes behind the wire and cost one exchange latency each -- long captures on few ranks take more, short captures or many
+    ranks fewer; a cheaper exchange (WFX_LINK_LAT_US) moves the choice up, never down."""
+    def subsets(params, world):
+        return [e["name"] for e in nat.shard_wire_plan(params, world)].count("hilbert E2")
+    monkeypatch.delenv("WFX_SHARD_CHUNKS", raising=False)
+    monkeypatch.delenv("WFX_LINK_LAT_US", raising=False)
+    c3, _ = build_params(2, 57600000, 16000, 0.5, n_out=39690000, shard_plan=sharded.plan_code("dist"))
+    c1, _ = build_params(0, 7166250, 11025, 0.5, shard_plan=sharded.plan_code("dist"))
+    at20 = [subsets(c3, w) for w in (2, 4, 8)]
+    assert all(1 <= k <= 4 for k in at20) and at20[0] >= at20[1] >= at20[2] and at20[0] >= 3
+    assert subsets(c1, 4) == 1                                    # 0.3 ms of work: nothing to hide an exchange behind
+    assert "k1 subset" in nat.shard_layout(c3, 8, 0).plan_reason.decode()
+    monkeypatch.setenv("WFX_LINK_LAT_US", "5")
+    at5 = [subsets(c3, w) for w in (2, 4, 8)]
+    assert all(a >= b for a, b in zip(at5, at20)) and at5[0] == 4
+    for w in (2, 4, 8):
+        nat.shard_dry_run(c3, w)
+    monkeypatch.setenv("WFX_SHARD_CHUNKS", "4")
+    assert [subsets(c3, w) for w in (2, 4, 8)] == [4, 4, 4]
+
+
 def test_the_cost_model_declines_a_distributed_plan_that_would_lose(monkeypatch):
     """shard_plan 0 (the default): with 50 GB/s links two ranks would spend longer exchanging configs[3]'s arrays than one GPU
     needs for the whole decode -- the single plan is taken and says why; eight ranks get the distributed (columns) plan; links
     that are fast enough flip the choice; the caller can force either."""
     n0, n = 57600000, 39690000
     monkeypatch.delenv("WFX_LINK_GBS", raising=False)
+    monkeypatch.delenv("WFX_LINK_LAT_US", raising=False)
+    monkeypatch.delenv("WFX_SHARD_CHUNKS", raising=False)
     p, _ = build_params(2, n0, 16000, 0.5, n_out=n)
     lay2, lay8 = nat.shard_layout(p, 2, 0), nat.shard_layout(p, 8, 0)
     assert lay2.plan == 0 and lay2.plan_forced == 0 and lay2.plan_reason.decode().startswith("cost model")
@@ -138,9 +163,11 @@ def test_the_cost_model_declines_a_distributed_plan_that_would_lose(monkeypatch)
     single, _ = build_params(2, n0, 16000, 0.5, n_out=n, shard_plan=sharded.plan_code("single"))
     assert nat.shard_layout(single, 8, 0).plan == 0 and nat.shard_layout(single, 8, 3).own_samples == 0
     nat.shard_dry_run(single, 8)
-    # the 10-minute capture of configs[1]: 0.33 ms on one GPU -- only eight ranks' exchanges are short enough
+    # the 10-minute capture of configs[1]: 0.33 ms on one GPU -- only eight ranks' exchanges are short enough, and only just
     c2, _ = build_params(0, 7166250, 11025, 0.5)
     assert [nat.shard_layout(c2, w, 0).plan for w in (2, 4, 8)] == [0, 0, 2]
+    monkeypatch.setenv("WFX_LINK_LAT_US", "40")
+    assert [nat.shard_layout(c2, w, 0).plan for w in (2, 4, 8)] == [0, 0, 0]
 
 
 @pytest.mark.parametrize("n0", [2 * 1000003, 1433252, 7166252, 2 * 3583126 + 2, 9000 * 2 + 2, 39690002, 2 * 104729, 600000 + 2 * 7919,

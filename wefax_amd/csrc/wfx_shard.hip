@@ -96,6 +96,14 @@ static double link_gbs()
     return v > 0.0 ? v : 50.0;
 }
 
+// per-exchange launch latency the model charges (a grouped send / recv of RCCL: 10-30 us); WFX_LINK_LAT_US overrides
+static double link_lat_s()
+{
+    const char *e = getenv("WFX_LINK_LAT_US");
+    const double us = e ? atof(e) : 20.0;
+    return (us > 0.0 && us < 1e4 ? us : 20.0) * 1e-6;
+}
+
 static void plan_cost(shard_plan &pl, bool cols)
 {
     const int W = pl.world;
@@ -112,13 +120,15 @@ static void plan_cost(shard_plan &pl, bool cols)
         nex += cols ? 2 : 4;
         ncopy += cols ? 1 : 3;
     }
-    const double lat = 20e-6, bl = link_gbs() * 1e9;
+    const double lat = link_lat_s(), bl = link_gbs() * 1e9;
     const double small = (cols ? (pl.resample ? 2 : 1) : 0) + 3;          // halo exchanges, two all-reduces, one all-gather
     // columns layout: every transpose travels as C k1 subsets on the communicator's own stream while the slab passes of the subsets
     // already there run (about 45 % of a rank's transform work sits in slab passes): (C - 1) / C of the shorter of the two is hidden
+    // -- and every subset is an exchange of its own, with its own launch latency
+    const int C = cols ? std::max(1, pl.nchunk) : 1;
     const double t_arrays = W > 1 ? arrays / ((double)W * W) / bl : 0.0;
-    const double hidden = (cols && pl.nchunk > 1) ? (double)(pl.nchunk - 1) / pl.nchunk * std::min(0.45 * pl.model_single / W, t_arrays) : 0.0;
-    pl.model_wire = W > 1 ? t_arrays - hidden + (nex + small) * lat + (n / W) / bl + lat : 0.0;
+    const double hidden = C > 1 ? (double)(C - 1) / C * std::min(0.45 * pl.model_single / W, t_arrays) : 0.0;
+    pl.model_wire = W > 1 ? t_arrays - hidden + (nex * C + small) * lat + (n / W) / bl + lat : 0.0;
     pl.model_comp = pl.model_single / W + ncopy * (32.0 * (double)pl.Kp / W) / 4e12 + (W > 1 ? 80e-6 : 0.0);      // + rank 0's tail: sync search, image
     pl.model_bytes = W > 1 ? (unsigned long long)(arrays * (W - 1) / W + n * (W - 1) / W) : 0ull;
 }
@@ -272,21 +282,43 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         if (pl.resample) colrange(pl.M1s, rank, pl.cF0, pl.wF);
         pl.hs = world > 1 ? SH_HALO : 0;
         pl.xrs = 2 * pl.wH + 2 * pl.hs;
-        {
-            const char *e = getenv("WFX_SHARD_CHUNKS");
-            int want_c = e ? atoi(e) : (world > 1 ? 4 : 1);
-            if (want_c < 1) want_c = 1;
-            if (want_c > 8) want_c = 8;
-            wfx_dist_geom gv;
-            while (want_c > 1 && !wfx_dist_make_geom(gv, world * want_c, 0, pl.g.ra1, pl.g.rb1)) --want_c;
-            pl.nchunk = want_c;
-        }
+        pl.nchunk = 1;       // (chosen below, once the rest of the plan is known)
         pl.own_lo = 2ull * (uint64_t)pl.cH0;
         pl.own_hi = 2ull * (uint64_t)((long long)(R1 - 1) * pl.Ms + pl.cH0 + pl.wH);
         pl.in_lo = pl.resample ? 2ull * (uint64_t)pl.cF0 : pl.own_lo;
         pl.in_hi = pl.resample ? 2ull * (uint64_t)((long long)(R1 - 1) * pl.M1s + pl.cF0 + pl.wF) : pl.own_hi;
         pl.seg_lo = pl.own_lo;
         pl.seg_hi = pl.own_hi;
+    }
+    // ---- k1 subsets per rank: WFX_SHARD_CHUNKS, else what the model says is cheapest among 1 .. 4 (more subsets hide more slab
+    // passes behind the wire, and pay one exchange latency each: long captures on few ranks take 4, short ones or many ranks 1 - 2) ----
+    if (pl.cols) {
+        auto feasible = [&](int c) {
+            wfx_dist_geom gv;
+            return c == 1 || wfx_dist_make_geom(gv, world * c, 0, pl.g.ra1, pl.g.rb1);
+        };
+        const char *e = getenv("WFX_SHARD_CHUNKS");
+        if (e) {
+            int want_c = atoi(e);
+            if (want_c < 1) want_c = 1;
+            if (want_c > 8) want_c = 8;
+            while (want_c > 1 && !feasible(want_c)) --want_c;
+            pl.nchunk = want_c;
+        } else if (world > 1) {
+            double best = 0.0;
+            int best_c = 1;
+            for (int c2 = 1; c2 <= 4; ++c2) {
+                if (!feasible(c2)) continue;
+                pl.nchunk = c2;
+                plan_cost(pl, true);
+                const double t = pl.model_comp + pl.model_wire;
+                if (c2 == 1 || t < best) {
+                    best = t;
+                    best_c = c2;
+                }
+            }
+            pl.nchunk = best_c;
+        }
     }
     // ---- the cost model's choice (unless the caller forced one) ----
     plan_cost(pl, pl.cols);
@@ -1136,7 +1168,10 @@ int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_
     out->model_dist_compute_s = pl.model_comp;
     out->model_dist_wire_s = pl.model_wire;
     out->model_wire_bytes = pl.model_bytes;
-    snprintf(out->plan_reason, sizeof out->plan_reason, "%s", pl.single ? pl.single_reason : (pl.cols ? "columns layout" : (pl.padded ? "rows layout (padded form)" : "rows layout")));
+    if (pl.cols && !pl.single)
+        snprintf(out->plan_reason, sizeof out->plan_reason, "columns layout, every transpose in %d k1 subset%s", pl.nchunk, pl.nchunk == 1 ? "" : "s");
+    else
+        snprintf(out->plan_reason, sizeof out->plan_reason, "%s", pl.single ? pl.single_reason : (pl.padded ? "rows layout (padded form)" : "rows layout"));
     if (pl.cols && world > 1) {
         out->nseg = pl.g.R1;
         out->own_seg_len = 2ull * (uint64_t)pl.wH;
