@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--plan", choices=["auto", "dist", "single", "rows", "auto-rows"], default="auto",
                     help="sharded decodes: auto = the library's cost model picks the distributed form or rank 0 alone (DESIGN 6.6); dist / single "
                          "force one; rows = distributed in the rows layout of rounds 2-3 (8 array transposes instead of 4: A/B runs)")
-    ap.add_argument("--trim", type=int, default=0, help="c2: drop this many samples from the end of the capture (--trim 2 with --shard: the padded distributed convolution; odd: one point per sample)")
+    ap.add_argument("--trim", type=int, default=0, help="c2: drop this many samples from the end of the capture (--trim 2 with --shard: the padded distributed convolution; odd: the real convolution on packed transforms)")
     ap.add_argument("--no-c4", action="store_true", help="c2: leave the c4_strong object out (quick runs)")
     ap.add_argument("--no-extras", action="store_true", help="c2: leave the general_length and c3 objects out (kernel profiles of the headline alone)")
     ap.add_argument("--no-pcie", action="store_true", help="c2: skip the PCIe-inclusive leg (it runs two decodes concurrently: keep it out of kernel profiles)")

@@ -369,7 +369,7 @@ typedef struct {
 } wfx_shard_layout;
 
 /* host only (no GPU needed): how a capture described by `p` is cut for `world` ranks.  Captures at 11 025 Hz shard at ANY
- * length (odd ones with one point per sample: own_lo / own_hi need not be even then).  A capture
+ * length (odd ones too: every own_lo / own_hi is even except the last rank's own_hi = n).  A capture
  * with no distributed form -- resampled with odd or non-13-smooth half-lengths, or too short for the world size -- gets the
  * SINGLE plan: first_radix = {0, 0}, rank 0 owns (and must provide) the whole capture and decodes it alone with the fused
  * one-GPU path, the other ranks provide nothing and receive the scalars; the calls below behave the same either way.

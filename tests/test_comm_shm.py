@@ -185,7 +185,7 @@ def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, wo
     apart: uint8 stream, image, start_frame and the float64 envelope blocks equal the fused one-GPU decode / the in-process
     emulation bit for bit.  ``trim``: an arbitrary even length (half-length not 13-smooth): the padded distributed convolution,
     whose first decode carries three extra phases (on a transform object of their own: the kernel has taps in the padding rows
-    too, the capture does not); an odd trim gives an ODD length (one point per sample, real rows)."""
+    too, the capture does not); an odd trim gives an ODD length (a real convolution on packed transforms: the last pair of samples is half empty)."""
     from wefax_amd import sharded
     from wefax_amd.wefax import DecodeJob
     x = _capture(rate, 5, lpm, trim)

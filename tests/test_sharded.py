@@ -177,7 +177,8 @@ def test_any_length_at_the_native_rate_gets_a_padded_plan(n0):
     Hilbert convolution is embedded in a 13-smooth transform of Kp >= n - 1 points whose rows are dealt to the ranks; a rank owns
     the samples of its rows that lie inside the capture (the ranks whose rows are all padding own none and still take part in
     every exchange).  The layouts tile the capture and every rank's exchange lists agree (host-only dry run).
-    ODD lengths (nothing to pack: scipy's kernel has taps on every lag) take the same form with one point per sample, Kp >= 2n - 1."""
+    ODD lengths (scipy's kernel has taps on every lag) take the same form as a REAL convolution on packed transforms: a point is a
+    pair of samples here too, Kp >= n, and a glue step between the forward and inverse slab passes (round 4; before: one point per sample)."""
     p, meta = build_params(0, n0, 11025, 0.5, shard_plan=sharded.plan_code("dist"))
     for world in (1, 2, 3, 8):
         if n0 < 40000 and world == 8:

@@ -162,3 +162,7 @@ int wfx_dist_scatter_k(wfx_ctx *ctx, const wfx_dist_piece *dev_pieces, int npiec
 int wfx_dist_resample_glue(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Z, long long n0, long long num, cplx *W);
 // the same for one k1 subset of a rank (its own slab [.][km.B] in, its own slab out)
 int wfx_dist_resample_glue_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, const cplx *Z, long long n0, long long num, cplx *W);
+// odd capture lengths on packed real transforms (the sharded counterpart of wfx_dev_hilbert_conv_mr_real): the kernel's table
+// c[slab entry] from the packed transform of its pairs, and the glue between the samples' forward and inverse transforms, in place
+int wfx_dist_real_untangle(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Zg, long long Mh, double *ctab);
+int wfx_dist_real_conv_glue(wfx_ctx *ctx, const wfx_dist_geom &g, cplx *Z, long long Mh, const double *ctab);

@@ -833,6 +833,85 @@ __global__ void __launch_bounds__(256) dist_resample_glue_kernel(const cplx *__r
     }
 }
 
+// ---- odd capture lengths: real samples against scipy's real kernel on PACKED transforms (the one-GPU form: wfx_mrfft.hip,
+// wfx_dev_hilbert_conv_mr_real), here on a rank's slab [Mh / R1][B] of an Mh-point transform.  Bin k pairs with bin Mh - k, which
+// lives on the same rank (k1 sets closed under negation), like the resampler's glue above.
+__device__ __forceinline__ long long dist_slot(long long k, int R1, const wfx_dist_kmap &km)
+{
+    const unsigned q = (unsigned)k / (unsigned)R1;
+    const int k1 = (int)((unsigned)k - q * (unsigned)R1);
+    const int kk = (k1 >= km.kb0 && k1 < km.kb0 + km.kc0) ? k1 - km.kb0 : km.kc0 + (k1 - km.kb1);
+    return (long long)q * km.B + kk;
+}
+
+// c[e] = Im G[k(e)] for every slab entry, from the packed transform Zg of the kernel's pairs (g[2q], g[2q+1]) (mr_real_kernel_untangle)
+__global__ void __launch_bounds__(256) dist_real_untangle_kernel(const cplx *__restrict__ Zg, long long Mh, int R1, wfx_dist_kmap km, double *__restrict__ c)
+{
+    const int B = km.B;
+    const long long total = (Mh / R1) * B;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long k2 = (long long)((unsigned)e / (unsigned)B);
+        const int kk = (int)(e - k2 * B);
+        const long long k = (long long)(kk < km.kc0 ? km.kb0 + kk : km.kb1 + (kk - km.kc0)) + k2 * R1;
+        const cplx zk = Zg[e], zr = Zg[k == 0 ? e : dist_slot(Mh - k, R1, km)];
+        const cplx zc = make_double2(zr.x, -zr.y);
+        double sn, cs;
+        sincospi((double)k / (double)Mh, &sn, &cs);
+        const cplx dif = make_double2(zk.x - zc.x, zk.y - zc.y);
+        c[e] = 0.5 * (zk.y + zc.y) - 0.5 * (cs * dif.x + sn * dif.y);
+    }
+}
+
+// Z (the transform of the packed samples, first pass IN_MODE 1) -> W (the input of the packed inverse), in place: mr_real_conv_glue
+__global__ void __launch_bounds__(256) dist_real_conv_glue_kernel(cplx *__restrict__ Z, long long Mh, int R1, wfx_dist_kmap km, const double *__restrict__ c)
+{
+    const int B = km.B;
+    const long long total = (Mh / R1) * B;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long k2 = (long long)((unsigned)e / (unsigned)B);
+        const int kk = (int)(e - k2 * B);
+        const long long k = (long long)(kk < km.kc0 ? km.kb0 + kk : km.kb1 + (kk - km.kc0)) + k2 * R1;
+        if (k == 0) {                                                    // Y[0] = Y[Mh] = 0: the kernel sums to zero both ways
+            Z[e] = make_double2(0.0, 0.0);
+            continue;
+        }
+        const long long r = Mh - k;
+        if (k > r) continue;                                             // the partner makes this one
+        const long long er = dist_slot(r, R1, km);
+        const cplx a = Z[e], b = Z[er];                                  // Z'[k], Z'[Mh - k]
+        const cplx zk = make_double2(b.y, b.x), zm = make_double2(a.y, a.x);      // Z[k] = i conj Z'[r], Z[r] = i conj Z'[k]
+        double sn, cs;
+        sincospi((double)k / (double)Mh, &sn, &cs);
+        const cplx zmc = make_double2(zm.x, -zm.y), zkc = make_double2(zk.x, -zk.y);
+        const cplx dk = make_double2(zk.x - zmc.x, zk.y - zmc.y), dr = make_double2(zm.x - zkc.x, zm.y - zkc.y);
+        const cplx xk = make_double2(0.5 * (zk.x + zmc.x) + 0.5 * (cs * dk.y - sn * dk.x), 0.5 * (zk.y + zmc.y) - 0.5 * (cs * dk.x + sn * dk.y));
+        const cplx xr = make_double2(0.5 * (zm.x + zkc.x) + 0.5 * (-cs * dr.y - sn * dr.x), 0.5 * (zm.y + zkc.y) - 0.5 * (-cs * dr.x + sn * dr.y));
+        const double ck = c[e], cr = c[er];
+        const cplx yk = make_double2(-xk.y * ck, xk.x * ck), yr = make_double2(-xr.y * cr, xr.x * cr);
+        const cplx yrc = make_double2(yr.x, -yr.y), ykc = make_double2(yk.x, -yk.y);
+        const cplx sk = make_double2(yk.x + yrc.x, yk.y + yrc.y), ek = make_double2(yk.x - yrc.x, yk.y - yrc.y);
+        const cplx sr = make_double2(yr.x + ykc.x, yr.y + ykc.y), er2 = make_double2(yr.x - ykc.x, yr.y - ykc.y);
+        Z[e] = make_double2(sk.x - (sn * ek.x + cs * ek.y), sk.y + (cs * ek.x - sn * ek.y));
+        if (r != k) Z[er] = make_double2(sr.x - (sn * er2.x - cs * er2.y), sr.y - (cs * er2.x + sn * er2.y));
+    }
+}
+
+int wfx_dist_real_untangle(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Zg, long long Mh, double *ctab)
+{
+    const wfx_dist_kmap &km = g.km[g.rank];
+    const long long total = (Mh / g.R1) * km.B;
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, dist_real_untangle_kernel, dim3(wfx_stream_grid((uint64_t)total, 256)), dim3(256), Zg, Mh, g.R1, km, ctab);
+    return 0;
+}
+
+int wfx_dist_real_conv_glue(wfx_ctx *ctx, const wfx_dist_geom &g, cplx *Z, long long Mh, const double *ctab)
+{
+    const wfx_dist_kmap &km = g.km[g.rank];
+    const long long total = (Mh / g.R1) * km.B;
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, dist_real_conv_glue_kernel, dim3(wfx_stream_grid((uint64_t)total, 256)), dim3(256), Z, Mh, g.R1, km, ctab);
+    return 0;
+}
+
 int wfx_dist_resample_glue_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, const cplx *Z, long long n0, long long num, cplx *W)
 {
     const long long total = (num / 2 / R1) * km.B;

@@ -1017,8 +1017,9 @@ int wfx_dev_env_median_segs(wfx_ctx *ctx, const cplx *V_rows, long long v_rs, co
     return 0;
 }
 
-// One rank's block [s0, s1) of a sharded capture of ODD length: one point per sample, V[n].x = H[n].  V and x are indexed by
-// global sample index and valid two samples beyond the block on either side; zeros beyond the capture's true ends.
+// One rank's block [s0, s1) of a sharded capture of ODD length: the packed inverse delivers H itself, point q = (H[2q], H[2q + 1]) --
+// a flat array of doubles.  H (through V) and x are indexed by global sample index and valid two samples beyond the block on
+// either side; zeros beyond the capture's true ends.
 __global__ void __launch_bounds__(256) hconv_env_median_block_plain(const cplx *__restrict__ V, const double *__restrict__ x, long long N, long long s0,
                                                                    long long s1, double *__restrict__ env, unsigned *__restrict__ l0hist)
 {
@@ -1033,7 +1034,7 @@ __global__ void __launch_bounds__(256) hconv_env_median_block_plain(const cplx *
         __syncthreads();
         for (int i = t; i < 1024 + 4; i += 256) {
             const long long n = base - 2 + i;
-            tile[i] = (n >= 0 && n < N && n >= s0 - 2 && n < s1 + 2) ? env_abs(x[n], V[n].x) : 0.0;
+            tile[i] = (n >= 0 && n < N && n >= s0 - 2 && n < s1 + 2) ? env_abs(x[n], ((const double *)V)[n]) : 0.0;
         }
         __syncthreads();
 #pragma unroll

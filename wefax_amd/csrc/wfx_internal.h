@@ -242,7 +242,7 @@ int wfx_dev_hilbert_env_bluestein(wfx_ctx *ctx, const double *x, uint64_t n, dou
 // |x + i H| + median 5 + level-0 histogram of the block [s0, s1) of a sharded capture: V_global[m] = (H[2m], H[2m-1]) and x_global[i]
 // are pointers pre-offset to GLOBAL indices, valid two samples beyond the block on either side; env_block[i - s0]
 int wfx_dev_env_median_block_plain(wfx_ctx *ctx, const cplx *V_global, const double *x_global, uint64_t n_total, uint64_t s0, uint64_t s1, double *env_block,
-                                   unsigned *l0hist);                // odd captures: V[n].x = H[n]
+                                   unsigned *l0hist);                // odd captures: H as a flat array, ((const double *)V_global)[n] = H[n]
 int wfx_dev_env_median_block(wfx_ctx *ctx, const cplx *V_global, const double *x_global, uint64_t n_total, uint64_t s0, uint64_t s1, double *env_block,
                              unsigned *l0hist);
 // one rank's COLUMNS: nseg segments of seg_len samples; V_rows / x_rows point at the first OWN pair / sample of row 0 (halos on both sides)
@@ -343,7 +343,7 @@ int wfx_dev_hilbert_conv_mr_real(wfx_ctx *ctx, const double *x, uint64_t n, cplx
 long long wfx_mr_padded_length(long long min_len);
 void wfx_mr_smooth_numbers(long long lo, long long hi, std::vector<long long> &out);       // ascending 13-smooth numbers in [lo, hi]
 int wfx_dev_hilbert_kernel_rows(wfx_ctx *ctx, cplx *dst, long long p0, long long count, long long N, long long M);
-int wfx_dev_hilbert_kernel_rows_plain(wfx_ctx *ctx, double *dst, long long p0, long long count, long long N, long long M);      // odd N
+int wfx_dev_hilbert_kernel_rows_real(wfx_ctx *ctx, cplx *dst, long long p0, long long count, long long N, long long Mh);       // odd N: pairs (g[2q], g[2q+1]) / 2 Mh
 bool wfx_mr_resample_supported(uint64_t n0, uint64_t num);
 int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16 = false);
 

@@ -640,8 +640,6 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                     if (IN_MODE == 2) {
                         const short2 x2 = SUP > 1 ? stage[(a * RB + b) * SW + (tix & (SUP - 1)) * T + c] : ((const short2 *)in)[adr];
                         v = make_double2((double)x2.x, (double)x2.y);
-                    } else if (IN_MODE == 3) {                    // one real sample per point (odd capture lengths: nothing to pack)
-                        v = make_double2(((const double *)in)[adr], 0.0);
                     } else {
                         v = in[adr];
                         if (IN_MODE == 1) v = make_double2(v.y, v.x);
@@ -1260,8 +1258,6 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 4, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 1 && out_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
-        else if (dir == 0 && in_mode == 3 && out_mode == 0)                                                                          \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 3, 0, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 0 && out_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else                                                                                                                          \
@@ -1568,7 +1564,7 @@ __global__ void __launch_bounds__(256) mr_padded_fill_range(cplx *__restrict__ G
 }
 
 // odd N: kh[r] = cot(pi r / 2N) / N on odd lags, -tan(pi r / 2N) / N on even ones (r reduced to (-N/2, N/2]); the kernel is real
-// and so are the samples -- one point per sample, rows of plain doubles (mr2_pass IN_MODE 3)
+// and so are the samples
 __device__ __forceinline__ double mr_hilbert_tap_odd(long long r, long long N)
 {
     r %= N;
@@ -1580,20 +1576,27 @@ __device__ __forceinline__ double mr_hilbert_tap_odd(long long r, long long N)
     return ((r & 1) ? (c / s) : -(s / c)) / (double)N;
 }
 
-__global__ void __launch_bounds__(256) mr_padded_fill_range_plain(double *__restrict__ G, long long p0, long long count, long long N, long long M, double inv_m)
+// rows of the odd-length kernel for a distributed PACKED transform of Mh points: point q = (g[2q], g[2q + 1]) / M, M = 2 Mh
+// (mr_real_kernel_fill over a range)
+__global__ void __launch_bounds__(256) mr_real_kernel_fill_range(cplx *__restrict__ G, long long p0, long long count, long long N, long long Mh, double inv_m)
 {
+    const long long M = 2 * Mh;
     for (long long e = blockIdx.x * 256ll + threadIdx.x; e < count; e += (long long)gridDim.x * 256ll) {
-        const long long i = p0 + e;
-        double v = 0.0;
-        if (i < N || M - i < N) v = mr_hilbert_tap_odd(i < N ? i : i - M, N) * inv_m;
-        G[e] = v;
+        const long long q = p0 + e;
+        double v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long i = 2 * q + h;
+            v[h] = (i < N || M - i < N) ? mr_hilbert_tap_odd(i < N ? i : i - M, N) * inv_m : 0.0;
+        }
+        G[e] = make_double2(v[0], v[1]);
     }
 }
 
-int wfx_dev_hilbert_kernel_rows_plain(wfx_ctx *ctx, double *dst, long long p0, long long count, long long N, long long M)
+int wfx_dev_hilbert_kernel_rows_real(wfx_ctx *ctx, cplx *dst, long long p0, long long count, long long N, long long Mh)
 {
     if (count <= 0) return 0;
-    WFX_LAUNCH(ctx, K_BS_CHIRP, mr_padded_fill_range_plain, dim3(wfx_stream_grid((uint64_t)count, 256)), dim3(256), dst, p0, count, N, M, 1.0 / (double)M);
+    WFX_LAUNCH(ctx, K_BS_CHIRP, mr_real_kernel_fill_range, dim3(wfx_stream_grid((uint64_t)count, 256)), dim3(256), dst, p0, count, N, Mh, 0.5 / (double)Mh);
     return 0;
 }
 

@@ -170,9 +170,11 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     if (want == 2) return single("asked for by the caller (wfx_decode_params.shard_plan)");
     if (p->n >= (1ull << 31)) return single("2^31 samples: beyond the distributed transforms' 32-bit indices");
     if (p->resample && ((p->n & 1) || (p->n0 & 1))) return single("a resampled capture with an odd sample count (its transforms are packed)");
+    // odd length: real samples against scipy's real kernel on PACKED transforms (round 4; rounds 1-3: one complex point per sample,
+    // twice the points) -- a point is a pair of samples here too, the last one half empty
     pl.plain = (p->n & 1) != 0;
-    pl.spp = pl.plain ? 1 : 2;
-    pl.K = pl.plain ? (long long)p->n : (long long)(p->n / 2);
+    pl.spp = 2;
+    pl.K = (long long)((p->n + 1) / 2);
     pl.M1 = (long long)(p->n0 / 2);
     long long lens[2] = {pl.K, pl.M1};
     int ra1 = 0, rb1 = 0;
@@ -227,8 +229,9 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     pl.Ms = pl.Kp / R1;
     pl.M1s = pl.M1 / R1;
     auto clipK = [&](long long pts) { return (uint64_t)(pts < pl.K ? pts : pl.K); };
-    pl.own_lo = (uint64_t)pl.spp * clipK((long long)pl.g.rows[rank] * pl.Ms);
-    pl.own_hi = (uint64_t)pl.spp * clipK((long long)pl.g.rows[rank + 1] * pl.Ms);
+    auto clipN = [&](uint64_t smp) { return smp < (uint64_t)p->n ? smp : (uint64_t)p->n; };        // (odd length: the last point holds one sample)
+    pl.own_lo = clipN((uint64_t)pl.spp * clipK((long long)pl.g.rows[rank] * pl.Ms));
+    pl.own_hi = clipN((uint64_t)pl.spp * clipK((long long)pl.g.rows[rank + 1] * pl.Ms));
     pl.wrap_rank = 0;
     for (int r = 0; r < world; ++r)
         if ((long long)pl.g.rows[r] * pl.Ms < pl.K) pl.wrap_rank = r;           // the last rank that owns samples
@@ -249,7 +252,7 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         if (!dist_ok(pl.Kp, SH_VHALO) || (pl.resample && (!dist_ok(pl.M1, 0) || !dist_ok(pl.K, SH_HALO / 2)))) return single("too short for this world size");
     }
     for (int r = 0; r < world; ++r) {
-        const uint64_t lo = (uint64_t)pl.spp * clipK((long long)pl.g.rows[r] * pl.Ms), hi = (uint64_t)pl.spp * clipK((long long)pl.g.rows[r + 1] * pl.Ms);
+        const uint64_t lo = clipN((uint64_t)pl.spp * clipK((long long)pl.g.rows[r] * pl.Ms)), hi = clipN((uint64_t)pl.spp * clipK((long long)pl.g.rows[r + 1] * pl.Ms));
         if ((r > 0 && hi > lo && lo < SH_HALO) || (hi - lo < 1024 && !(pl.padded && r > 0)) || (pl.padded && hi > lo && hi - lo < 64))
             return single("too short for this world size");
     }
@@ -708,16 +711,19 @@ static int run_phase(wfx_shard *sh, int ph)
         const wfx_dist_geom &gk = pl.split_kernel ? pl.gk : pl.g;
         if (ph == 0) {
             if (pl.plain)
-                WFX_TRY(wfx_dev_hilbert_kernel_rows_plain(ctx, (double *)sh->b_grow.p, (long long)gk.rows[me] * pl.Ms, (long long)gk.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
+                WFX_TRY(wfx_dev_hilbert_kernel_rows_real(ctx, (cplx *)sh->b_grow.p, (long long)gk.rows[me] * pl.Ms, (long long)gk.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
             else
                 WFX_TRY(wfx_dev_hilbert_kernel_rows(ctx, (cplx *)sh->b_grow.p, (long long)gk.rows[me] * pl.Ms, (long long)gk.nrows(me) * pl.Ms, (long long)pl.n, pl.Kp));
             return dk.fwd_pack_exchange(c, sh->b_grow.p);
         }
-        if (ph == 1) return dk.fwd_pass1_exchange(c, pl.plain ? 3 : 0);
+        if (ph == 1) return dk.fwd_pass1_exchange(c, 0);
         if (ph == 2) {
             cplx *G = nullptr;
             WFX_TRY(dk.fwd_slab(0, &G));
-            WFX_HIP(ctx, hipMemcpyAsync(sh->b_ghat.p, G, (size_t)sh->dH.slab_points() * sizeof(cplx), hipMemcpyDeviceToDevice, ctx->stream));
+            if (pl.plain)      // the real kernel's table: one double per slab entry, untangled from its packed transform
+                WFX_TRY(wfx_dist_real_untangle(ctx, pl.g, G, pl.Kp, (double *)sh->b_ghat.p));
+            else
+                WFX_HIP(ctx, hipMemcpyAsync(sh->b_ghat.p, G, (size_t)sh->dH.slab_points() * sizeof(cplx), hipMemcpyDeviceToDevice, ctx->stream));
             // the kernel's transform exists from here on: a decode that aborts in a later phase and is retried must NOT re-run
             // these three phases (the forward half is re-bound to the audio rows below)
             if (pl.split_kernel) {       // the kernel's transform object and its rows have done their work
@@ -742,7 +748,7 @@ static int run_phase(wfx_shard *sh, int ph)
             WFX_TRY(sh->dH.inv_unpack((cplx *)sh->b_v.p));
             cplx *vown = (cplx *)sh->b_v.p + SH_VHALO;
             wfx_xfer x{};
-            if (pl.plain) return wfx_comm_exchange(c, ctx, &x, 0);         // (one point per sample: H[n] = V[n].x, nothing wraps)
+            if (pl.plain) return wfx_comm_exchange(c, ctx, &x, 0);         // (odd length: a LINEAR convolution with both signs of the lag in the kernel -- nothing wraps)
             x.peer = me == 0 ? pl.wrap_rank : 0;
             if (me == 0) {
                 x.send = vown;
@@ -799,10 +805,13 @@ static int run_phase(wfx_shard *sh, int ph)
         if (n_seg) WFX_TRY(wfx_dev_notch_fir_only(ctx, nin, nkind, n_seg, p.notch_b, p.notch_a, audio, flags, use_ext ? ext18 : nullptr));
         return sh->dH.fwd_pack_exchange(c, audio + (pl.own_lo - pl.seg_lo));
     }
-    case 5: return sh->dH.fwd_pass1_exchange(c, pl.plain ? 3 : 1);
+    case 5: return sh->dH.fwd_pass1_exchange(c, 1);
     case 6: {
         cplx *G = nullptr;
-        if (pl.padded)
+        if (pl.plain) {     // real samples, real kernel: the glue between the packed forward and inverse transforms, in place
+            WFX_TRY(sh->dH.fwd_slab(0, &G));
+            WFX_TRY(wfx_dist_real_conv_glue(ctx, pl.g, G, pl.Kp, (const double *)sh->b_ghat.p));
+        } else if (pl.padded)
             WFX_TRY(sh->dH.fwd_slab(0, &G, 0, 0, (const cplx *)sh->b_ghat.p));
         else
             WFX_TRY(sh->dH.fwd_slab(1, &G));
@@ -1051,8 +1060,8 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
         WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward"));
         WFX_TRY(dry_check_transform(pl, p, pl.K, 16, SH_HALO / 2, SH_HALO / 2, false, true, "resample inverse"));
     }
-    if (pl.split_kernel) WFX_TRY(dry_check_transform(pl, p, pl.Kp, pl.plain ? 8 : 16, 0, 0, true, false, "hilbert kernel (all rows)"));
-    return dry_check_transform(pl, p, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO, true, true, pl.plain ? "hilbert (odd length)" : (pl.padded ? "hilbert (padded)" : "hilbert"),
+    if (pl.split_kernel) WFX_TRY(dry_check_transform(pl, p, pl.Kp, 16, 0, 0, true, false, "hilbert kernel (all rows)"));
+    return dry_check_transform(pl, p, pl.Kp, 16, SH_VHALO, SH_VHALO, true, true, pl.plain ? "hilbert (odd length)" : (pl.padded ? "hilbert (padded)" : "hilbert"),
                                pl.g.rows_used);
 }
 
@@ -1114,7 +1123,7 @@ extern "C" int wfx_shard_wire_plan(const wfx_decode_params *p, int world, wfx_wi
         const int h = pl.cols ? pl.hs / 2 : SH_HALO / 2;
         WFX_TRY(transform("resample inv", pl.K, 16, h, h, false, true, 0));
     }
-    WFX_TRY(transform("hilbert", pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO, true, true, pl.g.rows_used));
+    WFX_TRY(transform("hilbert", pl.Kp, 16, SH_VHALO, SH_VHALO, true, true, pl.g.rows_used));
     const unsigned long long ar0 = 2ull * (W - 1) * WFX_SEL_BINS * 4 / W, ar1 = 2ull * (W - 1) * WFX_SEL_H1_WORDS * 4 / W;
     put("select level 0", ar0 * W, ar0, WFX_SEL_BINS * 4ull / W);
     put("select level 1", ar1 * W, ar1, WFX_SEL_H1_WORDS * 4ull / W);
@@ -1222,8 +1231,8 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
         rc = sh->dF.init(ctx, pl.g, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, false, 0, nc);
         if (rc == 0) rc = sh->dI.init(ctx, pl.g, pl.K, 16, pl.cols ? pl.hs / 2 : SH_HALO / 2, pl.cols ? pl.hs / 2 : SH_HALO / 2, false, 0, nc);
     }
-    if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.Kp, pl.plain ? 8 : 16, SH_VHALO, SH_VHALO, false, 0, pl.cols ? pl.nchunk : 1);
-    if (rc == 0 && pl.split_kernel) rc = sh->dHk.init(ctx, pl.gk, pl.Kp, pl.plain ? 8 : 16, 0, 0);
+    if (rc == 0) rc = sh->dH.init(ctx, pl.g, pl.Kp, 16, SH_VHALO, SH_VHALO, false, 0, pl.cols ? pl.nchunk : 1);
+    if (rc == 0 && pl.split_kernel) rc = sh->dHk.init(ctx, pl.gk, pl.Kp, 16, 0, 0);
     if (rc != 0) {
         wfx_shard_destroy(sh);
         return rc;
