@@ -109,11 +109,14 @@ static void plan_cost(shard_plan &pl, bool cols)
     const int W = pl.world;
     const double n = (double)pl.n, n0 = (double)pl.n0;
     const double per = n * 16.0 <= 256e6 ? 46e-12 : 70e-12;
-    pl.model_single = 20e-6 + per * n + (pl.resample ? 8.7e-12 * n0 : 0.0);
+    // (a length whose half is not 13-smooth runs its convolution on twice the points: 1.55x measured on one GPU, odd lengths 1.63x)
+    pl.model_single = 20e-6 + per * n * (pl.plain ? 1.63 : (pl.padded ? 1.55 : 1.0)) + (pl.resample ? 8.7e-12 * n0 : 0.0);
     const double K16 = 16.0 * (double)pl.Kp, M16 = 16.0 * (double)pl.M1;
     const double in_es = pl.in_kind == WFX_IN_I16_MONO ? 4.0 : 16.0;
-    // array transposes: rows layout E1..E4 per transform, columns layout E2 / E3 only
-    double arrays = cols ? 2.0 * K16 : 4.0 * K16;
+    // array transposes: rows layout E1..E4 per transform (a padded form's E1 / E4 carry the sample-bearing rows only), columns
+    // layout E2 / E3 only
+    const double used = (!cols && pl.g.rows_used > 0 && pl.g.R1 > 0) ? (double)pl.g.rows_used / (double)pl.g.R1 : 1.0;
+    double arrays = cols ? 2.0 * K16 : (2.0 + 2.0 * used) * K16;
     int nex = cols ? 2 : 4, ncopy = cols ? 1 : 3;
     if (pl.resample) {
         arrays += cols ? (M16 + K16) : (M16 * (in_es / 16.0) + M16 + 2.0 * K16);
