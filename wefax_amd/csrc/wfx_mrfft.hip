@@ -1254,6 +1254,8 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 3 && in_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 3, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 1 && out_mode == 3 && in_mode == 0)                                                                          \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 3, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 4 && in_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 4, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && in_mode == 1 && out_mode == 0)                                                                          \
@@ -1404,7 +1406,7 @@ static int mr_run(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *src, cplx *A, cpl
     cplx *dst = (src == A) ? B : A;
     for (int i = 0; i < np; ++i) {
         mr_pass_desc d = pc->h.pass[i];
-        if (i == np - 1 && dir == 0 && skip_hi > skip_lo + 1 && np > 1) {      // (a first pass stores whole tiles: never skipped)
+        if (i == np - 1 && skip_hi > skip_lo + 1 && np > 1) {      // (a first pass stores whole tiles: never skipped; inverse: the padded forms' unread outputs)
             d.skip_lo = skip_lo;
             d.skip_hi = skip_hi;
         }
@@ -1671,7 +1673,8 @@ int wfx_dev_hilbert_conv_mr_padded(wfx_ctx *ctx, const double *x, uint64_t n, cp
         src = dst;
         dst = dst == A ? B : A;
     }
-    WFX_TRY(mr_run(ctx, pc, src, A, B, 1, false, nullptr, V_out));
+    // (the envelope kernel reads V[0 .. L) only -- its index L is V[0] again: the last inverse pass does not store the rest)
+    WFX_TRY(mr_run(ctx, pc, src, A, B, 1, false, nullptr, V_out, false, L - 1, M));
     *handled = 1;
     return 0;
 }
@@ -1812,7 +1815,8 @@ int wfx_dev_hilbert_conv_mr_real(wfx_ctx *ctx, const double *x, uint64_t n, cplx
     }
     cplx *Zs = (cplx *)src;
     WFX_LAUNCH(ctx, K_RESAMPLE_PW, mr_real_conv_glue, dim3(wfx_stream_grid((uint64_t)Mh / 2 + 1, 256)), dim3(256), Zs, Mh, (const double *)pd->ctab.p);
-    WFX_TRY(mr_run(ctx, pc, Zs, A, B, 1, false, nullptr, V_out));
+    // (H[0 .. n) = the first (n + 1) / 2 points: the last inverse pass does not store the rest)
+    WFX_TRY(mr_run(ctx, pc, Zs, A, B, 1, false, nullptr, V_out, false, (long long)((n + 1) / 2) - 1, Mh));
     *handled = 1;
     return 0;
 }
