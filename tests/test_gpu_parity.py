@@ -246,6 +246,23 @@ def test_resample_mixed_radix_form(ctx, n0, num):
     assert _rel(ctx.resample(x, num), wo.resample_fft(x, num)) <= FLOAT_TOL
 
 
+@pytest.mark.parametrize("n0,num", [(1440001, 330750), (1440002, 330750), (1439998, 330749), (1439999, 330749), (330749, 1439999), (330750, 1440001),
+                                    (100003, 100003), (100004, 100004), (100003, 100004), (100004, 100003), (16000 * 7 + 2, 11025 * 7 + 1),
+                                    (44100 * 9 + 17, 11025 * 9 + 4), (8192, 8193), (8193, 8192), (2 * 1000003, 459376)])
+def test_resample_of_any_length_by_chirp_z_transforms(ctx, n0, num, monkeypatch):
+    """Lengths the wav happens to have -- odd, prime, a non-smooth half; down- and up-sampling; every parity of input and output; the
+    Nyquist-bin rules of scipy.signal.resample and irfft -- take two chirp-z transforms on the mixed-radix passes (round 4; the
+    power-of-two Bluestein form they replace stays reachable with WFX_NO_CZT and must agree)."""
+    from oracle import wefax_oracle as wo
+    x = _signal(n0, n0 + 5 * num)
+    want = wo.resample_fft(x, num)
+    got = ctx.resample(x, num)
+    assert got.shape == want.shape
+    assert _rel(got, want) <= FLOAT_TOL
+    monkeypatch.setenv("WFX_NO_CZT", "1")
+    assert _rel(ctx.resample(x, num), want) <= FLOAT_TOL
+
+
 @pytest.mark.parametrize("n", [1, 2, 5, 1000, 65537, 300001])
 def test_order_statistics_exact(ctx, n):
     rng = np.random.default_rng(n)

@@ -1244,6 +1244,12 @@ int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t nu
     if (n0 < 1 || num < 1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "resample: empty input or output");
     // even lengths with 13-smooth halves: packed real transforms on the mixed-radix passes (no padding, no chirps)
     if (!ctx->force_pow2 && wfx_mr_resample_supported(n0, num)) return wfx_dev_resample_mr(ctx, x, n0, num, out, x_is_i16);
+    // any other lengths: two chirp-z transforms on the mixed-radix passes (WFX_NO_CZT=1: the power-of-two Bluestein form below)
+    if (!ctx->force_pow2 && !getenv("WFX_NO_CZT")) {
+        int handled = 0;
+        WFX_TRY(wfx_dev_resample_czt(ctx, x, x_is_i16, n0, num, out, &handled));
+        if (handled) return 0;
+    }
     if (x_is_i16) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "resample: int16 input needs the mixed-radix form");
     wfx_bs_plan *p1 = nullptr;
     WFX_TRY(get_plan(ctx, n0, &p1));

@@ -346,6 +346,9 @@ int wfx_dev_hilbert_kernel_rows(wfx_ctx *ctx, cplx *dst, long long p0, long long
 int wfx_dev_hilbert_kernel_rows_real(wfx_ctx *ctx, cplx *dst, long long p0, long long count, long long N, long long Mh);       // odd N: pairs (g[2q], g[2q+1]) / 2 Mh
 bool wfx_mr_resample_supported(uint64_t n0, uint64_t num);
 int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16 = false);
+// any lengths: two chirp-z transforms on the mixed-radix passes (x: float64 or int16 samples); *handled = 0 when the lengths are out
+// of its range (too short, no plan) and nothing was enqueued
+int wfx_dev_resample_czt(wfx_ctx *ctx, const void *x, bool x_is_i16, uint64_t n0, uint64_t num, double *out, int *handled);
 
 int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long fixed, int width, long long room, long long *hdr);
 
