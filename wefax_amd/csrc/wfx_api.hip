@@ -373,7 +373,9 @@ int wfx_decode_run(wfx_ctx *ctx)
     ctx->force_pow2 = p.hilbert_mode == WFX_HILBERT_FFT_POW2;       // (also selects the padded resampler)
     if (p.resample) {
         // an int16 capture whose lengths the mixed-radix resampler takes is read in place by its first pass
-        const bool in_place16 = cur_kind == WFX_IN_I16_MONO && !ctx->force_pow2 && wfx_mr_resample_supported(n0, n) && !getenv("WFX_NO_I16_RESAMPLE");
+        // (so is one of any other length by the chirp-z form's prologue)
+        const bool in_place16 = cur_kind == WFX_IN_I16_MONO && !ctx->force_pow2 && !getenv("WFX_NO_I16_RESAMPLE") &&
+                                (wfx_mr_resample_supported(n0, n) || wfx_czt_resample_supported(ctx, n0, n));
         if (cur_kind == WFX_IN_I16_MONO && !in_place16) {
             WFX_TRY(wfx_reserve(ctx, ctx->b_x, n0 * 8));
             WFX_TRY(wfx_dev_i16_to_f64(ctx, (const int16_t *)cur, n0, (double *)ctx->b_x.p));

@@ -1250,7 +1250,11 @@ int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t nu
         WFX_TRY(wfx_dev_resample_czt(ctx, x, x_is_i16, n0, num, out, &handled));
         if (handled) return 0;
     }
-    if (x_is_i16) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "resample: int16 input needs the mixed-radix form");
+    if (x_is_i16) {      // (the power-of-two form reads float64: only reached when the forms above were switched off)
+        WFX_TRY(wfx_reserve(ctx, ctx->b_x, n0 * 8));
+        WFX_TRY(wfx_dev_i16_to_f64(ctx, (const int16_t *)x, n0, (double *)ctx->b_x.p));
+        x = (const double *)ctx->b_x.p;
+    }
     wfx_bs_plan *p1 = nullptr;
     WFX_TRY(get_plan(ctx, n0, &p1));
     const int log2m1 = p1->log2m;

@@ -349,6 +349,7 @@ int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num
 // any lengths: two chirp-z transforms on the mixed-radix passes (x: float64 or int16 samples); *handled = 0 when the lengths are out
 // of its range (too short, no plan) and nothing was enqueued
 int wfx_dev_resample_czt(wfx_ctx *ctx, const void *x, bool x_is_i16, uint64_t n0, uint64_t num, double *out, int *handled);
+bool wfx_czt_resample_supported(wfx_ctx *ctx, uint64_t n0, uint64_t num);
 
 int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long fixed, int width, long long room, long long *hdr);
 

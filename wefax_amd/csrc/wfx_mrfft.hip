@@ -610,7 +610,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
         gpow[t] = make_double2(cs, -sn);
     }
     cplx pre[NA][RA];
-    const long long in_lim = (IN_MODE == 1 && d.in_len > 0) ? d.in_len : 0x7fffffffffffffffll;     // zero padding behind the packed reals
+    const long long in_lim = ((IN_MODE == 1 || IN_MODE == 0) && d.in_len > 0) ? d.in_len : 0x7fffffffffffffffll;     // zero padding behind the input
     constexpr int SW = SUP * T, NSL = SUP > 1 ? (R * SW + NT - 1) / NT : 1;
     __shared__ short2 stage[SUP > 1 ? R * SW : 1];
     short2 sreg[NSL];
@@ -636,7 +636,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             for (int a = 0; a < RA; ++a) {
                 cplx v = make_double2(0.0, 0.0);
                 const long long adr = (long long)j + (long long)(a * RB + b) * in_rs;
-                if (ok && (IN_MODE != 1 || adr < in_lim)) {
+                if (ok && ((IN_MODE != 1 && IN_MODE != 0) || adr < in_lim)) {
                     if (IN_MODE == 2) {
                         const short2 x2 = SUP > 1 ? stage[(a * RB + b) * SW + (tix & (SUP - 1)) * T + c] : ((const short2 *)in)[adr];
                         v = make_double2((double)x2.x, (double)x2.y);
@@ -1944,18 +1944,14 @@ __global__ void __launch_bounds__(256) czt_fill_b2(cplx *__restrict__ B, long lo
     }
 }
 
-// A[q] = (x[2q] + i x[2q+1]) c1[q] for q < L1, zero behind
+// A[q] = (x[2q] + i x[2q+1]) c1[q] for q < L1 (the first pass counts everything behind as zero)
 template <typename T>
-__global__ void __launch_bounds__(256) czt_prologue(const T *__restrict__ x, long long n0, long long L1, long long M1, cplx *__restrict__ A)
+__global__ void __launch_bounds__(256) czt_prologue(const T *__restrict__ x, long long n0, long long L1, cplx *__restrict__ A)
 {
-    for (long long q = blockIdx.x * 256ll + threadIdx.x; q < M1; q += (long long)gridDim.x * 256ll) {
-        cplx v = make_double2(0.0, 0.0);
-        if (q < L1) {
-            const double a = (double)x[2 * q], b = 2 * q + 1 < n0 ? (double)x[2 * q + 1] : 0.0;
-            const cplx c = czt_chirp(q, n0, -1.0);
-            v = make_double2(a * c.x - b * c.y, a * c.y + b * c.x);
-        }
-        A[q] = v;
+    for (long long q = blockIdx.x * 256ll + threadIdx.x; q < L1; q += (long long)gridDim.x * 256ll) {
+        const double a = (double)x[2 * q], b = 2 * q + 1 < n0 ? (double)x[2 * q + 1] : 0.0;
+        const cplx c = czt_chirp(q, n0, -1.0);
+        A[q] = make_double2(a * c.x - b * c.y, a * c.y + b * c.x);
     }
 }
 
@@ -2031,14 +2027,15 @@ static void czt_release(wfx_ctx *ctx)
 
 // one cyclic convolution on the plan's passes: src (M points, natural order) * table, ping-ponging between A and B; the last inverse
 // pass stores the outputs outside (skip_lo, skip_hi) only
-static int czt_convolve(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *table, const cplx *src, cplx *A, cplx *B, long long skip_lo, long long skip_hi,
-                        cplx **result)
+static int czt_convolve(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *table, const cplx *src, long long in_len, cplx *A, cplx *B, long long skip_lo,
+                        long long skip_hi, cplx **result)
 {
     const cplx *tb = (const cplx *)pc->tables.p;
     const int np = pc->h.npass;
     cplx *dst = (src == A) ? B : A;
     for (int i = 0; i < np; ++i) {
         mr_pass_desc d = pc->h.pass[i];
+        if (i == 0) d.in_len = in_len;                               // the points behind the input count as zero: never written, never read
         if (i == np - 1) d.gtab = (const double2 *)table;
         WFX_TRY(wfx_mr_launch_pair(ctx, d, tb + pc->h.lo_off[i], 0, i == np - 1 ? 4 : 0, 0, src, dst));
         src = dst;
@@ -2047,11 +2044,8 @@ static int czt_convolve(wfx_ctx *ctx, mr_plan_cache *pc, const cplx *table, cons
     return mr_run(ctx, pc, src, A, B, 1, false, nullptr, result, false, skip_lo, skip_hi);
 }
 
-int wfx_dev_resample_czt(wfx_ctx *ctx, const void *x, bool x_is_i16, uint64_t n0u, uint64_t numu, double *out, int *handled)
+static czt_cache *czt_lookup(wfx_ctx *ctx, long long n0, long long num)
 {
-    *handled = 0;
-    if (n0u < 8192 || numu < 8192 || n0u >= (1ull << 31) || numu >= (1ull << 31)) return 0;
-    const long long n0 = (long long)n0u, num = (long long)numu;
     const long long L1 = (n0 + 1) / 2, P = (num + 1) / 2, h = (n0 < num ? n0 : num) / 2;
     czt_cache *cz = nullptr;
     {
@@ -2076,6 +2070,24 @@ int wfx_dev_resample_czt(wfx_ctx *ctx, const void *x, bool x_is_i16, uint64_t n0
         }
         cz = &it->second;
     }
+    return cz;
+}
+
+// whether wfx_dev_resample_czt takes these lengths (the decode then hands it an int16 capture as it is)
+bool wfx_czt_resample_supported(wfx_ctx *ctx, uint64_t n0u, uint64_t numu)
+{
+    if (n0u < 8192 || numu < 8192 || n0u >= (1ull << 31) || numu >= (1ull << 31) || getenv("WFX_NO_CZT")) return false;
+    const czt_cache *cz = czt_lookup(ctx, (long long)n0u, (long long)numu);
+    return cz->M1 != 0 && cz->M2 != 0;
+}
+
+int wfx_dev_resample_czt(wfx_ctx *ctx, const void *x, bool x_is_i16, uint64_t n0u, uint64_t numu, double *out, int *handled)
+{
+    *handled = 0;
+    if (n0u < 8192 || numu < 8192 || n0u >= (1ull << 31) || numu >= (1ull << 31)) return 0;
+    const long long n0 = (long long)n0u, num = (long long)numu;
+    const long long L1 = (n0 + 1) / 2, P = (num + 1) / 2, h = (n0 < num ? n0 : num) / 2;
+    czt_cache *cz = czt_lookup(ctx, n0, num);
     if (cz->M1 == 0 || cz->M2 == 0) return 0;
     const long long M1 = cz->M1, M2 = cz->M2;
     mr_plan_cache *p1 = nullptr, *p2 = nullptr;
@@ -2101,16 +2113,15 @@ int wfx_dev_resample_czt(wfx_ctx *ctx, const void *x, bool x_is_i16, uint64_t n0
         cz->ready = true;
     }
     if (x_is_i16)
-        WFX_LAUNCH(ctx, K_RESAMPLE_PW, czt_prologue<short>, dim3(wfx_stream_grid((uint64_t)M1, 256)), dim3(256), (const short *)x, n0, L1, M1, A);
+        WFX_LAUNCH(ctx, K_RESAMPLE_PW, czt_prologue<short>, dim3(wfx_stream_grid((uint64_t)L1, 256)), dim3(256), (const short *)x, n0, L1, A);
     else
-        WFX_LAUNCH(ctx, K_RESAMPLE_PW, czt_prologue<double>, dim3(wfx_stream_grid((uint64_t)M1, 256)), dim3(256), (const double *)x, n0, L1, M1, A);
+        WFX_LAUNCH(ctx, K_RESAMPLE_PW, czt_prologue<double>, dim3(wfx_stream_grid((uint64_t)L1, 256)), dim3(256), (const double *)x, n0, L1, A);
     cplx *C1 = nullptr;
-    WFX_TRY(czt_convolve(ctx, p1, (const cplx *)cz->b1.p, A, A, B, h, M1 - h, &C1));          // outputs [0, h] and [M1 - h, M1)
+    WFX_TRY(czt_convolve(ctx, p1, (const cplx *)cz->b1.p, A, L1, A, B, h, M1 - h, &C1));      // outputs [0, h] and [M1 - h, M1)
     cplx *A2 = C1 == A ? B : A;
-    WFX_HIP(ctx, hipMemsetAsync(A2, 0, (size_t)M2 * sizeof(cplx), ctx->stream));
     WFX_LAUNCH(ctx, K_RESAMPLE_PW, czt_glue, dim3(wfx_stream_grid((uint64_t)h + 1, 256)), dim3(256), (const cplx *)C1, n0, num, h, M1, A2);
     cplx *C2 = nullptr;
-    WFX_TRY(czt_convolve(ctx, p2, (const cplx *)cz->b2.p, A2, A, B, P - 1, M2, &C2));           // outputs [0, P)
+    WFX_TRY(czt_convolve(ctx, p2, (const cplx *)cz->b2.p, A2, 2 * h + 1, A, B, P - 1, M2, &C2));  // outputs [0, P)
     WFX_LAUNCH(ctx, K_RESAMPLE_PW, czt_epilogue, dim3(wfx_stream_grid((uint64_t)P, 256)), dim3(256), (const cplx *)C2, num, P, out);
     *handled = 1;
     return 0;
