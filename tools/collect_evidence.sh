@@ -100,6 +100,15 @@ done
 WFX_SHARD_CHUNKS=4 WFX_BENCH_FORCE_DIST=1 python bench.py --workload iq --no-cpu > "$OUT/bench_iq_rccl1_chunks4.json" 2>> "$OUT/bench.err"
 WFX_SHARD_CHUNKS=4 WFX_COMM_ASYNC=0 WFX_BENCH_FORCE_DIST=1 python bench.py --workload iq --no-cpu > "$OUT/bench_iq_rccl1_chunks4_inorder.json" 2>> "$OUT/bench.err"
 
+# the same, one decode in launch order with the queue of every dispatch: the exchanges (copies on the communicator's stream) against the passes
+WFX_SHARD_CHUNKS=4 WFX_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tr_ov" -o run -- python3 bench.py --workload iq --iq-seconds 450 --steps 3 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+python tools/kseq.py "$OUT/tr_ov" 'decimate_kernel<1' > "$OUT/kseq_iq450_rccl1_chunks4.txt" 2>&1
+rm -rf "$OUT/tr_ov"
+# captures of ANY length through the resampler (chirp-z form) against the whole-second ones
+timeout 600 python tools/resample_any_length.py --minutes 10 > "$OUT/any_length_10min.jsonl" 2>> "$OUT/bench.err"
+timeout 900 python tools/resample_any_length.py --minutes 60 > "$OUT/any_length_60min.jsonl" 2>> "$OUT/bench.err"
+python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
+
 # randomised whole-path parity sweep against the oracle
 timeout 1200 python tools/random_parity.py --cases 200 --seed 14 > "$OUT/random_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_parity.jsonl"
 
