@@ -476,7 +476,7 @@ def bench_c3(args, rk: Ranks) -> dict:
     if not (rk.world == 1 and not rk.use_rccl):
         out["wire"] = wire_object(rk, dec.params, dec.layout, run, ctx.sync)
     closer()
-    if rk.world == 1 and not rk.use_rccl and not args.short:
+    if rk.world == 1 and not rk.use_rccl and not args.short and not args.no_extras:
         # A recording is as long as it is: the same capture less two samples (n0 even with a prime-ridden half, the reference's output
         # length int(11025 n0 / fs) odd) and less one (n0 odd) -- resampled by two chirp-z transforms on the mixed-radix passes
         # (round 4; rounds 1-3: Bluestein on power-of-two transforms, 41 ms), the Hilbert transform in its odd-length form behind it.

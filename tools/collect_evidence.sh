@@ -68,12 +68,12 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
 python tools/pmc_summary.py "$OUT/pmc_fetch_iq" "$OUT/pmc_write_iq" "$OUT/pmc_traffic_iq.json" > /dev/null 2>&1
 rm -rf "$OUT/trace_iq" "$OUT/pmc_fetch_iq" "$OUT/pmc_write_iq"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -o run -- python3 bench.py --workload c3 --steps 5 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -o run -- python3 bench.py --workload c3 --steps 5 --warmup 1 --no-cpu --no-extras > /dev/null 2>> "$OUT/bench.err"
 python tools/kstats.py "$OUT/trace_c3" "select_|notch|median|image|quantise|sync|mr2_pass|mr_pass|resample" > "$OUT/kernel_stats_c3.txt"
 rm -rf "$OUT/trace_c3"
 # BASELINE configs[2] asks for "rocprof HBM GB/s": FETCH_SIZE / WRITE_SIZE per kernel, separate passes
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c3" -o run -- python3 bench.py --workload c3 --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c3" -o run -- python3 bench.py --workload c3 --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c3" -o run -- python3 bench.py --workload c3 --steps 2 --warmup 1 --no-cpu --no-extras > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c3" -o run -- python3 bench.py --workload c3 --steps 2 --warmup 1 --no-cpu --no-extras > /dev/null 2>> "$OUT/bench.err"
 python tools/pmc_summary.py "$OUT/pmc_fetch_c3" "$OUT/pmc_write_c3" "$OUT/pmc_traffic_c3.json" > /dev/null 2>&1
 rm -rf "$OUT/pmc_fetch_c3" "$OUT/pmc_write_c3"
 
