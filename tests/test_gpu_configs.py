@@ -178,6 +178,31 @@ def test_sixty_minute_48k_capture_full_size():
     ctx.close()
 
 
+@pytest.mark.parametrize("trim", [1, 2])
+def test_ten_minute_48k_capture_of_arbitrary_length(trim):
+    """A 48 kHz recording stopped by hand: a 570-second capture less one sample (N0 odd) and less two (N0 / 2 = 13 679 999 =
+    1229 x 11 131; the reference's output length 6 284 249 odd).  The resampler's chirp-z form on
+    21 M-point convolutions, the int16 samples read in place, the Hilbert transform in its odd-length form behind it -- stream,
+    start frame and image equal to the oracle's."""
+    from wefax_amd import _native as nat
+    from wefax_amd import synth
+    from wefax_amd.wefax import DecodeJob
+    x = synth.synth_capture(48000.0, noise=0.05, seed=7, start_tone_s=5.0, phasing_lines=60, image_lines=1060, stop_tone_s=2.0, black_tail_s=3.0)
+    assert x.shape[0] == 27360000                                  # 570 s: 13-smooth halves as generated
+    x = np.ascontiguousarray(x[:x.shape[0] - trim])
+    ctx = nat.Context(0)
+    job = DecodeJob(ctx, x, 48000, 120)
+    assert job.n == 6284249                                        # int(11025 * (n0 / 48000)): odd
+    job.run()
+    info = job.result()
+    ref = _oracle(x, 48000, 120)
+    assert info.start_frame == ref["start_frame"]
+    assert np.array_equal(job.fetch("digitalized"), ref["digitalized"])
+    img = job.fetch("image")
+    assert img.shape == ref["image"].shape and np.array_equal(img, ref["image"])
+    ctx.close()
+
+
 def test_sixty_minute_iq_stream_full_size_properties():
     """BASELINE configs[3] at FULL size: one 60-minute 1.536 MS/s int16 IQ stream, 5 529 600 000 frames = 22 GB synthesised in
     HBM.  Neither the reference (wefax.py:360-373 merges per sample in Python) nor the oracle can process it, so the checks are
