@@ -26,6 +26,22 @@ def manifest():
         return json.load(fh)
 
 
+def _recipes():
+    sys.path.insert(0, GOLDEN)
+    try:
+        import recipes
+    finally:
+        sys.path.remove(GOLDEN)
+    return recipes
+
+
+@pytest.fixture(scope="session", autouse=True)
+def golden_inputs_in_place():
+    """The golden inputs are not kept in the repository (tests/golden/recipes.py regenerates them, the manifest pins their SHA-256):
+    in place before the first test of a session, whichever file it collects."""
+    _recipes().ensure_all(GOLDEN)
+
+
 def golden_cases():
     """The manifest's cases; inputs that are not kept in the repository (tests/golden/recipes.py) are regenerated on first use."""
     import json

@@ -152,66 +152,28 @@ def main():
         print("case", name, data.shape, flush=True)
         c = run_case(wefax, name, p, lpm)
         c["input"] = "inputs/" + name + ".wav"
-        if recipe:      # too large to keep: regenerated from tests/golden/recipes.py wherever it is missing (.gitignore lists the file)
+        if recipe:      # not kept: regenerated from tests/golden/recipes.py wherever it is missing (.gitignore lists the directory's wavs)
             c["recipe"] = recipe
             c["input_sha256"] = recipes.file_sha256(p)
         manifest["cases"].append(c)
 
-    # 1. clean mono 11 025 Hz, 120 LPM (even N)
-    emit("mono_clean_120", 11025,
-         synth.synth_capture(11025.0, phasing_lines=8, image_lines=24, **short), 120)
-    # 2. noisy mono (non-empty phasing group, odd N)
-    x = synth.synth_capture(11025.0, noise=0.05, seed=1, phasing_lines=20,
-                            image_lines=30, **short)
-    emit("mono_noisy_120", 11025, x[:-1] if x.shape[0] % 2 == 0 else x, 120)
-    # 3. 240 LPM noisy
-    emit("mono_noisy_240", 11025,
-         synth.synth_capture(11025.0, noise=0.05, seed=2, lpm=240, ioc=288,
-                             phasing_lines=40, image_lines=60, **short), 240)
-    # 4. heavy noise + leading silence, prime-ish length
-    x = synth.synth_capture(11025.0, noise=0.2, seed=3, phasing_lines=20,
-                            image_lines=20, lead_silence_s=0.7, **short)
-    emit("mono_noise20_lead", 11025, x[:250007], 120)
-    # 5. 48 kHz mono (resample path)
-    emit("mono48k_noisy_120", 48000,
-         synth.synth_capture(48000.0, noise=0.05, seed=4, phasing_lines=20,
-                             image_lines=16, **short), 120)
-    # 6. 48 kHz stereo (merge + resample); short, the merge loop is slow
-    iq = synth.synth_capture(48000.0, noise=0.02, seed=5, iq=True,
-                             phasing_lines=12, image_lines=8, **short)
-    emit("stereo48k_120", 48000, iq, 120)
-    # 7. 11 025 Hz stereo that overflows int16 in the merge (wefax.py:372)
-    m = synth.synth_capture(11025.0, noise=0.05, seed=6, amplitude=0.9,
-                            phasing_lines=12, image_lines=8, **short)
-    emit("stereo_overflow_120", 11025, np.stack([m, m], axis=1), 120)
-    # 8. upsampling path: 8 kHz mono
-    emit("mono8k_noisy_120", 8000,
-         synth.synth_capture(8000.0, noise=0.05, seed=7, phasing_lines=12,
-                             image_lines=8, **short), 120)
-
-    # 9. resample-path captures long enough that a phasing group closes: an IMAGE downstream of scipy.signal.resample
-    #    (wefax.py:384) and of the stereo merge + resample (240 LPM keeps them short)
-    emit("mono48k_image_240", 48000,
-         synth.synth_capture(48000.0, noise=0.05, seed=22, lpm=240, phasing_lines=40, image_lines=30, **short), 240)
-    emit("stereo48k_image_240", 48000,
-         synth.synth_capture(48000.0, noise=0.05, seed=31, lpm=240, phasing_lines=40, image_lines=24, iq=True, **short), 240)
-    # 10. sample formats other than int16: scipy.io.wavfile returns uint8 / int32 / float32 arrays and filtfilt's odd extension
-    #     (wefax.py:72) is evaluated in THAT dtype (wrapping for the integers, rounded to float32 for float32)
-    base = synth.synth_capture(11025.0, noise=0.05, seed=40, lpm=240, phasing_lines=40, image_lines=40, **short)
-    emit("mono_u8_240", 11025, (base.astype(np.int32) // 256 + 128).astype(np.uint8), 240)
-    base = synth.synth_capture(11025.0, noise=0.05, seed=42, lpm=240, phasing_lines=40, image_lines=40, **short)
-    emit("mono_f32_240", 11025, base.astype(np.float32) / np.float32(32768.0), 240)
-    emit("mono_i32_240", 11025, base.astype(np.int32) * 65536, 240)
-
-    # 10b. the same sample formats in STEREO: the merge loop (wefax.py:360-373) adds two numpy scalars of the file's dtype -- uint8
-    #      wraps modulo 256, int32 modulo 2**32, float32 stays float32 (and so does the list filtfilt later extends at its ends)
-    base = synth.synth_capture(11025.0, noise=0.05, seed=43, lpm=240, phasing_lines=40, image_lines=40, **short)
-    u8 = (base.astype(np.int32) // 300 + 170).astype(np.uint8)                 # 61 .. 279 -> sums of the two channels wrap
-    emit("stereo_u8_240", 11025, np.stack([u8, (u8.astype(np.int32) * 3 // 4).astype(np.uint8)], axis=1), 240)
-    i32 = base.astype(np.int32) * 50000                                         # up to 1.6e9 per channel: sums wrap
-    emit("stereo_i32_240", 11025, np.stack([i32, i32 // 2 + 7], axis=1), 240)
-    f32 = base.astype(np.float32) / np.float32(32768.0)
-    emit("stereo_f32_240", 11025, np.stack([f32, f32 * np.float32(0.3333333)], axis=1), 240)
+    # The inputs are made by tests/golden/recipes.py (deterministic) and are not kept in the repository: the manifest records each
+    # wav's SHA-256 as the reference saw it, and a missing input is regenerated and checked against it wherever the tests run.
+    #  1 clean mono 11 025 Hz 120 LPM (even N)          2 noisy mono (non-empty phasing group, odd N)       3 240 LPM noisy, IOC 288
+    #  4 heavy noise + leading silence, prime-ish N      5 48 kHz mono (resample path)                       6 48 kHz stereo (merge + resample)
+    #  7 11 025 Hz stereo that overflows int16 in the merge (wefax.py:372)                                   8 8 kHz mono (upsampling)
+    #  9 resample-path captures long enough that a phasing group closes: an IMAGE downstream of scipy.signal.resample (wefax.py:384)
+    #    and of the stereo merge + resample (240 LPM keeps them short)
+    # 10 sample formats other than int16: scipy.io.wavfile returns uint8 / int32 / float32 arrays and filtfilt's odd extension
+    #    (wefax.py:72) is evaluated in THAT dtype (wrapping for the integers, rounded to float32 for float32)
+    # 10b the same formats in STEREO: the merge loop (wefax.py:360-373) adds two numpy scalars of the file's dtype -- uint8 wraps
+    #    modulo 256, int32 modulo 2**32, float32 stays float32 (and so does the list filtfilt later extends at its ends)
+    for rname in ("mono_clean_120", "mono_noisy_120", "mono_noisy_240", "mono_noise20_lead", "mono48k_noisy_120", "stereo48k_120",
+                  "stereo_overflow_120", "mono8k_noisy_120", "mono48k_image_240", "stereo48k_image_240", "mono_u8_240", "mono_f32_240",
+                  "mono_i32_240", "stereo_u8_240", "stereo_i32_240", "stereo_f32_240"):
+        if only is None or rname in only:
+            fs_r, data_r, lpm_r = recipes.RECIPES[rname]()
+            emit(rname, fs_r, data_r, lpm_r, recipe=rname)
 
     # 10b'. a float32 wav that is RESAMPLED: scipy.signal.resample keeps single precision for float32 input (complex64 transforms,
     #       float32 result, and filtfilt then extends THAT array) -- the oracle and the device compute in float64, which is more

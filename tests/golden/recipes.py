@@ -1,4 +1,4 @@
-"""Inputs of golden cases that are too large to keep in the repository: they are REGENERATED from these recipes
+"""Inputs of the golden cases (all but the reference's own five clips): not kept in the repository, REGENERATED from these recipes
 (deterministic: ``wefax_amd.synth`` + NumPy's PCG64 streams) wherever the file is missing, and checked against the SHA-256
 that ``make_golden.py`` recorded in the manifest when the reference ran on them.  Data generators only -- nothing of the
 reference is here.
@@ -36,7 +36,97 @@ def _mono48k_f32_240():
     return 48000, b48.astype(np.float32) / np.float32(32768.0), 240
 
 
-RECIPES = {"iq1536k_2s_240": _iq1536k_2s_240, "stereo192k_6s_240": _stereo192k_6s_240, "mono48k_f32_240": _mono48k_f32_240}
+# ---- the small cases: generated from the same few lines since round 1 (they lived in make_golden.py and their wavs in the repository,
+# 20 MB of them, until round 4) ----
+_SHORT = dict(start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0)
+
+
+def _cap(fs, **kw):
+    from wefax_amd import synth
+    return synth.synth_capture(float(fs), **kw, **_SHORT)
+
+
+def _mono_clean_120():
+    return 11025, _cap(11025, phasing_lines=8, image_lines=24), 120
+
+
+def _mono_noisy_120():
+    x = _cap(11025, noise=0.05, seed=1, phasing_lines=20, image_lines=30)
+    return 11025, (x[:-1] if x.shape[0] % 2 == 0 else x), 120               # odd N
+
+
+def _mono_noisy_240():
+    return 11025, _cap(11025, noise=0.05, seed=2, lpm=240, ioc=288, phasing_lines=40, image_lines=60), 240
+
+
+def _mono_noise20_lead():
+    x = _cap(11025, noise=0.2, seed=3, phasing_lines=20, image_lines=20, lead_silence_s=0.7)
+    return 11025, x[:250007], 120
+
+
+def _mono48k_noisy_120():
+    return 48000, _cap(48000, noise=0.05, seed=4, phasing_lines=20, image_lines=16), 120
+
+
+def _stereo48k_120():
+    return 48000, _cap(48000, noise=0.02, seed=5, iq=True, phasing_lines=12, image_lines=8), 120
+
+
+def _stereo_overflow_120():
+    m = _cap(11025, noise=0.05, seed=6, amplitude=0.9, phasing_lines=12, image_lines=8)
+    return 11025, np.stack([m, m], axis=1), 120
+
+
+def _mono8k_noisy_120():
+    return 8000, _cap(8000, noise=0.05, seed=7, phasing_lines=12, image_lines=8), 120
+
+
+def _mono48k_image_240():
+    return 48000, _cap(48000, noise=0.05, seed=22, lpm=240, phasing_lines=40, image_lines=30), 240
+
+
+def _stereo48k_image_240():
+    return 48000, _cap(48000, noise=0.05, seed=31, lpm=240, phasing_lines=40, image_lines=24, iq=True), 240
+
+
+def _base240(seed):
+    return _cap(11025, noise=0.05, seed=seed, lpm=240, phasing_lines=40, image_lines=40)
+
+
+def _mono_u8_240():
+    return 11025, (_base240(40).astype(np.int32) // 256 + 128).astype(np.uint8), 240
+
+
+def _mono_f32_240():
+    return 11025, _base240(42).astype(np.float32) / np.float32(32768.0), 240
+
+
+def _mono_i32_240():
+    return 11025, _base240(42).astype(np.int32) * 65536, 240
+
+
+def _stereo_u8_240():
+    u8 = (_base240(43).astype(np.int32) // 300 + 170).astype(np.uint8)                 # 61 .. 279 -> sums of the two channels wrap
+    return 11025, np.stack([u8, (u8.astype(np.int32) * 3 // 4).astype(np.uint8)], axis=1), 240
+
+
+def _stereo_i32_240():
+    i32 = _base240(43).astype(np.int32) * 50000                                         # up to 1.6e9 per channel: sums wrap
+    return 11025, np.stack([i32, i32 // 2 + 7], axis=1), 240
+
+
+def _stereo_f32_240():
+    f32 = _base240(43).astype(np.float32) / np.float32(32768.0)
+    return 11025, np.stack([f32, f32 * np.float32(0.3333333)], axis=1), 240
+
+
+RECIPES = {"iq1536k_2s_240": _iq1536k_2s_240, "stereo192k_6s_240": _stereo192k_6s_240, "mono48k_f32_240": _mono48k_f32_240,
+           "mono_clean_120": _mono_clean_120, "mono_noisy_120": _mono_noisy_120, "mono_noisy_240": _mono_noisy_240,
+           "mono_noise20_lead": _mono_noise20_lead, "mono48k_noisy_120": _mono48k_noisy_120, "stereo48k_120": _stereo48k_120,
+           "stereo_overflow_120": _stereo_overflow_120, "mono8k_noisy_120": _mono8k_noisy_120, "mono48k_image_240": _mono48k_image_240,
+           "stereo48k_image_240": _stereo48k_image_240, "mono_u8_240": _mono_u8_240, "mono_f32_240": _mono_f32_240,
+           "mono_i32_240": _mono_i32_240, "stereo_u8_240": _stereo_u8_240, "stereo_i32_240": _stereo_i32_240,
+           "stereo_f32_240": _stereo_f32_240}
 
 
 def file_sha256(path: str) -> str:
@@ -63,3 +153,13 @@ def ensure_input(golden_dir: str, case: dict) -> str:
                            "(a different NumPy random stream?)")
     os.replace(tmp, path)
     return path
+
+
+def ensure_all(golden_dir: str) -> None:
+    """Every golden input in place (regenerated where missing): conftest.py, __graft_entry__.smoke() and the tools call this before
+    they open a wav by path."""
+    import json
+    with open(os.path.join(golden_dir, "manifest.json")) as fh:
+        cases = json.load(fh)["cases"]
+    for c in cases:
+        ensure_input(golden_dir, c)

@@ -27,6 +27,9 @@ def rel(a, b):
 def main():
     only = sys.argv[1:] or None
     ctx = nat.Context(0)
+    sys.path.insert(0, G)
+    import recipes
+    recipes.ensure_all(G)                      # the inputs are regenerated from their recipes where they are missing
     cases = json.load(open(os.path.join(G, "manifest.json")))["cases"]
     for c in cases:
         if only and c["name"] not in only:

@@ -75,6 +75,9 @@ def main():
     a = ap.parse_args()
     bad = 0
     gold = os.path.join(REPO, "tests", "golden")
+    sys.path.insert(0, gold)
+    import recipes
+    recipes.ensure_all(gold)
     man = json.load(open(os.path.join(gold, "manifest.json")))
     for c in man["cases"] if isinstance(man, dict) else man:
         name, lpm = c["name"], c.get("lpm", 120)
