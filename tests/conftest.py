@@ -42,6 +42,12 @@ def golden_inputs_in_place():
     _recipes().ensure_all(GOLDEN)
 
 
+def load_golden(name: str):
+    """The stage arrays the REFERENCE produced for a case (tests/golden/recipes.py: load_golden): `np.load`-like, the image rebuilt
+    from the golden stream where only its SHA-256 is stored -- and handed out only if it hashes to the reference's."""
+    return _recipes().load_golden(GOLDEN, name)
+
+
 def golden_cases():
     """The manifest's cases; inputs that are not kept in the repository (tests/golden/recipes.py) are regenerated on first use."""
     import json

@@ -18,7 +18,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, REPO
+from conftest import GOLDEN, REPO, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -324,7 +324,7 @@ def test_command_line_wav_to_png(name, lpm, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(REPO, "wefax.py"), wav, str(lpm), str(out)], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "filename : " + name + ".wav" in r.stdout and "sample_rate :" in r.stdout        # wefax.py:418-419
-    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    g = load_golden(name)
     img = _read_png_gray8(str(out))
     assert img.shape == g["image"].shape and np.array_equal(img, g["image"])
     try:
@@ -341,7 +341,7 @@ def test_png_assembled_on_the_device_and_the_compressed_alternative(tmp_path, mo
     zlib encoder on the host.  Same pixels every way, and a context that has moved on to another decode falls back to encoding the
     host copy."""
     from wefax_amd import Demodulator
-    g = np.load(os.path.join(GOLDEN, "mono_noisy_120.npz"))
+    g = load_golden("mono_noisy_120")
     d = Demodulator(os.path.join(GOLDEN, "inputs", "mono_noisy_120.wav"), lines_per_minute=120, quiet=True)
     d.process()
     a, b, c, e = str(tmp_path / "a.png"), str(tmp_path / "b.png"), str(tmp_path / "c.png"), str(tmp_path / "e.png")
@@ -379,7 +379,7 @@ def test_device_deflate_png(name, lpm, tmp_path):
     d.process()
     img = d.output_array
     if name != "synthetic":
-        assert np.array_equal(img, np.load(os.path.join(GOLDEN, name + ".npz"))["image"])
+        assert np.array_equal(img, load_golden(name)["image"])
     blob, stored = d._ctx.decode_png(deflate=True), d._ctx.decode_png()
     assert blob == d._ctx.decode_png(deflate=True)
     out = str(tmp_path / "d.png")
@@ -415,7 +415,7 @@ def test_demodulators_share_idle_contexts():
     Demodulator hands it to the idle pool and the next one takes it from there; two that are alive at once get two contexts;
     a Demodulator keeps its image until it is closed."""
     from wefax_amd import Demodulator, wefax as wx
-    g = np.load(os.path.join(GOLDEN, "mono_noisy_120.npz"))
+    g = load_golden("mono_noisy_120")
     wav = os.path.join(GOLDEN, "inputs", "mono_noisy_120.wav")
     wx.release_contexts()
     d1 = Demodulator(wav, lines_per_minute=120, quiet=True)

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases
+from conftest import GOLDEN, golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,7 @@ def _rel(a, b):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_demodulator_matches_reference_golden(case):
     from wefax_amd import Demodulator
-    g = np.load(os.path.join(GOLDEN, case["name"] + ".npz"))
+    g = load_golden(case["name"])
     d = Demodulator(os.path.join(GOLDEN, case["input"]), lines_per_minute=case["lpm"],
                     quiet=True, tcp_stream=True)
     info = d.file_info()

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases
+from conftest import GOLDEN, golden_cases, load_golden
 from oracle import wefax_oracle as wo
 
 CASES = golden_cases()
@@ -18,7 +18,7 @@ def _sha(a):
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_oracle_matches_reference_every_stage(case):
-    g = np.load(os.path.join(GOLDEN, case["name"] + ".npz"))
+    g = load_golden(case["name"])
     r = wo.process(os.path.join(GOLDEN, case["input"]), case["lpm"])
     assert r["sample_rate"] == case["sample_rate"]
     assert r["length"] == case["length"]

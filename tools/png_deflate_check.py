@@ -81,7 +81,7 @@ def main():
     man = json.load(open(os.path.join(gold, "manifest.json")))
     for c in man["cases"] if isinstance(man, dict) else man:
         name, lpm = c["name"], c.get("lpm", 120)
-        g = np.load(os.path.join(gold, name + ".npz"))
+        g = recipes.load_golden(gold, name)
         if "image" not in g.files or g["image"].ndim != 2 or g["image"].size == 0:
             continue
         d = Demodulator(os.path.join(gold, "inputs", name + ".wav"), lines_per_minute=lpm, quiet=True)
