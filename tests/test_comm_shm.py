@@ -213,7 +213,7 @@ def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, wo
     p, _ = build_params(sharded.capture_kind(x), x.shape[0], rate, 1 / (lpm / 60), shard_plan=sharded.plan_code("dist"))
     lays = [nat.shard_layout(p, world, r) for r in range(world)]
     assert np.array_equal(sharded.assemble(lays, [np.load(tmp_path / f"env{r}.npy") for r in range(world)], emu["n"]), emu["envelope"])
-    assert lays[0].plan == (1 if trim else 2)               # whole seconds: the columns layout; arbitrary lengths: the padded rows form
+    assert lays[0].plan == 2                                # the columns layout -- since later in round 4 also for arbitrary lengths (padded forms)
     if trim:
         sizes = [nat.shard_layout(p, world, r).own_hi - nat.shard_layout(p, world, r).own_lo for r in range(world)]
         assert min(sizes) > 0 and max(sizes) - min(sizes) <= x.shape[0] // 16   # only the rows that hold samples are dealt: equal shares

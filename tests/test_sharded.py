@@ -179,16 +179,35 @@ def test_any_length_at_the_native_rate_gets_a_padded_plan(n0):
     every exchange).  The layouts tile the capture and every rank's exchange lists agree (host-only dry run).
     ODD lengths (scipy's kernel has taps on every lag) take the same form as a REAL convolution on packed transforms: a point is a
     pair of samples here too, Kp >= n, and a glue step between the forward and inverse slab passes (round 4; before: one point per sample)."""
-    p, meta = build_params(0, n0, 11025, 0.5, shard_plan=sharded.plan_code("dist"))
     for world in (1, 2, 3, 8):
         if n0 < 40000 and world == 8:
             continue
+        # the rows layout (rounds 2-3; what one rank still takes): contiguous ranges that tile the capture
+        p, meta = build_params(0, n0, 11025, 0.5, shard_plan=sharded.plan_code("rows"))
         lays = [nat.shard_layout(p, world, r) for r in range(world)]
+        assert all(lay.plan == 1 and lay.nseg == 1 for lay in lays)
         assert lays[0].own_lo == 0 and lays[-1].own_hi == n0
         assert all(lays[i].own_hi == lays[i + 1].own_lo for i in range(world - 1))
         sizes = [lay.own_hi - lay.own_lo for lay in lays]
         assert min(sizes) >= 4096 and (world == 1 or max(sizes) - min(sizes) <= n0 // 12)     # only rows that hold samples are dealt
         assert all(lay.in_lo == max(0, lay.own_lo - 32) and lay.in_hi == min(n0, lay.own_hi + 32) for lay in lays if lay.own_hi > lay.own_lo)
+        nat.shard_dry_run(p, world)
+        # the columns layout (later in round 4, more than one rank): a rank's columns of EVERY row of the padded arrangement -- the
+        # segments reach past the capture's end (the slots behind it hold nothing), their halos are 192 samples (filtfilt's exact
+        # edge where the capture ends inside a segment), and every sample of the capture has exactly one owner
+        p, meta = build_params(0, n0, 11025, 0.5, shard_plan=sharded.plan_code("dist"))
+        lays = [nat.shard_layout(p, world, r) for r in range(world)]
+        if world == 1 or lays[0].plan != 2:
+            assert all(lay.plan == 1 for lay in lays)
+        else:
+            assert all(lay.plan == 2 and lay.nseg == lays[0].nseg and lay.in_halo == 192 for lay in lays)
+            stride = int(lays[0].own_seg_stride)
+            assert lays[0].own_lo == 0 and lays[-1].own_lo + lays[-1].own_seg_len == stride
+            assert all(lays[i].own_lo + lays[i].own_seg_len == lays[i + 1].own_lo for i in range(world - 1))
+            assert 2 * (n0 - 1) <= int(lays[0].nseg) * stride < 2.2 * n0 + stride       # the padded arrangement: Kp >= n - 1 POINTS
+            owned = np.concatenate([lay.own_index() for lay in lays])
+            owned = np.sort(owned[owned < n0])
+            assert owned.shape[0] == n0 and owned[0] == 0 and owned[-1] == n0 - 1 and np.all(np.diff(owned) == 1)
         nat.shard_dry_run(p, world)
 
 

@@ -89,7 +89,8 @@ class wfx_dist {
     // ---- subset by subset (nchunk >= 1; `slot`: which of the communicator's completion events the exchange records) -------
     int fwd_pass1(int in_mode);                                                    // pass 1: every subset's E2 messages are ready
     int e2_exchange(wfx_comm *c, int chunk, int slot);                             // E2 of one subset (asynchronous where the transport can)
-    int fwd_slab_chunk(int chunk, int hilbert_spectrum, cplx **spectrum, long long skip_lo = 0, long long skip_hi = 0);
+    int fwd_slab_chunk(int chunk, int hilbert_spectrum, cplx **spectrum, long long skip_lo = 0, long long skip_hi = 0, const cplx *gtab = nullptr);
+    long long chunk_offset(int chunk) const { return soff[chunk]; }             // points in front of the subset's slab in a slab buffer
     int inv_slab_chunk(int chunk, cplx *slab_in);                                  // passes np..2 of one subset
     int e3_exchange(wfx_comm *c, int chunk, int slot);
     cplx *slab_chunk(int i, int chunk) { return slab_buffer(i) + soff[chunk]; }
@@ -166,3 +167,6 @@ int wfx_dist_resample_glue_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, con
 // c[slab entry] from the packed transform of its pairs, and the glue between the samples' forward and inverse transforms, in place
 int wfx_dist_real_untangle(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Zg, long long Mh, double *ctab);
 int wfx_dist_real_conv_glue(wfx_ctx *ctx, const wfx_dist_geom &g, cplx *Z, long long Mh, const double *ctab);
+// the same for one k1 subset of a rank (its own slab [.][km.B])
+int wfx_dist_real_untangle_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, const cplx *Zg, long long Mh, double *ctab);
+int wfx_dist_real_conv_glue_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, cplx *Z, long long Mh, const double *ctab);

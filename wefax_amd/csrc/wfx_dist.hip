@@ -635,7 +635,7 @@ int wfx_dist::fwd_pass1_exchange(wfx_comm *c, int in_mode)
     return 0;
 }
 
-int wfx_dist::fwd_slab_chunk(int chunk, int hilbert_spectrum, cplx **spectrum, long long skip_lo, long long skip_hi)
+int wfx_dist::fwd_slab_chunk(int chunk, int hilbert_spectrum, cplx **spectrum, long long skip_lo, long long skip_hi, const cplx *gtab)
 {
     const cplx *tb = (const cplx *)tables.p;
     cplx *src = (cplx *)b_a.p + soff[chunk], *dst = (cplx *)b_a2.p + soff[chunk];
@@ -647,7 +647,12 @@ int wfx_dist::fwd_slab_chunk(int chunk, int hilbert_spectrum, cplx **spectrum, l
             d.skip_hi = skip_hi;
         }
         const bool skipping = d.skip_hi != 0;
-        const int out_mode = (hilbert_spectrum && i == ns - 1) ? 1 : ((skipping && d.ra > 0) ? 3 : 0);
+        int out_mode = (hilbert_spectrum && i == ns - 1) ? 1 : ((skipping && d.ra > 0) ? 3 : 0);
+        if (gtab && i == ns - 1) {       // a zero-padded convolution: this subset's slab of the transformed kernel (indexed like the slab itself)
+            if (d.ra <= 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "distributed padded convolution needs radix-pair passes");
+            d.gtab = (const double2 *)gtab;
+            out_mode = 4;
+        }
         WFX_TRY(wfx_mr_launch(ctx, d, tb + tw_fwd[i], 0, out_mode, 0, src, dst));
         std::swap(src, dst);
     }
@@ -896,20 +901,28 @@ __global__ void __launch_bounds__(256) dist_real_conv_glue_kernel(cplx *__restri
     }
 }
 
+int wfx_dist_real_untangle_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, const cplx *Zg, long long Mh, double *ctab)
+{
+    const long long total = (Mh / R1) * km.B;
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, dist_real_untangle_kernel, dim3(wfx_stream_grid((uint64_t)total, 256)), dim3(256), Zg, Mh, R1, km, ctab);
+    return 0;
+}
+
+int wfx_dist_real_conv_glue_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, cplx *Z, long long Mh, const double *ctab)
+{
+    const long long total = (Mh / R1) * km.B;
+    WFX_LAUNCH(ctx, K_RESAMPLE_PW, dist_real_conv_glue_kernel, dim3(wfx_stream_grid((uint64_t)total, 256)), dim3(256), Z, Mh, R1, km, ctab);
+    return 0;
+}
+
 int wfx_dist_real_untangle(wfx_ctx *ctx, const wfx_dist_geom &g, const cplx *Zg, long long Mh, double *ctab)
 {
-    const wfx_dist_kmap &km = g.km[g.rank];
-    const long long total = (Mh / g.R1) * km.B;
-    WFX_LAUNCH(ctx, K_RESAMPLE_PW, dist_real_untangle_kernel, dim3(wfx_stream_grid((uint64_t)total, 256)), dim3(256), Zg, Mh, g.R1, km, ctab);
-    return 0;
+    return wfx_dist_real_untangle_km(ctx, g.R1, g.km[g.rank], Zg, Mh, ctab);
 }
 
 int wfx_dist_real_conv_glue(wfx_ctx *ctx, const wfx_dist_geom &g, cplx *Z, long long Mh, const double *ctab)
 {
-    const wfx_dist_kmap &km = g.km[g.rank];
-    const long long total = (Mh / g.R1) * km.B;
-    WFX_LAUNCH(ctx, K_RESAMPLE_PW, dist_real_conv_glue_kernel, dim3(wfx_stream_grid((uint64_t)total, 256)), dim3(256), Z, Mh, g.R1, km, ctab);
-    return 0;
+    return wfx_dist_real_conv_glue_km(ctx, g.R1, g.km[g.rank], Z, Mh, ctab);
 }
 
 int wfx_dist_resample_glue_km(wfx_ctx *ctx, int R1, const wfx_dist_kmap &km, const cplx *Z, long long n0, long long num, cplx *W)

@@ -910,9 +910,12 @@ int wfx_dev_env_median_block(wfx_ctx *ctx, const cplx *V_global, const double *x
 // global samples [g0 + s g_stride, + seg_len).  V rows (pairs; row s at V + s v_rs, the segment's first pair at index 0, valid
 // from -1 to seg_len / 2 + 1) and x rows (samples; row s at x + s x_rs, valid from -2 to seg_len + 1) carry the halos the
 // neighbouring ranks' columns delivered; zeros beyond the capture's true ends as in the reference.  env: dense [nseg][seg_len].
+// flat: the rows of V hold H itself, point q = (H[2q], H[2q + 1]) (odd lengths on packed real transforms), instead of the packed
+// (H[2q], H[2q - 1]).  Slots whose global index lies beyond the capture (a padded form's segments reach past its end) get the
+// median of zeros and stay out of the histogram.
 __global__ void __launch_bounds__(256) hconv_env_median_segs(const cplx *__restrict__ V, long long v_rs, const double *__restrict__ x, long long x_rs, int nseg,
                                                             int seg_len, long long g0, long long g_stride, long long N, double *__restrict__ env,
-                                                            unsigned *__restrict__ l0hist)
+                                                            unsigned *__restrict__ l0hist, int flat)
 {
     __shared__ double tile[1024 + 8];
     __shared__ unsigned h0[WFX_SEL_BINS];
@@ -934,9 +937,14 @@ __global__ void __launch_bounds__(256) hconv_env_median_segs(const cplx *__restr
             const int m = base / 2 - 1 + t + 256 * k;                       // pair (2m - 1, 2m), local
             const int mc = m > mhi ? mhi : m;                               // (m >= -1 always)
             const int i1 = 2 * m, i0 = 2 * m - 1;
-            pv[k] = Vs[mc];
-            px0[k] = xs[i0 < -2 ? -2 : (i0 > xhi ? xhi : i0)];
-            px1[k] = xs[i1 > xhi ? xhi : i1];
+            const int c0 = i0 < -2 ? -2 : (i0 > xhi ? xhi : i0), c1 = i1 > xhi ? xhi : i1;
+            if (flat) {
+                const double *Hs = (const double *)Vs;
+                pv[k] = make_double2(Hs[c1], Hs[c0]);
+            } else
+                pv[k] = Vs[mc];
+            px0[k] = xs[c0];
+            px1[k] = xs[c1];
         }
     };
     long long tix = blockIdx.x;
@@ -985,7 +993,7 @@ __global__ void __launch_bounds__(256) hconv_env_median_segs(const cplx *__restr
             if (l0hist) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    if (base + j + h >= seg_len) continue;
+                    if (base + j + h >= seg_len || gseg + base + j + h >= N) continue;
                     const unsigned dg = (unsigned)(wfx_f64_key(r[h]) >> 53);
                     if (dg == run_digit)
                         ++run_count;
@@ -1007,13 +1015,13 @@ __global__ void __launch_bounds__(256) hconv_env_median_segs(const cplx *__restr
 }
 
 int wfx_dev_env_median_segs(wfx_ctx *ctx, const cplx *V_rows, long long v_rs, const double *x_rows, long long x_rs, int nseg, int seg_len, long long g0,
-                            long long g_stride, uint64_t n_total, double *env, unsigned *l0hist)
+                            long long g_stride, uint64_t n_total, double *env, unsigned *l0hist, int flat)
 {
     if (nseg < 1 || seg_len < 2 || (seg_len & 1)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "envelope segments of %d samples", seg_len);
     const long long ntiles = (long long)nseg * ((seg_len + 1023) >> 10);
     const unsigned grid = (unsigned)std::min<long long>(ntiles, 1024);
     WFX_LAUNCH(ctx, K_ENV_MEDIAN, hconv_env_median_segs, dim3(grid), dim3(256), V_rows, v_rs, x_rows, x_rs, nseg, seg_len, g0, g_stride, (long long)n_total, env,
-               l0hist);
+               l0hist, flat);
     return 0;
 }
 

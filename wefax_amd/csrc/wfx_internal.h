@@ -247,7 +247,7 @@ int wfx_dev_env_median_block(wfx_ctx *ctx, const cplx *V_global, const double *x
                              unsigned *l0hist);
 // one rank's COLUMNS: nseg segments of seg_len samples; V_rows / x_rows point at the first OWN pair / sample of row 0 (halos on both sides)
 int wfx_dev_env_median_segs(wfx_ctx *ctx, const cplx *V_rows, long long v_rs, const double *x_rows, long long x_rs, int nseg, int seg_len, long long g0,
-                            long long g_stride, uint64_t n_total, double *env, unsigned *l0hist);
+                            long long g_stride, uint64_t n_total, double *env, unsigned *l0hist, int flat = 0);
 // x_is_i16: x points at int16 samples; valid only when wfx_mr_resample_supported(n0, num) (the mixed-radix form reads them in place)
 int wfx_dev_resample_fft(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *out, bool x_is_i16 = false);
 

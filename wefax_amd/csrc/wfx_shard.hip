@@ -31,6 +31,8 @@
 //   a8 as before; the gather delivers every rank's segments to rank 0, which puts them in order (one 2-D copy) -- a9, a10
 #define SH_HALO 32          // samples of audio kept beyond the own range on either side (>= 24 notch taps + 2 median)
 #define SH_VHALO 2          // points of the Hilbert transform delivered beyond the own rows
+#define SH_HALO_END 192     // columns layout of a PADDED form: the capture ends inside a segment, and filtfilt's exact edge there
+                            // is made of the last 127 samples -- the ranks whose own samples lie within 64 of the end must see it
 #define SH_CAND_CAP 4096    // least number of candidate keys per query and rank that travel in the all-gather
 
 struct shard_plan {
@@ -266,13 +268,16 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         pl.in_lo = pl.seg_lo;
         pl.in_hi = pl.seg_hi;
     }
-    // ---- columns layout: unpadded even captures (every BASELINE size); the any-length padded forms keep the rows layout ----
+    // ---- columns layout: unpadded even captures (every BASELINE size) and, since later in round 4, the any-length padded forms ----
     auto colrange = [&](long long M, int r, long long &c0, long long &w) {
         c0 = (long long)r * M / world / 4 * 4;
         const long long c1 = r + 1 == world ? M : (long long)(r + 1) * M / world / 4 * 4;
         w = c1 - c0;
     };
-    bool cols_ok = !want_rows && !pl.padded && !pl.plain;
+    // (padded forms -- arbitrary lengths at the native rate -- take it too when there is more than one rank; one rank keeps the rows
+    // form, whose first pass reads the capture in place)
+    const bool cols_padded = pl.padded && world > 1 && !pl.resample;
+    bool cols_ok = !want_rows && ((!pl.padded && !pl.plain) || cols_padded);
     for (int r = 0; r < world && cols_ok; ++r) {
         long long c0, w;
         colrange(pl.Ms, r, c0, w);
@@ -284,9 +289,13 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     }
     if (cols_ok) {
         pl.cols = true;
+        if (pl.padded) {      // every rank holds its columns of ALL rows of the padded arrangement (the rows behind the capture are zeros)
+            pl.split_kernel = false;
+            if (!wfx_dist_make_geom(pl.g, world, rank, ra1, rb1, 0)) return single("no geometry for this world size");
+        }
         colrange(pl.Ms, rank, pl.cH0, pl.wH);
         if (pl.resample) colrange(pl.M1s, rank, pl.cF0, pl.wF);
-        pl.hs = world > 1 ? SH_HALO : 0;
+        pl.hs = world > 1 ? (pl.padded ? SH_HALO_END : SH_HALO) : 0;
         pl.xrs = 2 * pl.wH + 2 * pl.hs;
         pl.nchunk = 1;       // (chosen below, once the rest of the plan is known)
         pl.own_lo = 2ull * (uint64_t)pl.cH0;
@@ -396,6 +405,21 @@ static uint64_t cols_in_frames(const shard_plan &pl)
     return pl.resample ? (uint64_t)pl.g.R1 * 2ull * (uint64_t)pl.wF : (uint64_t)pl.g.R1 * (uint64_t)pl.xrs;
 }
 
+// Padded forms: a rank's segments reach past the capture's end.  Its stage buffers hold the slots of all R1 segments in order, so
+// the slots that hold samples are a PREFIX: the segments in front of the row the capture ends in, and the part of that row's
+// segment below n.  (Unpadded: every slot.)
+static uint64_t cols_valid_of(const shard_plan &pl, int r)
+{
+    const long long c0 = (long long)r * pl.Ms / pl.world / 4 * 4, c1 = r + 1 == pl.world ? pl.Ms : (long long)(r + 1) * pl.Ms / pl.world / 4 * 4;
+    const long long w = c1 - c0;
+    if (!pl.padded) return (uint64_t)pl.g.R1 * 2ull * (uint64_t)w;
+    const long long qe = (pl.K - 1) / pl.Ms;                       // the row that holds the capture's last point
+    long long part = (long long)pl.n - 2 * (qe * pl.Ms + c0);
+    part = part < 0 ? 0 : (part > 2 * w ? 2 * w : part);
+    return (uint64_t)qe * 2ull * (uint64_t)w + (uint64_t)part;
+}
+static uint64_t cols_valid(const shard_plan &pl) { return cols_valid_of(pl, pl.rank); }
+
 static int shard_bind_cols(wfx_shard *sh)
 {
     wfx_ctx *ctx = sh->ctx;
@@ -407,7 +431,7 @@ static int shard_bind_cols(wfx_shard *sh)
     WFX_TRY(wfx_reserve(ctx, sh->b_v, (size_t)R1 * (size_t)(pl.wH + 2 * SH_VHALO) * sizeof(cplx) + 64));
     WFX_TRY(wfx_reserve(ctx, sh->b_env, n_own * 8 + 64));
     WFX_TRY(wfx_reserve(ctx, sh->b_dig, (me == 0 ? pl.n : n_own) + 64));
-    if (me == 0 && W > 1) WFX_TRY(wfx_reserve(ctx, sh->b_gath, pl.n + 64));
+    if (me == 0 && W > 1) WFX_TRY(wfx_reserve(ctx, sh->b_gath, std::max((size_t)pl.n, (size_t)n_own) + 64 + 2 * (size_t)W));      // (n_own: wfx_shard_fetch reads all slots)
     WFX_TRY(wfx_reserve(ctx, sh->b_blk, wfx_select_block_bytes(sh->cap)));
     WFX_TRY(wfx_reserve(ctx, sh->b_blks, wfx_select_block_bytes(sh->cap) * W));
     WFX_TRY(wfx_reserve(ctx, sh->b_nan, 8 * (size_t)W + 64));
@@ -429,25 +453,49 @@ static int shard_bind_cols(wfx_shard *sh)
     } else if (pl.in_kind == WFX_IN_I16_STEREO) {
         WFX_TRY(wfx_reserve(ctx, sh->b_merged, flat * 8 + 64));
     }
-    WFX_TRY(sh->dH.bind_cols(audio_row0, pl.xrs / 2, (cplx *)sh->b_v.p, pl.wH + 2 * SH_VHALO, sh->dH.fwd_result_index()));
+    if (pl.padded) WFX_TRY(wfx_reserve(ctx, sh->b_ghat, (size_t)sh->dH.slab_points() * sizeof(cplx) + 64));
+    // (until the kernel's transform exists the Hilbert transform's forward half reads the kernel's columns, which are written into
+    // the V rows -- free until the first inverse pass; run_phase_cols re-binds it to the audio afterwards)
+    if (pl.padded && !sh->ghat_ready)
+        WFX_TRY(sh->dH.bind_cols((cplx *)sh->b_v.p + SH_VHALO, pl.wH + 2 * SH_VHALO, (cplx *)sh->b_v.p, pl.wH + 2 * SH_VHALO, sh->dH.fwd_result_index()));
+    else
+        WFX_TRY(sh->dH.bind_cols(audio_row0, pl.xrs / 2, (cplx *)sh->b_v.p, pl.wH + 2 * SH_VHALO, sh->dH.fwd_result_index()));
     // rank 0: the gathered segments of every rank -> the stream in order (2-byte elements: every offset is even)
     sh->n_pieces = 0;
     if (me == 0 && W > 1) {
         std::vector<wfx_dist_piece> ps;
         unsigned long long off = 0;
         sh->piece_max = 0;
+        const long long qe = pl.padded ? (pl.K - 1) / pl.Ms : (long long)R1;      // rows in front of it are whole
         for (int r = 0; r < W; ++r) {
             const long long c0 = (long long)r * pl.Ms / W / 4 * 4, c1 = r + 1 == W ? pl.Ms : (long long)(r + 1) * pl.Ms / W / 4 * 4;
+            const uint64_t nv = cols_valid_of(pl, r);
             wfx_dist_piece q{};
             q.src = (unsigned long long)((uint8_t *)sh->b_gath.p + off);
             q.dst = (unsigned long long)((uint8_t *)sh->b_dig.p + 2 * c0);
-            q.rows = R1;
+            q.rows = (int)(pl.padded ? qe : R1);
             q.cols = (int)(c1 - c0);                // 2-byte elements: one per packed point
             q.src_rs = c1 - c0;
             q.dst_rs = pl.Ms;
-            ps.push_back(q);
-            sh->piece_max = std::max(sh->piece_max, (long long)q.rows * q.cols);
-            off += (unsigned long long)R1 * 2ull * (unsigned long long)(c1 - c0);
+            if (q.rows > 0) {
+                ps.push_back(q);
+                sh->piece_max = std::max(sh->piece_max, (long long)q.rows * q.cols);
+            }
+            if (pl.padded) {      // the row the capture ends in: the part of the rank's segment below n (an odd count: one byte more, into the slack)
+                const uint64_t part = nv - (uint64_t)qe * 2ull * (uint64_t)(c1 - c0);
+                if (part) {
+                    wfx_dist_piece e{};
+                    e.src = q.src + (unsigned long long)qe * 2ull * (unsigned long long)(c1 - c0);
+                    e.dst = (unsigned long long)((uint8_t *)sh->b_dig.p + 2 * (qe * pl.Ms + c0));
+                    e.rows = 1;
+                    e.cols = (int)((part + 1) / 2);
+                    e.src_rs = e.cols;
+                    e.dst_rs = e.cols;
+                    ps.push_back(e);
+                    sh->piece_max = std::max(sh->piece_max, (long long)e.cols);
+                }
+            }
+            off += (nv + 1) & ~(uint64_t)1;          // (2-byte copies: every rank's bytes start on an even offset)
         }
         WFX_TRY(wfx_reserve(ctx, sh->b_pieces, ps.size() * sizeof(wfx_dist_piece) + 64));
         WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -520,7 +568,9 @@ static int shard_bind(wfx_shard *sh)
 static int phase_count(const wfx_shard *sh)
 {
     if (sh->pl.single) return 1;
-    if (sh->pl.cols) return sh->pl.resample ? 4 * sh->pl.nchunk + 7 : 2 * sh->pl.nchunk + 6;
+    if (sh->pl.cols)      // padded: + 1 (V[K] := V[0], even lengths) and, in front of the first decode, + 2 C (the kernel's transform)
+        return (sh->pl.resample ? 4 * sh->pl.nchunk + 7 : 2 * sh->pl.nchunk + 6) + (sh->pl.padded && !sh->pl.plain ? 1 : 0) +
+               (sh->pl.padded && !sh->ghat_ready ? 2 * sh->pl.nchunk : 0);
     return sh->pl.resample ? 13 : (sh->pl.padded ? (sh->ghat_ready ? 10 : 13) : 9);
 }
 
@@ -545,6 +595,43 @@ static int run_phase_cols(wfx_shard *sh, int ph)
     //   [2 C]          wait every E3; last pass; halo exchange
     // the resampler's pair first (when there is one), then the Hilbert transform's, then the five phases of the tail.
     const int C = pl.nchunk, TP = 2 * C + 1;
+    const uint64_t n_valid = cols_valid(pl);                               // slots of the stage buffers that hold samples (a prefix)
+    const long long vrs = pl.wH + 2 * SH_VHALO;
+    if (pl.padded && !sh->ghat_ready) {
+        // ---- the padded convolution's kernel, transformed once per shard, in columns: this rank's columns of the kernel's rows
+        // (written into the V rows) -> first pass -> E2 subset by subset -> slab passes -> the table, subset by subset ----
+        if (ph < 2 * C) {
+            if (ph == 0) {
+                cplx *vrow0 = (cplx *)sh->b_v.p + SH_VHALO;
+                for (int q = 0; q < R1; ++q) {
+                    const long long p0 = (long long)q * pl.Ms + pl.cH0;
+                    if (pl.plain)
+                        WFX_TRY(wfx_dev_hilbert_kernel_rows_real(ctx, vrow0 + (long long)q * vrs, p0, pl.wH, (long long)pl.n, pl.Kp));
+                    else
+                        WFX_TRY(wfx_dev_hilbert_kernel_rows(ctx, vrow0 + (long long)q * vrs, p0, pl.wH, (long long)pl.n, pl.Kp));
+                }
+                WFX_TRY(sh->dH.fwd_pass1(0));
+                return sh->dH.e2_exchange(c, 0, 0);
+            }
+            if (ph < C) return sh->dH.e2_exchange(c, ph, ph);
+            const int k = ph - C;
+            WFX_TRY(wfx_comm_wait(c, ctx, k));
+            cplx *G = nullptr;
+            WFX_TRY(sh->dH.fwd_slab_chunk(k, 0, &G));
+            const long long off = sh->dH.chunk_offset(k), cnt = sh->dH.chunk_offset(k + 1) - off;
+            if (pl.plain)      // the real kernel's table: one double per slab entry, untangled from its packed transform
+                WFX_TRY(wfx_dist_real_untangle_km(ctx, R1, sh->dH.chunk_kmap(k), G, pl.Kp, (double *)sh->b_ghat.p + off));
+            else
+                WFX_HIP(ctx, hipMemcpyAsync((cplx *)sh->b_ghat.p + off, G, (size_t)cnt * sizeof(cplx), hipMemcpyDeviceToDevice, ctx->stream));
+            if (k == C - 1) {
+                // from here on the forward half reads the audio rows (re-binding rebuilds the lists: a host synchronisation, once)
+                WFX_TRY(sh->dH.bind_cols(audio + pl.hs, pl.xrs / 2, (cplx *)sh->b_v.p, vrs, sh->dH.fwd_result_index()));
+                sh->ghat_pending = true;
+            }
+            return 0;
+        }
+        ph -= 2 * C;
+    }
     if (!pl.resample) ph += TP;
     if (ph < TP) {
         // ---- a4 + a5: distributed rfft -> scipy.signal.resample's bin copy -> distributed irfft, in columns ----
@@ -588,8 +675,24 @@ static int run_phase_cols(wfx_shard *sh, int ph)
             }
             // rank 0's first row starts at the capture's true start, the last rank's last row ends at its true end: filtfilt's exact
             // edges there; everywhere else the 49-tap form, whose outputs within 24 samples of a row's end are never read
-            const uint64_t lo = me == 0 ? (uint64_t)pl.hs : 0, hi = flat - (me == W - 1 ? (uint64_t)pl.hs : 0);
-            const int flags = (me == 0 ? 1 : 0) | (me == W - 1 ? 2 : 0);
+            uint64_t lo = me == 0 ? (uint64_t)pl.hs : 0, hi = flat - (me == W - 1 ? (uint64_t)pl.hs : 0);
+            int flags = (me == 0 ? 1 : 0) | (me == W - 1 ? 2 : 0);
+            if (pl.padded) {
+                // The capture ends inside row qe of the arrangement: at position e of this rank's segment of that row (left halo
+                // included), if it sees it.  The filter runs up to there -- with filtfilt's exact edge when the end lies at or
+                // behind the rank's own columns (its 127-sample history is then inside the segment: hs = 192) -- and not at all
+                // behind it: what follows in the audio rows is the convolution's zero padding, cleared when they were bound.
+                const long long qe = (pl.K - 1) / pl.Ms;
+                const long long e = (long long)pl.n - (2 * (qe * pl.Ms + pl.cH0) - pl.hs);
+                flags &= 1;
+                if (e < pl.hs)
+                    hi = (uint64_t)qe * (uint64_t)pl.xrs;                 // nothing of row qe is this rank's
+                else if (e <= pl.xrs) {
+                    hi = (uint64_t)qe * (uint64_t)pl.xrs + (uint64_t)e;
+                    flags |= 2;
+                } else
+                    hi = (uint64_t)(qe + 1) * (uint64_t)pl.xrs;
+            }
             double ext18[18];
             const bool use_ext = p.has_ext && !pl.resample && pl.in_kind != WFX_IN_I16_STEREO;
             for (int i = 0; i < 9; ++i) {
@@ -597,7 +700,7 @@ static int run_phase_cols(wfx_shard *sh, int ph)
                 ext18[9 + i] = p.ext_right[i];
             }
             const void *nin_lo = nkind == WFX_IN_I16_MONO ? (const void *)((const int16_t *)nin + lo) : (const void *)((const double *)nin + lo);
-            WFX_TRY(wfx_dev_notch_fir_only(ctx, nin_lo, nkind, hi - lo, p.notch_b, p.notch_a, audio + lo, flags, use_ext ? ext18 : nullptr));
+            if (hi > lo) WFX_TRY(wfx_dev_notch_fir_only(ctx, nin_lo, nkind, hi - lo, p.notch_b, p.notch_a, audio + lo, flags, use_ext ? ext18 : nullptr));
             WFX_TRY(sh->dH.fwd_pass1(1));
             return sh->dH.e2_exchange(c, 0, 2 * C);
         }
@@ -606,49 +709,87 @@ static int run_phase_cols(wfx_shard *sh, int ph)
             const int k = ph - C;
             WFX_TRY(wfx_comm_wait(c, ctx, 2 * C + k));
             cplx *G = nullptr;
-            WFX_TRY(sh->dH.fwd_slab_chunk(k, 1, &G));
+            const long long goff = sh->dH.chunk_offset(k);
+            if (pl.plain) {       // odd length: real samples, real kernel -- the glue between the packed forward and inverse transforms
+                WFX_TRY(sh->dH.fwd_slab_chunk(k, 0, &G));
+                WFX_TRY(wfx_dist_real_conv_glue_km(ctx, R1, sh->dH.chunk_kmap(k), G, pl.Kp, (const double *)sh->b_ghat.p + goff));
+            } else if (pl.padded)
+                WFX_TRY(sh->dH.fwd_slab_chunk(k, 0, &G, 0, 0, (const cplx *)sh->b_ghat.p + goff));
+            else
+                WFX_TRY(sh->dH.fwd_slab_chunk(k, 1, &G));
             WFX_TRY(sh->dH.inv_slab_chunk(k, G));
             return sh->dH.e3_exchange(c, k, 3 * C + k);
         }
         for (int k = 0; k < C; ++k) WFX_TRY(wfx_comm_wait(c, ctx, 3 * C + k));
         return sh->dH.inv_pass1_halo_exchange(c);
     }
-    ph = ph - TP + 6;
+    ph -= TP;
+    const bool wrap = pl.padded && !pl.plain;
+    if (wrap) {
+        if (ph == 0) {
+            // even padded form: the cyclic result's V[K] is V[0] (H[n - 1] sits in its .y) -- it lives in rank 0's first column, the
+            // rank that holds the capture's last point needs it in the slot behind that point (its next column, or its right halo)
+            WFX_TRY(sh->dH.inv_halo_unpack());
+            const long long q1 = (pl.K - 1) / pl.Ms, c1 = (pl.K - 1) - q1 * pl.Ms;
+            int rk = 0;
+            long long ck0 = 0;
+            for (int r = 0; r < W; ++r) {
+                const long long a0 = (long long)r * pl.Ms / W / 4 * 4, a1 = r + 1 == W ? pl.Ms : (long long)(r + 1) * pl.Ms / W / 4 * 4;
+                if (c1 >= a0 && c1 < a1) {
+                    rk = r;
+                    ck0 = a0;
+                }
+            }
+            wfx_xfer x{};
+            x.peer = me == 0 ? rk : 0;
+            if (me == 0) {
+                x.send = (cplx *)sh->b_v.p + SH_VHALO;
+                x.send_bytes = sizeof(cplx);
+            }
+            if (me == rk) {
+                x.recv = (cplx *)sh->b_v.p + q1 * vrs + SH_VHALO + (c1 - ck0) + 1;
+                x.recv_bytes = sizeof(cplx);
+            }
+            wfx_comm_label(c, "hilbert wrap");
+            return (x.send_bytes || x.recv_bytes) ? wfx_comm_exchange(c, ctx, &x, 1) : wfx_comm_exchange(c, ctx, &x, 0);
+        }
+        ph -= 1;
+    }
+    ph += 6;
     switch (ph) {
     case 6: {   // a7 envelope + median per segment, level-0 histogram; first all-reduce
-        WFX_TRY(sh->dH.inv_halo_unpack());
+        if (!wrap) WFX_TRY(sh->dH.inv_halo_unpack());                          // (even padded form: done with the wrap, one phase earlier)
         WFX_TRY(wfx_dev_select_sharded_ws(ctx, &sh->ws));
         WFX_TRY(wfx_dev_env_median_segs(ctx, (const cplx *)sh->b_v.p + SH_VHALO, pl.wH + 2 * SH_VHALO, audio + pl.hs, pl.xrs, R1, (int)(2 * pl.wH),
-                                        2 * pl.cH0, 2 * pl.Ms, pl.n, env, sh->ws));
+                                        2 * pl.cH0, 2 * pl.Ms, pl.n, env, sh->ws, pl.plain ? 1 : 0));
         wfx_comm_label(c, "select level 0");
         return wfx_comm_allreduce_u32(c, ctx, sh->ws, WFX_SEL_BINS);
     }
     case 7: {
         const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
-        WFX_TRY(wfx_dev_select_l1(ctx, env, n_own, ranks, sh->ws, ds));
+        WFX_TRY(wfx_dev_select_l1(ctx, env, n_valid, ranks, sh->ws, ds));
         wfx_comm_label(c, "select level 1");
         return wfx_comm_allreduce_u32(c, ctx, sh->ws + WFX_SEL_H1_OFFSET, WFX_SEL_H1_WORDS);
     }
     case 8: {
-        WFX_TRY(wfx_dev_select_compact_block(ctx, env, n_own, sh->ws, ds, sh->b_blk.p, sh->cap));
+        WFX_TRY(wfx_dev_select_compact_block(ctx, env, n_valid, sh->ws, ds, sh->b_blk.p, sh->cap));
         wfx_comm_label(c, "select candidates");
         return wfx_comm_allgather(c, ctx, sh->b_blk.p, sh->b_blks.p, wfx_select_block_bytes(sh->cap));
     }
     case 9: {   // a8 finish + quantise; the one gather of the stream (every rank's segments, back to back)
         WFX_TRY(wfx_dev_select_finish_blocks(ctx, sh->ws, ds, sh->b_blks.p, W, sh->cap, p.gamma_lo, p.gamma_hi, (unsigned *)sh->b_flags.p));
-        WFX_TRY(wfx_dev_quantise(ctx, env, n_own, ds, dig_own, ds));
+        if (n_valid) WFX_TRY(wfx_dev_quantise(ctx, env, n_valid, ds, dig_own, ds));
         std::vector<wfx_xfer> xs;
         if (me == 0) {
-            uint64_t off = n_own;
+            uint64_t off = (n_valid + 1) & ~(uint64_t)1;                      // (as shard_bind_cols lays the pieces out)
             for (int s = 1; s < W; ++s) {
-                const long long c0 = (long long)s * pl.Ms / W / 4 * 4, c1 = s + 1 == W ? pl.Ms : (long long)(s + 1) * pl.Ms / W / 4 * 4;
-                const uint64_t nb = (uint64_t)R1 * 2ull * (uint64_t)(c1 - c0);
+                const uint64_t nb = cols_valid_of(pl, s);
                 xs.push_back(wfx_xfer{s, nullptr, 0, (uint8_t *)sh->b_gath.p + off, (size_t)nb});
                 xs.push_back(wfx_xfer{s, nullptr, 0, (unsigned long long *)sh->b_nan.p + s, 8});
-                off += nb;
+                off += (nb + 1) & ~(uint64_t)1;
             }
         } else {
-            xs.push_back(wfx_xfer{0, dig_own, (size_t)n_own, nullptr, 0});
+            xs.push_back(wfx_xfer{0, dig_own, (size_t)n_valid, nullptr, 0});
             xs.push_back(wfx_xfer{0, &ds->nan_count, 8, nullptr, 0});
         }
         wfx_comm_label(c, "stream gather");
@@ -1047,7 +1188,8 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
         }
     }
     if (pl.cols) {
-        if (next != 2ull * (uint64_t)pl.Ms || (pl.resample && next_in != 2ull * (uint64_t)pl.M1s) || (uint64_t)pl.g.R1 * 2ull * (uint64_t)pl.Ms != p->n)
+        if (next != 2ull * (uint64_t)pl.Ms || (pl.resample && next_in != 2ull * (uint64_t)pl.M1s) ||
+            (pl.padded ? (uint64_t)pl.g.R1 * 2ull * (uint64_t)pl.Ms < p->n : (uint64_t)pl.g.R1 * 2ull * (uint64_t)pl.Ms != p->n))
             return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: the ranks' columns do not cover the rows");
     } else if (next != p->n || (pl.resample && next_in != p->n0))
         return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: the ranks' ranges do not cover the capture");
@@ -1057,7 +1199,7 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
             WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward (columns)", 0, true));
             WFX_TRY(dry_check_transform(pl, p, pl.K, 16, pl.hs / 2, pl.hs / 2, false, true, "resample inverse (columns)", 0, true));
         }
-        return dry_check_transform(pl, p, pl.K, 16, SH_VHALO, SH_VHALO, true, true, "hilbert (columns)", 0, true);
+        return dry_check_transform(pl, p, pl.Kp, 16, SH_VHALO, SH_VHALO, true, true, "hilbert (columns)", 0, true);
     }
     if (pl.resample) {
         WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward"));

@@ -221,11 +221,17 @@ def gather_frames(lay, data=None, loader=None, n0: int | None = None) -> np.ndar
     parts = []
     for sgm in range(int(lay.nseg)):
         a, b = lo + sgm * st - h, lo + sgm * st + ln + h
-        ca, cb = max(a, 0), min(b, n0)
-        part = np.asarray(data[ca:cb] if data is not None else loader(ca, cb))
-        if ca > a or cb < b:
-            pad = [(ca - a, b - cb)] + [(0, 0)] * (part.ndim - 1)
-            part = np.pad(part, pad)
+        ca, cb = max(a, 0), min(b, n0)                          # (a padded form's last segments lie beyond the capture: all zeros)
+        if cb > ca:
+            src = np.asarray(data[ca:cb] if data is not None else loader(ca, cb))
+            if ca == a and cb == b:
+                parts.append(src)
+                continue
+            part = np.zeros((b - a,) + src.shape[1:], dtype=src.dtype)
+            part[ca - a:cb - a] = src
+        else:
+            ref = np.asarray(data[:1] if data is not None else loader(0, 1))
+            part = np.zeros((b - a,) + ref.shape[1:], dtype=ref.dtype)
         parts.append(part)
     return np.concatenate(parts)
 
@@ -235,7 +241,12 @@ def assemble(layouts, blocks, n: int, dtype=None) -> np.ndarray:
     out = np.zeros(int(n), dtype=dtype if dtype is not None else np.asarray(blocks[0]).dtype)
     for lay, blk in zip(layouts, blocks):
         if lay.own_samples:
-            out[lay.own_index()] = blk
+            idx = lay.own_index()
+            if idx.size and idx[-1] >= out.shape[0]:        # a padded form's segments reach past the capture's end: those slots hold nothing
+                keep = idx < out.shape[0]
+                out[idx[keep]] = np.asarray(blk)[keep]
+            else:
+                out[idx] = blk
     return out
 
 
