@@ -357,7 +357,9 @@ typedef struct {
      * provides the input frames [in_lo + s * in_seg_stride - in_halo, in_lo + s * in_seg_stride + in_seg_len + in_halo) of
      * every segment, back to back: nseg * (in_seg_len + 2 in_halo) frames (frames outside the capture: anything).  The stage
      * buffers wfx_shard_fetch returns are the segments back to back.  nseg == 1: one range, as in_lo / in_hi / own_lo /
-     * own_hi say (rows layout, single plan, one rank). */
+     * own_hi say (rows layout, single plan, one rank).  A capture of arbitrary length at 11 025 Hz (padded forms) is laid out on
+     * a longer arrangement: its last segments reach past the capture's end -- provide zeros (anything) there, and ignore the slots
+     * of the stage buffers whose sample index is >= n; in_halo is 192 for those (32 otherwise). */
     int      nseg, in_halo;
     uint64_t in_seg_len, in_seg_stride, own_seg_len, own_seg_stride;
     int      plan;             /* 0 single (rank 0 alone), 1 rows layout, 2 columns layout                              */
