@@ -555,6 +555,34 @@ def test_sharded_decode_of_any_length_equals_the_oracle(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,n", [(2, 600570), (2, 600599), (2, 601420), (2, 601421), (2, 633824), (2, 633877),
+                                     (3, 602946), (3, 602975), (3, 602976), (3, 602977), (3, 602986), (3, 603039),
+                                     (4, 601420), (4, 602394), (4, 602447), (8, 600599), (8, 601421), (8, 602394)])
+def test_capture_that_ends_at_a_segment_boundary(world, n):
+    """Padded forms in the columns layout: the capture ends INSIDE the padded arrangement.  These lengths put the end exactly at a
+    rank's first column of a row, one sample before or behind it, 10 / 30 / 63 samples to either side -- where filtfilt's exact
+    edge (the last 64 outputs, made of the last 127 samples) straddles two ranks' columns and each of them has to compute its part
+    from its own segment and halo.  Found by `nat.shard_layout` for these world sizes; the test checks that they still are."""
+    p, _ = build_params(0, n, 11025, 0.5, shard_plan=sharded.plan_code("dist"))
+    lays = [nat.shard_layout(p, world, r) for r in range(world)]
+    assert lays[0].plan == 2 and lays[0].nseg > 1 and lays[0].in_halo == 192
+    stride = int(lays[0].own_seg_stride)
+    d = min(min((n - int(lay.own_lo)) % stride, (int(lay.own_lo) - n) % stride) for lay in lays[1:])
+    assert d <= 63
+    lines = max(20, int(n / 5512.5) - 40)
+    x = synth.synth_capture(11025.0, noise=0.05, seed=n % 1000, start_tone_s=2.0, phasing_lines=20, image_lines=lines, stop_tone_s=1.0, black_tail_s=1.0)
+    x = np.concatenate([x, x[:max(0, n - x.shape[0])]])[:n]
+    ref = _oracle(x, 11025, 120)
+    r = sharded.decode_emulated(x, 11025, world, 120, repeat=2)
+    assert np.array_equal(r["digitalized"], ref["digitalized"]), "uint8 stream differs"
+    assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
+    scale = np.max(np.abs(ref["audio"]))
+    assert np.max(np.abs(r["audio"] - ref["audio"])) <= 1e-9 * scale                    # the notch's output up to the very last sample
+    if ref.get("exception") is None:
+        assert r["sync"]["start_frame"] == ref["start_frame"] and np.array_equal(r["image"], ref["image"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fs,n0,stereo", [(48000, 1440001, False), (48000, 1200002 + 2 * 7919, True), (22050, 749700, False), (44100, 792000, False),
                                           (11025, 6000, False)])
 def test_captures_on_the_single_plan_decode_like_the_one_gpu_path(fs, n0, stereo):
