@@ -555,6 +555,29 @@ def test_sharded_decode_of_any_length_equals_the_oracle(n):
 
 
 @pytest.mark.gpu
+def test_sixty_minute_native_rate_capture_of_arbitrary_length_on_eight_ranks():
+    """Full size: 60 minutes at 11 025 Hz plus one sample (odd: packed real transforms, 39.7 M-point padded arrangement) and plus two
+    (even, non-smooth half) in the columns layout on 4 and 8 emulated ranks -- stream, start frame and image of the one-GPU decode."""
+    from wefax_amd.wefax import DecodeJob
+    x0 = synth.synth_capture(11025.0, noise=0.05, seed=3, image_lines=7110, black_tail_s=5.0)
+    assert x0.shape[0] == 39690000
+    for n in (39690001, 39690002):
+        x = np.concatenate([x0, x0[:2]])[:n]
+        ctx = nat.Context(0)
+        job = DecodeJob(ctx, x, 11025, 120)
+        job.run()
+        info = job.result()
+        stream, img = job.fetch("digitalized").copy(), job.fetch("image").copy()
+        del job
+        ctx.close()
+        for world in (4, 8):
+            r = sharded.decode_emulated(x, 11025, world, 120, want=("image", "stream"))
+            assert r["plan"] == 2
+            assert np.array_equal(r["digitalized"], stream) and np.array_equal(r["image"], img)
+            assert r["sync"]["start_frame"] == info.start_frame
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,n", [(2, 600570), (2, 600599), (2, 601420), (2, 601421), (2, 633824), (2, 633877),
                                      (3, 602946), (3, 602975), (3, 602976), (3, 602977), (3, 602986), (3, 603039),
                                      (4, 601420), (4, 602394), (4, 602447), (8, 600599), (8, 601421), (8, 602394)])
