@@ -240,6 +240,105 @@ class Ranks:
         self.ctx.close()
 
 
+# ---- what the box was doing: clocks, power, temperature from sysfs ------------------------------------------------
+class GpuState:
+    """Reads the amdgpu sysfs nodes of the first GPU (shader / memory / fabric clock, socket power, temperatures) -- at a
+    point in time (``read``) or sampled by a thread while a timed region runs (``with GpuState.sample() as s``): a reader of the
+    line can then tell a slow box from a slow kernel.  Everything is optional: a node that is missing or unreadable is left out."""
+    _dev = None
+
+    @classmethod
+    def dev(cls):
+        if cls._dev is None:
+            import glob
+            cls._dev = ""
+            for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+                try:
+                    if open(os.path.join(d, "vendor")).read().strip() == "0x1002" and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                        cls._dev = d
+                        break
+                except OSError:
+                    pass
+        return cls._dev
+
+    @staticmethod
+    def _cur_mhz(path):
+        try:
+            for ln in open(path).read().splitlines():
+                if ln.rstrip().endswith("*"):
+                    return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    @classmethod
+    def read(cls) -> dict:
+        import glob
+        d = cls.dev()
+        out = {}
+        if not d:
+            return out
+        for key, node in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
+            v = cls._cur_mhz(os.path.join(d, node))
+            if v is not None:
+                out[key] = v
+        for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+            for key, node, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6), ("temp_c", "temp1_input", 1e-3),
+                                     ("temp_mem_c", "temp3_input", 1e-3), ("power_cap_w", "power1_cap", 1e-6)):
+                if key in out:
+                    continue
+                try:
+                    out[key] = round(int(open(os.path.join(hw, node)).read().strip()) * scale, 1)
+                except (OSError, ValueError):
+                    pass
+        try:
+            out["busy_pct"] = int(open(os.path.join(d, "gpu_busy_percent")).read().strip())
+        except (OSError, ValueError):
+            pass
+        return out
+
+    class _Sampler:
+        def __init__(self, period):
+            import threading
+            self.period, self.rows, self._stop = period, [], threading.Event()
+            self._thr = threading.Thread(target=self._run, daemon=True)
+
+        def _run(self):
+            while not self._stop.is_set():
+                r = GpuState.read()
+                if r:
+                    self.rows.append(r)
+                self._stop.wait(self.period)
+
+        def __enter__(self):
+            self._thr.start()
+            return self
+
+        def __exit__(self, *exc):
+            self._stop.set()
+            self._thr.join(timeout=2.0)
+
+        def summary(self) -> dict:
+            out = {"samples": len(self.rows)}
+            for key in ("sclk_mhz", "mclk_mhz", "fclk_mhz", "power_w", "temp_c", "temp_mem_c"):
+                vals = sorted(r[key] for r in self.rows if key in r)
+                if vals:
+                    out[key] = {"min": vals[0], "median": vals[len(vals) // 2], "max": vals[-1]}
+            return out
+
+    @classmethod
+    def sample(cls, period: float = 0.02):
+        return cls._Sampler(period)
+
+
+def dist_of(vals) -> dict:
+    """min / median / p90 / max of a list of per-step figures (a mean of 10 hides a 30 % spread)."""
+    v = sorted(float(x) for x in vals)
+    if not v:
+        return {}
+    return {"n": len(v), "min": round(v[0], 3), "median": round(v[len(v) // 2], 3), "p90": round(v[min(len(v) - 1, int(0.9 * len(v)))], 3), "max": round(v[-1], 3)}
+
+
 def kernel_table(prof: dict, steps: int) -> dict:
     return {k: {"launches_per_step": round(v[0] / steps, 2), "avg_us": round(1e3 * v[1] / v[0], 2), "us_per_step": round(1e3 * v[1] / steps, 1)}
             for k, v in prof.items()}
@@ -366,8 +465,24 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
         own_in, own_out = dec.raw_frames, dec.layout.own_samples
     ctx.sync()
     t_syn = time.perf_counter() - t_syn
+    state_before = GpuState.read()
     dt = rk.timed(dec.run, steps, max(warmup, 1))
     ms = 1e3 * dt / steps
+    # step by step (after the timed region, same buffers): wall time of every decode and the HIP-event time of its ingest launch, with
+    # the clocks / power / temperature sampled meanwhile -- a slow box shows in the clocks, a slow kernel in the distribution
+    step_ms, ingest_us = [], []
+    with GpuState.sample() as smp:
+        for _ in range(max(steps, 10)):
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            t0 = time.perf_counter()
+            dec.run()
+            ctx.sync()
+            step_ms.append(1e3 * (time.perf_counter() - t0))
+            ctx.profile_enable(False)
+            pr = ctx.profile()
+            if "polyphase_ingest" in pr:
+                ingest_us.append(1e3 * pr["polyphase_ingest"][1])
     prof = profile_pass(ctx, dec.run, 1)
     info = dec.result()
     alg_bytes = own_in * 4 + 4 * own_out                     # N0 * B_in + 4 N, this rank's share
@@ -384,7 +499,13 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
            "ms_per_step": round(ms, 4), "value": round(n0 / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "steps": steps,
            "synthesis_s": round(t_syn, 2), "dtype": "i16 integer-exact ingest / f64 everywhere behind it",
            "start_frame": int(info.start_frame) if rk.rank == 0 else None, "image": [int(info.width), 4 * int(info.height)] if rk.rank == 0 else None,
-           "roofline": roofline_of(prof, 1, alg_bytes, ms, pmc, merge_fft=True), "kernels": kernel_table(prof, 1)}
+           "roofline": roofline_of(prof, 1, alg_bytes, ms, pmc, merge_fft=True), "kernels": kernel_table(prof, 1),
+           "per_step": {"decode_ms_profiled": dist_of(step_ms), "ingest_us": dist_of(ingest_us),
+                        "note": "one decode at a time, device synchronised after each, HIP-event pairs on (adds ~0.1 ms per decode): the spread, not the level"},
+           "gpu_state": {"before": state_before, "during_steps": smp.summary(), "after": GpuState.read(),
+                         "source": "amdgpu sysfs (pp_dpm_*clk, hwmon), sampled every 20 ms while the per-step pass ran"}}
+    if getattr(getattr(dec, "fe", None), "fused_ingest", False):
+        out["front_end"] += " [stages 1+2 in one streaming kernel, csrc/wfx_ingest.hip]"
     if not fused:
         out["wire"] = wire_object(rk, dec.dec.params, dec.layout, dec.run, ctx.sync)
     dec.close()
@@ -747,7 +868,8 @@ def main():
                     "dtype": c4["dtype"], "data": "synthetic", "config": {k: c4[k] for k in ("workload", "form", "front_end", "ranks_rccl", "start_frame", "image")},
                     "roofline": c4["roofline"], "cpu_baseline": c4.get("cpu_baseline"), "kernels": c4["kernels"],
                     "one_gpu_ms": c4.get("one_gpu_ms"), "speedup_vs_one_gpu": c4.get("speedup_vs_one_gpu"),
-                    "efficiency_vs_one_gpu": c4.get("efficiency_vs_one_gpu"), "transport": c4.get("transport"), "wire": c4.get("wire")}
+                    "efficiency_vs_one_gpu": c4.get("efficiency_vs_one_gpu"), "transport": c4.get("transport"), "wire": c4.get("wire"),
+                    "per_step": c4.get("per_step"), "gpu_state": c4.get("gpu_state")}
         elif args.workload == "c3":
             line = bench_c3(args, rk)
         else:

@@ -296,6 +296,15 @@ int wfx_d_decimate_fir64(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n
  * reads in_dev + b * in_stride frames (b * in_stride * frame bytes must be a multiple of 16) and writes out_dev + b * out_stride */
 int wfx_d_decimate_fir64_batch(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int64_t first, int factor, const double *coef,
                                int ntaps, double *out_dev, size_t n_out, int fix_shift, int *exact, int nbatch, size_t in_stride, size_t out_stride);
+/* The first TWO stages of such a chain in one kernel that reads the capture once and keeps the intermediate rate on chip (the
+ * 1.536 MS/s ingest: / 32 integer-exact, / 3 float64 behind it):
+ *   y1[i] = sum_j round(coef1[j] 2^s) * in[factor i + j] / 2^s,   out[k] = sum_j coef2[j] * y1[factor2 k + j]   (factor2 = 0: out = y1)
+ * with `in` 16-byte aligned, frames beyond n_in reading as zero, and results BIT-IDENTICAL to the two wfx_d_decimate_fir64 calls
+ * it replaces.  *handled = 0 and nothing enqueued for shapes it is not built for (factor != 32, factor2 not in {0, 2, 3}, more than
+ * 256 / 120 taps, a misaligned pointer, taps the grid does not hold): the caller then makes those two calls.  Batches as above. */
+int wfx_d_ingest_chain(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int factor, const double *coef1, int ntaps1, int fix_shift,
+                       int factor2, const double *coef2, int ntaps2, double *out_dev, size_t n_out, int nbatch, size_t in_stride, size_t out_stride,
+                       int *handled);
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev);
 /* a8: one level of the radix select: hist_dev[q*2048 + digit] += count over values whose bits above the level equal prefix[q] */
 int wfx_d_select_hist(wfx_ctx *ctx, const double *env_dev, size_t n, int level, const uint64_t prefix[4], uint32_t *hist_dev);
@@ -399,6 +408,21 @@ int wfx_shard_wire_plan(const wfx_decode_params *p, int world, wfx_wire_entry *o
 uint64_t wfx_comm_async_exchanges(wfx_comm *comm);
 int wfx_comm_wire_reset(wfx_comm *comm);
 int wfx_comm_wire_stats(wfx_comm *comm, wfx_wire_entry *out, int cap);
+/* Time per collective, parallel to the entries of wfx_comm_wire_stats.  wfx_comm_wire_timing(comm, 1) resets the records and from
+ * then on brackets every collective with a HIP-event pair on the stream it is enqueued on (RCCL) or reads the host clock around
+ * it (the shm / local transports, which complete it before returning); for an exchange on the communicator's own stream a second
+ * pair on the CONTEXT's stream brackets the wait for it.  After the streams have been synchronised wfx_comm_wire_times reports
+ *   us       the collective itself (RCCL: from its first kernel's start to its last one's end -- waiting for a late peer included),
+ *   wait_us  what the compute stream spent standing still for it: = us for a collective in stream order or on a blocking
+ *            transport; for an overlapped exchange the time between reaching its wfx_comm_wait and being released (0 when it
+ *            had already finished: fully hidden),
+ * -1 where nothing was measured.  timed: 0 no, 1 HIP events, 2 host clock.  Returns the number of entries. */
+typedef struct {
+    double us, wait_us;
+    int    on_comm_stream, timed;
+} wfx_wire_time;
+int wfx_comm_wire_timing(wfx_comm *comm, int on);
+int wfx_comm_wire_times(wfx_comm *comm, wfx_wire_time *out, int cap);
 /* `p` describes the WHOLE capture (as for wfx_decode_upload); hilbert_mode must be WFX_HILBERT_FFT */
 int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, wfx_shard **out);
 /* this rank's input frames [in_lo, in_hi): host memory (copied) or caller-owned device memory (kept, not copied) */

@@ -35,11 +35,18 @@ def _recipes():
     return recipes
 
 
-@pytest.fixture(scope="session", autouse=True)
-def golden_inputs_in_place():
-    """The golden inputs are not kept in the repository (tests/golden/recipes.py regenerates them, the manifest pins their SHA-256):
-    in place before the first test of a session, whichever file it collects."""
-    _recipes().ensure_all(GOLDEN)
+def input_path(case: dict) -> str:
+    """Path of a golden case's input wav, regenerated from its recipe when it is not kept in the repository and not there yet.
+    A recipe that does not reproduce the manifest's SHA-256 on this host fails THIS test (one case), nothing else."""
+    recipes = _recipes()
+    try:
+        return recipes.ensure_input(GOLDEN, case)
+    except recipes.GoldenInputMismatch as e:
+        pytest.fail(str(e), pytrace=False)
+
+
+def input_by_name(name: str) -> str:
+    return input_path(next(c for c in golden_cases() if c["name"] == name))
 
 
 def load_golden(name: str):
@@ -49,16 +56,7 @@ def load_golden(name: str):
 
 
 def golden_cases():
-    """The manifest's cases; inputs that are not kept in the repository (tests/golden/recipes.py) are regenerated on first use."""
+    """The manifest's cases (collection time: nothing is generated here; a test asks `input_path(case)` for its wav)."""
     import json
     with open(os.path.join(GOLDEN, "manifest.json")) as fh:
-        cases = json.load(fh)["cases"]
-    if any("recipe" in c for c in cases):
-        sys.path.insert(0, GOLDEN)
-        try:
-            import recipes
-        finally:
-            sys.path.remove(GOLDEN)
-        for c in cases:
-            recipes.ensure_input(GOLDEN, c)
-    return cases
+        return json.load(fh)["cases"]

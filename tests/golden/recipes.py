@@ -1,7 +1,8 @@
-"""Inputs of the golden cases (all but the reference's own five clips): not kept in the repository, REGENERATED from these recipes
-(deterministic: ``wefax_amd.synth`` + NumPy's PCG64 streams) wherever the file is missing, and checked against the SHA-256
-that ``make_golden.py`` recorded in the manifest when the reference ran on them.  Data generators only -- nothing of the
-reference is here.
+"""Inputs of the golden cases.  The reference's own five clips and every synthetic input up to ~1 MB (the ten 11 025 Hz / 8 kHz
+cases, 5.7 MB) are KEPT in the repository (the GPU box must not depend on bit-reproducible ``np.sin``); the larger
+ones are REGENERATED from these recipes (deterministic: ``wefax_amd.synth`` + NumPy's PCG64 streams) wherever the file is
+missing and checked against the SHA-256 that ``make_golden.py`` recorded in the manifest when the reference ran on them -- a
+mismatch costs that ONE case (``GoldenInputMismatch``), not the session.  Data generators only -- nothing of the reference is here.
 
 The two cases pin the oracle in the format of BASELINE configs[3] itself (round-3 verdict): a two-channel
 int16 stream at 1.536 MS/s through the reference's merge (wefax.py:360-373) and its FFT resample by 147 / 20480
@@ -137,32 +138,52 @@ def file_sha256(path: str) -> str:
     return h.hexdigest()
 
 
+class GoldenInputMismatch(RuntimeError):
+    """A recipe regenerated a wav whose SHA-256 is not the manifest's (NumPy's SIMD sin / cos are not promised to be bit-identical
+    across hosts): THAT case cannot be compared with the reference's arrays on this host -- the others can."""
+
+
+FAILED: dict = {}        # case name -> message, for every input that could not be put in place this session
+
+
 def ensure_input(golden_dir: str, case: dict) -> str:
-    """Path of the case's input wav; written from its recipe when it is not there (and verified against the manifest)."""
+    """Path of the case's input wav; written from its recipe when it is not there and verified against the manifest
+    (``GoldenInputMismatch`` otherwise, remembered in ``FAILED`` so that the recipe is not run again for every test)."""
     path = os.path.join(golden_dir, case["input"])
     if os.path.exists(path) or "recipe" not in case:
         return path
+    if case["name"] in FAILED:
+        raise GoldenInputMismatch(FAILED[case["name"]])
     from wefax_amd import synth
     fs, data, _ = RECIPES[case["recipe"]]()
+    os.makedirs(os.path.dirname(path), exist_ok=True)
     tmp = path + ".tmp%d" % os.getpid()
     synth.write_wav(tmp, fs, data)
     got = file_sha256(tmp)
     if case.get("input_sha256") and got != case["input_sha256"]:
         os.remove(tmp)
-        raise RuntimeError(f"golden input {case['name']}: regenerated wav hashes to {got}, the manifest says {case['input_sha256']} "
-                           "(a different NumPy random stream?)")
+        FAILED[case["name"]] = (f"golden input {case['name']}: regenerated wav hashes to {got}, the manifest says {case['input_sha256']} "
+                                "(NumPy's sin / cos or random stream differ on this host); only this case is affected")
+        raise GoldenInputMismatch(FAILED[case["name"]])
     os.replace(tmp, path)
     return path
 
 
-def ensure_all(golden_dir: str) -> None:
-    """Every golden input in place (regenerated where missing): conftest.py, __graft_entry__.smoke() and the tools call this before
-    they open a wav by path."""
+def ensure_all(golden_dir: str, strict: bool = True) -> dict:
+    """Every golden input in place (regenerated where missing).  ``strict`` False: a case whose recipe does not reproduce the manifest's
+    hash is skipped and reported in the returned {name: message} instead of raising -- one irreproducible input costs one case."""
     import json
     with open(os.path.join(golden_dir, "manifest.json")) as fh:
         cases = json.load(fh)["cases"]
+    bad = {}
     for c in cases:
-        ensure_input(golden_dir, c)
+        try:
+            ensure_input(golden_dir, c)
+        except GoldenInputMismatch as e:
+            if strict:
+                raise
+            bad[c["name"]] = str(e)
+    return bad
 
 
 class Golden(dict):

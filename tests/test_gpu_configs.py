@@ -18,7 +18,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, REPO, load_golden
+from conftest import GOLDEN, REPO, load_golden, input_by_name
 
 pytestmark = pytest.mark.gpu
 
@@ -320,7 +320,7 @@ def test_command_line_wav_to_png(name, lpm, tmp_path):
     """`python wefax.py <wav> <lpm> <out.png>` (wefax.py:411-424), run as a child process from the reference's working
     directory layout: prints file_info, writes an 8-bit gray PNG whose pixels are the reference's image."""
     out = tmp_path / "out.png"
-    wav = os.path.join(GOLDEN, "inputs", name + ".wav")
+    wav = input_by_name(name)
     r = subprocess.run([sys.executable, os.path.join(REPO, "wefax.py"), wav, str(lpm), str(out)], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "filename : " + name + ".wav" in r.stdout and "sample_rate :" in r.stdout        # wefax.py:418-419
@@ -342,7 +342,7 @@ def test_png_assembled_on_the_device_and_the_compressed_alternative(tmp_path, mo
     host copy."""
     from wefax_amd import Demodulator
     g = load_golden("mono_noisy_120")
-    d = Demodulator(os.path.join(GOLDEN, "inputs", "mono_noisy_120.wav"), lines_per_minute=120, quiet=True)
+    d = Demodulator(input_by_name("mono_noisy_120"), lines_per_minute=120, quiet=True)
     d.process()
     a, b, c, e = str(tmp_path / "a.png"), str(tmp_path / "b.png"), str(tmp_path / "c.png"), str(tmp_path / "e.png")
     monkeypatch.setenv("WEFAX_PNG_STORED", "1")
@@ -374,7 +374,7 @@ def test_device_deflate_png(name, lpm, tmp_path):
         wav = str(tmp_path / "s.wav")
         synth.write_wav(wav, 11025, synth.synth_capture(11025.0, noise=0.02, seed=5, lpm=lpm, image_lines=90, phasing_lines=20))
     else:
-        wav = os.path.join(GOLDEN, "inputs", name + ".wav")
+        wav = input_by_name(name)
     d = Demodulator(wav, lines_per_minute=lpm, quiet=True)
     d.process()
     img = d.output_array
@@ -416,7 +416,7 @@ def test_demodulators_share_idle_contexts():
     a Demodulator keeps its image until it is closed."""
     from wefax_amd import Demodulator, wefax as wx
     g = load_golden("mono_noisy_120")
-    wav = os.path.join(GOLDEN, "inputs", "mono_noisy_120.wav")
+    wav = input_by_name("mono_noisy_120")
     wx.release_contexts()
     d1 = Demodulator(wav, lines_per_minute=120, quiet=True)
     d1.process()

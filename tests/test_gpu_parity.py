@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases, load_golden
+from conftest import GOLDEN, golden_cases, load_golden, input_path
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +38,7 @@ def _rel(a, b):
 def test_demodulator_matches_reference_golden(case):
     from wefax_amd import Demodulator
     g = load_golden(case["name"])
-    d = Demodulator(os.path.join(GOLDEN, case["input"]), lines_per_minute=case["lpm"],
+    d = Demodulator(input_path(case), lines_per_minute=case["lpm"],
                     quiet=True, tcp_stream=True)
     info = d.file_info()
     assert info["channels"] == case["file_info"]["channels"]

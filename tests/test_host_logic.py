@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, REPO, golden_cases
+from conftest import GOLDEN, REPO, golden_cases, input_path
 from oracle import wefax_oracle as wo
 from wefax_amd import _native as nat
 from wefax_amd import hostparams as hp
@@ -78,17 +78,17 @@ def test_constructor_contract():
     with pytest.raises(Exception) as e:
         Demodulator(os.path.join(REPO, "README.md"))
     assert str(e.value) == "INVALID FILETYPE: only .wav files are supported at this moment"  # wefax.py:28
-    d = Demodulator(os.path.join(GOLDEN, "inputs", "stereo48k_120.wav"), lines_per_minute=120, quiet=True)
+    d = Demodulator(os.path.join(GOLDEN, "inputs", "stereo_overflow_120.wav"), lines_per_minute=120, quiet=True)
     assert d.websocket_stack == [] and d.time_for_one_frame == 0.5
     d.update_lines_per_minute(240)
     assert d.lines_per_minute == 240 and d.time_for_one_frame == 0.25
     fi = d.file_info()
-    assert fi == {"filename": "stereo48k_120.wav", "channels": 2, "sample_rate": 48000, "length": 13.0}
+    assert fi == {"filename": "stereo_overflow_120.wav", "channels": 2, "sample_rate": 11025, "length": 13.0}
 
 
 @pytest.mark.parametrize("case", golden_cases(), ids=[c["name"] for c in golden_cases()])
 def test_wav_reader_matches_oracle_reader(case):
-    p = os.path.join(GOLDEN, case["input"])
+    p = input_path(case)
     sr0, d0 = wo.read_wav(p)
     sr1, d1 = hp.read_wav(p)
     assert sr0 == sr1 and d0.dtype == d1.dtype and np.array_equal(d0, d1)
@@ -98,12 +98,12 @@ def test_wav_reader_matches_oracle_reader(case):
 def test_file_info_from_the_headers_equals_the_references(case):
     """file_info (wefax.py:342-346) is answered from the wav's headers alone; the manifest holds what the reference printed."""
     from wefax_amd import Demodulator
-    d = Demodulator(os.path.join(GOLDEN, case["input"]), lines_per_minute=case.get("lpm", 120), quiet=True)
+    d = Demodulator(input_path(case), lines_per_minute=case.get("lpm", 120), quiet=True)
     fi, ref = d.file_info(), case["file_info"]
     assert fi["filename"] == ref["filename"] and fi["channels"] == ref["channels"] and fi["sample_rate"] == ref["sample_rate"]
     assert fi["length"] == ref["length"]
-    sr, frames, ch = hp.wav_info(os.path.join(GOLDEN, case["input"]))
-    sr1, data = hp.read_wav(os.path.join(GOLDEN, case["input"]))
+    sr, frames, ch = hp.wav_info(input_path(case))
+    sr1, data = hp.read_wav(input_path(case))
     assert (sr, frames, ch) == (sr1, data.shape[0], 1 if data.ndim == 1 else data.shape[1])
 
 
@@ -300,3 +300,61 @@ def test_bench_guard_prints_the_headline_when_the_sharded_part_hangs(tmp_path):
     code2 = code.replace("time.sleep(30)", "assert g.claim(); print('LINE'); g.printed_exit_only(); time.sleep(0.6)")
     r = subprocess.run([sys.executable, "-c", code2, "0"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout.strip() == "LINE", (r.stdout, r.stderr)
+
+
+def test_golden_inputs_regenerate_from_nothing_and_a_mismatch_costs_one_case(tmp_path):
+    """A directory with the manifest and NO wav: every recipe input comes back with the manifest's SHA-256 (what a fresh checkout
+    does for the inputs that are not kept in the repository); a recipe that does not reproduce its hash -- another NumPy build's
+    sin / cos -- is reported for THAT case and leaves the others alone (round-4 verdict: it used to turn the whole session red)."""
+    import json
+    import shutil
+    import sys
+    sys.path.insert(0, GOLDEN)
+    try:
+        import recipes
+    finally:
+        sys.path.remove(GOLDEN)
+    gold = tmp_path / "golden"
+    (gold / "inputs").mkdir(parents=True)
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    small = [c for c in man["cases"] if "recipe" in c and c["recipe"] in ("mono8k_noisy_120", "mono_clean_120", "mono_u8_240", "stereo_overflow_120")]
+    assert len(small) == 4
+    bad_name = small[1]["name"]
+    small[1] = dict(small[1], input_sha256="0" * 64)
+    json.dump({"cases": small}, open(gold / "manifest.json", "w"))
+    recipes.FAILED.pop(bad_name, None)
+    try:
+        bad = recipes.ensure_all(str(gold), strict=False)
+        assert list(bad) == [bad_name] and "only this case is affected" in bad[bad_name]
+        for c in small:
+            p = gold / c["input"]
+            if c["name"] == bad_name:
+                assert not p.exists()
+                with pytest.raises(recipes.GoldenInputMismatch):
+                    recipes.ensure_input(str(gold), c)
+            else:       # identical to the copy kept in the repository
+                assert recipes.file_sha256(str(p)) == c["input_sha256"] == recipes.file_sha256(os.path.join(GOLDEN, c["input"]))
+        with pytest.raises(recipes.GoldenInputMismatch):
+            recipes.ensure_all(str(gold), strict=True)
+    finally:
+        recipes.FAILED.pop(bad_name, None)
+    shutil.rmtree(gold)
+
+
+def test_every_recipe_still_hashes_to_the_manifest(tmp_path):
+    """All 19 recipes, the 12 MB IQ clip included, in a directory of their own (the kept copies are not consulted)."""
+    import json
+    import sys
+    sys.path.insert(0, GOLDEN)
+    try:
+        import recipes
+    finally:
+        sys.path.remove(GOLDEN)
+    gold = tmp_path / "golden"
+    (gold / "inputs").mkdir(parents=True)
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    cases = [c for c in man["cases"] if "recipe" in c]
+    assert len(cases) == 19
+    json.dump({"cases": cases}, open(gold / "manifest.json", "w"))
+    assert recipes.ensure_all(str(gold), strict=False) == {}
+    assert sorted(os.listdir(gold / "inputs")) == sorted(os.path.basename(c["input"]) for c in cases)

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases, load_golden
+from conftest import GOLDEN, golden_cases, load_golden, input_path
 from oracle import wefax_oracle as wo
 
 CASES = golden_cases()
@@ -19,7 +19,7 @@ def _sha(a):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_oracle_matches_reference_every_stage(case):
     g = load_golden(case["name"])
-    r = wo.process(os.path.join(GOLDEN, case["input"]), case["lpm"])
+    r = wo.process(input_path(case), case["lpm"])
     assert r["sample_rate"] == case["sample_rate"]
     assert r["length"] == case["length"]
     # float stages: a6 notch output, a7 envelope.  Bit-exact here (same pocketfft),
@@ -65,7 +65,7 @@ def test_oracle_float_stages_are_bit_identical_here(manifest):
     if np.__version__ != manifest["versions"]["numpy"]:
         pytest.skip("different numpy build")
     c = CASES[1]
-    r = wo.process(os.path.join(GOLDEN, c["input"]), c["lpm"])
+    r = wo.process(input_path(c), c["lpm"])
     assert _sha(r["audio"]) == c["audio_sha256"]
     assert _sha(r["demod"]) == c["demod_sha256"]
 
@@ -137,7 +137,7 @@ def test_faithful_loops_form_gives_the_same_results(name):
     """oracle.process(faithful_loops=True) keeps the reference's per-sample Python loops (the CPU timing of
     bench.py that stands for wefax.py itself): identical stream, peaks, start_frame, image or exception."""
     case = next(c for c in golden_cases() if c["name"] == name)
-    path = os.path.join(GOLDEN, case["input"])
+    path = input_path(case)
     a = wo.process(path, case["lpm"], want_messages=False)
     b = wo.process(path, case["lpm"], want_messages=False, faithful_loops=True)
     assert np.array_equal(a["digitalized"], b["digitalized"]) and list(a["peaks"]) == list(b["peaks"])

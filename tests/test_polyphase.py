@@ -359,3 +359,58 @@ def test_each_rank_loads_only_its_slice_of_the_raw_stream(ctx, layout):
         d.close()
     for c in comms:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["iq1536k_2s_240", "stereo192k_6s_240", "mono48k_image_240", "stereo48k_image_240", "mono48k_noisy_120", "mono_noisy_240",
+                                  "mono48k_f32_240"])
+def test_demodulator_reaches_the_time_domain_front_end_on_request(name):
+    """`Demodulator(front_end=...)`: the drop-in's two routes for a capture that is not at 11 025 Hz (wefax.py:351-394), on the
+    REFERENCE's goldens.  "exact" (default) = the reference's own operators, bit-identical; "time-domain" = the decimator chain of
+    BASELINE configs[3] (for 1.536 MS/s: the streaming / 32 -> / 3 kernel) + exact FFT resample from the hand-over rate: same
+    exception, same start frame, stream and image within one grey level.  Captures the chain does not take (11 025 Hz, float32)
+    run the exact route whatever was asked."""
+    from conftest import golden_cases, input_by_name, load_golden
+    from wefax_amd import Demodulator
+    case = next(c for c in golden_cases() if c["name"] == name)
+    g = load_golden(name)
+    for mode in ("exact", "time-domain"):
+        d = Demodulator(input_by_name(name), lines_per_minute=case["lpm"], quiet=True, tcp_stream=True, front_end=mode)
+        try:
+            d.process()
+            exc = None
+        except (ValueError, IndexError) as e:
+            exc = [type(e).__name__, str(e)]
+        takes = mode == "time-domain" and case["file_info"]["sample_rate"] >= 28000 and name != "mono48k_f32_240"
+        assert d.front_end_used == ("time-domain" if takes else "exact")
+        assert exc == case["exception"]
+        assert d.sample_rate == case["sample_rate"] and d.length == case["length"]
+        dig = d.digitalized_data
+        assert dig.shape == g["digitalized"].shape
+        delta = np.abs(dig.astype(np.int16) - g["digitalized"].astype(np.int16))
+        exact = case.get("oracle_exact", True) and not takes
+        print(f"{name} via {mode}: stream differing {np.count_nonzero(delta)} of {delta.size}, max {delta.max()}")
+        assert delta.max() <= STREAM_MAX
+        assert np.count_nonzero(delta) <= (0 if exact else max(3, 1e-3 * delta.size if not case.get("oracle_exact", True) else 2 * STREAM_NE_FRAC * delta.size))
+        if exc is None:
+            assert d.start_frame == case["start_frame"]
+            img = d.output_array
+            di = np.abs(img.astype(np.int16) - g["image"].astype(np.int16))
+            assert img.shape == g["image"].shape and di.max() <= IMAGE_MAX
+            assert not exact or not di.any()
+        msgs = [[m.get("data_type"), m.get("progress_title", m.get("message_content")),
+                 None if "percentage" not in m else float(m["percentage"])] for m in d.websocket_stack]
+        assert msgs == [list(m) for m in case["websocket_stack"]] or (takes and exc is None and len(msgs) == len(case["websocket_stack"]))
+        d.close()
+
+
+def test_demodulator_front_end_argument_is_checked(tmp_path, monkeypatch):
+    from wefax_amd import Demodulator
+    p = tmp_path / "x.wav"
+    synth.write_wav(str(p), 11025, np.zeros(100, dtype=np.int16))
+    with pytest.raises(ValueError):
+        Demodulator(str(p), quiet=True, front_end="fir")
+    assert Demodulator(str(p), quiet=True).front_end == "exact"
+    monkeypatch.setenv("WEFAX_FRONT_END", "time-domain")
+    assert Demodulator(str(p), quiet=True).front_end == "time-domain"
+    assert Demodulator(str(p), quiet=True, front_end="exact").front_end == "exact"

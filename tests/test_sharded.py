@@ -530,7 +530,7 @@ def test_sharded_decode_of_any_length_equals_the_oracle(n):
     samples) through the padded distributed convolution, worlds 1 / 2 / 3 / 8: stream, peaks, start_frame, image equal to the
     oracle's; the float stages do not depend on the world size; decoding twice (the second decode skips the kernel's transform)
     gives the same again."""
-    lines = max(20, int(n / 5512.5) - 40)
+    lines = max(12, int(n / 5512.5) - 40)
     x = synth.synth_capture(11025.0, noise=0.05, seed=n % 1000, start_tone_s=2.0, phasing_lines=20, image_lines=lines, stop_tone_s=1.0, black_tail_s=1.0)
     x = np.concatenate([x, x[:max(0, n - x.shape[0])]])[:n]
     assert x.shape[0] == n
@@ -580,19 +580,22 @@ def test_sixty_minute_native_rate_capture_of_arbitrary_length_on_eight_ranks():
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,n", [(2, 600570), (2, 600599), (2, 601420), (2, 601421), (2, 633824), (2, 633877),
                                      (3, 602946), (3, 602975), (3, 602976), (3, 602977), (3, 602986), (3, 603039),
-                                     (4, 601420), (4, 602394), (4, 602447), (8, 600599), (8, 601421), (8, 602394)])
+                                     (4, 601420), (4, 602394), (4, 602447), (8, 600599), (8, 601421), (8, 602394),
+                                     (2, 112001), (2, 112010), (2, 112063), (3, 112002), (4, 112033), (8, 112062)])
 def test_capture_that_ends_at_a_segment_boundary(world, n):
     """Padded forms in the columns layout: the capture ends INSIDE the padded arrangement.  These lengths put the end exactly at a
     rank's first column of a row, one sample before or behind it, 10 / 30 / 63 samples to either side -- where filtfilt's exact
     edge (the last 64 outputs, made of the last 127 samples) straddles two ranks' columns and each of them has to compute its part
-    from its own segment and halo.  Found by `nat.shard_layout` for these world sizes; the test checks that they still are."""
+    from its own segment and halo.  The 112 0xx lengths end 1..63 samples behind a ROW boundary (rank 0's first column): part of the
+    edge then lies among the LAST rank's own samples of the row before, which sees the end through its right halo (round-4 advisor
+    finding).  Found by `nat.shard_layout` for these world sizes; the test checks that they still are."""
     p, _ = build_params(0, n, 11025, 0.5, shard_plan=sharded.plan_code("dist"))
     lays = [nat.shard_layout(p, world, r) for r in range(world)]
     assert lays[0].plan == 2 and lays[0].nseg > 1 and lays[0].in_halo == 192
     stride = int(lays[0].own_seg_stride)
-    d = min(min((n - int(lay.own_lo)) % stride, (int(lay.own_lo) - n) % stride) for lay in lays[1:])
+    d = min(min((n - int(lay.own_lo)) % stride, (int(lay.own_lo) - n) % stride) for lay in (lays if n < 200000 else lays[1:]))
     assert d <= 63
-    lines = max(20, int(n / 5512.5) - 40)
+    lines = max(12, int(n / 5512.5) - 40)
     x = synth.synth_capture(11025.0, noise=0.05, seed=n % 1000, start_tone_s=2.0, phasing_lines=20, image_lines=lines, stop_tone_s=1.0, black_tail_s=1.0)
     x = np.concatenate([x, x[:max(0, n - x.shape[0])]])[:n]
     ref = _oracle(x, 11025, 120)

@@ -30,7 +30,7 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
@@ -223,6 +223,7 @@ def load():
     lib.wfx_d_notch_fir_f64.argtypes = [vp, vp, sz, dp, dp, vp, i]
     lib.wfx_d_decimate_fir64.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int)]
     lib.wfx_d_decimate_fir64_batch.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int), i, sz, sz]
+    lib.wfx_d_ingest_chain.argtypes = [vp, vp, i, sz, i, vp, i, i, i, vp, i, vp, sz, i, sz, sz, C.POINTER(C.c_int)]
     lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
     lib.wfx_d_select_hist.argtypes = [vp, vp, sz, i, C.POINTER(C.c_uint64), vp]
     lib.wfx_d_quantise.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, C.POINTER(C.c_uint64)]
@@ -603,6 +604,19 @@ class Context:
             self._check(self.lib.wfx_d_decimate_fir64(self.h, C.c_void_p(in_ptr), in_kind, n_in, first, factor, _ptr(c), c.shape[0],
                                                       C.c_void_p(out_ptr), n_out, int(fix_shift), C.byref(ex)))
         return bool(ex.value)
+
+    def d_ingest_chain(self, in_ptr: int, in_kind: int, n_in: int, factor: int, coef1: np.ndarray, fix_shift: int, factor2: int, coef2,
+                       out_ptr: int, n_out: int, nbatch: int = 1, in_stride: int = 0, out_stride: int = 0) -> bool:
+        """The integer-exact ingest (``factor`` 32) and the float64 stage behind it (``factor2`` 2 or 3; 0: none) in one streaming
+        kernel (csrc/wfx_ingest.hip); bit-identical to the two ``d_decimate_fir64`` calls it replaces.  False: not a shape that
+        kernel takes, nothing was enqueued."""
+        c1 = np.ascontiguousarray(coef1, dtype=np.float64)
+        c2 = np.ascontiguousarray(coef2 if coef2 is not None else np.zeros(1), dtype=np.float64)
+        handled = C.c_int(0)
+        self._check(self.lib.wfx_d_ingest_chain(self.h, C.c_void_p(in_ptr), in_kind, n_in, int(factor), _ptr(c1), c1.shape[0], int(fix_shift),
+                                                int(factor2), _ptr(c2), c2.shape[0] if factor2 else 0, C.c_void_p(out_ptr), n_out,
+                                                int(nbatch), int(in_stride), int(out_stride), C.byref(handled)))
+        return bool(handled.value)
 
     def d_median5(self, in_ptr: int, n: int, out_ptr: int):
         self._check(self.lib.wfx_d_median5(self.h, C.c_void_p(in_ptr), n, C.c_void_p(out_ptr)))

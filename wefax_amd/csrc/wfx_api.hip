@@ -562,6 +562,16 @@ int wfx_d_decimate_fir64_batch(wfx_ctx *ctx, const void *in_dev, int in_kind, si
     return wfx_dev_decimate_fir64(ctx, in_dev, in_kind, n_in, first, factor, coef, ntaps, out_dev, n_out, fix_shift, exact, nbatch, in_stride, out_stride);
 }
 
+int wfx_d_ingest_chain(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int factor, const double *coef1, int ntaps1, int fix_shift,
+                       int factor2, const double *coef2, int ntaps2, double *out_dev, size_t n_out, int nbatch, size_t in_stride, size_t out_stride,
+                       int *handled)
+{
+    CHECK_CTX(ctx);
+    if (!in_dev || !out_dev || !coef1 || !handled || (factor2 && !coef2)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return wfx_dev_ingest_stream(ctx, in_dev, in_kind, n_in, factor, coef1, ntaps1, fix_shift, factor2, coef2, ntaps2, out_dev, n_out, nbatch, in_stride,
+                                 out_stride, handled);
+}
+
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev)
 {
     CHECK_CTX(ctx);

@@ -163,6 +163,18 @@ struct wfx_comm {
     std::vector<wfx_wire_entry> wire;
     unsigned long long wire_count = 0;
     char label[24] = {0};
+    // optional timing of every collective (wfx_comm_wire_timing): a HIP-event pair on the stream the collective runs on (RCCL), the
+    // host clock around the call (the transports that complete it before returning), and -- for an exchange on the communicator's
+    // own stream -- a second pair on the CONTEXT's stream around the wait for it: the time the compute stream actually stood still
+    struct wire_clock {
+        hipEvent_t a = nullptr, b = nullptr, wa = nullptr, wb = nullptr;
+        double host_us = -1.0;
+        int on_comm_stream = 0;
+    };
+    bool timing = false;
+    std::vector<wire_clock> clocks;          // parallel to `wire`
+    std::vector<hipEvent_t> ev_free;
+    int slot_entry[64];
     // RCCL backend: exchanges that may overlap compute go to a stream of the communicator's own (wfx_comm_exchange_async): an
     // event recorded on the context's stream gates them, an event per slot marks their completion (wfx_comm_wait)
     hipStream_t xstream = nullptr;
@@ -177,7 +189,31 @@ void wfx_comm_label(wfx_comm *c, const char *name)
     if (c) snprintf(c->label, sizeof c->label, "%s", name ? name : "");
 }
 
-static void wire_record(wfx_comm *c, const char *fallback, unsigned long long sent, unsigned long long received, unsigned long long largest)
+static hipEvent_t clock_event(wfx_comm *c)
+{
+    if (!c->ev_free.empty()) {
+        hipEvent_t e = c->ev_free.back();
+        c->ev_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+static void clock_release(wfx_comm *c, wfx_comm::wire_clock &k)
+{
+    for (hipEvent_t *e : {&k.a, &k.b, &k.wa, &k.wb})
+        if (*e) {
+            c->ev_free.push_back(*e);
+            *e = nullptr;
+        }
+    k.host_us = -1.0;
+    k.on_comm_stream = 0;
+}
+
+// returns the index of the record (its clock is c->clocks[index] while timing is on)
+static int wire_record(wfx_comm *c, const char *fallback, unsigned long long sent, unsigned long long received, unsigned long long largest)
 {
     wfx_wire_entry e;
     memset(&e, 0, sizeof e);
@@ -185,10 +221,36 @@ static void wire_record(wfx_comm *c, const char *fallback, unsigned long long se
     e.total_bytes = sent;
     e.max_rank_bytes = received;
     e.max_link_bytes = largest;
-    if (c->wire.size() < 256) c->wire.push_back(e);
-    else c->wire[(size_t)(c->wire_count % 256)] = e;
+    size_t at;
+    if (c->wire.size() < 256) {
+        at = c->wire.size();
+        c->wire.push_back(e);
+        c->clocks.emplace_back();
+    } else {
+        at = (size_t)(c->wire_count % 256);
+        c->wire[at] = e;
+        clock_release(c, c->clocks[at]);
+    }
     ++c->wire_count;
     c->label[0] = 0;
+    return (int)at;
+}
+
+// event pair around what the caller enqueues on `st` next (RCCL); no-ops while timing is off
+static void clock_begin(wfx_comm *c, int at, hipStream_t st, int on_comm_stream)
+{
+    if (!c->timing) return;
+    wfx_comm::wire_clock &k = c->clocks[(size_t)at];
+    k.on_comm_stream = on_comm_stream;
+    k.a = clock_event(c);
+    k.b = clock_event(c);
+    if (k.a) (void)hipEventRecord(k.a, st);
+}
+static void clock_end(wfx_comm *c, int at, hipStream_t st)
+{
+    if (!c->timing) return;
+    wfx_comm::wire_clock &k = c->clocks[(size_t)at];
+    if (k.b) (void)hipEventRecord(k.b, st);
 }
 
 static double now_s()
@@ -591,6 +653,7 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
     if (!c) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null communicator");
     for (int i = 0; i < n; ++i)
         if (list[i].peer < 0 || list[i].peer >= c->world) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "exchange: peer %d out of range", list[i].peer);
+    int at = 0;
     {
         unsigned long long sent = 0, got = 0, big = 0;
         for (int i = 0; i < n; ++i)
@@ -599,7 +662,7 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
                 got += list[i].recv_bytes;
                 if (list[i].send_bytes > big) big = list[i].send_bytes;
             }
-        wire_record(c, "exchange", sent, got, big);
+        at = wire_record(c, "exchange", sent, got, big);
     }
     if (c->group) {
         local_op op;
@@ -607,7 +670,13 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
         op.list.assign(list, list + n);
         return local_post(c, ctx, std::move(op));
     }
-    if (c->shm) return shm_exchange(c->shm, ctx, list, n);
+    if (c->shm) {
+        const double t0 = now_s();
+        const int rc = shm_exchange(c->shm, ctx, list, n);
+        if (c->timing) c->clocks[(size_t)at].host_us = 1e6 * (now_s() - t0);
+        return rc;
+    }
+    clock_begin(c, at, ctx->stream, 0);
     bool any_remote = false;
     for (int i = 0; i < n; ++i) any_remote = any_remote || list[i].peer != c->rank;
     // a rank's message to itself is a copy on the stream (normally the packer has already written it in place)
@@ -617,7 +686,10 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
             if (list[i].send != list[i].recv)
                 WFX_HIP(ctx, hipMemcpyAsync(list[i].recv, list[i].send, list[i].send_bytes, hipMemcpyDeviceToDevice, ctx->stream));
         }
-    if (!any_remote) return 0;
+    if (!any_remote) {
+        clock_end(c, at, ctx->stream);
+        return 0;
+    }
     WFX_NCCL(ctx, g_rccl.GroupStart());
     ncclResult_t bad = ncclSuccess;
     for (int i = 0; i < n && bad == ncclSuccess; ++i) {
@@ -628,6 +700,7 @@ int wfx_comm_exchange(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int n)
     const ncclResult_t end = g_rccl.GroupEnd();          // the group is closed on the error path too: the communicator stays usable
     if (bad != ncclSuccess) return fail_nccl(ctx, bad, "ncclSend / ncclRecv of an exchange");
     if (end != ncclSuccess) return fail_nccl(ctx, end, "ncclGroupEnd");
+    clock_end(c, at, ctx->stream);
     return 0;
 }
 
@@ -663,6 +736,7 @@ int wfx_comm_exchange_async(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int
         c->done = std::move(done);
         c->pending.assign(64, 0);
     }
+    int at = 0;
     {
         unsigned long long sent = 0, got = 0, big = 0;
         for (int i = 0; i < n; ++i)
@@ -671,10 +745,12 @@ int wfx_comm_exchange_async(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int
                 got += list[i].recv_bytes;
                 if (list[i].send_bytes > big) big = list[i].send_bytes;
             }
-        wire_record(c, "exchange", sent, got, big);
+        at = wire_record(c, "exchange", sent, got, big);
     }
     WFX_HIP(ctx, hipEventRecord(c->ready, ctx->stream));
     WFX_HIP(ctx, hipStreamWaitEvent(c->xstream, c->ready, 0));
+    clock_begin(c, at, c->xstream, 1);
+    c->slot_entry[slot] = c->timing ? at : -1;
     bool any_remote = false;
     for (int i = 0; i < n; ++i) {
         any_remote = any_remote || list[i].peer != c->rank;
@@ -696,6 +772,7 @@ int wfx_comm_exchange_async(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int
         if (bad != ncclSuccess) return fail_nccl(ctx, bad, "ncclSend / ncclRecv of an exchange");
         if (end != ncclSuccess) return fail_nccl(ctx, end, "ncclGroupEnd");
     }
+    clock_end(c, at, c->xstream);
     WFX_HIP(ctx, hipEventRecord(c->done[(size_t)slot], c->xstream));
     c->pending[(size_t)slot] = 1;
     ++c->async_count;
@@ -706,7 +783,16 @@ int wfx_comm_exchange_async(wfx_comm *c, wfx_ctx *ctx, const wfx_xfer *list, int
 int wfx_comm_wait(wfx_comm *c, wfx_ctx *ctx, int slot)
 {
     if (!c || slot < 0 || slot >= (int)c->pending.size() || !c->pending[(size_t)slot]) return 0;
+    wfx_comm::wire_clock *k = (c->timing && c->slot_entry[slot] >= 0 && (size_t)c->slot_entry[slot] < c->clocks.size()) ? &c->clocks[(size_t)c->slot_entry[slot]] : nullptr;
+    if (k && !k->wa) {
+        k->wa = clock_event(c);
+        k->wb = clock_event(c);
+        if (k->wa) (void)hipEventRecord(k->wa, ctx->stream);
+    } else
+        k = nullptr;
     WFX_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->done[(size_t)slot], 0));
+    if (k && k->wb) (void)hipEventRecord(k->wb, ctx->stream);
+    c->slot_entry[slot] = -1;
     c->pending[(size_t)slot] = 0;
     return 0;
 }
@@ -717,8 +803,8 @@ int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t coun
 {
     if (!c) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null communicator");
     // (a ring all-reduce moves 2 (W - 1) / W of the buffer out of and into every rank)
-    wire_record(c, "all-reduce", 2ull * (unsigned long long)(c->world - 1) * count * 4 / (unsigned long long)c->world,
-                2ull * (unsigned long long)(c->world - 1) * count * 4 / (unsigned long long)c->world, count * 4 / (unsigned long long)c->world);
+    const int at = wire_record(c, "all-reduce", 2ull * (unsigned long long)(c->world - 1) * count * 4 / (unsigned long long)c->world,
+                               2ull * (unsigned long long)(c->world - 1) * count * 4 / (unsigned long long)c->world, count * 4 / (unsigned long long)c->world);
     if (c->group) {
         local_op op;
         op.kind = 2;
@@ -726,15 +812,22 @@ int wfx_comm_allreduce_u32(wfx_comm *c, wfx_ctx *ctx, unsigned *buf, size_t coun
         op.count = count;
         return local_post(c, ctx, std::move(op));
     }
-    if (c->shm) return shm_allreduce_u32(c->shm, ctx, buf, count);
+    if (c->shm) {
+        const double t0 = now_s();
+        const int rc = shm_allreduce_u32(c->shm, ctx, buf, count);
+        if (c->timing) c->clocks[(size_t)at].host_us = 1e6 * (now_s() - t0);
+        return rc;
+    }
+    clock_begin(c, at, ctx->stream, 0);
     WFX_NCCL(ctx, g_rccl.AllReduce(buf, buf, count, ncclUint32, ncclSum, c->nccl, ctx->stream));
+    clock_end(c, at, ctx->stream);
     return 0;
 }
 
 int wfx_comm_allgather(wfx_comm *c, wfx_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank)
 {
     if (!c) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null communicator");
-    wire_record(c, "all-gather", (unsigned long long)(c->world - 1) * bytes_per_rank, (unsigned long long)(c->world - 1) * bytes_per_rank, bytes_per_rank);
+    const int at = wire_record(c, "all-gather", (unsigned long long)(c->world - 1) * bytes_per_rank, (unsigned long long)(c->world - 1) * bytes_per_rank, bytes_per_rank);
     if (c->group) {
         local_op op;
         op.kind = 3;
@@ -743,8 +836,15 @@ int wfx_comm_allgather(wfx_comm *c, wfx_ctx *ctx, const void *send, void *recv, 
         op.count = bytes_per_rank;
         return local_post(c, ctx, std::move(op));
     }
-    if (c->shm) return shm_allgather(c->shm, ctx, send, recv, bytes_per_rank, false);
+    if (c->shm) {
+        const double t0 = now_s();
+        const int rc = shm_allgather(c->shm, ctx, send, recv, bytes_per_rank, false);
+        if (c->timing) c->clocks[(size_t)at].host_us = 1e6 * (now_s() - t0);
+        return rc;
+    }
+    clock_begin(c, at, ctx->stream, 0);
     WFX_NCCL(ctx, g_rccl.AllGather(send, recv, bytes_per_rank, ncclUint8, c->nccl, ctx->stream));
+    clock_end(c, at, ctx->stream);
     return 0;
 }
 
@@ -1067,7 +1167,46 @@ int wfx_comm_wire_reset(wfx_comm *comm)
     if (!comm) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null communicator");
     comm->wire.clear();
     comm->wire_count = 0;
+    for (auto &k : comm->clocks) clock_release(comm, k);
+    comm->clocks.clear();
+    for (int &e : comm->slot_entry) e = -1;
     return 0;
+}
+
+int wfx_comm_wire_timing(wfx_comm *comm, int on)
+{
+    if (!comm) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null communicator");
+    comm->timing = on != 0;
+    return wfx_comm_wire_reset(comm);
+}
+
+// The streams the collectives ran on must have been synchronised (wfx_sync / wfx_shard_result); entries whose events have not
+// completed report -1.
+int wfx_comm_wire_times(wfx_comm *comm, wfx_wire_time *out, int cap)
+{
+    if (!comm) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null communicator");
+    const int n = (int)comm->clocks.size();
+    for (int i = 0; i < n && i < cap && out; ++i) {
+        const wfx_comm::wire_clock &k = comm->clocks[(size_t)i];
+        wfx_wire_time t;
+        t.us = t.wait_us = -1.0;
+        t.on_comm_stream = k.on_comm_stream;
+        t.timed = 0;
+        float ms = 0.0f;
+        if (k.host_us >= 0.0) {           // completed before the call returned: all of it kept the caller waiting
+            t.us = t.wait_us = k.host_us;
+            t.timed = 2;
+        } else if (k.a && k.b && hipEventElapsedTime(&ms, k.a, k.b) == hipSuccess) {
+            t.us = 1e3 * (double)ms;
+            t.timed = 1;
+            if (!k.on_comm_stream)
+                t.wait_us = t.us;         // in stream order: the compute stream did nothing else meanwhile
+            else if (k.wa && k.wb && hipEventElapsedTime(&ms, k.wa, k.wb) == hipSuccess)
+                t.wait_us = 1e3 * (double)ms;
+        }
+        out[i] = t;
+    }
+    return n;
 }
 
 int wfx_comm_wire_stats(wfx_comm *comm, wfx_wire_entry *out, int cap)

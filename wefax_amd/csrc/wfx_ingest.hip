@@ -1,0 +1,375 @@
+// Streaming ingest of an oversampled int16 capture (BASELINE configs[3]: 1.536 MS/s IQ; round 5): the time-domain counterpart of
+// wefax.py:360-394 (stereo merge + scipy FFT resample) for the first one or two stages of the front end's chain,
+//
+//   y1[i] = sum_j c1[j] * x[32 i + j]          int16 samples (IQ pairs merged as (int16)(I + Q), wefax.py:360-373), integer-exact
+//   y2[k] = sum_j c2[j] * y1[M2 k + j]         float64, the stage behind it (M2 = 3 for 1.536 MS/s -> 48 kHz -> 16 kHz), optional
+//
+// in ONE kernel that reads every input byte once and never writes y1 to memory.  It replaces the tile kernel of
+// wfx_polyphase.hip (`decimate_kernel<..., MODE 1>` + a second `MODE 2` launch) on that path; the results are bit-identical to
+// that pair: stage 1 is an integer sum (no rounding, any order), stage 2 keeps the tile kernel's canonical order (three polyphase
+// FMA chains in ascending tap order, summed row 0 + row 1 + row 2).
+//
+// Why another kernel: the tile kernel kept its window in LDS in POLYPHASE order (row = sample index mod 32) so that one window
+// read fed many taps, and paid for it with a 2-byte scatter of every input sample (four ds_write_b16 per IQ chunk) and tiles
+// that re-staged their halo; its time did not move with the tap count (profiles/r03_v4/ingest_probe.txt: 32 taps as slow as 256)
+// -- the staging, not the arithmetic, kept it at 4.5-5.5 TB/s.  Here a workgroup STREAMS through a long contiguous run:
+//
+//   * samples lie in LDS in their natural order, one row = the 32 frames of one decimation step = 16 dwords of int16 pairs;
+//     a 16-byte IQ chunk is merged with two v_perm + one v_pk_add_u16 per pair and stored with ONE ds_write_b64;
+//   * a thread owns two consecutive outputs (2t, 2t+1): their windows are rows 2t .. 2t+8, read once with ds_read_b128 (rows
+//     are padded by 4 dwords per pair of rows: lane stride 36 dwords, conflict-free), and every window dword feeds the two
+//     outputs' tap pairs -- adjacent samples ARE the pair v_dot2_i32_i16 wants, the taps are scalar operands;
+//   * taps on the grid 2^-s are split into three pieces a * 2^18 + b * 2^9 + c (b, c nine bits): each piece's int32 sum over the
+//     whole window holds the worst-case input (sum |piece| * 32768 < 2^31, checked by the host), so there is no 64-bit
+//     arithmetic inside the loop and the result is exact for every input;
+//   * an iteration handles 512 outputs = 64 KiB of IQ frames; the next block's 16 chunks per lane are requested right after this
+//     block's registers were stored to LDS and stay in flight during the whole compute phase; the last 8 rows are carried over
+//     as the next iteration's halo (128 dwords through registers), so nothing is read twice inside a run;
+//   * stage 2 runs from a 1024-entry LDS ring of y1 one iteration behind stage 1 (<= 171 outputs per iteration).
+//
+// Roofline: HBM.  Algorithmic bytes per launch = 4 B per IQ frame + 8 B per output.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+#include "wfx_internal.h"
+
+namespace {
+
+constexpr int IG_THREADS = 256;
+constexpr int IG_M = 32;                        // stage-1 factor = frames per LDS row
+constexpr int IG_BLK = 512;                     // stage-1 outputs (= new LDS rows) per iteration: two per thread
+constexpr int IG_HALO = 8;                      // rows of history: a window spans 8 rows (<= 256 taps)
+constexpr int IG_ROWS = IG_BLK + IG_HALO;
+constexpr int IG_RD = IG_M / 2;                 // dwords per row
+constexpr int IG_NPAIR = 4 * IG_M;              // tap pairs per output (zero padded): 128
+constexpr int IG_NGRP = IG_NPAIR / 4;           // groups of four pairs = one ds_read_b128: 32 per output
+constexpr int IG_YRING = 1024, IG_YMIRROR = 128;
+constexpr int IG_PIECE = 9;                      // a fixed-point tap is a * 2^18 + b * 2^9 + c with b, c in [-256, 255]
+
+__host__ __device__ constexpr int ig_row_off(int r) { return r * IG_RD + (r >> 1) * 4; }       // dword offset of row r
+constexpr int IG_XS_BYTES = ig_row_off(IG_ROWS) * 4;
+constexpr int IG_YS_BYTES = (IG_YRING + IG_YMIRROR) * 8;
+
+typedef short ig_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short ig_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int ig_dot2(int w, int c, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(ig_s2, w), __builtin_bit_cast(ig_s2, c), acc, false);
+}
+// two IQ frames (I | Q << 16 each) -> one dword of two merged samples, (int16)(I + Q) with the int16 wrap of wefax.py:367
+__device__ __forceinline__ unsigned ig_merge2(unsigned w0, unsigned w1)
+{
+    const unsigned lo = __builtin_amdgcn_perm(w1, w0, 0x05040100u);      // (I0, I1)
+    const unsigned hi = __builtin_amdgcn_perm(w1, w0, 0x07060302u);      // (Q0, Q1)
+    return __builtin_bit_cast(unsigned, (ig_us2)(__builtin_bit_cast(ig_us2, lo) + __builtin_bit_cast(ig_us2, hi)));
+}
+
+struct ig_params {
+    const void *in;
+    long long n_in;             // frames readable behind `in`; anything beyond reads as zero
+    double sc;                  // 2^-shift (IQ: half of it)
+    int nper, ntaps2;           // stage 2: taps per polyphase row of the table (zero padded), taps
+    double *out;
+    long long n_out;            // outputs of the last stage
+    long long run_out;          // outputs per workgroup run
+    long long in_bs, out_bs;    // batch strides (bytes / elements)
+    long long run0;             // index of the launch's first run
+    int dbg_rows, dbg_flags;    // diagnostics (WFX_INGEST_DBG=rows,flags; results are WRONG unless 8,0): tap rows applied; 1 no stash, 2 no stage 2
+};
+
+// frames [e0, e0 + FPC) as one 16-byte chunk; frames at or beyond n_in read as zero
+template <int FB>
+__device__ __forceinline__ uint4 ig_fetch_guarded(const unsigned char *in, long long e0, long long n_in)
+{
+    constexpr int FPC = 16 / FB;
+    if (e0 + FPC <= n_in) return *(const uint4 *)(in + e0 * FB);
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (FB == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e0 + k < n_in) w[k] = ((const unsigned *)in)[e0 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (e0 + k < n_in) w[k >> 1] |= (unsigned)((const unsigned short *)in)[e0 + k] << (16 * (k & 1));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// GUARD: the run may reach beyond n_in (the last runs of a capture, launched on their own): every chunk is range-checked.  All other
+// runs load without a test.
+template <int IN, int M2, bool GUARD>
+__global__ void __launch_bounds__(IG_THREADS, 3) ingest_stream_kernel(const ig_params P, const int *__restrict__ tp, const double *__restrict__ c2tab)
+{
+    constexpr int FB = IN == WFX_IN_I16_STEREO ? 4 : 2;                   // bytes per frame
+    constexpr int FPC = 16 / FB;                                          // frames per 16-byte chunk
+    constexpr int CPR = IG_M / FPC;                                       // chunks per row: 8 (IQ), 4 (mono)
+    constexpr int CPT = IG_BLK * CPR / IG_THREADS;                        // chunks per thread and iteration: 16 (IQ), 8 (mono)
+    constexpr int HC = IG_HALO * CPR;                                     // chunks of the first halo
+    extern __shared__ __align__(16) unsigned char ig_lds[];
+    int *xs = (int *)ig_lds;
+    double *ys = (double *)(ig_lds + IG_XS_BYTES);
+    const int t = threadIdx.x;
+    const unsigned char *in = (const unsigned char *)P.in + (size_t)blockIdx.y * (size_t)P.in_bs;
+    double *out = P.out + (size_t)blockIdx.y * (size_t)P.out_bs;
+
+    const long long o0 = (P.run0 + (long long)blockIdx.x) * P.run_out;               // first output of this run
+    const long long ocnt = P.n_out - o0 < P.run_out ? P.n_out - o0 : P.run_out;
+    const long long s0 = M2 ? o0 * M2 : o0;                               // first stage-1 output the run needs
+    const long long cnt1 = M2 ? (ocnt - 1) * M2 + P.ntaps2 : ocnt;
+    const int niter = (int)((cnt1 + IG_BLK - 1) / IG_BLK);
+    const long long f0 = s0 * IG_M;                                       // its first frame
+
+    // chunk c of a block of rows goes to row c / CPR, dword (c % CPR) * (IG_RD / CPR); a thread's chunks of one iteration are
+    // IG_THREADS / CPR rows (an even number) apart: a constant LDS offset
+    auto put = [&](int *dst, const uint4 &v) {
+        if (IN == WFX_IN_I16_STEREO)
+            *(uint2 *)dst = make_uint2(ig_merge2(v.x, v.y), ig_merge2(v.z, v.w));
+        else
+            *(uint4 *)dst = v;
+    };
+    constexpr int RPU = IG_THREADS / CPR;
+    static_assert(RPU % 2 == 0 && IG_HALO % 2 == 0, "row padding is per pair of rows");
+    int *const xput = xs + ig_row_off(IG_HALO + t / CPR) + (t % CPR) * (IG_RD / CPR);
+    uint4 v[CPT];
+    auto load_block = [&](int n) {
+        const long long fb = f0 + ((long long)IG_HALO + (long long)n * IG_BLK) * IG_M;
+        if (!GUARD) {                                                     // straight-line loads, all in flight at once
+            const unsigned char *pb = in + fb * FB;                      // (uniform)
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) v[u] = *(const uint4 *)(pb + (size_t)u * IG_THREADS * 16 + (unsigned)t * 16u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) v[u] = ig_fetch_guarded<FB>(in, fb + (long long)(u * IG_THREADS + t) * FPC, P.n_in);
+        }
+    };
+
+    uint4 h0 = make_uint4(0u, 0u, 0u, 0u);
+    if (t < HC) h0 = ig_fetch_guarded<FB>(in, f0 + (long long)t * FPC, P.n_in);
+    load_block(0);
+    int carry = 0;
+    long long kdone = 0;                                                  // stage-2 outputs of this run already written
+
+    auto stage1 = [&](int n) {
+        const int *base = xs + 36 * t;                                    // = ig_row_off(2 t)
+        // step j: tap row j (16 pairs in three pieces: 48 scalar registers) against window row 2t + j for output A and row 2t + 1 + j
+        // for output B, which step j + 1 uses again for A: every window row and every tap row is fetched once.  (The loop is kept
+        // rolled: unrolled, the scheduler hoists all window reads and tap loads and spills a thousand registers.)
+        int sA[3] = {0, 0, 0}, sB[3] = {0, 0, 0};
+        int4 wa[4], wb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wa[q] = *(const int4 *)(base + 4 * q);
+#pragma unroll 1
+        for (int j = 0; j < P.dbg_rows; ++j) {
+            const int *nx = base + 16 * (j + 1) + 4 * ((j + 1) >> 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wb[q] = *(const int4 *)(nx + 4 * q);
+            const int *tr = tp + 16 * j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int wv[4] = {wa[q].x, wa[q].y, wa[q].z, wa[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) sA[k] = ig_dot2(wv[i], tr[k * IG_NPAIR + 4 * q + i], sA[k]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int wv[4] = {wb[q].x, wb[q].y, wb[q].z, wb[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) sB[k] = ig_dot2(wv[i], tr[k * IG_NPAIR + 4 * q + i], sB[k]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wa[q] = wb[q];
+        }
+        const long long tA = ((long long)sA[0] << (2 * IG_PIECE)) + ((long long)sA[1] << IG_PIECE) + (long long)sA[2];
+        const long long tB = ((long long)sB[0] << (2 * IG_PIECE)) + ((long long)sB[1] << IG_PIECE) + (long long)sB[2];
+        const double yA = (double)tA * P.sc, yB = (double)tB * P.sc;     // |t| < 2^51, sc a power of two: exact
+        const long long i1 = (long long)n * IG_BLK + 2 * t;              // run-local index of output A
+        if (M2 == 0) {
+            double *o = out + o0 + i1;
+            if (i1 + 1 < ocnt && ((uintptr_t)o & 15u) == 0) {
+                *(double2 *)o = make_double2(yA, yB);
+            } else {
+                if (i1 < ocnt) o[0] = yA;
+                if (i1 + 1 < ocnt) o[1] = yB;
+            }
+        } else {
+            const int s = (int)(i1 & (IG_YRING - 1));
+            *(double2 *)(ys + s) = make_double2(yA, yB);
+            if (s < IG_YMIRROR) *(double2 *)(ys + IG_YRING + s) = make_double2(yA, yB);
+        }
+    };
+    // stage 2 on everything iteration n made complete: outputs k with M2 k + ntaps2 <= (n + 1) * IG_BLK
+    auto stage2 = [&](int n) {
+        if (M2 == 0) return;
+        constexpr int MM = M2 ? M2 : 1;
+        const long long avail = (long long)(n + 1) * IG_BLK;
+        long long kend = avail >= P.ntaps2 ? (avail - P.ntaps2) / MM + 1 : 0;
+        if (kend > ocnt) kend = ocnt;
+        for (long long k = kdone + t; k < kend; k += IG_THREADS) {
+            const double *y = ys + (int)((k * MM) & (IG_YRING - 1));     // the window is contiguous: slots 0..127 are mirrored behind the ring
+            double tot = 0.0;
+#pragma unroll
+            for (int r = 0; r < MM; ++r) {
+                const double *c = c2tab + r * P.nper;
+                const int cnt = (P.ntaps2 - r + MM - 1) / MM;             // taps of this polyphase row
+                double acc = 0.0;
+#pragma unroll 8
+                for (int j = 0; j < cnt; ++j) acc = fma(c[j], y[r + MM * j], acc);
+                tot += acc;
+            }
+            out[o0 + k] = tot;
+        }
+        kdone = kend;
+    };
+
+    for (int n = 0; n < niter; ++n) {
+        __syncthreads();                       // A: stage 1 of iteration n - 1 is done with the rows, its ring entries are visible
+        if (n == 0) {
+            if (t < HC) put(xs + ig_row_off(t / CPR) + (t % CPR) * (IG_RD / CPR), h0);
+        } else if (t < IG_HALO * IG_RD) {
+            xs[ig_row_off(t / IG_RD) + (t % IG_RD)] = carry;
+        }
+        if (!(P.dbg_flags & 1)) {
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) put(xput + u * ig_row_off(RPU), v[u]);
+        } else {      // (keeps the loads alive)
+            unsigned acc = 0;
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+            if (acc == 0x9e3779b9u) xput[0] = (int)acc;
+        }
+        if (n + 1 < niter) load_block(n + 1);   // in flight during the whole compute phase
+        if (n > 0 && !(P.dbg_flags & 2)) stage2(n - 1);
+        __syncthreads();                       // B
+        stage1(n);
+        if (t < IG_HALO * IG_RD) carry = xs[ig_row_off(IG_BLK + t / IG_RD) + (t % IG_RD)];
+    }
+    if (M2) {
+        __syncthreads();
+        stage2(niter - 1);
+    }
+}
+
+}   // namespace
+
+// y1[i] = sum_j coef1[j] x[32 i + j] on the grid 2^-fix_shift (exact), and -- factor2 > 0 -- out[k] = sum_j coef2[j] y1[factor2 k + j]
+// in float64 behind it; factor2 == 0: out = y1.  x = the int16 frames behind `in` (16-byte aligned), zero beyond n_in.
+// *handled = 0 (and nothing enqueued) when the shapes are not the ones this kernel is built for: the caller runs the tile kernels.
+int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int factor, const double *coef1, int ntaps1, int fix_shift,
+                          int factor2, const double *coef2, int ntaps2, double *out, uint64_t n_out, int nbatch, uint64_t in_stride,
+                          uint64_t out_stride, int *handled)
+{
+    *handled = 0;
+    if (getenv("WFX_INGEST_TILE")) return 0;                               // A/B switch: the tile kernels of rounds 1-4
+    if (factor != IG_M || (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_I16_STEREO)) return 0;
+    if (ntaps1 < 1 || ntaps1 > 2 * IG_NPAIR || fix_shift < 8 || fix_shift > 40) return 0;
+    if (factor2 != 0 && factor2 != 2 && factor2 != 3) return 0;
+    if (nbatch < 1 || nbatch > 65535 || n_out == 0) return 0;
+    const int fb = in_kind == WFX_IN_I16_STEREO ? 4 : 2;
+    if (((uintptr_t)in & 15u) || (nbatch > 1 && ((in_stride * fb) & 15u))) return 0;
+    int nper = 0;
+    if (factor2) {
+        if (ntaps2 < factor2 || ntaps2 > IG_YMIRROR - 8) return 0;
+        nper = 4 * (((ntaps2 + factor2 - 1) / factor2 + 3) / 4);          // the tile kernel's row length (canonical order)
+    }
+    // fixed-point taps v = a * 2^18 + b * 2^9 + c with b, c in [-256, 255]: each piece's int32 sum over a whole window holds
+    // sum |piece| * 32768 < 2^31 for the worst-case input, so nothing is moved to 64 bits before the end
+    std::vector<int32_t> fix(2 * IG_NPAIR, 0);
+    for (int j = 0; j < ntaps1; ++j) {
+        const double v = nearbyint(ldexp(coef1[j], fix_shift));
+        if (!(fabs(v) < (double)(1 << 30))) return 0;
+        fix[j] = (int32_t)v;
+    }
+    const int pm = (1 << IG_PIECE) - 1, ph = 1 << (IG_PIECE - 1);
+    std::vector<int32_t> pc[3];
+    long long sum[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) pc[k].assign(2 * IG_NPAIR, 0);
+    for (int j = 0; j < 2 * IG_NPAIR; ++j) {
+        const int32_t v = fix[j];
+        const int32_t c = ((v + ph) & pm) - ph;
+        const int32_t v1 = (v - c) >> IG_PIECE;
+        const int32_t b = ((v1 + ph) & pm) - ph;
+        const int32_t a = (v1 - b) >> IG_PIECE;
+        pc[0][j] = a; pc[1][j] = b; pc[2][j] = c;
+        sum[0] += llabs((long long)a); sum[1] += llabs((long long)b); sum[2] += llabs((long long)c);
+        if (a < -32768 || a > 32767) return 0;
+    }
+    if (sum[0] > 65535 || sum[1] > 65535 || sum[2] > 65535) return 0;
+    std::vector<int32_t> tab(3 * IG_NPAIR);
+    auto pack = [](int a, int b) { return (int32_t)(((uint32_t)(uint16_t)(int16_t)a) | ((uint32_t)(uint16_t)(int16_t)b << 16)); };
+    for (int k = 0; k < 3; ++k)
+        for (int p = 0; p < IG_NPAIR; ++p) tab[k * IG_NPAIR + p] = pack(pc[k][2 * p], pc[k][2 * p + 1]);
+    const int *dtab = (const int *)wfx_coef_device(ctx, (const float *)tab.data(), tab.size());
+    if (!dtab) return WFX_ERR_HIP;
+    const double *dc2 = nullptr;
+    if (factor2) {
+        std::vector<double> c2((size_t)factor2 * nper, 0.0);
+        for (int j = 0; j < ntaps2; ++j) c2[(size_t)(j % factor2) * nper + (size_t)(j / factor2)] = coef2[j];
+        dc2 = (const double *)wfx_coef_device(ctx, (const float *)c2.data(), c2.size() * 2);
+        if (!dc2) return WFX_ERR_HIP;
+    }
+    // run length: `ni` iterations of 512 stage-1 outputs per workgroup.  Long runs amortise the halo (8 rows of frames, and with
+    // stage 2 the ntaps2 - factor2 stage-1 outputs two neighbouring runs both compute); short captures still fill the GPU
+    const long long n1_total = factor2 ? ((long long)n_out - 1) * factor2 + ntaps2 : (long long)n_out;
+    long long ni = 16;
+    if (const char *e = getenv("WFX_INGEST_NI")) ni = std::max(1, atoi(e));
+    while (ni > 1 && n1_total * nbatch / (ni * IG_BLK) < 2048) ni >>= 1;
+    long long run_out = ni * IG_BLK;
+    if (factor2) {
+        run_out = (ni * IG_BLK - (ntaps2 - factor2)) / factor2;
+        if (run_out < 1) return 0;
+    }
+    const long long runs = ((long long)n_out + run_out - 1) / run_out;
+    if (runs > 0x7fffffffll) return 0;
+    ig_params P;
+    P.in = in;
+    P.n_in = (long long)n_in;
+    P.sc = ldexp(in_kind == WFX_IN_I16_STEREO ? 0.5 : 1.0, -fix_shift);
+    P.nper = nper;
+    P.ntaps2 = ntaps2;
+    P.out = out;
+    P.n_out = (long long)n_out;
+    P.run_out = run_out;
+    P.in_bs = nbatch > 1 ? (long long)in_stride * fb : 0;
+    P.out_bs = nbatch > 1 ? (long long)out_stride : 0;
+    P.run0 = 0;
+    P.dbg_rows = IG_HALO;
+    P.dbg_flags = 0;
+    if (const char *e = getenv("WFX_INGEST_DBG")) sscanf(e, "%d,%d", &P.dbg_rows, &P.dbg_flags);
+    // runs whose last block of frames ends inside the capture load without range checks; the few behind them are launched on their own
+    // with the checked form of the kernel
+    const long long blk_frames = (long long)IG_BLK * IG_M;
+    const long long run_y1 = factor2 ? run_out * factor2 : run_out;       // stage-1 outputs between the starts of two runs
+    const long long run_iters = factor2 ? (run_y1 - factor2 + ntaps2 + IG_BLK - 1) / IG_BLK : ni;
+    const long long run_frames = (IG_HALO + run_iters * IG_BLK) * (long long)IG_M;
+    long long full = 0;                                                    // run r is unchecked iff r * run_y1 * 32 + run_frames <= n_in
+    if ((long long)n_in >= run_frames) full = std::min(runs, ((long long)n_in - run_frames) / (run_y1 * IG_M) + 1);
+    (void)blk_frames;
+    typedef void (*kern_t)(const ig_params, const int *, const double *);
+    auto pick = [&](bool guard) -> kern_t {
+        if (in_kind == WFX_IN_I16_STEREO) {
+            if (guard) return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_STEREO, 0, true> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_STEREO, 2, true> : ingest_stream_kernel<WFX_IN_I16_STEREO, 3, true>;
+            return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_STEREO, 0, false> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_STEREO, 2, false> : ingest_stream_kernel<WFX_IN_I16_STEREO, 3, false>;
+        }
+        if (guard) return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_MONO, 0, true> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_MONO, 2, true> : ingest_stream_kernel<WFX_IN_I16_MONO, 3, true>;
+        return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_MONO, 0, false> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_MONO, 2, false> : ingest_stream_kernel<WFX_IN_I16_MONO, 3, false>;
+    };
+    const size_t lds = (size_t)IG_XS_BYTES + (factor2 ? (size_t)IG_YS_BYTES : 0);
+    wfx_prof_begin(ctx, K_POLYPHASE_IN);                                  // (one record: the checked tail is part of the same pass)
+    if (full > 0) hipLaunchKernelGGL(pick(false), dim3((unsigned)full, (unsigned)nbatch), dim3(IG_THREADS), lds, ctx->stream, P, dtab, dc2);
+    if (full < runs) {
+        P.run0 = full;
+        hipLaunchKernelGGL(pick(true), dim3((unsigned)(runs - full), (unsigned)nbatch), dim3(IG_THREADS), lds, ctx->stream, P, dtab, dc2);
+    }
+    wfx_prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch ingest_stream_kernel");
+    *handled = 1;
+    return 0;
+}

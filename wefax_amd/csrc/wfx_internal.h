@@ -359,6 +359,12 @@ int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long
 int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const double *coef, int ntaps,
                            double *out, uint64_t n_out, int fix_shift, int *exact_out, int nbatch = 1, uint64_t in_stride = 0, uint64_t out_stride = 0);
 
+// wfx_ingest.hip: the streaming form of the ingest (factor 32, int16 frames, taps on a 2^-s grid) with the float64 stage behind it
+// fused (factor2 = 2 or 3; 0: stage 1 alone).  *handled = 0 and nothing enqueued when the shapes are not its own
+int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int factor, const double *coef1, int ntaps1, int fix_shift,
+                          int factor2, const double *coef2, int ntaps2, double *out, uint64_t n_out, int nbatch, uint64_t in_stride,
+                          uint64_t out_stride, int *handled);
+
 // wfx_comm.hip: the communicator behind the sharded decode (RCCL bound directly, or every rank in this process)
 struct wfx_xfer {            // one message pair of a personalised exchange; several entries per peer are matched in order
     int peer;

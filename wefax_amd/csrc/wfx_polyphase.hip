@@ -512,6 +512,17 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
     const long long in_bs = nbatch > 1 ? (long long)in_stride * ebytes : 0, out_bs = nbatch > 1 ? (long long)out_stride : 0;
     if (in_bs % 16) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "decimate: the members of a batch must start a multiple of 16 bytes apart (%lld)", in_bs);
     const bool aligned = M >= per16 && ilog2_exact(M) >= 0;
+    // the streaming kernel (wfx_ingest.hip) takes the ingest when the first window sits on the 16-byte grid (no tap shift needed)
+    if (aligned && in_kind != WFX_IN_F64_MONO && fix_shift >= 8 && first >= 0 && (uint64_t)first < n_in && (first + misalign) % per16 == 0 &&
+        !getenv("WFX_FE_NO_EXACT")) {
+        int handled = 0;
+        WFX_TRY(wfx_dev_ingest_stream(ctx, (const unsigned char *)in + (size_t)first * ebytes, in_kind, n_in - (uint64_t)first, M, coef, ntaps, fix_shift,
+                                      0, nullptr, 0, out, n_out, nbatch, in_stride, out_stride, &handled));
+        if (handled) {
+            if (exact_out) *exact_out = 1;
+            return 0;
+        }
+    }
     int d = 0;
     if (aligned) {
         d = (int)(((first + misalign) % per16 + per16) % per16);

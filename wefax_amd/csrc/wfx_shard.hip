@@ -685,7 +685,14 @@ static int run_phase_cols(wfx_shard *sh, int ph)
                 const long long qe = (pl.K - 1) / pl.Ms;
                 const long long e = (long long)pl.n - (2 * (qe * pl.Ms + pl.cH0) - pl.hs);
                 flags &= 1;
-                if (e < pl.hs)
+                // (the LAST rank's segment of row qe - 1 ends with row qe's first columns as its right halo: a capture that ends up to
+                // 63 samples behind a row boundary has part of filtfilt's edge -- the last 64 outputs -- among this rank's own samples
+                // of row qe - 1, and the edge is then applied where the capture ends inside that halo)
+                const long long e1 = qe > 0 ? e + 2 * pl.Ms : -1;        // the end relative to this rank's segment of row qe - 1
+                if (e < pl.hs && me == W - 1 && e1 >= pl.hs && e1 <= pl.xrs) {
+                    hi = (uint64_t)(qe - 1) * (uint64_t)pl.xrs + (uint64_t)e1;
+                    flags |= 2;
+                } else if (e < pl.hs)
                     hi = (uint64_t)qe * (uint64_t)pl.xrs;                 // nothing of row qe is this rank's
                 else if (e <= pl.xrs) {
                     hi = (uint64_t)qe * (uint64_t)pl.xrs + (uint64_t)e;

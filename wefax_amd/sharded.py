@@ -20,6 +20,7 @@ frames, and drives the phases.  No PyTorch anywhere: the communicator is RCCL bo
 """
 from __future__ import annotations
 
+import os
 import socket
 import struct
 import time
@@ -378,23 +379,43 @@ class FrontEndDevice:
         self.stage_stride = {}
         for k, (st, (a, b), _) in enumerate(chain[:-1]):
             stride = (b - a) + ((b - a) & 1)                    # members of a batch start a multiple of 16 bytes apart
-            self.stage_stride[k] = stride
-            self.p_stage[k] = self._alloc(8 * stride * self.nbatch)
+            self.stage_stride[k] = stride           # (buffers on first use: the fused ingest never needs stage 0's)
         self.exact_ingest = None
+        self.fused_ingest = False           # run() took the one-kernel form of the first two stages (csrc/wfx_ingest.hip)
 
     def _alloc(self, nbytes):
         p = self.ctx.dev_malloc(nbytes)
         self.ptrs.append(p)
         return p
 
+    def _stage(self, k):
+        if k not in self.p_stage:
+            self.p_stage[k] = self._alloc(8 * self.stage_stride[k] * self.nbatch)
+        return self.p_stage[k]
+
     def run(self):
         """Enqueue the chain (asynchronous); the float64 audio of the slice ends at ``p_out``."""
         cur, kind, n_cur = self.p_raw, self.in_kind, self.n_raw
+        first_stage = 0
+        if len(self.chain) >= 2 and self.chain[0][0].fix_shift and not os.environ.get("WFX_FE_UNFUSED"):
+            # the ingest and the stage behind it in ONE streaming kernel (csrc/wfx_ingest.hip): the intermediate rate never reaches
+            # memory; bit-identical to the two launches below, which run when the shapes are not that kernel's
+            (s1, _, (ia, ib)), (s2, (a, b), _) = self.chain[0], self.chain[1]
+            assert ib - ia == n_cur, (ib - ia, n_cur)
+            last = len(self.chain) == 2
+            out = self.p_out if last else self._stage(1)
+            if self.ctx.d_ingest_chain(cur, kind, n_cur, s1.factor, s1.coef64, s1.fix_shift, s2.factor, s2.coef64, out, b - a, nbatch=self.nbatch,
+                                       in_stride=self.raw_stride, out_stride=(b - a) if last else self.stage_stride[1]):
+                self.exact_ingest = True
+                self.fused_ingest = True
+                cur, kind, n_cur, first_stage = out, nat.WFX_IN_F64_MONO, b - a, 2
         for k, (st, (a, b), (ia, ib)) in enumerate(self.chain):
+            if k < first_stage:
+                continue
             assert ib - ia == n_cur, (ib - ia, n_cur)
             last = k == len(self.chain) - 1
             n_out = b - a
-            out = self.p_out if last else self.p_stage[k]
+            out = self.p_out if last else self._stage(k)
             in_stride = self.raw_stride if k == 0 else self.stage_stride[k - 1]
             ex = self.ctx.d_decimate_fir64(cur, kind, n_cur, 0, st.factor, st.coef64, out, n_out, st.fix_shift if k == 0 else 0,
                                            nbatch=self.nbatch, in_stride=in_stride, out_stride=n_out if last else self.stage_stride[k])

@@ -102,6 +102,19 @@ def release_contexts():
         c.close()
 
 
+_FE_CACHE: dict = {}
+
+
+def _front_end_for(sample_rate: int):
+    """polyphase.FrontEnd per input rate (the least-squares designs of the 1.536 MS/s pair take 2 s: once per process)."""
+    from . import polyphase
+    if sample_rate not in _FE_CACHE:
+        if sample_rate != int(sample_rate):
+            raise ValueError("not an integer rate")
+        _FE_CACHE[sample_rate] = polyphase.FrontEnd(int(sample_rate))
+    return _FE_CACHE[sample_rate]
+
+
 class DecodeJob:
     """One capture resident on the GPU: upload once, run the path any number of
     times (bench.py times ``run()``), then read results."""
@@ -231,7 +244,16 @@ class Demodulator:
                  quiet: bool = False,
                  tcp_stream: bool = True,
                  device: int | None = None,
-                 hilbert_mode: int = DEFAULT_HILBERT_MODE):
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE,
+                 front_end: str | None = None):
+        """``front_end`` (not in the reference; default ``"exact"``, or the environment's WEFAX_FRONT_END): how a capture that is not
+        at 11 025 Hz gets there.  ``"exact"``: the reference's own operators -- merge, then ONE FFT resample over the whole capture
+        (wefax.py:351-394), bit-identical to it.  ``"time-domain"``: int16 captures at integer rates >= 28 kHz go through the
+        halo-local decimator chain of wefax_amd/polyphase.py (1.536 MS/s: / 32 integer-exact and / 3 float64 in one streaming
+        kernel) down to a hand-over rate, where the exact FFT resampler takes the last step -- the form BASELINE configs[3] is
+        timed on and the one that shards; uint8 stream and image within 1 grey level of the reference's (measured: identical on
+        98 % of random clips, tests/test_polyphase.py).  Captures that form cannot keep the reference's sampling grid for (other
+        dtypes, rates, lengths that are not a whole number of hand-over samples) take the exact route either way."""
         if not os.path.exists(filepath):                                   # wefax.py:24-25
             raise Exception(f"INVALID FILE: file at path: {filepath} does not exist")
         if filepath.split('.')[-1] != 'wav':                               # wefax.py:27-28
@@ -245,6 +267,12 @@ class Demodulator:
         self.websocket_stack = []
         self._device = _device_index(device)
         self._hilbert_mode = hilbert_mode
+        front_end = front_end or os.environ.get("WEFAX_FRONT_END", "exact")
+        if front_end not in ("exact", "time-domain"):
+            raise ValueError(f"front_end: 'exact' or 'time-domain', not {front_end!r}")
+        self.front_end = front_end
+        self.front_end_used = None          # after process(): which of the two ran
+        self._fe_dec = None
         self._ctx = None
         self._job = None
         self._cache = {}
@@ -296,10 +324,16 @@ class Demodulator:
             self._progress("resampling audio", 0)
 
         notch = hp.load_notch_settings()
-        job = DecodeJob(self._ctx, data, sample_rate, self.lines_per_minute, notch,
-                        self._hilbert_mode)
+        if self._fe_dec is not None:
+            self._fe_dec.close()
+            self._fe_dec = None
+        job = self._time_domain_job(data, sample_rate) if (self.front_end == "time-domain" and sample_rate != hp.TARGET_RATE) else None
+        self.front_end_used = "time-domain" if job is not None else "exact"
+        if job is None:
+            job = DecodeJob(self._ctx, data, sample_rate, self.lines_per_minute, notch,
+                            self._hilbert_mode)
+            job.run()
         self._job = job
-        job.run()
         info = job.result()
 
         if sample_rate != hp.TARGET_RATE:
@@ -344,6 +378,24 @@ class Demodulator:
         if self.stream:                                                     # wefax.py:87-90
             self._send_websocket_packet({"data_type": "message",
                                          "message_content": "convert_end"})
+
+    def _time_domain_job(self, data, sample_rate):
+        """The opt-in route of ``front_end="time-domain"``: decimator chain on the device, then the fused exact decode attached to its
+        output (sharded.FrontEndExactDecoder).  None when the capture is not one this route keeps the reference's grid for."""
+        from . import polyphase, sharded
+        if data.dtype != np.int16 or data.ndim > 2 or (data.ndim == 2 and data.shape[1] != 2):
+            return None
+        try:
+            fe = _front_end_for(int(sample_rate))
+            fe.n_out(int(data.shape[0]))
+        except ValueError:
+            return None
+        if fe.n_target(int(data.shape[0])) < 2:
+            return None
+        dec = sharded.FrontEndExactDecoder(self._ctx, fe, data, lines_per_minute=self.lines_per_minute)
+        self._fe_dec = dec
+        dec.run()
+        return dec.job
 
     # stage arrays, copied back on demand -----------------------------------------
     def _lazy(self, key):
@@ -420,6 +472,13 @@ class Demodulator:
     def close(self):
         """Hand the context back (the image, if nobody has looked at it yet, goes with it)."""
         ctx, self._ctx, self._job = self._ctx, None, None
+        if self._fe_dec is not None and ctx is not None:
+            try:
+                ctx.sync()
+                self._fe_dec.fe.close()          # (the job inside it belongs to the context)
+            except Exception:       # noqa: BLE001 -- a context that is already gone
+                pass
+        self._fe_dec = None
         if ctx is not None:
             _release_context(ctx, self._device)
 
