@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1,
                     help="captures decoded concurrently per GPU, one native context (= HIP stream) each; "
                          "BASELINE configs[4] uses 8 per GPU with mixed 120/240 LPM, IOC576/288 members")
+    ap.add_argument("--rccl-probe", action="store_true", help=argparse.SUPPRESS)      # child of a rank: RCCL bootstrap + self-test, see Ranks
     return ap.parse_args()
 
 
@@ -155,9 +156,68 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+def _rank_env():
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    mport = int(os.environ.get("MASTER_PORT", "29511"))
+    # spawn_ranks reserves a port of its own; under a launcher: next to its rendezvous port, kept inside the valid range
+    port = int(os.environ.get("WFX_BOOT_PORT", str(mport + 1009 if mport + 1009 + 16 < 65536 else mport - 1009)))
+    return addr, mport, port
+
+
+def _rank_device(nat) -> int:
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("WFX_BENCH_OVERSUBSCRIBE") == "1":       # several ranks per GPU: only to exercise the launch path on a small box
+        dev = dev % max(1, nat.device_count())
+    return dev
+
+
+def rccl_probe_main() -> int:
+    """`bench.py --rccl-probe`, started by every rank as a CHILD before it creates its own communicator: RCCL bootstrap, the first
+    collective, and the communicator's self-test (grouped send / recv exchanges in stream order and on the communicator's own stream,
+    all-reduce, all-gather, every answer checked).  One line on stdout: `ok`, or the error text.  A hang -- a bootstrap that never
+    completes, P2P that does not come up -- stays in this child, which its parent kills after a time limit; the parent then runs
+    the job on the host-staged transport and reports why."""
+    from wefax_amd import _native as nat
+    from wefax_amd import sharded
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    addr, mport, port = _rank_env()
+    nonce = os.environ.get("WFX_JOB_NONCE", f"{addr}:{mport}") + ":probe"
+    t0 = time.time()
+    try:
+        ctx = nat.Context(_rank_device(nat))
+        with _StdoutToStderr():
+            uid = sharded.bootstrap_unique_id(rank, world, addr=addr, port=port, nonce=nonce, timeout=float(os.environ.get("WFX_BENCH_RCCL_PROBE_S", "75")))
+            comm = nat.Comm.rccl(ctx, uid, world, rank)
+            comm.barrier(ctx)
+            sys.stderr.write(f"rccl probe rank {rank}: communicator up after {time.time() - t0:.1f} s\n")
+            comm.selftest(ctx, 3, 20261004)
+            comm.barrier(ctx)
+        comm.close()
+        ctx.close()
+    except Exception as e:      # noqa: BLE001 -- the text IS the result
+        print(("error: " + f"{type(e).__name__}: {e}").replace("\n", " ")[:300], flush=True)
+        return 1
+    print(f"ok ({time.time() - t0:.1f} s)", flush=True)
+    return 0
+
+
 class Ranks:
     """This process's place in the job: context on its GPU, RCCL communicator when there is more than one rank (or when
     WFX_BENCH_FORCE_DIST=1 asks for the real transport with a single rank on a one-GPU box)."""
+
+    def _probe_rccl(self) -> str:
+        """Run the RCCL self-test in a child of this rank (see rccl_probe_main); 'ok ...' or what went wrong, never a hang."""
+        limit = float(os.environ.get("WFX_BENCH_RCCL_PROBE_S", "75"))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-probe"], capture_output=True, text=True, timeout=limit + 15)
+            last = (r.stdout.strip().splitlines() or ["(no output)"])[-1]
+            if r.returncode == 0 and last.startswith("ok"):
+                return last
+            tail = " | ".join(ln for ln in r.stderr.strip().splitlines()[-3:])
+            return f"rc {r.returncode}: {last}" + (f" [stderr: {tail[-300:]}]" if tail and not last.startswith("error") else "")
+        except subprocess.TimeoutExpired:
+            return (f"timeout: RCCL bootstrap + self-test of {self.world} ranks did not complete within {limit + 15:.0f} s on rank {self.rank} "
+                    "(communicator never came up, or a send/recv never completed)")
 
     def __init__(self, args):
         from wefax_amd import _native as nat
@@ -168,36 +228,53 @@ class Ranks:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if args.gpus != self.world and self.world > 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
-        dev = self.local_rank
-        if os.environ.get("WFX_BENCH_OVERSUBSCRIBE") == "1":       # several ranks per GPU: only to exercise the launch path on a small box
-            dev = self.local_rank % max(1, nat.device_count())
+        dev = _rank_device(nat)
         self.device = dev
-        self.ctx = nat.Context(dev)
+        self.rccl_probe = None               # what the RCCL self-test said (world > 1 on RCCL only)
         self.use_rccl = self.world > 1 or os.environ.get("WFX_BENCH_FORCE_DIST") == "1"
         # transport: RCCL (one rank per GPU), or the library's shared-memory communicator -- real processes, host-staged messages --
         # where RCCL cannot run the job: several ranks on ONE GPU (WFX_BENCH_OVERSUBSCRIBE=1 on a box with fewer devices than ranks).
         # WFX_BENCH_COMM=rccl|shm forces one.
         over = os.environ.get("WFX_BENCH_OVERSUBSCRIBE") == "1"
         self.transport = os.environ.get("WFX_BENCH_COMM") or ("shm" if over and self.world > max(1, nat.device_count()) else "rccl")
-        if self.use_rccl and self.transport == "shm":
+        addr, mport, port = _rank_env()
+        # Before this rank touches RCCL itself, a CHILD of it runs the RCCL bootstrap and the communicator's self-test under a time
+        # limit (rccl_probe_main).  All ranks then compare notes over the host-staged communicator (plain shared memory and sockets):
+        # unanimous `ok` -> RCCL; anything else -> the job runs on the host-staged transport (the weak-scaling headline has no
+        # data-path collective and is measured all the same) and the line carries every rank's verdict in `rccl_probe`.
+        probing = self.world > 1 and self.transport == "rccl" and os.environ.get("WFX_BENCH_RCCL_PROBE", "1") != "0"
+        verdict = self._probe_rccl() if probing else None
+        self.ctx = nat.Context(dev)
+        if self.use_rccl and (self.transport == "shm" or probing):
             job = os.environ.get("WFX_JOB_NONCE")
             if not job:
                 # under a launcher there is no nonce from spawn_ranks: rank 0 draws one per LAUNCH and hands it out over the
                 # bootstrap socket (a job name reused across launches would let a rank attach to the control block a crashed
                 # earlier run left in /dev/shm)
-                addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-                mport = int(os.environ.get("MASTER_PORT", "29511"))
-                port = int(os.environ.get("WFX_BOOT_PORT", str(mport + 1009 if mport + 1009 + 16 < 65536 else mport - 1009)))
-                blob = sharded.bootstrap_unique_id(self.rank, self.world, addr=addr, port=port, nonce=f"{addr}:{mport}",
+                blob = sharded.bootstrap_unique_id(self.rank, self.world, addr=addr, port=port, nonce=f"{addr}:{mport}:job",
                                                    make_id=lambda: os.urandom(nat.WFX_COMM_ID_BYTES))
                 job = "p" + str(mport) + "-" + bytes(blob[:8]).hex()
-            self.comm = nat.Comm.shm(self.ctx, job, self.world, self.rank, timeout=float(os.environ.get("WFX_BENCH_TIMEOUT", "600")))
-            self.comm.barrier(self.ctx)
+            shm = nat.Comm.shm(self.ctx, job, self.world, self.rank, timeout=float(os.environ.get("WFX_BENCH_TIMEOUT", "600")))
+            shm.barrier(self.ctx)
+            if probing:
+                import numpy as np
+                mine = np.zeros(320, dtype=np.uint8)
+                raw = verdict.encode()[:320]
+                mine[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+                every = [bytes(row).rstrip(b"\0").decode(errors="replace") for row in shm.allgather(self.ctx, mine)]
+                self.rccl_probe = {"ok": all(v.startswith("ok") for v in every), "per_rank": every,
+                                   "what": "child process per rank: RCCL bootstrap, barrier, 3 rounds of checked exchanges (in stream order and on the "
+                                           "communicator's own stream) / all-reduce / all-gather, under a time limit"}
+                if self.rccl_probe["ok"]:
+                    shm.close()
+                else:
+                    self.transport = "shm"
+                    sys.stderr.write(f"bench.py rank {self.rank}: RCCL self-test failed ({every}); running on the host-staged transport\n")
+            if self.transport == "shm":
+                self.comm = shm
+        if self.use_rccl and self.transport == "shm":
+            pass
         elif self.use_rccl:
-            addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-            mport = int(os.environ.get("MASTER_PORT", "29511"))
-            # spawn_ranks reserves a port of its own; under a launcher: next to its rendezvous port, kept inside the valid range
-            port = int(os.environ.get("WFX_BOOT_PORT", str(mport + 1009 if mport + 1009 + 16 < 65536 else mport - 1009)))
             nonce = os.environ.get("WFX_JOB_NONCE", f"{addr}:{mport}")        # peers of another job on this host are turned away
             with _StdoutToStderr():
                 uid = sharded.bootstrap_unique_id(self.rank, self.world, addr=addr, port=port, nonce=nonce)
@@ -425,20 +502,32 @@ def iq_recipe(seconds: float):
 
 def wire_object(rk: Ranks, params, layout, run, sync) -> dict:
     """What one sharded decode puts on the wire: the plan's collectives with their bytes (host-only: every rank's exchange lists),
-    what THIS rank's communicator counted during one decode (transport-independent), and the cost model's figures behind the
-    choice of plan."""
+    what THIS rank's communicator counted AND TIMED during one decode -- per collective: `us` on the stream it ran on (HIP-event pair;
+    host clock on the blocking transports), `wait_us` the compute stream stood still for it, `hidden_us` = the rest (only an exchange
+    on the communicator's own stream can hide anything), `link_GBs` = its largest message / us -- and the cost model's figures
+    behind the choice of plan, so that ONE run on real links calibrates the model."""
     nat = rk.nat
     plan = nat.shard_wire_plan(params, rk.world)
-    rk.comm.wire_reset()
+    rk.comm.wire_timing(True)
     run()
     sync()
     mine = rk.comm.wire_stats()
+    times = rk.comm.wire_times()
+    rk.comm.wire_timing(False)
+    for e, t in zip(mine, times):
+        e.update(t)
+        e["link_GBs"] = round(e["largest_message"] / (t["us"] * 1e-6) / 1e9, 2) if (t["us"] and e["largest_message"]) else None
+    tot = lambda key: round(sum(e.get(key) or 0.0 for e in mine), 1)       # noqa: E731
     return {"layout": {0: "single (rank 0 alone)", 1: "rows", 2: "columns"}[int(layout.plan)], "chosen_by": "caller" if layout.plan_forced else "cost model",
             "reason": layout.plan_reason.decode(), "total_bytes": sum(e["bytes"] for e in plan),
             "array_transposes": sum(1 for e in plan if " E" in e["name"]),
             "per_collective": plan, "this_rank_sent": sum(e["sent"] for e in mine), "this_rank": mine,
-            "model": {"link_GBs": float(os.environ.get("WFX_LINK_GBS", "50")), "one_gpu_ms": round(1e3 * layout.model_single_s, 3),
+            "this_rank_us": {"collectives": tot("us"), "compute_stream_waited": tot("wait_us"), "hidden": tot("hidden_us"),
+                             "clock": sorted({str(e.get("clock")) for e in mine})},
+            "model": {"link_GBs": float(os.environ.get("WFX_LINK_GBS", "50")), "latency_us": float(os.environ.get("WFX_LINK_LAT_US", "20")),
+                      "one_gpu_ms": round(1e3 * layout.model_single_s, 3),
                       "dist_compute_ms": round(1e3 * layout.model_dist_compute_s, 3), "dist_wire_ms": round(1e3 * layout.model_dist_wire_s, 3),
+                      "dist_ms": round(1e3 * (layout.model_dist_compute_s + layout.model_dist_wire_s), 3),
                       "wire_bytes": int(layout.model_wire_bytes)}}
 
 
@@ -466,7 +555,23 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
     ctx.sync()
     t_syn = time.perf_counter() - t_syn
     state_before = GpuState.read()
-    dt = rk.timed(dec.run, steps, max(warmup, 1))
+    # The shader clock of an idle MI355X takes ~10 decodes (40-80 ms of work) to come up -- consecutive launches of the ingest kernel
+    # right after an idle second read 5.4, 4.2, 4.0, 3.8, 3.7 ... 3.5 ms (tools/ingest_lab.py) -- so this object warms up by TIME:
+    # untimed decodes until 0.3 s have passed (at least `warmup`), the count is printed as `warmup_steps`
+    wsteps, t_w = max(warmup, 1), time.perf_counter()
+    for _ in range(wsteps):
+        dec.run()
+    ctx.sync()
+    spent = time.perf_counter() - t_w
+    import numpy as np
+    extra = int(min(200, np.ceil(max(0.0, float(os.environ.get("WFX_BENCH_C4_WARM_S", "0.3")) - spent) / max(spent / wsteps, 1e-4))))
+    if rk.world > 1:       # every rank runs the same number of decodes (they carry collectives): rank 0's count
+        extra = int(rk.comm.allgather(ctx, np.array([extra], dtype=np.int64))[0][0])
+    for _ in range(extra):
+        dec.run()
+    ctx.sync()
+    wsteps += extra
+    dt = rk.timed(dec.run, steps, 0)
     ms = 1e3 * dt / steps
     # step by step (after the timed region, same buffers): wall time of every decode and the HIP-event time of its ingest launch, with
     # the clocks / power / temperature sampled meanwhile -- a slow box shows in the clocks, a slow kernel in the distribution
@@ -496,7 +601,7 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
                      f"{'columns layout: 4' if dec.layout.plan == 2 else 'rows layout: 8'} array transposes, 2 histogram all-reduces, 1 candidate all-gather, "
                      "1 stream gather per decode)")),
            "front_end": fe.describe() + f" -> exact FFT resample {fe.out_rate} -> 11025 Hz",
-           "ms_per_step": round(ms, 4), "value": round(n0 / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "steps": steps,
+           "ms_per_step": round(ms, 4), "value": round(n0 / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "steps": steps, "warmup_steps": wsteps,
            "synthesis_s": round(t_syn, 2), "dtype": "i16 integer-exact ingest / f64 everywhere behind it",
            "start_frame": int(info.start_frame) if rk.rank == 0 else None, "image": [int(info.width), 4 * int(info.height)] if rk.rank == 0 else None,
            "roofline": roofline_of(prof, 1, alg_bytes, ms, pmc, merge_fft=True), "kernels": kernel_table(prof, 1),
@@ -508,7 +613,26 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
         out["front_end"] += " [stages 1+2 in one streaming kernel, csrc/wfx_ingest.hip]"
     if not fused:
         out["wire"] = wire_object(rk, dec.dec.params, dec.layout, dec.run, ctx.sync)
+        m = out["wire"]["model"]
+        out["model_ms"] = m["one_gpu_ms"] if dec.layout.plan == 0 else m["dist_ms"]
+        out["measured_ms"] = out["ms_per_step"]
     dec.close()
+    if not fused and rk.world > 1 and args.plan == "auto" and os.environ.get("WFX_BENCH_BOTH_PLANS", "1") != "0":
+        # the other side of the cost model's decision, in the same run: the distributed plan forced (when `auto` chose it too, this
+        # is a second measurement of it).  model_ms beside measured_ms for both is what calibrates WFX_LINK_GBS / WFX_LINK_LAT_US
+        try:
+            d2 = sharded.FrontEndShardedDecoder(ctx, rk.comm, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,
+                                                raw_loader=raw_loader, plan="dist")
+            dt2 = rk.timed(d2.run, max(2, steps // 2), 1)
+            ms2 = 1e3 * dt2 / max(2, steps // 2)
+            w2 = wire_object(rk, d2.dec.params, d2.layout, d2.run, ctx.sync)
+            i2 = d2.result()
+            out["forced_dist"] = {"plan": "dist", "ms_per_step": round(ms2, 4), "measured_ms": round(ms2, 4), "model_ms": w2["model"]["dist_ms"],
+                                  "start_frame": int(i2.start_frame) if rk.rank == 0 else None, "wire": w2,
+                                  "kernels": kernel_table(profile_pass(ctx, d2.run, 1), 1)}
+            d2.close()
+        except Exception as e:      # noqa: BLE001 -- a layout the distributed plan does not take: said, not fatal
+            out["forced_dist"] = {"plan": "dist", "error": f"{type(e).__name__}: {e}"[:300]}
     raw_loader.close()
     # the one-GPU time of the same stream, measured in this run on rank 0, and the efficiency against it
     if rk.world > 1:
@@ -823,7 +947,9 @@ class _LineGuard:
         self.line, self.rk, self.seconds = line, rk, seconds
         self.lock = threading.Lock()
         self.done = False
-        self.timer = threading.Timer(seconds, self._fire)
+        # (rank 0's guard prints the line; the other ranks' guards fire a little later, so that their non-zero exit -- on which a
+        # parent that spawned the ranks terminates the rest -- cannot cut rank 0 off before the line is out)
+        self.timer = threading.Timer(seconds + (0.0 if rk.rank == 0 else 10.0), self._fire)
         self.timer.daemon = True
         self.timer.start()
 
@@ -855,6 +981,8 @@ class _LineGuard:
 
 def main():
     args = parse()
+    if args.rccl_probe:
+        sys.exit(rccl_probe_main())
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     rk = Ranks(args)
@@ -869,7 +997,8 @@ def main():
                     "roofline": c4["roofline"], "cpu_baseline": c4.get("cpu_baseline"), "kernels": c4["kernels"],
                     "one_gpu_ms": c4.get("one_gpu_ms"), "speedup_vs_one_gpu": c4.get("speedup_vs_one_gpu"),
                     "efficiency_vs_one_gpu": c4.get("efficiency_vs_one_gpu"), "transport": c4.get("transport"), "wire": c4.get("wire"),
-                    "per_step": c4.get("per_step"), "gpu_state": c4.get("gpu_state")}
+                    "per_step": c4.get("per_step"), "gpu_state": c4.get("gpu_state"), "model_ms": c4.get("model_ms"),
+                    "measured_ms": c4.get("measured_ms"), "forced_dist": c4.get("forced_dist")}
         elif args.workload == "c3":
             line = bench_c3(args, rk)
         else:
@@ -898,6 +1027,8 @@ def main():
                     if rk.world == 1:
                         raise
                     line["c4_strong"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if rk.rccl_probe is not None:
+            line["rccl_probe"] = rk.rccl_probe
         if guard is None or guard.claim():
             if rk.rank == 0:
                 print(json.dumps(line), flush=True)

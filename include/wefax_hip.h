@@ -305,6 +305,10 @@ int wfx_d_decimate_fir64_batch(wfx_ctx *ctx, const void *in_dev, int in_kind, si
 int wfx_d_ingest_chain(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int factor, const double *coef1, int ntaps1, int fix_shift,
                        int factor2, const double *coef2, int ntaps2, double *out_dev, size_t n_out, int nbatch, size_t in_stride, size_t out_stride,
                        int *handled);
+/* measurement aid: GB/s at which this GPU reads `bytes` (>= 1 MiB, 16-byte aligned) of device memory with a kernel that only loads
+ * (16-byte loads, 16 in flight per lane, 64 KiB blocks), best of `reps` launches by HIP events; waits for the stream.  bench.py puts
+ * the ingest kernel's rate beside it: a slow box shows here, a slow kernel in the ratio */
+int wfx_d_read_rate(wfx_ctx *ctx, const void *dev, size_t bytes, int reps, double *gbs);
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev);
 /* a8: one level of the radix select: hist_dev[q*2048 + digit] += count over values whose bits above the level equal prefix[q] */
 int wfx_d_select_hist(wfx_ctx *ctx, const double *env_dev, size_t n, int level, const uint64_t prefix[4], uint32_t *hist_dev);

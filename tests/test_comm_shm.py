@@ -248,3 +248,35 @@ def test_candidate_overflow_is_repeated_inside_the_library_on_real_ranks():
     job = _job()
     out = _run(2, _silence_worker, lambda r: (job, r), timeout=300)
     assert out == {0: "ok", 1: "ok"}, out
+
+
+def _timed_worker(job, world, rank, q):
+    try:
+        comm = nat.Comm.shm(None, job, world, rank, timeout=30.0)
+        comm.wire_timing(True)
+        comm.selftest(None, 3, 99)
+        stats, times = comm.wire_stats(), comm.wire_times()
+        comm.wire_timing(False)
+        comm.selftest(None, 1, 5)
+        after = (len(comm.wire_stats()), len(comm.wire_times()), [t["clock"] for t in comm.wire_times()])
+        comm.barrier(None)
+        comm.close()
+        q.put((rank, (stats, times, after)))
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}"))
+
+
+def test_collectives_are_timed_one_record_each_in_call_order():
+    """wfx_comm_wire_timing / wfx_comm_wire_times (round 5): one time record per collective, parallel to the byte records -- the shape
+    `bench.py` prints per collective (`us`, `wait_us`, `hidden_us`, `stream`, `clock`).  On this transport a collective completes
+    before the call returns: the host clock times it and nothing of it is hidden."""
+    job = _job()
+    out = _run(2, _timed_worker, lambda r: (job, 2, r))
+    for r in range(2):
+        assert not isinstance(out[r], str), out[r]
+        stats, times, after = out[r]
+        assert len(stats) == len(times) == 9 and [s["name"] for s in stats] == ["exchange", "all-reduce", "all-gather"] * 3
+        for t in times:
+            assert set(t) == {"us", "wait_us", "hidden_us", "stream", "clock"}
+            assert t["clock"] == "host" and t["stream"] == "context" and t["us"] >= 0 and t["wait_us"] == t["us"] and t["hidden_us"] == 0
+        assert after == (3, 3, [None, None, None])          # timing off: records are counted, not timed

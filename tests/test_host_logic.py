@@ -34,6 +34,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
 #include <stddef.h>
 #include "wefax_hip.h"
 int main(void) {
+  printf("%zu %zu %zu %zu ", sizeof(wfx_wire_entry), sizeof(wfx_wire_time), offsetof(wfx_wire_time, wait_us), offsetof(wfx_wire_time, timed));
   printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(wfx_decode_params), offsetof(wfx_decode_params, notch_b),
          offsetof(wfx_decode_params, rank_lo), offsetof(wfx_decode_params, mindistance),
          offsetof(wfx_decode_params, width), sizeof(wfx_decode_info), offsetof(wfx_decode_info, peak_pos),
@@ -44,6 +45,9 @@ int main(void) {
     subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     P, I, L, S = nat.DecodeParams, nat.DecodeInfo, nat.ShardLayout, nat.SynthParams
+    W, T = nat.WireEntry, nat.WireTime
+    assert got[:4] == [ctypes.sizeof(W), ctypes.sizeof(T), T.wait_us.offset, T.timed.offset]
+    got = got[4:]
     assert got == [ctypes.sizeof(P), P.notch_b.offset, P.rank_lo.offset, P.mindistance.offset, P.width.offset,
                    ctypes.sizeof(I), I.peak_pos.offset, P.ext_left.offset, ctypes.sizeof(L), L.in_lo.offset,
                    ctypes.sizeof(S), S.seed.offset, S.iq.offset]

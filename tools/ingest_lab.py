@@ -56,16 +56,31 @@ def report(name, dt):
     print(f"{name:44s} {dt * 1e3:8.3f} ms  {frames * 4 / dt / 1e12:5.2f} TB/s", flush=True)
 
 
+print(f"plain read of the same buffer: {ctx.d_read_rate(p_in, frames * 4, 3) / 1e3:.2f} TB/s", flush=True)
+# does the clock ramp?  consecutive calls right after an idle second, each timed on its own
+time.sleep(1.0)
+seq = []
+for _ in range(40):
+    t0 = time.perf_counter()
+    fused()
+    ctx.sync()
+    seq.append(1e3 * (time.perf_counter() - t0))
+print("consecutive fused calls after 1 s idle (ms):", " ".join(f"{v:.2f}" for v in seq), flush=True)
 report("fused", timed(fused))
 report("stage 1 only (y1 to memory)", timed(stage1_only))
 os.environ["WFX_INGEST_TILE"] = "1"
 report("tile kernel (rounds 1-4), stage 1", timed(tile))
 del os.environ["WFX_INGEST_TILE"]
-for rows, flags in ((8, 2), (6, 2), (4, 2), (2, 2), (0, 2), (0, 3), (8, 3), (8, 0), (0, 0)):
+for rows, flags in ((8, 0), (8, 2), (0, 2), (0, 3), (0, 7), (0, 15), (8, 10)):
     os.environ["WFX_INGEST_DBG"] = f"{rows},{flags}"
-    report(f"fused  rows={rows} flags={flags} ({'no stash ' if flags & 1 else ''}{'no stage2' if flags & 2 else ''})", timed(fused))
+    what = " ".join(w for b, w in ((1, "no-stash"), (2, "no-stage2"), (4, "no-stage1"), (8, "no-barrier-B")) if flags & b)
+    report(f"fused  rows={rows} flags={flags} ({what})", timed(fused))
 del os.environ["WFX_INGEST_DBG"]
-for ni in (1, 2, 4, 8, 16, 32):
+for extra in (0, 8192, 36000, 100000):
+    os.environ["WFX_INGEST_DBG_LDS"] = str(extra)
+    report(f"fused  + {extra} bytes of LDS ({160 * 1024 // (46656 + extra)} workgroups per CU)", timed(fused))
+del os.environ["WFX_INGEST_DBG_LDS"]
+for ni in (4, 8, 16, 24):
     os.environ["WFX_INGEST_NI"] = str(ni)
     report(f"fused  run length {ni} iterations", timed(fused))
 del os.environ["WFX_INGEST_NI"]

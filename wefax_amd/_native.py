@@ -30,11 +30,11 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_read_rate", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
-    "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_wire_plan", "wfx_comm_wire_reset", "wfx_comm_wire_stats", "wfx_comm_async_exchanges", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
+    "wfx_shard_layout_query", "wfx_shard_dry_run", "wfx_shard_wire_plan", "wfx_comm_wire_reset", "wfx_comm_wire_stats", "wfx_comm_wire_timing", "wfx_comm_wire_times", "wfx_comm_async_exchanges", "wfx_shard_create", "wfx_shard_upload", "wfx_shard_attach", "wfx_shard_phase_count", "wfx_shard_phase",
     "wfx_decode_sharded", "wfx_shard_result", "wfx_shard_fetch", "wfx_shard_destroy",
     "wfx_synth_frames", "wfx_synth_capture", "wfx_decode_png", "wfx_decode_save_png", "wfx_decode_png_ex", "wfx_decode_save_png_ex", "wfx_host_alloc", "wfx_host_free",
     "wfx_decode_reload", "wfx_decode_fetch_async", "wfx_plan_padded_length", "wfx_plan_describe",
@@ -157,6 +157,10 @@ class WireEntry(C.Structure):
     _fields_ = [("name", C.c_char * 24), ("total_bytes", C.c_uint64), ("max_rank_bytes", C.c_uint64), ("max_link_bytes", C.c_uint64)]
 
 
+class WireTime(C.Structure):
+    _fields_ = [("us", C.c_double), ("wait_us", C.c_double), ("on_comm_stream", C.c_int), ("timed", C.c_int)]
+
+
 WFX_COMM_ID_BYTES = 128
 WFX_ERR_COMM = -5
 
@@ -223,6 +227,7 @@ def load():
     lib.wfx_d_notch_fir_f64.argtypes = [vp, vp, sz, dp, dp, vp, i]
     lib.wfx_d_decimate_fir64.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int)]
     lib.wfx_d_decimate_fir64_batch.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int), i, sz, sz]
+    lib.wfx_d_read_rate.argtypes = [vp, vp, sz, i, C.POINTER(C.c_double)]
     lib.wfx_d_ingest_chain.argtypes = [vp, vp, i, sz, i, vp, i, i, i, vp, i, vp, sz, i, sz, sz, C.POINTER(C.c_int)]
     lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
     lib.wfx_d_select_hist.argtypes = [vp, vp, sz, i, C.POINTER(C.c_uint64), vp]
@@ -245,6 +250,8 @@ def load():
     lib.wfx_comm_async_exchanges.argtypes = [vp]
     lib.wfx_comm_async_exchanges.restype = C.c_uint64
     lib.wfx_comm_wire_stats.argtypes = [vp, C.POINTER(WireEntry), i]
+    lib.wfx_comm_wire_timing.argtypes = [vp, i]
+    lib.wfx_comm_wire_times.argtypes = [vp, C.POINTER(WireTime), i]
     lib.wfx_shard_create.argtypes = [vp, vp, C.POINTER(DecodeParams), C.POINTER(vp)]
     lib.wfx_shard_upload.argtypes = [vp, vp]
     lib.wfx_shard_attach.argtypes = [vp, vp]
@@ -618,6 +625,12 @@ class Context:
                                                 int(nbatch), int(in_stride), int(out_stride), C.byref(handled)))
         return bool(handled.value)
 
+    def d_read_rate(self, ptr: int, nbytes: int, reps: int = 3) -> float:
+        """GB/s of a plain read of device memory (include/wefax_hip.h: wfx_d_read_rate): the box's read-stream ceiling."""
+        g = C.c_double(0.0)
+        self._check(self.lib.wfx_d_read_rate(self.h, C.c_void_p(ptr), int(nbytes), int(reps), C.byref(g)))
+        return float(g.value)
+
     def d_median5(self, in_ptr: int, n: int, out_ptr: int):
         self._check(self.lib.wfx_d_median5(self.h, C.c_void_p(in_ptr), n, C.c_void_p(out_ptr)))
 
@@ -747,6 +760,26 @@ class Comm:
         out = _wire_list(arr, max(0, min(n, 256)))
         for e in out:
             e["sent"], e["received"], e["largest_message"] = e.pop("bytes"), e.pop("max_rank_bytes"), e.pop("max_link_bytes")
+        return out
+
+    def wire_timing(self, on: bool = True):
+        """Reset the records and bracket every collective from now on with a HIP-event pair (RCCL) or the host clock (shm / local)."""
+        self.lib.wfx_comm_wire_timing(self.h, 1 if on else 0)
+
+    def wire_times(self) -> list:
+        """Per collective, parallel to ``wire_stats()`` (call after the streams were synchronised): ``us`` the collective itself,
+        ``wait_us`` what the compute stream stood still for it, ``hidden_us`` the rest (only an exchange on the communicator's own
+        stream can hide anything), ``clock`` = events / host / None (include/wefax_hip.h: wfx_comm_wire_times)."""
+        arr = (WireTime * 256)()
+        n = max(0, min(self.lib.wfx_comm_wire_times(self.h, arr, 256), 256))
+        out = []
+        for k in range(n):
+            t = arr[k]
+            ok = t.timed != 0 and t.us >= 0
+            wait = t.wait_us if (ok and t.wait_us >= 0) else None
+            out.append({"us": round(t.us, 2) if ok else None, "wait_us": round(wait, 2) if wait is not None else None,
+                        "hidden_us": round(max(0.0, t.us - wait), 2) if (ok and wait is not None) else None,
+                        "stream": "communicator" if t.on_comm_stream else "context", "clock": {0: None, 1: "events", 2: "host"}[int(t.timed)]})
         return out
 
     @classmethod

@@ -1111,7 +1111,11 @@ int wfx_comm_selftest(wfx_comm *comm, wfx_ctx *ctx, int rounds, uint64_t seed)
                 else list.push_back({me, sbuf.back(), m.bytes, d, m.bytes});      // (the send entry of a self message was skipped above)
             }
         }
-        WFX_TRY(wfx_comm_exchange(comm, ctx, list.data(), (int)list.size()));
+        if (ctx && (round & 1)) {      // odd rounds: on the communicator's own stream (RCCL), ordered back by wfx_comm_wait
+            WFX_TRY(wfx_comm_exchange_async(comm, ctx, list.data(), (int)list.size(), round % 64));
+            WFX_TRY(wfx_comm_wait(comm, ctx, round % 64));
+        } else
+            WFX_TRY(wfx_comm_exchange(comm, ctx, list.data(), (int)list.size()));
         if (ctx) WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (size_t q = 0; q < rbuf.size(); ++q) {
             std::vector<uint64_t> host(rmsg[q]->bytes / 8);

@@ -37,20 +37,29 @@
 
 namespace {
 
-constexpr int IG_THREADS = 256;
+#ifndef WFX_IG_THREADS
+#define WFX_IG_THREADS 256
+#endif
+constexpr int IG_THREADS = WFX_IG_THREADS;      // (build-time A/B switch; 128 threads x 256 outputs, six workgroups per CU, measured 3 % slower)
 constexpr int IG_M = 32;                        // stage-1 factor = frames per LDS row
-constexpr int IG_BLK = 512;                     // stage-1 outputs (= new LDS rows) per iteration: two per thread
+constexpr int IG_BLK = 2 * IG_THREADS;          // stage-1 outputs (= new LDS rows) per iteration: two per thread
 constexpr int IG_HALO = 8;                      // rows of history: a window spans 8 rows (<= 256 taps)
 constexpr int IG_ROWS = IG_BLK + IG_HALO;
 constexpr int IG_RD = IG_M / 2;                 // dwords per row
 constexpr int IG_NPAIR = 4 * IG_M;              // tap pairs per output (zero padded): 128
 constexpr int IG_NGRP = IG_NPAIR / 4;           // groups of four pairs = one ds_read_b128: 32 per output
-constexpr int IG_YRING = 1024, IG_YMIRROR = 128;
+constexpr int IG_YRING = 2 * IG_BLK, IG_YMIRROR = 128;      // (a power of two >= one iteration's outputs + a stage-2 window)
+static_assert(IG_YRING >= IG_BLK + IG_YMIRROR && IG_THREADS >= IG_HALO * (IG_M / 2), "ring / carry sizes");
+#ifndef WFX_IG_DBG_PIECES
+#define WFX_IG_DBG_PIECES 3
+#endif
+constexpr int IG_DBG_PIECES = WFX_IG_DBG_PIECES;      // (timing experiments only: fewer pieces give wrong sums)
 constexpr int IG_PIECE = 9;                      // a fixed-point tap is a * 2^18 + b * 2^9 + c with b, c in [-256, 255]
 
 __host__ __device__ constexpr int ig_row_off(int r) { return r * IG_RD + (r >> 1) * 4; }       // dword offset of row r
 constexpr int IG_XS_BYTES = ig_row_off(IG_ROWS) * 4;
-constexpr int IG_YS_BYTES = (IG_YRING + IG_YMIRROR) * 8;
+constexpr int IG_C2PAD = 120;                   // stage-2 taps in LDS, zero padded to whole trips of 12
+constexpr int IG_YS_BYTES = (IG_YRING + IG_YMIRROR + IG_C2PAD) * 8;
 
 typedef short ig_s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short ig_us2 __attribute__((ext_vector_type(2)));
@@ -70,13 +79,13 @@ struct ig_params {
     const void *in;
     long long n_in;             // frames readable behind `in`; anything beyond reads as zero
     double sc;                  // 2^-shift (IQ: half of it)
-    int nper, ntaps2;           // stage 2: taps per polyphase row of the table (zero padded), taps
+    int nper, ntaps2;           // stage 2: taps (nper: the tile kernel's padded row length, unused here)
     double *out;
     long long n_out;            // outputs of the last stage
     long long run_out;          // outputs per workgroup run
     long long in_bs, out_bs;    // batch strides (bytes / elements)
     long long run0;             // index of the launch's first run
-    int dbg_rows, dbg_flags;    // diagnostics (WFX_INGEST_DBG=rows,flags; results are WRONG unless 8,0): tap rows applied; 1 no stash, 2 no stage 2
+    int dbg_rows, dbg_flags;    // diagnostics (WFX_INGEST_DBG=rows,flags; results are WRONG unless 8,0): tap rows applied; 1 no stash, 2 no stage 2, 4 no stage 1, 8 no barrier B; WFX_INGEST_DBG_LDS: extra LDS bytes
 };
 
 // frames [e0, e0 + FPC) as one 16-byte chunk; frames at or beyond n_in read as zero
@@ -101,7 +110,7 @@ __device__ __forceinline__ uint4 ig_fetch_guarded(const unsigned char *in, long 
 // GUARD: the run may reach beyond n_in (the last runs of a capture, launched on their own): every chunk is range-checked.  All other
 // runs load without a test.
 template <int IN, int M2, bool GUARD>
-__global__ void __launch_bounds__(IG_THREADS, 3) ingest_stream_kernel(const ig_params P, const int *__restrict__ tp, const double *__restrict__ c2tab)
+__global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_stream_kernel(const ig_params P, const int *__restrict__ tp, const double *__restrict__ c2tab)
 {
     constexpr int FB = IN == WFX_IN_I16_STEREO ? 4 : 2;                   // bytes per frame
     constexpr int FPC = 16 / FB;                                          // frames per 16-byte chunk
@@ -111,6 +120,7 @@ __global__ void __launch_bounds__(IG_THREADS, 3) ingest_stream_kernel(const ig_p
     extern __shared__ __align__(16) unsigned char ig_lds[];
     int *xs = (int *)ig_lds;
     double *ys = (double *)(ig_lds + IG_XS_BYTES);
+    double *cs = ys + IG_YRING + IG_YMIRROR;
     const int t = threadIdx.x;
     const unsigned char *in = (const unsigned char *)P.in + (size_t)blockIdx.y * (size_t)P.in_bs;
     double *out = P.out + (size_t)blockIdx.y * (size_t)P.out_bs;
@@ -161,30 +171,38 @@ __global__ void __launch_bounds__(IG_THREADS, 3) ingest_stream_kernel(const ig_p
         int4 wa[4], wb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) wa[q] = *(const int4 *)(base + 4 * q);
-#pragma unroll 1
-        for (int j = 0; j < P.dbg_rows; ++j) {
-            const int *nx = base + 16 * (j + 1) + 4 * ((j + 1) >> 1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wb[q] = *(const int4 *)(nx + 4 * q);
+        // one step: output A against window row `lo`, output B against row `hi` (= A's row of the next step), both with tap row j
+        auto step = [&](const int4 (&lo)[4], const int4 (&hi)[4], int j) {
             const int *tr = tp + 16 * j;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int wv[4] = {wa[q].x, wa[q].y, wa[q].z, wa[q].w};
+                const int wv[4] = {lo[q].x, lo[q].y, lo[q].z, lo[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) sA[k] = ig_dot2(wv[i], tr[k * IG_NPAIR + 4 * q + i], sA[k]);
+                    for (int k = 0; k < IG_DBG_PIECES; ++k) sA[k] = ig_dot2(wv[i], tr[k * IG_NPAIR + 4 * q + i], sA[k]);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int wv[4] = {wb[q].x, wb[q].y, wb[q].z, wb[q].w};
+                const int wv[4] = {hi[q].x, hi[q].y, hi[q].z, hi[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) sB[k] = ig_dot2(wv[i], tr[k * IG_NPAIR + 4 * q + i], sB[k]);
+                    for (int k = 0; k < IG_DBG_PIECES; ++k) sB[k] = ig_dot2(wv[i], tr[k * IG_NPAIR + 4 * q + i], sB[k]);
             }
+        };
+        auto fetch_row = [&](int4 (&w)[4], int r) {
+            const int *nx = base + 16 * r + 4 * (r >> 1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) wa[q] = wb[q];
+            for (int q = 0; q < 4; ++q) w[q] = *(const int4 *)(nx + 4 * q);
+        };
+        // two steps per trip: the two window buffers swap roles by NAME (no register moves)
+#pragma unroll 1
+        for (int j = 0; j < P.dbg_rows; j += 2) {
+            fetch_row(wb, j + 1);
+            step(wa, wb, j);
+            fetch_row(wa, j + 2);                // (the last trip fetches row 8: output B's last one)
+            step(wb, wa, j + 1);
         }
         const long long tA = ((long long)sA[0] << (2 * IG_PIECE)) + ((long long)sA[1] << IG_PIECE) + (long long)sA[2];
         const long long tB = ((long long)sB[0] << (2 * IG_PIECE)) + ((long long)sB[1] << IG_PIECE) + (long long)sB[2];
@@ -204,30 +222,63 @@ __global__ void __launch_bounds__(IG_THREADS, 3) ingest_stream_kernel(const ig_p
             if (s < IG_YMIRROR) *(double2 *)(ys + IG_YRING + s) = make_double2(yA, yB);
         }
     };
-    // stage 2 on everything iteration n made complete: outputs k with M2 k + ntaps2 <= (n + 1) * IG_BLK
+    // stage 2 on everything iteration n made complete: outputs k with M2 k + ntaps2 <= (n + 1) * IG_BLK.  The tile kernel's canonical
+    // order -- one FMA chain per polyphase row r = i mod M2 in ascending tap order, then row 0 + row 1 (+ row 2) -- is walked tap by tap:
+    // consecutive taps, consecutive ring entries, M2 independent chains; GRP taps are fetched (scalar loads, LDS reads) before
+    // their FMAs so that one wait serves GRP of them
     auto stage2 = [&](int n) {
         if (M2 == 0) return;
         constexpr int MM = M2 ? M2 : 1;
+        constexpr int GRP = 6;
+        static_assert(GRP % MM == 0 && IG_C2PAD % (2 * GRP) == 0, "a group of taps covers whole rounds of the chains");
         const long long avail = (long long)(n + 1) * IG_BLK;
         long long kend = avail >= P.ntaps2 ? (avail - P.ntaps2) / MM + 1 : 0;
         if (kend > ocnt) kend = ocnt;
+        const int ngrp2 = (P.ntaps2 + 2 * GRP - 1) / (2 * GRP);          // trips of two groups (the table is zero padded)
         for (long long k = kdone + t; k < kend; k += IG_THREADS) {
             const double *y = ys + (int)((k * MM) & (IG_YRING - 1));     // the window is contiguous: slots 0..127 are mirrored behind the ring
+            double acc[MM];
+#pragma unroll
+            for (int r = 0; r < MM; ++r) acc[r] = 0.0;
+            // taps (broadcast reads of the copy in LDS) and ring entries of the NEXT group are requested before this group's FMAs;
+            // the two register sets swap roles by name
+            double ca[GRP], wa[GRP], cb[GRP], wb[GRP];
+            auto fetch = [&](double (&c)[GRP], double (&w)[GRP], int i) {
+#pragma unroll
+                for (int q = 0; q < GRP; q += 2) {
+                    const double2 cc = *(const double2 *)(cs + i + q);
+                    c[q] = cc.x;
+                    c[q + 1] = cc.y;
+                }
+#pragma unroll
+                for (int q = 0; q < GRP; ++q) w[q] = y[i + q];
+            };
+            auto mac = [&](const double (&c)[GRP], const double (&w)[GRP]) {
+#pragma unroll
+                for (int q = 0; q < GRP; ++q) acc[q % MM] = fma(c[q], w[q], acc[q % MM]);
+            };
+            fetch(ca, wa, 0);
+#pragma unroll 1
+            for (int g = 0; g < ngrp2; ++g) {
+                fetch(cb, wb, 2 * GRP * g + GRP);
+                mac(ca, wa);
+                if (g + 1 < ngrp2) fetch(ca, wa, 2 * GRP * (g + 1));
+                mac(cb, wb);
+            }
             double tot = 0.0;
 #pragma unroll
-            for (int r = 0; r < MM; ++r) {
-                const double *c = c2tab + r * P.nper;
-                const int cnt = (P.ntaps2 - r + MM - 1) / MM;             // taps of this polyphase row
-                double acc = 0.0;
-#pragma unroll 8
-                for (int j = 0; j < cnt; ++j) acc = fma(c[j], y[r + MM * j], acc);
-                tot += acc;
-            }
+            for (int r = 0; r < MM; ++r) tot += acc[r];
             out[o0 + k] = tot;
         }
         kdone = kend;
     };
 
+    if (M2) {
+        // stage-2 taps into LDS, zero padded (a padded tap times a ring entry outside the window adds nothing -- the ring starts cleared,
+        // so that entry is a finite number)
+        for (int i = t; i < IG_C2PAD; i += IG_THREADS) cs[i] = i < P.ntaps2 ? c2tab[i] : 0.0;
+        for (int i = t; i < IG_YRING + IG_YMIRROR; i += IG_THREADS) ys[i] = 0.0;
+    }
     for (int n = 0; n < niter; ++n) {
         __syncthreads();                       // A: stage 1 of iteration n - 1 is done with the rows, its ring entries are visible
         if (n == 0) {
@@ -244,10 +295,14 @@ __global__ void __launch_bounds__(IG_THREADS, 3) ingest_stream_kernel(const ig_p
             for (int u = 0; u < CPT; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
             if (acc == 0x9e3779b9u) xput[0] = (int)acc;
         }
+        // (the fence keeps the scheduler from hoisting these loads above the stash: it would rename the registers and then wait for
+        // BOTH blocks before the stash -- vmcnt counts in order --, i.e. expose the whole latency every iteration)
+        __builtin_amdgcn_sched_barrier(0);
         if (n + 1 < niter) load_block(n + 1);   // in flight during the whole compute phase
+        __builtin_amdgcn_sched_barrier(0);
         if (n > 0 && !(P.dbg_flags & 2)) stage2(n - 1);
-        __syncthreads();                       // B
-        stage1(n);
+        if (!(P.dbg_flags & 8)) __syncthreads();                       // B
+        if (!(P.dbg_flags & 4)) stage1(n);
         if (t < IG_HALO * IG_RD) carry = xs[ig_row_off(IG_BLK + t / IG_RD) + (t % IG_RD)];
     }
     if (M2) {
@@ -256,7 +311,56 @@ __global__ void __launch_bounds__(IG_THREADS, 3) ingest_stream_kernel(const ig_p
     }
 }
 
+// plain read of a buffer in the ingest's own access shape (16-byte loads, 16 in flight per lane, contiguous 64 KiB blocks dealt round-robin):
+// what this GPU delivers to a kernel that does nothing with the bytes -- the ceiling the ingest's rate is put beside (bench.py)
+__global__ void __launch_bounds__(256) read_rate_kernel(const uint4 *__restrict__ v, unsigned long long nblocks, unsigned *__restrict__ sink)
+{
+    const int t = threadIdx.x;
+    unsigned acc = 0;
+    for (unsigned long long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const uint4 *p = v + b * 4096ull + t;
+        uint4 a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = p[u * 256];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += a[u].x ^ a[u].y ^ a[u].z ^ a[u].w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 }   // namespace
+
+int wfx_dev_read_rate(wfx_ctx *ctx, const void *dev, uint64_t bytes, int reps, double *gbs)
+{
+    if (((uintptr_t)dev & 15u) || bytes < (1ull << 20) || reps < 1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "read rate: a 16-byte aligned buffer of at least 1 MiB");
+    const unsigned long long nblocks = bytes >> 16;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_tmp, 64));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    WFX_HIP(ctx, hipEventCreate(&e0));
+    WFX_HIP(ctx, hipEventCreate(&e1));
+    const unsigned grid = (unsigned)std::min<unsigned long long>(nblocks, 4096ull);
+    hipLaunchKernelGGL(read_rate_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)dev, nblocks, (unsigned *)ctx->b_tmp.p);
+    double best = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        (void)hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL(read_rate_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)dev, nblocks, (unsigned *)ctx->b_tmp.p);
+        (void)hipEventRecord(e1, ctx->stream);
+        hipError_t e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return wfx_fail_hip(ctx, e, "read rate");
+        }
+        const double g = (double)(nblocks << 16) / (ms * 1e-3) / 1e9;
+        if (g > best) best = g;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (gbs) *gbs = best;
+    return 0;
+}
 
 // y1[i] = sum_j coef1[j] x[32 i + j] on the grid 2^-fix_shift (exact), and -- factor2 > 0 -- out[k] = sum_j coef2[j] y1[factor2 k + j]
 // in float64 behind it; factor2 == 0: out = y1.  x = the int16 frames behind `in` (16-byte aligned), zero beyond n_in.
@@ -275,7 +379,7 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
     if (((uintptr_t)in & 15u) || (nbatch > 1 && ((in_stride * fb) & 15u))) return 0;
     int nper = 0;
     if (factor2) {
-        if (ntaps2 < factor2 || ntaps2 > IG_YMIRROR - 8) return 0;
+        if (ntaps2 < factor2 || ntaps2 > IG_C2PAD) return 0;
         nper = 4 * (((ntaps2 + factor2 - 1) / factor2 + 3) / 4);          // the tile kernel's row length (canonical order)
     }
     // fixed-point taps v = a * 2^18 + b * 2^9 + c with b, c in [-256, 255]: each piece's int32 sum over a whole window holds
@@ -309,20 +413,23 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
     if (!dtab) return WFX_ERR_HIP;
     const double *dc2 = nullptr;
     if (factor2) {
-        std::vector<double> c2((size_t)factor2 * nper, 0.0);
-        for (int j = 0; j < ntaps2; ++j) c2[(size_t)(j % factor2) * nper + (size_t)(j / factor2)] = coef2[j];
+        std::vector<double> c2((size_t)ntaps2 + 16, 0.0);
+        for (int j = 0; j < ntaps2; ++j) c2[(size_t)j] = coef2[j];
         dc2 = (const double *)wfx_coef_device(ctx, (const float *)c2.data(), c2.size() * 2);
         if (!dc2) return WFX_ERR_HIP;
     }
     // run length: `ni` iterations of 512 stage-1 outputs per workgroup.  Long runs amortise the halo (8 rows of frames, and with
     // stage 2 the ntaps2 - factor2 stage-1 outputs two neighbouring runs both compute); short captures still fill the GPU
     const long long n1_total = factor2 ? ((long long)n_out - 1) * factor2 + ntaps2 : (long long)n_out;
-    long long ni = 16;
+    long long ni = 16 * 512 / IG_BLK;      // 8192 stage-1 outputs = 1 MiB of IQ frames per run
     if (const char *e = getenv("WFX_INGEST_NI")) ni = std::max(1, atoi(e));
     while (ni > 1 && n1_total * nbatch / (ni * IG_BLK) < 2048) ni >>= 1;
     long long run_out = ni * IG_BLK;
     if (factor2) {
         run_out = (ni * IG_BLK - (ntaps2 - factor2)) / factor2;
+        // runs start on the 1 KiB grid of the input (a wave's 64 x 16 bytes then never straddle one more 128-byte line than they must):
+        // an IQ run of run_out outputs starts run_out * factor2 * 128 bytes behind the previous one
+        if (run_out >= 64) run_out &= ~(long long)31;
         if (run_out < 1) return 0;
     }
     const long long runs = ((long long)n_out + run_out - 1) / run_out;
@@ -360,7 +467,12 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
         if (guard) return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_MONO, 0, true> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_MONO, 2, true> : ingest_stream_kernel<WFX_IN_I16_MONO, 3, true>;
         return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_MONO, 0, false> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_MONO, 2, false> : ingest_stream_kernel<WFX_IN_I16_MONO, 3, false>;
     };
-    const size_t lds = (size_t)IG_XS_BYTES + (factor2 ? (size_t)IG_YS_BYTES : 0);
+    size_t lds = (size_t)IG_XS_BYTES + (factor2 ? (size_t)IG_YS_BYTES : 0);
+    if (const char *e = getenv("WFX_INGEST_DBG_LDS")) {
+        lds += (size_t)atoi(e);
+        (void)hipFuncSetAttribute((const void *)pick(false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)pick(true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     wfx_prof_begin(ctx, K_POLYPHASE_IN);                                  // (one record: the checked tail is part of the same pass)
     if (full > 0) hipLaunchKernelGGL(pick(false), dim3((unsigned)full, (unsigned)nbatch), dim3(IG_THREADS), lds, ctx->stream, P, dtab, dc2);
     if (full < runs) {

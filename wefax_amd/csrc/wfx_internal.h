@@ -365,6 +365,9 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
                           int factor2, const double *coef2, int ntaps2, double *out, uint64_t n_out, int nbatch, uint64_t in_stride,
                           uint64_t out_stride, int *handled);
 
+// GB/s of a plain read of `bytes` at `dev` (best of `reps` launches, HIP events): the box's read-stream ceiling, measured beside the ingest
+int wfx_dev_read_rate(wfx_ctx *ctx, const void *dev, uint64_t bytes, int reps, double *gbs);
+
 // wfx_comm.hip: the communicator behind the sharded decode (RCCL bound directly, or every rank in this process)
 struct wfx_xfer {            // one message pair of a personalised exchange; several entries per peer are matched in order
     int peer;
