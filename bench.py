@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--trim", type=int, default=0, help="c2: drop this many samples from the end of the capture (--trim 2 with --shard: the padded distributed convolution; odd: the real convolution on packed transforms)")
     ap.add_argument("--no-c4", action="store_true", help="c2: leave the c4_strong object out (quick runs)")
     ap.add_argument("--no-extras", action="store_true", help="c2: leave the general_length and c3 objects out (kernel profiles of the headline alone)")
+    ap.add_argument("--no-e2e", action="store_true", help="leave the file-to-file objects (wav on tmpfs -> png on tmpfs) out")
     ap.add_argument("--no-pcie", action="store_true", help="c2: skip the PCIe-inclusive leg (it runs two decodes concurrently: keep it out of kernel profiles)")
     ap.add_argument("--batch", type=int, default=1,
                     help="captures decoded concurrently per GPU, one native context (= HIP stream) each; "
@@ -670,6 +671,97 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
     return out
 
 
+# ---- file to file: wav on tmpfs -> Demodulator -> png on tmpfs (SURVEY.md 8d asks for both timings) -------------------
+def bench_e2e(x, sample_rate: int, lpm: int, what: str, with_cpu: bool, reps: int = 5, cpu_x=None, cpu_what: str = "") -> dict:
+    """What a user of the drop-in sees: ``Demodulator(path).process(); save_output_image(png)`` with the wav and the png on tmpfs
+    (/dev/shm), one warm-up, then best of ``reps`` with a FRESH Demodulator per file (its context comes from the idle pool, like a
+    service's would).  ``stages`` splits one more pass through the same calls the Demodulator makes: read_wav (page cache -> the
+    context's pinned staging buffer), upload (DMA + parameter block), decode (all kernels, to the synchronised result), png
+    (device deflate + copy of the file image to the host), write (the file image to tmpfs).  With ``with_cpu``: the oracle + PIL on
+    the same file beside it (one run) -- or on ``cpu_x``, a bounded sample of the same format, when the workload itself would keep
+    the host busy for minutes (``cpu_what`` says what it is)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from wefax_amd import Demodulator, synth
+    from wefax_amd import hostparams as hp
+    from wefax_amd.wefax import DecodeJob, _acquire_context, _release_context
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    td = tempfile.mkdtemp(prefix="wfx_e2e_", dir=base)
+    out = {"workload": what, "samples": int(x.shape[0]), "files_on": "tmpfs (/dev/shm)" if base else "the default temporary directory"}
+    try:
+        wav, png = os.path.join(td, "in.wav"), os.path.join(td, "out.png")
+        synth.write_wav(wav, sample_rate, x)
+        out["wav_bytes"] = os.path.getsize(wav)
+
+        def once(k):
+            t0 = time.perf_counter()
+            d = Demodulator(wav, lpm, quiet=True, tcp_stream=False)
+            d.process()
+            t1 = time.perf_counter()
+            d.save_output_image(os.path.join(td, f"out{k}.png"))
+            t2 = time.perf_counter()
+            d.close()
+            return t2 - t0, t1 - t0, t2 - t1
+
+        once(0)                                              # warm-up: context, plans, buffers, filter tables, page cache
+        runs = [once(1 + k) for k in range(reps)]
+        best = min(runs)
+        out["ms"] = round(1e3 * best[0], 3)
+        out["process_ms"], out["save_png_ms"] = round(1e3 * best[1], 3), round(1e3 * best[2], 3)
+        out["all_ms"] = [round(1e3 * r[0], 3) for r in runs]
+        out["png_bytes"] = os.path.getsize(os.path.join(td, "out1.png"))
+        out["value"] = round(x.shape[0] / best[0] / 1e6, 2)
+        out["unit"] = "Msamples/s file to file"
+        # the stage split, through the calls Demodulator.process / save_output_image make (wefax_amd/wefax.py)
+        ctx = _acquire_context(0)
+        T = [time.perf_counter()]
+        sr, data = hp.read_wav(wav, alloc=ctx.staging)
+        T.append(time.perf_counter())
+        job = DecodeJob(ctx, data, sr, lpm, hp.load_notch_settings())
+        ctx.sync()
+        T.append(time.perf_counter())
+        job.run()
+        job.result()
+        T.append(time.perf_counter())
+        blob = ctx.decode_png(deflate=True)
+        T.append(time.perf_counter())
+        with open(png, "wb") as fh:
+            fh.write(blob)
+        T.append(time.perf_counter())
+        out["stages_ms"] = {k: round(1e3 * (b - a), 3) for k, a, b in zip(("read_wav", "upload", "decode", "png", "write"), T, T[1:])}
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        ctx.decode_png(deflate=True)
+        ctx.sync()
+        ctx.profile_enable(False)
+        pk = {k: round(v[1], 3) for k, v in ctx.profile().items()}
+        out["png_kernels_ms"] = pk
+        _release_context(ctx, 0)
+        if with_cpu:
+            from PIL import Image
+            from oracle import wefax_oracle as wo
+            cwav, cn = wav, x.shape[0]
+            if cpu_x is not None:
+                cwav, cn = os.path.join(td, "cpu.wav"), cpu_x.shape[0]
+                synth.write_wav(cwav, sample_rate, cpu_x)
+            t0 = time.perf_counter()
+            ref = wo.process(cwav, lpm, want_messages=False)
+            t1 = time.perf_counter()
+            if "image" in ref:
+                Image.fromarray(ref["image"], "L").save(os.path.join(td, "ref.png"))
+            t2 = time.perf_counter()
+            out["cpu_baseline"] = {"kind": "port", "cores": 1, "process_ms": round(1e3 * (t1 - t0), 1), "save_png_ms": round(1e3 * (t2 - t1), 1),
+                                   "ms": round(1e3 * (t2 - t0), 1), "value": round(cn / (t2 - t0) / 1e6, 3), "unit": "Msamples/s file to file",
+                                   "sample": (cpu_what if cpu_x is not None else "the same wav file") + "; oracle (NumPy/C port of wefax.py) + PIL's PNG writer, one run"}
+            if "image" in ref and cpu_x is None:
+                got = np.asarray(Image.open(os.path.join(td, "out1.png")))
+                out["png_pixels_equal_to_oracle"] = bool(got.shape == ref["image"].shape and np.array_equal(got, ref["image"]))
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return out
+
+
 # ---- BASELINE configs[2]: 60 minutes at 48 kHz (exact FFT resample) ------------------------------------------------
 def bench_c3(args, rk: Ranks) -> dict:
     import numpy as np
@@ -744,6 +836,12 @@ def bench_c3(args, rk: Ranks) -> dict:
         cb = cpu_baseline(xs, 48000, 120, False, f"a 10-minute capture of the same format ({xs.shape[0]} samples: 1/6 of the workload), one run, read from a wav file")
         cb.pop("_result")
         out["cpu_baseline"] = cb
+    if rk.rank == 0 and rk.world == 1 and not args.short and not getattr(args, "no_e2e", False):
+        xs = None
+        if not args.no_cpu:
+            xs = synth.synth_capture(48000.0, noise=args.noise, seed=0, start_tone_s=5.0, phasing_lines=60, image_lines=1060, stop_tone_s=2.0, black_tail_s=3.0)
+        out["e2e"] = bench_e2e(x, 48000, 120, f"BASELINE configs[2] file to file: a {x.nbytes + 44}-byte wav on tmpfs -> Demodulator -> png on tmpfs", not args.no_cpu,
+                               reps=3, cpu_x=xs, cpu_what="a 10-minute 48 kHz wav of the same format (1/6 of the workload)")
     return out
 
 
@@ -861,6 +959,8 @@ def bench_c2(args, rk: Ranks) -> dict:
         job.close()
     for cb, _ in extra:
         cb.close()
+    if rk.rank == 0 and rk.world == 1 and not args.shard and args.batch == 1 and not args.short and not args.no_extras and not getattr(args, "no_e2e", False) and not args.trim:
+        out["e2e"] = bench_e2e(x, 11025, 120, f"BASELINE configs[1] file to file: a {x.nbytes + 44}-byte wav on tmpfs -> Demodulator -> png on tmpfs", not args.no_cpu)
     return out
 
 
@@ -1010,7 +1110,7 @@ def main():
                 a3 = argparse.Namespace(**vars(args))
                 a3.steps, a3.warmup = max(3, min(args.steps, 10)), 2
                 c3 = bench_c3(a3, rk)
-                line["c3"] = {k: c3[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "kernels", "general_length") if k in c3}
+                line["c3"] = {k: c3[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "kernels", "general_length", "e2e") if k in c3}
             if not args.no_c4 and not args.shard and args.batch == 1:
                 rk.barrier()
                 secs = 40.0 if args.short else float(args.iq_seconds)

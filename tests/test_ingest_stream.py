@@ -77,8 +77,11 @@ def test_stage1_equals_the_integer_model(ctx, kind, worst, n_out, slack):
         if kind == "iq":
             raw[:, 1] = 0
         col[:] = -32768
-        outs = [0, 9, 18, 27, 255 - 8, 256 + 1, 511 - 8, 512 + 1, 521, n_out - 10, n_out - 1]      # (around the ends of an iteration's block)
-        pats = [fix, -fix, a, -a, b, -b, c, -c, fix, -a, -c]
+        # (rows of small taps run in two pieces hi * 2^12 + lo instead: their signs too)
+        hi = (fix + 2048) >> 12
+        lo = fix - (hi << 12)
+        outs = [0, 9, 18, 27, 255 - 8, 256 + 1, 511 - 8, 512 + 1, 521, 530, 539, 548, 557, n_out - 10, n_out - 1]      # (around the ends of an iteration's block)
+        pats = [fix, -fix, a, -a, b, -b, c, -c, fix, hi, -hi, lo, -lo, -a, -c]
         for o, q in zip(outs, pats):       # (at least 9 outputs apart: the windows do not overlap)
             col[32 * o:32 * o + coef.shape[0]] = np.where(q >= 0, -32768, 32767).astype(np.int16)
     k = nat.WFX_IN_I16_STEREO if kind == "iq" else nat.WFX_IN_I16_MONO

@@ -56,6 +56,14 @@ ctx.profile_enable(False)
 pr = ctx.profile()
 print("ingest inside the decode (events): %.3f ms per launch; whole decode kernels %.3f ms" % (pr["polyphase_ingest"][1] / pr["polyphase_ingest"][0], sum(v[1] for v in pr.values()) / 5), flush=True)
 print("synthesised stream again, back to back: min %.3f median %.3f ms" % timed(fused), flush=True)
+os.environ["WFX_INGEST_3PIECE"] = "1"
+print("  every tap row in three pieces (WFX_INGEST_3PIECE=1): min %.3f median %.3f ms" % timed(fused), flush=True)
+del os.environ["WFX_INGEST_3PIECE"]
+print("  product form again: min %.3f median %.3f ms" % timed(fused), flush=True)
+for ni in (8, 12, 16, 20, 24, 32, 48):
+    os.environ["WFX_INGEST_NI"] = str(ni)
+    print("  run length %2d iterations: min %.3f median %.3f ms" % ((ni,) + timed(fused, 5, 4)), flush=True)
+del os.environ["WFX_INGEST_NI"]
 # overwrite the stream with the repeating ramp of tools/ingest_lab.py
 x = (np.arange(1 << 20, dtype=np.int32) % 2001 - 1000).astype(np.int16)
 blk = np.stack([x, x[::-1]], axis=1).copy()

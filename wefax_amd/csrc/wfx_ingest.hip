@@ -54,6 +54,7 @@ static_assert(IG_YRING >= IG_BLK + IG_YMIRROR && IG_THREADS >= IG_HALO * (IG_M /
 #define WFX_IG_DBG_PIECES 3
 #endif
 constexpr int IG_DBG_PIECES = WFX_IG_DBG_PIECES;      // (timing experiments only: fewer pieces give wrong sums)
+constexpr int IG_HILO = 12;                     // ... or, in a row of small taps, hi * 2^12 + lo
 constexpr int IG_PIECE = 9;                      // a fixed-point tap is a * 2^18 + b * 2^9 + c with b, c in [-256, 255]
 
 __host__ __device__ constexpr int ig_row_off(int r) { return r * IG_RD + (r >> 1) * 4; }       // dword offset of row r
@@ -84,7 +85,8 @@ struct ig_params {
     long long n_out;            // outputs of the last stage
     long long run_out;          // outputs per workgroup run
     long long in_bs, out_bs;    // batch strides (bytes / elements)
-    long long run0;             // index of the launch's first run
+    long long out0;             // first output of the launch's first run
+    unsigned mask3;             // bit j: tap row j runs in three pieces (else two)
     int dbg_rows, dbg_flags;    // diagnostics (WFX_INGEST_DBG=rows,flags; results are WRONG unless 8,0): tap rows applied; 1 no stash, 2 no stage 2, 4 no stage 1, 8 no barrier B; WFX_INGEST_DBG_LDS: extra LDS bytes
 };
 
@@ -125,7 +127,7 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     const unsigned char *in = (const unsigned char *)P.in + (size_t)blockIdx.y * (size_t)P.in_bs;
     double *out = P.out + (size_t)blockIdx.y * (size_t)P.out_bs;
 
-    const long long o0 = (P.run0 + (long long)blockIdx.x) * P.run_out;               // first output of this run
+    const long long o0 = P.out0 + (long long)blockIdx.x * P.run_out;                 // first output of this run
     const long long ocnt = P.n_out - o0 < P.run_out ? P.n_out - o0 : P.run_out;
     const long long s0 = M2 ? o0 * M2 : o0;                               // first stage-1 output the run needs
     const long long cnt1 = M2 ? (ocnt - 1) * M2 + P.ntaps2 : ocnt;
@@ -167,28 +169,57 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
         // step j: tap row j (16 pairs in three pieces: 48 scalar registers) against window row 2t + j for output A and row 2t + 1 + j
         // for output B, which step j + 1 uses again for A: every window row and every tap row is fetched once.  (The loop is kept
         // rolled: unrolled, the scheduler hoists all window reads and tap loads and spills a thousand registers.)
-        int sA[3] = {0, 0, 0}, sB[3] = {0, 0, 0};
+        int sA[3] = {0, 0, 0}, sB[3] = {0, 0, 0};          // three-piece rows: a, b, c
+        int hA = 0, hB = 0;                                 // two-piece rows: the high parts (their low parts leave per row)
+        long long tA = 0, tB = 0;
         int4 wa[4], wb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) wa[q] = *(const int4 *)(base + 4 * q);
-        // one step: output A against window row `lo`, output B against row `hi` (= A's row of the next step), both with tap row j
+        // one step: output A against window row `lo`, output B against row `hi` (= A's row of the next step), both with tap row j.
+        // A row whose taps are small enough (the six outer rows of the 253-tap ingest filter) runs in TWO pieces hi * 2^12 + lo: its
+        // high parts share one int32 with the other such rows (the host checked sum |hi| * 32768 < 2^31 over all of them), its low
+        // parts -- up to 32 x 2048 x 32768 -- fill an int32 of their own and are moved to the 64-bit sum when the row is done
         auto step = [&](const int4 (&lo)[4], const int4 (&hi)[4], int j) {
-            const int *tr = tp + 16 * j;
+            const int *tr = tp + 48 * j;
+            if ((P.mask3 >> j) & 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int wv[4] = {lo[q].x, lo[q].y, lo[q].z, lo[q].w};
+                for (int q = 0; q < 4; ++q) {
+                    const int wv[4] = {lo[q].x, lo[q].y, lo[q].z, lo[q].w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int k = 0; k < IG_DBG_PIECES; ++k) sA[k] = ig_dot2(wv[i], tr[k * IG_NPAIR + 4 * q + i], sA[k]);
-            }
+                        for (int k = 0; k < IG_DBG_PIECES; ++k) sA[k] = ig_dot2(wv[i], tr[16 * k + 4 * q + i], sA[k]);
+                }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int wv[4] = {hi[q].x, hi[q].y, hi[q].z, hi[q].w};
+                for (int q = 0; q < 4; ++q) {
+                    const int wv[4] = {hi[q].x, hi[q].y, hi[q].z, hi[q].w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int k = 0; k < IG_DBG_PIECES; ++k) sB[k] = ig_dot2(wv[i], tr[k * IG_NPAIR + 4 * q + i], sB[k]);
+                        for (int k = 0; k < IG_DBG_PIECES; ++k) sB[k] = ig_dot2(wv[i], tr[16 * k + 4 * q + i], sB[k]);
+                }
+            } else {
+                int lA = 0, lB = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int wv[4] = {lo[q].x, lo[q].y, lo[q].z, lo[q].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        hA = ig_dot2(wv[i], tr[4 * q + i], hA);
+                        lA = ig_dot2(wv[i], tr[16 + 4 * q + i], lA);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int wv[4] = {hi[q].x, hi[q].y, hi[q].z, hi[q].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        hB = ig_dot2(wv[i], tr[4 * q + i], hB);
+                        lB = ig_dot2(wv[i], tr[16 + 4 * q + i], lB);
+                    }
+                }
+                tA += (long long)lA;
+                tB += (long long)lB;
             }
         };
         auto fetch_row = [&](int4 (&w)[4], int r) {
@@ -204,8 +235,8 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
             fetch_row(wa, j + 2);                // (the last trip fetches row 8: output B's last one)
             step(wb, wa, j + 1);
         }
-        const long long tA = ((long long)sA[0] << (2 * IG_PIECE)) + ((long long)sA[1] << IG_PIECE) + (long long)sA[2];
-        const long long tB = ((long long)sB[0] << (2 * IG_PIECE)) + ((long long)sB[1] << IG_PIECE) + (long long)sB[2];
+        tA += ((long long)sA[0] << (2 * IG_PIECE)) + ((long long)sA[1] << IG_PIECE) + (long long)sA[2] + ((long long)hA << IG_HILO);
+        tB += ((long long)sB[0] << (2 * IG_PIECE)) + ((long long)sB[1] << IG_PIECE) + (long long)sB[2] + ((long long)hB << IG_HILO);
         const double yA = (double)tA * P.sc, yB = (double)tB * P.sc;     // |t| < 2^51, sc a power of two: exact
         const long long i1 = (long long)n * IG_BLK + 2 * t;              // run-local index of output A
         if (M2 == 0) {
@@ -391,9 +422,11 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
         fix[j] = (int32_t)v;
     }
     const int pm = (1 << IG_PIECE) - 1, ph = 1 << (IG_PIECE - 1);
-    std::vector<int32_t> pc[3];
-    long long sum[3] = {0, 0, 0};
+    std::vector<int32_t> pc[3], hl[2];
     for (int k = 0; k < 3; ++k) pc[k].assign(2 * IG_NPAIR, 0);
+    for (int k = 0; k < 2; ++k) hl[k].assign(2 * IG_NPAIR, 0);
+    long long row3[IG_HALO][3] = {}, rowh[IG_HALO] = {}, rowl[IG_HALO] = {};
+    bool can2[IG_HALO];
     for (int j = 0; j < 2 * IG_NPAIR; ++j) {
         const int32_t v = fix[j];
         const int32_t c = ((v + ph) & pm) - ph;
@@ -401,14 +434,47 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
         const int32_t b = ((v1 + ph) & pm) - ph;
         const int32_t a = (v1 - b) >> IG_PIECE;
         pc[0][j] = a; pc[1][j] = b; pc[2][j] = c;
-        sum[0] += llabs((long long)a); sum[1] += llabs((long long)b); sum[2] += llabs((long long)c);
+        const int32_t hi = (v + (1 << (IG_HILO - 1))) >> IG_HILO, lo = v - hi * (1 << IG_HILO);
+        hl[0][j] = hi; hl[1][j] = lo;
+        const int r = j / IG_M;
+        row3[r][0] += llabs((long long)a); row3[r][1] += llabs((long long)b); row3[r][2] += llabs((long long)c);
+        rowh[r] += llabs((long long)hi); rowl[r] += llabs((long long)lo);
         if (a < -32768 || a > 32767) return 0;
     }
+    // rows in two pieces: as many as their high parts' common int32 holds (smallest sums first), each with its low parts in range
+    unsigned mask3 = (1u << IG_HALO) - 1u;
+    {
+        long long hsum = 0;
+        bool used[IG_HALO] = {};
+        for (int r = 0; r < IG_HALO; ++r) can2[r] = rowl[r] <= 65535 && rowh[r] <= 65535;
+        for (int pick = 0; pick < IG_HALO; ++pick) {
+            int best = -1;
+            for (int r = 0; r < IG_HALO; ++r)
+                if (!used[r] && can2[r] && (best < 0 || rowh[r] < rowh[best])) best = r;
+            if (best < 0 || hsum + rowh[best] > 65535) break;
+            used[best] = true;
+            hsum += rowh[best];
+            mask3 &= ~(1u << best);
+        }
+        if (getenv("WFX_INGEST_3PIECE")) mask3 = (1u << IG_HALO) - 1u;     // A/B switch: every row in three pieces (the first form)
+    }
+    long long sum[3] = {0, 0, 0};
+    for (int r = 0; r < IG_HALO; ++r)
+        if ((mask3 >> r) & 1u)
+            for (int k = 0; k < 3; ++k) sum[k] += row3[r][k];
     if (sum[0] > 65535 || sum[1] > 65535 || sum[2] > 65535) return 0;
-    std::vector<int32_t> tab(3 * IG_NPAIR);
+    // table: row j = 48 dwords, three slots of 16 tap pairs: (a, b, c), or (hi, lo, -) for a two-piece row
+    std::vector<int32_t> tab(3 * IG_NPAIR, 0);
     auto pack = [](int a, int b) { return (int32_t)(((uint32_t)(uint16_t)(int16_t)a) | ((uint32_t)(uint16_t)(int16_t)b << 16)); };
-    for (int k = 0; k < 3; ++k)
-        for (int p = 0; p < IG_NPAIR; ++p) tab[k * IG_NPAIR + p] = pack(pc[k][2 * p], pc[k][2 * p + 1]);
+    for (int r = 0; r < IG_HALO; ++r)
+        for (int p = 0; p < 16; ++p) {
+            const int j0 = 2 * (16 * r + p);
+            if ((mask3 >> r) & 1u) {
+                for (int k = 0; k < 3; ++k) tab[48 * r + 16 * k + p] = pack(pc[k][j0], pc[k][j0 + 1]);
+            } else {
+                for (int k = 0; k < 2; ++k) tab[48 * r + 16 * k + p] = pack(hl[k][j0], hl[k][j0 + 1]);
+            }
+        }
     const int *dtab = (const int *)wfx_coef_device(ctx, (const float *)tab.data(), tab.size());
     if (!dtab) return WFX_ERR_HIP;
     const double *dc2 = nullptr;
@@ -445,7 +511,8 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
     P.run_out = run_out;
     P.in_bs = nbatch > 1 ? (long long)in_stride * fb : 0;
     P.out_bs = nbatch > 1 ? (long long)out_stride : 0;
-    P.run0 = 0;
+    P.out0 = 0;
+    P.mask3 = mask3;
     P.dbg_rows = IG_HALO;
     P.dbg_flags = 0;
     if (const char *e = getenv("WFX_INGEST_DBG")) sscanf(e, "%d,%d", &P.dbg_rows, &P.dbg_flags);
@@ -476,8 +543,14 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
     wfx_prof_begin(ctx, K_POLYPHASE_IN);                                  // (one record: the checked tail is part of the same pass)
     if (full > 0) hipLaunchKernelGGL(pick(false), dim3((unsigned)full, (unsigned)nbatch), dim3(IG_THREADS), lds, ctx->stream, P, dtab, dc2);
     if (full < runs) {
-        P.run0 = full;
-        hipLaunchKernelGGL(pick(true), dim3((unsigned)(runs - full), (unsigned)nbatch), dim3(IG_THREADS), lds, ctx->stream, P, dtab, dc2);
+        // what is left (less than two runs) goes to the range-checked form in runs of ONE iteration each: side by side on as many CUs
+        // instead of one workgroup walking a whole run alone while the GPU waits for it (that cost 5 % of the pass)
+        P.out0 = full * run_out;
+        P.run_out = factor2 ? (IG_BLK - (ntaps2 - factor2)) / factor2 : IG_BLK;
+        if (factor2 && P.run_out >= 64) P.run_out &= ~(long long)31;
+        if (P.run_out < 1) P.run_out = run_out;
+        const long long tail_runs = ((long long)n_out - P.out0 + P.run_out - 1) / P.run_out;
+        hipLaunchKernelGGL(pick(true), dim3((unsigned)tail_runs, (unsigned)nbatch), dim3(IG_THREADS), lds, ctx->stream, P, dtab, dc2);
     }
     wfx_prof_end(ctx);
     hipError_t e = hipGetLastError();
