@@ -470,3 +470,30 @@ def test_odd_extension_in_the_captures_own_dtype(dtype):
     if dtype != "float32":
         assert np.max(np.abs(plain[:20] - want[:20])) > 1e-3 * scale
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mono_noisy_240", "stereo_overflow_120", "stereo48k_image_240", "mono48k_noisy_120"])
+def test_pipelined_file_upload_equals_read_then_upload(name, monkeypatch):
+    """16-bit PCM files go from the page cache to the device as one pipeline (wfx_decode_upload_fd: slices read by a few threads,
+    each on its way by DMA when it is complete); WEFAX_UPLOAD_PIPELINE=0 reads the whole file first (hostparams.read_wav) and uploads
+    it then.  Same bytes on the device: same stream, same image, same messages."""
+    from conftest import golden_cases
+    from wefax_amd import Demodulator
+    case = next(c for c in golden_cases() if c["name"] == name)
+    res = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("WEFAX_UPLOAD_PIPELINE", pipe)
+        d = Demodulator(input_by_name(name), lines_per_minute=case["lpm"], quiet=True, tcp_stream=True)
+        try:
+            d.process()
+            exc = None
+        except (ValueError, IndexError) as e:
+            exc = [type(e).__name__, str(e)]
+        res.append((exc, d.digitalized_data.copy(), d.audio_data.copy(), None if exc else d.output_array.copy(), list(d.websocket_stack)))
+        d.close()
+    a, b = res
+    assert a[0] == b[0] == case["exception"]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[4] == b[4]
+    assert (a[3] is None and b[3] is None) or np.array_equal(a[3], b[3])
+    assert np.array_equal(a[1], load_golden(name)["digitalized"])

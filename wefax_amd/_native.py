@@ -26,7 +26,7 @@ SYMBOLS = [
     "wfx_device_count", "wfx_create", "wfx_destroy", "wfx_last_error", "wfx_sync",
     "wfx_version", "wfx_merge_channels", "wfx_merge_channels_any", "wfx_resample", "wfx_notch_filtfilt", "wfx_notch_filtfilt_ext",
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
-    "wfx_sync_peaks", "wfx_lines_to_image", "wfx_packet_process", "wfx_packets_process", "wfx_packet_spectrum", "wfx_decode_upload", "wfx_decode_attach", "wfx_decode_run",
+    "wfx_sync_peaks", "wfx_lines_to_image", "wfx_packet_process", "wfx_packets_process", "wfx_packet_spectrum", "wfx_decode_upload", "wfx_decode_upload_fd", "wfx_decode_attach", "wfx_decode_run",
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
@@ -204,6 +204,7 @@ def load():
     lib.wfx_sync_peaks.argtypes = [vp, vp, sz, i, i, C.c_int64, vp, vp, C.POINTER(i), C.POINTER(i)]
     lib.wfx_lines_to_image.argtypes = [vp, vp, sz, sz, i, vp]
     lib.wfx_decode_upload.argtypes = [vp, vp, C.POINTER(DecodeParams)]
+    lib.wfx_decode_upload_fd.argtypes = [vp, i, C.c_uint64, vp, sz, C.POINTER(DecodeParams)]
     lib.wfx_decode_run.argtypes = [vp]
     lib.wfx_decode_result.argtypes = [vp, C.POINTER(DecodeInfo)]
     lib.wfx_debug_counters.argtypes = [vp, C.POINTER(C.c_longlong)]
@@ -442,6 +443,13 @@ class Context:
         data = np.ascontiguousarray(data)
         self._keep = data
         self._check(self.lib.wfx_decode_upload(self.h, _ptr(data), C.byref(params)))
+
+    def decode_upload_fd(self, fd: int, file_offset: int, nbytes: int, params: DecodeParams):
+        """The capture straight from an open file (16-bit PCM): slices read into this context's staging buffer by a few threads, each
+        on its way to the device as soon as it is complete (include/wefax_hip.h: wfx_decode_upload_fd)."""
+        buf = self.staging(nbytes)
+        self._keep = buf
+        self._check(self.lib.wfx_decode_upload_fd(self.h, int(fd), int(file_offset), _ptr(buf), buf.nbytes, C.byref(params)))
 
     def decode_run(self):
         self._check(self.lib.wfx_decode_run(self.h))

@@ -121,7 +121,7 @@ def _read_into(fd: int, dest: np.ndarray, offset: int):
         return
     if _READ_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _READ_POOL = ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1), thread_name_prefix="wfx-read")
+        _READ_POOL = ThreadPoolExecutor(max_workers=min(12, os.cpu_count() or 1), thread_name_prefix="wfx-read")
     list(_READ_POOL.map(part, starts))
 
 
@@ -164,6 +164,17 @@ def wav_info(path: str):
     if (tag, bits) not in _WAV_ITEM:
         raise ValueError(f"Unsupported wav format tag {tag:#x} with {bits} bits")
     return int(rate), (nbytes // (_WAV_ITEM[(tag, bits)] * ch) if ch else 0), int(ch)
+
+
+def wav_pcm16_layout(path: str):
+    """(sample_rate, channels, offset of the samples in the file, frames) of a 16-bit PCM wav with one or two channels -- the
+    captures that reach the device exactly as they lie in the file -- else None (scipy.io.wavfile.read's other dtypes, more
+    channels: ``read_wav`` handles those)."""
+    with open(path, "rb") as fh:
+        tag, ch, rate, bits, body, nbytes = _wav_header(fh)
+    if tag != 1 or bits != 16 or ch not in (1, 2):
+        return None
+    return int(rate), int(ch), int(body), int(nbytes // (2 * ch))
 
 
 def read_wav(path: str, alloc=None):

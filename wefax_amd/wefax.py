@@ -102,6 +102,18 @@ def release_contexts():
         c.close()
 
 
+class _Shape:
+    """What process() asks of the samples before they are decoded (their count and whether there are two channels), for a file
+    whose samples it never holds (DecodeJob.from_wav)."""
+
+    def __init__(self, frames: int, channels: int):
+        self.ndim = 2 if channels > 1 else 1
+        self._n = frames
+
+    def __len__(self):
+        return self._n
+
+
 _FE_CACHE: dict = {}
 
 
@@ -179,6 +191,25 @@ class DecodeJob:
         self.length = meta["length"]
         self.params = p
         self.width = p.width
+
+    @classmethod
+    def from_wav(cls, ctx: nat.Context, path: str, layout, lines_per_minute: int = 120, notch=hp.DEFAULT_NOTCH,
+                 hilbert_mode: int = DEFAULT_HILBERT_MODE):
+        """A 16-bit PCM wav (``layout`` = hostparams.wav_pcm16_layout(path)) read and uploaded as ONE pipeline: the copy out of the
+        page cache and the DMA overlap slice by slice (wefax.py:349 + the upload; include/wefax_hip.h: wfx_decode_upload_fd).
+        Same state as ``DecodeJob(ctx, read_wav(path)[1], ...)``."""
+        rate, ch, body, frames = layout
+        job = object.__new__(cls)
+        job.ctx = ctx
+        job.frame_len = 1 / (lines_per_minute / 60)
+        job.merged_on_host = False
+        job._in_shape, job._in_dtype = ((frames, 2) if ch == 2 else (frames,)), np.dtype(np.int16)
+        kind = nat.WFX_IN_I16_STEREO if ch == 2 else nat.WFX_IN_I16_MONO
+        job._configure(kind, frames, rate, notch, hilbert_mode)
+        with open(path, "rb") as fh:
+            ctx.decode_upload_fd(fh.fileno(), body, frames * ch * 2, job.params)
+        job.info = None
+        return job
 
     @classmethod
     def from_device(cls, ctx: nat.Context, dev_ptr: int, n: int, lines_per_minute: int = 120, notch=hp.DEFAULT_NOTCH,
@@ -307,8 +338,15 @@ class Demodulator:
         if self._ctx is None:
             self._ctx = _acquire_context(self._device)
         # the samples go from the page cache into the context's page-locked staging buffer (a few threads) and from there to the
-        # device by DMA; `data` is a view of that buffer, used before process() returns
-        sample_rate, data = hp.read_wav(self.filepath, alloc=self._ctx.staging)    # wefax.py:349
+        # device by DMA; `data` is a view of that buffer, used before process() returns.  A 16-bit PCM file on the exact route takes
+        # the pipelined form of the two (DecodeJob.from_wav): only its header is read here
+        layout = hp.wav_pcm16_layout(self.filepath) if os.environ.get("WEFAX_UPLOAD_PIPELINE", "1") != "0" else None
+        if layout is not None and (self.front_end == "time-domain" and layout[0] != hp.TARGET_RATE or layout[3] < 2):
+            layout = None
+        if layout is not None:
+            sample_rate, data = layout[0], _Shape(layout[3], layout[1])
+        else:
+            sample_rate, data = hp.read_wav(self.filepath, alloc=self._ctx.staging)    # wefax.py:349
         if data.ndim == 2:                                                  # wefax.py:351-355
             self._say("\033[0;33mWARNING: two channels audio detected. Program will try to merge audio to one channel\033[0m")
             self._say("MERGING AUDIO CHANNELS:")
@@ -330,8 +368,11 @@ class Demodulator:
         job = self._time_domain_job(data, sample_rate) if (self.front_end == "time-domain" and sample_rate != hp.TARGET_RATE) else None
         self.front_end_used = "time-domain" if job is not None else "exact"
         if job is None:
-            job = DecodeJob(self._ctx, data, sample_rate, self.lines_per_minute, notch,
-                            self._hilbert_mode)
+            if layout is not None:
+                job = DecodeJob.from_wav(self._ctx, self.filepath, layout, self.lines_per_minute, notch, self._hilbert_mode)
+            else:
+                job = DecodeJob(self._ctx, data, sample_rate, self.lines_per_minute, notch,
+                                self._hilbert_mode)
             job.run()
         self._job = job
         info = job.result()
