@@ -149,7 +149,7 @@ typedef struct {
     /* sharded decode only (ignored by the one-GPU calls): which plan wfx_shard_* takes.  0 = the library's cost model decides
      * (distributed transforms, or -- where their exchanges would take longer than one GPU needs for the whole capture -- the
      * single plan: rank 0 alone); 1 = distributed whenever a distributed form exists; 2 = single.  Bit 4 (value 16) set:
-     * the ROWS layout of rounds 2-3 instead of the columns layout (A/B runs and the any-length padded forms, which still use it) */
+     * the ROWS layout of rounds 2-3 instead of the columns layout (A/B runs only: every form, the padded ones too, has the columns layout) */
     int      shard_plan;
     /* np.percentile(., (0.5, 99.5)) 'linear': rank pairs and lerp weights        */
     uint64_t rank_lo[2];
