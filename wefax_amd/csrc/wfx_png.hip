@@ -762,7 +762,7 @@ int wfx_decode_save_png_ex(wfx_ctx *ctx, const char *path, int deflate, size_t *
     const auto tp1 = std::chrono::steady_clock::now();
     // the file image sits in pinned memory; copying 27 MB into the page cache is memcpy-bound per thread (8 ms for one
     // writer), so the file is written in slices by a few threads
-    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);      // (read access too: a shared writable mapping needs it)
     if (fd < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "cannot open %s for writing", path);
     static const size_t slice = getenv("WFX_PNG_SLICE_KB") ? (size_t)atol(getenv("WFX_PNG_SLICE_KB")) << 10 : (size_t)4 << 20;
     // (a 158 MB picture -- the 60-minute 48 kHz capture -- compresses to 79 MB: up to 24 writers there; 8 filled a page cache at 3-5 GB/s)
