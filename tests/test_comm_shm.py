@@ -280,3 +280,32 @@ def test_collectives_are_timed_one_record_each_in_call_order():
             assert set(t) == {"us", "wait_us", "hidden_us", "stream", "clock"}
             assert t["clock"] == "host" and t["stream"] == "context" and t["us"] >= 0 and t["wait_us"] == t["us"] and t["hidden_us"] == 0
         assert after == (3, 3, [None, None, None])          # timing off: records are counted, not timed
+
+
+def _disagreeing_env_worker(job, rank, q):
+    """Rank 1 was started with another WFX_SHARD_CHUNKS: the plans differ in the number of k1 subsets, i.e. in the exchanges."""
+    try:
+        from wefax_amd import sharded
+        os.environ["WFX_SHARD_CHUNKS"] = "4" if rank == 0 else "2"
+        x = _capture(11025, 5, 240)
+        ctx = nat.Context(0)
+        comm = nat.Comm.shm(ctx, job, 2, rank, timeout=60.0)
+        try:
+            sharded.ShardedDecoder(ctx, comm, x.shape[0], 11025, 240, nat.WFX_IN_I16_MONO, data=x, plan="dist")
+            q.put((rank, "created"))
+        except nat.NativeError as e:
+            q.put((rank, str(e)))
+        comm.close()
+        ctx.close()
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}"))
+
+
+@pytest.mark.gpu
+def test_ranks_whose_environments_disagree_about_the_plan_are_told_so_at_creation():
+    """Round-4 advisor finding: part of the sharded plan comes from each process's own environment; ranks that decided differently used to
+    issue mismatched exchanges (RCCL: a hang).  wfx_shard_create compares a digest across the ranks and fails with WFX_ERR_COMM."""
+    job = _job()
+    out = _run(2, _disagreeing_env_worker, lambda r: (job, r), timeout=300)
+    for r in (0, 1):
+        assert "k1 subsets" in out[r] and "environments" in out[r] and "error -5" in out[r], out

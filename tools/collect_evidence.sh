@@ -63,7 +63,7 @@ python tools/shard_check2.py iq > "$OUT/shard_check_iq.jsonl" 2>> "$OUT/bench.er
 
 # BASELINE configs[3] under the profiler
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_iq" -o run -- python3 bench.py --workload iq --steps 5 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
-python tools/kstats.py "$OUT/trace_iq" "decimate|rational|select_|notch|median|image|quantise|sync|mr2_pass|mr_pass|resample|synth|dist_" > "$OUT/kernel_stats_iq.txt"
+python tools/kstats.py "$OUT/trace_iq" "ingest_stream|decimate|rational|select_|notch|median|image|quantise|sync|mr2_pass|mr_pass|resample|synth|dist_" > "$OUT/kernel_stats_iq.txt"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
 python tools/pmc_summary.py "$OUT/pmc_fetch_iq" "$OUT/pmc_write_iq" "$OUT/pmc_traffic_iq.json" > /dev/null 2>&1
@@ -102,7 +102,7 @@ WFX_SHARD_CHUNKS=4 WFX_COMM_ASYNC=0 WFX_BENCH_FORCE_DIST=1 python bench.py --wor
 
 # the same, one decode in launch order with the queue of every dispatch: the exchanges (copies on the communicator's stream) against the passes
 WFX_SHARD_CHUNKS=4 WFX_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tr_ov" -o run -- python3 bench.py --workload iq --iq-seconds 450 --steps 3 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
-python tools/kseq.py "$OUT/tr_ov" 'decimate_kernel<1' > "$OUT/kseq_iq450_rccl1_chunks4.txt" 2>&1
+python tools/kseq.py "$OUT/tr_ov" 'ingest_stream' > "$OUT/kseq_iq450_rccl1_chunks4.txt" 2>&1
 rm -rf "$OUT/tr_ov"
 # captures of ANY length through the resampler (chirp-z form) against the whole-second ones
 timeout 600 python tools/resample_any_length.py --minutes 10 > "$OUT/any_length_10min.jsonl" 2>> "$OUT/bench.err"
@@ -114,6 +114,20 @@ timeout 1200 python tools/random_parity.py --cases 200 --seed 14 > "$OUT/random_
 
 timeout 2400 python tools/random_fe_parity.py --cases 120 --seed 9 > "$OUT/random_fe_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_fe_parity.jsonl" | cut -c1-400
 timeout 1200 python tools/random_shard_parity.py --cases 80 --seed 6 > "$OUT/random_shard_parity.jsonl" 2>> "$OUT/bench.err"; tail -1 "$OUT/random_shard_parity.jsonl"
+
+# round 5: the changed launch forms of bench.py (default line with e2e, 2 ranks over shm with both plans and timed collectives, the RCCL
+# self-test failing -> fallback, one RCCL rank with event-timed collectives), the ingest kernel taken apart, instruction rates
+bash tools/r05_bench_paths.sh "$TAG/paths" > "$OUT/bench_paths.txt" 2>&1
+timeout 600 python tools/ingest_lab.py 16 > "$OUT/ingest_lab_16GiB.txt" 2>> "$OUT/bench.err"
+timeout 600 python tools/ingest_lab2.py > "$OUT/ingest_lab_60min_stream.txt" 2>> "$OUT/bench.err"
+timeout 600 python tools/alloc_lab.py 16 > "$OUT/alloc_lab.txt" 2>> "$OUT/bench.err"
+[ -x tools/micro/build/valu_rate ] && timeout 120 tools/micro/build/valu_rate > "$OUT/valu_rate.txt" 2>&1
+[ -x tools/micro/build/stream_pattern ] && timeout 300 tools/micro/build/stream_pattern > "$OUT/stream_pattern.txt" 2>&1
+python tools/e2e_c3_debug.py 2>&1 | grep -v sync_pick > "$OUT/e2e_c3_stages.txt"
+# where the ingest kernel's cycles go (SQ counters of the IQ workload, one pass)
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/sq_iq" -o run -- python3 bench.py --workload iq --steps 2 --warmup 1 --no-cpu > /dev/null 2>> "$OUT/bench.err"
+python tools/pmc_sq.py "$OUT/sq_iq" > "$OUT/sq_counters_iq.txt"
+rm -rf "$OUT/sq_iq"
 
 # the read-streaming ceiling of this box and the ingest stage against it
 if [ -x tools/micro/build/stream_big ]; then timeout 120 tools/micro/build/stream_big > "$OUT/stream_ceiling.txt" 2>&1; fi

@@ -27,7 +27,7 @@ GROUPS = [
     (r"image_kernel", "lines_to_image"), (r"median5_kernel", "median5"), (r"fir_hilbert", "fir_analytic"),
     (r"merge_kernel|i16_to_f64", "merge_channels"), (r"bs_|hilbert_mid|hconv_fill|hconv_pack", "bluestein_pointwise"),
     (r"resample_", "resample_pointwise"),
-    (r"decimate_kernel<[01],", "polyphase_ingest"), (r"decimate_kernel<[23],|rational_kernel", "polyphase_stages"),
+    (r"ingest_stream_kernel<[01], [0-9], false|decimate_kernel<[01],", "polyphase_ingest"), (r"ingest_stream_kernel<[01], [0-9], true", "polyphase_ingest_tail"), (r"decimate_kernel<[23],|rational_kernel", "polyphase_stages"),
     (r"mr_padded_fill", "bluestein_pointwise"),
     (r"select_level_kernel", "select_hist"), (r"quantise_kernel", "quantise"),
 ]

@@ -1190,8 +1190,9 @@ int wfx_comm_wire_times(wfx_comm *comm, wfx_wire_time *out, int cap)
 {
     if (!comm) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null communicator");
     const int n = (int)comm->clocks.size();
+    const size_t first = comm->wire_count > 256 ? (size_t)(comm->wire_count % 256) : 0;
     for (int i = 0; i < n && i < cap && out; ++i) {
-        const wfx_comm::wire_clock &k = comm->clocks[(size_t)i];
+        const wfx_comm::wire_clock &k = comm->clocks[(first + (size_t)i) % (size_t)n];
         wfx_wire_time t;
         t.us = t.wait_us = -1.0;
         t.on_comm_stream = k.on_comm_stream;
@@ -1217,7 +1218,9 @@ int wfx_comm_wire_stats(wfx_comm *comm, wfx_wire_entry *out, int cap)
 {
     if (!comm) return wfx_fail(nullptr, WFX_ERR_BAD_ARG, "null communicator");
     const int n = (int)comm->wire.size();
-    for (int i = 0; i < n && i < cap && out; ++i) out[i] = comm->wire[(size_t)i];
+    // (more than 256 collectives since the reset: the ring holds the last 256, handed out oldest first)
+    const size_t first = comm->wire_count > 256 ? (size_t)(comm->wire_count % 256) : 0;
+    for (int i = 0; i < n && i < cap && out; ++i) out[i] = comm->wire[(first + (size_t)i) % (size_t)n];
     return (int)(comm->wire_count < 0x7fffffffull ? comm->wire_count : 0x7fffffffull);
 }
 

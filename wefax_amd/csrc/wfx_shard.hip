@@ -1364,6 +1364,37 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
         sh->cap = cap;
     }
     if (rc == 0) rc = wfx_reserve(ctx, ctx->b_scal, sizeof(wfx_dev_scalars));
+    // The plan fixes the sequence and sizes of the collectives, and part of it comes from each process's OWN environment (WFX_LINK_GBS,
+    // WFX_LINK_LAT_US, WFX_SHARD_CHUNKS, WFX_SHARD_ROWS): a rank started with another environment would issue other exchanges, and
+    // RCCL then hangs instead of reporting anything.  The ranks compare a digest of what they decided before any of it is used
+    // (real multi-process transports only: the ranks of an in-process world share one environment and are created one by one).
+    if (rc == 0 && pl.world > 1 && !wfx_comm_is_local(comm)) {
+        long long dig[8] = {pl.single ? 1 : 0, pl.cols ? 1 : 0, (long long)pl.nchunk, (long long)pl.g.R1, (long long)pl.Kp, (long long)pl.M1,
+                            (long long)p->n0, (long long)p->n};
+        wfx_devbuf &b = sh->b_flags;
+        rc = wfx_reserve(ctx, b, 64 + (size_t)pl.world * 64);
+        std::vector<long long> all((size_t)pl.world * 8, -1);
+        if (rc == 0 && hipMemcpyAsync(b.p, dig, 64, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = wfx_fail(ctx, WFX_ERR_HIP, "plan digest upload");
+        if (rc == 0) {
+            wfx_comm_label(comm, "plan digest");
+            rc = wfx_comm_allgather(comm, ctx, b.p, (char *)b.p + 64, 64);
+        }
+        if (rc == 0 && (hipMemcpyAsync(all.data(), (char *)b.p + 64, (size_t)pl.world * 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx->stream) != hipSuccess))
+            rc = wfx_fail(ctx, WFX_ERR_HIP, "plan digest download");
+        for (int r = 0; rc == 0 && r < pl.world; ++r)
+            for (int k = 0; k < 8; ++k)
+                if (all[(size_t)r * 8 + k] != dig[k]) {
+                    static const char *what[8] = {"single plan", "columns layout", "k1 subsets", "first radix", "Hilbert length", "resampler length", "input frames", "samples"};
+                    rc = wfx_fail(ctx, WFX_ERR_COMM, "sharded decode: rank %d decided %s = %lld, rank %d %lld -- the ranks' environments (WFX_LINK_GBS, "
+                                  "WFX_LINK_LAT_US, WFX_SHARD_CHUNKS, WFX_SHARD_ROWS) or parameters differ", r, what[k], all[(size_t)r * 8 + k], pl.rank, dig[k]);
+                    break;
+                }
+        if (rc != 0) {
+            wfx_shard_destroy(sh);
+            return rc;
+        }
+    }
     if (rc == 0 && pl.single) {
         rc = wfx_reserve(ctx, sh->b_flags, 64);
         if (rc == 0 && hipMemsetAsync(sh->b_flags.p, 0, 64, ctx->stream) != hipSuccess) rc = wfx_fail(ctx, WFX_ERR_HIP, "memset");
