@@ -19,7 +19,6 @@
 #include <thread>
 #include <vector>
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <unistd.h>
 
 #define PNG_SEG 65536         // bytes per CRC span (one workgroup)
@@ -762,34 +761,23 @@ int wfx_decode_save_png_ex(wfx_ctx *ctx, const char *path, int deflate, size_t *
     const auto tp1 = std::chrono::steady_clock::now();
     // the file image sits in pinned memory; copying 27 MB into the page cache is memcpy-bound per thread (8 ms for one
     // writer), so the file is written in slices by a few threads
-    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);      // (read access too: a shared writable mapping needs it)
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "cannot open %s for writing", path);
     static const size_t slice = getenv("WFX_PNG_SLICE_KB") ? (size_t)atol(getenv("WFX_PNG_SLICE_KB")) << 10 : (size_t)4 << 20;
-    // (a 158 MB picture -- the 60-minute 48 kHz capture -- compresses to 79 MB: up to 24 writers there; 8 filled a page cache at 3-5 GB/s)
-    unsigned nthr = std::thread::hardware_concurrency(), cap = getenv("WFX_PNG_THREADS") ? (unsigned)atoi(getenv("WFX_PNG_THREADS")) : (n > ((size_t)48 << 20) ? 24u : 8u);
+    unsigned nthr = std::thread::hardware_concurrency(), cap = getenv("WFX_PNG_THREADS") ? (unsigned)atoi(getenv("WFX_PNG_THREADS")) : 8u;
     nthr = nthr < 1 ? 1 : nthr > cap ? cap : nthr;
     const size_t nslices = (n + slice - 1) / slice;
     if (nthr > nslices) nthr = (unsigned)nslices;
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
-    // large files: the threads copy into a shared mapping of the (pre-sized) file instead of calling pwrite -- page faults on distinct
-    // pages of one mapping run side by side, writes into one tmpfs / page-cache inode largely do not (79 MB: 15-25 ms by pwrite
-    // whatever the thread count).  WFX_PNG_MMAP=0 keeps pwrite; a mapping that cannot be had falls back to it
-    unsigned char *map = nullptr;
-    if (n > ((size_t)32 << 20) && !(getenv("WFX_PNG_MMAP") && atoi(getenv("WFX_PNG_MMAP")) == 0) && ftruncate(fd, (off_t)n) == 0) {
-        void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m != MAP_FAILED) map = (unsigned char *)m;
-    }
+    // (measured on the 79 MB file of the 60-minute 48 kHz picture: 15-27 ms whether 8 or 19 threads write, and the same through a shared
+    // mapping of the pre-sized file -- the time is the kernel's page allocation for the new file, not the copy)
     auto writer = [&]() {
         for (;;) {
             const size_t k = next.fetch_add(1);
             if (k >= nslices || failed.load()) return;
             size_t off = k * slice;
             const size_t end = off + slice < n ? off + slice : n;
-            if (map) {
-                memcpy(map + off, (const unsigned char *)p + off, end - off);
-                continue;
-            }
             while (off < end) {
                 const ssize_t wr = pwrite(fd, (const unsigned char *)p + off, end - off, (off_t)off);
                 if (wr <= 0) {
@@ -804,12 +792,11 @@ int wfx_decode_save_png_ex(wfx_ctx *ctx, const char *path, int deflate, size_t *
     for (unsigned i = 1; i < nthr; ++i) pool.emplace_back(writer);
     writer();
     for (auto &th : pool) th.join();
-    if (map && munmap(map, n) != 0) failed.store(true);
     const int rc = close(fd);
     if (failed.load() || rc != 0) return wfx_fail(ctx, WFX_ERR_STATE, "short write to %s", path);
     if (getenv("WFX_DEBUG"))
-        fprintf(stderr, "[wfx] png: assemble + DMA %.2f ms, write (%u threads, %s) %.2f ms\n", std::chrono::duration<double, std::milli>(tp1 - tp0).count(),
-                nthr, map ? "shared mapping" : "pwrite", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp1).count());
+        fprintf(stderr, "[wfx] png: assemble + DMA %.2f ms, write (%u threads) %.2f ms\n", std::chrono::duration<double, std::milli>(tp1 - tp0).count(),
+                nthr, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp1).count());
     if (bytes_written) *bytes_written = n;
     return 0;
 }
