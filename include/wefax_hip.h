@@ -55,8 +55,11 @@ typedef enum {
     /* 1 was WFX_HILBERT_FIR (rounds 1-2): a truncated sliding-window FIR.  It cannot stay within one grey level of the
      * reference's global FFT on noisy captures and no product path used it: removed in round 3. */
     WFX_HILBERT_BLUESTEIN = 2, /* exact, literal fft -> h -> ifft via two Bluestein DFTs (cross-check) */
-    WFX_HILBERT_FFT_POW2 = 3  /* exact, like WFX_HILBERT_FFT but always the zero-padded power-of-two form
+    WFX_HILBERT_FFT_POW2 = 3, /* exact, like WFX_HILBERT_FFT but always the zero-padded power-of-two form
                                  (WFX_HILBERT_FFT picks the unpadded mixed-radix form when N/2 is 13-smooth) */
+    WFX_HILBERT_FMM = 4       /* no transform over the capture: near field summed directly + fast multipole far field on 16 Chebyshev
+                                 nodes per box (csrc/wfx_fmm.hip; 1e-14 relative against the transform forms); even N >= 32768,
+                                 other lengths run WFX_HILBERT_FFT */
 } wfx_hilbert_mode;
 
 #define WFX_MAX_PEAKS 100   /* wefax.py:251 */
@@ -309,6 +312,9 @@ int wfx_d_decimate_fir64_batch(wfx_ctx *ctx, const void *in_dev, int in_kind, si
 int wfx_d_ingest_chain(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int factor, const double *coef1, int ntaps1, int fix_shift,
                        int factor2, const double *coef2, int ntaps2, double *out_dev, size_t n_out, int nbatch, size_t in_stride, size_t out_stride,
                        int *handled);
+/* a7 on device memory without a transform over the whole capture: out = |x + i H| (out_env != 0) or H = imag(scipy.signal.hilbert(x)),
+ * by the fast multipole form of WFX_HILBERT_FMM; *handled = 0 and nothing enqueued for lengths it does not take */
+int wfx_d_hilbert_fmm(wfx_ctx *ctx, const double *x_dev, size_t n, double *out_dev, int out_env, int *handled);
 /* measurement aid: GB/s at which this GPU reads `bytes` (>= 1 MiB, 16-byte aligned) of device memory with a kernel that only loads
  * (16-byte loads, 16 in flight per lane, 64 KiB blocks), best of `reps` launches by HIP events; waits for the stream.  bench.py puts
  * the ingest kernel's rate beside it: a slow box shows here, a slow kernel in the ratio */

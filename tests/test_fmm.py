@@ -1,0 +1,87 @@
+"""a7 without a transform over the capture (csrc/wfx_fmm.hip, hilbert mode WFX_HILBERT_FMM; round 5): the imaginary part of
+scipy.signal.hilbert as a directly summed near field plus a fast multipole far field on 16 Chebyshev nodes per box.  Held against
+the oracle's FFT form (= scipy's arithmetic) to 1e-12 relative -- the NumPy model of the same arithmetic (tools/farfield_model.py,
+tests/test_farfield_model.py) reaches 1e-14 -- and, through the whole decode, against the reference's goldens: identical uint8
+stream, peaks, start frame and image."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases, input_path, load_golden
+from oracle import wefax_oracle as wo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from wefax_amd import _native as nat
+    c = nat.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n", [32768, 65536, 40000, 100002, 250008, 1433250, 7166250, 4194304 + 2])
+def test_device_hilbert_by_fast_multipole_equals_the_transform_form(ctx, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) * 1000 + 3000 * np.sin(np.arange(n) * 0.7)
+    ref = wo.hilbert_fft(x)
+    px, po = ctx.dev_malloc(n * 8 + 64), ctx.dev_malloc(n * 8 + 64)
+    ctx.dev_upload(px, x)
+    assert ctx.d_hilbert_fmm(px, n, po)
+    got = ctx.dev_download(po, (n,), np.float64)
+    scale = np.max(np.abs(ref.imag))
+    assert np.max(np.abs(got - ref.imag)) <= 1e-12 * scale
+    assert ctx.d_hilbert_fmm(px, n, po, True)
+    env = ctx.dev_download(po, (n,), np.float64)
+    assert np.max(np.abs(env - np.abs(ref))) <= 1e-12 * scale
+    ctx.dev_free(px)
+    ctx.dev_free(po)
+
+
+def test_lengths_the_fast_multipole_form_does_not_take(ctx):
+    p = ctx.dev_malloc(1 << 20)
+    for n in (1000, 32766, 100001):          # short; below the smallest tree; odd
+        assert not ctx.d_hilbert_fmm(p, n, p + (1 << 19))
+    ctx.dev_free(p)
+
+
+@pytest.mark.parametrize("name", ["mono_noisy_240", "mono_clean_120", "stereo_overflow_120", "mono48k_image_240", "mono_noise20_lead", "mono_noisy_120",
+                                  "stereo48k_image_240", "mono_u8_240", "stereo_i32_240"])
+def test_whole_decode_with_the_fast_multipole_hilbert_matches_the_reference_goldens(name):
+    """The reference's own streams: nothing moves when the decode takes the multipole form (an odd-length capture -- mono_noisy_120 --
+    runs the transform form under the same mode)."""
+    from wefax_amd import Demodulator, _native as nat
+    case = next(c for c in golden_cases() if c["name"] == name)
+    g = load_golden(name)
+    d = Demodulator(input_path(case), lines_per_minute=case["lpm"], quiet=True, tcp_stream=True, hilbert_mode=nat.WFX_HILBERT_FMM)
+    try:
+        d.process()
+        exc = None
+    except (ValueError, IndexError) as e:
+        exc = [type(e).__name__, str(e)]
+    assert exc == case["exception"]
+    assert np.array_equal(d.digitalized_data, g["digitalized"])
+    assert d.peaks == g["peaks"].tolist()
+    st = case.get("float_stride", 5)
+    scale = np.max(np.abs(g["demod_sub"]))
+    assert np.max(np.abs(d.demodulated_data[::st] - g["demod_sub"])) <= 1e-11 * scale
+    if exc is None:
+        assert d.start_frame == case["start_frame"] and np.array_equal(d.output_array, g["image"])
+    d.close()
+
+
+def test_ten_minute_capture_both_hilbert_forms_give_one_stream():
+    from wefax_amd import _native as nat, synth
+    from wefax_amd.wefax import DecodeJob
+    x = synth.config_c2(noise=0.05, seed=3)
+    c = nat.Context(0)
+    res = []
+    for mode in (nat.WFX_HILBERT_FFT, nat.WFX_HILBERT_FMM):
+        job = DecodeJob(c, x, 11025, 120, hilbert_mode=mode)
+        job.run()
+        info = job.result()
+        res.append((job.fetch("digitalized"), job.fetch("envelope"), info.start_frame, job.fetch("image")))
+    a, b = res
+    assert np.array_equal(a[0], b[0]) and a[2] == b[2] and np.array_equal(a[3], b[3])
+    assert np.max(np.abs(a[1] - b[1])) <= 1e-12 * np.max(a[1])
+    c.close()

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("WFX_LIB") or os.path.join(_HERE, "libwefax_hip.so")  
 WFX_IN_I16_MONO, WFX_IN_I16_STEREO, WFX_IN_F64_MONO, WFX_IN_F32_MONO = 0, 1, 2, 3
 WFX_IN_U8_STEREO, WFX_IN_I32_STEREO, WFX_IN_F32_STEREO = 4, 5, 6
 STEREO_KIND_OF = {np.dtype(np.int16): 1, np.dtype(np.uint8): 4, np.dtype(np.int32): 5, np.dtype(np.float32): 6}
-WFX_HILBERT_FFT, WFX_HILBERT_BLUESTEIN, WFX_HILBERT_FFT_POW2 = 0, 2, 3      # (1 was the truncated FIR mode of rounds 1-2: removed)
+WFX_HILBERT_FFT, WFX_HILBERT_BLUESTEIN, WFX_HILBERT_FFT_POW2, WFX_HILBERT_FMM = 0, 2, 3, 4      # (1 was the truncated FIR mode of rounds 1-2: removed)
 WFX_BUF_AUDIO, WFX_BUF_ENVELOPE, WFX_BUF_DIGITAL, WFX_BUF_IMAGE = 0, 1, 2, 3
 WFX_MAX_PEAKS = 100
 
@@ -30,7 +30,7 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_read_rate", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_hilbert_fmm", "wfx_d_read_rate", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
@@ -228,6 +228,7 @@ def load():
     lib.wfx_d_notch_fir_f64.argtypes = [vp, vp, sz, dp, dp, vp, i]
     lib.wfx_d_decimate_fir64.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int)]
     lib.wfx_d_decimate_fir64_batch.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int), i, sz, sz]
+    lib.wfx_d_hilbert_fmm.argtypes = [vp, vp, sz, vp, i, C.POINTER(C.c_int)]
     lib.wfx_d_read_rate.argtypes = [vp, vp, sz, i, C.POINTER(C.c_double)]
     lib.wfx_d_ingest_chain.argtypes = [vp, vp, i, sz, i, vp, i, i, i, vp, i, vp, sz, i, sz, sz, C.POINTER(C.c_int)]
     lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
@@ -631,6 +632,13 @@ class Context:
         self._check(self.lib.wfx_d_ingest_chain(self.h, C.c_void_p(in_ptr), in_kind, n_in, int(factor), _ptr(c1), c1.shape[0], int(fix_shift),
                                                 int(factor2), _ptr(c2), c2.shape[0] if factor2 else 0, C.c_void_p(out_ptr), n_out,
                                                 int(nbatch), int(in_stride), int(out_stride), C.byref(handled)))
+        return bool(handled.value)
+
+    def d_hilbert_fmm(self, x_ptr: int, n: int, out_ptr: int, out_env: bool = False) -> bool:
+        """H = imag(scipy.signal.hilbert(x)) (or |x + i H|) by near field + fast multipole far field (csrc/wfx_fmm.hip); False: a length
+        that form does not take, nothing was enqueued."""
+        handled = C.c_int(0)
+        self._check(self.lib.wfx_d_hilbert_fmm(self.h, C.c_void_p(x_ptr), int(n), C.c_void_p(out_ptr), 1 if out_env else 0, C.byref(handled)))
         return bool(handled.value)
 
     def d_read_rate(self, ptr: int, nbytes: int, reps: int = 3) -> float:

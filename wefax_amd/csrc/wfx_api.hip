@@ -124,6 +124,15 @@ static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode,
         ctx->force_pow2 = mode == WFX_HILBERT_FFT_POW2;
         return wfx_dev_hilbert_envmed_fft(ctx, x, n, env, l0hist);
     }
+    else if (mode == WFX_HILBERT_FMM) {
+        // near field + fast multipole far field (wfx_fmm.hip); lengths it does not take (odd, short) run the transform path
+        int handled = 0;
+        WFX_TRY(wfx_dev_hilbert_fmm(ctx, x, n, env_raw, 1, &handled));
+        if (!handled) {
+            ctx->force_pow2 = false;
+            return wfx_dev_hilbert_envmed_fft(ctx, x, n, env, l0hist);
+        }
+    }
     else if (mode == WFX_HILBERT_BLUESTEIN)
         WFX_TRY(wfx_dev_hilbert_env_bluestein(ctx, x, n, env_raw));
     else
@@ -265,7 +274,8 @@ static int check_params(wfx_ctx *ctx, const wfx_decode_params *p)
     if (p->width <= 0) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "bad line width");
     if (p->rank_lo[0] >= p->n || p->rank_lo[1] >= p->n || p->rank_hi[0] >= p->n || p->rank_hi[1] >= p->n)
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "percentile rank out of range");
-    if (p->hilbert_mode != WFX_HILBERT_FFT && p->hilbert_mode != WFX_HILBERT_BLUESTEIN && p->hilbert_mode != WFX_HILBERT_FFT_POW2)
+    if (p->hilbert_mode != WFX_HILBERT_FFT && p->hilbert_mode != WFX_HILBERT_BLUESTEIN && p->hilbert_mode != WFX_HILBERT_FFT_POW2 &&
+        p->hilbert_mode != WFX_HILBERT_FMM)
         return wfx_fail(ctx, WFX_ERR_BAD_ARG, "unknown hilbert mode %d", p->hilbert_mode);
     return 0;
 }
@@ -640,6 +650,13 @@ int wfx_d_ingest_chain(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_i
     if (!in_dev || !out_dev || !coef1 || !handled || (factor2 && !coef2)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
     return wfx_dev_ingest_stream(ctx, in_dev, in_kind, n_in, factor, coef1, ntaps1, fix_shift, factor2, coef2, ntaps2, out_dev, n_out, nbatch, in_stride,
                                  out_stride, handled);
+}
+
+int wfx_d_hilbert_fmm(wfx_ctx *ctx, const double *x_dev, size_t n, double *out_dev, int out_env, int *handled)
+{
+    CHECK_CTX(ctx);
+    if (!x_dev || !out_dev || !handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return wfx_dev_hilbert_fmm(ctx, x_dev, n, out_dev, out_env, handled);
 }
 
 int wfx_d_read_rate(wfx_ctx *ctx, const void *dev, size_t bytes, int reps, double *gbs)

@@ -101,6 +101,7 @@ struct wfx_ctx {
         void *dev;
     };
     std::vector<coef_entry> coef_cache;
+    std::vector<std::pair<uint64_t, const double *>> fmm_tables;      // per capture length: tables of the fast-multipole Hilbert transform (wfx_fmm.hip)
 
     // decode state
     wfx_decode_params dp{};
@@ -358,6 +359,10 @@ int wfx_dev_export_header(wfx_ctx *ctx, const wfx_dev_scalars *d_scal, long long
 // writes out + b * out_stride
 int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_in, int64_t first, int M, const double *coef, int ntaps,
                            double *out, uint64_t n_out, int fix_shift, int *exact_out, int nbatch = 1, uint64_t in_stride = 0, uint64_t out_stride = 0);
+
+// wfx_fmm.hip: |x + i H| (out_env) or H = imag(scipy.signal.hilbert(x)) for even n by near field + fast multipole far field; *handled = 0
+// for lengths it does not take (odd, short)
+int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, int out_env, int *handled);
 
 // wfx_ingest.hip: the streaming form of the ingest (factor 32, int16 frames, taps on a 2^-s grid) with the float64 stage behind it
 // fused (factor2 = 2 or 3; 0: stage 1 alone).  *handled = 0 and nothing enqueued when the shapes are not its own

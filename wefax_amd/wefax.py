@@ -23,7 +23,9 @@ import numpy as np
 from . import _native as nat
 from . import hostparams as hp
 
-DEFAULT_HILBERT_MODE = nat.WFX_HILBERT_FFT
+# how a7 runs: "fft" = one packed circular convolution on the mixed-radix transform passes; "fmm" = near field + fast multipole far
+# field (csrc/wfx_fmm.hip: reads the audio twice instead of six passes; even N >= 32768, other lengths take the transform form)
+DEFAULT_HILBERT_MODE = nat.WFX_HILBERT_FMM if os.environ.get("WEFAX_HILBERT", "fft") == "fmm" else nat.WFX_HILBERT_FFT
 
 
 def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEFAULT_NOTCH,
