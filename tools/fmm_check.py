@@ -25,7 +25,12 @@ for n in (32768, 40000, 100000, 250008, 1433250, 7166250):
         ctx.d_hilbert_fmm(px, n, po, True)
         ctx.sync()
         ts.append(time.perf_counter() - t0)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    for _ in range(5):
+        ctx.d_hilbert_fmm(px, n, po, True)
+    ctx.sync(); ctx.profile_enable(False)
+    pr = {k: round(1e3 * v[1] / v[0], 1) for k, v in ctx.profile().items()}
     env = ctx.dev_download(po, (n,), np.float64)
     eerr = np.max(np.abs(env - np.abs(x + 1j * ref))) / np.max(np.abs(ref))
-    print(f"n {n:8d} handled {ok} max relative error H {err:.3e}  envelope {eerr:.3e}  worst at {int(np.argmax(np.abs(got - ref)))}   {1e3 * min(ts):.3f} ms", flush=True)
+    print(f"n {n:8d} handled {ok} max relative error H {err:.3e}  envelope {eerr:.3e}  {1e3 * min(ts):.3f} ms  kernels (us): {pr}", flush=True)
     ctx.dev_free(px), ctx.dev_free(po)

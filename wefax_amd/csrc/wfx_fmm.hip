@@ -26,11 +26,14 @@
 namespace {
 
 constexpr int FP = 16;                      // Chebyshev nodes per box
-constexpr int FW = 7;                       // levels inside a workgroup's subtree
-constexpr int FLV = 1 << FW;                // leaves per workgroup
-constexpr int FTH = 512;                    // threads: 8 waves x 16 leaves
+constexpr int FW = 6;                       // levels inside a leaf workgroup's subtree
+constexpr int FLV = 1 << FW;                // leaves per leaf workgroup
+constexpr int FTH = 512;                    // its threads: 8 waves x 8 leaves
 constexpr int FNEAR = 256;                  // near-field table: odd lags -255 .. 255
 constexpr int FROW = 65;                    // padded row of the P2M transposition scratch (doubles)
+constexpr int FXW = FLV * 64 + 2 * 64;      // capacity of a leaf workgroup's sample window (its leaves and one more on either side)
+constexpr int FTD = 6;                      // deepest tier of the kernels between the leaf workgroups and the top
+constexpr int FHB = 3;                      // boxes beyond either end of a subtree that its interaction lists reach
 
 struct fmm_geom {
     long long n;
@@ -55,183 +58,293 @@ struct fmm_tabs {
     const double *gnear;    // [FNEAR]: cot(pi d / n), d = 2 q - 255
 };
 
-// ---- P2M + M2M ------------------------------------------------------------------------------------------------------------------
+// M2M of one level inside LDS: nb parents from 2 nb children ([box][parity][16]); As = [2][16 i][16 j]
+template <int NT>
+__device__ __forceinline__ void fmm_m2m_level(const double *src, double *dst, const double *As, int nb, int t, double *gout)
+{
+    for (int it = t; it < nb * 2 * FP; it += NT) {
+        const int j = it & 15, hh = (it >> 4) & 1, bb = it >> 5;
+        const double *c0 = src + ((2 * bb) * 2 + hh) * FP, *c1 = c0 + 2 * FP;
+        double w = 0.0;
+#pragma unroll
+        for (int i = 0; i < FP; ++i) w = fma(As[i * FP + j], c0[i], fma(As[FP * FP + i * FP + j], c1[i], w));
+        dst[it] = w;
+        gout[it] = w;
+    }
+}
+
+// ---- P2M + M2M: a workgroup = 64 consecutive leaves -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(FTH, 4) fmm_up_leaf(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg)
 {
     extern __shared__ __align__(16) double fl[];
-    double *scr = fl;                                   // [8 waves][16][FROW]
-    double *As = fl + 8 * FP * FROW;                    // [2][16][16] i-major (M2M)
+    double *scr = fl;                                   // [8 waves][8 rows][FROW]
+    double *pw = scr + 8 * 8 * FROW;                    // [8 waves][8 rows][2][4]
+    double *mus = pw + 8 * 64;                          // [8 waves][2][16]
+    double *wb0 = mus + 8 * 32;                         // [64][2][16]
+    double *wb1 = wb0 + FLV * 2 * FP;                   // [32][2][16]
+    double *As = wb1 + (FLV / 2) * 2 * FP;              // [2][16][16] i-major
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, l = lane & 31;
     for (int i = t; i < 2 * FP * FP; i += FTH) As[i] = T.Aj[i];
-    double *ws = scr + wave * FP * FROW;
-    // this lane's row of Cw (j = l < 16)
-    double cw[FP];
+    double *ws = scr + wave * 8 * FROW, *pww = pw + wave * 64, *mw = mus + wave * 32;
+    double cw[FP];                                      // this lane's column of Cw (j = l & 15)
 #pragma unroll
     for (int k = 0; k < FP; ++k) cw[k] = T.Cw[k * FP + (l & 15)];
     const long long leaf0 = (long long)blockIdx.x * FLV;
-    for (int q = 0; q < FLV / 8; ++q) {
-        const long long k = leaf0 + wave * (FLV / 8) + q;
+    constexpr int LPW = FLV / 8;                        // leaves per wave
+    // the first leaf's sample; the next one's is requested a step ahead
+    auto sample_of = [&](long long k, long long &m, bool &valid) {
         const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1);
-        const long long m = a + ((h - a) & 1) + 2 * l;                   // lanes 0-31: even samples of the leaf, 32-63: odd ones
-        const bool valid = m < b;
-        const long long r = (m << g.L) - k * g.n;                         // position inside the leaf, in units of 1 / 2^L of a sample: [0, n)
-        const double u = valid ? 2.0 * ((double)r / (double)g.n) - 1.0 : 0.0;
-        const double xv = valid ? x[m] : 0.0;
-        double t0 = 1.0, t1 = u;
-        ws[0 * FROW + lane] = xv;
-        ws[1 * FROW + lane] = u * xv;
+        m = a + ((h - a) & 1) + 2 * l;                  // lanes 0-31: even samples of the leaf, 32-63: odd ones
+        valid = m < b;
+    };
+    long long m_cur;
+    bool v_cur;
+    sample_of(leaf0 + wave * LPW, m_cur, v_cur);
+    double x_cur = v_cur ? x[m_cur] : 0.0;
+    for (int q = 0; q < LPW; ++q) {
+        const int lk = wave * LPW + q;
+        const long long k = leaf0 + lk;
+        long long m_nxt = 0;
+        bool v_nxt = false;
+        double x_nxt = 0.0;
+        if (q + 1 < LPW) {
+            sample_of(k + 1, m_nxt, v_nxt);
+            x_nxt = v_nxt ? x[m_nxt] : 0.0;
+        }
+        const long long r = (m_cur << g.L) - k * g.n;   // position inside the leaf in units of 2^-L samples: [0, n)
+        const double u = v_cur ? 2.0 * ((double)r / (double)g.n) - 1.0 : 0.0;
+        const double xv = x_cur;
+        double tk[FP];
+        tk[0] = xv;
+        tk[1] = u * xv;
+        {
+            double t0 = 1.0, t1 = u;
 #pragma unroll
-        for (int kk = 2; kk < FP; ++kk) {
-            const double t2 = fma(2.0 * u, t1, -t0);
-            ws[kk * FROW + lane] = t2 * xv;
-            t0 = t1;
-            t1 = t2;
+            for (int kk = 2; kk < FP; ++kk) {
+                const double t2 = fma(2.0 * u, t1, -t0);
+                tk[kk] = t2 * xv;
+                t0 = t1;
+                t1 = t2;
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        // lanes l < 16 of each half: moment j = l over the half's 32 samples, then the nodal weights
-        double mu = 0.0;
-        if (l < FP) {
-            const double *row = ws + l * FROW + 32 * h;
-#pragma unroll 8
-            for (int s = 0; s < 32; ++s) mu += row[s];
+        // moments mu_k = sum over the half's 32 lanes of tk[k], eight k at a time: rows to LDS, (row, quarter) partial sums, four-way join
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) ws[kk * FROW + lane] = tk[8 * round + kk];
+            __builtin_amdgcn_wave_barrier();
+            const int row = l & 7, quarter = l >> 3;
+            const double *rp = ws + row * FROW + 32 * h + 8 * quarter;
+            double part = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) part += rp[s2];
+            pww[(row * 2 + h) * 4 + quarter] = part;
+            __builtin_amdgcn_wave_barrier();
+            if (l < 8) {
+                const double *pp = pww + (l * 2 + h) * 4;
+                mw[h * FP + 8 * round + l] = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        if (l < FP) ws[h * FP + l] = mu;                                  // (row 0 is free again)
-        __builtin_amdgcn_wave_barrier();
         if (l < FP) {
             double w = 0.0;
 #pragma unroll
-            for (int kk = 0; kk < FP; ++kk) w = fma(cw[kk], ws[h * FP + kk], w);
+            for (int kk = 0; kk < FP; ++kk) w = fma(cw[kk], mw[h * FP + kk], w);
+            wb0[(lk * 2 + h) * FP + l] = w;
             Wg[(fmm_box(g.L, k) * 2 + h) * FP + l] = w;
         }
         __builtin_amdgcn_wave_barrier();
+        m_cur = m_nxt;
+        v_cur = v_nxt;
+        x_cur = x_nxt;
     }
-    // M2M: seven levels inside the subtree, children read back from memory (written by this workgroup)
+    // M2M: six levels inside the subtree, in LDS; every level also goes to memory
+    double *src = wb0, *dst = wb1;
     for (int d = 1; d <= FW; ++d) {
-        __threadfence_block();
         __syncthreads();
-        const int lev = g.L - d, nb = FLV >> d;
-        const long long b0 = (long long)blockIdx.x * nb;
-        for (int it = t; it < nb * 2 * FP; it += FTH) {
-            const int j = it & 15, hh = (it >> 4) & 1, bb = it >> 5;
-            const double *c0 = Wg + (fmm_box(lev + 1, 2 * (b0 + bb)) * 2 + hh) * FP, *c1 = c0 + 2 * FP;
-            double w = 0.0;
-#pragma unroll
-            for (int i = 0; i < FP; ++i) w = fma(As[i * FP + j], c0[i], fma(As[FP * FP + i * FP + j], c1[i], w));
-            Wg[(fmm_box(lev, b0 + bb) * 2 + hh) * FP + j] = w;
-        }
+        const int nb = FLV >> d;
+        fmm_m2m_level<FTH>(src, dst, As, nb, t, Wg + fmm_box(g.L - d, (long long)blockIdx.x * nb) * 2 * FP);
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
     }
 }
 
-// M2L into one box: target box tb of a level with nb boxes, target parity h hears source parity 1 - h; lanes run over the target node i
-__device__ __forceinline__ double fmm_m2l(const double *__restrict__ Wlev, const double *__restrict__ Gl, long long tb, long long nb, int h, int i)
+// ---- a tier between the leaf workgroups and the top, upwards: a workgroup = the subtree of depth D under box `root` of level a --------------
+__global__ void __launch_bounds__(256) fmm_up_tier(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, int a, int D)
 {
-    // interaction list: children of the parent's neighbours that do not touch the box.  raw offset r = target - source
-    double acc = 0.0;
-    const int par = (int)(tb & 1);
-    const int offs[3] = {par ? -3 : -2, par ? -2 : 2, par ? 2 : 3};
-    const int cnt = nb == 4 ? 1 : 3;                                       // level 2: only the box opposite
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        if (s >= cnt) break;
-        const int off = nb == 4 ? 2 : offs[s];
-        const long long sb = (tb + off + nb) & (nb - 1);
-        const int r = -off;                                               // target - source
-        const double *w = Wlev + (sb * 2 + (1 - h)) * FP;
-        // r > 0: G_r[i][j], read j-major; r < 0: -G_|r|[j][i]
-        const double *gm = Gl + ((size_t)((r > 0 ? r : -r) - 2) * 2 + (r > 0 ? 0 : 1)) * FP * FP;
-        double a = 0.0;
-#pragma unroll
-        for (int j = 0; j < FP; ++j) a = fma(gm[j * FP + i], w[j], a);
-        acc += r > 0 ? a : -a;
-    }
-    return acc;
-}
-
-// ---- the levels above the workgroups' subtrees, one workgroup -----------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) fmm_top(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, double *__restrict__ Lg)
-{
-    __shared__ double As[2 * FP * FP], At[2 * FP * FP];
+    __shared__ double b0[(1 << FTD) * 2 * FP], b1[(1 << (FTD - 1)) * 2 * FP], As[2 * FP * FP];
     const int t = threadIdx.x;
-    for (int i = t; i < 2 * FP * FP; i += 1024) {
+    for (int i = t; i < 2 * FP * FP; i += 256) As[i] = T.Aj[i];
+    const double *ch = Wg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
+    for (int i = t; i < (2 * FP) << D; i += 256) b0[i] = ch[i];
+    double *src = b0, *dst = b1;
+    for (int d = 1; d <= D; ++d) {
+        __syncthreads();
+        const int nb = 1 << (D - d);
+        fmm_m2m_level<256>(src, dst, As, nb, t, Wg + fmm_box(a + D - d, (long long)blockIdx.x * nb) * 2 * FP);
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+}
+
+// L2L + M2L of one level into `dst` ([box][parity][16]) for the nb boxes b0 .. b0 + nb of a level with nbl boxes.  `lsrc`: the parents' values;
+// `wst`: weights of boxes b0 - 3 .. b0 + nb + 3 (wrapped round the circle by whoever loaded them), [slot][parity][16]; `Gs`: the level's
+// M2L matrices [r - 2][2][16][16]; `At`: [2][16 j][16 i].  Lanes run over the target node i.
+template <int NT>
+__device__ __forceinline__ void fmm_down_level(const double *lsrc, double *dst, const double *wst, const double *Gs, const double *At, long long b0, int nb,
+                                               long long nbl, int t)
+{
+    for (int it = t; it < nb * 2 * FP; it += NT) {
+        const int i = it & 15, hh = (it >> 4) & 1, bb = it >> 5;
+        const long long tb = b0 + bb;
+        double v = 0.0;
+        if (lsrc) {
+            const double *lp = lsrc + ((bb >> 1) * 2 + hh) * FP;
+            const double *am = At + (tb & 1) * FP * FP;
+#pragma unroll
+            for (int j = 0; j < FP; ++j) v = fma(am[j * FP + i], lp[j], v);
+        }
+        // interaction list: the children of the parent's neighbours that do not touch the box (raw offset r = target - source)
+        const int par = (int)(tb & 1);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            int off = s == 0 ? (par ? -3 : -2) : (s == 1 ? (par ? -2 : 2) : (par ? 2 : 3));
+            if (nbl == 4) {                                      // level 2: only the box opposite
+                if (s > 0) break;
+                off = 2;
+            }
+            const int r = -off;
+            const double *w = wst + ((bb + off + FHB) * 2 + (1 - hh)) * FP;
+            const double *gm = Gs + ((size_t)((r > 0 ? r : -r) - 2) * 2 + (r > 0 ? 0 : 1)) * FP * FP;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < FP; ++j) acc = fma(gm[j * FP + i], w[j], acc);
+            v += r > 0 ? acc : -acc;
+        }
+        dst[it] = v;
+    }
+}
+
+// weights of boxes b0 - 3 .. b0 + nb + 3 of a level with nbl boxes into LDS, round the circle
+template <int NT>
+__device__ __forceinline__ void fmm_load_halo(double *wst, const double *Wlev, long long b0, int nb, long long nbl, int t)
+{
+    for (int i = t; i < (nb + 2 * FHB) * 2 * FP; i += NT) {
+        const long long sb = (b0 - FHB + (i >> 5) + nbl) & (nbl - 1);
+        wst[i] = Wlev[sb * 2 * FP + (i & 31)];
+    }
+}
+
+// ---- the top of the tree: levels 2 .. atop (<= 5), one workgroup ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fmm_top(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, double *__restrict__ Lg, int atop)
+{
+    __shared__ double wall[64 * 2 * FP];                // weights of levels 2 .. atop at their global box index
+    __shared__ double wst[(32 + 2 * FHB) * 2 * FP];
+    __shared__ double la[32 * 2 * FP], lb[32 * 2 * FP], As[2 * FP * FP], At[2 * FP * FP], Gs[4 * FP * FP];
+    const int t = threadIdx.x;
+    for (int i = t; i < 2 * FP * FP; i += 256) {
         As[i] = T.Aj[i];
         At[i] = T.At[i];
     }
-    const int ltop = g.L - FW;                                            // level of the subtree roots
-    for (int lev = ltop - 1; lev >= 2; --lev) {                           // M2M
-        __threadfence_block();
+    const int ntop = 1 << atop;
+    for (int i = t; i < ntop * 2 * FP; i += 256) wall[fmm_box(atop, 0) * 2 * FP + i] = Wg[fmm_box(atop, 0) * 2 * FP + i];
+    for (int lev = atop - 1; lev >= 2; --lev) {
         __syncthreads();
-        const long long nb = 1ll << lev;
-        for (long long it = t; it < nb * 2 * FP; it += 1024) {
-            const int j = (int)(it & 15), hh = (int)((it >> 4) & 1);
-            const long long bb = it >> 5;
-            const double *c0 = Wg + (fmm_box(lev + 1, 2 * bb) * 2 + hh) * FP, *c1 = c0 + 2 * FP;
-            double w = 0.0;
-#pragma unroll
-            for (int i = 0; i < FP; ++i) w = fma(As[i * FP + j], c0[i], fma(As[FP * FP + i * FP + j], c1[i], w));
-            Wg[(fmm_box(lev, bb) * 2 + hh) * FP + j] = w;
-        }
+        fmm_m2m_level<256>(wall + fmm_box(lev + 1, 0) * 2 * FP, wall + fmm_box(lev, 0) * 2 * FP, As, 1 << lev, t, Wg + fmm_box(lev, 0) * 2 * FP);
     }
-    for (int lev = 2; lev <= ltop; ++lev) {                               // M2L + L2L
-        __threadfence_block();
+    double *src = nullptr, *dst = la;
+    for (int lev = 2; lev <= atop; ++lev) {
         __syncthreads();
-        const long long nb = 1ll << lev;
-        const double *Wlev = Wg + fmm_box(lev, 0) * 2 * FP;
-        const double *Gl = T.G + (size_t)(lev - 2) * 4 * FP * FP;
-        for (long long it = t; it < nb * 2 * FP; it += 1024) {
-            const int i = (int)(it & 15), hh = (int)((it >> 4) & 1);
-            const long long bb = it >> 5;
-            double v = fmm_m2l(Wlev, Gl, bb, nb, hh, i);
-            if (lev > 2) {
-                const double *lp = Lg + (fmm_box(lev - 1, bb >> 1) * 2 + hh) * FP;
-                const double *a = At + (bb & 1) * FP * FP;
-#pragma unroll
-                for (int j = 0; j < FP; ++j) v = fma(a[j * FP + i], lp[j], v);
-            }
-            Lg[(fmm_box(lev, bb) * 2 + hh) * FP + i] = v;
-        }
+        const int nb = 1 << lev;
+        for (int i = t; i < 4 * FP * FP; i += 256) Gs[i] = T.G[(size_t)(lev - 2) * 4 * FP * FP + i];
+        for (int i = t; i < (nb + 2 * FHB) * 2 * FP; i += 256) wst[i] = wall[(fmm_box(lev, ((i >> 5) - FHB + nb) & (nb - 1))) * 2 * FP + (i & 31)];
+        __syncthreads();
+        fmm_down_level<256>(src, dst, wst, Gs, At, 0, nb, nb, t);
+        src = dst;
+        dst = dst == la ? lb : la;
     }
+    __syncthreads();
+    for (int i = t; i < ntop * 2 * FP; i += 256) Lg[fmm_box(atop, 0) * 2 * FP + i] = src[i];
 }
 
-// ---- L2L + M2L inside a subtree, then the leaves ---------------------------------------------------------------------------------------
+// ---- a tier downwards: from the local expansion of box `root` of level a to those of its 2^D descendants of level a + D --------------------------
+__global__ void __launch_bounds__(256) fmm_down_tier(const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg, double *__restrict__ Lg, int a, int D)
+{
+    __shared__ double la[(1 << FTD) * 2 * FP], lb[(1 << (FTD - 1)) * 2 * FP], wst[((1 << FTD) + 2 * FHB) * 2 * FP], At[2 * FP * FP], Gs[4 * FP * FP];
+    const int t = threadIdx.x;
+    for (int i = t; i < 2 * FP * FP; i += 256) At[i] = T.At[i];
+    double *src = (D & 1) ? lb : la, *dst = (D & 1) ? la : lb;          // (the last level ends in `la`)
+    if (t < 2 * FP) src[t] = Lg[fmm_box(a, blockIdx.x) * 2 * FP + t];
+    for (int d = 1; d <= D; ++d) {
+        const int lev = a + d, nb = 1 << d;
+        const long long nbl = 1ll << lev, b0 = (long long)blockIdx.x << d;
+        __syncthreads();
+        for (int i = t; i < 4 * FP * FP; i += 256) Gs[i] = T.G[(size_t)(lev - 2) * 4 * FP * FP + i];
+        fmm_load_halo<256>(wst, Wg + fmm_box(lev, 0) * 2 * FP, b0, nb, nbl, t);
+        __syncthreads();
+        fmm_down_level<256>(src, dst, wst, Gs, At, b0, nb, nbl, t);
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    __syncthreads();
+    double *o = Lg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
+    for (int i = t; i < (2 * FP) << D; i += 256) o[i] = src[i];
+}
+
+// ---- L2L + M2L inside a leaf subtree, then the leaves -----------------------------------------------------------------------------------
 template <int OUT_ENV>
 __global__ void __launch_bounds__(FTH, 4) fmm_down_leaf(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg,
                                                         const double *__restrict__ Lg, double *__restrict__ out)
 {
     extern __shared__ __align__(16) double fl[];
-    double *la = fl;                                    // [128][2][16]  ping
-    double *lb = la + FLV * 2 * FP;                     // [64][2][16]   pong (the last level is written to `la`)
+    double *la = fl;                                    // [64][2][16]
+    double *lb = la + FLV * 2 * FP;                     // [32][2][16]
     double *At = lb + (FLV / 2) * 2 * FP;               // [2][16 j][16 i]
-    double *Gs = At + 2 * FP * FP;                      // [2 r][2][16][16] of the current level
-    double *gn = Gs + 4 * FP * FP;                      // [FNEAR]
-    double *win = gn + FNEAR;                           // [8 waves][200]
+    double *gn = At + 2 * FP * FP;                      // [FNEAR]
+    double *un = gn + FNEAR;                            // the tree phase: weights of a level + its M2L matrices; the leaf phase: the sample window
+    double *wst = un, *Gs = un + (FLV + 2 * FHB) * 2 * FP;
+    double *xw = un;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, l = lane & 31;
+    const long long leaf0 = (long long)blockIdx.x * FLV, nleaf = 1ll << g.L;
+    // the workgroup's samples -- its 64 leaves and one more on either side, round the circle -- are requested now and wait in registers
+    // until the tree phase is through with the LDS they go to
+    const long long km = leaf0 == 0 ? nleaf - 1 : leaf0 - 1;
+    const long long w0 = fmm_leaf_first(g, km) - (leaf0 == 0 ? g.n : 0);                       // may be negative
+    const long long kl = leaf0 + FLV == nleaf ? 0 : leaf0 + FLV;                              // the leaf behind the last one
+    const long long w1 = (leaf0 + FLV == nleaf ? g.n : 0) + fmm_leaf_first(g, kl + 1);
+    const int wlen = (int)(w1 - w0);                                                            // <= FXW
+    constexpr int XPT = (FXW + FTH - 1) / FTH;
+    double xr[XPT];
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+        const int idx = t + q * FTH;
+        long long m = w0 + idx;
+        m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
+        xr[q] = idx < wlen ? x[m] : 0.0;
+    }
     for (int i = t; i < 2 * FP * FP; i += FTH) At[i] = T.At[i];
     for (int i = t; i < FNEAR; i += FTH) gn[i] = T.gnear[i];
     const int ltop = g.L - FW;
-    if (t < 2 * FP) lb[t] = Lg[fmm_box(ltop, blockIdx.x) * 2 * FP + t];
-    // seven levels down: the current level's values alternate between `lb` and `la`, the leaf level ends in `la`
+    static_assert((FW & 1) == 0, "root in the large buffer: an even number of levels later the leaf level is there again");
+    double *src = la, *dst = lb;
+    if (t < 2 * FP) src[t] = Lg[fmm_box(ltop, blockIdx.x) * 2 * FP + t];
     for (int d = 1; d <= FW; ++d) {
         const int lev = ltop + d, nb = 1 << d;
-        double *src = (d & 1) ? lb : la, *dst = (d & 1) ? la : lb;
+        const long long nbl = 1ll << lev, b0 = (long long)blockIdx.x << d;
         __syncthreads();
         for (int i = t; i < 4 * FP * FP; i += FTH) Gs[i] = T.G[(size_t)(lev - 2) * 4 * FP * FP + i];
+        fmm_load_halo<FTH>(wst, Wg + fmm_box(lev, 0) * 2 * FP, b0, nb, nbl, t);
         __syncthreads();
-        const long long nbl = 1ll << lev, b0 = (long long)blockIdx.x * nb;
-        const double *Wlev = Wg + fmm_box(lev, 0) * 2 * FP;
-        for (int it = t; it < nb * 2 * FP; it += FTH) {
-            const int i = it & 15, hh = (it >> 4) & 1, bb = it >> 5;
-            double v = fmm_m2l(Wlev, Gs, b0 + bb, nbl, hh, i);
-            const double *lp = src + ((bb >> 1) * 2 + hh) * FP;
-            const double *a = At + (bb & 1) * FP * FP;
-#pragma unroll
-            for (int j = 0; j < FP; ++j) v = fma(a[j * FP + i], lp[j], v);
-            dst[(bb * 2 + hh) * FP + i] = v;
-        }
+        fmm_down_level<FTH>(src, dst, wst, Gs, At, b0, nb, nbl, t);
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
     }
-    static_assert(FW & 1, "the leaf level must end in the large buffer");
-    __syncthreads();
-    // nodal values -> Chebyshev coefficients, in place (one lane per (leaf, parity): 16 values in, 16 out)
+    __syncthreads();                                    // (src == la: the 64 leaves' nodal values)
+    // nodal values -> Chebyshev coefficients, in place (one lane per leaf and parity)
     for (int it = t; it < FLV * 2; it += FTH) {
         double *p = la + it * FP;
         double v[FP], c[FP];
@@ -239,43 +352,31 @@ __global__ void __launch_bounds__(FTH, 4) fmm_down_leaf(const double *__restrict
         for (int j = 0; j < FP; ++j) v[j] = p[j];
 #pragma unroll
         for (int k = 0; k < FP; ++k) {
-            double s = 0.0;
+            double s2 = 0.0;
 #pragma unroll
-            for (int j = 0; j < FP; ++j) s = fma(T.Ca[j * FP + k], v[j], s);
-            c[k] = s;
+            for (int j = 0; j < FP; ++j) s2 = fma(T.Ca[j * FP + k], v[j], s2);
+            c[k] = s2;
         }
 #pragma unroll
         for (int k = 0; k < FP; ++k) p[k] = c[k];
     }
-    __syncthreads();
-    // the leaves: lanes 0-31 the even samples of a leaf, 32-63 the odd ones
-    double *ww = win + wave * 200;
-    const long long leaf0 = (long long)blockIdx.x * FLV, nleaf = 1ll << g.L;
-    for (int q = 0; q < FLV / 8; ++q) {
-        const int lk = wave * (FLV / 8) + q;
-        const long long k = leaf0 + lk;
-        const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1);
-        // window: leaves k - 1 .. k + 1 on the circle, positions relative to its first sample
-        const long long km = k == 0 ? nleaf - 1 : k - 1, kp = k + 1 == nleaf ? 0 : k + 1;
-        const long long w0 = fmm_leaf_first(g, km) - (k == 0 ? g.n : 0);            // may be negative
-        const long long w1 = (k + 1 == nleaf ? g.n : 0) + fmm_leaf_first(g, kp + 1);   // one past the window
-        const int wlen = (int)(w1 - w0);                                              // <= 192
-        __builtin_amdgcn_wave_barrier();
+    // the samples take the place of the tree phase's weights
 #pragma unroll
-        for (int s = 0; s < 200; s += 64) {
-            const int idx = s + lane;
-            if (idx < 200) {
-                long long m = w0 + idx;
-                m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
-                ww[idx] = idx < wlen ? x[m] : 0.0;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const long long m = a + ((h - a) & 1) + 2 * l;
+    for (int q = 0; q < XPT; ++q) {
+        const int idx = t + q * FTH;
+        if (idx < FXW) xw[idx] = xr[q];
+    }
+    __syncthreads();
+    constexpr int LPW = FLV / 8;
+    for (int q = 0; q < LPW; ++q) {
+        const int lk = wave * LPW + q;
+        const long long k = leaf0 + lk;
+        // unwrapped sample positions (fmm_leaf_first continues round the circle: leaf -1 starts at a negative position, leaf 2^L at n)
+        const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1), ws0 = fmm_leaf_first(g, k - 1), we = fmm_leaf_first(g, k + 2);
+        const long long m = a + ((h - a) & 1) + 2 * l;   // lanes 0-31: even samples of the leaf, 32-63: odd ones
         const bool valid = m < b;
         const long long r = (m << g.L) - k * g.n;
         const double u = valid ? 2.0 * ((double)r / (double)g.n) - 1.0 : 0.0;
-        const int rel = (int)(m - w0);                                                 // position of the target in the window
         // far field: sum_k a_k T_k(u)
         const double *ac = la + (lk * 2 + h) * FP;
         double t0 = 1.0, t1 = u, far = fma(ac[1], u, ac[0]);
@@ -286,21 +387,23 @@ __global__ void __launch_bounds__(FTH, 4) fmm_down_leaf(const double *__restrict
             t0 = t1;
             t1 = t2;
         }
-        // near field: every sample of the other parity in the window (absolute parity: (w0 + p) & 1 == 1 - h)
-        const int p0 = (int)(((1 - h) - w0) & 1);                                     // first window position of the source parity
-        int gi = (rel - p0 + (FNEAR - 1)) >> 1;                                       // table index of lag rel - p0 (odd)
+        // near field: every sample of the OTHER parity in leaves k - 1 .. k + 1, kernel from the table of odd lags
+        const long long ps0 = ws0 + (((1 - h) - ws0) & 1);
+        const int cnt = (int)((we - ps0 + 1) >> 1);
+        const double *sp = xw + (ps0 - w0);
+        int gi = (int)((m - ps0 + (FNEAR - 1)) >> 1);
         double n0 = 0.0, n1 = 0.0;
-        const double *sp = ww + p0;
-#pragma unroll 4
-        for (int s = 0; s < 96; s += 2) {
-            n0 = fma(gn[gi & (FNEAR - 1)], sp[2 * s], n0);
-            n1 = fma(gn[(gi - 1) & (FNEAR - 1)], sp[2 * s + 2], n1);
+        int s2 = 0;
+        for (; s2 + 1 < cnt; s2 += 2) {
+            n0 = fma(gn[gi], sp[2 * s2], n0);
+            n1 = fma(gn[gi - 1], sp[2 * s2 + 2], n1);
             gi -= 2;
         }
+        if (s2 < cnt) n0 = fma(gn[gi], sp[2 * s2], n0);
         const double H = g.scale * (far + (n0 + n1));
         if (valid) {
             if (OUT_ENV) {
-                const double xv = ww[rel];
+                const double xv = xw[m - w0];
                 out[m] = sqrt(fma(xv, xv, H * H));
             } else {
                 out[m] = H;
@@ -367,10 +470,10 @@ static double cot_unit(double z, int lev)
 int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, int out_env, int *handled)
 {
     *handled = 0;
-    if (n % 2 || n < (64ull << (FW + 2)) || n > (1ull << 40)) return 0;
+    if (n % 2 || n < 32768 || n > (1ull << 32)) return 0;
     int L = 0;
     while (((double)n / (double)(1ull << L)) > 64.0) ++L;                 // leaf size in (32, 64]
-    if (L < FW + 2 || L > 26) return 0;                                   // ((sample << L) stays inside 63 bits)
+    if (L < FW + 2 || L > 26) return 0;                                   // ((sample << L) stays inside 63 bits; at least level 2 above the leaf roots)
     // device tables, cached per n: the static ones, the M2L matrices of levels 2..L (unit kernel), the near table of THIS n
     const double *dt = nullptr;
     for (auto &e : ctx->fmm_tables)
@@ -419,11 +522,12 @@ int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, 
     g.scale = 2.0 / (double)n;
     const size_t nbox = (size_t)1 << (L + 1);                             // all levels
     WFX_TRY(wfx_reserve(ctx, ctx->b_work, nbox * 2 * FP * 8));           // weights W
-    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, ((size_t)1 << (L - FW + 1)) * 2 * FP * 8 + 64));    // local expansions of the top levels
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, ((size_t)1 << (L - FW + 1)) * 2 * FP * 8 + 64));    // local expansions down to the leaf workgroups' roots
     double *Wg = (double *)ctx->b_work.p, *Lg = (double *)ctx->b_work2.p;
     const unsigned nwg = 1u << (L - FW);
-    const size_t lds_up = (size_t)(8 * FP * FROW + 2 * FP * FP) * 8;
-    const size_t lds_dn = (size_t)(FLV * 2 * FP + (FLV / 2) * 2 * FP + 2 * FP * FP + 4 * FP * FP + FNEAR + 8 * 200) * 8;
+    const size_t lds_up = (size_t)(8 * 8 * FROW + 8 * 64 + 8 * 32 + FLV * 2 * FP + (FLV / 2) * 2 * FP + 2 * FP * FP) * 8;
+    const size_t lds_dn = (size_t)(FLV * 2 * FP + (FLV / 2) * 2 * FP + 2 * FP * FP + FNEAR + FXW) * 8;
+    static_assert(FXW >= (FLV + 2 * FHB) * 2 * FP + 4 * FP * FP, "the sample window is also the tree phase's staging area");
     static bool attr_done = false;
     if (!attr_done) {
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up));
@@ -431,11 +535,24 @@ int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, 
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn));
         attr_done = true;
     }
+    // tiers between the leaf workgroups' roots (level L - 6) and the top (levels 2 .. atop <= 5): at most six levels each
+    int tier_a[8], tier_d[8], ntier = 0, cur = L - FW;
+    while (cur > 5) {
+        const int D = std::min(FTD, cur - 2);
+        tier_a[ntier] = cur - D;
+        tier_d[ntier] = D;
+        ++ntier;
+        cur -= D;
+    }
+    const int atop = cur;
     wfx_prof_begin(ctx, K_FFT_FWD);
     hipLaunchKernelGGL(fmm_up_leaf, dim3(nwg), dim3(FTH), lds_up, ctx->stream, x, g, T, Wg);
     wfx_prof_end(ctx);
     wfx_prof_begin(ctx, K_BS_CHIRP);
-    hipLaunchKernelGGL(fmm_top, dim3(1), dim3(1024), 0, ctx->stream, g, T, Wg, Lg);
+    for (int k = 0; k < ntier; ++k) hipLaunchKernelGGL(fmm_up_tier, dim3(1u << tier_a[k]), dim3(256), 0, ctx->stream, g, T, Wg, tier_a[k], tier_d[k]);
+    hipLaunchKernelGGL(fmm_top, dim3(1), dim3(256), 0, ctx->stream, g, T, Wg, Lg, atop);
+    for (int k = ntier - 1; k >= 0; --k)
+        hipLaunchKernelGGL(fmm_down_tier, dim3(1u << tier_a[k]), dim3(256), 0, ctx->stream, g, T, (const double *)Wg, Lg, tier_a[k], tier_d[k]);
     wfx_prof_end(ctx);
     wfx_prof_begin(ctx, K_FFT_INV);
     if (out_env)
