@@ -1,5 +1,5 @@
 """Where the streaming ingest kernel (csrc/wfx_ingest.hip) spends its time: the fused / 32 -> / 3 chain on 16 GiB of int16 IQ frames
-with parts of the kernel switched off (WFX_INGEST_DBG=rows,flags -- tap rows applied, 1 = no LDS stash, 2 = no stage 2; results are
+with parts of the kernel switched off (WFX_INGEST_DBG=flags -- 1 = no LDS stash, 2 = no stage 2, 4 = no stage 1, 8 = no barrier B; results are
 wrong, times are what is asked), other run lengths, and the tile kernels of rounds 1-4 beside it.
     gpurun -- 'python tools/ingest_lab.py [GiB]'"""
 import os
@@ -71,8 +71,9 @@ report("stage 1 only (y1 to memory)", timed(stage1_only))
 os.environ["WFX_INGEST_TILE"] = "1"
 report("tile kernel (rounds 1-4), stage 1", timed(tile))
 del os.environ["WFX_INGEST_TILE"]
-for rows, flags in ((8, 0), (8, 2), (0, 2), (0, 3), (0, 7), (0, 15), (8, 10)):
-    os.environ["WFX_INGEST_DBG"] = f"{rows},{flags}"
+for flags in (0, 2, 4, 6, 7, 15, 10):
+    rows = 8
+    os.environ["WFX_INGEST_DBG"] = str(flags)
     what = " ".join(w for b, w in ((1, "no-stash"), (2, "no-stage2"), (4, "no-stage1"), (8, "no-barrier-B")) if flags & b)
     report(f"fused  rows={rows} flags={flags} ({what})", timed(fused))
 del os.environ["WFX_INGEST_DBG"]

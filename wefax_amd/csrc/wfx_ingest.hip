@@ -14,14 +14,22 @@
 // that re-staged their halo; its time did not move with the tap count (profiles/r03_v4/ingest_probe.txt: 32 taps as slow as 256)
 // -- the staging, not the arithmetic, kept it at 4.5-5.5 TB/s.  Here a workgroup STREAMS through a long contiguous run:
 //
-//   * samples lie in LDS in their natural order, one row = the 32 frames of one decimation step = 16 dwords of int16 pairs;
-//     a 16-byte IQ chunk is merged with two v_perm + one v_pk_add_u16 per pair and stored with ONE ds_write_b64;
-//   * a thread owns two consecutive outputs (2t, 2t+1): their windows are rows 2t .. 2t+8, read once with ds_read_b128 (rows
-//     are padded by 4 dwords per pair of rows: lane stride 36 dwords, conflict-free), and every window dword feeds the two
-//     outputs' tap pairs -- adjacent samples ARE the pair v_dot2_i32_i16 wants, the taps are scalar operands;
-//   * taps on the grid 2^-s are split into three pieces a * 2^18 + b * 2^9 + c (b, c nine bits): each piece's int32 sum over the
-//     whole window holds the worst-case input (sum |piece| * 32768 < 2^31, checked by the host), so there is no 64-bit
-//     arithmetic inside the loop and the result is exact for every input;
+//   * samples lie in LDS in their natural order as two BYTE PLANES: a sample s = 256 hi + (lo ^ 0x80) + 128 with hi, lo signed bytes;
+//     one row = the 32 frames of one decimation step = 16 dwords: per 16 samples four dwords of high bytes, then four of low ones.
+//     A 16-byte IQ chunk is merged (two v_perm + one v_pk_add_u16 per pair), split (two v_perm, one v_xor) and stored with one
+//     ds_write2_b32;
+//   * the 256-tap window sums run on the matrix cores, every sample read from LDS ONCE per byte plane: v_mfma_i32_16x16x64_i8 with
+//     the TAPS as the A operand -- a fixed-point tap is four balanced signed bytes t = q0 + 2^8 q1 + 2^16 q2 + 2^24 q3; row 4 c + q
+//     of A = digit plane q of taps 64 c .. 64 c + 63 (the whole filter: 16 rows x 64, four registers per lane for the whole kernel)
+//     -- and 16 consecutive LDS rows R as the B operand's columns (lane (j, g): the 16 bytes at sample 16 g of the two-row window
+//     that starts at row R0 + j, one ds_read_b128).  Column j of the product is then what rows R, R + 1 contribute, through tap
+//     chunk c, to output R - 2 c: lane (g = c, j) holds that chunk's four digit sums in its four accumulator registers, folds
+//     them (sum_q 2^(8q) (2^8 Dh[q] + Dl[q]), 64-bit) and adds the result to the output's cell of an LDS array with ds_add_u64 --
+//     integer sums, any order, exact for every input (a digit sum is at most 64 x 128 x 128 = 2^20).  Two MFMAs, two window reads
+//     and one atomic per 16 rows; 128 sum(taps) for the low plane's offset joins when the cell is converted to float64.
+//     (Round 5 first ran this stage on v_dot2_i32_i16 with the taps as scalar operands, then as MFMAs over windows read once per
+//     output: both read every sample 8 x from LDS, and with noisy data that -- not the arithmetic -- pulled the shader clock from
+//     2.36 to 2.02 GHz and the whole kernel, loads included, with it: EXPERIMENTS.md §11.)
 //   * an iteration handles 512 outputs = 64 KiB of IQ frames; the next block's 16 chunks per lane are requested right after this
 //     block's registers were stored to LDS and stay in flight during the whole compute phase; the last 8 rows are carried over
 //     as the next iteration's halo (128 dwords through registers), so nothing is read twice inside a run;
@@ -30,6 +38,7 @@
 // Roofline: HBM.  Algorithmic bytes per launch = 4 B per IQ frame + 8 B per output.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -46,38 +55,35 @@ constexpr int IG_BLK = 2 * IG_THREADS;          // stage-1 outputs (= new LDS ro
 constexpr int IG_HALO = 8;                      // rows of history: a window spans 8 rows (<= 256 taps)
 constexpr int IG_ROWS = IG_BLK + IG_HALO;
 constexpr int IG_RD = IG_M / 2;                 // dwords per row
-constexpr int IG_NPAIR = 4 * IG_M;              // tap pairs per output (zero padded): 128
-constexpr int IG_NGRP = IG_NPAIR / 4;           // groups of four pairs = one ds_read_b128: 32 per output
 constexpr int IG_YRING = 2 * IG_BLK, IG_YMIRROR = 128;      // (a power of two >= one iteration's outputs + a stage-2 window)
 static_assert(IG_YRING >= IG_BLK + IG_YMIRROR && IG_THREADS >= IG_HALO * (IG_M / 2), "ring / carry sizes");
-#ifndef WFX_IG_DBG_PIECES
-#define WFX_IG_DBG_PIECES 3
-#endif
-constexpr int IG_DBG_PIECES = WFX_IG_DBG_PIECES;      // (timing experiments only: fewer pieces give wrong sums)
 #ifndef WFX_IG_LOAD_AUX
 #define WFX_IG_LOAD_AUX 2
 #endif
 constexpr int IG_LOAD_AUX = WFX_IG_LOAD_AUX;      // cache policy of the block loads: 2 = nt (every byte is read once; measured 1.5 % over the default, 0)
-constexpr int IG_HILO = 12;                     // ... or, in a row of small taps, hi * 2^12 + lo
-constexpr int IG_PIECE = 9;                      // a fixed-point tap is a * 2^18 + b * 2^9 + c with b, c in [-256, 255]
+constexpr int IG_KC = 4;                        // chunks of 64 taps per window = row groups of the MFMA's A operand
+constexpr int IG_TAB = 64 * 4;                  // tap table: [lane][4 dwords]
+constexpr int IG_TILES = IG_BLK / 16 + 1;       // tiles of 16 rows per iteration: rows 0 .. IG_BLK + 6 start a two-row window somebody needs
 
 __host__ __device__ constexpr int ig_row_off(int r) { return r * IG_RD + (r >> 1) * 4; }       // dword offset of row r
 constexpr int IG_XS_BYTES = ig_row_off(IG_ROWS) * 4;
 constexpr int IG_C2PAD = 120;                   // stage-2 taps in LDS, zero padded to whole trips of 12
 constexpr int IG_YS_BYTES = (IG_YRING + IG_YMIRROR + IG_C2PAD) * 8;
 
-typedef short ig_s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short ig_us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int ig_dot2(int w, int c, int acc)
-{
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(ig_s2, w), __builtin_bit_cast(ig_s2, c), acc, false);
-}
+typedef int ig_v4i __attribute__((ext_vector_type(4)));
 // two IQ frames (I | Q << 16 each) -> one dword of two merged samples, (int16)(I + Q) with the int16 wrap of wefax.py:367
 __device__ __forceinline__ unsigned ig_merge2(unsigned w0, unsigned w1)
 {
     const unsigned lo = __builtin_amdgcn_perm(w1, w0, 0x05040100u);      // (I0, I1)
     const unsigned hi = __builtin_amdgcn_perm(w1, w0, 0x07060302u);      // (Q0, Q1)
     return __builtin_bit_cast(unsigned, (ig_us2)(__builtin_bit_cast(ig_us2, lo) + __builtin_bit_cast(ig_us2, hi)));
+}
+// four samples (two dwords of int16 pairs) -> their high bytes and their low bytes ^ 0x80, sample k in byte k
+__device__ __forceinline__ void ig_planes(unsigned m0, unsigned m1, unsigned &hi, unsigned &lo)
+{
+    hi = __builtin_amdgcn_perm(m1, m0, 0x07050301u);
+    lo = __builtin_amdgcn_perm(m1, m0, 0x06040200u) ^ 0x80808080u;
 }
 
 struct ig_params {
@@ -90,8 +96,9 @@ struct ig_params {
     long long run_out;          // outputs per workgroup run
     long long in_bs, out_bs;    // batch strides (bytes / elements)
     long long out0;             // first output of the launch's first run
-    unsigned mask3;             // bit j: tap row j runs in three pieces (else two)
-    int dbg_rows, dbg_flags;    // diagnostics (WFX_INGEST_DBG=rows,flags; results are WRONG unless 8,0): tap rows applied; 1 no stash, 2 no stage 2, 4 no stage 1, 8 no barrier B; WFX_INGEST_DBG_LDS: extra LDS bytes
+    long long bias;             // 128 * sum of the fixed-point taps (the low plane is stored less 128)
+    unsigned long long *dbg_clk;        // diagnostics (WFX_INGEST_CLK=1): every 64th run's (shader clocks, 100 MHz ticks) -> the effective shader clock
+    int dbg_flags;              // diagnostics (WFX_INGEST_DBG=flags; results are WRONG unless 0): 1 no stash, 2 no stage 2, 4 no stage 1, 8 no barrier B; WFX_INGEST_DBG_LDS: extra LDS bytes
 };
 
 // frames [e0, e0 + FPC) as one 16-byte chunk; frames at or beyond n_in read as zero
@@ -125,30 +132,45 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     constexpr int HC = IG_HALO * CPR;                                     // chunks of the first halo
     extern __shared__ __align__(16) unsigned char ig_lds[];
     int *xs = (int *)ig_lds;
-    double *ys = (double *)(ig_lds + IG_XS_BYTES);
+    unsigned long long *acc = (unsigned long long *)(ig_lds + IG_XS_BYTES);                // [IG_BLK]: the iteration's window sums
+    double *ys = (double *)(ig_lds + IG_XS_BYTES + IG_BLK * 8);
     double *cs = ys + IG_YRING + IG_YMIRROR;
     const int t = threadIdx.x;
     const unsigned char *in = (const unsigned char *)P.in + (size_t)blockIdx.y * (size_t)P.in_bs;
     double *out = P.out + (size_t)blockIdx.y * (size_t)P.out_bs;
 
-    const long long o0 = P.out0 + (long long)blockIdx.x * P.run_out;                 // first output of this run
+    const unsigned long long clk0 = P.dbg_clk ? (unsigned long long)clock64() : 0ull, wall0 = P.dbg_clk ? (unsigned long long)wall_clock64() : 0ull;
+    // run = blockIdx.x: workgroups go round-robin to the 8 XCDs, so the ~768 resident ones stream through 768 neighbouring runs, every
+    // XCD through every eighth one.  (Dealing each XCD ONE eighth of the capture -- its 96 workgroups on 96 neighbouring runs -- measured
+    // 9 % slower, 4.00 against 3.68 ms on the 60-minute stream: EXPERIMENTS.md §11.)
+    const long long run = blockIdx.x;
+    const long long o0 = P.out0 + run * P.run_out;                          // first output of this run
     const long long ocnt = P.n_out - o0 < P.run_out ? P.n_out - o0 : P.run_out;
     const long long s0 = M2 ? o0 * M2 : o0;                               // first stage-1 output the run needs
     const long long cnt1 = M2 ? (ocnt - 1) * M2 + P.ntaps2 : ocnt;
     const int niter = (int)((cnt1 + IG_BLK - 1) / IG_BLK);
     const long long f0 = s0 * IG_M;                                       // its first frame
 
-    // chunk c of a block of rows goes to row c / CPR, dword (c % CPR) * (IG_RD / CPR); a thread's chunks of one iteration are
-    // IG_THREADS / CPR rows (an even number) apart: a constant LDS offset
+    // chunk c of a block of rows goes to row c / CPR; inside the row a group of 16 samples is 8 dwords, high bytes then low bytes.  A
+    // thread's chunks of one iteration are IG_THREADS / CPR rows (an even number) apart: a constant LDS offset
+    auto chunk_off = [](int cc) { return IN == WFX_IN_I16_STEREO ? 8 * (cc >> 2) + (cc & 3) : 8 * (cc >> 1) + 2 * (cc & 1); };
     auto put = [&](int *dst, const uint4 &v) {
-        if (IN == WFX_IN_I16_STEREO)
-            *(uint2 *)dst = make_uint2(ig_merge2(v.x, v.y), ig_merge2(v.z, v.w));
-        else
-            *(uint4 *)dst = v;
+        if (IN == WFX_IN_I16_STEREO) {
+            unsigned hi, lo;
+            ig_planes(ig_merge2(v.x, v.y), ig_merge2(v.z, v.w), hi, lo);
+            dst[0] = (int)hi;
+            dst[4] = (int)lo;
+        } else {
+            unsigned h0, l0, h1, l1;
+            ig_planes(v.x, v.y, h0, l0);
+            ig_planes(v.z, v.w, h1, l1);
+            *(uint2 *)dst = make_uint2(h0, h1);
+            *(uint2 *)(dst + 4) = make_uint2(l0, l1);
+        }
     };
     constexpr int RPU = IG_THREADS / CPR;
     static_assert(RPU % 2 == 0 && IG_HALO % 2 == 0, "row padding is per pair of rows");
-    int *const xput = xs + ig_row_off(IG_HALO + t / CPR) + (t % CPR) * (IG_RD / CPR);
+    int *const xput = xs + ig_row_off(IG_HALO + t / CPR) + chunk_off(t % CPR);
     uint4 v[CPT];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(in + f0 * FB), 0, 0x7fffffff, 0x00020000);      // (gfx9 raw buffer, 32-bit data)
     auto load_block = [&](int n) {
@@ -176,80 +198,36 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     int carry = 0;
     long long kdone = 0;                                                  // stage-2 outputs of this run already written
 
+    // the taps' digit planes: this lane's share of the A operand
+    const ig_v4i tapA = ((const ig_v4i *)tp)[t & 63];
+
     auto stage1 = [&](int n) {
-        const int *base = xs + 36 * t;                                    // = ig_row_off(2 t)
-        // step j: tap row j (16 pairs in three pieces: 48 scalar registers) against window row 2t + j for output A and row 2t + 1 + j
-        // for output B, which step j + 1 uses again for A: every window row and every tap row is fetched once.  (The loop is kept
-        // rolled: unrolled, the scheduler hoists all window reads and tap loads and spills a thousand registers.)
-        int sA[3] = {0, 0, 0}, sB[3] = {0, 0, 0};          // three-piece rows: a, b, c
-        int hA = 0, hB = 0;                                 // two-piece rows: the high parts (their low parts leave per row)
-        long long tA = 0, tB = 0;
-        int4 wa[4], wb[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wa[q] = *(const int4 *)(base + 4 * q);
-        // one step: output A against window row `lo`, output B against row `hi` (= A's row of the next step), both with tap row j.
-        // A row whose taps are small enough (the six outer rows of the 253-tap ingest filter) runs in TWO pieces hi * 2^12 + lo: its
-        // high parts share one int32 with the other such rows (the host checked sum |hi| * 32768 < 2^31 over all of them), its low
-        // parts -- up to 32 x 2048 x 32768 -- fill an int32 of their own and are moved to the 64-bit sum when the row is done
-        auto step = [&](const int4 (&lo)[4], const int4 (&hi)[4], int j) {
-            const int *tr = tp + 48 * j;
-            if ((P.mask3 >> j) & 1) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int wv[4] = {lo[q].x, lo[q].y, lo[q].z, lo[q].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int k = 0; k < IG_DBG_PIECES; ++k) sA[k] = ig_dot2(wv[i], tr[16 * k + 4 * q + i], sA[k]);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int wv[4] = {hi[q].x, hi[q].y, hi[q].z, hi[q].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int k = 0; k < IG_DBG_PIECES; ++k) sB[k] = ig_dot2(wv[i], tr[16 * k + 4 * q + i], sB[k]);
-                }
-            } else {
-                int lA = 0, lB = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int wv[4] = {lo[q].x, lo[q].y, lo[q].z, lo[q].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        hA = ig_dot2(wv[i], tr[4 * q + i], hA);
-                        lA = ig_dot2(wv[i], tr[16 + 4 * q + i], lA);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int wv[4] = {hi[q].x, hi[q].y, hi[q].z, hi[q].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        hB = ig_dot2(wv[i], tr[4 * q + i], hB);
-                        lB = ig_dot2(wv[i], tr[16 + 4 * q + i], lB);
-                    }
-                }
-                tA += (long long)lA;
-                tB += (long long)lB;
-            }
-        };
-        auto fetch_row = [&](int4 (&w)[4], int r) {
-            const int *nx = base + 16 * r + 4 * (r >> 1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = *(const int4 *)(nx + 4 * q);
-        };
-        // two steps per trip: the two window buffers swap roles by NAME (no register moves)
+        const int lane = t & 63, j = lane & 15, g = lane >> 4;
+        // lane (j, g) of a tile reads the 16 samples at 16 g of the two-row window that starts at row R0 + j: row R0 + j + (g >> 1), its
+        // first or second half (8 dwords: four of high bytes, four of low bytes); tiles are 16 rows = 288 dwords apart
+        const int *base = xs + ig_row_off(j + (g >> 1)) + 8 * (g & 1);
+        const ig_v4i zero = {0, 0, 0, 0};
 #pragma unroll 1
-        for (int j = 0; j < P.dbg_rows; j += 2) {
-            fetch_row(wb, j + 1);
-            step(wa, wb, j);
-            fetch_row(wa, j + 2);                // (the last trip fetches row 8: output B's last one)
-            step(wb, wa, j + 1);
+        for (int tile = t >> 6; tile < IG_TILES; tile += IG_THREADS / 64) {
+            const int *p = base + ig_row_off(16) * tile;
+            const ig_v4i sh = *(const ig_v4i *)p, sl = *(const ig_v4i *)(p + 4);
+            const ig_v4i dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(tapA, sh, zero, 0, 0, 0);
+            const ig_v4i dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(tapA, sl, zero, 0, 0, 0);
+            // accumulator register q of lane (g, j) = row 4 g + q of the product, column j: digit plane q of tap chunk g against the
+            // window at row 16 tile + j, a share of output 16 tile + j - 2 g
+            long long part = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part += (long long)(dh[q] * 256 + dl[q]) << (8 * q);
+            const int o = 16 * tile + j - 2 * g;
+            if (o >= 0 && o < IG_BLK) atomicAdd(acc + o, (unsigned long long)part);
         }
-        tA += ((long long)sA[0] << (2 * IG_PIECE)) + ((long long)sA[1] << IG_PIECE) + (long long)sA[2] + ((long long)hA << IG_HILO);
-        tB += ((long long)sB[0] << (2 * IG_PIECE)) + ((long long)sB[1] << IG_PIECE) + (long long)sB[2] + ((long long)hB << IG_HILO);
-        const double yA = (double)tA * P.sc, yB = (double)tB * P.sc;     // |t| < 2^51, sc a power of two: exact
+    };
+    // block n's window sums -> y1 (float64), into stage 2's ring or, without a stage 2, to memory; the cells are cleared for the next block
+    auto convert = [&](int n) {
+        const ulonglong2 a = *(const ulonglong2 *)(acc + 2 * t);
+        *(ulonglong2 *)(acc + 2 * t) = make_ulonglong2(0ull, 0ull);
+        const long long tA = (long long)a.x + P.bias, tB = (long long)a.y + P.bias;
+        const double yA = (double)tA * P.sc, yB = (double)tB * P.sc;     // |t| < 2^51 (checked by the host), sc a power of two: exact
         const long long i1 = (long long)n * IG_BLK + 2 * t;              // run-local index of output A
         if (M2 == 0) {
             double *o = out + o0 + i1;
@@ -322,35 +300,41 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
         for (int i = t; i < IG_C2PAD; i += IG_THREADS) cs[i] = i < P.ntaps2 ? c2tab[i] : 0.0;
         for (int i = t; i < IG_YRING + IG_YMIRROR; i += IG_THREADS) ys[i] = 0.0;
     }
+    *(ulonglong2 *)(acc + 2 * t) = make_ulonglong2(0ull, 0ull);
+    int *const cw = xs + ig_row_off(t / IG_RD) + (t % IG_RD);      // the carried rows: dword t of rows 0..7 <- dword t of rows IG_BLK ..
+    if (t < HC) put(xs + ig_row_off(t / CPR) + chunk_off(t % CPR), h0);      // (the first iteration's come from memory)
     for (int n = 0; n < niter; ++n) {
-        __syncthreads();                       // A: stage 1 of iteration n - 1 is done with the rows, its ring entries are visible
-        if (n == 0) {
-            if (t < HC) put(xs + ig_row_off(t / CPR) + (t % CPR) * (IG_RD / CPR), h0);
-        } else if (t < IG_HALO * IG_RD) {
-            xs[ig_row_off(t / IG_RD) + (t % IG_RD)] = carry;
-        }
+        __syncthreads();                       // A: stage 1 of iteration n - 1 is done with the rows and its sums are complete; stage 2 is done with the ring
+        if (n > 0 && t < IG_HALO * IG_RD) cw[0] = carry;
         if (!(P.dbg_flags & 1)) {
 #pragma unroll
             for (int u = 0; u < CPT; ++u) put(xput + u * ig_row_off(RPU), v[u]);
         } else {      // (keeps the loads alive)
-            unsigned acc = 0;
+            unsigned accx = 0;
 #pragma unroll
-            for (int u = 0; u < CPT; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
-            if (acc == 0x9e3779b9u) xput[0] = (int)acc;
+            for (int u = 0; u < CPT; ++u) accx ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+            if (accx == 0x9e3779b9u) xput[0] = (int)accx;
         }
         // (the fence keeps the scheduler from hoisting these loads above the stash: it would rename the registers and then wait for
         // BOTH blocks before the stash -- vmcnt counts in order --, i.e. expose the whole latency every iteration)
         __builtin_amdgcn_sched_barrier(0);
         if (n + 1 < niter) load_block(n + 1);   // in flight during the whole compute phase
         __builtin_amdgcn_sched_barrier(0);
-        if (n > 0 && !(P.dbg_flags & 2)) stage2(n - 1);
-        if (!(P.dbg_flags & 8)) __syncthreads();                       // B
+        if (n > 0) convert(n - 1);
+        if (!(P.dbg_flags & 8)) __syncthreads();                       // B: the rows are in place, block n - 1 is in the ring
         if (!(P.dbg_flags & 4)) stage1(n);
-        if (t < IG_HALO * IG_RD) carry = xs[ig_row_off(IG_BLK + t / IG_RD) + (t % IG_RD)];
+        if (n > 0 && !(P.dbg_flags & 2)) stage2(n - 1);
+        if (t < IG_HALO * IG_RD) carry = cw[ig_row_off(IG_BLK)];
     }
+    __syncthreads();
+    convert(niter - 1);
     if (M2) {
         __syncthreads();
         stage2(niter - 1);
+    }
+    if (P.dbg_clk && t == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x >> 6) < 2048) {
+        P.dbg_clk[2 * (blockIdx.x >> 6)] = (unsigned long long)clock64() - clk0;
+        P.dbg_clk[2 * (blockIdx.x >> 6) + 1] = (unsigned long long)wall_clock64() - wall0;
     }
 }
 
@@ -415,7 +399,7 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
     *handled = 0;
     if (getenv("WFX_INGEST_TILE")) return 0;                               // A/B switch: the tile kernels of rounds 1-4
     if (factor != IG_M || (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_I16_STEREO)) return 0;
-    if (ntaps1 < 1 || ntaps1 > 2 * IG_NPAIR || fix_shift < 8 || fix_shift > 40) return 0;
+    if (ntaps1 < 1 || ntaps1 > IG_KC * 64 || fix_shift < 8 || fix_shift > 40) return 0;
     if (factor2 != 0 && factor2 != 2 && factor2 != 3) return 0;
     if (nbatch < 1 || nbatch > 65535 || n_out == 0) return 0;
     const int fb = in_kind == WFX_IN_I16_STEREO ? 4 : 2;
@@ -425,68 +409,30 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
         if (ntaps2 < factor2 || ntaps2 > IG_C2PAD) return 0;
         nper = 4 * (((ntaps2 + factor2 - 1) / factor2 + 3) / 4);          // the tile kernel's row length (canonical order)
     }
-    // fixed-point taps v = a * 2^18 + b * 2^9 + c with b, c in [-256, 255]: each piece's int32 sum over a whole window holds
-    // sum |piece| * 32768 < 2^31 for the worst-case input, so nothing is moved to 64 bits before the end
-    std::vector<int32_t> fix(2 * IG_NPAIR, 0);
+    // fixed-point taps as four balanced signed bytes v = q0 + 2^8 q1 + 2^16 q2 + 2^24 q3; the table is the MFMA's A operand as the lanes
+    // hold it: lane (row i = lane & 15, group g = lane >> 4), byte b of its 16 = digit plane i & 3 of tap 64 (i >> 2) + 16 g + b
+    std::vector<int32_t> fix(IG_KC * 64, 0);
+    long long tsum = 0, tabs = 0;
     for (int j = 0; j < ntaps1; ++j) {
         const double v = nearbyint(ldexp(coef1[j], fix_shift));
         if (!(fabs(v) < (double)(1 << 30))) return 0;
         fix[j] = (int32_t)v;
+        tsum += fix[j];
+        tabs += llabs((long long)fix[j]);
     }
-    const int pm = (1 << IG_PIECE) - 1, ph = 1 << (IG_PIECE - 1);
-    std::vector<int32_t> pc[3], hl[2];
-    for (int k = 0; k < 3; ++k) pc[k].assign(2 * IG_NPAIR, 0);
-    for (int k = 0; k < 2; ++k) hl[k].assign(2 * IG_NPAIR, 0);
-    long long row3[IG_HALO][3] = {}, rowh[IG_HALO] = {}, rowl[IG_HALO] = {};
-    bool can2[IG_HALO];
-    for (int j = 0; j < 2 * IG_NPAIR; ++j) {
-        const int32_t v = fix[j];
-        const int32_t c = ((v + ph) & pm) - ph;
-        const int32_t v1 = (v - c) >> IG_PIECE;
-        const int32_t b = ((v1 + ph) & pm) - ph;
-        const int32_t a = (v1 - b) >> IG_PIECE;
-        pc[0][j] = a; pc[1][j] = b; pc[2][j] = c;
-        const int32_t hi = (v + (1 << (IG_HILO - 1))) >> IG_HILO, lo = v - hi * (1 << IG_HILO);
-        hl[0][j] = hi; hl[1][j] = lo;
-        const int r = j / IG_M;
-        row3[r][0] += llabs((long long)a); row3[r][1] += llabs((long long)b); row3[r][2] += llabs((long long)c);
-        rowh[r] += llabs((long long)hi); rowl[r] += llabs((long long)lo);
-        if (a < -32768 || a > 32767) return 0;
-    }
-    // rows in two pieces: as many as their high parts' common int32 holds (smallest sums first), each with its low parts in range
-    unsigned mask3 = (1u << IG_HALO) - 1u;
-    {
-        long long hsum = 0;
-        bool used[IG_HALO] = {};
-        for (int r = 0; r < IG_HALO; ++r) can2[r] = rowl[r] <= 65535 && rowh[r] <= 65535;
-        for (int pick = 0; pick < IG_HALO; ++pick) {
-            int best = -1;
-            for (int r = 0; r < IG_HALO; ++r)
-                if (!used[r] && can2[r] && (best < 0 || rowh[r] < rowh[best])) best = r;
-            if (best < 0 || hsum + rowh[best] > 65535) break;
-            used[best] = true;
-            hsum += rowh[best];
-            mask3 &= ~(1u << best);
+    if (tabs >= (1ll << 35)) return 0;                                     // |sum| <= 32768 sum |tap| < 2^50: the float64 result is exact
+    std::vector<int32_t> tab(IG_TAB, 0);
+    for (int j = 0; j < IG_KC * 64; ++j) {
+        int32_t v = fix[j];
+        for (int q = 0; q < 4; ++q) {
+            const int32_t d = ((v + 128) & 255) - 128;
+            v = (v - d) >> 8;
+            const int c = j / 64, g = (j % 64) / 16, bb = j % 16;
+            uint32_t &w = (uint32_t &)tab[(size_t)((16 * g + 4 * c + q) * 4 + bb / 4)];
+            w |= (uint32_t)(uint8_t)(int8_t)d << (8 * (bb % 4));
         }
-        if (getenv("WFX_INGEST_3PIECE")) mask3 = (1u << IG_HALO) - 1u;     // A/B switch: every row in three pieces (the first form)
+        if (v != 0) return 0;
     }
-    long long sum[3] = {0, 0, 0};
-    for (int r = 0; r < IG_HALO; ++r)
-        if ((mask3 >> r) & 1u)
-            for (int k = 0; k < 3; ++k) sum[k] += row3[r][k];
-    if (sum[0] > 65535 || sum[1] > 65535 || sum[2] > 65535) return 0;
-    // table: row j = 48 dwords, three slots of 16 tap pairs: (a, b, c), or (hi, lo, -) for a two-piece row
-    std::vector<int32_t> tab(3 * IG_NPAIR, 0);
-    auto pack = [](int a, int b) { return (int32_t)(((uint32_t)(uint16_t)(int16_t)a) | ((uint32_t)(uint16_t)(int16_t)b << 16)); };
-    for (int r = 0; r < IG_HALO; ++r)
-        for (int p = 0; p < 16; ++p) {
-            const int j0 = 2 * (16 * r + p);
-            if ((mask3 >> r) & 1u) {
-                for (int k = 0; k < 3; ++k) tab[48 * r + 16 * k + p] = pack(pc[k][j0], pc[k][j0 + 1]);
-            } else {
-                for (int k = 0; k < 2; ++k) tab[48 * r + 16 * k + p] = pack(hl[k][j0], hl[k][j0 + 1]);
-            }
-        }
     const int *dtab = (const int *)wfx_coef_device(ctx, (const float *)tab.data(), tab.size());
     if (!dtab) return WFX_ERR_HIP;
     const double *dc2 = nullptr;
@@ -524,10 +470,16 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
     P.in_bs = nbatch > 1 ? (long long)in_stride * fb : 0;
     P.out_bs = nbatch > 1 ? (long long)out_stride : 0;
     P.out0 = 0;
-    P.mask3 = mask3;
-    P.dbg_rows = IG_HALO;
+    P.bias = 128 * tsum;
     P.dbg_flags = 0;
-    if (const char *e = getenv("WFX_INGEST_DBG")) sscanf(e, "%d,%d", &P.dbg_rows, &P.dbg_flags);
+    if (const char *e = getenv("WFX_INGEST_DBG")) P.dbg_flags = atoi(e);
+    P.dbg_clk = nullptr;
+    static unsigned long long *clk_buf = nullptr;
+    if (getenv("WFX_INGEST_CLK")) {
+        if (!clk_buf) (void)hipMalloc((void **)&clk_buf, 2 * 2048 * sizeof(unsigned long long));
+        if (clk_buf) (void)hipMemsetAsync(clk_buf, 0, 2 * 2048 * sizeof(unsigned long long), ctx->stream);
+        P.dbg_clk = clk_buf;
+    }
     // runs whose last block of frames ends inside the capture load without range checks; the few behind them are launched on their own
     // with the checked form of the kernel
     const long long blk_frames = (long long)IG_BLK * IG_M;
@@ -546,7 +498,7 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
         if (guard) return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_MONO, 0, true> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_MONO, 2, true> : ingest_stream_kernel<WFX_IN_I16_MONO, 3, true>;
         return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_MONO, 0, false> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_MONO, 2, false> : ingest_stream_kernel<WFX_IN_I16_MONO, 3, false>;
     };
-    size_t lds = (size_t)IG_XS_BYTES + (factor2 ? (size_t)IG_YS_BYTES : 0);
+    size_t lds = (size_t)IG_XS_BYTES + IG_BLK * 8 + (factor2 ? (size_t)IG_YS_BYTES : 0);
     if (const char *e = getenv("WFX_INGEST_DBG_LDS")) {
         lds += (size_t)atoi(e);
         (void)hipFuncSetAttribute((const void *)pick(false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -565,6 +517,23 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
         hipLaunchKernelGGL(pick(true), dim3((unsigned)tail_runs, (unsigned)nbatch), dim3(IG_THREADS), lds, ctx->stream, P, dtab, dc2);
     }
     wfx_prof_end(ctx);
+    if (P.dbg_clk && full > 0) {
+        std::vector<unsigned long long> hc(2 * 2048);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(hc.data(), clk_buf, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sc = 0.0, sw = 0.0, lo = 1e30, hi = 0.0;
+        int cnt = 0;
+        for (int i = 0; i < 2048; ++i)
+            if (hc[2 * i + 1]) {
+                const double mhz = (double)hc[2 * i] / ((double)hc[2 * i + 1] / 100.0);
+                sc += (double)hc[2 * i];
+                sw += (double)hc[2 * i + 1];
+                lo = std::min(lo, mhz);
+                hi = std::max(hi, mhz);
+                ++cnt;
+            }
+        if (cnt) fprintf(stderr, "[wfx ingest] shader clock over %d sampled runs: mean %.0f MHz (min %.0f, max %.0f); mean run %.1f us\n", cnt, sc / (sw / 100.0), lo, hi, sw / 100.0 / cnt);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch ingest_stream_kernel");
     *handled = 1;
