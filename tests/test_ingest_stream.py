@@ -65,23 +65,23 @@ def test_stage1_equals_the_integer_model(ctx, kind, worst, n_out, slack):
     shape = (n_in, 2) if kind == "iq" else (n_in,)
     raw = rng.integers(-32768, 32768, size=shape).astype(np.int16)
     if worst:
-        # full-scale samples whose signs follow the taps -- and each of the three pieces a tap is split into (a * 2^18 + b * 2^9 + c,
-        # csrc/wfx_ingest.hip): the windows of some outputs drive one int32 accumulator each to its largest magnitude, both signs
+        # full-scale samples (both byte planes at their extremes: -32768 = (-128, -128), 32767 = (127, 127)) whose signs follow the
+        # taps -- and each of the four balanced byte digits a tap is split into (q0 + 2^8 q1 + 2^16 q2 + 2^24 q3, csrc/wfx_ingest.hip):
+        # the windows of some outputs drive the int32 digit sums of every tap chunk to their largest magnitude, both signs
         fix = np.rint(coef * 2.0 ** sh).astype(np.int64)
-        c = ((fix + 256) & 511) - 256
-        v1 = (fix - c) >> 9
-        b = ((v1 + 256) & 511) - 256
-        a = (v1 - b) >> 9
-        assert np.array_equal((a << 18) + (b << 9) + c, fix) and all(np.abs(q).sum() <= 65535 for q in (a, b, c))
+        digits, v = [], fix.copy()
+        for _ in range(4):
+            d = ((v + 128) & 255) - 128
+            v = (v - d) >> 8
+            digits.append(d)
+        assert not v.any() and np.array_equal(sum(d << (8 * q) for q, d in enumerate(digits)), fix)
         col = raw[:, 0] if kind == "iq" else raw
         if kind == "iq":
             raw[:, 1] = 0
         col[:] = -32768
-        # (rows of small taps run in two pieces hi * 2^12 + lo instead: their signs too)
-        hi = (fix + 2048) >> 12
-        lo = fix - (hi << 12)
         outs = [0, 9, 18, 27, 255 - 8, 256 + 1, 511 - 8, 512 + 1, 521, 530, 539, 548, 557, n_out - 10, n_out - 1]      # (around the ends of an iteration's block)
-        pats = [fix, -fix, a, -a, b, -b, c, -c, fix, hi, -hi, lo, -lo, -a, -c]
+        q0, q1, q2, q3 = digits
+        pats = [fix, -fix, q0, -q0, q1, -q1, q2, -q2, fix, q3, -q3, q0 + q1, -q2 - q3, -q0, -q2]
         for o, q in zip(outs, pats):       # (at least 9 outputs apart: the windows do not overlap)
             col[32 * o:32 * o + coef.shape[0]] = np.where(q >= 0, -32768, 32767).astype(np.int16)
     k = nat.WFX_IN_I16_STEREO if kind == "iq" else nat.WFX_IN_I16_MONO
@@ -197,6 +197,29 @@ def test_fused_chain_in_batches(ctx, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["iq", "i16"])
+@pytest.mark.parametrize("ntaps,bits,sh", [(256, 26, 30), (255, 26, 28), (253, 12, 12), (64, 27, 30), (17, 29, 33), (1, 29, 30), (200, 8, 8)])
+def test_stage1_with_any_taps_on_the_grid(ctx, kind, ntaps, bits, sh):
+    """Not only the front end's own low-pass: any <= 256 taps on the grid 2^-sh below 2^30 (sum |tap| < 2^35) go through the digit planes
+    exactly -- random ones, full-range samples."""
+    from wefax_amd import _native as nat
+    rng = np.random.default_rng(ntaps * 100 + bits)
+    fix = rng.integers(-(1 << bits) + 1, 1 << bits, size=ntaps).astype(np.int64)
+    fix[rng.integers(0, ntaps, size=max(1, ntaps // 8))] = 0
+    fix[0] = (1 << bits) - 1
+    coef = fix.astype(np.float64) / 2.0 ** sh
+    n_out = 2100
+    n_in = (n_out - 1) * 32 + ntaps + 77
+    raw = rng.integers(-32768, 32768, size=(n_in, 2) if kind == "iq" else (n_in,)).astype(np.int16)
+    k = nat.WFX_IN_I16_STEREO if kind == "iq" else nat.WFX_IN_I16_MONO
+    p_in, p_out = _dev(ctx, raw), ctx.dev_malloc(n_out * 8)
+    assert ctx.d_ingest_chain(p_in, k, n_in, 32, coef, sh, 0, None, p_out, n_out)
+    assert np.array_equal(ctx.dev_download(p_out, (n_out,), np.float64), _model_stage1(raw, coef, sh, n_out))
+    ctx.dev_free(p_in)
+    ctx.dev_free(p_out)
+
+
+@pytest.mark.gpu
 def test_shapes_the_streaming_kernel_declines(ctx):
     """Nothing is enqueued and False comes back: the caller runs the tile kernels (same results, see above)."""
     from wefax_amd import _native as nat
@@ -207,6 +230,6 @@ def test_shapes_the_streaming_kernel_declines(ctx):
     assert not ctx.d_ingest_chain(p_in, k, 70000, 16, s1.coef64[:125], 30, 3, s2.coef64, p_out, 10)            # another factor
     assert not ctx.d_ingest_chain(p_in + 4, k, 69999, 32, s1.coef64, 30, 3, s2.coef64, p_out, 10)             # not on the 16-byte grid
     assert not ctx.d_ingest_chain(p_in, k, 70000, 32, s1.coef64, 30, 5, s2.coef64, p_out, 10)                 # a factor behind it the kernel has no form for
-    assert not ctx.d_ingest_chain(p_in, k, 70000, 32, np.full(253, 0.9), 30, 3, s2.coef64, p_out, 10)         # taps the int32 sums cannot hold
+    assert not ctx.d_ingest_chain(p_in, k, 70000, 32, np.full(253, 0.9), 30, 3, s2.coef64, p_out, 10)         # taps whose sums a float64 cannot hold exactly
     ctx.dev_free(p_in)
     ctx.dev_free(p_out)

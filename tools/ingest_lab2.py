@@ -73,6 +73,29 @@ x = (np.arange(1 << 20, dtype=np.int32) % 2001 - 1000).astype(np.int16)
 blk = np.stack([x, x[::-1]], axis=1).copy()
 for off in range(0, frames, 1 << 20):
     ctx.dev_upload(p_in + off * 4, blk[:min(1 << 20, frames - off)])
+if os.environ.get("WFX_LAB_SHORT"):
+    os.environ["WFX_INGEST_DBG"] = "15"
+    print("loads only: min %.3f median %.3f ms" % timed(fused, 5, 6), flush=True)
+    del os.environ["WFX_INGEST_DBG"]
+    print("all on: min %.3f median %.3f ms" % timed(fused, 5, 6), flush=True)
+    sys.exit(0)
+def triple(tag):
+    print("%s: plain read %.2f TB/s" % (tag, ctx.d_read_rate(p_in, frames * 4, 3) / 1e3), flush=True)
+    for flags in (0, 15, 4, 2, 0):
+        os.environ["WFX_INGEST_DBG"] = str(flags)
+        print("%s: flags %d: min %.3f median %.3f ms" % ((tag, flags) + timed(fused, 5, 8)), flush=True)
+        os.environ["WFX_INGEST_CLK"] = "1"
+        fused()
+        del os.environ["WFX_INGEST_CLK"]
+    del os.environ["WFX_INGEST_DBG"]
+
+
+triple("synthesised stream")
+# overwrite the stream with the repeating ramp of tools/ingest_lab.py
+x = (np.arange(1 << 20, dtype=np.int32) % 2001 - 1000).astype(np.int16)
+blk = np.stack([x, x[::-1]], axis=1).copy()
+for off in range(0, frames, 1 << 20):
+    ctx.dev_upload(p_in + off * 4, blk[:min(1 << 20, frames - off)])
 for rep in range(3):
     for xcd in (1, 0):
         if not xcd:

@@ -29,7 +29,7 @@
 //     and one atomic per 16 rows; 128 sum(taps) for the low plane's offset joins when the cell is converted to float64.
 //     (Round 5 first ran this stage on v_dot2_i32_i16 with the taps as scalar operands, then as MFMAs over windows read once per
 //     output: both read every sample 8 x from LDS, and with noisy data that -- not the arithmetic -- pulled the shader clock from
-//     2.36 to 2.02 GHz and the whole kernel, loads included, with it: EXPERIMENTS.md §11.)
+//     2.36 to 2.02 GHz and the whole kernel, loads included, with it: EXPERIMENTS.md §9.)
 //   * an iteration handles 512 outputs = 64 KiB of IQ frames; the next block's 16 chunks per lane are requested right after this
 //     block's registers were stored to LDS and stay in flight during the whole compute phase; the last 8 rows are carried over
 //     as the next iteration's halo (128 dwords through registers), so nothing is read twice inside a run;
@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     extern __shared__ __align__(16) unsigned char ig_lds[];
     int *xs = (int *)ig_lds;
     unsigned long long *acc = (unsigned long long *)(ig_lds + IG_XS_BYTES);                // [IG_BLK]: the iteration's window sums
-    double *ys = (double *)(ig_lds + IG_XS_BYTES + IG_BLK * 8);
+    int *ts = (int *)(ig_lds + IG_XS_BYTES + IG_BLK * 8);                                  // [IG_TAB]
+    double *ys = (double *)(ig_lds + IG_XS_BYTES + IG_BLK * 8 + IG_TAB * 4);
     double *cs = ys + IG_YRING + IG_YMIRROR;
     const int t = threadIdx.x;
     const unsigned char *in = (const unsigned char *)P.in + (size_t)blockIdx.y * (size_t)P.in_bs;
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     const unsigned long long clk0 = P.dbg_clk ? (unsigned long long)clock64() : 0ull, wall0 = P.dbg_clk ? (unsigned long long)wall_clock64() : 0ull;
     // run = blockIdx.x: workgroups go round-robin to the 8 XCDs, so the ~768 resident ones stream through 768 neighbouring runs, every
     // XCD through every eighth one.  (Dealing each XCD ONE eighth of the capture -- its 96 workgroups on 96 neighbouring runs -- measured
-    // 9 % slower, 4.00 against 3.68 ms on the 60-minute stream: EXPERIMENTS.md §11.)
+    // 9 % slower, 4.00 against 3.68 ms on the 60-minute stream: EXPERIMENTS.md §9.)
     const long long run = blockIdx.x;
     const long long o0 = P.out0 + run * P.run_out;                          // first output of this run
     const long long ocnt = P.n_out - o0 < P.run_out ? P.n_out - o0 : P.run_out;
@@ -198,11 +199,13 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     int carry = 0;
     long long kdone = 0;                                                  // stage-2 outputs of this run already written
 
-    // the taps' digit planes: this lane's share of the A operand
-    const ig_v4i tapA = ((const ig_v4i *)tp)[t & 63];
+    // the taps' digit planes, the A operand as the 64 lanes hold it: parked in LDS between the iterations' stage-1 phases (four registers
+    // that stage 2 needs)
+    if (t < 64) ((ig_v4i *)ts)[t] = ((const ig_v4i *)tp)[t];
 
     auto stage1 = [&](int n) {
         const int lane = t & 63, j = lane & 15, g = lane >> 4;
+        const ig_v4i tapA = ((const ig_v4i *)ts)[lane];
         // lane (j, g) of a tile reads the 16 samples at 16 g of the two-row window that starts at row R0 + j: row R0 + j + (g >> 1), its
         // first or second half (8 dwords: four of high bytes, four of low bytes); tiles are 16 rows = 288 dwords apart
         const int *base = xs + ig_row_off(j + (g >> 1)) + 8 * (g & 1);
@@ -498,7 +501,7 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
         if (guard) return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_MONO, 0, true> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_MONO, 2, true> : ingest_stream_kernel<WFX_IN_I16_MONO, 3, true>;
         return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_MONO, 0, false> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_MONO, 2, false> : ingest_stream_kernel<WFX_IN_I16_MONO, 3, false>;
     };
-    size_t lds = (size_t)IG_XS_BYTES + IG_BLK * 8 + (factor2 ? (size_t)IG_YS_BYTES : 0);
+    size_t lds = (size_t)IG_XS_BYTES + IG_BLK * 8 + IG_TAB * 4 + (factor2 ? (size_t)IG_YS_BYTES : 0);
     if (const char *e = getenv("WFX_INGEST_DBG_LDS")) {
         lds += (size_t)atoi(e);
         (void)hipFuncSetAttribute((const void *)pick(false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
