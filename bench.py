@@ -541,6 +541,10 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
     n0 = int(ctx.lib.wfx_synth_frames(sp))
     fe = polyphase.FrontEnd(IQ_FS, stop_rate=args.iq_stop_rate)
     raw_loader = synth_device.SliceLoader(ctx, sp)
+    # where a capture's pages lie is worth up to 15 % to the ingest's ~770 streams (EXPERIMENTS.md 9.2): the capture buffer is the
+    # best of a few allocations (Context.dev_malloc_placed; every candidate's rate is in `placement`).  WFX_PLACE_TRIES=1 takes the first.
+    os.environ.setdefault("WFX_PLACE_TRIES", "4")
+    del synth_device.PLACEMENTS[:]
     t_syn = time.perf_counter()
     fused = rk.world == 1 and (args.iq_form == "fused" or (args.iq_form == "auto" and not rk.use_rccl))
     if fused:
@@ -612,6 +616,15 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
                          "source": "amdgpu sysfs (pp_dpm_*clk, hwmon), sampled every 20 ms while the per-step pass ran"}}
     if getattr(getattr(dec, "fe", None), "fused_ingest", False):
         out["front_end"] += " [stages 1+2 in one streaming kernel, csrc/wfx_ingest.hip]"
+    if fused:
+        p_raw, n_raw = dec.fe.p_raw, dec.fe.n_raw
+        try:
+            out["placement"] = {"tries": int(os.environ["WFX_PLACE_TRIES"]), "candidates_stream_GBs": [[round(v, 1) for v in r] for r in synth_device.PLACEMENTS],
+                                "output_candidates_stream_GBs": [round(v, 1) for v in getattr(dec.fe, "placement_out", [])],
+                                "kept_stream_GBs": round(ctx.d_stream_rate(p_raw, n_raw * 4, out_ptr=dec.fe.p_out), 1), "kept_plain_read_GBs": round(ctx.d_read_rate(p_raw, n_raw * 4, 2), 1),
+                                "note": "stream = input bytes per second of the ingest kernel itself on that allocation, outputs into a scratch buffer (wfx_d_stream_rate); plain = a dense sweep"}
+        except Exception as e:      # noqa: BLE001
+            out["placement"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if not fused:
         out["wire"] = wire_object(rk, dec.dec.params, dec.layout, dec.run, ctx.sync)
         m = out["wire"]["model"]
@@ -1113,7 +1126,7 @@ def main():
                     "one_gpu_ms": c4.get("one_gpu_ms"), "speedup_vs_one_gpu": c4.get("speedup_vs_one_gpu"),
                     "efficiency_vs_one_gpu": c4.get("efficiency_vs_one_gpu"), "transport": c4.get("transport"), "wire": c4.get("wire"),
                     "per_step": c4.get("per_step"), "gpu_state": c4.get("gpu_state"), "model_ms": c4.get("model_ms"),
-                    "measured_ms": c4.get("measured_ms"), "forced_dist": c4.get("forced_dist")}
+                    "measured_ms": c4.get("measured_ms"), "forced_dist": c4.get("forced_dist"), "placement": c4.get("placement")}
         elif args.workload == "c3":
             line = bench_c3(args, rk)
         else:

@@ -319,6 +319,12 @@ int wfx_d_hilbert_fmm(wfx_ctx *ctx, const double *x_dev, size_t n, double *out_d
  * (16-byte loads, 16 in flight per lane, 64 KiB blocks), best of `reps` launches by HIP events; waits for the stream.  bench.py puts
  * the ingest kernel's rate beside it: a slow box shows here, a slow kernel in the ratio */
 int wfx_d_read_rate(wfx_ctx *ctx, const void *dev, size_t bytes, int reps, double *gbs);
+/* measurement aid: GB/s (input bytes per second) at which the streaming ingest itself (wfx_d_ingest_chain's / 32 -> / 3 kernel, outputs
+ * into out_dev -- bytes / 48 of them -- or, out_dev == NULL, into a scratch allocation) works through `bytes` (>= 64 MiB, 16-byte aligned) of device memory taken as an IQ capture.
+ * The kernel's time does not depend on the data but -- unlike the dense sweep above -- on WHERE the allocation lies (up to 15 %
+ * between two buffers of one process; the output's place counts too): a caller that keeps its buffers can time a few allocations and keep the best
+ * (wefax_amd/_native.py: Context.dev_malloc_placed) */
+int wfx_d_stream_rate(wfx_ctx *ctx, const void *dev, size_t bytes, double *out_dev, int reps, double *gbs);
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev);
 /* a8: one level of the radix select: hist_dev[q*2048 + digit] += count over values whose bits above the level equal prefix[q] */
 int wfx_d_select_hist(wfx_ctx *ctx, const double *env_dev, size_t n, int level, const uint64_t prefix[4], uint32_t *hist_dev);

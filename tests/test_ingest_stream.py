@@ -233,3 +233,23 @@ def test_shapes_the_streaming_kernel_declines(ctx):
     assert not ctx.d_ingest_chain(p_in, k, 70000, 32, np.full(253, 0.9), 30, 3, s2.coef64, p_out, 10)         # taps whose sums a float64 cannot hold exactly
     ctx.dev_free(p_in)
     ctx.dev_free(p_out)
+
+
+@pytest.mark.gpu
+def test_stream_rate_probe_and_placed_allocation(ctx):
+    """The ingest's own access pattern as a read-rate probe (nothing is written), and the allocation helper built on it."""
+    nbytes = 1 << 30
+    p = ctx.dev_malloc(nbytes)
+    g = ctx.d_stream_rate(p, nbytes)
+    assert 500.0 < g < 8000.0
+    with pytest.raises(Exception):
+        ctx.d_stream_rate(p, 1 << 20)                  # too small to say anything
+    ctx.dev_free(p)
+    q, rates = ctx.dev_malloc_placed(nbytes, tries=3, good_gbs=1e9)       # (an unreachable bar: all three candidates are timed)
+    assert len(rates) == 3 and all(500.0 < r < 8000.0 for r in rates)
+    ctx.dev_upload(q, np.arange(16, dtype=np.int16))
+    assert np.array_equal(ctx.dev_download(q, (16,), np.int16), np.arange(16, dtype=np.int16))
+    ctx.dev_free(q)
+    r, none = ctx.dev_malloc_placed(1 << 20, tries=3)                     # small buffers: the first allocation
+    assert none == []
+    ctx.dev_free(r)

@@ -21,8 +21,8 @@ n2 = chain.n_out(frames)
 p_out = ctx.dev_malloc(n2 * 8 + 64)
 
 
-def skeleton(p, reps=4, warm=6):
-    os.environ["WFX_INGEST_DBG"] = "15"
+def skeleton(p, reps=4, warm=6, flags="15"):
+    os.environ["WFX_INGEST_DBG"] = flags
     def fn():
         assert ctx.d_ingest_chain(p, nat.WFX_IN_I16_STEREO, frames, 32, s1.coef64, s1.fix_shift, 3, s2.coef64, p_out, n2)
     for _ in range(warm):
@@ -45,18 +45,19 @@ def round_of(tag, k=8):
         p = ctx.dev_malloc(frames * 4 + (1 << 21))
         dt = time.perf_counter() - t0
         ps.append(p)
-        print(f"{tag} allocation {i} at {p:#x} ({dt * 1e3:.1f} ms to allocate): loads only {skeleton(p):.3f} ms, plain read {ctx.d_read_rate(p, frames * 4, 2) / 1e3:.2f} TB/s", flush=True)
+        print(f"{tag} allocation {i} at {p:#x} ({dt * 1e3:.1f} ms to allocate): loads only {skeleton(p):.3f} ms, loads + stage 2 {skeleton(p, flags='13'):.3f}, stage 2 without its stores {skeleton(p, flags='16'):.3f},  all {skeleton(p, flags='0'):.3f}, plain read {ctx.d_read_rate(p, frames * 4, 2) / 1e3:.2f} TB/s", flush=True)
     for p in ps:
         ctx.dev_free(p)
 
 
-round_of("fresh process:")
+round_of("fresh process:", 5)
+sys.exit(0)
 loader = synth_device.SliceLoader(ctx, sp)
 dec = sharded.FrontEndExactDecoder(ctx, chain, None, n_in_total=frames, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120, raw_loader=loader)
 for _ in range(3):
     dec.run()
 ctx.sync()
 print(f"the decoder's own buffer at {dec.fe.p_raw:#x}: loads only {skeleton(dec.fe.p_raw):.3f} ms", flush=True)
-round_of("after three decodes:")
+
 dec.close()
-round_of("after the decoder was closed:", 4)
+

@@ -30,7 +30,7 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_hilbert_fmm", "wfx_d_read_rate", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_hilbert_fmm", "wfx_d_read_rate", "wfx_d_stream_rate", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
@@ -230,6 +230,7 @@ def load():
     lib.wfx_d_decimate_fir64_batch.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int), i, sz, sz]
     lib.wfx_d_hilbert_fmm.argtypes = [vp, vp, sz, vp, i, C.POINTER(C.c_int)]
     lib.wfx_d_read_rate.argtypes = [vp, vp, sz, i, C.POINTER(C.c_double)]
+    lib.wfx_d_stream_rate.argtypes = [vp, vp, sz, vp, i, C.POINTER(C.c_double)]
     lib.wfx_d_ingest_chain.argtypes = [vp, vp, i, sz, i, vp, i, i, i, vp, i, vp, sz, i, sz, sz, C.POINTER(C.c_int)]
     lib.wfx_d_median5.argtypes = [vp, vp, sz, vp]
     lib.wfx_d_select_hist.argtypes = [vp, vp, sz, i, C.POINTER(C.c_uint64), vp]
@@ -646,6 +647,37 @@ class Context:
         g = C.c_double(0.0)
         self._check(self.lib.wfx_d_read_rate(self.h, C.c_void_p(ptr), int(nbytes), int(reps), C.byref(g)))
         return float(g.value)
+
+    def d_stream_rate(self, ptr: int, nbytes: int, reps: int = 2, out_ptr: int = 0) -> float:
+        """GB/s at which the streaming ingest kernel works through the buffer taken as an IQ capture (include/wefax_hip.h: wfx_d_stream_rate)."""
+        g = C.c_double(0.0)
+        self._check(self.lib.wfx_d_stream_rate(self.h, C.c_void_p(ptr), int(nbytes), C.c_void_p(out_ptr or None), int(reps), C.byref(g)))
+        return float(g.value)
+
+    def dev_malloc_placed(self, nbytes: int, tries: int | None = None, good_gbs: float = 6000.0, probe=None):
+        """Device memory for a capture the streaming ingest will read many times (or, with ``probe``, for the buffer it writes): the same
+        bytes stream up to 15 % slower through one allocation than through another of the same process (EXPERIMENTS.md §9.2), so up
+        to ``tries`` allocations (``WFX_PLACE_TRIES``, default 1 = take the first) are held side by side and timed -- ``probe(ptr)`` ->
+        GB/s, default ``d_stream_rate`` on the allocation as the capture -- until one reaches ``good_gbs``; the best is kept, the others
+        are freed.  Returns (pointer, [GB/s of every candidate, in order]); without a probe, captures under 1 GiB are not timed."""
+        if tries is None:
+            tries = int(os.environ.get("WFX_PLACE_TRIES", "1"))
+        if tries <= 1 or (probe is None and nbytes < (1 << 30)):
+            return self.dev_malloc(nbytes), []
+        if probe is None:
+            probe = lambda p: self.d_stream_rate(p, nbytes)      # noqa: E731
+        cands, rates = [], []
+        for _ in range(tries):
+            p = self.dev_malloc(nbytes)
+            cands.append(p)
+            rates.append(probe(p))
+            if rates[-1] >= good_gbs:
+                break
+        best = max(range(len(cands)), key=lambda k: rates[k])
+        for k, p in enumerate(cands):
+            if k != best:
+                self.dev_free(p)
+        return cands[best], rates
 
     def d_median5(self, in_ptr: int, n: int, out_ptr: int):
         self._check(self.lib.wfx_d_median5(self.h, C.c_void_p(in_ptr), n, C.c_void_p(out_ptr)))

@@ -666,6 +666,13 @@ int wfx_d_read_rate(wfx_ctx *ctx, const void *dev, size_t bytes, int reps, doubl
     return wfx_dev_read_rate(ctx, dev, bytes, reps, gbs);
 }
 
+int wfx_d_stream_rate(wfx_ctx *ctx, const void *dev, size_t bytes, double *out_dev, int reps, double *gbs)
+{
+    CHECK_CTX(ctx);
+    if (!dev || !gbs) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return wfx_dev_stream_rate(ctx, dev, bytes, out_dev, reps, gbs);
+}
+
 int wfx_d_median5(wfx_ctx *ctx, const double *in_dev, size_t n, double *out_dev)
 {
     CHECK_CTX(ctx);

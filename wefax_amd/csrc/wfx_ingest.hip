@@ -61,6 +61,7 @@ static_assert(IG_YRING >= IG_BLK + IG_YMIRROR && IG_THREADS >= IG_HALO * (IG_M /
 #define WFX_IG_LOAD_AUX 2
 #endif
 constexpr int IG_LOAD_AUX = WFX_IG_LOAD_AUX;      // cache policy of the block loads: 2 = nt (every byte is read once; measured 1.5 % over the default, 0)
+constexpr int IG_STORE_AUX = 2;                 // cache policy of stage 2's stores: nt (0.1-0.2 ms of 3.6 on the 60-minute stream over the default)
 constexpr int IG_KC = 4;                        // chunks of 64 taps per window = row groups of the MFMA's A operand
 constexpr int IG_TAB = 64 * 4;                  // tap table: [lane][4 dwords]
 constexpr int IG_TILES = IG_BLK / 16 + 1;       // tiles of 16 rows per iteration: rows 0 .. IG_BLK + 6 start a two-row window somebody needs
@@ -197,6 +198,8 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     if (t < HC) h0 = ig_fetch_guarded<FB>(in, f0 + (long long)t * FPC, P.n_in);
     load_block(0);
     int carry = 0;
+    double pend = 0.0;                                                    // a stage-2 output on its way to memory, and its run-local index
+    int pend_k = -1;
     long long kdone = 0;                                                  // stage-2 outputs of this run already written
 
     // the taps' digit planes, the A operand as the 64 lanes hold it: parked in LDS between the iterations' stage-1 phases (four registers
@@ -246,6 +249,20 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
             if (s < IG_YMIRROR) *(double2 *)(ys + IG_YRING + s) = make_double2(yA, yB);
         }
     };
+    // Stage 2's outputs leave between the stash and the next block's requests, one iteration after they were computed, as non-temporal
+    // stores.  They are what the kernel pays for beyond its loads: 0.46 GB written beside 22 GB read cost 0.25-0.4 ms of 3.45-3.55
+    // (the same stores into 2 KiB per run: 0.05) -- small write bursts that turn the channels around under the read streams; where
+    // they are issued inside the iteration, how many iterations' worth are issued together (1, 4, 8) and whether only whole 128-byte
+    // lines are written made no difference, the cache policy did (EXPERIMENTS.md 9.1).
+    auto flush = [&]() {
+        if (M2 == 0) return;
+        if (pend_k >= 0 && !(P.dbg_flags & 16)) {                          // (16: nothing is stored)
+            typedef unsigned ig_v2u __attribute__((ext_vector_type(2)));
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(out + o0), 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ig_v2u, pend), orsrc, (unsigned)pend_k * 8u, 0, IG_STORE_AUX);
+        }
+        pend_k = -1;
+    };
     // stage 2 on everything iteration n made complete: outputs k with M2 k + ntaps2 <= (n + 1) * IG_BLK.  The tile kernel's canonical
     // order -- one FMA chain per polyphase row r = i mod M2 in ascending tap order, then row 0 + row 1 (+ row 2) -- is walked tap by tap:
     // consecutive taps, consecutive ring entries, M2 independent chains; GRP taps are fetched (scalar loads, LDS reads) before
@@ -268,11 +285,16 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
             // the two register sets swap roles by name
             double ca[GRP], wa[GRP], cb[GRP], wb[GRP];
             auto fetch = [&](double (&c)[GRP], double (&w)[GRP], int i) {
+                if (GRP % 2 == 0) {
 #pragma unroll
-                for (int q = 0; q < GRP; q += 2) {
-                    const double2 cc = *(const double2 *)(cs + i + q);
-                    c[q] = cc.x;
-                    c[q + 1] = cc.y;
+                    for (int q = 0; q + 1 < GRP; q += 2) {
+                        const double2 cc = *(const double2 *)(cs + i + q);
+                        c[q] = cc.x;
+                        c[q + 1] = cc.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < GRP; ++q) c[q] = cs[i + q];
                 }
 #pragma unroll
                 for (int q = 0; q < GRP; ++q) w[q] = y[i + q];
@@ -292,7 +314,10 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
             double tot = 0.0;
 #pragma unroll
             for (int r = 0; r < MM; ++r) tot += acc[r];
-            out[o0 + k] = tot;
+            // the output waits in a register for `flush`
+            if (pend_k >= 0) flush();                                    // (a second output of this thread in one call: never with the run lengths the host picks)
+            pend = tot;
+            pend_k = (int)k;
         }
         kdone = kend;
     };
@@ -321,9 +346,12 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
         // (the fence keeps the scheduler from hoisting these loads above the stash: it would rename the registers and then wait for
         // BOTH blocks before the stash -- vmcnt counts in order --, i.e. expose the whole latency every iteration)
         __builtin_amdgcn_sched_barrier(0);
+        flush();
+        if (M2 == 0 && n > 0) convert(n - 1);   // (without a stage 2 the sums themselves go to memory: before the loads, for the same reason)
+        __builtin_amdgcn_sched_barrier(0);
         if (n + 1 < niter) load_block(n + 1);   // in flight during the whole compute phase
         __builtin_amdgcn_sched_barrier(0);
-        if (n > 0) convert(n - 1);
+        if (M2 != 0 && n > 0) convert(n - 1);
         if (!(P.dbg_flags & 8)) __syncthreads();                       // B: the rows are in place, block n - 1 is in the ring
         if (!(P.dbg_flags & 4)) stage1(n);
         if (n > 0 && !(P.dbg_flags & 2)) stage2(n - 1);
@@ -331,10 +359,11 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     }
     __syncthreads();
     convert(niter - 1);
-    if (M2) {
+    if (M2 && !(P.dbg_flags & 2)) {
         __syncthreads();
         stage2(niter - 1);
     }
+    flush();
     if (P.dbg_clk && t == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x >> 6) < 2048) {
         P.dbg_clk[2 * (blockIdx.x >> 6)] = (unsigned long long)clock64() - clk0;
         P.dbg_clk[2 * (blockIdx.x >> 6) + 1] = (unsigned long long)wall_clock64() - wall0;
@@ -541,4 +570,48 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch ingest_stream_kernel");
     *handled = 1;
     return 0;
+}
+
+// GB/s (input bytes per second) at which the streaming ingest itself -- the fused / 32 -> / 3 kernel, outputs into a scratch allocation --
+// works through `bytes` of device memory taken as an IQ capture (`out` != nullptr: outputs there, bytes / 48 of them).  Its time does not depend on the data, but it does depend on WHERE the
+// allocation lies: ~770 workgroups each walking a megabyte of their own, with small write bursts in between, ran 3.43-3.56 ms on some
+// 22 GB allocations of a process and 3.9-4.1 ms on others, the same ones in every process of the box, while the dense sweep of
+// wfx_dev_read_rate showed 6.2-6.4 TB/s on all of them (EXPERIMENTS.md 9.2).  Callers that keep a capture buffer for long can time a few
+// allocations with this and keep the best (wefax_amd/_native.py: Context.dev_malloc_placed).
+int wfx_dev_stream_rate(wfx_ctx *ctx, const void *dev, uint64_t bytes, double *out, int reps, double *gbs)
+{
+    if (((uintptr_t)dev & 15u) || bytes < (64ull << 20) || reps < 1) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "stream rate: a 16-byte aligned buffer of at least 64 MiB");
+    const uint64_t frames = bytes / 4;
+    const int ntaps1 = 253, ntaps2 = 119;
+    const uint64_t n1 = frames / IG_M - IG_HALO, n2 = (n1 - ntaps2) / 3 + 1;
+    std::vector<double> c1(ntaps1, ldexp(1.0, -20)), c2(ntaps2, 1.0 / ntaps2);
+    double *scratch = nullptr;                                             // (`out`: bytes / 48 are written there instead)
+    if (!out) WFX_HIP(ctx, hipMalloc((void **)&scratch, n2 * sizeof(double)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    double best = 0.0;
+    int rc = he == hipSuccess ? 0 : wfx_fail_hip(ctx, he, "stream rate");
+    for (int r = -2; r < reps && rc == 0; ++r) {                           // (two launches to bring the clocks up)
+        int handled = 0;
+        (void)hipEventRecord(e0, ctx->stream);
+        rc = wfx_dev_ingest_stream(ctx, dev, WFX_IN_I16_STEREO, frames, IG_M, c1.data(), ntaps1, 30, 3, c2.data(), ntaps2, out ? out : scratch, n2, 1, 0, 0, &handled);
+        (void)hipEventRecord(e1, ctx->stream);
+        if (rc == 0 && !handled) rc = wfx_fail(ctx, WFX_ERR_BAD_ARG, "stream rate: the ingest kernel declined the probe");
+        if (rc) break;
+        hipError_t e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) {
+            rc = wfx_fail_hip(ctx, e, "stream rate");
+            break;
+        }
+        if (r >= 0) best = std::max(best, (double)(frames * 4) / (ms * 1e-3) / 1e9);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (scratch) (void)hipFree(scratch);
+    if (rc == 0 && gbs) *gbs = best;
+    return rc;
 }

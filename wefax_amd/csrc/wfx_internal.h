@@ -372,6 +372,7 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
 
 // GB/s of a plain read of `bytes` at `dev` (best of `reps` launches, HIP events): the box's read-stream ceiling, measured beside the ingest
 int wfx_dev_read_rate(wfx_ctx *ctx, const void *dev, uint64_t bytes, int reps, double *gbs);
+int wfx_dev_stream_rate(wfx_ctx *ctx, const void *dev, uint64_t bytes, double *out, int reps, double *gbs);
 
 // wfx_comm.hip: the communicator behind the sharded decode (RCCL bound directly, or every rank in this process)
 struct wfx_xfer {            // one message pair of a personalised exchange; several entries per peer are matched in order

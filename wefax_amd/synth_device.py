@@ -42,11 +42,16 @@ def synth_into(ctx: nat.Context, params: nat.SynthParams, ptr: int, lo: int, hi:
         g += c
 
 
+PLACEMENTS = []        # stream rates (GB/s) of the candidates of every placed allocation (Context.dev_malloc_placed), for bench.py's report
+
+
 def synth_slice(ctx: nat.Context, params: nat.SynthParams, lo: int, hi: int) -> int:
     """Device pointer (owned by the caller: ``ctx.dev_free``) to frames lo..hi-1 of the capture, global indices wrapping
     modulo its length.  int16 [hi - lo] or, with ``params.iq``, interleaved [hi - lo, 2]."""
     fb = 4 if params.iq else 2
-    ptr = ctx.dev_malloc((hi - lo) * fb)
+    ptr, rates = ctx.dev_malloc_placed((hi - lo) * fb)
+    if rates:
+        PLACEMENTS.append(rates)
     synth_into(ctx, params, ptr, lo, hi)
     return ptr
 
