@@ -119,7 +119,9 @@ timeout 1200 python tools/random_shard_parity.py --cases 80 --seed 6 > "$OUT/ran
 # self-test failing -> fallback, one RCCL rank with event-timed collectives), the ingest kernel taken apart, instruction rates
 bash tools/r05_bench_paths.sh "$TAG/paths" > "$OUT/bench_paths.txt" 2>&1
 timeout 600 python tools/ingest_lab.py 16 > "$OUT/ingest_lab_16GiB.txt" 2>> "$OUT/bench.err"
-timeout 600 python tools/ingest_lab2.py > "$OUT/ingest_lab_60min_stream.txt" 2>> "$OUT/bench.err"
+timeout 600 python tools/ingest_lab2.py > "$OUT/ingest_lab_60min_stream.txt" 2>&1
+timeout 600 python tools/ingest_lab3.py > "$OUT/ingest_lab_placement.txt" 2>> "$OUT/bench.err"
+timeout 600 python tools/ingest_lab4.py > "$OUT/ingest_lab_allocations.txt" 2>> "$OUT/bench.err"
 timeout 600 python tools/alloc_lab.py 16 > "$OUT/alloc_lab.txt" 2>> "$OUT/bench.err"
 [ -x tools/micro/build/valu_rate ] && timeout 120 tools/micro/build/valu_rate > "$OUT/valu_rate.txt" 2>&1
 [ -x tools/micro/build/stream_pattern ] && timeout 300 tools/micro/build/stream_pattern > "$OUT/stream_pattern.txt" 2>&1

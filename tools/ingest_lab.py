@@ -1,5 +1,5 @@
 """Where the streaming ingest kernel (csrc/wfx_ingest.hip) spends its time: the fused / 32 -> / 3 chain on 16 GiB of int16 IQ frames
-with parts of the kernel switched off (WFX_INGEST_DBG=flags -- 1 = no LDS stash, 2 = no stage 2, 4 = no stage 1, 8 = no barrier B; results are
+with parts of the kernel switched off (WFX_INGEST_DBG=flags -- 1 = no LDS stash, 2 = no stage 2, 4 = no stage 1, 8 = no barrier B, 16 = stage 2's stores dropped; results are
 wrong, times are what is asked), other run lengths, and the tile kernels of rounds 1-4 beside it.
     gpurun -- 'python tools/ingest_lab.py [GiB]'"""
 import os
@@ -71,10 +71,10 @@ report("stage 1 only (y1 to memory)", timed(stage1_only))
 os.environ["WFX_INGEST_TILE"] = "1"
 report("tile kernel (rounds 1-4), stage 1", timed(tile))
 del os.environ["WFX_INGEST_TILE"]
-for flags in (0, 2, 4, 6, 7, 15, 10):
+for flags in (0, 16, 2, 4, 6, 7, 15):
     rows = 8
     os.environ["WFX_INGEST_DBG"] = str(flags)
-    what = " ".join(w for b, w in ((1, "no-stash"), (2, "no-stage2"), (4, "no-stage1"), (8, "no-barrier-B")) if flags & b)
+    what = " ".join(w for b, w in ((1, "no-stash"), (2, "no-stage2"), (4, "no-stage1"), (8, "no-barrier-B"), (16, "no-stores")) if flags & b)
     report(f"fused  rows={rows} flags={flags} ({what})", timed(fused))
 del os.environ["WFX_INGEST_DBG"]
 for extra in (0, 8192, 36000, 100000):

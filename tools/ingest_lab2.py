@@ -55,87 +55,39 @@ ctx.sync()
 ctx.profile_enable(False)
 pr = ctx.profile()
 print("ingest inside the decode (events): %.3f ms per launch; whole decode kernels %.3f ms" % (pr["polyphase_ingest"][1] / pr["polyphase_ingest"][0], sum(v[1] for v in pr.values()) / 5), flush=True)
-print("synthesised stream again, back to back: min %.3f median %.3f ms" % timed(fused), flush=True)
-def triple(tag):
-    print("%s: plain read %.2f TB/s" % (tag, ctx.d_read_rate(p_in, frames * 4, 3) / 1e3), flush=True)
-    for flags in (0, 15, 4, 2, 0):
-        os.environ["WFX_INGEST_DBG"] = str(flags)
-        print("%s: flags %d: min %.3f median %.3f ms" % ((tag, flags) + timed(fused, 5, 8)), flush=True)
-        os.environ["WFX_INGEST_CLK"] = "1"
-        fused()
-        del os.environ["WFX_INGEST_CLK"]
-    del os.environ["WFX_INGEST_DBG"]
-
-
-triple("synthesised stream")
-# overwrite the stream with the repeating ramp of tools/ingest_lab.py
-x = (np.arange(1 << 20, dtype=np.int32) % 2001 - 1000).astype(np.int16)
-blk = np.stack([x, x[::-1]], axis=1).copy()
-for off in range(0, frames, 1 << 20):
-    ctx.dev_upload(p_in + off * 4, blk[:min(1 << 20, frames - off)])
-if os.environ.get("WFX_LAB_SHORT"):
-    os.environ["WFX_INGEST_DBG"] = "15"
-    print("loads only: min %.3f median %.3f ms" % timed(fused, 5, 6), flush=True)
-    del os.environ["WFX_INGEST_DBG"]
-    print("all on: min %.3f median %.3f ms" % timed(fused, 5, 6), flush=True)
-    sys.exit(0)
-def triple(tag):
-    print("%s: plain read %.2f TB/s" % (tag, ctx.d_read_rate(p_in, frames * 4, 3) / 1e3), flush=True)
-    for flags in (0, 15, 4, 2, 0):
-        os.environ["WFX_INGEST_DBG"] = str(flags)
-        print("%s: flags %d: min %.3f median %.3f ms" % ((tag, flags) + timed(fused, 5, 8)), flush=True)
-        os.environ["WFX_INGEST_CLK"] = "1"
-        fused()
-        del os.environ["WFX_INGEST_CLK"]
-    del os.environ["WFX_INGEST_DBG"]
-
-
-triple("synthesised stream")
-# overwrite the stream with the repeating ramp of tools/ingest_lab.py
-x = (np.arange(1 << 20, dtype=np.int32) % 2001 - 1000).astype(np.int16)
-blk = np.stack([x, x[::-1]], axis=1).copy()
-for off in range(0, frames, 1 << 20):
-    ctx.dev_upload(p_in + off * 4, blk[:min(1 << 20, frames - off)])
-for rep in range(3):
-    for xcd in (1, 0):
-        if not xcd:
-            os.environ["WFX_INGEST_NO_XCD"] = "1"
-        for flags in (0, 15):
-            os.environ["WFX_INGEST_DBG"] = str(flags)
-            print("xcd-aware %d flags %2d: min %.3f median %.3f ms" % ((xcd, flags) + timed(fused, 5, 6)), flush=True)
-        os.environ.pop("WFX_INGEST_NO_XCD", None)
-del os.environ["WFX_INGEST_DBG"]
-sys.exit(0)
-def triple(tag):
-    print("%s: plain read %.2f TB/s" % (tag, ctx.d_read_rate(p_in, frames * 4, 3) / 1e3), flush=True)
-    for flags in (0, 15, 4, 2, 0):
-        os.environ["WFX_INGEST_DBG"] = str(flags)
-        print("%s: flags %d: min %.3f median %.3f ms" % ((tag, flags) + timed(fused, 5, 8)), flush=True)
-        os.environ["WFX_INGEST_CLK"] = "1"
-        fused()
-        del os.environ["WFX_INGEST_CLK"]
-    del os.environ["WFX_INGEST_DBG"]
-
-
-triple("synthesised stream")
-# overwrite the stream with the repeating ramp of tools/ingest_lab.py
-x = (np.arange(1 << 20, dtype=np.int32) % 2001 - 1000).astype(np.int16)
-blk = np.stack([x, x[::-1]], axis=1).copy()
-for off in range(0, frames, 1 << 20):
-    ctx.dev_upload(p_in + off * 4, blk[:min(1 << 20, frames - off)])
 for ni in (8, 16, 32):
     os.environ["WFX_INGEST_NI"] = str(ni)
-    for flags in (15, 0):
+    print("  run length %2d iterations: min %.3f median %.3f ms" % ((ni,) + timed(fused, 5, 4)), flush=True)
+del os.environ["WFX_INGEST_NI"]
+FLAGS = ((1, "no-stash"), (2, "no-stage2"), (4, "no-stage1"), (8, "no-barrier-B"), (16, "no-stores"))
+
+
+def parts(tag):
+    """the kernel on what the buffer holds now: whole, and with parts switched off (results wrong, times asked for); one more launch of
+    each with the in-kernel clock probe on (its line goes to stderr)"""
+    print("%s: plain read %.2f TB/s" % (tag, ctx.d_read_rate(p_in, frames * 4, 3) / 1e3), flush=True)
+    for flags in (0, 16, 2, 6, 15, 0):
         os.environ["WFX_INGEST_DBG"] = str(flags)
-        print("run length %2d iterations, flags %2d: min %.3f median %.3f ms" % ((ni, flags) + timed(fused, 5, 6)), flush=True)
-del os.environ["WFX_INGEST_NI"], os.environ["WFX_INGEST_DBG"]
-triple("repeating ramp in the same buffer")
+        what = " ".join(w for b, w in FLAGS if flags & b) or "everything on"
+        print("%s: %-40s min %.3f median %.3f ms" % ((tag, what) + timed(fused, 5, 8)), flush=True)
+        os.environ["WFX_INGEST_CLK"] = "1"
+        fused()
+        del os.environ["WFX_INGEST_CLK"]
+    del os.environ["WFX_INGEST_DBG"]
+
+
+parts("synthesised stream")
+x = (np.arange(1 << 20, dtype=np.int32) % 2001 - 1000).astype(np.int16)
+blk = np.stack([x, x[::-1]], axis=1).copy()
+for off in range(0, frames, 1 << 20):
+    ctx.dev_upload(p_in + off * 4, blk[:min(1 << 20, frames - off)])
+parts("repeating ramp in the same buffer")
 z = np.zeros((1 << 22, 2), dtype=np.int16)
 for off in range(0, frames, 1 << 22):
     ctx.dev_upload(p_in + off * 4, z[:min(1 << 22, frames - off)])
-triple("zeros in the same buffer")
+parts("zeros in the same buffer")
 rng = np.random.default_rng(1)
 r = rng.integers(-32768, 32767, size=(1 << 22, 2), dtype=np.int16)
 for off in range(0, frames, 1 << 22):
     ctx.dev_upload(p_in + off * 4, r[:min(1 << 22, frames - off)])
-triple("uniform random int16 in the same buffer")
+parts("uniform random int16 in the same buffer")

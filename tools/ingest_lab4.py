@@ -1,5 +1,5 @@
-"""How often is a 22 GB allocation a slow one for the ingest's 768 streams?  Eight allocations held side by side, before and after a few
-whole decodes have churned the context's buffers; loads-only form of the kernel (data does not matter to it) and a plain read of each."""
+"""How often is a 22 GB allocation a slow one for the ingest's 768 streams?  Allocations held side by side, before and after a few whole
+decodes have churned the context's buffers; the kernel with parts switched off (data does not matter to it) and a plain read of each."""
 import os
 import sys
 import time
@@ -50,14 +50,13 @@ def round_of(tag, k=8):
         ctx.dev_free(p)
 
 
-round_of("fresh process:", 5)
-sys.exit(0)
+round_of("fresh process:", 6)
 loader = synth_device.SliceLoader(ctx, sp)
 dec = sharded.FrontEndExactDecoder(ctx, chain, None, n_in_total=frames, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120, raw_loader=loader)
 for _ in range(3):
     dec.run()
 ctx.sync()
 print(f"the decoder's own buffer at {dec.fe.p_raw:#x}: loads only {skeleton(dec.fe.p_raw):.3f} ms", flush=True)
-
+round_of("after three decodes:", 4)
 dec.close()
 
