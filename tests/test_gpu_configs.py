@@ -153,6 +153,31 @@ def test_int16_capture_is_resampled_in_place_thirty_seconds():
     ctx.close()
 
 
+@pytest.mark.parametrize("fs", [48000.0, 11025.0])
+def test_non_temporal_loads_in_the_transform_passes_change_nothing(fs, monkeypatch):
+    """The passes read arrays beyond the Infinity Cache with non-temporal loads (mr_pass_desc::nt_in, compile-time variants of the
+    kernels): forced on for a small capture (WFX_MR_NT=1) and forced off (0), the same bytes and the same float64 audio come out."""
+    from wefax_amd import _native as nat
+    from wefax_amd import synth
+    from wefax_amd.wefax import DecodeJob
+    x = synth.synth_capture(fs, noise=0.05, seed=11, start_tone_s=2.0, phasing_lines=20, image_lines=40, stop_tone_s=1.0, black_tail_s=2.0)
+    ctx = nat.Context(0)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WFX_MR_NT", mode)
+        job = DecodeJob(ctx, x, int(fs), 120)
+        job.run()
+        info = job.result()
+        got[mode] = (int(info.start_frame), job.fetch("digitalized"), job.fetch("audio"), job.fetch("image"))
+    monkeypatch.delenv("WFX_MR_NT")
+    assert got["0"][0] == got["1"][0]
+    for k in (1, 2, 3):
+        assert np.array_equal(got["0"][k], got["1"][k])
+    ref = _oracle(x, int(fs), 120)
+    assert np.array_equal(got["1"][1], ref["digitalized"]) and np.array_equal(got["1"][3], ref["image"])
+    ctx.close()
+
+
 def test_sixty_minute_48k_capture_full_size():
     """BASELINE configs[2] at full size: 172 800 000 int16 samples (synthesised on the device, checked against the NumPy
     generator elsewhere) -> 39 690 000 at 11 025 Hz -> 5512 x 28 784 image.  The oracle needs ~10 s for it."""

@@ -145,6 +145,9 @@ struct mr_pass_desc {
     // reads row m of its input at in + m * in_rs (elements) instead of m * ncol, the last inverse pass (P == ncol) writes output
     // row q at out + q * out_rs -- rows that carry a halo between them.  0: the dense strides
     long long in_rs, out_rs;
+    // the pass reads its input with non-temporal loads: set by wfx_mr_launch_pair for arrays the Infinity Cache cannot hold anyway (there
+    // the passes of the 60-minute captures run 10-13 % faster with it, those of the 10-minute one -- 57 MB arrays -- 3 % slower)
+    int nt_in;
 };
 struct mr_qmap {
     unsigned long long base;

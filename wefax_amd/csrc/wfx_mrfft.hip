@@ -580,7 +580,9 @@ constexpr int mr2_i16_sup(int r)
         if (t * r * 16 + r * sw * 4 + r * 16 + 2048 <= 80 * 1024) return sw / t;
     return 1;
 }
-template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
+// NTL: the input is read with non-temporal loads (mr_pass_desc::nt_in: arrays the Infinity Cache cannot hold).  A compile-time choice --
+// decided per tile at run time it cost the forward passes 3-8 % -- so the passes the 60-minute captures use have two instantiations
+template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE, int NTL = 0>
 __global__ void __launch_bounds__(mr2_nt(RA * RB), mr2_nt(RA * RB) == 512 ? 1 : OUT_MODE == 2 ? MR2_FUSED_LB : 2)
 mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, const cplx *__restrict__ tw_lo, const cplx *__restrict__ tw_hi,
          int ntiles)
@@ -625,7 +627,8 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             sreg[i] = v;
         }
     };
-    auto prefetch = [&](int tix) {
+    auto prefetch_as = [&](int tix, auto ntc) {
+        constexpr bool NTLOAD = decltype(ntc)::value;    // non-temporal loads (arrays the Infinity Cache cannot hold: mr_pass_desc::nt_in)
 #pragma unroll
         for (int ia = 0; ia < NA; ++ia) {
             const int item = t + NT * ia;
@@ -641,7 +644,12 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                         const short2 x2 = SUP > 1 ? stage[(a * RB + b) * SW + (tix & (SUP - 1)) * T + c] : ((const short2 *)in)[adr];
                         v = make_double2((double)x2.x, (double)x2.y);
                     } else {
-                        v = in[adr];
+                        if (NTLOAD) {
+                            typedef double mr_v2d __attribute__((ext_vector_type(2)));
+                            const mr_v2d q = __builtin_nontemporal_load((const mr_v2d *)&in[adr]);
+                            v = make_double2(q.x, q.y);
+                        } else
+                            v = in[adr];
                         if (IN_MODE == 1) v = make_double2(v.y, v.x);
                     }
                 }
@@ -649,6 +657,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
             }
         }
     };
+    auto prefetch = [&](int tix) { prefetch_as(tix, std::integral_constant<bool, NTL == 1>()); };
     auto lookup = [&](int e) { return mconj_if(mcmul(tw_hi[e >> MR_LO_BITS], tw_lo[e & (MR_LO - 1)]), inv); };
     int tix = blockIdx.x * SUP;
     if (PF && tix < ntiles) prefetch(tix);
@@ -1230,8 +1239,15 @@ void wfx_mr_release(wfx_ctx *ctx)
 }
 
 // hi table = lo + 2048 in every plan (mr_fill_pass lays them out that way)
-int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int in_mode, int out_mode, int dir, const void *src_v, cplx *dst)
+int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d_in, const cplx *tw, int in_mode, int out_mode, int dir, const void *src_v, cplx *dst)
 {
+    mr_pass_desc d = d_in;
+    {
+        const char *e = getenv("WFX_MR_NT");                                                 // (A/B and test switch: 0 never, 1 always)
+        const int forced = e ? atoi(e) : -1;
+        const double in_bytes = (double)d.ncol * (double)d.R * (in_mode == 2 ? 4.0 : 16.0);
+        d.nt_in = forced >= 0 ? forced : (in_bytes > 128.0 * 1048576.0);
+    }
     const cplx *src = (const cplx *)src_v;
     const cplx *lo = tw, *hi = tw + MR_LO;
     const int kid = dir == 0 ? K_FFT_FWD : K_FFT_INV;
@@ -1247,10 +1263,20 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d, const cplx *tw, int 
     if (!done && d.ra == (RA_) && d.rb == (RB_)) {                                                                                    \
         if (in_mode == 2 && dir == 0 && out_mode == 0)                                                                               \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 2, 0, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 1 && in_mode == 0 && out_mode == 0 && d.nt_in)                                                               \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
+        else if (dir == 0 && in_mode == 0 && out_mode == 0 && d.nt_in)                                                               \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
         else if (dir == 1 && in_mode == 0 && out_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 1 && in_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
+        else if (dir == 0 && out_mode == 2 && in_mode == 0 && d.nt_in)                                                               \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
+        else if (dir == 0 && out_mode == 3 && in_mode == 0 && d.nt_in)                                                               \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 3, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
+        else if (dir == 0 && in_mode == 1 && out_mode == 0 && d.nt_in)                                                               \
+            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
         else if (dir == 0 && out_mode == 2 && in_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 3 && in_mode == 0)                                                                          \
