@@ -916,6 +916,20 @@ __global__ void __launch_bounds__(256) mr_fill_tables(cplx *__restrict__ lo, cpl
 struct mr2_pair {
     int ra, rb;
 };
+// pairs whose passes have a non-temporal-load instantiation: the radices of the whole-second captures (5, 7, 8, 9, 15, 16, 25); a long
+// capture whose length brings 4, 11 or 13 into play runs the default loads (each instantiation is compile time: 43 pairs x 16 forms)
+constexpr bool mr2_nt_pair(int ra, int rb)
+{
+    return ra != 4 && ra != 11 && ra != 13 && rb != 11 && rb != 13;
+}
+template <int RA, int RB, int IN_MODE, int OUT_MODE, int INVERSE>
+static auto mr2_pass_nt()
+{
+    if constexpr (mr2_nt_pair(RA, RB))
+        return &mr2_pass<RA, RB, IN_MODE, OUT_MODE, INVERSE, 1>;
+    else
+        return &mr2_pass<RA, RB, IN_MODE, OUT_MODE, INVERSE, 0>;
+}
 static const mr2_pair g_mr2_pairs[] = {
 #define X(a, b) {a, b},
     WFX_MR2_PAIRS(X)
@@ -1264,19 +1278,19 @@ int wfx_mr_launch_pair(wfx_ctx *ctx, const mr_pass_desc &d_in, const cplx *tw, i
         if (in_mode == 2 && dir == 0 && out_mode == 0)                                                                               \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 2, 0, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 1 && in_mode == 0 && out_mode == 0 && d.nt_in)                                                               \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
+            WFX_LAUNCH(ctx, kid, (mr2_pass_nt<RA_, RB_, 0, 0, 1>()), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
         else if (dir == 0 && in_mode == 0 && out_mode == 0 && d.nt_in)                                                               \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
+            WFX_LAUNCH(ctx, kid, (mr2_pass_nt<RA_, RB_, 0, 0, 0>()), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
         else if (dir == 1 && in_mode == 0 && out_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 1 && in_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 1, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 2 && in_mode == 0 && d.nt_in)                                                               \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
+            WFX_LAUNCH(ctx, kid, (mr2_pass_nt<RA_, RB_, 0, 2, 0>()), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
         else if (dir == 0 && out_mode == 3 && in_mode == 0 && d.nt_in)                                                               \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 3, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
+            WFX_LAUNCH(ctx, kid, (mr2_pass_nt<RA_, RB_, 0, 3, 0>()), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
         else if (dir == 0 && in_mode == 1 && out_mode == 0 && d.nt_in)                                                               \
-            WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 1, 0, 0, 1>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
+            WFX_LAUNCH(ctx, kid, (mr2_pass_nt<RA_, RB_, 1, 0, 0>()), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                     \
         else if (dir == 0 && out_mode == 2 && in_mode == 0)                                                                          \
             WFX_LAUNCH(ctx, kid, (mr2_pass<RA_, RB_, 0, 2, 0>), dim3(g2), dim3(mr2_nt((RA_) * (RB_))), src, dst, d, lo, hi, nt);                        \
         else if (dir == 0 && out_mode == 3 && in_mode == 0)                                                                          \
