@@ -20,7 +20,7 @@ from collections import defaultdict
 GROUPS = [
     (r"fft_pass<\d+, 1,", "fft_pass_fwd"), (r"fft_pass<\d+, -1,", "fft_pass_inv"),
     (r"mr_pass<\d+, \d+, 0>", "fft_pass_fwd"), (r"mr_pass<\d+, \d+, 1>", "fft_pass_inv"),
-    (r"mr2_pass<[\d, ]+, 0>", "fft_pass_fwd"), (r"mr2_pass<[\d, ]+, 1>", "fft_pass_inv"),
+    (r"mr2_pass<\d+, \d+, \d+, \d+, 0(, \d+)?>", "fft_pass_fwd"), (r"mr2_pass<\d+, \d+, \d+, \d+, 1(, \d+)?>", "fft_pass_inv"),      # (RA, RB, IN_MODE, OUT_MODE, INVERSE[, NTL])
     (r"notch_kernel", "notch_filtfilt"), (r"hconv_env_median|hilbert_abs|hconv_env\b", "env_median"),
     (r"select_l0|select_l1|select_compact", "select_hist"), (r"select_finish|select_lerp", "select_scan"),
     (r"quantise_kernel|quantise_corr_kernel", "quantise"), (r"sync_corr_kernel", "sync_corr"), (r"sync_pick_kernel", "sync_pick"),

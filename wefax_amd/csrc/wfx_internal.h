@@ -6,6 +6,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <map>
 #include <string>
@@ -193,6 +194,29 @@ void wfx_prof_end(wfx_ctx *ctx);
         hipError_t e_ = hipGetLastError();                                                                      \
         if (e_ != hipSuccess) return wfx_fail_hip(ctx, e_, "launch " #kern);                                    \
     } while (0)
+
+// Loads of arrays that are read ONCE and are larger than the Infinity Cache can hold anyway: non-temporal.  The transform passes gain
+// 10-13 % with them on the 60-minute captures (wfx_mrfft.hip), the resampler's glue pass 18 %; kernels whose lanes share lines with
+// their neighbours do not (envelope + median: 8 % slower; the notch: no change) and keep the default loads.  `nt` is a kernel argument
+// the launcher sets with wfx_nt_for(bytes of the array); WFX_MR_NT=0|1 forces it off / on (tests run small captures with 1).
+#ifdef __HIPCC__
+typedef double wfx_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double wfx_ld(const double *p, int nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ short wfx_ld(const short *p, int nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ double2 wfx_ld(const double2 *p, int nt)
+{
+    if (nt) {
+        const wfx_v2d q = __builtin_nontemporal_load((const wfx_v2d *)p);
+        return make_double2(q.x, q.y);
+    }
+    return *p;
+}
+#endif
+static inline int wfx_nt_for(double bytes)
+{
+    const char *e = getenv("WFX_MR_NT");
+    return e ? atoi(e) : (bytes > 128.0 * 1048576.0 ? 1 : 0);
+}
 
 static inline unsigned wfx_blocks(uint64_t n, unsigned per_block)
 {

@@ -1894,7 +1894,7 @@ static void mr_padded_release(wfx_ctx *ctx)
 //   Y = the kept bins of X (scipy's Nyquist-bin factors; irfft ignores Im Y[0], Im Y[K])
 //   W[k] = (Y[k] + conj Y[K-k]) + i e^{2 pi i k/num} (Y[k] - conj Y[K-k]);  out[2q] + i out[2q+1] = IFFT_K(W)[q] / n0
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) resample_mr_glue(const cplx *__restrict__ Z, long long n0, long long num, cplx *__restrict__ W)
+__global__ void __launch_bounds__(256) resample_mr_glue(const cplx *__restrict__ Z, long long n0, long long num, cplx *__restrict__ W, int nt)
 {
     const long long M = n0 / 2, K = num / 2, nmin = n0 < num ? n0 : num, half = nmin / 2;
     const double edge = (nmin % 2 == 0) ? (num < n0 ? 2.0 : (num > n0 ? 0.5 : 1.0)) : 1.0;
@@ -1902,7 +1902,7 @@ __global__ void __launch_bounds__(256) resample_mr_glue(const cplx *__restrict__
     auto bin = [&](long long j) {                       // Y[j], j in [0, K]
         if (j > half) return make_double2(0.0, 0.0);
         const long long a = j >= M ? j - M : j, b = (j == 0 || j >= M) ? 0 : M - j;       // j % M, (M - j) % M for j <= M
-        const cplx zk = Z[a], zc = make_double2(Z[b].x, -Z[b].y);
+        const cplx zk = wfx_ld(Z + a, nt), zb = wfx_ld(Z + b, nt), zc = make_double2(zb.x, -zb.y);
         double sn, cs;
         sincospi(2.0 * (double)j / (double)n0, &sn, &cs);
         const cplx dif = make_double2(zk.x - zc.x, zk.y - zc.y);
@@ -2189,7 +2189,7 @@ int wfx_dev_resample_mr(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num
     WFX_TRY(mr_run(ctx, p1, (const cplx *)x, A, B, 0, false, nullptr, &Z, x_is_i16, half, M - half));
     cplx *Wb = (Z == A) ? B : A;
     WFX_LAUNCH(ctx, K_RESAMPLE_PW, resample_mr_glue, dim3(wfx_stream_grid((uint64_t)K / 2 + 1, 256)), dim3(256), (const cplx *)Z, (long long)n0,
-               (long long)num, Wb);
+               (long long)num, Wb, wfx_nt_for(8.0 * (double)nmin));
     WFX_TRY(mr_get_plan(ctx, K, &p2));        // (std::map: p1 stays valid)
     cplx *res = nullptr;
     return mr_run(ctx, p2, Wb, A, B, 1, false, (cplx *)out, &res);
