@@ -309,3 +309,37 @@ def test_ranks_whose_environments_disagree_about_the_plan_are_told_so_at_creatio
     out = _run(2, _disagreeing_env_worker, lambda r: (job, r), timeout=300)
     for r in (0, 1):
         assert "k1 subsets" in out[r] and "environments" in out[r] and "error -5" in out[r], out
+
+
+def _abandoning_worker(job, world, rank, q):
+    try:
+        keep = nat.Comm.shm(None, job, world, rank, timeout=10.0)             # (held: dropping it would close it)
+        q.put((rank, "created" if keep is not None else "?"))
+        time.sleep(0.2)
+        os._exit(0)                                                          # no clean-up: the control block and the outboxes stay in /dev/shm
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}"))
+
+
+def test_a_peer_that_joined_the_leftover_of_an_earlier_job_attaches_again():
+    """A job that died without cleaning up leaves an initialised control block under its name.  In the next launch of that name a
+    peer that starts BEFORE rank 0 passes every check on the leftover and waits at its first barrier there; rank 0 then replaces
+    the block.  The peer must notice (barrier failed, its block no longer linked) and join the new one -- not fail, not leave rank 0
+    waiting for the timeout."""
+    job = _job()
+    out = _run(2, _abandoning_worker, lambda r: (job, 2, r))
+    assert out == {0: "created", 1: "created"}
+    assert [f for f in os.listdir("/dev/shm") if job in f]                   # the leftover is there
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = {r: ctx.Process(target=_selftest_worker, args=(job, 2, r, 6, 99, q, None)) for r in (0, 1)}
+    t0 = time.time()
+    procs[1].start()
+    time.sleep(1.0)                                                          # the peer is on the leftover's barrier by now
+    procs[0].start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs.values():
+        p.join(30)
+    assert got == {0: "ok", 1: "ok"}
+    assert time.time() - t0 < 30.0                                           # (the communicator's timeout is 60 s: nobody sat it out)
+    assert not [f for f in os.listdir("/dev/shm") if job in f]

@@ -900,6 +900,8 @@ int wfx_comm_create_local(int world, wfx_comm **out)
     return 0;
 }
 
+static int shm_attach(wfx_ctx *ctx, const char *job, int world, int rank, double timeout_s, double t0, wfx_comm **out, bool *leftover);
+
 int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, double timeout_s, wfx_comm **out)
 {
     if (!job || !out) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null argument");
@@ -909,6 +911,21 @@ int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, doub
         if (!((*q >= '0' && *q <= '9') || (*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || *q == '-' || *q == '.'))
             return wfx_fail(ctx, WFX_ERR_BAD_ARG, "shm job name: letters, digits, '-' and '.' only");
     if (strlen(job) < 1 || strlen(job) > 100) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "shm job name: 1..100 characters");
+    // A peer can pass every check on the control block of an EARLIER job of this name a moment before rank 0 takes that block away
+    // (marks it failed, unlinks it, creates its own): its first barrier then fails on a dead block while rank 0 waits for it.  Such a
+    // peer notices -- the barrier failed AND the block it holds is no longer linked under the job's name -- lets go of everything
+    // WITHOUT touching the names (they belong to the new job now) and attaches again.
+    const double t_start = now_s();
+    for (;;) {
+        bool leftover = false;
+        const int rc = shm_attach(ctx, job, world, rank, timeout_s, t_start, out, &leftover);
+        if (rc == 0 || !leftover) return rc;
+        usleep(2000);
+    }
+}
+
+static int shm_attach(wfx_ctx *ctx, const char *job, int world, int rank, double timeout_s, double t0, wfx_comm **out, bool *leftover)
+{
     wfx_shm *s = new wfx_shm();
     s->job = job;
     s->world = world;
@@ -917,7 +934,6 @@ int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, doub
     s->host_mode = ctx == nullptr;
     const std::string cn = shm_name(s->job, "ctl");
     int cfd = -1;
-    const double t0 = now_s();
     if (rank == 0) {
         // a leftover of a crashed job of the same name: a peer of THIS launch may already have opened it -- take its magic away
         // and mark it failed before unlinking, so that such a peer finds out (it re-opens: see below) instead of sitting on a
@@ -991,7 +1007,11 @@ int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, doub
         close(cfd);
         usleep(2000);
     }
-    close(cfd);
+    int ctl_fd = -1;                         // (a peer keeps its descriptor until the first barrier is through: see wfx_comm_create_shm)
+    if (rank == 0)
+        close(cfd);
+    else
+        ctl_fd = cfd;
     s->ctl = (shm_ctl *)m;
     if (rank == 0) {
         s->ctl->world = (uint32_t)world;
@@ -1006,6 +1026,7 @@ int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, doub
             const unsigned theirs = s->ctl->world;
             munmap(m, sizeof(shm_ctl));
             s->ctl = nullptr;
+            close(ctl_fd);
             delete s;
             return wfx_fail(ctx, WFX_ERR_COMM, "shm communicator: job %s has world size %u, this rank was told %d", job, theirs, world);
         }
@@ -1016,6 +1037,7 @@ int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, doub
     s->fd[rank] = shm_open(bn.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
     if (s->fd[rank] < 0) {
         const int rc = shm_fail(s, ctx, "cannot create the outbox %s", bn.c_str());
+        if (ctl_fd >= 0) close(ctl_fd);
         shm_close(s);
         return rc;
     }
@@ -1028,10 +1050,24 @@ int wfx_comm_create_shm(wfx_ctx *ctx, const char *job, int world, int rank, doub
     int rc = shm_own_box(s, ctx, 1u << 20, &box);        // outboxes exist before anyone looks for them
     if (rc == 0) rc = shm_barrier(s, ctx);
     if (rc != 0) {
-        shm_close(s);
+        struct stat st;
+        if (ctl_fd >= 0 && fstat(ctl_fd, &st) == 0 && st.st_nlink == 0 && now_s() - t0 < s->timeout) {
+            // the block this peer joined was a leftover that rank 0 has replaced since: let go of the mappings only -- the names
+            // (control block, outboxes) are the new job's, and so is the count of attached ranks it will keep in ITS block
+            *leftover = true;
+            for (int r = 0; r < 64; ++r) {
+                if (s->map[r]) munmap(s->map[r], s->mapped[r]);
+                if (s->fd[r] >= 0) close(s->fd[r]);
+            }
+            munmap(s->ctl, sizeof(shm_ctl));
+            delete s;
+        } else
+            shm_close(s);
+        if (ctl_fd >= 0) close(ctl_fd);
         delete c;
         return rc;
     }
+    if (ctl_fd >= 0) close(ctl_fd);
     *out = c;
     return 0;
 }
