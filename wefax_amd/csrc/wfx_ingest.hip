@@ -20,7 +20,7 @@
 //     ds_write2_b32;
 //   * the 256-tap window sums run on the matrix cores, every sample read from LDS ONCE per byte plane: v_mfma_i32_16x16x64_i8 with
 //     the TAPS as the A operand -- a fixed-point tap is four balanced signed bytes t = q0 + 2^8 q1 + 2^16 q2 + 2^24 q3; row 4 c + q
-//     of A = digit plane q of taps 64 c .. 64 c + 63 (the whole filter: 16 rows x 64, four registers per lane for the whole kernel)
+//     of A = digit plane q of taps 64 c .. 64 c + 63 (the whole filter: 16 rows x 64 = four registers per lane, parked in 1 KiB of LDS between the iterations)
 //     -- and 16 consecutive LDS rows R as the B operand's columns (lane (j, g): the 16 bytes at sample 16 g of the two-row window
 //     that starts at row R0 + j, one ds_read_b128).  Column j of the product is then what rows R, R + 1 contribute, through tap
 //     chunk c, to output R - 2 c: lane (g = c, j) holds that chunk's four digit sums in its four accumulator registers, folds
