@@ -196,8 +196,9 @@ void wfx_prof_end(wfx_ctx *ctx);
     } while (0)
 
 // Loads of arrays that are read ONCE and are larger than the Infinity Cache can hold anyway: non-temporal.  The transform passes gain
-// 10-13 % with them on the 60-minute captures (wfx_mrfft.hip), the resampler's glue pass 18 %; kernels whose lanes share lines with
-// their neighbours do not (envelope + median: 8 % slower; the notch: no change) and keep the default loads.  `nt` is a kernel argument
+// 10-13 % with them on the 60-minute captures (wfx_mrfft.hip), the resampler's glue pass 18 %, the percentile select's two passes 4-7 %;
+// kernels whose lanes share lines with their neighbours, or that find their input still in the caches from the kernel before, do not
+// (envelope + median: 8 % slower; the notch: no change; the quantiser: 75 % slower) and keep the default loads.  `nt` is a kernel argument
 // the launcher sets with wfx_nt_for(bytes of the array); WFX_MR_NT=0|1 forces it off / on (tests run small captures with 1).
 #ifdef __HIPCC__
 typedef double wfx_v2d __attribute__((ext_vector_type(2)));

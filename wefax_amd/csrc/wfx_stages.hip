@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(256) select_l0_kernel(const double *__restrict
 // not occupancy, hide the HBM latency of these one-pass kernels.
 #define SEL_UN 4
 template <int NT = 256, typename FN>
-__device__ __forceinline__ void sel_stream(const double *__restrict__ v, uint64_t n, FN fn)
+__device__ __forceinline__ void sel_stream(const double *__restrict__ v, uint64_t n, FN fn, int nt)
 {
     const int t = threadIdx.x;
     const uint64_t quads = (n + 3) / 4;
@@ -750,8 +750,8 @@ __device__ __forceinline__ void sel_stream(const double *__restrict__ v, uint64_
 #pragma unroll
         for (int u = 0; u < SEL_UN; ++u) {
             const uint64_t i0 = ((it + u) * stride + blockIdx.x * (uint64_t)NT + t) * 4;
-            lo[u] = *(const double2 *)(v + i0);
-            hi[u] = *(const double2 *)(v + i0 + 2);
+            lo[u] = wfx_ld((const double2 *)(v + i0), nt);
+            hi[u] = wfx_ld((const double2 *)(v + i0 + 2), nt);
         }
 #pragma unroll
         for (int u = 0; u < SEL_UN; ++u) {
@@ -786,7 +786,7 @@ __device__ __forceinline__ void sel_stream(const double *__restrict__ v, uint64_
 // value goes through `second` (the compaction counts a lane's matches, reserves list space for the whole wave with ONE atomic,
 // then writes -- an atomic per element slot and wave made the pass latency-bound on captures whose bins are full)
 template <int NT, typename F1, typename FB, typename F2>
-__device__ __forceinline__ void sel_stream2(const double *__restrict__ v, uint64_t n, F1 first, FB between, F2 second)
+__device__ __forceinline__ void sel_stream2(const double *__restrict__ v, uint64_t n, F1 first, FB between, F2 second, int nt)
 {
     const int t = threadIdx.x;
     const uint64_t quads = (n + 3) / 4;
@@ -798,8 +798,8 @@ __device__ __forceinline__ void sel_stream2(const double *__restrict__ v, uint64
 #pragma unroll
         for (int u = 0; u < SEL_UN; ++u) {
             const uint64_t i0 = ((it + u) * stride + blockIdx.x * (uint64_t)NT + t) * 4;
-            lo[u] = *(const double2 *)(v + i0);
-            hi[u] = *(const double2 *)(v + i0 + 2);
+            lo[u] = wfx_ld((const double2 *)(v + i0), nt);
+            hi[u] = wfx_ld((const double2 *)(v + i0 + 2), nt);
         }
 #pragma unroll
         for (int u = 0; u < SEL_UN; ++u) {
@@ -843,7 +843,7 @@ __device__ __forceinline__ void sel_stream2(const double *__restrict__ v, uint64
 // values whose top 11 bits match
 template <int NT>
 __global__ void __launch_bounds__(NT) select_l1_kernel(const double *__restrict__ v, uint64_t n, uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3,
-                                                       unsigned *__restrict__ ws, wfx_dev_scalars *__restrict__ s)
+                                                       unsigned *__restrict__ ws, wfx_dev_scalars *__restrict__ s, int nt)
 {
     __shared__ unsigned h[4][SEL_BINS];
     __shared__ unsigned long long pfx[4], rnk[4], rin[4];
@@ -886,7 +886,7 @@ __global__ void __launch_bounds__(NT) select_l1_kernel(const double *__restrict_
         for (int q = 0; q < 4; ++q)
             if (active[q] && valid && hi == mypfx[q]) atomicAdd(&h[q][digit], 1u);   // level-1 digits are diverse: no wave aggregation
     };
-    sel_stream<NT>(v, n, count);
+    sel_stream<NT>(v, n, count, nt);
     __syncthreads();
     for (int i = t; i < 4 * SEL_BINS; i += NT) {
         const unsigned c = (&h[0][0])[i];
@@ -898,7 +898,7 @@ __global__ void __launch_bounds__(NT) select_l1_kernel(const double *__restrict_
 // 22 bits match to the query's candidate list (one atomic per wave and list)
 template <int NT>
 __global__ void __launch_bounds__(NT) select_compact_kernel(const double *__restrict__ v, uint64_t n, unsigned *__restrict__ ws,
-                                                            wfx_dev_scalars *__restrict__ s, unsigned long long *__restrict__ cand, uint64_t cap)
+                                                            wfx_dev_scalars *__restrict__ s, unsigned long long *__restrict__ cand, uint64_t cap, int nt)
 {
     __shared__ unsigned long long pfx[4], rnk[4], rin[4];
     __shared__ unsigned dig[4];
@@ -969,7 +969,7 @@ __global__ void __launch_bounds__(NT) select_compact_kernel(const double *__rest
                 if (slot < cap) cand[(uint64_t)q * cap + slot] = key;
             }
     };
-    sel_stream2<NT>(v, n, count, reserve, append);
+    sel_stream2<NT>(v, n, count, reserve, append, nt);
 }
 
 // levels 2..5 on the candidate lists, numpy's lerp, and clearing of the workspace
@@ -1117,8 +1117,8 @@ static int select_after_l0(wfx_ctx *ctx, const double *env, uint64_t n, const ui
     // wave-instructions that execute at the memory side (~1.3 TB/s chip-wide), so fewer, larger workgroups
     // (18.5 us) beat 512 x 256 lanes (28 us)
     const unsigned g1 = std::min(wfx_stream_grid(n, 16384), 256u);
-    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l1_kernel<1024>, dim3(g1), dim3(1024), env, n, ranks[0], ranks[1], ranks[2], ranks[3], ws, d_scal);
-    WFX_LAUNCH(ctx, K_SELECT_HIST, select_compact_kernel<1024>, dim3(g1), dim3(1024), env, n, ws, d_scal, cand, n);
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l1_kernel<1024>, dim3(g1), dim3(1024), env, n, ranks[0], ranks[1], ranks[2], ranks[3], ws, d_scal, wfx_nt_for(8.0 * (double)n));
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_compact_kernel<1024>, dim3(g1), dim3(1024), env, n, ws, d_scal, cand, n, wfx_nt_for(8.0 * (double)n));
     WFX_LAUNCH(ctx, K_SELECT_SCAN, select_finish_kernel, dim3(4), dim3(1024), ws, d_scal, (const unsigned long long *)cand, n, do_lerp, gamma_lo,
                gamma_hi);
     return 0;
@@ -1183,7 +1183,7 @@ int wfx_dev_select_sharded_ws(wfx_ctx *ctx, unsigned **ws)
 int wfx_dev_select_l1(wfx_ctx *ctx, const double *env, uint64_t n, const uint64_t ranks[4], unsigned *ws, wfx_dev_scalars *d_scal)
 {
     const unsigned g1 = std::min(wfx_stream_grid(n, 16384), 256u);
-    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l1_kernel<1024>, dim3(g1), dim3(1024), env, n, ranks[0], ranks[1], ranks[2], ranks[3], ws, d_scal);
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_l1_kernel<1024>, dim3(g1), dim3(1024), env, n, ranks[0], ranks[1], ranks[2], ranks[3], ws, d_scal, wfx_nt_for(8.0 * (double)n));
     return 0;
 }
 
@@ -1195,7 +1195,7 @@ __global__ void select_block_counts_kernel(const unsigned *__restrict__ ws, unsi
 int wfx_dev_select_compact_block(wfx_ctx *ctx, const double *env, uint64_t n, unsigned *ws, wfx_dev_scalars *d_scal, void *block, uint64_t cap)
 {
     const unsigned g1 = std::min(wfx_stream_grid(n, 16384), 256u);
-    WFX_LAUNCH(ctx, K_SELECT_HIST, select_compact_kernel<1024>, dim3(g1), dim3(1024), env, n, ws, d_scal, (unsigned long long *)block, cap);
+    WFX_LAUNCH(ctx, K_SELECT_HIST, select_compact_kernel<1024>, dim3(g1), dim3(1024), env, n, ws, d_scal, (unsigned long long *)block, cap, wfx_nt_for(8.0 * (double)n));
     WFX_LAUNCH(ctx, K_SELECT_SCAN, select_block_counts_kernel, dim3(1), dim3(64), (const unsigned *)ws, (unsigned *)((char *)block + cap * 32));
     return 0;
 }
