@@ -362,3 +362,43 @@ def test_every_recipe_still_hashes_to_the_manifest(tmp_path):
     json.dump({"cases": cases}, open(gold / "manifest.json", "w"))
     assert recipes.ensure_all(str(gold), strict=False) == {}
     assert sorted(os.listdir(gold / "inputs")) == sorted(os.path.basename(c["input"]) for c in cases)
+
+
+def test_placed_allocation_keeps_the_best_candidate_and_frees_the_rest(monkeypatch):
+    """Context.dev_malloc_placed (host logic only, a stand-in for the context): candidates are held side by side while they are timed,
+    the first one that reaches the bar ends the search, the best is kept, every other one is freed; one try or a small buffer: no timing."""
+    from wefax_amd import _native as nat
+
+    class Fake:
+        def __init__(self, rates):
+            self.rates, self.live, self.freed, self.n = list(rates), [], [], 0
+
+        def dev_malloc(self, nbytes):
+            self.n += 1
+            self.live.append(self.n)
+            return self.n
+
+        def dev_free(self, p):
+            self.live.remove(p)
+            self.freed.append(p)
+
+        def d_stream_rate(self, p, nbytes):
+            assert len(self.live) == p                      # (earlier candidates are still allocated: the next one lies elsewhere)
+            return self.rates[p - 1]
+
+    placed = nat.Context.dev_malloc_placed
+    f = Fake([5200.0, 5900.0, 5600.0, 7000.0])
+    p, rates = placed(f, 2 << 30, tries=3)
+    assert p == 2 and rates == [5200.0, 5900.0, 5600.0] and f.live == [2] and sorted(f.freed) == [1, 3]
+    f = Fake([5200.0, 6100.0, 7000.0])
+    p, rates = placed(f, 2 << 30, tries=4)                  # the second candidate reaches the bar (6000 GB/s): the search ends there
+    assert p == 2 and rates == [5200.0, 6100.0] and f.live == [2] and f.freed == [1]
+    f = Fake([1.0])
+    assert placed(f, 2 << 30, tries=1) == (1, []) and placed(f, 1 << 20, tries=4) == (2, [])      # one try / a small buffer: not timed
+    monkeypatch.setenv("WFX_PLACE_TRIES", "2")
+    f = Fake([10.0, 20.0, 30.0])
+    p, rates = placed(f, 2 << 30)
+    assert p == 2 and rates == [10.0, 20.0]
+    f = Fake([3.0, 2.0])
+    p, rates = placed(f, 1 << 20, tries=2, probe=lambda q: {1: 3.0, 2: 2.0}[q])      # with a probe of the caller's, any size is timed
+    assert p == 1 and rates == [3.0, 2.0] and f.live == [1]
