@@ -32,7 +32,8 @@ typedef enum {
     WFX_ERR_HIP = -2,
     WFX_ERR_OOM = -3,
     WFX_ERR_STATE = -4,
-    WFX_ERR_COMM = -5
+    WFX_ERR_COMM = -5,
+    WFX_ERR_SHORT_FILE = -6     /* a wav whose data chunk is shorter than its header says: the binding raises what scipy.io.wavfile.read raises (ValueError) */
 } wfx_status;
 
 /* sample formats accepted at ingest (wefax.py:348-373) */
@@ -201,7 +202,7 @@ typedef enum {
 int wfx_decode_upload(wfx_ctx *ctx, const void *host_in, const wfx_decode_params *p);
 /* the same from an open file: `in_bytes` of 16-bit PCM samples at `file_offset` of `fd` (the data chunk of a wav file: wefax.py:349)
  * go through `pinned` -- page-locked host memory of the caller, at least that large -- to the device in slices, the reads (a few
- * threads) overlapping the DMA.  WFX_IN_I16_MONO / WFX_IN_I16_STEREO only; a short file is WFX_ERR_BAD_ARG ("Incomplete wav file") */
+ * threads) overlapping the DMA.  WFX_IN_I16_MONO / WFX_IN_I16_STEREO only; a short file is WFX_ERR_SHORT_FILE ("Incomplete wav file") */
 int wfx_decode_upload_fd(wfx_ctx *ctx, int fd, uint64_t file_offset, void *pinned, size_t pinned_bytes, const wfx_decode_params *p);
 /* enqueue every kernel of the path on the context's stream (asynchronous) */
 /* like wfx_decode_upload, but the capture already lives in DEVICE memory owned by the caller (e.g. the output of the

@@ -163,6 +163,7 @@ class WireTime(C.Structure):
 
 WFX_COMM_ID_BYTES = 128
 WFX_ERR_COMM = -5
+WFX_ERR_SHORT_FILE = -6
 
 
 class NativeError(RuntimeError):
@@ -451,7 +452,11 @@ class Context:
         on its way to the device as soon as it is complete (include/wefax_hip.h: wfx_decode_upload_fd)."""
         buf = self.staging(nbytes)
         self._keep = buf
-        self._check(self.lib.wfx_decode_upload_fd(self.h, int(fd), int(file_offset), _ptr(buf), buf.nbytes, C.byref(params)))
+        rc = self.lib.wfx_decode_upload_fd(self.h, int(fd), int(file_offset), _ptr(buf), buf.nbytes, C.byref(params))
+        if rc == WFX_ERR_SHORT_FILE:        # the same exception as hostparams.read_wav (= scipy.io.wavfile.read, wefax.py:349)
+            msg = self.lib.wfx_last_error(self.h)
+            raise ValueError(msg.decode() if msg else "Incomplete wav file")
+        self._check(rc)
 
     def decode_run(self):
         self._check(self.lib.wfx_decode_run(self.h))

@@ -342,8 +342,14 @@ int wfx_decode_upload_fd(wfx_ctx *ctx, int fd, uint64_t file_offset, void *pinne
             done[k].store(1, std::memory_order_release);
         }
     };
+    // (a std::thread constructor may throw std::system_error at the process's thread limit: nothing may cross the C boundary, so
+    // whatever could not be started is made up for by this thread, which then reads the remaining slices itself -- ADVICE r5)
     std::vector<std::thread> pool;
-    for (unsigned i = 0; i < nthr; ++i) pool.emplace_back(reader);
+    try {
+        for (unsigned i = 0; i < nthr; ++i) pool.emplace_back(reader);
+    } catch (...) {
+    }
+    if (pool.empty()) reader();
     int rc = 0;
     for (size_t k = 0; k < nsl && rc == 0; ++k) {
         int st;
@@ -357,7 +363,7 @@ int wfx_decode_upload_fd(wfx_ctx *ctx, int fd, uint64_t file_offset, void *pinne
     if (rc != 0) return wfx_fail(ctx, WFX_ERR_HIP, "upload from a file: DMA failed");
     if (failed.load()) {
         (void)hipStreamSynchronize(ctx->stream);
-        return wfx_fail(ctx, WFX_ERR_BAD_ARG, "Incomplete wav file: data chunk is shorter than its header says");
+        return wfx_fail(ctx, WFX_ERR_SHORT_FILE, "Incomplete wav file: data chunk is shorter than its header says");
     }
     WFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_input = true;

@@ -1308,6 +1308,16 @@ int wfx_comm_allgather_host(wfx_comm *comm, wfx_ctx *ctx, const void *send_host,
 int wfx_comm_destroy(wfx_comm *comm)
 {
     if (!comm) return 0;
+    {   // the events of wfx_comm_wire_timing: those still attached to records and the free list
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > comm->device && hipSetDevice(comm->device) == hipSuccess) {
+            for (auto &k : comm->clocks) clock_release(comm, k);
+            for (hipEvent_t e : comm->ev_free)
+                if (e) (void)hipEventDestroy(e);
+        }
+        comm->clocks.clear();
+        comm->ev_free.clear();
+    }
     if (comm->xstream) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > comm->device && hipSetDevice(comm->device) == hipSuccess) {

@@ -77,7 +77,10 @@ const float *wfx_coef_device(wfx_ctx *ctx, const float *host, size_t count)
         if (e.hash == h && e.bytes == bytes) return (const float *)e.dev;
     if (ctx->coef_cache.size() >= 64) {           // a long-lived context fed ever new filters: start over
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
-        for (auto &e : ctx->coef_cache) (void)hipFree(e.dev);
+        // the tables of this generation may be in a caller's hands (a launcher fetches two tables before it launches: ADVICE r5):
+        // they are retired, and what was retired one eviction ago is freed
+        for (auto &e : ctx->coef_retired) (void)hipFree(e.dev);
+        ctx->coef_retired.swap(ctx->coef_cache);
         ctx->coef_cache.clear();
     }
     void *d = nullptr;
@@ -161,6 +164,8 @@ void wfx_destroy(wfx_ctx *ctx)
     if (ctx->h_png) hipHostFree(ctx->h_png);
     for (auto *b : bufs) free_buf(*b);
     for (auto &e : ctx->coef_cache) (void)hipFree(e.dev);
+    for (auto &e : ctx->coef_retired) (void)hipFree(e.dev);
+    for (auto &e : ctx->fmm_tables) (void)hipFree((void *)e.second);
     for (auto &kv : ctx->plans) free_buf(kv.second.bhat);
     for (auto &kv : ctx->hplans) free_buf(kv.second.bhat);
     wfx_mr_release(ctx);

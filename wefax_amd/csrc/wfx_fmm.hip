@@ -39,6 +39,7 @@ struct fmm_geom {
     long long n;
     int L;                                  // leaves = 2^L, each (k n / 2^L, (k+1) n / 2^L]: <= 64 samples
     double scale;                           // 2 / n
+    double du;                              // a sample's step in a leaf's box coordinate: 2^(L+1) / n
 };
 
 // global index of box b of level lev (levels 2 ..): both parities of a box lie side by side, 2 x 16 doubles
@@ -412,6 +413,501 @@ __global__ void __launch_bounds__(FTH, 4) fmm_down_leaf(const double *__restrict
     }
 }
 
+// ---- the leaf phase on the matrix cores (round 6) ----------------------------------------------------------------------------------------
+// The near field of 16 leaves at once is ONE Toeplitz product: with sources and targets counted from the target leaf's first sample
+// (tau = 2 (16 I + i) + e, sigma = sigma0 + 2 (4 K + k)) the tap cot(pi (tau - sigma) / n) does not depend on the leaf, so
+//     D[i][leaf] += A_{I,K}[i][k] * B_K[k][leaf],   A = taps (a 16 x 4 block of the Toeplitz matrix),  B = the leaves' samples
+// is v_mfma_f64_16x16x4_f64 with the leaves on the 16 columns.  A wave takes (16 leaves, target parity e): two row blocks I (a leaf
+// has <= 32 samples of a parity) x ~21 source blocks K; what the window of three leaves does not hold for a given leaf (sizes differ
+// by one) is masked to zero in B.  Operand traffic: two ds_read_b64 per lane and 1024 multiply-adds (the VALU form: two per one).
+// The far field (L2P) is evaluated by the lane that holds the target's near sum: accumulator register r of lane (g, leaf) is row
+// g + 4 r, i.e. 8 targets of ONE leaf and parity per lane, whose 16 Chebyshev coefficients wait in registers.
+typedef double fmm_d4 __attribute__((ext_vector_type(4)));
+constexpr int FXP0 = 8, FXP1 = 24;          // unread-but-addressable doubles before / behind the sample window (masked operand reads)
+
+// lab build (tools/build_variant.sh ... -DWFX_FMM_STAMPS): cycle stamps of the leaf kernels' phases, printed by the launcher
+#ifdef WFX_FMM_STAMPS
+__device__ unsigned long long fmm_stamp_buf[2][4096 * 16];
+#define FSTAMP(kern, i)                                                                                  \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) fmm_stamp_buf[kern][blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define FSTAMP(kern, i)
+#endif
+
+constexpr int FS = 18;                      // LDS stride of a box's 16 numbers per parity (16 would put the 16 columns of an operand read into one bank pair)
+constexpr int FWALL = ((2 << FW) - 2 + FW * 2 * FHB) * 2 * FS;      // every level's weights of a leaf workgroup's subtree, halos included (doubles)
+static_assert(FWALL >= FXW + FXP0 + FXP1, "the sample window takes the place of the tree phase's weights");
+
+// weights of boxes b0 - 3 .. b0 + nb + 3 of a level with nbl boxes into LDS (padded stride), round the circle
+template <int NT>
+__device__ __forceinline__ void fmm_load_halo_p(double *wst, const double *Wlev, long long b0, int nb, long long nbl, int t)
+{
+    for (int i = t; i < (nb + 2 * FHB) * 2 * FP; i += NT) {
+        const long long sb = (b0 - FHB + (i >> 5) + nbl) & (nbl - 1);
+        wst[(i >> 4) * FS + (i & 15)] = Wlev[sb * 2 * FP + (i & 31)];
+    }
+}
+
+// the M2L matrices of one level for the boxes of parity class c as A operands: offsets (-2, +2, +3) for even boxes, (-3, -2, +2) for odd ones;
+// r = -offset selects G_|r| (r > 0) or -G_|r| transposed (r < 0).  Every matrix of the tables is stored [K index][row], so a lane's A operand
+// of K-step ks is table[64 ks + lane].
+__device__ __forceinline__ void fmm_ga_load(const double *__restrict__ Gl, int c, int lane, double (&ga)[3][4])
+{
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int off = s == 0 ? (c ? -3 : -2) : (s == 1 ? (c ? -2 : 2) : (c ? 2 : 3));
+        const int r = -off;
+        const double *gm = Gl + ((size_t)((r > 0 ? r : -r) - 2) * 2 + (r > 0 ? 0 : 1)) * FP * FP + lane;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ga[s][ks] = r > 0 ? gm[64 * ks] : -gm[64 * ks];
+    }
+}
+
+// One level of the downward pass on the matrix cores: L2L from the parents + M2L over the interaction list, for the workgroup's nb = 2^d
+// boxes of the level.  The 16 columns of a product are 16 boxes of ONE parity class c = wave & 1 (same interaction offsets, same L2L matrix):
+//   d >= 5: a task = (class, 16 boxes q, weight parity h);  d <= 4: a task = (class), columns = (q, h) -- d <= 3 leaves columns empty.
+// src: the parents' nodal values [box][h][FS]; dst: this level's; wl: the level's weights [slot = box - first + FHB][h][FS]; ga: the class's M2L
+// matrices; atr: the class's L2L matrix as A operands.  conv != nullptr: the result leaves as Chebyshev coefficients (one more product with the
+// accumulators as its B operand: register r IS K-step r).
+__device__ __forceinline__ void fmm_down_level_mfma(const double *src, double *dst, const double *wl, const double (&ga)[3][4], const double (&atr)[4], int d,
+                                                     int wave, int lane, const double *__restrict__ conv)
+{
+    const int nb = 1 << d, half = nb >> 1;
+    const int col = lane & 15, kq = lane >> 4;
+    const int c = wave & 1;
+    int q, h;
+    bool valid = true;
+    if (d >= 5) {
+        const int ng = half >> 4;                       // groups of 16 boxes per class: 1 or 2
+        if (wave >= 4 * ng) return;
+        const int rest = wave >> 1;
+        q = 16 * (rest & (ng - 1)) + col;
+        h = rest / ng;
+    } else {
+        if ((wave >> 1) != (d & 1)) return;             // (two waves; which two alternates with the level: one SIMD pair would carry all small levels otherwise)
+        const int cc = col & (nb - 1);                  // (columns beyond the level's boxes repeat earlier ones and are not stored)
+        q = cc & (half - 1);
+        h = cc >> (d - 1);
+        valid = col < nb;
+    }
+    const int b = 2 * q + c;
+    fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    {
+        const double *bp = src + (q * 2 + h) * FS + kq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[ks], bp[4 * ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int off = s == 0 ? (c ? -3 : -2) : (s == 1 ? (c ? -2 : 2) : (c ? 2 : 3));
+        const double *bp = wl + ((b + off + FHB) * 2 + (1 - h)) * FS + kq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s][ks], bp[4 * ks], acc, 0, 0, 0);
+    }
+    if (conv) {
+        fmm_d4 cf = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(conv[64 * ks + lane], acc[ks], cf, 0, 0, 0);
+        acc = cf;
+    }
+    if (valid) {
+        double *o = dst + (b * 2 + h) * FS + kq;        // accumulator register r of lane (kq, column) is row kq + 4 r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[4 * r] = acc[r];
+    }
+}
+
+// The weights of levels ltop + 1 .. ltop + D of a workgroup's subtree (its boxes and three more on either side, round the circle) into LDS
+// ([level][slot][parity][FS], level d at box offset (2^d - 2) + 6 (d - 1)), as ONE batch of independent 16-byte requests per lane: one
+// memory latency for the whole tree phase (a loop per level waits for memory once per trip).
+__device__ __forceinline__ void fmm_load_walls(double *un, const double *__restrict__ Wg, int ltop, int D, int t)
+{
+    static_assert(FW == 6 && FHB == 3 && FTD <= 6, "the slot table below");
+    constexpr int NV2MAX = ((2 << FW) - 2 + FW * 2 * FHB) * 2 * (FP / 2);      // pairs of doubles
+    constexpr int NQ = (NV2MAX + FTH - 1) / FTH;
+    const int nv2 = ((2 << D) - 2 + D * 2 * FHB) * 2 * (FP / 2);
+    double2 wv[NQ];
+    int wdst[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i2 = t + q * FTH;                     // pair j2 of vector v = (slot, parity)
+        const int v = i2 >> 3, j2 = i2 & 7, bs = v >> 1, hh = v & 1;
+        const int d = 1 + (bs >= 8) + (bs >= 18) + (bs >= 32) + (bs >= 54) + (bs >= 92);
+        const int base = d == 1 ? 0 : (d == 2 ? 8 : (d == 3 ? 18 : (d == 4 ? 32 : (d == 5 ? 54 : 92))));
+        const int lev = ltop + d;
+        const long long sb = (((long long)blockIdx.x << d) - FHB + (bs - base) + (1ll << lev)) & ((1ll << lev) - 1);
+        wdst[q] = i2 < nv2 ? v * FS + 2 * j2 : -1;
+        wv[q] = i2 < nv2 ? *(const double2 *)(Wg + (fmm_box(lev, 0) + sb) * 2 * FP + hh * FP + 2 * j2) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (wdst[q] >= 0) *(double2 *)(un + wdst[q]) = wv[q];
+}
+
+template <int OUT_ENV>
+__global__ void __launch_bounds__(FTH, 2) fmm_down_leaf2(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg,
+                                                         const double *__restrict__ Lg, double *__restrict__ out, int smax)
+{
+    extern __shared__ __align__(16) double fl[];
+    double *la = fl;                                    // [64][2][FS]
+    double *lb = la + FLV * 2 * FS;                     // [32][2][FS]
+    double *gn = lb + (FLV / 2) * 2 * FS;               // [FNEAR]
+    double *un = gn + FNEAR;                            // the tree phase: the weights of all six levels; the leaf phase: the sample window
+    double *xw = un + FXP0;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long leaf0 = (long long)blockIdx.x * FLV, nleaf = 1ll << g.L;
+    const long long km = leaf0 == 0 ? nleaf - 1 : leaf0 - 1;
+    const long long w0 = fmm_leaf_first(g, km) - (leaf0 == 0 ? g.n : 0);                       // may be negative
+    const long long kl = leaf0 + FLV == nleaf ? 0 : leaf0 + FLV;                              // the leaf behind the last one
+    const long long w1 = (leaf0 + FLV == nleaf ? g.n : 0) + fmm_leaf_first(g, kl + 1);
+    const int wlen = (int)(w1 - w0);                                                            // <= FXW
+    constexpr int XPT = (FXW + FTH - 1) / FTH;
+    double xr[XPT];
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+        const int idx = t + q * FTH;
+        long long m = w0 + idx;
+        m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
+        xr[q] = idx < wlen ? x[m] : 0.0;
+    }
+    const int ltop = g.L - FW;
+    FSTAMP(1, 0);
+    fmm_load_walls(un, Wg, ltop, FW, t);
+    for (int i = t; i < FNEAR; i += FTH) gn[i] = T.gnear[i];
+    double atr[4];                                      // the L2L matrix of the wave's box class (wave & 1) as A operands
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
+    double *src = la, *dst = lb;
+    if (t < 2 * FP) src[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(ltop, blockIdx.x) * 2 * FP + t];
+    {
+        // (the matrices of level d + 1 are requested before level d's products are issued)
+        double ga[3][4], gnx[3][4];
+        fmm_ga_load(T.G + (size_t)(ltop + 1 - 2) * 4 * FP * FP, wave & 1, lane, ga);
+        int woff = 0;
+#pragma unroll 1
+        for (int d = 1; d <= FW; ++d) {
+            if (d < FW) fmm_ga_load(T.G + (size_t)(ltop + d + 1 - 2) * 4 * FP * FP, wave & 1, lane, gnx);
+            __syncthreads();
+            FSTAMP(1, d);
+            fmm_down_level_mfma(src, dst, un + woff, ga, atr, d, wave, lane, d == FW ? T.Ca : nullptr);
+            woff += ((1 << d) + 2 * FHB) * 2 * FS;
+            double *tmp = src;
+            src = dst;
+            dst = tmp;
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ga[s2][ks] = gnx[s2][ks];
+        }
+    }
+    __syncthreads();                                    // (src == la: the 64 leaves' Chebyshev coefficients; the weights are no longer needed)
+    FSTAMP(1, 7);
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+        const int idx = t + q * FTH;
+        if (idx < FXW) xw[idx] = xr[q];
+    }
+    __syncthreads();
+    FSTAMP(1, 8);
+    // ---- the leaf phase: wave = (16 leaves G, target parity e relative to the leaf's first sample) ----------------------------------------
+    const int n16 = lane & 15, gq = lane >> 4;
+    const int SMe = (smax + 1) & ~1;
+    const int NKB = ((2 * smax + SMe) / 2 + 3) / 4;
+    const int G = wave >> 1, e = wave & 1;
+    const int lk = 16 * G + n16;
+    const long long k = leaf0 + lk;
+    const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1), am = fmm_leaf_first(g, k - 1), ap2 = fmm_leaf_first(g, k + 2);
+    const int s0 = (int)(b - a), slo = -(int)(a - am), shi = (int)(ap2 - a);      // sources of the near field: slo <= sigma < shi
+    const int sigma0 = -SMe + (1 - e);
+    const double *bp = xw + ((int)(a - w0) + sigma0 + 2 * gq);                   // B: lane (k = gq, column n16) reads sample sigma0 + 2 (4 K + gq) of ITS leaf
+    int sig = sigma0 + 2 * gq;
+    const double *ap = gn + (n16 - gq + e + (SMe + 254) / 2);                     // A: lane (row n16, k = gq) reads the tap of lag 2 (16 I + row - 4 K - k + e) + SMe - 1
+    fmm_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // (operands of block K + 1 are requested before block K's products are issued; the window's pads make the last, unused request legal)
+    double bn = bp[0], a0n = ap[0], a1n = ap[16];
+    for (int K = 0; K < NKB; ++K) {
+        const bool in = (sig >= slo) & (sig < shi);
+        const double bv = in ? bn : 0.0, a0 = a0n, a1 = a1n;
+        sig += 8;
+        bn = bp[8 * (K + 1)];
+        a0n = ap[-4 * (K + 1)];
+        a1n = ap[16 - 4 * (K + 1)];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc1, 0, 0, 0);
+    }
+    FSTAMP(1, 9);
+    // far field + output: register r of block I is target tau = 2 (16 I + gq + 4 r) + e of leaf lk.  Its place in the box: u = ua + tau du
+    // (one division per lane, not per target)
+    const int ht = (int)((a + e) & 1);
+    const double ua = 2.0 * ((double)((a << g.L) - k * g.n) / (double)g.n) - 1.0;
+    double ac[FP];
+    {
+        const double *cp = la + (lk * 2 + ht) * FS;
+#pragma unroll
+        for (int kk = 0; kk < FP; ++kk) ac[kk] = cp[kk];
+    }
+    const double *xp = xw + (int)(a - w0);
+    double *op = out + a;
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tau = 2 * (16 * I + gq + 4 * r) + e;
+            const bool valid = tau < s0;
+            const double u = valid ? fma((double)tau, g.du, ua) : 0.0;
+            double t0 = 1.0, t1 = u, far = fma(ac[1], u, ac[0]);
+            const double u2 = 2.0 * u;
+#pragma unroll
+            for (int kk = 2; kk < FP; ++kk) {
+                const double t2 = fma(u2, t1, -t0);
+                far = fma(ac[kk], t2, far);
+                t0 = t1;
+                t1 = t2;
+            }
+            const double near = I == 0 ? acc0[r] : acc1[r];
+            const double H = g.scale * (far + near);
+            if (valid) {
+                if (OUT_ENV) {
+                    const double xv = xp[tau];
+                    op[tau] = sqrt(fma(xv, xv, H * H));
+                } else {
+                    op[tau] = H;
+                }
+            }
+        }
+    }
+    FSTAMP(1, 10);
+}
+
+// ---- P2M + M2M on the matrix cores: a workgroup = 64 consecutive leaves ------------------------------------------------------------------------
+// P2M: wave = (16 leaves G, sample parity e relative to the leaf's first sample); lane (column = leaf, quarter gq) sums the Chebyshev moments
+// of its quarter of the leaf's samples of that parity (samples j = gq + 4 r: 31 multiply-adds each).  The sum over the four quarters and
+// the step from moments to nodal weights are ONE product per moment k: A[row j][K index = quarter] = Cw[k][j] for all four quarters,
+// B[quarter][leaf] = the lane's own register mu_k -- 16 products, no cross-lane traffic.  M2M: columns = (parent, parity), two matrices.
+__device__ __forceinline__ void fmm_up_level_mfma(const double *src, double *dst, double *__restrict__ gout, const double (&ajr)[2][4], int d, int wave, int lane)
+{
+    const int ncol = 2 << d;                            // (parent, parity) pairs of the level
+    if (16 * wave >= ncol) return;
+    const int col = lane & 15, kq = lane >> 4;
+    const int colg = 16 * wave + col, cc = colg & (ncol - 1);
+    const bool valid = colg < ncol;
+    const int p = cc >> 1, h = cc & 1;
+    fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const double *bp = src + ((2 * p + c) * 2 + h) * FS + kq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ajr[c][ks], bp[4 * ks], acc, 0, 0, 0);
+    }
+    if (valid) {
+        double *o = dst + cc * FS + kq, *go = gout + cc * FP + kq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[4 * r] = acc[r];
+            go[4 * r] = acc[r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(FTH, 2) fmm_up_leaf2(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg)
+{
+    extern __shared__ __align__(16) double fl[];
+    double *wb0 = fl;                                   // [64][2][FS]
+    double *wb1 = wb0 + FLV * 2 * FS;                   // [32][2][FS]
+    double *xw = wb1 + (FLV / 2) * 2 * FS;              // the workgroup's samples: <= 64 x 64
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long leaf0 = (long long)blockIdx.x * FLV;
+    const long long w0 = fmm_leaf_first(g, leaf0), w1 = fmm_leaf_first(g, leaf0 + FLV);
+    const int wlen = (int)(w1 - w0);
+    FSTAMP(0, 0);
+    constexpr int XPT = (FLV * 64) / FTH;
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+        const int idx = t + q * FTH;
+        xw[idx] = idx < wlen ? x[w0 + idx] : 0.0;
+    }
+    double ajr[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ajr[c][ks] = T.Aj[c * FP * FP + 64 * ks + lane];
+    const int n16 = lane & 15, gq = lane >> 4;
+    const int G = wave >> 1, e = wave & 1;
+    const int lk = 16 * G + n16;
+    const long long k = leaf0 + lk;
+    const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1);
+    const int s0 = (int)(b - a);
+    const int ht = (int)((a + e) & 1);
+    const double ua = 2.0 * ((double)((a << g.L) - k * g.n) / (double)g.n) - 1.0;
+    double cwa[FP];                                     // A operands: Cw[k][row], the same for the four quarters
+#pragma unroll
+    for (int kk = 0; kk < FP; ++kk) cwa[kk] = T.Cw[kk * FP + n16];
+    __syncthreads();
+    FSTAMP(0, 1);
+    double mu[FP];
+#pragma unroll
+    for (int kk = 0; kk < FP; ++kk) mu[kk] = 0.0;
+    const double *xp = xw + (int)(a - w0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int tau = 2 * (gq + 4 * r) + e;
+        const bool valid = tau < s0;
+        const double xv = valid ? xp[valid ? tau : 0] : 0.0;
+        const double u = valid ? fma((double)tau, g.du, ua) : 0.0;
+        const double u2 = 2.0 * u;
+        mu[0] += xv;
+        mu[1] = fma(u, xv, mu[1]);
+        double t0 = 1.0, t1 = u;
+#pragma unroll
+        for (int kk = 2; kk < FP; ++kk) {
+            const double t2 = fma(u2, t1, -t0);
+            mu[kk] = fma(t2, xv, mu[kk]);
+            t0 = t1;
+            t1 = t2;
+        }
+    }
+    FSTAMP(0, 2);
+    {
+        fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < FP; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cwa[kk], mu[kk], acc, 0, 0, 0);
+        double *o = wb0 + (lk * 2 + ht) * FS + gq, *go = Wg + (fmm_box(g.L, k) * 2 + ht) * FP + gq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[4 * r] = acc[r];
+            go[4 * r] = acc[r];
+        }
+    }
+    double *src = wb0, *dst = wb1;
+#pragma unroll 1
+    for (int d = FW - 1; d >= 0; --d) {
+        __syncthreads();
+        FSTAMP(0, 3 + (FW - 1 - d));
+        fmm_up_level_mfma(src, dst, Wg + fmm_box(g.L - FW + d, (long long)blockIdx.x << d) * 2 * FP, ajr, d, wave, lane);
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+}
+
+// ---- the tiers and the top of the tree on the matrix cores (512 threads; the same level routines as the leaf kernels) --------------------
+__global__ void __launch_bounds__(FTH) fmm_up_tier2(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, int a, int D)
+{
+    __shared__ __align__(16) double b0[(1 << FTD) * 2 * FS], b1[(1 << (FTD - 1)) * 2 * FS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double ajr[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ajr[c][ks] = T.Aj[c * FP * FP + 64 * ks + lane];
+    const double *ch = Wg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
+    constexpr int NQ = ((1 << FTD) * 2 * FP / 2) / FTH;        // pairs per thread: 2
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i2 = t + q * FTH;
+        if (i2 < ((2 * FP / 2) << D)) *(double2 *)(b0 + (i2 >> 3) * FS + 2 * (i2 & 7)) = *(const double2 *)(ch + 2 * i2);
+    }
+    double *src = b0, *dst = b1;
+#pragma unroll 1
+    for (int d = D - 1; d >= 0; --d) {
+        __syncthreads();
+        fmm_up_level_mfma(src, dst, Wg + fmm_box(a + d, (long long)blockIdx.x << d) * 2 * FP, ajr, d, wave, lane);
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+}
+
+__global__ void __launch_bounds__(FTH) fmm_down_tier2(const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg, double *__restrict__ Lg, int a, int D)
+{
+    __shared__ __align__(16) double la[(1 << FTD) * 2 * FS], lb[(1 << (FTD - 1)) * 2 * FS], un[FWALL];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    fmm_load_walls(un, Wg, a, D, t);
+    double atr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
+    double *src = la, *dst = lb;
+    if (t < 2 * FP) src[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(a, blockIdx.x) * 2 * FP + t];
+    double ga[3][4], gnx[3][4];
+    fmm_ga_load(T.G + (size_t)(a + 1 - 2) * 4 * FP * FP, wave & 1, lane, ga);
+    int woff = 0;
+#pragma unroll 1
+    for (int d = 1; d <= D; ++d) {
+        if (d < D) fmm_ga_load(T.G + (size_t)(a + d + 1 - 2) * 4 * FP * FP, wave & 1, lane, gnx);
+        __syncthreads();
+        fmm_down_level_mfma(src, dst, un + woff, ga, atr, d, wave, lane, nullptr);
+        woff += ((1 << d) + 2 * FHB) * 2 * FS;
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ga[s2][ks] = gnx[s2][ks];
+    }
+    __syncthreads();
+    double *o = Lg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
+    for (int i2 = t; i2 < ((2 * FP / 2) << D); i2 += FTH) *(double2 *)(o + 2 * i2) = *(const double2 *)(src + (i2 >> 3) * FS + 2 * (i2 & 7));
+}
+
+// the top: levels 2 .. atop (<= 5), one workgroup.  M2M up to level 2 with every level's weights kept in LDS (halo slots filled round the
+// circle), level 2 by the scalar routine (its interaction list is the one box opposite), levels 3 .. atop on the matrix cores.
+__global__ void __launch_bounds__(FTH) fmm_top2(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, double *__restrict__ Lg, int atop)
+{
+    constexpr int WLV = (32 + 2 * FHB) * 2 * FS;        // one level's weights, halo slots included
+    __shared__ __align__(16) double wl[4][WLV];         // levels 2 .. 5
+    __shared__ __align__(16) double la[32 * 2 * FS], lb[32 * 2 * FS];
+    __shared__ double w2[(4 + 2 * FHB) * 2 * FP], l2[4 * 2 * FP], Ats[2 * FP * FP], Gs[4 * FP * FP];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double ajr[2][4], atr[4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ajr[c][ks] = T.Aj[c * FP * FP + 64 * ks + lane];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
+    for (int i = t; i < 2 * FP * FP; i += FTH) Ats[i] = T.At[i];
+    for (int i = t; i < 4 * FP * FP; i += FTH) Gs[i] = T.G[i];                     // level 2
+    const int ntop = 1 << atop;
+    for (int i = t; i < ntop * 2 * FP; i += FTH) wl[atop - 2][(FHB * 2 + (i >> 4)) * FS + (i & 15)] = Wg[fmm_box(atop, 0) * 2 * FP + i];
+    for (int lev = atop - 1; lev >= 2; --lev) {
+        __syncthreads();
+        fmm_up_level_mfma(&wl[lev + 1 - 2][FHB * 2 * FS], &wl[lev - 2][FHB * 2 * FS], Wg + fmm_box(lev, 0) * 2 * FP, ajr, lev, wave, lane);
+    }
+    __syncthreads();
+    // halo slots of every level (three boxes before the first and behind the last, round the circle); level 2 also in the scalar routine's layout
+    for (int lev = 2; lev <= atop; ++lev) {
+        const int nb = 1 << lev;
+        double *w = wl[lev - 2];
+        for (int i = t; i < 2 * FHB * 2 * FP; i += FTH) {
+            const int v = i >> 4, side = v / (FHB * 2), vv = v % (FHB * 2);                // side 0: slots 0..2, side 1: slots nb+3 .. nb+5
+            const int slot = side ? nb + FHB + (vv >> 1) : (vv >> 1);
+            const int sb = (slot - FHB + 4 * nb) & (nb - 1);
+            w[(slot * 2 + (vv & 1)) * FS + (i & 15)] = w[((sb + FHB) * 2 + (vv & 1)) * FS + (i & 15)];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < (4 + 2 * FHB) * 2 * FP; i += FTH) w2[i] = wl[0][(i >> 4) * FS + (i & 15)];
+    __syncthreads();
+    fmm_down_level<FTH>(nullptr, l2, w2, Gs, Ats, 0, 4, 4, t);
+    __syncthreads();
+    for (int i = t; i < 4 * 2 * FP; i += FTH) la[(i >> 4) * FS + (i & 15)] = l2[i];
+    double *src = la, *dst = lb;
+    double ga[3][4];
+    for (int lev = 3; lev <= atop; ++lev) {
+        fmm_ga_load(T.G + (size_t)(lev - 2) * 4 * FP * FP, wave & 1, lane, ga);
+        __syncthreads();
+        fmm_down_level_mfma(src, dst, wl[lev - 2], ga, atr, lev, wave, lane, nullptr);
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    __syncthreads();
+    for (int i = t; i < ntop * 2 * FP; i += FTH) Lg[fmm_box(atop, 0) * 2 * FP + i] = src[(i >> 4) * FS + (i & 15)];
+}
+
 // ---- host: tables -------------------------------------------------------------------------------------------------------------------
 struct fmm_static {
     std::vector<double> At, Aj, Cw, Ca;
@@ -520,6 +1016,7 @@ int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, 
     g.n = (long long)n;
     g.L = L;
     g.scale = 2.0 / (double)n;
+    g.du = ldexp(2.0, L) / (double)n;
     const size_t nbox = (size_t)1 << (L + 1);                             // all levels
     WFX_TRY(wfx_reserve(ctx, ctx->b_work, nbox * 2 * FP * 8));           // weights W
     WFX_TRY(wfx_reserve(ctx, ctx->b_work2, ((size_t)1 << (L - FW + 1)) * 2 * FP * 8 + 64));    // local expansions down to the leaf workgroups' roots
@@ -527,12 +1024,18 @@ int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, 
     const unsigned nwg = 1u << (L - FW);
     const size_t lds_up = (size_t)(8 * 8 * FROW + 8 * 64 + 8 * 32 + FLV * 2 * FP + (FLV / 2) * 2 * FP + 2 * FP * FP) * 8;
     const size_t lds_dn = (size_t)(FLV * 2 * FP + (FLV / 2) * 2 * FP + 2 * FP * FP + FNEAR + FXW) * 8;
+    const size_t lds_dn2 = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FNEAR + FWALL) * 8;
+    const size_t lds_up2 = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FLV * 64) * 8;
+    const int smax = (int)((n + ((1ull << L) - 1)) >> L);                  // the largest leaf
     static_assert(FXW >= (FLV + 2 * FHB) * 2 * FP + 4 * FP * FP, "the sample window is also the tree phase's staging area");
     static bool attr_done = false;
     if (!attr_done) {
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up2));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn2));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn2));
         attr_done = true;
     }
     // tiers between the leaf workgroups' roots (level L - 6) and the top (levels 2 .. atop <= 5): at most six levels each
@@ -545,21 +1048,59 @@ int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, 
         cur -= D;
     }
     const int atop = cur;
+    static const int leaf_v = getenv("WFX_FMM_LEAF") ? atoi(getenv("WFX_FMM_LEAF")) : 2;
     wfx_prof_begin(ctx, K_FFT_FWD);
-    hipLaunchKernelGGL(fmm_up_leaf, dim3(nwg), dim3(FTH), lds_up, ctx->stream, x, g, T, Wg);
+    if (leaf_v == 2)
+        hipLaunchKernelGGL(fmm_up_leaf2, dim3(nwg), dim3(FTH), lds_up2, ctx->stream, x, g, T, Wg);
+    else
+        hipLaunchKernelGGL(fmm_up_leaf, dim3(nwg), dim3(FTH), lds_up, ctx->stream, x, g, T, Wg);
     wfx_prof_end(ctx);
     wfx_prof_begin(ctx, K_BS_CHIRP);
-    for (int k = 0; k < ntier; ++k) hipLaunchKernelGGL(fmm_up_tier, dim3(1u << tier_a[k]), dim3(256), 0, ctx->stream, g, T, Wg, tier_a[k], tier_d[k]);
-    hipLaunchKernelGGL(fmm_top, dim3(1), dim3(256), 0, ctx->stream, g, T, Wg, Lg, atop);
-    for (int k = ntier - 1; k >= 0; --k)
-        hipLaunchKernelGGL(fmm_down_tier, dim3(1u << tier_a[k]), dim3(256), 0, ctx->stream, g, T, (const double *)Wg, Lg, tier_a[k], tier_d[k]);
+    if (leaf_v == 2) {
+        for (int k = 0; k < ntier; ++k) hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << tier_a[k]), dim3(FTH), 0, ctx->stream, g, T, Wg, tier_a[k], tier_d[k]);
+        hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, g, T, Wg, Lg, atop);
+        for (int k = ntier - 1; k >= 0; --k)
+            hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << tier_a[k]), dim3(FTH), 0, ctx->stream, g, T, (const double *)Wg, Lg, tier_a[k], tier_d[k]);
+    } else {
+        for (int k = 0; k < ntier; ++k) hipLaunchKernelGGL(fmm_up_tier, dim3(1u << tier_a[k]), dim3(256), 0, ctx->stream, g, T, Wg, tier_a[k], tier_d[k]);
+        hipLaunchKernelGGL(fmm_top, dim3(1), dim3(256), 0, ctx->stream, g, T, Wg, Lg, atop);
+        for (int k = ntier - 1; k >= 0; --k)
+            hipLaunchKernelGGL(fmm_down_tier, dim3(1u << tier_a[k]), dim3(256), 0, ctx->stream, g, T, (const double *)Wg, Lg, tier_a[k], tier_d[k]);
+    }
     wfx_prof_end(ctx);
     wfx_prof_begin(ctx, K_FFT_INV);
-    if (out_env)
+    if (leaf_v == 2) {
+        if (out_env)
+            hipLaunchKernelGGL(fmm_down_leaf2<1>, dim3(nwg), dim3(FTH), lds_dn2, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out, smax);
+        else
+            hipLaunchKernelGGL(fmm_down_leaf2<0>, dim3(nwg), dim3(FTH), lds_dn2, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out, smax);
+    } else if (out_env)
         hipLaunchKernelGGL(fmm_down_leaf<1>, dim3(nwg), dim3(FTH), lds_dn, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out);
     else
         hipLaunchKernelGGL(fmm_down_leaf<0>, dim3(nwg), dim3(FTH), lds_dn, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out);
     wfx_prof_end(ctx);
+#ifdef WFX_FMM_STAMPS
+    {
+        static std::vector<unsigned long long> hb(2 * 4096 * 16);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpyFromSymbol(hb.data(), HIP_SYMBOL(fmm_stamp_buf), hb.size() * 8);
+        for (int kern = 0; kern < 2; ++kern) {
+            const unsigned nb = std::min(nwg, 4096u);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            double sum[16] = {0};
+            const int ns = kern ? 11 : 9;
+            for (unsigned b2 = 0; b2 < nb; ++b2) {
+                const unsigned long long *p = &hb[(size_t)kern * 4096 * 16 + (size_t)b2 * 16];
+                t0 = std::min(t0, p[0]);
+                t1 = std::max(t1, p[ns - 1]);
+                for (int i = 1; i < ns; ++i) sum[i] += (double)(p[i] - p[i - 1]);
+            }
+            fprintf(stderr, "fmm stamps kernel %d (%u workgroups, 100 MHz ticks -> us): span %.1f us; mean phase us:", kern, nb, (double)(t1 - t0) / 100.0);
+            for (int i = 1; i < ns; ++i) fprintf(stderr, " %.2f", sum[i] / nb / 100.0);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
     *handled = 1;

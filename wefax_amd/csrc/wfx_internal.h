@@ -102,6 +102,7 @@ struct wfx_ctx {
         void *dev;
     };
     std::vector<coef_entry> coef_cache;
+    std::vector<coef_entry> coef_retired;                            // the generation before: freed at the NEXT eviction, so a table a caller just fetched outlives 64 further misses
     std::vector<std::pair<uint64_t, const double *>> fmm_tables;      // per capture length: tables of the fast-multipole Hilbert transform (wfx_fmm.hip)
 
     // decode state

@@ -454,8 +454,9 @@ class FrontEndExactDecoder:
     filtfilt, FFT resample by 2, FFT Hilbert, global percentiles, sync search, bicubic image.  Differs from the reference
     only by the front end's pass band (polyphase.py)."""
 
-    def __init__(self, ctx, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None):
-        from .wefax import DecodeJob
+    def __init__(self, ctx, frontend, x, n_in_total=None, in_kind=None, lines_per_minute: int = 120, raw_loader=None, notch=None,
+                 hilbert_mode=None):
+        from .wefax import DecodeJob, DEFAULT_HILBERT_MODE
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
         n_fe = frontend.n_out(n_in_total)                   # at 11 025 Hz, or at the hand-over rate (FrontEnd(stop_rate=...))
         rate = frontend.out_rate
@@ -466,7 +467,8 @@ class FrontEndExactDecoder:
         if in_kind is None:
             in_kind = 1 if (not isinstance(raw, tuple) and raw.ndim == 2) else 0
         self.fe = FrontEndDevice(ctx, self.chain, raw, in_kind)
-        self.job = DecodeJob.from_device(ctx, self.fe.p_out, n_fe, lines_per_minute, notch=hp.load_notch_settings(), sample_rate=rate,
+        self.job = DecodeJob.from_device(ctx, self.fe.p_out, n_fe, lines_per_minute, notch=notch if notch is not None else hp.load_notch_settings(),
+                                         hilbert_mode=DEFAULT_HILBERT_MODE if hilbert_mode is None else hilbert_mode, sample_rate=rate,
                                          n_out=self.n if frontend.exact_tail else None)
         assert self.job.n == self.n
         self.width = self.job.width

@@ -271,6 +271,9 @@ class DecodeJob:
         raise KeyError(which)
 
 
+_PNG_FALLBACK_SAID = False
+
+
 class Demodulator:
     def __init__(self, filepath: str,
                  lines_per_minute: int = 120,
@@ -367,7 +370,7 @@ class Demodulator:
         if self._fe_dec is not None:
             self._fe_dec.close()
             self._fe_dec = None
-        job = self._time_domain_job(data, sample_rate) if (self.front_end == "time-domain" and sample_rate != hp.TARGET_RATE) else None
+        job = self._time_domain_job(data, sample_rate, notch) if (self.front_end == "time-domain" and sample_rate != hp.TARGET_RATE) else None
         self.front_end_used = "time-domain" if job is not None else "exact"
         if job is None:
             if layout is not None:
@@ -422,7 +425,7 @@ class Demodulator:
             self._send_websocket_packet({"data_type": "message",
                                          "message_content": "convert_end"})
 
-    def _time_domain_job(self, data, sample_rate):
+    def _time_domain_job(self, data, sample_rate, notch):
         """The opt-in route of ``front_end="time-domain"``: decimator chain on the device, then the fused exact decode attached to its
         output (sharded.FrontEndExactDecoder).  None when the capture is not one this route keeps the reference's grid for."""
         from . import polyphase, sharded
@@ -435,7 +438,7 @@ class Demodulator:
             return None
         if fe.n_target(int(data.shape[0])) < 2:
             return None
-        dec = sharded.FrontEndExactDecoder(self._ctx, fe, data, lines_per_minute=self.lines_per_minute)
+        dec = sharded.FrontEndExactDecoder(self._ctx, fe, data, lines_per_minute=self.lines_per_minute, notch=notch, hilbert_mode=self._hilbert_mode)
         self._fe_dec = dec
         dec.run()
         return dec.job
@@ -503,8 +506,14 @@ class Demodulator:
                 try:
                     self._ctx.decode_save_png(filepath, deflate=os.environ.get("WEFAX_PNG_STORED") != "1")
                     return
-                except nat.NativeError:
-                    pass                    # the context has moved on to another decode: encode the host copy instead
+                except nat.NativeError as exc:
+                    # the context has moved on to another decode (or the device encoder failed): the host copy is encoded instead --
+                    # said once per process, so that a broken device encoder does not hide behind a 10x slower save
+                    global _PNG_FALLBACK_SAID
+                    if not _PNG_FALLBACK_SAID:
+                        _PNG_FALLBACK_SAID = True
+                        import warnings
+                        warnings.warn(f"wefax_amd: device PNG encoder not used ({exc}); falling back to the host encoder", RuntimeWarning, stacklevel=2)
             from .pngio import write_png_gray8
             write_png_gray8(filepath, self.output_array, level=compress or 1)
             return
