@@ -313,8 +313,8 @@ int wfx_d_decimate_fir64_batch(wfx_ctx *ctx, const void *in_dev, int in_kind, si
 int wfx_d_ingest_chain(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_in, int factor, const double *coef1, int ntaps1, int fix_shift,
                        int factor2, const double *coef2, int ntaps2, double *out_dev, size_t n_out, int nbatch, size_t in_stride, size_t out_stride,
                        int *handled);
-/* a7 on device memory without a transform over the whole capture: out = |x + i H| (out_env != 0) or H = imag(scipy.signal.hilbert(x)),
- * by the fast multipole form of WFX_HILBERT_FMM; *handled = 0 and nothing enqueued for lengths it does not take */
+/* a7 on device memory without a transform over the whole capture: out = H = imag(scipy.signal.hilbert(x)) (out_env 0), |x + i H| (1) or
+ * the 5-tap median of that envelope, zeros beyond both ends (2: wefax.py:174-175 complete), by the fast multipole form of WFX_HILBERT_FMM; *handled = 0 and nothing enqueued for lengths it does not take */
 int wfx_d_hilbert_fmm(wfx_ctx *ctx, const double *x_dev, size_t n, double *out_dev, int out_env, int *handled);
 /* measurement aid: GB/s at which this GPU reads `bytes` (>= 1 MiB, 16-byte aligned) of device memory with a kernel that only loads
  * (16-byte loads, 16 in flight per lane, 64 KiB blocks), best of `reps` launches by HIP events; waits for the stream.  bench.py puts

@@ -5,24 +5,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from wefax_amd import _native as nat
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 7166250
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2      # 0: H, 1: envelope, 2: envelope + median
 ctx = nat.Context(0)
 rng = np.random.default_rng(3)
 x = rng.standard_normal(n) * 1000 + 3000 * np.sin(np.arange(n) * 0.7)
 px, po = ctx.dev_malloc(n * 8 + 64), ctx.dev_malloc(n * 8 + 64)
 ctx.dev_upload(px, x)
 for _ in range(3):
-    ctx.d_hilbert_fmm(px, n, po, True)
+    ctx.d_hilbert_fmm(px, n, po, mode)
 ctx.sync()
 ts = []
 for _ in range(10):
     t0 = time.perf_counter()
     for _ in range(10):
-        ctx.d_hilbert_fmm(px, n, po, True)
+        ctx.d_hilbert_fmm(px, n, po, mode)
     ctx.sync()
     ts.append((time.perf_counter() - t0) / 10)
 ctx.profile_reset(); ctx.profile_enable(True)
 for _ in range(10):
-    ctx.d_hilbert_fmm(px, n, po, True)
+    ctx.d_hilbert_fmm(px, n, po, mode)
 ctx.sync(); ctx.profile_enable(False)
 pr = {k: round(1e3 * v[1] / v[0], 1) for k, v in ctx.profile().items()}
-print(f"n {n}: {1e3 * min(ts):.3f} ms per transform (10 back to back); kernel groups (us): up {pr.get('fft_pass_fwd')} mid {pr.get('bluestein_pointwise')} down {pr.get('fft_pass_inv')}", flush=True)
+print(f"n {n}: {1e3 * min(ts):.3f} ms per transform (10 back to back); kernel groups (us): up {pr.get('fft_pass_fwd')} mid {pr.get('bluestein_pointwise')} tree {pr.get('fft_pass_inv')} leaf {pr.get('env_median')}  all {pr}", flush=True)

@@ -640,11 +640,11 @@ class Context:
                                                 int(nbatch), int(in_stride), int(out_stride), C.byref(handled)))
         return bool(handled.value)
 
-    def d_hilbert_fmm(self, x_ptr: int, n: int, out_ptr: int, out_env: bool = False) -> bool:
-        """H = imag(scipy.signal.hilbert(x)) (or |x + i H|) by near field + fast multipole far field (csrc/wfx_fmm.hip); False: a length
-        that form does not take, nothing was enqueued."""
+    def d_hilbert_fmm(self, x_ptr: int, n: int, out_ptr: int, out_env=False) -> bool:
+        """H = imag(scipy.signal.hilbert(x)) (``out_env`` True / 1: |x + i H|; 2: its 5-tap median, wefax.py:174-175) by near field + fast
+        multipole far field (csrc/wfx_fmm.hip); False: a length that form does not take, nothing was enqueued."""
         handled = C.c_int(0)
-        self._check(self.lib.wfx_d_hilbert_fmm(self.h, C.c_void_p(x_ptr), int(n), C.c_void_p(out_ptr), 1 if out_env else 0, C.byref(handled)))
+        self._check(self.lib.wfx_d_hilbert_fmm(self.h, C.c_void_p(x_ptr), int(n), C.c_void_p(out_ptr), int(out_env), C.byref(handled)))
         return bool(handled.value)
 
     def d_read_rate(self, ptr: int, nbytes: int, reps: int = 3) -> float:

@@ -23,7 +23,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libwefax_hip.so")
 SOURCES = ["wfx_context.hip", "wfx_fft.hip", "wfx_mrfft.hip", "wfx_stages.hip", "wfx_polyphase.hip", "wfx_ingest.hip", "wfx_fmm.hip", "wfx_api.hip",
            "wfx_comm.hip", "wfx_dist.hip", "wfx_shard.hip", "wfx_synth.hip", "wfx_png.hip"]
-HEADERS = [os.path.join(CSRC, "wfx_internal.h"), os.path.join(CSRC, "wfx_dist.h"), os.path.join(REPO, "include", "wefax_hip.h")]
+HEADERS = [os.path.join(CSRC, "wfx_internal.h"), os.path.join(CSRC, "wfx_dist.h"), os.path.join(CSRC, "wfx_notch.h"), os.path.join(REPO, "include", "wefax_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(REPO, "include"), "-I", CSRC]
 

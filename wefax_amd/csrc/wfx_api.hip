@@ -126,12 +126,14 @@ static int analytic_env_dev(wfx_ctx *ctx, const double *x, uint64_t n, int mode,
     }
     else if (mode == WFX_HILBERT_FMM) {
         // near field + fast multipole far field (wfx_fmm.hip); lengths it does not take (odd, short) run the transform path
+        // (envelope, 5-tap median and the select's level-0 histogram are fused into its leaf kernel)
         int handled = 0;
-        WFX_TRY(wfx_dev_hilbert_fmm(ctx, x, n, env_raw, 1, &handled));
+        WFX_TRY(wfx_dev_hilbert_fmm(ctx, x, n, env, 2, l0hist, &handled));
         if (!handled) {
             ctx->force_pow2 = false;
             return wfx_dev_hilbert_envmed_fft(ctx, x, n, env, l0hist);
         }
+        return 0;
     }
     else if (mode == WFX_HILBERT_BLUESTEIN)
         WFX_TRY(wfx_dev_hilbert_env_bluestein(ctx, x, n, env_raw));
@@ -480,11 +482,19 @@ int wfx_decode_run(wfx_ctx *ctx)
         ext18[i] = p.ext_left[i];
         ext18[9 + i] = p.ext_right[i];
     }
-    WFX_TRY(wfx_dev_notch(ctx, cur, cur_kind, n, p.notch_b, p.notch_a, (double *)ctx->b_audio.p, ds, &cleared, use_ext ? ext18 : nullptr));
-    if (!cleared) WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
     unsigned *sel_ws = nullptr;
     WFX_TRY(wfx_dev_select_workspace(ctx, n, &sel_ws));           // level-0 histogram is fused into the envelope kernel
-    WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, p.hilbert_mode, (double *)ctx->b_envraw.p, (double *)ctx->b_env.p, sel_ws));
+    int fused = 0;
+    if (p.hilbert_mode == WFX_HILBERT_FMM)
+        // a6 + a7 as one chain: the notch runs inside the multipole form's first kernel (which also zeroes the scalars), the median and the
+        // histogram inside its last
+        WFX_TRY(wfx_dev_notch_hilbert_fmm(ctx, cur, cur_kind, n, p.notch_b, p.notch_a, use_ext ? ext18 : nullptr, (double *)ctx->b_audio.p, (double *)ctx->b_env.p,
+                                          sel_ws, ds, &fused));
+    if (!fused) {
+        WFX_TRY(wfx_dev_notch(ctx, cur, cur_kind, n, p.notch_b, p.notch_a, (double *)ctx->b_audio.p, ds, &cleared, use_ext ? ext18 : nullptr));
+        if (!cleared) WFX_HIP(ctx, hipMemsetAsync(ds, 0, sizeof(wfx_dev_scalars), ctx->stream));
+        WFX_TRY(analytic_env_dev(ctx, (const double *)ctx->b_audio.p, n, p.hilbert_mode, (double *)ctx->b_envraw.p, (double *)ctx->b_env.p, sel_ws));
+    }
     const uint64_t ranks[4] = {p.rank_lo[0], p.rank_lo[1], p.rank_hi[0], p.rank_hi[1]};
     WFX_TRY(wfx_dev_percentiles_fused(ctx, (const double *)ctx->b_env.p, n, ranks, p.gamma_lo, p.gamma_hi, ds));
     WFX_TRY(wfx_dev_quantise_corr(ctx, (const double *)ctx->b_env.p, n, ds, (uint8_t *)ctx->b_dig.p, p.n1, p.n0_gap));   // a8 + correlation of a9
@@ -662,7 +672,7 @@ int wfx_d_hilbert_fmm(wfx_ctx *ctx, const double *x_dev, size_t n, double *out_d
 {
     CHECK_CTX(ctx);
     if (!x_dev || !out_dev || !handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
-    return wfx_dev_hilbert_fmm(ctx, x_dev, n, out_dev, out_env, handled);
+    return wfx_dev_hilbert_fmm(ctx, x_dev, n, out_dev, out_env, nullptr, handled);
 }
 
 int wfx_d_read_rate(wfx_ctx *ctx, const void *dev, size_t bytes, int reps, double *gbs)

@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "wfx_internal.h"
+#include "wfx_notch.h"
 
 namespace {
 
@@ -423,11 +424,12 @@ __global__ void __launch_bounds__(FTH, 4) fmm_down_leaf(const double *__restrict
 // The far field (L2P) is evaluated by the lane that holds the target's near sum: accumulator register r of lane (g, leaf) is row
 // g + 4 r, i.e. 8 targets of ONE leaf and parity per lane, whose 16 Chebyshev coefficients wait in registers.
 typedef double fmm_d4 __attribute__((ext_vector_type(4)));
+constexpr int UP3W = 4;                     // fmm_up_leaf3 on an int16 capture: waves per SIMD the register budget is set for
 constexpr int FXP0 = 8, FXP1 = 24;          // unread-but-addressable doubles before / behind the sample window (masked operand reads)
 
 // lab build (tools/build_variant.sh ... -DWFX_FMM_STAMPS): cycle stamps of the leaf kernels' phases, printed by the launcher
 #ifdef WFX_FMM_STAMPS
-__device__ unsigned long long fmm_stamp_buf[2][4096 * 16];
+__device__ unsigned long long fmm_stamp_buf[3][4096 * 16];
 #define FSTAMP(kern, i)                                                                                  \
     do {                                                                                                 \
         if (threadIdx.x == 0 && blockIdx.x < 4096) fmm_stamp_buf[kern][blockIdx.x * 16 + (i)] = wall_clock64(); \
@@ -546,16 +548,66 @@ __device__ __forceinline__ void fmm_load_walls(double *un, const double *__restr
         if (wdst[q] >= 0) *(double2 *)(un + wdst[q]) = wv[q];
 }
 
-template <int OUT_ENV>
-__global__ void __launch_bounds__(FTH, 2) fmm_down_leaf2(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg,
-                                                         const double *__restrict__ Lg, double *__restrict__ out, int smax)
+// ---- downward pass inside a leaf subtree: six levels of L2L + M2L, out come the leaves' far fields as Chebyshev coefficients ----------------
+__global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf(const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg, const double *__restrict__ Lg,
+                                                        double *__restrict__ Cg)
 {
     extern __shared__ __align__(16) double fl[];
     double *la = fl;                                    // [64][2][FS]
     double *lb = la + FLV * 2 * FS;                     // [32][2][FS]
-    double *gn = lb + (FLV / 2) * 2 * FS;               // [FNEAR]
-    double *un = gn + FNEAR;                            // the tree phase: the weights of all six levels; the leaf phase: the sample window
-    double *xw = un + FXP0;
+    double *un = lb + (FLV / 2) * 2 * FS;               // the weights of all six levels
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ltop = g.L - FW;
+    FSTAMP(1, 0);
+    fmm_load_walls(un, Wg, ltop, FW, t);
+    double atr[4];                                      // the L2L matrix of the wave's box class (wave & 1) as A operands
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
+    double *src = la, *dst = lb;
+    if (t < 2 * FP) src[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(ltop, blockIdx.x) * 2 * FP + t];
+    {
+        // the matrices of level d + 2 are requested before level d's products are issued (three register sets in rotation: requested one
+        // level ahead they arrive after the level's sixteen products and every level waits for memory)
+        double gs[3][3][4];
+        fmm_ga_load(T.G + (size_t)(ltop + 1 - 2) * 4 * FP * FP, wave & 1, lane, gs[1]);
+        fmm_ga_load(T.G + (size_t)(ltop + 2 - 2) * 4 * FP * FP, wave & 1, lane, gs[2]);
+        int woff = 0;
+#pragma unroll
+        for (int d = 1; d <= FW; ++d) {
+            if (d + 2 <= FW) fmm_ga_load(T.G + (size_t)(ltop + d + 2 - 2) * 4 * FP * FP, wave & 1, lane, gs[(d + 2) % 3]);
+            __syncthreads();
+            FSTAMP(1, d);
+            fmm_down_level_mfma(src, dst, un + woff, gs[d % 3], atr, d, wave, lane, d == FW ? T.Ca : nullptr);
+            woff += ((1 << d) + 2 * FHB) * 2 * FS;
+            double *tmp = src;
+            src = dst;
+            dst = tmp;
+        }
+    }
+    __syncthreads();                                    // (src == la: the 64 leaves' Chebyshev coefficients)
+    FSTAMP(1, 7);
+    double *o = Cg + (size_t)blockIdx.x * FLV * 2 * FP;
+#pragma unroll
+    for (int q = 0; q < (FLV * 2 * FP / 2) / FTH; ++q) {
+        const int i2 = t + q * FTH;
+        *(double2 *)(o + 2 * i2) = *(const double2 *)(src + (i2 >> 3) * FS + 2 * (i2 & 7));
+    }
+    FSTAMP(1, 8);
+}
+
+// ---- the leaves: near field + far field -> H -> |x + iH| -> 5-tap median + level-0 histogram (OUT 0: H, 1: the envelope, 2: median + histogram) ----
+// OUT 2: the envelope takes the samples' place in LDS once every near field has read them; medians of positions that need a neighbour
+// workgroup's envelope (its first and last two) are left to fmm_edge_median, which finds the four envelope values at either end of every
+// workgroup in `edge`.  scipy.signal.medfilt pads with ZEROS at the capture's ends: those four medians are complete here.
+template <int OUT>
+__global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Cg,
+                                                       double *__restrict__ out, int smax, int xcap, double *__restrict__ edge, unsigned *__restrict__ l0hist)
+{
+    extern __shared__ __align__(16) double fl[];
+    double *ca = fl;                                    // [64][2][FS]: Chebyshev coefficients of the leaves' far fields
+    double *gn = ca + FLV * 2 * FS;                     // [FNEAR]
+    double *xw = gn + FNEAR + FXP0;                     // the sample window: the workgroup's leaves and one more on either side (xcap = 66 smax doubles + pads)
+    unsigned *h0 = (unsigned *)ca;                      // [WFX_SEL_BINS] (OUT 2): in the coefficients' place once the far fields are evaluated
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const long long leaf0 = (long long)blockIdx.x * FLV, nleaf = 1ll << g.L;
     const long long km = leaf0 == 0 ? nleaf - 1 : leaf0 - 1;
@@ -563,55 +615,36 @@ __global__ void __launch_bounds__(FTH, 2) fmm_down_leaf2(const double *__restric
     const long long kl = leaf0 + FLV == nleaf ? 0 : leaf0 + FLV;                              // the leaf behind the last one
     const long long w1 = (leaf0 + FLV == nleaf ? g.n : 0) + fmm_leaf_first(g, kl + 1);
     const int wlen = (int)(w1 - w0);                                                            // <= FXW
+    FSTAMP(2, 0);
     constexpr int XPT = (FXW + FTH - 1) / FTH;
-    double xr[XPT];
-#pragma unroll
-    for (int q = 0; q < XPT; ++q) {
-        const int idx = t + q * FTH;
-        long long m = w0 + idx;
-        m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
-        xr[q] = idx < wlen ? x[m] : 0.0;
-    }
-    const int ltop = g.L - FW;
-    FSTAMP(1, 0);
-    fmm_load_walls(un, Wg, ltop, FW, t);
-    for (int i = t; i < FNEAR; i += FTH) gn[i] = T.gnear[i];
-    double atr[4];                                      // the L2L matrix of the wave's box class (wave & 1) as A operands
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
-    double *src = la, *dst = lb;
-    if (t < 2 * FP) src[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(ltop, blockIdx.x) * 2 * FP + t];
     {
-        // (the matrices of level d + 1 are requested before level d's products are issued)
-        double ga[3][4], gnx[3][4];
-        fmm_ga_load(T.G + (size_t)(ltop + 1 - 2) * 4 * FP * FP, wave & 1, lane, ga);
-        int woff = 0;
-#pragma unroll 1
-        for (int d = 1; d <= FW; ++d) {
-            if (d < FW) fmm_ga_load(T.G + (size_t)(ltop + d + 1 - 2) * 4 * FP * FP, wave & 1, lane, gnx);
-            __syncthreads();
-            FSTAMP(1, d);
-            fmm_down_level_mfma(src, dst, un + woff, ga, atr, d, wave, lane, d == FW ? T.Ca : nullptr);
-            woff += ((1 << d) + 2 * FHB) * 2 * FS;
-            double *tmp = src;
-            src = dst;
-            dst = tmp;
+        double xr[XPT];
 #pragma unroll
-            for (int s2 = 0; s2 < 3; ++s2)
+        for (int q = 0; q < XPT; ++q) {
+            const int idx = t + q * FTH;
+            long long m = w0 + idx;
+            m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
+            xr[q] = idx < wlen ? x[m] : 0.0;
+        }
+        double2 cr[(FLV * 2 * FP / 2) / FTH];
+        const double *cg = Cg + (size_t)blockIdx.x * FLV * 2 * FP;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) ga[s2][ks] = gnx[s2][ks];
+        for (int q = 0; q < (FLV * 2 * FP / 2) / FTH; ++q) cr[q] = *(const double2 *)(cg + 2 * (t + q * FTH));
+        for (int i = t; i < FNEAR; i += FTH) gn[i] = T.gnear[i];
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const int idx = t + q * FTH;
+            if (idx < xcap) xw[idx] = xr[q];
+        }
+#pragma unroll
+        for (int q = 0; q < (FLV * 2 * FP / 2) / FTH; ++q) {
+            const int i2 = t + q * FTH;
+            *(double2 *)(ca + (i2 >> 3) * FS + 2 * (i2 & 7)) = cr[q];
         }
     }
-    __syncthreads();                                    // (src == la: the 64 leaves' Chebyshev coefficients; the weights are no longer needed)
-    FSTAMP(1, 7);
-#pragma unroll
-    for (int q = 0; q < XPT; ++q) {
-        const int idx = t + q * FTH;
-        if (idx < FXW) xw[idx] = xr[q];
-    }
     __syncthreads();
-    FSTAMP(1, 8);
-    // ---- the leaf phase: wave = (16 leaves G, target parity e relative to the leaf's first sample) ----------------------------------------
+    FSTAMP(2, 1);
+    // ---- wave = (16 leaves G, target parity e relative to the leaf's first sample) ---------------------------------------------------------
     const int n16 = lane & 15, gq = lane >> 4;
     const int SMe = (smax + 1) & ~1;
     const int NKB = ((2 * smax + SMe) / 2 + 3) / 4;
@@ -637,19 +670,20 @@ __global__ void __launch_bounds__(FTH, 2) fmm_down_leaf2(const double *__restric
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc1, 0, 0, 0);
     }
-    FSTAMP(1, 9);
+    FSTAMP(2, 2);
     // far field + output: register r of block I is target tau = 2 (16 I + gq + 4 r) + e of leaf lk.  Its place in the box: u = ua + tau du
     // (one division per lane, not per target)
     const int ht = (int)((a + e) & 1);
     const double ua = 2.0 * ((double)((a << g.L) - k * g.n) / (double)g.n) - 1.0;
     double ac[FP];
     {
-        const double *cp = la + (lk * 2 + ht) * FS;
+        const double *cp = ca + (lk * 2 + ht) * FS;
 #pragma unroll
         for (int kk = 0; kk < FP; ++kk) ac[kk] = cp[kk];
     }
-    const double *xp = xw + (int)(a - w0);
+    double *xp = xw + (int)(a - w0);
     double *op = out + a;
+    double res[8];
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
 #pragma unroll
@@ -668,17 +702,95 @@ __global__ void __launch_bounds__(FTH, 2) fmm_down_leaf2(const double *__restric
             }
             const double near = I == 0 ? acc0[r] : acc1[r];
             const double H = g.scale * (far + near);
-            if (valid) {
-                if (OUT_ENV) {
-                    const double xv = xp[tau];
-                    op[tau] = sqrt(fma(xv, xv, H * H));
+            if (OUT == 0) {
+                if (valid) op[tau] = H;
+            } else {
+                const double xv = xp[valid ? tau : 0];
+                const double ev = sqrt(fma(xv, xv, H * H));
+                if (OUT == 1) {
+                    if (valid) op[tau] = ev;
                 } else {
-                    op[tau] = H;
+                    res[4 * I + r] = ev;
                 }
             }
         }
     }
-    FSTAMP(1, 10);
+    FSTAMP(2, 3);
+    if (OUT != 2) return;
+    __syncthreads();                                    // every near field has read its samples: the envelope takes their place
+    static_assert(FLV * 2 * FS * 8 >= WFX_SEL_BINS * 4, "the histogram fits where the coefficients were");
+    for (int i = t; i < WFX_SEL_BINS; i += FTH) h0[i] = 0;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tau = 2 * (16 * I + gq + 4 * r) + e;
+            if (tau < s0) xp[tau] = res[4 * I + r];
+        }
+    __syncthreads();
+    FSTAMP(2, 4);
+    {
+        const long long wa = fmm_leaf_first(g, leaf0), wb = fmm_leaf_first(g, leaf0 + FLV);   // the workgroup's own samples [wa, wb)
+        const int own = (int)(wb - wa);
+        const double *ew = xw + (int)(wa - w0);
+        const bool first = wa == 0, last = wb == g.n;
+        for (int i0 = 0; i0 < own; i0 += FTH) {
+            const int i = i0 + t;
+            // medians that are complete here: all but the first and last two -- and those too where zeros stand beyond the capture's end
+            const bool valid = i < own && (i >= 2 || first) && (i < own - 2 || last);
+            double m = 0.0;
+            if (valid) {
+                const double e0 = i >= 2 ? ew[i - 2] : 0.0, e1 = i >= 1 ? ew[i - 1] : 0.0;
+                const double e3 = i + 1 < own ? ew[i + 1] : 0.0, e4 = i + 2 < own ? ew[i + 2] : 0.0;
+                m = wfx_median5(e0, e1, ew[i], e3, e4);
+                out[wa + i] = m;
+            }
+            if (l0hist) wfx_sel_count(h0, (unsigned)(wfx_f64_key(m) >> 53), valid, lane);
+        }
+        if (t < 8) edge[(size_t)blockIdx.x * 8 + t] = t < 4 ? ew[t] : ew[own - 8 + t];
+    }
+    if (l0hist) {
+        __syncthreads();
+        for (int i = t; i < WFX_SEL_BINS; i += FTH)
+            if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
+    }
+    FSTAMP(2, 5);
+}
+
+// medians across the seam of workgroups b and b + 1 of fmm_leaf_env<2> (positions end - 2, end - 1, end, end + 1): one thread per seam
+__global__ void __launch_bounds__(256) fmm_edge_median(const fmm_geom g, const double *__restrict__ edge, double *__restrict__ out, unsigned *__restrict__ l0hist,
+                                                       int nwg)
+{
+    // (the histogram goes through LDS with one atomic per wave and digit: 8 000 global atomics on a handful of bins took 69 us)
+    __shared__ unsigned h0[WFX_SEL_BINS];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x * 256 + t;
+    const bool act = b < nwg - 1;
+    if (l0hist)
+        for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
+    __syncthreads();
+    double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+    if (act) {
+        const long long pos = fmm_leaf_first(g, (long long)(b + 1) * FLV);         // first sample of workgroup b + 1
+        const double *l = edge + (size_t)b * 8 + 4, *f = edge + (size_t)(b + 1) * 8;
+        m0 = wfx_median5(l[0], l[1], l[2], l[3], f[0]);
+        m1 = wfx_median5(l[1], l[2], l[3], f[0], f[1]);
+        m2 = wfx_median5(l[2], l[3], f[0], f[1], f[2]);
+        m3 = wfx_median5(l[3], f[0], f[1], f[2], f[3]);
+        out[pos - 2] = m0;
+        out[pos - 1] = m1;
+        out[pos] = m2;
+        out[pos + 1] = m3;
+    }
+    if (l0hist) {
+        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m0) >> 53), act, t & 63);
+        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m1) >> 53), act, t & 63);
+        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m2) >> 53), act, t & 63);
+        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m3) >> 53), act, t & 63);
+        __syncthreads();
+        for (int i = t; i < WFX_SEL_BINS; i += 256)
+            if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
+    }
 }
 
 // ---- P2M + M2M on the matrix cores: a workgroup = 64 consecutive leaves ------------------------------------------------------------------------
@@ -792,6 +904,194 @@ __global__ void __launch_bounds__(FTH, 2) fmm_up_leaf2(const double *__restrict_
     }
 }
 
+// ---- a6 + P2M + M2M in one kernel (round 6): the notch / slope filter (wefax.py:63-72) applied to the workgroup's own 64 leaves -----------
+// The raw capture is read ONCE (int16: 2 bytes per sample instead of a float64 round trip through memory): window of the leaves' samples and
+// 24 more on either side -> LDS -> the 49-tap form of filtfilt (notch_kernel's arithmetic, wfx_stages.hip: eight outputs per lane from a
+// 56-sample register window, ascending taps) -> the filtered samples in LDS for P2M and in `y` for the leaf kernel.  The first and last
+// 64 samples of the capture come from the exact recurrences (odd extension, lfilter_zi), run by the first / last workgroup.
+template <typename TIN> struct up3_win;
+template <> struct up3_win<short> {
+    static __device__ __forceinline__ void load8(const short *w, double (&v)[8])
+    {
+        const uint4 q = *(const uint4 *)w;             // (8 t shorts from a 16-byte aligned base)
+        const unsigned d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = (double)(short)(d[i] & 0xffffu);
+            v[2 * i + 1] = (double)((int)d[i] >> 16);
+        }
+    }
+};
+template <> struct up3_win<double> {
+    static __device__ __forceinline__ void load8(const double *w, double (&v)[8])
+    {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = w[i];
+    }
+};
+
+template <typename TIN, int MINW>
+__global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict__ raw, const notch_coef c, double *__restrict__ y, const fmm_geom g, const fmm_tabs T,
+                                                           double *__restrict__ Wg, int xc, wfx_dev_scalars *__restrict__ clear)
+{
+    extern __shared__ __align__(16) double fl[];
+    double *wb0 = fl;                                   // [64][2][FS]; before P2M: the raw window (int16 capture) and the edge routine's scratch
+    double *xw = wb0 + FLV * 2 * FS;                    // the workgroup's filtered samples (xc = 64 x the largest leaf); after P2M: wb1
+    double *wb1 = xw;                                   // [32][2][FS]
+    TIN *rw = sizeof(TIN) == 2 ? (TIN *)wb0 : (TIN *)(xw + xc);        // raw[wa - 24 .. wb + 24) (a float64 capture has its own region)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long leaf0 = (long long)blockIdx.x * FLV;
+    const long long wa = fmm_leaf_first(g, leaf0), wb = fmm_leaf_first(g, leaf0 + FLV);
+    const int own = (int)(wb - wa);
+    FSTAMP(0, 0);
+    if (clear && blockIdx.x == 0)        // the decode's device scalars start from zero (this is the first kernel of the path that sees them)
+        for (int i = t; i < (int)(sizeof(wfx_dev_scalars) / 8); i += FTH) ((unsigned long long *)clear)[i] = 0ull;
+    {
+        constexpr int NQ = (FLV * 64 + 2 * NOTCH_K + FTH - 1) / FTH;
+        TIN pre[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const long long src = wa - NOTCH_K + t + q * FTH;
+            pre[q] = raw[src < 0 ? 0 : (src >= g.n ? g.n - 1 : src)];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int j = t + q * FTH;
+            const long long src = wa - NOTCH_K + j;
+            if (j < own + 2 * NOTCH_K + 8) rw[j] = (src >= 0 && src < g.n) ? pre[q] : (TIN)0;
+        }
+    }
+    double ajr[2][4];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ajr[cc][ks] = T.Aj[cc * FP * FP + 64 * ks + lane];
+    __syncthreads();
+    FSTAMP(0, 1);
+    if (8 * t < own) {
+        // window element i feeds output u with tap |i - u - K|: ascending i for every output, as notch_kernel sums
+        double acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+#pragma unroll
+        for (int blk = 0; blk < 7; ++blk) {
+            double wv[8];
+            up3_win<TIN>::load8(rw + 8 * t + 8 * blk, wv);
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                const int i = 8 * blk + ii;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = i - u - NOTCH_K;
+                    if (k >= -NOTCH_K && k <= NOTCH_K) acc[u] = fma(c.g[k < 0 ? -k : k], wv[ii], acc[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xw[8 * t + u] = acc[u];
+    }
+    __syncthreads();
+    // the capture's first / last 64 samples: exact forward / backward recurrences on the odd extension (notch_kernel's edge workgroup)
+    if (wa < NOTCH_EDGE || wb > g.n - NOTCH_EDGE) {
+        constexpr int EL = NOTCH_EDGE + NOTCH_SETTLE, LEN = NOTCH_PAD + EL;     // 127, 136
+        double *e = (double *)wb0;                                            // (the raw window is no longer needed)
+        const bool left = wa < NOTCH_EDGE;                                     // (a capture of >= 32 768 samples: never both in one workgroup)
+        for (int i = t; i < LEN; i += FTH)
+            e[i] = left ? (i < NOTCH_PAD ? notch_left<TIN>(c, raw, NOTCH_PAD - i) : (double)raw[i - NOTCH_PAD])
+                        : (i < EL ? (double)raw[g.n - EL + i] : notch_right<TIN>(c, raw, (uint64_t)g.n, i - EL + 1));
+        __syncthreads();
+        if (t == 0) {
+            // left: exact forward start, backward started SETTLE samples to the right with a zero state
+            // right: forward started SETTLE samples early with a zero state, exact backward start
+            double z0 = left ? c.zi[0] * e[0] : 0.0, z1 = left ? c.zi[1] * e[0] : 0.0;
+            for (int i0 = 0; i0 < LEN; i0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = e[i0 + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = biquad_step(c, v[k], z0, z1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[i0 + k] = v[k];
+            }
+            z0 = left ? 0.0 : c.zi[0] * e[LEN - 1];
+            z1 = left ? 0.0 : c.zi[1] * e[LEN - 1];
+            for (int i0 = LEN - 8; i0 >= 0; i0 -= 8) {
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = e[i0 + k];
+#pragma unroll
+                for (int k = 7; k >= 0; --k) v[k] = biquad_step(c, v[k], z0, z1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[i0 + k] = v[k];
+            }
+        }
+        __syncthreads();
+        if (t < NOTCH_EDGE) {
+            if (left)
+                xw[t] = e[NOTCH_PAD + t];
+            else
+                xw[(int)(g.n - NOTCH_EDGE - wa) + t] = e[EL - NOTCH_EDGE + t];
+        }
+        __syncthreads();
+    }
+    FSTAMP(0, 2);
+    for (int i = t; i < own; i += FTH) y[wa + i] = xw[i];
+    // ---- P2M: wave = (16 leaves G, sample parity e relative to the leaf's first sample); lane (column = leaf, quarter gq) -----------------------
+    const int n16 = lane & 15, gq = lane >> 4;
+    const int G = wave >> 1, e = wave & 1;
+    const int lk = 16 * G + n16;
+    const long long k = leaf0 + lk;
+    const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1);
+    const int s0 = (int)(b - a);
+    const int ht = (int)((a + e) & 1);
+    const double ua = 2.0 * ((double)((a << g.L) - k * g.n) / (double)g.n) - 1.0;
+    double mu[FP];
+#pragma unroll
+    for (int kk = 0; kk < FP; ++kk) mu[kk] = 0.0;
+    const double *xp = xw + (int)(a - wa);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int tau = 2 * (gq + 4 * r) + e;
+        const bool valid = tau < s0;
+        const double xv = valid ? xp[valid ? tau : 0] : 0.0;
+        const double u = valid ? fma((double)tau, g.du, ua) : 0.0;
+        const double u2 = 2.0 * u;
+        mu[0] += xv;
+        mu[1] = fma(u, xv, mu[1]);
+        double t0 = 1.0, t1 = u;
+#pragma unroll
+        for (int kk = 2; kk < FP; ++kk) {
+            const double t2 = fma(u2, t1, -t0);
+            mu[kk] = fma(t2, xv, mu[kk]);
+            t0 = t1;
+            t1 = t2;
+        }
+    }
+    FSTAMP(0, 3);
+    {
+        // sum over the four quarters and moments -> nodal weights: one product per moment, A[row j][quarter] = Cw[k][j]
+        fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < FP; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T.Cw[kk * FP + n16], mu[kk], acc, 0, 0, 0);
+        double *o = wb0 + (lk * 2 + ht) * FS + gq, *go = Wg + (fmm_box(g.L, k) * 2 + ht) * FP + gq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[4 * r] = acc[r];
+            go[4 * r] = acc[r];
+        }
+    }
+    double *src = wb0, *dst = wb1;
+#pragma unroll 1
+    for (int d = FW - 1; d >= 0; --d) {
+        __syncthreads();
+        FSTAMP(0, 4 + (FW - 1 - d));
+        fmm_up_level_mfma(src, dst, Wg + fmm_box(g.L - FW + d, (long long)blockIdx.x << d) * 2 * FP, ajr, d, wave, lane);
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+}
+
 // ---- the tiers and the top of the tree on the matrix cores (512 threads; the same level routines as the leaf kernels) --------------------
 __global__ void __launch_bounds__(FTH) fmm_up_tier2(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, int a, int D)
 {
@@ -830,22 +1130,21 @@ __global__ void __launch_bounds__(FTH) fmm_down_tier2(const fmm_geom g, const fm
     for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
     double *src = la, *dst = lb;
     if (t < 2 * FP) src[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(a, blockIdx.x) * 2 * FP + t];
-    double ga[3][4], gnx[3][4];
-    fmm_ga_load(T.G + (size_t)(a + 1 - 2) * 4 * FP * FP, wave & 1, lane, ga);
+    double gs[3][3][4];                                 // (three sets in rotation, requested two levels ahead: fmm_tree_leaf)
+    fmm_ga_load(T.G + (size_t)(a + 1 - 2) * 4 * FP * FP, wave & 1, lane, gs[1]);
+    if (D >= 2) fmm_ga_load(T.G + (size_t)(a + 2 - 2) * 4 * FP * FP, wave & 1, lane, gs[2]);
     int woff = 0;
-#pragma unroll 1
-    for (int d = 1; d <= D; ++d) {
-        if (d < D) fmm_ga_load(T.G + (size_t)(a + d + 1 - 2) * 4 * FP * FP, wave & 1, lane, gnx);
-        __syncthreads();
-        fmm_down_level_mfma(src, dst, un + woff, ga, atr, d, wave, lane, nullptr);
-        woff += ((1 << d) + 2 * FHB) * 2 * FS;
-        double *tmp = src;
-        src = dst;
-        dst = tmp;
 #pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ga[s2][ks] = gnx[s2][ks];
+    for (int d = 1; d <= FTD; ++d) {
+        if (d <= D) {
+            if (d + 2 <= D) fmm_ga_load(T.G + (size_t)(a + d + 2 - 2) * 4 * FP * FP, wave & 1, lane, gs[(d + 2) % 3]);
+            __syncthreads();
+            fmm_down_level_mfma(src, dst, un + woff, gs[d % 3], atr, d, wave, lane, nullptr);
+            woff += ((1 << d) + 2 * FHB) * 2 * FS;
+            double *tmp = src;
+            src = dst;
+            dst = tmp;
+        }
     }
     __syncthreads();
     double *o = Lg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
@@ -895,14 +1194,21 @@ __global__ void __launch_bounds__(FTH) fmm_top2(const fmm_geom g, const fmm_tabs
     __syncthreads();
     for (int i = t; i < 4 * 2 * FP; i += FTH) la[(i >> 4) * FS + (i & 15)] = l2[i];
     double *src = la, *dst = lb;
-    double ga[3][4];
-    for (int lev = 3; lev <= atop; ++lev) {
-        fmm_ga_load(T.G + (size_t)(lev - 2) * 4 * FP * FP, wave & 1, lane, ga);
-        __syncthreads();
-        fmm_down_level_mfma(src, dst, wl[lev - 2], ga, atr, lev, wave, lane, nullptr);
-        double *tmp = src;
-        src = dst;
-        dst = tmp;
+    {
+        double gs[3][3][4];                             // levels 3, 4, 5: all requested at once
+#pragma unroll
+        for (int lev = 3; lev <= 5; ++lev)
+            if (lev <= atop) fmm_ga_load(T.G + (size_t)(lev - 2) * 4 * FP * FP, wave & 1, lane, gs[lev - 3]);
+#pragma unroll
+        for (int lev = 3; lev <= 5; ++lev) {
+            if (lev <= atop) {
+                __syncthreads();
+                fmm_down_level_mfma(src, dst, wl[lev - 2], gs[lev - 3], atr, lev, wave, lane, nullptr);
+                double *tmp = src;
+                src = dst;
+                dst = tmp;
+            }
+        }
     }
     __syncthreads();
     for (int i = t; i < ntop * 2 * FP; i += FTH) Lg[fmm_box(atop, 0) * 2 * FP + i] = src[(i >> 4) * FS + (i & 15)];
@@ -963,7 +1269,10 @@ static double cot_unit(double z, int lev)
 
 // env_raw[i] = |x[i] + i H[i]| (out_env) or H itself, for an even n large enough for the tree; *handled = 0 otherwise (the caller
 // runs the transform path)
-int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, int out_env, int *handled)
+// x != nullptr: the filtered capture is given.  x == nullptr: `raw` (int16 or float64 mono) goes through the notch inside the first kernel, which
+// leaves the filtered capture in `audio` (wefax.py:63-72 + 174-175 in four leaf-level passes over the capture's bytes)
+static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind, const notch_coef *nc, double *audio, wfx_dev_scalars *clear, uint64_t n, double *out,
+                   int out_mode, unsigned *l0hist, int *handled)
 {
     *handled = 0;
     if (n % 2 || n < 32768 || n > (1ull << 32)) return 0;
@@ -1019,23 +1328,35 @@ int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, 
     g.du = ldexp(2.0, L) / (double)n;
     const size_t nbox = (size_t)1 << (L + 1);                             // all levels
     WFX_TRY(wfx_reserve(ctx, ctx->b_work, nbox * 2 * FP * 8));           // weights W
-    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, ((size_t)1 << (L - FW + 1)) * 2 * FP * 8 + 64));    // local expansions down to the leaf workgroups' roots
-    double *Wg = (double *)ctx->b_work.p, *Lg = (double *)ctx->b_work2.p;
     const unsigned nwg = 1u << (L - FW);
+    const size_t lg_doubles = ((size_t)1 << (L - FW + 1)) * 2 * FP + 8, cg_doubles = ((size_t)1 << L) * 2 * FP;
+    // local expansions down to the leaf workgroups' roots | the leaves' far fields as Chebyshev coefficients | eight envelope values per workgroup
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (lg_doubles + cg_doubles + (size_t)nwg * 8) * 8 + 64));
+    double *Wg = (double *)ctx->b_work.p, *Lg = (double *)ctx->b_work2.p, *Cg = Lg + lg_doubles, *Eg = Cg + cg_doubles;
     const size_t lds_up = (size_t)(8 * 8 * FROW + 8 * 64 + 8 * 32 + FLV * 2 * FP + (FLV / 2) * 2 * FP + 2 * FP * FP) * 8;
     const size_t lds_dn = (size_t)(FLV * 2 * FP + (FLV / 2) * 2 * FP + 2 * FP * FP + FNEAR + FXW) * 8;
-    const size_t lds_dn2 = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FNEAR + FWALL) * 8;
-    const size_t lds_up2 = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FLV * 64) * 8;
+    const size_t lds_tree = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FWALL) * 8;
     const int smax = (int)((n + ((1ull << L) - 1)) >> L);                  // the largest leaf
+    const int xcap = std::min(FXW, ((FLV + 2) * smax + 1) & ~1);             // the leaf kernel's sample window: 64 leaves and one more on either side
+    const size_t lds_leaf = (size_t)(FLV * 2 * FS + FNEAR + FXP0 + xcap + FXP1) * 8;      // 49 776 bytes for leaves of <= 55 samples: three workgroups per CU
+    const size_t lds_up2 = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FLV * 64) * 8;
+    const int xc3 = FLV * smax;                                             // the fused notch kernel's sample window
+    const size_t lds_up3_i16 = (size_t)(FLV * 2 * FS + xc3) * 8, lds_up3_f64 = lds_up3_i16 + (size_t)(xc3 + 2 * NOTCH_K + 8) * 8;
+    const size_t lds_up3_max = (size_t)(FLV * 2 * FS + FLV * 64 + FLV * 64 + 2 * NOTCH_K + 8) * 8;
     static_assert(FXW >= (FLV + 2 * FHB) * 2 * FP + 4 * FP * FP, "the sample window is also the tree phase's staging area");
+    const size_t lds_leaf_max = (size_t)(FLV * 2 * FS + FNEAR + FXP0 + FXW + FXP1) * 8;
     static bool attr_done = false;
     if (!attr_done) {
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up2));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn2));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn2));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf3<short, UP3W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up3_max));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf3<double, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up3_max));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tree));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
         attr_done = true;
     }
     // tiers between the leaf workgroups' roots (level L - 6) and the top (levels 2 .. atop <= 5): at most six levels each
@@ -1050,7 +1371,13 @@ int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, 
     const int atop = cur;
     static const int leaf_v = getenv("WFX_FMM_LEAF") ? atoi(getenv("WFX_FMM_LEAF")) : 2;
     wfx_prof_begin(ctx, K_FFT_FWD);
-    if (leaf_v == 2)
+    if (!x) {
+        if (raw_kind == WFX_IN_I16_MONO)
+            hipLaunchKernelGGL((fmm_up_leaf3<short, UP3W>), dim3(nwg), dim3(FTH), lds_up3_i16, ctx->stream, (const short *)raw, *nc, audio, g, T, Wg, xc3, clear);
+        else
+            hipLaunchKernelGGL((fmm_up_leaf3<double, 4>), dim3(nwg), dim3(FTH), lds_up3_f64, ctx->stream, (const double *)raw, *nc, audio, g, T, Wg, xc3, clear);
+        x = audio;
+    } else if (leaf_v == 2)
         hipLaunchKernelGGL(fmm_up_leaf2, dim3(nwg), dim3(FTH), lds_up2, ctx->stream, x, g, T, Wg);
     else
         hipLaunchKernelGGL(fmm_up_leaf, dim3(nwg), dim3(FTH), lds_up, ctx->stream, x, g, T, Wg);
@@ -1070,25 +1397,34 @@ int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, 
     wfx_prof_end(ctx);
     wfx_prof_begin(ctx, K_FFT_INV);
     if (leaf_v == 2) {
-        if (out_env)
-            hipLaunchKernelGGL(fmm_down_leaf2<1>, dim3(nwg), dim3(FTH), lds_dn2, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out, smax);
+        hipLaunchKernelGGL(fmm_tree_leaf, dim3(nwg), dim3(FTH), lds_tree, ctx->stream, g, T, (const double *)Wg, (const double *)Lg, Cg);
+        wfx_prof_end(ctx);
+        wfx_prof_begin(ctx, K_ENV_MEDIAN);
+        if (out_mode == 2) {
+            hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, l0hist);
+            if (nwg > 1) hipLaunchKernelGGL(fmm_edge_median, dim3((nwg + 255) / 256), dim3(256), 0, ctx->stream, g, (const double *)Eg, out, l0hist, (int)nwg);
+        } else if (out_mode == 1)
+            hipLaunchKernelGGL(fmm_leaf_env<1>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, (unsigned *)nullptr);
         else
-            hipLaunchKernelGGL(fmm_down_leaf2<0>, dim3(nwg), dim3(FTH), lds_dn2, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out, smax);
-    } else if (out_env)
-        hipLaunchKernelGGL(fmm_down_leaf<1>, dim3(nwg), dim3(FTH), lds_dn, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out);
-    else
-        hipLaunchKernelGGL(fmm_down_leaf<0>, dim3(nwg), dim3(FTH), lds_dn, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out);
+            hipLaunchKernelGGL(fmm_leaf_env<0>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, (unsigned *)nullptr);
+    } else {
+        if (out_mode == 2) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fmm: the fused median needs the matrix-core kernels");
+        if (out_mode)
+            hipLaunchKernelGGL(fmm_down_leaf<1>, dim3(nwg), dim3(FTH), lds_dn, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out);
+        else
+            hipLaunchKernelGGL(fmm_down_leaf<0>, dim3(nwg), dim3(FTH), lds_dn, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out);
+    }
     wfx_prof_end(ctx);
 #ifdef WFX_FMM_STAMPS
     {
-        static std::vector<unsigned long long> hb(2 * 4096 * 16);
+        static std::vector<unsigned long long> hb(3 * 4096 * 16);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipMemcpyFromSymbol(hb.data(), HIP_SYMBOL(fmm_stamp_buf), hb.size() * 8);
-        for (int kern = 0; kern < 2; ++kern) {
+        for (int kern = 0; kern < 3; ++kern) {
             const unsigned nb = std::min(nwg, 4096u);
             unsigned long long t0 = ~0ull, t1 = 0;
             double sum[16] = {0};
-            const int ns = kern ? 11 : 9;
+            const int ns = kern == 0 ? (raw ? 10 : 9) : (kern == 1 ? 9 : (out_mode == 2 ? 6 : 4));
             for (unsigned b2 = 0; b2 < nb; ++b2) {
                 const unsigned long long *p = &hb[(size_t)kern * 4096 * 16 + (size_t)b2 * 16];
                 t0 = std::min(t0, p[0]);
@@ -1105,4 +1441,22 @@ int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, 
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
     *handled = 1;
     return 0;
+}
+
+int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, int out_mode, unsigned *l0hist, int *handled)
+{
+    return fmm_run(ctx, x, nullptr, 0, nullptr, nullptr, nullptr, n, out, out_mode, l0hist, handled);
+}
+
+// a6 + a7 fused: `in` (int16 or float64 mono, n samples) -> notch filtfilt -> audio (float64) -> |audio + i H| -> 5-tap median -> env (+ level-0
+// histogram of the select).  *handled = 0 and nothing enqueued when the length has no multipole form or the biquad is not the 49-tap case.
+int wfx_dev_notch_hilbert_fmm(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], const double *ext18, double *audio,
+                              double *env, unsigned *l0hist, wfx_dev_scalars *clear, int *handled)
+{
+    *handled = 0;
+    if (in_kind != WFX_IN_I16_MONO && in_kind != WFX_IN_F64_MONO) return 0;
+    if (n < NOTCH_SMALL || pow(biquad_pole_radius(a), NOTCH_K) > 1e-16) return 0;
+    notch_coef c;
+    notch_prepare(c, b, a, ext18);
+    return fmm_run(ctx, nullptr, in, in_kind, &c, audio, clear, n, env, 2, l0hist, handled);
 }

@@ -260,6 +260,24 @@ __device__ __forceinline__ void wfx_sel_count(unsigned *h, unsigned digit, bool 
     }
     if (valid) atomicAdd(&h[digit], 1u);
 }
+// 5-tap median as scipy.signal.medfilt(., 5) orders it (wefax.py:175); the same exchange network in every kernel that fuses it
+__device__ __forceinline__ void wfx_cswap(double &a, double &b)
+{
+    const double lo = fmin(a, b), hi = fmax(a, b);
+    a = lo;
+    b = hi;
+}
+__device__ __forceinline__ double wfx_median5(double a, double b, double c, double d, double e)
+{
+    wfx_cswap(a, b);
+    wfx_cswap(d, e);
+    wfx_cswap(a, d);      // a is the smallest of a, b, d, e -> not the median
+    wfx_cswap(b, e);      // e is the largest of a, b, d, e  -> not the median
+    wfx_cswap(b, c);      // remaining: b, c, d -> median of three
+    wfx_cswap(c, d);
+    wfx_cswap(b, c);
+    return c;
+}
 #endif
 
 // ---- device-level stage functions (device pointers in, device pointers out) --
@@ -391,7 +409,9 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
 
 // wfx_fmm.hip: |x + i H| (out_env) or H = imag(scipy.signal.hilbert(x)) for even n by near field + fast multipole far field; *handled = 0
 // for lengths it does not take (odd, short)
-int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, int out_env, int *handled);
+int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, int out_mode, unsigned *l0hist, int *handled);
+int wfx_dev_notch_hilbert_fmm(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], const double *ext18, double *audio,
+                              double *env, unsigned *l0hist, wfx_dev_scalars *clear, int *handled);      // a6 + a7 in one chain of kernels (wfx_fmm.hip)   // out_mode 0: H, 1: |x + iH|, 2: its 5-tap median + level-0 histogram of the select
 
 // wfx_ingest.hip: the streaming form of the ingest (factor 32, int16 frames, taps on a 2^-s grid) with the float64 stage behind it
 // fused (factor2 = 2 or 3; 0: stage 1 alone).  *handled = 0 and nothing enqueued when the shapes are not its own

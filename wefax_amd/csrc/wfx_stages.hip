@@ -83,64 +83,7 @@ int wfx_dev_i16_to_f64(wfx_ctx *ctx, const int16_t *in, uint64_t n, double *out)
 // (9 samples) and lfilter_zi initial state, and are computed with the actual
 // recurrence by two single threads of one extra workgroup.
 // ===========================================================================
-#define NOTCH_K 24
-#define NOTCH_EDGE 64
-#define NOTCH_SETTLE 63
-#define NOTCH_PAD 9
-#define NOTCH_SMALL (2 * (NOTCH_EDGE + NOTCH_SETTLE))
-
-struct notch_coef {
-    double g[NOTCH_K + 1];
-    double b[3], a[3], zi[2];
-    int has_ext;                      // the odd extension is given (evaluated by the host in the capture's own dtype)
-    double extl[NOTCH_PAD], extr[NOTCH_PAD];
-};
-
-template <typename TIN>
-__device__ __forceinline__ double notch_ext_left(const TIN *x, int k);   // 2*x[0] - x[k]
-template <>
-__device__ __forceinline__ double notch_ext_left<short>(const short *x, int k)
-{
-    return (double)(short)(2 * (int)x[0] - (int)x[k]);     // int16 wrap, as numpy does for an int16 array
-}
-template <>
-__device__ __forceinline__ double notch_ext_left<double>(const double *x, int k)
-{
-    return 2 * x[0] - x[k];
-}
-template <typename TIN>
-__device__ __forceinline__ double notch_ext_right(const TIN *x, uint64_t n, int k);   // 2*x[n-1] - x[n-1-k]
-template <>
-__device__ __forceinline__ double notch_ext_right<short>(const short *x, uint64_t n, int k)
-{
-    return (double)(short)(2 * (int)x[n - 1] - (int)x[n - 1 - k]);
-}
-template <>
-__device__ __forceinline__ double notch_ext_right<double>(const double *x, uint64_t n, int k)
-{
-    return 2 * x[n - 1] - x[n - 1 - k];
-}
-
-// extended sample k places before x[0] / after x[n-1] (k = 1..9)
-template <typename TIN>
-__device__ __forceinline__ double notch_left(const notch_coef &c, const TIN *x, int k)
-{
-    return c.has_ext ? c.extl[NOTCH_PAD - k] : notch_ext_left<TIN>(x, k);
-}
-template <typename TIN>
-__device__ __forceinline__ double notch_right(const notch_coef &c, const TIN *x, uint64_t n, int k)
-{
-    return c.has_ext ? c.extr[k - 1] : notch_ext_right<TIN>(x, n, k);
-}
-
-// transposed direct form II step, the recurrence of scipy's lfilter
-__device__ __forceinline__ double biquad_step(const notch_coef &c, double xi, double &z0, double &z1)
-{
-    const double yi = z0 + c.b[0] * xi;
-    z0 = z1 + c.b[1] * xi - c.a[1] * yi;
-    z1 = c.b[2] * xi - c.a[2] * yi;
-    return yi;
-}
+#include "wfx_notch.h"
 
 // outputs per lane of the interior form: 8 halve the LDS reads per output and measure faster on float64 input (141 vs 155 us on the
 // 60-minute sizes), 4 on int16 input (29 vs 32.5 us on the 10-minute capture: nine 2-byte loads per lane and tile otherwise)
@@ -288,44 +231,6 @@ static unsigned notch_grid(uint64_t n_interior, int nu)
     return std::min(wfx_blocks(n_interior, 256 * nu), 1024u);
 }
 
-static void notch_prepare(notch_coef &c, const double b[3], const double a[3], const double *ext18 = nullptr)
-{
-    c.has_ext = ext18 != nullptr;
-    for (int i = 0; i < NOTCH_PAD; ++i) {
-        c.extl[i] = ext18 ? ext18[i] : 0.0;
-        c.extr[i] = ext18 ? ext18[NOTCH_PAD + i] : 0.0;
-    }
-    for (int i = 0; i < 3; ++i) {
-        c.b[i] = b[i] / a[0];
-        c.a[i] = a[i] / a[0];
-    }
-    // lfilter_zi: solve (I - companion(a).T) zi = b[1:] - a[1:] b[0]
-    {
-        const double m00 = 1.0 + c.a[1], m01 = -1.0, m10 = c.a[2], m11 = 1.0;
-        const double r0 = c.b[1] - c.a[1] * c.b[0], r1 = c.b[2] - c.a[2] * c.b[0];
-        const double det = m00 * m11 - m01 * m10;
-        c.zi[0] = (r0 * m11 - m01 * r1) / det;
-        c.zi[1] = (m00 * r1 - m10 * r0) / det;
-    }
-    // impulse response and its autocorrelation
-    {
-        double imp[160];
-        double z0 = 0.0, z1 = 0.0;
-        for (int i = 0; i < 160; ++i) {
-            const double xi = i == 0 ? 1.0 : 0.0;
-            const double yi = z0 + c.b[0] * xi;
-            z0 = z1 + c.b[1] * xi - c.a[1] * yi;
-            z1 = c.b[2] * xi - c.a[2] * yi;
-            imp[i] = yi;
-        }
-        for (int k = 0; k <= NOTCH_K; ++k) {
-            double s = 0.0;
-            for (int i = 0; i + k < 160; ++i) s += imp[i] * imp[i + k];
-            c.g[k] = s;
-        }
-    }
-}
-
 // ---- filtfilt for any stable biquad (the live path designs the notch at the sound card's rate:
 // data_packet.py:430-432; at 48 kHz the pole radius is 0.84 and the 49-tap form above does not apply) --------
 // The recurrence forgets its state at the rate of the pole radius r: a lane that starts `warm` samples early
@@ -402,15 +307,6 @@ __global__ void __launch_bounds__(64) biquad_backward_kernel(const double *__res
 }
 
 // largest pole modulus of 1 + a1 z^-1 + a2 z^-2
-static double biquad_pole_radius(const double a[3])
-{
-    const double a1 = a[1] / a[0], a2 = a[2] / a[0];
-    const double disc = a1 * a1 - 4.0 * a2;
-    if (disc < 0.0) return sqrt(a2);
-    const double s = sqrt(disc);
-    return fmax(fabs((-a1 + s) / 2.0), fabs((-a1 - s) / 2.0));
-}
-
 static int notch_general(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const notch_coef &c, double radius, double *out)
 {
     if (!(radius < 0.9995)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "notch: pole radius %.6f is too close to the unit circle", radius);
