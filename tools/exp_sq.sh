@@ -20,3 +20,6 @@ for name in sorted(acc):
     print(name[:44], " ".join(f"{k}={acc[name][k]/cnt[name][k]:.4g}" for k in sorted(acc[name])))
 PY
 tail -3 "$OUT/err.txt" | cut -c1-200
+# third pass: matrix-core activity
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d "$OUT/c" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie --no-extras $EXP_ARGS > /dev/null 2>> "$OUT/err.txt"
+python3 tools/pmc_sq.py "$OUT/c" "$1"

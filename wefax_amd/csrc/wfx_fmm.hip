@@ -424,7 +424,10 @@ __global__ void __launch_bounds__(FTH, 4) fmm_down_leaf(const double *__restrict
 // The far field (L2P) is evaluated by the lane that holds the target's near sum: accumulator register r of lane (g, leaf) is row
 // g + 4 r, i.e. 8 targets of ONE leaf and parity per lane, whose 16 Chebyshev coefficients wait in registers.
 typedef double fmm_d4 __attribute__((ext_vector_type(4)));
-constexpr int UP3W = 4;                     // fmm_up_leaf3 on an int16 capture: waves per SIMD the register budget is set for
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains every global load and store in flight (s_waitcnt vmcnt(0)) --
+// the matrices requested two levels ahead, the weights a level has just sent to memory -- and a tree level then lasts one memory latency
+__device__ __forceinline__ void fmm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int UP3W = 6;                     // fmm_up_leaf3 on an int16 capture: waves per SIMD the register budget is set for
 constexpr int FXP0 = 8, FXP1 = 24;          // unread-but-addressable doubles before / behind the sample window (masked operand reads)
 
 // lab build (tools/build_variant.sh ... -DWFX_FMM_STAMPS): cycle stamps of the leaf kernels' phases, printed by the launcher
@@ -467,64 +470,150 @@ __device__ __forceinline__ void fmm_ga_load(const double *__restrict__ Gl, int c
     }
 }
 
+// (d is a template parameter: a run-time level makes the three sets of matrices of the callers an indexed array, which lands in scratch memory)
 // One level of the downward pass on the matrix cores: L2L from the parents + M2L over the interaction list, for the workgroup's nb = 2^d
 // boxes of the level.  The 16 columns of a product are 16 boxes of ONE parity class c = wave & 1 (same interaction offsets, same L2L matrix):
-//   d >= 5: a task = (class, 16 boxes q, weight parity h);  d <= 4: a task = (class), columns = (q, h) -- d <= 3 leaves columns empty.
-// src: the parents' nodal values [box][h][FS]; dst: this level's; wl: the level's weights [slot = box - first + FHB][h][FS]; ga: the class's M2L
-// matrices; atr: the class's L2L matrix as A operands.  conv != nullptr: the result leaves as Chebyshev coefficients (one more product with the
-// accumulators as its B operand: register r IS K-step r).
-__device__ __forceinline__ void fmm_down_level_mfma(const double *src, double *dst, const double *wl, const double (&ga)[3][4], const double (&atr)[4], int d,
-                                                     int wave, int lane, const double *__restrict__ conv)
+//   d >= 5: a task = (class, 16 boxes q, weight parity h): sixteen products in one wave.
+//   d <= 4: columns = (q, h); the level's four matrices (L2L, three M2L) go to four WAVES per class, which leave four PARTIAL results
+//           ([matrix][box][h][FS]) -- a level is four dependent products long instead of sixteen (the kernel waits on exactly that chain);
+//           whoever reads such a level adds the four in a fixed order (fmm_lsum).
+// src: the parents' nodal values [box][h][FS] (sparts = 4: four partial arrays spstr doubles apart); dst: this level's; wl: the level's weights
+// [slot = box - first + FHB][h][FS]; ga: the class's M2L matrices; atr: the class's L2L matrix as A operands.  conv != nullptr: the result
+// leaves as Chebyshev coefficients (one more product with the accumulators as its B operand: register r IS K-step r).
+// (measured: 65.8 us with the small levels split over eight waves against 62.0 us without, tiers 31 against 28 -- a small level is not
+// its chain of products but ~150 other instructions per wave and the barrier: kept as a switch, off)
+__device__ __forceinline__ bool fmm_level_split(int d) { return false && d <= 4; }
+
+__device__ __forceinline__ double fmm_lsum(const double *p, int sparts, int spstr)
+{
+    return sparts == 4 ? (p[0] + p[spstr]) + (p[2 * spstr] + p[3 * spstr]) : p[0];
+}
+
+template <int d>
+__device__ __forceinline__ void fmm_down_level_mfma(const double *src, int sparts, int spstr, double *dst, const double *wl, const double (&ga)[3][4],
+                                                     const double (&atr)[4], int wave, int lane, const double *__restrict__ conv)
 {
     const int nb = 1 << d, half = nb >> 1;
     const int col = lane & 15, kq = lane >> 4;
     const int c = wave & 1;
-    int q, h;
-    bool valid = true;
     if (d >= 5) {
         const int ng = half >> 4;                       // groups of 16 boxes per class: 1 or 2
         if (wave >= 4 * ng) return;
         const int rest = wave >> 1;
-        q = 16 * (rest & (ng - 1)) + col;
-        h = rest / ng;
-    } else {
-        if ((wave >> 1) != (d & 1)) return;             // (two waves; which two alternates with the level: one SIMD pair would carry all small levels otherwise)
-        const int cc = col & (nb - 1);                  // (columns beyond the level's boxes repeat earlier ones and are not stored)
-        q = cc & (half - 1);
-        h = cc >> (d - 1);
-        valid = col < nb;
+        const int q = 16 * (rest & (ng - 1)) + col, h = rest / ng;
+        const int b = 2 * q + c;
+        fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        {
+            const double *bp = src + (q * 2 + h) * FS + kq;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[ks], fmm_lsum(bp + 4 * ks, sparts, spstr), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int off = s == 0 ? (c ? -3 : -2) : (s == 1 ? (c ? -2 : 2) : (c ? 2 : 3));
+            const double *bp = wl + ((b + off + FHB) * 2 + (1 - h)) * FS + kq;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s][ks], bp[4 * ks], acc, 0, 0, 0);
+        }
+        if (conv) {
+            fmm_d4 cf = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(conv[64 * ks + lane], acc[ks], cf, 0, 0, 0);
+            acc = cf;
+        }
+        double *o = dst + (b * 2 + h) * FS + kq;        // accumulator register r of lane (kq, column) is row kq + 4 r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[4 * r] = acc[r];
+        return;
     }
+    if (!fmm_level_split(d)) {
+        // two waves (which two alternates with the level: one SIMD pair would carry all small levels otherwise), sixteen products each
+        if ((wave >> 1) != (d & 1)) return;
+        const int cc = col & (nb - 1);                  // (columns beyond the level's boxes repeat earlier ones and are not stored)
+        const int q = cc & (half - 1), h = cc >> (d - 1);
+        const int b = 2 * q + c;
+        fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        {
+            const double *bp = src + (q * 2 + h) * FS + kq;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[ks], fmm_lsum(bp + 4 * ks, sparts, spstr), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int off = s == 0 ? (c ? -3 : -2) : (s == 1 ? (c ? -2 : 2) : (c ? 2 : 3));
+            const double *bp = wl + ((b + off + FHB) * 2 + (1 - h)) * FS + kq;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s][ks], bp[4 * ks], acc, 0, 0, 0);
+        }
+        if (col < nb) {
+            double *o = dst + (b * 2 + h) * FS + kq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[4 * r] = acc[r];
+        }
+        return;
+    }
+    // small levels, split: wave = (class c, matrix m): m = 0 the L2L matrix on the parents, m = 1 .. 3 the M2L matrices on the level's weights
+    const int m = wave >> 1;
+    const int cc = col & (nb - 1);                      // (columns beyond the level's boxes repeat earlier ones and are not stored)
+    const int q = cc & (half - 1), h = cc >> (d - 1);
+    const bool valid = col < nb;
     const int b = 2 * q + c;
     fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
-    {
+    if (m == 0) {
         const double *bp = src + (q * 2 + h) * FS + kq;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[ks], bp[4 * ks], acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int off = s == 0 ? (c ? -3 : -2) : (s == 1 ? (c ? -2 : 2) : (c ? 2 : 3));
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[ks], fmm_lsum(bp + 4 * ks, sparts, spstr), acc, 0, 0, 0);
+    } else {
+        const int off = m == 1 ? (c ? -3 : -2) : (m == 2 ? (c ? -2 : 2) : (c ? 2 : 3));
         const double *bp = wl + ((b + off + FHB) * 2 + (1 - h)) * FS + kq;
+        // (m is uniform over the wave: three branches, not a select -- the compiler turns a select between the register sets into an indexed
+        // array in scratch memory)
+        if (m == 1) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s][ks], bp[4 * ks], acc, 0, 0, 0);
-    }
-    if (conv) {
-        fmm_d4 cf = {0.0, 0.0, 0.0, 0.0};
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[0][ks], bp[4 * ks], acc, 0, 0, 0);
+        } else if (m == 2) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(conv[64 * ks + lane], acc[ks], cf, 0, 0, 0);
-        acc = cf;
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[1][ks], bp[4 * ks], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[2][ks], bp[4 * ks], acc, 0, 0, 0);
+        }
     }
     if (valid) {
-        double *o = dst + (b * 2 + h) * FS + kq;        // accumulator register r of lane (kq, column) is row kq + 4 r
+        double *o = dst + m * (nb * 2 * FS) + (b * 2 + h) * FS + kq;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[4 * r] = acc[r];
     }
 }
 
+// the six levels of a subtree, matrices requested two levels ahead into three register sets in rotation (requested one level ahead they
+// arrive after the level's products and every level waits for memory).  LEVELS <= 6 at run time; `lv0` = the level above the first.
+#define FMM_DOWN_STEP(D_, GCUR, GNEXT2, NLEV, CONVP)                                                                                    \
+    if ((D_) <= (NLEV)) {                                                                                                               \
+        if ((D_) + 2 <= (NLEV)) fmm_ga_load(T.G + (size_t)(lv0 + (D_) + 2 - 2) * 4 * FP * FP, wave & 1, lane, GNEXT2);                  \
+        fmm_lds_barrier();                                                                                                              \
+        FSTAMP(1, (D_));                                                                                                                \
+        fmm_down_level_mfma<(D_)>(((D_) & 1) ? la : lb, ((D_) >= 2 && fmm_level_split((D_) - 1)) ? 4 : 1, (1 << ((D_) - 1)) * 2 * FS,   \
+                                  ((D_) & 1) ? lb : la, un + (((1 << (D_)) - 2) + 2 * FHB * ((D_) - 1)) * 2 * FS, GCUR, atr, wave, lane, \
+                                  CONVP);                                                                                               \
+    }
+#define FMM_DOWN_CHAIN(NLEV, CONV6)                                                                   \
+    {                                                                                                 \
+        double gA[3][4], gB[3][4], gC[3][4];                                                          \
+        fmm_ga_load(T.G + (size_t)(lv0 + 1 - 2) * 4 * FP * FP, wave & 1, lane, gA);                   \
+        if (2 <= (NLEV)) fmm_ga_load(T.G + (size_t)(lv0 + 2 - 2) * 4 * FP * FP, wave & 1, lane, gB);  \
+        FMM_DOWN_STEP(1, gA, gC, NLEV, nullptr)                                                       \
+        FMM_DOWN_STEP(2, gB, gA, NLEV, nullptr)                                                       \
+        FMM_DOWN_STEP(3, gC, gB, NLEV, nullptr)                                                       \
+        FMM_DOWN_STEP(4, gA, gC, NLEV, nullptr)                                                       \
+        FMM_DOWN_STEP(5, gB, gA, NLEV, nullptr)                                                       \
+        FMM_DOWN_STEP(6, gC, gB, NLEV, CONV6)                                                         \
+    }
+
 // The weights of levels ltop + 1 .. ltop + D of a workgroup's subtree (its boxes and three more on either side, round the circle) into LDS
 // ([level][slot][parity][FS], level d at box offset (2^d - 2) + 6 (d - 1)), as ONE batch of independent 16-byte requests per lane: one
 // memory latency for the whole tree phase (a loop per level waits for memory once per trip).
-__device__ __forceinline__ void fmm_load_walls(double *un, const double *__restrict__ Wg, int ltop, int D, int t)
+__device__ __forceinline__ void fmm_load_walls(double *un, const double *__restrict__ Wg, int ltop, int D, int t, long long blk)
 {
     static_assert(FW == 6 && FHB == 3 && FTD <= 6, "the slot table below");
     constexpr int NV2MAX = ((2 << FW) - 2 + FW * 2 * FHB) * 2 * (FP / 2);      // pairs of doubles
@@ -539,7 +628,7 @@ __device__ __forceinline__ void fmm_load_walls(double *un, const double *__restr
         const int d = 1 + (bs >= 8) + (bs >= 18) + (bs >= 32) + (bs >= 54) + (bs >= 92);
         const int base = d == 1 ? 0 : (d == 2 ? 8 : (d == 3 ? 18 : (d == 4 ? 32 : (d == 5 ? 54 : 92))));
         const int lev = ltop + d;
-        const long long sb = (((long long)blockIdx.x << d) - FHB + (bs - base) + (1ll << lev)) & ((1ll << lev) - 1);
+        const long long sb = ((blk << d) - FHB + (bs - base) + (1ll << lev)) & ((1ll << lev) - 1);
         wdst[q] = i2 < nv2 ? v * FS + 2 * j2 : -1;
         wv[q] = i2 < nv2 ? *(const double2 *)(Wg + (fmm_box(lev, 0) + sb) * 2 * FP + hh * FP + 2 * j2) : make_double2(0.0, 0.0);
     }
@@ -550,8 +639,9 @@ __device__ __forceinline__ void fmm_load_walls(double *un, const double *__restr
 
 // ---- downward pass inside a leaf subtree: six levels of L2L + M2L, out come the leaves' far fields as Chebyshev coefficients ----------------
 __global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf(const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg, const double *__restrict__ Lg,
-                                                        double *__restrict__ Cg)
+                                                        double *__restrict__ Cg, int wg0)
 {
+    const long long blk = (long long)blockIdx.x + wg0;           // (a launch covers a chunk of the leaf workgroups: fmm_run)
     extern __shared__ __align__(16) double fl[];
     double *la = fl;                                    // [64][2][FS]
     double *lb = la + FLV * 2 * FS;                     // [32][2][FS]
@@ -559,34 +649,19 @@ __global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf(const fmm_geom g, const 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int ltop = g.L - FW;
     FSTAMP(1, 0);
-    fmm_load_walls(un, Wg, ltop, FW, t);
+    fmm_load_walls(un, Wg, ltop, FW, t, blk);
     double atr[4];                                      // the L2L matrix of the wave's box class (wave & 1) as A operands
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
-    double *src = la, *dst = lb;
-    if (t < 2 * FP) src[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(ltop, blockIdx.x) * 2 * FP + t];
+    if (t < 2 * FP) la[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(ltop, blk) * 2 * FP + t];
     {
-        // the matrices of level d + 2 are requested before level d's products are issued (three register sets in rotation: requested one
-        // level ahead they arrive after the level's sixteen products and every level waits for memory)
-        double gs[3][3][4];
-        fmm_ga_load(T.G + (size_t)(ltop + 1 - 2) * 4 * FP * FP, wave & 1, lane, gs[1]);
-        fmm_ga_load(T.G + (size_t)(ltop + 2 - 2) * 4 * FP * FP, wave & 1, lane, gs[2]);
-        int woff = 0;
-#pragma unroll
-        for (int d = 1; d <= FW; ++d) {
-            if (d + 2 <= FW) fmm_ga_load(T.G + (size_t)(ltop + d + 2 - 2) * 4 * FP * FP, wave & 1, lane, gs[(d + 2) % 3]);
-            __syncthreads();
-            FSTAMP(1, d);
-            fmm_down_level_mfma(src, dst, un + woff, gs[d % 3], atr, d, wave, lane, d == FW ? T.Ca : nullptr);
-            woff += ((1 << d) + 2 * FHB) * 2 * FS;
-            double *tmp = src;
-            src = dst;
-            dst = tmp;
-        }
+        const int lv0 = ltop;
+        FMM_DOWN_CHAIN(FW, T.Ca)
     }
-    __syncthreads();                                    // (src == la: the 64 leaves' Chebyshev coefficients)
+    double *src = la;                                   // (level 6 ends in the large buffer)
+    fmm_lds_barrier();                                    // (src == la: the 64 leaves' Chebyshev coefficients)
     FSTAMP(1, 7);
-    double *o = Cg + (size_t)blockIdx.x * FLV * 2 * FP;
+    double *o = Cg + (size_t)blk * FLV * 2 * FP;
 #pragma unroll
     for (int q = 0; q < (FLV * 2 * FP / 2) / FTH; ++q) {
         const int i2 = t + q * FTH;
@@ -601,15 +676,16 @@ __global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf(const fmm_geom g, const 
 // workgroup in `edge`.  scipy.signal.medfilt pads with ZEROS at the capture's ends: those four medians are complete here.
 template <int OUT>
 __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Cg,
-                                                       double *__restrict__ out, int smax, int xcap, double *__restrict__ edge, unsigned *__restrict__ l0hist)
+                                                       double *__restrict__ out, int smax, int xcap, double *__restrict__ edge, unsigned *__restrict__ l0hist, int wg0)
 {
+    const long long blk = (long long)blockIdx.x + wg0;
     extern __shared__ __align__(16) double fl[];
     double *ca = fl;                                    // [64][2][FS]: Chebyshev coefficients of the leaves' far fields
     double *gn = ca + FLV * 2 * FS;                     // [FNEAR]
     double *xw = gn + FNEAR + FXP0;                     // the sample window: the workgroup's leaves and one more on either side (xcap = 66 smax doubles + pads)
     unsigned *h0 = (unsigned *)ca;                      // [WFX_SEL_BINS] (OUT 2): in the coefficients' place once the far fields are evaluated
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long long leaf0 = (long long)blockIdx.x * FLV, nleaf = 1ll << g.L;
+    const long long leaf0 = blk * FLV, nleaf = 1ll << g.L;
     const long long km = leaf0 == 0 ? nleaf - 1 : leaf0 - 1;
     const long long w0 = fmm_leaf_first(g, km) - (leaf0 == 0 ? g.n : 0);                       // may be negative
     const long long kl = leaf0 + FLV == nleaf ? 0 : leaf0 + FLV;                              // the leaf behind the last one
@@ -627,7 +703,7 @@ __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict_
             xr[q] = idx < wlen ? x[m] : 0.0;
         }
         double2 cr[(FLV * 2 * FP / 2) / FTH];
-        const double *cg = Cg + (size_t)blockIdx.x * FLV * 2 * FP;
+        const double *cg = Cg + (size_t)blk * FLV * 2 * FP;
 #pragma unroll
         for (int q = 0; q < (FLV * 2 * FP / 2) / FTH; ++q) cr[q] = *(const double2 *)(cg + 2 * (t + q * FTH));
         for (int i = t; i < FNEAR; i += FTH) gn[i] = T.gnear[i];
@@ -642,7 +718,7 @@ __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict_
             *(double2 *)(ca + (i2 >> 3) * FS + 2 * (i2 & 7)) = cr[q];
         }
     }
-    __syncthreads();
+    fmm_lds_barrier();
     FSTAMP(2, 1);
     // ---- wave = (16 leaves G, target parity e relative to the leaf's first sample) ---------------------------------------------------------
     const int n16 = lane & 15, gq = lane >> 4;
@@ -717,7 +793,7 @@ __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict_
     }
     FSTAMP(2, 3);
     if (OUT != 2) return;
-    __syncthreads();                                    // every near field has read its samples: the envelope takes their place
+    fmm_lds_barrier();                                    // every near field has read its samples: the envelope takes their place
     static_assert(FLV * 2 * FS * 8 >= WFX_SEL_BINS * 4, "the histogram fits where the coefficients were");
     for (int i = t; i < WFX_SEL_BINS; i += FTH) h0[i] = 0;
 #pragma unroll
@@ -727,7 +803,7 @@ __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict_
             const int tau = 2 * (16 * I + gq + 4 * r) + e;
             if (tau < s0) xp[tau] = res[4 * I + r];
         }
-    __syncthreads();
+    fmm_lds_barrier();
     FSTAMP(2, 4);
     {
         const long long wa = fmm_leaf_first(g, leaf0), wb = fmm_leaf_first(g, leaf0 + FLV);   // the workgroup's own samples [wa, wb)
@@ -747,10 +823,10 @@ __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict_
             }
             if (l0hist) wfx_sel_count(h0, (unsigned)(wfx_f64_key(m) >> 53), valid, lane);
         }
-        if (t < 8) edge[(size_t)blockIdx.x * 8 + t] = t < 4 ? ew[t] : ew[own - 8 + t];
+        if (t < 8) edge[(size_t)blk * 8 + t] = t < 4 ? ew[t] : ew[own - 8 + t];
     }
     if (l0hist) {
-        __syncthreads();
+        fmm_lds_barrier();
         for (int i = t; i < WFX_SEL_BINS; i += FTH)
             if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
     }
@@ -768,7 +844,7 @@ __global__ void __launch_bounds__(256) fmm_edge_median(const fmm_geom g, const d
     const bool act = b < nwg - 1;
     if (l0hist)
         for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
-    __syncthreads();
+    fmm_lds_barrier();
     double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
     if (act) {
         const long long pos = fmm_leaf_first(g, (long long)(b + 1) * FLV);         // first sample of workgroup b + 1
@@ -787,7 +863,7 @@ __global__ void __launch_bounds__(256) fmm_edge_median(const fmm_geom g, const d
         wfx_sel_count(h0, (unsigned)(wfx_f64_key(m1) >> 53), act, t & 63);
         wfx_sel_count(h0, (unsigned)(wfx_f64_key(m2) >> 53), act, t & 63);
         wfx_sel_count(h0, (unsigned)(wfx_f64_key(m3) >> 53), act, t & 63);
-        __syncthreads();
+        fmm_lds_barrier();
         for (int i = t; i < WFX_SEL_BINS; i += 256)
             if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
     }
@@ -856,7 +932,7 @@ __global__ void __launch_bounds__(FTH, 2) fmm_up_leaf2(const double *__restrict_
     double cwa[FP];                                     // A operands: Cw[k][row], the same for the four quarters
 #pragma unroll
     for (int kk = 0; kk < FP; ++kk) cwa[kk] = T.Cw[kk * FP + n16];
-    __syncthreads();
+    fmm_lds_barrier();
     FSTAMP(0, 1);
     double mu[FP];
 #pragma unroll
@@ -895,7 +971,7 @@ __global__ void __launch_bounds__(FTH, 2) fmm_up_leaf2(const double *__restrict_
     double *src = wb0, *dst = wb1;
 #pragma unroll 1
     for (int d = FW - 1; d >= 0; --d) {
-        __syncthreads();
+        fmm_lds_barrier();
         FSTAMP(0, 3 + (FW - 1 - d));
         fmm_up_level_mfma(src, dst, Wg + fmm_box(g.L - FW + d, (long long)blockIdx.x << d) * 2 * FP, ajr, d, wave, lane);
         double *tmp = src;
@@ -961,12 +1037,7 @@ __global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict_
             if (j < own + 2 * NOTCH_K + 8) rw[j] = (src >= 0 && src < g.n) ? pre[q] : (TIN)0;
         }
     }
-    double ajr[2][4];
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ajr[cc][ks] = T.Aj[cc * FP * FP + 64 * ks + lane];
-    __syncthreads();
+    fmm_lds_barrier();
     FSTAMP(0, 1);
     if (8 * t < own) {
         // window element i feeds output u with tap |i - u - K|: ascending i for every output, as notch_kernel sums
@@ -990,7 +1061,7 @@ __global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict_
 #pragma unroll
         for (int u = 0; u < 8; ++u) xw[8 * t + u] = acc[u];
     }
-    __syncthreads();
+    fmm_lds_barrier();
     // the capture's first / last 64 samples: exact forward / backward recurrences on the odd extension (notch_kernel's edge workgroup)
     if (wa < NOTCH_EDGE || wb > g.n - NOTCH_EDGE) {
         constexpr int EL = NOTCH_EDGE + NOTCH_SETTLE, LEN = NOTCH_PAD + EL;     // 127, 136
@@ -999,7 +1070,7 @@ __global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict_
         for (int i = t; i < LEN; i += FTH)
             e[i] = left ? (i < NOTCH_PAD ? notch_left<TIN>(c, raw, NOTCH_PAD - i) : (double)raw[i - NOTCH_PAD])
                         : (i < EL ? (double)raw[g.n - EL + i] : notch_right<TIN>(c, raw, (uint64_t)g.n, i - EL + 1));
-        __syncthreads();
+        fmm_lds_barrier();
         if (t == 0) {
             // left: exact forward start, backward started SETTLE samples to the right with a zero state
             // right: forward started SETTLE samples early with a zero state, exact backward start
@@ -1025,14 +1096,14 @@ __global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict_
                 for (int k = 0; k < 8; ++k) e[i0 + k] = v[k];
             }
         }
-        __syncthreads();
+        fmm_lds_barrier();
         if (t < NOTCH_EDGE) {
             if (left)
                 xw[t] = e[NOTCH_PAD + t];
             else
                 xw[(int)(g.n - NOTCH_EDGE - wa) + t] = e[EL - NOTCH_EDGE + t];
         }
-        __syncthreads();
+        fmm_lds_barrier();
     }
     FSTAMP(0, 2);
     for (int i = t; i < own; i += FTH) y[wa + i] = xw[i];
@@ -1080,10 +1151,15 @@ __global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict_
             go[4 * r] = acc[r];
         }
     }
+    double ajr[2][4];                                   // (requested here, not at the top: the filter and P2M phases need the registers)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ajr[cc][ks] = T.Aj[cc * FP * FP + 64 * ks + lane];
     double *src = wb0, *dst = wb1;
 #pragma unroll 1
     for (int d = FW - 1; d >= 0; --d) {
-        __syncthreads();
+        fmm_lds_barrier();
         FSTAMP(0, 4 + (FW - 1 - d));
         fmm_up_level_mfma(src, dst, Wg + fmm_box(g.L - FW + d, (long long)blockIdx.x << d) * 2 * FP, ajr, d, wave, lane);
         double *tmp = src;
@@ -1112,7 +1188,7 @@ __global__ void __launch_bounds__(FTH) fmm_up_tier2(const fmm_geom g, const fmm_
     double *src = b0, *dst = b1;
 #pragma unroll 1
     for (int d = D - 1; d >= 0; --d) {
-        __syncthreads();
+        fmm_lds_barrier();
         fmm_up_level_mfma(src, dst, Wg + fmm_box(a + d, (long long)blockIdx.x << d) * 2 * FP, ajr, d, wave, lane);
         double *tmp = src;
         src = dst;
@@ -1124,31 +1200,23 @@ __global__ void __launch_bounds__(FTH) fmm_down_tier2(const fmm_geom g, const fm
 {
     __shared__ __align__(16) double la[(1 << FTD) * 2 * FS], lb[(1 << (FTD - 1)) * 2 * FS], un[FWALL];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    fmm_load_walls(un, Wg, a, D, t);
+    fmm_load_walls(un, Wg, a, D, t, blockIdx.x);
     double atr[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
-    double *src = la, *dst = lb;
-    if (t < 2 * FP) src[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(a, blockIdx.x) * 2 * FP + t];
-    double gs[3][3][4];                                 // (three sets in rotation, requested two levels ahead: fmm_tree_leaf)
-    fmm_ga_load(T.G + (size_t)(a + 1 - 2) * 4 * FP * FP, wave & 1, lane, gs[1]);
-    if (D >= 2) fmm_ga_load(T.G + (size_t)(a + 2 - 2) * 4 * FP * FP, wave & 1, lane, gs[2]);
-    int woff = 0;
-#pragma unroll
-    for (int d = 1; d <= FTD; ++d) {
-        if (d <= D) {
-            if (d + 2 <= D) fmm_ga_load(T.G + (size_t)(a + d + 2 - 2) * 4 * FP * FP, wave & 1, lane, gs[(d + 2) % 3]);
-            __syncthreads();
-            fmm_down_level_mfma(src, dst, un + woff, gs[d % 3], atr, d, wave, lane, nullptr);
-            woff += ((1 << d) + 2 * FHB) * 2 * FS;
-            double *tmp = src;
-            src = dst;
-            dst = tmp;
-        }
+    if (t < 2 * FP) la[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(a, blockIdx.x) * 2 * FP + t];
+    {
+        const int lv0 = a;
+        FMM_DOWN_CHAIN(D, nullptr)
     }
-    __syncthreads();
+    double *src = (D & 1) ? lb : la;                    // (level d writes lb for odd d)
+    fmm_lds_barrier();
     double *o = Lg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
-    for (int i2 = t; i2 < ((2 * FP / 2) << D); i2 += FTH) *(double2 *)(o + 2 * i2) = *(const double2 *)(src + (i2 >> 3) * FS + 2 * (i2 & 7));
+    const int lparts = fmm_level_split(D) ? 4 : 1, lstr = (1 << D) * 2 * FS;
+    for (int i2 = t; i2 < ((2 * FP / 2) << D); i2 += FTH) {
+        const double *p = src + (i2 >> 3) * FS + 2 * (i2 & 7);
+        *(double2 *)(o + 2 * i2) = make_double2(fmm_lsum(p, lparts, lstr), fmm_lsum(p + 1, lparts, lstr));
+    }
 }
 
 // the top: levels 2 .. atop (<= 5), one workgroup.  M2M up to level 2 with every level's weights kept in LDS (halo slots filled round the
@@ -1157,7 +1225,7 @@ __global__ void __launch_bounds__(FTH) fmm_top2(const fmm_geom g, const fmm_tabs
 {
     constexpr int WLV = (32 + 2 * FHB) * 2 * FS;        // one level's weights, halo slots included
     __shared__ __align__(16) double wl[4][WLV];         // levels 2 .. 5
-    __shared__ __align__(16) double la[32 * 2 * FS], lb[32 * 2 * FS];
+    __shared__ __align__(16) double la[64 * 2 * FS], lb[64 * 2 * FS];          // (levels 3 and 4 leave four partial arrays: fmm_down_level_mfma)
     __shared__ double w2[(4 + 2 * FHB) * 2 * FP], l2[4 * 2 * FP], Ats[2 * FP * FP], Gs[4 * FP * FP];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double ajr[2][4], atr[4];
@@ -1172,10 +1240,10 @@ __global__ void __launch_bounds__(FTH) fmm_top2(const fmm_geom g, const fmm_tabs
     const int ntop = 1 << atop;
     for (int i = t; i < ntop * 2 * FP; i += FTH) wl[atop - 2][(FHB * 2 + (i >> 4)) * FS + (i & 15)] = Wg[fmm_box(atop, 0) * 2 * FP + i];
     for (int lev = atop - 1; lev >= 2; --lev) {
-        __syncthreads();
+        fmm_lds_barrier();
         fmm_up_level_mfma(&wl[lev + 1 - 2][FHB * 2 * FS], &wl[lev - 2][FHB * 2 * FS], Wg + fmm_box(lev, 0) * 2 * FP, ajr, lev, wave, lane);
     }
-    __syncthreads();
+    fmm_lds_barrier();
     // halo slots of every level (three boxes before the first and behind the last, round the circle); level 2 also in the scalar routine's layout
     for (int lev = 2; lev <= atop; ++lev) {
         const int nb = 1 << lev;
@@ -1187,31 +1255,37 @@ __global__ void __launch_bounds__(FTH) fmm_top2(const fmm_geom g, const fmm_tabs
             w[(slot * 2 + (vv & 1)) * FS + (i & 15)] = w[((sb + FHB) * 2 + (vv & 1)) * FS + (i & 15)];
         }
     }
-    __syncthreads();
+    fmm_lds_barrier();
     for (int i = t; i < (4 + 2 * FHB) * 2 * FP; i += FTH) w2[i] = wl[0][(i >> 4) * FS + (i & 15)];
-    __syncthreads();
+    fmm_lds_barrier();
     fmm_down_level<FTH>(nullptr, l2, w2, Gs, Ats, 0, 4, 4, t);
-    __syncthreads();
+    fmm_lds_barrier();
     for (int i = t; i < 4 * 2 * FP; i += FTH) la[(i >> 4) * FS + (i & 15)] = l2[i];
-    double *src = la, *dst = lb;
+    double *src = la;
     {
-        double gs[3][3][4];                             // levels 3, 4, 5: all requested at once
-#pragma unroll
-        for (int lev = 3; lev <= 5; ++lev)
-            if (lev <= atop) fmm_ga_load(T.G + (size_t)(lev - 2) * 4 * FP * FP, wave & 1, lane, gs[lev - 3]);
-#pragma unroll
-        for (int lev = 3; lev <= 5; ++lev) {
-            if (lev <= atop) {
-                __syncthreads();
-                fmm_down_level_mfma(src, dst, wl[lev - 2], gs[lev - 3], atr, lev, wave, lane, nullptr);
-                double *tmp = src;
-                src = dst;
-                dst = tmp;
-            }
+        double g3[3][4], g4[3][4], g5[3][4];            // levels 3, 4, 5: all requested at once
+        if (3 <= atop) fmm_ga_load(T.G + (size_t)(3 - 2) * 4 * FP * FP, wave & 1, lane, g3);
+        if (4 <= atop) fmm_ga_load(T.G + (size_t)(4 - 2) * 4 * FP * FP, wave & 1, lane, g4);
+        if (5 <= atop) fmm_ga_load(T.G + (size_t)(5 - 2) * 4 * FP * FP, wave & 1, lane, g5);
+        if (3 <= atop) {
+            fmm_lds_barrier();
+            fmm_down_level_mfma<3>(la, 1, 0, lb, wl[1], g3, atr, wave, lane, nullptr);
+            src = lb;
+        }
+        if (4 <= atop) {
+            fmm_lds_barrier();
+            fmm_down_level_mfma<4>(lb, fmm_level_split(3) ? 4 : 1, 8 * 2 * FS, la, wl[2], g4, atr, wave, lane, nullptr);
+            src = la;
+        }
+        if (5 <= atop) {
+            fmm_lds_barrier();
+            fmm_down_level_mfma<5>(la, fmm_level_split(4) ? 4 : 1, 16 * 2 * FS, lb, wl[3], g5, atr, wave, lane, nullptr);
+            src = lb;
         }
     }
-    __syncthreads();
-    for (int i = t; i < ntop * 2 * FP; i += FTH) Lg[fmm_box(atop, 0) * 2 * FP + i] = src[(i >> 4) * FS + (i & 15)];
+    fmm_lds_barrier();
+    const int lparts = (atop >= 3 && fmm_level_split(atop)) ? 4 : 1, lstr = ntop * 2 * FS;
+    for (int i = t; i < ntop * 2 * FP; i += FTH) Lg[fmm_box(atop, 0) * 2 * FP + i] = fmm_lsum(src + (i >> 4) * FS + (i & 15), lparts, lstr);
 }
 
 // ---- host: tables -------------------------------------------------------------------------------------------------------------------
@@ -1397,16 +1471,18 @@ static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind,
     wfx_prof_end(ctx);
     wfx_prof_begin(ctx, K_FFT_INV);
     if (leaf_v == 2) {
-        hipLaunchKernelGGL(fmm_tree_leaf, dim3(nwg), dim3(FTH), lds_tree, ctx->stream, g, T, (const double *)Wg, (const double *)Lg, Cg);
-        wfx_prof_end(ctx);
-        wfx_prof_begin(ctx, K_ENV_MEDIAN);
-        if (out_mode == 2) {
-            hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, l0hist);
-            if (nwg > 1) hipLaunchKernelGGL(fmm_edge_median, dim3((nwg + 255) / 256), dim3(256), 0, ctx->stream, g, (const double *)Eg, out, l0hist, (int)nwg);
-        } else if (out_mode == 1)
-            hipLaunchKernelGGL(fmm_leaf_env<1>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, (unsigned *)nullptr);
+        // (measured and not kept: the leaf workgroups in four chunks, chunk c's leaf kernel on a second queue beside chunk c + 1's tree kernel --
+        // the tree kernel waits, the leaf kernel issues -- 165 us against 133 us one after the other: a chunk is a single round of workgroups
+        // with its full tail, and the queues' events cost more than the overlap gives)
+        hipLaunchKernelGGL(fmm_tree_leaf, dim3(nwg), dim3(FTH), lds_tree, ctx->stream, g, T, (const double *)Wg, (const double *)Lg, Cg, 0);
+        if (out_mode == 2)
+            hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, l0hist, 0);
+        else if (out_mode == 1)
+            hipLaunchKernelGGL(fmm_leaf_env<1>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, (unsigned *)nullptr, 0);
         else
-            hipLaunchKernelGGL(fmm_leaf_env<0>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, (unsigned *)nullptr);
+            hipLaunchKernelGGL(fmm_leaf_env<0>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, (unsigned *)nullptr, 0);
+        if (out_mode == 2 && nwg > 1)
+            hipLaunchKernelGGL(fmm_edge_median, dim3((nwg + 255) / 256), dim3(256), 0, ctx->stream, g, (const double *)Eg, out, l0hist, (int)nwg);
     } else {
         if (out_mode == 2) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fmm: the fused median needs the matrix-core kernels");
         if (out_mode)
