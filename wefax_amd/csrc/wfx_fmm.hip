@@ -60,137 +60,6 @@ struct fmm_tabs {
     const double *gnear;    // [FNEAR]: cot(pi d / n), d = 2 q - 255
 };
 
-// M2M of one level inside LDS: nb parents from 2 nb children ([box][parity][16]); As = [2][16 i][16 j]
-template <int NT>
-__device__ __forceinline__ void fmm_m2m_level(const double *src, double *dst, const double *As, int nb, int t, double *gout)
-{
-    for (int it = t; it < nb * 2 * FP; it += NT) {
-        const int j = it & 15, hh = (it >> 4) & 1, bb = it >> 5;
-        const double *c0 = src + ((2 * bb) * 2 + hh) * FP, *c1 = c0 + 2 * FP;
-        double w = 0.0;
-#pragma unroll
-        for (int i = 0; i < FP; ++i) w = fma(As[i * FP + j], c0[i], fma(As[FP * FP + i * FP + j], c1[i], w));
-        dst[it] = w;
-        gout[it] = w;
-    }
-}
-
-// ---- P2M + M2M: a workgroup = 64 consecutive leaves -------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FTH, 4) fmm_up_leaf(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg)
-{
-    extern __shared__ __align__(16) double fl[];
-    double *scr = fl;                                   // [8 waves][8 rows][FROW]
-    double *pw = scr + 8 * 8 * FROW;                    // [8 waves][8 rows][2][4]
-    double *mus = pw + 8 * 64;                          // [8 waves][2][16]
-    double *wb0 = mus + 8 * 32;                         // [64][2][16]
-    double *wb1 = wb0 + FLV * 2 * FP;                   // [32][2][16]
-    double *As = wb1 + (FLV / 2) * 2 * FP;              // [2][16][16] i-major
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, l = lane & 31;
-    for (int i = t; i < 2 * FP * FP; i += FTH) As[i] = T.Aj[i];
-    double *ws = scr + wave * 8 * FROW, *pww = pw + wave * 64, *mw = mus + wave * 32;
-    double cw[FP];                                      // this lane's column of Cw (j = l & 15)
-#pragma unroll
-    for (int k = 0; k < FP; ++k) cw[k] = T.Cw[k * FP + (l & 15)];
-    const long long leaf0 = (long long)blockIdx.x * FLV;
-    constexpr int LPW = FLV / 8;                        // leaves per wave
-    // the first leaf's sample; the next one's is requested a step ahead
-    auto sample_of = [&](long long k, long long &m, bool &valid) {
-        const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1);
-        m = a + ((h - a) & 1) + 2 * l;                  // lanes 0-31: even samples of the leaf, 32-63: odd ones
-        valid = m < b;
-    };
-    long long m_cur;
-    bool v_cur;
-    sample_of(leaf0 + wave * LPW, m_cur, v_cur);
-    double x_cur = v_cur ? x[m_cur] : 0.0;
-    for (int q = 0; q < LPW; ++q) {
-        const int lk = wave * LPW + q;
-        const long long k = leaf0 + lk;
-        long long m_nxt = 0;
-        bool v_nxt = false;
-        double x_nxt = 0.0;
-        if (q + 1 < LPW) {
-            sample_of(k + 1, m_nxt, v_nxt);
-            x_nxt = v_nxt ? x[m_nxt] : 0.0;
-        }
-        const long long r = (m_cur << g.L) - k * g.n;   // position inside the leaf in units of 2^-L samples: [0, n)
-        const double u = v_cur ? 2.0 * ((double)r / (double)g.n) - 1.0 : 0.0;
-        const double xv = x_cur;
-        double tk[FP];
-        tk[0] = xv;
-        tk[1] = u * xv;
-        {
-            double t0 = 1.0, t1 = u;
-#pragma unroll
-            for (int kk = 2; kk < FP; ++kk) {
-                const double t2 = fma(2.0 * u, t1, -t0);
-                tk[kk] = t2 * xv;
-                t0 = t1;
-                t1 = t2;
-            }
-        }
-        // moments mu_k = sum over the half's 32 lanes of tk[k], eight k at a time: rows to LDS, (row, quarter) partial sums, four-way join
-#pragma unroll
-        for (int round = 0; round < 2; ++round) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) ws[kk * FROW + lane] = tk[8 * round + kk];
-            __builtin_amdgcn_wave_barrier();
-            const int row = l & 7, quarter = l >> 3;
-            const double *rp = ws + row * FROW + 32 * h + 8 * quarter;
-            double part = 0.0;
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) part += rp[s2];
-            pww[(row * 2 + h) * 4 + quarter] = part;
-            __builtin_amdgcn_wave_barrier();
-            if (l < 8) {
-                const double *pp = pww + (l * 2 + h) * 4;
-                mw[h * FP + 8 * round + l] = (pp[0] + pp[1]) + (pp[2] + pp[3]);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (l < FP) {
-            double w = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < FP; ++kk) w = fma(cw[kk], mw[h * FP + kk], w);
-            wb0[(lk * 2 + h) * FP + l] = w;
-            Wg[(fmm_box(g.L, k) * 2 + h) * FP + l] = w;
-        }
-        __builtin_amdgcn_wave_barrier();
-        m_cur = m_nxt;
-        v_cur = v_nxt;
-        x_cur = x_nxt;
-    }
-    // M2M: six levels inside the subtree, in LDS; every level also goes to memory
-    double *src = wb0, *dst = wb1;
-    for (int d = 1; d <= FW; ++d) {
-        __syncthreads();
-        const int nb = FLV >> d;
-        fmm_m2m_level<FTH>(src, dst, As, nb, t, Wg + fmm_box(g.L - d, (long long)blockIdx.x * nb) * 2 * FP);
-        double *tmp = src;
-        src = dst;
-        dst = tmp;
-    }
-}
-
-// ---- a tier between the leaf workgroups and the top, upwards: a workgroup = the subtree of depth D under box `root` of level a --------------
-__global__ void __launch_bounds__(256) fmm_up_tier(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, int a, int D)
-{
-    __shared__ double b0[(1 << FTD) * 2 * FP], b1[(1 << (FTD - 1)) * 2 * FP], As[2 * FP * FP];
-    const int t = threadIdx.x;
-    for (int i = t; i < 2 * FP * FP; i += 256) As[i] = T.Aj[i];
-    const double *ch = Wg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
-    for (int i = t; i < (2 * FP) << D; i += 256) b0[i] = ch[i];
-    double *src = b0, *dst = b1;
-    for (int d = 1; d <= D; ++d) {
-        __syncthreads();
-        const int nb = 1 << (D - d);
-        fmm_m2m_level<256>(src, dst, As, nb, t, Wg + fmm_box(a + D - d, (long long)blockIdx.x * nb) * 2 * FP);
-        double *tmp = src;
-        src = dst;
-        dst = tmp;
-    }
-}
-
 // L2L + M2L of one level into `dst` ([box][parity][16]) for the nb boxes b0 .. b0 + nb of a level with nbl boxes.  `lsrc`: the parents' values;
 // `wst`: weights of boxes b0 - 3 .. b0 + nb + 3 (wrapped round the circle by whoever loaded them), [slot][parity][16]; `Gs`: the level's
 // M2L matrices [r - 2][2][16][16]; `At`: [2][16 j][16 i].  Lanes run over the target node i.
@@ -229,191 +98,6 @@ __device__ __forceinline__ void fmm_down_level(const double *lsrc, double *dst, 
     }
 }
 
-// weights of boxes b0 - 3 .. b0 + nb + 3 of a level with nbl boxes into LDS, round the circle
-template <int NT>
-__device__ __forceinline__ void fmm_load_halo(double *wst, const double *Wlev, long long b0, int nb, long long nbl, int t)
-{
-    for (int i = t; i < (nb + 2 * FHB) * 2 * FP; i += NT) {
-        const long long sb = (b0 - FHB + (i >> 5) + nbl) & (nbl - 1);
-        wst[i] = Wlev[sb * 2 * FP + (i & 31)];
-    }
-}
-
-// ---- the top of the tree: levels 2 .. atop (<= 5), one workgroup ------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) fmm_top(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, double *__restrict__ Lg, int atop)
-{
-    __shared__ double wall[64 * 2 * FP];                // weights of levels 2 .. atop at their global box index
-    __shared__ double wst[(32 + 2 * FHB) * 2 * FP];
-    __shared__ double la[32 * 2 * FP], lb[32 * 2 * FP], As[2 * FP * FP], At[2 * FP * FP], Gs[4 * FP * FP];
-    const int t = threadIdx.x;
-    for (int i = t; i < 2 * FP * FP; i += 256) {
-        As[i] = T.Aj[i];
-        At[i] = T.At[i];
-    }
-    const int ntop = 1 << atop;
-    for (int i = t; i < ntop * 2 * FP; i += 256) wall[fmm_box(atop, 0) * 2 * FP + i] = Wg[fmm_box(atop, 0) * 2 * FP + i];
-    for (int lev = atop - 1; lev >= 2; --lev) {
-        __syncthreads();
-        fmm_m2m_level<256>(wall + fmm_box(lev + 1, 0) * 2 * FP, wall + fmm_box(lev, 0) * 2 * FP, As, 1 << lev, t, Wg + fmm_box(lev, 0) * 2 * FP);
-    }
-    double *src = nullptr, *dst = la;
-    for (int lev = 2; lev <= atop; ++lev) {
-        __syncthreads();
-        const int nb = 1 << lev;
-        for (int i = t; i < 4 * FP * FP; i += 256) Gs[i] = T.G[(size_t)(lev - 2) * 4 * FP * FP + i];
-        for (int i = t; i < (nb + 2 * FHB) * 2 * FP; i += 256) wst[i] = wall[(fmm_box(lev, ((i >> 5) - FHB + nb) & (nb - 1))) * 2 * FP + (i & 31)];
-        __syncthreads();
-        fmm_down_level<256>(src, dst, wst, Gs, At, 0, nb, nb, t);
-        src = dst;
-        dst = dst == la ? lb : la;
-    }
-    __syncthreads();
-    for (int i = t; i < ntop * 2 * FP; i += 256) Lg[fmm_box(atop, 0) * 2 * FP + i] = src[i];
-}
-
-// ---- a tier downwards: from the local expansion of box `root` of level a to those of its 2^D descendants of level a + D --------------------------
-__global__ void __launch_bounds__(256) fmm_down_tier(const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg, double *__restrict__ Lg, int a, int D)
-{
-    __shared__ double la[(1 << FTD) * 2 * FP], lb[(1 << (FTD - 1)) * 2 * FP], wst[((1 << FTD) + 2 * FHB) * 2 * FP], At[2 * FP * FP], Gs[4 * FP * FP];
-    const int t = threadIdx.x;
-    for (int i = t; i < 2 * FP * FP; i += 256) At[i] = T.At[i];
-    double *src = (D & 1) ? lb : la, *dst = (D & 1) ? la : lb;          // (the last level ends in `la`)
-    if (t < 2 * FP) src[t] = Lg[fmm_box(a, blockIdx.x) * 2 * FP + t];
-    for (int d = 1; d <= D; ++d) {
-        const int lev = a + d, nb = 1 << d;
-        const long long nbl = 1ll << lev, b0 = (long long)blockIdx.x << d;
-        __syncthreads();
-        for (int i = t; i < 4 * FP * FP; i += 256) Gs[i] = T.G[(size_t)(lev - 2) * 4 * FP * FP + i];
-        fmm_load_halo<256>(wst, Wg + fmm_box(lev, 0) * 2 * FP, b0, nb, nbl, t);
-        __syncthreads();
-        fmm_down_level<256>(src, dst, wst, Gs, At, b0, nb, nbl, t);
-        double *tmp = src;
-        src = dst;
-        dst = tmp;
-    }
-    __syncthreads();
-    double *o = Lg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
-    for (int i = t; i < (2 * FP) << D; i += 256) o[i] = src[i];
-}
-
-// ---- L2L + M2L inside a leaf subtree, then the leaves -----------------------------------------------------------------------------------
-template <int OUT_ENV>
-__global__ void __launch_bounds__(FTH, 4) fmm_down_leaf(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg,
-                                                        const double *__restrict__ Lg, double *__restrict__ out)
-{
-    extern __shared__ __align__(16) double fl[];
-    double *la = fl;                                    // [64][2][16]
-    double *lb = la + FLV * 2 * FP;                     // [32][2][16]
-    double *At = lb + (FLV / 2) * 2 * FP;               // [2][16 j][16 i]
-    double *gn = At + 2 * FP * FP;                      // [FNEAR]
-    double *un = gn + FNEAR;                            // the tree phase: weights of a level + its M2L matrices; the leaf phase: the sample window
-    double *wst = un, *Gs = un + (FLV + 2 * FHB) * 2 * FP;
-    double *xw = un;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, l = lane & 31;
-    const long long leaf0 = (long long)blockIdx.x * FLV, nleaf = 1ll << g.L;
-    // the workgroup's samples -- its 64 leaves and one more on either side, round the circle -- are requested now and wait in registers
-    // until the tree phase is through with the LDS they go to
-    const long long km = leaf0 == 0 ? nleaf - 1 : leaf0 - 1;
-    const long long w0 = fmm_leaf_first(g, km) - (leaf0 == 0 ? g.n : 0);                       // may be negative
-    const long long kl = leaf0 + FLV == nleaf ? 0 : leaf0 + FLV;                              // the leaf behind the last one
-    const long long w1 = (leaf0 + FLV == nleaf ? g.n : 0) + fmm_leaf_first(g, kl + 1);
-    const int wlen = (int)(w1 - w0);                                                            // <= FXW
-    constexpr int XPT = (FXW + FTH - 1) / FTH;
-    double xr[XPT];
-#pragma unroll
-    for (int q = 0; q < XPT; ++q) {
-        const int idx = t + q * FTH;
-        long long m = w0 + idx;
-        m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
-        xr[q] = idx < wlen ? x[m] : 0.0;
-    }
-    for (int i = t; i < 2 * FP * FP; i += FTH) At[i] = T.At[i];
-    for (int i = t; i < FNEAR; i += FTH) gn[i] = T.gnear[i];
-    const int ltop = g.L - FW;
-    static_assert((FW & 1) == 0, "root in the large buffer: an even number of levels later the leaf level is there again");
-    double *src = la, *dst = lb;
-    if (t < 2 * FP) src[t] = Lg[fmm_box(ltop, blockIdx.x) * 2 * FP + t];
-    for (int d = 1; d <= FW; ++d) {
-        const int lev = ltop + d, nb = 1 << d;
-        const long long nbl = 1ll << lev, b0 = (long long)blockIdx.x << d;
-        __syncthreads();
-        for (int i = t; i < 4 * FP * FP; i += FTH) Gs[i] = T.G[(size_t)(lev - 2) * 4 * FP * FP + i];
-        fmm_load_halo<FTH>(wst, Wg + fmm_box(lev, 0) * 2 * FP, b0, nb, nbl, t);
-        __syncthreads();
-        fmm_down_level<FTH>(src, dst, wst, Gs, At, b0, nb, nbl, t);
-        double *tmp = src;
-        src = dst;
-        dst = tmp;
-    }
-    __syncthreads();                                    // (src == la: the 64 leaves' nodal values)
-    // nodal values -> Chebyshev coefficients, in place (one lane per leaf and parity)
-    for (int it = t; it < FLV * 2; it += FTH) {
-        double *p = la + it * FP;
-        double v[FP], c[FP];
-#pragma unroll
-        for (int j = 0; j < FP; ++j) v[j] = p[j];
-#pragma unroll
-        for (int k = 0; k < FP; ++k) {
-            double s2 = 0.0;
-#pragma unroll
-            for (int j = 0; j < FP; ++j) s2 = fma(T.Ca[j * FP + k], v[j], s2);
-            c[k] = s2;
-        }
-#pragma unroll
-        for (int k = 0; k < FP; ++k) p[k] = c[k];
-    }
-    // the samples take the place of the tree phase's weights
-#pragma unroll
-    for (int q = 0; q < XPT; ++q) {
-        const int idx = t + q * FTH;
-        if (idx < FXW) xw[idx] = xr[q];
-    }
-    __syncthreads();
-    constexpr int LPW = FLV / 8;
-    for (int q = 0; q < LPW; ++q) {
-        const int lk = wave * LPW + q;
-        const long long k = leaf0 + lk;
-        // unwrapped sample positions (fmm_leaf_first continues round the circle: leaf -1 starts at a negative position, leaf 2^L at n)
-        const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1), ws0 = fmm_leaf_first(g, k - 1), we = fmm_leaf_first(g, k + 2);
-        const long long m = a + ((h - a) & 1) + 2 * l;   // lanes 0-31: even samples of the leaf, 32-63: odd ones
-        const bool valid = m < b;
-        const long long r = (m << g.L) - k * g.n;
-        const double u = valid ? 2.0 * ((double)r / (double)g.n) - 1.0 : 0.0;
-        // far field: sum_k a_k T_k(u)
-        const double *ac = la + (lk * 2 + h) * FP;
-        double t0 = 1.0, t1 = u, far = fma(ac[1], u, ac[0]);
-#pragma unroll
-        for (int kk = 2; kk < FP; ++kk) {
-            const double t2 = fma(2.0 * u, t1, -t0);
-            far = fma(ac[kk], t2, far);
-            t0 = t1;
-            t1 = t2;
-        }
-        // near field: every sample of the OTHER parity in leaves k - 1 .. k + 1, kernel from the table of odd lags
-        const long long ps0 = ws0 + (((1 - h) - ws0) & 1);
-        const int cnt = (int)((we - ps0 + 1) >> 1);
-        const double *sp = xw + (ps0 - w0);
-        int gi = (int)((m - ps0 + (FNEAR - 1)) >> 1);
-        double n0 = 0.0, n1 = 0.0;
-        int s2 = 0;
-        for (; s2 + 1 < cnt; s2 += 2) {
-            n0 = fma(gn[gi], sp[2 * s2], n0);
-            n1 = fma(gn[gi - 1], sp[2 * s2 + 2], n1);
-            gi -= 2;
-        }
-        if (s2 < cnt) n0 = fma(gn[gi], sp[2 * s2], n0);
-        const double H = g.scale * (far + (n0 + n1));
-        if (valid) {
-            if (OUT_ENV) {
-                const double xv = xw[m - w0];
-                out[m] = sqrt(fma(xv, xv, H * H));
-            } else {
-                out[m] = H;
-            }
-        }
-    }
-}
-
 // ---- the leaf phase on the matrix cores (round 6) ----------------------------------------------------------------------------------------
 // The near field of 16 leaves at once is ONE Toeplitz product: with sources and targets counted from the target leaf's first sample
 // (tau = 2 (16 I + i) + e, sigma = sigma0 + 2 (4 K + k)) the tap cot(pi (tau - sigma) / n) does not depend on the leaf, so
@@ -444,16 +128,6 @@ __device__ unsigned long long fmm_stamp_buf[3][4096 * 16];
 constexpr int FS = 18;                      // LDS stride of a box's 16 numbers per parity (16 would put the 16 columns of an operand read into one bank pair)
 constexpr int FWALL = ((2 << FW) - 2 + FW * 2 * FHB) * 2 * FS;      // every level's weights of a leaf workgroup's subtree, halos included (doubles)
 static_assert(FWALL >= FXW + FXP0 + FXP1, "the sample window takes the place of the tree phase's weights");
-
-// weights of boxes b0 - 3 .. b0 + nb + 3 of a level with nbl boxes into LDS (padded stride), round the circle
-template <int NT>
-__device__ __forceinline__ void fmm_load_halo_p(double *wst, const double *Wlev, long long b0, int nb, long long nbl, int t)
-{
-    for (int i = t; i < (nb + 2 * FHB) * 2 * FP; i += NT) {
-        const long long sb = (b0 - FHB + (i >> 5) + nbl) & (nbl - 1);
-        wst[(i >> 4) * FS + (i & 15)] = Wlev[sb * 2 * FP + (i & 31)];
-    }
-}
 
 // the M2L matrices of one level for the boxes of parity class c as A operands: offsets (-2, +2, +3) for even boxes, (-3, -2, +2) for odd ones;
 // r = -offset selects G_|r| (r > 0) or -G_|r| transposed (r < 0).  Every matrix of the tables is stored [K index][row], so a lane's A operand
@@ -496,7 +170,7 @@ __device__ __forceinline__ void fmm_down_level_mfma(const double *src, int spart
     const int nb = 1 << d, half = nb >> 1;
     const int col = lane & 15, kq = lane >> 4;
     const int c = wave & 1;
-    if (d >= 5) {
+    if constexpr (d >= 5) {
         const int ng = half >> 4;                       // groups of 16 boxes per class: 1 or 2
         if (wave >= 4 * ng) return;
         const int rest = wave >> 1;
@@ -676,8 +350,10 @@ __global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf(const fmm_geom g, const 
 // workgroup in `edge`.  scipy.signal.medfilt pads with ZEROS at the capture's ends: those four medians are complete here.
 template <int OUT>
 __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Cg,
-                                                       double *__restrict__ out, int smax, int xcap, double *__restrict__ edge, unsigned *__restrict__ l0hist, int wg0)
+                                                       double *__restrict__ out, int smax, int xcap, double *__restrict__ edge, unsigned *__restrict__ l0hist, int wg0, int xwrap)
 {
+    // xwrap 0 (a rank of a sharded decode): x is addressed by the UNWRAPPED sample index -- the leaf before the rank's first (for rank 0: the
+    // capture's last) and the one behind its last lie in front of / behind its own samples in memory
     const long long blk = (long long)blockIdx.x + wg0;
     extern __shared__ __align__(16) double fl[];
     double *ca = fl;                                    // [64][2][FS]: Chebyshev coefficients of the leaves' far fields
@@ -699,7 +375,7 @@ __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict_
         for (int q = 0; q < XPT; ++q) {
             const int idx = t + q * FTH;
             long long m = w0 + idx;
-            m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
+            if (xwrap) m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
             xr[q] = idx < wlen ? x[m] : 0.0;
         }
         double2 cr[(FLV * 2 * FP / 2) / FTH];
@@ -835,16 +511,19 @@ __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict_
 
 // medians across the seam of workgroups b and b + 1 of fmm_leaf_env<2> (positions end - 2, end - 1, end, end + 1): one thread per seam
 __global__ void __launch_bounds__(256) fmm_edge_median(const fmm_geom g, const double *__restrict__ edge, double *__restrict__ out, unsigned *__restrict__ l0hist,
-                                                       int nwg)
+                                                       int b_lo, int b_hi, int own_lo, int own_hi)
 {
+    // seams b in [b_lo, b_hi): between workgroups b and b + 1.  A rank of a sharded decode writes (and counts) only the medians of workgroups
+    // it owns, [own_lo, own_hi): a seam with a neighbour rank is done half by either side (the neighbour's four values arrived in `edge`).
     // (the histogram goes through LDS with one atomic per wave and digit: 8 000 global atomics on a handful of bins took 69 us)
     __shared__ unsigned h0[WFX_SEL_BINS];
     const int t = threadIdx.x;
-    const int b = blockIdx.x * 256 + t;
-    const bool act = b < nwg - 1;
+    const int b = b_lo + blockIdx.x * 256 + t;
+    const bool act = b < b_hi;
+    const bool wl = act && b >= own_lo && b < own_hi, wr = act && b + 1 >= own_lo && b + 1 < own_hi;
     if (l0hist)
         for (int i = t; i < WFX_SEL_BINS; i += 256) h0[i] = 0;
-    fmm_lds_barrier();
+    __syncthreads();
     double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
     if (act) {
         const long long pos = fmm_leaf_first(g, (long long)(b + 1) * FLV);         // first sample of workgroup b + 1
@@ -853,17 +532,21 @@ __global__ void __launch_bounds__(256) fmm_edge_median(const fmm_geom g, const d
         m1 = wfx_median5(l[1], l[2], l[3], f[0], f[1]);
         m2 = wfx_median5(l[2], l[3], f[0], f[1], f[2]);
         m3 = wfx_median5(l[3], f[0], f[1], f[2], f[3]);
-        out[pos - 2] = m0;
-        out[pos - 1] = m1;
-        out[pos] = m2;
-        out[pos + 1] = m3;
+        if (wl) {
+            out[pos - 2] = m0;
+            out[pos - 1] = m1;
+        }
+        if (wr) {
+            out[pos] = m2;
+            out[pos + 1] = m3;
+        }
     }
     if (l0hist) {
-        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m0) >> 53), act, t & 63);
-        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m1) >> 53), act, t & 63);
-        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m2) >> 53), act, t & 63);
-        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m3) >> 53), act, t & 63);
-        fmm_lds_barrier();
+        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m0) >> 53), wl, t & 63);
+        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m1) >> 53), wl, t & 63);
+        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m2) >> 53), wr, t & 63);
+        wfx_sel_count(h0, (unsigned)(wfx_f64_key(m3) >> 53), wr, t & 63);
+        __syncthreads();
         for (int i = t; i < WFX_SEL_BINS; i += 256)
             if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
     }
@@ -1008,7 +691,7 @@ template <> struct up3_win<double> {
 
 template <typename TIN, int MINW>
 __global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict__ raw, const notch_coef c, double *__restrict__ y, const fmm_geom g, const fmm_tabs T,
-                                                           double *__restrict__ Wg, int xc, wfx_dev_scalars *__restrict__ clear)
+                                                           double *__restrict__ Wg, int xc, wfx_dev_scalars *__restrict__ clear, int wg0)
 {
     extern __shared__ __align__(16) double fl[];
     double *wb0 = fl;                                   // [64][2][FS]; before P2M: the raw window (int16 capture) and the edge routine's scratch
@@ -1016,7 +699,8 @@ __global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict_
     double *wb1 = xw;                                   // [32][2][FS]
     TIN *rw = sizeof(TIN) == 2 ? (TIN *)wb0 : (TIN *)(xw + xc);        // raw[wa - 24 .. wb + 24) (a float64 capture has its own region)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long long leaf0 = (long long)blockIdx.x * FLV;
+    const long long blk = (long long)blockIdx.x + wg0;               // (a rank of a sharded decode launches its own workgroups only)
+    const long long leaf0 = blk * FLV;
     const long long wa = fmm_leaf_first(g, leaf0), wb = fmm_leaf_first(g, leaf0 + FLV);
     const int own = (int)(wb - wa);
     FSTAMP(0, 0);
@@ -1161,7 +845,7 @@ __global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict_
     for (int d = FW - 1; d >= 0; --d) {
         fmm_lds_barrier();
         FSTAMP(0, 4 + (FW - 1 - d));
-        fmm_up_level_mfma(src, dst, Wg + fmm_box(g.L - FW + d, (long long)blockIdx.x << d) * 2 * FP, ajr, d, wave, lane);
+        fmm_up_level_mfma(src, dst, Wg + fmm_box(g.L - FW + d, blk << d) * 2 * FP, ajr, d, wave, lane);
         double *tmp = src;
         src = dst;
         dst = tmp;
@@ -1169,8 +853,9 @@ __global__ void __launch_bounds__(FTH, MINW) fmm_up_leaf3(const TIN *__restrict_
 }
 
 // ---- the tiers and the top of the tree on the matrix cores (512 threads; the same level routines as the leaf kernels) --------------------
-__global__ void __launch_bounds__(FTH) fmm_up_tier2(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, int a, int D)
+__global__ void __launch_bounds__(FTH) fmm_up_tier2(const fmm_geom g, const fmm_tabs T, double *__restrict__ Wg, int a, int D, int box0)
 {
+    const long long blk = (long long)blockIdx.x + box0;
     __shared__ __align__(16) double b0[(1 << FTD) * 2 * FS], b1[(1 << (FTD - 1)) * 2 * FS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double ajr[2][4];
@@ -1178,7 +863,7 @@ __global__ void __launch_bounds__(FTH) fmm_up_tier2(const fmm_geom g, const fmm_
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) ajr[c][ks] = T.Aj[c * FP * FP + 64 * ks + lane];
-    const double *ch = Wg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
+    const double *ch = Wg + fmm_box(a + D, blk << D) * 2 * FP;
     constexpr int NQ = ((1 << FTD) * 2 * FP / 2) / FTH;        // pairs per thread: 2
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -1189,29 +874,30 @@ __global__ void __launch_bounds__(FTH) fmm_up_tier2(const fmm_geom g, const fmm_
 #pragma unroll 1
     for (int d = D - 1; d >= 0; --d) {
         fmm_lds_barrier();
-        fmm_up_level_mfma(src, dst, Wg + fmm_box(a + d, (long long)blockIdx.x << d) * 2 * FP, ajr, d, wave, lane);
+        fmm_up_level_mfma(src, dst, Wg + fmm_box(a + d, blk << d) * 2 * FP, ajr, d, wave, lane);
         double *tmp = src;
         src = dst;
         dst = tmp;
     }
 }
 
-__global__ void __launch_bounds__(FTH) fmm_down_tier2(const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg, double *__restrict__ Lg, int a, int D)
+__global__ void __launch_bounds__(FTH) fmm_down_tier2(const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg, double *__restrict__ Lg, int a, int D, int box0)
 {
+    const long long blk = (long long)blockIdx.x + box0;
     __shared__ __align__(16) double la[(1 << FTD) * 2 * FS], lb[(1 << (FTD - 1)) * 2 * FS], un[FWALL];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    fmm_load_walls(un, Wg, a, D, t, blockIdx.x);
+    fmm_load_walls(un, Wg, a, D, t, blk);
     double atr[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
-    if (t < 2 * FP) la[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(a, blockIdx.x) * 2 * FP + t];
+    if (t < 2 * FP) la[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(a, blk) * 2 * FP + t];
     {
         const int lv0 = a;
         FMM_DOWN_CHAIN(D, nullptr)
     }
     double *src = (D & 1) ? lb : la;                    // (level d writes lb for odd d)
     fmm_lds_barrier();
-    double *o = Lg + fmm_box(a + D, (long long)blockIdx.x << D) * 2 * FP;
+    double *o = Lg + fmm_box(a + D, blk << D) * 2 * FP;
     const int lparts = fmm_level_split(D) ? 4 : 1, lstr = (1 << D) * 2 * FS;
     for (int i2 = t; i2 < ((2 * FP / 2) << D); i2 += FTH) {
         const double *p = src + (i2 >> 3) * FS + 2 * (i2 & 7);
@@ -1341,18 +1027,34 @@ static double cot_unit(double z, int lev)
 
 }   // namespace
 
-// env_raw[i] = |x[i] + i H[i]| (out_env) or H itself, for an even n large enough for the tree; *handled = 0 otherwise (the caller
-// runs the transform path)
-// x != nullptr: the filtered capture is given.  x == nullptr: `raw` (int16 or float64 mono) goes through the notch inside the first kernel, which
-// leaves the filtered capture in `audio` (wefax.py:63-72 + 174-175 in four leaf-level passes over the capture's bytes)
-static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind, const notch_coef *nc, double *audio, wfx_dev_scalars *clear, uint64_t n, double *out,
-                   int out_mode, unsigned *l0hist, int *handled)
+// ---- host -------------------------------------------------------------------------------------------------------------------------------
+// Everything a run needs for a capture of n samples: geometry, device tables (cached per n), work arrays (whole-capture size: a rank of a
+// sharded decode uses its own part and the boxes it receives), tiers, LDS sizes.  handled = 0: a length this form does not take (odd, short,
+// too long).
+struct fmm_plan {
+    fmm_geom g;
+    fmm_tabs T;
+    int L = 0, smax = 0, xcap = 0, xc3 = 0, ntier = 0, tier_a[8], tier_d[8], atop = 0;
+    unsigned nwg = 0;
+    double *Wg = nullptr, *Lg = nullptr, *Cg = nullptr, *Eg = nullptr;
+    size_t lds_tree = 0, lds_leaf = 0, lds_up2 = 0, lds_up3_i16 = 0, lds_up3_f64 = 0;
+};
+
+static bool fmm_levels(uint64_t n, int *L_out)
 {
-    *handled = 0;
-    if (n % 2 || n < 32768 || n > (1ull << 32)) return 0;
+    if (n % 2 || n < 32768 || n > (1ull << 32)) return false;
     int L = 0;
     while (((double)n / (double)(1ull << L)) > 64.0) ++L;                 // leaf size in (32, 64]
-    if (L < FW + 2 || L > 26) return 0;                                   // ((sample << L) stays inside 63 bits; at least level 2 above the leaf roots)
+    if (L < FW + 2 || L > 26) return false;                               // ((sample << L) stays inside 63 bits; at least level 2 above the leaf roots)
+    *L_out = L;
+    return true;
+}
+
+static int fmm_setup(wfx_ctx *ctx, uint64_t n, fmm_plan &P, int *handled)
+{
+    *handled = 0;
+    int L = 0;
+    if (!fmm_levels(n, &L)) return 0;
     // device tables, cached per n: the static ones, the M2L matrices of levels 2..L (unit kernel), the near table of THIS n
     const double *dt = nullptr;
     for (auto &e : ctx->fmm_tables)
@@ -1388,108 +1090,120 @@ static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind,
         ctx->fmm_tables.push_back({n, (const double *)dev});
         dt = (const double *)dev;
     }
-    fmm_tabs T;
-    T.At = dt;
-    T.Aj = dt + 2 * FP * FP;
-    T.Cw = dt + 4 * FP * FP;
-    T.Ca = dt + 5 * FP * FP;
-    T.G = dt + off_g;
-    T.gnear = dt + off_n;
-    fmm_geom g;
-    g.n = (long long)n;
-    g.L = L;
-    g.scale = 2.0 / (double)n;
-    g.du = ldexp(2.0, L) / (double)n;
+    P.T.At = dt;
+    P.T.Aj = dt + 2 * FP * FP;
+    P.T.Cw = dt + 4 * FP * FP;
+    P.T.Ca = dt + 5 * FP * FP;
+    P.T.G = dt + off_g;
+    P.T.gnear = dt + off_n;
+    P.g.n = (long long)n;
+    P.g.L = L;
+    P.g.scale = 2.0 / (double)n;
+    P.g.du = ldexp(2.0, L) / (double)n;
+    P.L = L;
     const size_t nbox = (size_t)1 << (L + 1);                             // all levels
     WFX_TRY(wfx_reserve(ctx, ctx->b_work, nbox * 2 * FP * 8));           // weights W
-    const unsigned nwg = 1u << (L - FW);
+    P.nwg = 1u << (L - FW);
     const size_t lg_doubles = ((size_t)1 << (L - FW + 1)) * 2 * FP + 8, cg_doubles = ((size_t)1 << L) * 2 * FP;
     // local expansions down to the leaf workgroups' roots | the leaves' far fields as Chebyshev coefficients | eight envelope values per workgroup
-    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (lg_doubles + cg_doubles + (size_t)nwg * 8) * 8 + 64));
-    double *Wg = (double *)ctx->b_work.p, *Lg = (double *)ctx->b_work2.p, *Cg = Lg + lg_doubles, *Eg = Cg + cg_doubles;
-    const size_t lds_up = (size_t)(8 * 8 * FROW + 8 * 64 + 8 * 32 + FLV * 2 * FP + (FLV / 2) * 2 * FP + 2 * FP * FP) * 8;
-    const size_t lds_dn = (size_t)(FLV * 2 * FP + (FLV / 2) * 2 * FP + 2 * FP * FP + FNEAR + FXW) * 8;
-    const size_t lds_tree = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FWALL) * 8;
-    const int smax = (int)((n + ((1ull << L) - 1)) >> L);                  // the largest leaf
-    const int xcap = std::min(FXW, ((FLV + 2) * smax + 1) & ~1);             // the leaf kernel's sample window: 64 leaves and one more on either side
-    const size_t lds_leaf = (size_t)(FLV * 2 * FS + FNEAR + FXP0 + xcap + FXP1) * 8;      // 49 776 bytes for leaves of <= 55 samples: three workgroups per CU
-    const size_t lds_up2 = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FLV * 64) * 8;
-    const int xc3 = FLV * smax;                                             // the fused notch kernel's sample window
-    const size_t lds_up3_i16 = (size_t)(FLV * 2 * FS + xc3) * 8, lds_up3_f64 = lds_up3_i16 + (size_t)(xc3 + 2 * NOTCH_K + 8) * 8;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_work2, (lg_doubles + cg_doubles + (size_t)P.nwg * 8) * 8 + 64));
+    P.Wg = (double *)ctx->b_work.p;
+    P.Lg = (double *)ctx->b_work2.p;
+    P.Cg = P.Lg + lg_doubles;
+    P.Eg = P.Cg + cg_doubles;
+    P.smax = (int)((n + ((1ull << L) - 1)) >> L);                         // the largest leaf
+    P.xcap = std::min(FXW, ((FLV + 2) * P.smax + 1) & ~1);                // the leaf kernel's sample window: 64 leaves and one more on either side
+    P.xc3 = FLV * P.smax;                                                 // the fused notch kernel's
+    P.lds_tree = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FWALL) * 8;
+    P.lds_leaf = (size_t)(FLV * 2 * FS + FNEAR + FXP0 + P.xcap + FXP1) * 8;      // 49 776 bytes for leaves of <= 55 samples: three workgroups per CU
+    P.lds_up2 = (size_t)(FLV * 2 * FS + (FLV / 2) * 2 * FS + FLV * 64) * 8;
+    P.lds_up3_i16 = (size_t)(FLV * 2 * FS + P.xc3) * 8;
+    P.lds_up3_f64 = P.lds_up3_i16 + (size_t)(P.xc3 + 2 * NOTCH_K + 8) * 8;
     const size_t lds_up3_max = (size_t)(FLV * 2 * FS + FLV * 64 + FLV * 64 + 2 * NOTCH_K + 8) * 8;
-    static_assert(FXW >= (FLV + 2 * FHB) * 2 * FP + 4 * FP * FP, "the sample window is also the tree phase's staging area");
     const size_t lds_leaf_max = (size_t)(FLV * 2 * FS + FNEAR + FXP0 + FXW + FXP1) * 8;
     static bool attr_done = false;
     if (!attr_done) {
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_down_leaf<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dn));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up2));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_up2));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf3<short, UP3W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up3_max));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf3<double, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up3_max));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tree));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_tree));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
         attr_done = true;
     }
     // tiers between the leaf workgroups' roots (level L - 6) and the top (levels 2 .. atop <= 5): at most six levels each
-    int tier_a[8], tier_d[8], ntier = 0, cur = L - FW;
+    int cur = L - FW;
+    P.ntier = 0;
     while (cur > 5) {
         const int D = std::min(FTD, cur - 2);
-        tier_a[ntier] = cur - D;
-        tier_d[ntier] = D;
-        ++ntier;
+        P.tier_a[P.ntier] = cur - D;
+        P.tier_d[P.ntier] = D;
+        ++P.ntier;
         cur -= D;
     }
-    const int atop = cur;
-    static const int leaf_v = getenv("WFX_FMM_LEAF") ? atoi(getenv("WFX_FMM_LEAF")) : 2;
-    wfx_prof_begin(ctx, K_FFT_FWD);
+    P.atop = cur;
+    *handled = 1;
+    return 0;
+}
+
+// notch + P2M + M2M of the leaf workgroups [wg_lo, wg_hi) (x == nullptr: from the raw capture `raw`, index = sample number; else from the
+// filtered capture x), all levels' weights to memory
+static void fmm_launch_up(wfx_ctx *ctx, const fmm_plan &P, const double *x, const void *raw, int raw_kind, const notch_coef *nc, double *audio,
+                          wfx_dev_scalars *clear, unsigned wg_lo, unsigned wg_hi)
+{
+    const unsigned cnt = wg_hi - wg_lo;
+    if (!cnt) return;
     if (!x) {
         if (raw_kind == WFX_IN_I16_MONO)
-            hipLaunchKernelGGL((fmm_up_leaf3<short, UP3W>), dim3(nwg), dim3(FTH), lds_up3_i16, ctx->stream, (const short *)raw, *nc, audio, g, T, Wg, xc3, clear);
+            hipLaunchKernelGGL((fmm_up_leaf3<short, UP3W>), dim3(cnt), dim3(FTH), P.lds_up3_i16, ctx->stream, (const short *)raw, *nc, audio, P.g, P.T, P.Wg, P.xc3,
+                               clear, (int)wg_lo);
         else
-            hipLaunchKernelGGL((fmm_up_leaf3<double, 4>), dim3(nwg), dim3(FTH), lds_up3_f64, ctx->stream, (const double *)raw, *nc, audio, g, T, Wg, xc3, clear);
-        x = audio;
-    } else if (leaf_v == 2)
-        hipLaunchKernelGGL(fmm_up_leaf2, dim3(nwg), dim3(FTH), lds_up2, ctx->stream, x, g, T, Wg);
-    else
-        hipLaunchKernelGGL(fmm_up_leaf, dim3(nwg), dim3(FTH), lds_up, ctx->stream, x, g, T, Wg);
+            hipLaunchKernelGGL((fmm_up_leaf3<double, 4>), dim3(cnt), dim3(FTH), P.lds_up3_f64, ctx->stream, (const double *)raw, *nc, audio, P.g, P.T, P.Wg, P.xc3,
+                               clear, (int)wg_lo);
+    } else {
+        hipLaunchKernelGGL(fmm_up_leaf2, dim3(cnt), dim3(FTH), P.lds_up2, ctx->stream, x, P.g, P.T, P.Wg);       // (whole capture only)
+    }
+}
+
+// x != nullptr: the filtered capture is given.  x == nullptr: `raw` (int16 or float64 mono) goes through the notch inside the first kernel, which
+// leaves the filtered capture in `audio` (wefax.py:63-72 + 174-175 in four leaf-level passes over the capture's bytes)
+static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind, const notch_coef *nc, double *audio, wfx_dev_scalars *clear, uint64_t n, double *out,
+                   int out_mode, unsigned *l0hist, int *handled)
+{
+    fmm_plan P;
+    WFX_TRY(fmm_setup(ctx, n, P, handled));
+    if (!*handled) return 0;
+    *handled = 0;
+    const unsigned nwg = P.nwg;
+    wfx_prof_begin(ctx, K_FFT_FWD);
+    fmm_launch_up(ctx, P, x, raw, raw_kind, nc, audio, clear, 0, nwg);
+    if (!x) x = audio;
     wfx_prof_end(ctx);
     wfx_prof_begin(ctx, K_BS_CHIRP);
-    if (leaf_v == 2) {
-        for (int k = 0; k < ntier; ++k) hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << tier_a[k]), dim3(FTH), 0, ctx->stream, g, T, Wg, tier_a[k], tier_d[k]);
-        hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, g, T, Wg, Lg, atop);
-        for (int k = ntier - 1; k >= 0; --k)
-            hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << tier_a[k]), dim3(FTH), 0, ctx->stream, g, T, (const double *)Wg, Lg, tier_a[k], tier_d[k]);
-    } else {
-        for (int k = 0; k < ntier; ++k) hipLaunchKernelGGL(fmm_up_tier, dim3(1u << tier_a[k]), dim3(256), 0, ctx->stream, g, T, Wg, tier_a[k], tier_d[k]);
-        hipLaunchKernelGGL(fmm_top, dim3(1), dim3(256), 0, ctx->stream, g, T, Wg, Lg, atop);
-        for (int k = ntier - 1; k >= 0; --k)
-            hipLaunchKernelGGL(fmm_down_tier, dim3(1u << tier_a[k]), dim3(256), 0, ctx->stream, g, T, (const double *)Wg, Lg, tier_a[k], tier_d[k]);
-    }
+    for (int k = 0; k < P.ntier; ++k)
+        hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[k], P.tier_d[k], 0);
+    hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.Lg, P.atop);
+    for (int k = P.ntier - 1; k >= 0; --k)
+        hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
     wfx_prof_end(ctx);
     wfx_prof_begin(ctx, K_FFT_INV);
-    if (leaf_v == 2) {
-        // (measured and not kept: the leaf workgroups in four chunks, chunk c's leaf kernel on a second queue beside chunk c + 1's tree kernel --
-        // the tree kernel waits, the leaf kernel issues -- 165 us against 133 us one after the other: a chunk is a single round of workgroups
-        // with its full tail, and the queues' events cost more than the overlap gives)
-        hipLaunchKernelGGL(fmm_tree_leaf, dim3(nwg), dim3(FTH), lds_tree, ctx->stream, g, T, (const double *)Wg, (const double *)Lg, Cg, 0);
-        if (out_mode == 2)
-            hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, l0hist, 0);
-        else if (out_mode == 1)
-            hipLaunchKernelGGL(fmm_leaf_env<1>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, (unsigned *)nullptr, 0);
-        else
-            hipLaunchKernelGGL(fmm_leaf_env<0>, dim3(nwg), dim3(FTH), lds_leaf, ctx->stream, x, g, T, (const double *)Cg, out, smax, xcap, Eg, (unsigned *)nullptr, 0);
-        if (out_mode == 2 && nwg > 1)
-            hipLaunchKernelGGL(fmm_edge_median, dim3((nwg + 255) / 256), dim3(256), 0, ctx->stream, g, (const double *)Eg, out, l0hist, (int)nwg);
-    } else {
-        if (out_mode == 2) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fmm: the fused median needs the matrix-core kernels");
-        if (out_mode)
-            hipLaunchKernelGGL(fmm_down_leaf<1>, dim3(nwg), dim3(FTH), lds_dn, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out);
-        else
-            hipLaunchKernelGGL(fmm_down_leaf<0>, dim3(nwg), dim3(FTH), lds_dn, ctx->stream, x, g, T, (const double *)Wg, (const double *)Lg, out);
-    }
+    // (measured and not kept: the leaf workgroups in four chunks, chunk c's leaf kernel on a second queue beside chunk c + 1's tree kernel --
+    // the tree kernel waits, the leaf kernel issues -- 165 us against 133 us one after the other: a chunk is a single round of workgroups
+    // with its full tail, and the queues' events cost more than the overlap gives)
+    hipLaunchKernelGGL(fmm_tree_leaf, dim3(nwg), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, 0);
+    wfx_prof_end(ctx);
+    wfx_prof_begin(ctx, K_ENV_MEDIAN);
+    if (out_mode == 2)
+        hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(nwg), dim3(FTH), P.lds_leaf, ctx->stream, x, P.g, P.T, (const double *)P.Cg, out, P.smax, P.xcap, P.Eg, l0hist, 0, 1);
+    else if (out_mode == 1)
+        hipLaunchKernelGGL(fmm_leaf_env<1>, dim3(nwg), dim3(FTH), P.lds_leaf, ctx->stream, x, P.g, P.T, (const double *)P.Cg, out, P.smax, P.xcap, P.Eg,
+                           (unsigned *)nullptr, 0, 1);
+    else
+        hipLaunchKernelGGL(fmm_leaf_env<0>, dim3(nwg), dim3(FTH), P.lds_leaf, ctx->stream, x, P.g, P.T, (const double *)P.Cg, out, P.smax, P.xcap, P.Eg,
+                           (unsigned *)nullptr, 0, 1);
+    if (out_mode == 2 && nwg > 1)
+        hipLaunchKernelGGL(fmm_edge_median, dim3((nwg + 254) / 256), dim3(256), 0, ctx->stream, P.g, (const double *)P.Eg, out, l0hist, 0, (int)nwg - 1, 0, (int)nwg);
     wfx_prof_end(ctx);
 #ifdef WFX_FMM_STAMPS
     {
@@ -1535,4 +1249,124 @@ int wfx_dev_notch_hilbert_fmm(wfx_ctx *ctx, const void *in, int in_kind, uint64_
     notch_coef c;
     notch_prepare(c, b, a, ext18);
     return fmm_run(ctx, nullptr, in, in_kind, &c, audio, clear, n, env, 2, l0hist, handled);
+}
+
+// ---- one capture over several GPUs: every rank runs the leaf-level kernels on its own workgroups, the top of the tree is computed by all ----
+// (wfx_shard.hip, plan 3).  The tree's geometry depends on n only, never on the world size, and every box is computed by
+// the same kernel from the same numbers wherever it is computed: the results are identical for every world size, and to the one-GPU run's.
+//   gather level lg = the deepest tier's top (the leaf workgroups' roots when there is no tier): ranks own whole boxes of that level --
+//   [gb_lo, gb_hi) -- hence the leaf workgroups [gb_lo, gb_hi) << (L - 6 - lg).  Exchanged: the weights of level lg (all-gather: 2^lg boxes of
+//   256 bytes), per finer level the three boxes beyond either end of a rank's range, and four envelope values per seam between ranks.
+int wfx_fmm_shard_geometry(uint64_t n, wfx_fmm_shard_geo *geo)
+{
+    int L = 0;
+    if (!fmm_levels(n, &L)) return -1;
+    int cur = L - FW, lg = cur;
+    if (cur > 5) lg = cur - std::min(FTD, cur - 2);                       // the top of the first (deepest) tier
+    geo->L = L;
+    geo->ltop = L - FW;
+    geo->lg = lg;
+    geo->smax = (int)((n + ((1ull << L) - 1)) >> L);
+    return 0;
+}
+
+long long wfx_fmm_leaf_first_host(uint64_t n, int L, long long k) { return (k * (long long)n + ((1ll << L) - 1)) >> L; }
+
+// device address of box b of level lev in the weights array (2 x 16 doubles per box); the array is (re)allocated by the first call for this n
+int wfx_fmm_shard_weights(wfx_ctx *ctx, uint64_t n, int lev, long long b, double **ptr)
+{
+    fmm_plan P;
+    int handled = 0;
+    WFX_TRY(fmm_setup(ctx, n, P, &handled));
+    if (!handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fmm: no multipole form for %llu samples", (unsigned long long)n);
+    *ptr = P.Wg + fmm_box(lev, b) * 2 * FP;
+    return 0;
+}
+
+int wfx_fmm_shard_edges(wfx_ctx *ctx, uint64_t n, long long wg, double **ptr)
+{
+    fmm_plan P;
+    int handled = 0;
+    WFX_TRY(fmm_setup(ctx, n, P, &handled));
+    if (!handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fmm: no multipole form for %llu samples", (unsigned long long)n);
+    *ptr = P.Eg + (size_t)wg * 8;
+    return 0;
+}
+
+// phase A: notch + P2M + M2M of the rank's leaf workgroups, then its own boxes of the deepest tier up to the gather level.  raw_index0 /
+// audio_index0: the sample number of raw[0] / audio[0] (the rank's buffers hold its own range and a halo)
+int wfx_fmm_shard_up(wfx_ctx *ctx, const void *raw, long long raw_index0, int raw_kind, const double b[3], const double a[3], const double *ext18, double *audio,
+                     long long audio_index0, uint64_t n, long long gb_lo, long long gb_hi, wfx_dev_scalars *clear)
+{
+    fmm_plan P;
+    int handled = 0;
+    WFX_TRY(fmm_setup(ctx, n, P, &handled));
+    if (!handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fmm: no multipole form for %llu samples", (unsigned long long)n);
+    if (raw_kind != WFX_IN_I16_MONO && raw_kind != WFX_IN_F64_MONO) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fmm: input kind %d", raw_kind);
+    notch_coef c;
+    notch_prepare(c, b, a, ext18);
+    wfx_fmm_shard_geo geo;
+    wfx_fmm_shard_geometry(n, &geo);
+    const int sh = geo.ltop - geo.lg;
+    const void *raw0 = raw_kind == WFX_IN_I16_MONO ? (const void *)((const short *)raw - raw_index0) : (const void *)((const double *)raw - raw_index0);
+    fmm_launch_up(ctx, P, nullptr, raw0, raw_kind, &c, audio - audio_index0, clear, (unsigned)(gb_lo << sh), (unsigned)(gb_hi << sh));
+    if (sh > 0 && gb_hi > gb_lo)
+        hipLaunchKernelGGL(fmm_up_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[0], P.tier_d[0], (int)gb_lo);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
+    return 0;
+}
+
+// phase B (the weights of level lg of ALL ranks and the halo boxes of the finer levels have arrived): the top of the tree (every rank the same),
+// the rank's part of the deepest tier downwards, tree and leaf kernels of its workgroups.  audio as in phase A, with one filtered leaf in
+// front of and behind the rank's own samples; env[0] = the envelope of sample env_index0.  Leaves the medians of all positions but two at
+// either end of every workgroup (wfx_fmm_shard_seams) and the level-0 histogram of what it wrote.
+int wfx_fmm_shard_down(wfx_ctx *ctx, const double *audio, long long audio_index0, uint64_t n, long long gb_lo, long long gb_hi, double *env, long long env_index0,
+                       unsigned *l0hist)
+{
+    fmm_plan P;
+    int handled = 0;
+    WFX_TRY(fmm_setup(ctx, n, P, &handled));
+    if (!handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fmm: no multipole form for %llu samples", (unsigned long long)n);
+    wfx_fmm_shard_geo geo;
+    wfx_fmm_shard_geometry(n, &geo);
+    const int sh = geo.ltop - geo.lg;
+    for (int k = 1; k < P.ntier; ++k)
+        hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[k], P.tier_d[k], 0);
+    hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.Lg, P.atop);
+    for (int k = P.ntier - 1; k >= 1; --k)
+        hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
+    const unsigned wg_lo = (unsigned)(gb_lo << sh), wg_hi = (unsigned)(gb_hi << sh);
+    if (wg_hi > wg_lo) {
+        if (sh > 0)
+            hipLaunchKernelGGL(fmm_down_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[0], P.tier_d[0],
+                               (int)gb_lo);
+        hipLaunchKernelGGL(fmm_tree_leaf, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, (int)wg_lo);
+        hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_leaf, ctx->stream, audio - audio_index0, P.g, P.T, (const double *)P.Cg,
+                           env - env_index0, P.smax, P.xcap, P.Eg, l0hist, (int)wg_lo, 0);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
+    return 0;
+}
+
+// phase C (the neighbours' four envelope values at either end of the rank's range have arrived): the medians at the seams of workgroups
+int wfx_fmm_shard_seams(wfx_ctx *ctx, uint64_t n, long long gb_lo, long long gb_hi, double *env, long long env_index0, unsigned *l0hist)
+{
+    fmm_plan P;
+    int handled = 0;
+    WFX_TRY(fmm_setup(ctx, n, P, &handled));
+    if (!handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "fmm: no multipole form for %llu samples", (unsigned long long)n);
+    wfx_fmm_shard_geo geo;
+    wfx_fmm_shard_geometry(n, &geo);
+    const int sh = geo.ltop - geo.lg;
+    const int wg_lo = (int)(gb_lo << sh), wg_hi = (int)(gb_hi << sh);
+    if (wg_hi <= wg_lo) return 0;
+    const int b_lo = wg_lo > 0 ? wg_lo - 1 : 0, b_hi = wg_hi < (int)P.nwg ? wg_hi : (int)P.nwg - 1;       // seams b: between workgroups b and b + 1
+    if (b_hi > b_lo)
+        hipLaunchKernelGGL(fmm_edge_median, dim3((unsigned)(b_hi - b_lo + 255) / 256), dim3(256), 0, ctx->stream, P.g, (const double *)P.Eg, env - env_index0, l0hist,
+                           b_lo, b_hi, wg_lo, wg_hi);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
+    return 0;
 }

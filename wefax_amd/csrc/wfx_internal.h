@@ -410,6 +410,19 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
 // wfx_fmm.hip: |x + i H| (out_env) or H = imag(scipy.signal.hilbert(x)) for even n by near field + fast multipole far field; *handled = 0
 // for lengths it does not take (odd, short)
 int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, int out_mode, unsigned *l0hist, int *handled);
+// one capture over several GPUs by the multipole form (wfx_shard.hip plan 3; the kernels are wfx_fmm.hip's)
+struct wfx_fmm_shard_geo {
+    int L, ltop, lg, smax;       // levels; the leaf workgroups' roots; the gather level (ranks own whole boxes of it); the largest leaf
+};
+int wfx_fmm_shard_geometry(uint64_t n, wfx_fmm_shard_geo *geo);      // host only; -1: no multipole form for n
+long long wfx_fmm_leaf_first_host(uint64_t n, int L, long long k);   // first sample of leaf k
+int wfx_fmm_shard_weights(wfx_ctx *ctx, uint64_t n, int lev, long long b, double **ptr);
+int wfx_fmm_shard_edges(wfx_ctx *ctx, uint64_t n, long long wg, double **ptr);
+int wfx_fmm_shard_up(wfx_ctx *ctx, const void *raw, long long raw_index0, int raw_kind, const double b[3], const double a[3], const double *ext18, double *audio,
+                     long long audio_index0, uint64_t n, long long gb_lo, long long gb_hi, wfx_dev_scalars *clear);
+int wfx_fmm_shard_down(wfx_ctx *ctx, const double *audio, long long audio_index0, uint64_t n, long long gb_lo, long long gb_hi, double *env, long long env_index0,
+                       unsigned *l0hist);
+int wfx_fmm_shard_seams(wfx_ctx *ctx, uint64_t n, long long gb_lo, long long gb_hi, double *env, long long env_index0, unsigned *l0hist);
 int wfx_dev_notch_hilbert_fmm(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], const double *ext18, double *audio,
                               double *env, unsigned *l0hist, wfx_dev_scalars *clear, int *handled);      // a6 + a7 in one chain of kernels (wfx_fmm.hip)   // out_mode 0: H, 1: |x + iH|, 2: its 5-tap median + level-0 histogram of the select
 
