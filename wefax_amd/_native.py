@@ -131,6 +131,8 @@ class ShardLayout(C.Structure):
     @property
     def in_frames(self) -> int:
         """Frames the rank hands over (segments with their halos, back to back)."""
+        if self.plan == 3:      # chunk-local multipole plan: one range with `in_halo` frames round the circle on either side
+            return int(self.in_hi - self.in_lo) + 2 * int(self.in_halo)
         return int(self.nseg) * (int(self.in_seg_len) + 2 * int(self.in_halo)) if self.nseg > 1 else int(self.in_hi - self.in_lo)
 
     @property
@@ -146,6 +148,8 @@ class ShardLayout(C.Structure):
 
     def in_index(self) -> "np.ndarray":
         """Global frame indices of the frames the rank hands over (may lie outside the capture: provide anything there)."""
+        if self.plan == 3:      # (negative / beyond the capture: take them modulo its length -- the halo wraps)
+            return np.arange(int(self.in_lo) - int(self.in_halo), int(self.in_hi) + int(self.in_halo), dtype=np.int64)
         if self.nseg <= 1:
             return np.arange(int(self.in_lo), int(self.in_hi), dtype=np.int64)
         h = int(self.in_halo)

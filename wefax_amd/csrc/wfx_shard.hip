@@ -33,6 +33,9 @@
 #define SH_VHALO 2          // points of the Hilbert transform delivered beyond the own rows
 #define SH_HALO_END 192     // columns layout of a PADDED form: the capture ends inside a segment, and filtfilt's exact edge there
                             // is made of the last 127 samples -- the ranks whose own samples lie within 64 of the end must see it
+#define SH_FMM_HR 320       // plan 3: raw samples handed over beyond the own range on either side, round the circle (a leaf of <= 64 for the near field + the
+                            // notch's 24 taps; at the capture's ends the exact filtfilt edge is made of 127 + 9 samples and the segment form wants >= 254)
+#define SH_FMM_HF (SH_FMM_HR - 24)      // filtered samples kept beyond the own range
 #define SH_CAND_CAP 4096    // least number of candidate keys per query and rank that travel in the all-gather
 
 struct shard_plan {
@@ -79,6 +82,12 @@ struct shard_plan {
     // the communicator's own stream) overlapping the passes of another.  4 where the first radix has enough outputs for
     // world * 4 subsets, 1 with one rank; WFX_SHARD_CHUNKS overrides (every rank must see the same value)
     int nchunk = 1;
+    // plan 3 (round 6): chunk-local fast multipole Hilbert transform (wfx_fmm.hip) -- every rank runs the leaf-level kernels on its own
+    // boxes of the gather level `fg.lg` (hence a contiguous range of leaf workgroups, hence of samples); what travels is the gather level's
+    // weights, three boxes per finer level and side, four envelope values per seam -- then the select's collectives and the one gather
+    bool fmm = false;
+    wfx_fmm_shard_geo fg{};
+    long long gb_lo = 0, gb_hi = 0;
     // the cost model's verdict
     int forced = 0;
     double model_single = 0, model_comp = 0, model_wire = 0;
@@ -169,10 +178,37 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         pl.seg_hi = pl.own_hi;
         return 0;
     };
-    const int want = p->shard_plan & 15;               // 0 auto, 1 distributed, 2 single
+    const int want = p->shard_plan & 15;               // 0 auto, 1 distributed, 2 single, 3 chunk-local multipole form
     const bool want_rows = (p->shard_plan & 16) != 0 || getenv("WFX_SHARD_ROWS") != nullptr;
     pl.forced = want != 0;
     if (want == 2) return single("asked for by the caller (wfx_decode_params.shard_plan)");
+    if (want == 3) {
+        // ---- plan 3: the capture cut into contiguous ranges of leaf workgroups of the multipole tree (geometry: a function of n alone) ----
+        if (p->resample) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode, multipole plan: captures at 11 025 Hz only (the resampler is a transform over the capture)");
+        if (wfx_fmm_shard_geometry(p->n, &pl.fg) != 0)
+            return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode, multipole plan: no multipole form for %llu samples (even, >= 32 768)", (unsigned long long)p->n);
+        const long long G = 1ll << pl.fg.lg;
+        if (G < world) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode, multipole plan: %lld boxes at the gather level for %d ranks", G, world);
+        pl.fmm = true;
+        pl.g = wfx_dist_geom();
+        pl.g.world = world;
+        pl.g.rank = rank;
+        pl.gb_lo = (long long)rank * G / world;
+        pl.gb_hi = (long long)(rank + 1) * G / world;
+        const int sh = pl.fg.ltop - pl.fg.lg + 6;                          // gather box -> leaves
+        pl.own_lo = (uint64_t)wfx_fmm_leaf_first_host(p->n, pl.fg.L, pl.gb_lo << sh);
+        pl.own_hi = (uint64_t)wfx_fmm_leaf_first_host(p->n, pl.fg.L, pl.gb_hi << sh);
+        pl.in_lo = pl.seg_lo = pl.own_lo;
+        pl.in_hi = pl.seg_hi = pl.own_hi;
+        // model: the leaf-level kernels divide by the world size, the top is repeated by every rank; five small exchanges + the gather
+        const double nn = (double)p->n;
+        pl.model_single = 20e-6 + (nn * 16.0 <= 256e6 ? 46e-12 : 70e-12) * nn;
+        pl.model_comp = 60e-6 + 52e-12 * nn / world + (world > 1 ? 80e-6 : 0.0);
+        const double lat = link_lat_s(), bl = link_gbs() * 1e9;
+        pl.model_wire = world > 1 ? 6 * lat + (nn / world) / bl + lat : 0.0;
+        pl.model_bytes = world > 1 ? (unsigned long long)(G * 256 * (world - 1) + (unsigned long long)world * (pl.fg.L - pl.fg.lg) * 6 * 256 + nn * (world - 1) / world) : 0ull;
+        return 0;
+    }
     if (p->n >= (1ull << 31)) return single("2^31 samples: beyond the distributed transforms' 32-bit indices");
     if (p->resample && ((p->n & 1) || (p->n0 & 1))) return single("a resampled capture with an odd sample count (its transforms are packed)");
     // odd length: real samples against scipy's real kernel on PACKED transforms (round 4; rounds 1-3: one complex point per sample,
@@ -516,6 +552,23 @@ static int shard_bind(wfx_shard *sh)
         return 0;
     }
     if (pl.cols) return shard_bind_cols(sh);
+    if (pl.fmm) {
+        const int me = pl.rank;
+        const uint64_t n_own = pl.own_hi - pl.own_lo;
+        WFX_TRY(wfx_reserve(ctx, sh->b_audio, (n_own + 2 * SH_FMM_HF) * 8 + 64));
+        WFX_TRY(wfx_reserve(ctx, sh->b_res, 2 * (size_t)(SH_FMM_HR + 24) * 8 + 64));          // the two halo segments as the notch leaves them
+        if (pl.in_kind == WFX_IN_I16_STEREO) WFX_TRY(wfx_reserve(ctx, sh->b_merged, (n_own + 2 * SH_FMM_HR) * 8 + 64));
+        WFX_TRY(wfx_reserve(ctx, sh->b_env, n_own * 8 + 64));
+        WFX_TRY(wfx_reserve(ctx, sh->b_dig, (me == 0 ? pl.n : n_own) + 64));
+        WFX_TRY(wfx_reserve(ctx, sh->b_blk, wfx_select_block_bytes(sh->cap)));
+        WFX_TRY(wfx_reserve(ctx, sh->b_blks, wfx_select_block_bytes(sh->cap) * pl.world));
+        WFX_TRY(wfx_reserve(ctx, sh->b_nan, 8 * (size_t)pl.world + 64));
+        WFX_TRY(wfx_reserve(ctx, sh->b_flags, 64));
+        WFX_HIP(ctx, hipMemsetAsync(sh->b_flags.p, 0, 64, ctx->stream));
+        WFX_HIP(ctx, hipMemsetAsync(sh->b_nan.p, 0, 8 * (size_t)pl.world + 64, ctx->stream));
+        sh->bound = true;
+        return 0;
+    }
     const int me = pl.rank;
     const long long nr = pl.g.nrows(me);
     const uint64_t n_own = pl.own_hi - pl.own_lo, n_seg = pl.seg_hi - pl.seg_lo;
@@ -568,6 +621,7 @@ static int shard_bind(wfx_shard *sh)
 static int phase_count(const wfx_shard *sh)
 {
     if (sh->pl.single) return 1;
+    if (sh->pl.fmm) return 7;
     if (sh->pl.cols)      // padded: + 1 (V[K] := V[0], even lengths) and, in front of the first decode, + 2 C (the kernel's transform)
         return (sh->pl.resample ? 4 * sh->pl.nchunk + 7 : 2 * sh->pl.nchunk + 6) + (sh->pl.padded && !sh->pl.plain ? 1 : 0) +
                (sh->pl.padded && !sh->ghat_ready ? 2 * sh->pl.nchunk : 0);
@@ -818,6 +872,170 @@ static int run_phase_cols(wfx_shard *sh, int ph)
     }
 }
 
+// ---- plan 3: the phases in front of the select (wfx_fmm.hip has the kernels) ---------------------------------------
+static void fmm_rank_boxes(const shard_plan &pl, int r, long long *lo, long long *hi)
+{
+    const long long G = 1ll << pl.fg.lg;
+    *lo = (long long)r * G / pl.world;
+    *hi = (long long)(r + 1) * G / pl.world;
+}
+
+static void fmm_rank_range(const shard_plan &pl, int r, uint64_t *lo, uint64_t *hi)
+{
+    long long a, b;
+    fmm_rank_boxes(pl, r, &a, &b);
+    const int sh = pl.fg.ltop - pl.fg.lg + 6;
+    *lo = (uint64_t)wfx_fmm_leaf_first_host(pl.n, pl.fg.L, a << sh);
+    *hi = (uint64_t)wfx_fmm_leaf_first_host(pl.n, pl.fg.L, b << sh);
+}
+
+static int fmm_owner(const shard_plan &pl, long long gbox)          // the rank that owns box `gbox` of the gather level
+{
+    const long long G = 1ll << pl.fg.lg;
+    int r = (int)((gbox * pl.world + pl.world - 1) / G);             // a first guess, then settle
+    if (r >= pl.world) r = pl.world - 1;
+    for (;;) {
+        long long a, b;
+        fmm_rank_boxes(pl, r, &a, &b);
+        if (gbox < a)
+            --r;
+        else if (gbox >= b)
+            ++r;
+        else
+            return r;
+    }
+}
+
+// what travels after the upward pass, as (sender, receiver, level, first box, boxes) in ONE order every rank enumerates alike: the gather level's
+// boxes of every rank to every other rank, then per finer level and receiver the three boxes before its range and the three behind it
+template <typename F>
+static void fmm_weight_messages(const shard_plan &pl, F &&f)
+{
+    const int W = pl.world, lg = pl.fg.lg, L = pl.fg.L;
+    for (int s = 0; s < W; ++s)
+        for (int r = 0; r < W; ++r) {
+            if (s == r) continue;
+            long long a, b;
+            fmm_rank_boxes(pl, s, &a, &b);
+            f(s, r, lg, a, b - a);
+        }
+    for (int lev = lg + 1; lev <= L; ++lev) {
+        const long long nbl = 1ll << lev;
+        for (int r = 0; r < W; ++r) {
+            long long a, b;
+            fmm_rank_boxes(pl, r, &a, &b);
+            const long long lo = a << (lev - lg), hi = b << (lev - lg);
+            for (int side = 0; side < 2; ++side)
+                for (int j = 0; j < 3; ++j) {
+                    const long long raw = side == 0 ? lo - 3 + j : hi + j;
+                    const long long box = (raw + nbl) & (nbl - 1);
+                    if (box >= lo && box < hi) continue;                    // (one rank, or a range that is the whole level: its own)
+                    const int s = fmm_owner(pl, box >> (lev - lg));
+                    if (s != r) f(s, r, lev, box, 1ll);
+                }
+        }
+    }
+}
+
+static int run_phase_fmm(wfx_shard *sh, int ph)
+{
+    wfx_ctx *ctx = sh->ctx;
+    wfx_comm *c = sh->comm;
+    shard_plan &pl = sh->pl;
+    const wfx_decode_params &p = sh->dp;
+    const int me = pl.rank, W = pl.world;
+    const uint64_t n_own = pl.own_hi - pl.own_lo;
+    wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
+    const void *in = sh->ext_in ? sh->ext_in : sh->b_in.p;
+    double *audio = (double *)sh->b_audio.p;
+    const long long audio0 = (long long)pl.own_lo - SH_FMM_HF, raw0 = (long long)pl.own_lo - SH_FMM_HR;
+    double ext18[18];
+    const bool use_ext = p.has_ext && pl.in_kind != WFX_IN_I16_STEREO;
+    for (int i = 0; i < 9; ++i) {
+        ext18[i] = p.ext_left[i];
+        ext18[9 + i] = p.ext_right[i];
+    }
+    if (ph == 0) {
+        // the rank's frames: [own_lo - 320, own_hi + 320) round the circle.  a4, then the leaf before the first own sample and the one behind the
+        // last through the notch (segment form; at the capture's ends filtfilt's exact edges), then notch + P2M + M2M of the own workgroups
+        int kind = pl.in_kind;
+        if (pl.in_kind == WFX_IN_I16_STEREO) {
+            WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, n_own + 2 * SH_FMM_HR, (double *)sh->b_merged.p));
+            in = sh->b_merged.p;
+            kind = WFX_IN_F64_MONO;
+        }
+        const size_t fb = kind == WFX_IN_I16_MONO ? 2 : 8;
+        double *tl = (double *)sh->b_res.p, *tr = tl + SH_FMM_HR + 24;
+        const bool at_start = pl.own_lo == 0, at_end = pl.own_hi == pl.n;
+        // left: the samples [own_lo - 320, own_lo) -- for the rank that holds the capture's start they are its END (exact right edge)
+        WFX_TRY(wfx_dev_notch_fir_only(ctx, in, kind, at_start ? SH_FMM_HR : SH_FMM_HR + 24, p.notch_b, p.notch_a, tl, at_start ? 2 : 0, use_ext ? ext18 : nullptr));
+        WFX_HIP(ctx, hipMemcpyAsync(audio, tl + 24, SH_FMM_HF * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        // right: [own_hi, own_hi + 320) -- for the rank that holds the capture's end they are its START (exact left edge)
+        const char *rin = (const char *)in + (size_t)(SH_FMM_HR + n_own - (at_end ? 0 : 24)) * fb;
+        WFX_TRY(wfx_dev_notch_fir_only(ctx, rin, kind, at_end ? SH_FMM_HR : SH_FMM_HR + 24, p.notch_b, p.notch_a, tr, at_end ? 1 : 0, use_ext ? ext18 : nullptr));
+        WFX_HIP(ctx, hipMemcpyAsync(audio + SH_FMM_HF + n_own, tr + (at_end ? 0 : 24), SH_FMM_HF * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        WFX_TRY(wfx_fmm_shard_up(ctx, in, raw0, kind, p.notch_b, p.notch_a, use_ext ? ext18 : nullptr, audio, audio0, pl.n, pl.gb_lo, pl.gb_hi, ds));
+        std::vector<wfx_xfer> xs;
+        int rc = 0;
+        fmm_weight_messages(pl, [&](int s, int r, int lev, long long box, long long cnt) {
+            if (rc != 0 || (s != me && r != me)) return;
+            double *ptr = nullptr;
+            rc = wfx_fmm_shard_weights(ctx, pl.n, lev, box, &ptr);
+            wfx_xfer x{};
+            x.peer = s == me ? r : s;
+            if (s == me) {
+                x.send = ptr;
+                x.send_bytes = (size_t)cnt * 256;
+            } else {
+                x.recv = ptr;
+                x.recv_bytes = (size_t)cnt * 256;
+            }
+            xs.push_back(x);
+        });
+        WFX_TRY(rc);
+        wfx_comm_label(c, "fmm weights");
+        return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
+    }
+    if (ph == 1) {
+        WFX_TRY(wfx_dev_select_sharded_ws(ctx, &sh->ws));
+        WFX_TRY(wfx_fmm_shard_down(ctx, audio, audio0, pl.n, pl.gb_lo, pl.gb_hi, (double *)sh->b_env.p, (long long)pl.own_lo, sh->ws));
+        // four envelope values across every seam between two ranks, either way (r's last four to r + 1, r + 1's first four to r)
+        const int shf = pl.fg.ltop - pl.fg.lg;
+        std::vector<wfx_xfer> xs;
+        for (int r = 0; r + 1 < W; ++r) {
+            if (me != r && me != r + 1) continue;
+            long long a, b;
+            fmm_rank_boxes(pl, r, &a, &b);
+            const long long seam_wg = b << shf;                             // first workgroup of rank r + 1
+            double *last4 = nullptr, *first4 = nullptr;
+            WFX_TRY(wfx_fmm_shard_edges(ctx, pl.n, seam_wg - 1, &last4));
+            WFX_TRY(wfx_fmm_shard_edges(ctx, pl.n, seam_wg, &first4));
+            last4 += 4;
+            wfx_xfer x{}, y{};
+            x.peer = y.peer = me == r ? r + 1 : r;
+            if (me == r) {
+                x.send = last4;
+                x.send_bytes = 32;
+                y.recv = first4;
+                y.recv_bytes = 32;
+            } else {
+                x.recv = last4;
+                x.recv_bytes = 32;
+                y.send = first4;
+                y.send_bytes = 32;
+            }
+            xs.push_back(x);
+            xs.push_back(y);
+        }
+        wfx_comm_label(c, "fmm seams");
+        return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
+    }
+    // ph == 2: the medians at the seams, then the select's first all-reduce
+    WFX_TRY(wfx_fmm_shard_seams(ctx, pl.n, pl.gb_lo, pl.gb_hi, (double *)sh->b_env.p, (long long)pl.own_lo, sh->ws));
+    wfx_comm_label(c, "select level 0");
+    return wfx_comm_allreduce_u32(c, ctx, sh->ws, WFX_SEL_BINS);
+}
+
 static int run_phase(wfx_shard *sh, int ph)
 {
     wfx_ctx *ctx = sh->ctx;
@@ -853,6 +1071,10 @@ static int run_phase(wfx_shard *sh, int ph)
         return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
     }
     if (pl.cols) return run_phase_cols(sh, ph);
+    if (pl.fmm) {
+        if (ph <= 2) return run_phase_fmm(sh, ph);
+        ph += 2;                            // 3 .. 6 = the select's level 1, its candidates, finish + quantise + gather, rank 0's tail (cases 9 .. 12)
+    }
     double *audio = (double *)sh->b_audio.p;
     double *env = (double *)sh->b_env.p;
     uint8_t *dig_own = (uint8_t *)sh->b_dig.p + (me == 0 ? pl.own_lo : 0);
@@ -997,7 +1219,13 @@ static int run_phase(wfx_shard *sh, int ph)
         std::vector<wfx_xfer> xs;
         if (me == 0) {
             for (int s = 1; s < W; ++s) {
-                uint64_t lo = (uint64_t)pl.spp * (uint64_t)pl.g.rows[s] * (uint64_t)pl.Ms, hi = (uint64_t)pl.spp * (uint64_t)pl.g.rows[s + 1] * (uint64_t)pl.Ms;
+                uint64_t lo, hi;
+                if (pl.fmm) {
+                    fmm_rank_range(pl, s, &lo, &hi);
+                } else {
+                    lo = (uint64_t)pl.spp * (uint64_t)pl.g.rows[s] * (uint64_t)pl.Ms;
+                    hi = (uint64_t)pl.spp * (uint64_t)pl.g.rows[s + 1] * (uint64_t)pl.Ms;
+                }
                 lo = lo < pl.n ? lo : pl.n;                      // (padded form: rows beyond the capture hold no samples)
                 hi = hi < pl.n ? hi : pl.n;
                 wfx_xfer a{};
@@ -1201,6 +1429,35 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
     } else if (next != p->n || (pl.resample && next_in != p->n0))
         return wfx_fail(nullptr, WFX_ERR_COMM, "dry run: the ranks' ranges do not cover the capture");
     if (pl.single) return 0;              // rank 0 alone: one message of scalars per peer, nothing to cross-check
+    if (pl.fmm) {
+        // plan 3: every rank walks ONE enumeration of (sender, receiver, level, box): the two ends of a message agree by construction; what is
+        // checked here is that every box a rank's kernels read beyond its own range is delivered exactly once and by its owner
+        for (int r = 0; r < world; ++r) {
+            long long a, b;
+            fmm_rank_boxes(pl, r, &a, &b);
+            for (int lev = pl.fg.lg + 1; lev <= pl.fg.L; ++lev) {
+                const long long nbl = 1ll << lev, lo = a << (lev - pl.fg.lg), hi = b << (lev - pl.fg.lg);
+                std::vector<long long> need, got;
+                for (int j = 0; j < 3; ++j) {
+                    for (long long raw : {lo - 3 + j, hi + j}) {
+                        const long long box = (raw + nbl) & (nbl - 1);
+                        if (box < lo || box >= hi) need.push_back(box);
+                    }
+                }
+                fmm_weight_messages(pl, [&](int s, int rr, int lv, long long box, long long cnt) {
+                    if (rr == r && lv == lev) {
+                        long long sa, sb;
+                        fmm_rank_boxes(pl, s, &sa, &sb);
+                        if ((box >> (lev - pl.fg.lg)) >= sa && (box >> (lev - pl.fg.lg)) < sb && cnt == 1) got.push_back(box);
+                    }
+                });
+                std::sort(need.begin(), need.end());
+                std::sort(got.begin(), got.end());
+                if (need != got) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run (multipole plan): rank %d, level %d: the boxes delivered are not the boxes read", r, lev);
+            }
+        }
+        return 0;
+    }
     if (pl.cols) {
         if (pl.resample) {
             WFX_TRY(dry_check_transform(pl, p, pl.M1, pl.in_kind == WFX_IN_I16_MONO ? 4 : 16, 0, 0, true, false, "resample forward (columns)", 0, true));
@@ -1236,6 +1493,41 @@ extern "C" int wfx_shard_wire_plan(const wfx_decode_params *p, int world, wfx_wi
     };
     if (pl.single) {
         put("scalars", (unsigned long long)(W - 1) * sizeof(wfx_dev_scalars), (unsigned long long)(W - 1) * sizeof(wfx_dev_scalars), sizeof(wfx_dev_scalars));
+        return n;
+    }
+    if (pl.fmm) {
+        std::vector<unsigned long long> sent((size_t)W, 0ull), link((size_t)W * W, 0ull);
+        fmm_weight_messages(pl, [&](int s, int r, int, long long, long long cnt) {
+            sent[(size_t)s] += (unsigned long long)cnt * 256;
+            link[(size_t)s * W + r] += (unsigned long long)cnt * 256;
+        });
+        unsigned long long total = 0, mr = 0, ml = 0;
+        for (int r = 0; r < W; ++r) {
+            total += sent[(size_t)r];
+            mr = std::max(mr, sent[(size_t)r]);
+        }
+        for (unsigned long long v : link) ml = std::max(ml, v);
+        put("fmm weights", total, mr, ml);
+        put("fmm seams", W > 1 ? 64ull * (W - 1) : 0ull, W > 1 ? 64ull : 0ull, W > 1 ? 32ull : 0ull);
+        const unsigned long long ar0 = 2ull * (W - 1) * WFX_SEL_BINS * 4 / W, ar1 = 2ull * (W - 1) * WFX_SEL_H1_WORDS * 4 / W;
+        put("select level 0", ar0 * W, ar0, WFX_SEL_BINS * 4ull / W);
+        put("select level 1", ar1 * W, ar1, WFX_SEL_H1_WORDS * 4ull / W);
+        uint64_t cap_c = SH_CAND_CAP;
+        {
+            const uint64_t want_c = p->n / (512ull * (uint64_t)W);
+            while (cap_c < want_c && cap_c < (1ull << 20)) cap_c *= 2;
+        }
+        const unsigned long long blk = wfx_select_block_bytes(cap_c);
+        put("select candidates", blk * W * (W - 1), blk * (W - 1), blk);
+        uint64_t lo0, hi0;
+        fmm_rank_range(pl, 0, &lo0, &hi0);
+        unsigned long long big = 0;
+        for (int r = 1; r < W; ++r) {
+            uint64_t lo, hi;
+            fmm_rank_range(pl, r, &lo, &hi);
+            big = std::max(big, (unsigned long long)(hi - lo) + 8);
+        }
+        put("stream gather", W > 1 ? (unsigned long long)(p->n - (hi0 - lo0)) + 8ull * (W - 1) : 0ull, big, big);
         return n;
     }
     // one transform's exchanges, from every rank's (dry) exchange lists
@@ -1323,13 +1615,16 @@ int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_
     out->own_lo = pl.own_lo;
     out->own_hi = pl.own_hi;
     out->nseg = 1;
-    out->plan = pl.single ? 0 : (pl.cols ? 2 : 1);
+    out->plan = pl.single ? 0 : (pl.fmm ? 3 : (pl.cols ? 2 : 1));
+    if (pl.fmm) out->in_halo = SH_FMM_HR;                              // frames beyond [in_lo, in_hi) on either side, ROUND THE CIRCLE (the capture's other end)
     out->plan_forced = pl.forced;
     out->model_single_s = pl.model_single;
     out->model_dist_compute_s = pl.model_comp;
     out->model_dist_wire_s = pl.model_wire;
     out->model_wire_bytes = pl.model_bytes;
-    if (pl.cols && !pl.single)
+    if (pl.fmm)
+        snprintf(out->plan_reason, sizeof out->plan_reason, "chunk-local multipole form: ranks own boxes of level %d of a %d-level tree", pl.fg.lg, pl.fg.L);
+    else if (pl.cols && !pl.single)
         snprintf(out->plan_reason, sizeof out->plan_reason, "columns layout, every transpose in %d k1 subset%s", pl.nchunk, pl.nchunk == 1 ? "" : "s");
     else
         snprintf(out->plan_reason, sizeof out->plan_reason, "%s", pl.single ? pl.single_reason : (pl.padded ? "rows layout (padded form)" : "rows layout"));
@@ -1369,7 +1664,7 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
     // RCCL then hangs instead of reporting anything.  The ranks compare a digest of what they decided before any of it is used
     // (real multi-process transports only: the ranks of an in-process world share one environment and are created one by one).
     if (rc == 0 && pl.world > 1 && !wfx_comm_is_local(comm)) {
-        long long dig[8] = {pl.single ? 1 : 0, pl.cols ? 1 : 0, (long long)pl.nchunk, (long long)pl.g.R1, (long long)pl.Kp, (long long)pl.M1,
+        long long dig[8] = {pl.single ? 1 : (pl.fmm ? 3 : 0), pl.cols ? 1 : 0, (long long)pl.nchunk, (long long)pl.g.R1, (long long)pl.Kp, (long long)pl.M1,
                             (long long)p->n0, (long long)p->n};
         wfx_devbuf &b = sh->b_flags;
         rc = wfx_reserve(ctx, b, 64 + (size_t)pl.world * 64);
@@ -1405,6 +1700,10 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
         *out = sh;
         return 0;
     }
+    if (rc == 0 && pl.fmm) {      // plan 3: no distributed transform objects
+        *out = sh;
+        return 0;
+    }
     sh->dF.set_tag("resample fwd");
     sh->dI.set_tag("resample inv");
     sh->dH.set_tag("hilbert");
@@ -1428,7 +1727,7 @@ int wfx_shard_upload(wfx_shard *sh, const void *host_frames)
 {
     CHECK_SH(sh);
     wfx_ctx *ctx = sh->ctx;
-    const size_t nb = (size_t)(sh->pl.cols ? cols_in_frames(sh->pl) : sh->pl.in_hi - sh->pl.in_lo) * frame_bytes(sh->pl.in_kind);
+    const size_t nb = (size_t)(sh->pl.cols ? cols_in_frames(sh->pl) : sh->pl.in_hi - sh->pl.in_lo + (sh->pl.fmm ? 2 * SH_FMM_HR : 0)) * frame_bytes(sh->pl.in_kind);
     if (!host_frames && nb) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
     const bool moved = !sh->b_in.p || sh->b_in.cap < nb + 64 || sh->ext_in;
     WFX_TRY(wfx_reserve(ctx, sh->b_in, nb + 64));
@@ -1602,7 +1901,7 @@ int wfx_shard_fetch(wfx_shard *sh, int buffer_id, void *host_out, size_t bytes)
     const void *src = nullptr;
     size_t nb = 0;
     switch (buffer_id) {
-    case WFX_BUF_AUDIO: src = (const double *)sh->b_audio.p + (pl.own_lo - pl.seg_lo); nb = n_own * 8; break;
+    case WFX_BUF_AUDIO: src = (const double *)sh->b_audio.p + (pl.fmm ? (uint64_t)SH_FMM_HF : pl.own_lo - pl.seg_lo); nb = n_own * 8; break;
     case WFX_BUF_ENVELOPE: src = sh->b_env.p; nb = n_own * 8; break;
     case WFX_BUF_DIGITAL:
         if (pl.rank == 0 && bytes == pl.n) {

@@ -201,19 +201,37 @@ class ShardedDecoder:
         self.shard.close()
 
 
-PLAN_CODES = {"auto": 0, "dist": 1, "single": 2, "rows": 17, "auto-rows": 16}
+PLAN_CODES = {"auto": 0, "dist": 1, "single": 2, "fmm": 3, "rows": 17, "auto-rows": 16}
 
 
 def plan_code(plan) -> int:
     """``wfx_decode_params.shard_plan``: "auto" (the library's cost model picks distributed or single), "dist" (distributed
     whenever a distributed form exists), "single" (rank 0 alone), "rows" (distributed in the rows layout of rounds 2-3: A/B runs),
-    "auto-rows"; or the integer itself."""
+    "auto-rows"; "fmm" (round 6: captures at 11 025 Hz cut into contiguous ranges, the Hilbert transform by the fast multipole form of
+    csrc/wfx_fmm.hip -- kilobytes on the wire instead of four transposes of the capture); or the integer itself."""
     return int(PLAN_CODES[plan]) if isinstance(plan, str) else int(plan)
 
 
 def gather_frames(lay, data=None, loader=None, n0: int | None = None) -> np.ndarray:
     """The frames a rank hands over for its layout: one range (rows layout, single plan, one rank), or -- columns layout --
     ``nseg`` segments with ``in_halo`` frames on either side, back to back; frames outside the capture are zeros."""
+    if lay.plan == 3:
+        # the multipole plan: the own range and `in_halo` frames on either side ROUND THE CIRCLE (rank 0's left halo is the capture's end: the
+        # Hilbert transform is cyclic; the kernels apply filtfilt's exact edges there)
+        n0 = int(np.asarray(data).shape[0] if data is not None else n0)
+        lo, hi, h = int(lay.in_lo), int(lay.in_hi), int(lay.in_halo)
+        take = (lambda a, b: np.asarray(data)[a:b]) if data is not None else loader
+        parts = []
+        if lo - h < 0:
+            parts += [take(n0 + lo - h, n0), take(0, lo)] if lo > 0 else [take(n0 - h, n0)]
+        else:
+            parts.append(take(lo - h, lo))
+        parts.append(take(lo, hi))
+        if hi + h > n0:
+            parts += [take(hi, n0), take(0, hi + h - n0)] if hi < n0 else [take(0, h)]
+        else:
+            parts.append(take(hi, hi + h))
+        return np.concatenate([np.asarray(q) for q in parts])
     if lay.nseg <= 1:
         lo, hi = int(lay.in_lo), int(lay.in_hi)
         return np.asarray(data)[lo:hi] if data is not None else loader(lo, hi)
