@@ -211,6 +211,54 @@ def test_any_length_at_the_native_rate_gets_a_padded_plan(n0):
         nat.shard_dry_run(p, world)
 
 
+
+@pytest.mark.parametrize("n", [7166250, 1433250, 661500, 39690000, 32768, 2 * 1000003])
+def test_multipole_plan_cuts_the_capture_at_leaf_workgroups_and_keeps_the_wire_in_kilobytes(n):
+    """Plan 3 (round 6; csrc/wfx_shard.hip run_phase_fmm, csrc/wfx_fmm.hip): contiguous ranges whose ends are leaf-workgroup boundaries of a tree
+    that depends on n alone; 320 frames of halo round the circle; the boxes a rank reads beyond its range are the boxes delivered (dry run);
+    everything but the select's candidates and the final gather of the stream stays in kilobytes -- the gather level's weights + three boxes
+    per finer level and side: ~25 KB per rank for the 10-minute capture on eight ranks (the transposing plans: ~100 MB)."""
+    p, meta = build_params(0, n, 11025, 0.5, shard_plan=sharded.plan_code("fmm"))
+    assert meta["n"] == n
+    cuts = None
+    for world in (1, 2, 3, 8):
+        lays = [nat.shard_layout(p, world, r) for r in range(world)]
+        assert all(lay.plan == 3 and lay.plan_forced == 1 and lay.nseg == 1 and lay.in_halo == 320 for lay in lays)
+        assert lays[0].own_lo == 0 and lays[-1].own_hi == n and all(lays[i].own_hi == lays[i + 1].own_lo for i in range(world - 1))
+        assert all(lay.in_lo == lay.own_lo and lay.in_hi == lay.own_hi and lay.in_frames == lay.own_samples + 640 for lay in lays)
+        assert all(lay.in_index()[0] == int(lay.own_lo) - 320 and lay.in_index().shape[0] == lay.in_frames for lay in lays)
+        sizes = [lay.own_samples for lay in lays]
+        assert min(sizes) >= 2048 and max(sizes) <= 2 * min(sizes) + 4096
+        if world == 8:
+            cuts = {int(lay.own_lo) for lay in lays}
+        nat.shard_dry_run(p, world)
+        wire = {e["name"]: e for e in nat.shard_wire_plan(p, world)}
+        assert list(wire) == ["fmm weights", "fmm seams", "select level 0", "select level 1", "select candidates", "stream gather"]
+        if world == 1:
+            assert all(e["bytes"] == 0 for e in wire.values())
+            continue
+        assert wire["fmm weights"]["max_rank_bytes"] <= 96 * 1024 and wire["fmm seams"]["max_rank_bytes"] == 64
+        assert wire["stream gather"]["bytes"] == n - lays[0].own_samples + 8 * (world - 1)
+        small = sum(wire[k]["max_rank_bytes"] for k in ("fmm weights", "fmm seams", "select level 0", "select level 1", "select candidates"))
+        if n <= 7166250:
+            assert small <= 600 * 1024, small
+    # the cuts of 2 ranks are cuts of 8 ranks: the tree's boxes, not the world size, decide where a range may end
+    lays2 = [nat.shard_layout(p, 2, r) for r in range(2)]
+    assert {int(lay.own_lo) for lay in lays2} <= cuts
+
+
+def test_multipole_plan_refuses_what_it_cannot_shard():
+    p, _ = build_params(0, 1440000, 48000, 0.5, shard_plan=sharded.plan_code("fmm"))       # needs the resampler: a transform over the capture
+    with pytest.raises(nat.NativeError, match="11 025 Hz only"):
+        nat.shard_layout(p, 2, 0)
+    p, _ = build_params(0, 100001, 11025, 0.5, shard_plan=sharded.plan_code("fmm"))        # odd: no multipole form
+    with pytest.raises(nat.NativeError, match="no multipole form"):
+        nat.shard_layout(p, 2, 0)
+    p, _ = build_params(0, 40000, 11025, 0.5, shard_plan=sharded.plan_code("fmm"))         # 16 boxes at the gather level
+    with pytest.raises(nat.NativeError, match="boxes at the gather level"):
+        nat.shard_layout(p, 32, 0)
+
+
 def test_captures_without_a_distributed_form_get_the_single_plan():
     """A resampled capture whose half-lengths are odd or not 13-smooth (its inverse transform's length is the reference's to
     choose), or a capture too short for the world size, is not refused: rank 0 owns it whole and decodes it alone (first_radix
@@ -442,6 +490,57 @@ def test_full_size_ten_minute_capture_on_eight_emulated_ranks():
     assert r["first_radix"] == (15, 15)
     assert np.array_equal(r["digitalized"], stream) and np.array_equal(r["image"], img)
     assert r["sync"]["start_frame"] == info.start_frame and r["sync"]["npeaks"] == info.npeaks
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["mono_11025_130s", "mono_11025_30s", "float_11025_130s", "uint8_11025_130s", "float32_11025_130s"])
+def test_multipole_plan_gives_the_one_gpu_decodes_bytes_for_every_world_size(case):
+    """Plan 3: every world size gives the bytes of the one-GPU decode in the same Hilbert form -- filtered audio, envelope, stream, start frame,
+    image -- and the oracle's stream and image (max |delta pixel| 0); what the communicator counted is what the plan says."""
+    from wefax_amd.wefax import DecodeJob
+    x, sr, lpm = CASES[case]()
+    ref = _oracle(x, sr, lpm)
+    c = nat.Context(0)
+    job = DecodeJob(c, x, sr, lpm, hilbert_mode=nat.WFX_HILBERT_FMM)
+    job.run()
+    info = job.result()
+    one = {"digitalized": job.fetch("digitalized"), "envelope": job.fetch("envelope"), "audio": job.fetch("audio"), "image": job.fetch("image")}
+    assert np.array_equal(one["digitalized"], ref["digitalized"]) and info.start_frame == ref["start_frame"]
+    kind = sharded.capture_kind(x)
+    p, _ = build_params(kind, x.shape[0], sr, 1 / (lpm / 60), shard_plan=sharded.plan_code("fmm"))
+    for world in (1, 2, 3, 8):
+        r = sharded.decode_emulated(x, sr, world, lpm, plan="fmm")
+        assert r["plan"] == 3
+        for k in ("digitalized", "envelope", "audio", "image"):
+            assert np.array_equal(r[k], one[k]), f"{case} world {world}: {k} differs from the one-GPU decode"
+        assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
+        assert r["sync"]["start_frame"] == ref["start_frame"] and r["sync"]["peaks"] == [int(v) for v in ref["peaks"]]
+        assert np.array_equal(r["image"], ref["image"])
+        assert len(set(r["lows"])) == 1 and len(set(r["highs"])) == 1 and r["low"] == info.low and r["high"] == info.high
+        plan = nat.shard_wire_plan(p, world)
+        counted = {}
+        for ws in r["wire"]:
+            for e in ws:
+                counted[e["name"]] = counted.get(e["name"], 0) + int(e["sent"])
+        for e in plan:
+            assert counted.get(e["name"], 0) == e["bytes"], (world, e["name"], counted.get(e["name"]), e["bytes"])
+
+
+@pytest.mark.gpu
+def test_multipole_plan_full_size_ten_minute_capture_on_eight_emulated_ranks():
+    from wefax_amd.wefax import DecodeJob
+    x = synth.config_c2(noise=0.05, seed=2)
+    c = nat.Context(0)
+    job = DecodeJob(c, x, 11025, 120)                     # the default (transform) route
+    job.run()
+    info = job.result()
+    r = sharded.decode_emulated(x, 11025, 8, 120, plan="fmm", want=("image", "stream"))
+    assert r["plan"] == 3 and np.array_equal(r["digitalized"], job.fetch("digitalized")) and r["sync"]["start_frame"] == info.start_frame
+    assert np.array_equal(r["image"], job.fetch("image"))
+    sent = [sum(int(e["sent"]) for e in ws if e["name"] != "stream gather") for ws in r["wire"]]
+    assert max(sent) <= 600 * 1024, sent                  # (the transposing plans: ~100 MB per rank)
+    assert max(int(e["sent"]) for ws in r["wire"] for e in ws if e["name"] == "fmm weights") <= 32 * 1024
 
 
 @pytest.mark.gpu

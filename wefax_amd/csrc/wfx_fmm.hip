@@ -1261,8 +1261,10 @@ int wfx_fmm_shard_geometry(uint64_t n, wfx_fmm_shard_geo *geo)
 {
     int L = 0;
     if (!fmm_levels(n, &L)) return -1;
+    // the top of the first (deepest) tier -- or, where that leaves fewer than 64 boxes, a level inside the tier: the tier is then run in two
+    // parts (below the gather level by the ranks, above it by everybody), which computes every level exactly as the one-GPU run does
     int cur = L - FW, lg = cur;
-    if (cur > 5) lg = cur - std::min(FTD, cur - 2);                       // the top of the first (deepest) tier
+    if (cur > 5) lg = std::min(cur, std::max(cur - std::min(FTD, cur - 2), 6));
     geo->L = L;
     geo->ltop = L - FW;
     geo->lg = lg;
@@ -1310,8 +1312,8 @@ int wfx_fmm_shard_up(wfx_ctx *ctx, const void *raw, long long raw_index0, int ra
     const int sh = geo.ltop - geo.lg;
     const void *raw0 = raw_kind == WFX_IN_I16_MONO ? (const void *)((const short *)raw - raw_index0) : (const void *)((const double *)raw - raw_index0);
     fmm_launch_up(ctx, P, nullptr, raw0, raw_kind, &c, audio - audio_index0, clear, (unsigned)(gb_lo << sh), (unsigned)(gb_hi << sh));
-    if (sh > 0 && gb_hi > gb_lo)
-        hipLaunchKernelGGL(fmm_up_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[0], P.tier_d[0], (int)gb_lo);
+    if (sh > 0 && gb_hi > gb_lo)        // the part of the deepest tier below the gather level, own boxes
+        hipLaunchKernelGGL(fmm_up_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, geo.lg, sh, (int)gb_lo);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
     return 0;
@@ -1331,16 +1333,19 @@ int wfx_fmm_shard_down(wfx_ctx *ctx, const double *audio, long long audio_index0
     wfx_fmm_shard_geo geo;
     wfx_fmm_shard_geometry(n, &geo);
     const int sh = geo.ltop - geo.lg;
+    // everybody: the deepest tier's part above the gather level, the other tiers, the top -- and down again to the gather level
+    const int up0 = P.ntier > 0 ? geo.lg - P.tier_a[0] : 0;
+    if (up0 > 0) hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[0]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[0], up0, 0);
     for (int k = 1; k < P.ntier; ++k)
         hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[k], P.tier_d[k], 0);
     hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.Lg, P.atop);
     for (int k = P.ntier - 1; k >= 1; --k)
         hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
+    if (up0 > 0) hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[0]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[0], up0, 0);
     const unsigned wg_lo = (unsigned)(gb_lo << sh), wg_hi = (unsigned)(gb_hi << sh);
     if (wg_hi > wg_lo) {
-        if (sh > 0)
-            hipLaunchKernelGGL(fmm_down_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[0], P.tier_d[0],
-                               (int)gb_lo);
+        if (sh > 0)         // own boxes: from the gather level to the leaf workgroups' roots
+            hipLaunchKernelGGL(fmm_down_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, geo.lg, sh, (int)gb_lo);
         hipLaunchKernelGGL(fmm_tree_leaf, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, (int)wg_lo);
         hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_leaf, ctx->stream, audio - audio_index0, P.g, P.T, (const double *)P.Cg,
                            env - env_index0, P.smax, P.xcap, P.Eg, l0hist, (int)wg_lo, 0);

@@ -1512,7 +1512,7 @@ extern "C" int wfx_shard_wire_plan(const wfx_decode_params *p, int world, wfx_wi
         const unsigned long long ar0 = 2ull * (W - 1) * WFX_SEL_BINS * 4 / W, ar1 = 2ull * (W - 1) * WFX_SEL_H1_WORDS * 4 / W;
         put("select level 0", ar0 * W, ar0, WFX_SEL_BINS * 4ull / W);
         put("select level 1", ar1 * W, ar1, WFX_SEL_H1_WORDS * 4ull / W);
-        uint64_t cap_c = SH_CAND_CAP;
+        uint64_t cap_c = SH_CAND_CAP / 4;
         {
             const uint64_t want_c = p->n / (512ull * (uint64_t)W);
             while (cap_c < want_c && cap_c < (1ull << 20)) cap_c *= 2;
@@ -1654,7 +1654,9 @@ int wfx_shard_create(wfx_ctx *ctx, wfx_comm *comm, const wfx_decode_params *p, w
         // envelope range in all, a world-th of that per rank; four times the even share absorbs what a picture does to the
         // distribution.  (An overflow is detected, reported by wfx_shard_result and cured by a larger capacity.)
         uint64_t want = p->n / (512ull * (uint64_t)(pl.world > 0 ? pl.world : 1));
-        uint64_t cap = SH_CAND_CAP;
+        // (plan 3 keeps everything else on the wire in kilobytes: its floor is a quarter of the transposing plans' -- an overflow is
+        // reported and cured like theirs)
+        uint64_t cap = pl.fmm ? SH_CAND_CAP / 4 : SH_CAND_CAP;
         while (cap < want && cap < (1ull << 20)) cap *= 2;
         sh->cap = cap;
     }
