@@ -60,10 +60,11 @@ def parse():
                     help="rate at which the time-domain front end hands the IQ stream to the exact FFT resampler")
     ap.add_argument("--iq-form", choices=["auto", "fused", "sharded"], default="auto",
                     help="one GPU: the fused exact decode behind the front end (auto) or the sharded form with one rank")
-    ap.add_argument("--plan", choices=["auto", "dist", "single", "rows", "auto-rows"], default="auto",
+    ap.add_argument("--plan", choices=["auto", "dist", "single", "rows", "auto-rows", "fmm"], default="auto",
                     help="sharded decodes: auto = the library's cost model picks the distributed form or rank 0 alone (DESIGN 6.6); dist / single "
                          "force one; rows = distributed in the rows layout of rounds 2-3 (8 array transposes instead of 4: A/B runs)")
     ap.add_argument("--trim", type=int, default=0, help="c2: drop this many samples from the end of the capture (--trim 2 with --shard: the padded distributed convolution; odd: the real convolution on packed transforms)")
+    ap.add_argument("--no-c5", action="store_true", help="c2: leave the c5 object (64 mixed captures on 8 contexts) out")
     ap.add_argument("--no-c4", action="store_true", help="c2: leave the c4_strong object out (quick runs)")
     ap.add_argument("--no-extras", action="store_true", help="c2: leave the general_length and c3 objects out (kernel profiles of the headline alone)")
     ap.add_argument("--no-e2e", action="store_true", help="leave the file-to-file objects (wav on tmpfs -> png on tmpfs) out")
@@ -246,6 +247,7 @@ class Ranks:
         probing = self.world > 1 and self.transport == "rccl" and os.environ.get("WFX_BENCH_RCCL_PROBE", "1") != "0"
         verdict = self._probe_rccl() if probing else None
         self.ctx = nat.Context(dev)
+        GpuState.bind(self.ctx)
         if self.use_rccl and (self.transport == "shm" or probing):
             job = os.environ.get("WFX_JOB_NONCE")
             if not job:
@@ -324,19 +326,36 @@ class GpuState:
     point in time (``read``) or sampled by a thread while a timed region runs (``with GpuState.sample() as s``): a reader of the
     line can then tell a slow box from a slow kernel.  Everything is optional: a node that is missing or unreadable is left out."""
     _dev = None
+    _pci = None          # PCI address of the GPU the bench's context runs on (GpuState.bind): the card to read
+    _matched = False
+
+    @classmethod
+    def bind(cls, ctx):
+        """Read the card whose PCI address is the context's device's (round-5 verdict: on an 8-GPU box the first card is somebody else's GPU)."""
+        try:
+            cls._pci = ctx.pci_bus_id().lower()
+        except Exception:       # noqa: BLE001
+            cls._pci = None
+        cls._dev = None
 
     @classmethod
     def dev(cls):
         if cls._dev is None:
             import glob
             cls._dev = ""
+            first = ""
             for d in sorted(glob.glob("/sys/class/drm/card*/device")):
                 try:
-                    if open(os.path.join(d, "vendor")).read().strip() == "0x1002" and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
-                        cls._dev = d
-                        break
+                    if open(os.path.join(d, "vendor")).read().strip() != "0x1002" or not os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                        continue
                 except OSError:
-                    pass
+                    continue
+                first = first or d
+                if cls._pci and os.path.basename(os.path.realpath(d)).lower() == cls._pci:
+                    cls._dev, cls._matched = d, True
+                    break
+            if not cls._dev:
+                cls._dev, cls._matched = first, False
         return cls._dev
 
     @staticmethod
@@ -356,6 +375,8 @@ class GpuState:
         out = {}
         if not d:
             return out
+        out["pci"] = os.path.basename(os.path.realpath(d))
+        out["is_the_contexts_gpu"] = bool(cls._matched)
         for key, node in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
             v = cls._cur_mhz(os.path.join(d, node))
             if v is not None:
@@ -459,8 +480,18 @@ def roofline_of(prof: dict, steps: int, alg_bytes: int, ms_per_step: float, pmc_
                 traffic = tj.get(dom[0], {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # every kernel's counter bytes of one step against the algorithmic bytes (33x for configs[1]: the exact transform path streams its work
+    # arrays six times; 1.03x for the ingest) -- from the committed counter summary and THIS run's launch counts
+    traffic_ratio = None
+    if pmc_file and os.path.exists(pmc_file):
+        try:
+            tj = json.load(open(pmc_file))
+            tot = sum(tj[k]["hbm_bytes_per_launch"] * (v[0] / steps) for k, v in prof.items() if k in tj and isinstance(tj[k], dict))
+            traffic_ratio = round(tot / alg_bytes, 2) if tot else None
+        except Exception:      # noqa: BLE001
+            traffic_ratio = None
     achieved = alg_bytes / avg_s / 1e9
-    return {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": dom[0], "traffic_ratio_whole_path": traffic_ratio, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": round(dom[1][0] / steps, 2),
@@ -492,6 +523,96 @@ def cpu_baseline(x, sample_rate: int, lpm: int, faithful: bool, what: str) -> di
             out["faithful_loops"] = {"value": round(x.shape[0] / dtf / 1e6, 4), "seconds": round(dtf, 2),
                                      "value_with_reference_sleeps": round(x.shape[0] / (dtf + 7.0) / 1e6, 4), "same_result_as_vectorised": same}
     return out
+
+
+
+# ---- the fast multipole route (round 6): a6 + a7 without a transform over the capture ----------------------------------------------
+F64_PEAK_TFLOPS = 78.6          # MI355X float64, vector = matrix (tools/micro/mfma_f64_rate.hip measures 76-77 with either or any mix of the two)
+FMM_FMA_PER_SAMPLE = 307        # near field 82, P2M 32, L2P 32, M2L 56, M2M + L2L 38, moments <-> nodes <-> coefficients 18, notch 49
+
+
+def bench_fmm(args, rk: Ranks, x) -> dict:
+    """The same capture with hilbert_mode = WFX_HILBERT_FMM: notch inside the P2M kernel, near field + tree levels on the f64 matrix cores,
+    envelope + median + histogram inside the leaf kernel.  Compute-bound: its roof is the float64 rate, reported beside the HBM fraction."""
+    import numpy as np
+    from wefax_amd.wefax import DecodeJob
+    nat, ctx = rk.nat, rk.ctx
+    job = DecodeJob(ctx, x, 11025, 120, hilbert_mode=nat.WFX_HILBERT_FMM)
+    dt = rk.timed(job.run, args.steps, args.warmup)
+    ms = 1e3 * dt / args.steps
+    info = job.result()
+    ref = DecodeJob(ctx, x, 11025, 120)
+    ref.run()
+    rinfo = ref.result()
+    same = bool(np.array_equal(job.fetch("digitalized"), ref.fetch("digitalized")) and info.start_frame == rinfo.start_frame)
+    prof = profile_pass(ctx, job.run, args.steps)
+    groups = {"notch_p2m_m2m": "fft_pass_fwd", "tiers_and_top": "bluestein_pointwise", "tree_levels": "fft_pass_inv", "near_l2p_env_median": "env_median"}
+    us = {k: round(1e3 * prof[v][1] / args.steps, 1) for k, v in groups.items() if v in prof}
+    t_fmm = sum(us.values()) * 1e-6
+    flops = 2.0 * FMM_FMA_PER_SAMPLE * x.shape[0]
+    n = x.shape[0]
+    return {"what": "BASELINE configs[1] with a6 + a7 by the fast multipole form (csrc/wfx_fmm.hip; Demodulator(hilbert_mode=4) / WEFAX_HILBERT=fmm)",
+            "ms_per_step": round(ms, 4), "value": round(n / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "stream_and_start_frame_equal_to_transform_route": same,
+            "notch_hilbert_envelope_median_us": round(1e6 * t_fmm, 1), "kernel_groups_us": us,
+            "roofline": {"bound": "f64", "achieved": round(flops / t_fmm / 1e12, 2) if t_fmm else None, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops / t_fmm / 1e12 / F64_PEAK_TFLOPS, 4) if t_fmm else None,
+                         "algorithmic_flops": int(flops), "fma_per_sample": FMM_FMA_PER_SAMPLE,
+                         "hbm_frac_of_these_kernels": round((2 * n + 4 * n) / t_fmm / 1e9 / HBM_PEAK_GBS, 4) if t_fmm else None}}
+
+
+# ---- BASELINE configs[4]: 64 independent captures, 8 contexts (= one capture per GPU stream, 8 per GPU) -----------------------------
+def bench_c5(args, rk: Ranks) -> dict:
+    """64 mixed captures (120 / 240 LPM, IOC576 / 288, seeds 0..63: synth.config_c5_member) decoded eight at a time on eight contexts of this GPU
+    by eight host threads; every member's stream is hashed, members 0, 6, 12, ... (the ones tests/test_gpu_configs.py checks in full) against
+    the oracle's where the CPU leg is on."""
+    import hashlib
+    import threading
+    import numpy as np
+    from wefax_amd import synth
+    from wefax_amd.wefax import DecodeJob
+    nat = rk.nat
+    ctxs = [nat.Context(rk.device) for _ in range(8)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:      # (0.7 s of NumPy per member on one core)
+        members = list(ex.map(lambda i: synth.config_c5_member(i, noise=args.noise), range(64)))
+    total = sum(m[0].shape[0] for m in members)
+
+    def run_round(js):
+        ths = [threading.Thread(target=lambda j=j: (j.run(), j.result())) for j in js]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+
+    digests, checked, ok = {}, [], True
+    t_all = 0.0
+    for rnd in range(8):
+        js = [DecodeJob(ctxs[k], members[8 * rnd + k][0], 11025, members[8 * rnd + k][1]) for k in range(8)]
+        run_round(js)                                   # (uploads and first-use plans outside the timed region)
+        t0 = time.perf_counter()
+        run_round(js)
+        t_all += time.perf_counter() - t0
+        for k, j in enumerate(js):
+            i = 8 * rnd + k
+            st = j.fetch("digitalized")
+            digests[i] = hashlib.sha256(st.tobytes()).hexdigest()[:16]
+            if i % 6 == 0 and not args.no_cpu and i < 24:
+                from oracle import wefax_oracle as wo
+                import tempfile
+                with tempfile.TemporaryDirectory() as td:
+                    pth = os.path.join(td, "m.wav")
+                    synth.write_wav(pth, 11025, members[i][0])
+                    r = wo.process(pth, members[i][1], want_messages=False)
+                good = bool(np.array_equal(st, r["digitalized"]) and j.result().start_frame == r["start_frame"])
+                checked.append(i)
+                ok &= good
+    for c in ctxs:
+        c.close()
+    h = hashlib.sha256("".join(digests[i] for i in range(64)).encode()).hexdigest()[:16]
+    return {"workload": "BASELINE configs[4]: 64 independent 11.025 kHz captures (mixed 120 / 240 LPM, IOC576 / 288, seeds 0..63), 8 contexts of ONE GPU, 8 at a time",
+            "value": round(total / t_all / 1e6, 2), "unit": "Msamples/s", "seconds_for_64": round(t_all, 4), "samples": int(total), "contexts": 8,
+            "stream_digest_of_all_64": h, "members_checked_against_the_oracle": checked, "checked_equal": ok if checked else None,
+            "note": "captures resident in HBM when a round's clock starts; eight host threads enqueue and wait; no collective (replicas only)"}
 
 
 # ---- BASELINE configs[3]: the oversampled IQ stream, all ranks on ONE capture ---------------------------------------
@@ -1139,6 +1260,15 @@ def main():
                 a3.steps, a3.warmup = max(3, min(args.steps, 10)), 2
                 c3 = bench_c3(a3, rk)
                 line["c3"] = {k: c3[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "kernels", "general_length", "e2e") if k in c3}
+                try:
+                    line["fmm"] = bench_fmm(args, rk, synth.config_c2(noise=args.noise, seed=rk.rank))
+                except Exception as e:      # noqa: BLE001
+                    line["fmm"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                if not args.no_c5:
+                    try:
+                        line["c5"] = bench_c5(args, rk)
+                    except Exception as e:      # noqa: BLE001
+                        line["c5"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             if not args.no_c4 and not args.shard and args.batch == 1:
                 rk.barrier()
                 secs = 40.0 if args.short else float(args.iq_seconds)
@@ -1157,6 +1287,33 @@ def main():
                     line["c4_strong"] = {"error": f"{type(e).__name__}: {e}"[:400]}
         if rk.rccl_probe is not None:
             line["rccl_probe"] = rk.rccl_probe
+        if rk.rank == 0 and isinstance(line.get("roofline"), dict):
+            # the driver's record keeps `config`, `roofline` and `cpu_baseline` as objects and only the names of the rest: one compact row per
+            # BASELINE config -- and the file-to-file totals -- ride inside `roofline`
+            def row(o):
+                r = o.get("roofline") or {}
+                return {"ms_per_step": o.get("ms_per_step"), "Msamples_s": o.get("value"), "kernel": r.get("kernel"), "frac": r.get("frac"),
+                        "whole_path_frac": r.get("whole_path_frac"), "traffic_ratio": r.get("traffic_ratio_whole_path")}
+            cfgs = {"c2": row(line)}
+            for key, name in (("c3", "c3"), ("c4_strong", "c4")):
+                if isinstance(line.get(key), dict) and "error" not in line[key]:
+                    cfgs[name] = row(line[key])
+            if isinstance(line.get("c5"), dict) and "error" not in line["c5"]:
+                cfgs["c5"] = {"Msamples_s": line["c5"]["value"], "seconds_for_64": line["c5"]["seconds_for_64"], "checked_equal": line["c5"]["checked_equal"]}
+            if isinstance(line.get("fmm"), dict) and "error" not in line["fmm"]:
+                f = line["fmm"]
+                cfgs["c2_fmm_route"] = {"ms_per_step": f["ms_per_step"], "notch_hilbert_envelope_median_us": f["notch_hilbert_envelope_median_us"],
+                                        "f64_frac": f["roofline"]["frac"], "same_stream": f["stream_and_start_frame_equal_to_transform_route"]}
+            e2e = {}
+            if isinstance(line.get("e2e"), dict):
+                e2e["c2_ms"] = line["e2e"].get("ms")
+            if isinstance(line.get("c3"), dict) and isinstance(line["c3"].get("e2e"), dict):
+                e2e["c3_ms"] = line["c3"]["e2e"].get("ms")
+            if isinstance(line.get("c4_strong"), dict) and isinstance(line["c4_strong"].get("gpu_state"), dict):
+                cfgs.setdefault("c4", {})["gpu_state_during"] = line["c4_strong"]["gpu_state"].get("during_steps")
+                cfgs["c4"]["ingest_us"] = (line["c4_strong"].get("per_step") or {}).get("ingest_us")
+            line["roofline"]["configs"] = cfgs
+            line["roofline"]["file_to_file_ms"] = e2e
         if guard is None or guard.claim():
             if rk.rank == 0:
                 print(json.dumps(line), flush=True)

@@ -72,6 +72,9 @@ void        wfx_destroy(wfx_ctx *ctx);
 const char *wfx_last_error(wfx_ctx *ctx);               /* ctx may be NULL      */
 int         wfx_sync(wfx_ctx *ctx);                     /* wait for the stream  */
 const char *wfx_version(void);
+/* PCI address of the context's GPU as the driver's sysfs tree names it ("0000:05:00.0"): lets a measurement harness read the clocks and power of
+ * THE GPU the context runs on, not of the first card of the machine; WFX_ERR_BAD_ARG when `cap` is too small */
+int         wfx_device_pci_bus_id(wfx_ctx *ctx, char *out, int cap);
 
 /* ---- stage entry points (host in, host out), one per reference stage --- */
 

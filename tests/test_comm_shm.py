@@ -140,7 +140,7 @@ def test_randomised_collectives_between_processes_device_memory(world):
     assert out == {r: "ok" for r in range(world)}
 
 
-def _decode_worker(job, world, rank, seed, rate, lpm, out_dir, q, trim=0):
+def _decode_worker(job, world, rank, seed, rate, lpm, out_dir, q, trim=0, plan="dist"):
     """One rank of a sharded decode in its own process: own context, own slice of the capture, the shm transport."""
     try:
         from wefax_amd import sharded, synth
@@ -148,7 +148,7 @@ def _decode_worker(job, world, rank, seed, rate, lpm, out_dir, q, trim=0):
         ctx = nat.Context(0)
         comm = nat.Comm.shm(ctx, job, world, rank, timeout=120.0)
         time.sleep(0.02 * ((rank * 7) % 5))                                 # the ranks drift apart
-        dec = sharded.ShardedDecoder(ctx, comm, x.shape[0], rate, lpm, sharded.capture_kind(x), data=x, plan="dist")
+        dec = sharded.ShardedDecoder(ctx, comm, x.shape[0], rate, lpm, sharded.capture_kind(x), data=x, plan=plan)
         for rep in range(3):                                                 # buffers are reused decode after decode
             dec.run()
             if rank % 2 == rep % 2:
@@ -217,6 +217,40 @@ def test_sharded_decode_in_real_processes_equals_the_one_gpu_decode(tmp_path, wo
     if trim:
         sizes = [nat.shard_layout(p, world, r).own_hi - nat.shard_layout(p, world, r).own_lo for r in range(world)]
         assert min(sizes) > 0 and max(sizes) - min(sizes) <= x.shape[0] // 16   # only the rows that hold samples are dealt: equal shares
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,lpm,trim", [(2, 240, 0), (3, 120, 4478), (8, 240, 1234)])
+def test_multipole_plan_in_real_processes_equals_the_one_gpu_decode(tmp_path, world, lpm, trim):
+    """Plan 3 (chunk-local fast multipole Hilbert transform, csrc/wfx_shard.hip run_phase_fmm) over the shm transport: `world` processes on one
+    GPU, three decodes back to back, the ranks drifting apart -- stream, image, start frame equal the one-GPU decode, the envelope blocks
+    the one-GPU decode in the same Hilbert form bit for bit."""
+    from wefax_amd import sharded
+    from wefax_amd.wefax import DecodeJob, build_params
+    x = _capture(11025, 5, lpm, trim)
+    job = _job()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_decode_worker, args=(job, world, r, 5, 11025, lpm, str(tmp_path), q, trim, "fmm")) for r in range(world)]
+    for r in reversed(range(world)):
+        procs[r].start()
+        time.sleep(0.05)
+    out = dict(q.get(timeout=600) for _ in range(world))
+    for p_ in procs:
+        p_.join(30)
+    assert out == {r: "ok" for r in range(world)}, out
+    ctx = nat.Context(0)
+    ref = DecodeJob(ctx, x, 11025, lpm, hilbert_mode=nat.WFX_HILBERT_FMM)
+    ref.run()
+    info = ref.result()
+    assert np.array_equal(np.load(tmp_path / "stream.npy"), ref.fetch("digitalized"))
+    assert np.array_equal(np.load(tmp_path / "image.npy"), ref.fetch("image"))
+    assert list(np.load(tmp_path / "sync.npy")) == [info.start_frame, info.height, info.npeaks]
+    p, _ = build_params(sharded.capture_kind(x), x.shape[0], 11025, 1 / (lpm / 60), shard_plan=sharded.plan_code("fmm"))
+    lays = [nat.shard_layout(p, world, r) for r in range(world)]
+    assert lays[0].plan == 3
+    assert np.array_equal(sharded.assemble(lays, [np.load(tmp_path / f"env{r}.npy") for r in range(world)], x.shape[0]), ref.fetch("envelope"))
     ctx.close()
 
 

@@ -24,7 +24,7 @@ WFX_MAX_PEAKS = 100
 # every symbol include/wefax_hip.h declares (tests check that all are exported)
 SYMBOLS = [
     "wfx_device_count", "wfx_create", "wfx_destroy", "wfx_last_error", "wfx_sync",
-    "wfx_version", "wfx_merge_channels", "wfx_merge_channels_any", "wfx_resample", "wfx_notch_filtfilt", "wfx_notch_filtfilt_ext",
+    "wfx_version", "wfx_device_pci_bus_id", "wfx_merge_channels", "wfx_merge_channels_any", "wfx_resample", "wfx_notch_filtfilt", "wfx_notch_filtfilt_ext",
     "wfx_analytic_env", "wfx_order_stats", "wfx_quantise", "wfx_sync_corr",
     "wfx_sync_peaks", "wfx_lines_to_image", "wfx_packet_process", "wfx_packets_process", "wfx_packet_spectrum", "wfx_decode_upload", "wfx_decode_upload_fd", "wfx_decode_attach", "wfx_decode_run",
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
@@ -197,6 +197,7 @@ def load():
     lib.wfx_last_error.restype = C.c_char_p
     lib.wfx_version.restype = C.c_char_p
     lib.wfx_sync.argtypes = [vp]
+    lib.wfx_device_pci_bus_id.argtypes = [vp, C.c_char_p, i]
     lib.wfx_merge_channels.argtypes = [vp, vp, sz, vp]
     lib.wfx_merge_channels_any.argtypes = [vp, vp, i, sz, vp]
     lib.wfx_resample.argtypes = [vp, vp, sz, sz, vp]
@@ -717,6 +718,12 @@ class Context:
 
     def sync(self):
         self._check(self.lib.wfx_sync(self.h))
+
+    def pci_bus_id(self) -> str:
+        """PCI address of this context's GPU as sysfs names it (include/wefax_hip.h: wfx_device_pci_bus_id)."""
+        buf = C.create_string_buffer(32)
+        self._check(self.lib.wfx_device_pci_bus_id(self.h, buf, 32))
+        return buf.value.decode()
 
     # ---- measurement ------------------------------------------------------------
     def timer_start(self):

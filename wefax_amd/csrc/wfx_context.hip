@@ -100,6 +100,15 @@ extern "C" {
 
 const char *wfx_version(void) { return "wefax_hip 0.1 (gfx950)"; }
 
+int wfx_device_pci_bus_id(wfx_ctx *ctx, char *out, int cap)
+{
+    if (!ctx || !out || cap < 16) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "pci bus id: buffer of at least 16 bytes");
+    WFX_HIP(ctx, hipDeviceGetPCIBusId(out, cap, ctx->device));
+    for (char *p = out; *p; ++p)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+    return 0;
+}
+
 int wfx_device_count(void)
 {
     int n = 0;
