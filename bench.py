@@ -541,11 +541,15 @@ def bench_fmm(args, rk: Ranks, x) -> dict:
     dt = rk.timed(job.run, args.steps, args.warmup)
     ms = 1e3 * dt / args.steps
     info = job.result()
-    ref = DecodeJob(ctx, x, 11025, 120)
+    prof = profile_pass(ctx, job.run, args.steps)
+    dig = job.fetch("digitalized")
+    cref = nat.Context(rk.device)                      # (a context decodes the capture it was handed last: the comparison runs on another one)
+    ref = DecodeJob(cref, x, 11025, 120)
     ref.run()
     rinfo = ref.result()
-    same = bool(np.array_equal(job.fetch("digitalized"), ref.fetch("digitalized")) and info.start_frame == rinfo.start_frame)
-    prof = profile_pass(ctx, job.run, args.steps)
+    same = bool(np.array_equal(dig, ref.fetch("digitalized")) and info.start_frame == rinfo.start_frame)
+    del ref
+    cref.close()
     groups = {"notch_p2m_m2m": "fft_pass_fwd", "tiers_and_top": "bluestein_pointwise", "tree_levels": "fft_pass_inv", "near_l2p_env_median": "env_median"}
     us = {k: round(1e3 * prof[v][1] / args.steps, 1) for k, v in groups.items() if v in prof}
     t_fmm = sum(us.values()) * 1e-6

@@ -492,3 +492,27 @@ def test_decode_into_a_bound_image_buffer(ctx):
     finally:
         ctx.decode_bind_image(0, 0)
         ctx.dev_free(buf)
+
+
+@pytest.mark.gpu
+def test_lab_switches_set_to_garbage_change_nothing(monkeypatch):
+    """The switches that lived in the shipped library until round 5 (results "WRONG unless 0") are compiled out: with every one of them set to
+    garbage a golden still decodes to the reference's bytes."""
+    for v in ("WFX_INGEST_DBG", "WFX_INGEST_DBG_LDS", "WFX_INGEST_CLK", "WFX_FE_NO_EXACT", "WFX_NO_REAL_ODD", "WFX_NO_SMOOTH_PAD", "WFX_MR2", "WFX_MR2_PLAN",
+              "WFX_FUSED_SPECTRUM", "WFX_SHARD_ALL_ROWS", "WFX_FMM_LEAF"):
+        monkeypatch.setenv(v, "31")
+    from wefax_amd import Demodulator
+    for name in ("mono_noisy_240", "mono48k_noisy_120"):
+        case = next(c for c in golden_cases() if c["name"] == name)
+        g = load_golden(name)
+        d = Demodulator(input_path(case), lines_per_minute=case["lpm"], quiet=True, tcp_stream=True)
+        d.process()
+        assert np.array_equal(d.digitalized_data, g["digitalized"]) and d.start_frame == case["start_frame"]
+        assert np.array_equal(d.output_array, g["image"])
+        d.close()
+    d = Demodulator(input_path(next(c for c in golden_cases() if c["name"] == "iq1536k_2s_240")), lines_per_minute=240, quiet=True, tcp_stream=True, front_end="time-domain")
+    try:
+        d.process()
+    except (ValueError, IndexError):
+        pass
+    d.close()

@@ -402,3 +402,25 @@ def test_placed_allocation_keeps_the_best_candidate_and_frees_the_rest(monkeypat
     f = Fake([3.0, 2.0])
     p, rates = placed(f, 1 << 20, tries=2, probe=lambda q: {1: 3.0, 2: 2.0}[q])      # with a probe of the caller's, any size is timed
     assert p == 1 and rates == [3.0, 2.0] and f.live == [1]
+
+
+def test_the_shipped_library_reads_no_lab_switch_from_the_environment():
+    """Round-5 verdict: diagnostics that change results (WFX_INGEST_DBG: "results are WRONG unless 0") were read by the production library on
+    every launch.  They exist in variant builds only now (-DWFX_LAB: wfx_internal.h WFX_LAB_ENV); what the shipped sources still read with
+    getenv() is this list -- deployment settings and test hooks that select another, equivalent code path."""
+    import glob
+    import re
+    allowed = {"WFX_LINK_GBS", "WFX_LINK_LAT_US", "WFX_SHARD_CHUNKS", "WFX_SHARD_ROWS", "WFX_PNG_SLICE_KB", "WFX_PNG_THREADS", "WFX_DEBUG",
+               "WFX_INGEST_NI", "WFX_INGEST_TILE", "WFX_NO_CZT", "WFX_NO_I16_RESAMPLE", "WFX_MR_NT", "WFX_PICK_SEG", "WFX_COMM_ASYNC"}
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wefax_amd", "csrc")
+    seen = set()
+    for f in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
+        for line in open(f):
+            if "#define WFX_LAB_ENV(name) getenv(name)" in line:
+                continue
+            seen |= set(re.findall(r'(?<!LAB_ENV\()\bgetenv\("([A-Z0-9_]+)"\)', line))
+    assert seen <= allowed, sorted(seen - allowed)
+    lab = set()
+    for f in glob.glob(os.path.join(root, "*.hip")):
+        lab |= set(re.findall(r'WFX_LAB_ENV\("([A-Z0-9_]+)"\)', open(f).read()))
+    assert "WFX_INGEST_DBG" in lab and not (lab & allowed)

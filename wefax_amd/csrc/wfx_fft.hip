@@ -1097,7 +1097,7 @@ static int hilbert_conv(wfx_ctx *ctx, const double *x, uint64_t n, cplx **W_out,
         return wfx_dev_hilbert_conv_mr(ctx, x, n, W_out);
     }
     // any other even N: the same packed convolution zero-padded to a 13-smooth M >= N - 1 on the mixed-radix passes
-    if ((n & 1) == 0 && n >= 8192 && !ctx->force_pow2 && !getenv("WFX_NO_SMOOTH_PAD")) {
+    if ((n & 1) == 0 && n >= 8192 && !ctx->force_pow2 && !WFX_LAB_ENV("WFX_NO_SMOOTH_PAD")) {
         int handled = 0;
         WFX_TRY(wfx_dev_hilbert_conv_mr_padded(ctx, x, n, W_out, &handled));
         if (handled) {
@@ -1109,7 +1109,7 @@ static int hilbert_conv(wfx_ctx *ctx, const double *x, uint64_t n, cplx **W_out,
     // odd N: samples and kernel are real -- two packed transforms of M/2 >= N points and a glue pass (wfx_mrfft.hip, round 4);
     // the result is H as a flat array of doubles (*packed_out = 2).  x[n] (the odd sample's partner in the last pair) must be zero:
     // every caller hands over a context buffer with slack behind the n samples
-    if ((n & 1) == 1 && n >= 8192 && !ctx->force_pow2 && !getenv("WFX_NO_REAL_ODD")) {
+    if ((n & 1) == 1 && n >= 8192 && !ctx->force_pow2 && !WFX_LAB_ENV("WFX_NO_REAL_ODD")) {
         WFX_HIP(ctx, hipMemsetAsync((void *)(x + n), 0, sizeof(double), ctx->stream));
         int handled = 0;
         WFX_TRY(wfx_dev_hilbert_conv_mr_real(ctx, x, n, W_out, &handled));

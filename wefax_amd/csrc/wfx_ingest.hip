@@ -98,8 +98,8 @@ struct ig_params {
     long long in_bs, out_bs;    // batch strides (bytes / elements)
     long long out0;             // first output of the launch's first run
     long long bias;             // 128 * sum of the fixed-point taps (the low plane is stored less 128)
-    unsigned long long *dbg_clk;        // diagnostics (WFX_INGEST_CLK=1): every 64th run's (shader clocks, 100 MHz ticks) -> the effective shader clock
-    int dbg_flags;              // diagnostics (WFX_INGEST_DBG=flags; results are WRONG unless 0): 1 no stash, 2 no stage 2, 4 no stage 1, 8 no barrier B; WFX_INGEST_DBG_LDS: extra LDS bytes
+    unsigned long long *dbg_clk;        // lab builds only (-DWFX_LAB; WFX_INGEST_CLK=1): every 64th run's (shader clocks, 100 MHz ticks) -> the effective shader clock
+    int dbg_flags;              // lab builds only (-DWFX_LAB; WFX_INGEST_DBG=flags; results are WRONG unless 0): 1 no stash, 2 no stage 2, 4 no stage 1, 8 no barrier B; WFX_INGEST_DBG_LDS: extra LDS bytes
 };
 
 // frames [e0, e0 + FPC) as one 16-byte chunk; frames at or beyond n_in read as zero
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     const unsigned char *in = (const unsigned char *)P.in + (size_t)blockIdx.y * (size_t)P.in_bs;
     double *out = P.out + (size_t)blockIdx.y * (size_t)P.out_bs;
 
-    const unsigned long long clk0 = P.dbg_clk ? (unsigned long long)clock64() : 0ull, wall0 = P.dbg_clk ? (unsigned long long)wall_clock64() : 0ull;
+    const unsigned long long clk0 = WFX_LAB_FLAGS(P.dbg_clk != nullptr) ? (unsigned long long)clock64() : 0ull, wall0 = WFX_LAB_FLAGS(P.dbg_clk != nullptr) ? (unsigned long long)wall_clock64() : 0ull;
     // run = blockIdx.x: workgroups go round-robin to the 8 XCDs, so the ~768 resident ones stream through 768 neighbouring runs, every
     // XCD through every eighth one.  (Dealing each XCD ONE eighth of the capture -- its 96 workgroups on 96 neighbouring runs -- measured
     // 9 % slower, 4.00 against 3.68 ms on the 60-minute stream: EXPERIMENTS.md §9.)
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     // lines are written made no difference, the cache policy did (EXPERIMENTS.md 9.1).
     auto flush = [&]() {
         if (M2 == 0) return;
-        if (pend_k >= 0 && !(P.dbg_flags & 16)) {                          // (16: nothing is stored)
+        if (pend_k >= 0 && !WFX_LAB_FLAGS(P.dbg_flags & 16)) {                          // (16: nothing is stored)
             typedef unsigned ig_v2u __attribute__((ext_vector_type(2)));
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(out + o0), 0, 0x7fffffff, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ig_v2u, pend), orsrc, (unsigned)pend_k * 8u, 0, IG_STORE_AUX);
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     for (int n = 0; n < niter; ++n) {
         __syncthreads();                       // A: stage 1 of iteration n - 1 is done with the rows and its sums are complete; stage 2 is done with the ring
         if (n > 0 && t < IG_HALO * IG_RD) cw[0] = carry;
-        if (!(P.dbg_flags & 1)) {
+        if (!WFX_LAB_FLAGS(P.dbg_flags & 1)) {
 #pragma unroll
             for (int u = 0; u < CPT; ++u) put(xput + u * ig_row_off(RPU), v[u]);
         } else {      // (keeps the loads alive)
@@ -352,19 +352,19 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
         if (n + 1 < niter) load_block(n + 1);   // in flight during the whole compute phase
         __builtin_amdgcn_sched_barrier(0);
         if (M2 != 0 && n > 0) convert(n - 1);
-        if (!(P.dbg_flags & 8)) __syncthreads();                       // B: the rows are in place, block n - 1 is in the ring
-        if (!(P.dbg_flags & 4)) stage1(n);
-        if (n > 0 && !(P.dbg_flags & 2)) stage2(n - 1);
+        if (!WFX_LAB_FLAGS(P.dbg_flags & 8)) __syncthreads();                       // B: the rows are in place, block n - 1 is in the ring
+        if (!WFX_LAB_FLAGS(P.dbg_flags & 4)) stage1(n);
+        if (n > 0 && !WFX_LAB_FLAGS(P.dbg_flags & 2)) stage2(n - 1);
         if (t < IG_HALO * IG_RD) carry = cw[ig_row_off(IG_BLK)];
     }
     __syncthreads();
     convert(niter - 1);
-    if (M2 && !(P.dbg_flags & 2)) {
+    if (M2 && !WFX_LAB_FLAGS(P.dbg_flags & 2)) {
         __syncthreads();
         stage2(niter - 1);
     }
     flush();
-    if (P.dbg_clk && t == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x >> 6) < 2048) {
+    if (WFX_LAB_FLAGS(P.dbg_clk != nullptr) && t == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x >> 6) < 2048) {
         P.dbg_clk[2 * (blockIdx.x >> 6)] = (unsigned long long)clock64() - clk0;
         P.dbg_clk[2 * (blockIdx.x >> 6) + 1] = (unsigned long long)wall_clock64() - wall0;
     }
@@ -504,10 +504,10 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
     P.out0 = 0;
     P.bias = 128 * tsum;
     P.dbg_flags = 0;
-    if (const char *e = getenv("WFX_INGEST_DBG")) P.dbg_flags = atoi(e);
+    if (const char *e = WFX_LAB_ENV("WFX_INGEST_DBG")) P.dbg_flags = atoi(e);
     P.dbg_clk = nullptr;
     static unsigned long long *clk_buf = nullptr;
-    if (getenv("WFX_INGEST_CLK")) {
+    if (WFX_LAB_ENV("WFX_INGEST_CLK")) {
         if (!clk_buf) (void)hipMalloc((void **)&clk_buf, 2 * 2048 * sizeof(unsigned long long));
         if (clk_buf) (void)hipMemsetAsync(clk_buf, 0, 2 * 2048 * sizeof(unsigned long long), ctx->stream);
         P.dbg_clk = clk_buf;
@@ -531,7 +531,7 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
         return factor2 == 0 ? ingest_stream_kernel<WFX_IN_I16_MONO, 0, false> : factor2 == 2 ? ingest_stream_kernel<WFX_IN_I16_MONO, 2, false> : ingest_stream_kernel<WFX_IN_I16_MONO, 3, false>;
     };
     size_t lds = (size_t)IG_XS_BYTES + IG_BLK * 8 + IG_TAB * 4 + (factor2 ? (size_t)IG_YS_BYTES : 0);
-    if (const char *e = getenv("WFX_INGEST_DBG_LDS")) {
+    if (const char *e = WFX_LAB_ENV("WFX_INGEST_DBG_LDS")) {
         lds += (size_t)atoi(e);
         (void)hipFuncSetAttribute((const void *)pick(false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)pick(true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -234,6 +234,19 @@ static inline unsigned wfx_stream_grid(uint64_t n, unsigned per_block)
     return (unsigned)b;
 }
 
+// Lab switches (A/B experiments, diagnostics that CHANGE results) exist only in variant builds: `bash tools/build_variant.sh <name> <source>
+// -DWFX_LAB` -- in the shipped library WFX_LAB_ENV(x) is a constant null pointer and the branches behind it are compiled away.  What remains
+// readable from the environment are settings a deployment may want (WFX_LINK_GBS, WFX_LINK_LAT_US, WFX_SHARD_CHUNKS, WFX_SHARD_ROWS,
+// WFX_PNG_*, WFX_PLACE_TRIES, WFX_DEBUG) and test hooks that select another, EQUIVALENT code path (WFX_INGEST_NI, WFX_INGEST_TILE, WFX_NO_CZT,
+// WFX_NO_I16_RESAMPLE, WFX_MR_NT, WFX_PICK_SEG, WFX_COMM_ASYNC): none of them can make a result wrong.
+#ifdef WFX_LAB
+#define WFX_LAB_ENV(name) getenv(name)
+#define WFX_LAB_FLAGS(expr) (expr)
+#else
+#define WFX_LAB_ENV(name) ((const char *)nullptr)
+#define WFX_LAB_FLAGS(expr) (0)
+#endif
+
 // ---- radix-select helpers shared by the kernels that fuse the level-0 histogram ----
 #define WFX_SEL_BINS 2048
 #ifdef __HIPCC__

@@ -1058,7 +1058,7 @@ static bool mr_make_plan(long long L, mr_plan_host &pl)
     std::vector<int> cur, best;
     double best_cost = 1e30;
     bool forced = false;
-    if (const char *e = getenv("WFX_MR2_PLAN")) {       // experiments: "7x13,7x25,15x15" = the passes in this order
+    if (const char *e = WFX_LAB_ENV("WFX_MR2_PLAN")) {       // experiments: "7x13,7x25,15x15" = the passes in this order
         const int np = (int)(sizeof(g_mr2_pairs) / sizeof(g_mr2_pairs[0]));
         long long prod = 1;
         int a = 0, b = 0, used = 0;
@@ -1198,14 +1198,14 @@ static int mr_get_plan(wfx_ctx *ctx, long long L, mr_plan_cache **out)
     mr_plan_cache pc;
     if (!mr_make_plan(L, pc.h)) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "length %lld is not 13-smooth", L);
     {
-        const char *e = getenv("WFX_MR2");
+        const char *e = WFX_LAB_ENV("WFX_MR2");
         pc.use_mr2 = !(e && e[0] == '0');
     }
     // The fused spectral pass (last forward + first inverse pass in one kernel, inverse radices reversed) saves one trip of the
     // array through memory.  That pays where the array lives in HBM (the 60-minute captures: 317 MB per array, -30 us of 1140);
     // on the 10-minute capture (57 MB, Infinity-Cache resident) the passes are bound by their on-chip work and the two orders
     // measure 161 against 158 us, so the classic order stays there.  WFX_FUSED_SPECTRUM=1 / 0 forces it on / off.
-    const char *fe = getenv("WFX_FUSED_SPECTRUM");
+    const char *fe = WFX_LAB_ENV("WFX_FUSED_SPECTRUM");
     const bool want_fused = fe ? fe[0] != '0' : L >= (1ll << 23);
     const bool have_inv = pc.use_mr2 && want_fused && mr_make_reverse(pc.h, pc.hinv);
     if (!have_inv) pc.hinv.npass = 0;

@@ -514,7 +514,7 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
     const bool aligned = M >= per16 && ilog2_exact(M) >= 0;
     // the streaming kernel (wfx_ingest.hip) takes the ingest when the first window sits on the 16-byte grid (no tap shift needed)
     if (aligned && in_kind != WFX_IN_F64_MONO && fix_shift >= 8 && first >= 0 && (uint64_t)first < n_in && (first + misalign) % per16 == 0 &&
-        !getenv("WFX_FE_NO_EXACT")) {
+        !WFX_LAB_ENV("WFX_FE_NO_EXACT")) {
         int handled = 0;
         WFX_TRY(wfx_dev_ingest_stream(ctx, (const unsigned char *)in + (size_t)first * ebytes, in_kind, n_in - (uint64_t)first, M, coef, ntaps, fix_shift,
                                       0, nullptr, 0, out, n_out, nbatch, in_stride, out_stride, &handled));
@@ -532,7 +532,7 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
     const int per_row = (nt + M - 1) / M;
     const int q4 = (per_row + 3) / 4;
     const long long ni = (long long)n_in, no = (long long)n_out;
-    if (aligned && in_kind != WFX_IN_F64_MONO && fix_shift >= 8 && fix_shift <= 40 && !getenv("WFX_FE_NO_EXACT")) {
+    if (aligned && in_kind != WFX_IN_F64_MONO && fix_shift >= 8 && fix_shift <= 40 && !WFX_LAB_ENV("WFX_FE_NO_EXACT")) {
         // fixed-point taps; row r: E_hi[2 q4] E_lo[2 q4] D_hi[2 q4 + 2] D_lo[2 q4 + 2] as int16 pairs (E[p] = (c[2p], c[2p+1]) of the
         // row's taps c[k] = coef[r + M k - d], D[p] = (c[2p-1], c[2p]))
         const size_t rowlen = (size_t)8 * q4 + 4;

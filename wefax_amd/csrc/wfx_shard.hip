@@ -262,7 +262,7 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     {
         const long long ms = pl.Kp / (ra1 * rb1);
         const int rv = (int)((pl.K + ms - 1) / ms);
-        pl.split_kernel = pl.padded && world > 1 && rv < ra1 * rb1 && !getenv("WFX_SHARD_ALL_ROWS");      // (A/B switch: all R1 rows dealt, as before)
+        pl.split_kernel = pl.padded && world > 1 && rv < ra1 * rb1 && !WFX_LAB_ENV("WFX_SHARD_ALL_ROWS");      // (A/B switch: all R1 rows dealt, as before)
         if (!wfx_dist_make_geom(pl.g, world, rank, ra1, rb1, pl.split_kernel ? rv : 0)) return single("no geometry for this world size");
         if (pl.split_kernel && !wfx_dist_make_geom(pl.gk, world, rank, ra1, rb1)) return single("no geometry for this world size");
     }
