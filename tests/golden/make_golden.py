@@ -170,7 +170,10 @@ def main():
     #    modulo 256, int32 modulo 2**32, float32 stays float32 (and so does the list filtfilt later extends at its ends)
     for rname in ("mono_clean_120", "mono_noisy_120", "mono_noisy_240", "mono_noise20_lead", "mono48k_noisy_120", "stereo48k_120",
                   "stereo_overflow_120", "mono8k_noisy_120", "mono48k_image_240", "stereo48k_image_240", "mono_u8_240", "mono_f32_240",
-                  "mono_i32_240", "stereo_u8_240", "stereo_i32_240", "stereo_f32_240"):
+                  "mono_i32_240", "stereo_u8_240", "stereo_i32_240", "stereo_f32_240",
+                  # 10d (round 6) wav shapes the reader accepts and nothing pinned: 24-bit PCM (int32, left-justified, in scipy's hands), float64,
+                  #     three channels (wefax.py:365 merges the first two and ignores the rest)
+                  "mono_i24_240", "mono_f64_240", "three_ch_240"):
         if only is None or rname in only:
             fs_r, data_r, lpm_r = recipes.RECIPES[rname]()
             emit(rname, fs_r, data_r, lpm_r, recipe=rname)

@@ -121,7 +121,25 @@ def _stereo_f32_240():
     return 11025, np.stack([f32, f32 * np.float32(0.3333333)], axis=1), 240
 
 
-RECIPES = {"iq1536k_2s_240": _iq1536k_2s_240, "stereo192k_6s_240": _stereo192k_6s_240, "mono48k_f32_240": _mono48k_f32_240,
+def _mono_i24_240():
+    # 24-bit PCM: scipy.io.wavfile.read hands the reference int32 samples, left-justified (value * 256)
+    from wefax_amd import synth
+    v = np.clip(_base240(44).astype(np.int32) * 200 + 77, -(1 << 23), (1 << 23) - 1).astype(np.int32)
+    return 11025, v.view(synth.Pcm24), 240
+
+
+def _mono_f64_240():
+    return 11025, _base240(45).astype(np.float64) / 32768.0 * 1.0000001, 240
+
+
+def _three_ch_240():
+    # wefax.py:365 merges channels 0 and 1 and never looks at a third one
+    x = _base240(46)
+    rng = np.random.default_rng(46)
+    return 11025, np.stack([x, (x.astype(np.int32) * 3 // 4).astype(np.int16), rng.integers(-30000, 30000, x.shape[0]).astype(np.int16)], axis=1), 240
+
+
+RECIPES = {"mono_i24_240": _mono_i24_240, "mono_f64_240": _mono_f64_240, "three_ch_240": _three_ch_240, "iq1536k_2s_240": _iq1536k_2s_240, "stereo192k_6s_240": _stereo192k_6s_240, "mono48k_f32_240": _mono48k_f32_240,
            "mono_clean_120": _mono_clean_120, "mono_noisy_120": _mono_noisy_120, "mono_noisy_240": _mono_noisy_240,
            "mono_noise20_lead": _mono_noise20_lead, "mono48k_noisy_120": _mono48k_noisy_120, "stereo48k_120": _stereo48k_120,
            "stereo_overflow_120": _stereo_overflow_120, "mono8k_noisy_120": _mono8k_noisy_120, "mono48k_image_240": _mono48k_image_240,

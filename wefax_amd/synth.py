@@ -132,8 +132,13 @@ def config_c5_member(i: int, noise: float = 0.0) -> tuple[np.ndarray, int]:
     return x, lpm
 
 
+class Pcm24(np.ndarray):
+    """Marker: an int32 array whose values are 24-bit samples (-2**23 .. 2**23 - 1); ``write_wav`` stores three bytes each."""
+
+
 def write_wav(path: str, fs: int, data: np.ndarray) -> None:
-    """Minimal PCM RIFF writer (int16 mono / multi-channel, uint8, int32, float32)."""
+    """Minimal PCM RIFF writer (int16 mono / multi-channel, uint8, int32, 24-bit via ``Pcm24``, float32, float64)."""
+    pcm24 = isinstance(data, Pcm24)
     data = np.ascontiguousarray(data)
     ch = 1 if data.ndim == 1 else data.shape[1]
     if data.dtype == np.float32 or data.dtype == np.float64:
@@ -142,6 +147,9 @@ def write_wav(path: str, fs: int, data: np.ndarray) -> None:
         fmt_tag = 1
     bits = data.dtype.itemsize * 8
     raw = data.astype(data.dtype.newbyteorder("<"), copy=False).tobytes()
+    if pcm24:
+        bits = 24
+        raw = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 4)[:, :3].tobytes()
     hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(raw), b"WAVE",
                       b"fmt ", 16, fmt_tag, ch, int(fs),
                       int(fs) * ch * bits // 8, ch * bits // 8, bits,
