@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--cases", type=int, default=12)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--fs", type=int, default=0, help="every clip at this rate (default: 1.536 MS/s, 192 kHz and 48 kHz mixed)")
+    ap.add_argument("--ugly", action="store_true", help="a short-wave channel: selective fading (0-100 %%), +-50 Hz carrier drift, impulsive noise, clipping, DC offset (synth.synth_capture ugly=...)")
     ap.add_argument("--out", default=None, help="also append the per-case records and the summary to this file (JSON lines)")
     a = ap.parse_args()
     sink = open(a.out, "a") if a.out else None
@@ -49,8 +50,13 @@ def main():
             t_line = 60.0 / lpm
             phasing = 40 if lpm == 240 else 20
             lines = int(round((seconds - 3.0) / t_line)) - phasing
+            ugly = None
+            if a.ugly:
+                ugly = dict(fade_depth=float(rng.choice([0.3, 0.7, 1.0])), fade_hz=float(rng.uniform(0.05, 0.5)), drift_hz=float(rng.uniform(-50, 50)),
+                            impulses_per_s=float(rng.choice([0.0, 2.0, 10.0])), impulse_fs=float(rng.uniform(0.3, 1.0)), clip=float(rng.choice([1.0, 1.6, 2.5])),
+                            dc=float(rng.uniform(-0.1, 0.1)))
             x = synth.synth_capture(float(fs), noise=float(rng.choice([0.01, 0.05, 0.1])), seed=int(rng.integers(1 << 30)), lpm=lpm, phasing_lines=phasing,
-                                    image_lines=lines, start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0, iq=iq)
+                                    image_lines=lines, start_tone_s=1.0, stop_tone_s=1.0, black_tail_s=1.0, iq=iq, ugly=ugly)
             fe = pp.FrontEnd(fs, stop_rate=pp.FrontEnd.handover_rate(fs))
             if rng.integers(0, 2):       # not a whole number of seconds (still whole hand-over samples): int(11025 * n0 / fs) != n0 * 11025 / fs
                 x = np.ascontiguousarray(x[:x.shape[0] - fe.granule() * int(rng.integers(1, 5000))])
@@ -60,7 +66,7 @@ def main():
             dec = sharded.FrontEndExactDecoder(ctx, fe, x, lines_per_minute=lpm)
             dec.run()
             info = dec.result()
-            rec = dict(fs=fs, lpm=lpm, seconds=seconds, frames=int(x.shape[0]), whole_seconds=bool(x.shape[0] % fs == 0), f64_chain=bool(fe.f64),
+            rec = dict(ugly=ugly, fs=fs, lpm=lpm, seconds=seconds, frames=int(x.shape[0]), whole_seconds=bool(x.shape[0] % fs == 0), f64_chain=bool(fe.f64),
                        exact_ingest=dec.fe.exact_ingest)
             if ref.get("exception") is not None or info.no_group:
                 rec["no_group"] = [ref.get("exception") is not None, bool(info.no_group)]

@@ -89,22 +89,48 @@ def synth_capture(fs: float = 11025.0, noise: float = 0.0, seed: int = 0,
     ``noise`` is the standard deviation of additive white Gaussian noise in
     units of full scale.
     """
+    ugly = kw.pop("ugly", None)
     f = wefax_frequency_track(fs, **kw)
-    phi = _phase(fs, f)
     rng = np.random.default_rng(seed)
+    n = f.shape[0]
+    env = 1.0
+    dc = 0.0
+    if ugly:
+        # a short-wave channel instead of a laboratory one (round 6): ``ugly`` = dict(fade_depth 0..1, fade_hz, drift_hz, impulses_per_s,
+        # impulse_fs, clip, dc): slow selective fading of the amplitude, a carrier that drifts by up to drift_hz, impulsive noise, clipping at
+        # full scale (clip = gain in front of the converter), a constant offset
+        t = np.arange(n) / fs
+        env = 1.0 - float(ugly.get("fade_depth", 0.0)) * 0.5 * (1.0 + np.sin(2 * np.pi * float(ugly.get("fade_hz", 0.2)) * t + rng.uniform(0, 2 * np.pi)))
+        f = np.where(f > 0, f + float(ugly.get("drift_hz", 0.0)) * np.sin(2 * np.pi * t / max(t[-1], 1.0) * float(ugly.get("drift_cycles", 1.5))), f)
+        dc = float(ugly.get("dc", 0.0))
+    phi = _phase(fs, f)
+
+    def dirt(x):
+        if not ugly:
+            return x
+        rate = float(ugly.get("impulses_per_s", 0.0))
+        if rate > 0:
+            k = rng.poisson(rate * n / fs)
+            pos = rng.integers(0, n, k)
+            width = max(1, int(fs * 2e-4))
+            amp = float(ugly.get("impulse_fs", 0.8)) * rng.choice([-1.0, 1.0], k)
+            for p_, a_ in zip(pos, amp):
+                x[p_:p_ + width] += a_
+        return np.clip((x + dc) * float(ugly.get("clip", 1.0)), -1.0, 32767.0 / 32768.0)
+
     if not iq:
-        x = amplitude * np.sin(phi)
+        x = amplitude * env * np.sin(phi)
         if kw.get("lead_silence_s", 0.0) > 0:
             x[f == 0.0] = 0.0
         if noise > 0:
             x = x + noise * rng.standard_normal(x.shape[0])
-        return _to_int16(x)
-    xi = amplitude * np.cos(phi)
-    xq = amplitude * np.sin(phi)
+        return _to_int16(dirt(x))
+    xi = amplitude * env * np.cos(phi)
+    xq = amplitude * env * np.sin(phi)
     if noise > 0:
         xi = xi + noise * rng.standard_normal(xi.shape[0])
         xq = xq + noise * rng.standard_normal(xq.shape[0])
-    return np.stack([_to_int16(xi), _to_int16(xq)], axis=1)
+    return np.stack([_to_int16(dirt(xi)), _to_int16(dirt(xq))], axis=1)
 
 
 # The workloads BASELINE.json names (SURVEY.md section 8d).
