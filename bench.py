@@ -619,6 +619,38 @@ def bench_c5(args, rk: Ranks) -> dict:
             "note": "captures resident in HBM when a round's clock starts; eight host threads enqueue and wait; no collective (replicas only)"}
 
 
+
+# ---- BASELINE configs[1] as ONE capture over all ranks: plan 3 (chunk-local multipole, KBs on the wire) beside plan 1 (distributed transforms) ----
+def bench_c2_strong(args, rk: Ranks) -> dict:
+    """Strong scaling of the 10-minute capture, both sharded plans in the same run (N > 1 only).  Unmeasured on hardware until a multi-GPU box
+    runs it: the plans' own cost-model projections ride beside the measured times."""
+    import numpy as np
+    from wefax_amd import sharded, synth
+    nat, ctx = rk.nat, rk.ctx
+    x = synth.config_c2(noise=args.noise, seed=0)
+    out = {"workload": f"ONE synthetic 10-min 11.025 kHz capture (BASELINE configs[1], {x.shape[0]} samples) decoded by {rk.world} ranks together",
+           "n_gpus": rk.world, "transport": rk.transport_name(), "scaling": "strong"}
+    steps = max(3, min(args.steps, 10))
+    for plan in ("fmm", "dist"):
+        try:
+            dec = sharded.ShardedDecoder(ctx, rk.comm, x.shape[0], 11025, 120, nat.WFX_IN_I16_MONO, data=x, plan=plan)
+            dt = rk.timed(dec.run, steps, 2)
+            ms = 1e3 * dt / steps
+            info = dec.result()
+            w = wire_object(rk, dec.params, dec.layout, dec.run, ctx.sync)
+            sent = [e for e in w["this_rank"]]
+            out[plan] = {"ms_per_step": round(ms, 4), "value": round(x.shape[0] / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s",
+                         "start_frame": int(info.start_frame) if rk.rank == 0 else None, "layout": w["layout"],
+                         "bytes_this_rank_sent": int(w["this_rank_sent"]),
+                         "bytes_this_rank_sent_without_the_stream_gather": int(sum(e["sent"] for e in sent if e["name"] != "stream gather")),
+                         "collectives_us": w["this_rank_us"], "model_ms": w["model"]["dist_ms"], "model_one_gpu_ms": w["model"]["one_gpu_ms"],
+                         "per_collective": [{k: e.get(k) for k in ("name", "sent", "received", "us", "wait_us", "link_GBs")} for e in sent]}
+            dec.close()
+        except Exception as e:      # noqa: BLE001
+            out[plan] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
 # ---- BASELINE configs[3]: the oversampled IQ stream, all ranks on ONE capture ---------------------------------------
 def iq_recipe(seconds: float):
     if seconds < 30:
@@ -644,7 +676,7 @@ def wire_object(rk: Ranks, params, layout, run, sync) -> dict:
         e.update(t)
         e["link_GBs"] = round(e["largest_message"] / (t["us"] * 1e-6) / 1e9, 2) if (t["us"] and e["largest_message"]) else None
     tot = lambda key: round(sum(e.get(key) or 0.0 for e in mine), 1)       # noqa: E731
-    return {"layout": {0: "single (rank 0 alone)", 1: "rows", 2: "columns"}[int(layout.plan)], "chosen_by": "caller" if layout.plan_forced else "cost model",
+    return {"layout": {0: "single (rank 0 alone)", 1: "rows", 2: "columns", 3: "chunk-local multipole (plan 3)"}[int(layout.plan)], "chosen_by": "caller" if layout.plan_forced else "cost model",
             "reason": layout.plan_reason.decode(), "total_bytes": sum(e["bytes"] for e in plan),
             "array_transposes": sum(1 for e in plan if " E" in e["name"]),
             "per_collective": plan, "this_rank_sent": sum(e["sent"] for e in mine), "this_rank": mine,
@@ -1285,6 +1317,8 @@ def main():
                     if os.environ.get("WFX_BENCH_TEST_FAIL_RANK") == str(rk.rank):      # exercises the guard (tools/, tests)
                         raise RuntimeError("injected failure on this rank")
                     line["c4_strong"] = bench_iq(args, rk, secs, min(args.steps, 10), 2, not args.no_cpu)
+                    if rk.world > 1:
+                        line["c2_strong"] = bench_c2_strong(args, rk)
                 except Exception as e:      # noqa: BLE001 -- reported in the line, the headline stands
                     if rk.world == 1:
                         raise

@@ -15,7 +15,7 @@ mkdir -p "$PWD/gpurun_out"
   echo "== ingest probe (16 GiB), clocks sampled every 0.5 s while it runs"
   ( for i in $(seq 1 40); do rocm-smi --showclocks --showpower 2>/dev/null | grep -E 'sclk|mclk|fclk|Power' | tr -s ' ' | tr '\n' ';'; echo; sleep 0.5; done ) > /tmp/clk_samples.txt &
   SAMPLER=$!
-  timeout 300 python tools/ingest_probe.py 2>&1 | tail -5
+  timeout 300 python tools/ingest_lab.py taps 2>&1 | tail -5
   kill $SAMPLER 2>/dev/null; wait $SAMPLER 2>/dev/null
   echo "-- clock samples under load (distinct lines, with counts)"; sort /tmp/clk_samples.txt | uniq -c | sort -rn | head -12
   echo "== configs[3] on this box"; python bench.py --workload iq --no-cpu --steps 10 --warmup 2 2>/dev/null | python -c "

@@ -119,10 +119,10 @@ timeout 1200 python tools/random_shard_parity.py --cases 80 --seed 6 > "$OUT/ran
 # self-test failing -> fallback, one RCCL rank with event-timed collectives), the ingest kernel taken apart, instruction rates
 bash tools/r05_bench_paths.sh "$TAG/paths" > "$OUT/bench_paths.txt" 2>&1
 timeout 600 python tools/ingest_lab.py 16 > "$OUT/ingest_lab_16GiB.txt" 2>> "$OUT/bench.err"
-timeout 600 python tools/ingest_lab2.py > "$OUT/ingest_lab_60min_stream.txt" 2>&1
-timeout 600 python tools/ingest_lab3.py > "$OUT/ingest_lab_placement.txt" 2>> "$OUT/bench.err"
-timeout 600 python tools/ingest_lab4.py > "$OUT/ingest_lab_allocations.txt" 2>> "$OUT/bench.err"
-timeout 600 python tools/alloc_lab.py 16 > "$OUT/alloc_lab.txt" 2>> "$OUT/bench.err"
+timeout 600 python tools/ingest_lab.py stream > "$OUT/ingest_lab_60min_stream.txt" 2>&1
+timeout 600 python tools/ingest_lab.py where > "$OUT/ingest_lab_placement.txt" 2>> "$OUT/bench.err"
+timeout 600 python tools/ingest_lab.py allocations > "$OUT/ingest_lab_allocations.txt" 2>> "$OUT/bench.err"
+timeout 600 python tools/ingest_lab.py realloc 16 > "$OUT/alloc_lab.txt" 2>> "$OUT/bench.err"
 [ -x tools/micro/build/valu_rate ] && timeout 120 tools/micro/build/valu_rate > "$OUT/valu_rate.txt" 2>&1
 [ -x tools/micro/build/stream_pattern ] && timeout 300 tools/micro/build/stream_pattern > "$OUT/stream_pattern.txt" 2>&1
 python tools/e2e_c3_debug.py 2>&1 | grep -v sync_pick > "$OUT/e2e_c3_stages.txt"
@@ -133,7 +133,7 @@ rm -rf "$OUT/sq_iq"
 
 # the read-streaming ceiling of this box and the ingest stage against it
 if [ -x tools/micro/build/stream_big ]; then timeout 120 tools/micro/build/stream_big > "$OUT/stream_ceiling.txt" 2>&1; fi
-timeout 600 python tools/ingest_probe.py > "$OUT/ingest_probe.txt" 2>> "$OUT/bench.err"
+timeout 600 python tools/ingest_lab.py taps > "$OUT/ingest_probe.txt" 2>> "$OUT/bench.err"
 
 # where the waves' cycles go (SQ counters, one pass)
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/sq" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-c4 --no-pcie --no-extras > /dev/null 2>> "$OUT/bench.err"
