@@ -698,7 +698,7 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
     n0 = int(ctx.lib.wfx_synth_frames(sp))
     fe = polyphase.FrontEnd(IQ_FS, stop_rate=args.iq_stop_rate)
     raw_loader = synth_device.SliceLoader(ctx, sp)
-    # where a capture's pages lie is worth up to 15 % to the ingest's ~770 streams (EXPERIMENTS.md 9.2): the capture buffer is the
+    # where a capture's pages lie is worth up to 15 % to the ingest's ~770 streams (docs/history/EXPERIMENTS_rounds1-5.md 9.2): the capture buffer is the
     # best of a few allocations (Context.dev_malloc_placed; every candidate's rate is in `placement`).  WFX_PLACE_TRIES=1 takes the first.
     os.environ.setdefault("WFX_PLACE_TRIES", "4")
     del synth_device.PLACEMENTS[:]

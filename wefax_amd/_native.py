@@ -666,12 +666,13 @@ class Context:
 
     def dev_malloc_placed(self, nbytes: int, tries: int | None = None, good_gbs: float = 6000.0, probe=None):
         """Device memory for a capture the streaming ingest will read many times (or, with ``probe``, for the buffer it writes): the same
-        bytes stream up to 15 % slower through one allocation than through another of the same process (EXPERIMENTS.md §9.2), so up
-        to ``tries`` allocations (``WFX_PLACE_TRIES``, default 1 = take the first) are held side by side and timed -- ``probe(ptr)`` ->
+        bytes stream up to 15 % slower through one allocation than through another of the same process (docs/history/EXPERIMENTS_rounds1-5.md §9.2), so up
+        to ``tries`` allocations (``WFX_PLACE_TRIES``, default 4 since round 6 -- what bench.py always used, so that the product and the
+        bench line agree; 1 = take the first) are held side by side and timed (~4 ms each at 22 GB) -- ``probe(ptr)`` ->
         GB/s, default ``d_stream_rate`` on the allocation as the capture -- until one reaches ``good_gbs``; the best is kept, the others
         are freed.  Returns (pointer, [GB/s of every candidate, in order]); without a probe, captures under 1 GiB are not timed."""
         if tries is None:
-            tries = int(os.environ.get("WFX_PLACE_TRIES", "1"))
+            tries = int(os.environ.get("WFX_PLACE_TRIES", "4"))
         if tries <= 1 or (probe is None and nbytes < (1 << 30)):
             return self.dev_malloc(nbytes), []
         if probe is None:

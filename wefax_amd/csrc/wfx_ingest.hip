@@ -29,7 +29,7 @@
 //     and one atomic per 16 rows; 128 sum(taps) for the low plane's offset joins when the cell is converted to float64.
 //     (Round 5 first ran this stage on v_dot2_i32_i16 with the taps as scalar operands, then as MFMAs over windows read once per
 //     output: both read every sample 8 x from LDS, and with noisy data that -- not the arithmetic -- pulled the shader clock from
-//     2.36 to 2.02 GHz and the whole kernel, loads included, with it: EXPERIMENTS.md §9.)
+//     2.36 to 2.02 GHz and the whole kernel, loads included, with it: docs/history/EXPERIMENTS_rounds1-5.md §9.)
 //   * an iteration handles 512 outputs = 64 KiB of IQ frames; the next block's 16 chunks per lane are requested right after this
 //     block's registers were stored to LDS and stay in flight during the whole compute phase; the last 8 rows are carried over
 //     as the next iteration's halo (128 dwords through registers), so nothing is read twice inside a run;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     const unsigned long long clk0 = WFX_LAB_FLAGS(P.dbg_clk != nullptr) ? (unsigned long long)clock64() : 0ull, wall0 = WFX_LAB_FLAGS(P.dbg_clk != nullptr) ? (unsigned long long)wall_clock64() : 0ull;
     // run = blockIdx.x: workgroups go round-robin to the 8 XCDs, so the ~768 resident ones stream through 768 neighbouring runs, every
     // XCD through every eighth one.  (Dealing each XCD ONE eighth of the capture -- its 96 workgroups on 96 neighbouring runs -- measured
-    // 9 % slower, 4.00 against 3.68 ms on the 60-minute stream: EXPERIMENTS.md §9.)
+    // 9 % slower, 4.00 against 3.68 ms on the 60-minute stream: docs/history/EXPERIMENTS_rounds1-5.md §9.)
     const long long run = blockIdx.x;
     const long long o0 = P.out0 + run * P.run_out;                          // first output of this run
     const long long ocnt = P.n_out - o0 < P.run_out ? P.n_out - o0 : P.run_out;
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(IG_THREADS, IG_THREADS == 256 ? 3 : 4) ingest_
     // stores.  They are what the kernel pays for beyond its loads: 0.46 GB written beside 22 GB read cost 0.25-0.4 ms of 3.45-3.55
     // (the same stores into 2 KiB per run: 0.05) -- small write bursts that turn the channels around under the read streams; where
     // they are issued inside the iteration, how many iterations' worth are issued together (1, 4, 8) and whether only whole 128-byte
-    // lines are written made no difference, the cache policy did (EXPERIMENTS.md 9.1).
+    // lines are written made no difference, the cache policy did (docs/history/EXPERIMENTS_rounds1-5.md 9.1).
     auto flush = [&]() {
         if (M2 == 0) return;
         if (pend_k >= 0 && !WFX_LAB_FLAGS(P.dbg_flags & 16)) {                          // (16: nothing is stored)
@@ -576,7 +576,7 @@ int wfx_dev_ingest_stream(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n_
 // works through `bytes` of device memory taken as an IQ capture (`out` != nullptr: outputs there, bytes / 48 of them).  Its time does not depend on the data, but it does depend on WHERE the
 // allocation lies: ~770 workgroups each walking a megabyte of their own, with small write bursts in between, ran 3.43-3.56 ms on some
 // 22 GB allocations of a process and 3.9-4.1 ms on others, the same ones in every process of the box, while the dense sweep of
-// wfx_dev_read_rate showed 6.2-6.4 TB/s on all of them (EXPERIMENTS.md 9.2).  Callers that keep a capture buffer for long can time a few
+// wfx_dev_read_rate showed 6.2-6.4 TB/s on all of them (docs/history/EXPERIMENTS_rounds1-5.md 9.2).  Callers that keep a capture buffer for long can time a few
 // allocations with this and keep the best (wefax_amd/_native.py: Context.dev_malloc_placed).
 int wfx_dev_stream_rate(wfx_ctx *ctx, const void *dev, uint64_t bytes, double *out, int reps, double *gbs)
 {
