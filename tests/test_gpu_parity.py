@@ -506,9 +506,15 @@ def test_lab_switches_set_to_garbage_change_nothing(monkeypatch):
         case = next(c for c in golden_cases() if c["name"] == name)
         g = load_golden(name)
         d = Demodulator(input_path(case), lines_per_minute=case["lpm"], quiet=True, tcp_stream=True)
-        d.process()
-        assert np.array_equal(d.digitalized_data, g["digitalized"]) and d.start_frame == case["start_frame"]
-        assert np.array_equal(d.output_array, g["image"])
+        try:
+            d.process()
+            exc = None
+        except (ValueError, IndexError) as e:
+            exc = [type(e).__name__, str(e)]
+        assert exc == case["exception"]
+        assert np.array_equal(d.digitalized_data, g["digitalized"])
+        if exc is None:
+            assert d.start_frame == case["start_frame"] and np.array_equal(d.output_array, g["image"])
         d.close()
     d = Demodulator(input_path(next(c for c in golden_cases() if c["name"] == "iq1536k_2s_240")), lines_per_minute=240, quiet=True, tcp_stream=True, front_end="time-domain")
     try:

@@ -346,7 +346,7 @@ def test_golden_inputs_regenerate_from_nothing_and_a_mismatch_costs_one_case(tmp
 
 
 def test_every_recipe_still_hashes_to_the_manifest(tmp_path):
-    """All 19 recipes, the 12 MB IQ clip included, in a directory of their own (the kept copies are not consulted)."""
+    """All 22 recipes, the 12 MB IQ clip included, in a directory of their own (the kept copies are not consulted)."""
     import json
     import sys
     sys.path.insert(0, GOLDEN)
@@ -358,7 +358,7 @@ def test_every_recipe_still_hashes_to_the_manifest(tmp_path):
     (gold / "inputs").mkdir(parents=True)
     man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
     cases = [c for c in man["cases"] if "recipe" in c]
-    assert len(cases) == 19
+    assert len(cases) == 22
     json.dump({"cases": cases}, open(gold / "manifest.json", "w"))
     assert recipes.ensure_all(str(gold), strict=False) == {}
     assert sorted(os.listdir(gold / "inputs")) == sorted(os.path.basename(c["input"]) for c in cases)
