@@ -925,14 +925,29 @@ static void fmm_weight_messages(const shard_plan &pl, F &&f)
             long long a, b;
             fmm_rank_boxes(pl, r, &a, &b);
             const long long lo = a << (lev - lg), hi = b << (lev - lg);
-            for (int side = 0; side < 2; ++side)
+            for (int side = 0; side < 2; ++side) {
+                // the three boxes of a side travel as ONE message where they are neighbours in memory and have one owner (a rank owns at
+                // least two boxes of every finer level, and the circle closes only between the last box and the first)
+                long long run_box = -1, run_cnt = 0;
+                int run_s = -1;
                 for (int j = 0; j < 3; ++j) {
                     const long long raw = side == 0 ? lo - 3 + j : hi + j;
                     const long long box = (raw + nbl) & (nbl - 1);
-                    if (box >= lo && box < hi) continue;                    // (one rank, or a range that is the whole level: its own)
-                    const int s = fmm_owner(pl, box >> (lev - lg));
-                    if (s != r) f(s, r, lev, box, 1ll);
+                    const bool own = box >= lo && box < hi;                 // (one rank, or a range that is the whole level: its own)
+                    const int s = own ? r : fmm_owner(pl, box >> (lev - lg));
+                    if (run_cnt && (own || s != run_s || box != run_box + run_cnt)) {
+                        f(run_s, r, lev, run_box, run_cnt);
+                        run_cnt = 0;
+                    }
+                    if (own) continue;
+                    if (!run_cnt) {
+                        run_box = box;
+                        run_s = s;
+                    }
+                    ++run_cnt;
                 }
+                if (run_cnt) f(run_s, r, lev, run_box, run_cnt);
+            }
         }
     }
 }
@@ -1448,7 +1463,8 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
                     if (rr == r && lv == lev) {
                         long long sa, sb;
                         fmm_rank_boxes(pl, s, &sa, &sb);
-                        if ((box >> (lev - pl.fg.lg)) >= sa && (box >> (lev - pl.fg.lg)) < sb && cnt == 1) got.push_back(box);
+                        for (long long q = 0; q < cnt; ++q)
+                            if (((box + q) >> (lev - pl.fg.lg)) >= sa && ((box + q) >> (lev - pl.fg.lg)) < sb && box + q < nbl) got.push_back(box + q);
                     }
                 });
                 std::sort(need.begin(), need.end());
