@@ -247,6 +247,23 @@ def test_multipole_plan_cuts_the_capture_at_leaf_workgroups_and_keeps_the_wire_i
     assert {int(lay.own_lo) for lay in lays2} <= cuts
 
 
+def test_the_cost_model_takes_the_multipole_plan_where_the_capture_is_long_enough(monkeypatch):
+    """`plan="auto"`: a 60-minute capture at 11 025 Hz (39.69 M samples) is cut by plan 3 at every world size (its exchanges are kilobytes:
+    model 1.7 / 1.0 / 0.64 ms on 2 / 4 / 8 ranks against 2.8 ms on one GPU and more for the transposing plan); the 10-minute capture is too
+    short to be worth it below 8 ranks, where the transposing plan's model is still a little ahead; resampled captures never get it."""
+    for v in ("WFX_LINK_GBS", "WFX_LINK_LAT_US", "WFX_SHARD_CHUNKS", "WFX_SHARD_ROWS"):
+        monkeypatch.delenv(v, raising=False)
+    p, _ = build_params(0, 39690000, 11025, 0.5)
+    for world in (2, 4, 8):
+        lay = nat.shard_layout(p, world, 0)
+        assert lay.plan == 3 and lay.plan_forced == 0
+        assert lay.model_dist_compute_s + lay.model_dist_wire_s < 0.7 * lay.model_single_s
+    p, _ = build_params(0, 7166250, 11025, 0.5)
+    assert [nat.shard_layout(p, w, 0).plan for w in (2, 4, 8)] == [0, 0, 2]
+    p, _ = build_params(0, 172800000, 48000, 0.5)
+    assert all(nat.shard_layout(p, w, 0).plan != 3 for w in (2, 4, 8))
+
+
 def test_multipole_plan_refuses_what_it_cannot_shard():
     p, _ = build_params(0, 1440000, 48000, 0.5, shard_plan=sharded.plan_code("fmm"))       # needs the resampler: a transform over the capture
     with pytest.raises(nat.NativeError, match="11 025 Hz only"):

@@ -386,6 +386,21 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         pl.model_bytes = mb;
         pl.cols = false;
     }
+    // ---- plan 3 against whatever was chosen above (round 6): captures at 11 025 Hz that have a multipole form take it where the model puts it
+    // 3 % or more ahead -- its exchanges are kilobytes, so it wins wherever the capture is long enough to be worth cutting at all ----
+    if (want == 0 && world > 1 && !p->resample && !want_rows) {
+        wfx_decode_params q = *p;
+        q.shard_plan = 3;
+        shard_plan f;
+        wfx_fmm_shard_geo fgeo;
+        if (wfx_fmm_shard_geometry(p->n, &fgeo) == 0 && (1ll << fgeo.lg) >= world && make_plan(nullptr, &q, world, rank, f) == 0) {
+            const double now = pl.single ? pl.model_single : pl.model_comp + pl.model_wire;
+            if (f.model_comp + f.model_wire < 0.97 * now) {
+                pl = f;
+                pl.forced = 0;
+            }
+        }
+    }
     return 0;
 }
 
