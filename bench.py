@@ -555,13 +555,24 @@ def bench_fmm(args, rk: Ranks, x) -> dict:
     t_fmm = sum(us.values()) * 1e-6
     flops = 2.0 * FMM_FMA_PER_SAMPLE * x.shape[0]
     n = x.shape[0]
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic_fmm.json")
+    if os.path.exists(pmc):
+        try:
+            tj = json.load(open(pmc))
+            traffic = {"bytes_per_decode": int(sum(v["hbm_bytes_per_launch"] * (v["launches_seen"][0] / max(1, tj["fmm_tree_levels"]["launches_seen"][0]))
+                                                   for k, v in tj.items() if k.startswith("fmm_") and isinstance(v, dict))),
+                       "source": os.path.relpath(pmc, REPO) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; " + str(tj.get("_collected_at", "")) + ")"}
+        except Exception:      # noqa: BLE001
+            traffic = None
     return {"what": "BASELINE configs[1] with a6 + a7 by the fast multipole form (csrc/wfx_fmm.hip; Demodulator(hilbert_mode=4) / WEFAX_HILBERT=fmm)",
             "ms_per_step": round(ms, 4), "value": round(n / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "stream_and_start_frame_equal_to_transform_route": same,
             "notch_hilbert_envelope_median_us": round(1e6 * t_fmm, 1), "kernel_groups_us": us,
             "roofline": {"bound": "f64", "achieved": round(flops / t_fmm / 1e12, 2) if t_fmm else None, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / t_fmm / 1e12 / F64_PEAK_TFLOPS, 4) if t_fmm else None,
                          "algorithmic_flops": int(flops), "fma_per_sample": FMM_FMA_PER_SAMPLE,
-                         "hbm_frac_of_these_kernels": round((2 * n + 4 * n) / t_fmm / 1e9 / HBM_PEAK_GBS, 4) if t_fmm else None}}
+                         "hbm_frac_of_these_kernels": round((2 * n + 4 * n) / t_fmm / 1e9 / HBM_PEAK_GBS, 4) if t_fmm else None,
+                         "traffic": traffic}}
 
 
 # ---- BASELINE configs[4]: 64 independent captures, 8 contexts (= one capture per GPU stream, 8 per GPU) -----------------------------

@@ -426,6 +426,8 @@ CASES = {
     "mono_11025_30s": lambda: (synth.synth_capture(11025.0, noise=0.05, seed=12, **KW30), 11025, 120),
     "mono_48000_30s": lambda: (synth.synth_capture(48000.0, noise=0.05, seed=4, **KW30), 48000, 120),
     "stereo_48000_30s": lambda: (synth.synth_capture(48000.0, noise=0.05, seed=5, iq=True, **KW30), 48000, 120),
+    # two channels at the native rate: the merge of wefax.py:360-373 (int16 wrap) on every rank's own frames, no resampler
+    "stereo_11025_130s": lambda: (synth.synth_capture(11025.0, noise=0.05, seed=13, iq=True, amplitude=0.9, **KW130), 11025, 120),
     "float_11025_130s": lambda: (synth.synth_capture(11025.0, noise=0.02, seed=8, **KW130).astype(np.float64) * 0.37, 11025, 120),
     # sample formats whose filtfilt odd extension scipy evaluates in the file's own dtype: uint8 wraps (the capture starts and ends
     # near the top of the range), int32 wraps, float32 rounds -- the sharded path takes the 9 + 9 numbers from the host like DecodeJob
@@ -511,7 +513,7 @@ def test_full_size_ten_minute_capture_on_eight_emulated_ranks():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["mono_11025_130s", "mono_11025_30s", "float_11025_130s", "uint8_11025_130s", "float32_11025_130s"])
+@pytest.mark.parametrize("case", ["mono_11025_130s", "mono_11025_30s", "float_11025_130s", "uint8_11025_130s", "float32_11025_130s", "stereo_11025_130s"])
 def test_multipole_plan_gives_the_one_gpu_decodes_bytes_for_every_world_size(case):
     """Plan 3: every world size gives the bytes of the one-GPU decode in the same Hilbert form -- filtered audio, envelope, stream, start frame,
     image -- and the oracle's stream and image (max |delta pixel| 0); what the communicator counted is what the plan says."""
