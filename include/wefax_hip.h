@@ -319,6 +319,10 @@ int wfx_d_ingest_chain(wfx_ctx *ctx, const void *in_dev, int in_kind, size_t n_i
 /* a7 on device memory without a transform over the whole capture: out = H = imag(scipy.signal.hilbert(x)) (out_env 0), |x + i H| (1) or
  * the 5-tap median of that envelope, zeros beyond both ends (2: wefax.py:174-175 complete), by the fast multipole form of WFX_HILBERT_FMM; *handled = 0 and nothing enqueued for lengths it does not take */
 int wfx_d_hilbert_fmm(wfx_ctx *ctx, const double *x_dev, size_t n, double *out_dev, int out_env, int *handled);
+/* a5's resampler (wefax.py:160-161: scipy.signal.resample(x, num)) on device memory without a transform over the capture: y_dev[0 .. num) from the
+ * n0 real samples x_dev, by the multipole form of the periodic sinc sum (downsampling to an even count: the IQ hand-over and the 48 kHz captures);
+ * *handled = 0 and nothing enqueued for other lengths (upsampling, odd counts, < 32768 samples: the transform route serves those) */
+int wfx_d_resample_fmm(wfx_ctx *ctx, const double *x_dev, size_t n0, size_t num, double *y_dev, int *handled);
 /* measurement aid: GB/s at which this GPU reads `bytes` (>= 1 MiB, 16-byte aligned) of device memory with a kernel that only loads
  * (16-byte loads, 16 in flight per lane, 64 KiB blocks), best of `reps` launches by HIP events; waits for the stream.  bench.py puts
  * the ingest kernel's rate beside it: a slow box shows here, a slow kernel in the ratio */

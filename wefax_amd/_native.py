@@ -30,7 +30,7 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_hilbert_fmm", "wfx_d_read_rate", "wfx_d_stream_rate", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_hilbert_fmm", "wfx_d_resample_fmm", "wfx_d_read_rate", "wfx_d_stream_rate", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
@@ -235,6 +235,7 @@ def load():
     lib.wfx_d_decimate_fir64.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int)]
     lib.wfx_d_decimate_fir64_batch.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int), i, sz, sz]
     lib.wfx_d_hilbert_fmm.argtypes = [vp, vp, sz, vp, i, C.POINTER(C.c_int)]
+    lib.wfx_d_resample_fmm.argtypes = [vp, vp, sz, sz, vp, C.POINTER(C.c_int)]
     lib.wfx_d_read_rate.argtypes = [vp, vp, sz, i, C.POINTER(C.c_double)]
     lib.wfx_d_stream_rate.argtypes = [vp, vp, sz, vp, i, C.POINTER(C.c_double)]
     lib.wfx_d_ingest_chain.argtypes = [vp, vp, i, sz, i, vp, i, i, i, vp, i, vp, sz, i, sz, sz, C.POINTER(C.c_int)]
@@ -650,6 +651,13 @@ class Context:
         multipole far field (csrc/wfx_fmm.hip); False: a length that form does not take, nothing was enqueued."""
         handled = C.c_int(0)
         self._check(self.lib.wfx_d_hilbert_fmm(self.h, C.c_void_p(x_ptr), int(n), C.c_void_p(out_ptr), int(out_env), C.byref(handled)))
+        return bool(handled.value)
+
+    def d_resample_fmm(self, x_ptr: int, n0: int, num: int, y_ptr: int) -> bool:
+        """scipy.signal.resample(x, num) (wefax.py:160-161) of n0 float64 samples in device memory by the multipole form of the periodic sinc
+        sum (csrc/wfx_fmm.hip); False: lengths that form does not take (upsampling, odd counts, short captures), nothing was enqueued."""
+        handled = C.c_int(0)
+        self._check(self.lib.wfx_d_resample_fmm(self.h, C.c_void_p(x_ptr), int(n0), int(num), C.c_void_p(y_ptr), C.byref(handled)))
         return bool(handled.value)
 
     def d_read_rate(self, ptr: int, nbytes: int, reps: int = 3) -> float:

@@ -675,6 +675,13 @@ int wfx_d_hilbert_fmm(wfx_ctx *ctx, const double *x_dev, size_t n, double *out_d
     return wfx_dev_hilbert_fmm(ctx, x_dev, n, out_dev, out_env, nullptr, handled);
 }
 
+int wfx_d_resample_fmm(wfx_ctx *ctx, const double *x_dev, size_t n0, size_t num, double *y_dev, int *handled)
+{
+    CHECK_CTX(ctx);
+    if (!x_dev || !y_dev || !handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
+    return wfx_dev_resample_fmm(ctx, x_dev, n0, num, y_dev, handled);
+}
+
 int wfx_d_read_rate(wfx_ctx *ctx, const void *dev, size_t bytes, int reps, double *gbs)
 {
     CHECK_CTX(ctx);

@@ -1031,6 +1031,311 @@ static double cot_unit(double z, int lev)
 // Everything a run needs for a capture of n samples: geometry, device tables (cached per n), work arrays (whole-capture size: a rank of a
 // sharded decode uses its own part and the boxes it receives), tiers, LDS sizes.  handled = 0: a length this form does not take (odd, short,
 // too long).
+// ---- scipy.signal.resample (wefax.py:160-161) as a multipole sum: DESIGN.md 8.1, the gated model is tools/resample_farfield_model.py ------
+// Downsampling n0 -> num (num even, num < n0): y[k] = (-1)^k / n0 (C - sum_n x_n s_n cot(pi (k / num - n / n0))) + [k n0 = n num] x_n num / n0,
+// s_n = sin(pi num n / n0), C = sum_n x_n cos(pi num n / n0).  The sources are the n0 input samples at n / n0, the targets the num outputs at
+// k / num, both cut into the SAME 2^L dyadic arcs (<= 64 sources each); the tree between them is the Hilbert transform's (unit cotangent
+// kernel, both parity slots used as two halves of one source set), the near field three source leaves per target leaf on the vector pipe
+// (no two pairs share a lag: nothing for the matrix cores here).
+struct rs_geom {
+    fmm_geom s;                             // sources: n = n0
+    fmm_geom t;                             // targets: n = num (same L)
+    double kappa;                           // pi / (n0 num): the angle of one unit of m = k n0 - n num
+    double inv_n0, ratio;                   // 1 / n0, num / n0
+};
+
+// sin and cos of pi num n / n0 with the angle reduced in integers to the nearest multiple of pi: s_n multiplies cotangents of 1e9 exactly
+// where it is small, so it needs RELATIVE accuracy there (an exact zero at the coincident pairs)
+__device__ __forceinline__ void rs_sin_cos(long long n0, long long num, long long n, double *s, double *c)
+{
+    const long long r = (num * n) % (2 * n0);
+    const long long j = (2 * r + n0) / (2 * n0);
+    double sv, cv;
+    sincospi((double)(r - j * n0) / (double)n0, &sv, &cv);
+    *s = (j & 1) ? -sv : sv;
+    *c = (j & 1) ? -cv : cv;
+}
+
+// P2M + M2M of one workgroup of 64 source leaves (fmm_up_leaf2 with the weights x_n s_n, which it also leaves in `w` for the near field) and
+// the workgroup's part of C
+__global__ void __launch_bounds__(FTH, 2) rs_up_leaf(const double *__restrict__ x, const rs_geom rg, const fmm_tabs T, double *__restrict__ Wg, double *__restrict__ w,
+                                                     double *__restrict__ cpart, int wg0, long long x_index0)
+{
+    const fmm_geom g = rg.s;
+    extern __shared__ __align__(16) double fl[];
+    double *wb0 = fl;                                   // [64][2][FS]
+    double *wb1 = wb0 + FLV * 2 * FS;                   // [32][2][FS]
+    double *xw = wb1 + (FLV / 2) * 2 * FS;              // the workgroup's weighted samples: <= 64 x 64
+    __shared__ double cred[FTH / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long blk = (long long)blockIdx.x + wg0;
+    const long long leaf0 = blk * FLV;
+    const long long w0 = fmm_leaf_first(g, leaf0), w1 = fmm_leaf_first(g, leaf0 + FLV);
+    const int wlen = (int)(w1 - w0);
+    constexpr int XPT = (FLV * 64) / FTH;
+    double cp = 0.0;
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+        const int idx = t + q * FTH;
+        double wv = 0.0;
+        if (idx < wlen) {
+            const double xv = x[w0 + idx - x_index0];
+            double sv, cv;
+            rs_sin_cos(g.n, rg.t.n, w0 + idx, &sv, &cv);
+            wv = xv * sv;
+            cp = fma(xv, cv, cp);
+            w[w0 + idx] = wv;
+        }
+        xw[idx] = wv;
+    }
+    // the workgroup's part of C: a fixed order of additions (lanes by halving, then the eight waves one after the other)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cp += __shfl_xor(cp, o, 64);
+    if (lane == 0) cred[wave] = cp;
+    double ajr[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ajr[c][ks] = T.Aj[c * FP * FP + 64 * ks + lane];
+    const int n16 = lane & 15, gq = lane >> 4;
+    const int G = wave >> 1, e = wave & 1;
+    const int lk = 16 * G + n16;
+    const long long k = leaf0 + lk;
+    const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1);
+    const int s0 = (int)(b - a);
+    const int ht = (int)((a + e) & 1);
+    const double ua = 2.0 * ((double)((a << g.L) - k * g.n) / (double)g.n) - 1.0;
+    double cwa[FP];
+#pragma unroll
+    for (int kk = 0; kk < FP; ++kk) cwa[kk] = T.Cw[kk * FP + n16];
+    __syncthreads();
+    if (t == 0) {
+        double c8 = 0.0;
+        for (int i = 0; i < FTH / 64; ++i) c8 += cred[i];
+        cpart[blk] = c8;
+    }
+    double mu[FP];
+#pragma unroll
+    for (int kk = 0; kk < FP; ++kk) mu[kk] = 0.0;
+    const double *xp = xw + (int)(a - w0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int tau = 2 * (gq + 4 * r) + e;
+        const bool valid = tau < s0;
+        const double xv = valid ? xp[valid ? tau : 0] : 0.0;
+        const double u = valid ? fma((double)tau, g.du, ua) : 0.0;
+        const double u2 = 2.0 * u;
+        mu[0] += xv;
+        mu[1] = fma(u, xv, mu[1]);
+        double t0 = 1.0, t1 = u;
+#pragma unroll
+        for (int kk = 2; kk < FP; ++kk) {
+            const double t2 = fma(u2, t1, -t0);
+            mu[kk] = fma(t2, xv, mu[kk]);
+            t0 = t1;
+            t1 = t2;
+        }
+    }
+    {
+        fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < FP; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cwa[kk], mu[kk], acc, 0, 0, 0);
+        double *o = wb0 + (lk * 2 + ht) * FS + gq, *go = Wg + (fmm_box(g.L, k) * 2 + ht) * FP + gq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[4 * r] = acc[r];
+            go[4 * r] = acc[r];
+        }
+    }
+    double *src = wb0, *dst = wb1;
+#pragma unroll 1
+    for (int d = FW - 1; d >= 0; --d) {
+        fmm_lds_barrier();
+        fmm_up_level_mfma(src, dst, Wg + fmm_box(g.L - FW + d, blk << d) * 2 * FP, ajr, d, wave, lane);
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+}
+
+// C = the sum of the workgroups' parts in a fixed order: groups of `grp` consecutive parts (a power of two: the boxes of one level of the
+// tree, so that ranks of a sharded decode own whole groups), then the groups one after the other
+__global__ void __launch_bounds__(256) rs_csum(const double *__restrict__ cpart, int nparts, int grp, double *__restrict__ gsum, double *__restrict__ csum)
+{
+    __shared__ double part[256];
+    const int t = threadIdx.x;
+    const int ngrp = nparts / grp;
+    for (int gi = t; gi < ngrp; gi += 256) {
+        double a = 0.0;
+        for (int i = 0; i < grp; ++i) a += cpart[(size_t)gi * grp + i];
+        gsum[gi] = a;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double a = 0.0;
+        for (int gi = 0; gi < ngrp; ++gi) a += gsum[gi];
+        *csum = a;
+        (void)part;
+    }
+}
+
+// near field + far field + the closing factors for one workgroup of 64 target leaves.  Its targets are taken 64 at a time, one per lane,
+// whatever leaf they lie in (a wave's lanes span at most three leaves when a leaf holds >= 32 targets, more when it holds few): every lane
+// walks ITS leaf's three source leaves in LDS (lanes of one leaf read the same address: a broadcast).
+// Per pair: m = k n0 - n num (an exact integer in a double), x = kappa m, cot x = 1 / x - x / 3 - x^3 / 45 - 2 x^5 / 945 (|x| <= 2 pi / 2^L <=
+// 0.0123: the next term is below 1e-17 of 1 / x).  Reciprocals four at a time from ONE v_rcp_f64 + Newton step (2e-15: tools/micro/rcp_f64.hip)
+// of the product, 1 / x0 = x1 / (x0 x1) ...: 28 issue cycles a pair instead of 39.  The odd powers are sums over the leaf's window with
+// per-leaf moments S_j = sum_i i^j w_i: -1/3 sum w x = -(kappa / 3) (m0 S0 - num S1), computed once per leaf; POLY (L < 13, where x^3 / 45
+// still counts) evaluates them per pair instead.  A coincident pair has m = 0 AND an exactly zero weight: 1e-60 added to x (no change
+// to any other x: |x| >= 7e-19) keeps its product a finite zero.
+template <bool POLY>
+__global__ void __launch_bounds__(FTH, 4) rs_leaf(const double *__restrict__ w, const double *__restrict__ x, const rs_geom rg, const double *__restrict__ Cg,
+                                                  const double *__restrict__ csum, double *__restrict__ y, int swin, int wg0, int wrap, long long x_index0,
+                                                  long long y_index0)
+{
+    const fmm_geom gs = rg.s, gt = rg.t;
+    const long long blk = (long long)blockIdx.x + wg0;
+    extern __shared__ __align__(16) double fl[];
+    double *ca = fl;                                    // [64][FS]: Chebyshev coefficients of the leaves' far fields (both slots added)
+    double *sm = ca + FLV * FS;                         // [64][2]: S0, S1 of the leaves' windows
+    double *ww = sm + FLV * 2;                          // the weighted sources of leaves leaf0 - 1 .. leaf0 + 64 (+ 4 zeros)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long leaf0 = blk * FLV, nleaf = 1ll << gs.L;
+    const long long km = leaf0 == 0 ? nleaf - 1 : leaf0 - 1;
+    const long long ws0 = fmm_leaf_first(gs, km) - (leaf0 == 0 ? gs.n : 0);                       // may be negative
+    const long long kl = leaf0 + FLV == nleaf ? 0 : leaf0 + FLV;
+    const long long ws1 = (leaf0 + FLV == nleaf ? gs.n : 0) + fmm_leaf_first(gs, kl + 1);
+    const int wlen = (int)(ws1 - ws0);
+    for (int idx = t; idx < swin; idx += FTH) {
+        long long m = ws0 + idx;
+        if (wrap) m = m < 0 ? m + gs.n : (m >= gs.n ? m - gs.n : m);
+        ww[idx] = idx < wlen ? w[m] : 0.0;
+    }
+    {
+        const double *cg = Cg + (size_t)blk * FLV * 2 * FP;
+        for (int i = t; i < FLV * FP; i += FTH) {
+            const int lf = i >> 4, kk = i & 15;
+            ca[lf * FS + kk] = cg[(lf * 2) * FP + kk] + cg[(lf * 2 + 1) * FP + kk];
+        }
+    }
+    fmm_lds_barrier();
+    if (!POLY) {
+        // the moments of every leaf's window (a fixed order of additions: lanes take every 64th source, then halve)
+#pragma unroll 1
+        for (int li = 0; li < FLV / 8; ++li) {
+            const int lk = wave * (FLV / 8) + li;
+            const long long k = leaf0 + lk;
+            const long long sa = k == 0 ? fmm_leaf_first(gs, nleaf - 1) - gs.n : fmm_leaf_first(gs, k - 1);
+            const long long sb = k + 2 > nleaf ? fmm_leaf_first(gs, k + 2 - nleaf) + gs.n : fmm_leaf_first(gs, k + 2);
+            const int cnt = (int)(sb - sa);
+            const double *wp = ww + (int)(sa - ws0);
+            double s0 = 0.0, s1 = 0.0;
+            for (int i = lane; i < cnt; i += 64) {
+                const double wv = wp[i];
+                s0 += wv;
+                s1 = fma((double)i, wv, s1);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                s0 += __shfl_xor(s0, o, 64);
+                s1 += __shfl_xor(s1, o, 64);
+            }
+            if (lane == 0) {
+                sm[2 * lk] = s0;
+                sm[2 * lk + 1] = s1;
+            }
+        }
+        fmm_lds_barrier();
+    }
+    const double cs = *csum;
+    const double numd = (double)gt.n;
+    const long long T0 = fmm_leaf_first(gt, leaf0), T1 = fmm_leaf_first(gt, leaf0 + FLV);
+    const int nchunk = (int)((T1 - T0 + 63) >> 6);
+#pragma unroll 1
+    for (int ch = wave; ch < nchunk; ch += FTH / 64) {
+        const long long kraw = T0 + 64ll * ch + lane;
+        const bool valid = kraw < T1;
+        const long long kt = valid ? kraw : T1 - 1;
+        const long long k = (kt << gt.L) / gt.n;                   // the target's leaf
+        const int lk = (int)(k - leaf0);
+        const long long sa = k == 0 ? fmm_leaf_first(gs, nleaf - 1) - gs.n : fmm_leaf_first(gs, k - 1);
+        const long long sb = k + 2 > nleaf ? fmm_leaf_first(gs, k + 2 - nleaf) + gs.n : fmm_leaf_first(gs, k + 2);
+        const int cnt = (int)(sb - sa);
+        int cmin = cnt, cmax = cnt;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            cmin = min(cmin, __shfl_xor(cmin, o, 64));
+            cmax = max(cmax, __shfl_xor(cmax, o, 64));
+        }
+        const double *wp = ww + (int)(sa - ws0);
+        const double m0 = (double)(kt * gs.n - sa * gt.n);
+        double m = m0;
+        double acc0 = 0.0, acc1 = 0.0;
+        const int c4 = cmin & ~3;
+        for (int i = 0; i < c4; i += 4) {
+            const double w0 = wp[i], w1 = wp[i + 1], w2 = wp[i + 2], w3 = wp[i + 3];
+            const double x0 = fma(m, rg.kappa, 1e-60);
+            const double ma = m - numd;
+            const double x1 = fma(ma, rg.kappa, 1e-60);
+            const double mb = ma - numd;
+            const double x2 = fma(mb, rg.kappa, 1e-60);
+            const double mc = mb - numd;
+            const double x3 = fma(mc, rg.kappa, 1e-60);
+            m = mc - numd;
+            const double p01 = x0 * x1, p23 = x2 * x3;
+            const double pp = p01 * p23;
+            double R = __builtin_amdgcn_rcp(pp);
+            const double e1 = fma(-pp, R, 1.0);
+            R = fma(R, e1, R);
+            const double r01 = R * p23, r23 = R * p01;
+            double r0 = r01 * x1, r1 = r01 * x0, r2 = r23 * x3, r3 = r23 * x2;
+            if (POLY) {
+                const double q0 = x0 * x0, q1 = x1 * x1, q2 = x2 * x2, q3 = x3 * x3;
+                r0 = fma(-x0, fma(q0, fma(q0, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), r0);
+                r1 = fma(-x1, fma(q1, fma(q1, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), r1);
+                r2 = fma(-x2, fma(q2, fma(q2, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), r2);
+                r3 = fma(-x3, fma(q3, fma(q3, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), r3);
+            }
+            acc0 = fma(w0, r0, acc0);
+            acc1 = fma(w1, r1, acc1);
+            acc0 = fma(w2, r2, acc0);
+            acc1 = fma(w3, r3, acc1);
+        }
+        for (int i = c4; i < cmax; ++i) {                          // the last few, and what only some lanes' leaves hold
+            const double wv = i < cnt ? wp[i] : 0.0;
+            const double xx = fma(m, rg.kappa, 1e-60);
+            m -= numd;
+            double r = __builtin_amdgcn_rcp(xx);
+            const double e1 = fma(-xx, r, 1.0);
+            r = fma(r, e1, r);
+            if (POLY) {
+                const double q = xx * xx;
+                r = fma(-xx, fma(q, fma(q, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), r);
+            }
+            acc0 = fma(wv, r, acc0);
+        }
+        double acc = acc0 + acc1;
+        if (!POLY) acc = fma(-rg.kappa * (1.0 / 3.0), fma(m0, sm[2 * lk], -numd * sm[2 * lk + 1]), acc);
+        // far field: the target's place in its box
+        const double u = 2.0 * ((double)((kt << gt.L) - k * gt.n) / numd) - 1.0;
+        const double *cp = ca + lk * FS;
+        double t0 = 1.0, t1 = u, far = fma(cp[1], u, cp[0]);
+        const double u2 = 2.0 * u;
+#pragma unroll
+        for (int kk = 2; kk < FP; ++kk) {
+            const double t2 = fma(u2, t1, -t0);
+            far = fma(cp[kk], t2, far);
+            t0 = t1;
+            t1 = t2;
+        }
+        double yv = ((kt & 1) ? -rg.inv_n0 : rg.inv_n0) * (cs - (far + acc));
+        // a target that coincides with a source: D(0) = (num + 1) / n0, of which the C term carries 1 / n0
+        const long long q = (kt * gs.n) / gt.n;
+        if (q * gt.n == kt * gs.n) yv = fma(x[q - x_index0], rg.ratio, yv);
+        if (valid) y[kt - y_index0] = yv;
+    }
+}
+
 struct fmm_plan {
     fmm_geom g;
     fmm_tabs T;
@@ -1249,6 +1554,92 @@ int wfx_dev_notch_hilbert_fmm(wfx_ctx *ctx, const void *in, int in_kind, uint64_
     notch_coef c;
     notch_prepare(c, b, a, ext18);
     return fmm_run(ctx, nullptr, in, in_kind, &c, audio, clear, n, env, 2, l0hist, handled);
+}
+
+// ---- the resampler: host side ---------------------------------------------------------------------------------------------------------------
+constexpr int RS_POLY_BELOW = 13;            // levels below which cot's x^3 term still counts (x <= 2 pi / 2^L)
+
+struct rs_plan {
+    fmm_plan P;                              // tables, levels, tiers and the tree's arrays (shared with the Hilbert transform: one after the other)
+    rs_geom rg;
+    int swin = 0, grp = 1;
+    size_t lds_leaf = 0;
+    double *w = nullptr, *cpart = nullptr, *gsum = nullptr, *csum = nullptr;
+};
+
+// handled = 0: no multipole form for these lengths (upsampling, odd counts, short captures: the transform route serves them)
+static int rs_setup(wfx_ctx *ctx, uint64_t n0, uint64_t num, rs_plan &R, int *handled)
+{
+    *handled = 0;
+    if (num >= n0 || (num & 1) || num < 2 || (double)n0 * (double)num >= 4.0e18) return 0;
+    const uint64_t nkey = n0 + (n0 & 1);                                  // the tree's depth and tables depend on the level count only
+    WFX_TRY(fmm_setup(ctx, nkey, R.P, handled));
+    if (!*handled) return 0;
+    *handled = 0;
+    const int L = R.P.L;
+    R.rg.s.n = (long long)n0;
+    R.rg.s.L = L;
+    R.rg.s.scale = 2.0 / (double)n0;
+    R.rg.s.du = ldexp(2.0, L) / (double)n0;
+    R.rg.t.n = (long long)num;
+    R.rg.t.L = L;
+    R.rg.t.scale = 2.0 / (double)num;
+    R.rg.t.du = ldexp(2.0, L) / (double)num;
+    R.rg.kappa = M_PI / ((double)n0 * (double)num);
+    R.rg.inv_n0 = 1.0 / (double)n0;
+    R.rg.ratio = (double)num / (double)n0;
+    const int smax = (int)((n0 + ((1ull << L) - 1)) >> L);
+    R.swin = (FLV + 2) * smax + 4;
+    R.lds_leaf = (size_t)(FLV * FS + FLV * 2 + R.swin) * 8;
+    wfx_fmm_shard_geo geo;
+    wfx_fmm_shard_geometry(nkey, &geo);
+    R.grp = 1 << (geo.ltop - geo.lg);
+    const size_t nwg = R.P.nwg;
+    WFX_TRY(wfx_reserve(ctx, ctx->b_envraw, ((size_t)n0 + 2 * nwg + 8) * 8));
+    R.w = (double *)ctx->b_envraw.p;
+    R.cpart = R.w + n0;
+    R.gsum = R.cpart + nwg;
+    R.csum = R.gsum + nwg;
+    static bool attr_done = false;
+    if (!attr_done) {
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)rs_up_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.P.lds_up2));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)rs_leaf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((FLV * FS + FLV * 2 + (FLV + 2) * 64 + 4) * 8)));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)rs_leaf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((FLV * FS + FLV * 2 + (FLV + 2) * 64 + 4) * 8)));
+        attr_done = true;
+    }
+    *handled = 1;
+    return 0;
+}
+
+// scipy.signal.resample(x, num) of the n0 real samples x -> y (num samples), wefax.py:160-161, without a transform over the capture
+int wfx_dev_resample_fmm(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *y, int *handled)
+{
+    rs_plan R;
+    WFX_TRY(rs_setup(ctx, n0, num, R, handled));
+    if (!*handled) return 0;
+    *handled = 0;
+    const fmm_plan &P = R.P;
+    const unsigned nwg = P.nwg;
+    wfx_prof_begin(ctx, K_RESAMPLE_PW);
+    hipLaunchKernelGGL(rs_up_leaf, dim3(nwg), dim3(FTH), P.lds_up2, ctx->stream, x, R.rg, P.T, P.Wg, R.w, R.cpart, 0, 0ll);
+    hipLaunchKernelGGL(rs_csum, dim3(1), dim3(256), 0, ctx->stream, (const double *)R.cpart, (int)nwg, R.grp, R.gsum, R.csum);
+    for (int k = 0; k < P.ntier; ++k)
+        hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[k], P.tier_d[k], 0);
+    hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.Lg, P.atop);
+    for (int k = P.ntier - 1; k >= 0; --k)
+        hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
+    hipLaunchKernelGGL(fmm_tree_leaf, dim3(nwg), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, 0);
+    if (P.L < RS_POLY_BELOW)
+        hipLaunchKernelGGL(rs_leaf<true>, dim3(nwg), dim3(FTH), R.lds_leaf, ctx->stream, (const double *)R.w, x, R.rg, (const double *)P.Cg, (const double *)R.csum, y, R.swin,
+                           0, 1, 0ll, 0ll);
+    else
+        hipLaunchKernelGGL(rs_leaf<false>, dim3(nwg), dim3(FTH), R.lds_leaf, ctx->stream, (const double *)R.w, x, R.rg, (const double *)P.Cg, (const double *)R.csum, y, R.swin,
+                           0, 1, 0ll, 0ll);
+    wfx_prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch resampler kernels");
+    *handled = 1;
+    return 0;
 }
 
 // ---- one capture over several GPUs: every rank runs the leaf-level kernels on its own workgroups, the top of the tree is computed by all ----

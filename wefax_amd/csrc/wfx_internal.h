@@ -423,6 +423,7 @@ int wfx_dev_decimate_fir64(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n
 // wfx_fmm.hip: |x + i H| (out_env) or H = imag(scipy.signal.hilbert(x)) for even n by near field + fast multipole far field; *handled = 0
 // for lengths it does not take (odd, short)
 int wfx_dev_hilbert_fmm(wfx_ctx *ctx, const double *x, uint64_t n, double *out, int out_mode, unsigned *l0hist, int *handled);
+int wfx_dev_resample_fmm(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t num, double *y, int *handled);
 // one capture over several GPUs by the multipole form (wfx_shard.hip plan 3; the kernels are wfx_fmm.hip's)
 struct wfx_fmm_shard_geo {
     int L, ltop, lg, smax;       // levels; the leaf workgroups' roots; the gather level (ranks own whole boxes of it); the largest leaf
