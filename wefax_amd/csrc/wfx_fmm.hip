@@ -31,7 +31,6 @@ constexpr int FW = 6;                       // levels inside a leaf workgroup's 
 constexpr int FLV = 1 << FW;                // leaves per leaf workgroup
 constexpr int FTH = 512;                    // its threads: 8 waves x 8 leaves
 constexpr int FNEAR = 256;                  // near-field table: odd lags -255 .. 255
-constexpr int FROW = 65;                    // padded row of the P2M transposition scratch (doubles)
 constexpr int FXW = FLV * 64 + 2 * 64;      // capacity of a leaf workgroup's sample window (its leaves and one more on either side)
 constexpr int FTD = 6;                      // deepest tier of the kernels between the leaf workgroups and the top
 constexpr int FHB = 3;                      // boxes beyond either end of a subtree that its interaction lists reach
@@ -1042,16 +1041,48 @@ struct rs_geom {
     fmm_geom t;                             // targets: n = num (same L)
     double kappa;                           // pi / (n0 num): the angle of one unit of m = k n0 - n num
     double inv_n0, ratio;                   // 1 / n0, num / n0
+    unsigned pk, pn;                        // num / gcd, n0 / gcd: target j pk lies on source j pn
 };
 
-// sin and cos of pi num n / n0 with the angle reduced in integers to the nearest multiple of pi: s_n multiplies cotangents of 1e9 exactly
-// where it is small, so it needs RELATIVE accuracy there (an exact zero at the coincident pairs)
-__device__ __forceinline__ void rs_sin_cos(long long n0, long long num, long long n, double *s, double *c)
+// sin and cos of pi t for |t| <= 1/2 by their Taylor series in x = pi t (|x| <= 1.571: x^23 / 23! = 1.3e-18, x^24 / 24! = 8e-20), the sine as
+// x (1 + x^2 P(x^2)) so that it keeps its RELATIVE accuracy where it is small; a quarter of the library routine's instructions (no range
+// reduction, no special cases)
+__device__ __forceinline__ void rs_sincos_half(double t, double *s, double *c)
 {
-    const long long r = (num * n) % (2 * n0);
-    const long long j = (2 * r + n0) / (2 * n0);
+    const double x = 3.14159265358979323846 * t, z = x * x;
+    double ps = -1.0 / 51090942171709440000.0;                     // -1 / 21!
+    ps = fma(ps, z, 1.0 / 121645100408832000.0);                   // 1 / 19!
+    ps = fma(ps, z, -1.0 / 355687428096000.0);                     // -1 / 17!
+    ps = fma(ps, z, 1.0 / 1307674368000.0);                        // 1 / 15!
+    ps = fma(ps, z, -1.0 / 6227020800.0);                          // -1 / 13!
+    ps = fma(ps, z, 1.0 / 39916800.0);                             // 1 / 11!
+    ps = fma(ps, z, -1.0 / 362880.0);                              // -1 / 9!
+    ps = fma(ps, z, 1.0 / 5040.0);                                 // 1 / 7!
+    ps = fma(ps, z, -1.0 / 120.0);                                 // -1 / 5!
+    ps = fma(ps, z, 1.0 / 6.0);                                    // 1 / 3!
+    *s = fma(-x * z, ps, x);
+    double pc = 1.0 / 1124000727777607680000.0;                    // 1 / 22!
+    pc = fma(pc, z, -1.0 / 2432902008176640000.0);                 // -1 / 20!
+    pc = fma(pc, z, 1.0 / 6402373705728000.0);                     // 1 / 18!
+    pc = fma(pc, z, -1.0 / 20922789888000.0);                      // -1 / 16!
+    pc = fma(pc, z, 1.0 / 87178291200.0);                          // 1 / 14!
+    pc = fma(pc, z, -1.0 / 479001600.0);                           // -1 / 12!
+    pc = fma(pc, z, 1.0 / 3628800.0);                              // 1 / 10!
+    pc = fma(pc, z, -1.0 / 40320.0);                               // -1 / 8!
+    pc = fma(pc, z, 1.0 / 720.0);                                  // 1 / 6!
+    pc = fma(pc, z, -1.0 / 24.0);                                  // -1 / 4!
+    pc = fma(pc, z, 0.5);
+    *c = fma(-z, pc, 1.0);
+}
+
+// sin and cos of pi num n / n0 with the angle reduced in integers to the nearest multiple of pi: s_n multiplies cotangents of 1e9 exactly
+// where it is small, so it needs RELATIVE accuracy there (an exact zero at the coincident pairs).  r = num n mod 2 n0.  (ONE routine for
+// every place that needs a weight: a sample's weight must not depend on which kernel computed it)
+__device__ __forceinline__ void rs_sin_cos_r(long long r, long long n0, double inv_n0, double *s, double *c)
+{
+    const int j = (2 * r >= n0) + (2 * r >= 3 * n0);
     double sv, cv;
-    sincospi((double)(r - j * n0) / (double)n0, &sv, &cv);
+    rs_sincos_half((double)(r - j * n0) * inv_n0, &sv, &cv);
     *s = (j & 1) ? -sv : sv;
     *c = (j & 1) ? -cv : cv;
 }
@@ -1074,6 +1105,11 @@ __global__ void __launch_bounds__(FTH, 2) rs_up_leaf(const double *__restrict__ 
     const int wlen = (int)(w1 - w0);
     constexpr int XPT = (FLV * 64) / FTH;
     double cp = 0.0;
+    // the angle pi num n / n0 of sample n, kept as the integer r = num n mod 2 n0 and stepped by (num FTH) mod 2 n0 from one of the thread's
+    // samples to the next; reduced to the nearest multiple of n0 by comparisons
+    const long long two_n0 = 2 * g.n;
+    long long r = (rg.t.n * (w0 + t)) % two_n0;
+    const long long rstep = (rg.t.n * FTH) % two_n0;
 #pragma unroll
     for (int q = 0; q < XPT; ++q) {
         const int idx = t + q * FTH;
@@ -1081,11 +1117,13 @@ __global__ void __launch_bounds__(FTH, 2) rs_up_leaf(const double *__restrict__ 
         if (idx < wlen) {
             const double xv = x[w0 + idx - x_index0];
             double sv, cv;
-            rs_sin_cos(g.n, rg.t.n, w0 + idx, &sv, &cv);
+            rs_sin_cos_r(r, g.n, rg.inv_n0, &sv, &cv);
             wv = xv * sv;
             cp = fma(xv, cv, cp);
             w[w0 + idx] = wv;
         }
+        r += rstep;
+        r = r >= two_n0 ? r - two_n0 : r;
         xw[idx] = wv;
     }
     // the workgroup's part of C: a fixed order of additions (lanes by halving, then the eight waves one after the other)
@@ -1158,25 +1196,56 @@ __global__ void __launch_bounds__(FTH, 2) rs_up_leaf(const double *__restrict__ 
     }
 }
 
+// the groups' sums added in a fixed order: 256 runs of consecutive groups, then the runs by halving
+__device__ __forceinline__ void rs_csum_groups(const double *__restrict__ gsum, int ngrp, double *part, double *__restrict__ csum)
+{
+    const int t = threadIdx.x;
+    const int run = (ngrp + 255) / 256;
+    double a = 0.0;
+    for (int i = 0; i < run; ++i) {
+        const int gi = t * run + i;
+        if (gi < ngrp) a += gsum[gi];
+    }
+    part[t] = a;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (t < o) part[t] += part[t + o];
+        __syncthreads();
+    }
+    if (t == 0) *csum = part[0];
+}
+
 // C = the sum of the workgroups' parts in a fixed order: groups of `grp` consecutive parts (a power of two: the boxes of one level of the
 // tree, so that ranks of a sharded decode own whole groups), then the groups one after the other
 __global__ void __launch_bounds__(256) rs_csum(const double *__restrict__ cpart, int nparts, int grp, double *__restrict__ gsum, double *__restrict__ csum)
 {
     __shared__ double part[256];
     const int t = threadIdx.x;
-    const int ngrp = nparts / grp;
+    const int ngrp = nparts / grp;                          // a power of two
     for (int gi = t; gi < ngrp; gi += 256) {
         double a = 0.0;
         for (int i = 0; i < grp; ++i) a += cpart[(size_t)gi * grp + i];
         gsum[gi] = a;
     }
     __syncthreads();
-    if (t == 0) {
-        double a = 0.0;
-        for (int gi = 0; gi < ngrp; ++gi) a += gsum[gi];
-        *csum = a;
-        (void)part;
-    }
+    rs_csum_groups(gsum, ngrp, part, csum);
+}
+
+// the first half alone, for the groups [g_lo, g_hi) of a rank
+__global__ void __launch_bounds__(256) rs_csum_own(const double *__restrict__ cpart, int grp, double *__restrict__ gsum, int g_lo, int g_hi)
+{
+    const int gi = g_lo + (int)(blockIdx.x * 256 + threadIdx.x);
+    if (gi >= g_hi) return;
+    double a = 0.0;
+    for (int i = 0; i < grp; ++i) a += cpart[(size_t)gi * grp + i];
+    gsum[gi] = a;
+}
+
+// the second half alone (a sharded decode: the groups' sums have been gathered from all ranks)
+__global__ void __launch_bounds__(256) rs_csum2(const double *__restrict__ gsum, int ngrp, double *__restrict__ csum)
+{
+    __shared__ double part[256];
+    rs_csum_groups(gsum, ngrp, part, csum);
 }
 
 // near field + far field + the closing factors for one workgroup of 64 target leaves.  Its targets are taken 64 at a time, one per lane,
@@ -1256,7 +1325,11 @@ __global__ void __launch_bounds__(FTH, 4) rs_leaf(const double *__restrict__ w, 
         const long long kraw = T0 + 64ll * ch + lane;
         const bool valid = kraw < T1;
         const long long kt = valid ? kraw : T1 - 1;
-        const long long k = (kt << gt.L) / gt.n;                   // the target's leaf
+        // the target's leaf floor(kt 2^L / num): an estimate in floating point, put right against the leaves' first targets
+        long long k = (long long)((double)kt * rg.t.du * 0.5);
+        k = k > nleaf - 1 ? nleaf - 1 : k;
+        k -= fmm_leaf_first(gt, k) > kt;
+        k += fmm_leaf_first(gt, k + 1) <= kt;
         const int lk = (int)(k - leaf0);
         const long long sa = k == 0 ? fmm_leaf_first(gs, nleaf - 1) - gs.n : fmm_leaf_first(gs, k - 1);
         const long long sb = k + 2 > nleaf ? fmm_leaf_first(gs, k + 2 - nleaf) + gs.n : fmm_leaf_first(gs, k + 2);
@@ -1317,7 +1390,7 @@ __global__ void __launch_bounds__(FTH, 4) rs_leaf(const double *__restrict__ w, 
         double acc = acc0 + acc1;
         if (!POLY) acc = fma(-rg.kappa * (1.0 / 3.0), fma(m0, sm[2 * lk], -numd * sm[2 * lk + 1]), acc);
         // far field: the target's place in its box
-        const double u = 2.0 * ((double)((kt << gt.L) - k * gt.n) / numd) - 1.0;
+        const double u = fma((double)((kt << gt.L) - k * gt.n), rg.t.scale, -1.0);
         const double *cp = ca + lk * FS;
         double t0 = 1.0, t1 = u, far = fma(cp[1], u, cp[0]);
         const double u2 = 2.0 * u;
@@ -1330,8 +1403,9 @@ __global__ void __launch_bounds__(FTH, 4) rs_leaf(const double *__restrict__ w, 
         }
         double yv = ((kt & 1) ? -rg.inv_n0 : rg.inv_n0) * (cs - (far + acc));
         // a target that coincides with a source: D(0) = (num + 1) / n0, of which the C term carries 1 / n0
-        const long long q = (kt * gs.n) / gt.n;
-        if (q * gt.n == kt * gs.n) yv = fma(x[q - x_index0], rg.ratio, yv);
+        // (k n0 = n num  <=>  k = j num / g, n = j n0 / g with g = gcd(n0, num))
+        const unsigned jq = (unsigned)kt / rg.pk;
+        if (jq * rg.pk == (unsigned)kt) yv = fma(x[(long long)jq * rg.pn - x_index0], rg.ratio, yv);
         if (valid) y[kt - y_index0] = yv;
     }
 }
@@ -1571,7 +1645,7 @@ struct rs_plan {
 static int rs_setup(wfx_ctx *ctx, uint64_t n0, uint64_t num, rs_plan &R, int *handled)
 {
     *handled = 0;
-    if (num >= n0 || (num & 1) || num < 2 || (double)n0 * (double)num >= 4.0e18) return 0;
+    if (num >= n0 || (num & 1) || num < 2 || n0 >= (1ull << 32) || (double)n0 * (double)num >= 4.0e18) return 0;
     const uint64_t nkey = n0 + (n0 & 1);                                  // the tree's depth and tables depend on the level count only
     WFX_TRY(fmm_setup(ctx, nkey, R.P, handled));
     if (!*handled) return 0;
@@ -1588,6 +1662,16 @@ static int rs_setup(wfx_ctx *ctx, uint64_t n0, uint64_t num, rs_plan &R, int *ha
     R.rg.kappa = M_PI / ((double)n0 * (double)num);
     R.rg.inv_n0 = 1.0 / (double)n0;
     R.rg.ratio = (double)num / (double)n0;
+    {
+        uint64_t ga = n0, gb = num;
+        while (gb) {
+            const uint64_t tmp = ga % gb;
+            ga = gb;
+            gb = tmp;
+        }
+        R.rg.pk = (unsigned)(num / ga);
+        R.rg.pn = (unsigned)(n0 / ga);
+    }
     const int smax = (int)((n0 + ((1ull << L) - 1)) >> L);
     R.swin = (FLV + 2) * smax + 4;
     R.lds_leaf = (size_t)(FLV * FS + FLV * 2 + R.swin) * 8;
@@ -1710,6 +1794,19 @@ int wfx_fmm_shard_up(wfx_ctx *ctx, const void *raw, long long raw_index0, int ra
     return 0;
 }
 
+// everybody: the deepest tier's part above the gather level, the other tiers, the top -- and down again to the gather level
+static void fmm_shard_middle(wfx_ctx *ctx, const fmm_plan &P, const wfx_fmm_shard_geo &geo)
+{
+    const int up0 = P.ntier > 0 ? geo.lg - P.tier_a[0] : 0;
+    if (up0 > 0) hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[0]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[0], up0, 0);
+    for (int k = 1; k < P.ntier; ++k)
+        hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[k], P.tier_d[k], 0);
+    hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.Lg, P.atop);
+    for (int k = P.ntier - 1; k >= 1; --k)
+        hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
+    if (up0 > 0) hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[0]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[0], up0, 0);
+}
+
 // phase B (the weights of level lg of ALL ranks and the halo boxes of the finer levels have arrived): the top of the tree (every rank the same),
 // the rank's part of the deepest tier downwards, tree and leaf kernels of its workgroups.  audio as in phase A, with one filtered leaf in
 // front of and behind the rank's own samples; env[0] = the envelope of sample env_index0.  Leaves the medians of all positions but two at
@@ -1724,15 +1821,7 @@ int wfx_fmm_shard_down(wfx_ctx *ctx, const double *audio, long long audio_index0
     wfx_fmm_shard_geo geo;
     wfx_fmm_shard_geometry(n, &geo);
     const int sh = geo.ltop - geo.lg;
-    // everybody: the deepest tier's part above the gather level, the other tiers, the top -- and down again to the gather level
-    const int up0 = P.ntier > 0 ? geo.lg - P.tier_a[0] : 0;
-    if (up0 > 0) hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[0]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[0], up0, 0);
-    for (int k = 1; k < P.ntier; ++k)
-        hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[k], P.tier_d[k], 0);
-    hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.Lg, P.atop);
-    for (int k = P.ntier - 1; k >= 1; --k)
-        hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
-    if (up0 > 0) hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[0]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[0], up0, 0);
+    fmm_shard_middle(ctx, P, geo);
     const unsigned wg_lo = (unsigned)(gb_lo << sh), wg_hi = (unsigned)(gb_hi << sh);
     if (wg_hi > wg_lo) {
         if (sh > 0)         // own boxes: from the gather level to the leaf workgroups' roots
@@ -1766,3 +1855,79 @@ int wfx_fmm_shard_seams(wfx_ctx *ctx, uint64_t n, long long gb_lo, long long gb_
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
     return 0;
 }
+
+// ---- the resampler of a sharded decode (plan 3 with a resampled capture): a rank owns whole boxes [gb_lo, gb_hi) of the RESAMPLER tree's
+// gather level -- the same arcs of the circle as its boxes of the Hilbert tree behind it -- hence the sources [first(gb_lo), first(gb_hi)) and
+// the targets of the same arcs.  x holds its sources and one leaf (<= 64) beyond either end, round the circle; x[0] = source x_index0.
+int wfx_rs_shard_geometry(uint64_t n0, uint64_t num, wfx_fmm_shard_geo *geo)
+{
+    if (num >= n0 || (num & 1) || num < 2 || n0 >= (1ull << 32) || (double)n0 * (double)num >= 4.0e18) return -1;
+    return wfx_fmm_shard_geometry(n0 + (n0 & 1), geo);
+}
+
+// weights of the one leaf beyond either end (the near field of the rank's first and last target leaves reads them)
+__global__ void __launch_bounds__(128) rs_halo_weights(const double *__restrict__ x, const rs_geom rg, double *__restrict__ w, long long src_lo, long long src_hi,
+                                                       long long x_index0)
+{
+    const int t = threadIdx.x;
+    const long long nu = t < 64 ? src_lo - 64 + t : src_hi + (t - 64);         // unwrapped
+    const long long n = nu < 0 ? nu + rg.s.n : (nu >= rg.s.n ? nu - rg.s.n : nu);
+    double sv, cv;
+    rs_sin_cos_r((rg.t.n * n) % (2 * rg.s.n), rg.s.n, rg.inv_n0, &sv, &cv);
+    w[n] = x[nu - x_index0] * sv;
+}
+
+int wfx_rs_shard_up(wfx_ctx *ctx, const double *x, long long x_index0, uint64_t n0, uint64_t num, long long gb_lo, long long gb_hi, double **gsum)
+{
+    rs_plan R;
+    int handled = 0;
+    WFX_TRY(rs_setup(ctx, n0, num, R, &handled));
+    if (!handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "resampler: no multipole form for %llu -> %llu samples", (unsigned long long)n0, (unsigned long long)num);
+    const fmm_plan &P = R.P;
+    wfx_fmm_shard_geo geo;
+    wfx_fmm_shard_geometry(n0 + (n0 & 1), &geo);
+    const int sh = geo.ltop - geo.lg;
+    const unsigned wg_lo = (unsigned)(gb_lo << sh), wg_hi = (unsigned)(gb_hi << sh);
+    *gsum = R.gsum;
+    if (wg_hi > wg_lo) {
+        const long long src_lo = wfx_fmm_leaf_first_host(n0, P.L, (long long)wg_lo * FLV), src_hi = wfx_fmm_leaf_first_host(n0, P.L, (long long)wg_hi * FLV);
+        hipLaunchKernelGGL(rs_up_leaf, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_up2, ctx->stream, x, R.rg, P.T, P.Wg, R.w, R.cpart, (int)wg_lo, x_index0);
+        hipLaunchKernelGGL(rs_halo_weights, dim3(1), dim3(128), 0, ctx->stream, x, R.rg, R.w, src_lo, src_hi, x_index0);
+        hipLaunchKernelGGL(rs_csum_own, dim3((unsigned)(gb_hi - gb_lo + 255) / 256), dim3(256), 0, ctx->stream, (const double *)R.cpart, R.grp, R.gsum, (int)gb_lo, (int)gb_hi);
+        if (sh > 0) hipLaunchKernelGGL(fmm_up_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, geo.lg, sh, (int)gb_lo);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch resampler kernels");
+    return 0;
+}
+
+// (the gather level's weights and group sums of ALL ranks and the halo boxes of the finer levels have arrived)  y[0] = target y_index0
+int wfx_rs_shard_down(wfx_ctx *ctx, const double *x, long long x_index0, uint64_t n0, uint64_t num, long long gb_lo, long long gb_hi, double *y, long long y_index0)
+{
+    rs_plan R;
+    int handled = 0;
+    WFX_TRY(rs_setup(ctx, n0, num, R, &handled));
+    if (!handled) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "resampler: no multipole form for %llu -> %llu samples", (unsigned long long)n0, (unsigned long long)num);
+    const fmm_plan &P = R.P;
+    wfx_fmm_shard_geo geo;
+    wfx_fmm_shard_geometry(n0 + (n0 & 1), &geo);
+    const int sh = geo.ltop - geo.lg;
+    hipLaunchKernelGGL(rs_csum2, dim3(1), dim3(256), 0, ctx->stream, (const double *)R.gsum, (int)(P.nwg / (unsigned)R.grp), R.csum);
+    fmm_shard_middle(ctx, P, geo);
+    const unsigned wg_lo = (unsigned)(gb_lo << sh), wg_hi = (unsigned)(gb_hi << sh);
+    if (wg_hi > wg_lo) {
+        if (sh > 0)
+            hipLaunchKernelGGL(fmm_down_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, geo.lg, sh, (int)gb_lo);
+        hipLaunchKernelGGL(fmm_tree_leaf, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, (int)wg_lo);
+        if (P.L < RS_POLY_BELOW)
+            hipLaunchKernelGGL(rs_leaf<true>, dim3(wg_hi - wg_lo), dim3(FTH), R.lds_leaf, ctx->stream, (const double *)R.w, x, R.rg, (const double *)P.Cg,
+                               (const double *)R.csum, y, R.swin, (int)wg_lo, 1, x_index0, y_index0);
+        else
+            hipLaunchKernelGGL(rs_leaf<false>, dim3(wg_hi - wg_lo), dim3(FTH), R.lds_leaf, ctx->stream, (const double *)R.w, x, R.rg, (const double *)P.Cg,
+                               (const double *)R.csum, y, R.swin, (int)wg_lo, 1, x_index0, y_index0);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch resampler kernels");
+    return 0;
+}
+

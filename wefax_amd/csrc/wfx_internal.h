@@ -437,6 +437,10 @@ int wfx_fmm_shard_up(wfx_ctx *ctx, const void *raw, long long raw_index0, int ra
 int wfx_fmm_shard_down(wfx_ctx *ctx, const double *audio, long long audio_index0, uint64_t n, long long gb_lo, long long gb_hi, double *env, long long env_index0,
                        unsigned *l0hist);
 int wfx_fmm_shard_seams(wfx_ctx *ctx, uint64_t n, long long gb_lo, long long gb_hi, double *env, long long env_index0, unsigned *l0hist);
+// the resampler's multipole form, sharded (wfx_fmm.hip; plan 3 in front of a resampler)
+int wfx_rs_shard_geometry(uint64_t n0, uint64_t num, wfx_fmm_shard_geo *geo);
+int wfx_rs_shard_up(wfx_ctx *ctx, const double *x, long long x_index0, uint64_t n0, uint64_t num, long long gb_lo, long long gb_hi, double **gsum);
+int wfx_rs_shard_down(wfx_ctx *ctx, const double *x, long long x_index0, uint64_t n0, uint64_t num, long long gb_lo, long long gb_hi, double *y, long long y_index0);
 int wfx_dev_notch_hilbert_fmm(wfx_ctx *ctx, const void *in, int in_kind, uint64_t n, const double b[3], const double a[3], const double *ext18, double *audio,
                               double *env, unsigned *l0hist, wfx_dev_scalars *clear, int *handled);      // a6 + a7 in one chain of kernels (wfx_fmm.hip)   // out_mode 0: H, 1: |x + iH|, 2: its 5-tap median + level-0 histogram of the select
 

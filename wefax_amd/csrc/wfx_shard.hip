@@ -36,6 +36,7 @@
 #define SH_FMM_HR 320       // plan 3: raw samples handed over beyond the own range on either side, round the circle (a leaf of <= 64 for the near field + the
                             // notch's 24 taps; at the capture's ends the exact filtfilt edge is made of 127 + 9 samples and the segment form wants >= 254)
 #define SH_FMM_HF (SH_FMM_HR - 24)      // filtered samples kept beyond the own range
+#define SH_RS_HS 64         // plan 3 in front of a resampler: input samples beyond the own sources on either side (one leaf of the resampler tree)
 #define SH_CAND_CAP 4096    // least number of candidate keys per query and rank that travel in the all-gather
 
 struct shard_plan {
@@ -88,6 +89,14 @@ struct shard_plan {
     bool fmm = false;
     wfx_fmm_shard_geo fg{};
     long long gb_lo = 0, gb_hi = 0;
+    // ... in front of it, for a capture at another rate, the resampler's multipole form on ITS tree (sources: the n0 input samples): the ranks
+    // are dealt boxes of a level `lgc` at or above both trees' gather levels, so that a rank's arc of the circle is the same in both --
+    // its resampled samples are the Hilbert tree's own samples, and only the 320 beyond either end travel
+    bool rs = false;
+    wfx_fmm_shard_geo fgr{};
+    long long gbr_lo = 0, gbr_hi = 0;
+    int lgc = 0;
+    int in_halo = 0;                      // input frames held beyond [in_lo, in_hi) on either side, round the circle
     // the cost model's verdict
     int forced = 0;
     double model_single = 0, model_comp = 0, model_wire = 0;
@@ -184,28 +193,44 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
     if (want == 2) return single("asked for by the caller (wfx_decode_params.shard_plan)");
     if (want == 3) {
         // ---- plan 3: the capture cut into contiguous ranges of leaf workgroups of the multipole tree (geometry: a function of n alone) ----
-        if (p->resample) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode, multipole plan: captures at 11 025 Hz only (the resampler is a transform over the capture)");
+        if (p->resample) {
+            if (wfx_rs_shard_geometry(p->n0, p->n, &pl.fgr) != 0)
+                return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode, multipole plan: no multipole form of the resampler for %llu -> %llu samples (downsampling to an even count)",
+                                (unsigned long long)p->n0, (unsigned long long)p->n);
+            pl.rs = true;
+        }
         if (wfx_fmm_shard_geometry(p->n, &pl.fg) != 0)
             return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode, multipole plan: no multipole form for %llu samples (even, >= 32 768)", (unsigned long long)p->n);
-        const long long G = 1ll << pl.fg.lg;
+        pl.lgc = pl.rs ? std::min(pl.fg.lg, pl.fgr.lg) : pl.fg.lg;
+        const long long G = 1ll << pl.lgc;
         if (G < world) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "sharded decode, multipole plan: %lld boxes at the gather level for %d ranks", G, world);
         pl.fmm = true;
         pl.g = wfx_dist_geom();
         pl.g.world = world;
         pl.g.rank = rank;
-        pl.gb_lo = (long long)rank * G / world;
-        pl.gb_hi = (long long)(rank + 1) * G / world;
+        pl.gb_lo = ((long long)rank * G / world) << (pl.fg.lg - pl.lgc);
+        pl.gb_hi = ((long long)(rank + 1) * G / world) << (pl.fg.lg - pl.lgc);
         const int sh = pl.fg.ltop - pl.fg.lg + 6;                          // gather box -> leaves
         pl.own_lo = (uint64_t)wfx_fmm_leaf_first_host(p->n, pl.fg.L, pl.gb_lo << sh);
         pl.own_hi = (uint64_t)wfx_fmm_leaf_first_host(p->n, pl.fg.L, pl.gb_hi << sh);
         pl.in_lo = pl.seg_lo = pl.own_lo;
         pl.in_hi = pl.seg_hi = pl.own_hi;
+        pl.in_halo = SH_FMM_HR;
+        if (pl.rs) {
+            pl.gbr_lo = ((long long)rank * G / world) << (pl.fgr.lg - pl.lgc);
+            pl.gbr_hi = ((long long)(rank + 1) * G / world) << (pl.fgr.lg - pl.lgc);
+            const int shr = pl.fgr.ltop - pl.fgr.lg + 6;
+            pl.in_lo = (uint64_t)wfx_fmm_leaf_first_host(p->n0, pl.fgr.L, pl.gbr_lo << shr);
+            pl.in_hi = (uint64_t)wfx_fmm_leaf_first_host(p->n0, pl.fgr.L, pl.gbr_hi << shr);
+            pl.in_halo = SH_RS_HS;
+        }
         // model: the leaf-level kernels divide by the world size, the top is repeated by every rank; five small exchanges + the gather
         const double nn = (double)p->n;
-        pl.model_single = 20e-6 + (nn * 16.0 <= 256e6 ? 46e-12 : 70e-12) * nn;
-        pl.model_comp = 60e-6 + 52e-12 * nn / world + (world > 1 ? 80e-6 : 0.0);
+        pl.model_single = 20e-6 + (nn * 16.0 <= 256e6 ? 46e-12 : 70e-12) * nn + (pl.rs ? 8.7e-12 * (double)p->n0 : 0.0);
+        // (the resampler's multipole form: 52 ps per input sample on one GPU at the IQ hand-over's size, near field 2/3 of it)
+        pl.model_comp = 60e-6 + (52e-12 * nn + (pl.rs ? 60e-6 * world + 52e-12 * (double)p->n0 : 0.0)) / world + (world > 1 ? 80e-6 : 0.0);
         const double lat = link_lat_s(), bl = link_gbs() * 1e9;
-        pl.model_wire = world > 1 ? 6 * lat + (nn / world) / bl + lat : 0.0;
+        pl.model_wire = world > 1 ? (pl.rs ? 8 : 6) * lat + (nn / world) / bl + lat : 0.0;
         pl.model_bytes = world > 1 ? (unsigned long long)(G * 256 * (world - 1) + (unsigned long long)world * (pl.fg.L - pl.fg.lg) * 6 * 256 + nn * (world - 1) / world) : 0ull;
         return 0;
     }
@@ -386,14 +411,14 @@ static int make_plan(wfx_ctx *ctx, const wfx_decode_params *p, int world, int ra
         pl.model_bytes = mb;
         pl.cols = false;
     }
-    // ---- plan 3 against whatever was chosen above (round 6): captures at 11 025 Hz that have a multipole form take it where the model puts it
-    // 3 % or more ahead -- its exchanges are kilobytes, so it wins wherever the capture is long enough to be worth cutting at all ----
-    if (want == 0 && world > 1 && !p->resample && !want_rows) {
+    // ---- plan 3 against whatever was chosen above (round 6): captures that have a multipole form (of the Hilbert transform and, where they are
+    // resampled, of the resampler) take it where the model puts it 3 % or more ahead -- its exchanges are kilobytes, so it wins wherever the capture is long enough to be worth cutting at all ----
+    if (want == 0 && world > 1 && !want_rows) {
         wfx_decode_params q = *p;
         q.shard_plan = 3;
         shard_plan f;
-        wfx_fmm_shard_geo fgeo;
-        if (wfx_fmm_shard_geometry(p->n, &fgeo) == 0 && (1ll << fgeo.lg) >= world && make_plan(nullptr, &q, world, rank, f) == 0) {
+        wfx_fmm_shard_geo fgeo, rgeo;
+        if (wfx_fmm_shard_geometry(p->n, &fgeo) == 0 && (!p->resample || wfx_rs_shard_geometry(p->n0, p->n, &rgeo) == 0) && make_plan(nullptr, &q, world, rank, f) == 0) {
             const double now = pl.single ? pl.model_single : pl.model_comp + pl.model_wire;
             if (f.model_comp + f.model_wire < 0.97 * now) {
                 pl = f;
@@ -572,7 +597,12 @@ static int shard_bind(wfx_shard *sh)
         const uint64_t n_own = pl.own_hi - pl.own_lo;
         WFX_TRY(wfx_reserve(ctx, sh->b_audio, (n_own + 2 * SH_FMM_HF) * 8 + 64));
         WFX_TRY(wfx_reserve(ctx, sh->b_res, 2 * (size_t)(SH_FMM_HR + 24) * 8 + 64));          // the two halo segments as the notch leaves them
-        if (pl.in_kind == WFX_IN_I16_STEREO) WFX_TRY(wfx_reserve(ctx, sh->b_merged, (n_own + 2 * SH_FMM_HR) * 8 + 64));
+        if (pl.rs) {
+            // the rank's input samples as float64 (unless they arrive so), and its resampled samples with 320 beyond either end
+            if (pl.in_kind != WFX_IN_F64_MONO) WFX_TRY(wfx_reserve(ctx, sh->b_merged, (pl.in_hi - pl.in_lo + 2 * SH_RS_HS) * 8 + 64));
+            WFX_TRY(wfx_reserve(ctx, sh->b_v, (n_own + 2 * SH_FMM_HR) * 8 + 64));
+        } else if (pl.in_kind == WFX_IN_I16_STEREO)
+            WFX_TRY(wfx_reserve(ctx, sh->b_merged, (n_own + 2 * SH_FMM_HR) * 8 + 64));
         WFX_TRY(wfx_reserve(ctx, sh->b_env, n_own * 8 + 64));
         WFX_TRY(wfx_reserve(ctx, sh->b_dig, (me == 0 ? pl.n : n_own) + 64));
         WFX_TRY(wfx_reserve(ctx, sh->b_blk, wfx_select_block_bytes(sh->cap)));
@@ -636,7 +666,7 @@ static int shard_bind(wfx_shard *sh)
 static int phase_count(const wfx_shard *sh)
 {
     if (sh->pl.single) return 1;
-    if (sh->pl.fmm) return 7;
+    if (sh->pl.fmm) return sh->pl.rs ? 9 : 7;
     if (sh->pl.cols)      // padded: + 1 (V[K] := V[0], even lengths) and, in front of the first decode, + 2 C (the kernel's transform)
         return (sh->pl.resample ? 4 * sh->pl.nchunk + 7 : 2 * sh->pl.nchunk + 6) + (sh->pl.padded && !sh->pl.plain ? 1 : 0) +
                (sh->pl.padded && !sh->ghat_ready ? 2 * sh->pl.nchunk : 0);
@@ -888,12 +918,15 @@ static int run_phase_cols(wfx_shard *sh, int ph)
 }
 
 // ---- plan 3: the phases in front of the select (wfx_fmm.hip has the kernels) ---------------------------------------
-static void fmm_rank_boxes(const shard_plan &pl, int r, long long *lo, long long *hi)
+// the boxes of level lg (>= the level the ranks are dealt boxes of) that rank r owns
+static void fmm_rank_boxes_lv(const shard_plan &pl, int lg, int r, long long *lo, long long *hi)
 {
-    const long long G = 1ll << pl.fg.lg;
-    *lo = (long long)r * G / pl.world;
-    *hi = (long long)(r + 1) * G / pl.world;
+    const long long G = 1ll << pl.lgc;
+    *lo = ((long long)r * G / pl.world) << (lg - pl.lgc);
+    *hi = ((long long)(r + 1) * G / pl.world) << (lg - pl.lgc);
 }
+
+static void fmm_rank_boxes(const shard_plan &pl, int r, long long *lo, long long *hi) { fmm_rank_boxes_lv(pl, pl.fg.lg, r, lo, hi); }
 
 static void fmm_rank_range(const shard_plan &pl, int r, uint64_t *lo, uint64_t *hi)
 {
@@ -904,17 +937,16 @@ static void fmm_rank_range(const shard_plan &pl, int r, uint64_t *lo, uint64_t *
     *hi = (uint64_t)wfx_fmm_leaf_first_host(pl.n, pl.fg.L, b << sh);
 }
 
-static int fmm_owner(const shard_plan &pl, long long gbox)          // the rank that owns box `gbox` of the gather level
+static int fmm_owner_lv(const shard_plan &pl, int lg, long long gbox)          // the rank that owns box `gbox` of level lg
 {
-    const long long G = 1ll << pl.fg.lg;
-    int r = (int)((gbox * pl.world + pl.world - 1) / G);             // a first guess, then settle
+    const long long G = 1ll << pl.lgc, cb = gbox >> (lg - pl.lgc);
+    int r = (int)((cb * pl.world + pl.world - 1) / G);               // a first guess, then settle
     if (r >= pl.world) r = pl.world - 1;
     for (;;) {
-        long long a, b;
-        fmm_rank_boxes(pl, r, &a, &b);
-        if (gbox < a)
+        const long long a = (long long)r * G / pl.world, b = (long long)(r + 1) * G / pl.world;
+        if (cb < a)
             --r;
-        else if (gbox >= b)
+        else if (cb >= b)
             ++r;
         else
             return r;
@@ -924,21 +956,21 @@ static int fmm_owner(const shard_plan &pl, long long gbox)          // the rank 
 // what travels after the upward pass, as (sender, receiver, level, first box, boxes) in ONE order every rank enumerates alike: the gather level's
 // boxes of every rank to every other rank, then per finer level and receiver the three boxes before its range and the three behind it
 template <typename F>
-static void fmm_weight_messages(const shard_plan &pl, F &&f)
+static void fmm_weight_messages_lv(const shard_plan &pl, int lg, int L, F &&f)
 {
-    const int W = pl.world, lg = pl.fg.lg, L = pl.fg.L;
+    const int W = pl.world;
     for (int s = 0; s < W; ++s)
         for (int r = 0; r < W; ++r) {
             if (s == r) continue;
             long long a, b;
-            fmm_rank_boxes(pl, s, &a, &b);
+            fmm_rank_boxes_lv(pl, lg, s, &a, &b);
             f(s, r, lg, a, b - a);
         }
     for (int lev = lg + 1; lev <= L; ++lev) {
         const long long nbl = 1ll << lev;
         for (int r = 0; r < W; ++r) {
             long long a, b;
-            fmm_rank_boxes(pl, r, &a, &b);
+            fmm_rank_boxes_lv(pl, lg, r, &a, &b);
             const long long lo = a << (lev - lg), hi = b << (lev - lg);
             for (int side = 0; side < 2; ++side) {
                 // the three boxes of a side travel as ONE message where they are neighbours in memory and have one owner (a rank owns at
@@ -949,7 +981,7 @@ static void fmm_weight_messages(const shard_plan &pl, F &&f)
                     const long long raw = side == 0 ? lo - 3 + j : hi + j;
                     const long long box = (raw + nbl) & (nbl - 1);
                     const bool own = box >= lo && box < hi;                 // (one rank, or a range that is the whole level: its own)
-                    const int s = own ? r : fmm_owner(pl, box >> (lev - lg));
+                    const int s = own ? r : fmm_owner_lv(pl, lg, box >> (lev - lg));
                     if (run_cnt && (own || s != run_s || box != run_box + run_cnt)) {
                         f(run_s, r, lev, run_box, run_cnt);
                         run_cnt = 0;
@@ -967,6 +999,101 @@ static void fmm_weight_messages(const shard_plan &pl, F &&f)
     }
 }
 
+template <typename F>
+static void fmm_weight_messages(const shard_plan &pl, F &&f)
+{
+    fmm_weight_messages_lv(pl, pl.fg.lg, pl.fg.L, f);
+}
+
+// plan 3 in front of a resampler: the two phases that leave the rank's resampled samples (and 320 of either neighbour's) where the phases of
+// run_phase_fmm expect a float64 capture at 11 025 Hz
+static int run_phase_rs(wfx_shard *sh, int ph)
+{
+    wfx_ctx *ctx = sh->ctx;
+    wfx_comm *c = sh->comm;
+    shard_plan &pl = sh->pl;
+    const int me = pl.rank, W = pl.world;
+    const uint64_t n_own = pl.own_hi - pl.own_lo, n_src = pl.in_hi - pl.in_lo;
+    const void *in = sh->ext_in ? sh->ext_in : sh->b_in.p;
+    const double *x = pl.in_kind == WFX_IN_F64_MONO ? (const double *)in : (const double *)sh->b_merged.p;
+    const long long x0 = (long long)pl.in_lo - SH_RS_HS;
+    double *y = (double *)sh->b_v.p;
+    const uint64_t nkey = pl.n0 + (pl.n0 & 1);
+    if (ph == 0) {
+        if (pl.in_kind == WFX_IN_I16_STEREO)
+            WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, n_src + 2 * SH_RS_HS, (double *)sh->b_merged.p));
+        else if (pl.in_kind == WFX_IN_I16_MONO)
+            WFX_TRY(wfx_dev_i16_to_f64(ctx, (const int16_t *)in, n_src + 2 * SH_RS_HS, (double *)sh->b_merged.p));
+        double *gsum = nullptr;
+        WFX_TRY(wfx_rs_shard_up(ctx, x, x0, pl.n0, pl.n, pl.gbr_lo, pl.gbr_hi, &gsum));
+        std::vector<wfx_xfer> xs;
+        int rc = 0;
+        fmm_weight_messages_lv(pl, pl.fgr.lg, pl.fgr.L, [&](int s, int r, int lev, long long box, long long cnt) {
+            if (rc != 0 || (s != me && r != me)) return;
+            double *ptr = nullptr;
+            rc = wfx_fmm_shard_weights(ctx, nkey, lev, box, &ptr);
+            wfx_xfer xf{};
+            xf.peer = s == me ? r : s;
+            if (s == me) {
+                xf.send = ptr;
+                xf.send_bytes = (size_t)cnt * 256;
+            } else {
+                xf.recv = ptr;
+                xf.recv_bytes = (size_t)cnt * 256;
+            }
+            xs.push_back(xf);
+        });
+        WFX_TRY(rc);
+        // the parts of C = sum x_n cos(..): one number per box of the resampler's gather level, every rank's to every other rank
+        for (int s = 0; s < W; ++s)
+            for (int r = 0; r < W; ++r) {
+                if (s == r || (s != me && r != me)) continue;
+                long long a, b;
+                fmm_rank_boxes_lv(pl, pl.fgr.lg, s, &a, &b);
+                wfx_xfer xf{};
+                xf.peer = s == me ? r : s;
+                if (s == me) {
+                    xf.send = gsum + a;
+                    xf.send_bytes = (size_t)(b - a) * 8;
+                } else {
+                    xf.recv = gsum + a;
+                    xf.recv_bytes = (size_t)(b - a) * 8;
+                }
+                xs.push_back(xf);
+            }
+        wfx_comm_label(c, "resampler weights");
+        return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
+    }
+    // ph == 1: the rest of the tree, the rank's targets; then its first 320 resampled samples to the rank before it, its last 320 to the one
+    // behind it (round the circle: the capture's ends meet)
+    WFX_TRY(wfx_rs_shard_down(ctx, x, x0, pl.n0, pl.n, pl.gbr_lo, pl.gbr_hi, y, (long long)pl.own_lo - SH_FMM_HR));
+    std::vector<wfx_xfer> xs;
+    double *own = y + SH_FMM_HR;
+    for (int dir = 0; dir < 2; ++dir)
+        for (int s = 0; s < W; ++s) {
+            const int r = dir == 0 ? (s + 1) % W : (s + W - 1) % W;
+            if (s != me && r != me) continue;
+            // dir 0: s's last 320 -> the 320 in front of r's own; dir 1: s's first 320 -> the 320 behind r's own
+            double *src = dir == 0 ? own + n_own - SH_FMM_HR : own, *dst = dir == 0 ? y : own + n_own;
+            if (s == r) {
+                WFX_HIP(ctx, hipMemcpyAsync(dst, src, SH_FMM_HR * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                continue;
+            }
+            wfx_xfer xf{};
+            xf.peer = s == me ? r : s;
+            if (s == me) {
+                xf.send = src;
+                xf.send_bytes = SH_FMM_HR * 8;
+            } else {
+                xf.recv = dst;
+                xf.recv_bytes = SH_FMM_HR * 8;
+            }
+            xs.push_back(xf);
+        }
+    wfx_comm_label(c, "resampled halos");
+    return wfx_comm_exchange(c, ctx, xs.data(), (int)xs.size());
+}
+
 static int run_phase_fmm(wfx_shard *sh, int ph)
 {
     wfx_ctx *ctx = sh->ctx;
@@ -976,11 +1103,13 @@ static int run_phase_fmm(wfx_shard *sh, int ph)
     const int me = pl.rank, W = pl.world;
     const uint64_t n_own = pl.own_hi - pl.own_lo;
     wfx_dev_scalars *ds = (wfx_dev_scalars *)ctx->b_scal.p;
-    const void *in = sh->ext_in ? sh->ext_in : sh->b_in.p;
+    // (behind the resampler: its output, float64, [own_lo - 320, own_hi + 320) as run_phase_rs left it)
+    const void *in = pl.rs ? sh->b_v.p : (sh->ext_in ? sh->ext_in : sh->b_in.p);
+    const int in_kind = pl.rs ? WFX_IN_F64_MONO : pl.in_kind;
     double *audio = (double *)sh->b_audio.p;
     const long long audio0 = (long long)pl.own_lo - SH_FMM_HF, raw0 = (long long)pl.own_lo - SH_FMM_HR;
     double ext18[18];
-    const bool use_ext = p.has_ext && pl.in_kind != WFX_IN_I16_STEREO;
+    const bool use_ext = p.has_ext && in_kind != WFX_IN_I16_STEREO && !pl.rs;
     for (int i = 0; i < 9; ++i) {
         ext18[i] = p.ext_left[i];
         ext18[9 + i] = p.ext_right[i];
@@ -988,8 +1117,8 @@ static int run_phase_fmm(wfx_shard *sh, int ph)
     if (ph == 0) {
         // the rank's frames: [own_lo - 320, own_hi + 320) round the circle.  a4, then the leaf before the first own sample and the one behind the
         // last through the notch (segment form; at the capture's ends filtfilt's exact edges), then notch + P2M + M2M of the own workgroups
-        int kind = pl.in_kind;
-        if (pl.in_kind == WFX_IN_I16_STEREO) {
+        int kind = in_kind;
+        if (in_kind == WFX_IN_I16_STEREO) {
             WFX_TRY(wfx_dev_merge(ctx, (const int16_t *)in, n_own + 2 * SH_FMM_HR, (double *)sh->b_merged.p));
             in = sh->b_merged.p;
             kind = WFX_IN_F64_MONO;
@@ -1102,7 +1231,12 @@ static int run_phase(wfx_shard *sh, int ph)
     }
     if (pl.cols) return run_phase_cols(sh, ph);
     if (pl.fmm) {
+        if (pl.rs) {
+            if (ph <= 1) return run_phase_rs(sh, ph);
+            ph -= 2;
+        }
         if (ph <= 2) return run_phase_fmm(sh, ph);
+        if (pl.rs) ph += 4;                 // (the transposing plans' numbering below: 0 .. 3 are THEIR resampler's)
         ph += 2;                            // 3 .. 6 = the select's level 1, its candidates, finish + quantise + gather, rank 0's tail (cases 9 .. 12)
     }
     double *audio = (double *)sh->b_audio.p;
@@ -1462,29 +1596,34 @@ extern "C" int wfx_shard_dry_run(const wfx_decode_params *p, int world)
     if (pl.fmm) {
         // plan 3: every rank walks ONE enumeration of (sender, receiver, level, box): the two ends of a message agree by construction; what is
         // checked here is that every box a rank's kernels read beyond its own range is delivered exactly once and by its owner
-        for (int r = 0; r < world; ++r) {
-            long long a, b;
-            fmm_rank_boxes(pl, r, &a, &b);
-            for (int lev = pl.fg.lg + 1; lev <= pl.fg.L; ++lev) {
-                const long long nbl = 1ll << lev, lo = a << (lev - pl.fg.lg), hi = b << (lev - pl.fg.lg);
-                std::vector<long long> need, got;
-                for (int j = 0; j < 3; ++j) {
-                    for (long long raw : {lo - 3 + j, hi + j}) {
-                        const long long box = (raw + nbl) & (nbl - 1);
-                        if (box < lo || box >= hi) need.push_back(box);
+        for (int tree = 0; tree < (pl.rs ? 2 : 1); ++tree) {
+            const int tlg = tree ? pl.fgr.lg : pl.fg.lg, tL = tree ? pl.fgr.L : pl.fg.L;
+            for (int r = 0; r < world; ++r) {
+                long long a, b;
+                fmm_rank_boxes_lv(pl, tlg, r, &a, &b);
+                for (int lev = tlg + 1; lev <= tL; ++lev) {
+                    const long long nbl = 1ll << lev, lo = a << (lev - tlg), hi = b << (lev - tlg);
+                    std::vector<long long> need, got;
+                    for (int j = 0; j < 3; ++j) {
+                        for (long long raw : {lo - 3 + j, hi + j}) {
+                            const long long box = (raw + nbl) & (nbl - 1);
+                            if (box < lo || box >= hi) need.push_back(box);
+                        }
                     }
+                    fmm_weight_messages_lv(pl, tlg, tL, [&](int s, int rr, int lv, long long box, long long cnt) {
+                        if (rr == r && lv == lev) {
+                            long long sa, sb;
+                            fmm_rank_boxes_lv(pl, tlg, s, &sa, &sb);
+                            for (long long q = 0; q < cnt; ++q)
+                                if (((box + q) >> (lev - tlg)) >= sa && ((box + q) >> (lev - tlg)) < sb && box + q < nbl) got.push_back(box + q);
+                        }
+                    });
+                    std::sort(need.begin(), need.end());
+                    std::sort(got.begin(), got.end());
+                    if (need != got)
+                        return wfx_fail(nullptr, WFX_ERR_COMM, "dry run (multipole plan, %s tree): rank %d, level %d: the boxes delivered are not the boxes read",
+                                        tree ? "resampler" : "Hilbert", r, lev);
                 }
-                fmm_weight_messages(pl, [&](int s, int rr, int lv, long long box, long long cnt) {
-                    if (rr == r && lv == lev) {
-                        long long sa, sb;
-                        fmm_rank_boxes(pl, s, &sa, &sb);
-                        for (long long q = 0; q < cnt; ++q)
-                            if (((box + q) >> (lev - pl.fg.lg)) >= sa && ((box + q) >> (lev - pl.fg.lg)) < sb && box + q < nbl) got.push_back(box + q);
-                    }
-                });
-                std::sort(need.begin(), need.end());
-                std::sort(got.begin(), got.end());
-                if (need != got) return wfx_fail(nullptr, WFX_ERR_COMM, "dry run (multipole plan): rank %d, level %d: the boxes delivered are not the boxes read", r, lev);
             }
         }
         return 0;
@@ -1527,6 +1666,30 @@ extern "C" int wfx_shard_wire_plan(const wfx_decode_params *p, int world, wfx_wi
         return n;
     }
     if (pl.fmm) {
+        if (pl.rs) {
+            std::vector<unsigned long long> sent((size_t)W, 0ull), link((size_t)W * W, 0ull);
+            fmm_weight_messages_lv(pl, pl.fgr.lg, pl.fgr.L, [&](int s, int r, int, long long, long long cnt) {
+                sent[(size_t)s] += (unsigned long long)cnt * 256;
+                link[(size_t)s * W + r] += (unsigned long long)cnt * 256;
+            });
+            for (int s2 = 0; s2 < W; ++s2)
+                for (int r = 0; r < W; ++r) {
+                    if (s2 == r) continue;
+                    long long a, b;
+                    fmm_rank_boxes_lv(pl, pl.fgr.lg, s2, &a, &b);
+                    sent[(size_t)s2] += (unsigned long long)(b - a) * 8;
+                    link[(size_t)s2 * W + r] += (unsigned long long)(b - a) * 8;
+                }
+            unsigned long long total = 0, mr = 0, ml = 0;
+            for (int r = 0; r < W; ++r) {
+                total += sent[(size_t)r];
+                mr = std::max(mr, sent[(size_t)r]);
+            }
+            for (unsigned long long v : link) ml = std::max(ml, v);
+            put("resampler weights", total, mr, ml);
+            const unsigned long long hb = SH_FMM_HR * 8ull;
+            put("resampled halos", W > 1 ? 2 * hb * W : 0ull, W > 1 ? 2 * hb : 0ull, W > 1 ? (W == 2 ? 2 * hb : hb) : 0ull);
+        }
         std::vector<unsigned long long> sent((size_t)W, 0ull), link((size_t)W * W, 0ull);
         fmm_weight_messages(pl, [&](int s, int r, int, long long, long long cnt) {
             sent[(size_t)s] += (unsigned long long)cnt * 256;
@@ -1647,14 +1810,15 @@ int wfx_shard_layout_query(const wfx_decode_params *p, int world, int rank, wfx_
     out->own_hi = pl.own_hi;
     out->nseg = 1;
     out->plan = pl.single ? 0 : (pl.fmm ? 3 : (pl.cols ? 2 : 1));
-    if (pl.fmm) out->in_halo = SH_FMM_HR;                              // frames beyond [in_lo, in_hi) on either side, ROUND THE CIRCLE (the capture's other end)
+    if (pl.fmm) out->in_halo = (unsigned)pl.in_halo;                              // frames beyond [in_lo, in_hi) on either side, ROUND THE CIRCLE (the capture's other end)
     out->plan_forced = pl.forced;
     out->model_single_s = pl.model_single;
     out->model_dist_compute_s = pl.model_comp;
     out->model_dist_wire_s = pl.model_wire;
     out->model_wire_bytes = pl.model_bytes;
     if (pl.fmm)
-        snprintf(out->plan_reason, sizeof out->plan_reason, "chunk-local multipole form: ranks own boxes of level %d of a %d-level tree", pl.fg.lg, pl.fg.L);
+        snprintf(out->plan_reason, sizeof out->plan_reason, pl.rs ? "chunk-local multipole forms (resampler + Hilbert transform): ranks own boxes of level %d of a %d-level tree"
+                                                                   : "chunk-local multipole form: ranks own boxes of level %d of a %d-level tree", pl.lgc, pl.fg.L);
     else if (pl.cols && !pl.single)
         snprintf(out->plan_reason, sizeof out->plan_reason, "columns layout, every transpose in %d k1 subset%s", pl.nchunk, pl.nchunk == 1 ? "" : "s");
     else
@@ -1760,7 +1924,7 @@ int wfx_shard_upload(wfx_shard *sh, const void *host_frames)
 {
     CHECK_SH(sh);
     wfx_ctx *ctx = sh->ctx;
-    const size_t nb = (size_t)(sh->pl.cols ? cols_in_frames(sh->pl) : sh->pl.in_hi - sh->pl.in_lo + (sh->pl.fmm ? 2 * SH_FMM_HR : 0)) * frame_bytes(sh->pl.in_kind);
+    const size_t nb = (size_t)(sh->pl.cols ? cols_in_frames(sh->pl) : sh->pl.in_hi - sh->pl.in_lo + (sh->pl.fmm ? 2 * sh->pl.in_halo : 0)) * frame_bytes(sh->pl.in_kind);
     if (!host_frames && nb) return wfx_fail(ctx, WFX_ERR_BAD_ARG, "null buffer");
     const bool moved = !sh->b_in.p || sh->b_in.cap < nb + 64 || sh->ext_in;
     WFX_TRY(wfx_reserve(ctx, sh->b_in, nb + 64));
