@@ -316,6 +316,33 @@ def test_front_end_then_exact_path_one_gpu_and_sharded(ctx, fs, iq, lpm, seconds
         else:       # the float stages too do not depend on the number of ranks
             assert np.array_equal(r["envelope"], first["envelope"]) and np.array_equal(r["audio"], first["audio"])
             assert r["low"] == first["low"] and r["high"] == first["high"]
+    # plan 3 (round 6): the hand-over-rate signal cut into contiguous arcs, resampler AND Hilbert transform by their multipole forms -- nothing
+    # but kilobytes of weights, 320 resampled samples per seam and the select's collectives travel before the gather.  Where the lengths have
+    # those forms (downsampling to an even count): the same bytes for every world size; against the fused form (transforms over the
+    # capture: the same sums in another order, 1e-13 apart) the stream within the parity bar.
+    n_fe, n_t = fe.n_out(x.shape[0]), fe.n_target(x.shape[0])
+    if n_t % 2 == 0 and n_fe >= 32768 and n_t >= 32768:
+        first = None
+        for world in (1, 2, 3, 8):
+            mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, x, lines_per_minute=lpm, plan="fmm")      # noqa: E731
+            r = sharded.decode_emulated(x, fs, world, lpm, make_decoder=mk)
+            assert r["plan"] == 3
+            assert r["sync"]["start_frame"] == ref["start_frame"]
+            assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
+            if first is None:
+                first = r
+                d = np.abs(r["digitalized"].astype(np.int16) - st1.astype(np.int16))
+                assert d.max() <= 1 and np.count_nonzero(d) <= 1e-5 * d.size + 2, (int(d.max()), int(np.count_nonzero(d)))
+                assert np.abs(r["image"].astype(np.int16) - img1.astype(np.int16)).max() <= 1
+            else:
+                for k in ("digitalized", "image", "envelope", "audio"):
+                    assert np.array_equal(r[k], first[k]), (world, k)
+                assert r["low"] == first["low"] and r["high"] == first["high"]
+            sent = [sum(int(e["sent"]) for e in ws if e["name"] != "stream gather") for ws in r["wire"]]
+            assert max(sent) <= 1 << 20                  # a rank puts less than a megabyte on the wire in front of the gather
+    else:
+        with pytest.raises(nat.NativeError, match="no multipole form"):
+            sharded.FrontEndShardedDecoder(ctx, nat.Comm.local(1)[0], fe, x, lines_per_minute=lpm, plan="fmm")
 
 
 @pytest.mark.gpu

@@ -371,7 +371,7 @@ class FrontEndDevice:
 
     ``raw``: host array (int16 [n] or [n, 2]) or a (device pointer, frames) pair that stays owned by the caller."""
 
-    def __init__(self, ctx: nat.Context, chain, raw, in_kind: int, nbatch: int = 1, raw_stride: int = 0):
+    def __init__(self, ctx: nat.Context, chain, raw, in_kind: int, nbatch: int = 1, raw_stride: int = 0, out_ptr: int | None = None):
         """``nbatch`` > 1 (the segments a rank owns in the columns layout of the sharded decode): ``raw`` holds that many equally
         long slices, ``raw_stride`` frames apart (a multiple of 16 bytes); every stage runs them in ONE launch and the result is
         ``nbatch`` rows of ``n_out`` samples back to back.  Float64 chains only."""
@@ -389,9 +389,9 @@ class FrontEndDevice:
         self.raw_stride = int(raw_stride) if self.nbatch > 1 else 0
         a, b = chain[-1][1]
         self.n_out = b - a
-        self.p_out = None
+        self.p_out = int(out_ptr) if out_ptr else None          # (given: the caller's buffer, e.g. a slot of a larger one -- not freed here)
         probe_out = ((self.n_raw // 32 - 8) - 119) // 3 + 1            # outputs wfx_d_stream_rate writes for a capture of n_raw frames
-        if (self.nbatch == 1 and self.n_raw * 4 >= (1 << 30) and in_kind == nat.WFX_IN_I16_STEREO and len(chain) == 2 and chain[0][0].factor == 32
+        if (self.p_out is None and self.nbatch == 1 and self.n_raw * 4 >= (1 << 30) and in_kind == nat.WFX_IN_I16_STEREO and len(chain) == 2 and chain[0][0].factor == 32
                 and chain[1][0].factor == 3 and probe_out <= self.n_out):
             # the 1.536 MS/s ingest writes its output in small bursts under 22 GB of reads: where THAT buffer lies counts as much as where
             # the capture does (WFX_PLACE_TRIES > 1: the best of a few allocations, timed with the capture in place)
@@ -565,6 +565,34 @@ class FrontEndShardedDecoder:
             self.raw_range = (ia, ia + (nseg - 1) * seg_raw + (ib - ia))
             self.raw_frames = nseg * (ib - ia)
             return
+        self.extra = []
+        if lay.plan == 3:
+            # the multipole plan: the rank's range of the hand-over-rate signal with `in_halo` samples on either side ROUND THE CIRCLE -- the
+            # resampler is cyclic in that signal, so what lies beyond its ends is its other end (computed from the raw frames THERE, by a
+            # second small chain), not what the FIR chain would make of raw frames wrapped round the capture
+            lo, hi, h = int(lay.in_lo), int(lay.in_hi), int(lay.in_halo)
+            m_lo, m_hi = max(lo - h, 0), min(hi + h, n_fe)
+            self._comb = ctx.dev_malloc(8 * (hi - lo + 2 * h) + 64)
+            pieces = [(m_lo, m_hi, m_lo - (lo - h))]
+            if lo - h < 0:
+                pieces.append((n_fe + lo - h, n_fe, 0))
+            if hi + h > n_fe:
+                pieces.append((0, hi + h - n_fe, n_fe - (lo - h)))
+            fes = []
+            self.raw_frames = 0
+            for a, b, off in pieces:
+                ch = frontend.chain(a, b)
+                ia, ib = ch[0][2]
+                raw = _raw_slice(x, raw_loader, ia, ib, n_in_total)
+                if in_kind is None:
+                    in_kind = 1 if (not isinstance(raw, tuple) and raw.ndim == 2) else 0
+                fes.append(FrontEndDevice(ctx, ch, raw, in_kind, out_ptr=self._comb + 8 * off))
+                self.raw_frames += ib - ia
+            self.chain = fes[0].chain
+            self.fe, self.extra = fes[0], fes[1:]
+            self.raw_range = tuple(self.chain[0][2])
+            self.dec.attach(self._comb)
+            return
         self.chain = frontend.chain(int(lay.in_lo), int(lay.in_hi))
         ia, ib = self.chain[0][2]
         raw = _raw_slice(x, raw_loader, ia, ib, n_in_total)
@@ -582,6 +610,8 @@ class FrontEndShardedDecoder:
     def front_end(self):
         if self.fe is not None:
             self.fe.run()
+        for fe in getattr(self, "extra", []):
+            fe.run()
 
     def result(self):
         return self.dec.result()
@@ -594,6 +624,11 @@ class FrontEndShardedDecoder:
         if getattr(self, "_raw_ptr", None):
             self.dec.ctx.dev_free(self._raw_ptr)
             self._raw_ptr = None
+        for fe in getattr(self, "extra", []):
+            fe.close()
+        if getattr(self, "_comb", None):
+            self.dec.ctx.dev_free(self._comb)
+            self._comb = None
         if self.fe is not None:
             self.fe.close()
         elif getattr(self, "_none", None):
