@@ -770,6 +770,9 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
            "n_gpus": rk.world, "ranks_rccl": rk.world if rk.comm.is_rccl else 0, "transport": rk.transport_name(), "scaling": "strong",
            "form": ("front end + fused exact decode on one GPU" if fused else
                     ("rank 0 alone behind the sharded interface (the cost model declined the distributed plan)" if dec.layout.plan == 0 else
+                     f"front end on each rank's 1/{rk.world} of the stream + chunk-local exact path (plan 3: resampler and Hilbert transform by their multipole forms on the "
+                     "rank's arc; kilobytes of weights, 320 samples per seam, 2 histogram all-reduces, 1 candidate all-gather, 1 stream gather per decode)"
+                     if dec.layout.plan == 3 else
                      f"front end on each rank's 1/{rk.world} of the stream + sharded exact path (distributed FFT resample and Hilbert, "
                      f"{'columns layout: 4' if dec.layout.plan == 2 else 'rows layout: 8'} array transposes, 2 histogram all-reduces, 1 candidate all-gather, "
                      "1 stream gather per decode)")),
@@ -800,21 +803,22 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
         out["measured_ms"] = out["ms_per_step"]
     dec.close()
     if not fused and rk.world > 1 and args.plan == "auto" and os.environ.get("WFX_BENCH_BOTH_PLANS", "1") != "0":
-        # the other side of the cost model's decision, in the same run: the distributed plan forced (when `auto` chose it too, this
-        # is a second measurement of it).  model_ms beside measured_ms for both is what calibrates WFX_LINK_GBS / WFX_LINK_LAT_US
-        try:
-            d2 = sharded.FrontEndShardedDecoder(ctx, rk.comm, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,
-                                                raw_loader=raw_loader, plan="dist")
-            dt2 = rk.timed(d2.run, max(2, steps // 2), 1)
-            ms2 = 1e3 * dt2 / max(2, steps // 2)
-            w2 = wire_object(rk, d2.dec.params, d2.layout, d2.run, ctx.sync)
-            i2 = d2.result()
-            out["forced_dist"] = {"plan": "dist", "ms_per_step": round(ms2, 4), "measured_ms": round(ms2, 4), "model_ms": w2["model"]["dist_ms"],
-                                  "start_frame": int(i2.start_frame) if rk.rank == 0 else None, "wire": w2,
-                                  "kernels": kernel_table(profile_pass(ctx, d2.run, 1), 1)}
-            d2.close()
-        except Exception as e:      # noqa: BLE001 -- a layout the distributed plan does not take: said, not fatal
-            out["forced_dist"] = {"plan": "dist", "error": f"{type(e).__name__}: {e}"[:300]}
+        # the other sides of the cost model's decision, in the same run: the transposing plan and the chunk-local plan forced (when `auto` chose
+        # one of them, this is a second measurement of it).  model_ms beside measured_ms for both is what calibrates WFX_LINK_GBS / WFX_LINK_LAT_US
+        for forced in ("dist", "fmm"):
+            try:
+                d2 = sharded.FrontEndShardedDecoder(ctx, rk.comm, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,
+                                                    raw_loader=raw_loader, plan=forced)
+                dt2 = rk.timed(d2.run, max(2, steps // 2), 1)
+                ms2 = 1e3 * dt2 / max(2, steps // 2)
+                w2 = wire_object(rk, d2.dec.params, d2.layout, d2.run, ctx.sync)
+                i2 = d2.result()
+                out["forced_" + forced] = {"plan": forced, "ms_per_step": round(ms2, 4), "measured_ms": round(ms2, 4), "model_ms": w2["model"]["dist_ms"],
+                                           "start_frame": int(i2.start_frame) if rk.rank == 0 else None, "wire": w2,
+                                           "kernels": kernel_table(profile_pass(ctx, d2.run, 1), 1)}
+                d2.close()
+            except Exception as e:      # noqa: BLE001 -- a layout the plan does not take: said, not fatal
+                out["forced_" + forced] = {"plan": forced, "error": f"{type(e).__name__}: {e}"[:300]}
     raw_loader.close()
     # the one-GPU time of the same stream, measured in this run on rank 0, and the efficiency against it
     if rk.world > 1:
@@ -1294,7 +1298,7 @@ def main():
                     "one_gpu_ms": c4.get("one_gpu_ms"), "speedup_vs_one_gpu": c4.get("speedup_vs_one_gpu"),
                     "efficiency_vs_one_gpu": c4.get("efficiency_vs_one_gpu"), "transport": c4.get("transport"), "wire": c4.get("wire"),
                     "per_step": c4.get("per_step"), "gpu_state": c4.get("gpu_state"), "model_ms": c4.get("model_ms"),
-                    "measured_ms": c4.get("measured_ms"), "forced_dist": c4.get("forced_dist"), "placement": c4.get("placement")}
+                    "measured_ms": c4.get("measured_ms"), "forced_dist": c4.get("forced_dist"), "forced_fmm": c4.get("forced_fmm"), "placement": c4.get("placement")}
         elif args.workload == "c3":
             line = bench_c3(args, rk)
         else:
@@ -1361,6 +1365,12 @@ def main():
             if isinstance(line.get("c4_strong"), dict) and isinstance(line["c4_strong"].get("gpu_state"), dict):
                 cfgs.setdefault("c4", {})["gpu_state_during"] = line["c4_strong"]["gpu_state"].get("during_steps")
                 cfgs["c4"]["ingest_us"] = (line["c4_strong"].get("per_step") or {}).get("ingest_us")
+            if rk.world > 1 and isinstance(line.get("c4_strong"), dict) and "error" not in line["c4_strong"]:
+                c4s = line["c4_strong"]
+                cfgs.setdefault("c4", {})["plans_ms"] = {"auto": {"plan": (c4s.get("wire") or {}).get("layout"), "ms": c4s.get("ms_per_step"), "model_ms": c4s.get("model_ms")},
+                                                          **{k: {"ms": (c4s.get("forced_" + k) or {}).get("ms_per_step"), "model_ms": (c4s.get("forced_" + k) or {}).get("model_ms"),
+                                                                 "error": (c4s.get("forced_" + k) or {}).get("error")} for k in ("dist", "fmm")},
+                                                          "one_gpu_ms": c4s.get("one_gpu_ms")}
             line["roofline"]["configs"] = cfgs
             line["roofline"]["file_to_file_ms"] = e2e
         if guard is None or guard.claim():

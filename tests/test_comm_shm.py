@@ -254,6 +254,46 @@ def test_multipole_plan_in_real_processes_equals_the_one_gpu_decode(tmp_path, wo
     ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,lpm", [(2, 240), (5, 120)])
+def test_multipole_plan_in_front_of_a_resampler_in_real_processes(tmp_path, world, lpm):
+    """Plan 3 for a 48 kHz capture (the resampler's multipole form sharded as well; csrc/wfx_shard.hip run_phase_rs) over the shm transport: the
+    processes' stream, image and envelope blocks are the in-process emulation's bit for bit, the stream within the parity bar of the one-GPU
+    decode (whose resampler is the transform over the capture: the same sums in another order)."""
+    from wefax_amd import sharded
+    from wefax_amd.wefax import DecodeJob
+    x = _capture(48000, 5, lpm)
+    job = _job()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_decode_worker, args=(job, world, r, 5, 48000, lpm, str(tmp_path), q, 0, "fmm")) for r in range(world)]
+    for r in reversed(range(world)):
+        procs[r].start()
+        time.sleep(0.05)
+    out = dict(q.get(timeout=600) for _ in range(world))
+    for p_ in procs:
+        p_.join(30)
+    assert out == {r: "ok" for r in range(world)}, out
+    emu = sharded.decode_emulated(x, 48000, world, lpm, plan="fmm")
+    assert emu["plan"] == 3
+    assert np.array_equal(np.load(tmp_path / "stream.npy"), emu["digitalized"]) and np.array_equal(np.load(tmp_path / "image.npy"), emu["image"])
+    lays = [nat.shard_layout(build_params_fmm(x, 48000, lpm), world, r) for r in range(world)]
+    assert np.array_equal(sharded.assemble(lays, [np.load(tmp_path / f"env{r}.npy") for r in range(world)], emu["n"]), emu["envelope"])
+    ctx = nat.Context(0)
+    ref = DecodeJob(ctx, x, 48000, lpm)
+    ref.run()
+    info = ref.result()
+    d = np.abs(emu["digitalized"].astype(np.int16) - ref.fetch("digitalized").astype(np.int16))
+    assert d.max() <= 1 and np.count_nonzero(d) <= 2 and list(np.load(tmp_path / "sync.npy"))[0] == info.start_frame
+    ctx.close()
+
+
+def build_params_fmm(x, rate, lpm):
+    from wefax_amd import sharded
+    from wefax_amd.wefax import build_params
+    return build_params(sharded.capture_kind(x), x.shape[0], rate, 1 / (lpm / 60), shard_plan=sharded.plan_code("fmm"))[0]
+
+
 def _silence_worker(job, rank, q):
     """A constant capture overflows the select's candidate lists: the library repeats the decode by itself on every rank."""
     try:

@@ -85,3 +85,32 @@ def test_ten_minute_capture_both_hilbert_forms_give_one_stream():
     assert np.array_equal(a[0], b[0]) and a[2] == b[2] and np.array_equal(a[3], b[3])
     assert np.max(np.abs(a[1] - b[1])) <= 1e-12 * np.max(a[1])
     c.close()
+
+
+@pytest.mark.parametrize("n0,num", [(960000, 220500), (960000, 661500), (596801, 411220), (32768, 22580), (1000000, 999998), (3000000, 689062), (1048576, 524288),
+                                    (65536 + 13, 45164)])
+def test_device_resampler_by_fast_multipole_equals_the_transform_form(ctx, n0, num):
+    """a5's scipy.signal.resample(x, num) (wefax.py:160-161) without a transform over the capture (round 6, csrc/wfx_fmm.hip rs_*): periodic sinc sum =
+    one global constant minus a cotangent sum between the input grid and the output grid, near field on the vector pipe, far field on the Hilbert
+    transform's tree.  Against the oracle's FFT form (= scipy's arithmetic) to 1e-12 of the largest sample (measured: 5e-14; the NumPy model of the
+    same arithmetic, tests/test_resample_farfield_model.py, is gated at 1e-11).  Covers odd input counts, coincident grids (2 : 1), leaves of 32
+    and of 64 samples, and the short-capture variant that keeps cot's x^3 term (levels < 13)."""
+    rng = np.random.default_rng(n0 + num)
+    x = rng.standard_normal(n0) * 1000 + 3000 * np.sin(np.arange(n0) * 0.7)
+    ref = wo.resample_fft(x, num)
+    px, py = ctx.dev_malloc(n0 * 8 + 64), ctx.dev_malloc(num * 8 + 64)
+    ctx.dev_upload(px, x)
+    assert ctx.d_resample_fmm(px, n0, num, py)
+    got = ctx.dev_download(py, (num,), np.float64)
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+    assert np.array_equal(ctx.dev_download(px, (n0,), np.float64), x)          # the input is left alone
+    ctx.dev_free(px)
+    ctx.dev_free(py)
+
+
+def test_device_resampler_declines_what_it_has_no_form_for(ctx):
+    p = ctx.dev_malloc(1 << 21)
+    for n0, num in ((100000, 100001), (100000, 200000), (100000, 68907), (20000, 13780)):       # upsampling, an odd count, a short capture
+        assert not ctx.d_resample_fmm(p, n0, num, p + (1 << 20))
+    ctx.dev_free(p)
+

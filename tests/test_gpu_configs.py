@@ -295,6 +295,28 @@ def test_sixty_minute_iq_stream_full_size_properties():
     assert sum(own) == 39690000 and max(own) - min(own) <= 39690000 // 200           # even shares up to a few columns of every row
     sent = sum(e["sent"] for rank_stats in r["wire"] for e in rank_stats)
     assert 1.2e9 < sent < 1.32e9                                                      # (rows layout: 2.54 GB)
+    del r
+    # (3) round 6, the north star's shape: the same eight ranks on plan 3 -- every rank ingests its eighth of the stream, resamples and
+    # Hilbert-transforms its arc by the multipole forms; in front of the ONE gather of the uint8 stream a rank sends well under a megabyte
+    keep = []
+    mk = lambda c, m: sharded.FrontEndShardedDecoder(c, m, fe, None, n_in_total=n0, in_kind=nat.WFX_IN_I16_STEREO, lines_per_minute=120,   # noqa: E731
+                                                     raw_loader=synth_device.SliceLoader(c, sp), plan="fmm")
+    r = sharded.decode_emulated(np.zeros(1, dtype=np.int16), fs, 8, 120, want=("image", "stream"), make_decoder=mk, free_after=keep)
+    assert r["plan"] == 3
+    assert r["sync"]["start_frame"] == s16
+    assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
+    ds = np.abs(r["digitalized"].astype(np.int16) - st16.astype(np.int16))
+    d = np.abs(r["image"].astype(np.int16) - img16.astype(np.int16))
+    print(f"plan 3 against the transposing plan, full size: stream differs on {np.count_nonzero(ds)} of {ds.size} (max {ds.max()}), image on {np.count_nonzero(d)} (max {d.max()})")
+    assert ds.max() <= 1 and np.count_nonzero(ds) <= 1e-6 * ds.size + 2 and d.max() <= 1
+    own = r["own"]
+    assert sum(own) == 39690000 and max(own) - min(own) <= 64
+    small = [sum(int(e["sent"]) for e in ws if e["name"] != "stream gather") for ws in r["wire"]]
+    gather = sum(int(e["sent"]) for ws in r["wire"] for e in ws if e["name"] == "stream gather")
+    trees = [sum(int(e["sent"]) for e in ws if e["name"] in ("resampler weights", "resampled halos", "fmm weights", "fmm seams")) for ws in r["wire"]]
+    print("plan 3, bytes a rank sends in front of the gather:", small, " of which for the two trees:", trees, " gather:", gather)
+    # (the rest is the exact percentile select's: two histogram all-reduces and the candidates of the two bins, every rank's to every rank)
+    assert max(trees) <= 256 * 1024 and max(small) <= 4 << 20 and gather <= 39690000
     ctx.close()
 
 

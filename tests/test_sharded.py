@@ -142,8 +142,8 @@ def test_the_number_of_k1_subsets_follows_the_cost_model(monkeypatch):
 
 def test_the_cost_model_declines_a_distributed_plan_that_would_lose(monkeypatch):
     """shard_plan 0 (the default): with 50 GB/s links two ranks would spend longer exchanging configs[3]'s arrays than one GPU
-    needs for the whole decode -- the single plan is taken and says why; eight ranks get the distributed (columns) plan; links
-    that are fast enough flip the choice; the caller can force either."""
+    needs for the whole decode -- the single plan is taken and says why; eight ranks get a sharded plan (since round 6 the chunk-local
+    one); links that are fast enough flip the choice; the caller can force either."""
     n0, n = 57600000, 39690000
     monkeypatch.delenv("WFX_LINK_GBS", raising=False)
     monkeypatch.delenv("WFX_LINK_LAT_US", raising=False)
@@ -153,8 +153,12 @@ def test_the_cost_model_declines_a_distributed_plan_that_would_lose(monkeypatch)
     assert lay2.plan == 0 and lay2.plan_forced == 0 and lay2.plan_reason.decode().startswith("cost model")
     assert lay2.model_dist_compute_s + lay2.model_dist_wire_s > lay2.model_single_s > 0
     assert (lay2.own_lo, lay2.own_hi) == (0, n) and nat.shard_layout(p, 2, 1).own_samples == 0
-    assert lay8.plan == 2 and lay8.model_dist_compute_s + lay8.model_dist_wire_s < lay8.model_single_s
-    assert 1.2e9 < lay8.model_wire_bytes < 1.35e9
+    # (round 6: eight ranks take plan 3 -- both multipole forms, kilobytes on the wire; the transposing plan, when asked for, moves 1.3 GB)
+    assert lay8.plan == 3 and lay8.model_dist_compute_s + lay8.model_dist_wire_s < 0.5 * lay8.model_single_s and lay8.model_wire_bytes < 64e6
+    dist8, _ = build_params(2, n0, 16000, 0.5, n_out=n, shard_plan=sharded.plan_code("dist"))
+    lay8d = nat.shard_layout(dist8, 8, 0)
+    assert lay8d.plan == 2 and lay8d.model_dist_compute_s + lay8d.model_dist_wire_s < lay8d.model_single_s
+    assert 1.2e9 < lay8d.model_wire_bytes < 1.35e9
     monkeypatch.setenv("WFX_LINK_GBS", "400")
     assert nat.shard_layout(p, 2, 0).plan == 2
     monkeypatch.delenv("WFX_LINK_GBS")
@@ -250,7 +254,7 @@ def test_multipole_plan_cuts_the_capture_at_leaf_workgroups_and_keeps_the_wire_i
 def test_the_cost_model_takes_the_multipole_plan_where_the_capture_is_long_enough(monkeypatch):
     """`plan="auto"`: a 60-minute capture at 11 025 Hz (39.69 M samples) is cut by plan 3 at every world size (its exchanges are kilobytes:
     model 1.7 / 1.0 / 0.64 ms on 2 / 4 / 8 ranks against 2.8 ms on one GPU and more for the transposing plan); the 10-minute capture is too
-    short to be worth it below 8 ranks, where the transposing plan's model is still a little ahead; resampled captures never get it."""
+    short to be worth it below 8 ranks, where the transposing plan's model is still a little ahead."""
     for v in ("WFX_LINK_GBS", "WFX_LINK_LAT_US", "WFX_SHARD_CHUNKS", "WFX_SHARD_ROWS"):
         monkeypatch.delenv(v, raising=False)
     p, _ = build_params(0, 39690000, 11025, 0.5)
@@ -260,13 +264,22 @@ def test_the_cost_model_takes_the_multipole_plan_where_the_capture_is_long_enoug
         assert lay.model_dist_compute_s + lay.model_dist_wire_s < 0.7 * lay.model_single_s
     p, _ = build_params(0, 7166250, 11025, 0.5)
     assert [nat.shard_layout(p, w, 0).plan for w in (2, 4, 8)] == [0, 0, 2]
+    # resampled captures (round 6: the resampler has its multipole form too): the 60-minute IQ stream's hand-over signal (57.6 M -> 39.69 M) from
+    # four ranks on; the 60-minute 48 kHz capture (172.8 M sources: the tree over them is the cost) on four ranks, where the transposing plan's
+    # exchanges are still too long -- on eight that plan's model is a little ahead again
+    p, _ = build_params(2, 57600000, 16000, 0.5, n_out=39690000)
+    assert [nat.shard_layout(p, w, 0).plan for w in (4, 8)] == [3, 3]
     p, _ = build_params(0, 172800000, 48000, 0.5)
-    assert all(nat.shard_layout(p, w, 0).plan != 3 for w in (2, 4, 8))
+    assert [nat.shard_layout(p, w, 0).plan for w in (2, 4, 8)] == [0, 3, 2]
 
 
 def test_multipole_plan_refuses_what_it_cannot_shard():
-    p, _ = build_params(0, 1440000, 48000, 0.5, shard_plan=sharded.plan_code("fmm"))       # needs the resampler: a transform over the capture
-    with pytest.raises(nat.NativeError, match="11 025 Hz only"):
+    p, _ = build_params(0, 480000, 8000, 0.5, shard_plan=sharded.plan_code("fmm"))         # upsampling: the resampler's multipole form is built for downsampling
+    with pytest.raises(nat.NativeError, match="no multipole form of the resampler"):
+        nat.shard_layout(p, 2, 0)
+    p, _ = build_params(0, 1440000 - 3, 48000, 0.5, shard_plan=sharded.plan_code("fmm"))   # an odd count at 11 025 Hz
+    assert _["n"] % 2 == 1
+    with pytest.raises(nat.NativeError, match="no multipole form"):
         nat.shard_layout(p, 2, 0)
     p, _ = build_params(0, 100001, 11025, 0.5, shard_plan=sharded.plan_code("fmm"))        # odd: no multipole form
     with pytest.raises(nat.NativeError, match="no multipole form"):
@@ -274,6 +287,34 @@ def test_multipole_plan_refuses_what_it_cannot_shard():
     p, _ = build_params(0, 40000, 11025, 0.5, shard_plan=sharded.plan_code("fmm"))         # 16 boxes at the gather level
     with pytest.raises(nat.NativeError, match="boxes at the gather level"):
         nat.shard_layout(p, 32, 0)
+
+
+@pytest.mark.parametrize("kind,n0,sr,n_out", [(0, 2880000, 48000, None), (2, 57600000, 16000, 39690000), (0, 172800000, 48000, None), (1, 960000, 16000, None),
+                                              (0, 1440001, 48000, None)])
+def test_multipole_plan_in_front_of_a_resampler(kind, n0, sr, n_out):
+    """Plan 3 for a capture at another rate (round 6): the resampler's own multipole form on a tree over the INPUT samples, the Hilbert transform's
+    on a tree over the resampled ones; the ranks are dealt boxes of a level common to both, so a rank's input range and its range at 11 025 Hz
+    are the same arc of the circle.  64 input frames of halo round the circle; two more exchanges (the resampler's weights and the parts of its
+    constant; 320 resampled samples per seam), kilobytes both."""
+    p, meta = build_params(kind, n0, sr, 0.5, shard_plan=sharded.plan_code("fmm"), **({"n_out": n_out} if n_out else {}))
+    n = meta["n"]
+    for world in (1, 2, 3, 8):
+        lays = [nat.shard_layout(p, world, r) for r in range(world)]
+        assert all(lay.plan == 3 and lay.nseg == 1 and lay.in_halo == 64 for lay in lays)
+        assert lays[0].own_lo == 0 and lays[-1].own_hi == n and all(lays[i].own_hi == lays[i + 1].own_lo for i in range(world - 1))
+        assert lays[0].in_lo == 0 and lays[-1].in_hi == n0 and all(lays[i].in_hi == lays[i + 1].in_lo for i in range(world - 1))
+        for lay in lays:
+            # the same arc: the first input sample at or behind the arc's start is the rank's first, likewise its first resampled sample
+            assert abs(int(lay.in_lo) / n0 - int(lay.own_lo) / n) <= 1.0 / n and abs(int(lay.in_hi) / n0 - int(lay.own_hi) / n) <= 1.0 / n
+            assert lay.in_frames == int(lay.in_hi - lay.in_lo) + 128 and lay.in_index()[0] == int(lay.in_lo) - 64
+        nat.shard_dry_run(p, world)
+        wire = {e["name"]: e for e in nat.shard_wire_plan(p, world)}
+        assert list(wire) == ["resampler weights", "resampled halos", "fmm weights", "fmm seams", "select level 0", "select level 1", "select candidates", "stream gather"]
+        if world == 1:
+            assert all(e["bytes"] == 0 for e in wire.values())
+            continue
+        assert wire["resampler weights"]["max_rank_bytes"] <= 320 * 1024 and wire["resampled halos"]["max_rank_bytes"] == 2 * 320 * 8
+        assert wire["stream gather"]["bytes"] == n - lays[0].own_samples + 8 * (world - 1)
 
 
 def test_captures_without_a_distributed_form_get_the_single_plan():
@@ -537,6 +578,53 @@ def test_multipole_plan_gives_the_one_gpu_decodes_bytes_for_every_world_size(cas
         assert r["sync"]["start_frame"] == ref["start_frame"] and r["sync"]["peaks"] == [int(v) for v in ref["peaks"]]
         assert np.array_equal(r["image"], ref["image"])
         assert len(set(r["lows"])) == 1 and len(set(r["highs"])) == 1 and r["low"] == info.low and r["high"] == info.high
+        plan = nat.shard_wire_plan(p, world)
+        counted = {}
+        for ws in r["wire"]:
+            for e in ws:
+                counted[e["name"]] = counted.get(e["name"], 0) + int(e["sent"])
+        for e in plan:
+            assert counted.get(e["name"], 0) == e["bytes"], (world, e["name"], counted.get(e["name"]), e["bytes"])
+
+
+RS_CASES = {
+    "mono_48000_30s": CASES["mono_48000_30s"],
+    "stereo_48000_30s": CASES["stereo_48000_30s"],
+    "float_16000_60s": lambda: (synth.synth_capture(16000.0, noise=0.03, seed=21, start_tone_s=3.0, phasing_lines=20, image_lines=80, stop_tone_s=2.0,
+                                                    black_tail_s=3.0).astype(np.float64) * 0.41, 16000, 120),
+    "mono_44100_odd_count": lambda: (synth.synth_capture(44100.0, noise=0.05, seed=22, **KW30)[:-7], 44100, 120),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(RS_CASES))
+def test_multipole_plan_in_front_of_a_resampler_gives_the_same_bytes_for_every_world_size(case):
+    """Plan 3 for captures at another rate: resampler and Hilbert transform both chunk-local (csrc/wfx_shard.hip run_phase_rs + run_phase_fmm).
+    Every world size gives the same bytes -- resampled + filtered audio, envelope, stream, image; against the oracle (whose resampler is scipy's
+    transform over the capture: the same sums in another order, 1e-13 apart) the stream within the parity bar with the start frame equal; what
+    the communicator counted is what the plan says."""
+    x, sr, lpm = RS_CASES[case]()
+    ref = _oracle(x, sr, lpm)
+    kind = sharded.capture_kind(x)
+    p, meta = build_params(kind, x.shape[0], sr, 1 / (lpm / 60), shard_plan=sharded.plan_code("fmm"))
+    first = None
+    for world in (1, 2, 3, 8):
+        r = sharded.decode_emulated(x, sr, world, lpm, plan="fmm")
+        assert r["plan"] == 3 and r["n"] == meta["n"]
+        assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
+        assert r["sync"]["start_frame"] == ref["start_frame"]
+        if first is None:
+            first = r
+            d = np.abs(r["digitalized"].astype(np.int16) - ref["digitalized"].astype(np.int16))
+            assert d.max() <= 1 and np.count_nonzero(d) <= 2, (int(d.max()), int(np.count_nonzero(d)))
+            assert np.abs(r["image"].astype(np.int16) - ref["image"].astype(np.int16)).max() <= 1
+            scale = np.max(np.abs(ref["audio"])) if "audio" in ref else None
+            if scale:
+                assert np.max(np.abs(r["audio"] - ref["audio"])) <= 1e-11 * scale
+        else:
+            for k in ("digitalized", "envelope", "audio", "image"):
+                assert np.array_equal(r[k], first[k]), f"{case} world {world}: {k} differs from world 1"
+            assert r["low"] == first["low"] and r["high"] == first["high"]
         plan = nat.shard_wire_plan(p, world)
         counted = {}
         for ws in r["wire"]:
