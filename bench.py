@@ -550,7 +550,7 @@ def bench_fmm(args, rk: Ranks, x) -> dict:
     same = bool(np.array_equal(dig, ref.fetch("digitalized")) and info.start_frame == rinfo.start_frame)
     del ref
     cref.close()
-    groups = {"notch_p2m_m2m": "fft_pass_fwd", "tiers_and_top": "bluestein_pointwise", "tree_levels": "fft_pass_inv", "near_l2p_env_median": "env_median"}
+    groups = {"notch_p2m_m2m": "fmm_notch_p2m_m2m", "tiers_and_top": "fmm_tiers_and_top", "tree_levels": "fmm_tree_levels", "near_l2p_env_median": "fmm_near_l2p_env_median"}
     us = {k: round(1e3 * prof[v][1] / args.steps, 1) for k, v in groups.items() if v in prof}
     t_fmm = sum(us.values()) * 1e-6
     flops = 2.0 * FMM_FMA_PER_SAMPLE * x.shape[0]

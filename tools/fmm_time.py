@@ -26,4 +26,4 @@ for _ in range(10):
     ctx.d_hilbert_fmm(px, n, po, mode)
 ctx.sync(); ctx.profile_enable(False)
 pr = {k: round(1e3 * v[1] / v[0], 1) for k, v in ctx.profile().items()}
-print(f"n {n}: {1e3 * min(ts):.3f} ms per transform (10 back to back); kernel groups (us): up {pr.get('fft_pass_fwd')} mid {pr.get('bluestein_pointwise')} tree {pr.get('fft_pass_inv')} leaf {pr.get('env_median')}  all {pr}", flush=True)
+print(f"n {n}: {1e3 * min(ts):.3f} ms per transform (10 back to back); kernel groups (us): up {pr.get('fmm_notch_p2m_m2m')} mid {pr.get('fmm_tiers_and_top')} tree {pr.get('fmm_tree_levels')} leaf {pr.get('fmm_near_l2p_env_median')}  all {pr}", flush=True)

@@ -237,7 +237,8 @@ static const char *k_names[K_COUNT] = {
     "merge_channels", "notch_filtfilt", "bluestein_pointwise", "fft_pass_fwd", "fft_pass_inv",
     "env_median",     "fir_analytic",   "median5",             "select_hist",  "select_scan",
     "quantise",       "sync_corr",      "sync_pick",           "lines_to_image", "resample_pointwise",
-    "polyphase_ingest", "polyphase_stages", "dist_copy"};
+    "polyphase_ingest", "polyphase_stages", "dist_copy",
+    "fmm_notch_p2m_m2m", "fmm_tiers_and_top", "fmm_tree_levels", "fmm_near_l2p_env_median", "resample_fmm_p2m_m2m", "resample_fmm_near_l2p"};
 
 int wfx_profile_kernel_count(void) { return K_COUNT; }
 const char *wfx_profile_kernel_name(int i) { return (i >= 0 && i < K_COUNT) ? k_names[i] : ""; }

@@ -1555,24 +1555,24 @@ static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind,
     if (!*handled) return 0;
     *handled = 0;
     const unsigned nwg = P.nwg;
-    wfx_prof_begin(ctx, K_FFT_FWD);
+    wfx_prof_begin(ctx, K_FMM_UP);
     fmm_launch_up(ctx, P, x, raw, raw_kind, nc, audio, clear, 0, nwg);
     if (!x) x = audio;
     wfx_prof_end(ctx);
-    wfx_prof_begin(ctx, K_BS_CHIRP);
+    wfx_prof_begin(ctx, K_FMM_MID);
     for (int k = 0; k < P.ntier; ++k)
         hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[k], P.tier_d[k], 0);
     hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.Lg, P.atop);
     for (int k = P.ntier - 1; k >= 0; --k)
         hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
     wfx_prof_end(ctx);
-    wfx_prof_begin(ctx, K_FFT_INV);
+    wfx_prof_begin(ctx, K_FMM_TREE);
     // (measured and not kept: the leaf workgroups in four chunks, chunk c's leaf kernel on a second queue beside chunk c + 1's tree kernel --
     // the tree kernel waits, the leaf kernel issues -- 165 us against 133 us one after the other: a chunk is a single round of workgroups
     // with its full tail, and the queues' events cost more than the overlap gives)
     hipLaunchKernelGGL(fmm_tree_leaf, dim3(nwg), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, 0);
     wfx_prof_end(ctx);
-    wfx_prof_begin(ctx, K_ENV_MEDIAN);
+    wfx_prof_begin(ctx, K_FMM_LEAF);
     if (out_mode == 2)
         hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(nwg), dim3(FTH), P.lds_leaf, ctx->stream, x, P.g, P.T, (const double *)P.Cg, out, P.smax, P.xcap, P.Eg, l0hist, 0, 1);
     else if (out_mode == 1)
@@ -1704,15 +1704,21 @@ int wfx_dev_resample_fmm(wfx_ctx *ctx, const double *x, uint64_t n0, uint64_t nu
     *handled = 0;
     const fmm_plan &P = R.P;
     const unsigned nwg = P.nwg;
-    wfx_prof_begin(ctx, K_RESAMPLE_PW);
+    wfx_prof_begin(ctx, K_RS_UP);
     hipLaunchKernelGGL(rs_up_leaf, dim3(nwg), dim3(FTH), P.lds_up2, ctx->stream, x, R.rg, P.T, P.Wg, R.w, R.cpart, 0, 0ll);
     hipLaunchKernelGGL(rs_csum, dim3(1), dim3(256), 0, ctx->stream, (const double *)R.cpart, (int)nwg, R.grp, R.gsum, R.csum);
+    wfx_prof_end(ctx);
+    wfx_prof_begin(ctx, K_FMM_MID);
     for (int k = 0; k < P.ntier; ++k)
         hipLaunchKernelGGL(fmm_up_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.tier_a[k], P.tier_d[k], 0);
     hipLaunchKernelGGL(fmm_top2, dim3(1), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, P.Lg, P.atop);
     for (int k = P.ntier - 1; k >= 0; --k)
         hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
+    wfx_prof_end(ctx);
+    wfx_prof_begin(ctx, K_FMM_TREE);
     hipLaunchKernelGGL(fmm_tree_leaf, dim3(nwg), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, 0);
+    wfx_prof_end(ctx);
+    wfx_prof_begin(ctx, K_RS_LEAF);
     if (P.L < RS_POLY_BELOW)
         hipLaunchKernelGGL(rs_leaf<true>, dim3(nwg), dim3(FTH), R.lds_leaf, ctx->stream, (const double *)R.w, x, R.rg, (const double *)P.Cg, (const double *)R.csum, y, R.swin,
                            0, 1, 0ll, 0ll);
@@ -1786,9 +1792,13 @@ int wfx_fmm_shard_up(wfx_ctx *ctx, const void *raw, long long raw_index0, int ra
     wfx_fmm_shard_geometry(n, &geo);
     const int sh = geo.ltop - geo.lg;
     const void *raw0 = raw_kind == WFX_IN_I16_MONO ? (const void *)((const short *)raw - raw_index0) : (const void *)((const double *)raw - raw_index0);
+    wfx_prof_begin(ctx, K_FMM_UP);
     fmm_launch_up(ctx, P, nullptr, raw0, raw_kind, &c, audio - audio_index0, clear, (unsigned)(gb_lo << sh), (unsigned)(gb_hi << sh));
+    wfx_prof_end(ctx);
+    wfx_prof_begin(ctx, K_FMM_MID);
     if (sh > 0 && gb_hi > gb_lo)        // the part of the deepest tier below the gather level, own boxes
         hipLaunchKernelGGL(fmm_up_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, geo.lg, sh, (int)gb_lo);
+    wfx_prof_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
     return 0;
@@ -1821,14 +1831,20 @@ int wfx_fmm_shard_down(wfx_ctx *ctx, const double *audio, long long audio_index0
     wfx_fmm_shard_geo geo;
     wfx_fmm_shard_geometry(n, &geo);
     const int sh = geo.ltop - geo.lg;
+    wfx_prof_begin(ctx, K_FMM_MID);
     fmm_shard_middle(ctx, P, geo);
     const unsigned wg_lo = (unsigned)(gb_lo << sh), wg_hi = (unsigned)(gb_hi << sh);
+    if (wg_hi > wg_lo && sh > 0)         // own boxes: from the gather level to the leaf workgroups' roots
+        hipLaunchKernelGGL(fmm_down_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, geo.lg, sh, (int)gb_lo);
+    wfx_prof_end(ctx);
     if (wg_hi > wg_lo) {
-        if (sh > 0)         // own boxes: from the gather level to the leaf workgroups' roots
-            hipLaunchKernelGGL(fmm_down_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, geo.lg, sh, (int)gb_lo);
+        wfx_prof_begin(ctx, K_FMM_TREE);
         hipLaunchKernelGGL(fmm_tree_leaf, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, (int)wg_lo);
+        wfx_prof_end(ctx);
+        wfx_prof_begin(ctx, K_FMM_LEAF);
         hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_leaf, ctx->stream, audio - audio_index0, P.g, P.T, (const double *)P.Cg,
                            env - env_index0, P.smax, P.xcap, P.Eg, l0hist, (int)wg_lo, 0);
+        wfx_prof_end(ctx);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
@@ -1848,9 +1864,11 @@ int wfx_fmm_shard_seams(wfx_ctx *ctx, uint64_t n, long long gb_lo, long long gb_
     const int wg_lo = (int)(gb_lo << sh), wg_hi = (int)(gb_hi << sh);
     if (wg_hi <= wg_lo) return 0;
     const int b_lo = wg_lo > 0 ? wg_lo - 1 : 0, b_hi = wg_hi < (int)P.nwg ? wg_hi : (int)P.nwg - 1;       // seams b: between workgroups b and b + 1
+    wfx_prof_begin(ctx, K_FMM_LEAF);
     if (b_hi > b_lo)
         hipLaunchKernelGGL(fmm_edge_median, dim3((unsigned)(b_hi - b_lo + 255) / 256), dim3(256), 0, ctx->stream, P.g, (const double *)P.Eg, env - env_index0, l0hist,
                            b_lo, b_hi, wg_lo, wg_hi);
+    wfx_prof_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch fmm kernels");
     return 0;
@@ -1889,6 +1907,7 @@ int wfx_rs_shard_up(wfx_ctx *ctx, const double *x, long long x_index0, uint64_t 
     const int sh = geo.ltop - geo.lg;
     const unsigned wg_lo = (unsigned)(gb_lo << sh), wg_hi = (unsigned)(gb_hi << sh);
     *gsum = R.gsum;
+    wfx_prof_begin(ctx, K_RS_UP);
     if (wg_hi > wg_lo) {
         const long long src_lo = wfx_fmm_leaf_first_host(n0, P.L, (long long)wg_lo * FLV), src_hi = wfx_fmm_leaf_first_host(n0, P.L, (long long)wg_hi * FLV);
         hipLaunchKernelGGL(rs_up_leaf, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_up2, ctx->stream, x, R.rg, P.T, P.Wg, R.w, R.cpart, (int)wg_lo, x_index0);
@@ -1896,6 +1915,7 @@ int wfx_rs_shard_up(wfx_ctx *ctx, const double *x, long long x_index0, uint64_t 
         hipLaunchKernelGGL(rs_csum_own, dim3((unsigned)(gb_hi - gb_lo + 255) / 256), dim3(256), 0, ctx->stream, (const double *)R.cpart, R.grp, R.gsum, (int)gb_lo, (int)gb_hi);
         if (sh > 0) hipLaunchKernelGGL(fmm_up_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, P.Wg, geo.lg, sh, (int)gb_lo);
     }
+    wfx_prof_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch resampler kernels");
     return 0;
@@ -1912,19 +1932,25 @@ int wfx_rs_shard_down(wfx_ctx *ctx, const double *x, long long x_index0, uint64_
     wfx_fmm_shard_geo geo;
     wfx_fmm_shard_geometry(n0 + (n0 & 1), &geo);
     const int sh = geo.ltop - geo.lg;
+    wfx_prof_begin(ctx, K_FMM_MID);
     hipLaunchKernelGGL(rs_csum2, dim3(1), dim3(256), 0, ctx->stream, (const double *)R.gsum, (int)(P.nwg / (unsigned)R.grp), R.csum);
     fmm_shard_middle(ctx, P, geo);
     const unsigned wg_lo = (unsigned)(gb_lo << sh), wg_hi = (unsigned)(gb_hi << sh);
+    if (wg_hi > wg_lo && sh > 0)
+        hipLaunchKernelGGL(fmm_down_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, geo.lg, sh, (int)gb_lo);
+    wfx_prof_end(ctx);
     if (wg_hi > wg_lo) {
-        if (sh > 0)
-            hipLaunchKernelGGL(fmm_down_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, geo.lg, sh, (int)gb_lo);
+        wfx_prof_begin(ctx, K_FMM_TREE);
         hipLaunchKernelGGL(fmm_tree_leaf, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, (int)wg_lo);
+        wfx_prof_end(ctx);
+        wfx_prof_begin(ctx, K_RS_LEAF);
         if (P.L < RS_POLY_BELOW)
             hipLaunchKernelGGL(rs_leaf<true>, dim3(wg_hi - wg_lo), dim3(FTH), R.lds_leaf, ctx->stream, (const double *)R.w, x, R.rg, (const double *)P.Cg,
                                (const double *)R.csum, y, R.swin, (int)wg_lo, 1, x_index0, y_index0);
         else
             hipLaunchKernelGGL(rs_leaf<false>, dim3(wg_hi - wg_lo), dim3(FTH), R.lds_leaf, ctx->stream, (const double *)R.w, x, R.rg, (const double *)P.Cg,
                                (const double *)R.csum, y, R.swin, (int)wg_lo, 1, x_index0, y_index0);
+        wfx_prof_end(ctx);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wfx_fail_hip(ctx, e, "launch resampler kernels");

@@ -38,6 +38,12 @@ enum wfx_kernel_id {
     K_POLYPHASE_IN,    // time-domain front end, stage that reads the raw int16 capture (merge fused)
     K_POLYPHASE,       // time-domain front end, later stages (float64 in)
     K_DIST_COPY,       // sharded decode: pack / unpack copies around an exchange (wfx_dist.hip)
+    K_FMM_UP,          // multipole Hilbert transform: notch + P2M + M2M of the leaf workgroups (wfx_fmm.hip)
+    K_FMM_MID,         // ... the tiers above them and the top of the tree
+    K_FMM_TREE,        // ... the leaf workgroups' six levels downwards
+    K_FMM_LEAF,        // ... near field + L2P + envelope + median
+    K_RS_UP,           // multipole resampler: weights + P2M + M2M
+    K_RS_LEAF,         // ... near field + L2P
     K_COUNT
 };
 
