@@ -54,4 +54,18 @@ tools/micro/build/mfma_f64_rate > "$OUT/mfma_f64_rate.txt" 2>&1
 # plan 3 of the sharded decode: every world size against the one-GPU decode, bytes on the wire
 python tools/shard_fmm_check.py 650 1 2 3 8 > "$OUT/shard_fmm_check.txt" 2>&1; tail -1 "$OUT/shard_fmm_check.txt"
 python bench.py --shard --plan fmm --no-c4 --no-cpu > "$OUT/bench_shard_fmm_rccl1.json" 2>> "$OUT/bench.err"
+# the resampler's multipole form: accuracy + time on the device, plan 3 in front of it in emulated worlds (48 kHz and 16 kHz captures),
+# the 60-minute IQ stream through the sharded interface at ONE rank on plan 3 and on the transposing plan (= each plan's total work), and
+# plan 3's kernels under rocprofv3
+python tools/rs_fmm_check.py --big > "$OUT/rs_fmm_check.txt" 2>&1; tail -2 "$OUT/rs_fmm_check.txt"
+python tools/shard_rs_check.py 48000 200 1 2 3 8 > "$OUT/shard_rs_check_48k.txt" 2>&1; tail -1 "$OUT/shard_rs_check_48k.txt"
+python tools/shard_rs_check.py 16000 300 1 2 5 8 > "$OUT/shard_rs_check_16k.txt" 2>&1; tail -1 "$OUT/shard_rs_check_16k.txt"
+for pl in fmm dist; do
+  python bench.py --workload iq --iq-form sharded --plan $pl --steps 10 --warmup 3 --no-cpu > "$OUT/bench_iq_world1_$pl.json" 2> "$OUT/bench_iq_world1_$pl.err"
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_iq_fmm" -o run -- python3 bench.py --workload iq --iq-form sharded --plan fmm --steps 5 --warmup 2 --no-cpu > "$OUT/prof_bench_iq_fmm.json" 2> "$OUT/prof_bench_iq_fmm.err"
+find "$OUT/trace_iq_fmm" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_iq_plan3.csv" \;
+rm -rf "$OUT/trace_iq_fmm"
+# two ranks on this one GPU over the shm transport: the N > 1 bench path end to end (protocol, not speed: the ranks share the GPU)
+WFX_BENCH_OVERSUBSCRIBE=1 WFX_BENCH_COMM=shm python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu > "$OUT/bench_n2_shm_one_gpu.json" 2> "$OUT/bench_n2_shm_one_gpu.err"
 ls "$OUT"

@@ -595,7 +595,11 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
     constexpr int NA = (T * RB + NT - 1) / NT, NB = (T * RA + NT - 1) / NT;
     constexpr bool inv = INVERSE != 0;
     constexpr double sg = inv ? 1.0 : -1.0;
-    __shared__ cplx tile[T * R];
+    // column-major read-out of a first pass (a column's R outputs contiguous): lanes run over columns, R points apart -- for R a multiple of
+    // 16 that is ONE bank pair for every lane (mr2_pass<8,8>: 0.21 of its LDS cycles were conflicts, profiles/r05_v3/sq_counters_iq.txt):
+    // such radices keep one point of padding per column
+    constexpr int CS = R + ((R % 16 == 0) ? 1 : 0);
+    __shared__ cplx tile[T * CS];
     __shared__ cplx wr[R];
     const int t = (int)threadIdx.x;
     const int ncol = (int)d.ncol, P = (int)d.P;
@@ -727,7 +731,7 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                 if (item < T * RA) {
                     const int c = item & (T - 1), qa = item >> LOG2T;
 #pragma unroll
-                    for (int qb = 0; qb < RB; ++qb) tile[c * R + qa + RA * qb] = res[ib][qb];
+                    for (int qb = 0; qb < RB; ++qb) tile[c * CS + qa + RA * qb] = res[ib][qb];
                 }
             }
             mr_lds_barrier();
@@ -737,11 +741,11 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                 for (int e = t; e < R * tn; e += NT) {
                     const int c = e / R, q = e - c * R;
                     const mr_qmap m = d.qmap[q];
-                    ((cplx *)m.base)[(long long)(j0 + c) * m.stride] = tile[e];
+                    ((cplx *)m.base)[(long long)(j0 + c) * m.stride] = tile[c * CS + q];
                 }
             } else {
                 const long long o0 = (long long)j0 * R;
-                for (int e = t; e < R * tn; e += NT) out[o0 + e] = tile[e];
+                for (int e = t; e < R * tn; e += NT) out[o0 + e] = tile[CS == R ? e : e + e / R];
             }
         } else if (OUT_MODE == 2) {
             // LAST forward pass fused with the FIRST inverse pass.  With the inverse's radices taken in the reverse order, column j
@@ -800,12 +804,12 @@ mr2_pass(const cplx *__restrict__ in, cplx *__restrict__ out, mr_pass_desc d, co
                 if (item < T * RB) {
                     const int c = item & (T - 1), nb = item >> LOG2T;
 #pragma unroll
-                    for (int na = 0; na < RA; ++na) tile[c * R + nb + RB * na] = xo[ia][na];
+                    for (int na = 0; na < RA; ++na) tile[c * CS + nb + RB * na] = xo[ia][na];
                 }
             }
             mr_lds_barrier();
             const long long o0 = (long long)j0 * R;
-            for (int e = t; e < R * tn; e += NT) out[o0 + e] = tile[e];
+            for (int e = t; e < R * tn; e += NT) out[o0 + e] = tile[CS == R ? e : e + e / R];
         } else {
             // few, long transforms (T * RA <= 128 items): two threads share one, each producing half of the output pairs
             constexpr int SPLIT = (T * RA <= NT / 2 && RB >= 9 && RB != 25 && !mr2_rows(RB)) ? 2 : 1;
