@@ -60,7 +60,9 @@ typedef enum {
                                  (WFX_HILBERT_FFT picks the unpadded mixed-radix form when N/2 is 13-smooth) */
     WFX_HILBERT_FMM = 4       /* no transform over the capture: near field summed directly + fast multipole far field on 16 Chebyshev
                                  nodes per box (csrc/wfx_fmm.hip; 1e-14 relative against the transform forms); even N >= 32768,
-                                 other lengths run WFX_HILBERT_FFT */
+                                 other lengths run WFX_HILBERT_FFT.  A capture that is resampled on the way takes the resampler's
+                                 multipole form as well where its lengths have one (down-sampling to an even count): the arithmetic of
+                                 the sharded plan 3, whose bytes a decode in this mode reproduces on one GPU */
 } wfx_hilbert_mode;
 
 #define WFX_MAX_PEAKS 100   /* wefax.py:251 */

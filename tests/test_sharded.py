@@ -603,16 +603,26 @@ def test_multipole_plan_in_front_of_a_resampler_gives_the_same_bytes_for_every_w
     Every world size gives the same bytes -- resampled + filtered audio, envelope, stream, image; against the oracle (whose resampler is scipy's
     transform over the capture: the same sums in another order, 1e-13 apart) the stream within the parity bar with the start frame equal; what
     the communicator counted is what the plan says."""
+    from wefax_amd.wefax import DecodeJob
     x, sr, lpm = RS_CASES[case]()
     ref = _oracle(x, sr, lpm)
     kind = sharded.capture_kind(x)
     p, meta = build_params(kind, x.shape[0], sr, 1 / (lpm / 60), shard_plan=sharded.plan_code("fmm"))
+    # the one-GPU decode on the multipole route (hilbert_mode 4 takes the resampler's multipole form too): the bytes every world size must give
+    c = nat.Context(0)
+    job = DecodeJob(c, x, sr, lpm, hilbert_mode=nat.WFX_HILBERT_FMM)
+    job.run()
+    info = job.result()
+    one = {"digitalized": job.fetch("digitalized"), "envelope": job.fetch("envelope"), "audio": job.fetch("audio"), "image": job.fetch("image")}
+    assert info.start_frame == ref["start_frame"]
     first = None
     for world in (1, 2, 3, 8):
         r = sharded.decode_emulated(x, sr, world, lpm, plan="fmm")
         assert r["plan"] == 3 and r["n"] == meta["n"]
         assert np.array_equal(r["digitalized"], r["digitalized_blocks"])
         assert r["sync"]["start_frame"] == ref["start_frame"]
+        for k in ("digitalized", "envelope", "audio", "image"):
+            assert np.array_equal(r[k], one[k]), f"{case} world {world}: {k} differs from the one-GPU decode on the multipole route"
         if first is None:
             first = r
             d = np.abs(r["digitalized"].astype(np.int16) - ref["digitalized"].astype(np.int16))

@@ -459,7 +459,26 @@ int wfx_decode_run(wfx_ctx *ctx)
         cur_kind = WFX_IN_F64_MONO;
     }
     ctx->force_pow2 = p.hilbert_mode == WFX_HILBERT_FFT_POW2;       // (also selects the padded resampler)
-    if (p.resample) {
+    bool resampled = false;
+    wfx_fmm_shard_geo rs_geo;
+    if (p.resample && p.hilbert_mode == WFX_HILBERT_FMM && wfx_rs_shard_geometry(n0, n, &rs_geo) == 0) {
+        // the multipole route takes the resampler's multipole form too (wfx_fmm.hip rs_*): slower than the transform on ONE GPU, but the very
+        // arithmetic of the sharded plan 3 -- a decode in this mode gives that plan's bytes
+        if (cur_kind == WFX_IN_I16_MONO) {
+            WFX_TRY(wfx_reserve(ctx, ctx->b_x, n0 * 8));
+            WFX_TRY(wfx_dev_i16_to_f64(ctx, (const int16_t *)cur, n0, (double *)ctx->b_x.p));
+            cur = ctx->b_x.p;
+            cur_kind = WFX_IN_F64_MONO;
+        }
+        WFX_TRY(wfx_reserve(ctx, ctx->b_tmp, n * 8));
+        int handled = 0;
+        WFX_TRY(wfx_dev_resample_fmm(ctx, (const double *)cur, n0, n, (double *)ctx->b_tmp.p, &handled));
+        if (handled) {
+            cur = ctx->b_tmp.p;
+            resampled = true;
+        }
+    }
+    if (p.resample && !resampled) {
         // an int16 capture whose lengths the mixed-radix resampler takes is read in place by its first pass
         // (so is one of any other length by the chirp-z form's prologue)
         const bool in_place16 = cur_kind == WFX_IN_I16_MONO && !ctx->force_pow2 && !getenv("WFX_NO_I16_RESAMPLE") &&
