@@ -74,6 +74,24 @@ def test_product_never_imports_the_oracle():
     assert "oracle" not in open(os.path.join(REPO, "wefax.py")).read()
 
 
+def test_bench_reaches_the_oracle_from_bench_py_alone():
+    """bench.py is split into bench.py (command line, headline, the CPU baseline) and benchlib/ (round 6).  The oracle is the checker and
+    the CPU baseline of bench.py's legs only: no module of benchlib imports it -- they ask bench.py's hooks -- and the names tests and tools
+    use (`bench._LineGuard`, `bench.iq_recipe`, ...) are still bench's."""
+    import re
+    import subprocess
+    import sys
+    lib = os.path.join(REPO, "benchlib")
+    for f in sorted(os.listdir(lib)):
+        if f.endswith(".py"):
+            text = open(os.path.join(lib, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), f
+    r = subprocess.run([sys.executable, "-c", "import bench, benchlib; assert benchlib.ORACLE is bench._oracle and benchlib.CPU_BASELINE is bench.cpu_baseline; "
+                        "print(all(hasattr(bench, n) for n in ('_LineGuard', 'iq_recipe', 'Ranks', 'GpuState', 'roofline_of', 'bench_c2', 'bench_iq', 'main')))"],
+                       capture_output=True, text=True, cwd=REPO, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "True", r.stderr
+
+
 def test_constructor_contract():
     from wefax_amd import Demodulator
     with pytest.raises(Exception) as e:
