@@ -1042,6 +1042,7 @@ struct rs_geom {
     double kappa;                           // pi / (n0 num): the angle of one unit of m = k n0 - n num
     double inv_n0, ratio;                   // 1 / n0, num / n0
     unsigned pk, pn;                        // num / gcd, n0 / gcd: target j pk lies on source j pn
+    int cmin, cmax;                         // sources in three consecutive leaves: at least 3 floor(n0 / 2^L), at most 3 ceil
 };
 
 // sin and cos of pi t for |t| <= 1/2 by their Taylor series in x = pi t (|x| <= 1.571: x^23 / 23! = 1.3e-18, x^24 / 24! = 8e-20), the sine as
@@ -1289,27 +1290,27 @@ __global__ void __launch_bounds__(FTH, 4) rs_leaf(const double *__restrict__ w, 
     }
     fmm_lds_barrier();
     if (!POLY) {
-        // the moments of every leaf's window (a fixed order of additions: lanes take every 64th source, then halve)
-#pragma unroll 1
-        for (int li = 0; li < FLV / 8; ++li) {
-            const int lk = wave * (FLV / 8) + li;
+        // the moments of every leaf's window, all 64 leaves at once: eight lanes a leaf, each over every eighth source, then three halvings
+        // (a fixed order of additions)
+        {
+            const int lk = t >> 3, part = t & 7;
             const long long k = leaf0 + lk;
             const long long sa = k == 0 ? fmm_leaf_first(gs, nleaf - 1) - gs.n : fmm_leaf_first(gs, k - 1);
             const long long sb = k + 2 > nleaf ? fmm_leaf_first(gs, k + 2 - nleaf) + gs.n : fmm_leaf_first(gs, k + 2);
             const int cnt = (int)(sb - sa);
             const double *wp = ww + (int)(sa - ws0);
             double s0 = 0.0, s1 = 0.0;
-            for (int i = lane; i < cnt; i += 64) {
+            for (int i = part; i < cnt; i += 8) {
                 const double wv = wp[i];
                 s0 += wv;
                 s1 = fma((double)i, wv, s1);
             }
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
+            for (int o = 4; o >= 1; o >>= 1) {
                 s0 += __shfl_xor(s0, o, 64);
                 s1 += __shfl_xor(s1, o, 64);
             }
-            if (lane == 0) {
+            if (part == 0) {
                 sm[2 * lk] = s0;
                 sm[2 * lk + 1] = s1;
             }
@@ -1334,46 +1335,45 @@ __global__ void __launch_bounds__(FTH, 4) rs_leaf(const double *__restrict__ w, 
         const long long sa = k == 0 ? fmm_leaf_first(gs, nleaf - 1) - gs.n : fmm_leaf_first(gs, k - 1);
         const long long sb = k + 2 > nleaf ? fmm_leaf_first(gs, k + 2 - nleaf) + gs.n : fmm_leaf_first(gs, k + 2);
         const int cnt = (int)(sb - sa);
-        int cmin = cnt, cmax = cnt;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            cmin = min(cmin, __shfl_xor(cmin, o, 64));
-            cmax = max(cmax, __shfl_xor(cmax, o, 64));
-        }
+        // (a leaf holds floor or ceil(n0 / 2^L) sources: three of them between rg.cmin and rg.cmax -- bounds every lane shares, no vote)
+        const int cmin = rg.cmin, cmax = rg.cmax;
         const double *wp = ww + (int)(sa - ws0);
         const double m0 = (double)(kt * gs.n - sa * gt.n);
         double m = m0;
         double acc0 = 0.0, acc1 = 0.0;
-        const int c4 = cmin & ~3;
-        for (int i = 0; i < c4; i += 4) {
-            const double w0 = wp[i], w1 = wp[i + 1], w2 = wp[i + 2], w3 = wp[i + 3];
-            const double x0 = fma(m, rg.kappa, 1e-60);
-            const double ma = m - numd;
-            const double x1 = fma(ma, rg.kappa, 1e-60);
-            const double mb = ma - numd;
-            const double x2 = fma(mb, rg.kappa, 1e-60);
-            const double mc = mb - numd;
-            const double x3 = fma(mc, rg.kappa, 1e-60);
-            m = mc - numd;
-            const double p01 = x0 * x1, p23 = x2 * x3;
-            const double pp = p01 * p23;
+        // eight pairs a trip, ONE reciprocal: sum_j w_j / x_j = N / (x_0 .. x_7) with the numerator built pairwise --
+        // (w0 x1 + w1 x0) x2 x3 + (w2 x3 + w3 x2) x0 x1 for four, two fours combined the same way: 40 operations + one v_rcp_f64 per 8 pairs
+        // (back-substituting every 1 / x_j from the product's reciprocal, four at a time: 46 + 2).  The product of eight stays between
+        // 1e-111 (a coincident pair's 1e-60 and seven neighbours >= pi / N0 apart) and 1e-15: no underflow, no overflow of its reciprocal
+        const int c4 = cmin & ~7;
+        double accp = 0.0;
+        for (int i = 0; i < c4; i += 8) {
+            double xv[8], wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                wv[j] = wp[i + j];
+                xv[j] = fma(m, rg.kappa, 1e-60);
+                m -= numd;
+            }
+            const double p01 = xv[0] * xv[1], p23 = xv[2] * xv[3], p45 = xv[4] * xv[5], p67 = xv[6] * xv[7];
+            const double pa = p01 * p23, pb = p45 * p67;
+            const double n01 = fma(wv[1], xv[0], wv[0] * xv[1]), n23 = fma(wv[3], xv[2], wv[2] * xv[3]);
+            const double n45 = fma(wv[5], xv[4], wv[4] * xv[5]), n67 = fma(wv[7], xv[6], wv[6] * xv[7]);
+            const double na = fma(n23, p01, n01 * p23), nb = fma(n67, p45, n45 * p67);
+            const double nn = fma(nb, pa, na * pb), pp = pa * pb;
             double R = __builtin_amdgcn_rcp(pp);
             const double e1 = fma(-pp, R, 1.0);
             R = fma(R, e1, R);
-            const double r01 = R * p23, r23 = R * p01;
-            double r0 = r01 * x1, r1 = r01 * x0, r2 = r23 * x3, r3 = r23 * x2;
+            acc0 = fma(nn, R, acc0);
             if (POLY) {
-                const double q0 = x0 * x0, q1 = x1 * x1, q2 = x2 * x2, q3 = x3 * x3;
-                r0 = fma(-x0, fma(q0, fma(q0, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), r0);
-                r1 = fma(-x1, fma(q1, fma(q1, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), r1);
-                r2 = fma(-x2, fma(q2, fma(q2, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), r2);
-                r3 = fma(-x3, fma(q3, fma(q3, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), r3);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double q = xv[j] * xv[j];
+                    accp = fma(wv[j], xv[j] * fma(q, fma(q, 2.0 / 945.0, 1.0 / 45.0), 1.0 / 3.0), accp);
+                }
             }
-            acc0 = fma(w0, r0, acc0);
-            acc1 = fma(w1, r1, acc1);
-            acc0 = fma(w2, r2, acc0);
-            acc1 = fma(w3, r3, acc1);
         }
+        if (POLY) acc0 -= accp;
         for (int i = c4; i < cmax; ++i) {                          // the last few, and what only some lanes' leaves hold
             const double wv = i < cnt ? wp[i] : 0.0;
             const double xx = fma(m, rg.kappa, 1e-60);
@@ -1673,7 +1673,9 @@ static int rs_setup(wfx_ctx *ctx, uint64_t n0, uint64_t num, rs_plan &R, int *ha
         R.rg.pn = (unsigned)(n0 / ga);
     }
     const int smax = (int)((n0 + ((1ull << L) - 1)) >> L);
-    R.swin = (FLV + 2) * smax + 4;
+    R.rg.cmin = 3 * (int)(n0 >> L);
+    R.rg.cmax = 3 * smax;
+    R.swin = (FLV + 2) * smax + 8;
     R.lds_leaf = (size_t)(FLV * FS + FLV * 2 + R.swin) * 8;
     wfx_fmm_shard_geo geo;
     wfx_fmm_shard_geometry(nkey, &geo);
@@ -1687,8 +1689,8 @@ static int rs_setup(wfx_ctx *ctx, uint64_t n0, uint64_t num, rs_plan &R, int *ha
     static bool attr_done = false;
     if (!attr_done) {
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)rs_up_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.P.lds_up2));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)rs_leaf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((FLV * FS + FLV * 2 + (FLV + 2) * 64 + 4) * 8)));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)rs_leaf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((FLV * FS + FLV * 2 + (FLV + 2) * 64 + 4) * 8)));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)rs_leaf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((FLV * FS + FLV * 2 + (FLV + 2) * 64 + 8) * 8)));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)rs_leaf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((FLV * FS + FLV * 2 + (FLV + 2) * 64 + 8) * 8)));
         attr_done = true;
     }
     *handled = 1;
