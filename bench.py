@@ -196,8 +196,9 @@ def main():
                 cfgs["c5"] = {"Msamples_s": line["c5"]["value"], "seconds_for_64": line["c5"]["seconds_for_64"], "checked_equal": line["c5"]["checked_equal"]}
             if isinstance(line.get("fmm"), dict) and "error" not in line["fmm"]:
                 f = line["fmm"]
-                cfgs["c2_fmm_route"] = {"ms_per_step": f["ms_per_step"], "notch_hilbert_envelope_median_us": f["notch_hilbert_envelope_median_us"],
-                                        "f64_frac": f["roofline"]["frac"], "same_stream": f["stream_and_start_frame_equal_to_transform_route"]}
+                cfgs["c2_routes"] = {"default": line["config"].get("hilbert"), "multipole_ms": f["ms_per_step"], "transform_ms": f.get("transform_route_ms_per_step"),
+                                     "notch_hilbert_envelope_median_us": f["notch_hilbert_envelope_median_us"],
+                                     "f64_frac_of_the_four_kernels": f["roofline"]["frac"], "same_stream": f["stream_and_start_frame_equal_to_transform_route"]}
             e2e = {}
             if isinstance(line.get("e2e"), dict):
                 e2e["c2_ms"] = line["e2e"].get("ms")

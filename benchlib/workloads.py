@@ -27,6 +27,32 @@ F64_PEAK_TFLOPS = 78.6          # MI355X float64, vector = matrix (tools/micro/m
 FMM_FMA_PER_SAMPLE = 307        # near field 82, P2M 32, L2P 32, M2L 56, M2M + L2L 38, moments <-> nodes <-> coefficients 18, notch 49
 
 
+# float64 multiply-adds per sample of the multipole route's kernel groups: notch 49 + P2M 32 + M2M 19 + moments -> nodes 9 |
+# the levels above the leaf workgroups (1 / 64 of a level each) | M2L 56 + L2L 19 + nodes -> coefficients 9 + near field 82 + L2P 32
+FMM_GROUP_FMA = {"fmm_notch_p2m_m2m": 109, "fmm_tiers_and_top": 2, "fmm_tree_levels": 84, "fmm_near_l2p_env_median": 114}
+
+
+def fmm_roofline(hbm_view: dict, prof: dict, steps: int, n: int) -> dict:
+    """The headline's roofline when the decode runs the multipole route: its dominant kernel (tree levels + near field + L2P + envelope + median
+    in one launch) is bound by the float64 unit -- the matrix and the vector pipe share ONE (tools/micro/mfma_f64_rate.hip: 76-77 TFLOP/s with
+    either or any mix) -- so achieved = that kernel's multiply-adds x 2 / its average launch time against 78.6 TFLOP/s.  The HBM view of the
+    same kernel (algorithmic bytes of the step / its launch time) stays beside it."""
+    fam = {k: v for k, v in prof.items() if k in FMM_GROUP_FMA}
+    if not fam:
+        return hbm_view
+    dom = max(fam.items(), key=lambda kv: kv[1][1])
+    fma = FMM_GROUP_FMA[dom[0]] + (FMM_GROUP_FMA["fmm_tree_levels"] if dom[0] == "fmm_near_l2p_env_median" and "fmm_tree_levels" not in prof else 0)
+    avg_s = dom[1][1] / dom[1][0] / 1e3
+    flops = 2.0 * fma * n
+    return {"bound": "mfma", "kernel": dom[0], "achieved": round(flops / avg_s / 1e12, 2), "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / avg_s / 1e12 / F64_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": int(flops), "fma_per_sample": fma,
+            "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": round(dom[1][0] / steps, 2),
+            "traffic": hbm_view.get("traffic") if hbm_view.get("kernel") == dom[0] else None, "traffic_source": hbm_view.get("traffic_source"),
+            "traffic_ratio_whole_path": hbm_view.get("traffic_ratio_whole_path"), "whole_path_frac": hbm_view.get("whole_path_frac"),
+            "hbm_view": {k: hbm_view.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")},
+            "note": "float64 multiply-adds of the dominant launch against the float64 peak (matrix = vector pipe); hbm_view: the step's algorithmic bytes over the same launch"}
+
+
 def bench_fmm(args, rk: Ranks, x) -> dict:
     """The same capture with hilbert_mode = WFX_HILBERT_FMM: notch inside the P2M kernel, near field + tree levels on the f64 matrix cores,
     envelope + median + histogram inside the leaf kernel.  Compute-bound: its roof is the float64 rate, reported beside the HBM fraction."""
@@ -40,13 +66,21 @@ def bench_fmm(args, rk: Ranks, x) -> dict:
     prof = profile_pass(ctx, job.run, args.steps)
     dig = job.fetch("digitalized")
     cref = nat.Context(rk.device)                      # (a context decodes the capture it was handed last: the comparison runs on another one)
-    ref = DecodeJob(cref, x, 11025, 120)
-    ref.run()
+    ref = DecodeJob(cref, x, 11025, 120, hilbert_mode=nat.WFX_HILBERT_FFT)
+    for _ in range(args.warmup + 1):
+        ref.run()
+    cref.sync()
+    t_ref = time.perf_counter()
+    for _ in range(args.steps):
+        ref.run()
+    cref.sync()
+    ms_ref = 1e3 * (time.perf_counter() - t_ref) / args.steps
     rinfo = ref.result()
     same = bool(np.array_equal(dig, ref.fetch("digitalized")) and info.start_frame == rinfo.start_frame)
     del ref
     cref.close()
     groups = {"notch_p2m_m2m": "fmm_notch_p2m_m2m", "tiers_and_top": "fmm_tiers_and_top", "tree_levels": "fmm_tree_levels", "near_l2p_env_median": "fmm_near_l2p_env_median"}
+    # (since the tree levels run inside the leaf kernel, "tree_levels" is absent and "near_l2p_env_median" is tree + near field + L2P + envelope + median)
     us = {k: round(1e3 * prof[v][1] / args.steps, 1) for k, v in groups.items() if v in prof}
     t_fmm = sum(us.values()) * 1e-6
     flops = 2.0 * FMM_FMA_PER_SAMPLE * x.shape[0]
@@ -56,13 +90,15 @@ def bench_fmm(args, rk: Ranks, x) -> dict:
     if os.path.exists(pmc):
         try:
             tj = json.load(open(pmc))
-            traffic = {"bytes_per_decode": int(sum(v["hbm_bytes_per_launch"] * (v["launches_seen"][0] / max(1, tj["fmm_tree_levels"]["launches_seen"][0]))
+            once = tj.get("fmm_notch_p2m_m2m", tj.get("fmm_tree_levels", {})).get("launches_seen", [1])[0]          # a kernel that runs once per decode
+            traffic = {"bytes_per_decode": int(sum(v["hbm_bytes_per_launch"] * (v["launches_seen"][0] / max(1, once))
                                                    for k, v in tj.items() if k.startswith("fmm_") and isinstance(v, dict))),
                        "source": os.path.relpath(pmc, REPO) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; " + str(tj.get("_collected_at", "")) + ")"}
         except Exception:      # noqa: BLE001
             traffic = None
     return {"what": "BASELINE configs[1] with a6 + a7 by the fast multipole form (csrc/wfx_fmm.hip; Demodulator(hilbert_mode=4) / WEFAX_HILBERT=fmm)",
             "ms_per_step": round(ms, 4), "value": round(n / (ms / 1e3) / 1e6, 2), "unit": "Msamples/s", "stream_and_start_frame_equal_to_transform_route": same,
+            "transform_route_ms_per_step": round(ms_ref, 4),
             "notch_hilbert_envelope_median_us": round(1e6 * t_fmm, 1), "kernel_groups_us": us,
             "roofline": {"bound": "f64", "achieved": round(flops / t_fmm / 1e12, 2) if t_fmm else None, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / t_fmm / 1e12 / F64_PEAK_TFLOPS, 4) if t_fmm else None,
@@ -478,7 +514,9 @@ def bench_c2(args, rk: Ranks) -> dict:
            "scaling": "strong" if args.shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": ("synthetic 10-min 11.025 kHz WEFAX capture (BASELINE configs[1]): "
                                    f"{n0} int16 mono samples, 120 LPM, AWGN sigma {args.noise} FS" if not args.short else "SHORT debugging capture"),
-                      "captures_per_gpu": args.batch, "hilbert": "fft (exact)",
+                      "captures_per_gpu": args.batch,
+                      "hilbert": ("sharded: the plan's forms" if args.shard else
+                                  ("multipole route (exact to 1e-13; csrc/wfx_fmm.hip)" if getattr(job, "hilbert_mode", None) == nat.WFX_HILBERT_FMM else "transform route (fft, exact)")),
                       "image": [int(info.width), 4 * int(info.height)] if rk.rank == 0 else None,
                       "start_frame": int(info.start_frame) if rk.rank == 0 else None,
                       "parallelism": (f"ONE capture sharded over {rk.world} rank(s): distributed Hilbert transform, 1 stream gather" if args.shard else
@@ -489,7 +527,10 @@ def bench_c2(args, rk: Ranks) -> dict:
         out["wire"] = wire_object(rk, job.params, job.layout, job.run, ctx.sync)
     if rk.rank == 0:
         alg_bytes = (n0 * 2 + 4 * n) // (rk.world if args.shard else 1)          # N0 * B_in + 4 N (this rank's share when sharded)
-        out["roofline"] = roofline_of(prof, args.steps, alg_bytes, ms, os.path.join(REPO, "profiles", "pmc_traffic.json"))
+        on_fmm = (not args.shard) and getattr(job, "hilbert_mode", None) == nat.WFX_HILBERT_FMM
+        out["roofline"] = roofline_of(prof, args.steps, alg_bytes, ms, os.path.join(REPO, "profiles", "pmc_traffic_fmm.json" if on_fmm else "pmc_traffic.json"))
+        if on_fmm:
+            out["roofline"] = fmm_roofline(out["roofline"], prof, args.steps, n)
         out["kernels"] = kernel_table(prof, args.steps)
     if rk.rank == 0 and rk.world == 1 and not args.shard and args.batch == 1 and not args.short and not args.no_extras:
         out["cache_state"] = bench_cold(ctx, job, max(5, min(args.steps, 20)))

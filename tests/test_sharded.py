@@ -780,11 +780,22 @@ def test_sixty_minute_native_rate_capture_of_arbitrary_length_on_eight_ranks():
     for n in (39690001, 39690002):
         x = np.concatenate([x0, x0[:2]])[:n]
         ctx = nat.Context(0)
-        job = DecodeJob(ctx, x, 11025, 120)
+        # (the transposing plans' arithmetic is the transform route's: asked for by name -- a one-GPU decode of an even capture this long
+        # takes the multipole route by default, whose envelope is 8e-14 from scipy's where the PADDED transform form of a general length is
+        # 1e-10 .. 1e-9 (tools/route_accuracy.py): over 39.7 M samples that is a handful of bytes one grey level apart)
+        job = DecodeJob(ctx, x, 11025, 120, hilbert_mode=nat.WFX_HILBERT_FFT)
         job.run()
         info = job.result()
         stream, img = job.fetch("digitalized").copy(), job.fetch("image").copy()
         del job
+        if n % 2 == 0:
+            dflt = DecodeJob(ctx, x, 11025, 120)
+            assert dflt.hilbert_mode == nat.WFX_HILBERT_FMM
+            dflt.run()
+            i2 = dflt.result()
+            d = np.abs(dflt.fetch("digitalized").astype(np.int16) - stream.astype(np.int16))
+            assert d.max() <= 1 and np.count_nonzero(d) <= 64 and i2.start_frame == info.start_frame
+            del dflt
         ctx.close()
         for world in (4, 8):
             r = sharded.decode_emulated(x, 11025, world, 120, want=("image", "stream"))

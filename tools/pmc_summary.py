@@ -18,8 +18,9 @@ import sys
 from collections import defaultdict
 
 GROUPS = [
-    (r"fmm_up_leaf", "fmm_notch_p2m_m2m"), (r"fmm_up_tier|fmm_top|fmm_down_tier", "fmm_tiers_and_top"), (r"fmm_tree_leaf", "fmm_tree_levels"),
-    (r"fmm_leaf_env|fmm_edge_median", "fmm_near_l2p_env_median"),
+    (r"fmm_up_leaf", "fmm_notch_p2m_m2m"), (r"fmm_up_tier|fmm_top|fmm_down_tier", "fmm_tiers_and_top"),
+    (r"fmm_tree_leaf_env|fmm_leaf_env|fmm_edge_median", "fmm_near_l2p_env_median"), (r"fmm_tree_leaf", "fmm_tree_levels"),
+    (r"rs_up_leaf|rs_csum|rs_halo", "resample_fmm_p2m_m2m"), (r"rs_leaf", "resample_fmm_near_l2p"),
     (r"fft_pass<\d+, 1,", "fft_pass_fwd"), (r"fft_pass<\d+, -1,", "fft_pass_inv"),
     (r"mr_pass<\d+, \d+, 0>", "fft_pass_fwd"), (r"mr_pass<\d+, \d+, 1>", "fft_pass_inv"),
     (r"mr2_pass<\d+, \d+, \d+, \d+, 0(, \d+)?>", "fft_pass_fwd"), (r"mr2_pass<\d+, \d+, \d+, \d+, 1(, \d+)?>", "fft_pass_inv"),      # (RA, RB, IN_MODE, OUT_MODE, INVERSE[, NTL])

@@ -508,6 +508,177 @@ __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict_
     FSTAMP(2, 5);
 }
 
+// ---- tree + leaves in ONE kernel (round 6, late): fmm_tree_leaf followed by fmm_leaf_env in the same workgroup -- the coefficients never leave LDS --
+template <int OUT>
+__global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf_env(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg,
+                                                            const double *__restrict__ Lg, double *__restrict__ out, int smax, int xcap, double *__restrict__ edge, unsigned *__restrict__ l0hist, int wg0, int xwrap)
+{
+    // xwrap 0 (a rank of a sharded decode): x is addressed by the UNWRAPPED sample index -- the leaf before the rank's first (for rank 0: the
+    // capture's last) and the one behind its last lie in front of / behind its own samples in memory
+    const long long blk = (long long)blockIdx.x + wg0;
+    extern __shared__ __align__(16) double fl[];
+    // ---- phase 1 (fmm_tree_leaf's): six levels of L2L + M2L; the 64 leaves' coefficients end in `la` -------------------------------------------
+    double *la = fl;                                    // [64][2][FS]
+    double *lb = la + FLV * 2 * FS;                     // [32][2][FS]
+    double *un = lb + (FLV / 2) * 2 * FS;               // the weights of all six levels
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    {
+        const int ltop = g.L - FW;
+        fmm_load_walls(un, Wg, ltop, FW, t, blk);
+        double atr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) atr[ks] = T.At[(wave & 1) * FP * FP + 64 * ks + lane];
+        if (t < 2 * FP) la[(t >> 4) * FS + (t & 15)] = Lg[fmm_box(ltop, blk) * 2 * FP + t];
+        const int lv0 = ltop;
+        FMM_DOWN_CHAIN(FW, T.Ca)
+    }
+    // ---- phase 2 (fmm_leaf_env's): the coefficients stay where they are; the near-field table and the sample window take the place of the
+    // weights.  A workgroup WAITS in phase 1 and ISSUES in phase 2: the two workgroups of a CU drift apart and fill each other's gaps ----
+    double *ca = la;
+    double *gn = lb;                                    // [FNEAR]
+    double *xw = gn + FNEAR + FXP0;                     // the sample window (xcap doubles + pads)
+    unsigned *h0 = (unsigned *)ca;
+    static_assert((FLV / 2) * 2 * FS + FWALL >= FNEAR + FXP0 + FXW + FXP1, "the window fits where the weights were");
+    const long long leaf0 = blk * FLV, nleaf = 1ll << g.L;
+    const long long km = leaf0 == 0 ? nleaf - 1 : leaf0 - 1;
+    const long long w0 = fmm_leaf_first(g, km) - (leaf0 == 0 ? g.n : 0);                       // may be negative
+    const long long kl = leaf0 + FLV == nleaf ? 0 : leaf0 + FLV;                              // the leaf behind the last one
+    const long long w1 = (leaf0 + FLV == nleaf ? g.n : 0) + fmm_leaf_first(g, kl + 1);
+    const int wlen = (int)(w1 - w0);                                                            // <= FXW
+    constexpr int XPT = (FXW + FTH - 1) / FTH;
+    {
+        double xr[XPT];
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const int idx = t + q * FTH;
+            long long m = w0 + idx;
+            if (xwrap) m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
+            xr[q] = idx < wlen ? x[m] : 0.0;
+        }
+        fmm_lds_barrier();                              // every wave has read the last level's operands: `lb` and `un` are free
+        for (int i = t; i < FNEAR; i += FTH) gn[i] = T.gnear[i];
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const int idx = t + q * FTH;
+            if (idx < xcap) xw[idx] = xr[q];
+        }
+    }
+    fmm_lds_barrier();
+    FSTAMP(2, 1);
+    // ---- wave = (16 leaves G, target parity e relative to the leaf's first sample) ---------------------------------------------------------
+    const int n16 = lane & 15, gq = lane >> 4;
+    const int SMe = (smax + 1) & ~1;
+    const int NKB = ((2 * smax + SMe) / 2 + 3) / 4;
+    const int G = wave >> 1, e = wave & 1;
+    const int lk = 16 * G + n16;
+    const long long k = leaf0 + lk;
+    const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1), am = fmm_leaf_first(g, k - 1), ap2 = fmm_leaf_first(g, k + 2);
+    const int s0 = (int)(b - a), slo = -(int)(a - am), shi = (int)(ap2 - a);      // sources of the near field: slo <= sigma < shi
+    const int sigma0 = -SMe + (1 - e);
+    const double *bp = xw + ((int)(a - w0) + sigma0 + 2 * gq);                   // B: lane (k = gq, column n16) reads sample sigma0 + 2 (4 K + gq) of ITS leaf
+    int sig = sigma0 + 2 * gq;
+    const double *ap = gn + (n16 - gq + e + (SMe + 254) / 2);                     // A: lane (row n16, k = gq) reads the tap of lag 2 (16 I + row - 4 K - k + e) + SMe - 1
+    fmm_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // (operands of block K + 1 are requested before block K's products are issued; the window's pads make the last, unused request legal)
+    double bn = bp[0], a0n = ap[0], a1n = ap[16];
+    for (int K = 0; K < NKB; ++K) {
+        const bool in = (sig >= slo) & (sig < shi);
+        const double bv = in ? bn : 0.0, a0 = a0n, a1 = a1n;
+        sig += 8;
+        bn = bp[8 * (K + 1)];
+        a0n = ap[-4 * (K + 1)];
+        a1n = ap[16 - 4 * (K + 1)];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc1, 0, 0, 0);
+    }
+    FSTAMP(2, 2);
+    // far field + output: register r of block I is target tau = 2 (16 I + gq + 4 r) + e of leaf lk.  Its place in the box: u = ua + tau du
+    // (one division per lane, not per target)
+    const int ht = (int)((a + e) & 1);
+    const double ua = 2.0 * ((double)((a << g.L) - k * g.n) / (double)g.n) - 1.0;
+    double ac[FP];
+    {
+        const double *cp = ca + (lk * 2 + ht) * FS;
+#pragma unroll
+        for (int kk = 0; kk < FP; ++kk) ac[kk] = cp[kk];
+    }
+    double *xp = xw + (int)(a - w0);
+    double *op = out + a;
+    double res[8];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tau = 2 * (16 * I + gq + 4 * r) + e;
+            const bool valid = tau < s0;
+            const double u = valid ? fma((double)tau, g.du, ua) : 0.0;
+            double t0 = 1.0, t1 = u, far = fma(ac[1], u, ac[0]);
+            const double u2 = 2.0 * u;
+#pragma unroll
+            for (int kk = 2; kk < FP; ++kk) {
+                const double t2 = fma(u2, t1, -t0);
+                far = fma(ac[kk], t2, far);
+                t0 = t1;
+                t1 = t2;
+            }
+            const double near = I == 0 ? acc0[r] : acc1[r];
+            const double H = g.scale * (far + near);
+            if (OUT == 0) {
+                if (valid) op[tau] = H;
+            } else {
+                const double xv = xp[valid ? tau : 0];
+                const double ev = sqrt(fma(xv, xv, H * H));
+                if (OUT == 1) {
+                    if (valid) op[tau] = ev;
+                } else {
+                    res[4 * I + r] = ev;
+                }
+            }
+        }
+    }
+    FSTAMP(2, 3);
+    if (OUT != 2) return;
+    fmm_lds_barrier();                                    // every near field has read its samples: the envelope takes their place
+    static_assert(FLV * 2 * FS * 8 >= WFX_SEL_BINS * 4, "the histogram fits where the coefficients were");
+    for (int i = t; i < WFX_SEL_BINS; i += FTH) h0[i] = 0;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tau = 2 * (16 * I + gq + 4 * r) + e;
+            if (tau < s0) xp[tau] = res[4 * I + r];
+        }
+    fmm_lds_barrier();
+    FSTAMP(2, 4);
+    {
+        const long long wa = fmm_leaf_first(g, leaf0), wb = fmm_leaf_first(g, leaf0 + FLV);   // the workgroup's own samples [wa, wb)
+        const int own = (int)(wb - wa);
+        const double *ew = xw + (int)(wa - w0);
+        const bool first = wa == 0, last = wb == g.n;
+        for (int i0 = 0; i0 < own; i0 += FTH) {
+            const int i = i0 + t;
+            // medians that are complete here: all but the first and last two -- and those too where zeros stand beyond the capture's end
+            const bool valid = i < own && (i >= 2 || first) && (i < own - 2 || last);
+            double m = 0.0;
+            if (valid) {
+                const double e0 = i >= 2 ? ew[i - 2] : 0.0, e1 = i >= 1 ? ew[i - 1] : 0.0;
+                const double e3 = i + 1 < own ? ew[i + 1] : 0.0, e4 = i + 2 < own ? ew[i + 2] : 0.0;
+                m = wfx_median5(e0, e1, ew[i], e3, e4);
+                out[wa + i] = m;
+            }
+            if (l0hist) wfx_sel_count(h0, (unsigned)(wfx_f64_key(m) >> 53), valid, lane);
+        }
+        if (t < 8) edge[(size_t)blk * 8 + t] = t < 4 ? ew[t] : ew[own - 8 + t];
+    }
+    if (l0hist) {
+        fmm_lds_barrier();
+        for (int i = t; i < WFX_SEL_BINS; i += FTH)
+            if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
+    }
+    FSTAMP(2, 5);
+}
+
+
 // medians across the seam of workgroups b and b + 1 of fmm_leaf_env<2> (positions end - 2, end - 1, end, end + 1): one thread per seam
 __global__ void __launch_bounds__(256) fmm_edge_median(const fmm_geom g, const double *__restrict__ edge, double *__restrict__ out, unsigned *__restrict__ l0hist,
                                                        int b_lo, int b_hi, int own_lo, int own_hi)
@@ -1509,6 +1680,9 @@ static int fmm_setup(wfx_ctx *ctx, uint64_t n, fmm_plan &P, int *handled)
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf_env<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_tree));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf_env<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_tree));
+        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf_env<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_tree));
         attr_done = true;
     }
     // tiers between the leaf workgroups' roots (level L - 6) and the top (levels 2 .. atop <= 5): at most six levels each
@@ -1545,6 +1719,20 @@ static void fmm_launch_up(wfx_ctx *ctx, const fmm_plan &P, const double *x, cons
     }
 }
 
+static void fmm_launch_tree_leaf(wfx_ctx *ctx, const fmm_plan &P, const double *x, double *out, int out_mode, unsigned *l0hist, unsigned wg_lo, unsigned wg_hi, int xwrap)
+{
+    const dim3 grid(wg_hi - wg_lo), block(FTH);
+    if (out_mode == 2)
+        hipLaunchKernelGGL(fmm_tree_leaf_env<2>, grid, block, P.lds_tree, ctx->stream, x, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, out, P.smax, P.xcap, P.Eg, l0hist,
+                           (int)wg_lo, xwrap);
+    else if (out_mode == 1)
+        hipLaunchKernelGGL(fmm_tree_leaf_env<1>, grid, block, P.lds_tree, ctx->stream, x, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, out, P.smax, P.xcap, P.Eg,
+                           (unsigned *)nullptr, (int)wg_lo, xwrap);
+    else
+        hipLaunchKernelGGL(fmm_tree_leaf_env<0>, grid, block, P.lds_tree, ctx->stream, x, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, out, P.smax, P.xcap, P.Eg,
+                           (unsigned *)nullptr, (int)wg_lo, xwrap);
+}
+
 // x != nullptr: the filtered capture is given.  x == nullptr: `raw` (int16 or float64 mono) goes through the notch inside the first kernel, which
 // leaves the filtered capture in `audio` (wefax.py:63-72 + 174-175 in four leaf-level passes over the capture's bytes)
 static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind, const notch_coef *nc, double *audio, wfx_dev_scalars *clear, uint64_t n, double *out,
@@ -1566,6 +1754,7 @@ static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind,
     for (int k = P.ntier - 1; k >= 0; --k)
         hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
     wfx_prof_end(ctx);
+#ifdef WFX_FMM_SPLIT_LEAF
     wfx_prof_begin(ctx, K_FMM_TREE);
     // (measured and not kept: the leaf workgroups in four chunks, chunk c's leaf kernel on a second queue beside chunk c + 1's tree kernel --
     // the tree kernel waits, the leaf kernel issues -- 165 us against 133 us one after the other: a chunk is a single round of workgroups
@@ -1581,6 +1770,12 @@ static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind,
     else
         hipLaunchKernelGGL(fmm_leaf_env<0>, dim3(nwg), dim3(FTH), P.lds_leaf, ctx->stream, x, P.g, P.T, (const double *)P.Cg, out, P.smax, P.xcap, P.Eg,
                            (unsigned *)nullptr, 0, 1);
+#else
+    // tree + leaves in one kernel: a workgroup waits through its six tree levels and issues through its near field; the two workgroups of a
+    // CU drift apart and fill each other's gaps, and the coefficients never leave LDS
+    wfx_prof_begin(ctx, K_FMM_LEAF);
+    fmm_launch_tree_leaf(ctx, P, x, out, out_mode, l0hist, 0, nwg, 1);
+#endif
     if (out_mode == 2 && nwg > 1)
         hipLaunchKernelGGL(fmm_edge_median, dim3((nwg + 254) / 256), dim3(256), 0, ctx->stream, P.g, (const double *)P.Eg, out, l0hist, 0, (int)nwg - 1, 0, (int)nwg);
     wfx_prof_end(ctx);
@@ -1840,12 +2035,8 @@ int wfx_fmm_shard_down(wfx_ctx *ctx, const double *audio, long long audio_index0
         hipLaunchKernelGGL(fmm_down_tier2, dim3((unsigned)(gb_hi - gb_lo)), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, geo.lg, sh, (int)gb_lo);
     wfx_prof_end(ctx);
     if (wg_hi > wg_lo) {
-        wfx_prof_begin(ctx, K_FMM_TREE);
-        hipLaunchKernelGGL(fmm_tree_leaf, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, (int)wg_lo);
-        wfx_prof_end(ctx);
         wfx_prof_begin(ctx, K_FMM_LEAF);
-        hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(wg_hi - wg_lo), dim3(FTH), P.lds_leaf, ctx->stream, audio - audio_index0, P.g, P.T, (const double *)P.Cg,
-                           env - env_index0, P.smax, P.xcap, P.Eg, l0hist, (int)wg_lo, 0);
+        fmm_launch_tree_leaf(ctx, P, audio - audio_index0, env - env_index0, 2, l0hist, wg_lo, wg_hi, 0);
         wfx_prof_end(ctx);
     }
     hipError_t e = hipGetLastError();

@@ -23,9 +23,23 @@ import numpy as np
 from . import _native as nat
 from . import hostparams as hp
 
-# how a7 runs: "fft" = one packed circular convolution on the mixed-radix transform passes; "fmm" = near field + fast multipole far
-# field (csrc/wfx_fmm.hip: reads the audio twice instead of six passes; even N >= 32768, other lengths take the transform form)
-DEFAULT_HILBERT_MODE = nat.WFX_HILBERT_FMM if os.environ.get("WEFAX_HILBERT", "fft") == "fmm" else nat.WFX_HILBERT_FFT
+# how a6 + a7 run: "fft" = notch kernel + one packed circular convolution on the mixed-radix transform passes; "fmm" = notch + near field +
+# fast multipole far field in four kernels (csrc/wfx_fmm.hip; even N >= 32768, other lengths take the transform form).  "auto" (the default
+# since round 6): the multipole route where it is the faster one on one GPU -- captures at 11 025 Hz of an even length >= 1 M samples
+# (tools/route_time.py: 1.06x at 130 s, 1.17x at 5 min, 1.005x at 10 min, 1.11x at 20 min, 1.03x at 60 min; 0.96x at 30 s; and no
+# dependence on the length's factors: the padded transforms of a general length cost 1.55x) -- the transform route otherwise (short
+# captures; resampled ones, whose multipole resampler is the slower one on one GPU).  Both give the same uint8 stream.
+HILBERT_AUTO = -1
+FMM_FROM_SAMPLES = 1000000
+DEFAULT_HILBERT_MODE = {"fft": nat.WFX_HILBERT_FFT, "fmm": nat.WFX_HILBERT_FMM}.get(os.environ.get("WEFAX_HILBERT", "auto"), HILBERT_AUTO)
+
+
+def resolve_hilbert_mode(mode: int, n: int, resampled: bool) -> int:
+    """The route a one-GPU decode of n samples at 11 025 Hz takes under ``mode`` (HILBERT_AUTO: see above)."""
+    if mode != HILBERT_AUTO:
+        return int(mode)
+    return nat.WFX_HILBERT_FMM if (not resampled and n % 2 == 0 and n >= FMM_FROM_SAMPLES) else nat.WFX_HILBERT_FFT
+
 
 
 def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEFAULT_NOTCH,
@@ -50,7 +64,9 @@ def build_params(kind: int, n0: int, sample_rate, frame_len: float, notch=hp.DEF
     p.in_kind, p.n0, p.n, p.resample = kind, n0, n, int(resampled)
     p.notch_b[:] = [float(v) for v in b]
     p.notch_a[:] = [float(v) for v in a]
-    p.hilbert_mode = hilbert_mode
+    # (HILBERT_AUTO is resolved by the one-GPU decode, DecodeJob._configure; a sharded decode's plan decides the forms itself and wants the
+    # exact transform mode here)
+    p.hilbert_mode = nat.WFX_HILBERT_FFT if hilbert_mode == HILBERT_AUTO else hilbert_mode
     p.shard_plan = int(shard_plan)       # sharded decodes only: 0 cost model, 1 distributed, 2 single; + 16 rows layout (include/wefax_hip.h)
     lo0, lo1, glo = hp.percentile_plan(n, 0.5)                         # wefax.py:194-196
     hi0, hi1, ghi = hp.percentile_plan(n, 99.5)
@@ -187,6 +203,8 @@ class DecodeJob:
     def _configure(self, kind, n0, sample_rate, notch, hilbert_mode, n_out=None):
         """The scalar arithmetic of the reference (lengths, notch, percentile ranks, sync constants) -> self.params."""
         p, meta = build_params(kind, n0, sample_rate, self.frame_len, notch, hilbert_mode, n_out)
+        p.hilbert_mode = resolve_hilbert_mode(hilbert_mode, meta["n"], meta["resampled"])
+        self.hilbert_mode = int(p.hilbert_mode)
         self.input_length, self.resampled = meta["input_length"], meta["resampled"]
         self.n0, self.n = n0, meta["n"]
         self.sample_rate = hp.TARGET_RATE
