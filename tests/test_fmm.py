@@ -116,3 +116,28 @@ def test_device_resampler_declines_what_it_has_no_form_for(ctx):
         assert not ctx.d_resample_fmm(p, n0, num, p + (1 << 20))
     ctx.dev_free(p)
 
+
+@pytest.mark.parametrize("n", [2 * 1000003, 4000002])
+def test_both_routes_stay_within_1e_12_of_scipy_at_a_general_length(n):
+    """A GENERAL even length (half-length with a large prime factor) costs the transform route a padded convolution.  Its kernel's largest taps are
+    the small NEGATIVE lags, laid out just below N: formed from r / N next to 1 they had lost N x 1e-16 of their relative accuracy (2e-10 .. 8e-10
+    in the envelope at 14 .. 40 M samples, found in round 6 beside the multipole route's 8e-14) -- the lag is reduced to (-N/2, N/2] first now.
+    Envelope + median of either route against scipy on the same filtered audio."""
+    from scipy.signal import hilbert, medfilt
+    from wefax_amd import _native as nat, synth
+    from wefax_amd.wefax import DecodeJob
+    x = synth.config_c2(noise=0.05, seed=5)[:n]
+    assert x.shape[0] == n
+    ref = None
+    for mode in (nat.WFX_HILBERT_FFT, nat.WFX_HILBERT_FMM):
+        c = nat.Context(0)
+        job = DecodeJob(c, x, 11025, 120, hilbert_mode=mode)
+        job.run()
+        job.result()
+        audio, env = job.fetch("audio"), job.fetch("envelope")
+        if ref is None:
+            ref = medfilt(np.abs(hilbert(audio)), 5)
+        assert np.max(np.abs(env - ref)) <= 1e-12 * np.max(ref), mode
+        del job
+        c.close()
+

@@ -781,8 +781,8 @@ def test_sixty_minute_native_rate_capture_of_arbitrary_length_on_eight_ranks():
         x = np.concatenate([x0, x0[:2]])[:n]
         ctx = nat.Context(0)
         # (the transposing plans' arithmetic is the transform route's: asked for by name -- a one-GPU decode of an even capture this long
-        # takes the multipole route by default, whose envelope is 8e-14 from scipy's where the PADDED transform form of a general length is
-        # 1e-10 .. 1e-9 (tools/route_accuracy.py): over 39.7 M samples that is a handful of bytes one grey level apart)
+        # takes the multipole route by default, 8e-14 from scipy where the transform route is 3e-15: over 39.7 M samples a byte or two may
+        # sit one grey level apart)
         job = DecodeJob(ctx, x, 11025, 120, hilbert_mode=nat.WFX_HILBERT_FFT)
         job.run()
         info = job.result()

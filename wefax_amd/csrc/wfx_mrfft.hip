@@ -1576,8 +1576,11 @@ long long wfx_mr_padded_length(long long min_len)
 
 __device__ __forceinline__ double mr_hilbert_tap_even(long long r, long long N)      // kh[r], N even: (2/N) cot(pi r / N) on odd lags
 {
+    // reduced to (-N/2, N/2]: a lag just below N is a SMALL negative lag, and r / N next to 1 would have lost the digits of its distance from 1
+    // (relative error N x 1e-16 in the largest taps: the padded form was 2e-10 .. 8e-10 from scipy at 14 .. 40 M samples until round 6)
     r %= N;
-    if (r < 0) r += N;
+    if (r > N / 2) r -= N;
+    if (r < -(N / 2)) r += N;
     if ((r & 1) == 0) return 0.0;
     double s, c;
     sincospi((double)r / (double)N, &s, &c);
