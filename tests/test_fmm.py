@@ -47,7 +47,7 @@ def test_lengths_the_fast_multipole_form_does_not_take(ctx):
 
 @pytest.mark.parametrize("name", ["mono_noisy_240", "mono_clean_120", "stereo_overflow_120", "mono48k_image_240", "mono_noise20_lead", "mono_noisy_120",
                                   "stereo48k_image_240", "mono_u8_240", "stereo_i32_240", "stereo48k_120", "stereo192k_6s_240", "mono48k_noisy_120",
-                                  "mono_i24_240", "mono_f64_240", "three_ch_240"])
+                                  "mono_i24_240", "mono_f64_240", "three_ch_240", "iq1536k_2s_240"])
 def test_whole_decode_with_the_fast_multipole_hilbert_matches_the_reference_goldens(name):
     """The reference's own streams: nothing moves when the decode takes the multipole forms (an odd-length capture -- mono_noisy_120 --
     runs the transform form under the same mode).  The 48 kHz and 192 kHz cases go through the RESAMPLER's multipole form as well
