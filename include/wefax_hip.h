@@ -157,8 +157,11 @@ typedef struct {
     int      hilbert_mode;     /* wfx_hilbert_mode                                */
     /* sharded decode only (ignored by the one-GPU calls): which plan wfx_shard_* takes.  0 = the library's cost model decides
      * (distributed transforms, or -- where their exchanges would take longer than one GPU needs for the whole capture -- the
-     * single plan: rank 0 alone); 1 = distributed whenever a distributed form exists; 2 = single.  Bit 4 (value 16) set:
-     * the ROWS layout of rounds 2-3 instead of the columns layout (A/B runs only: every form, the padded ones too, has the columns layout) */
+     * single plan: rank 0 alone -- or, round 6, plan 3 where its model is ahead); 1 = distributed whenever a distributed form exists; 2 = single;
+     * 3 = the chunk-local plan: contiguous arcs of the capture, the Hilbert transform (and, for a capture at another rate, the resampler) by
+     * their multipole forms on the rank's own arc, kilobytes exchanged before the one gather (even length >= 32768 at 11 025 Hz; down-sampling).
+     * Bit 4 (value 16) set: the ROWS layout of rounds 2-3 instead of the columns layout (A/B runs only: every form, the padded ones too, has
+     * the columns layout) */
     int      shard_plan;
     /* np.percentile(., (0.5, 99.5)) 'linear': rank pairs and lerp weights        */
     uint64_t rank_lo[2];
@@ -401,7 +404,9 @@ typedef struct {
      * of the stage buffers whose sample index is >= n; in_halo is 192 for those (32 otherwise). */
     int      nseg, in_halo;
     uint64_t in_seg_len, in_seg_stride, own_seg_len, own_seg_stride;
-    int      plan;             /* 0 single (rank 0 alone), 1 rows layout, 2 columns layout                              */
+    int      plan;             /* 0 single (rank 0 alone), 1 rows layout, 2 columns layout, 3 chunk-local multipole forms: ONE range
+                                  [in_lo, in_hi) with in_halo frames on either side taken ROUND THE CIRCLE (320 at 11 025 Hz, 64 in
+                                  front of a resampler: in_hi - in_lo + 2 in_halo frames in all)                         */
     int      plan_forced;      /* 1: wfx_decode_params.shard_plan asked for it; 0: the cost model chose                   */
     /* the cost model's figures for this capture and world size, seconds (0 when no distributed form exists) */
     double   model_single_s, model_dist_compute_s, model_dist_wire_s;
