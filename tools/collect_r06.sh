@@ -45,6 +45,16 @@ for mode in fft fmm; do
 done
 unset WEFAX_HILBERT
 cp "$OUT/pmc_traffic_fft.json" "$OUT/pmc_traffic.json"
+# ... configs[2] and configs[3] (what their `roofline.traffic` quotes)
+if [ "${COLLECT_PMC_BIG:-1}" = "1" ]; then
+  for w in iq c3; do
+    [ $w = iq ] && args="--workload iq --steps 2 --warmup 1 --no-cpu" || args="--workload c3 --steps 2 --warmup 1 --no-cpu --no-extras --no-e2e"
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$w" -o run -- python3 bench.py $args > /dev/null 2> "$OUT/pmc_fetch_$w.err"
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$w" -o run -- python3 bench.py $args > /dev/null 2> "$OUT/pmc_write_$w.err"
+    python tools/pmc_summary.py "$OUT/pmc_fetch_$w" "$OUT/pmc_write_$w" "$OUT/pmc_traffic_$w.json" > "$OUT/pmc_summary_$w.log" 2>&1
+    rm -rf "$OUT/pmc_fetch_$w" "$OUT/pmc_write_$w"
+  done
+fi
 
 # SQ counters of the multipole kernels
 EXP_ARGS="--no-e2e --no-c5" bash tools/exp_sq.sh "fmm_|mr2_pass|notch|hconv" "WEFAX_HILBERT=fmm" > "$OUT/sq_counters_fmm.txt" 2>&1
