@@ -259,28 +259,121 @@ __device__ __forceinline__ void fmm_down_level_mfma(const double *src, int spart
     }
 }
 
-// the six levels of a subtree, matrices requested two levels ahead into three register sets in rotation (requested one level ahead they
-// arrive after the level's products and every level waits for memory).  LEVELS <= 6 at run time; `lv0` = the level above the first.
-#define FMM_DOWN_STEP(D_, GCUR, GNEXT2, NLEV, CONVP)                                                                                    \
-    if ((D_) <= (NLEV)) {                                                                                                               \
-        if ((D_) + 2 <= (NLEV)) fmm_ga_load(T.G + (size_t)(lv0 + (D_) + 2 - 2) * 4 * FP * FP, wave & 1, lane, GNEXT2);                  \
-        fmm_lds_barrier();                                                                                                              \
-        FSTAMP(1, (D_));                                                                                                                \
-        fmm_down_level_mfma<(D_)>(((D_) & 1) ? la : lb, ((D_) >= 2 && fmm_level_split((D_) - 1)) ? 4 : 1, (1 << ((D_) - 1)) * 2 * FS,   \
-                                  ((D_) & 1) ? lb : la, un + (((1 << (D_)) - 2) + 2 * FHB * ((D_) - 1)) * 2 * FS, GCUR, atr, wave, lane, \
-                                  CONVP);                                                                                               \
+// ---- the same level in two halves (late round 6): the M2L sums of ALL levels of a subtree depend on the weights alone, not on one another --
+// only the L2L product walks down the levels.  Per level the old routine ran sixteen DEPENDENT products (4 L2L + 12 M2L) behind a barrier and
+// the kernel waited through six such chains (17 of the fused leaf kernel's 25 us per workgroup); now a wave first runs the M2L chains of all
+// its tasks (<= 4, independent of one another: they pipeline) and keeps the sums in registers, then the levels are four products each.
+// Tasks: d >= 5: (class, 16 boxes, weight parity) -- level 6 on all eight waves, level 5 on waves 0 .. 3; d <= 4: columns = (box, parity), waves
+// 4 + 2 (d & 1) + class: every wave has at most three tasks, and all their matrices are requested before the first barrier.
+template <int d>
+__device__ __forceinline__ bool fmm_level_task(int wave, int col, int &q, int &h, bool &store)
+{
+    constexpr int nb = 1 << d, half = nb >> 1;
+    if constexpr (d >= 5) {
+        constexpr int ng = half >> 4;                   // groups of 16 boxes per class: 1 or 2
+        if (wave >= 4 * ng) return false;
+        const int rest = wave >> 1;
+        q = 16 * (rest & (ng - 1)) + col;
+        h = rest / ng;
+        store = true;
+        return true;
+    } else {
+        if ((wave >> 1) != 2 + (d & 1)) return false;   // waves 4, 5: levels 4 and 2; waves 6, 7: levels 3 and 1 (waves 0 .. 3 carry level 5)
+        const int cc = col & (nb - 1);                  // (columns beyond the level's boxes repeat earlier ones and are not stored)
+        q = cc & (half - 1);
+        h = cc >> (d - 1);
+        store = col < nb;
+        return true;
     }
-#define FMM_DOWN_CHAIN(NLEV, CONV6)                                                                   \
-    {                                                                                                 \
-        double gA[3][4], gB[3][4], gC[3][4];                                                          \
-        fmm_ga_load(T.G + (size_t)(lv0 + 1 - 2) * 4 * FP * FP, wave & 1, lane, gA);                   \
-        if (2 <= (NLEV)) fmm_ga_load(T.G + (size_t)(lv0 + 2 - 2) * 4 * FP * FP, wave & 1, lane, gB);  \
-        FMM_DOWN_STEP(1, gA, gC, NLEV, nullptr)                                                       \
-        FMM_DOWN_STEP(2, gB, gA, NLEV, nullptr)                                                       \
-        FMM_DOWN_STEP(3, gC, gB, NLEV, nullptr)                                                       \
-        FMM_DOWN_STEP(4, gA, gC, NLEV, nullptr)                                                       \
-        FMM_DOWN_STEP(5, gB, gA, NLEV, nullptr)                                                       \
-        FMM_DOWN_STEP(6, gC, gB, NLEV, CONV6)                                                         \
+}
+
+template <int d>
+__device__ __forceinline__ fmm_d4 fmm_m2l_level(const double *wl, const double (&ga)[3][4], int wave, int lane)
+{
+    fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    int q = 0, h = 0;
+    bool store = false;
+    if (!fmm_level_task<d>(wave, lane & 15, q, h, store)) return acc;
+    const int c = wave & 1, kq = lane >> 4;
+    const int b = 2 * q + c;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int off = s == 0 ? (c ? -3 : -2) : (s == 1 ? (c ? -2 : 2) : (c ? 2 : 3));
+        const double *bp = wl + ((b + off + FHB) * 2 + (1 - h)) * FS + kq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s][ks], bp[4 * ks], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// acc = the level's M2L sums (fmm_m2l_level); + L2L from the parents in `src` ([box][h][FS]); -> dst (conv: as Chebyshev coefficients)
+template <int d>
+__device__ __forceinline__ void fmm_l2l_level(const double *src, double *dst, fmm_d4 acc, const double (&atr)[4], int wave, int lane, const double *__restrict__ conv)
+{
+    int q = 0, h = 0;
+    bool store = false;
+    if (!fmm_level_task<d>(wave, lane & 15, q, h, store)) return;
+    const int c = wave & 1, kq = lane >> 4;
+    const int b = 2 * q + c;
+    const double *bp = src + (q * 2 + h) * FS + kq;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[ks], bp[4 * ks], acc, 0, 0, 0);
+    if (conv) {
+        fmm_d4 cf = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(conv[64 * ks + lane], acc[ks], cf, 0, 0, 0);
+        acc = cf;
+    }
+    if (store) {
+        double *o = dst + (b * 2 + h) * FS + kq;        // accumulator register r of lane (kq, column) is row kq + 4 r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[4 * r] = acc[r];
+    }
+}
+
+#define FMM_WALL(D_) (un + (((1 << (D_)) - 2) + 2 * FHB * ((D_) - 1)) * 2 * FS)
+#define FMM_GLV(D_) (T.G + (size_t)(lv0 + (D_) - 2) * 4 * FP * FP)
+#define FMM_L2L_STEP(D_, ACC, NLEV, CONVP)                                                                              \
+    if ((D_) <= (NLEV)) {                                                                                               \
+        if ((D_) > 1) fmm_lds_barrier();                                                                                \
+        FSTAMP(1, (D_));                                                                                                \
+        fmm_l2l_level<(D_)>(((D_) & 1) ? la : lb, ((D_) & 1) ? lb : la, ACC, atr, wave, lane, CONVP);                   \
+    }
+// the levels lv0 + 1 .. lv0 + NLEV (NLEV <= 6 at run time) of a subtree whose weights wait in `un` and whose root's values wait in `la`
+#define FMM_DOWN_CHAIN(NLEV, CONV6)                                                                                     \
+    {                                                                                                                   \
+        fmm_d4 m6 = {0.0, 0.0, 0.0, 0.0}, m5 = m6, ms0 = m6, ms1 = m6;                                                  \
+        {                                                                                                               \
+            double gA[3][4], gB[3][4], gC[3][4];                                                                        \
+            if (6 <= (NLEV)) fmm_ga_load(FMM_GLV(6), wave & 1, lane, gA);                                               \
+            if (wave < 4) {                                                                                             \
+                if (5 <= (NLEV)) fmm_ga_load(FMM_GLV(5), wave & 1, lane, gB);                                           \
+            } else if (wave < 6) {                                                                                      \
+                if (4 <= (NLEV)) fmm_ga_load(FMM_GLV(4), wave & 1, lane, gB);                                           \
+                if (2 <= (NLEV)) fmm_ga_load(FMM_GLV(2), wave & 1, lane, gC);                                           \
+            } else {                                                                                                    \
+                if (3 <= (NLEV)) fmm_ga_load(FMM_GLV(3), wave & 1, lane, gB);                                           \
+                if (1 <= (NLEV)) fmm_ga_load(FMM_GLV(1), wave & 1, lane, gC);                                           \
+            }                                                                                                           \
+            fmm_lds_barrier();                  /* the weights and the root's values are in LDS */                      \
+            FSTAMP(1, 0);                                                                                               \
+            if (6 <= (NLEV)) m6 = fmm_m2l_level<6>(FMM_WALL(6), gA, wave, lane);                                        \
+            if (wave < 4) {                                                                                             \
+                if (5 <= (NLEV)) m5 = fmm_m2l_level<5>(FMM_WALL(5), gB, wave, lane);                                    \
+            } else if (wave < 6) {                                                                                      \
+                if (4 <= (NLEV)) ms0 = fmm_m2l_level<4>(FMM_WALL(4), gB, wave, lane);                                   \
+                if (2 <= (NLEV)) ms1 = fmm_m2l_level<2>(FMM_WALL(2), gC, wave, lane);                                   \
+            } else {                                                                                                    \
+                if (3 <= (NLEV)) ms0 = fmm_m2l_level<3>(FMM_WALL(3), gB, wave, lane);                                   \
+                if (1 <= (NLEV)) ms1 = fmm_m2l_level<1>(FMM_WALL(1), gC, wave, lane);                                   \
+            }                                                                                                           \
+        }                                                                                                               \
+        FMM_L2L_STEP(1, ms1, NLEV, nullptr)                                                                             \
+        FMM_L2L_STEP(2, ms1, NLEV, nullptr)                                                                             \
+        FMM_L2L_STEP(3, ms0, NLEV, nullptr)                                                                             \
+        FMM_L2L_STEP(4, ms0, NLEV, nullptr)                                                                             \
+        FMM_L2L_STEP(5, m5, NLEV, nullptr)                                                                              \
+        FMM_L2L_STEP(6, m6, NLEV, CONV6)                                                                                \
     }
 
 // The weights of levels ltop + 1 .. ltop + D of a workgroup's subtree (its boxes and three more on either side, round the circle) into LDS
@@ -311,7 +404,7 @@ __device__ __forceinline__ void fmm_load_walls(double *un, const double *__restr
 }
 
 // ---- downward pass inside a leaf subtree: six levels of L2L + M2L, out come the leaves' far fields as Chebyshev coefficients ----------------
-__global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf(const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg, const double *__restrict__ Lg,
+__global__ void __launch_bounds__(FTH, 4) fmm_tree_leaf(const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg, const double *__restrict__ Lg,
                                                         double *__restrict__ Cg, int wg0)
 {
     const long long blk = (long long)blockIdx.x + wg0;           // (a launch covers a chunk of the leaf workgroups: fmm_run)
@@ -510,7 +603,7 @@ __global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict_
 
 // ---- tree + leaves in ONE kernel (round 6, late): fmm_tree_leaf followed by fmm_leaf_env in the same workgroup -- the coefficients never leave LDS --
 template <int OUT>
-__global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf_env(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg,
+__global__ void __launch_bounds__(FTH, 4) fmm_tree_leaf_env(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg,
                                                             const double *__restrict__ Lg, double *__restrict__ out, int smax, int xcap, double *__restrict__ edge, unsigned *__restrict__ l0hist, int wg0, int xwrap)
 {
     // xwrap 0 (a rank of a sharded decode): x is addressed by the UNWRAPPED sample index -- the leaf before the rank's first (for rank 0: the
@@ -522,6 +615,7 @@ __global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf_env(const double *__rest
     double *lb = la + FLV * 2 * FS;                     // [32][2][FS]
     double *un = lb + (FLV / 2) * 2 * FS;               // the weights of all six levels
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    FSTAMP(2, 0);
     {
         const int ltop = g.L - FW;
         fmm_load_walls(un, Wg, ltop, FW, t, blk);
@@ -532,6 +626,7 @@ __global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf_env(const double *__rest
         const int lv0 = ltop;
         FMM_DOWN_CHAIN(FW, T.Ca)
     }
+    FSTAMP(1, 7);
     // ---- phase 2 (fmm_leaf_env's): the coefficients stay where they are; the near-field table and the sample window take the place of the
     // weights.  A workgroup WAITS in phase 1 and ISSUES in phase 2: the two workgroups of a CU drift apart and fill each other's gaps ----
     double *ca = la;
@@ -539,6 +634,8 @@ __global__ void __launch_bounds__(FTH, 2) fmm_tree_leaf_env(const double *__rest
     double *xw = gn + FNEAR + FXP0;                     // the sample window (xcap doubles + pads)
     unsigned *h0 = (unsigned *)ca;
     static_assert((FLV / 2) * 2 * FS + FWALL >= FNEAR + FXP0 + FXW + FXP1, "the window fits where the weights were");
+    // (measured and not kept: the window requested at the kernel's start and held in registers through phase 1 -- 18 more registers spill at
+    // two workgroups per CU and the requests compete with the weights': phase 1 16.6 against 14.6 us)
     const long long leaf0 = blk * FLV, nleaf = 1ll << g.L;
     const long long km = leaf0 == 0 ? nleaf - 1 : leaf0 - 1;
     const long long w0 = fmm_leaf_first(g, km) - (leaf0 == 0 ? g.n : 0);                       // may be negative
