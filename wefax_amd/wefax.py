@@ -25,12 +25,12 @@ from . import hostparams as hp
 
 # how a6 + a7 run: "fft" = notch kernel + one packed circular convolution on the mixed-radix transform passes; "fmm" = notch + near field +
 # fast multipole far field in four kernels (csrc/wfx_fmm.hip; even N >= 32768, other lengths take the transform form).  "auto" (the default
-# since round 6): the multipole route where it is the faster one on one GPU -- captures at 11 025 Hz of an even length >= 1 M samples
-# (tools/route_time.py: 1.06x at 130 s, 1.17x at 5 min, 1.005x at 10 min, 1.11x at 20 min, 1.03x at 60 min; 0.96x at 30 s; and no
+# since round 6): the multipole route where it is the faster one on one GPU -- captures at 11 025 Hz of an even length >= 400 000 samples
+# (tools/route_time.py: 0.98x at 30 s, 1.05x at 40 s, 1.0-1.3x at 50-110 s, 1.09x at 130 s, 1.20x at 5 min, 1.06x at 10 min, 1.13x at 20 min, 1.05x at 60 min; and no
 # dependence on the length's factors: the padded transforms of a general length cost 1.55x) -- the transform route otherwise (short
 # captures; resampled ones, whose multipole resampler is the slower one on one GPU).  Both give the same uint8 stream.
 HILBERT_AUTO = -1
-FMM_FROM_SAMPLES = 1000000
+FMM_FROM_SAMPLES = 400000
 DEFAULT_HILBERT_MODE = {"fft": nat.WFX_HILBERT_FFT, "fmm": nat.WFX_HILBERT_FMM}.get(os.environ.get("WEFAX_HILBERT", "auto"), HILBERT_AUTO)
 
 
