@@ -332,6 +332,12 @@ def bench_iq(args, rk: Ranks, seconds: float, steps: int, warmup: int, with_cpu:
         m = out["wire"]["model"]
         out["model_ms"] = m["one_gpu_ms"] if dec.layout.plan == 0 else m["dist_ms"]
         out["measured_ms"] = out["ms_per_step"]
+        if getattr(dec, "plan_choice", None):
+            # an oversampled capture left open by the caller: the choice was made with the front end's time added (sharded.choose_plan_with_front_end)
+            pc = dec.plan_choice
+            out["plan_choice"] = {"front_end_ms": round(1e3 * pc["front_end_s"], 3), "chosen": pc["chosen"],
+                                  "candidates_model_ms": {k: {"plan": v["plan"], "ms": round(1e3 * v["model_s"], 3)} for k, v in pc["candidates"].items()}}
+            out["model_ms"] = round(1e3 * pc["candidates"][pc["chosen"]]["model_s"], 3)
     dec.close()
     if not fused and rk.world > 1 and args.plan == "auto" and os.environ.get("WFX_BENCH_BOTH_PLANS", "1") != "0":
         # the other sides of the cost model's decision, in the same run: the transposing plan and the chunk-local plan forced (when `auto` chose

@@ -273,6 +273,23 @@ def test_the_cost_model_takes_the_multipole_plan_where_the_capture_is_long_enoug
     assert [nat.shard_layout(p, w, 0).plan for w in (2, 4, 8)] == [0, 3, 2]
 
 
+def test_an_oversampled_capture_left_open_is_sharded_from_two_ranks_on(monkeypatch):
+    """The library's cost model sees the capture at the hand-over rate; the front end in front of it (the 22 GB ingest of configs[3]: 3.7 ms of
+    the 6.7) is divided by the world size only under a sharded plan.  `FrontEndShardedDecoder(plan="auto")` therefore chooses with that time
+    added (sharded.choose_plan_with_front_end, host only): the chunk-local plan from TWO ranks on, where the library alone would leave rank 0
+    to ingest the whole stream."""
+    for v in ("WFX_LINK_GBS", "WFX_LINK_LAT_US", "WFX_SHARD_CHUNKS", "WFX_SHARD_ROWS"):
+        monkeypatch.delenv(v, raising=False)
+    raw_bytes = 5529600000 * 4
+    for world, want in ((2, 3), (4, 3), (8, 3)):
+        name, fig = sharded.choose_plan_with_front_end(57600000, 16000, 120, None, 39690000, world, raw_bytes)
+        assert fig["candidates"][name]["plan"] == want
+        assert fig["candidates"][name]["model_s"] == min(c["model_s"] for c in fig["candidates"].values())
+        assert abs(fig["front_end_s"] - raw_bytes / 6.0e12) < 1e-12
+    name, fig = sharded.choose_plan_with_front_end(57600000, 16000, 120, None, 39690000, 2, raw_bytes)
+    assert name == "fmm" and fig["candidates"]["auto"]["plan"] == 0 and fig["candidates"]["auto"]["model_s"] > 1.3 * fig["candidates"]["fmm"]["model_s"]
+
+
 def test_multipole_plan_refuses_what_it_cannot_shard():
     p, _ = build_params(0, 480000, 8000, 0.5, shard_plan=sharded.plan_code("fmm"))         # upsampling: the resampler's multipole form is built for downsampling
     with pytest.raises(nat.NativeError, match="no multipole form of the resampler"):

@@ -506,6 +506,32 @@ class FrontEndExactDecoder:
         self.fe.close()
 
 
+INGEST_BYTES_PER_S = 6.0e12          # the streaming ingest reads a capture at 0.75-0.8 of the 8 TB/s HBM peak
+
+
+def choose_plan_with_front_end(n_fe: int, rate, lines_per_minute: int, notch, n_out: int, world: int, raw_bytes: int):
+    """Which plan an oversampled capture takes on `world` ranks when the caller leaves it open: the library's model of every candidate (its own
+    choice, the chunk-local plan, the transposing plan) for the hand-over-rate signal PLUS the front end's time -- the whole stream on rank 0
+    under the single plan, 1 / world of it under a sharded one.  Host only; every rank computes the same answer.  Returns (plan name, figures)."""
+    frame_len = 1 / (lines_per_minute / 60)
+    if notch is None:
+        notch = hp.load_notch_settings()
+    fe_s = raw_bytes / INGEST_BYTES_PER_S
+    figures = {}
+    for name in ("auto", "fmm", "dist"):
+        try:
+            p, _ = build_params(nat.WFX_IN_F64_MONO, int(n_fe), rate, frame_len, notch, n_out=n_out, shard_plan=plan_code(name))
+            lay = nat.shard_layout(p, world, 0)
+        except nat.NativeError:
+            continue
+        if lay.plan == 0:
+            figures[name] = {"plan": 0, "model_s": lay.model_single_s + fe_s}
+        else:
+            figures[name] = {"plan": int(lay.plan), "model_s": lay.model_dist_compute_s + lay.model_dist_wire_s + fe_s / world}
+    best = min(figures, key=lambda k: (figures[k]["model_s"], k != "auto"))
+    return best, {"front_end_s": fe_s, "candidates": figures, "chosen": best}
+
+
 class FrontEndShardedDecoder:
     """One rank of the sharded decode of an oversampled capture (BASELINE configs[3]): the rank runs the front end over the raw
     frames its rows of the hand-over-rate signal need (halo of the FIR chain included: ``raw_loader(lo, hi)`` with indices
@@ -517,6 +543,12 @@ class FrontEndShardedDecoder:
                  notch=None, plan="auto"):
         n_in_total = int(n_in_total if n_in_total is not None else np.asarray(x).shape[0])
         n_fe = frontend.n_out(n_in_total)
+        self.plan_choice = None
+        if plan == "auto" and comm.world > 1:
+            # the library's cost model sees the capture at the hand-over rate only; the front end in front of it is most of an oversampled
+            # decode, and only a sharded plan divides it by the world size -- the choice is made here, with the front end's time added
+            plan, self.plan_choice = choose_plan_with_front_end(n_fe, frontend.out_rate, lines_per_minute, notch, frontend.n_target(n_in_total), comm.world,
+                                                                n_in_total * (4 if (in_kind == nat.WFX_IN_I16_STEREO or (x is not None and np.asarray(x).ndim == 2)) else 2))
         self.dec = ShardedDecoder(ctx, comm, n_fe, frontend.out_rate, lines_per_minute, nat.WFX_IN_F64_MONO, notch,
                                   n_out=frontend.n_target(n_in_total), plan=plan)
         lay = self.dec.layout
