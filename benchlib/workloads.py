@@ -449,7 +449,9 @@ def bench_c3(args, rk: Ranks) -> dict:
         # length int(11025 n0 / fs) odd) and less one (n0 odd) -- resampled by two chirp-z transforms on the mixed-radix passes
         # (round 4; rounds 1-3: Bluestein on power-of-two transforms, 41 ms), the Hilbert transform in its odd-length form behind it.
         anyl = {}
-        for trim in (2, 1):
+        # (trim 6: an EVEN count at 11 025 Hz -- the multipole forms of the resampler and of the Hilbert transform take it, `auto`'s choice for
+        # lengths the mixed-radix resampler does not take; trims 2 and 1: odd counts, the chirp-z resampler + the odd-length Hilbert form)
+        for trim in (6, 2, 1):
             j2 = DecodeJob(ctx, np.ascontiguousarray(x[:n0 - trim]), 48000, 120)
             for _ in range(2):
                 j2.run()
@@ -459,7 +461,8 @@ def bench_c3(args, rk: Ranks) -> dict:
                 j2.run()
             ctx.sync()
             t_any = 1e3 * (time.perf_counter() - t0) / 3
-            anyl["n0_minus_%d" % trim] = {"n0": int(n0 - trim), "n": int(j2.n), "ms_per_step": round(t_any, 3), "ratio_to_whole_seconds": round(t_any / ms, 2)}
+            anyl["n0_minus_%d" % trim] = {"n0": int(n0 - trim), "n": int(j2.n), "ms_per_step": round(t_any, 3), "ratio_to_whole_seconds": round(t_any / ms, 2),
+                                          "route": "multipole (resampler + Hilbert transform)" if j2.hilbert_mode == nat.WFX_HILBERT_FMM else "transform (chirp-z resampler)"}
             del j2
         out["general_length"] = anyl
     if rk.rank == 0 and rk.world == 1 and not args.no_cpu:

@@ -252,6 +252,9 @@ void  wfx_host_free(void *p);
  * 8 % above it; 0 when min_len is below 4096 (such captures pad to a power of two).  wfx_plan_describe: the passes of the
  * transform of length L as text ("7x13,7x25,15x15"; "" when L is not 13-smooth), returns the number of passes. */
 uint64_t wfx_plan_padded_length(uint64_t min_len);
+/* 1: the transform-based resampler takes n0 -> num directly (both half-lengths 13-smooth: mixed-radix passes); 0: it needs the chirp-z form
+ * (any length, ~3.5x the time) -- where the multipole form of the resampler exists (wfx_d_resample_fmm) that one is the faster */
+int wfx_plan_resample_direct(uint64_t n0, uint64_t num);
 int wfx_plan_describe(uint64_t L, char *buf, int cap);
 /* copy a new capture of the same description into the context (asynchronous when host_in is pinned memory).  `bytes` must equal
  * the size of the capture described to wfx_decode_upload (n0 frames of in_kind) -- WFX_ERR_BAD_ARG otherwise, nothing is read.

@@ -141,3 +141,29 @@ def test_both_routes_stay_within_1e_12_of_scipy_at_a_general_length(n):
         del job
         c.close()
 
+
+def test_auto_takes_the_multipole_route_for_a_resampled_capture_of_general_length():
+    """A 48 kHz recording of arbitrary length: the transform-based resampler needs its chirp-z form (3.5x), the multipole forms do not care about the
+    lengths' factors -- `auto` takes them (resampler AND Hilbert transform) where they exist; whole-second lengths keep the mixed-radix passes.
+    The stream is the oracle's either way."""
+    from wefax_amd import _native as nat, synth
+    from wefax_amd.wefax import DecodeJob
+    kw = dict(start_tone_s=2.0, phasing_lines=20, image_lines=30, stop_tone_s=1.0, black_tail_s=2.0)
+    x = synth.synth_capture(48000.0, noise=0.05, seed=7, **kw)
+    assert x.shape[0] == 1440000
+    import os, tempfile
+    for drop, want in ((14, nat.WFX_HILBERT_FMM), (0, nat.WFX_HILBERT_FFT), (10, nat.WFX_HILBERT_FFT)):
+        xs = np.ascontiguousarray(x[:x.shape[0] - drop])
+        c = nat.Context(0)
+        job = DecodeJob(c, xs, 48000, 120)
+        assert job.hilbert_mode == want, (drop, job.n, job.hilbert_mode)
+        job.run()
+        info = job.result()
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "x.wav")
+            synth.write_wav(path, 48000, xs)
+            ref = wo.process(path, 120, want_messages=False)
+        assert info.start_frame == ref["start_frame"] and np.array_equal(job.fetch("digitalized"), ref["digitalized"])
+        del job
+        c.close()
+

@@ -30,7 +30,7 @@ SYMBOLS = [
     "wfx_decode_result", "wfx_debug_counters", "wfx_decode_bind_image", "wfx_decode_fetch", "wfx_decode_device_ptr",
     "wfx_decode_copy_to_device", "wfx_stream_handle", "wfx_decode_export_async",
     "wfx_dev_malloc", "wfx_dev_free", "wfx_dev_upload", "wfx_dev_download", "wfx_dev_copy",
-    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_hilbert_fmm", "wfx_d_resample_fmm", "wfx_d_read_rate", "wfx_d_stream_rate", "wfx_d_median5", "wfx_d_select_hist",
+    "wfx_d_notch_fir", "wfx_d_notch_fir_f64", "wfx_d_decimate_fir64", "wfx_d_decimate_fir64_batch", "wfx_d_ingest_chain", "wfx_d_hilbert_fmm", "wfx_d_resample_fmm", "wfx_plan_resample_direct", "wfx_d_read_rate", "wfx_d_stream_rate", "wfx_d_median5", "wfx_d_select_hist",
     "wfx_d_quantise", "wfx_d_sync_search", "wfx_d_image_rows",
     "wfx_comm_unique_id", "wfx_comm_create", "wfx_comm_create_local", "wfx_comm_create_shm", "wfx_comm_selftest", "wfx_comm_info", "wfx_comm_destroy",
     "wfx_comm_barrier", "wfx_comm_allgather_host",
@@ -236,6 +236,7 @@ def load():
     lib.wfx_d_decimate_fir64_batch.argtypes = [vp, vp, i, sz, C.c_int64, i, vp, i, vp, sz, i, C.POINTER(C.c_int), i, sz, sz]
     lib.wfx_d_hilbert_fmm.argtypes = [vp, vp, sz, vp, i, C.POINTER(C.c_int)]
     lib.wfx_d_resample_fmm.argtypes = [vp, vp, sz, sz, vp, C.POINTER(C.c_int)]
+    lib.wfx_plan_resample_direct.argtypes = [C.c_uint64, C.c_uint64]
     lib.wfx_d_read_rate.argtypes = [vp, vp, sz, i, C.POINTER(C.c_double)]
     lib.wfx_d_stream_rate.argtypes = [vp, vp, sz, vp, i, C.POINTER(C.c_double)]
     lib.wfx_d_ingest_chain.argtypes = [vp, vp, i, sz, i, vp, i, i, i, vp, i, vp, sz, i, sz, sz, C.POINTER(C.c_int)]
@@ -301,6 +302,11 @@ def load():
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def resample_direct(n0: int, num: int) -> bool:
+    """True: the transform-based resampler takes n0 -> num with mixed-radix passes; False: it needs the chirp-z form (any length, ~3.5x the time)."""
+    return bool(load().wfx_plan_resample_direct(int(n0), int(num)))
 
 
 def padded_length(min_len: int) -> int:

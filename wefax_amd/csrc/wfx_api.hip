@@ -694,6 +694,11 @@ int wfx_d_hilbert_fmm(wfx_ctx *ctx, const double *x_dev, size_t n, double *out_d
     return wfx_dev_hilbert_fmm(ctx, x_dev, n, out_dev, out_env, nullptr, handled);
 }
 
+int wfx_plan_resample_direct(uint64_t n0, uint64_t num)
+{
+    return wfx_mr_resample_supported(n0, num) ? 1 : 0;
+}
+
 int wfx_d_resample_fmm(wfx_ctx *ctx, const double *x_dev, size_t n0, size_t num, double *y_dev, int *handled)
 {
     CHECK_CTX(ctx);
