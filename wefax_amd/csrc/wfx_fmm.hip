@@ -143,124 +143,10 @@ __device__ __forceinline__ void fmm_ga_load(const double *__restrict__ Gl, int c
     }
 }
 
-// (d is a template parameter: a run-time level makes the three sets of matrices of the callers an indexed array, which lands in scratch memory)
-// One level of the downward pass on the matrix cores: L2L from the parents + M2L over the interaction list, for the workgroup's nb = 2^d
-// boxes of the level.  The 16 columns of a product are 16 boxes of ONE parity class c = wave & 1 (same interaction offsets, same L2L matrix):
-//   d >= 5: a task = (class, 16 boxes q, weight parity h): sixteen products in one wave.
-//   d <= 4: columns = (q, h); the level's four matrices (L2L, three M2L) go to four WAVES per class, which leave four PARTIAL results
-//           ([matrix][box][h][FS]) -- a level is four dependent products long instead of sixteen (the kernel waits on exactly that chain);
-//           whoever reads such a level adds the four in a fixed order (fmm_lsum).
-// src: the parents' nodal values [box][h][FS] (sparts = 4: four partial arrays spstr doubles apart); dst: this level's; wl: the level's weights
-// [slot = box - first + FHB][h][FS]; ga: the class's M2L matrices; atr: the class's L2L matrix as A operands.  conv != nullptr: the result
-// leaves as Chebyshev coefficients (one more product with the accumulators as its B operand: register r IS K-step r).
-// (measured: 65.8 us with the small levels split over eight waves against 62.0 us without, tiers 31 against 28 -- a small level is not
-// its chain of products but ~150 other instructions per wave and the barrier: kept as a switch, off)
-__device__ __forceinline__ bool fmm_level_split(int d) { return false && d <= 4; }
-
-__device__ __forceinline__ double fmm_lsum(const double *p, int sparts, int spstr)
-{
-    return sparts == 4 ? (p[0] + p[spstr]) + (p[2 * spstr] + p[3 * spstr]) : p[0];
-}
-
-template <int d>
-__device__ __forceinline__ void fmm_down_level_mfma(const double *src, int sparts, int spstr, double *dst, const double *wl, const double (&ga)[3][4],
-                                                     const double (&atr)[4], int wave, int lane, const double *__restrict__ conv)
-{
-    const int nb = 1 << d, half = nb >> 1;
-    const int col = lane & 15, kq = lane >> 4;
-    const int c = wave & 1;
-    if constexpr (d >= 5) {
-        const int ng = half >> 4;                       // groups of 16 boxes per class: 1 or 2
-        if (wave >= 4 * ng) return;
-        const int rest = wave >> 1;
-        const int q = 16 * (rest & (ng - 1)) + col, h = rest / ng;
-        const int b = 2 * q + c;
-        fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        {
-            const double *bp = src + (q * 2 + h) * FS + kq;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[ks], fmm_lsum(bp + 4 * ks, sparts, spstr), acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int off = s == 0 ? (c ? -3 : -2) : (s == 1 ? (c ? -2 : 2) : (c ? 2 : 3));
-            const double *bp = wl + ((b + off + FHB) * 2 + (1 - h)) * FS + kq;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s][ks], bp[4 * ks], acc, 0, 0, 0);
-        }
-        if (conv) {
-            fmm_d4 cf = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(conv[64 * ks + lane], acc[ks], cf, 0, 0, 0);
-            acc = cf;
-        }
-        double *o = dst + (b * 2 + h) * FS + kq;        // accumulator register r of lane (kq, column) is row kq + 4 r
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[4 * r] = acc[r];
-        return;
-    }
-    if (!fmm_level_split(d)) {
-        // two waves (which two alternates with the level: one SIMD pair would carry all small levels otherwise), sixteen products each
-        if ((wave >> 1) != (d & 1)) return;
-        const int cc = col & (nb - 1);                  // (columns beyond the level's boxes repeat earlier ones and are not stored)
-        const int q = cc & (half - 1), h = cc >> (d - 1);
-        const int b = 2 * q + c;
-        fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        {
-            const double *bp = src + (q * 2 + h) * FS + kq;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[ks], fmm_lsum(bp + 4 * ks, sparts, spstr), acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int off = s == 0 ? (c ? -3 : -2) : (s == 1 ? (c ? -2 : 2) : (c ? 2 : 3));
-            const double *bp = wl + ((b + off + FHB) * 2 + (1 - h)) * FS + kq;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s][ks], bp[4 * ks], acc, 0, 0, 0);
-        }
-        if (col < nb) {
-            double *o = dst + (b * 2 + h) * FS + kq;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[4 * r] = acc[r];
-        }
-        return;
-    }
-    // small levels, split: wave = (class c, matrix m): m = 0 the L2L matrix on the parents, m = 1 .. 3 the M2L matrices on the level's weights
-    const int m = wave >> 1;
-    const int cc = col & (nb - 1);                      // (columns beyond the level's boxes repeat earlier ones and are not stored)
-    const int q = cc & (half - 1), h = cc >> (d - 1);
-    const bool valid = col < nb;
-    const int b = 2 * q + c;
-    fmm_d4 acc = {0.0, 0.0, 0.0, 0.0};
-    if (m == 0) {
-        const double *bp = src + (q * 2 + h) * FS + kq;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[ks], fmm_lsum(bp + 4 * ks, sparts, spstr), acc, 0, 0, 0);
-    } else {
-        const int off = m == 1 ? (c ? -3 : -2) : (m == 2 ? (c ? -2 : 2) : (c ? 2 : 3));
-        const double *bp = wl + ((b + off + FHB) * 2 + (1 - h)) * FS + kq;
-        // (m is uniform over the wave: three branches, not a select -- the compiler turns a select between the register sets into an indexed
-        // array in scratch memory)
-        if (m == 1) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[0][ks], bp[4 * ks], acc, 0, 0, 0);
-        } else if (m == 2) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[1][ks], bp[4 * ks], acc, 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[2][ks], bp[4 * ks], acc, 0, 0, 0);
-        }
-    }
-    if (valid) {
-        double *o = dst + m * (nb * 2 * FS) + (b * 2 + h) * FS + kq;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[4 * r] = acc[r];
-    }
-}
-
-// ---- the same level in two halves (late round 6): the M2L sums of ALL levels of a subtree depend on the weights alone, not on one another --
-// only the L2L product walks down the levels.  Per level the old routine ran sixteen DEPENDENT products (4 L2L + 12 M2L) behind a barrier and
+// ---- one level of the downward pass on the matrix cores, in two halves.  The 16 columns of a product are 16 boxes of ONE parity class
+// c = wave & 1 (same interaction offsets, same L2L matrix; d is a template parameter: a run-time level turns the callers' register sets into
+// an indexed array in scratch memory).  The M2L sums of ALL levels of a subtree depend on the weights alone, not on one another --
+// only the L2L product walks down the levels.  Per level the first form ran sixteen DEPENDENT products (4 L2L + 12 M2L) behind a barrier and
 // the kernel waited through six such chains (17 of the fused leaf kernel's 25 us per workgroup); now a wave first runs the M2L chains of all
 // its tasks (<= 4, independent of one another: they pipeline) and keeps the sums in registers, then the levels are four products each.
 // Tasks: d >= 5: (class, 16 boxes, weight parity) -- level 6 on all eight waves, level 5 on waves 0 .. 3; d <= 4: columns = (box, parity), waves
@@ -436,172 +322,10 @@ __global__ void __launch_bounds__(FTH, 4) fmm_tree_leaf(const fmm_geom g, const 
     FSTAMP(1, 8);
 }
 
-// ---- the leaves: near field + far field -> H -> |x + iH| -> 5-tap median + level-0 histogram (OUT 0: H, 1: the envelope, 2: median + histogram) ----
+// ---- tree levels + leaves in ONE kernel (the coefficients never leave LDS): near field + far field -> H -> |x + iH| -> 5-tap median + level-0 histogram (OUT 0: H, 1: the envelope, 2: median + histogram) ----
 // OUT 2: the envelope takes the samples' place in LDS once every near field has read them; medians of positions that need a neighbour
 // workgroup's envelope (its first and last two) are left to fmm_edge_median, which finds the four envelope values at either end of every
 // workgroup in `edge`.  scipy.signal.medfilt pads with ZEROS at the capture's ends: those four medians are complete here.
-template <int OUT>
-__global__ void __launch_bounds__(FTH, 6) fmm_leaf_env(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Cg,
-                                                       double *__restrict__ out, int smax, int xcap, double *__restrict__ edge, unsigned *__restrict__ l0hist, int wg0, int xwrap)
-{
-    // xwrap 0 (a rank of a sharded decode): x is addressed by the UNWRAPPED sample index -- the leaf before the rank's first (for rank 0: the
-    // capture's last) and the one behind its last lie in front of / behind its own samples in memory
-    const long long blk = (long long)blockIdx.x + wg0;
-    extern __shared__ __align__(16) double fl[];
-    double *ca = fl;                                    // [64][2][FS]: Chebyshev coefficients of the leaves' far fields
-    double *gn = ca + FLV * 2 * FS;                     // [FNEAR]
-    double *xw = gn + FNEAR + FXP0;                     // the sample window: the workgroup's leaves and one more on either side (xcap = 66 smax doubles + pads)
-    unsigned *h0 = (unsigned *)ca;                      // [WFX_SEL_BINS] (OUT 2): in the coefficients' place once the far fields are evaluated
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long long leaf0 = blk * FLV, nleaf = 1ll << g.L;
-    const long long km = leaf0 == 0 ? nleaf - 1 : leaf0 - 1;
-    const long long w0 = fmm_leaf_first(g, km) - (leaf0 == 0 ? g.n : 0);                       // may be negative
-    const long long kl = leaf0 + FLV == nleaf ? 0 : leaf0 + FLV;                              // the leaf behind the last one
-    const long long w1 = (leaf0 + FLV == nleaf ? g.n : 0) + fmm_leaf_first(g, kl + 1);
-    const int wlen = (int)(w1 - w0);                                                            // <= FXW
-    FSTAMP(2, 0);
-    constexpr int XPT = (FXW + FTH - 1) / FTH;
-    {
-        double xr[XPT];
-#pragma unroll
-        for (int q = 0; q < XPT; ++q) {
-            const int idx = t + q * FTH;
-            long long m = w0 + idx;
-            if (xwrap) m = m < 0 ? m + g.n : (m >= g.n ? m - g.n : m);
-            xr[q] = idx < wlen ? x[m] : 0.0;
-        }
-        double2 cr[(FLV * 2 * FP / 2) / FTH];
-        const double *cg = Cg + (size_t)blk * FLV * 2 * FP;
-#pragma unroll
-        for (int q = 0; q < (FLV * 2 * FP / 2) / FTH; ++q) cr[q] = *(const double2 *)(cg + 2 * (t + q * FTH));
-        for (int i = t; i < FNEAR; i += FTH) gn[i] = T.gnear[i];
-#pragma unroll
-        for (int q = 0; q < XPT; ++q) {
-            const int idx = t + q * FTH;
-            if (idx < xcap) xw[idx] = xr[q];
-        }
-#pragma unroll
-        for (int q = 0; q < (FLV * 2 * FP / 2) / FTH; ++q) {
-            const int i2 = t + q * FTH;
-            *(double2 *)(ca + (i2 >> 3) * FS + 2 * (i2 & 7)) = cr[q];
-        }
-    }
-    fmm_lds_barrier();
-    FSTAMP(2, 1);
-    // ---- wave = (16 leaves G, target parity e relative to the leaf's first sample) ---------------------------------------------------------
-    const int n16 = lane & 15, gq = lane >> 4;
-    const int SMe = (smax + 1) & ~1;
-    const int NKB = ((2 * smax + SMe) / 2 + 3) / 4;
-    const int G = wave >> 1, e = wave & 1;
-    const int lk = 16 * G + n16;
-    const long long k = leaf0 + lk;
-    const long long a = fmm_leaf_first(g, k), b = fmm_leaf_first(g, k + 1), am = fmm_leaf_first(g, k - 1), ap2 = fmm_leaf_first(g, k + 2);
-    const int s0 = (int)(b - a), slo = -(int)(a - am), shi = (int)(ap2 - a);      // sources of the near field: slo <= sigma < shi
-    const int sigma0 = -SMe + (1 - e);
-    const double *bp = xw + ((int)(a - w0) + sigma0 + 2 * gq);                   // B: lane (k = gq, column n16) reads sample sigma0 + 2 (4 K + gq) of ITS leaf
-    int sig = sigma0 + 2 * gq;
-    const double *ap = gn + (n16 - gq + e + (SMe + 254) / 2);                     // A: lane (row n16, k = gq) reads the tap of lag 2 (16 I + row - 4 K - k + e) + SMe - 1
-    fmm_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    // (operands of block K + 1 are requested before block K's products are issued; the window's pads make the last, unused request legal)
-    double bn = bp[0], a0n = ap[0], a1n = ap[16];
-    for (int K = 0; K < NKB; ++K) {
-        const bool in = (sig >= slo) & (sig < shi);
-        const double bv = in ? bn : 0.0, a0 = a0n, a1 = a1n;
-        sig += 8;
-        bn = bp[8 * (K + 1)];
-        a0n = ap[-4 * (K + 1)];
-        a1n = ap[16 - 4 * (K + 1)];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc1, 0, 0, 0);
-    }
-    FSTAMP(2, 2);
-    // far field + output: register r of block I is target tau = 2 (16 I + gq + 4 r) + e of leaf lk.  Its place in the box: u = ua + tau du
-    // (one division per lane, not per target)
-    const int ht = (int)((a + e) & 1);
-    const double ua = 2.0 * ((double)((a << g.L) - k * g.n) / (double)g.n) - 1.0;
-    double ac[FP];
-    {
-        const double *cp = ca + (lk * 2 + ht) * FS;
-#pragma unroll
-        for (int kk = 0; kk < FP; ++kk) ac[kk] = cp[kk];
-    }
-    double *xp = xw + (int)(a - w0);
-    double *op = out + a;
-    double res[8];
-#pragma unroll
-    for (int I = 0; I < 2; ++I) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tau = 2 * (16 * I + gq + 4 * r) + e;
-            const bool valid = tau < s0;
-            const double u = valid ? fma((double)tau, g.du, ua) : 0.0;
-            double t0 = 1.0, t1 = u, far = fma(ac[1], u, ac[0]);
-            const double u2 = 2.0 * u;
-#pragma unroll
-            for (int kk = 2; kk < FP; ++kk) {
-                const double t2 = fma(u2, t1, -t0);
-                far = fma(ac[kk], t2, far);
-                t0 = t1;
-                t1 = t2;
-            }
-            const double near = I == 0 ? acc0[r] : acc1[r];
-            const double H = g.scale * (far + near);
-            if (OUT == 0) {
-                if (valid) op[tau] = H;
-            } else {
-                const double xv = xp[valid ? tau : 0];
-                const double ev = sqrt(fma(xv, xv, H * H));
-                if (OUT == 1) {
-                    if (valid) op[tau] = ev;
-                } else {
-                    res[4 * I + r] = ev;
-                }
-            }
-        }
-    }
-    FSTAMP(2, 3);
-    if (OUT != 2) return;
-    fmm_lds_barrier();                                    // every near field has read its samples: the envelope takes their place
-    static_assert(FLV * 2 * FS * 8 >= WFX_SEL_BINS * 4, "the histogram fits where the coefficients were");
-    for (int i = t; i < WFX_SEL_BINS; i += FTH) h0[i] = 0;
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tau = 2 * (16 * I + gq + 4 * r) + e;
-            if (tau < s0) xp[tau] = res[4 * I + r];
-        }
-    fmm_lds_barrier();
-    FSTAMP(2, 4);
-    {
-        const long long wa = fmm_leaf_first(g, leaf0), wb = fmm_leaf_first(g, leaf0 + FLV);   // the workgroup's own samples [wa, wb)
-        const int own = (int)(wb - wa);
-        const double *ew = xw + (int)(wa - w0);
-        const bool first = wa == 0, last = wb == g.n;
-        for (int i0 = 0; i0 < own; i0 += FTH) {
-            const int i = i0 + t;
-            // medians that are complete here: all but the first and last two -- and those too where zeros stand beyond the capture's end
-            const bool valid = i < own && (i >= 2 || first) && (i < own - 2 || last);
-            double m = 0.0;
-            if (valid) {
-                const double e0 = i >= 2 ? ew[i - 2] : 0.0, e1 = i >= 1 ? ew[i - 1] : 0.0;
-                const double e3 = i + 1 < own ? ew[i + 1] : 0.0, e4 = i + 2 < own ? ew[i + 2] : 0.0;
-                m = wfx_median5(e0, e1, ew[i], e3, e4);
-                out[wa + i] = m;
-            }
-            if (l0hist) wfx_sel_count(h0, (unsigned)(wfx_f64_key(m) >> 53), valid, lane);
-        }
-        if (t < 8) edge[(size_t)blk * 8 + t] = t < 4 ? ew[t] : ew[own - 8 + t];
-    }
-    if (l0hist) {
-        fmm_lds_barrier();
-        for (int i = t; i < WFX_SEL_BINS; i += FTH)
-            if (h0[i]) atomicAdd(&l0hist[i], h0[i]);
-    }
-    FSTAMP(2, 5);
-}
-
-// ---- tree + leaves in ONE kernel (round 6, late): fmm_tree_leaf followed by fmm_leaf_env in the same workgroup -- the coefficients never leave LDS --
 template <int OUT>
 __global__ void __launch_bounds__(FTH, 4) fmm_tree_leaf_env(const double *__restrict__ x, const fmm_geom g, const fmm_tabs T, const double *__restrict__ Wg,
                                                             const double *__restrict__ Lg, double *__restrict__ out, int smax, int xcap, double *__restrict__ edge, unsigned *__restrict__ l0hist, int wg0, int xwrap)
@@ -1165,10 +889,9 @@ __global__ void __launch_bounds__(FTH) fmm_down_tier2(const fmm_geom g, const fm
     double *src = (D & 1) ? lb : la;                    // (level d writes lb for odd d)
     fmm_lds_barrier();
     double *o = Lg + fmm_box(a + D, blk << D) * 2 * FP;
-    const int lparts = fmm_level_split(D) ? 4 : 1, lstr = (1 << D) * 2 * FS;
     for (int i2 = t; i2 < ((2 * FP / 2) << D); i2 += FTH) {
         const double *p = src + (i2 >> 3) * FS + 2 * (i2 & 7);
-        *(double2 *)(o + 2 * i2) = make_double2(fmm_lsum(p, lparts, lstr), fmm_lsum(p + 1, lparts, lstr));
+        *(double2 *)(o + 2 * i2) = make_double2(p[0], p[1]);
     }
 }
 
@@ -1178,7 +901,7 @@ __global__ void __launch_bounds__(FTH) fmm_top2(const fmm_geom g, const fmm_tabs
 {
     constexpr int WLV = (32 + 2 * FHB) * 2 * FS;        // one level's weights, halo slots included
     __shared__ __align__(16) double wl[4][WLV];         // levels 2 .. 5
-    __shared__ __align__(16) double la[64 * 2 * FS], lb[64 * 2 * FS];          // (levels 3 and 4 leave four partial arrays: fmm_down_level_mfma)
+    __shared__ __align__(16) double la[64 * 2 * FS], lb[64 * 2 * FS];
     __shared__ double w2[(4 + 2 * FHB) * 2 * FP], l2[4 * 2 * FP], Ats[2 * FP * FP], Gs[4 * FP * FP];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double ajr[2][4], atr[4];
@@ -1209,36 +932,40 @@ __global__ void __launch_bounds__(FTH) fmm_top2(const fmm_geom g, const fmm_tabs
         }
     }
     fmm_lds_barrier();
+    // the M2L sums of levels 3 .. 5 need the weights alone: they run here, beside level 2's scalar routine, and wait in registers
+    fmm_d4 m3 = {0.0, 0.0, 0.0, 0.0}, m4 = m3, m5 = m3;
+    {
+        double g3[3][4], g4[3][4], g5[3][4];
+        if (3 <= atop && (wave >> 1) == 3) fmm_ga_load(T.G + (size_t)(3 - 2) * 4 * FP * FP, wave & 1, lane, g3);
+        if (4 <= atop && (wave >> 1) == 2) fmm_ga_load(T.G + (size_t)(4 - 2) * 4 * FP * FP, wave & 1, lane, g4);
+        if (5 <= atop && wave < 4) fmm_ga_load(T.G + (size_t)(5 - 2) * 4 * FP * FP, wave & 1, lane, g5);
+        if (3 <= atop && (wave >> 1) == 3) m3 = fmm_m2l_level<3>(wl[1], g3, wave, lane);
+        if (4 <= atop && (wave >> 1) == 2) m4 = fmm_m2l_level<4>(wl[2], g4, wave, lane);
+        if (5 <= atop && wave < 4) m5 = fmm_m2l_level<5>(wl[3], g5, wave, lane);
+    }
     for (int i = t; i < (4 + 2 * FHB) * 2 * FP; i += FTH) w2[i] = wl[0][(i >> 4) * FS + (i & 15)];
     fmm_lds_barrier();
     fmm_down_level<FTH>(nullptr, l2, w2, Gs, Ats, 0, 4, 4, t);
     fmm_lds_barrier();
     for (int i = t; i < 4 * 2 * FP; i += FTH) la[(i >> 4) * FS + (i & 15)] = l2[i];
     double *src = la;
-    {
-        double g3[3][4], g4[3][4], g5[3][4];            // levels 3, 4, 5: all requested at once
-        if (3 <= atop) fmm_ga_load(T.G + (size_t)(3 - 2) * 4 * FP * FP, wave & 1, lane, g3);
-        if (4 <= atop) fmm_ga_load(T.G + (size_t)(4 - 2) * 4 * FP * FP, wave & 1, lane, g4);
-        if (5 <= atop) fmm_ga_load(T.G + (size_t)(5 - 2) * 4 * FP * FP, wave & 1, lane, g5);
-        if (3 <= atop) {
-            fmm_lds_barrier();
-            fmm_down_level_mfma<3>(la, 1, 0, lb, wl[1], g3, atr, wave, lane, nullptr);
-            src = lb;
-        }
-        if (4 <= atop) {
-            fmm_lds_barrier();
-            fmm_down_level_mfma<4>(lb, fmm_level_split(3) ? 4 : 1, 8 * 2 * FS, la, wl[2], g4, atr, wave, lane, nullptr);
-            src = la;
-        }
-        if (5 <= atop) {
-            fmm_lds_barrier();
-            fmm_down_level_mfma<5>(la, fmm_level_split(4) ? 4 : 1, 16 * 2 * FS, lb, wl[3], g5, atr, wave, lane, nullptr);
-            src = lb;
-        }
+    if (3 <= atop) {
+        fmm_lds_barrier();
+        fmm_l2l_level<3>(la, lb, m3, atr, wave, lane, nullptr);
+        src = lb;
+    }
+    if (4 <= atop) {
+        fmm_lds_barrier();
+        fmm_l2l_level<4>(lb, la, m4, atr, wave, lane, nullptr);
+        src = la;
+    }
+    if (5 <= atop) {
+        fmm_lds_barrier();
+        fmm_l2l_level<5>(la, lb, m5, atr, wave, lane, nullptr);
+        src = lb;
     }
     fmm_lds_barrier();
-    const int lparts = (atop >= 3 && fmm_level_split(atop)) ? 4 : 1, lstr = ntop * 2 * FS;
-    for (int i = t; i < ntop * 2 * FP; i += FTH) Lg[fmm_box(atop, 0) * 2 * FP + i] = fmm_lsum(src + (i >> 4) * FS + (i & 15), lparts, lstr);
+    for (int i = t; i < ntop * 2 * FP; i += FTH) Lg[fmm_box(atop, 0) * 2 * FP + i] = src[(i >> 4) * FS + (i & 15)];
 }
 
 // ---- host: tables -------------------------------------------------------------------------------------------------------------------
@@ -1767,16 +1494,12 @@ static int fmm_setup(wfx_ctx *ctx, uint64_t n, fmm_plan &P, int *handled)
     P.lds_up3_i16 = (size_t)(FLV * 2 * FS + P.xc3) * 8;
     P.lds_up3_f64 = P.lds_up3_i16 + (size_t)(P.xc3 + 2 * NOTCH_K + 8) * 8;
     const size_t lds_up3_max = (size_t)(FLV * 2 * FS + FLV * 64 + FLV * 64 + 2 * NOTCH_K + 8) * 8;
-    const size_t lds_leaf_max = (size_t)(FLV * 2 * FS + FNEAR + FXP0 + FXW + FXP1) * 8;
     static bool attr_done = false;
     if (!attr_done) {
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_up2));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf3<short, UP3W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up3_max));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_up_leaf3<double, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_up3_max));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_tree));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
-        WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_leaf_env<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_max));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf_env<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_tree));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf_env<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_tree));
         WFX_HIP(ctx, hipFuncSetAttribute((const void *)fmm_tree_leaf_env<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_tree));
@@ -1851,28 +1574,10 @@ static int fmm_run(wfx_ctx *ctx, const double *x, const void *raw, int raw_kind,
     for (int k = P.ntier - 1; k >= 0; --k)
         hipLaunchKernelGGL(fmm_down_tier2, dim3(1u << P.tier_a[k]), dim3(FTH), 0, ctx->stream, P.g, P.T, (const double *)P.Wg, P.Lg, P.tier_a[k], P.tier_d[k], 0);
     wfx_prof_end(ctx);
-#ifdef WFX_FMM_SPLIT_LEAF
-    wfx_prof_begin(ctx, K_FMM_TREE);
-    // (measured and not kept: the leaf workgroups in four chunks, chunk c's leaf kernel on a second queue beside chunk c + 1's tree kernel --
-    // the tree kernel waits, the leaf kernel issues -- 165 us against 133 us one after the other: a chunk is a single round of workgroups
-    // with its full tail, and the queues' events cost more than the overlap gives)
-    hipLaunchKernelGGL(fmm_tree_leaf, dim3(nwg), dim3(FTH), P.lds_tree, ctx->stream, P.g, P.T, (const double *)P.Wg, (const double *)P.Lg, P.Cg, 0);
-    wfx_prof_end(ctx);
-    wfx_prof_begin(ctx, K_FMM_LEAF);
-    if (out_mode == 2)
-        hipLaunchKernelGGL(fmm_leaf_env<2>, dim3(nwg), dim3(FTH), P.lds_leaf, ctx->stream, x, P.g, P.T, (const double *)P.Cg, out, P.smax, P.xcap, P.Eg, l0hist, 0, 1);
-    else if (out_mode == 1)
-        hipLaunchKernelGGL(fmm_leaf_env<1>, dim3(nwg), dim3(FTH), P.lds_leaf, ctx->stream, x, P.g, P.T, (const double *)P.Cg, out, P.smax, P.xcap, P.Eg,
-                           (unsigned *)nullptr, 0, 1);
-    else
-        hipLaunchKernelGGL(fmm_leaf_env<0>, dim3(nwg), dim3(FTH), P.lds_leaf, ctx->stream, x, P.g, P.T, (const double *)P.Cg, out, P.smax, P.xcap, P.Eg,
-                           (unsigned *)nullptr, 0, 1);
-#else
     // tree + leaves in one kernel: a workgroup waits through its six tree levels and issues through its near field; the two workgroups of a
     // CU drift apart and fill each other's gaps, and the coefficients never leave LDS
     wfx_prof_begin(ctx, K_FMM_LEAF);
     fmm_launch_tree_leaf(ctx, P, x, out, out_mode, l0hist, 0, nwg, 1);
-#endif
     if (out_mode == 2 && nwg > 1)
         hipLaunchKernelGGL(fmm_edge_median, dim3((nwg + 254) / 256), dim3(256), 0, ctx->stream, P.g, (const double *)P.Eg, out, l0hist, 0, (int)nwg - 1, 0, (int)nwg);
     wfx_prof_end(ctx);
